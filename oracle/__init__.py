@@ -1,0 +1,449 @@
+"""oracle -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+CPU restatement (plain C for loop-shaped integer work, numpy fp32 for the rest) of the algorithms on
+the PCAccumulation hot path.  Every function cites the
+reference file:line it follows (paths relative to /root/reference).
+
+Who may import this package: tests/, __graft_entry__.smoke(), and the cpu_baseline leg of bench.py --
+as the checker only.  Nothing under pcaccumulation_amd/ imports it; the product path fails loudly when
+the HIP library is missing instead of falling back to this code.
+
+Pinned by: tests/golden/*.npz, emitted by tests/golden/make_golden.py from the reference itself
+imported in the build container (the reference ships no tests of its own), and
+by oracle/_ref (the reference's own Chamfer C++ CPU path compiled from its sources) where present.
+Third-party semantics restated here because the modules are absent from /root/reference:
+torch_scatter.scatter (unpinned wheel, README.md:28) -- "parity unpinned" for that dependency beyond
+its documented definition (sum/mean/max per index, empty segments = 0).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, 'libpcacc_oracle.so')
+    src = os.path.join(_HERE, 'csrc', 'pcacc_oracle.c')
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(['gcc', '-O2', '-ffp-contract=off', '-fPIC', '-shared', '-o', so, src, '-lm'])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = ctypes.CDLL(build())
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+# ------------------------------------------------------------------------------------------------
+# A1  voxelisation  (libs/voxel_generator.py:4-61, 64-114, 117-154)
+# ------------------------------------------------------------------------------------------------
+def grid_size(voxel_size, pc_range):
+    """libs/voxel_generator.py:123-125: round((max - min) / voxel_size) in fp32."""
+    vs = np.asarray(voxel_size, np.float32)
+    r = np.asarray(pc_range, np.float32)
+    return np.round((r[3:] - r[:3]) / vs).astype(np.int64)
+
+
+def voxelize(points, voxel_size, pc_range, n_sweeps, max_voxels=None):
+    """Voxelization.__call__ (libs/voxel_generator.py:131-154). points [N,4] f32 = (x,y,z,t)."""
+    points = np.ascontiguousarray(points, np.float32)
+    vs = np.ascontiguousarray(voxel_size, np.float32)
+    r = np.ascontiguousarray(pc_range, np.float32)
+    g = grid_size(vs, r)
+    if max_voxels is None:
+        max_voxels = int(g[0] * g[1] * g[2] * n_sweeps)
+    g32 = np.ascontiguousarray(g, np.int32)
+    table = np.full(int(g[2] * g[1] * g[0] * n_sweeps), -1, np.int32)
+    coors = np.zeros((max_voxels, 4), np.int32)
+    npv = np.zeros(max_voxels, np.int32)
+    p2v = np.empty((points.shape[0], 1), np.int32)
+    f = lib().orc_voxelize
+    f.restype = ctypes.c_int
+    m = f(_p(points), ctypes.c_int64(points.shape[0]), _p(vs), _p(r), _p(g32), ctypes.c_int32(n_sweeps),
+          ctypes.c_int32(max_voxels), _p(table), _p(coors), _p(npv), _p(p2v))
+    return {
+        'coordinates': coors[:m].copy(),
+        'num_voxels': np.array([m], dtype=np.int64),
+        'shape': np.hstack((g, np.array([n_sweeps]))).astype(np.int64),
+        'point_to_voxel_map': p2v,
+        'num_points_per_voxel': npv[:m].copy(),
+    }
+
+
+# ------------------------------------------------------------------------------------------------
+# A3 / A4 pooling  (models/motionnet.py:159-160, models/pillar_encoder.py:116,120)
+# ------------------------------------------------------------------------------------------------
+def segment_mean(src, seg, m):
+    src = np.ascontiguousarray(src, np.float32)
+    seg = np.ascontiguousarray(seg, np.int64)
+    out = np.empty((m, src.shape[1]), np.float32)
+    lib().orc_segment_mean_f32(_p(src), _p(seg), ctypes.c_int64(src.shape[0]), ctypes.c_int64(m),
+                               ctypes.c_int(src.shape[1]), _p(out))
+    return out
+
+
+def segment_max_label(labels, seg, m):
+    labels = np.ascontiguousarray(labels, np.int64).reshape(-1)
+    seg = np.ascontiguousarray(seg, np.int64)
+    out = np.empty(m, np.int64)
+    lib().orc_segment_max_i64(_p(labels), _p(seg), ctypes.c_int64(labels.shape[0]), ctypes.c_int64(m), _p(out))
+    return out[:, None]
+
+
+def segment_max(src, seg, m):
+    """Returns (max [m,C], arg [m,C] = lowest point index attaining it)."""
+    src = np.ascontiguousarray(src, np.float32)
+    seg = np.ascontiguousarray(seg, np.int64)
+    out = np.empty((m, src.shape[1]), np.float32)
+    arg = np.empty((m, src.shape[1]), np.int32)
+    lib().orc_segment_max_f32(_p(src), _p(seg), ctypes.c_int64(src.shape[0]), ctypes.c_int64(m),
+                              ctypes.c_int(src.shape[1]), _p(out), _p(arg))
+    return out, arg
+
+
+def _linear(x, w, b=None):
+    y = x @ w.T.astype(np.float32)
+    return y + b if b is not None else y
+
+
+def _relu(x):
+    return np.maximum(x, 0)
+
+
+def _resblock(x, sd, prefix):
+    """ResnetBlockFC.forward, models/pillar_encoder.py:46-55."""
+    net = _linear(_relu(x), sd[prefix + 'fc_0.weight'], sd[prefix + 'fc_0.bias'])
+    dx = _linear(_relu(net), sd[prefix + 'fc_1.weight'], sd[prefix + 'fc_1.bias'])
+    return _linear(x, sd[prefix + 'shortcut.weight']) + dx
+
+
+def pfn_features(points, p2v, coordinates, pillar_mean, time_indice, voxel_size, pc_range, n_frames):
+    """The 9 per-point inputs, models/pillar_encoder.py:98-110 (fp32 after the .float() cast)."""
+    points = np.asarray(points, np.float32)
+    vx, vy = voxel_size[0], voxel_size[1]
+    x_off, y_off = vx / 2 + pc_range[0], vy / 2 + pc_range[1]
+    mc = np.asarray(coordinates, np.float64)[p2v]
+    d_mean = points - np.asarray(pillar_mean, np.float32)[p2v]
+    f_center = np.zeros_like(points[:, :2])
+    # f64 coordinate * python float, subtracted from the f32 point and stored into an f32 tensor
+    f_center[:, 0] = (points[:, 0].astype(np.float64) - (mc[:, 3] * vx + x_off)).astype(np.float32)
+    f_center[:, 1] = (points[:, 1].astype(np.float64) - (mc[:, 2] * vy + y_off)).astype(np.float32)
+    feats = np.concatenate([points.astype(np.float64), d_mean.astype(np.float64), f_center.astype(np.float64),
+                            np.asarray(time_indice, np.float64)[:, 1:2]], axis=1).astype(np.float32)
+    feats[:, :-1] /= np.float32(abs(pc_range[0]))
+    feats[:, -1] /= np.float32(n_frames)
+    return feats
+
+
+def pfn_forward(sd, feats, p2v, m, depth=3, prefix='pillar_encoder.'):
+    """PillarFeatureNet.forward after feature build, models/pillar_encoder.py:112-122."""
+    net = _linear(feats, sd[prefix + 'fc_pos.weight'], sd[prefix + 'fc_pos.bias'])
+    net = _resblock(net, sd, prefix + 'blocks.0.')
+    for i in range(1, depth):
+        pooled = segment_max(net, p2v, m)[0][p2v]
+        net = _resblock(np.concatenate([net, pooled], axis=1), sd, prefix + 'blocks.%d.' % i)
+    out = _linear(net, sd[prefix + 'fc_c.weight'], sd[prefix + 'fc_c.bias'])
+    return segment_max(out, p2v, m)[0]
+
+
+# ------------------------------------------------------------------------------------------------
+# A5 / A6 pillar <-> BEV canvas  (models/pillar_encoder.py:125-174, 177-204)
+# ------------------------------------------------------------------------------------------------
+def _cell_index(coords, nx, ny):
+    c = np.asarray(coords)
+    return (c[:, 4] * nx * ny + c[:, 2] * nx + c[:, 3]).astype(np.int64)
+
+
+def scatter_point_pillar(voxel_features, coords, batch_size, input_shape):
+    """[M,C] + coords [M,5]=(b,z,y,x,t) -> [B,C,nt,ny,nx]; later rows win on duplicate cells."""
+    vf = np.asarray(voxel_features)
+    nx, ny, nt = int(input_shape[0]), int(input_shape[1]), int(input_shape[3])
+    c = vf.shape[1]
+    out = np.zeros((batch_size, c, nt * ny * nx), vf.dtype)
+    b = np.asarray(coords)[:, 0].astype(np.int64)
+    idx = _cell_index(coords, nx, ny)
+    for bi in range(batch_size):
+        sel = b == bi
+        out[bi][:, idx[sel]] = vf[sel].T
+    return out.reshape(batch_size, c, nt, ny, nx)
+
+
+def inverse_scatter_point_pillar(canvas, coords, batch_size, input_shape):
+    """[B,C,nt,ny,nx] -> [M,C], rows grouped by batch index ascending (pillar_encoder.py:193-203)."""
+    cv = np.asarray(canvas)
+    nx, ny = int(input_shape[0]), int(input_shape[1])
+    c = cv.shape[1]
+    b = np.asarray(coords)[:, 0].astype(np.int64)
+    idx = _cell_index(coords, nx, ny)
+    outs = []
+    for bi in range(batch_size):
+        sel = b == bi
+        outs.append(cv[bi].reshape(c, -1)[:, idx[sel]].T)
+    return np.concatenate(outs, axis=0)
+
+
+# ------------------------------------------------------------------------------------------------
+# A9 / A11 bilinear sampling  (F.grid_sample, mode='bilinear', align_corners=False)
+# ------------------------------------------------------------------------------------------------
+def _grid_sample(feat, gx, gy, padding):
+    """feat [C,H,W] f32, normalised coords gx (width axis), gy (height axis) [K] -> [K,C].
+
+    ATen grid_sampler_2d: x = ((g + 1) * W - 1) / 2; 'border' clamps x to [0, W-1] before the
+    corner split; 'zeros' drops out-of-range corners.  All arithmetic in fp32.
+    """
+    feat = np.asarray(feat, np.float32)
+    c, h, w = feat.shape
+    f32 = np.float32
+    x = ((np.asarray(gx, f32) + f32(1)) * f32(w) - f32(1)) / f32(2)
+    y = ((np.asarray(gy, f32) + f32(1)) * f32(h) - f32(1)) / f32(2)
+    if padding == 'border':
+        x = np.minimum(np.maximum(x, f32(0)), f32(w - 1))
+        y = np.minimum(np.maximum(y, f32(0)), f32(h - 1))
+    x0, y0 = np.floor(x), np.floor(y)
+    x1, y1 = x0 + f32(1), y0 + f32(1)
+    wts = [((x1 - x) * (y1 - y), x0, y0), ((x - x0) * (y1 - y), x1, y0),
+           ((x1 - x) * (y - y0), x0, y1), ((x - x0) * (y - y0), x1, y1)]
+    out = np.zeros((x.shape[0], c), f32)
+    flat = feat.reshape(c, -1)
+    for wt, xi, yi in wts:
+        ok = (xi >= 0) & (xi <= w - 1) & (yi >= 0) & (yi <= h - 1)
+        xi_c = np.clip(xi, 0, w - 1).astype(np.int64)
+        yi_c = np.clip(yi, 0, h - 1).astype(np.int64)
+        v = flat[:, yi_c * w + xi_c].T
+        out += (wt * ok.astype(f32))[:, None] * v
+    return out
+
+
+def ungrid(feats, points, pc_range, time_indice):
+    """models/pillar_encoder.py:231-267: per-point bilinear sample (border) of [B,C,H,W] at
+    (x/|x_min|, y/|y_min|); output rows grouped by batch index ascending.  Does not mutate points."""
+    feats = np.asarray(feats, np.float32)
+    pts = np.asarray(points, np.float32)
+    u = pts[:, 0] / np.float32(abs(pc_range[0]))
+    v = pts[:, 1] / np.float32(abs(pc_range[1]))
+    b = np.asarray(time_indice)[:, 0]
+    outs = []
+    for bi in range(feats.shape[0]):
+        sel = b == bi
+        outs.append(_grid_sample(feats[bi], u[sel], v[sel], 'border'))
+    return np.concatenate(outs, axis=0) if outs else np.zeros((0, feats.shape[1]), np.float32)
+
+
+def temporal_ungrid(feats, points, pc_range, time_indice):
+    """models/pillar_encoder.py:206-228. feats [B,T,C,H,W]."""
+    feats = np.asarray(feats, np.float32)
+    ti = np.asarray(time_indice)
+    out = np.zeros((points.shape[0], feats.shape[2]), np.float32)
+    for t in range(feats.shape[1]):
+        sel = ti[:, 1] == t
+        if sel.sum():
+            out[sel] = ungrid(feats[:, t], np.asarray(points)[sel], pc_range, ti[sel])
+    return out
+
+
+def get_transformed_grid(pose, h, w, x_reso, y_reso, x_min, y_min):
+    """models/motionnet.py:45-80: pixel centres -> metres -> pose[:2,:2] @ g + pose[:2,3] -> /|min|."""
+    f32 = np.float32
+    xx = np.tile(np.arange(w, dtype=f32)[None, :] + f32(0.5), (h, 1))
+    yy = np.tile(np.arange(h, dtype=f32)[:, None] + f32(0.5), (1, w))
+    gx = (xx * f32(x_reso) + f32(x_min)).reshape(-1)
+    gy = (yy * f32(y_reso) + f32(y_min)).reshape(-1)
+    p = np.asarray(pose, f32)
+    tx = p[0, 0] * gx + p[0, 1] * gy + p[0, 3]
+    ty = p[1, 0] * gx + p[1, 1] * gy + p[1, 3]
+    return tx / f32(abs(x_min)), ty / f32(abs(y_min))
+
+
+def warp_feats(bev_feats, pose_est, resolution, pc_range):
+    """models/motionnet.py:82-114.  bev_feats [B,T,C,H,W]; frames 1..T-1 are resampled (zeros
+    padding) at the inverse-pose grid; slot 0 holds frame T-1 UNWARPED (the loop variable leaks,
+    motionnet.py:100,111) -- kept, the released weights were trained with it."""
+    bev = np.asarray(bev_feats, np.float32)
+    b_, t_, c, h, w = bev.shape
+    out = np.empty_like(bev)
+    for b in range(b_):
+        out[b, 0] = bev[b, t_ - 1]
+        for t in range(1, t_):
+            inv = np.linalg.inv(np.asarray(pose_est[b, t], np.float32)).astype(np.float32)
+            gx, gy = get_transformed_grid(inv, h, w, resolution[0], resolution[1], pc_range[0], pc_range[1])
+            out[b, t] = _grid_sample(bev[b, t], gx, gy, 'zeros').T.reshape(c, h, w)
+    return out
+
+
+def transform_points(points, time_indice, transformation):
+    """models/motionnet.py:117-135: p' = R_{b,t} p + t_{b,t} per point (fp32)."""
+    pts = np.asarray(points, np.float32)
+    ti = np.asarray(time_indice).astype(np.int64)
+    tr = np.asarray(transformation, np.float32)[ti[:, 0], ti[:, 1]]
+    return (np.einsum('nij,nj->ni', tr[:, :3, :3], pts) + tr[:, :3, 3]).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------------
+# A8 ego-motion: cost, Sinkhorn, weighted Kabsch
+# ------------------------------------------------------------------------------------------------
+def square_distance(src, dst, normalised=False):
+    """toolbox/utils.py:125-144 (clamped at 1e-12)."""
+    src, dst = np.asarray(src, np.float32), np.asarray(dst, np.float32)
+    d = np.float32(-2) * (src @ dst.T)
+    if normalised:
+        d = d + np.float32(2)
+    else:
+        d = d + (src ** 2).sum(-1)[:, None] + (dst ** 2).sum(-1)[None, :]
+    return np.maximum(d, np.float32(1e-12))
+
+
+def _logsumexp(a, axis):
+    m = a.max(axis=axis, keepdims=True)
+    return m + np.log(np.exp(a - m).sum(axis=axis, keepdims=True))
+
+
+def sinkhorn(log_alpha, n_iters):
+    """models/egomotion.py:100-137: zero-padded slack row/column, last row/column not normalised."""
+    la = np.asarray(log_alpha, np.float32)
+    pad = np.zeros((la.shape[0] + 1, la.shape[1] + 1), np.float32)
+    pad[:-1, :-1] = la
+    for _ in range(n_iters):
+        pad[:-1, :] = pad[:-1, :] - _logsumexp(pad[:-1, :], 1)
+        pad[:, :-1] = pad[:, :-1] - _logsumexp(pad[:, :-1], 0)
+    return pad[:-1, :-1]
+
+
+def kabsch(x1, x2, weights, eps=1e-7):
+    """toolbox/register_utils.py:247-317 with normalize_w=True, best_k=0, w_threshold=0."""
+    f32 = np.float32
+    x1, x2 = np.asarray(x1, f32), np.asarray(x2, f32)
+    w = np.asarray(weights, f32)
+    w = w / (w.sum() + f32(eps))
+    x1_mean = (w[None] @ x1) / (w.sum() + f32(eps))
+    x2_mean = (w[None] @ x2) / (w.sum() + f32(eps))
+    x1c, x2c = x1 - x1_mean, x2 - x2_mean
+    cov = x1c.T @ (w[:, None] * x2c)
+    u, s, vt = np.linalg.svd(cov.astype(f32))
+    v = vt.T
+    det = np.linalg.det((v.T @ u.T).astype(np.float64))
+    d = np.diag(np.array([1, 1, det], f32))
+    r = (v @ d @ u.T).astype(f32)
+    t = x2_mean.T - r @ x1_mean.T
+    return r, t.astype(f32)
+
+
+def pairwise_ego_motion(feats_s, feats_t, coor_s, coor_t, choice_s, choice_t, duration, max_speed,
+                        alpha, beta, n_iters):
+    """models/egomotion.py:169-192 after key-point choice.  Returns (pose [4,4], perm [n,n])."""
+    f32 = np.float32
+    fs, cs = np.asarray(feats_s, f32)[choice_s], np.asarray(coor_s, f32)[choice_s]
+    ft, ct = np.asarray(feats_t, f32)[choice_t], np.asarray(coor_t, f32)[choice_t]
+    thr = duration * max_speed
+    support = (square_distance(cs, ct) < f32(thr ** 2)).astype(f32)
+    feat_dist = square_distance(fs, ft, normalised=True)
+    softplus = f32(np.log1p(np.exp(np.float64(alpha))))
+    affinity = -(feat_dist - softplus) / (f32(np.exp(np.float64(beta))) + f32(0.02))
+    perm = np.exp(sinkhorn(affinity, n_iters)) * support
+    rowsum = perm.sum(1, keepdims=True)
+    weighted_t = (perm @ ct) / (rowsum + f32(1e-20))
+    r, t = kabsch(cs, weighted_t, rowsum[:, 0])
+    pose = np.eye(4, dtype=f32)
+    pose[:3, :3] = r
+    pose[:3, 3] = t[:, 0]
+    return pose, perm
+
+
+# ------------------------------------------------------------------------------------------------
+# A12 Chamfer  (chamfer_distance/chamfer_distance.cpp:59-111, 114-177)
+# ------------------------------------------------------------------------------------------------
+def chamfer_forward(xyz1, xyz2):
+    xyz1 = np.ascontiguousarray(xyz1, np.float32)
+    xyz2 = np.ascontiguousarray(xyz2, np.float32)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    d1, d2 = np.empty((b, n), np.float32), np.empty((b, m), np.float32)
+    i1, i2 = np.empty((b, n), np.int32), np.empty((b, m), np.int32)
+    f = lib().orc_nnsearch
+    f(b, n, m, _p(xyz1), _p(xyz2), _p(d1), _p(i1))
+    f(b, m, n, _p(xyz2), _p(xyz1), _p(d2), _p(i2))
+    return d1, d2, i1, i2
+
+
+def chamfer_backward(xyz1, xyz2, gd1, gd2, idx1, idx2):
+    xyz1 = np.ascontiguousarray(xyz1, np.float32)
+    xyz2 = np.ascontiguousarray(xyz2, np.float32)
+    gd1, gd2 = np.ascontiguousarray(gd1, np.float32), np.ascontiguousarray(gd2, np.float32)
+    idx1, idx2 = np.ascontiguousarray(idx1, np.int32), np.ascontiguousarray(idx2, np.int32)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    g1, g2 = np.empty_like(xyz1), np.empty_like(xyz2)
+    lib().orc_chamfer_backward(b, n, m, _p(xyz1), _p(xyz2), _p(gd1), _p(gd2), _p(idx1), _p(idx2), _p(g1), _p(g2))
+    return g1, g2
+
+
+# ------------------------------------------------------------------------------------------------
+# M1-M3 metric definitions
+# ------------------------------------------------------------------------------------------------
+def compute_iou(predictions, gt, n_class=2, ignore_index=-1):
+    """libs/loss.py:17-50: per-class counts divided by 1e3."""
+    predictions, gt = np.asarray(predictions), np.asarray(gt)
+    inter, union, pp, gp = [], [], [], []
+    for c in range(n_class):
+        if c == ignore_index:
+            continue
+        sg, sp = gt == c, predictions == c
+        i = (predictions[sg] == c).sum() / 1e3
+        pp.append(sp.sum() / 1e3)
+        gp.append(sg.sum() / 1e3)
+        inter.append(i)
+        union.append(sp.sum() / 1e3 + sg.sum() / 1e3 - i)
+    return {'intersection': np.array(inter), 'union': np.array(union),
+            'pred_positives': np.array(pp), 'gt_positives': np.array(gp)}
+
+
+def mean_iou(stats_list):
+    """toolbox/metrics.py:43-60 over accumulated batch stats: IoU = sum(I) / (sum(U) + 1e-20), class mean."""
+    i = sum(s['intersection'] for s in stats_list)
+    u = sum(s['union'] for s in stats_list)
+    return float((i / (u + 1e-20)).mean())
+
+
+def rotation_error(r1, r2):
+    """toolbox/register_utils.py:19-43 (degrees)."""
+    r = np.einsum('bji,bjk->bik', np.asarray(r1, np.float32), np.asarray(r2, np.float32))
+    e = np.clip((np.trace(r, axis1=1, axis2=2) - 1) / 2, -1, 1)
+    return np.degrees(np.arccos(e))
+
+
+def translation_error(t1, t2):
+    """toolbox/register_utils.py:46-56."""
+    return np.linalg.norm(np.asarray(t1, np.float32) - np.asarray(t2, np.float32), axis=(1, 2))
+
+
+def ego_motion_compensation(points, time_indice, tsfm):
+    """toolbox/register_utils.py:59-70."""
+    tr = np.asarray(tsfm)[np.asarray(time_indice).astype(np.int64)]
+    return np.einsum('nij,nj->ni', tr[:, :3, :3], np.asarray(points)) + tr[:, :3, 3]
+
+
+def reconstruct_sequence(points, time_indice, inst_labels, tsfm, n_frames):
+    """toolbox/register_utils.py:73-93."""
+    tr = np.asarray(tsfm).reshape(-1, 4, 4)
+    idx = (np.asarray(inst_labels).astype(np.int64) * n_frames + np.asarray(time_indice).astype(np.int64))
+    tr = tr[idx]
+    return np.einsum('nij,nj->ni', tr[:, :3, :3], np.asarray(points)) + tr[:, :3, 3]
+
+
+def scene_flow_epe(rec_est, input_points, time_indice, ego_motion_gt, inst_labels, inst_motion_gt, n_frames):
+    """libs/tester.py:67-77: EPE per point = ||(rec_est - x) - (rec_gt - x)||_2 for points with t > 0."""
+    x = np.asarray(input_points, np.float64)
+    t = np.asarray(time_indice).astype(np.int64)
+    gt = reconstruct_sequence(ego_motion_compensation(x, t, np.asarray(ego_motion_gt, np.float32)), t,
+                              inst_labels, np.asarray(inst_motion_gt, np.float64), n_frames)
+    err = np.linalg.norm((np.asarray(rec_est, np.float64) - x) - (gt - x), axis=1)
+    return err[t > 0]

@@ -1,0 +1,44 @@
+"""Shared builders for the parity tests (inputs are regenerated from seeds, never read from /root/reference)."""
+import numpy as np
+
+import oracle
+from pcaccumulation_amd.config import default_config
+from pcaccumulation_amd.dataloader import collate_fn
+from pcaccumulation_amd.synthetic import make_sequence, attach_voxels
+
+
+def oracle_voxeliser(cfg):
+    vg = cfg['voxel_generator']
+
+    def f(points):
+        out = oracle.voxelize(points, vg['voxel_size'], vg['range'], vg['n_sweeps'])
+        out.pop('num_points_per_voxel')
+        return out
+    return f
+
+
+def small_cfg(mode='val'):
+    return default_config('waymo', mode, n_sweeps=3, xy_range=8)
+
+
+def make_batch(cfg, seeds, n_frames, pts_per_frame, mode='uniform', voxeliser=None):
+    vox = voxeliser or oracle_voxeliser(cfg)
+    samples = [attach_voxels(make_sequence(s, n_frames, pts_per_frame, cfg, mode=mode), vox) for s in seeds]
+    return collate_fn(samples)
+
+
+def vox_points(seed, n, cfg, frac_out=0.1):
+    """Same generator as tests/golden/make_golden.py:vox_points."""
+    rng = np.random.RandomState(seed)
+    r = np.asarray(cfg['voxel_generator']['range'], np.float64)
+    T = cfg['voxel_generator']['n_sweeps']
+    lo, hi = r[:3], r[3:]
+    span = hi - lo
+    p = lo + rng.uniform(-frac_out / 2, 1 + frac_out / 2, (n, 3)) * span
+    t = rng.randint(0, T, n)
+    edge = rng.randint(0, n, 32)
+    p[edge[:8], 0] = lo[0]
+    p[edge[8:16], 0] = hi[0]
+    p[edge[16:24], 1] = lo[1] + 0.25 * rng.randint(0, int(span[1] / 0.25), 8)
+    p[edge[24:], 2] = hi[2]
+    return np.concatenate([p, t[:, None]], axis=1).astype(np.float32)
