@@ -1,0 +1,177 @@
+/*
+ * pcacc.h -- C ABI of libpcacc_hip.so, the MI355X (gfx950) implementation of the PCAccumulation
+ * per-frame forward hot path.
+ *
+ * The reference has no FFI for this path: it is Python calling torch / torch_scatter / numba and one
+ * JIT-built torch extension (chamfer_distance).  Each entry point below therefore names the Python
+ * (or C++) interface of the reference it stands in for, `file:line` relative to the reference root.
+ * The host mirror (the .py files in pcaccumulation_amd/) binds these with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its comment says "host";
+ *   - no allocation, no synchronisation, no global state: the caller owns all buffers, passes scratch
+ *     through `workspace` (size from the matching *_workspace_bytes) and the HIP stream to launch on;
+ *   - return value: 0 on success, a negative PCACC_E_* code otherwise (launch errors are reported,
+ *     never printed-and-ignored as chamfer_distance.cu:152-154 does);
+ *   - tensors are dense row-major; BEV canvases and feature maps are CHANNELS-LAST
+ *     ([frame, y, x, channel]) -- the layout the scatter/gather kernels coalesce on;
+ *   - `dtype` arguments: PCACC_F32 or PCACC_BF16 for the canvas / feature-map element type.
+ */
+#ifndef PCACC_H_
+#define PCACC_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCACC_OK 0
+#define PCACC_E_ARG (-1)      /* bad argument (null pointer, negative size, unsupported channel count) */
+#define PCACC_E_WORKSPACE (-2) /* workspace too small */
+#define PCACC_E_LAUNCH (-3)   /* hipGetLastError() != hipSuccess after a launch */
+
+#define PCACC_F32 0
+#define PCACC_BF16 1
+
+/* Library / build identification: returns the gfx target string the kernels were compiled for. */
+const char *pcacc_target(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * A1. 4-D pillar voxelisation, first-touch numbering, bit-exact.
+ * Replaces libs/voxel_generator.py:4-61 (_points_to_voxel_reverse_kernel), :64-114 (points_to_voxel)
+ * and the array part of Voxelization.__call__ (:131-154).
+ *   points      [n,4] f32 (x,y,z,t)
+ *   voxel_size  host float[3], range host float[6] (xyz min, xyz max)
+ *   coords      [max_voxels,4] i32 (z,y,x,t); rows >= *num_voxels are left untouched
+ *   p2v         [n] i32, pillar id or -1 (out of range, t outside [0,nt), or beyond max_voxels)
+ *   num_voxels  [1] i32 (device)
+ * Pillar ids are the order in which cells are first touched when the points are visited in index
+ * order, exactly as the sequential reference numbers them.
+ * ---------------------------------------------------------------------------------------------- */
+int pcacc_voxelize_workspace_bytes(int64_t n, int nx, int ny, int nz, int nt, size_t *bytes /*host*/);
+int pcacc_voxelize(const float *points, int64_t n, const float *voxel_size, const float *range,
+                   int nx, int ny, int nz, int nt, int max_voxels,
+                   int32_t *coords, int32_t *p2v, int32_t *num_voxels,
+                   void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * A2'. Decode the collated `coordinates` tensor once per forward.
+ * Replaces the index arithmetic repeated in models/pillar_encoder.py:153-158 and :188-197:
+ * cell = b*nt*ny*nx + t*ny*nx + y*nx + x from rows (b,z,y,x,t).
+ *   coords        [m,5] f64 (collate_fn layout, libs/dataloader.py:18-20) when coords_is_f64 != 0,
+ *                 else [m,5] i32
+ *   cell          [m] i32
+ *   cell2pillar   [n_batch*nt*ny*nx] i32: pillar id occupying the cell, -1 if empty; on duplicate
+ *                 cells the highest pillar id wins ("later writes win", pillar_encoder.py:163)
+ * ---------------------------------------------------------------------------------------------- */
+int pcacc_cell_index(const void *coords, int coords_is_f64, int64_t m, int nx, int ny, int nt, int n_batch,
+                     int32_t *cell, int32_t *cell2pillar, void *stream);
+
+/* Occupied pillars of every frame in ascending cell order -- the order in which
+ * models/egomotion.py:419-424 enumerates them through the boolean occupancy mask.
+ *   sorted_pillars [m] i32; frame_offsets [n_frames+1] i32 (n_frames = n_batch*nt) */
+int pcacc_frame_pillars_workspace_bytes(int64_t n_cells, size_t *bytes /*host*/);
+int pcacc_frame_pillars(const int32_t *cell2pillar, int64_t n_cells, int64_t cells_per_frame,
+                        int32_t *sorted_pillars, int32_t *frame_offsets,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Point -> pillar CSR (points grouped by pillar, ascending point index inside a pillar for
+ * pillars of <= 64 points).  Internal layout shared by every per-pillar reduction below; it is what
+ * removes the atomics torch_scatter uses (models/motionnet.py:159-160, models/pillar_encoder.py:116,120).
+ *   p2v [n] i32 (all >= 0), seg_offsets [m+1] i32, order [n] i32
+ * ---------------------------------------------------------------------------------------------- */
+int pcacc_csr_workspace_bytes(int64_t n, int64_t m, size_t *bytes /*host*/);
+int pcacc_csr_build(const int32_t *p2v, int64_t n, int64_t m, int32_t *seg_offsets, int32_t *order,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
+/* A3. scatter(points, p2v, 'mean') and scatter(fb_labels, p2v, 'max') -- models/motionnet.py:159-160.
+ *   points [n,3] f32; labels [n] i64 or NULL; mean [m,3] f32; max_label [m] i64 (ignored if labels NULL) */
+int pcacc_segment_mean3_maxlabel(const float *points, const int64_t *labels, const int32_t *seg_offsets,
+                                 const int32_t *order, int64_t m, float *mean, int64_t *max_label, void *stream);
+
+/* A4 (pooling step). scatter(net, p2v, dim=0, reduce='max') -- models/pillar_encoder.py:116,120.
+ *   src [n,c] f32, c % 4 == 0, c <= 256; out [m,c] f32; arg [m,c] i32 = lowest point index attaining
+ *   the maximum (the element torch_scatter routes the gradient to). */
+int pcacc_segment_max(const float *src, int c, const int32_t *seg_offsets, const int32_t *order, int64_t m,
+                      float *out, int32_t *arg, void *stream);
+/* Backward of segment_max followed by the [p2v] gather is not needed separately: both reduce to
+ * grad_src[i,k] += grad_out[p2v[i],k] * (arg[p2v[i],k] == i). */
+int pcacc_segment_max_backward(const float *grad_out, const int32_t *arg, const int32_t *p2v, int64_t n, int c,
+                               float *grad_src, void *stream);
+
+/* Per-pillar sum of point rows: the backward of the `[point_to_voxel_map]` broadcast that follows each
+ * pooling (models/pillar_encoder.py:116).  src [n,c] f32, out [m,c] f32, c % 4 == 0, c <= 256. */
+int pcacc_segment_sum(const float *src, int c, const int32_t *seg_offsets, const int32_t *order, int64_t m,
+                      float *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * A5. Pillar scatter into the BEV canvas -- models/pillar_encoder.py:125-174 (scatter_point_pillar).
+ * One pass writes every canvas element exactly once (feature row or zeros), so there is no separate
+ * zero-fill: canvas[cell, :] = cell2pillar[cell] >= 0 ? feats[cell2pillar[cell], :] : 0.
+ *   feats [m,c] f32, c % 4 == 0 or c in {1,2,3}; canvas [n_cells, c] of `dtype` (channels-last)
+ * ---------------------------------------------------------------------------------------------- */
+int pcacc_pillar_scatter(const float *feats, const int32_t *cell2pillar, int64_t n_cells, int c,
+                         void *canvas, int dtype, void *stream);
+
+/* A6 and the backward of A5: row gather out[i,:] = src[idx[i],:] for rows of row_bytes bytes
+ * (row_bytes % 4 == 0).  Replaces models/pillar_encoder.py:177-204 (inverse_scatter_point_pillar)
+ * and the [point_to_voxel_map] gathers at models/motionnet.py:192-193. */
+int pcacc_gather_rows(const void *src, int row_bytes, const int32_t *idx, int64_t n_idx, void *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * A11. Per-point bilinear feature gather ("ungrid") -- models/pillar_encoder.py:231-267 and
+ * temporal_ungrid :206-228.  Direct 4-tap gather; the reference's replication of the feature map
+ * into fake H x W grids is not reproduced.  grid_sample semantics: bilinear, padding 'border',
+ * align_corners=False; u = x / x_scale, v = y / y_scale (fp32 division as in pillar_encoder.py:247-249).
+ *   fmap [n_maps,h,w,c] `dtype` channels-last; points [k,3] f32; map_idx [k] i32; out [k,c] f32; c % 4 == 0
+ * Backward accumulates into grad_fmap [n_maps,h,w,c] f32 (caller zero-fills) with fp32 atomics.
+ * ---------------------------------------------------------------------------------------------- */
+int pcacc_bilinear_gather(const void *fmap, int dtype, int n_maps, int h, int w, int c,
+                          const float *points, const int32_t *map_idx, int64_t k,
+                          float x_scale, float y_scale, float *out, void *stream);
+int pcacc_bilinear_gather_backward(const float *grad_out, int n_maps, int h, int w, int c,
+                                   const float *points, const int32_t *map_idx, int64_t k,
+                                   float x_scale, float y_scale, float *grad_fmap, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * A9. Ego-motion BEV warp -- models/motionnet.py:45-80 (get_transformed_grid) + :82-114 (warp_feats).
+ *   bev    [n_batch, nt, h, w, c] `dtype`; out same shape/dtype
+ *   inv_pose [n_batch, nt, 16] f32 row-major 4x4 = inverse of the estimated pose of frame t
+ * Frames 1..nt-1 are resampled bilinearly (zeros padding, align_corners=False) on the grid
+ * inv_pose[:2,:2] @ (pixel centre in metres) + inv_pose[:2,3], divided by |x_min|, |y_min|.
+ * Slot 0 receives frame nt-1 UNWARPED: bug-compatible with the leaked loop variable at
+ * models/motionnet.py:100,111 (trap 1).
+ * ---------------------------------------------------------------------------------------------- */
+int pcacc_bev_warp(const void *bev, int dtype, int n_batch, int nt, int h, int w, int c,
+                   const float *inv_pose, float x_reso, float y_reso, float x_min, float y_min,
+                   void *out, void *stream);
+
+/* A10. Per-point rigid transform -- models/motionnet.py:117-135 (transform_points).
+ *   points [n,3] f32; frame_idx [n] i32 = b*nt + t; tsfm [n_frames,16] f32; out [n,3] f32 */
+int pcacc_rigid_transform(const float *points, const int32_t *frame_idx, const float *tsfm, int64_t n,
+                          float *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * A12. Chamfer nearest neighbour -- chamfer_distance/chamfer_distance.cu:6-155 (forward kernel and
+ * launcher), chamfer_distance.cpp:59-111 (CPU twin), called through
+ * chamfer_distance/chamfer_distance.py:9-31.  dist = squared fp32 distance (x*x + y*y) + z*z of
+ * (target - query), idx = LOWEST target index attaining it (chamfer_distance.cu:39,49,129).
+ *   xyz1 [b,n,3], xyz2 [b,m,3] f32; dist1 [b,n], dist2 [b,m] f32; idx1 [b,n], idx2 [b,m] i32
+ * Backward -- chamfer_distance.cu:158-209 / chamfer_distance.cpp:114-177; grad_xyz* are zero-filled
+ * by the call.
+ * ---------------------------------------------------------------------------------------------- */
+int pcacc_chamfer_workspace_bytes(int b, int n, int m, size_t *bytes /*host*/);
+int pcacc_chamfer_forward(const float *xyz1, const float *xyz2, int b, int n, int m,
+                          float *dist1, int32_t *idx1, float *dist2, int32_t *idx2,
+                          void *workspace, size_t workspace_bytes, void *stream);
+int pcacc_chamfer_backward(const float *xyz1, const float *xyz2, int b, int n, int m,
+                           const float *grad_dist1, const int32_t *idx1, const float *grad_dist2, const int32_t *idx2,
+                           float *grad_xyz1, float *grad_xyz2, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCACC_H_ */

@@ -1,0 +1,246 @@
+// Bilinear sampling kernels on channels-last feature maps.
+//
+// With [map, y, x, channel] storage each of the 4 taps of a sample is ONE contiguous run of C elements,
+// so C/4 adjacent lanes fetch it with a single coalesced request.  The reference instead packs the points
+// into fake H x W sampling grids and replicates the whole feature map once per grid
+// (models/pillar_encoder.py:252-264); none of that traffic exists here.
+//
+// grid_sample semantics reproduced (ATen grid_sampler_2d, bilinear, align_corners=False):
+//   pix = ((g + 1) * size - 1) / 2;  'border': clamp pix to [0, size-1];  'zeros': drop outside corners
+//   weights: nw=(xe-x)(ye-y) ne=(x-xw)(ye-y) sw=(xe-x)(y-yn) se=(x-xw)(y-yn), xw=floor(x), xe=xw+1 ...
+#include "common.h"
+
+struct Taps {
+    int x0, y0;          // north-west corner
+    float w00, w01, w10, w11;   // (y0,x0) (y0,x1) (y1,x0) (y1,x1)
+    bool vx0, vx1, vy0, vy1;    // corner inside the map
+};
+
+template <bool BORDER>
+__device__ __forceinline__ Taps make_taps(float gx, float gy, int w, int h)
+{
+#pragma clang fp contract(off)
+    float x = ((gx + 1.0f) * (float)w - 1.0f) / 2.0f;
+    float y = ((gy + 1.0f) * (float)h - 1.0f) / 2.0f;
+    if (BORDER) {
+        x = fminf(fmaxf(x, 0.0f), (float)(w - 1));
+        y = fminf(fmaxf(y, 0.0f), (float)(h - 1));
+    }
+    const float xw = floorf(x), yn = floorf(y);
+    const float xe = xw + 1.0f, ys = yn + 1.0f;
+    Taps t;
+    t.w00 = (xe - x) * (ys - y);
+    t.w01 = (x - xw) * (ys - y);
+    t.w10 = (xe - x) * (y - yn);
+    t.w11 = (x - xw) * (y - yn);
+    // NaN / huge coordinates: every validity test fails, the sample is zero (never an OOB access)
+    t.vx0 = xw >= 0.0f && xw <= (float)(w - 1);
+    t.vx1 = xe >= 0.0f && xe <= (float)(w - 1);
+    t.vy0 = yn >= 0.0f && yn <= (float)(h - 1);
+    t.vy1 = ys >= 0.0f && ys <= (float)(h - 1);
+    t.x0 = t.vx0 ? (int)xw : (t.vx1 ? (int)xe - 1 : 0);
+    t.y0 = t.vy0 ? (int)yn : (t.vy1 ? (int)ys - 1 : 0);
+    return t;
+}
+
+template <int BF16>
+__device__ __forceinline__ float4 load4(const void *base, int64_t elem_off)
+{
+    if (BF16) {
+        const uint2 r = *reinterpret_cast<const uint2 *>(static_cast<const uint16_t *>(base) + elem_off);
+        return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u),
+                           __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
+    }
+    return *reinterpret_cast<const float4 *>(static_cast<const float *>(base) + elem_off);
+}
+
+template <int BF16>
+__device__ __forceinline__ void store4(void *base, int64_t elem_off, float4 v)
+{
+    if (BF16) {
+        uint2 r;
+        r.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+        r.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+        *reinterpret_cast<uint2 *>(static_cast<uint16_t *>(base) + elem_off) = r;
+    } else {
+        *reinterpret_cast<float4 *>(static_cast<float *>(base) + elem_off) = v;
+    }
+}
+
+__device__ __forceinline__ void axpy4(float4 &acc, float a, const float4 &v)
+{
+    acc.x += a * v.x; acc.y += a * v.y; acc.z += a * v.z; acc.w += a * v.w;
+}
+
+template <int BF16>
+__device__ __forceinline__ float4 sample4(const void *map, int w, int c, const Taps &t, int ch)
+{
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t r0 = ((int64_t)t.y0 * w + t.x0) * c + ch;
+    const int64_t r1 = r0 + (int64_t)w * c;
+    if (t.vy0 && t.vx0) axpy4(acc, t.w00, load4<BF16>(map, r0));
+    if (t.vy0 && t.vx1) axpy4(acc, t.w01, load4<BF16>(map, r0 + c));
+    if (t.vy1 && t.vx0) axpy4(acc, t.w10, load4<BF16>(map, r1));
+    if (t.vy1 && t.vx1) axpy4(acc, t.w11, load4<BF16>(map, r1 + c));
+    return acc;
+}
+
+// ---- A11 forward ---------------------------------------------------------------------------------------
+template <int BF16>
+__global__ __launch_bounds__(256) void bilinear_gather_kernel(const void *__restrict__ fmap, int n_maps, int h, int w, int c,
+                                                              const float *__restrict__ pts, const int32_t *__restrict__ map_idx,
+                                                              int64_t k, float xs, float ys, float *__restrict__ out)
+{
+    const int lpp = c / 4;
+    const int64_t total = k * lpp;
+    const int esz = BF16 ? 2 : 4;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t i = e / lpp;
+        const int ch = (int)(e - i * lpp) * 4;
+        const int mi = map_idx[i];
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (mi >= 0 && mi < n_maps) {
+            const float gx = __fdiv_rn(pts[i * 3 + 0], xs);       // pillar_encoder.py:248-249
+            const float gy = __fdiv_rn(pts[i * 3 + 1], ys);
+            const Taps t = make_taps<true>(gx, gy, w, h);
+            r = sample4<BF16>(static_cast<const char *>(fmap) + (int64_t)mi * h * w * c * esz, w, c, t, ch);
+        }
+        *reinterpret_cast<float4 *>(out + i * c + ch) = r;
+    }
+}
+
+extern "C" int pcacc_bilinear_gather(const void *fmap, int dtype, int n_maps, int h, int w, int c,
+                                     const float *points, const int32_t *map_idx, int64_t k,
+                                     float x_scale, float y_scale, float *out, void *stream)
+{
+    if (k < 0 || n_maps <= 0 || h <= 0 || w <= 0 || c <= 0 || (c % 4) || (dtype != PCACC_F32 && dtype != PCACC_BF16)) return PCACC_E_ARG;
+    if (k > 0 && (!fmap || !points || !map_idx || !out)) return PCACC_E_ARG;
+    if (k == 0) return PCACC_OK;
+    hipStream_t s = pcacc_stream(stream);
+    const int grid = pcacc_grid(k * (c / 4), 256);
+    if (dtype == PCACC_BF16)
+        bilinear_gather_kernel<1><<<grid, 256, 0, s>>>(fmap, n_maps, h, w, c, points, map_idx, k, x_scale, y_scale, out);
+    else
+        bilinear_gather_kernel<0><<<grid, 256, 0, s>>>(fmap, n_maps, h, w, c, points, map_idx, k, x_scale, y_scale, out);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}
+
+// ---- A11 backward (w.r.t. the feature map): 4 weighted scatter-adds of the C-vector, fp32 HW atomics -----
+__device__ __forceinline__ void atomic_axpy4(float *dst, float a, const float4 &g)
+{
+    atomicAdd(dst + 0, a * g.x); atomicAdd(dst + 1, a * g.y); atomicAdd(dst + 2, a * g.z); atomicAdd(dst + 3, a * g.w);
+}
+
+__global__ __launch_bounds__(256) void bilinear_gather_bwd_kernel(const float *__restrict__ grad_out, int n_maps, int h, int w, int c,
+                                                                  const float *__restrict__ pts, const int32_t *__restrict__ map_idx,
+                                                                  int64_t k, float xs, float ys, float *grad_fmap)
+{
+    const int lpp = c / 4;
+    const int64_t total = k * lpp;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t i = e / lpp;
+        const int ch = (int)(e - i * lpp) * 4;
+        const int mi = map_idx[i];
+        if (mi < 0 || mi >= n_maps) continue;
+        const float gx = __fdiv_rn(pts[i * 3 + 0], xs);
+        const float gy = __fdiv_rn(pts[i * 3 + 1], ys);
+        const Taps t = make_taps<true>(gx, gy, w, h);
+        const float4 g = *reinterpret_cast<const float4 *>(grad_out + i * c + ch);
+        float *base = grad_fmap + (int64_t)mi * h * w * c;
+        const int64_t r0 = ((int64_t)t.y0 * w + t.x0) * c + ch;
+        const int64_t r1 = r0 + (int64_t)w * c;
+        if (t.vy0 && t.vx0) atomic_axpy4(base + r0, t.w00, g);
+        if (t.vy0 && t.vx1) atomic_axpy4(base + r0 + c, t.w01, g);
+        if (t.vy1 && t.vx0) atomic_axpy4(base + r1, t.w10, g);
+        if (t.vy1 && t.vx1) atomic_axpy4(base + r1 + c, t.w11, g);
+    }
+}
+
+extern "C" int pcacc_bilinear_gather_backward(const float *grad_out, int n_maps, int h, int w, int c,
+                                              const float *points, const int32_t *map_idx, int64_t k,
+                                              float x_scale, float y_scale, float *grad_fmap, void *stream)
+{
+    if (k < 0 || n_maps <= 0 || h <= 0 || w <= 0 || c <= 0 || (c % 4)) return PCACC_E_ARG;
+    if (k > 0 && (!grad_out || !points || !map_idx || !grad_fmap)) return PCACC_E_ARG;
+    if (k == 0) return PCACC_OK;
+    bilinear_gather_bwd_kernel<<<pcacc_grid(k * (c / 4), 256), 256, 0, pcacc_stream(stream)>>>(
+        grad_out, n_maps, h, w, c, points, map_idx, k, x_scale, y_scale, grad_fmap);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}
+
+// ---- A9: ego-motion BEV warp -------------------------------------------------------------------------------
+template <int BF16>
+__global__ __launch_bounds__(256) void bev_warp_kernel(const void *__restrict__ bev, int n_batch, int nt, int h, int w, int c,
+                                                       const float *__restrict__ inv_pose, float x_reso, float y_reso,
+                                                       float x_min, float y_min, void *__restrict__ out)
+{
+    const int lpp = c / 4;
+    const int64_t total = (int64_t)n_batch * nt * h * w * lpp;
+    const int esz = BF16 ? 2 : 4;
+    const int64_t frame_elems = (int64_t)h * w * c;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int ch = (int)(e % lpp) * 4;
+        int64_t q = e / lpp;
+        const int x = (int)(q % w); q /= w;
+        const int y = (int)(q % h); q /= h;
+        const int t = (int)(q % nt);
+        const int b = (int)(q / nt);
+        const int64_t dst = (((int64_t)(b * nt + t) * h + y) * w + x) * c + ch;
+        float4 r;
+        if (t == 0) {
+            // motionnet.py:111: bev_feats[batch_idx, frame_idx:frame_idx+1] with frame_idx leaked = nt-1
+            r = load4<BF16>(bev, (((int64_t)(b * nt + nt - 1) * h + y) * w + x) * c + ch);
+        } else {
+#pragma clang fp contract(off)
+            const float *p = inv_pose + (int64_t)(b * nt + t) * 16;
+            const float mx = ((float)x + 0.5f) * x_reso + x_min;          // motionnet.py:60-68
+            const float my = ((float)y + 0.5f) * y_reso + y_min;
+            const float tx = (p[0] * mx + p[1] * my) + p[3];              // pose[:2,:2] @ grid + pose[:2,3:4]
+            const float ty = (p[4] * mx + p[5] * my) + p[7];
+            const Taps tp = make_taps<false>(tx / fabsf(x_min), ty / fabsf(y_min), w, h);
+            r = sample4<BF16>(static_cast<const char *>(bev) + (int64_t)(b * nt + t) * frame_elems * esz, w, c, tp, ch);
+        }
+        store4<BF16>(out, dst, r);
+    }
+}
+
+extern "C" int pcacc_bev_warp(const void *bev, int dtype, int n_batch, int nt, int h, int w, int c,
+                              const float *inv_pose, float x_reso, float y_reso, float x_min, float y_min,
+                              void *out, void *stream)
+{
+    if (n_batch <= 0 || nt <= 0 || h <= 0 || w <= 0 || c <= 0 || (c % 4) || (dtype != PCACC_F32 && dtype != PCACC_BF16)) return PCACC_E_ARG;
+    if (!bev || !inv_pose || !out) return PCACC_E_ARG;
+    hipStream_t s = pcacc_stream(stream);
+    const int64_t total = (int64_t)n_batch * nt * h * w * (c / 4);
+    if (dtype == PCACC_BF16)
+        bev_warp_kernel<1><<<pcacc_grid(total, 256), 256, 0, s>>>(bev, n_batch, nt, h, w, c, inv_pose, x_reso, y_reso, x_min, y_min, out);
+    else
+        bev_warp_kernel<0><<<pcacc_grid(total, 256), 256, 0, s>>>(bev, n_batch, nt, h, w, c, inv_pose, x_reso, y_reso, x_min, y_min, out);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}
+
+// ---- A10: per-point rigid transform ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rigid_transform_kernel(const float *__restrict__ pts, const int32_t *__restrict__ frame_idx,
+                                                              const float *__restrict__ tsfm, int64_t n, float *__restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float *m = tsfm + (int64_t)frame_idx[i] * 16;
+        const float x = pts[i * 3 + 0], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
+        out[i * 3 + 0] = m[0] * x + m[1] * y + m[2] * z + m[3];
+        out[i * 3 + 1] = m[4] * x + m[5] * y + m[6] * z + m[7];
+        out[i * 3 + 2] = m[8] * x + m[9] * y + m[10] * z + m[11];
+    }
+}
+
+extern "C" int pcacc_rigid_transform(const float *points, const int32_t *frame_idx, const float *tsfm, int64_t n,
+                                     float *out, void *stream)
+{
+    if (n < 0 || (n > 0 && (!points || !frame_idx || !tsfm || !out))) return PCACC_E_ARG;
+    if (n == 0) return PCACC_OK;
+    rigid_transform_kernel<<<pcacc_grid(n, 256), 256, 0, pcacc_stream(stream)>>>(points, frame_idx, tsfm, n, out);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}

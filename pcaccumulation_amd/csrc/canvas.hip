@@ -1,0 +1,241 @@
+// Pillar <-> BEV canvas movement in channels-last layout.
+//
+// The reference builds the canvas per batch element with `canvas[:, indices] = voxels.t()` on an NCHW
+// tensor (models/pillar_encoder.py:144-170): a zero fill of the whole canvas followed by M writes of C
+// values each at a stride of nt*ny*nx floats.  Here the canvas is [cell, channel]; a dense inverse table
+// cell -> pillar id (built once per forward from the collated coordinates) turns the scatter into ONE
+// streaming pass that writes every canvas byte exactly once, in 16-byte pieces, 1 KiB per wave store:
+//   HBM traffic = canvas bytes (write) + 4 B/cell (table) + one feature row per occupied cell (read)
+// which is the algorithmic minimum (SURVEY.md 8d "pillar scatter").
+#include "scan.h"
+
+// ---- coordinates [m,5] = (b,z,y,x,t) -> linear cell index + inverse table ----------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void cell_index_kernel(const T *__restrict__ coords, int64_t m, int nx, int ny, int nt,
+                                                         int64_t n_cells, int32_t *__restrict__ cell, int32_t *cell2pillar)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = (int64_t)coords[i * 5 + 0];
+        const int64_t y = (int64_t)coords[i * 5 + 2];
+        const int64_t x = (int64_t)coords[i * 5 + 3];
+        const int64_t t = (int64_t)coords[i * 5 + 4];
+        // pillar_encoder.py:158: t*nx*ny + y*nx + x inside sample b
+        const int64_t c = ((b * nt + t) * ny + y) * nx + x;
+        const bool ok = c >= 0 && c < n_cells && x >= 0 && x < nx && y >= 0 && y < ny && t >= 0 && t < nt;
+        cell[i] = ok ? (int32_t)c : -1;
+        if (ok) atomicMax(&cell2pillar[c], (int32_t)i);
+    }
+}
+
+extern "C" int pcacc_cell_index(const void *coords, int coords_is_f64, int64_t m, int nx, int ny, int nt, int n_batch,
+                                int32_t *cell, int32_t *cell2pillar, void *stream)
+{
+    if (m < 0 || nx <= 0 || ny <= 0 || nt <= 0 || n_batch <= 0 || !cell2pillar) return PCACC_E_ARG;
+    const int64_t n_cells = (int64_t)n_batch * nt * ny * nx;
+    if (n_cells >= 0x7fffffffLL || m >= 0x7fffffffLL) return PCACC_E_ARG;
+    if (m > 0 && (!coords || !cell)) return PCACC_E_ARG;
+    hipStream_t s = pcacc_stream(stream);
+    if (hipMemsetAsync(cell2pillar, 0xFF, (size_t)n_cells * 4, s) != hipSuccess) return PCACC_E_LAUNCH;   // -1
+    if (m == 0) return PCACC_OK;
+    if (coords_is_f64)
+        cell_index_kernel<double><<<pcacc_grid(m, 256), 256, 0, s>>>(static_cast<const double *>(coords), m, nx, ny, nt,
+                                                                   n_cells, cell, cell2pillar);
+    else
+        cell_index_kernel<int32_t><<<pcacc_grid(m, 256), 256, 0, s>>>(static_cast<const int32_t *>(coords), m, nx, ny, nt,
+                                                                    n_cells, cell, cell2pillar);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}
+
+// ---- occupied pillars per frame in ascending cell order (stream compaction of cell2pillar) -------------
+__global__ __launch_bounds__(256) void fp_count(const int32_t *__restrict__ c2p, int64_t n_cells, int *chunk_sums)
+{
+    __shared__ int lds[4];
+    const int64_t base = (int64_t)blockIdx.x * PCACC_CHUNK;
+    int acc = 0;
+#pragma unroll
+    for (int r = 0; r < PCACC_CHUNK_ROWS; ++r) {
+        const int64_t i = base + r * 256 + threadIdx.x;
+        acc += __popcll(__ballot(i < n_cells && c2p[i] >= 0));
+    }
+    if (lane_id() == 0) lds[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_sums[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+}
+
+__global__ __launch_bounds__(256) void fp_assign(const int32_t *__restrict__ c2p, int64_t n_cells, int64_t cells_per_frame,
+                                                 const int *chunk_offsets, int32_t *sorted_pillars, int32_t *frame_offsets)
+{
+    __shared__ int lds[4];
+    const int64_t base = (int64_t)blockIdx.x * PCACC_CHUNK;
+    int carry = chunk_offsets[blockIdx.x];
+    for (int r = 0; r < PCACC_CHUNK_ROWS; ++r) {
+        const int64_t i = base + r * 256 + threadIdx.x;
+        const int p = (i < n_cells) ? c2p[i] : -1;
+        const int f = p >= 0;
+        int tot;
+        const int rank = carry + block256_exclusive_scan(f, lds, &tot);
+        carry += tot;
+        if (f) sorted_pillars[rank] = p;
+        if (i < n_cells && (i % cells_per_frame) == 0) frame_offsets[i / cells_per_frame] = rank;
+        if (i == n_cells - 1) frame_offsets[n_cells / cells_per_frame] = rank + f;
+    }
+}
+
+extern "C" int pcacc_frame_pillars_workspace_bytes(int64_t n_cells, size_t *bytes)
+{
+    if (!bytes || n_cells < 0) return PCACC_E_ARG;
+    *bytes = pcacc_align((size_t)(pcacc_chunks(n_cells) + 1) * 4);
+    return PCACC_OK;
+}
+
+extern "C" int pcacc_frame_pillars(const int32_t *cell2pillar, int64_t n_cells, int64_t cells_per_frame,
+                                   int32_t *sorted_pillars, int32_t *frame_offsets,
+                                   void *workspace, size_t workspace_bytes, void *stream)
+{
+    size_t need;
+    if (pcacc_frame_pillars_workspace_bytes(n_cells, &need) != PCACC_OK) return PCACC_E_ARG;
+    if (n_cells <= 0 || cells_per_frame <= 0 || (n_cells % cells_per_frame) || !cell2pillar || !frame_offsets ||
+        !sorted_pillars)
+        return PCACC_E_ARG;
+    if (!workspace || workspace_bytes < need) return PCACC_E_WORKSPACE;
+    hipStream_t s = pcacc_stream(stream);
+    int *sums = static_cast<int *>(workspace);
+    const int chunks = pcacc_chunks(n_cells);
+    fp_count<<<chunks, 256, 0, s>>>(cell2pillar, n_cells, sums);
+    scan_chunk_sums<<<1, 1024, 0, s>>>(sums, chunks, nullptr, -1);
+    fp_assign<<<chunks, 256, 0, s>>>(cell2pillar, n_cells, cells_per_frame, sums, sorted_pillars, frame_offsets);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}
+
+// ---- A5: the pillar-scatter kernel -----------------------------------------------------------------------
+// One 16-byte piece of the canvas per lane per iteration.  For C=32 fp32 a cell is 8 pieces (128 B), so a
+// wave covers 8 consecutive cells = 1 KiB contiguous; the 8 lanes of a cell read the same table word
+// (one broadcast request) and one contiguous 128-byte feature row.  XCD note: block b runs on XCD b%8 and
+// a grid-stride step moves all blocks forward together, so each XCD streams its own 1/8 interleave of the
+// canvas with no reuse to lose -- no remap needed for a pure streaming pass.
+template <int OUT_BF16>
+__global__ __launch_bounds__(256) void pillar_scatter_vec4(const float4 *__restrict__ feats, const int32_t *__restrict__ c2p,
+                                                           int64_t n_pieces, int ppc /*pieces per cell, f32 side*/,
+                                                           void *__restrict__ canvas)
+{
+    if (OUT_BF16) {
+        // one lane produces 8 bf16 channels = 16 B of output from two float4 of input
+        const int opc = ppc / 2;                               // output pieces per cell
+        uint4 *out = static_cast<uint4 *>(canvas);
+        for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n_pieces; e += (int64_t)gridDim.x * 256) {
+            const int64_t cell = e / opc;
+            const int sub = (int)(e - cell * opc);
+            const int p = c2p[cell];
+            uint4 o = make_uint4(0u, 0u, 0u, 0u);
+            if (p >= 0) {
+                const float4 a = feats[(int64_t)p * ppc + sub * 2];
+                const float4 b = feats[(int64_t)p * ppc + sub * 2 + 1];
+                o.x = (uint32_t)f32_to_bf16(a.x) | ((uint32_t)f32_to_bf16(a.y) << 16);
+                o.y = (uint32_t)f32_to_bf16(a.z) | ((uint32_t)f32_to_bf16(a.w) << 16);
+                o.z = (uint32_t)f32_to_bf16(b.x) | ((uint32_t)f32_to_bf16(b.y) << 16);
+                o.w = (uint32_t)f32_to_bf16(b.z) | ((uint32_t)f32_to_bf16(b.w) << 16);
+            }
+            out[e] = o;
+        }
+    } else {
+        float4 *out = static_cast<float4 *>(canvas);
+        for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n_pieces; e += (int64_t)gridDim.x * 256) {
+            const int64_t cell = e / ppc;
+            const int sub = (int)(e - cell * ppc);
+            const int p = c2p[cell];
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p >= 0) o = feats[(int64_t)p * ppc + sub];
+            out[e] = o;
+        }
+    }
+}
+
+// narrow canvases (C = 1, 2, 3: occupancy, labels, pillar means) -- one element per lane
+template <int OUT_BF16>
+__global__ __launch_bounds__(256) void pillar_scatter_scalar(const float *__restrict__ feats, const int32_t *__restrict__ c2p,
+                                                             int64_t n_elems, int c, void *__restrict__ canvas)
+{
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n_elems; e += (int64_t)gridDim.x * 256) {
+        const int64_t cell = e / c;
+        const int k = (int)(e - cell * c);
+        const int p = c2p[cell];
+        const float v = (p >= 0) ? feats[(int64_t)p * c + k] : 0.f;
+        if (OUT_BF16) static_cast<uint16_t *>(canvas)[e] = f32_to_bf16(v);
+        else static_cast<float *>(canvas)[e] = v;
+    }
+}
+
+extern "C" int pcacc_pillar_scatter(const float *feats, const int32_t *cell2pillar, int64_t n_cells, int c,
+                                    void *canvas, int dtype, void *stream)
+{
+    if (n_cells < 0 || c <= 0 || !cell2pillar || !canvas || (dtype != PCACC_F32 && dtype != PCACC_BF16)) return PCACC_E_ARG;
+    if (n_cells == 0) return PCACC_OK;
+    hipStream_t s = pcacc_stream(stream);
+    const bool vec = dtype == PCACC_F32 ? (c % 4 == 0) : (c % 8 == 0);
+    if (vec) {
+        const int ppc = c / 4;
+        if (dtype == PCACC_F32) {
+            const int64_t n = n_cells * ppc;
+            pillar_scatter_vec4<0><<<pcacc_grid(n, 256), 256, 0, s>>>(reinterpret_cast<const float4 *>(feats), cell2pillar, n,
+                                                                       ppc, canvas);
+        } else {
+            const int64_t n = n_cells * (ppc / 2);
+            pillar_scatter_vec4<1><<<pcacc_grid(n, 256), 256, 0, s>>>(reinterpret_cast<const float4 *>(feats), cell2pillar, n,
+                                                                       ppc, canvas);
+        }
+    } else {
+        const int64_t n = n_cells * c;
+        if (dtype == PCACC_F32) pillar_scatter_scalar<0><<<pcacc_grid(n, 256), 256, 0, s>>>(feats, cell2pillar, n, c, canvas);
+        else pillar_scatter_scalar<1><<<pcacc_grid(n, 256), 256, 0, s>>>(feats, cell2pillar, n, c, canvas);
+    }
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}
+
+// ---- A6 / backward of A5: row gather -----------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint32_t *__restrict__ src, int words, const int32_t *__restrict__ idx,
+                                                          int64_t n_idx, uint32_t *__restrict__ out)
+{
+    const int64_t total = n_idx * words;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / words;
+        const int k = (int)(e - r * words);
+        const int64_t j = idx[r];
+        out[e] = (j >= 0) ? src[j * words + k] : 0u;
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel16(const uint4 *__restrict__ src, int pieces, const int32_t *__restrict__ idx,
+                                                            int64_t n_idx, uint4 *__restrict__ out)
+{
+    const int64_t total = n_idx * pieces;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / pieces;
+        const int k = (int)(e - r * pieces);
+        const int64_t j = idx[r];
+        out[e] = (j >= 0) ? src[j * pieces + k] : make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+
+extern "C" int pcacc_gather_rows(const void *src, int row_bytes, const int32_t *idx, int64_t n_idx, void *out, void *stream)
+{
+    if (n_idx < 0 || row_bytes <= 0 || (row_bytes % 4)) return PCACC_E_ARG;
+    if (n_idx > 0 && (!src || !idx || !out)) return PCACC_E_ARG;
+    if (n_idx == 0) return PCACC_OK;
+    hipStream_t s = pcacc_stream(stream);
+    if (row_bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(src) % 16 == 0) && (reinterpret_cast<uintptr_t>(out) % 16 == 0)) {
+        const int pieces = row_bytes / 16;
+        gather_rows_kernel16<<<pcacc_grid(n_idx * pieces, 256), 256, 0, s>>>(static_cast<const uint4 *>(src), pieces, idx, n_idx,
+                                                                            static_cast<uint4 *>(out));
+    } else {
+        const int words = row_bytes / 4;
+        gather_rows_kernel<<<pcacc_grid(n_idx * words, 256), 256, 0, s>>>(static_cast<const uint32_t *>(src), words, idx, n_idx,
+                                                                         static_cast<uint32_t *>(out));
+    }
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}
+
+extern "C" const char *pcacc_target(void) { return "gfx950"; }

@@ -1,0 +1,173 @@
+// A12: brute-force Chamfer nearest neighbour for gfx950.
+//
+// Reference kernel (chamfer_distance/chamfer_distance.cu:6-137): 512-thread blocks, 512-target tiles in
+// shared memory, grid (32,16) whose x dimension strides over the batch -- with the only caller's b = 1
+// (models/tpointnet.py:128) 16 blocks do all the work.  This version sizes the grid from the work:
+//   * a lane owns QPT queries in registers;
+//   * the target index is wave-uniform, so targets are fetched through the SCALAR cache (s_load) and
+//     used as SGPR operands: no LDS staging, no LDS bandwidth, no barriers;
+//   * when there are too few queries to fill 256 CUs the target range is split over blockIdx.y and the
+//     partial results are merged with a 64-bit atomicMin on (distance bits << 32 | index): unsigned order
+//     of that key is "smaller distance first, then LOWER index", which is exactly the reference's tie
+//     rule (strict '<' while scanning targets in ascending order, chamfer_distance.cu:39,49,129).
+// Distances are computed as (x*x + y*y) + z*z with x = target - query, un-fused, so they are bit-identical
+// to the scalar C++ path (chamfer_distance.cpp:72-76), which is the oracle twin that runs without CUDA.
+#include "common.h"
+
+#define CH_QPT 2
+#define CH_BLOCK 256
+
+__global__ __launch_bounds__(CH_BLOCK) void chamfer_nn_kernel(const float *__restrict__ q, int n, const float *__restrict__ tg, int m,
+                                                              int m_per_split, unsigned long long *__restrict__ packed,
+                                                              float *__restrict__ dist, int32_t *__restrict__ idx, int direct)
+{
+#pragma clang fp contract(off)
+    const int bi = blockIdx.z;
+    q += (int64_t)bi * n * 3;
+    tg += (int64_t)bi * m * 3;
+    const int k_begin = blockIdx.y * m_per_split;
+    const int k_end = min(m, k_begin + m_per_split);
+    const int j0 = (blockIdx.x * CH_BLOCK + threadIdx.x) * CH_QPT;
+
+    float qx[CH_QPT], qy[CH_QPT], qz[CH_QPT], best[CH_QPT];
+    int besti[CH_QPT];
+#pragma unroll
+    for (int r = 0; r < CH_QPT; ++r) {
+        const int j = min(j0 + r, n - 1);
+        qx[r] = q[(int64_t)j * 3 + 0];
+        qy[r] = q[(int64_t)j * 3 + 1];
+        qz[r] = q[(int64_t)j * 3 + 2];
+        best[r] = __builtin_inff();
+        besti[r] = k_begin;
+    }
+    for (int k = k_begin; k < k_end; ++k) {
+        const float tx = tg[(int64_t)k * 3 + 0];      // wave-uniform -> scalar loads
+        const float ty = tg[(int64_t)k * 3 + 1];
+        const float tz = tg[(int64_t)k * 3 + 2];
+#pragma unroll
+        for (int r = 0; r < CH_QPT; ++r) {
+            const float x = tx - qx[r], y = ty - qy[r], z = tz - qz[r];
+            const float d = (x * x + y * y) + z * z;
+            // first target of the range is always taken (the reference's `k == 0 ||`), so a NaN
+            // distance at k_begin behaves as in the reference
+            const bool take = (k == k_begin) || (d < best[r]);
+            best[r] = take ? d : best[r];
+            besti[r] = take ? k : besti[r];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < CH_QPT; ++r) {
+        const int j = j0 + r;
+        if (j >= n || k_begin >= k_end) continue;
+        if (direct) {
+            dist[(int64_t)bi * n + j] = best[r];
+            idx[(int64_t)bi * n + j] = besti[r];
+        } else {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(best[r]) << 32) | (unsigned)besti[r];
+            atomicMin(&packed[(int64_t)bi * n + j], key);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void chamfer_unpack_kernel(const unsigned long long *__restrict__ packed, int64_t total,
+                                                             float *__restrict__ dist, int32_t *__restrict__ idx)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const unsigned long long key = packed[i];
+        dist[i] = __uint_as_float((unsigned)(key >> 32));
+        idx[i] = (int32_t)(key & 0xffffffffu);
+    }
+}
+
+static int chamfer_dir(const float *q, int n, const float *tg, int m, int b, unsigned long long *packed,
+                       float *dist, int32_t *idx, hipStream_t s)
+{
+    if (n == 0) return PCACC_OK;
+    if (m == 0) {   // no target: the reference leaves dist = 0, idx = 0
+        if (hipMemsetAsync(dist, 0, (size_t)b * n * 4, s) != hipSuccess) return PCACC_E_LAUNCH;
+        if (hipMemsetAsync(idx, 0, (size_t)b * n * 4, s) != hipSuccess) return PCACC_E_LAUNCH;
+        return PCACC_OK;
+    }
+    const int qblocks = (n + CH_BLOCK * CH_QPT - 1) / (CH_BLOCK * CH_QPT);
+    int splits = 1;
+    const int want = PCACC_CUS * 4;
+    if (qblocks * b < want) {
+        splits = (want + qblocks * b - 1) / (qblocks * b);
+        const int max_splits = (m + 1023) / 1024;           // keep >= 1024 targets per split
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+    }
+    const int per = (m + splits - 1) / splits;
+    splits = (m + per - 1) / per;
+    const int direct = splits == 1;
+    if (!direct && hipMemsetAsync(packed, 0xFF, (size_t)b * n * 8, s) != hipSuccess) return PCACC_E_LAUNCH;
+    chamfer_nn_kernel<<<dim3(qblocks, splits, b), CH_BLOCK, 0, s>>>(q, n, tg, m, per, packed, dist, idx, direct);
+    if (!direct) chamfer_unpack_kernel<<<pcacc_grid((int64_t)b * n, 256), 256, 0, s>>>(packed, (int64_t)b * n, dist, idx);
+    return PCACC_OK;
+}
+
+extern "C" int pcacc_chamfer_workspace_bytes(int b, int n, int m, size_t *bytes)
+{
+    if (!bytes || b < 0 || n < 0 || m < 0) return PCACC_E_ARG;
+    const size_t mx = (size_t)(n > m ? n : m);
+    *bytes = pcacc_align((size_t)b * mx * 8);
+    return PCACC_OK;
+}
+
+extern "C" int pcacc_chamfer_forward(const float *xyz1, const float *xyz2, int b, int n, int m,
+                                     float *dist1, int32_t *idx1, float *dist2, int32_t *idx2,
+                                     void *workspace, size_t workspace_bytes, void *stream)
+{
+    size_t need;
+    if (pcacc_chamfer_workspace_bytes(b, n, m, &need) != PCACC_OK) return PCACC_E_ARG;
+    if (b > 65535) return PCACC_E_ARG;
+    if (b == 0 || (n == 0 && m == 0)) return PCACC_OK;
+    if ((n > 0 && (!xyz1 || !dist1 || !idx1)) || (m > 0 && (!xyz2 || !dist2 || !idx2))) return PCACC_E_ARG;
+    if (need > 0 && (!workspace || workspace_bytes < need)) return PCACC_E_WORKSPACE;
+    hipStream_t s = pcacc_stream(stream);
+    unsigned long long *packed = static_cast<unsigned long long *>(workspace);
+    int rc = chamfer_dir(xyz1, n, xyz2, m, b, packed, dist1, idx1, s);
+    if (rc != PCACC_OK) return rc;
+    rc = chamfer_dir(xyz2, m, xyz1, n, b, packed, dist2, idx2, s);
+    if (rc != PCACC_OK) return rc;
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}
+
+// Backward: chamfer_distance.cu:158-209.  g = 2*grad_dist[j]; +g*(p-q) on the query, -g*(p-q) on its nearest
+// target.  The query-side term is unique per element; both terms use fp32 atomics because the two
+// directions write both gradient arrays.
+__global__ __launch_bounds__(256) void chamfer_grad_kernel(const float *__restrict__ xyz1, int n, const float *__restrict__ xyz2, int m,
+                                                           int b, const float *__restrict__ gd1, const int32_t *__restrict__ idx1,
+                                                           float *g1, float *g2)
+{
+    const int64_t total = (int64_t)b * n;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t bi = e / n;
+        const int64_t a = e * 3;
+        const int64_t c = (bi * m + idx1[e]) * 3;
+        const float g = gd1[e] * 2.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float d = g * (xyz1[a + k] - xyz2[c + k]);
+            atomicAdd(&g1[a + k], d);
+            atomicAdd(&g2[c + k], -d);
+        }
+    }
+}
+
+extern "C" int pcacc_chamfer_backward(const float *xyz1, const float *xyz2, int b, int n, int m,
+                                      const float *grad_dist1, const int32_t *idx1, const float *grad_dist2, const int32_t *idx2,
+                                      float *grad_xyz1, float *grad_xyz2, void *stream)
+{
+    if (b < 0 || n < 0 || m < 0) return PCACC_E_ARG;
+    if (b == 0) return PCACC_OK;
+    hipStream_t s = pcacc_stream(stream);
+    if (n > 0 && hipMemsetAsync(grad_xyz1, 0, (size_t)b * n * 12, s) != hipSuccess) return PCACC_E_LAUNCH;
+    if (m > 0 && hipMemsetAsync(grad_xyz2, 0, (size_t)b * m * 12, s) != hipSuccess) return PCACC_E_LAUNCH;
+    if (n == 0 || m == 0) return PCACC_OK;
+    chamfer_grad_kernel<<<pcacc_grid((int64_t)b * n, 256), 256, 0, s>>>(xyz1, n, xyz2, m, b, grad_dist1, idx1, grad_xyz1, grad_xyz2);
+    chamfer_grad_kernel<<<pcacc_grid((int64_t)b * m, 256), 256, 0, s>>>(xyz2, m, xyz1, n, b, grad_dist2, idx2, grad_xyz2, grad_xyz1);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}

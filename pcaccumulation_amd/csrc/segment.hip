@@ -1,0 +1,254 @@
+// Point -> pillar CSR and the per-pillar reductions built on it.
+//
+// torch_scatter reduces with one atomic per (point, channel).  Here the points are grouped by pillar
+// once per forward (counting sort: histogram, exclusive scan, cursor fill, then a tiny per-pillar
+// index sort so that the order inside a pillar is ascending point index = the order a sequential CPU
+// scatter visits them).  Every reduction afterwards is a contiguous, atomic-free, deterministic
+// segmented loop: pillars have ~3 points on average (models/motionnet.py:142).
+#include "scan.h"
+
+#define CSR_SORT_MAX 64      // pillars with more points keep the (arbitrary) cursor order
+
+__global__ __launch_bounds__(256) void csr_histogram(const int32_t *__restrict__ p2v, int64_t n, int *counts)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        atomicAdd(&counts[p2v[i]], 1);
+}
+
+__global__ __launch_bounds__(256) void csr_fill(const int32_t *__restrict__ p2v, int64_t n,
+                                                const int32_t *__restrict__ seg_offsets, int *cursor,
+                                                int32_t *order)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int s = p2v[i];
+        const int pos = seg_offsets[s] + atomicAdd(&cursor[s], 1);
+        order[pos] = (int32_t)i;
+    }
+}
+
+// one thread per pillar: insertion sort of its (few) point indices
+__global__ __launch_bounds__(256) void csr_sort_segments(const int32_t *__restrict__ seg_offsets, int64_t m,
+                                                         int32_t *order)
+{
+    for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < m; s += (int64_t)gridDim.x * 256) {
+        const int b = seg_offsets[s], e = seg_offsets[s + 1];
+        const int cnt = e - b;
+        if (cnt < 2 || cnt > CSR_SORT_MAX) continue;
+        for (int i = b + 1; i < e; ++i) {
+            const int32_t v = order[i];
+            int j = i - 1;
+            while (j >= b && order[j] > v) { order[j + 1] = order[j]; --j; }
+            order[j + 1] = v;
+        }
+    }
+}
+
+extern "C" int pcacc_csr_workspace_bytes(int64_t n, int64_t m, size_t *bytes)
+{
+    if (!bytes || n < 0 || m < 0) return PCACC_E_ARG;
+    *bytes = pcacc_align((size_t)(m + 1) * 4) + pcacc_align((size_t)(pcacc_chunks(m) + 1) * 4);
+    return PCACC_OK;
+}
+
+extern "C" int pcacc_csr_build(const int32_t *p2v, int64_t n, int64_t m, int32_t *seg_offsets, int32_t *order,
+                               void *workspace, size_t workspace_bytes, void *stream)
+{
+    size_t need;
+    if (pcacc_csr_workspace_bytes(n, m, &need) != PCACC_OK || !seg_offsets) return PCACC_E_ARG;
+    if (n > 0 && (!p2v || !order)) return PCACC_E_ARG;
+    if (n >= 0x7fffffffLL || m >= 0x7fffffffLL) return PCACC_E_ARG;
+    if (!workspace || workspace_bytes < need) return PCACC_E_WORKSPACE;
+    hipStream_t s = pcacc_stream(stream);
+    char *ws = static_cast<char *>(workspace);
+    int *counts = reinterpret_cast<int *>(ws);
+    int *sums = reinterpret_cast<int *>(ws + pcacc_align((size_t)(m + 1) * 4));
+    if (hipMemsetAsync(seg_offsets, 0, (size_t)(m + 1) * 4, s) != hipSuccess) return PCACC_E_LAUNCH;
+    if (m == 0 || n == 0) return PCACC_OK;
+    if (hipMemsetAsync(counts, 0, (size_t)(m + 1) * 4, s) != hipSuccess) return PCACC_E_LAUNCH;
+    const int chunks = pcacc_chunks(m);
+    csr_histogram<<<pcacc_grid(n, 256), 256, 0, s>>>(p2v, n, counts);
+    chunk_sums_i32<<<chunks, 256, 0, s>>>(counts, m, sums);
+    scan_chunk_sums<<<1, 1024, 0, s>>>(sums, chunks, nullptr, -1);
+    chunk_scan_i32<<<chunks, 256, 0, s>>>(counts, m, sums, seg_offsets, 1);
+    if (hipMemsetAsync(counts, 0, (size_t)m * 4, s) != hipSuccess) return PCACC_E_LAUNCH;
+    csr_fill<<<pcacc_grid(n, 256), 256, 0, s>>>(p2v, n, seg_offsets, counts, order);
+    csr_sort_segments<<<pcacc_grid(m, 256), 256, 0, s>>>(seg_offsets, m, order);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// A3: per-pillar mean of xyz (+ max of an int64 label).  One lane per pillar; the sum runs in ascending
+// point index (fp32, sequential) and is divided by the count -- torch_scatter's 'mean'.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void seg_mean3_maxlabel(const float *__restrict__ pts, const int64_t *__restrict__ labels,
+                                                          const int32_t *__restrict__ seg_offsets,
+                                                          const int32_t *__restrict__ order, int64_t m,
+                                                          float *__restrict__ mean, int64_t *__restrict__ max_label)
+{
+    for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < m; s += (int64_t)gridDim.x * 256) {
+        const int b = seg_offsets[s], e = seg_offsets[s + 1];
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        int64_t lab = 0;
+        for (int k = b; k < e; ++k) {
+            const int64_t i = order[k];
+            sx = __fadd_rn(sx, pts[i * 3 + 0]);
+            sy = __fadd_rn(sy, pts[i * 3 + 1]);
+            sz = __fadd_rn(sz, pts[i * 3 + 2]);
+            if (labels) {
+                const int64_t l = labels[i];
+                lab = (k == b || l > lab) ? l : lab;
+            }
+        }
+        const float cnt = (float)(e - b);
+        if (e > b) { sx = __fdiv_rn(sx, cnt); sy = __fdiv_rn(sy, cnt); sz = __fdiv_rn(sz, cnt); }
+        mean[s * 3 + 0] = sx; mean[s * 3 + 1] = sy; mean[s * 3 + 2] = sz;
+        if (labels) max_label[s] = lab;
+    }
+}
+
+extern "C" int pcacc_segment_mean3_maxlabel(const float *points, const int64_t *labels, const int32_t *seg_offsets,
+                                            const int32_t *order, int64_t m, float *mean, int64_t *max_label,
+                                            void *stream)
+{
+    if (m < 0 || (m > 0 && (!points || !seg_offsets || !order || !mean))) return PCACC_E_ARG;
+    if (labels && !max_label) return PCACC_E_ARG;
+    if (m == 0) return PCACC_OK;
+    seg_mean3_maxlabel<<<pcacc_grid(m, 256), 256, 0, pcacc_stream(stream)>>>(points, labels, seg_offsets, order, m,
+                                                                           mean, max_label);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// A4 pooling: per-pillar channel-wise max with arg (lowest point index).  c/4 lanes per pillar, each lane
+// owns 4 consecutive channels and streams the pillar's rows as float4 (a row of c floats is contiguous).
+// ---------------------------------------------------------------------------------------------------
+template <int LPP>   // lanes per pillar = c / 4
+__global__ __launch_bounds__(256) void seg_max_kernel(const float4 *__restrict__ src, const int32_t *__restrict__ seg_offsets,
+                                                      const int32_t *__restrict__ order, int64_t m,
+                                                      float4 *__restrict__ out, int4 *__restrict__ arg)
+{
+    const int sub = threadIdx.x % LPP;
+    const int64_t per_block = 256 / LPP;
+    for (int64_t s = (int64_t)blockIdx.x * per_block + threadIdx.x / LPP; s < m; s += (int64_t)gridDim.x * per_block) {
+        const int b = seg_offsets[s], e = seg_offsets[s + 1];
+        float4 best = make_float4(0.f, 0.f, 0.f, 0.f);
+        int4 bi = make_int4(-1, -1, -1, -1);
+        for (int k = b; k < e; ++k) {
+            const int i = order[k];
+            const float4 v = src[(int64_t)i * LPP + sub];
+            // strict '>' in ascending index order, but the lowest INDEX must win even when the cursor
+            // order of a >64-point pillar is not sorted: tie-break on the index explicitly.
+            if (bi.x < 0 || v.x > best.x || (v.x == best.x && i < bi.x)) { best.x = v.x; bi.x = i; }
+            if (bi.y < 0 || v.y > best.y || (v.y == best.y && i < bi.y)) { best.y = v.y; bi.y = i; }
+            if (bi.z < 0 || v.z > best.z || (v.z == best.z && i < bi.z)) { best.z = v.z; bi.z = i; }
+            if (bi.w < 0 || v.w > best.w || (v.w == best.w && i < bi.w)) { best.w = v.w; bi.w = i; }
+        }
+        out[s * LPP + sub] = best;
+        arg[s * LPP + sub] = bi;
+    }
+}
+
+extern "C" int pcacc_segment_max(const float *src, int c, const int32_t *seg_offsets, const int32_t *order, int64_t m,
+                                 float *out, int32_t *arg, void *stream)
+{
+    if (m < 0 || c <= 0 || (c % 4) || c > 256) return PCACC_E_ARG;
+    if (m > 0 && (!src || !seg_offsets || !order || !out || !arg)) return PCACC_E_ARG;
+    if (m == 0) return PCACC_OK;
+    hipStream_t s = pcacc_stream(stream);
+    const float4 *in4 = reinterpret_cast<const float4 *>(src);
+    float4 *out4 = reinterpret_cast<float4 *>(out);
+    int4 *arg4 = reinterpret_cast<int4 *>(arg);
+#define LAUNCH(L) seg_max_kernel<L><<<pcacc_grid(m * L, 256), 256, 0, s>>>(in4, seg_offsets, order, m, out4, arg4)
+    switch (c / 4) {
+        case 1: LAUNCH(1); break;
+        case 2: LAUNCH(2); break;
+        case 4: LAUNCH(4); break;
+        case 8: LAUNCH(8); break;
+        case 16: LAUNCH(16); break;
+        case 32: LAUNCH(32); break;
+        case 64: LAUNCH(64); break;
+        default: return PCACC_E_ARG;
+    }
+#undef LAUNCH
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}
+
+// grad_src[i,k] = (arg[p2v[i],k] == i) ? grad_out[p2v[i],k] : 0        (fully coalesced, no atomics)
+__global__ __launch_bounds__(256) void seg_max_bwd_kernel(const float4 *__restrict__ grad_out, const int4 *__restrict__ arg,
+                                                          const int32_t *__restrict__ p2v, int64_t n, int lpp,
+                                                          float4 *__restrict__ grad_src)
+{
+    const int64_t total = n * lpp;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t i = e / lpp;
+        const int sub = (int)(e - i * lpp);
+        const int64_t s = p2v[i];
+        const int4 a = arg[s * lpp + sub];
+        const float4 g = grad_out[s * lpp + sub];
+        float4 r;
+        r.x = (a.x == (int)i) ? g.x : 0.f;
+        r.y = (a.y == (int)i) ? g.y : 0.f;
+        r.z = (a.z == (int)i) ? g.z : 0.f;
+        r.w = (a.w == (int)i) ? g.w : 0.f;
+        grad_src[e] = r;
+    }
+}
+
+extern "C" int pcacc_segment_max_backward(const float *grad_out, const int32_t *arg, const int32_t *p2v, int64_t n, int c,
+                                          float *grad_src, void *stream)
+{
+    if (n < 0 || c <= 0 || (c % 4)) return PCACC_E_ARG;
+    if (n > 0 && (!grad_out || !arg || !p2v || !grad_src)) return PCACC_E_ARG;
+    if (n == 0) return PCACC_OK;
+    seg_max_bwd_kernel<<<pcacc_grid(n * (c / 4), 256), 256, 0, pcacc_stream(stream)>>>(
+        reinterpret_cast<const float4 *>(grad_out), reinterpret_cast<const int4 *>(arg), p2v, n, c / 4,
+        reinterpret_cast<float4 *>(grad_src));
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}
+
+// Backward of the [point_to_voxel_map] broadcast (models/pillar_encoder.py:116): per-pillar sum of point rows.
+template <int LPP>
+__global__ __launch_bounds__(256) void seg_sum_kernel(const float4 *__restrict__ src, const int32_t *__restrict__ seg_offsets,
+                                                      const int32_t *__restrict__ order, int64_t m, float4 *__restrict__ out)
+{
+    const int sub = threadIdx.x % LPP;
+    const int64_t per_block = 256 / LPP;
+    for (int64_t s = (int64_t)blockIdx.x * per_block + threadIdx.x / LPP; s < m; s += (int64_t)gridDim.x * per_block) {
+        const int b = seg_offsets[s], e = seg_offsets[s + 1];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = b; k < e; ++k) {
+            const float4 v = src[(int64_t)order[k] * LPP + sub];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        out[s * LPP + sub] = acc;
+    }
+}
+
+extern "C" int pcacc_segment_sum(const float *src, int c, const int32_t *seg_offsets, const int32_t *order, int64_t m,
+                                 float *out, void *stream)
+{
+    if (m < 0 || c <= 0 || (c % 4) || c > 256) return PCACC_E_ARG;
+    if (m > 0 && (!src || !seg_offsets || !order || !out)) return PCACC_E_ARG;
+    if (m == 0) return PCACC_OK;
+    hipStream_t s = pcacc_stream(stream);
+    const float4 *in4 = reinterpret_cast<const float4 *>(src);
+    float4 *out4 = reinterpret_cast<float4 *>(out);
+#define LAUNCH(L) seg_sum_kernel<L><<<pcacc_grid(m * L, 256), 256, 0, s>>>(in4, seg_offsets, order, m, out4)
+    switch (c / 4) {
+        case 1: LAUNCH(1); break;
+        case 2: LAUNCH(2); break;
+        case 4: LAUNCH(4); break;
+        case 8: LAUNCH(8); break;
+        case 16: LAUNCH(16); break;
+        case 32: LAUNCH(32); break;
+        case 64: LAUNCH(64); break;
+        default: return PCACC_E_ARG;
+    }
+#undef LAUNCH
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}

@@ -1,0 +1,273 @@
+"""ctypes binding of libpcacc_hip.so (include/pcacc.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; the entry points get raw device
+pointers, sizes and the current HIP stream.  There is NO fallback: if the library is missing or a
+tensor lives on the CPU the call raises -- the oracle under oracle/ is test infrastructure and is
+never reached from this module.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libpcacc_hip.so')
+
+F32, BF16 = 0, 1
+_ERR = {-1: 'PCACC_E_ARG', -2: 'PCACC_E_WORKSPACE', -3: 'PCACC_E_LAUNCH'}
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libpcacc_hip.so (after torch, so that it binds to the HIP runtime torch already loaded)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError('libpcacc_hip.so is not built (%s): run `python -c "import __graft_entry__ as g; '
+                              'g.build()"` or `make -C pcaccumulation_amd/csrc`. There is no CPU fallback.' % LIB_PATH)
+        _lib = ctypes.CDLL(LIB_PATH)
+        for name in EXPORTS:
+            getattr(_lib, name).restype = ctypes.c_int
+        _lib.pcacc_target.restype = ctypes.c_char_p
+    return _lib
+
+
+# every symbol include/pcacc.h declares (tests check the .so exports exactly these)
+EXPORTS = [
+    'pcacc_voxelize_workspace_bytes', 'pcacc_voxelize', 'pcacc_cell_index',
+    'pcacc_frame_pillars_workspace_bytes', 'pcacc_frame_pillars',
+    'pcacc_csr_workspace_bytes', 'pcacc_csr_build', 'pcacc_segment_mean3_maxlabel',
+    'pcacc_segment_max', 'pcacc_segment_max_backward', 'pcacc_segment_sum',
+    'pcacc_pillar_scatter', 'pcacc_gather_rows',
+    'pcacc_bilinear_gather', 'pcacc_bilinear_gather_backward', 'pcacc_bev_warp', 'pcacc_rigid_transform',
+    'pcacc_chamfer_workspace_bytes', 'pcacc_chamfer_forward', 'pcacc_chamfer_backward',
+]
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise NativeError('%s failed: %s' % (what, _ERR.get(rc, rc)))
+
+
+def _dev(t, dtype=None, what='tensor'):
+    if not t.is_cuda:
+        raise NativeError('%s must live on the GPU (got %s); the HIP path has no CPU fallback' % (what, t.device))
+    if dtype is not None and t.dtype != dtype:
+        raise NativeError('%s must be %s, got %s' % (what, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise NativeError('%s must be contiguous' % what)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def _i64(v):
+    return ctypes.c_int64(int(v))
+
+
+def _dtype_code(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise NativeError('canvas / feature map must be float32 or bfloat16, got %s' % t.dtype)
+
+
+# ---------------------------------------------------------------------------------------------------
+def voxelize(points, voxel_size, pc_range, grid, nt, max_voxels):
+    """points [n,4] f32 cuda -> (coords [max_voxels,4] i32, p2v [n] i32, num_voxels [1] i32), all on device."""
+    n = points.shape[0]
+    nx, ny, nz = (int(g) for g in grid)
+    dev = points.device
+    coords = torch.empty((max_voxels, 4), dtype=torch.int32, device=dev)
+    p2v = torch.empty((n,), dtype=torch.int32, device=dev)
+    num = torch.empty((1,), dtype=torch.int32, device=dev)
+    need = ctypes.c_size_t(0)
+    _check(lib().pcacc_voxelize_workspace_bytes(_i64(n), nx, ny, nz, int(nt), ctypes.byref(need)), 'voxelize_workspace')
+    ws = _ws(need.value, dev)
+    vs = (ctypes.c_float * 3)(*[float(v) for v in voxel_size])
+    rg = (ctypes.c_float * 6)(*[float(v) for v in pc_range])
+    _check(lib().pcacc_voxelize(_dev(points, torch.float32, 'points'), _i64(n), vs, rg, nx, ny, nz, int(nt),
+                                int(max_voxels), _dev(coords), _dev(p2v), _dev(num), _dev(ws),
+                                ctypes.c_size_t(ws.numel()), _stream()), 'voxelize')
+    return coords, p2v, num
+
+
+def cell_index(coords, nx, ny, nt, n_batch):
+    """coords [m,5] (b,z,y,x,t) f64 or i32 -> (cell [m] i32, cell2pillar [n_batch*nt*ny*nx] i32)."""
+    m = coords.shape[0]
+    dev = coords.device
+    if coords.dtype == torch.float64:
+        is_f64 = 1
+    elif coords.dtype == torch.int32:
+        is_f64 = 0
+    else:
+        raise NativeError('coordinates must be float64 (collate layout) or int32, got %s' % coords.dtype)
+    cell = torch.empty((m,), dtype=torch.int32, device=dev)
+    c2p = torch.empty((n_batch * nt * ny * nx,), dtype=torch.int32, device=dev)
+    _check(lib().pcacc_cell_index(_dev(coords, None, 'coordinates'), is_f64, _i64(m), int(nx), int(ny), int(nt),
+                                  int(n_batch), _dev(cell), _dev(c2p), _stream()), 'cell_index')
+    return cell, c2p
+
+
+def frame_pillars(cell2pillar, cells_per_frame, m):
+    dev = cell2pillar.device
+    n_cells = cell2pillar.numel()
+    sorted_p = torch.empty((m,), dtype=torch.int32, device=dev)
+    offs = torch.empty((n_cells // cells_per_frame + 1,), dtype=torch.int32, device=dev)
+    need = ctypes.c_size_t(0)
+    _check(lib().pcacc_frame_pillars_workspace_bytes(_i64(n_cells), ctypes.byref(need)), 'frame_pillars_workspace')
+    ws = _ws(need.value, dev)
+    _check(lib().pcacc_frame_pillars(_dev(cell2pillar, torch.int32), _i64(n_cells), _i64(cells_per_frame),
+                                     _dev(sorted_p), _dev(offs), _dev(ws), ctypes.c_size_t(ws.numel()), _stream()),
+           'frame_pillars')
+    return sorted_p, offs
+
+
+def csr_build(p2v, m):
+    n = p2v.shape[0]
+    dev = p2v.device
+    offs = torch.empty((m + 1,), dtype=torch.int32, device=dev)
+    order = torch.empty((n,), dtype=torch.int32, device=dev)
+    need = ctypes.c_size_t(0)
+    _check(lib().pcacc_csr_workspace_bytes(_i64(n), _i64(m), ctypes.byref(need)), 'csr_workspace')
+    ws = _ws(need.value, dev)
+    _check(lib().pcacc_csr_build(_dev(p2v, torch.int32, 'p2v'), _i64(n), _i64(m), _dev(offs), _dev(order), _dev(ws),
+                                 ctypes.c_size_t(ws.numel()), _stream()), 'csr_build')
+    return offs, order
+
+
+def segment_mean3_maxlabel(points, labels, offs, order, m):
+    dev = points.device
+    mean = torch.empty((m, 3), dtype=torch.float32, device=dev)
+    lab_out = torch.empty((m,), dtype=torch.int64, device=dev) if labels is not None else None
+    _check(lib().pcacc_segment_mean3_maxlabel(
+        _dev(points, torch.float32, 'points'), _dev(labels, torch.int64, 'labels') if labels is not None else None,
+        _dev(offs, torch.int32), _dev(order, torch.int32), _i64(m), _dev(mean),
+        _dev(lab_out) if lab_out is not None else None, _stream()), 'segment_mean3_maxlabel')
+    return mean, lab_out
+
+
+def segment_max(src, offs, order, m):
+    c = src.shape[1]
+    out = torch.empty((m, c), dtype=torch.float32, device=src.device)
+    arg = torch.empty((m, c), dtype=torch.int32, device=src.device)
+    _check(lib().pcacc_segment_max(_dev(src, torch.float32, 'src'), int(c), _dev(offs, torch.int32), _dev(order, torch.int32),
+                                   _i64(m), _dev(out), _dev(arg), _stream()), 'segment_max')
+    return out, arg
+
+
+def segment_max_backward(grad_out, arg, p2v, n):
+    c = grad_out.shape[1]
+    g = torch.empty((n, c), dtype=torch.float32, device=grad_out.device)
+    _check(lib().pcacc_segment_max_backward(_dev(grad_out, torch.float32, 'grad_out'), _dev(arg, torch.int32),
+                                            _dev(p2v, torch.int32), _i64(n), int(c), _dev(g), _stream()),
+           'segment_max_backward')
+    return g
+
+
+def segment_sum(src, offs, order, m):
+    c = src.shape[1]
+    out = torch.empty((m, c), dtype=torch.float32, device=src.device)
+    _check(lib().pcacc_segment_sum(_dev(src, torch.float32, 'src'), int(c), _dev(offs, torch.int32), _dev(order, torch.int32),
+                                   _i64(m), _dev(out), _stream()), 'segment_sum')
+    return out
+
+
+def pillar_scatter(feats, cell2pillar, out_dtype=torch.float32):
+    """feats [m,c] f32 -> canvas [n_cells, c] (channels-last) of out_dtype."""
+    c = feats.shape[1]
+    n_cells = cell2pillar.numel()
+    canvas = torch.empty((n_cells, c), dtype=out_dtype, device=feats.device)
+    _check(lib().pcacc_pillar_scatter(_dev(feats, torch.float32, 'feats'), _dev(cell2pillar, torch.int32), _i64(n_cells),
+                                      int(c), _dev(canvas), _dtype_code(canvas), _stream()), 'pillar_scatter')
+    return canvas
+
+
+def gather_rows(src, idx):
+    """out[i] = src[idx[i]] for a 2-D src with row size a multiple of 4 bytes; idx i32 (-1 -> zeros)."""
+    row_bytes = src.shape[1] * src.element_size()
+    out = torch.empty((idx.shape[0], src.shape[1]), dtype=src.dtype, device=src.device)
+    _check(lib().pcacc_gather_rows(_dev(src, None, 'src'), int(row_bytes), _dev(idx, torch.int32, 'idx'),
+                                   _i64(idx.shape[0]), _dev(out), _stream()), 'gather_rows')
+    return out
+
+
+def bilinear_gather(fmap, points, map_idx, x_scale, y_scale):
+    """fmap [n_maps,h,w,c] channels-last f32/bf16; points [k,3] f32; map_idx [k] i32 -> [k,c] f32."""
+    n_maps, h, w, c = fmap.shape
+    k = points.shape[0]
+    out = torch.empty((k, c), dtype=torch.float32, device=fmap.device)
+    _check(lib().pcacc_bilinear_gather(_dev(fmap, None, 'fmap'), _dtype_code(fmap), n_maps, h, w, c,
+                                       _dev(points, torch.float32, 'points'), _dev(map_idx, torch.int32, 'map_idx'),
+                                       _i64(k), ctypes.c_float(x_scale), ctypes.c_float(y_scale), _dev(out), _stream()),
+           'bilinear_gather')
+    return out
+
+
+def bilinear_gather_backward(grad_out, shape, points, map_idx, x_scale, y_scale):
+    n_maps, h, w, c = shape
+    g = torch.zeros(shape, dtype=torch.float32, device=grad_out.device)
+    _check(lib().pcacc_bilinear_gather_backward(_dev(grad_out, torch.float32, 'grad_out'), n_maps, h, w, c,
+                                                _dev(points, torch.float32), _dev(map_idx, torch.int32),
+                                                _i64(points.shape[0]), ctypes.c_float(x_scale), ctypes.c_float(y_scale),
+                                                _dev(g), _stream()), 'bilinear_gather_backward')
+    return g
+
+
+def bev_warp(bev, inv_pose, x_reso, y_reso, x_min, y_min):
+    """bev [B,T,H,W,C] channels-last; inv_pose [B,T,4,4] f32 -> warped [B,T,H,W,C]."""
+    b, t, h, w, c = bev.shape
+    out = torch.empty_like(bev)
+    _check(lib().pcacc_bev_warp(_dev(bev, None, 'bev'), _dtype_code(bev), b, t, h, w, c,
+                                _dev(inv_pose, torch.float32, 'inv_pose'), ctypes.c_float(x_reso), ctypes.c_float(y_reso),
+                                ctypes.c_float(x_min), ctypes.c_float(y_min), _dev(out), _stream()), 'bev_warp')
+    return out
+
+
+def rigid_transform(points, frame_idx, tsfm):
+    out = torch.empty_like(points)
+    _check(lib().pcacc_rigid_transform(_dev(points, torch.float32, 'points'), _dev(frame_idx, torch.int32, 'frame_idx'),
+                                       _dev(tsfm, torch.float32, 'tsfm'), _i64(points.shape[0]), _dev(out), _stream()),
+           'rigid_transform')
+    return out
+
+
+def chamfer_forward(xyz1, xyz2):
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    dev = xyz1.device
+    d1 = torch.empty((b, n), dtype=torch.float32, device=dev)
+    d2 = torch.empty((b, m), dtype=torch.float32, device=dev)
+    i1 = torch.empty((b, n), dtype=torch.int32, device=dev)
+    i2 = torch.empty((b, m), dtype=torch.int32, device=dev)
+    need = ctypes.c_size_t(0)
+    _check(lib().pcacc_chamfer_workspace_bytes(b, n, m, ctypes.byref(need)), 'chamfer_workspace')
+    ws = _ws(need.value, dev)
+    _check(lib().pcacc_chamfer_forward(_dev(xyz1, torch.float32, 'xyz1'), _dev(xyz2, torch.float32, 'xyz2'), b, n, m,
+                                       _dev(d1), _dev(i1), _dev(d2), _dev(i2), _dev(ws), ctypes.c_size_t(ws.numel()),
+                                       _stream()), 'chamfer_forward')
+    return d1, d2, i1, i2
+
+
+def chamfer_backward(xyz1, xyz2, gd1, gd2, i1, i2):
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    g1 = torch.empty_like(xyz1)
+    g2 = torch.empty_like(xyz2)
+    _check(lib().pcacc_chamfer_backward(_dev(xyz1, torch.float32), _dev(xyz2, torch.float32), b, n, m,
+                                        _dev(gd1, torch.float32, 'grad_dist1'), _dev(i1, torch.int32),
+                                        _dev(gd2, torch.float32, 'grad_dist2'), _dev(i2, torch.int32),
+                                        _dev(g1), _dev(g2), _stream()), 'chamfer_backward')
+    return g1, g2

@@ -1,0 +1,321 @@
+"""GPU parity tests: every HIP entry point (called through the C ABI via pcaccumulation_amd.native) against
+the oracle on the same seeded inputs and against the golden vectors the reference produced.
+Integer / index outputs bit-exact; fp32 tolerances are written at each assert."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from helpers import small_cfg, make_batch, vox_points
+from pcaccumulation_amd.config import default_config
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    return torch.device('cuda:0')
+
+
+@pytest.fixture(scope='module')
+def native():
+    from pcaccumulation_amd import native as n
+    n.lib()
+    return n
+
+
+def _vox(native, dev, pts, cfg, max_voxels=None):
+    vg = cfg['voxel_generator']
+    g = oracle.grid_size(vg['voxel_size'], vg['range'])
+    nt = vg['n_sweeps']
+    mv = int(g[0] * g[1] * g[2] * nt) if max_voxels is None else max_voxels
+    coords, p2v, num = native.voxelize(torch.from_numpy(pts).to(dev), vg['voxel_size'], vg['range'], g, nt, mv)
+    m = int(num.item())
+    return coords[:m].cpu().numpy(), p2v.cpu().numpy(), m
+
+
+# ---------------------------------------------------------------- A1
+def test_voxelize_golden_small(native, dev, golden):
+    g = golden('vox_small')
+    cfg = small_cfg()
+    coords, p2v, m = _vox(native, dev, g['points'], cfg)
+    assert m == int(g['num_voxels'][0])
+    assert np.array_equal(coords, g['coordinates'])
+    assert np.array_equal(p2v, g['point_to_voxel_map'][:, 0])
+    coords, p2v, m = _vox(native, dev, g['points'], cfg, max_voxels=200)
+    assert m == 200
+    assert np.array_equal(coords, g['cap_coordinates'])
+    assert np.array_equal(p2v, g['cap_p2v'][:, 0])
+
+
+@pytest.mark.parametrize('n,T', [(100000, 5), (800000, 5), (2000000, 10)])
+def test_voxelize_full_size_vs_oracle(native, dev, n, T):
+    cfg = default_config('waymo', 'val', n_sweeps=T)
+    pts = vox_points(5, n, cfg, frac_out=0.02)
+    vg = cfg['voxel_generator']
+    ref = oracle.voxelize(pts, vg['voxel_size'], vg['range'], vg['n_sweeps'])
+    coords, p2v, m = _vox(native, dev, pts, cfg)
+    assert m == int(ref['num_voxels'][0])
+    assert np.array_equal(coords, ref['coordinates'])
+    assert np.array_equal(p2v, ref['point_to_voxel_map'][:, 0])
+
+
+def test_voxelize_edge_cases(native, dev):
+    cfg = small_cfg()
+    coords, p2v, m = _vox(native, dev, np.zeros((0, 4), np.float32), cfg)
+    assert m == 0 and p2v.shape == (0,)
+    # all points in one cell; all points rejected; a NaN coordinate
+    one = np.tile(np.array([[0.1, 0.1, 0.0, 1.0]], np.float32), (1000, 1))
+    coords, p2v, m = _vox(native, dev, one, cfg)
+    assert m == 1 and (p2v == 0).all() and coords.tolist() == [[0, 32, 32, 1]]
+    out = np.tile(np.array([[100.0, 0.1, 0.0, 1.0]], np.float32), (300, 1))
+    out[7, 0] = np.nan
+    coords, p2v, m = _vox(native, dev, out, cfg)
+    assert m == 0 and (p2v == -1).all()
+
+
+# ---------------------------------------------------------------- A2', A3, A4
+def _batch(dev):
+    cfg = small_cfg()
+    inp = make_batch(cfg, (10, 11), 3, 1500)
+    return cfg, inp
+
+
+def test_cell_index_and_frame_pillars(native, dev):
+    cfg, inp = _batch(dev)
+    coords = inp['coordinates']
+    nx, ny, nz, nt = (int(v) for v in inp['shape'][0])
+    cell, c2p = native.cell_index(coords.to(dev), nx, ny, nt, 2)
+    c = coords.numpy().astype(np.int64)
+    ref_cell = ((c[:, 0] * nt + c[:, 4]) * ny + c[:, 2]) * nx + c[:, 3]
+    assert np.array_equal(cell.cpu().numpy(), ref_cell)
+    ref_c2p = np.full(2 * nt * ny * nx, -1, np.int64)
+    ref_c2p[ref_cell] = np.arange(c.shape[0])
+    assert np.array_equal(c2p.cpu().numpy(), ref_c2p)
+    # int32 coordinates take the same path
+    cell_i, c2p_i = native.cell_index(coords.to(torch.int32).to(dev), nx, ny, nt, 2)
+    assert torch.equal(cell_i, cell) and torch.equal(c2p_i, c2p)
+    sp, offs = native.frame_pillars(c2p, ny * nx, c.shape[0])
+    occ = ref_c2p >= 0
+    assert np.array_equal(sp.cpu().numpy(), ref_c2p[occ])
+    ref_offs = np.concatenate([[0], np.cumsum(occ.reshape(-1, ny * nx).sum(1))])
+    assert np.array_equal(offs.cpu().numpy(), ref_offs)
+
+
+def test_csr_and_segment_ops(native, dev, golden):
+    g = golden('segops')
+    cfg, inp = _batch(dev)
+    p2v = inp['point_to_voxel_map'][:, 0].contiguous()
+    m = inp['coordinates'].shape[0]
+    offs, order = native.csr_build(p2v.to(dev), m)
+    o, r = offs.cpu().numpy(), order.cpu().numpy()
+    cnt = np.bincount(p2v.numpy(), minlength=m)
+    assert np.array_equal(o, np.concatenate([[0], np.cumsum(cnt)]))
+    # stable: ascending point index inside every pillar, each pillar's points complete
+    assert np.array_equal(r, np.argsort(p2v.numpy(), kind='stable'))
+    pts = inp['input_points'].float().contiguous()
+    lab = inp['fb_labels'][:, 0].contiguous()
+    mean, mlab = native.segment_mean3_maxlabel(pts.to(dev), lab.to(dev), offs, order, m)
+    # same summation order as a sequential CPU scatter => tight tolerance
+    np.testing.assert_allclose(mean.cpu().numpy(), g['pillar_mean'], rtol=1e-6, atol=1e-6)
+    assert np.array_equal(mlab.cpu().numpy()[:, None], g['fb_labels_sub'])
+    np.testing.assert_array_equal(mean.cpu().numpy(), oracle.segment_mean(pts.numpy(), p2v.numpy().astype(np.int64), m))
+
+
+@pytest.mark.parametrize('c', [4, 32, 64])
+def test_segment_max_sum_and_backward(native, dev, c):
+    cfg, inp = _batch(dev)
+    p2v = inp['point_to_voxel_map'][:, 0].contiguous()
+    n, m = p2v.shape[0], inp['coordinates'].shape[0]
+    rng = np.random.RandomState(c)
+    src = rng.randn(n, c).astype(np.float32)
+    src[rng.randint(0, n, 200)] = src[rng.randint(0, n, 200)]          # exact ties across points
+    offs, order = native.csr_build(p2v.to(dev), m)
+    out, arg = native.segment_max(torch.from_numpy(src).to(dev), offs, order, m)
+    ro, ra = oracle.segment_max(src, p2v.numpy().astype(np.int64), m)
+    assert np.array_equal(out.cpu().numpy(), ro)
+    assert np.array_equal(arg.cpu().numpy(), ra)
+    go = rng.randn(m, c).astype(np.float32)
+    gs = native.segment_max_backward(torch.from_numpy(go).to(dev), arg, p2v.to(dev), n)
+    ref = np.zeros((n, c), np.float32)
+    mm, cc = np.meshgrid(np.arange(m), np.arange(c), indexing='ij')
+    ref[ra, cc] = go[mm, cc]
+    assert np.array_equal(gs.cpu().numpy(), ref)
+    ssum = native.segment_sum(torch.from_numpy(src).to(dev), offs, order, m)
+    ref_sum = np.zeros((m, c), np.float32)
+    np.add.at(ref_sum, p2v.numpy(), src)
+    np.testing.assert_allclose(ssum.cpu().numpy(), ref_sum, rtol=1e-5, atol=1e-5)
+
+
+def test_csr_large_pillar_unsorted_is_still_correct(native, dev):
+    """Pillars with > 64 points skip the index sort; max / arg / sum must not depend on it."""
+    rng = np.random.RandomState(0)
+    n, m = 5000, 7
+    p2v = np.sort(rng.randint(0, m, n)).astype(np.int32)
+    rng.shuffle(p2v)
+    src = np.round(rng.randn(n, 4) * 2).astype(np.float32)            # many exact ties
+    offs, order = native.csr_build(torch.from_numpy(p2v).to(dev), m)
+    out, arg = native.segment_max(torch.from_numpy(src).to(dev), offs, order, m)
+    ro, ra = oracle.segment_max(src, p2v.astype(np.int64), m)
+    assert np.array_equal(out.cpu().numpy(), ro) and np.array_equal(arg.cpu().numpy(), ra)
+
+
+# ---------------------------------------------------------------- A5, A6
+def test_pillar_scatter_and_gather_golden(native, dev, golden):
+    g = golden('scatter')
+    cfg, inp = _batch(dev)
+    nx, ny, nz, nt = (int(v) for v in inp['shape'][0])
+    cell, c2p = native.cell_index(inp['coordinates'].to(dev), nx, ny, nt, 2)
+    canvas = native.pillar_scatter(torch.from_numpy(g['feats']).to(dev), c2p)           # [cells, C]
+    got = canvas.view(2, nt, ny, nx, 4).permute(0, 4, 1, 2, 3).cpu().numpy()          # reference layout [B,C,T,H,W]
+    assert np.array_equal(got, g['canvas'])
+    # bf16 canvas = round-to-nearest-even of the f32 one
+    cb = native.pillar_scatter(torch.from_numpy(np.tile(g['feats'], (1, 2))).to(dev), c2p, torch.bfloat16)
+    ref = torch.from_numpy(np.tile(g['feats'], (1, 2))).to(torch.bfloat16)
+    dense = torch.zeros((c2p.numel(), 8), dtype=torch.bfloat16)
+    dense[cell.cpu().long()] = ref
+    assert torch.equal(cb.cpu(), dense)
+    # narrow canvases (occupancy, 3-channel means)
+    for c in (1, 3):
+        f = torch.from_numpy(np.random.RandomState(c).randn(cell.numel(), c).astype(np.float32))
+        cv = native.pillar_scatter(f.to(dev), c2p).cpu()
+        d = torch.zeros((c2p.numel(), c))
+        d[cell.cpu().long()] = f
+        assert torch.equal(cv, d)
+    # inverse scatter of an int64 canvas [B,1,T,H,W] == row gather at the cell index
+    ic = torch.from_numpy(g['icanvas']).reshape(-1, 1).contiguous()
+    inv = native.gather_rows(ic.to(dev), cell)
+    assert np.array_equal(inv.cpu().numpy(), g['inverse'])
+    # backward of the scatter: gather canvas rows back to pillars
+    back = native.gather_rows(canvas, cell)
+    assert np.array_equal(back.cpu().numpy(), g['feats'])
+
+
+def test_pillar_scatter_full_size_roundtrip(native, dev):
+    """c3-size property test: scatter then gather is the identity on pillars; empty cells are zero."""
+    nx = ny = 288
+    nt = 5
+    rng = np.random.RandomState(1)
+    n_cells = nt * ny * nx
+    occ = rng.permutation(n_cells)[:300000].astype(np.int32)
+    coords = np.zeros((occ.size, 5), np.int32)
+    coords[:, 4] = occ // (ny * nx)
+    coords[:, 2] = (occ % (ny * nx)) // nx
+    coords[:, 3] = occ % nx
+    cell, c2p = native.cell_index(torch.from_numpy(coords).to(dev), nx, ny, nt, 1)
+    assert np.array_equal(cell.cpu().numpy(), occ)
+    feats = torch.randn(occ.size, 32, device=dev)
+    for dt in (torch.float32, torch.bfloat16):
+        cv = native.pillar_scatter(feats, c2p, dt)
+        assert torch.equal(native.gather_rows(cv, cell), feats.to(dt))
+        assert float(cv.float().abs().sum(1).gt(0).sum()) <= occ.size
+        assert abs(float(cv.double().sum()) - float(feats.to(dt).double().sum())) < 1e-3
+
+
+# ---------------------------------------------------------------- A11
+def _cl(x):
+    """[N,C,H,W] numpy -> channels-last torch tensor [N,H,W,C]."""
+    return torch.from_numpy(np.ascontiguousarray(np.transpose(x, (0, 2, 3, 1))))
+
+
+def test_bilinear_gather_golden(native, dev, golden):
+    g = golden('ungrid')
+    pts = torch.from_numpy(g['points']).to(dev)
+    bidx = torch.from_numpy(g['time_indice'][:, 0].astype(np.int32)).to(dev)
+    out = native.bilinear_gather(_cl(g['fmap']).to(dev), pts, bidx, 8.0, 8.0)
+    # reference output is grouped by batch index; the fixture's batch column is sorted, so order matches
+    np.testing.assert_allclose(out.cpu().numpy(), g['out'], rtol=1e-5, atol=1e-5)
+    assert torch.equal(pts.cpu(), torch.from_numpy(g['points']))               # no in-place normalisation (trap 2)
+    # temporal_ungrid: maps flattened to [B*T], index b*T + t
+    fm_t = torch.from_numpy(np.ascontiguousarray(np.transpose(g['fmap_t'], (0, 1, 3, 4, 2)))).reshape(6, 16, 16, 4)
+    tidx = torch.from_numpy((g['time_indice'][:, 0] * 3 + g['time_indice'][:, 1]).astype(np.int32)).to(dev)
+    out_t = native.bilinear_gather(fm_t.to(dev), pts, tidx, 8.0, 8.0)
+    np.testing.assert_allclose(out_t.cpu().numpy(), g['out_t'], rtol=1e-5, atol=1e-5)
+    # bf16 map: equals sampling the bf16-rounded map in fp32
+    fb = _cl(g['fmap']).to(torch.bfloat16)
+    ob = native.bilinear_gather(fb.to(dev), pts, bidx, 8.0, 8.0)
+    ref = oracle.ungrid(np.transpose(fb.float().numpy(), (0, 3, 1, 2)), g['points'], [-8, -8, -2, 8, 8, 6], g['time_indice'])
+    np.testing.assert_allclose(ob.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+
+
+def test_bilinear_gather_backward_vs_autograd(native, dev):
+    rng = np.random.RandomState(4)
+    fmap = torch.from_numpy(rng.randn(2, 8, 12, 10).astype(np.float32))              # [N,C,H,W]
+    k = 500
+    pts = torch.from_numpy(rng.uniform(-9, 9, (k, 3)).astype(np.float32))
+    bidx = torch.from_numpy(rng.randint(0, 2, k).astype(np.int32))
+    go = torch.from_numpy(rng.randn(k, 8).astype(np.float32))
+    f = fmap.clone().requires_grad_(True)
+    tot = 0
+    for b in range(2):
+        sel = bidx == b
+        grid = (pts[sel, :2] / 8.0).view(1, -1, 1, 2)
+        s = torch.nn.functional.grid_sample(f[b:b + 1], grid, mode='bilinear', padding_mode='border', align_corners=False)
+        tot = tot + (s[0, :, :, 0].T * go[sel]).sum()
+    tot.backward()
+    gf = native.bilinear_gather_backward(go.to(dev), (2, 12, 10, 8), pts.to(dev), bidx.to(dev), 8.0, 8.0)
+    np.testing.assert_allclose(gf.permute(0, 3, 1, 2).cpu().numpy(), f.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+# ---------------------------------------------------------------- A9, A10
+def test_bev_warp_and_transform_golden(native, dev, golden):
+    g = golden('warp')
+    bev = torch.from_numpy(np.ascontiguousarray(np.transpose(g['bev'], (0, 1, 3, 4, 2))))   # [B,T,H,W,C]
+    inv = torch.linalg.inv(torch.from_numpy(g['poses'])).contiguous()
+    out = native.bev_warp(bev.to(dev), inv.to(dev), 0.25, 0.25, -8.0, -8.0)
+    got = out.permute(0, 1, 4, 2, 3).cpu().numpy()
+    np.testing.assert_allclose(got, g['warped'], rtol=1e-4, atol=2e-4)
+    assert np.array_equal(got[:, 0], g['bev'][:, -1])                                   # trap 1
+    ob = native.bev_warp(bev.to(torch.bfloat16).to(dev), inv.to(dev), 0.25, 0.25, -8.0, -8.0)
+    np.testing.assert_allclose(ob.float().permute(0, 1, 4, 2, 3).cpu().numpy(), g['warped'], rtol=2e-2, atol=3e-2)
+    cfg, inp = _batch(dev)
+    ti = inp['time_indice']
+    fidx = (ti[:, 0] * 3 + ti[:, 1]).to(torch.int32)
+    tp = native.rigid_transform(inp['input_points'].float().to(dev), fidx.to(dev),
+                                torch.from_numpy(g['poses']).reshape(-1, 16).contiguous().to(dev))
+    np.testing.assert_allclose(tp.cpu().numpy(), g['transformed'], rtol=1e-5, atol=1e-5)
+
+
+# ---------------------------------------------------------------- A12
+@pytest.mark.parametrize('b,n,m', [(1, 2000, 3000), (2, 513, 77), (1, 40000, 40000), (1, 5, 1), (3, 1, 2500)])
+def test_chamfer_forward_backward_vs_oracle(native, dev, b, n, m):
+    rng = np.random.RandomState(n + m)
+    x1 = rng.uniform(-10, 10, (b, n, 3)).astype(np.float32)
+    x2 = rng.uniform(-10, 10, (b, m, 3)).astype(np.float32)
+    if m > 10 and n > 10:                                       # exact ties: duplicated targets, and a shared point
+        x2[:, 7] = x2[:, 3]
+        x2[:, m - 1] = x2[:, 3]
+        x1[:, 0] = x2[:, 3]
+        x1[:, 5] = x1[:, 2]
+    d1, d2, i1, i2 = native.chamfer_forward(torch.from_numpy(x1).to(dev), torch.from_numpy(x2).to(dev))
+    r1, r2, j1, j2 = oracle.chamfer_forward(x1, x2)
+    assert np.array_equal(i1.cpu().numpy(), j1) and np.array_equal(i2.cpu().numpy(), j2)      # indices bit-exact
+    assert np.array_equal(d1.cpu().numpy(), r1) and np.array_equal(d2.cpu().numpy(), r2)      # un-fused fp32: bit-exact
+    g1 = rng.randn(b, n).astype(np.float32)
+    g2 = rng.randn(b, m).astype(np.float32)
+    a, c = native.chamfer_backward(torch.from_numpy(x1).to(dev), torch.from_numpy(x2).to(dev),
+                                   torch.from_numpy(g1).to(dev), torch.from_numpy(g2).to(dev), i1, i2)
+    ra, rc = oracle.chamfer_backward(x1, x2, g1, g2, j1, j2)
+    np.testing.assert_allclose(a.cpu().numpy(), ra, rtol=1e-4, atol=1e-4)                     # atomics: order differs
+    np.testing.assert_allclose(c.cpu().numpy(), rc, rtol=1e-4, atol=1e-4)
+
+
+def test_chamfer_full_size_properties(native, dev):
+    """160k x 160k (BASELINE c3 size): too slow for the scalar oracle; check size-independent properties."""
+    n = m = 160000
+    g = torch.Generator().manual_seed(0)
+    x1 = (torch.rand(1, n, 3, generator=g) * 60 - 30).to(dev)
+    perm = torch.randperm(n, generator=g)
+    x2 = x1[:, perm.to(dev)].contiguous()                   # same cloud, permuted: every NN distance is exactly 0
+    d1, d2, i1, i2 = native.chamfer_forward(x1, x2)
+    assert float(d1.max()) == 0.0 and float(d2.max()) == 0.0
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(n)
+    assert torch.equal(i1[0].cpu().long(), inv) and torch.equal(i2[0].cpu().long(), perm)
+    # a sampled subset against the oracle on the full target set
+    x3 = (torch.rand(1, m, 3, generator=g) * 60 - 30).to(dev)
+    d1, _, i1, _ = native.chamfer_forward(x1, x3)
+    sub = x1[:, :256].cpu().numpy()
+    r1, _, j1, _ = oracle.chamfer_forward(sub, x3.cpu().numpy())
+    assert np.array_equal(i1[:, :256].cpu().numpy(), j1) and np.array_equal(d1[:, :256].cpu().numpy(), r1)
