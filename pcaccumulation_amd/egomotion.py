@@ -1,0 +1,227 @@
+"""Ego-motion head: host mirror of models/egomotion.py plus the registration helpers it uses from
+toolbox/register_utils.py (kabsch_transformation_estimation, get_relative_pose_torch, rotation_error,
+translation_error) and toolbox/utils.py (square_distance, _EPS).
+
+Numerics stay fp32 throughout (Sinkhorn logsumexp, inverse, SVD must not be bf16).
+Key points are drawn with torch.randperm on the HOST generator exactly where the reference draws them
+(models/egomotion.py:157,163: source first, then target, per pair, per batch element), so that the same
+torch.manual_seed gives the same key points.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+_EPS = 1e-20                       # toolbox/utils.py:13
+
+
+def square_distance(src, dst, normalised=False):
+    """toolbox/utils.py:125-144.  src [B,N,C], dst [B,M,C] -> [B,N,M], clamped at 1e-12."""
+    dist = -2 * torch.matmul(src, dst.permute(0, 2, 1))
+    if normalised:
+        dist += 2
+    else:
+        dist += torch.sum(src ** 2, dim=-1)[:, :, None]
+        dist += torch.sum(dst ** 2, dim=-1)[:, None, :]
+    return torch.clamp(dist, min=1e-12, max=None)
+
+
+def rotation_error(R1, R2):
+    """toolbox/register_utils.py:19-43: acos((tr(R1^T R2) - 1) / 2) in degrees, [b,1]."""
+    R_ = torch.matmul(R1.transpose(1, 2), R2)
+    e = ((R_.diagonal(dim1=1, dim2=2).sum(-1) - 1) / 2).unsqueeze(1)
+    ae = torch.acos(torch.clamp(e, -1, 1))
+    return 180. * ae / math.pi
+
+
+def translation_error(t1, t2):
+    """toolbox/register_utils.py:46-56."""
+    return torch.norm(t1 - t2, dim=(1, 2))
+
+
+def get_relative_pose_torch(tsfm_src, tsfm_tgt, dataset):
+    """toolbox/register_utils.py:184-197: T_tgt^-1 @ T_src (waymo / nuscene branch)."""
+    if dataset not in ('waymo', 'nuscene'):
+        raise NotImplementedError('only the waymo / nuscene branch of get_relative_pose_torch is on the hot path')
+    return torch.linalg.solve(tsfm_tgt, tsfm_src)
+
+
+def kabsch_transformation_estimation(x1, x2, weights=None, normalize_w=True, eps=1e-7, best_k=0, w_threshold=0):
+    """toolbox/register_utils.py:247-317 (best_k = 0, w_threshold = 0 path).  Returns (R [b,3,3], t [b,3,1], res, flag)."""
+    if weights is None:
+        weights = torch.ones(x1.shape[0], x1.shape[1]).type_as(x1).to(x1.device)
+    if normalize_w:
+        weights = weights / (torch.sum(weights, dim=1, keepdim=True) + eps)
+    weights = weights.unsqueeze(2)
+    assert best_k == 0 and w_threshold == 0
+    wsum = torch.sum(weights, dim=1).unsqueeze(1) + eps
+    x1_mean = torch.matmul(weights.transpose(1, 2), x1) / wsum
+    x2_mean = torch.matmul(weights.transpose(1, 2), x2) / wsum
+    x1_centered = x1 - x1_mean
+    x2_centered = x2 - x2_mean
+    # diag_embed(w) @ x2c == w * x2c exactly (the dropped terms are +0): no 1024x1024 dense weight matrix
+    cov_mat = torch.matmul(x1_centered.transpose(1, 2), weights * x2_centered)
+    try:
+        u, s, v = torch.svd(cov_mat)
+    except Exception:                                                  # register_utils.py:295-304
+        r = torch.eye(3, device=x1.device).repeat(x1_mean.shape[0], 1, 1)
+        t = torch.zeros((x1_mean.shape[0], 3, 1), device=x1.device)
+        res = torch.norm((torch.matmul(r, x1.transpose(1, 2)) + t).transpose(1, 2) - x2, dim=2)
+        return r, t, res, True
+    det = torch.det(torch.matmul(v.transpose(1, 2), u.transpose(1, 2)))
+    dmat = torch.diag_embed(torch.cat((torch.ones((det.shape[0], 2), device=x1.device), det.unsqueeze(1)), 1))
+    rotation = torch.matmul(v, torch.matmul(dmat, u.transpose(1, 2)))
+    translation = x2_mean.transpose(1, 2) - torch.matmul(rotation, x1_mean.transpose(1, 2))
+    res = torch.norm((torch.matmul(rotation, x1.transpose(1, 2)) + translation).transpose(1, 2) - x2, dim=2)
+    return rotation, translation, res, False
+
+
+class EgoMotionHead(nn.Module):
+    """models/egomotion.py:30-469.  Parameters: alpha, beta (scalars, init -5)."""
+
+    def __init__(self, config):
+        nn.Module.__init__(self)
+        pe = config['pose_estimation']
+        self.slack = pe['add_slack']
+        self.sinkhorn_iter = pe['sinkhorn_iter']
+        self.beta = torch.nn.Parameter(torch.tensor(-5.0))
+        self.alpha = torch.nn.Parameter(torch.tensor(-5.0))
+        self.softplus = torch.nn.Softplus()
+        self.ego_n_points = pe['n_kpts']
+        self.frequence = config['data']['freq']
+        self.n_sweeps = config['voxel_generator']['n_sweeps']
+        self.ego_max_speed = config['data']['max_speed']
+        self.dataset = config['data']['dataset']
+        self.icp_threshold = pe['icp_threshold']
+        self.icp_max_iter = pe['icp_max_iter']
+        self.refine_with_icp = config['model']['ego_icp']
+        if self.refine_with_icp:
+            raise NotImplementedError('model.ego_icp (Open3D ICP refinement) is off the hot path (configs/default.yaml:115)')
+        self.seq_pose = pe['seq_pose']
+        if self.seq_pose != 'skip':
+            raise NotImplementedError("pose_estimation.seq_pose='%s': only 'skip' (configs/default.yaml:83) is built" % self.seq_pose)
+
+    def sinkhorn(self, log_alpha, n_iters=5, slack=True):
+        """models/egomotion.py:100-137: slack row/column padded with zeros, never normalised themselves."""
+        la = torch.nn.functional.pad(log_alpha, (0, 1, 0, 1))
+        for _ in range(n_iters):
+            la = torch.cat((la[:, :-1, :] - torch.logsumexp(la[:, :-1, :], dim=2, keepdim=True), la[:, -1, None, :]), dim=1)
+            la = torch.cat((la[:, :, :-1] - torch.logsumexp(la[:, :, :-1], dim=1, keepdim=True), la[:, :, -1, None]), dim=2)
+        return la[:, :-1, :-1]
+
+    def _choice(self, n):
+        """models/egomotion.py:156-166: random subset when n > n_kpts, else arange with the tail clamped to n-1."""
+        if n > self.ego_n_points:
+            return torch.randperm(n)[:self.ego_n_points]
+        c = torch.arange(self.ego_n_points)
+        c[n:] = n - 1
+        return c
+
+    def pairwise_ego_motion_estimation(self, feats_s, feats_t, coor_s, coor_t, duration):
+        """models/egomotion.py:140-192.  Returns (pose [4,4], perm_matrix [1,k,k])."""
+        choice_source = self._choice(feats_s.size(0)).to(feats_s.device)
+        choice_target = self._choice(feats_t.size(0)).to(feats_t.device)
+        feats_s_ego, coor_s_ego = feats_s[choice_source][None], coor_s[choice_source][None]
+        feats_t_ego, coor_t_ego = feats_t[choice_target][None], coor_t[choice_target][None]
+        threshold_distance = duration * self.ego_max_speed
+        support_ego = (square_distance(coor_s_ego, coor_t_ego, normalised=False) < threshold_distance ** 2).float()
+        feat_dist = square_distance(feats_s_ego, feats_t_ego, normalised=True)
+        affinity = -(feat_dist - self.softplus(self.alpha)) / (torch.exp(self.beta) + 0.02)
+        log_perm = self.sinkhorn(affinity, n_iters=self.sinkhorn_iter, slack=self.slack)
+        perm_matrix = torch.exp(log_perm) * support_ego
+        rowsum = torch.sum(perm_matrix, dim=2, keepdim=True)
+        weighted_t = perm_matrix @ coor_t_ego / (rowsum + _EPS)
+        R_est, t_est, _, _ = kabsch_transformation_estimation(coor_s_ego, weighted_t, weights=rowsum[:, :, 0])
+        pose_est = torch.eye(4, device=feats_s.device, dtype=t_est.dtype)
+        pose_est[:3, :3] = R_est[0]
+        pose_est[:3, 3] = t_est[0][:, 0]
+        return pose_est, perm_matrix
+
+    def sequence_pose_est_skip(self, points_list, feats_list, bg_mask_list, c_ego_motion_gt, T, perm_matrix_list,
+                               relative_pose_est_list, relative_pose_gt_list, chained_pose_est_list, chained_pose_gt_list):
+        """models/egomotion.py:309-357: every frame t >= 1 is registered against the anchor frame 0."""
+        anchor_mask = bg_mask_list[0]
+        anchor_points_est = points_list[0][anchor_mask]
+        anchor_feats = feats_list[0][anchor_mask]
+        identity = torch.eye(4, device=feats_list[0].device)
+        for lst in (relative_pose_est_list, relative_pose_gt_list, chained_pose_est_list, chained_pose_gt_list):
+            lst.append(identity)
+        total_l1, total_l2 = 0, 0
+        for frame_idx in range(T - 1):
+            ref_idx = frame_idx + 1
+            ref_points, ref_feats = points_list[ref_idx], feats_list[ref_idx]
+            mask = bg_mask_list[ref_idx]
+            duration = (frame_idx + 1) / self.frequence
+            pose_est, perm_matrix = self.pairwise_ego_motion_estimation(ref_feats[mask], anchor_feats, ref_points[mask],
+                                                                        anchor_points_est, duration)
+            pose_gt = get_relative_pose_torch(c_ego_motion_gt[ref_idx], c_ego_motion_gt[0], self.dataset)
+            perm_matrix_list.append(perm_matrix)
+            chained_pose_est_list.append(pose_est)
+            chained_pose_gt_list.append(pose_gt)
+            hom = torch.cat([ref_points, torch.ones((ref_points.size(0), 1), device=ref_points.device)], dim=1)
+            pc_est = (pose_est @ hom.T).T[:, :3]
+            pc_gt = (pose_gt @ hom.T).T[:, :3]
+            total_l1 = total_l1 + torch.norm(pc_est - pc_gt, p=1, dim=1).mean()
+            total_l2 = total_l2 + torch.norm(pc_est - pc_gt, p=2, dim=1).mean()
+            relative_pose_gt_list.append(get_relative_pose_torch(c_ego_motion_gt[ref_idx], c_ego_motion_gt[ref_idx - 1], self.dataset))
+            relative_pose_est_list.append(get_relative_pose_torch(chained_pose_est_list[-1], chained_pose_est_list[-2], self.dataset))
+        return total_l1, total_l2, T - 1
+
+    def _finish(self, B, T, total_l1, total_l2, count, perm_matrix_list, chained_pose_est_list, chained_pose_gt_list, results):
+        """models/egomotion.py:448-469."""
+        chained_pose_est = torch.stack(chained_pose_est_list)
+        chained_pose_gt = torch.stack(chained_pose_gt_list)
+        rot_est, rot_gt = chained_pose_est[:, :3, :3], chained_pose_gt[:, :3, :3]
+        trans_est, trans_gt = chained_pose_est[:, :3, 3].unsqueeze(-1), chained_pose_gt[:, :3, 3].unsqueeze(-1)
+        rot_error = rotation_error(rot_est, rot_gt).mean().item() * self.n_sweeps / (self.n_sweeps - 1)
+        trans_error = translation_error(trans_est, trans_gt).mean().item() * self.n_sweeps / (self.n_sweeps - 1)
+        results['ego_l1_loss'] = total_l1 / count
+        results['ego_l2_loss'] = total_l2 / count
+        results['ego_rot_error'] = rot_error
+        results['ego_trans_error'] = trans_error
+        results['perm_matrix'] = perm_matrix_list
+        results['ego_motion_est'] = chained_pose_est.view(B, T, 4, 4)
+        results['ego_motion_gt'] = chained_pose_gt.view(B, T, 4, 4)
+
+    def forward_pillars(self, geo_rows, pillar_mean, fb_est_pillar, pidx, ego_motion_gt, results):
+        """Same computation as forward(), fed from pillar-level tensors instead of dense canvases:
+        geo_rows [n_cells, C] (L2-normalised feature map rows), pillar_mean [M,3], fb_est_pillar [M].
+        Frame lists enumerate occupied pillars in ascending cell order, as models/egomotion.py:419-424 does
+        through the boolean occupancy mask."""
+        B, T = pidx.batch_size, pidx.nt
+        sorted_pillars, frame_offsets = pidx.frame_pillars()
+        offs = frame_offsets.cpu().tolist()                             # the one host sync for the frame sizes
+        sp = sorted_pillars.long()
+        cells = pidx.cell.long()
+        total_l1, total_l2, count = 0, 0, 0
+        perm_l, rel_est, rel_gt, ch_est, ch_gt = [], [], [], [], []
+        for b in range(B):
+            points_list, feats_list, bg_list = [], [], []
+            for t in range(T):
+                ids = sp[offs[b * T + t]:offs[b * T + t + 1]]
+                points_list.append(pillar_mean[ids])
+                feats_list.append(geo_rows[cells[ids]])
+                bg_list.append(fb_est_pillar[ids] == 0)
+            l1, l2, c = self.sequence_pose_est_skip(points_list, feats_list, bg_list, ego_motion_gt[b], T, perm_l, rel_est,
+                                                    rel_gt, ch_est, ch_gt)
+            total_l1, total_l2, count = total_l1 + l1, total_l2 + l2, count + c
+        self._finish(B, T, total_l1, total_l2, count, perm_l, ch_est, ch_gt, results)
+
+    def forward(self, bev_feats, fb_est, occ_map, pts_mean_map, ego_motion_gt, input_points, fb_est_per_point, time_indice, results):
+        """Reference signature (models/egomotion.py:387-469): dense [B,T,C,Ny,Nx] maps in, results dict filled."""
+        B, T, C, Ny, Nx = bev_feats.size()
+        total_l1, total_l2, count = 0, 0, 0
+        perm_l, rel_est, rel_gt, ch_est, ch_gt = [], [], [], [], []
+        for b in range(B):
+            points_list, feats_list, bg_list = [], [], []
+            for t in range(T):
+                occ = occ_map[b, t, 0].reshape(-1) > 0
+                points_list.append(pts_mean_map[b, t].permute(1, 2, 0).reshape(Ny * Nx, 3)[occ])
+                feats_list.append(bev_feats[b, t].permute(1, 2, 0).reshape(Ny * Nx, C)[occ])
+                bg_list.append((fb_est[b, t, 0].reshape(-1) == 0)[occ])
+            l1, l2, c = self.sequence_pose_est_skip(points_list, feats_list, bg_list, ego_motion_gt[b], T, perm_l, rel_est,
+                                                    rel_gt, ch_est, ch_gt)
+            total_l1, total_l2, count = total_l1 + l1, total_l2 + l2, count + c
+        self._finish(B, T, total_l1, total_l2, count, perm_l, ch_est, ch_gt, results)

@@ -1,0 +1,214 @@
+"""Training loss and the IoU bookkeeping that defines `mos_iou`: host mirror of libs/loss.py (FuseLoss,
+compute_iou), libs/lovasz_softmax.py (Lovasz-Softmax, Berman et al. 2018, MIT) and libs/outlier_loss.py.
+
+Needed so that BASELINE.json's "fwd+bwd" metric runs end to end; plain PyTorch-ROCm (SURVEY.md 8f rank 3 lists
+fused loss kernels as a later row).  The cluster-evaluation hook (test mode only) is not carried over.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .ops import scatter
+from .tpointnet import ego_motion_compensation, reconstruct_sequence
+
+_EPS = 1e-20
+
+
+def compute_iou(predictions, gt, n_class, ignore_index):
+    """libs/loss.py:17-50: per-class intersection / union / positives, each divided by 1e3."""
+    inter, union, pred_pos, gt_pos = [], [], [], []
+    for idx in range(n_class):
+        if idx == ignore_index:
+            continue
+        sel_gt, sel_pred = gt == idx, predictions == idx
+        n_pred, n_gt = sel_pred.sum().item() / 1e3, sel_gt.sum().item() / 1e3
+        i = (predictions[sel_gt] == idx).sum().item() / 1e3
+        pred_pos.append(n_pred)
+        gt_pos.append(n_gt)
+        inter.append(i)
+        union.append(n_pred + n_gt - i)
+    return {'intersection': np.array(inter), 'union': np.array(union),
+            'pred_positives': np.array(pred_pos), 'gt_positives': np.array(gt_pos)}
+
+
+def mean_iou(stats_list):
+    """toolbox/metrics.py:43-60 over a list of per-batch stats: sum(I) / (sum(U) + 1e-20), mean over classes."""
+    i = sum(s['intersection'] for s in stats_list)
+    u = sum(s['union'] for s in stats_list)
+    return float((i / (u + _EPS)).mean())
+
+
+def lovasz_grad(gt_sorted):
+    """libs/lovasz_softmax.py:56-68."""
+    p = len(gt_sorted)
+    gts = gt_sorted.sum()
+    intersection = gts - gt_sorted.float().cumsum(0)
+    union = gts + (1 - gt_sorted).float().cumsum(0)
+    jaccard = 1. - intersection / union
+    if p > 1:
+        jaccard[1:p] = jaccard[1:p] - jaccard[0:-1]
+    return jaccard
+
+
+def lovasz_softmax_flat(probas, labels):
+    """libs/lovasz_softmax.py:71-94: mean over present classes of <sorted errors, Lovasz gradient>."""
+    if probas.numel() == 0:
+        return probas * 0.
+    losses = []
+    for c in range(probas.size(1)):
+        fg = (labels == c).float()
+        if fg.sum() == 0:
+            continue
+        errors = (fg - probas[:, c]).abs()
+        errors_sorted, perm = torch.sort(errors, 0, descending=True)
+        losses.append(torch.dot(errors_sorted, lovasz_grad(fg[perm.data])))
+    if not losses:
+        return 0
+    acc = losses[0]
+    for v in losses[1:]:
+        acc = acc + v
+    return acc if len(losses) == 1 else acc / len(losses)
+
+
+class Lovasz_softmax(nn.Module):
+    def forward(self, probas, labels):
+        return lovasz_softmax_flat(probas, labels)
+
+
+class OutlierLoss(object):
+    """libs/outlier_loss.py: mean mass missing from the rows and columns of each permutation matrix."""
+
+    def __call__(self, perm_matrix):
+        ref = torch.cat([1.0 - torch.sum(p, dim=1) for p in perm_matrix], 1)
+        src = torch.cat([1.0 - torch.sum(p, dim=2) for p in perm_matrix], 0)
+        return torch.mean(ref) + torch.mean(src)
+
+
+class FuseLoss(nn.Module):
+    def __init__(self, config):
+        super(FuseLoss, self).__init__()
+        self.outlier_loss = OutlierLoss()
+        self.lovasz_loss = Lovasz_softmax()
+        self.n_classes = 2
+        self.ignore_index = -1
+        self.softmax = nn.Softmax(dim=1)
+        for k, v in config.items():
+            if k.startswith('w_') or k == 'obj_gamma':
+                setattr(self, k, v)
+
+    def get_ce_weights(self, gt_label, max_weights=50):
+        """libs/loss.py:90-108, 'sqrt_inv_freq' mode."""
+        counts = torch.tensor([(gt_label == c).sum().item() + _EPS for c in range(self.n_classes)]).to(gt_label.device)
+        return torch.clamp(torch.sqrt(counts.sum() / counts), 0, max_weights)
+
+    def get_seg_loss(self, gt, est):
+        """libs/loss.py:110-137."""
+        criterion = torch.nn.CrossEntropyLoss(weight=self.get_ce_weights(gt), ignore_index=self.ignore_index)
+        stats = {'bce_loss': criterion(est, gt), 'lovasz_loss': self.lovasz_loss(self.softmax(est), gt)}
+        stats['metric'] = compute_iou(est.argmax(1), gt, self.n_classes, self.ignore_index)
+        return stats
+
+    def get_mos_loss(self, predictions, input_dict):
+        """libs/loss.py:140-165: supervised on points that are foreground in GT or in the estimate."""
+        mos_gt, mos_est = input_dict['sd_labels'][:, 0].long(), predictions['mos_est']
+        fb_mask = torch.logical_or(input_dict['fb_labels'][:, 0] == 1, predictions['fb_est_per_points'][:, 0] == 1)
+        if fb_mask.sum():
+            return self.get_seg_loss(mos_gt[fb_mask], mos_est[fb_mask])
+        zero = {k: np.zeros(2) for k in ('intersection', 'union', 'pred_positives', 'gt_positives')}
+        return {'metric': zero, 'bce_loss': torch.tensor(0., requires_grad=True).to(mos_gt.device),
+                'lovasz_loss': torch.tensor(0., requires_grad=True).to(mos_gt.device)}
+
+    def get_fb_loss(self, predictions):
+        """libs/loss.py:167-191: only occupied pillars are supervised."""
+        est = predictions['fb_seg_est'].permute(0, 1, 3, 4, 2).contiguous().view(-1, 2)
+        gt = predictions['fb_seg_gt'].permute(0, 1, 3, 4, 2).contiguous().view(-1)
+        mask = predictions['occ_map'].permute(0, 1, 3, 4, 2).contiguous().view(-1) == 1
+        return self.get_seg_loss(gt[mask], est[mask])
+
+    def get_offset_loss(self, input_dict, predictions):
+        """libs/loss.py:194-250."""
+        input_points = input_dict['input_points']
+        time_indice = input_dict['time_indice']
+        ego_motion_gt = input_dict['ego_motion_gt']
+        inst_labels = input_dict['inst_labels'][:, 0].long()
+        bbox_tsfm = input_dict['inst_motion_gt']
+        fb_mask = input_dict['fb_labels'][:, 0] == 1
+        device = input_points.device
+        if not fb_mask.sum():
+            z = torch.tensor(0., requires_grad=True).to(device)
+            return z, torch.tensor(0., requires_grad=True).to(device), 0
+        n_frames = ego_motion_gt.size(1)
+        centres = []
+        for b in range(len(bbox_tsfm)):
+            sel = time_indice[:, 0] == b
+            lab, t = inst_labels[sel], time_indice[sel, 1]
+            comp = ego_motion_compensation(input_points[sel], t, ego_motion_gt[b])
+            rec = reconstruct_sequence(comp, t, lab, bbox_tsfm[b].to(device), n_frames)
+            centre = scatter(rec, lab, dim=0, reduce='mean')
+            assert centre.size(0) == lab.max() + 1
+            centres.append(centre[lab])
+        inst_centers = torch.cat(centres, dim=0)[:, :2]
+        gt_offset = (inst_centers - predictions['transformed_points'][:, :2])[fb_mask]
+        est_offset = predictions['offset_est'][fb_mask]
+        offset_norm_loss = torch.abs(gt_offset - est_offset).mean(dim=0).sum()
+        offset_l2_error = torch.norm(gt_offset - est_offset, p=2, dim=1).mean().item()
+        ngt = gt_offset / (torch.norm(gt_offset, dim=1, p=2).unsqueeze(-1) + _EPS)
+        nest = est_offset / (torch.norm(est_offset, dim=1, p=2).unsqueeze(-1) + _EPS)
+        offset_dir_loss = (1 - (ngt * nest).sum(-1)).mean()
+        predictions['offset_gt'] = gt_offset
+        return offset_norm_loss, offset_dir_loss, offset_l2_error
+
+    def get_tpointnet_loss(self, predictions):
+        """libs/loss.py:253-263."""
+        total, n_th = 0, 1
+        n_it = len(predictions['tpointnet_loss_terms'])
+        for value in predictions['tpointnet_loss_terms'].values():
+            pose_loss = self.w_obj_trans_loss * value['trans_loss'] + self.w_obj_rot_loss * value['rot_loss']
+            total = total + (self.w_obj_l1_loss * value['l1_loss'] + self.w_obj_pose_loss * pose_loss) * self.obj_gamma ** (n_it - n_th)
+            n_th += 1
+        return total
+
+    def forward(self, predictions, input_dict):
+        """libs/loss.py:280-327."""
+        stats = dict()
+        ego = self.w_pose_l1_loss * predictions['ego_l1_loss']
+        total = ego
+        stats['ego_l1_loss'] = ego
+        stats['ego_l2_loss'] = predictions['ego_l2_loss']
+        stats['ego_rot_error'] = predictions['ego_rot_error']
+        stats['ego_trans_error'] = predictions['ego_trans_error']
+        perm_loss = self.outlier_loss(predictions['perm_matrix']) * self.w_perm_loss
+        total = total + perm_loss
+        stats['perm_loss'] = perm_loss
+        fb = self.get_fb_loss(predictions)
+        fb_loss = self.w_fb_bce_loss * fb['bce_loss'] + self.w_fb_lovasz_loss * fb['lovasz_loss']
+        total = total + fb_loss
+        stats['fb_loss'], stats['fb_metric'] = fb_loss, fb['metric']
+        mos = self.get_mos_loss(predictions, input_dict)
+        mos_loss = self.w_mos_bce_loss * mos['bce_loss'] + self.w_mos_lovasz_loss * mos['lovasz_loss']
+        total = total + mos_loss
+        stats['mos_loss'], stats['mos_metric'] = mos_loss, mos['metric']
+        o_norm, o_dir, o_l2 = self.get_offset_loss(input_dict, predictions)
+        offset_loss = o_dir * self.w_offset_dir_loss + o_norm * self.w_offset_norm_loss
+        total = total + offset_loss
+        stats.update(offset_loss=offset_loss, offset_l1_loss=o_norm, offset_dir_loss=o_dir, offset_l2_error=o_l2)
+        if 'tpointnet_loss_terms' in predictions:
+            obj_loss = self.get_tpointnet_loss(predictions) * self.w_obj_loss
+            total = total + obj_loss
+            stats['obj_loss'] = obj_loss
+            stats['inst_l2_error'] = predictions['inst_l2_error']
+            stats['dynamic_inst_l2_error'] = predictions['dynamic_inst_l2_error']
+        stats['loss'] = total
+        return stats
+
+
+def scene_flow_epe(predictions, input_dict, n_frames):
+    """libs/tester.py:58-77: per-point end-point error ||(rec_est - x) - (rec_gt - x)|| for points with t > 0
+    (batch size 1, as in SegTrainer.test)."""
+    x = input_dict['input_points'].float()      # the tester multiplies by ego_motion_gt.float(): fp32 throughout
+    t = input_dict['time_indice'][:, 1].long()
+    ego = input_dict['ego_motion_gt'].float()[0]
+    comp = ego_motion_compensation(x, t, ego)
+    rec_gt = reconstruct_sequence(comp, t, input_dict['inst_labels'][:, 0], input_dict['inst_motion_gt'][0].to(x.device).float(), n_frames)
+    err = torch.norm((predictions['rec_est'] - x) - (rec_gt - x), p=2, dim=1)
+    return err[t > 0]

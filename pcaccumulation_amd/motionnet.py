@@ -1,0 +1,204 @@
+"""MotionNet: host mirror of models/motionnet.py -- the drop-in boundary of the hot path.
+
+Same constructor (`MotionNet(cfg)`), same `forward(input_dict) -> results` keys and dtypes, same sub-module
+attribute names and therefore the same 195 state_dict keys, so a released checkpoint
+loads through the reference's key-filtered partial_load (toolbox/utils.py:16-24).
+
+What differs is where the work runs: voxel bookkeeping, per-pillar reductions, pillar scatter, bilinear
+gathers, BEV warp and the per-point transform are single launches of the gfx950 kernels behind include/pcacc.h
+(all batch elements and frames at once -- the reference loops over batch and frame in Python,
+models/pillar_encoder.py:144,193, models/motionnet.py:97-135), on channels-last canvases.
+
+cfg['misc']['compute_dtype'] ('fp32' default | 'bf16'): element type of the BEV canvas and of the conv stacks
+(autocast).  Sinkhorn / Kabsch / normalisation / grid arithmetic always stay fp32.
+"""
+import contextlib
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .alignnet import AlignNet
+from .cluster import Cluster
+from .egomotion import EgoMotionHead
+from .ops import PillarIndex
+from .pillar_encoder import PillarFeatureNet, temporal_ungrid
+from .stpn import STPN
+from .unet import SegHead2D, UNet
+
+MIN_POINTS = 15                          # models/motionnet.py:11
+
+
+def grid_shape(cfg):
+    """[nx, ny, nz, nt] as Voxelization computes it (libs/voxel_generator.py:123-125, fp32 round)."""
+    vg = cfg['voxel_generator']
+    r = torch.tensor(vg['range'], dtype=torch.float32)
+    vs = torch.tensor(vg['voxel_size'], dtype=torch.float32)
+    g = torch.round((r[3:] - r[:3]) / vs).to(torch.int64).tolist()
+    return g + [int(vg['n_sweeps'])]
+
+
+class MotionNet(nn.Module):
+    def __init__(self, cfg):
+        super(MotionNet, self).__init__()
+        unet_cfg = cfg['unet']
+        self.pillar_encoder = PillarFeatureNet(cfg['pillar_encoder'])
+        self.unet = UNet(**unet_cfg)
+        self.semseg_head = SegHead2D(unet_cfg['in_channels'], 2)
+        self.ego_feats_head = SegHead2D(unet_cfg['in_channels'], cfg['pose_estimation']['feats_dim'])
+        self.ego_motion_head = EgoMotionHead(cfg)
+        self.resolution = cfg['voxel_generator']['voxel_size']
+        self.pc_range = cfg['voxel_generator']['range']
+        self.motionhead = STPN(cfg['stpn']['feat_dim'])
+        self.cluster = Cluster(cfg)
+        self.mode = cfg['misc']['mode']
+        self.reconstructor = AlignNet(cfg)
+        self.grid = grid_shape(cfg)
+        self.compute_dtype = {'fp32': torch.float32, 'bf16': torch.bfloat16}[cfg['misc'].get('compute_dtype', 'fp32')]
+
+    # ------------------------------------------------------------------------------------------------
+    def channels_last_(self):
+        """Store conv weights in the layout the channels-last activations want (no state_dict change)."""
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+            elif isinstance(m, nn.Conv3d):
+                m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last_3d)
+        return self
+
+    def _dense(self):
+        if self.compute_dtype == torch.bfloat16:
+            return torch.autocast(device_type='cuda', dtype=torch.bfloat16)
+        return contextlib.nullcontext()
+
+    # reference helpers kept for callers that use them directly ------------------------------------------
+    def warp_feats(self, bev_feats, pose_estimation):
+        """models/motionnet.py:82-114.  bev_feats [B,T,C,Ny,Nx], pose [B,T,4,4] -> [B,T,C,Ny,Nx]."""
+        bev_cl = bev_feats.permute(0, 1, 3, 4, 2).contiguous()
+        inv = torch.linalg.inv(pose_estimation.float())
+        out = ops.bev_warp(bev_cl, inv, self.resolution[0], self.resolution[1], self.pc_range[0], self.pc_range[1])
+        return out.permute(0, 1, 4, 2, 3)
+
+    def transform_points(self, points, time_indice, transformation):
+        """models/motionnet.py:117-135."""
+        T = transformation.size(1)
+        frame_idx = (time_indice[:, 0] * T + time_indice[:, 1]).to(torch.int32)
+        return ops.rigid_transform(points, frame_idx, transformation)
+
+    # ------------------------------------------------------------------------------------------------
+    def forward(self, input_dict):
+        input_points = input_dict['input_points'].float()                    # [N,3]
+        time_indice = input_dict['time_indice']                                # [N,2] f64 (b,t)
+        fb_labels = input_dict['fb_labels']                                    # [N,1]
+        ego_motion_gt = input_dict['ego_motion_gt'].float()                    # [B,T,4,4]
+        coordinates = input_dict['coordinates']                                # [M,5] f64 (b,z,y,x,t)
+        num_voxels = input_dict['num_voxels']
+        batch_size = num_voxels.size(0)
+        nx, ny, nz, nt = self.grid                                             # == input_dict['shape'][0], no host sync
+        self.Nx, self.Ny, self.nt = nx, ny, nt
+        B, T, Ny, Nx = batch_size, nt, ny, nx
+        device = coordinates.device
+        results = dict()
+
+        # 0. index structures shared by every irregular op of this forward
+        pidx = PillarIndex(coordinates, input_dict['point_to_voxel_map'], B, self.grid)
+        assert pidx.n == input_points.size(0)
+        batch_idx = time_indice[:, 0].to(torch.int32).contiguous()
+        frame_idx = (time_indice[:, 0] * T + time_indice[:, 1]).to(torch.int32).contiguous()
+
+        pillar_mean, fb_labels_sub = ops.segment_mean3_maxlabel(input_points, fb_labels, pidx)   # motionnet.py:159-160
+        occ = ops.pillar_scatter(torch.ones((pidx.m, 1), device=device), pidx)
+        fb_map = ops.pillar_scatter(fb_labels_sub.float().unsqueeze(1), pidx)
+        results['fb_seg_gt'] = fb_map.view(B, T, 1, Ny, Nx).to(fb_labels.dtype)
+        results['occ_map'] = occ.view(B, T, 1, Ny, Nx)
+
+        # 1. pillar encoder -> BEV canvas (channels-last, one streaming pass)
+        input_features = self.pillar_encoder(input_points, None, coordinates, pillar_mean, time_indice, pidx=pidx)
+        canvas = ops.pillar_scatter(input_features, pidx, self.compute_dtype)
+        bev = ops.canvas_as_nchw(canvas, pidx)                                 # [B*T, C, Ny, Nx]
+
+        # 2. backbone + 3. fg/bg head
+        with self._dense():
+            bev_feats = self.unet(bev)
+            fb_seg = self.semseg_head(bev_feats)
+            geometric_feats = self.ego_feats_head(bev_feats)
+        fb_seg = fb_seg.float()
+        results['fb_seg_est'] = fb_seg.view(B, T, 2, Ny, Nx)
+        fb_est = (fb_seg[:, 1] > fb_seg[:, 0]).long()                          # argmax, ties -> 0 (motionnet.py:190)
+        fb_est_pillar = ops.gather_rows(fb_est.reshape(-1, 1), pidx.cell)      # inverse scatter  [M,1]
+        fb_est_per_point = ops.gather_rows(fb_est_pillar, pidx.p2v)            # [N,1]
+        results['fb_est_per_points'] = fb_est_per_point
+
+        # 4. ego motion (fp32)
+        geometric_feats = geometric_feats.float()
+        geometric_feats = geometric_feats / torch.norm(geometric_feats, p=2, dim=1, keepdim=True)   # no epsilon (trap 7)
+        self.ego_motion_head.forward_pillars(ops.nchw_as_rows(geometric_feats), pillar_mean, fb_est_pillar[:, 0], pidx,
+                                             ego_motion_gt, results)
+
+        # 5. motion segmentation on ego-motion-compensated features
+        pose_est = results['ego_motion_est'].float().detach()
+        bev_feats = bev_feats.detach()
+        C = bev_feats.size(1)
+        bev_cl = bev_feats.permute(0, 2, 3, 1).contiguous().view(B, T, Ny, Nx, C)
+        warped = ops.bev_warp(bev_cl, torch.linalg.inv(pose_est), self.resolution[0], self.resolution[1],
+                              self.pc_range[0], self.pc_range[1])
+        warped_feats = warped.permute(0, 4, 1, 2, 3)                           # [B,C,T,H,W], channels_last_3d memory
+        transformed_points = ops.rigid_transform(input_points, frame_idx, pose_est)
+        results['transformed_points'] = transformed_points
+
+        if self.mode in ['train', 'val']:
+            fb_mask = torch.logical_or(fb_labels[:, 0] == 1, fb_est_per_point[:, 0] == 1)
+        else:
+            fb_mask = fb_est_per_point[:, 0] == 1
+        full_mos = torch.zeros(transformed_points.size(0), 2, device=device)
+        full_offset = torch.zeros(transformed_points.size(0), 2, device=device)
+        full_mos[:, 0] = 1
+        mos_feats = None
+        if fb_mask.sum() > MIN_POINTS:
+            with self._dense():
+                stpn_map = self.motionhead.backbone(warped_feats)
+            mos, offset, mos_feats = self._stpn_heads(stpn_map, transformed_points[fb_mask], batch_idx[fb_mask])
+            full_mos[fb_mask] = mos
+            full_offset[fb_mask] = offset
+        results['mos_est'] = full_mos
+        results['offset_est'] = full_offset
+        results['rec_est'] = transformed_points.clone()
+
+        # 6. TubeNet
+        if self.mode in ['train', 'val']:
+            inst_labels = input_dict['inst_labels'][:, 0].long()
+            rec_mask = input_dict['fb_labels'][:, 0] == 1
+        else:
+            self.cluster(transformed_points, full_mos.argmax(1), full_offset, time_indice, results, use_offset=True)
+            inst_labels = results['inst_labels_est']
+            rec_mask = inst_labels != 0
+        if rec_mask.sum() > MIN_POINTS:
+            # mos_feats exists whenever rec_mask passes in train/val (fb_mask is a superset of rec_mask)
+            backbone_feats = ops.bilinear_gather(bev_feats, input_points[rec_mask], frame_idx[rec_mask],
+                                                 abs(self.pc_range[0]), abs(self.pc_range[1]))       # temporal_ungrid
+            motion_feats = ops.bilinear_gather(mos_feats, transformed_points[rec_mask], batch_idx[rec_mask],
+                                               abs(self.pc_range[0]), abs(self.pc_range[1]))          # ungrid
+            reconstructor_input = {
+                'inst_labels': inst_labels[rec_mask],
+                'time_indice': time_indice[rec_mask],
+                'transformed_points': transformed_points[rec_mask],
+                'backbone_feats': backbone_feats,
+                'motion_feats': motion_feats,
+                'inst_motion_gt': input_dict['inst_motion_gt'],
+                'mos_labels': input_dict['sd_labels'][rec_mask, 0].long(),
+                'ego_motion_est': results['ego_motion_est'],
+                'ego_motion_gt': results['ego_motion_gt'],
+            }
+            self.reconstructor(reconstructor_input, results)
+            results['rec_est'][rec_mask] = results['sub_rec_est']
+        return results
+
+    def _stpn_heads(self, stpn_map, points, batch_idx):
+        """Per-point part of STPN.forward (models/stpn.py:91-104) on the already computed map."""
+        mh = self.motionhead
+        ungridded = ops.bilinear_gather(stpn_map, points, batch_idx, abs(self.pc_range[0]), abs(self.pc_range[1]))
+        pos = mh.positional_encoding(points / abs(self.pc_range[0]))
+        enc = mh.final_proj(torch.cat([pos, ungridded], dim=-1))
+        classes = mh.mos_seg(enc)
+        offset = mh.safe_guard_offset(mh.offset_head(enc))
+        return classes, offset, stpn_map

@@ -1,0 +1,195 @@
+"""Torch-level operators of the hot path: thin autograd wrappers over the C ABI (native.py).
+
+Layout convention: BEV canvases and feature maps are channels-last in HBM.  A canvas of C
+channels is the 2-D tensor [n_cells, C] with n_cells = B*T*ny*nx in (b, t, y, x) order; viewed as
+[B*T, C, ny, nx] it is a torch channels_last tensor, as [B, C, T, ny, nx] a channels_last_3d one.
+"""
+import torch
+
+from . import native
+
+
+class PillarIndex(object):
+    """Everything derived from (coordinates, point_to_voxel_map) that the forward reuses:
+    linear cell index per pillar, dense cell -> pillar table, point -> pillar CSR, and the per-frame
+    pillar lists in ascending cell order.  Built once per forward (the reference recomputes the index
+    arithmetic inside every scatter call, models/pillar_encoder.py:144-170, 193-203)."""
+
+    def __init__(self, coordinates, point_to_voxel_map, batch_size, input_shape):
+        nx, ny, nz, nt = (int(v) for v in input_shape[:4])
+        self.nx, self.ny, self.nt, self.batch_size = nx, ny, nt, int(batch_size)
+        self.m = int(coordinates.shape[0])
+        self.n_cells = self.batch_size * nt * ny * nx
+        self.cells_per_frame = ny * nx
+        coords = coordinates.contiguous()
+        if coords.dtype not in (torch.float64, torch.int32):
+            coords = coords.to(torch.float64)
+        self.cell, self.cell2pillar = native.cell_index(coords, nx, ny, nt, self.batch_size)
+        if point_to_voxel_map is not None:
+            p2v = point_to_voxel_map
+            if p2v.dim() == 2:
+                p2v = p2v[:, 0]
+            self.p2v = p2v.to(torch.int32).contiguous()
+            self.n = int(self.p2v.shape[0])
+            self.seg_offsets, self.order = native.csr_build(self.p2v, self.m)
+        self._frames = None
+
+    @classmethod
+    def from_point_map(cls, point_to_voxel_map, m):
+        """CSR only (no canvas geometry): enough for the per-pillar reductions of the pillar encoder."""
+        self = cls.__new__(cls)
+        p2v = point_to_voxel_map[:, 0] if point_to_voxel_map.dim() == 2 else point_to_voxel_map
+        self.m = int(m)
+        self.p2v = p2v.to(torch.int32).contiguous()
+        self.n = int(self.p2v.shape[0])
+        self.seg_offsets, self.order = native.csr_build(self.p2v, self.m)
+        self._frames = None
+        return self
+
+    def frame_pillars(self):
+        """(sorted_pillars [M] i32, frame_offsets [B*T+1] i32): occupied pillars per frame in cell order."""
+        if self._frames is None:
+            self._frames = native.frame_pillars(self.cell2pillar, self.cells_per_frame, self.m)
+        return self._frames
+
+
+# ---------------------------------------------------------------------------------------------------
+class _SegmentMax(torch.autograd.Function):
+    """scatter(net, p2v, dim=0, reduce='max') -- models/pillar_encoder.py:116,120."""
+
+    @staticmethod
+    def forward(ctx, src, pidx):
+        out, arg = native.segment_max(src.contiguous().float(), pidx.seg_offsets, pidx.order, pidx.m)
+        ctx.pidx = pidx
+        ctx.save_for_backward(arg)
+        ctx.mark_non_differentiable(arg)
+        return out, arg
+
+    @staticmethod
+    def backward(ctx, grad_out, _grad_arg):
+        (arg,) = ctx.saved_tensors
+        pidx = ctx.pidx
+        return native.segment_max_backward(grad_out.contiguous().float(), arg, pidx.p2v, pidx.n), None
+
+
+def segment_max(src, pidx):
+    return _SegmentMax.apply(src, pidx)[0]
+
+
+class _BroadcastToPoints(torch.autograd.Function):
+    """pillar_feats[point_to_voxel_map] -- the gather after each pooling (pillar_encoder.py:116)."""
+
+    @staticmethod
+    def forward(ctx, pillar_feats, pidx):
+        ctx.pidx = pidx
+        return native.gather_rows(pillar_feats.contiguous(), pidx.p2v)
+
+    @staticmethod
+    def backward(ctx, grad):
+        pidx = ctx.pidx
+        return native.segment_sum(grad.contiguous().float(), pidx.seg_offsets, pidx.order, pidx.m), None
+
+
+def broadcast_to_points(pillar_feats, pidx):
+    return _BroadcastToPoints.apply(pillar_feats, pidx)
+
+
+def segment_mean3_maxlabel(points, labels, pidx):
+    """models/motionnet.py:159-160 (no gradient: inputs are data)."""
+    lab = None
+    if labels is not None:
+        lab = labels.reshape(-1).to(torch.int64).contiguous()
+    mean, mlab = native.segment_mean3_maxlabel(points.contiguous(), lab, pidx.seg_offsets, pidx.order, pidx.m)
+    return mean, mlab
+
+
+class _PillarScatter(torch.autograd.Function):
+    """scatter_point_pillar (models/pillar_encoder.py:125-174) into a channels-last canvas [n_cells, C]."""
+
+    @staticmethod
+    def forward(ctx, feats, pidx, out_dtype):
+        ctx.pidx = pidx
+        return native.pillar_scatter(feats.contiguous().float(), pidx.cell2pillar, out_dtype)
+
+    @staticmethod
+    def backward(ctx, grad_canvas):
+        g = native.gather_rows(grad_canvas.contiguous(), ctx.pidx.cell)
+        return g.float(), None, None
+
+
+def pillar_scatter(feats, pidx, out_dtype=torch.float32):
+    return _PillarScatter.apply(feats, pidx, out_dtype)
+
+
+def canvas_as_nchw(canvas, pidx):
+    """[n_cells, C] -> logical [B*T, C, ny, nx] (channels_last strides, zero copy)."""
+    c = canvas.shape[1]
+    return canvas.view(pidx.batch_size * pidx.nt, pidx.ny, pidx.nx, c).permute(0, 3, 1, 2)
+
+
+def canvas_as_reference(canvas, pidx):
+    """[n_cells, C] -> logical [B, C, nt, ny, nx], the reference's return layout (zero copy)."""
+    c = canvas.shape[1]
+    return canvas.view(pidx.batch_size, pidx.nt, pidx.ny, pidx.nx, c).permute(0, 4, 1, 2, 3)
+
+
+def nchw_as_rows(x):
+    """logical [N, C, H, W] -> [N*H*W, C] rows; free when x is channels_last."""
+    n, c, h, w = x.shape
+    return x.permute(0, 2, 3, 1).contiguous().view(n * h * w, c)
+
+
+class _BilinearGather(torch.autograd.Function):
+    """ungrid (models/pillar_encoder.py:231-267) as a direct 4-tap gather on a channels-last map."""
+
+    @staticmethod
+    def forward(ctx, fmap, points, map_idx, x_scale, y_scale):
+        fm = fmap.permute(0, 2, 3, 1).contiguous()                      # [N,H,W,C]; no copy if channels_last
+        if fm.dtype not in (torch.float32, torch.bfloat16):
+            fm = fm.float()
+        ctx.shape = tuple(fm.shape)
+        ctx.in_dtype = fmap.dtype
+        ctx.scales = (float(x_scale), float(y_scale))
+        ctx.save_for_backward(points, map_idx)
+        return native.bilinear_gather(fm, points, map_idx, float(x_scale), float(y_scale))
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        points, map_idx = ctx.saved_tensors
+        g = native.bilinear_gather_backward(grad_out.contiguous().float(), ctx.shape, points, map_idx, *ctx.scales)
+        return g.permute(0, 3, 1, 2).to(ctx.in_dtype), None, None, None, None
+
+
+def bilinear_gather(fmap, points, map_idx, x_scale, y_scale):
+    """fmap logical [N,C,H,W]; points [K,3] f32; map_idx [K] i32 -> [K,C] f32 (input order)."""
+    return _BilinearGather.apply(fmap, points.contiguous().float(), map_idx.to(torch.int32).contiguous(), x_scale, y_scale)
+
+
+def bev_warp(bev_cl, inv_pose, x_reso, y_reso, x_min, y_min):
+    """bev_cl [B,T,H,W,C] (detached); inv_pose [B,T,4,4] f32 -> warped [B,T,H,W,C] (motionnet.py:82-114)."""
+    return native.bev_warp(bev_cl.contiguous(), inv_pose.contiguous().float(), float(x_reso), float(y_reso),
+                           float(x_min), float(y_min))
+
+
+def rigid_transform(points, frame_idx, tsfm):
+    """points [N,3] f32, frame_idx [N] i32 = b*T+t, tsfm [B,T,4,4] -> [N,3] (motionnet.py:117-135)."""
+    return native.rigid_transform(points.contiguous().float(), frame_idx.to(torch.int32).contiguous(),
+                                  tsfm.reshape(-1, 16).contiguous().float())
+
+
+def gather_rows(src2d, idx):
+    return native.gather_rows(src2d.contiguous(), idx.to(torch.int32).contiguous())
+
+
+def scatter(src, index, dim=0, dim_size=None, reduce='sum'):
+    """torch_scatter.scatter as used by the per-instance TubeNet (models/tpointnet.py:227-284,
+    models/alignnet.py:133-134, libs/loss.py:216): tiny K*T-row outputs, plain PyTorch-ROCm
+    (SURVEY.md section 2 row 8).  Empty segments are 0."""
+    assert dim == 0
+    index = index.long()
+    n = int(dim_size) if dim_size is not None else (int(index.max()) + 1 if index.numel() else 0)
+    red = {'sum': 'sum', 'mean': 'mean', 'max': 'amax'}[reduce]
+    shape = (n,) + tuple(src.shape[1:])
+    idx = index.view((-1,) + (1,) * (src.dim() - 1)).expand_as(src)
+    out = torch.zeros(shape, dtype=src.dtype, device=src.device)
+    return out.scatter_reduce(0, idx, src, red, include_self=False)

@@ -1,0 +1,131 @@
+"""Pillar encoder and pillar <-> BEV movement: host mirror of models/pillar_encoder.py.
+
+Same class / function names, constructor arguments and state_dict keys as the reference
+(`fc_pos`, `fc_c`, `blocks.{i}.{fc_0,fc_1,shortcut}`); the per-pillar pooling,
+scatter and bilinear gather run in the HIP kernels behind pcaccumulation_amd.ops.
+"""
+import torch
+from torch import nn
+
+from . import ops
+from .ops import PillarIndex
+
+
+class ResnetBlockFC(nn.Module):
+    """models/pillar_encoder.py:13-55."""
+
+    def __init__(self, size_in, size_out=None, size_h=None):
+        super().__init__()
+        if size_out is None:
+            size_out = size_in
+        if size_h is None:
+            size_h = min(size_in, size_out)
+        self.size_in, self.size_h, self.size_out = size_in, size_h, size_out
+        self.fc_0 = nn.Linear(size_in, size_h)
+        self.fc_1 = nn.Linear(size_h, size_out)
+        self.actvn = nn.ReLU()
+        self.shortcut = None if size_in == size_out else nn.Linear(size_in, size_out, bias=False)
+        nn.init.zeros_(self.fc_1.weight)
+
+    def forward(self, x):
+        net = self.fc_0(self.actvn(x))
+        dx = self.fc_1(self.actvn(net))
+        x_s = self.shortcut(x) if self.shortcut is not None else x
+        return x_s + dx
+
+
+class PillarFeatureNet(nn.Module):
+    """models/pillar_encoder.py:59-122."""
+
+    def __init__(self, cfg):
+        super(PillarFeatureNet, self).__init__()
+        num_input_features = cfg['num_input_features']
+        num_filters = cfg['num_filters']
+        voxel_size = cfg['voxel_size']
+        pc_range = cfg['pc_range']
+        depth = cfg['depth']
+        self.scale = abs(pc_range[0])
+        self.n_frames = cfg['n_sweeps']
+        self.name = "PillarFeatureNet"
+        self.fc_pos = nn.Linear(num_input_features, 2 * num_filters)
+        self.fc_c = nn.Linear(num_filters, num_filters)
+        self.actvn = nn.ReLU()
+        self.blocks = nn.ModuleList([ResnetBlockFC(2 * num_filters, num_filters) for _ in range(depth)])
+        self.vx = voxel_size[0]
+        self.vy = voxel_size[1]
+        self.x_offset = self.vx / 2 + pc_range[0]
+        self.y_offset = self.vy / 2 + pc_range[1]
+
+    def point_features(self, raw_points, pidx, coordinates, pillar_mean, time_indice):
+        """The 9 inputs of pillar_encoder.py:98-110, in the same arithmetic (f64 coordinates, f32 points)."""
+        p2v = pidx.p2v
+        dist_to_pts_mean = raw_points - ops.gather_rows(pillar_mean, p2v)
+        mapped = ops.gather_rows(coordinates.contiguous(), p2v)           # [N,5] f64 rows of 40 bytes
+        f_center = torch.zeros_like(raw_points[:, :2])
+        f_center[:, 0] = raw_points[:, 0] - (mapped[:, 3] * self.vx + self.x_offset)
+        f_center[:, 1] = raw_points[:, 1] - (mapped[:, 2] * self.vy + self.y_offset)
+        features = torch.cat([raw_points, dist_to_pts_mean, f_center, time_indice[:, 1:2]], dim=-1).float()
+        features[:, :-1] /= self.scale
+        features[:, -1] /= self.n_frames
+        return features
+
+    def forward(self, raw_points, point_to_voxel_map, coordinates, pillar_mean, time_indice, pidx=None):
+        if pidx is None:                                                  # reference call signature
+            pidx = PillarIndex.from_point_map(point_to_voxel_map, coordinates.shape[0])
+        features = self.point_features(raw_points, pidx, coordinates, pillar_mean, time_indice)
+        net = self.fc_pos(features)
+        net = self.blocks[0](net)
+        for block in self.blocks[1:]:
+            pooled = ops.broadcast_to_points(ops.segment_max(net, pidx), pidx)
+            net = block(torch.cat([net, pooled], dim=1))
+        feats = self.fc_c(net)
+        return ops.segment_max(feats, pidx)
+
+
+def _index_for(coords, batch_size, input_shape):
+    return PillarIndex(coords, None, int(batch_size), [int(v) for v in input_shape])
+
+
+def scatter_point_pillar(voxel_features, coords, batch_size, input_shape, pidx=None):
+    """models/pillar_encoder.py:125-174.  Returns logical [B, C, nt, ny, nx] like the reference; the
+    memory behind it is channels-last ([B, nt, ny, nx, C])."""
+    if pidx is None:
+        pidx = _index_for(coords, batch_size, input_shape)
+    src = voxel_features
+    out_dtype = src.dtype if src.dtype in (torch.float32, torch.bfloat16) else torch.float32
+    canvas = ops.pillar_scatter(src.float(), pidx, out_dtype)
+    out = ops.canvas_as_reference(canvas, pidx)
+    return out if src.dtype == out.dtype else out.to(src.dtype)
+
+
+def inverse_scatter_point_pillar(voxel_features, coords, batch_size, input_shape, pidx=None):
+    """models/pillar_encoder.py:177-204: [B, C, nt, ny, nx] -> [M, C] (rows in pillar order)."""
+    if pidx is None:
+        pidx = _index_for(coords, batch_size, input_shape)
+    b, c = voxel_features.shape[0], voxel_features.shape[1]
+    rows = voxel_features.permute(0, 2, 3, 4, 1).contiguous().view(-1, c)
+    if rows.element_size() * c % 4:
+        raise ValueError('inverse_scatter_point_pillar: row size must be a multiple of 4 bytes')
+    return ops.gather_rows(rows, pidx.cell)
+
+
+def _batch_index(time_indice):
+    return time_indice[:, 0].to(torch.int32).contiguous()
+
+
+def ungrid(feats, points, pc_range, time_indice):
+    """models/pillar_encoder.py:231-267.  feats [B,C,H,W], points [N,3], time_indice [N,2] -> [N,C].
+    Like the reference it normalises points[:, :2] IN PLACE (callers pass clones; appendix C trap 2).
+    Output rows follow the input order, which equals the reference's batch-grouped order because the
+    batch column of a collated batch is sorted (trap 3)."""
+    out = ops.bilinear_gather(feats, points.detach().clone(), _batch_index(time_indice), abs(pc_range[0]), abs(pc_range[1]))
+    points[:, 0] = points[:, 0] / abs(pc_range[0])
+    points[:, 1] = points[:, 1] / abs(pc_range[1])
+    return out
+
+
+def temporal_ungrid(feats, points, pc_range, time_indice):
+    """models/pillar_encoder.py:206-228.  feats [B,T,C,H,W] -> [N,C]; one launch over all frames."""
+    b, t, c, h, w = feats.shape
+    idx = (time_indice[:, 0] * t + time_indice[:, 1]).to(torch.int32).contiguous()
+    return ops.bilinear_gather(feats.reshape(b * t, c, h, w), points, idx, abs(pc_range[0]), abs(pc_range[1]))

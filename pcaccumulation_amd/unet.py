@@ -1,0 +1,120 @@
+"""Dense 2-D encoder-decoder and the small conv / linear heads: host mirror of models/unet.py.
+
+Attribute names fix the state_dict contract: `down_convs.{i}.{conv1,conv2}`,
+`up_convs.{i}.{upconv,conv1,conv2}`, `conv_final`, `seg_head.{0,1,3}`.  The convolutions themselves are
+library GEMMs (MIOpen through PyTorch-ROCm) fed channels-last tensors; see DESIGN.md for why the C<=64
+full-resolution layers are HBM-bound and what is fused around them.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn import init
+
+
+def conv3x3(in_channels, out_channels):
+    return nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=True)
+
+
+class DownConv(nn.Module):
+    """models/unet.py:45-71: two 3x3 conv + ReLU, optional 2x2 max-pool; returns (pooled, before_pool)."""
+
+    def __init__(self, in_channels, out_channels, pooling=True):
+        super(DownConv, self).__init__()
+        self.in_channels, self.out_channels, self.pooling = in_channels, out_channels, pooling
+        self.conv1 = conv3x3(in_channels, out_channels)
+        self.conv2 = conv3x3(out_channels, out_channels)
+        if pooling:
+            self.pool = nn.MaxPool2d(kernel_size=2, stride=2)
+
+    def forward(self, x):
+        x = F.relu(self.conv2(F.relu(self.conv1(x))))
+        return (self.pool(x) if self.pooling else x), x
+
+
+class UpConv(nn.Module):
+    """models/unet.py:74-113: 2x2 transpose-conv upsample, concat with the skip, two 3x3 conv + ReLU."""
+
+    def __init__(self, in_channels, out_channels, merge_mode='concat', up_mode='transpose'):
+        super(UpConv, self).__init__()
+        assert up_mode == 'transpose', 'only the transpose-conv decoder the released weights use'
+        self.in_channels, self.out_channels, self.merge_mode, self.up_mode = in_channels, out_channels, merge_mode, up_mode
+        self.upconv = nn.ConvTranspose2d(in_channels, out_channels, kernel_size=2, stride=2)
+        self.conv1 = conv3x3(2 * out_channels if merge_mode == 'concat' else out_channels, out_channels)
+        self.conv2 = conv3x3(out_channels, out_channels)
+
+    def forward(self, from_down, from_up):
+        from_up = self.upconv(from_up)
+        x = torch.cat((from_up, from_down), 1) if self.merge_mode == 'concat' else from_up + from_down
+        return F.relu(self.conv2(F.relu(self.conv1(x))))
+
+
+class UNet(nn.Module):
+    """models/unet.py:116-233 (depth 5, 32..512 channels in the default config)."""
+
+    def __init__(self, in_channels=3, depth=5, start_filts=64, up_mode='transpose', merge_mode='concat', **kwargs):
+        super(UNet, self).__init__()
+        if up_mode not in ('transpose', 'upsample') or merge_mode not in ('concat', 'add'):
+            raise ValueError('unsupported up_mode / merge_mode: %s / %s' % (up_mode, merge_mode))
+        self.up_mode, self.merge_mode = up_mode, merge_mode
+        self.in_channels, self.start_filts, self.depth = in_channels, start_filts, depth
+        downs, ups = [], []
+        outs = in_channels
+        for i in range(depth):
+            ins = in_channels if i == 0 else outs
+            outs = start_filts * (2 ** i)
+            downs.append(DownConv(ins, outs, pooling=i < depth - 1))
+        for i in range(depth - 1):
+            ins = outs
+            outs = ins // 2
+            ups.append(UpConv(ins, outs, up_mode=up_mode, merge_mode=merge_mode))
+        self.down_convs = nn.ModuleList(downs)
+        self.up_convs = nn.ModuleList(ups)
+        self.conv_final = conv3x3(outs, in_channels)
+        self.reset_params()
+
+    @staticmethod
+    def weight_init(m):
+        if isinstance(m, nn.Conv2d):                 # ConvTranspose2d keeps its default init (unet.py:210-219)
+            init.xavier_normal_(m.weight)
+            init.constant_(m.bias, 0)
+
+    def reset_params(self):
+        for m in self.modules():
+            self.weight_init(m)
+
+    def forward(self, x):
+        skips = []
+        for module in self.down_convs:
+            x, before_pool = module(x)
+            skips.append(before_pool)
+        for i, module in enumerate(self.up_convs):
+            x = module(skips[-(i + 2)], x)
+        return self.conv_final(x)
+
+
+class SegHead1D(nn.Module):
+    """models/unet.py:235-256: Linear, BatchNorm1d, ReLU, Linear on [N, C] rows."""
+
+    def __init__(self, in_channel, out_channel, bias=True):
+        super(SegHead1D, self).__init__()
+        mid = max(in_channel, out_channel)
+        self.seg_head = nn.Sequential(nn.Linear(in_channel, mid, bias=bias), nn.BatchNorm1d(mid), nn.ReLU(),
+                                      nn.Linear(mid, out_channel, bias=bias))
+
+    def forward(self, feats):
+        return self.seg_head(feats)
+
+
+class SegHead2D(nn.Module):
+    """models/unet.py:259-277: conv, BatchNorm2d, ReLU, conv on [B, C, H, W]."""
+
+    def __init__(self, in_channel, out_channel, kernel_size=3, stride=1, padding=1, bias=True, groups=1):
+        super(SegHead2D, self).__init__()
+        mid = max(in_channel, out_channel)
+        self.seg_head = nn.Sequential(
+            nn.Conv2d(in_channel, mid, kernel_size=kernel_size, stride=stride, padding=padding, bias=bias, groups=groups),
+            nn.BatchNorm2d(mid), nn.ReLU(),
+            nn.Conv2d(mid, out_channel, kernel_size=kernel_size, stride=stride, padding=padding, bias=bias, groups=groups))
+
+    def forward(self, feats):
+        return self.seg_head(feats)

@@ -1,0 +1,159 @@
+"""TEST DOUBLE for pcaccumulation_amd.native, built on the oracle.
+
+Lets the CPU-only suite exercise the host logic of the product (autograd wrappers, module wiring, layouts,
+result keys) in a container without a GPU: tests monkeypatch these functions over the ctypes bindings.
+Lives under tests/ and is never importable from the product package; the `-m gpu` tests run the real HIP
+library instead.  Same signatures as pcaccumulation_amd/native.py, CPU torch tensors in and out."""
+import numpy as np
+import torch
+
+import oracle
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def voxelize(points, voxel_size, pc_range, grid, nt, max_voxels):
+    out = oracle.voxelize(_np(points), voxel_size, pc_range, nt, max_voxels=max_voxels)
+    m = int(out['num_voxels'][0])
+    coords = torch.zeros((max_voxels, 4), dtype=torch.int32)
+    coords[:m] = torch.from_numpy(out['coordinates'])
+    return coords, torch.from_numpy(out['point_to_voxel_map'][:, 0].copy()), torch.tensor([m], dtype=torch.int32)
+
+
+def cell_index(coords, nx, ny, nt, n_batch):
+    c = _np(coords).astype(np.int64)
+    cell = ((c[:, 0] * nt + c[:, 4]) * ny + c[:, 2]) * nx + c[:, 3]
+    c2p = np.full(n_batch * nt * ny * nx, -1, np.int32)
+    c2p[cell] = np.arange(c.shape[0], dtype=np.int32)
+    return torch.from_numpy(cell.astype(np.int32)), torch.from_numpy(c2p)
+
+
+def frame_pillars(cell2pillar, cells_per_frame, m):
+    c2p = _np(cell2pillar)
+    occ = c2p >= 0
+    offs = np.concatenate([[0], np.cumsum(occ.reshape(-1, cells_per_frame).sum(1))]).astype(np.int32)
+    return torch.from_numpy(c2p[occ].astype(np.int32)), torch.from_numpy(offs)
+
+
+def csr_build(p2v, m):
+    p = _np(p2v)
+    order = np.argsort(p, kind='stable').astype(np.int32)
+    offs = np.concatenate([[0], np.cumsum(np.bincount(p, minlength=m))]).astype(np.int32)
+    return torch.from_numpy(offs), torch.from_numpy(order)
+
+
+def _p2v_from_csr(offs, order):
+    o, r = _np(offs), _np(order)
+    seg = np.repeat(np.arange(o.shape[0] - 1), np.diff(o))
+    p2v = np.empty(r.shape[0], np.int64)
+    p2v[r] = seg
+    return p2v
+
+
+def segment_mean3_maxlabel(points, labels, offs, order, m):
+    p2v = _p2v_from_csr(offs, order)
+    mean = torch.from_numpy(oracle.segment_mean(_np(points), p2v, m))
+    lab = torch.from_numpy(oracle.segment_max_label(_np(labels), p2v, m)[:, 0].copy()) if labels is not None else None
+    return mean, lab
+
+
+def segment_max(src, offs, order, m):
+    out, arg = oracle.segment_max(_np(src), _p2v_from_csr(offs, order), m)
+    return torch.from_numpy(out), torch.from_numpy(arg)
+
+
+def segment_max_backward(grad_out, arg, p2v, n):
+    seg = p2v.long()
+    g = grad_out[seg]
+    hit = arg[seg].long() == torch.arange(n)[:, None]
+    return torch.where(hit, g, torch.zeros_like(g))
+
+
+def segment_sum(src, offs, order, m):
+    p2v = torch.from_numpy(_p2v_from_csr(offs, order))
+    return torch.zeros((m, src.shape[1]), dtype=torch.float32).index_add_(0, p2v, src.float())
+
+
+def pillar_scatter(feats, cell2pillar, out_dtype=torch.float32):
+    c2p = cell2pillar.long()
+    canvas = torch.zeros((c2p.numel(), feats.shape[1]), dtype=torch.float32)
+    occ = c2p >= 0
+    canvas[occ] = feats.detach().float()[c2p[occ]]
+    return canvas.to(out_dtype)
+
+
+def gather_rows(src, idx):
+    i = idx.long()
+    out = src[i.clamp(min=0)]
+    out[i < 0] = 0
+    return out
+
+
+def bilinear_gather(fmap, points, map_idx, x_scale, y_scale):
+    fm = np.transpose(_np(fmap.float()), (0, 3, 1, 2))
+    pts = _np(points)
+    u = pts[:, 0] / np.float32(x_scale)
+    v = pts[:, 1] / np.float32(y_scale)
+    mi = _np(map_idx)
+    out = np.zeros((pts.shape[0], fm.shape[1]), np.float32)
+    for b in range(fm.shape[0]):
+        sel = mi == b
+        if sel.any():
+            out[sel] = oracle._grid_sample(fm[b], u[sel], v[sel], 'border')
+    return torch.from_numpy(out)
+
+
+def bilinear_gather_backward(grad_out, shape, points, map_idx, x_scale, y_scale):
+    n, h, w, c = shape
+    with torch.enable_grad():                       # called from inside an autograd backward
+        f = torch.zeros((n, c, h, w), requires_grad=True)
+        tot = 0
+        for b in range(n):
+            sel = map_idx == b
+            if sel.any():
+                grid = torch.stack([points[sel, 0] / x_scale, points[sel, 1] / y_scale], 1).view(1, -1, 1, 2)
+                s = torch.nn.functional.grid_sample(f[b:b + 1], grid, mode='bilinear', padding_mode='border', align_corners=False)
+                tot = tot + (s[0, :, :, 0].T * grad_out[sel].detach()).sum()
+        if torch.is_tensor(tot):
+            tot.backward()
+            return f.grad.permute(0, 2, 3, 1).contiguous()
+    return torch.zeros(shape)
+
+
+def bev_warp(bev, inv_pose, x_reso, y_reso, x_min, y_min):
+    b_, t_, h, w, c = bev.shape
+    src = np.transpose(_np(bev.float()), (0, 1, 4, 2, 3))
+    out = np.empty_like(src)
+    ip = _np(inv_pose)
+    for b in range(b_):
+        out[b, 0] = src[b, t_ - 1]
+        for t in range(1, t_):
+            gx, gy = oracle.get_transformed_grid(ip[b, t], h, w, x_reso, y_reso, x_min, y_min)
+            out[b, t] = oracle._grid_sample(src[b, t], gx, gy, 'zeros').T.reshape(c, h, w)
+    return torch.from_numpy(np.ascontiguousarray(np.transpose(out, (0, 1, 3, 4, 2)))).to(bev.dtype)
+
+
+def rigid_transform(points, frame_idx, tsfm):
+    tr = tsfm.view(-1, 4, 4)[frame_idx.long()]
+    return (torch.matmul(tr[:, :3, :3], points[:, :, None])[:, :, 0] + tr[:, :3, 3]).float()
+
+
+def chamfer_forward(xyz1, xyz2):
+    return tuple(torch.from_numpy(a) for a in oracle.chamfer_forward(_np(xyz1), _np(xyz2)))
+
+
+def chamfer_backward(xyz1, xyz2, gd1, gd2, i1, i2):
+    return tuple(torch.from_numpy(a) for a in oracle.chamfer_backward(_np(xyz1), _np(xyz2), _np(gd1), _np(gd2), _np(i1), _np(i2)))
+
+
+NAMES = ['voxelize', 'cell_index', 'frame_pillars', 'csr_build', 'segment_mean3_maxlabel', 'segment_max',
+         'segment_max_backward', 'segment_sum', 'pillar_scatter', 'gather_rows', 'bilinear_gather',
+         'bilinear_gather_backward', 'bev_warp', 'rigid_transform', 'chamfer_forward', 'chamfer_backward']
+
+
+def install(monkeypatch):
+    from pcaccumulation_amd import native
+    for name in NAMES:
+        monkeypatch.setattr(native, name, globals()[name])
