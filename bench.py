@@ -1,0 +1,164 @@
+#!/usr/bin/env python
+"""Headline benchmark: LiDAR-frames/s of one training step of the hot path (BASELINE.json `metric`).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one pass of the hot path over one synthetic 5-frame x 160k-point sequence per GPU (BASELINE config
+c3 shape): GPU voxelisation + collate layout -> MotionNet forward (bf16 canvas / conv stacks, fp32 ego head)
+-> FuseLoss -> backward -> flat gradient all-reduce (N > 1) -> grad clip -> Adam step.  Inputs (raw points,
+labels, poses) are resident in HBM before the timed region.  Scenes are independent, so ranks run different
+scenes and the only collective is the gradient all-reduce: weak scaling.
+
+Extra objects on the JSON line: `roofline` for the pillar-scatter kernel (the kernel BASELINE.json's north_star
+names), timed live with HIP events on the launch stream inside the timed region; `cpu_baseline`: the same step
+on the host cores with the oracle-backed CPU backend (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from pcaccumulation_amd import distributed as pdist  # noqa: E402
+from pcaccumulation_amd import native  # noqa: E402
+from pcaccumulation_amd.config import default_config  # noqa: E402
+from pcaccumulation_amd.loss import FuseLoss  # noqa: E402
+from pcaccumulation_amd.motionnet import MotionNet  # noqa: E402
+from pcaccumulation_amd.pipeline import DeviceBatcher, sample_to_device  # noqa: E402
+from pcaccumulation_amd.synthetic import make_sequence  # noqa: E402
+
+T_FRAMES = 5
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy ceiling)
+
+
+def build(cfg, device, seed=0):
+    torch.manual_seed(seed)
+    model = MotionNet(cfg).to(device)
+    if device.type == 'cuda':
+        model.channels_last_()
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=cfg['Adam']['learning_rate'], weight_decay=cfg['Adam']['weight_decay'])
+    return model, opt, FuseLoss(cfg['loss'])
+
+
+def train_step(model, opt, loss_fn, batcher, scene, allreduce, clip):
+    inp = batcher([scene])
+    out = model(inp)
+    stats = loss_fn(out, inp)
+    stats['loss'].backward()
+    if allreduce is not None:
+        allreduce()
+    torch.nn.utils.clip_grad_norm_(model.parameters(), clip)
+    opt.step()
+    opt.zero_grad(set_to_none=True)
+    return stats
+
+
+def cpu_baseline(cfg, pts_per_frame, budget_s=40.0):
+    """Same step on the host cores: product host code + oracle CPU backend (kind 'port'), fp32."""
+    from oracle import cpu_backend
+    import oracle
+    oracle.lib()
+    cpu_backend.install()
+    cfg = json.loads(json.dumps(cfg))
+    cfg['misc']['compute_dtype'] = 'fp32'
+    dev = torch.device('cpu')
+    model, opt, loss_fn = build(cfg, dev)
+    batcher = DeviceBatcher(cfg)
+    batcher.voxeliser.device = dev
+    scene = sample_to_device(make_sequence(999, T_FRAMES, pts_per_frame, cfg), dev)
+    t0 = time.time()
+    torch.manual_seed(0)
+    train_step(model, opt, loss_fn, batcher, scene, None, cfg['train']['grad_clip'])
+    warm = time.time() - t0
+    if warm > budget_s / 2:
+        dt, what = warm, 'first (cold) step'
+    else:
+        t0 = time.time()
+        train_step(model, opt, loss_fn, batcher, scene, None, cfg['train']['grad_clip'])
+        dt, what = time.time() - t0, 'second (warm) step'
+    return {'value': T_FRAMES / dt, 'unit': 'LiDAR-frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '1 train step on one %dx%d-point sequence, fp32, %s, %.1f s' % (T_FRAMES, pts_per_frame, what, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--pts-per-frame', type=int, default=160000)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank, world, local_rank = pdist.init_from_env()
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit('--gpus %d needs torch.distributed.run with --nproc-per-node %d' % (args.gpus, args.gpus))
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+    native.lib()
+
+    cfg = default_config('waymo', 'train', n_sweeps=T_FRAMES)
+    cfg['misc']['compute_dtype'] = args.dtype
+    model, opt, loss_fn = build(cfg, device)
+    batcher = DeviceBatcher(cfg)
+    n_scenes = 4
+    scenes = [sample_to_device(make_sequence(1000 * rank + i, T_FRAMES, args.pts_per_frame, cfg), device) for i in range(n_scenes)]
+    allreduce = pdist.FlatGradAllReduce(model.parameters()) if world > 1 else None
+    clip = cfg['train']['grad_clip']
+
+    torch.manual_seed(1234 + rank)
+    for i in range(args.warmup):
+        train_step(model, opt, loss_fn, batcher, scenes[i % n_scenes], allreduce, clip)
+
+    native.scatter_timer = []
+    pdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        train_step(model, opt, loss_fn, batcher, scenes[i % n_scenes], allreduce, clip)
+    torch.cuda.synchronize()
+    pdist.barrier()
+    dt = pdist.max_over_ranks(time.perf_counter() - t0, device)
+    timer, native.scatter_timer = native.scatter_timer, None
+
+    if rank == 0:
+        frames = world * T_FRAMES * args.steps
+        s = 2 if args.dtype == 'bf16' else 4
+        durs = [e0.elapsed_time(e1) * 1e-3 for e0, e1, *_ in timer]
+        alg = [nc * c * s + m * c * 4 + 4 * m for _, _, nc, c, m, _ in timer]          # canvas + features + index
+        achieved = (sum(alg) / len(alg)) / (sum(durs) / len(durs)) / 1e9 if durs else 0.0
+        line = {
+            'metric': 'LiDAR-frames/sec (5-frame seq, 160k pts) fwd+bwd', 'value': frames / dt, 'unit': 'LiDAR-frames/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': 'c3 shape: Waymo geometry 288x288x%d, %d pts/frame uniform synthetic, 1 sequence per GPU, '
+                                   'train step = GPU voxelise + MotionNet fwd + FuseLoss + bwd + grad all-reduce + Adam'
+                                   % (T_FRAMES, args.pts_per_frame),
+                       'frames_per_sequence': T_FRAMES, 'pts_per_frame': args.pts_per_frame, 'sequences_per_gpu': 1,
+                       'parallelism': 'dp%d' % world},
+            'roofline': {'kernel': 'pillar_scatter_vec4 (BEV canvas fill)', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
+                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
+                         'launches_timed': len(durs), 'avg_launch_us': (sum(durs) / len(durs) * 1e6) if durs else None,
+                         'algorithmic_bytes_per_launch': (sum(alg) / len(alg)) if alg else None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line['cpu_baseline'] = cpu_baseline(cfg, args.pts_per_frame)
+            except Exception as e:                                     # the baseline must never take the bench line down
+                line['cpu_baseline'] = {'value': None, 'unit': 'LiDAR-frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+                                        'sample': 'failed: %r' % (e,)}
+        print(json.dumps(line))
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -94,9 +94,12 @@ int pcacc_segment_mean3_maxlabel(const float *points, const int64_t *labels, con
 
 /* A4 (pooling step). scatter(net, p2v, dim=0, reduce='max') -- models/pillar_encoder.py:116,120.
  *   src [n,c] f32, c % 4 == 0, c <= 256; out [m,c] f32; arg [m,c] i32 = lowest point index attaining
- *   the maximum (the element torch_scatter routes the gradient to). */
-int pcacc_segment_max(const float *src, int c, const int32_t *seg_offsets, const int32_t *order, int64_t m,
-                      float *out, int32_t *arg, void *stream);
+ *   the maximum (the element torch_scatter routes the gradient to), -1 for an empty segment (value 0).
+ *   When n/m > 16 (the per-instance poolings of models/tpointnet.py:227-259, few rows with thousands of
+ *   inputs each) the reduction runs in two levels over 64-row pieces and needs the workspace. */
+int pcacc_segment_workspace_bytes(int64_t n, int64_t m, int c, size_t *bytes /*host*/);
+int pcacc_segment_max(const float *src, int c, const int32_t *seg_offsets, const int32_t *order, int64_t n, int64_t m,
+                      float *out, int32_t *arg, void *workspace, size_t workspace_bytes, void *stream);
 /* Backward of segment_max followed by the [p2v] gather is not needed separately: both reduce to
  * grad_src[i,k] += grad_out[p2v[i],k] * (arg[p2v[i],k] == i). */
 int pcacc_segment_max_backward(const float *grad_out, const int32_t *arg, const int32_t *p2v, int64_t n, int c,
@@ -104,8 +107,8 @@ int pcacc_segment_max_backward(const float *grad_out, const int32_t *arg, const 
 
 /* Per-pillar sum of point rows: the backward of the `[point_to_voxel_map]` broadcast that follows each
  * pooling (models/pillar_encoder.py:116).  src [n,c] f32, out [m,c] f32, c % 4 == 0, c <= 256. */
-int pcacc_segment_sum(const float *src, int c, const int32_t *seg_offsets, const int32_t *order, int64_t m,
-                      float *out, void *stream);
+int pcacc_segment_sum(const float *src, int c, const int32_t *seg_offsets, const int32_t *order, int64_t n, int64_t m,
+                      float *out, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * A5. Pillar scatter into the BEV canvas -- models/pillar_encoder.py:125-174 (scatter_point_pillar).

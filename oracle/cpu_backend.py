@@ -1,9 +1,11 @@
-"""TEST DOUBLE for pcaccumulation_amd.native, built on the oracle.
+"""CPU stand-in for pcaccumulation_amd.native, built on the oracle -- TEST INFRASTRUCTURE.
 
-Lets the CPU-only suite exercise the host logic of the product (autograd wrappers, module wiring, layouts,
-result keys) in a container without a GPU: tests monkeypatch these functions over the ctypes bindings.
-Lives under tests/ and is never importable from the product package; the `-m gpu` tests run the real HIP
-library instead.  Same signatures as pcaccumulation_amd/native.py, CPU torch tensors in and out."""
+Same signatures as pcaccumulation_amd/native.py, CPU torch tensors in and out.  Two users, both allowed to
+touch oracle/: (1) the CPU-only test suite monkeypatches these functions over the ctypes bindings to exercise
+the host logic of the product (autograd wrappers, module wiring, layouts, result keys) in a container without
+a GPU; (2) bench.py's `cpu_baseline` leg times the whole path on the host cores with them.  The product never
+imports this module and has no switch that selects it: `install()` is an explicit patch applied by the caller.
+"""
 import numpy as np
 import torch
 
@@ -153,7 +155,11 @@ NAMES = ['voxelize', 'cell_index', 'frame_pillars', 'csr_build', 'segment_mean3_
          'bilinear_gather_backward', 'bev_warp', 'rigid_transform', 'chamfer_forward', 'chamfer_backward']
 
 
-def install(monkeypatch):
+def install(monkeypatch=None):
+    """Patch pcaccumulation_amd.native in this process (pytest monkeypatch when given, else plain setattr)."""
     from pcaccumulation_amd import native
     for name in NAMES:
-        monkeypatch.setattr(native, name, globals()[name])
+        if monkeypatch is not None:
+            monkeypatch.setattr(native, name, globals()[name])
+        else:
+            setattr(native, name, globals()[name])

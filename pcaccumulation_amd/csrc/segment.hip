@@ -26,6 +26,53 @@ __global__ __launch_bounds__(256) void csr_fill(const int32_t *__restrict__ p2v,
     }
 }
 
+// Few segments (TubeNet instances, K*T ~ 100 rows): one global atomic per point would serialise on a handful of
+// addresses.  Privatise the histogram in LDS per 2048-point chunk and touch global memory once per (chunk, bin).
+#define CSR_SMALL_M 2048
+
+__global__ __launch_bounds__(256) void csr_histogram_small(const int32_t *__restrict__ p2v, int64_t n, int m, int *counts)
+{
+    __shared__ int hist[CSR_SMALL_M];
+    for (int k = threadIdx.x; k < m; k += 256) hist[k] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * PCACC_CHUNK;
+#pragma unroll
+    for (int r = 0; r < PCACC_CHUNK_ROWS; ++r) {
+        const int64_t i = base + r * 256 + threadIdx.x;
+        if (i < n) atomicAdd(&hist[p2v[i]], 1);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < m; k += 256)
+        if (hist[k]) atomicAdd(&counts[k], hist[k]);
+}
+
+__global__ __launch_bounds__(256) void csr_fill_small(const int32_t *__restrict__ p2v, int64_t n, int m,
+                                                      const int32_t *__restrict__ seg_offsets, int *cursor, int32_t *order)
+{
+    __shared__ int hist[CSR_SMALL_M];
+    for (int k = threadIdx.x; k < m; k += 256) hist[k] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * PCACC_CHUNK;
+    int seg[PCACC_CHUNK_ROWS], rank[PCACC_CHUNK_ROWS];
+#pragma unroll
+    for (int r = 0; r < PCACC_CHUNK_ROWS; ++r) {
+        const int64_t i = base + r * 256 + threadIdx.x;
+        seg[r] = (i < n) ? p2v[i] : -1;
+        rank[r] = (seg[r] >= 0) ? atomicAdd(&hist[seg[r]], 1) : 0;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < m; k += 256) {
+        const int c = hist[k];
+        hist[k] = c ? seg_offsets[k] + atomicAdd(&cursor[k], c) : 0;     // start of this chunk's slice of segment k
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < PCACC_CHUNK_ROWS; ++r) {
+        const int64_t i = base + r * 256 + threadIdx.x;
+        if (seg[r] >= 0) order[hist[seg[r]] + rank[r]] = (int32_t)i;
+    }
+}
+
 // one thread per pillar: insertion sort of its (few) point indices
 __global__ __launch_bounds__(256) void csr_sort_segments(const int32_t *__restrict__ seg_offsets, int64_t m,
                                                          int32_t *order)
@@ -66,12 +113,15 @@ extern "C" int pcacc_csr_build(const int32_t *p2v, int64_t n, int64_t m, int32_t
     if (m == 0 || n == 0) return PCACC_OK;
     if (hipMemsetAsync(counts, 0, (size_t)(m + 1) * 4, s) != hipSuccess) return PCACC_E_LAUNCH;
     const int chunks = pcacc_chunks(m);
-    csr_histogram<<<pcacc_grid(n, 256), 256, 0, s>>>(p2v, n, counts);
+    const bool small = m <= CSR_SMALL_M;
+    if (small) csr_histogram_small<<<pcacc_chunks(n), 256, 0, s>>>(p2v, n, (int)m, counts);
+    else csr_histogram<<<pcacc_grid(n, 256), 256, 0, s>>>(p2v, n, counts);
     chunk_sums_i32<<<chunks, 256, 0, s>>>(counts, m, sums);
     scan_chunk_sums<<<1, 1024, 0, s>>>(sums, chunks, nullptr, -1);
     chunk_scan_i32<<<chunks, 256, 0, s>>>(counts, m, sums, seg_offsets, 1);
     if (hipMemsetAsync(counts, 0, (size_t)m * 4, s) != hipSuccess) return PCACC_E_LAUNCH;
-    csr_fill<<<pcacc_grid(n, 256), 256, 0, s>>>(p2v, n, seg_offsets, counts, order);
+    if (small) csr_fill_small<<<pcacc_chunks(n), 256, 0, s>>>(p2v, n, (int)m, seg_offsets, counts, order);
+    else csr_fill<<<pcacc_grid(n, 256), 256, 0, s>>>(p2v, n, seg_offsets, counts, order);
     csr_sort_segments<<<pcacc_grid(m, 256), 256, 0, s>>>(seg_offsets, m, order);
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
@@ -150,13 +200,159 @@ __global__ __launch_bounds__(256) void seg_max_kernel(const float4 *__restrict__
     }
 }
 
-extern "C" int pcacc_segment_max(const float *src, int c, const int32_t *seg_offsets, const int32_t *order, int64_t m,
-                                 float *out, int32_t *arg, void *stream)
+
+// ---------------------------------------------------------------------------------------------------
+// Long segments (n/m large: per-instance poolings of the TubeNet, the offset loss): one lane group per segment
+// would walk tens of thousands of rows serially.  Two levels instead: every segment is cut into pieces of
+// SEG_PIECE rows of the sorted order; level 1 reduces pieces in parallel, level 2 reduces the (contiguous)
+// pieces of each segment.  No atomics; pieces are found by binary search in the scanned piece counts.
+// ---------------------------------------------------------------------------------------------------
+#define SEG_PIECE 64
+
+__global__ __launch_bounds__(256) void seg_piece_counts(const int32_t *__restrict__ seg_offsets, int64_t m, int *pieces)
 {
-    if (m < 0 || c <= 0 || (c % 4) || c > 256) return PCACC_E_ARG;
-    if (m > 0 && (!src || !seg_offsets || !order || !out || !arg)) return PCACC_E_ARG;
+    for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < m; s += (int64_t)gridDim.x * 256) {
+        const int len = seg_offsets[s + 1] - seg_offsets[s];
+        pieces[s] = len > 0 ? (len + SEG_PIECE - 1) / SEG_PIECE : 1;
+    }
+}
+
+__device__ __forceinline__ int piece_segment(const int *__restrict__ piece_off, int m, int p)
+{
+    int lo = 0, hi = m;                        // largest s with piece_off[s] <= p
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (piece_off[mid] <= p) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+template <int LPP, bool IS_MAX>
+__global__ __launch_bounds__(256) void seg_level1(const float4 *__restrict__ src, const int32_t *__restrict__ seg_offsets,
+                                                  const int32_t *__restrict__ order, const int *__restrict__ piece_off, int m,
+                                                  float4 *__restrict__ pval, int4 *__restrict__ parg)
+{
+    const int sub = threadIdx.x % LPP;
+    const int per_block = 256 / LPP;
+    const int n_pieces = piece_off[m];
+    for (int p = blockIdx.x * per_block + threadIdx.x / LPP; p < n_pieces; p += gridDim.x * per_block) {
+        const int s = piece_segment(piece_off, m, p);
+        const int b = seg_offsets[s] + (p - piece_off[s]) * SEG_PIECE;
+        const int e = min(b + SEG_PIECE, seg_offsets[s + 1]);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int4 bi = make_int4(-1, -1, -1, -1);
+        for (int k = b; k < e; ++k) {
+            const int i = order[k];
+            const float4 v = src[(int64_t)i * LPP + sub];
+            if (IS_MAX) {
+                if (bi.x < 0 || v.x > acc.x || (v.x == acc.x && i < bi.x)) { acc.x = v.x; bi.x = i; }
+                if (bi.y < 0 || v.y > acc.y || (v.y == acc.y && i < bi.y)) { acc.y = v.y; bi.y = i; }
+                if (bi.z < 0 || v.z > acc.z || (v.z == acc.z && i < bi.z)) { acc.z = v.z; bi.z = i; }
+                if (bi.w < 0 || v.w > acc.w || (v.w == acc.w && i < bi.w)) { acc.w = v.w; bi.w = i; }
+            } else {
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        }
+        pval[(int64_t)p * LPP + sub] = acc;
+        if (IS_MAX) parg[(int64_t)p * LPP + sub] = bi;
+    }
+}
+
+template <int LPP, bool IS_MAX>
+__global__ __launch_bounds__(256) void seg_level2(const float4 *__restrict__ pval, const int4 *__restrict__ parg,
+                                                  const int *__restrict__ piece_off, int64_t m,
+                                                  float4 *__restrict__ out, int4 *__restrict__ arg)
+{
+    const int sub = threadIdx.x % LPP;
+    const int64_t per_block = 256 / LPP;
+    for (int64_t s = (int64_t)blockIdx.x * per_block + threadIdx.x / LPP; s < m; s += (int64_t)gridDim.x * per_block) {
+        const int b = piece_off[s], e = piece_off[s + 1];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int4 bi = make_int4(-1, -1, -1, -1);
+        for (int p = b; p < e; ++p) {
+            const float4 v = pval[(int64_t)p * LPP + sub];
+            if (IS_MAX) {
+                const int4 a = parg[(int64_t)p * LPP + sub];
+                if (a.x >= 0 && (bi.x < 0 || v.x > acc.x || (v.x == acc.x && a.x < bi.x))) { acc.x = v.x; bi.x = a.x; }
+                if (a.y >= 0 && (bi.y < 0 || v.y > acc.y || (v.y == acc.y && a.y < bi.y))) { acc.y = v.y; bi.y = a.y; }
+                if (a.z >= 0 && (bi.z < 0 || v.z > acc.z || (v.z == acc.z && a.z < bi.z))) { acc.z = v.z; bi.z = a.z; }
+                if (a.w >= 0 && (bi.w < 0 || v.w > acc.w || (v.w == acc.w && a.w < bi.w))) { acc.w = v.w; bi.w = a.w; }
+            } else {
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        }
+        out[s * LPP + sub] = acc;
+        if (IS_MAX) arg[s * LPP + sub] = bi;
+    }
+}
+
+static inline int64_t seg_max_pieces(int64_t n, int64_t m) { return m + n / SEG_PIECE + 1; }
+static inline bool seg_use_two_level(int64_t n, int64_t m) { return m > 0 && n / m > 16; }
+
+extern "C" int pcacc_segment_workspace_bytes(int64_t n, int64_t m, int c, size_t *bytes)
+{
+    if (!bytes || n < 0 || m < 0 || c <= 0) return PCACC_E_ARG;
+    *bytes = 0;
+    if (seg_use_two_level(n, m)) {
+        const size_t P = (size_t)seg_max_pieces(n, m);
+        *bytes = pcacc_align((size_t)(m + 1) * 4) * 2 + pcacc_align((size_t)(pcacc_chunks(m) + 1) * 4) +
+                 pcacc_align(P * c * 4) * 2;
+    }
+    return PCACC_OK;
+}
+
+template <bool IS_MAX>
+static int seg_two_level(const float *src, int c, const int32_t *seg_offsets, const int32_t *order, int64_t n, int64_t m,
+                         float *out, int32_t *arg, void *workspace, size_t workspace_bytes, hipStream_t s)
+{
+    size_t need;
+    pcacc_segment_workspace_bytes(n, m, c, &need);
+    if (!workspace || workspace_bytes < need) return PCACC_E_WORKSPACE;
+    char *ws = static_cast<char *>(workspace);
+    int *pieces = reinterpret_cast<int *>(ws); ws += pcacc_align((size_t)(m + 1) * 4);
+    int *piece_off = reinterpret_cast<int *>(ws); ws += pcacc_align((size_t)(m + 1) * 4);
+    int *sums = reinterpret_cast<int *>(ws); ws += pcacc_align((size_t)(pcacc_chunks(m) + 1) * 4);
+    const size_t P = (size_t)seg_max_pieces(n, m);
+    float4 *pval = reinterpret_cast<float4 *>(ws); ws += pcacc_align(P * c * 4);
+    int4 *parg = reinterpret_cast<int4 *>(ws);
+    const int chunks = pcacc_chunks(m);
+    seg_piece_counts<<<pcacc_grid(m, 256), 256, 0, s>>>(seg_offsets, m, pieces);
+    chunk_sums_i32<<<chunks, 256, 0, s>>>(pieces, m, sums);
+    scan_chunk_sums<<<1, 1024, 0, s>>>(sums, chunks, nullptr, -1);
+    chunk_scan_i32<<<chunks, 256, 0, s>>>(pieces, m, sums, piece_off, 1);
+    const float4 *in4 = reinterpret_cast<const float4 *>(src);
+    float4 *out4 = reinterpret_cast<float4 *>(out);
+    int4 *arg4 = reinterpret_cast<int4 *>(arg);
+#define LAUNCH2(L)                                                                                                   \
+    seg_level1<L, IS_MAX><<<pcacc_grid((int64_t)P * L, 256), 256, 0, s>>>(in4, seg_offsets, order, piece_off, (int)m, pval, parg); \
+    seg_level2<L, IS_MAX><<<pcacc_grid(m * L, 256), 256, 0, s>>>(pval, parg, piece_off, m, out4, arg4)
+    switch (c / 4) {
+        case 1: LAUNCH2(1); break;
+        case 2: LAUNCH2(2); break;
+        case 4: LAUNCH2(4); break;
+        case 8: LAUNCH2(8); break;
+        case 16: LAUNCH2(16); break;
+        case 32: LAUNCH2(32); break;
+        case 64: LAUNCH2(64); break;
+        default: return PCACC_E_ARG;
+    }
+#undef LAUNCH2
+    return PCACC_OK;
+}
+
+extern "C" int pcacc_segment_max(const float *src, int c, const int32_t *seg_offsets, const int32_t *order, int64_t n, int64_t m,
+                                 float *out, int32_t *arg, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (m < 0 || n < 0 || c <= 0 || (c % 4) || c > 256) return PCACC_E_ARG;
+    if (m > 0 && (!seg_offsets || !out || !arg || (n > 0 && (!src || !order)))) return PCACC_E_ARG;
     if (m == 0) return PCACC_OK;
     hipStream_t s = pcacc_stream(stream);
+    if (seg_use_two_level(n, m)) {
+        const int rc = seg_two_level<true>(src, c, seg_offsets, order, n, m, out, arg, workspace, workspace_bytes, s);
+        if (rc != PCACC_OK) return rc;
+        PCACC_CHECK_LAUNCH();
+        return PCACC_OK;
+    }
     const float4 *in4 = reinterpret_cast<const float4 *>(src);
     float4 *out4 = reinterpret_cast<float4 *>(out);
     int4 *arg4 = reinterpret_cast<int4 *>(arg);
@@ -228,13 +424,19 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const float4 *__restrict__
     }
 }
 
-extern "C" int pcacc_segment_sum(const float *src, int c, const int32_t *seg_offsets, const int32_t *order, int64_t m,
-                                 float *out, void *stream)
+extern "C" int pcacc_segment_sum(const float *src, int c, const int32_t *seg_offsets, const int32_t *order, int64_t n, int64_t m,
+                                 float *out, void *workspace, size_t workspace_bytes, void *stream)
 {
-    if (m < 0 || c <= 0 || (c % 4) || c > 256) return PCACC_E_ARG;
-    if (m > 0 && (!src || !seg_offsets || !order || !out)) return PCACC_E_ARG;
+    if (m < 0 || n < 0 || c <= 0 || (c % 4) || c > 256) return PCACC_E_ARG;
+    if (m > 0 && (!seg_offsets || !out || (n > 0 && (!src || !order)))) return PCACC_E_ARG;
     if (m == 0) return PCACC_OK;
     hipStream_t s = pcacc_stream(stream);
+    if (seg_use_two_level(n, m)) {
+        const int rc = seg_two_level<false>(src, c, seg_offsets, order, n, m, out, nullptr, workspace, workspace_bytes, s);
+        if (rc != PCACC_OK) return rc;
+        PCACC_CHECK_LAUNCH();
+        return PCACC_OK;
+    }
     const float4 *in4 = reinterpret_cast<const float4 *>(src);
     float4 *out4 = reinterpret_cast<float4 *>(out);
 #define LAUNCH(L) seg_sum_kernel<L><<<pcacc_grid(m * L, 256), 256, 0, s>>>(in4, seg_offsets, order, m, out4)

@@ -42,7 +42,7 @@ EXPORTS = [
     'pcacc_voxelize_workspace_bytes', 'pcacc_voxelize', 'pcacc_cell_index',
     'pcacc_frame_pillars_workspace_bytes', 'pcacc_frame_pillars',
     'pcacc_csr_workspace_bytes', 'pcacc_csr_build', 'pcacc_segment_mean3_maxlabel',
-    'pcacc_segment_max', 'pcacc_segment_max_backward', 'pcacc_segment_sum',
+    'pcacc_segment_workspace_bytes', 'pcacc_segment_max', 'pcacc_segment_max_backward', 'pcacc_segment_sum',
     'pcacc_pillar_scatter', 'pcacc_gather_rows',
     'pcacc_bilinear_gather', 'pcacc_bilinear_gather_backward', 'pcacc_bev_warp', 'pcacc_rigid_transform',
     'pcacc_chamfer_workspace_bytes', 'pcacc_chamfer_forward', 'pcacc_chamfer_backward',
@@ -159,12 +159,20 @@ def segment_mean3_maxlabel(points, labels, offs, order, m):
     return mean, lab_out
 
 
+def _segment_ws(n, m, c, dev):
+    need = ctypes.c_size_t(0)
+    _check(lib().pcacc_segment_workspace_bytes(_i64(n), _i64(m), int(c), ctypes.byref(need)), 'segment_workspace')
+    return _ws(need.value, dev)
+
+
 def segment_max(src, offs, order, m):
-    c = src.shape[1]
+    n, c = src.shape
     out = torch.empty((m, c), dtype=torch.float32, device=src.device)
     arg = torch.empty((m, c), dtype=torch.int32, device=src.device)
+    ws = _segment_ws(n, m, c, src.device)
     _check(lib().pcacc_segment_max(_dev(src, torch.float32, 'src'), int(c), _dev(offs, torch.int32), _dev(order, torch.int32),
-                                   _i64(m), _dev(out), _dev(arg), _stream()), 'segment_max')
+                                   _i64(n), _i64(m), _dev(out), _dev(arg), _dev(ws), ctypes.c_size_t(ws.numel()), _stream()),
+           'segment_max')
     return out, arg
 
 
@@ -178,11 +186,17 @@ def segment_max_backward(grad_out, arg, p2v, n):
 
 
 def segment_sum(src, offs, order, m):
-    c = src.shape[1]
+    n, c = src.shape
     out = torch.empty((m, c), dtype=torch.float32, device=src.device)
+    ws = _segment_ws(n, m, c, src.device)
     _check(lib().pcacc_segment_sum(_dev(src, torch.float32, 'src'), int(c), _dev(offs, torch.int32), _dev(order, torch.int32),
-                                   _i64(m), _dev(out), _stream()), 'segment_sum')
+                                   _i64(n), _i64(m), _dev(out), _dev(ws), ctypes.c_size_t(ws.numel()), _stream()), 'segment_sum')
     return out
+
+
+# bench.py sets this to a list to time the dominant kernel live: (start, end, n_cells, c, m, dtype) per launch,
+# HIP events recorded on the stream the kernel is launched on, only for canvases of >= 32 channels.
+scatter_timer = None
 
 
 def pillar_scatter(feats, cell2pillar, out_dtype=torch.float32):
@@ -190,8 +204,15 @@ def pillar_scatter(feats, cell2pillar, out_dtype=torch.float32):
     c = feats.shape[1]
     n_cells = cell2pillar.numel()
     canvas = torch.empty((n_cells, c), dtype=out_dtype, device=feats.device)
+    timed = scatter_timer is not None and c >= 32
+    if timed:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     _check(lib().pcacc_pillar_scatter(_dev(feats, torch.float32, 'feats'), _dev(cell2pillar, torch.int32), _i64(n_cells),
                                       int(c), _dev(canvas), _dtype_code(canvas), _stream()), 'pillar_scatter')
+    if timed:
+        ev1.record()
+        scatter_timer.append((ev0, ev1, n_cells, c, feats.shape[0], out_dtype))
     return canvas
 
 

@@ -181,15 +181,62 @@ def gather_rows(src2d, idx):
     return native.gather_rows(src2d.contiguous(), idx.to(torch.int32).contiguous())
 
 
-def scatter(src, index, dim=0, dim_size=None, reduce='sum'):
-    """torch_scatter.scatter as used by the per-instance TubeNet (models/tpointnet.py:227-284,
-    models/alignnet.py:133-134, libs/loss.py:216): tiny K*T-row outputs, plain PyTorch-ROCm
-    (SURVEY.md section 2 row 8).  Empty segments are 0."""
-    assert dim == 0
-    index = index.long()
-    n = int(dim_size) if dim_size is not None else (int(index.max()) + 1 if index.numel() else 0)
-    red = {'sum': 'sum', 'mean': 'mean', 'max': 'amax'}[reduce]
-    shape = (n,) + tuple(src.shape[1:])
-    idx = index.view((-1,) + (1,) * (src.dim() - 1)).expand_as(src)
-    out = torch.zeros(shape, dtype=src.dtype, device=src.device)
-    return out.scatter_reduce(0, idx, src, red, include_self=False)
+class ScatterPlan(object):
+    """CSR of an index vector, reusable across several scatter() calls with the same index."""
+
+    def __init__(self, index, dim_size=None):
+        idx = index.reshape(-1)
+        self.m = int(dim_size) if dim_size is not None else (int(idx.max()) + 1 if idx.numel() else 0)
+        self.p2v = idx.to(torch.int32).contiguous()
+        self.n = int(self.p2v.shape[0])
+        self.seg_offsets, self.order = native.csr_build(self.p2v, self.m)
+        self._count = None
+
+    def count(self):
+        if self._count is None:
+            self._count = (self.seg_offsets[1:] - self.seg_offsets[:-1]).to(torch.float32)
+        return self._count
+
+
+class _SegmentSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, plan):
+        ctx.plan = plan
+        return native.segment_sum(src, plan.seg_offsets, plan.order, plan.m)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return native.gather_rows(grad.contiguous(), ctx.plan.p2v), None
+
+
+def _pad4(x):
+    """[N,C] f32 with C padded up to a multiple of 4 (the segment kernels move float4)."""
+    c = x.shape[1]
+    pad = (-c) % 4
+    if pad:
+        x = torch.nn.functional.pad(x, (0, pad))
+    return x.contiguous(), c
+
+
+def scatter(src, index, dim=0, dim_size=None, reduce='sum', plan=None):
+    """torch_scatter.scatter(src, index, dim=0, dim_size, reduce) as the per-instance TubeNet and the offset
+    loss use it (models/tpointnet.py:227-284, models/alignnet.py:133-134, libs/loss.py:216): few output rows
+    (K*T ~ 100), many inputs per row.  torch's scatter_reduce resolves that with one atomic per element, which on
+    ROCm is a compare-and-swap loop for fp64 add and float max -- minutes at 800 k points on 21 rows.  Here the
+    index is sorted once into a CSR (ScatterPlan) and each reduction is an atomic-free segmented loop.
+    Values are reduced in fp32 and returned in src's dtype; empty segments are 0; 'max' routes the gradient to
+    the lowest index attaining the maximum."""
+    assert dim == 0 and reduce in ('sum', 'mean', 'max')
+    if plan is None:
+        plan = ScatterPlan(index, dim_size)
+    shape_tail = tuple(src.shape[1:])
+    x = src.reshape(src.shape[0], -1)
+    x32, c = _pad4(x.to(torch.float32))
+    if reduce == 'max':
+        out = _SegmentMax.apply(x32, plan)[0]
+    else:
+        out = _SegmentSum.apply(x32, plan)
+        if reduce == 'mean':
+            out = out / plan.count().clamp(min=1.0)[:, None]
+    out = out[:, :c].reshape((plan.m,) + shape_tail)
+    return out.to(src.dtype) if out.dtype != src.dtype else out

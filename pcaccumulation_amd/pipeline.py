@@ -1,0 +1,49 @@
+"""Device-side data step in front of MotionNet: prep_input's voxelisation (libs/dataset.py:183-199) and
+collate_fn (libs/dataloader.py:7-40) for samples that already live in HBM.
+
+Produces exactly the input_dict layout the reference's collate_fn produces (same keys, shapes and dtypes,
+see SURVEY.md 8b) so the model boundary does not change; only the voxeliser runs in the HIP kernel instead
+of numba on a DataLoader worker.
+"""
+import torch
+
+from .voxel_generator import Voxelization
+
+
+def sample_to_device(sample, device):
+    """numpy sample dict (pcaccumulation_amd.synthetic.make_sequence) -> torch tensors on `device`."""
+    out = {}
+    for k, v in sample.items():
+        out[k] = torch.from_numpy(v).to(device) if k != 'inst_motion_gt' else torch.from_numpy(v)
+    return out
+
+
+class DeviceBatcher(object):
+    def __init__(self, cfg):
+        self.voxeliser = Voxelization(cfg['voxel_generator'])
+
+    def __call__(self, samples):
+        vox = self.voxeliser
+        dev = samples[0]['input_points'].device
+        coords, p2vs, tis, n_vox = [], [], [], []
+        offset = 0
+        for b, s in enumerate(samples):
+            t = s['time_indice']
+            pts4 = torch.cat((s['input_points'].float(), t.float()), dim=1)
+            c, p2v, m = vox.voxelize_device(pts4)
+            bcol = torch.full((m, 1), float(b), dtype=torch.float64, device=dev)
+            coords.append(torch.cat((bcol, c.double()), dim=1))
+            tis.append(torch.cat((torch.full((t.shape[0], 1), float(b), dtype=torch.float64, device=dev), t.double()), dim=1))
+            p2vs.append((p2v + offset)[:, None])
+            n_vox.append(m)
+            offset += m
+        cat = lambda key: torch.cat([s[key] for s in samples], dim=0)
+        grid = torch.tensor(list(vox.grid_size) + [vox.n_sweeps], dtype=torch.int64)
+        return {
+            'input_points': cat('input_points'), 'num_points': cat('num_points'), 'time_indice': torch.cat(tis, 0),
+            'sd_labels': cat('sd_labels'), 'inst_labels': cat('inst_labels'), 'fb_labels': cat('fb_labels'),
+            'ego_motion_gt': torch.stack([s['ego_motion_gt'] for s in samples], 0),
+            'inst_motion_gt': [s['inst_motion_gt'] for s in samples],
+            'coordinates': torch.cat(coords, 0), 'num_voxels': torch.tensor(n_vox, dtype=torch.int64, device=dev),
+            'shape': grid[None].repeat(len(samples), 1).to(dev), 'point_to_voxel_map': torch.cat(p2vs, 0),
+        }

@@ -2,6 +2,7 @@
 `down_convs`, `up_convs`, `positional_encoding.{0,2}`, `final_proj.0`, `mos_seg`, `offset_head`)."""
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import ops
 from .unet import DownConv, UpConv, SegHead1D
@@ -42,10 +43,31 @@ class STPN(nn.Module):
         offset = torch.where(torch.isinf(offset), torch.zeros_like(offset), offset)
         return torch.clamp(offset, min, max)
 
+    def temporal_convs(self, x):
+        """The four Conv3d(3x3x3)+ReLU of models/stpn.py:13-22 and the max over T (:83), evaluated as 2-D
+        convolutions: out[t] = sum_kt W[:, :, kt] * in[t + kt - 1], i.e. a 3x3 Conv2d over the channel-stacked
+        frames (t-1, t, t+1) with the Conv3d weight viewed as [O, 3*C, 3, 3].  Same parameters (`init_conv.{0,2,4,6}`
+        keep their Conv3d shapes in the state_dict), same arithmetic up to summation order; what changes is that
+        the work lands on the channels-last implicit-GEMM conv kernels instead of the batched-GEMM Conv3d
+        backward-weights path, which took 48 ms per layer on MI355X (profiles/r01_*)."""
+        B, C, T, H, W = x.shape
+        rows = x.permute(0, 2, 3, 4, 1).contiguous()                               # [B,T,H,W,C]; free for warp output
+        for layer in self.init_conv:
+            if not isinstance(layer, nn.Conv3d):
+                continue
+            prev = F.pad(rows[:, :-1], (0, 0, 0, 0, 0, 0, 1, 0))                      # frame t-1 (zeros before frame 0)
+            nxt = F.pad(rows[:, 1:], (0, 0, 0, 0, 0, 0, 0, 1))                        # frame t+1 (zeros after the last)
+            stacked = torch.cat([prev, rows, nxt], dim=-1)                             # [B,T,H,W,3C]
+            cin = layer.in_channels
+            w2 = layer.weight.permute(0, 2, 1, 3, 4).reshape(layer.out_channels, 3 * cin, 3, 3)
+            y = F.conv2d(stacked.view(B * T, H, W, 3 * cin).permute(0, 3, 1, 2), w2, layer.bias, padding=1)
+            y = F.relu(y)
+            rows = y.permute(0, 2, 3, 1).contiguous().view(B, T, H, W, layer.out_channels)
+        return rows.max(dim=1)[0].permute(0, 3, 1, 2)                                  # [B,C,H,W], channels_last
+
     def backbone(self, x):
-        """[B, C, T, H, W] -> [B, 64, H, W]: Conv3d stack, max over T, U-Net (models/stpn.py:82-92)."""
-        x = self.init_conv(x)
-        x = torch.max(x, dim=2)[0]
+        """[B, C, T, H, W] -> [B, 64, H, W]: temporal conv stack, max over T, U-Net (models/stpn.py:82-92)."""
+        x = self.temporal_convs(x)
         skips = []
         for module in self.down_convs:
             x, before_pool = module(x)

@@ -11,7 +11,7 @@ import torch.nn.functional as F
 from scipy.spatial.transform import Rotation as R
 
 from .chamfer_distance import ChamferDistance
-from .ops import scatter
+from .ops import scatter, ScatterPlan
 
 _EPS = 1e-20
 
@@ -144,25 +144,27 @@ class TPointNet(BaseModel):
         K, T, _, _ = inst_motion_gt.size()
         device = mos_feat.device
         frame_indice = (inst_indice * T + time_indice).long()
+        per_frame = ScatterPlan(frame_indice, K * T)        # one CSR per index vector, shared by the poolings below
+        per_inst = ScatterPlan(inst_indice, K)
 
         # 1. per (instance, frame) weights: enough points, moving, later frames count more (tpointnet.py:223-237)
         count = torch.ones(frame_indice.size(0), device=device)
-        frame_count = scatter(count, frame_indice, dim=0, dim_size=K * T, reduce='sum')
+        frame_count = scatter(count, frame_indice, dim=0, dim_size=K * T, reduce='sum', plan=per_frame)
         frame_weights = (frame_count > self.min_points_per_frame).float()
-        inst_mos_label = scatter(mos_labels, frame_indice, dim=0, dim_size=K * T, reduce='max')
+        inst_mos_label = scatter(mos_labels, frame_indice, dim=0, dim_size=K * T, reduce='max', plan=per_frame)
         mos_weights = torch.ones_like(inst_mos_label)
         mos_weights[inst_mos_label == 0] = 0.2
         temporal_weights = (torch.arange(self.n_frames) + 1).to(device).repeat(K) / self.n_frames
         frame_weights = frame_weights * mos_weights * temporal_weights
 
         # 2. pooled embeddings (tpointnet.py:240-262)
-        mos_embedding = scatter(self.motion_embed(mos_feat), inst_indice, dim=0, dim_size=K, reduce='max')
-        geo_embedding = scatter(self.geo_embed(frame_feats), inst_indice, dim=0, dim_size=K, reduce='max')
-        frame_centroid = scatter(points, frame_indice, dim=0, dim_size=K * T, reduce='mean')
+        mos_embedding = scatter(self.motion_embed(mos_feat), inst_indice, dim=0, dim_size=K, reduce='max', plan=per_inst)
+        geo_embedding = scatter(self.geo_embed(frame_feats), inst_indice, dim=0, dim_size=K, reduce='max', plan=per_inst)
+        frame_centroid = scatter(points, frame_indice, dim=0, dim_size=K * T, reduce='mean', plan=per_frame)
         inst_centroid = frame_centroid[::T]
         centered_points = points - inst_centroid[inst_indice]
         frame_input = torch.cat((centered_points, time_indice.unsqueeze(-1) / T), dim=1).float()
-        frame_embedding = scatter(self.pos_embed(frame_input), frame_indice, dim=0, dim_size=K * T, reduce='max')
+        frame_embedding = scatter(self.pos_embed(frame_input), frame_indice, dim=0, dim_size=K * T, reduce='max', plan=per_frame)
 
         # 3. regress one pose per (instance, frame) (tpointnet.py:264-273)
         anchor_embedding = frame_embedding[::T].repeat_interleave(T, 0)
@@ -178,8 +180,8 @@ class TPointNet(BaseModel):
         diff = rec_est - rec_gt
         l1_loss = torch.norm(diff, p=2, dim=1)
         l2_loss = torch.norm(diff, p=1, dim=1)
-        frame_l1 = scatter(l1_loss, frame_indice, dim=0, dim_size=K * T, reduce='mean')
-        frame_l2 = scatter(l2_loss, frame_indice, dim=0, dim_size=K * T, reduce='mean')
+        frame_l1 = scatter(l1_loss, frame_indice, dim=0, dim_size=K * T, reduce='mean', plan=per_frame)
+        frame_l2 = scatter(l2_loss, frame_indice, dim=0, dim_size=K * T, reduce='mean', plan=per_frame)
         l1_loss = (frame_l1 * frame_weights).sum() / (frame_weights.sum() + _EPS)
         l2_loss = (frame_l2 * frame_weights).sum() / (frame_weights.sum() + _EPS)
         rot_loss, trans_loss = evaluate_pose(pose_est_rep, pose_gt_rep, frame_weights)

@@ -319,3 +319,25 @@ def test_chamfer_full_size_properties(native, dev):
     sub = x1[:, :256].cpu().numpy()
     r1, _, j1, _ = oracle.chamfer_forward(sub, x3.cpu().numpy())
     assert np.array_equal(i1[:, :256].cpu().numpy(), j1) and np.array_equal(d1[:, :256].cpu().numpy(), r1)
+
+
+# ---------------------------------------------------------------- TubeNet / loss poolings (few rows, many inputs)
+@pytest.mark.parametrize('c,k', [(1, 21), (3, 105), (128, 105)])
+def test_scatter_matches_torch_scatter_reduce(native, dev, c, k):
+    from pcaccumulation_amd import ops
+    rng = np.random.RandomState(c + k)
+    n = 20000
+    idx = torch.from_numpy(rng.randint(0, k - 2, n))                       # the last two rows stay empty
+    src = torch.from_numpy(rng.randn(n, c).astype(np.float32))
+    for reduce, tred in (('sum', 'sum'), ('mean', 'mean'), ('max', 'amax')):
+        a = src.clone().to(dev).requires_grad_(True)
+        out = ops.scatter(a if c > 1 else a[:, 0], idx.to(dev), dim=0, dim_size=k, reduce=reduce)
+        b = src.clone().requires_grad_(True)
+        ref = torch.zeros(k, c).scatter_reduce(0, idx[:, None].expand(n, c), b, tred, include_self=False)
+        got = out.detach().cpu().reshape(k, c)
+        np.testing.assert_allclose(got.numpy(), ref.detach().numpy(), rtol=1e-4, atol=1e-4)
+        assert float(got[k - 2:].abs().sum()) == 0.0
+        w = torch.from_numpy(rng.randn(k, c).astype(np.float32))
+        (out.reshape(k, c) * w.to(dev)).sum().backward()
+        (ref * w).sum().backward()
+        np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.numpy(), rtol=1e-4, atol=1e-5)

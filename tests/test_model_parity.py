@@ -3,7 +3,7 @@ on the same seeded inputs and closed-form weights.
 
 Two legs share one body:
   * `-m "not gpu"`: host logic only -- pcaccumulation_amd.native is replaced by the oracle-backed test double
-    (tests/native_double.py) so that module wiring, layouts, autograd wrappers and result keys are checked here;
+    (oracle/cpu_backend.py) so that module wiring, layouts, autograd wrappers and result keys are checked here;
   * `-m gpu`: the real HIP library on cuda:0, fp32 compute, then bf16 compute with tolerances on metrics only.
 Tolerance from BASELINE.json's north_star: metrics (mos_iou, ego rot/trans error, scene-flow EPE) within 1e-3;
 integer outputs bit-exact."""
@@ -134,8 +134,8 @@ def _assert_tiny_train(g, model, out, stats, rtol):
 # ------------------------------------------------------------------------------------------------ CPU leg
 @pytest.fixture
 def double(monkeypatch):
-    import native_double
-    native_double.install(monkeypatch)
+    from oracle import cpu_backend
+    cpu_backend.install(monkeypatch)
     return torch.device('cpu')
 
 
