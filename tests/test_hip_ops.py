@@ -341,3 +341,17 @@ def test_scatter_matches_torch_scatter_reduce(native, dev, c, k):
         (out.reshape(k, c) * w.to(dev)).sum().backward()
         (ref * w).sum().backward()
         np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_chamfer_golden_from_reference_cpp(native, dev, golden):
+    g = golden('chamfer')
+    x1, x2 = torch.from_numpy(g['xyz1']).to(dev), torch.from_numpy(g['xyz2']).to(dev)
+    d1, d2, i1, i2 = native.chamfer_forward(x1, x2)
+    assert np.array_equal(i1.cpu().numpy(), g['idx1']) and np.array_equal(i2.cpu().numpy(), g['idx2'])
+    assert np.array_equal(d1.cpu().numpy(), g['dist1']) and np.array_equal(d2.cpu().numpy(), g['dist2'])
+    from pcaccumulation_amd.chamfer_distance import ChamferDistance
+    a, b = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+    o1, o2 = ChamferDistance()(a, b)
+    ((o1 * torch.from_numpy(g['grad_dist1']).to(dev)).sum() + (o2 * torch.from_numpy(g['grad_dist2']).to(dev)).sum()).backward()
+    np.testing.assert_allclose(a.grad.cpu().numpy(), g['grad_xyz1'], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(b.grad.cpu().numpy(), g['grad_xyz2'], rtol=1e-4, atol=1e-4)

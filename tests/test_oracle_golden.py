@@ -159,3 +159,29 @@ def test_metrics(golden):
     s = oracle.compute_iou(g['pred'], g['gt'])
     for k in ('intersection', 'union', 'pred_positives', 'gt_positives'):
         np.testing.assert_allclose(s[k], g[k], rtol=0, atol=1e-12)
+
+
+def test_chamfer_against_reference_cpu_path(golden):
+    """tests/golden/chamfer.npz was produced by the reference's own chamfer_distance.cpp (oracle/_ref)."""
+    g = golden('chamfer')
+    d1, d2, i1, i2 = oracle.chamfer_forward(g['xyz1'], g['xyz2'])
+    assert np.array_equal(i1, g['idx1']) and np.array_equal(i2, g['idx2'])
+    assert np.array_equal(d1, g['dist1']) and np.array_equal(d2, g['dist2'])
+    assert (g['idx1'][:, 0] == 4).all()                      # tie rule: lowest index among equal minima
+    g1, g2 = oracle.chamfer_backward(g['xyz1'], g['xyz2'], g['grad_dist1'], g['grad_dist2'], i1, i2)
+    assert np.array_equal(g1, g['grad_xyz1']) and np.array_equal(g2, g['grad_xyz2'])
+
+
+def test_chamfer_against_live_reference_build_when_present():
+    from oracle import ref_chamfer
+    if not ref_chamfer.available():
+        import pytest
+        pytest.skip('oracle/_ref not built (needs /root/reference; `make -C oracle ref`)')
+    import torch
+    rng = np.random.RandomState(3)
+    a = rng.randn(1, 257, 3).astype(np.float32)
+    b = rng.randn(1, 1025, 3).astype(np.float32)
+    ref = ref_chamfer.forward(torch.from_numpy(a), torch.from_numpy(b))
+    got = oracle.chamfer_forward(a, b)
+    for r, o in zip(ref, got):
+        assert np.array_equal(r.numpy(), o)
