@@ -141,33 +141,71 @@ class EgoMotionHead(nn.Module):
 
     def sequence_pose_est_skip(self, points_list, feats_list, bg_mask_list, c_ego_motion_gt, T, perm_matrix_list,
                                relative_pose_est_list, relative_pose_gt_list, chained_pose_est_list, chained_pose_gt_list):
-        """models/egomotion.py:309-357: every frame t >= 1 is registered against the anchor frame 0."""
-        anchor_mask = bg_mask_list[0]
-        anchor_points_est = points_list[0][anchor_mask]
-        anchor_feats = feats_list[0][anchor_mask]
-        identity = torch.eye(4, device=feats_list[0].device)
-        for lst in (relative_pose_est_list, relative_pose_gt_list, chained_pose_est_list, chained_pose_gt_list):
-            lst.append(identity)
-        total_l1, total_l2 = 0, 0
-        for frame_idx in range(T - 1):
-            ref_idx = frame_idx + 1
-            ref_points, ref_feats = points_list[ref_idx], feats_list[ref_idx]
-            mask = bg_mask_list[ref_idx]
-            duration = (frame_idx + 1) / self.frequence
-            pose_est, perm_matrix = self.pairwise_ego_motion_estimation(ref_feats[mask], anchor_feats, ref_points[mask],
-                                                                        anchor_points_est, duration)
-            pose_gt = get_relative_pose_torch(c_ego_motion_gt[ref_idx], c_ego_motion_gt[0], self.dataset)
-            perm_matrix_list.append(perm_matrix)
-            chained_pose_est_list.append(pose_est)
-            chained_pose_gt_list.append(pose_gt)
-            hom = torch.cat([ref_points, torch.ones((ref_points.size(0), 1), device=ref_points.device)], dim=1)
-            pc_est = (pose_est @ hom.T).T[:, :3]
-            pc_gt = (pose_gt @ hom.T).T[:, :3]
-            total_l1 = total_l1 + torch.norm(pc_est - pc_gt, p=1, dim=1).mean()
-            total_l2 = total_l2 + torch.norm(pc_est - pc_gt, p=2, dim=1).mean()
-            relative_pose_gt_list.append(get_relative_pose_torch(c_ego_motion_gt[ref_idx], c_ego_motion_gt[ref_idx - 1], self.dataset))
-            relative_pose_est_list.append(get_relative_pose_torch(chained_pose_est_list[-1], chained_pose_est_list[-2], self.dataset))
-        return total_l1, total_l2, T - 1
+        """models/egomotion.py:309-357 for ONE batch element: every frame t >= 1 is registered against the anchor
+        frame 0.  Kept with the reference's signature; it runs the batched estimator on this element's pairs."""
+        l1, l2, n = self._estimate_pairs([(points_list, feats_list, bg_mask_list, c_ego_motion_gt)], T, perm_matrix_list,
+                                         relative_pose_est_list, relative_pose_gt_list, chained_pose_est_list,
+                                         chained_pose_gt_list)
+        return l1, l2, n
+
+    def _estimate_pairs(self, sequences, T, perm_matrix_list, relative_pose_est_list, relative_pose_gt_list,
+                        chained_pose_est_list, chained_pose_gt_list):
+        """All (T-1) registrations of all batch elements in ONE batched Sinkhorn / Kabsch evaluation
+        ([P,1024,1024] instead of P sequential [1,1024,1024] problems: the reference issues ~60 tiny launches and
+        several host syncs per pair).  Key points are still drawn pair by pair on the host
+        generator in the reference's order (source, then target), so a given torch.manual_seed gives the same draw."""
+        dev = sequences[0][1][0].device
+        fs, cs, ft, ct, durations = [], [], [], [], []
+        for points_list, feats_list, bg_mask_list, _ in sequences:
+            anchor_mask = bg_mask_list[0]
+            anchor_points, anchor_feats = points_list[0][anchor_mask], feats_list[0][anchor_mask]
+            for frame_idx in range(T - 1):
+                ref = frame_idx + 1
+                mask = bg_mask_list[ref]
+                ref_feats, ref_points = feats_list[ref][mask], points_list[ref][mask]
+                choice_s = self._choice(ref_feats.size(0)).to(dev)          # models/egomotion.py:156-166, same order
+                choice_t = self._choice(anchor_feats.size(0)).to(dev)
+                fs.append(ref_feats[choice_s]); cs.append(ref_points[choice_s])
+                ft.append(anchor_feats[choice_t]); ct.append(anchor_points[choice_t])
+                durations.append((frame_idx + 1) / self.frequence)
+        feats_s, coor_s = torch.stack(fs), torch.stack(cs)                  # [P,k,C], [P,k,3]
+        feats_t, coor_t = torch.stack(ft), torch.stack(ct)
+        thr2 = (torch.tensor(durations, device=dev, dtype=torch.float32) * self.ego_max_speed) ** 2
+        support = (square_distance(coor_s, coor_t, normalised=False) < thr2[:, None, None]).float()     # :173-174
+        feat_dist = square_distance(feats_s, feats_t, normalised=True)                                   # :177
+        affinity = -(feat_dist - self.softplus(self.alpha)) / (torch.exp(self.beta) + 0.02)              # :180
+        perm = torch.exp(self.sinkhorn(affinity, n_iters=self.sinkhorn_iter, slack=self.slack)) * support
+        rowsum = torch.sum(perm, dim=2, keepdim=True)
+        weighted_t = perm @ coor_t / (rowsum + _EPS)
+        R_est, t_est, _, _ = kabsch_transformation_estimation(coor_s, weighted_t, weights=rowsum[:, :, 0])
+        P = R_est.shape[0]
+        pose_est = torch.eye(4, device=dev, dtype=t_est.dtype).repeat(P, 1, 1)
+        pose_est[:, :3, :3] = R_est
+        pose_est[:, :3, 3] = t_est[:, :, 0]
+
+        identity = torch.eye(4, device=dev)
+        total_l1, total_l2, p = 0, 0, 0
+        for points_list, feats_list, bg_mask_list, gt in sequences:
+            for lst in (relative_pose_est_list, relative_pose_gt_list, chained_pose_est_list, chained_pose_gt_list):
+                lst.append(identity)
+            # T_anchor^-1 @ T_ref for all frames at once (get_relative_pose_torch, register_utils.py:184-197)
+            pose_gt_all = get_relative_pose_torch(gt[1:], gt[0:1].expand(T - 1, 4, 4), self.dataset)
+            rel_gt_all = get_relative_pose_torch(gt[1:], gt[:-1], self.dataset)
+            chain = [identity] + [pose_est[p + i] for i in range(T - 1)]
+            rel_est_all = get_relative_pose_torch(torch.stack(chain[1:]), torch.stack(chain[:-1]), self.dataset)
+            for frame_idx in range(T - 1):
+                ref_points = points_list[frame_idx + 1]
+                pe, pg = pose_est[p + frame_idx], pose_gt_all[frame_idx]
+                perm_matrix_list.append(perm[p + frame_idx:p + frame_idx + 1])
+                chained_pose_est_list.append(pe)
+                chained_pose_gt_list.append(pg)
+                diff = ref_points @ (pe[:3, :3] - pg[:3, :3]).T + (pe[:3, 3] - pg[:3, 3])      # pc_est - pc_gt (:342-346)
+                total_l1 = total_l1 + torch.norm(diff, p=1, dim=1).mean()
+                total_l2 = total_l2 + torch.norm(diff, p=2, dim=1).mean()
+                relative_pose_gt_list.append(rel_gt_all[frame_idx])
+                relative_pose_est_list.append(rel_est_all[frame_idx])
+            p += T - 1
+        return total_l1, total_l2, P
 
     def _finish(self, B, T, total_l1, total_l2, count, perm_matrix_list, chained_pose_est_list, chained_pose_gt_list, results):
         """models/egomotion.py:448-469."""
@@ -195,8 +233,8 @@ class EgoMotionHead(nn.Module):
         offs = frame_offsets.cpu().tolist()                             # the one host sync for the frame sizes
         sp = sorted_pillars.long()
         cells = pidx.cell.long()
-        total_l1, total_l2, count = 0, 0, 0
         perm_l, rel_est, rel_gt, ch_est, ch_gt = [], [], [], [], []
+        sequences = []
         for b in range(B):
             points_list, feats_list, bg_list = [], [], []
             for t in range(T):
@@ -204,16 +242,15 @@ class EgoMotionHead(nn.Module):
                 points_list.append(pillar_mean[ids])
                 feats_list.append(geo_rows[cells[ids]])
                 bg_list.append(fb_est_pillar[ids] == 0)
-            l1, l2, c = self.sequence_pose_est_skip(points_list, feats_list, bg_list, ego_motion_gt[b], T, perm_l, rel_est,
-                                                    rel_gt, ch_est, ch_gt)
-            total_l1, total_l2, count = total_l1 + l1, total_l2 + l2, count + c
+            sequences.append((points_list, feats_list, bg_list, ego_motion_gt[b]))
+        total_l1, total_l2, count = self._estimate_pairs(sequences, T, perm_l, rel_est, rel_gt, ch_est, ch_gt)
         self._finish(B, T, total_l1, total_l2, count, perm_l, ch_est, ch_gt, results)
 
     def forward(self, bev_feats, fb_est, occ_map, pts_mean_map, ego_motion_gt, input_points, fb_est_per_point, time_indice, results):
         """Reference signature (models/egomotion.py:387-469): dense [B,T,C,Ny,Nx] maps in, results dict filled."""
         B, T, C, Ny, Nx = bev_feats.size()
-        total_l1, total_l2, count = 0, 0, 0
         perm_l, rel_est, rel_gt, ch_est, ch_gt = [], [], [], [], []
+        sequences = []
         for b in range(B):
             points_list, feats_list, bg_list = [], [], []
             for t in range(T):
@@ -221,7 +258,6 @@ class EgoMotionHead(nn.Module):
                 points_list.append(pts_mean_map[b, t].permute(1, 2, 0).reshape(Ny * Nx, 3)[occ])
                 feats_list.append(bev_feats[b, t].permute(1, 2, 0).reshape(Ny * Nx, C)[occ])
                 bg_list.append((fb_est[b, t, 0].reshape(-1) == 0)[occ])
-            l1, l2, c = self.sequence_pose_est_skip(points_list, feats_list, bg_list, ego_motion_gt[b], T, perm_l, rel_est,
-                                                    rel_gt, ch_est, ch_gt)
-            total_l1, total_l2, count = total_l1 + l1, total_l2 + l2, count + c
+            sequences.append((points_list, feats_list, bg_list, ego_motion_gt[b]))
+        total_l1, total_l2, count = self._estimate_pairs(sequences, T, perm_l, rel_est, rel_gt, ch_est, ch_gt)
         self._finish(B, T, total_l1, total_l2, count, perm_l, ch_est, ch_gt, results)
