@@ -111,6 +111,24 @@ int pcacc_segment_sum(const float *src, int c, const int32_t *seg_offsets, const
                       float *out, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * A4 (MLP part). Per-point linear layers: nn.Linear applied to 10^5..10^6 rows with <= 128 features, as the pillar
+ * encoder (models/pillar_encoder.py:46-55, 112-121), the STPN point heads (models/stpn.py:94-102) and the TubeNet
+ * embeddings (models/tpointnet.py:170-193) use them.  One HBM pass per layer.
+ *   y[r,:] = post( pre(x[r,:]) @ w^T + bias + residual[r,:] )
+ *   x [rows,k] f32, k in {2,3,4,9,32,64,128}; w [n,k] f32, n <= 128; bias [n] or NULL; residual [rows,n] or NULL
+ *   flags: 1 = ReLU on x at load, 2 = ReLU on y before the store
+ *   in_mask [rows,k] or NULL: x is zeroed where in_mask <= 0;  out_mask [rows,n] or NULL: y is zeroed where out_mask <= 0
+ * The backward-data pass is the same entry point with w transposed, the forward output as in_mask (post-ReLU layers)
+ * and the forward input as out_mask (pre-ReLU layers).
+ * pcacc_rows_wgrad: dw_aug [n, k+1] f32 = dYeff^T @ [Xeff | 1] (column k is the bias gradient), fp32 MFMA;
+ *   dy [rows,n], dy_mask [rows,n] or NULL (dY zeroed where dy_mask <= 0), x [rows,k], x_relu: ReLU on x at load.
+ * ---------------------------------------------------------------------------------------------- */
+int pcacc_rows_linear(const float *x, const float *in_mask, const float *w, const float *bias, const float *residual,
+                      const float *out_mask, float *y, int64_t rows, int k, int n, int flags, void *stream);
+int pcacc_rows_wgrad(const float *dy, const float *dy_mask, const float *x, int x_relu, int64_t rows, int k, int n,
+                     float *dw_aug, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * A5. Pillar scatter into the BEV canvas -- models/pillar_encoder.py:125-174 (scatter_point_pillar).
  * One pass writes every canvas element exactly once (feature row or zeros), so there is no separate
  * zero-fill: canvas[cell, :] = cell2pillar[cell] >= 0 ? feats[cell2pillar[cell], :] : 0.

@@ -150,9 +150,35 @@ def chamfer_backward(xyz1, xyz2, gd1, gd2, i1, i2):
     return tuple(torch.from_numpy(a) for a in oracle.chamfer_backward(_np(xyz1), _np(xyz2), _np(gd1), _np(gd2), _np(i1), _np(i2)))
 
 
+def rows_linear_supported(k, n):
+    return k in (2, 3, 4, 9, 32, 64, 128) and 1 <= n <= 128
+
+
+def rows_linear(x, w, bias=None, residual=None, pre_relu=False, post_relu=False, in_mask=None, out_mask=None):
+    h = torch.relu(x) if pre_relu else x
+    if in_mask is not None:
+        h = h * (in_mask > 0)
+    y = torch.nn.functional.linear(h, w, bias)
+    if residual is not None:
+        y = y + residual
+    if post_relu:
+        y = torch.relu(y)
+    if out_mask is not None:
+        y = y * (out_mask > 0)
+    return y
+
+
+def rows_wgrad(dy, x, dy_mask=None, x_relu=False):
+    g = dy * (dy_mask > 0) if dy_mask is not None else dy
+    h = torch.relu(x) if x_relu else x
+    aug = torch.cat([h, torch.ones(h.shape[0], 1)], dim=1)
+    return g.t() @ aug
+
+
 NAMES = ['voxelize', 'cell_index', 'frame_pillars', 'csr_build', 'segment_mean3_maxlabel', 'segment_max',
          'segment_max_backward', 'segment_sum', 'pillar_scatter', 'gather_rows', 'bilinear_gather',
-         'bilinear_gather_backward', 'bev_warp', 'rigid_transform', 'chamfer_forward', 'chamfer_backward']
+         'bilinear_gather_backward', 'bev_warp', 'rigid_transform', 'chamfer_forward', 'chamfer_backward',
+         'rows_linear', 'rows_wgrad', 'rows_linear_supported']
 
 
 def install(monkeypatch=None):

@@ -1,0 +1,208 @@
+// Per-point linear layers ("rows x skinny weight") at HBM speed  (SURVEY.md 8a row A4 and the per-point heads of A10).
+//
+// The pillar encoder, the STPN point heads and the TubeNet embeddings are nn.Linear layers applied to 10^5..10^6 rows with
+// 3..128 input and 2..128 output features (models/pillar_encoder.py:112-121, models/stpn.py:94-102).  As library GEMMs these
+// skinny shapes ran at 0.5 TB/s (hipBLASLt, 0.6-1.1 ms per call, 39 ms per training step, profiles/r01_bench_v2).  They are
+// HBM-bound streams: read a row, multiply by a weight matrix that fits in the scalar cache, write a row.
+//
+//   rows_linear  : Y = [relu]( [relu|mask](X) @ W^T + b [+ residual] ) [masked]      -- forward AND backward-data (W^T passed in)
+//   rows_wgrad   : dW_aug[N, K+1] += dYeff^T @ [Xeff | 1]                            -- weight + bias gradient, fp32 MFMA
+//
+// rows_linear: one row per lane.  The 128-row tile is staged through LDS so that global loads/stores are fully coalesced
+// (row stride +1 float: conflict-free for both the row-major fill and the per-lane row read); the weight index is
+// wave-uniform, so weights come through the scalar cache as SGPR operands of v_fma (no LDS traffic for them).
+// rows_wgrad: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain): A = dY^T (n x 2 rows), B = X (2 rows x k), each half-wave loads
+// one contiguous 128-byte row piece; per-wave 32x32 tiles are reduced with fp32 atomics into the zero-filled output.
+#include "common.h"
+
+// rows per tile = threads per workgroup: 128 when max(K,N) <= 64 (33 KB of LDS), 64 otherwise (33 KB at 128 features)
+
+// flags
+#define MLP_PRE_RELU 1        // X := max(X, 0) on load
+#define MLP_POST_RELU 2       // Y := max(Y, 0) before the store
+
+template <int K, int MLP_ROWS>
+__global__ __launch_bounds__(MLP_ROWS) void rows_linear_kernel(const float *__restrict__ X, const float *__restrict__ in_mask,
+                                                               const float *__restrict__ W, const float *__restrict__ bias,
+                                                               const float *__restrict__ residual, const float *__restrict__ out_mask,
+                                                               float *__restrict__ Y, int64_t rows, int N, int flags)
+{
+    extern __shared__ __attribute__((aligned(16))) float tile[];       // MLP_ROWS x (max(K,N)+1)
+    const int tid = threadIdx.x;
+    const int n_tiles = (int)((rows + MLP_ROWS - 1) / MLP_ROWS);
+    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const int64_t row0 = (int64_t)t * MLP_ROWS;
+        const int64_t n_in = min((int64_t)MLP_ROWS, rows - row0) * K;
+        // 1. coalesced fill of the input tile (relu / mask applied here)
+        for (int idx = tid; idx < MLP_ROWS * K; idx += MLP_ROWS) {
+            float v = 0.f;
+            if (idx < n_in) {
+                v = X[row0 * K + idx];
+                if (flags & MLP_PRE_RELU) v = fmaxf(v, 0.f);
+                if (in_mask && !(in_mask[row0 * K + idx] > 0.f)) v = 0.f;
+            }
+            tile[(idx / K) * (K + 1) + (idx % K)] = v;
+        }
+        __syncthreads();
+        float x[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) x[k] = tile[tid * (K + 1) + k];
+        __syncthreads();
+        // 2. N outputs per row, 8 at a time; weights are wave-uniform -> scalar loads
+        for (int n0 = 0; n0 < N; n0 += 8) {
+            float acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = (bias && n0 + j < N) ? bias[n0 + j] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (n0 + j < N) {
+                    const float *w = W + (int64_t)(n0 + j) * K;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) acc[j] = fmaf(x[k], w[k], acc[j]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (n0 + j < N) tile[tid * (N + 1) + n0 + j] = acc[j];
+        }
+        __syncthreads();
+        // 3. coalesced store of the output tile (residual / relu / mask applied here)
+        const int64_t n_out = min((int64_t)MLP_ROWS, rows - row0) * N;
+        for (int idx = tid; idx < n_out; idx += MLP_ROWS) {
+            float v = tile[(idx / N) * (N + 1) + (idx % N)];
+            if (residual) v += residual[row0 * N + idx];
+            if (flags & MLP_POST_RELU) v = fmaxf(v, 0.f);
+            if (out_mask && !(out_mask[row0 * N + idx] > 0.f)) v = 0.f;
+            Y[row0 * N + idx] = v;
+        }
+        __syncthreads();
+    }
+}
+
+static bool mlp_k_supported(int k) { return k == 2 || k == 3 || k == 4 || k == 9 || k == 32 || k == 64 || k == 128; }
+
+extern "C" int pcacc_rows_linear(const float *x, const float *in_mask, const float *w, const float *bias, const float *residual,
+                                 const float *out_mask, float *y, int64_t rows, int k, int n, int flags, void *stream)
+{
+    if (rows < 0 || n <= 0 || n > 128 || !mlp_k_supported(k)) return PCACC_E_ARG;
+    if (rows == 0) return PCACC_OK;
+    if (!x || !w || !y) return PCACC_E_ARG;
+    hipStream_t s = pcacc_stream(stream);
+    const int feat = k > n ? k : n;
+    const int tile_rows = feat <= 64 ? 128 : 64;
+    const int n_tiles = (int)((rows + tile_rows - 1) / tile_rows);
+    const int grid = n_tiles < PCACC_CUS * 16 ? n_tiles : PCACC_CUS * 16;
+    const size_t lds = (size_t)tile_rows * (feat + 1) * sizeof(float);
+#define LAUNCH(KK)                                                                                                        \
+    do {                                                                                                                  \
+        if (tile_rows == 128)                                                                                             \
+            rows_linear_kernel<KK, 128><<<grid, 128, lds, s>>>(x, in_mask, w, bias, residual, out_mask, y, rows, n, flags); \
+        else                                                                                                              \
+            rows_linear_kernel<KK, 64><<<grid, 64, lds, s>>>(x, in_mask, w, bias, residual, out_mask, y, rows, n, flags);  \
+    } while (0)
+    switch (k) {
+        case 2: LAUNCH(2); break;
+        case 3: LAUNCH(3); break;
+        case 4: LAUNCH(4); break;
+        case 9: LAUNCH(9); break;
+        case 32: LAUNCH(32); break;
+        case 64: LAUNCH(64); break;
+        case 128: LAUNCH(128); break;
+        default: return PCACC_E_ARG;
+    }
+#undef LAUNCH
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight / bias gradient.  dW_aug[n][k] (k in [0,K]; column K is the bias gradient) += sum_r dY[r][n] * Xaug[r][k],
+// with Xaug[r][K] = 1.  dy_mask: dY is zeroed where dy_mask <= 0 (post-ReLU layers); x_relu: X := max(X,0) (pre-ReLU layers).
+// Tiles of 32 (n) x 32 (k); a workgroup's 4 waves each walk a strided share of the row pairs for up to TPB tiles.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define WG_TILES 4
+
+__global__ __launch_bounds__(256) void rows_wgrad_kernel(const float *__restrict__ dY, const float *__restrict__ dy_mask,
+                                                         const float *__restrict__ X, int x_relu, int64_t rows, int K, int N,
+                                                         int k_tiles, int n_tile_total, float *dW)
+{
+    __shared__ float red[WG_TILES * 1024];
+    const int lane = threadIdx.x & 63;
+    const int half = lane >> 5, li = lane & 31;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n_waves = gridDim.x * 4;
+    const int tile0 = blockIdx.y * WG_TILES;
+    f32x16 acc0, acc1, acc2, acc3;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; acc3[r] = 0.f; }
+    for (int i = threadIdx.x; i < WG_TILES * 1024; i += 256) red[i] = 0.f;
+
+#define WG_STEP(ACC, T)                                                                               \
+    if (tile0 + T < n_tile_total) {                                                                   \
+        const int n = ((tile0 + T) / k_tiles) * 32 + li;                                              \
+        const int k = ((tile0 + T) % k_tiles) * 32 + li;                                              \
+        float a = 0.f, b = 0.f;                                                                       \
+        if (rv && n < N) {                                                                            \
+            a = dY[r * N + n];                                                                        \
+            if (dy_mask && !(dy_mask[r * N + n] > 0.f)) a = 0.f;                                      \
+        }                                                                                             \
+        if (rv) {                                                                                     \
+            if (k < K) { b = X[r * K + k]; if (x_relu) b = fmaxf(b, 0.f); }                           \
+            else if (k == K) b = 1.0f;                                                                \
+        }                                                                                             \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, ACC, 0, 0, 0);                               \
+    }
+    for (int64_t r0 = (int64_t)wave * 2; r0 < rows; r0 += (int64_t)n_waves * 2) {
+        const int64_t r = r0 + half;
+        const bool rv = r < rows;
+        WG_STEP(acc0, 0)
+        WG_STEP(acc1, 1)
+        WG_STEP(acc2, 2)
+        WG_STEP(acc3, 3)
+    }
+#undef WG_STEP
+    __syncthreads();
+    // reduce the 4 waves of the workgroup in LDS (ds_add_f32), then one global atomic per element per workgroup
+#define WG_FLUSH(ACC, T)                                                                              \
+    if (tile0 + T < n_tile_total) {                                                                   \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                              \
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * half;                                          \
+            atomicAdd(&red[T * 1024 + i * 32 + li], ACC[r]);                                          \
+        }                                                                                             \
+    }
+    WG_FLUSH(acc0, 0)
+    WG_FLUSH(acc1, 1)
+    WG_FLUSH(acc2, 2)
+    WG_FLUSH(acc3, 3)
+#undef WG_FLUSH
+    __syncthreads();
+    const int KA = K + 1;
+    for (int e = threadIdx.x; e < WG_TILES * 1024; e += 256) {
+        const int t = e >> 10, i = (e >> 5) & 31, j = e & 31;
+        const int tile = tile0 + t;
+        if (tile >= n_tile_total) continue;
+        const int n = (tile / k_tiles) * 32 + i, k = (tile % k_tiles) * 32 + j;
+        if (n < N && k < KA) atomicAdd(&dW[(int64_t)n * KA + k], red[e]);
+    }
+}
+
+extern "C" int pcacc_rows_wgrad(const float *dy, const float *dy_mask, const float *x, int x_relu, int64_t rows, int k, int n,
+                                float *dw_aug, void *stream)
+{
+    if (rows < 0 || k <= 0 || n <= 0 || k > 512 || n > 512 || !dw_aug) return PCACC_E_ARG;
+    hipStream_t s = pcacc_stream(stream);
+    if (hipMemsetAsync(dw_aug, 0, (size_t)n * (k + 1) * sizeof(float), s) != hipSuccess) return PCACC_E_LAUNCH;
+    if (rows == 0) return PCACC_OK;
+    if (!dy || !x) return PCACC_E_ARG;
+    const int k_tiles = (k + 1 + 31) / 32, n_tiles = (n + 31) / 32;
+    const int total = k_tiles * n_tiles;
+    const int gy = (total + WG_TILES - 1) / WG_TILES;
+    int gx = (int)((rows / 2 + 4 * 64 - 1) / (4 * 64));          // >= 64 row pairs per wave
+    if (gx < 1) gx = 1;
+    const int cap = (PCACC_CUS * 2) / gy > 0 ? (PCACC_CUS * 2) / gy : 1;
+    if (gx > cap) gx = cap;
+    rows_wgrad_kernel<<<dim3(gx, gy), 256, 0, s>>>(dy, dy_mask, x, x_relu, rows, k, n, k_tiles, total, dw_aug);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}

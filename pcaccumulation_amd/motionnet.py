@@ -197,8 +197,8 @@ class MotionNet(nn.Module):
         """Per-point part of STPN.forward (models/stpn.py:91-104) on the already computed map."""
         mh = self.motionhead
         ungridded = ops.bilinear_gather(stpn_map, points, batch_idx, abs(self.pc_range[0]), abs(self.pc_range[1]))
-        pos = mh.positional_encoding(points / abs(self.pc_range[0]))
-        enc = mh.final_proj(torch.cat([pos, ungridded], dim=-1))
-        classes = mh.mos_seg(enc)
-        offset = mh.safe_guard_offset(mh.offset_head(enc))
+        pos = mh.point_mlp(mh.positional_encoding, points / abs(self.pc_range[0]))
+        enc = mh.point_mlp(mh.final_proj, torch.cat([pos, ungridded], dim=-1))
+        classes = mh.point_head(mh.mos_seg, enc)
+        offset = mh.safe_guard_offset(mh.point_head(mh.offset_head, enc))
         return classes, offset, stpn_map

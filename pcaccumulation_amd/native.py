@@ -43,7 +43,7 @@ EXPORTS = [
     'pcacc_frame_pillars_workspace_bytes', 'pcacc_frame_pillars',
     'pcacc_csr_workspace_bytes', 'pcacc_csr_build', 'pcacc_segment_mean3_maxlabel',
     'pcacc_segment_workspace_bytes', 'pcacc_segment_max', 'pcacc_segment_max_backward', 'pcacc_segment_sum',
-    'pcacc_pillar_scatter', 'pcacc_gather_rows',
+    'pcacc_rows_linear', 'pcacc_rows_wgrad', 'pcacc_pillar_scatter', 'pcacc_gather_rows',
     'pcacc_bilinear_gather', 'pcacc_bilinear_gather_backward', 'pcacc_bev_warp', 'pcacc_rigid_transform',
     'pcacc_chamfer_workspace_bytes', 'pcacc_chamfer_forward', 'pcacc_chamfer_backward',
 ]
@@ -292,3 +292,34 @@ def chamfer_backward(xyz1, xyz2, gd1, gd2, i1, i2):
                                         _dev(gd2, torch.float32, 'grad_dist2'), _dev(i2, torch.int32),
                                         _dev(g1), _dev(g2), _stream()), 'chamfer_backward')
     return g1, g2
+
+
+ROWS_LINEAR_K = (2, 3, 4, 9, 32, 64, 128)
+
+
+def rows_linear_supported(k, n):
+    return k in ROWS_LINEAR_K and 1 <= n <= 128
+
+
+def rows_linear(x, w, bias=None, residual=None, pre_relu=False, post_relu=False, in_mask=None, out_mask=None):
+    """y = post(pre(x) @ w^T + bias + residual); x [rows,k] f32, w [n,k] f32 (see include/pcacc.h)."""
+    rows, k = x.shape
+    n = w.shape[0]
+    y = torch.empty((rows, n), dtype=torch.float32, device=x.device)
+    opt = lambda t, what: _dev(t, torch.float32, what) if t is not None else None
+    _check(lib().pcacc_rows_linear(_dev(x, torch.float32, 'x'), opt(in_mask, 'in_mask'), _dev(w, torch.float32, 'w'),
+                                   opt(bias, 'bias'), opt(residual, 'residual'), opt(out_mask, 'out_mask'), _dev(y),
+                                   _i64(rows), int(k), int(n), (1 if pre_relu else 0) | (2 if post_relu else 0), _stream()),
+           'rows_linear')
+    return y
+
+
+def rows_wgrad(dy, x, dy_mask=None, x_relu=False):
+    """[n, k+1] = dYeff^T @ [Xeff | 1]: weight gradient with the bias gradient in the last column."""
+    rows, n = dy.shape
+    k = x.shape[1]
+    out = torch.empty((n, k + 1), dtype=torch.float32, device=dy.device)
+    _check(lib().pcacc_rows_wgrad(_dev(dy, torch.float32, 'dy'), _dev(dy_mask, torch.float32, 'dy_mask') if dy_mask is not None else None,
+                                  _dev(x, torch.float32, 'x'), 1 if x_relu else 0, _i64(rows), int(k), int(n), _dev(out), _stream()),
+           'rows_wgrad')
+    return out

@@ -28,10 +28,10 @@ class ResnetBlockFC(nn.Module):
         nn.init.zeros_(self.fc_1.weight)
 
     def forward(self, x):
-        net = self.fc_0(self.actvn(x))
-        dx = self.fc_1(self.actvn(net))
-        x_s = self.shortcut(x) if self.shortcut is not None else x
-        return x_s + dx
+        # fc_1(relu(fc_0(relu(x)))) + shortcut(x): three fused row-linear launches (ReLU on load, residual on store)
+        net = ops.linear_rows(x, self.fc_0, pre_relu=True)
+        x_s = ops.linear_rows(x, self.shortcut) if self.shortcut is not None else x
+        return ops.linear_rows(net, self.fc_1, pre_relu=True, residual=x_s)
 
 
 class PillarFeatureNet(nn.Module):
@@ -73,12 +73,12 @@ class PillarFeatureNet(nn.Module):
         if pidx is None:                                                  # reference call signature
             pidx = PillarIndex.from_point_map(point_to_voxel_map, coordinates.shape[0])
         features = self.point_features(raw_points, pidx, coordinates, pillar_mean, time_indice)
-        net = self.fc_pos(features)
+        net = ops.linear_rows(features, self.fc_pos)
         net = self.blocks[0](net)
         for block in self.blocks[1:]:
             pooled = ops.broadcast_to_points(ops.segment_max(net, pidx), pidx)
             net = block(torch.cat([net, pooled], dim=1))
-        feats = self.fc_c(net)
+        feats = ops.linear_rows(net, self.fc_c)
         return ops.segment_max(feats, pidx)
 
 

@@ -76,13 +76,31 @@ class STPN(nn.Module):
             x = module(skips[-(i + 2)], x)
         return x
 
+    @staticmethod
+    def point_mlp(seq, x):
+        """nn.Sequential of (Linear, ReLU)* evaluated with the fused row-linear kernels (ReLU folded into the store)."""
+        mods = list(seq)
+        i = 0
+        while i < len(mods):
+            relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+            x = ops.linear_rows(x, mods[i], post_relu=relu)
+            i += 2 if relu else 1
+        return x
+
+    @staticmethod
+    def point_head(head, x):
+        """SegHead1D = Linear, BatchNorm1d, ReLU, Linear (models/unet.py:240-245): the two Linear layers are fused row
+        kernels, BatchNorm1d (batch statistics over the K points in train mode, trap 16) stays the library op."""
+        lin0, bn, _, lin1 = head.seg_head
+        return ops.linear_rows(bn(ops.linear_rows(x, lin0)), lin1, pre_relu=True)
+
     def forward(self, x, points, time_indice, pc_range):
         """x [B,C,T,H,W]; points [K,3]; time_indice [K,2] -> (mos logits [K,2], offset [K,2], map [B,64,H,W])."""
         x = self.backbone(x)
         batch_idx = time_indice[:, 0].to(torch.int32).contiguous()
         ungridded = ops.bilinear_gather(x, points, batch_idx, abs(pc_range[0]), abs(pc_range[1]))
-        pos = self.positional_encoding(points / abs(pc_range[0]))
-        enc = self.final_proj(torch.cat([pos, ungridded.to(pos.dtype)], dim=-1))
-        classes = self.mos_seg(enc)
-        offset = self.safe_guard_offset(self.offset_head(enc))
+        pos = self.point_mlp(self.positional_encoding, points / abs(pc_range[0]))
+        enc = self.point_mlp(self.final_proj, torch.cat([pos, ungridded.to(pos.dtype)], dim=-1))
+        classes = self.point_head(self.mos_seg, enc)
+        offset = self.safe_guard_offset(self.point_head(self.offset_head, enc))
         return classes, offset, x

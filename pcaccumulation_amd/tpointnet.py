@@ -11,7 +11,7 @@ import torch.nn.functional as F
 from scipy.spatial.transform import Rotation as R
 
 from .chamfer_distance import ChamferDistance
-from .ops import scatter, ScatterPlan
+from .ops import scatter, ScatterPlan, linear_rows
 
 _EPS = 1e-20
 
@@ -123,6 +123,17 @@ def _mlp(dims):
     return nn.Sequential(*layers)
 
 
+def _embed(seq, x):
+    """(Linear, ReLU)*, Linear with the fused row-linear kernels."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+        x = linear_rows(x, mods[i], post_relu=relu)
+        i += 2 if relu else 1
+    return x
+
+
 class TPointNet(BaseModel):
     """models/tpointnet.py:167-305."""
 
@@ -158,13 +169,13 @@ class TPointNet(BaseModel):
         frame_weights = frame_weights * mos_weights * temporal_weights
 
         # 2. pooled embeddings (tpointnet.py:240-262)
-        mos_embedding = scatter(self.motion_embed(mos_feat), inst_indice, dim=0, dim_size=K, reduce='max', plan=per_inst)
-        geo_embedding = scatter(self.geo_embed(frame_feats), inst_indice, dim=0, dim_size=K, reduce='max', plan=per_inst)
+        mos_embedding = scatter(_embed(self.motion_embed, mos_feat), inst_indice, dim=0, dim_size=K, reduce='max', plan=per_inst)
+        geo_embedding = scatter(_embed(self.geo_embed, frame_feats), inst_indice, dim=0, dim_size=K, reduce='max', plan=per_inst)
         frame_centroid = scatter(points, frame_indice, dim=0, dim_size=K * T, reduce='mean', plan=per_frame)
         inst_centroid = frame_centroid[::T]
         centered_points = points - inst_centroid[inst_indice]
         frame_input = torch.cat((centered_points, time_indice.unsqueeze(-1) / T), dim=1).float()
-        frame_embedding = scatter(self.pos_embed(frame_input), frame_indice, dim=0, dim_size=K * T, reduce='max', plan=per_frame)
+        frame_embedding = scatter(_embed(self.pos_embed, frame_input), frame_indice, dim=0, dim_size=K * T, reduce='max', plan=per_frame)
 
         # 3. regress one pose per (instance, frame) (tpointnet.py:264-273)
         anchor_embedding = frame_embedding[::T].repeat_interleave(T, 0)

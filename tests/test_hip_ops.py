@@ -355,3 +355,59 @@ def test_chamfer_golden_from_reference_cpp(native, dev, golden):
     ((o1 * torch.from_numpy(g['grad_dist1']).to(dev)).sum() + (o2 * torch.from_numpy(g['grad_dist2']).to(dev)).sum()).backward()
     np.testing.assert_allclose(a.grad.cpu().numpy(), g['grad_xyz1'], rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(b.grad.cpu().numpy(), g['grad_xyz2'], rtol=1e-4, atol=1e-4)
+
+
+# ---------------------------------------------------------------- A4 MLP part: fused per-point linear layers
+@pytest.mark.parametrize('k,n', [(9, 64), (64, 32), (32, 32), (3, 32), (32, 64), (128, 128), (128, 2), (4, 32), (64, 128), (2, 7)])
+def test_rows_linear_and_wgrad_vs_torch(native, dev, k, n):
+    rng = np.random.RandomState(k * 131 + n)
+    rows = 5000 + k                                            # not a multiple of the tile size
+    x = torch.from_numpy(rng.randn(rows, k).astype(np.float32))
+    w = torch.from_numpy((rng.randn(n, k) / np.sqrt(k)).astype(np.float32))
+    b = torch.from_numpy(rng.randn(n).astype(np.float32))
+    res = torch.from_numpy(rng.randn(rows, n).astype(np.float32))
+    F = torch.nn.functional
+    for pre, post, use_res in [(False, False, False), (True, False, True), (False, True, False), (True, True, True)]:
+        ref = F.linear(torch.relu(x) if pre else x, w, b)
+        ref = ref + res if use_res else ref
+        ref = torch.relu(ref) if post else ref
+        got = native.rows_linear(x.to(dev), w.to(dev), b.to(dev), res.to(dev) if use_res else None, pre, post)
+        np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-4)
+    # masks (used by the backward-data pass)
+    im = torch.from_numpy(rng.randn(rows, k).astype(np.float32))
+    om = torch.from_numpy(rng.randn(rows, n).astype(np.float32))
+    ref = F.linear(x * (im > 0), w) * (om > 0)
+    got = native.rows_linear(x.to(dev), w.to(dev), None, None, False, False, in_mask=im.to(dev), out_mask=om.to(dev))
+    np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-4)
+    # weight + bias gradient
+    dy = torch.from_numpy(rng.randn(rows, n).astype(np.float32))
+    for mask, xrelu in [(None, False), (om, True)]:
+        g = dy * (mask > 0) if mask is not None else dy
+        h = torch.relu(x) if xrelu else x
+        ref_w, ref_b = g.t().double() @ h.double(), g.double().sum(0)
+        aug = native.rows_wgrad(dy.to(dev), x.to(dev), dy_mask=mask.to(dev) if mask is not None else None, x_relu=xrelu).cpu()
+        np.testing.assert_allclose(aug[:, :-1].numpy(), ref_w.numpy(), rtol=2e-4, atol=2e-3)
+        np.testing.assert_allclose(aug[:, -1].numpy(), ref_b.numpy(), rtol=2e-4, atol=2e-3)
+
+
+def test_linear_rows_autograd_matches_library(native, dev):
+    from pcaccumulation_amd import ops
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(64, 32).to(dev)
+    x = torch.randn(6000, 64, device=dev)
+    res = torch.randn(6000, 32, device=dev)
+    a = x.clone().requires_grad_(True)
+    r1 = res.clone().requires_grad_(True)
+    y = ops.linear_rows(a, lin, pre_relu=True, post_relu=True, residual=r1)
+    (y * y).sum().backward()
+    gw, gb = lin.weight.grad.clone(), lin.bias.grad.clone()
+    lin.zero_grad()
+    b = x.clone().requires_grad_(True)
+    r2 = res.clone().requires_grad_(True)
+    y2 = torch.relu(torch.nn.functional.linear(torch.relu(b), lin.weight, lin.bias) + r2)
+    (y2 * y2).sum().backward()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), y2.detach().cpu().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.cpu().numpy(), rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(r1.grad.cpu().numpy(), r2.grad.cpu().numpy(), rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(gw.cpu().numpy(), lin.weight.grad.cpu().numpy(), rtol=1e-3, atol=2e-2)
+    np.testing.assert_allclose(gb.cpu().numpy(), lin.bias.grad.cpu().numpy(), rtol=1e-3, atol=2e-2)
