@@ -17,6 +17,8 @@
 
 // rows per tile = threads per workgroup: 128 when max(K,N) <= 64 (33 KB of LDS), 64 otherwise (33 KB at 128 features)
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 // flags
 #define MLP_PRE_RELU 1        // X := max(X, 0) on load
 #define MLP_POST_RELU 2       // Y := max(Y, 0) before the store
@@ -48,17 +50,36 @@ __global__ __launch_bounds__(MLP_ROWS) void rows_linear_kernel(const float *__re
 #pragma unroll
         for (int k = 0; k < K; ++k) x[k] = tile[tid * (K + 1) + k];
         __syncthreads();
-        // 2. N outputs per row, 8 at a time; weights are wave-uniform -> scalar loads
+        // 2. N outputs per row, 8 at a time; weights are wave-uniform -> scalar loads.  For even K the dot product is
+        //    accumulated as two interleaved partial sums (even / odd k) in one v_pk_fma_f32 per pair: the fp32 VALU peak
+        //    of gfx950 (157 TF) is only reachable with packed FMA, and the 128x128 layers are VALU-bound, not HBM-bound.
         for (int n0 = 0; n0 < N; n0 += 8) {
             float acc[8];
+            if (K % 2 == 0 && K >= 32) {
+                f32x2 acc2[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = (bias && n0 + j < N) ? bias[n0 + j] : 0.f;
+                for (int j = 0; j < 8; ++j) acc2[j] = (f32x2){0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if (n0 + j < N) {
-                    const float *w = W + (int64_t)(n0 + j) * K;
+                for (int j = 0; j < 8; ++j) {
+                    if (n0 + j < N) {
+                        const f32x2 *w2 = reinterpret_cast<const f32x2 *>(W + (int64_t)(n0 + j) * K);
 #pragma unroll
-                    for (int k = 0; k < K; ++k) acc[j] = fmaf(x[k], w[k], acc[j]);
+                        for (int k = 0; k < K / 2; ++k)
+                            acc2[j] = __builtin_elementwise_fma((f32x2){x[2 * k], x[2 * k + 1]}, w2[k], acc2[j]);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = (acc2[j].x + acc2[j].y) + ((bias && n0 + j < N) ? bias[n0 + j] : 0.f);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = (bias && n0 + j < N) ? bias[n0 + j] : 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (n0 + j < N) {
+                        const float *w = W + (int64_t)(n0 + j) * K;
+#pragma unroll
+                        for (int k = 0; k < K; ++k) acc[j] = fmaf(x[k], w[k], acc[j]);
+                    }
                 }
             }
 #pragma unroll

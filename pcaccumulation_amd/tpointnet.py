@@ -11,7 +11,7 @@ import torch.nn.functional as F
 from scipy.spatial.transform import Rotation as R
 
 from .chamfer_distance import ChamferDistance
-from .ops import scatter, ScatterPlan, linear_rows
+from .ops import scatter, ScatterPlan, linear_rows, transform_by_index
 
 _EPS = 1e-20
 
@@ -36,16 +36,13 @@ def apply_tsfm(src, tsfm):
 def reconstruct_sequence(points, time_indice, inst_labels, tsfm, n_frames):
     """toolbox/register_utils.py:73-93: apply tsfm[inst, t] to every point."""
     assert n_frames == tsfm.size(1)
-    flat = tsfm.view(-1, 4, 4)
     idx = (inst_labels.long() * n_frames + time_indice).long()
-    pt = flat[idx]
-    return (torch.matmul(pt[:, :3, :3], points[:, :, None]) + pt[:, :3, 3][:, :, None]).squeeze(-1)
+    return transform_by_index(points, idx, tsfm.reshape(-1, 4, 4))
 
 
 def ego_motion_compensation(points, time_indice, tsfm):
     """toolbox/register_utils.py:59-70."""
-    pt = tsfm[time_indice.long()]
-    return (torch.matmul(pt[:, :3, :3], points[:, :, None]) + pt[:, :3, 3][:, :, None]).squeeze(-1)
+    return transform_by_index(points, time_indice.long(), tsfm)
 
 
 def batch_quat2mat(pose_est_rep):
