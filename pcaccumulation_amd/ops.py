@@ -210,11 +210,13 @@ class _SegmentSum(torch.autograd.Function):
 
 
 def _pad4(x):
-    """[N,C] f32 with C padded up to a multiple of 4 (the segment kernels move float4)."""
+    """[N,C] f32 with C padded up to the next width the segment kernels are instantiated for (4 * 2^k floats per row)."""
     c = x.shape[1]
-    pad = (-c) % 4
-    if pad:
-        x = torch.nn.functional.pad(x, (0, pad))
+    width = 4
+    while width < c:
+        width *= 2
+    if width != c:
+        x = torch.nn.functional.pad(x, (0, width - c))
     return x.contiguous(), c
 
 
