@@ -99,10 +99,17 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
-    rank, world, local_rank = pdist.init_from_env()
+    # PCACC_DIST_BACKEND=gloo lets the N > 1 path be exercised on a box with fewer GPUs than ranks (ranks then share
+    # cuda:0); the driver's multi-GPU runs use the default: nccl = RCCL over xGMI, one rank per GPU.
+    backend = os.environ.get('PCACC_DIST_BACKEND') or None
+    n_dev = max(torch.cuda.device_count(), 1)
+    if backend is None and int(os.environ.get('WORLD_SIZE', '1')) > n_dev:
+        raise SystemExit('WORLD_SIZE exceeds the %d visible GPU(s); set PCACC_DIST_BACKEND=gloo to share devices' % n_dev)
+    torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % n_dev)
+    rank, world, local_rank = pdist.init_from_env(backend)
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit('--gpus %d needs torch.distributed.run with --nproc-per-node %d' % (args.gpus, args.gpus))
-    device = torch.device('cuda', local_rank)
+    device = torch.device('cuda', local_rank % n_dev)
     torch.cuda.set_device(device)
     native.lib()
 

@@ -35,20 +35,44 @@ __global__ __launch_bounds__(MLP_ROWS) void rows_linear_kernel(const float *__re
     for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const int64_t row0 = (int64_t)t * MLP_ROWS;
         const int64_t n_in = min((int64_t)MLP_ROWS, rows - row0) * K;
-        // 1. coalesced fill of the input tile (relu / mask applied here)
-        for (int idx = tid; idx < MLP_ROWS * K; idx += MLP_ROWS) {
-            float v = 0.f;
-            if (idx < n_in) {
-                v = X[row0 * K + idx];
-                if (flags & MLP_PRE_RELU) v = fmaxf(v, 0.f);
-                if (in_mask && !(in_mask[row0 * K + idx] > 0.f)) v = 0.f;
+        const int NS = (N % 4 == 0) ? N + 4 : N + 1;
+        // 1. coalesced fill of the input tile (relu / mask applied here).  KS / NS = row strides in LDS: +4 floats when the
+        //    rows are moved as float4 (keeps 16-byte alignment, conflict-free for ds_read_b128), +1 float otherwise.
+        constexpr int KS = (K % 4 == 0) ? K + 4 : K + 1;
+        if (K % 4 == 0) {
+            const float4 *X4 = reinterpret_cast<const float4 *>(X + row0 * K);
+            const float4 *M4 = in_mask ? reinterpret_cast<const float4 *>(in_mask + row0 * K) : nullptr;
+            for (int i4 = tid; i4 < MLP_ROWS * K / 4; i4 += MLP_ROWS) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if ((int64_t)i4 * 4 < n_in) {
+                    v = X4[i4];
+                    if (flags & MLP_PRE_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    if (M4) {
+                        const float4 mk = M4[i4];
+                        if (!(mk.x > 0.f)) v.x = 0.f;
+                        if (!(mk.y > 0.f)) v.y = 0.f;
+                        if (!(mk.z > 0.f)) v.z = 0.f;
+                        if (!(mk.w > 0.f)) v.w = 0.f;
+                    }
+                }
+                const int e = i4 * 4;
+                *reinterpret_cast<float4 *>(&tile[(e / K) * KS + (e % K)]) = v;
             }
-            tile[(idx / K) * (K + 1) + (idx % K)] = v;
+        } else {
+            for (int idx = tid; idx < MLP_ROWS * K; idx += MLP_ROWS) {
+                float v = 0.f;
+                if (idx < n_in) {
+                    v = X[row0 * K + idx];
+                    if (flags & MLP_PRE_RELU) v = fmaxf(v, 0.f);
+                    if (in_mask && !(in_mask[row0 * K + idx] > 0.f)) v = 0.f;
+                }
+                tile[(idx / K) * KS + (idx % K)] = v;
+            }
         }
         __syncthreads();
         float x[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) x[k] = tile[tid * (K + 1) + k];
+        for (int k = 0; k < K; ++k) x[k] = tile[tid * KS + k];
         __syncthreads();
         // 2. N outputs per row, 8 at a time; weights are wave-uniform -> scalar loads.  For even K the dot product is
         //    accumulated as two interleaved partial sums (even / odd k) in one v_pk_fma_f32 per pair: the fp32 VALU peak
@@ -84,17 +108,37 @@ __global__ __launch_bounds__(MLP_ROWS) void rows_linear_kernel(const float *__re
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                if (n0 + j < N) tile[tid * (N + 1) + n0 + j] = acc[j];
+                if (n0 + j < N) tile[tid * NS + n0 + j] = acc[j];
         }
         __syncthreads();
         // 3. coalesced store of the output tile (residual / relu / mask applied here)
         const int64_t n_out = min((int64_t)MLP_ROWS, rows - row0) * N;
-        for (int idx = tid; idx < n_out; idx += MLP_ROWS) {
-            float v = tile[(idx / N) * (N + 1) + (idx % N)];
-            if (residual) v += residual[row0 * N + idx];
-            if (flags & MLP_POST_RELU) v = fmaxf(v, 0.f);
-            if (out_mask && !(out_mask[row0 * N + idx] > 0.f)) v = 0.f;
-            Y[row0 * N + idx] = v;
+        if (N % 4 == 0) {
+            float4 *Y4 = reinterpret_cast<float4 *>(Y + row0 * N);
+            const float4 *R4 = residual ? reinterpret_cast<const float4 *>(residual + row0 * N) : nullptr;
+            const float4 *O4 = out_mask ? reinterpret_cast<const float4 *>(out_mask + row0 * N) : nullptr;
+            for (int i4 = tid; (int64_t)i4 * 4 < n_out; i4 += MLP_ROWS) {
+                const int e = i4 * 4;
+                float4 v = *reinterpret_cast<const float4 *>(&tile[(e / N) * NS + (e % N)]);
+                if (R4) { const float4 r = R4[i4]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+                if (flags & MLP_POST_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (O4) {
+                    const float4 mk = O4[i4];
+                    if (!(mk.x > 0.f)) v.x = 0.f;
+                    if (!(mk.y > 0.f)) v.y = 0.f;
+                    if (!(mk.z > 0.f)) v.z = 0.f;
+                    if (!(mk.w > 0.f)) v.w = 0.f;
+                }
+                Y4[i4] = v;
+            }
+        } else {
+            for (int idx = tid; idx < n_out; idx += MLP_ROWS) {
+                float v = tile[(idx / N) * NS + (idx % N)];
+                if (residual) v += residual[row0 * N + idx];
+                if (flags & MLP_POST_RELU) v = fmaxf(v, 0.f);
+                if (out_mask && !(out_mask[row0 * N + idx] > 0.f)) v = 0.f;
+                Y[row0 * N + idx] = v;
+            }
         }
         __syncthreads();
     }
@@ -113,7 +157,7 @@ extern "C" int pcacc_rows_linear(const float *x, const float *in_mask, const flo
     const int tile_rows = feat <= 64 ? 128 : 64;
     const int n_tiles = (int)((rows + tile_rows - 1) / tile_rows);
     const int grid = n_tiles < PCACC_CUS * 16 ? n_tiles : PCACC_CUS * 16;
-    const size_t lds = (size_t)tile_rows * (feat + 1) * sizeof(float);
+    const size_t lds = (size_t)tile_rows * (feat + 4) * sizeof(float);
 #define LAUNCH(KK)                                                                                                        \
     do {                                                                                                                  \
         if (tile_rows == 128)                                                                                             \
