@@ -26,7 +26,7 @@ def main():
     scene = sample_to_device(make_sequence(1, 5, ppf, cfg), dev)
     log('scene on device')
     for it in range(steps):
-        inp = batcher([scene]); log('it%d batcher M=%d' % (it, inp['coordinates'].shape[0]))
+        inp = batcher([scene] * int(os.environ.get("BATCH", "1"))); log('it%d batcher M=%d' % (it, inp['coordinates'].shape[0]))
         out = model(inp); log('it%d forward' % it)
         stats = loss_fn(out, inp); log('it%d loss=%.4f' % (it, float(stats['loss'])))
         stats['loss'].backward(); log('it%d backward' % it)
