@@ -116,6 +116,7 @@ def main():
 
     cfg = default_config('waymo', 'train', n_sweeps=T_FRAMES)
     cfg['misc']['compute_dtype'] = args.dtype
+    cfg['pose_estimation']['kpt_sampler'] = 'device'          # same uniform key-point subset, drawn on the GPU generator
     model, opt, loss_fn = build(cfg, device)
     batcher = DeviceBatcher(cfg)
     n_scenes = 2 * args.batch

@@ -124,8 +124,9 @@ class AlignNet(BaseModel):
         l2_error = torch.norm(rec_est - rec_gt, p=2, dim=1)
         weights = time_indice[:, 1] > 0
         weights_mos = (input_dict['mos_labels'] == 1) & (time_indice[:, 1] > 0)
-        results['inst_l2_error'] = ((l2_error * weights).sum() / (weights.sum() + _EPS)).item()
-        results['dynamic_inst_l2_error'] = ((l2_error * weights_mos).sum() / (weights_mos.sum() + _EPS)).item()
+        # 0-d tensors; MotionNet.forward converts them to floats in its single end-of-forward sync (alignnet.py:280-281)
+        results['inst_l2_error'] = (l2_error * weights).sum() / (weights.sum() + _EPS)
+        results['dynamic_inst_l2_error'] = (l2_error * weights_mos).sum() / (weights_mos.sum() + _EPS)
         results['inst_labels_adjusted'] = inst_labels
         results['inst_pose_est'] = final_pose_est
         results['sub_rec_est'] = rec_est

@@ -99,6 +99,10 @@ class EgoMotionHead(nn.Module):
         self.refine_with_icp = config['model']['ego_icp']
         if self.refine_with_icp:
             raise NotImplementedError('model.ego_icp (Open3D ICP refinement) is off the hot path (configs/default.yaml:115)')
+        # 'reference': torch.randperm on the HOST generator, the reference's RNG stream (bit-reproducible against it);
+        # 'device'   : the same uniform subset drawn with torch.randperm on the GPU generator (no 50 k-element host shuffle,
+        #              1.8 ms each on the host, 32 of them per 4-sequence step).
+        self.kpt_sampler = pe.get('kpt_sampler', 'reference')
         self.seq_pose = pe['seq_pose']
         if self.seq_pose != 'skip':
             raise NotImplementedError("pose_estimation.seq_pose='%s': only 'skip' (configs/default.yaml:83) is built" % self.seq_pose)
@@ -111,9 +115,11 @@ class EgoMotionHead(nn.Module):
             la = torch.cat((la[:, :, :-1] - torch.logsumexp(la[:, :, :-1], dim=1, keepdim=True), la[:, :, -1, None]), dim=2)
         return la[:, :-1, :-1]
 
-    def _choice(self, n):
+    def _choice(self, n, device=None):
         """models/egomotion.py:156-166: random subset when n > n_kpts, else arange with the tail clamped to n-1."""
         if n > self.ego_n_points:
+            if self.kpt_sampler == 'device' and device is not None and device.type == 'cuda':
+                return torch.randperm(n, device=device)[:self.ego_n_points]
             return torch.randperm(n)[:self.ego_n_points]
         c = torch.arange(self.ego_n_points)
         c[n:] = n - 1
@@ -143,34 +149,47 @@ class EgoMotionHead(nn.Module):
                                relative_pose_est_list, relative_pose_gt_list, chained_pose_est_list, chained_pose_gt_list):
         """models/egomotion.py:309-357 for ONE batch element: every frame t >= 1 is registered against the anchor
         frame 0.  Kept with the reference's signature; it runs the batched estimator on this element's pairs."""
-        l1, l2, n = self._estimate_pairs([(points_list, feats_list, bg_mask_list, c_ego_motion_gt)], T, perm_matrix_list,
-                                         relative_pose_est_list, relative_pose_gt_list, chained_pose_est_list,
-                                         chained_pose_gt_list)
-        return l1, l2, n
+        seq = self._sequence_from_masks(points_list, feats_list, bg_mask_list, c_ego_motion_gt)
+        return self._estimate_pairs([seq], T, perm_matrix_list, relative_pose_est_list, relative_pose_gt_list,
+                                    chained_pose_est_list, chained_pose_gt_list)
+
+    @staticmethod
+    def _sequence_from_masks(points_list, feats_list, bg_mask_list, gt):
+        """Dense-map / mask inputs (reference signature) -> the index-list form _estimate_pairs consumes."""
+        bg, getters = [], []
+        for f, m in zip(feats_list, bg_mask_list):
+            idx = torch.nonzero(m)[:, 0]
+            bg.append((idx, int(idx.numel())))
+            getters.append(lambda i, f=f: f[i])
+        return points_list, getters, bg, gt
 
     def _estimate_pairs(self, sequences, T, perm_matrix_list, relative_pose_est_list, relative_pose_gt_list,
                         chained_pose_est_list, chained_pose_gt_list):
         """All (T-1) registrations of all batch elements in ONE batched Sinkhorn / Kabsch evaluation
         ([P,1024,1024] instead of P sequential [1,1024,1024] problems: the reference issues ~60 tiny launches and
-        several host syncs per pair).  Key points are still drawn pair by pair on the host
-        generator in the reference's order (source, then target), so a given torch.manual_seed gives the same draw."""
-        dev = sequences[0][1][0].device
+        several host syncs per pair).  Key points are still drawn pair by pair in the reference's
+        order (source, then target), so with the 'reference' sampler a given torch.manual_seed gives the same draw.
+
+        sequences: list of (points_list, feats_list, bg_list, gt) per batch element, where for frame t
+          points_list[t] = xyz of all occupied pillars, feats_list[t] = callable(idx)-> features of pillars `idx` of frame t,
+          bg_list[t] = (bg_idx LongTensor into the frame's pillar list, n_bg int)."""
+        dev = sequences[0][0][0].device
         fs, cs, ft, ct, durations = [], [], [], [], []
-        for points_list, feats_list, bg_mask_list, _ in sequences:
-            anchor_mask = bg_mask_list[0]
-            anchor_points, anchor_feats = points_list[0][anchor_mask], feats_list[0][anchor_mask]
+        for points_list, feats_list, bg_list, _ in sequences:
+            a_idx, a_n = bg_list[0]
             for frame_idx in range(T - 1):
                 ref = frame_idx + 1
-                mask = bg_mask_list[ref]
-                ref_feats, ref_points = feats_list[ref][mask], points_list[ref][mask]
-                choice_s = self._choice(ref_feats.size(0)).to(dev)          # models/egomotion.py:156-166, same order
-                choice_t = self._choice(anchor_feats.size(0)).to(dev)
-                fs.append(ref_feats[choice_s]); cs.append(ref_points[choice_s])
-                ft.append(anchor_feats[choice_t]); ct.append(anchor_points[choice_t])
+                r_idx, r_n = bg_list[ref]
+                choice_s = self._choice(r_n, dev).to(dev)                 # models/egomotion.py:156-166, same order
+                choice_t = self._choice(a_n, dev).to(dev)
+                si, ti = r_idx[choice_s], a_idx[choice_t]                   # key-point pillars (indices into the frame lists)
+                fs.append(feats_list[ref](si)); cs.append(points_list[ref][si])
+                ft.append(feats_list[0](ti)); ct.append(points_list[0][ti])
                 durations.append((frame_idx + 1) / self.frequence)
         feats_s, coor_s = torch.stack(fs), torch.stack(cs)                  # [P,k,C], [P,k,3]
         feats_t, coor_t = torch.stack(ft), torch.stack(ct)
-        thr2 = (torch.tensor(durations, device=dev, dtype=torch.float32) * self.ego_max_speed) ** 2
+        thr2 = (torch.tensor(durations, dtype=torch.float32) * self.ego_max_speed) ** 2
+        thr2 = thr2.to(dev)
         support = (square_distance(coor_s, coor_t, normalised=False) < thr2[:, None, None]).float()     # :173-174
         feat_dist = square_distance(feats_s, feats_t, normalised=True)                                   # :177
         affinity = -(feat_dist - self.softplus(self.alpha)) / (torch.exp(self.beta) + 0.02)              # :180
@@ -185,7 +204,7 @@ class EgoMotionHead(nn.Module):
 
         identity = torch.eye(4, device=dev)
         total_l1, total_l2, p = 0, 0, 0
-        for points_list, feats_list, bg_mask_list, gt in sequences:
+        for points_list, feats_list, bg_list, gt in sequences:
             for lst in (relative_pose_est_list, relative_pose_gt_list, chained_pose_est_list, chained_pose_gt_list):
                 lst.append(identity)
             # T_anchor^-1 @ T_ref for all frames at once (get_relative_pose_torch, register_utils.py:184-197)
@@ -213,8 +232,10 @@ class EgoMotionHead(nn.Module):
         chained_pose_gt = torch.stack(chained_pose_gt_list)
         rot_est, rot_gt = chained_pose_est[:, :3, :3], chained_pose_gt[:, :3, :3]
         trans_est, trans_gt = chained_pose_est[:, :3, 3].unsqueeze(-1), chained_pose_gt[:, :3, 3].unsqueeze(-1)
-        rot_error = rotation_error(rot_est, rot_gt).mean().item() * self.n_sweeps / (self.n_sweeps - 1)
-        trans_error = translation_error(trans_est, trans_gt).mean().item() * self.n_sweeps / (self.n_sweeps - 1)
+        # 0-d tensors here; MotionNet.forward turns them into Python floats (the reference's .item(), egomotion.py:456)
+        # together with the other scalar results in ONE host sync at the end of the forward
+        rot_error = rotation_error(rot_est, rot_gt).mean() * self.n_sweeps / (self.n_sweeps - 1)
+        trans_error = translation_error(trans_est, trans_gt).mean() * self.n_sweeps / (self.n_sweeps - 1)
         results['ego_l1_loss'] = total_l1 / count
         results['ego_l2_loss'] = total_l2 / count
         results['ego_rot_error'] = rot_error
@@ -223,26 +244,31 @@ class EgoMotionHead(nn.Module):
         results['ego_motion_est'] = chained_pose_est.view(B, T, 4, 4)
         results['ego_motion_gt'] = chained_pose_gt.view(B, T, 4, 4)
 
-    def forward_pillars(self, geo_rows, pillar_mean, fb_est_pillar, pidx, ego_motion_gt, results):
-        """Same computation as forward(), fed from pillar-level tensors instead of dense canvases:
-        geo_rows [n_cells, C] (L2-normalised feature map rows), pillar_mean [M,3], fb_est_pillar [M].
-        Frame lists enumerate occupied pillars in ascending cell order, as models/egomotion.py:419-424 does
-        through the boolean occupancy mask."""
+    def forward_pillars(self, geo_rows, pillar_mean, pidx, ego_motion_gt, results, frame_offsets, bg_sorted_idx, bg_counts):
+        """Same computation as forward(), fed from pillar-level tensors instead of dense canvases, with no host sync:
+          geo_rows [n_cells, C]  rows of the L2-normalised feature map;  pillar_mean [M,3]
+          frame_offsets  host list [B*T+1]: slice of the cell-ordered pillar list (pidx.frame_pillars) per frame
+          bg_sorted_idx  LongTensor: positions in that cell-ordered list whose pillar is predicted background
+          bg_counts      host list [B*T]: how many of them fall into each frame
+        Frame lists enumerate occupied pillars in ascending cell order, as models/egomotion.py:419-424 does through the
+        boolean occupancy mask."""
         B, T = pidx.batch_size, pidx.nt
-        sorted_pillars, frame_offsets = pidx.frame_pillars()
-        offs = frame_offsets.cpu().tolist()                             # the one host sync for the frame sizes
-        sp = sorted_pillars.long()
+        sp = pidx.frame_pillars()[0].long()
         cells = pidx.cell.long()
         perm_l, rel_est, rel_gt, ch_est, ch_gt = [], [], [], [], []
-        sequences = []
+        sequences, bg_start = [], 0
         for b in range(B):
-            points_list, feats_list, bg_list = [], [], []
+            points_list, getters, bg_list = [], [], []
             for t in range(T):
-                ids = sp[offs[b * T + t]:offs[b * T + t + 1]]
+                f = b * T + t
+                lo, hi = frame_offsets[f], frame_offsets[f + 1]
+                ids = sp[lo:hi]                                              # pillar ids of this frame, cell order
                 points_list.append(pillar_mean[ids])
-                feats_list.append(geo_rows[cells[ids]])
-                bg_list.append(fb_est_pillar[ids] == 0)
-            sequences.append((points_list, feats_list, bg_list, ego_motion_gt[b]))
+                getters.append(lambda i, ids=ids: geo_rows[cells[ids[i]]])
+                n_bg = bg_counts[f]
+                bg_list.append((bg_sorted_idx[bg_start:bg_start + n_bg] - lo, n_bg))
+                bg_start += n_bg
+            sequences.append((points_list, getters, bg_list, ego_motion_gt[b]))
         total_l1, total_l2, count = self._estimate_pairs(sequences, T, perm_l, rel_est, rel_gt, ch_est, ch_gt)
         self._finish(B, T, total_l1, total_l2, count, perm_l, ch_est, ch_gt, results)
 
@@ -258,6 +284,8 @@ class EgoMotionHead(nn.Module):
                 points_list.append(pts_mean_map[b, t].permute(1, 2, 0).reshape(Ny * Nx, 3)[occ])
                 feats_list.append(bev_feats[b, t].permute(1, 2, 0).reshape(Ny * Nx, C)[occ])
                 bg_list.append((fb_est[b, t, 0].reshape(-1) == 0)[occ])
-            sequences.append((points_list, feats_list, bg_list, ego_motion_gt[b]))
+            sequences.append(self._sequence_from_masks(points_list, feats_list, bg_list, ego_motion_gt[b]))
         total_l1, total_l2, count = self._estimate_pairs(sequences, T, perm_l, rel_est, rel_gt, ch_est, ch_gt)
         self._finish(B, T, total_l1, total_l2, count, perm_l, ch_est, ch_gt, results)
+        for k in ('ego_rot_error', 'ego_trans_error'):                       # reference signature returns floats
+            results[k] = results[k].item()

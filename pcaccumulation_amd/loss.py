@@ -31,6 +31,23 @@ def compute_iou(predictions, gt, n_class, ignore_index):
             'pred_positives': np.array(pred_pos), 'gt_positives': np.array(gt_pos)}
 
 
+def _iou_counts(predictions, gt, n_class, ignore_index):
+    """The four count vectors of compute_iou as ONE device tensor [4, n_kept] (intersection, union, pred+, gt+), / 1e3."""
+    rows = []
+    for idx in range(n_class):
+        if idx == ignore_index:
+            continue
+        sel_gt, sel_pred = gt == idx, predictions == idx
+        n_pred, n_gt, inter = sel_pred.sum(), sel_gt.sum(), (sel_gt & sel_pred).sum()
+        rows.append(torch.stack([inter, n_pred + n_gt - inter, n_pred, n_gt]))
+    return torch.stack(rows, dim=1).double() / 1e3
+
+
+def _metric_dict(t):
+    t = t.cpu().numpy() if torch.is_tensor(t) else t
+    return {'intersection': t[0], 'union': t[1], 'pred_positives': t[2], 'gt_positives': t[3]}
+
+
 def mean_iou(stats_list):
     """toolbox/metrics.py:43-60 over a list of per-batch stats: sum(I) / (sum(U) + 1e-20), mean over classes."""
     i = sum(s['intersection'] for s in stats_list)
@@ -51,23 +68,21 @@ def lovasz_grad(gt_sorted):
 
 
 def lovasz_softmax_flat(probas, labels):
-    """libs/lovasz_softmax.py:71-94: mean over present classes of <sorted errors, Lovasz gradient>."""
+    """libs/lovasz_softmax.py:71-94: mean over PRESENT classes of <sorted errors, Lovasz gradient>.  The reference skips
+    absent classes with a host-side `if fg.sum() == 0`; here every class is evaluated and weighted by its presence on the
+    device (same value, no sync)."""
     if probas.numel() == 0:
         return probas * 0.
-    losses = []
+    total, present = 0, 0
     for c in range(probas.size(1)):
         fg = (labels == c).float()
-        if fg.sum() == 0:
-            continue
+        here = (fg.sum() > 0).to(probas.dtype)
         errors = (fg - probas[:, c]).abs()
         errors_sorted, perm = torch.sort(errors, 0, descending=True)
-        losses.append(torch.dot(errors_sorted, lovasz_grad(fg[perm.data])))
-    if not losses:
-        return 0
-    acc = losses[0]
-    for v in losses[1:]:
-        acc = acc + v
-    return acc if len(losses) == 1 else acc / len(losses)
+        grad = torch.nan_to_num(lovasz_grad(fg[perm.data]), nan=0.0)           # gts == 0 gives 0/0 in the first entries
+        total = total + here * torch.dot(errors_sorted, grad)
+        present = present + here
+    return total / torch.clamp(present, min=1.0)
 
 
 class Lovasz_softmax(nn.Module):
@@ -97,22 +112,28 @@ class FuseLoss(nn.Module):
                 setattr(self, k, v)
 
     def get_ce_weights(self, gt_label, max_weights=50):
-        """libs/loss.py:90-108, 'sqrt_inv_freq' mode."""
-        counts = torch.tensor([(gt_label == c).sum().item() + _EPS for c in range(self.n_classes)]).to(gt_label.device)
+        """libs/loss.py:90-108, 'sqrt_inv_freq' mode (counts stay on the device: no .item())."""
+        counts = torch.stack([(gt_label == c).sum() for c in range(self.n_classes)]).to(torch.float32) + _EPS
         return torch.clamp(torch.sqrt(counts.sum() / counts), 0, max_weights)
 
     def get_seg_loss(self, gt, est):
         """libs/loss.py:110-137."""
         criterion = torch.nn.CrossEntropyLoss(weight=self.get_ce_weights(gt), ignore_index=self.ignore_index)
         stats = {'bce_loss': criterion(est, gt), 'lovasz_loss': self.lovasz_loss(self.softmax(est), gt)}
-        stats['metric'] = compute_iou(est.argmax(1), gt, self.n_classes, self.ignore_index)
+        stats['metric'] = _iou_counts(est.argmax(1), gt, self.n_classes, self.ignore_index)    # device tensor, see forward()
         return stats
 
     def get_mos_loss(self, predictions, input_dict):
         """libs/loss.py:140-165: supervised on points that are foreground in GT or in the estimate."""
         mos_gt, mos_est = input_dict['sd_labels'][:, 0].long(), predictions['mos_est']
-        fb_mask = torch.logical_or(input_dict['fb_labels'][:, 0] == 1, predictions['fb_est_per_points'][:, 0] == 1)
-        if fb_mask.sum():
+        if '_fb_idx' in predictions:                                      # index list MotionNet already built (no re-sync)
+            fb_idx = predictions['_fb_idx']
+            if fb_idx.numel():
+                return self.get_seg_loss(mos_gt[fb_idx], mos_est[fb_idx])
+            fb_mask = None
+        else:
+            fb_mask = torch.logical_or(input_dict['fb_labels'][:, 0] == 1, predictions['fb_est_per_points'][:, 0] == 1)
+        if fb_mask is not None and fb_mask.sum():
             return self.get_seg_loss(mos_gt[fb_mask], mos_est[fb_mask])
         zero = {k: np.zeros(2) for k in ('intersection', 'union', 'pred_positives', 'gt_positives')}
         return {'metric': zero, 'bce_loss': torch.tensor(0., requires_grad=True).to(mos_gt.device),
@@ -122,6 +143,9 @@ class FuseLoss(nn.Module):
         """libs/loss.py:167-191: only occupied pillars are supervised."""
         est = predictions['fb_seg_est'].permute(0, 1, 3, 4, 2).contiguous().view(-1, 2)
         gt = predictions['fb_seg_gt'].permute(0, 1, 3, 4, 2).contiguous().view(-1)
+        if '_cell' in predictions:                                        # occupied cells = the pillars' cell indices
+            cell = predictions['_cell'].long()
+            return self.get_seg_loss(gt[cell], est[cell])
         mask = predictions['occ_map'].permute(0, 1, 3, 4, 2).contiguous().view(-1) == 1
         return self.get_seg_loss(gt[mask], est[mask])
 
@@ -132,9 +156,14 @@ class FuseLoss(nn.Module):
         ego_motion_gt = input_dict['ego_motion_gt']
         inst_labels = input_dict['inst_labels'][:, 0].long()
         bbox_tsfm = input_dict['inst_motion_gt']
-        fb_mask = input_dict['fb_labels'][:, 0] == 1
         device = input_points.device
-        if not fb_mask.sum():
+        if '_rec_idx' in predictions:
+            fb_mask = predictions['_rec_idx']                              # index list of the GT-foreground points
+            empty = fb_mask.numel() == 0
+        else:
+            fb_mask = input_dict['fb_labels'][:, 0] == 1
+            empty = not fb_mask.sum()
+        if empty:
             z = torch.tensor(0., requires_grad=True).to(device)
             return z, torch.tensor(0., requires_grad=True).to(device), 0
         n_frames = ego_motion_gt.size(1)
@@ -144,14 +173,13 @@ class FuseLoss(nn.Module):
             lab, t = inst_labels[sel], time_indice[sel, 1]
             comp = ego_motion_compensation(input_points[sel], t, ego_motion_gt[b])
             rec = reconstruct_sequence(comp, t, lab, bbox_tsfm[b].to(device), n_frames)
-            centre = scatter(rec, lab, dim=0, reduce='mean')
-            assert centre.size(0) == lab.max() + 1
+            centre = scatter(rec, lab, dim=0, dim_size=bbox_tsfm[b].shape[0], reduce='mean')   # K known on the host: no lab.max() sync
             centres.append(centre[lab])
         inst_centers = torch.cat(centres, dim=0)[:, :2]
         gt_offset = (inst_centers - predictions['transformed_points'][:, :2])[fb_mask]
         est_offset = predictions['offset_est'][fb_mask]
         offset_norm_loss = torch.abs(gt_offset - est_offset).mean(dim=0).sum()
-        offset_l2_error = torch.norm(gt_offset - est_offset, p=2, dim=1).mean().item()
+        offset_l2_error = torch.norm(gt_offset - est_offset, p=2, dim=1).mean()       # float after forward()'s single sync
         ngt = gt_offset / (torch.norm(gt_offset, dim=1, p=2).unsqueeze(-1) + _EPS)
         nest = est_offset / (torch.norm(est_offset, dim=1, p=2).unsqueeze(-1) + _EPS)
         offset_dir_loss = (1 - (ngt * nest).sum(-1)).mean()
@@ -199,6 +227,21 @@ class FuseLoss(nn.Module):
             stats['inst_l2_error'] = predictions['inst_l2_error']
             stats['dynamic_inst_l2_error'] = predictions['dynamic_inst_l2_error']
         stats['loss'] = total
+        # one device->host transfer for everything the reference reads with .item() (loss.py:30-35, 226)
+        pend = [('fb_metric', None), ('mos_metric', None), ('offset_l2_error', None)]
+        flat = [stats['fb_metric'].reshape(-1) if torch.is_tensor(stats['fb_metric']) else None,
+                stats['mos_metric'].reshape(-1) if torch.is_tensor(stats['mos_metric']) else None,
+                stats['offset_l2_error'].detach().double().reshape(1) if torch.is_tensor(stats['offset_l2_error']) else None]
+        live = [f for f in flat if f is not None]
+        if live:
+            host = torch.cat(live).cpu().numpy()
+            off = 0
+            for (key, _), f in zip(pend, flat):
+                if f is None:
+                    continue
+                vals = host[off:off + f.numel()]
+                off += f.numel()
+                stats[key] = float(vals[0]) if key == 'offset_l2_error' else _metric_dict(vals.reshape(4, -1))
         return stats
 
 

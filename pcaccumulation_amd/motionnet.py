@@ -129,11 +129,33 @@ class MotionNet(nn.Module):
         fb_est_per_point = ops.gather_rows(fb_est_pillar, pidx.p2v)            # [N,1]
         results['fb_est_per_points'] = fb_est_per_point
 
+        # ---- the ONE host sync of the forward: every size the rest of the pass needs --------------------------------
+        # (the reference syncs at every boolean-mask index and .item(): ~100 times per step; each sync drains the
+        #  launch queue, so host and GPU stop overlapping)
+        if self.mode in ['train', 'val']:
+            fb_mask = torch.logical_or(fb_labels[:, 0] == 1, fb_est_per_point[:, 0] == 1)
+            rec_mask = fb_labels[:, 0] == 1
+        else:
+            fb_mask = fb_est_per_point[:, 0] == 1
+            rec_mask = None
+        sorted_pillars, frame_offsets_dev = pidx.frame_pillars()
+        bg_flag_sorted = ops.gather_rows(fb_est_pillar, sorted_pillars)[:, 0] == 0           # cell order, per frame
+        bg_cum = torch.cat([torch.zeros(1, dtype=torch.int64, device=device), torch.cumsum(bg_flag_sorted, 0)])
+        sizes = torch.cat([frame_offsets_dev.long(), bg_cum[frame_offsets_dev.long()], fb_mask.sum()[None],
+                           (rec_mask.sum() if rec_mask is not None else fb_mask.sum())[None]]).cpu().tolist()
+        nf = B * T + 1
+        frame_offsets, bg_at = sizes[:nf], sizes[nf:2 * nf]
+        bg_counts = [bg_at[i + 1] - bg_at[i] for i in range(B * T)]
+        n_fb, n_rec = int(sizes[2 * nf]), int(sizes[2 * nf + 1])
+        bg_sorted_idx = torch.nonzero_static(bg_flag_sorted, size=bg_at[-1])[:, 0]
+        fb_idx = torch.nonzero_static(fb_mask, size=n_fb)[:, 0]
+        results['_fb_idx'], results['_cell'] = fb_idx, pidx.cell                                # reused by FuseLoss (no re-sync)
+
         # 4. ego motion (fp32)
         geometric_feats = geometric_feats.float()
         geometric_feats = geometric_feats / torch.norm(geometric_feats, p=2, dim=1, keepdim=True)   # no epsilon (trap 7)
-        self.ego_motion_head.forward_pillars(ops.nchw_as_rows(geometric_feats), pillar_mean, fb_est_pillar[:, 0], pidx,
-                                             ego_motion_gt, results)
+        self.ego_motion_head.forward_pillars(ops.nchw_as_rows(geometric_feats), pillar_mean, pidx, ego_motion_gt, results,
+                                             frame_offsets, bg_sorted_idx, bg_counts)
 
         # 5. motion segmentation on ego-motion-compensated features
         pose_est = results['ego_motion_est'].float().detach()
@@ -146,20 +168,16 @@ class MotionNet(nn.Module):
         transformed_points = ops.rigid_transform(input_points, frame_idx, pose_est)
         results['transformed_points'] = transformed_points
 
-        if self.mode in ['train', 'val']:
-            fb_mask = torch.logical_or(fb_labels[:, 0] == 1, fb_est_per_point[:, 0] == 1)
-        else:
-            fb_mask = fb_est_per_point[:, 0] == 1
         full_mos = torch.zeros(transformed_points.size(0), 2, device=device)
         full_offset = torch.zeros(transformed_points.size(0), 2, device=device)
         full_mos[:, 0] = 1
         mos_feats = None
-        if fb_mask.sum() > MIN_POINTS:
+        if n_fb > MIN_POINTS:
             with self._dense():
                 stpn_map = self.motionhead.backbone(warped_feats)
-            mos, offset, mos_feats = self._stpn_heads(stpn_map, transformed_points[fb_mask], batch_idx[fb_mask])
-            full_mos[fb_mask] = mos
-            full_offset[fb_mask] = offset
+            mos, offset, mos_feats = self._stpn_heads(stpn_map, transformed_points[fb_idx], batch_idx[fb_idx])
+            full_mos = full_mos.index_copy(0, fb_idx, mos)
+            full_offset = full_offset.index_copy(0, fb_idx, offset)
         results['mos_est'] = full_mos
         results['offset_est'] = full_offset
         results['rec_est'] = transformed_points.clone()
@@ -167,31 +185,45 @@ class MotionNet(nn.Module):
         # 6. TubeNet
         if self.mode in ['train', 'val']:
             inst_labels = input_dict['inst_labels'][:, 0].long()
-            rec_mask = input_dict['fb_labels'][:, 0] == 1
         else:
             self.cluster(transformed_points, full_mos.argmax(1), full_offset, time_indice, results, use_offset=True)
             inst_labels = results['inst_labels_est']
             rec_mask = inst_labels != 0
-        if rec_mask.sum() > MIN_POINTS:
+            n_rec = int(rec_mask.sum())
+        if n_rec > MIN_POINTS:
+            rec_idx = torch.nonzero_static(rec_mask, size=n_rec)[:, 0]
+            results['_rec_idx'] = rec_idx
             # mos_feats exists whenever rec_mask passes in train/val (fb_mask is a superset of rec_mask)
-            backbone_feats = ops.bilinear_gather(bev_feats, input_points[rec_mask], frame_idx[rec_mask],
+            backbone_feats = ops.bilinear_gather(bev_feats, input_points[rec_idx], frame_idx[rec_idx],
                                                  abs(self.pc_range[0]), abs(self.pc_range[1]))       # temporal_ungrid
-            motion_feats = ops.bilinear_gather(mos_feats, transformed_points[rec_mask], batch_idx[rec_mask],
+            motion_feats = ops.bilinear_gather(mos_feats, transformed_points[rec_idx], batch_idx[rec_idx],
                                                abs(self.pc_range[0]), abs(self.pc_range[1]))          # ungrid
             reconstructor_input = {
-                'inst_labels': inst_labels[rec_mask],
-                'time_indice': time_indice[rec_mask],
-                'transformed_points': transformed_points[rec_mask],
+                'inst_labels': inst_labels[rec_idx],
+                'time_indice': time_indice[rec_idx],
+                'transformed_points': transformed_points[rec_idx],
                 'backbone_feats': backbone_feats,
                 'motion_feats': motion_feats,
                 'inst_motion_gt': input_dict['inst_motion_gt'],
-                'mos_labels': input_dict['sd_labels'][rec_mask, 0].long(),
+                'mos_labels': input_dict['sd_labels'][rec_idx, 0].long(),
                 'ego_motion_est': results['ego_motion_est'],
                 'ego_motion_gt': results['ego_motion_gt'],
             }
             self.reconstructor(reconstructor_input, results)
-            results['rec_est'][rec_mask] = results['sub_rec_est']
+            results['rec_est'] = results['rec_est'].index_copy(0, rec_idx, results['sub_rec_est'])
+        self._resolve_scalars(results)
         return results
+
+    @staticmethod
+    def _resolve_scalars(results):
+        """Python floats for the scalar results the reference produces with .item() (egomotion.py:456, alignnet.py:280-281):
+        one device->host transfer for all of them."""
+        keys = [k for k in ('ego_rot_error', 'ego_trans_error', 'inst_l2_error', 'dynamic_inst_l2_error')
+                if k in results and torch.is_tensor(results[k])]
+        if keys:
+            vals = torch.stack([results[k].detach().float().reshape(()) for k in keys]).cpu().tolist()
+            for k, v in zip(keys, vals):
+                results[k] = v
 
     def _stpn_heads(self, stpn_map, points, batch_idx):
         """Per-point part of STPN.forward (models/stpn.py:91-104) on the already computed map."""

@@ -27,10 +27,15 @@ class DeviceBatcher(object):
         dev = samples[0]['input_points'].device
         coords, p2vs, tis, n_vox = [], [], [], []
         offset = 0
+        launched = []
+        for s in samples:                                                # launch every voxelisation, then ONE host sync
+            pts4 = torch.cat((s['input_points'].float(), s['time_indice'].float()), dim=1)
+            launched.append(vox.voxelize_launch(pts4))
+        counts = torch.cat([l[2] for l in launched]).cpu().tolist()
         for b, s in enumerate(samples):
             t = s['time_indice']
-            pts4 = torch.cat((s['input_points'].float(), t.float()), dim=1)
-            c, p2v, m = vox.voxelize_device(pts4)
+            m = int(counts[b])
+            c, p2v = launched[b][0][:m], launched[b][1]
             bcol = torch.full((m, 1), float(b), dtype=torch.float64, device=dev)
             coords.append(torch.cat((bcol, c.double()), dim=1))
             tis.append(torch.cat((torch.full((t.shape[0], 1), float(b), dtype=torch.float64, device=dev), t.double()), dim=1))

@@ -21,6 +21,11 @@ class Voxelization(object):
         self.max_voxels = int(self.grid_size[0] * self.grid_size[1] * self.grid_size[2] * self.n_sweeps)
         self.device = torch.device('cuda')
 
+    def voxelize_launch(self, points):
+        """Asynchronous part of voxelize_device: (coords [max,4] i32, p2v [N] i32, num_voxels [1] i32 on device)."""
+        return native.voxelize(points.contiguous(), self.voxel_size.tolist(), self.point_cloud_range.tolist(),
+                               self.grid_size.tolist(), self.n_sweeps, self.max_voxels)
+
     def voxelize_device(self, points):
         """points [N,4] f32 cuda -> (coordinates [M,4] i32, point_to_voxel_map [N] i32, num_voxels int), on device."""
         coords, p2v, num = native.voxelize(points.contiguous(), self.voxel_size.tolist(), self.point_cloud_range.tolist(),
