@@ -181,93 +181,129 @@ extern "C" int pcacc_rows_linear(const float *x, const float *in_mask, const flo
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Weight / bias gradient.  dW_aug[n][k] (k in [0,K]; column K is the bias gradient) += sum_r dY[r][n] * Xaug[r][k],
+// Weight / bias gradient.  dW_aug[n][k] (k in [0,K]; column K is the bias gradient) = sum_r dY[r][n] * Xaug[r][k],
 // with Xaug[r][K] = 1.  dy_mask: dY is zeroed where dy_mask <= 0 (post-ReLU layers); x_relu: X := max(X,0) (pre-ReLU layers).
-// Tiles of 32 (n) x 32 (k); a workgroup's 4 waves each walk a strided share of the row pairs for up to TPB tiles.
+//
+// A workgroup (4 waves) walks chunks of WG_ROWS rows: the chunk's dY and X rows are contiguous in HBM and are staged
+// into LDS with 16-byte coalesced loads (masks / ReLU applied on the way), so every row is read from HBM exactly once
+// however many 32x32 output tiles there are.  Tiles are dealt round-robin to the waves; each tile is a chain of
+// v_mfma_f32_32x32x2_f32 (A = dY^T: n x 2 rows, B = X: 2 rows x k) whose operands are two ds_read_b32 per MFMA.
+// Workgroup partials go to the zero-filled output with one fp32 atomic per element per workgroup.
 // ---------------------------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-#define WG_TILES 4
+#define WG_ROWS 32
+#define WG_MAX_TILES 6            // tiles per wave: ceil(4*5 / 4) for 128 x 129, with one spare
 
 __global__ __launch_bounds__(256) void rows_wgrad_kernel(const float *__restrict__ dY, const float *__restrict__ dy_mask,
                                                          const float *__restrict__ X, int x_relu, int64_t rows, int K, int N,
                                                          int k_tiles, int n_tile_total, float *dW)
 {
-    __shared__ float red[WG_TILES * 1024];
-    const int lane = threadIdx.x & 63;
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // [WG_ROWS][NS] dY, then [WG_ROWS][KS] X
+    const int NS = N + 4, KS = K + 4;                                // +4: rows stay 16-byte aligned, bank-spread
+    float *sdy = lds, *sx = lds + WG_ROWS * NS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int half = lane >> 5, li = lane & 31;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int n_waves = gridDim.x * 4;
-    const int tile0 = blockIdx.y * WG_TILES;
-    f32x16 acc0, acc1, acc2, acc3;
+    f32x16 acc[WG_MAX_TILES];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; acc3[r] = 0.f; }
-    for (int i = threadIdx.x; i < WG_TILES * 1024; i += 256) red[i] = 0.f;
+    for (int t = 0; t < WG_MAX_TILES; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-#define WG_STEP(ACC, T)                                                                               \
-    if (tile0 + T < n_tile_total) {                                                                   \
-        const int n = ((tile0 + T) / k_tiles) * 32 + li;                                              \
-        const int k = ((tile0 + T) % k_tiles) * 32 + li;                                              \
-        float a = 0.f, b = 0.f;                                                                       \
-        if (rv && n < N) {                                                                            \
-            a = dY[r * N + n];                                                                        \
-            if (dy_mask && !(dy_mask[r * N + n] > 0.f)) a = 0.f;                                      \
-        }                                                                                             \
-        if (rv) {                                                                                     \
-            if (k < K) { b = X[r * K + k]; if (x_relu) b = fmaxf(b, 0.f); }                           \
-            else if (k == K) b = 1.0f;                                                                \
-        }                                                                                             \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, ACC, 0, 0, 0);                               \
+    const int64_t n_chunks = (rows + WG_ROWS - 1) / WG_ROWS;
+    for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+        const int64_t row0 = ch * WG_ROWS;
+        const int nrow = (int)min((int64_t)WG_ROWS, rows - row0);
+        // stage dY (N floats per row) and X (K floats per row); scalar path when the width is not a multiple of 4
+        if ((N & 3) == 0) {
+            const float4 *g = reinterpret_cast<const float4 *>(dY + row0 * N);
+            const float4 *m4 = dy_mask ? reinterpret_cast<const float4 *>(dy_mask + row0 * N) : nullptr;
+            for (int i = threadIdx.x; i < WG_ROWS * N / 4; i += 256) {
+                const int e = i * 4, r = e / N, c = e % N;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < nrow) {
+                    v = g[i];
+                    if (m4) { const float4 mk = m4[i]; if (!(mk.x > 0.f)) v.x = 0.f; if (!(mk.y > 0.f)) v.y = 0.f; if (!(mk.z > 0.f)) v.z = 0.f; if (!(mk.w > 0.f)) v.w = 0.f; }
+                }
+                *reinterpret_cast<float4 *>(&sdy[r * NS + c]) = v;
+            }
+        } else {
+            for (int i = threadIdx.x; i < WG_ROWS * N; i += 256) {
+                const int r = i / N, c = i % N;
+                float v = 0.f;
+                if (r < nrow) { v = dY[row0 * N + i]; if (dy_mask && !(dy_mask[row0 * N + i] > 0.f)) v = 0.f; }
+                sdy[r * NS + c] = v;
+            }
+        }
+        if ((K & 3) == 0) {
+            const float4 *g = reinterpret_cast<const float4 *>(X + row0 * K);
+            for (int i = threadIdx.x; i < WG_ROWS * K / 4; i += 256) {
+                const int e = i * 4, r = e / K, c = e % K;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < nrow) {
+                    v = g[i];
+                    if (x_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                }
+                *reinterpret_cast<float4 *>(&sx[r * KS + c]) = v;
+            }
+        } else {
+            for (int i = threadIdx.x; i < WG_ROWS * K; i += 256) {
+                const int r = i / K, c = i % K;
+                float v = 0.f;
+                if (r < nrow) { v = X[row0 * K + i]; if (x_relu) v = fmaxf(v, 0.f); }
+                sx[r * KS + c] = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < WG_MAX_TILES; ++t) {
+            const int tile = wave + 4 * t;                           // uniform per wave
+            if (tile < n_tile_total) {
+                const int n = (tile / k_tiles) * 32 + li;
+                const int k = (tile % k_tiles) * 32 + li;
+                const bool nv = n < N;
+                const int kind = k < K ? 0 : (k == K ? 1 : 2);       // data column / ones column (bias) / padding
+#pragma unroll 4
+                for (int r = 0; r < WG_ROWS; r += 2) {
+                    const int rr = r + half;
+                    const float a = nv ? sdy[rr * NS + n] : 0.f;
+                    const float b = kind == 0 ? sx[rr * KS + k] : ((kind == 1 && rr < nrow) ? 1.0f : 0.f);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
     }
-    for (int64_t r0 = (int64_t)wave * 2; r0 < rows; r0 += (int64_t)n_waves * 2) {
-        const int64_t r = r0 + half;
-        const bool rv = r < rows;
-        WG_STEP(acc0, 0)
-        WG_STEP(acc1, 1)
-        WG_STEP(acc2, 2)
-        WG_STEP(acc3, 3)
-    }
-#undef WG_STEP
-    __syncthreads();
-    // reduce the 4 waves of the workgroup in LDS (ds_add_f32), then one global atomic per element per workgroup
-#define WG_FLUSH(ACC, T)                                                                              \
-    if (tile0 + T < n_tile_total) {                                                                   \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                              \
-            const int i = (r & 3) + 8 * (r >> 2) + 4 * half;                                          \
-            atomicAdd(&red[T * 1024 + i * 32 + li], ACC[r]);                                          \
-        }                                                                                             \
-    }
-    WG_FLUSH(acc0, 0)
-    WG_FLUSH(acc1, 1)
-    WG_FLUSH(acc2, 2)
-    WG_FLUSH(acc3, 3)
-#undef WG_FLUSH
-    __syncthreads();
     const int KA = K + 1;
-    for (int e = threadIdx.x; e < WG_TILES * 1024; e += 256) {
-        const int t = e >> 10, i = (e >> 5) & 31, j = e & 31;
-        const int tile = tile0 + t;
-        if (tile >= n_tile_total) continue;
-        const int n = (tile / k_tiles) * 32 + i, k = (tile % k_tiles) * 32 + j;
-        if (n < N && k < KA) atomicAdd(&dW[(int64_t)n * KA + k], red[e]);
+#pragma unroll
+    for (int t = 0; t < WG_MAX_TILES; ++t) {
+        const int tile = wave + 4 * t;
+        if (tile < n_tile_total) {
+            const int nb = (tile / k_tiles) * 32, k = (tile % k_tiles) * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = nb + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (n < N && k < KA) atomicAdd(&dW[(int64_t)n * KA + k], acc[t][r]);
+            }
+        }
     }
 }
 
 extern "C" int pcacc_rows_wgrad(const float *dy, const float *dy_mask, const float *x, int x_relu, int64_t rows, int k, int n,
                                 float *dw_aug, void *stream)
 {
-    if (rows < 0 || k <= 0 || n <= 0 || k > 512 || n > 512 || !dw_aug) return PCACC_E_ARG;
+    if (rows < 0 || k <= 0 || n <= 0 || k > 128 || n > 128 || !dw_aug) return PCACC_E_ARG;
     hipStream_t s = pcacc_stream(stream);
     if (hipMemsetAsync(dw_aug, 0, (size_t)n * (k + 1) * sizeof(float), s) != hipSuccess) return PCACC_E_LAUNCH;
     if (rows == 0) return PCACC_OK;
     if (!dy || !x) return PCACC_E_ARG;
     const int k_tiles = (k + 1 + 31) / 32, n_tiles = (n + 31) / 32;
     const int total = k_tiles * n_tiles;
-    const int gy = (total + WG_TILES - 1) / WG_TILES;
-    int gx = (int)((rows / 2 + 4 * 64 - 1) / (4 * 64));          // >= 64 row pairs per wave
-    if (gx < 1) gx = 1;
-    const int cap = (PCACC_CUS * 2) / gy > 0 ? (PCACC_CUS * 2) / gy : 1;
-    if (gx > cap) gx = cap;
-    rows_wgrad_kernel<<<dim3(gx, gy), 256, 0, s>>>(dy, dy_mask, x, x_relu, rows, k, n, k_tiles, total, dw_aug);
+    if (total > 4 * WG_MAX_TILES) return PCACC_E_ARG;
+    const int64_t n_chunks = (rows + WG_ROWS - 1) / WG_ROWS;
+    int grid = PCACC_CUS * 3;
+    if (grid > n_chunks) grid = (int)n_chunks;
+    const size_t lds = (size_t)WG_ROWS * (n + 4 + k + 4) * sizeof(float);
+    rows_wgrad_kernel<<<grid, 256, lds, s>>>(dy, dy_mask, x, x_relu, rows, k, n, k_tiles, total, dw_aug);
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
 }

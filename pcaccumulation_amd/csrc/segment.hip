@@ -253,8 +253,14 @@ __global__ __launch_bounds__(256) void seg_level1(const float4 *__restrict__ src
                 acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
             }
         }
-        pval[(int64_t)p * LPP + sub] = acc;
-        if (IS_MAX) parg[(int64_t)p * LPP + sub] = bi;
+        if (IS_MAX) {
+            pval[(int64_t)p * LPP + sub] = acc;
+            parg[(int64_t)p * LPP + sub] = bi;
+        } else if (e > b) {
+            // sums need no second level: one fp32 atomic per (piece, channel) into the zero-filled output
+            float *o = reinterpret_cast<float *>(pval) + ((int64_t)s * LPP + sub) * 4;
+            atomicAdd(o + 0, acc.x); atomicAdd(o + 1, acc.y); atomicAdd(o + 2, acc.z); atomicAdd(o + 3, acc.w);
+        }
     }
 }
 
@@ -315,17 +321,21 @@ static int seg_two_level(const float *src, int c, const int32_t *seg_offsets, co
     const size_t P = (size_t)seg_max_pieces(n, m);
     float4 *pval = reinterpret_cast<float4 *>(ws); ws += pcacc_align(P * c * 4);
     int4 *parg = reinterpret_cast<int4 *>(ws);
+    const float4 *in4 = reinterpret_cast<const float4 *>(src);
+    float4 *out4 = reinterpret_cast<float4 *>(out);
+    int4 *arg4 = reinterpret_cast<int4 *>(arg);
     const int chunks = pcacc_chunks(m);
     seg_piece_counts<<<pcacc_grid(m, 256), 256, 0, s>>>(seg_offsets, m, pieces);
     chunk_sums_i32<<<chunks, 256, 0, s>>>(pieces, m, sums);
     scan_chunk_sums<<<1, 1024, 0, s>>>(sums, chunks, nullptr, -1);
     chunk_scan_i32<<<chunks, 256, 0, s>>>(pieces, m, sums, piece_off, 1);
-    const float4 *in4 = reinterpret_cast<const float4 *>(src);
-    float4 *out4 = reinterpret_cast<float4 *>(out);
-    int4 *arg4 = reinterpret_cast<int4 *>(arg);
+    if (!IS_MAX) {       // sum: level 1 adds into `out` directly
+        if (hipMemsetAsync(out, 0, (size_t)m * c * sizeof(float), s) != hipSuccess) return PCACC_E_LAUNCH;
+        pval = out4;
+    }
 #define LAUNCH2(L)                                                                                                   \
     seg_level1<L, IS_MAX><<<pcacc_grid((int64_t)P * L, 256), 256, 0, s>>>(in4, seg_offsets, order, piece_off, (int)m, pval, parg); \
-    seg_level2<L, IS_MAX><<<pcacc_grid(m * L, 256), 256, 0, s>>>(pval, parg, piece_off, m, out4, arg4)
+    if (IS_MAX) seg_level2<L, IS_MAX><<<pcacc_grid(m * L, 256), 256, 0, s>>>(pval, parg, piece_off, m, out4, arg4)
     switch (c / 4) {
         case 1: LAUNCH2(1); break;
         case 2: LAUNCH2(2); break;
