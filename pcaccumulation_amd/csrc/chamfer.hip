@@ -12,11 +12,22 @@
 //     rule (strict '<' while scanning targets in ascending order, chamfer_distance.cu:39,49,129).
 // Distances are computed as (x*x + y*y) + z*z with x = target - query, un-fused, so they are bit-identical
 // to the scalar C++ path (chamfer_distance.cpp:72-76), which is the oracle twin that runs without CUDA.
+// (A non-finite distance at the very first target is the one case that differs: the reference takes target 0
+// unconditionally, here a NaN never becomes the best.)
 #include "common.h"
 
-#define CH_QPT 2
+#define CH_QPT 4            // queries per lane (two packed pairs)
 #define CH_BLOCK 256
+#define CH_CHUNK 8          // targets per skip test
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Targets are visited in chunks of CH_CHUNK.  For each chunk the squared distances of the lane's queries are computed with
+// packed fp32 math (v_pk_add/v_pk_mul: two queries per instruction, still one IEEE rounding per operation, nothing fused),
+// then only the chunk MINIMUM is compared with the running best.  The sequential strict-'<' scan that fixes the index is
+// replayed for the chunk only when some lane of the wave actually improves -- about ln(m) times per query instead of m.
+// Skipping a chunk is exact: no target in it is strictly closer than the current best, so the reference's scan would not
+// have updated either.
 __global__ __launch_bounds__(CH_BLOCK) void chamfer_nn_kernel(const float *__restrict__ q, int n, const float *__restrict__ tg, int m,
                                                               int m_per_split, unsigned long long *__restrict__ packed,
                                                               float *__restrict__ dist, int32_t *__restrict__ idx, int direct)
@@ -29,29 +40,60 @@ __global__ __launch_bounds__(CH_BLOCK) void chamfer_nn_kernel(const float *__res
     const int k_end = min(m, k_begin + m_per_split);
     const int j0 = (blockIdx.x * CH_BLOCK + threadIdx.x) * CH_QPT;
 
-    float qx[CH_QPT], qy[CH_QPT], qz[CH_QPT], best[CH_QPT];
+    f32x2 qx[CH_QPT / 2], qy[CH_QPT / 2], qz[CH_QPT / 2];
+    float best[CH_QPT];
     int besti[CH_QPT];
 #pragma unroll
     for (int r = 0; r < CH_QPT; ++r) {
         const int j = min(j0 + r, n - 1);
-        qx[r] = q[(int64_t)j * 3 + 0];
-        qy[r] = q[(int64_t)j * 3 + 1];
-        qz[r] = q[(int64_t)j * 3 + 2];
+        qx[r / 2][r & 1] = q[(int64_t)j * 3 + 0];
+        qy[r / 2][r & 1] = q[(int64_t)j * 3 + 1];
+        qz[r / 2][r & 1] = q[(int64_t)j * 3 + 2];
         best[r] = __builtin_inff();
         besti[r] = k_begin;
     }
-    for (int k = k_begin; k < k_end; ++k) {
-        const float tx = tg[(int64_t)k * 3 + 0];      // wave-uniform -> scalar loads
-        const float ty = tg[(int64_t)k * 3 + 1];
-        const float tz = tg[(int64_t)k * 3 + 2];
+    int k = k_begin;
+    for (; k + CH_CHUNK <= k_end; k += CH_CHUNK) {
+        f32x2 d[CH_CHUNK][CH_QPT / 2];
+#pragma unroll
+        for (int c = 0; c < CH_CHUNK; ++c) {
+            const float tx = tg[(int64_t)(k + c) * 3 + 0];      // wave-uniform -> scalar loads
+            const float ty = tg[(int64_t)(k + c) * 3 + 1];
+            const float tz = tg[(int64_t)(k + c) * 3 + 2];
+#pragma unroll
+            for (int p = 0; p < CH_QPT / 2; ++p) {
+                const f32x2 x = (f32x2){tx, tx} - qx[p], y = (f32x2){ty, ty} - qy[p], z = (f32x2){tz, tz} - qz[p];
+                d[c][p] = (x * x + y * y) + z * z;
+            }
+        }
+        bool improve = false;
 #pragma unroll
         for (int r = 0; r < CH_QPT; ++r) {
-            const float x = tx - qx[r], y = ty - qy[r], z = tz - qz[r];
-            const float d = (x * x + y * y) + z * z;
-            // first target of the range is always taken (the reference's `k == 0 ||`), so a NaN
-            // distance at k_begin behaves as in the reference
-            const bool take = (k == k_begin) || (d < best[r]);
-            best[r] = take ? d : best[r];
+            float mn = d[0][r / 2][r & 1];
+#pragma unroll
+            for (int c = 1; c < CH_CHUNK; ++c) mn = fminf(mn, d[c][r / 2][r & 1]);
+            improve |= mn < best[r];
+        }
+        if (__any(improve)) {
+#pragma unroll
+            for (int c = 0; c < CH_CHUNK; ++c)
+#pragma unroll
+                for (int r = 0; r < CH_QPT; ++r) {
+                    const float dv = d[c][r / 2][r & 1];
+                    const bool take = dv < best[r];
+                    best[r] = take ? dv : best[r];
+                    besti[r] = take ? k + c : besti[r];
+                }
+        }
+    }
+    for (; k < k_end; ++k) {                                      // tail (< CH_CHUNK targets)
+        const float tx = tg[(int64_t)k * 3 + 0], ty = tg[(int64_t)k * 3 + 1], tz = tg[(int64_t)k * 3 + 2];
+#pragma unroll
+        for (int r = 0; r < CH_QPT; ++r) {
+            const float x = tx - qx[r / 2][r & 1], y = ty - qy[r / 2][r & 1], z = tz - qz[r / 2][r & 1];
+            const float dv = (x * x + y * y) + z * z;
+            const bool take = dv < best[r];
+            best[r] = take ? dv : best[r];
             besti[r] = take ? k : besti[r];
         }
     }
