@@ -164,7 +164,7 @@ class EgoMotionHead(nn.Module):
         return points_list, getters, bg, gt
 
     def _estimate_pairs(self, sequences, T, perm_matrix_list, relative_pose_est_list, relative_pose_gt_list,
-                        chained_pose_est_list, chained_pose_gt_list):
+                        chained_pose_est_list, chained_pose_gt_list, normalise=False):
         """All (T-1) registrations of all batch elements in ONE batched Sinkhorn / Kabsch evaluation
         ([P,1024,1024] instead of P sequential [1,1024,1024] problems: the reference issues ~60 tiny launches and
         several host syncs per pair).  Key points are still drawn pair by pair in the reference's
@@ -186,8 +186,14 @@ class EgoMotionHead(nn.Module):
                 fs.append(feats_list[ref](si)); cs.append(points_list[ref][si])
                 ft.append(feats_list[0](ti)); ct.append(points_list[0][ti])
                 durations.append((frame_idx + 1) / self.frequence)
-        feats_s, coor_s = torch.stack(fs), torch.stack(cs)                  # [P,k,C], [P,k,3]
-        feats_t, coor_t = torch.stack(ft), torch.stack(ct)
+        feats_s, coor_s = torch.stack(fs).float(), torch.stack(cs)          # [P,k,C], [P,k,3]
+        feats_t, coor_t = torch.stack(ft).float(), torch.stack(ct)
+        if normalise:
+            # models/motionnet.py:199 divides the WHOLE [B*T,64,Ny,Nx] map by its per-cell L2 norm (no epsilon); only the
+            # 2*P*1024 key-point rows are ever read, and the norm is per cell, so normalising the gathered rows is the same
+            # arithmetic on 0.03 % of the data (and of the backward).
+            feats_s = feats_s / torch.norm(feats_s, p=2, dim=2, keepdim=True)
+            feats_t = feats_t / torch.norm(feats_t, p=2, dim=2, keepdim=True)
         thr2 = (torch.tensor(durations, dtype=torch.float32) * self.ego_max_speed) ** 2
         thr2 = thr2.to(dev)
         support = (square_distance(coor_s, coor_t, normalised=False) < thr2[:, None, None]).float()     # :173-174
@@ -246,7 +252,7 @@ class EgoMotionHead(nn.Module):
 
     def forward_pillars(self, geo_rows, pillar_mean, pidx, ego_motion_gt, results, frame_offsets, bg_sorted_idx, bg_counts):
         """Same computation as forward(), fed from pillar-level tensors instead of dense canvases, with no host sync:
-          geo_rows [n_cells, C]  rows of the L2-normalised feature map;  pillar_mean [M,3]
+          geo_rows [n_cells, C]  rows of the (un-normalised) ego feature map, normalised after the key-point gather;  pillar_mean [M,3]
           frame_offsets  host list [B*T+1]: slice of the cell-ordered pillar list (pidx.frame_pillars) per frame
           bg_sorted_idx  LongTensor: positions in that cell-ordered list whose pillar is predicted background
           bg_counts      host list [B*T]: how many of them fall into each frame
@@ -269,7 +275,7 @@ class EgoMotionHead(nn.Module):
                 bg_list.append((bg_sorted_idx[bg_start:bg_start + n_bg] - lo, n_bg))
                 bg_start += n_bg
             sequences.append((points_list, getters, bg_list, ego_motion_gt[b]))
-        total_l1, total_l2, count = self._estimate_pairs(sequences, T, perm_l, rel_est, rel_gt, ch_est, ch_gt)
+        total_l1, total_l2, count = self._estimate_pairs(sequences, T, perm_l, rel_est, rel_gt, ch_est, ch_gt, normalise=True)
         self._finish(B, T, total_l1, total_l2, count, perm_l, ch_est, ch_gt, results)
 
     def forward(self, bev_feats, fb_est, occ_map, pts_mean_map, ego_motion_gt, input_points, fb_est_per_point, time_indice, results):

@@ -118,8 +118,15 @@ class FuseLoss(nn.Module):
 
     def get_seg_loss(self, gt, est):
         """libs/loss.py:110-137."""
-        criterion = torch.nn.CrossEntropyLoss(weight=self.get_ce_weights(gt), ignore_index=self.ignore_index)
-        stats = {'bce_loss': criterion(est, gt), 'lovasz_loss': self.lovasz_loss(self.softmax(est), gt)}
+        # CrossEntropyLoss(weight, ignore_index) written out: sum_i w[y_i] * (-log p_i[y_i]) / sum_i w[y_i] over kept rows.
+        # (the library's weighted nll reduction is a single-workgroup kernel: 0.6 ms forward + 0.7 ms backward per call)
+        w = self.get_ce_weights(gt)
+        keep = gt != self.ignore_index
+        safe = torch.where(keep, gt, torch.zeros_like(gt))
+        picked = torch.log_softmax(est, dim=1).gather(1, safe[:, None])[:, 0]
+        wi = w[safe] * keep
+        ce = -(wi * picked).sum() / wi.sum()
+        stats = {'bce_loss': ce, 'lovasz_loss': self.lovasz_loss(self.softmax(est), gt)}
         stats['metric'] = _iou_counts(est.argmax(1), gt, self.n_classes, self.ignore_index)    # device tensor, see forward()
         return stats
 

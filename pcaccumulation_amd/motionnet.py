@@ -151,9 +151,8 @@ class MotionNet(nn.Module):
         fb_idx = torch.nonzero_static(fb_mask, size=n_fb)[:, 0]
         results['_fb_idx'], results['_cell'] = fb_idx, pidx.cell                                # reused by FuseLoss (no re-sync)
 
-        # 4. ego motion (fp32)
-        geometric_feats = geometric_feats.float()
-        geometric_feats = geometric_feats / torch.norm(geometric_feats, p=2, dim=1, keepdim=True)   # no epsilon (trap 7)
+        # 4. ego motion (fp32).  The per-cell L2 normalisation of motionnet.py:199 (no epsilon, trap 7) is applied to the
+        #    gathered key-point rows inside the head instead of to the whole map.
         self.ego_motion_head.forward_pillars(ops.nchw_as_rows(geometric_feats), pillar_mean, pidx, ego_motion_gt, results,
                                              frame_offsets, bg_sorted_idx, bg_counts)
 
