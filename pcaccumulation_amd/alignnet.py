@@ -34,100 +34,93 @@ class AlignNet(BaseModel):
             raise NotImplementedError('model.tpointnet_icp (Open3D ICP) is off the hot path (configs/default.yaml:117)')
 
     def padding(self, inst_indice, time_indice, inst_motion):
-        """models/alignnet.py:115-163: drop empty instances, relabel, and for instances without anchor-frame
-        points duplicate the points of their first populated frame as frame-0 padding."""
+        """models/alignnet.py:115-163.  Returns (extra point indices or None, motions of the non-empty instances,
+        compacted instance label per point).  Instances that have points but none in the anchor frame get the points of
+        their first populated frame appended as frame-0 stand-ins."""
         device = inst_indice.device
-        K, T, _, _ = inst_motion.size()
-        frame_indice = (inst_indice * T + time_indice).long()
-        count = torch.ones(frame_indice.size(0), device=device)
-        frame_count = scatter(count, frame_indice, dim=0, dim_size=K * T, reduce='sum')
-        inst_count = scatter(count, inst_indice, dim=0, dim_size=K, reduce='sum')
-        anchor_count = frame_count[::T]
-        padding_list = []
-        sel_inst = (anchor_count == 0) & (inst_count > 0)
-        if sel_inst.sum():
-            for inst_idx in torch.where(sel_inst)[0].tolist():
-                c_count = frame_count[inst_idx * T:(inst_idx + 1) * T]
-                pad_frame_idx = inst_idx * T + torch.where(c_count > 0)[0][0]
-                padding_list.append(torch.where(frame_indice == pad_frame_idx)[0])
-        padding_indice = torch.cat(padding_list) if len(padding_list) else None
-        sel_inst = inst_count > 0
-        inst_motion = inst_motion[sel_inst]
-        mapping = -1 * torch.ones(K).long()
-        mapping[sel_inst.cpu()] = torch.arange(int(sel_inst.sum()))
-        updated = mapping.to(device)[inst_indice]
-        assert updated.min() != -1
-        return padding_indice, inst_motion, updated
+        K, T = inst_motion.size(0), inst_motion.size(1)
+        slot = (inst_indice * T + time_indice).long()
+        ones = torch.ones(slot.size(0), device=device)
+        per_slot = scatter(ones, slot, dim=0, dim_size=K * T, reduce='sum')
+        per_inst = scatter(ones, inst_indice, dim=0, dim_size=K, reduce='sum')
+        orphan = (per_slot[::T] == 0) & (per_inst > 0)
+        extra = []
+        if orphan.sum():
+            for k in torch.where(orphan)[0].tolist():
+                first = torch.where(per_slot[k * T:(k + 1) * T] > 0)[0][0]
+                extra.append(torch.where(slot == k * T + first)[0])
+        extra = torch.cat(extra) if extra else None
+        alive = per_inst > 0
+        relabel = -1 * torch.ones(K).long()
+        relabel[alive.cpu()] = torch.arange(int(alive.sum()))
+        compact = relabel.to(device)[inst_indice]
+        assert compact.min() != -1
+        return extra, inst_motion[alive], compact
+
+    def _merge_batch_instances(self, labels, batch_col, motions):
+        """Instance ids of sample b are shifted by the number of instances in samples < b (alignnet.py:199-206)."""
+        base = 0
+        for b, m in enumerate(motions):
+            sel = batch_col == b
+            if sel.sum():
+                labels[sel] += base
+                base += m.size(0)
+        return labels, torch.cat(motions)
 
     def forward(self, input_dict, results):
-        """models/alignnet.py:166-285."""
-        mos_labels = input_dict['mos_labels']
-        inst_labels = input_dict['inst_labels'].clone()
-        time_indice = input_dict['time_indice']
-        transformed_points = input_dict['transformed_points'].clone()
-        inst_motion_gt = input_dict['inst_motion_gt']
-        backbone_feats = input_dict['backbone_feats']
-        mos_feats = input_dict['motion_feats']
-        ego_motion_est, ego_motion_gt = input_dict['ego_motion_est'], input_dict['ego_motion_gt']
-        device = inst_labels.device
-        n_points = inst_labels.size(0)
-
+        """models/alignnet.py:166-285: iterative per-instance pose regression on the foreground points."""
+        moving = input_dict['mos_labels']
+        labels = input_dict['inst_labels'].clone()
+        tcol = input_dict['time_indice']
+        start_points = input_dict['transformed_points'].clone()
+        device = labels.device
+        n_pts = labels.size(0)
+        gt_list = input_dict['inst_motion_gt']
         if self.mode == 'test':
-            n_instance = inst_labels.max() + 1
-            inst_motion_gt = [torch.eye(4)[None, None].repeat(n_instance, self.n_frames, 1, 1).to(device)]
-        updated_inst_motion = update_gt_inst_motion(inst_motion_gt, ego_motion_gt, ego_motion_est)
+            gt_list = [torch.eye(4)[None, None].repeat(labels.max() + 1, self.n_frames, 1, 1).to(device)]
+        # GT instance motion relative to the ESTIMATED ego motion, all samples merged into one instance table
+        labels, remaining = self._merge_batch_instances(
+            labels, tcol[:, 0], update_gt_inst_motion(gt_list, input_dict['ego_motion_gt'], input_dict['ego_motion_est']))
+        extra, remaining, labels = self.padding(labels, tcol[:, 1], remaining)
+        gt_motion = remaining.clone()
+        K, T = remaining.size(0), remaining.size(1)
 
-        running_idx = 0
-        for b in range(len(updated_inst_motion)):
-            sel = time_indice[:, 0] == b
-            if sel.sum():
-                inst_labels[sel] += running_idx
-                running_idx += updated_inst_motion[b].size(0)
-        updated_inst_motion = torch.cat(updated_inst_motion)
+        take = torch.arange(n_pts, device=device).long()
+        frames = tcol[:, 1]
+        if extra is not None:                                              # stand-in points live in frame 0
+            frames = torch.cat((frames, torch.zeros_like(extra).long()))
+            take = torch.cat((take, extra))
+        p_labels, cloud = labels[take], start_points[take]
+        net_in = {'frame_feats': input_dict['backbone_feats'][take], 'time_indice': frames, 'inst_labels': p_labels,
+                  'mos_labels': moving[take], 'mos_feats': input_dict['motion_feats'][take]}
 
-        padding_indice, updated_inst_motion, inst_labels = self.padding(inst_labels, time_indice[:, 1], updated_inst_motion)
-        inst_motion_gt = updated_inst_motion.clone()
-        K, T, _, _ = updated_inst_motion.size()
-        if padding_indice is not None:
-            padded_time_indice = torch.cat((time_indice[:, 1], torch.zeros_like(padding_indice).long()))
-            padding_indice = torch.cat((torch.arange(n_points, device=device).long(), padding_indice))
-        else:
-            padding_indice = torch.arange(n_points, device=device).long()
-            padded_time_indice = time_indice[:, 1]
-
-        padded_inst_labels = inst_labels[padding_indice]
-        padded_points = transformed_points[padding_indice]
-        tpointnet_input = {'frame_feats': backbone_feats[padding_indice], 'time_indice': padded_time_indice,
-                           'inst_labels': padded_inst_labels, 'mos_labels': mos_labels[padding_indice],
-                           'mos_feats': mos_feats[padding_indice]}
         results['tpointnet_loss_terms'] = dict()
-        final_pose_est = None
-        for idx in range(self.n_iterations):
-            tpointnet_input['points'] = padded_points.detach()
-            tpointnet_input['inst_motion_gt'] = updated_inst_motion.detach()
-            predictions = self.alignment(tpointnet_input)
-            results['tpointnet_loss_terms'][f'{idx}_th'] = predictions
-            c_pose = predictions['inst_est_motion']
-            padded_points = reconstruct_sequence(padded_points, padded_time_indice, padded_inst_labels, c_pose, T)
-            # re-express the remaining GT motion after this iteration's estimate (alignnet.py:259-263)
-            updated_inst_motion = updated_inst_motion.view(-1, 4, 4)
-            c_pose = c_pose.view(-1, 4, 4)
-            updated_inst_motion[:, :3, :3] = torch.matmul(updated_inst_motion[:, :3, :3], c_pose[:, :3, :3].transpose(1, 2))
-            updated_inst_motion[:, :3, 3] = updated_inst_motion[:, :3, 3] - torch.matmul(
-                updated_inst_motion[:, :3, :3], c_pose[:, :3, 3].unsqueeze(-1)).squeeze(-1)
-            updated_inst_motion = updated_inst_motion.view(K, T, 4, 4)
-            final_pose_est = c_pose if final_pose_est is None else torch.matmul(c_pose, final_pose_est)
+        total = None
+        for it in range(self.n_iterations):
+            net_in['points'] = cloud.detach()
+            net_in['inst_motion_gt'] = remaining.detach()
+            out = self.alignment(net_in)
+            results['tpointnet_loss_terms'][f'{it}_th'] = out
+            step = out['inst_est_motion']                                  # [K,T,4,4]
+            cloud = reconstruct_sequence(cloud, frames, p_labels, step, T)
+            # what is left of the GT motion after this step: remaining <- remaining @ step^-1 (alignnet.py:259-263)
+            rem, stp = remaining.view(-1, 4, 4), step.view(-1, 4, 4)
+            rem[:, :3, :3] = torch.matmul(rem[:, :3, :3], stp[:, :3, :3].transpose(1, 2))
+            rem[:, :3, 3] = rem[:, :3, 3] - torch.matmul(rem[:, :3, :3], stp[:, :3, 3].unsqueeze(-1)).squeeze(-1)
+            remaining = rem.view(K, T, 4, 4)
+            total = stp if total is None else torch.matmul(stp, total)
+        total = total.view(K, T, 4, 4)
 
-        final_pose_est = final_pose_est.view(K, T, 4, 4)
-        rec_est = reconstruct_sequence(input_dict['transformed_points'], time_indice[:, 1], inst_labels, final_pose_est, T)
-        rec_gt = reconstruct_sequence(input_dict['transformed_points'], time_indice[:, 1], inst_labels, inst_motion_gt, T)
-        l2_error = torch.norm(rec_est - rec_gt, p=2, dim=1)
-        weights = time_indice[:, 1] > 0
-        weights_mos = (input_dict['mos_labels'] == 1) & (time_indice[:, 1] > 0)
+        src = input_dict['transformed_points']
+        moved_est = reconstruct_sequence(src, tcol[:, 1], labels, total, T)
+        moved_gt = reconstruct_sequence(src, tcol[:, 1], labels, gt_motion, T)
+        err = torch.norm(moved_est - moved_gt, p=2, dim=1)
+        later = tcol[:, 1] > 0
+        later_moving = (moving == 1) & later
         # 0-d tensors; MotionNet.forward converts them to floats in its single end-of-forward sync (alignnet.py:280-281)
-        results['inst_l2_error'] = (l2_error * weights).sum() / (weights.sum() + _EPS)
-        results['dynamic_inst_l2_error'] = (l2_error * weights_mos).sum() / (weights_mos.sum() + _EPS)
-        results['inst_labels_adjusted'] = inst_labels
-        results['inst_pose_est'] = final_pose_est
-        results['sub_rec_est'] = rec_est
+        results['inst_l2_error'] = (err * later).sum() / (later.sum() + _EPS)
+        results['dynamic_inst_l2_error'] = (err * later_moving).sum() / (later_moving.sum() + _EPS)
+        results['inst_labels_adjusted'] = labels
+        results['inst_pose_est'] = total
+        results['sub_rec_est'] = moved_est
         return results

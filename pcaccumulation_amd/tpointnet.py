@@ -132,7 +132,8 @@ def _embed(seq, x):
 
 
 class TPointNet(BaseModel):
-    """models/tpointnet.py:167-305."""
+    """Per-(instance, frame) pose regressor, models/tpointnet.py:167-305, organised here as four steps:
+    frame weights -> pooled embeddings -> pose regression -> losses / un-centring."""
 
     def __init__(self, config):
         BaseModel.__init__(self, config)
@@ -143,61 +144,69 @@ class TPointNet(BaseModel):
                                        nn.Linear(256, 128), nn.BatchNorm1d(128), nn.ReLU(), nn.Linear(128, 7))
         self.min_points_per_frame = config['tpointnet']['min_points']
 
+    # -- step 1 ---------------------------------------------------------------------------------------------
+    def _frame_weights(self, slot, per_slot, moving, n_inst, n_slots, device):
+        """Weight of every (instance, frame) slot: populated enough, moving (static slots get 0.2 -- assigned into an
+        integer tensor in the reference, models/tpointnet.py:231-233, i.e. 0; kept), later frames count more."""
+        ones = torch.ones(slot.size(0), device=device)
+        population = scatter(ones, slot, dim=0, dim_size=n_slots, reduce='sum', plan=per_slot)
+        enough = (population > self.min_points_per_frame).float()
+        slot_label = scatter(moving, slot, dim=0, dim_size=n_slots, reduce='max', plan=per_slot)
+        label_w = torch.ones_like(slot_label)
+        label_w[slot_label == 0] = 0.2
+        ramp = (torch.arange(self.n_frames) + 1).to(device).repeat(n_inst) / self.n_frames
+        return enough * label_w * ramp
+
+    # -- step 2 ---------------------------------------------------------------------------------------------
+    def _embeddings(self, feats_motion, feats_geo, xyz, t_idx, inst, slot, per_inst, per_slot, n_inst, n_slots, T):
+        e_motion = scatter(_embed(self.motion_embed, feats_motion), inst, dim=0, dim_size=n_inst, reduce='max', plan=per_inst)
+        e_geo = scatter(_embed(self.geo_embed, feats_geo), inst, dim=0, dim_size=n_inst, reduce='max', plan=per_inst)
+        slot_centre = scatter(xyz, slot, dim=0, dim_size=n_slots, reduce='mean', plan=per_slot)
+        anchor_centre = slot_centre[::T]                                   # centroid of each instance in frame 0
+        local = xyz - anchor_centre[inst]
+        e_frame = scatter(_embed(self.pos_embed, torch.cat((local, t_idx.unsqueeze(-1) / T), dim=1).float()), slot, dim=0,
+                          dim_size=n_slots, reduce='max', plan=per_slot)
+        return e_motion, e_geo, e_frame, anchor_centre, local
+
     def forward(self, input_dict):
-        mos_feat, frame_feats = input_dict['mos_feats'], input_dict['frame_feats']
-        points = input_dict['points']
-        time_indice, inst_indice = input_dict['time_indice'], input_dict['inst_labels']
-        inst_motion_gt = input_dict['inst_motion_gt']
-        mos_labels = input_dict['mos_labels']
-        K, T, _, _ = inst_motion_gt.size()
-        device = mos_feat.device
-        frame_indice = (inst_indice * T + time_indice).long()
-        per_frame = ScatterPlan(frame_indice, K * T)        # one CSR per index vector, shared by the poolings below
-        per_inst = ScatterPlan(inst_indice, K)
+        feats_motion, feats_geo = input_dict['mos_feats'], input_dict['frame_feats']
+        xyz = input_dict['points']
+        t_idx, inst = input_dict['time_indice'], input_dict['inst_labels']
+        gt_motion = input_dict['inst_motion_gt']
+        n_inst, T = gt_motion.size(0), gt_motion.size(1)
+        n_slots = n_inst * T
+        device = feats_motion.device
+        slot = (inst * T + t_idx).long()                                   # flat (instance, frame) index of every point
+        per_slot = ScatterPlan(slot, n_slots)                              # one CSR per index vector, shared below
+        per_inst = ScatterPlan(inst, n_inst)
 
-        # 1. per (instance, frame) weights: enough points, moving, later frames count more (tpointnet.py:223-237)
-        count = torch.ones(frame_indice.size(0), device=device)
-        frame_count = scatter(count, frame_indice, dim=0, dim_size=K * T, reduce='sum', plan=per_frame)
-        frame_weights = (frame_count > self.min_points_per_frame).float()
-        inst_mos_label = scatter(mos_labels, frame_indice, dim=0, dim_size=K * T, reduce='max', plan=per_frame)
-        mos_weights = torch.ones_like(inst_mos_label)
-        mos_weights[inst_mos_label == 0] = 0.2
-        temporal_weights = (torch.arange(self.n_frames) + 1).to(device).repeat(K) / self.n_frames
-        frame_weights = frame_weights * mos_weights * temporal_weights
+        weights = self._frame_weights(slot, per_slot, input_dict['mos_labels'], n_inst, n_slots, device)
+        e_motion, e_geo, e_frame, anchor_centre, local = self._embeddings(feats_motion, feats_geo, xyz, t_idx, inst, slot,
+                                                                          per_inst, per_slot, n_inst, n_slots, T)
 
-        # 2. pooled embeddings (tpointnet.py:240-262)
-        mos_embedding = scatter(_embed(self.motion_embed, mos_feat), inst_indice, dim=0, dim_size=K, reduce='max', plan=per_inst)
-        geo_embedding = scatter(_embed(self.geo_embed, frame_feats), inst_indice, dim=0, dim_size=K, reduce='max', plan=per_inst)
-        frame_centroid = scatter(points, frame_indice, dim=0, dim_size=K * T, reduce='mean', plan=per_frame)
-        inst_centroid = frame_centroid[::T]
-        centered_points = points - inst_centroid[inst_indice]
-        frame_input = torch.cat((centered_points, time_indice.unsqueeze(-1) / T), dim=1).float()
-        frame_embedding = scatter(_embed(self.pos_embed, frame_input), frame_indice, dim=0, dim_size=K * T, reduce='max', plan=per_frame)
+        # step 3: one 7-vector (quaternion xyzw + translation) per slot from [geometry | motion | frame | anchor frame]
+        code = torch.cat((e_geo.repeat_interleave(T, 0), e_motion.repeat_interleave(T, 0), e_frame,
+                          e_frame[::T].repeat_interleave(T, 0)), dim=1)
+        pose_vec = self.regressor(code)
+        pose_mat = batch_quat2mat(pose_vec)
 
-        # 3. regress one pose per (instance, frame) (tpointnet.py:264-273)
-        anchor_embedding = frame_embedding[::T].repeat_interleave(T, 0)
-        regressor_input = torch.cat((geo_embedding.repeat_interleave(T, 0), mos_embedding.repeat_interleave(T, 0),
-                                     frame_embedding, anchor_embedding), dim=1)
-        pose_est_rep = self.regressor(regressor_input)
-        pose_est_tsfm = batch_quat2mat(pose_est_rep)
+        # step 4: losses on the centred clouds (the reference's l1 / l2 names are swapped, tpointnet.py:281-282; kept)
+        gt_mat, gt_vec = batch_mat2quat(gt_motion, anchor_centre)
+        moved_est = reconstruct_sequence(local, t_idx, inst, pose_mat.view(n_inst, T, 4, 4), T)
+        moved_gt = reconstruct_sequence(local, t_idx, inst, gt_mat.view(n_inst, T, 4, 4), T)
+        gap = moved_est - moved_gt
+        slot_l1 = scatter(torch.norm(gap, p=2, dim=1), slot, dim=0, dim_size=n_slots, reduce='mean', plan=per_slot)
+        slot_l2 = scatter(torch.norm(gap, p=1, dim=1), slot, dim=0, dim_size=n_slots, reduce='mean', plan=per_slot)
+        wsum = weights.sum() + _EPS
+        l1_loss = (slot_l1 * weights).sum() / wsum
+        l2_loss = (slot_l2 * weights).sum() / wsum
+        rot_loss, trans_loss = evaluate_pose(pose_vec, gt_vec, weights)
 
-        # 4. losses (tpointnet.py:275-289; the names l1/l2 are swapped in the reference and kept so)
-        pose_gt_tsfm, pose_gt_rep = batch_mat2quat(inst_motion_gt, inst_centroid)
-        rec_est = reconstruct_sequence(centered_points, time_indice, inst_indice, pose_est_tsfm.view(K, T, 4, 4), T)
-        rec_gt = reconstruct_sequence(centered_points, time_indice, inst_indice, pose_gt_tsfm.view(K, T, 4, 4), T)
-        diff = rec_est - rec_gt
-        l1_loss = torch.norm(diff, p=2, dim=1)
-        l2_loss = torch.norm(diff, p=1, dim=1)
-        frame_l1 = scatter(l1_loss, frame_indice, dim=0, dim_size=K * T, reduce='mean', plan=per_frame)
-        frame_l2 = scatter(l2_loss, frame_indice, dim=0, dim_size=K * T, reduce='mean', plan=per_frame)
-        l1_loss = (frame_l1 * frame_weights).sum() / (frame_weights.sum() + _EPS)
-        l2_loss = (frame_l2 * frame_weights).sum() / (frame_weights.sum() + _EPS)
-        rot_loss, trans_loss = evaluate_pose(pose_est_rep, pose_gt_rep, frame_weights)
-
-        # 5. undo the centring; frame 0 is the identity (tpointnet.py:291-296)
-        cen = inst_centroid.repeat_interleave(T, 0).unsqueeze(-1)
-        pose_est_tsfm[:, :3, 3] += torch.matmul(torch.eye(3, device=device)[None].repeat(K * T, 1, 1) - pose_est_tsfm[:, :3, :3], cen).squeeze(2)
-        pose_est_tsfm = pose_est_tsfm.view(K, T, 4, 4)
-        pose_est_tsfm[:, 0] = torch.eye(4, device=device)[None].repeat(K, 1, 1)
+        # undo the centring (t += (I - R) c) and pin frame 0 to the identity (tpointnet.py:291-296)
+        centre = anchor_centre.repeat_interleave(T, 0).unsqueeze(-1)
+        eye3 = torch.eye(3, device=device)[None].repeat(n_slots, 1, 1)
+        pose_mat[:, :3, 3] += torch.matmul(eye3 - pose_mat[:, :3, :3], centre).squeeze(2)
+        pose_mat = pose_mat.view(n_inst, T, 4, 4)
+        pose_mat[:, 0] = torch.eye(4, device=device)[None].repeat(n_inst, 1, 1)
         return {'l1_loss': l1_loss, 'l2_loss': l2_loss, 'rot_loss': rot_loss, 'trans_loss': trans_loss,
-                'inst_est_motion': pose_est_tsfm}
+                'inst_est_motion': pose_mat}
