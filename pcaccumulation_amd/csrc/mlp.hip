@@ -191,9 +191,10 @@ extern "C" int pcacc_rows_linear(const float *x, const float *in_mask, const flo
 // Workgroup partials go to the zero-filled output with one fp32 atomic per element per workgroup.
 // ---------------------------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-#define WG_MAX_TILES 6            // tiles per wave: ceil(4*5 / 4) for 128 x 129, with one spare
+// tiles per wave (template parameter WG_MAX_TILES): 1 when there are <= 4 output tiles (keeps the register footprint of the
+// common 32/64-wide layers small: 4 workgroups per CU overlap staging and MFMA), 2 for <= 8, 6 for the 128 x 129 case.
 
-template <int WG_ROWS>
+template <int WG_ROWS, int WG_MAX_TILES>
 __global__ __launch_bounds__(256) void rows_wgrad_kernel(const float *__restrict__ dY, const float *__restrict__ dy_mask,
                                                          const float *__restrict__ X, int x_relu, int64_t rows, int K, int N,
                                                          int k_tiles, int n_tile_total, float *dW)
@@ -298,17 +299,24 @@ extern "C" int pcacc_rows_wgrad(const float *dy, const float *dy_mask, const flo
     if (!dy || !x) return PCACC_E_ARG;
     const int k_tiles = (k + 1 + 31) / 32, n_tiles = (n + 31) / 32;
     const int total = k_tiles * n_tiles;
-    if (total > 4 * WG_MAX_TILES) return PCACC_E_ARG;
+    if (total > 24) return PCACC_E_ARG;
     // rows per staged chunk: as many as ~48 KB of LDS hold (more MFMA work per barrier pair), 32 for the 128-wide layers
     const int wg_rows = (n + k + 8) * 4 * 96 <= 49152 ? 96 : 32;
     const int64_t n_chunks = (rows + wg_rows - 1) / wg_rows;
-    int grid = PCACC_CUS * 3;
+    int grid = PCACC_CUS * (total <= 4 ? 4 : 2);
     if (grid > n_chunks) grid = (int)n_chunks;
     const size_t lds = (size_t)wg_rows * (n + 4 + k + 4) * sizeof(float);
-    if (wg_rows == 96)
-        rows_wgrad_kernel<96><<<grid, 256, lds, s>>>(dy, dy_mask, x, x_relu, rows, k, n, k_tiles, total, dw_aug);
-    else
-        rows_wgrad_kernel<32><<<grid, 256, lds, s>>>(dy, dy_mask, x, x_relu, rows, k, n, k_tiles, total, dw_aug);
+#define WG_LAUNCH(R, T) rows_wgrad_kernel<R, T><<<grid, 256, lds, s>>>(dy, dy_mask, x, x_relu, rows, k, n, k_tiles, total, dw_aug)
+    if (wg_rows == 96) {
+        if (total <= 4) WG_LAUNCH(96, 1);
+        else if (total <= 8) WG_LAUNCH(96, 2);
+        else WG_LAUNCH(96, 6);
+    } else {
+        if (total <= 4) WG_LAUNCH(32, 1);
+        else if (total <= 8) WG_LAUNCH(32, 2);
+        else WG_LAUNCH(32, 6);
+    }
+#undef WG_LAUNCH
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
 }
