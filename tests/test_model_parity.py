@@ -202,3 +202,52 @@ def test_gpu_tiny_val_bf16_metrics(golden):
     i, u = stats['mos_metric']['intersection'], stats['mos_metric']['union']
     assert abs(float((i / (u + 1e-20)).mean()) - float(g['mos_iou'])) < 0.05
     assert (out['fb_est_per_points'].cpu().numpy() != g['fb_est_per_points']).mean() < 0.05
+
+
+@pytest.mark.gpu
+def test_gpu_vs_oracle_backend_ragged_batch(monkeypatch):
+    """Ragged batch (samples with different point and pillar counts, T = 5, train mode incl. backward): the HIP library and
+    the oracle-backed CPU backend under the SAME host code must agree -- every kernel is exercised in context at shapes the
+    golden vectors do not cover."""
+    from helpers import oracle_voxeliser
+    from pcaccumulation_amd.dataloader import collate_fn
+    from pcaccumulation_amd.synthetic import make_sequence, attach_voxels
+    cfg = default_config('waymo', 'train', n_sweeps=5, xy_range=8)
+    vox = oracle_voxeliser(cfg)
+    samples = [attach_voxels(make_sequence(40, 5, 1400, cfg), vox), attach_voxels(make_sequence(41, 5, 700, cfg, mode='lidar'), vox),
+               attach_voxels(make_sequence(42, 5, 2100, cfg), vox)]
+    inp = collate_fn(samples)
+    assert len(set(int(v) for v in inp['num_voxels'])) == 3
+
+    def run(dev):
+        torch.manual_seed(5)
+        model = MotionNet(cfg)
+        fill_state_dict_(model)
+        with torch.no_grad():                                   # both classes of the fb head occur (see make_golden_model.py)
+            model.semseg_head.seg_head[3].bias += torch.tensor([17.0, 0.0])
+        model = model.to(dev).train()
+        if dev.type == 'cuda':
+            model.channels_last_()
+        batch = _to(inp, dev)
+        torch.manual_seed(6)
+        out = model(batch)
+        stats = FuseLoss(cfg['loss'])(out, batch)
+        stats['loss'].backward()
+        grads = {k: (p.grad.detach().cpu().clone() if p.grad is not None else None) for k, p in model.named_parameters()}
+        keep = {k: out[k].detach().cpu() for k in ('fb_seg_est', 'fb_est_per_points', 'transformed_points', 'mos_est', 'ego_motion_est')}
+        return keep, float(stats['loss']), grads, out['ego_rot_error']
+
+    gpu = run(torch.device('cuda:0'))
+    from oracle import cpu_backend
+    cpu_backend.install(monkeypatch)
+    cpu = run(torch.device('cpu'))
+    np.testing.assert_allclose(gpu[0]['fb_seg_est'].numpy(), cpu[0]['fb_seg_est'].numpy(), rtol=1e-3, atol=1e-3)
+    assert (gpu[0]['fb_est_per_points'] != cpu[0]['fb_est_per_points']).float().mean() < 2e-3
+    np.testing.assert_allclose(gpu[0]['ego_motion_est'].numpy(), cpu[0]['ego_motion_est'].numpy(), atol=5e-3)
+    np.testing.assert_allclose(gpu[0]['transformed_points'].numpy(), cpu[0]['transformed_points'].numpy(), atol=5e-2)
+    assert abs(gpu[1] - cpu[1]) < 5e-3 * abs(cpu[1])
+    assert abs(gpu[3] - cpu[3]) < 1e-2
+    for k in ('pillar_encoder.fc_pos.weight', 'pillar_encoder.blocks.2.fc_0.weight', 'unet.conv_final.weight',
+              'motionhead.mos_seg.seg_head.3.weight', 'ego_feats_head.seg_head.3.weight'):
+        g, c = gpu[2][k], cpu[2][k]
+        assert abs(float(g.norm()) - float(c.norm())) < 3e-2 * max(float(c.norm()), 1e-3), k
