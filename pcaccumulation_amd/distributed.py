@@ -53,16 +53,16 @@ class FlatGradAllReduce(object):
         if ws == 1:
             return
         self.flat.zero_()
-        for p, v in zip(self.params, self.views):
-            if p.grad is not None:
-                v.copy_(p.grad)
+        have = [(p, v) for p, v in zip(self.params, self.views) if p.grad is not None]
+        if have:                                          # two multi-tensor launches instead of 2 x 195 small copies
+            torch._foreach_copy_([v for _, v in have], [p.grad for p, _ in have])
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         self.flat.div_(ws)
+        if have:
+            torch._foreach_copy_([p.grad for p, _ in have], [v for _, v in have])
         for p, v in zip(self.params, self.views):
-            if p.grad is None:
+            if p.grad is None:                            # branch not taken on this rank: adopt the other ranks' mean
                 p.grad = v.clone()
-            else:
-                p.grad.copy_(v)
 
 
 def all_ok(ok, device):
