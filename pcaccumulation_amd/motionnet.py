@@ -13,7 +13,6 @@ cfg['misc']['compute_dtype'] ('fp32' default | 'bf16'): element type of the BEV 
 (autocast).  Sinkhorn / Kabsch / normalisation / grid arithmetic always stay fp32.
 """
 import contextlib
-import os
 
 import torch
 import torch.nn as nn
@@ -56,7 +55,6 @@ class MotionNet(nn.Module):
         self.reconstructor = AlignNet(cfg)
         self.grid = grid_shape(cfg)
         self.compute_dtype = {'fp32': torch.float32, 'bf16': torch.bfloat16}[cfg['misc'].get('compute_dtype', 'fp32')]
-        self.heads_bf16 = self.compute_dtype == torch.bfloat16 and os.environ.get('PCACC_HEADS_BF16', '1') != '0'
 
     # ------------------------------------------------------------------------------------------------
     def channels_last_(self):
@@ -231,11 +229,7 @@ class MotionNet(nn.Module):
         mh = self.motionhead
         ungridded = ops.bilinear_gather(stpn_map, points, batch_idx, abs(self.pc_range[0]), abs(self.pc_range[1]))
         pos = mh.point_mlp(mh.positional_encoding, points / abs(self.pc_range[0]))
-        # The 128-wide layers (final_proj and the first layer of both heads) are fp32-VALU-bound in the row kernel; in the bf16
-        # compute mode they run as bf16 MFMA GEMMs with fp32 accumulation like the conv stacks (PCACC_HEADS_BF16=0 keeps fp32).
-        with (self._dense() if self.heads_bf16 else contextlib.nullcontext()):
-            enc = mh.point_mlp(mh.final_proj, torch.cat([pos, ungridded], dim=-1))
-            classes = mh.point_head(mh.mos_seg, enc)
-            offset = mh.point_head(mh.offset_head, enc)
-        offset = mh.safe_guard_offset(offset.float())
-        return classes.float(), offset, stpn_map
+        enc = mh.point_mlp(mh.final_proj, torch.cat([pos, ungridded], dim=-1))
+        classes = mh.point_head(mh.mos_seg, enc)
+        offset = mh.safe_guard_offset(mh.point_head(mh.offset_head, enc))
+        return classes, offset, stpn_map
