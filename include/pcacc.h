@@ -110,6 +110,16 @@ int pcacc_segment_max_backward(const float *grad_out, const int32_t *arg, const 
 int pcacc_segment_sum(const float *src, int c, const int32_t *seg_offsets, const int32_t *order, int64_t n, int64_t m,
                       float *out, void *workspace, size_t workspace_bytes, void *stream);
 
+/* A4 (feature build). The nine per-point inputs of the pillar encoder -- models/pillar_encoder.py:98-110:
+ * [xyz, xyz - pillar_mean, xy - pillar_centre, t], first eight divided by `scale` (= |x_min|), t by n_frames.
+ *   points [n,3] f32; p2v [n] i32; pillar_mean [m,3] f32; coords [m,5] (b,z,y,x,t) f64 or i32;
+ *   time_col: pointer to the t entry of row 0 of the collated `time_indice` (f64), time_stride = row stride in doubles (2);
+ *   vx, vy = pillar size; x_offset = vx/2 + x_min, y_offset = vy/2 + y_min (pillar_encoder.py:91-94); out [n,9] f32. */
+int pcacc_pfn_features(const float *points, const int32_t *p2v, const float *pillar_mean, const void *coords,
+                       int coords_is_f64, const double *time_col, int64_t time_stride, int64_t n,
+                       double vx, double vy, double x_offset, double y_offset, float scale, float n_frames,
+                       float *out, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * A4 (MLP part). Per-point linear layers: nn.Linear applied to 10^5..10^6 rows with <= 128 features, as the pillar
  * encoder (models/pillar_encoder.py:46-55, 112-121), the STPN point heads (models/stpn.py:94-102) and the TubeNet

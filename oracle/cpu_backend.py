@@ -175,10 +175,16 @@ def rows_wgrad(dy, x, dy_mask=None, x_relu=False):
     return g.t() @ aug
 
 
+def pfn_features(points, p2v, pillar_mean, coords, time_indice, vx, vy, x_offset, y_offset, scale, n_frames):
+    f = oracle.pfn_features(_np(points), _np(p2v).astype(np.int64), _np(coords), _np(pillar_mean), _np(time_indice),
+                            [vx, vy], [-scale, -scale], n_frames)
+    return torch.from_numpy(f)
+
+
 NAMES = ['voxelize', 'cell_index', 'frame_pillars', 'csr_build', 'segment_mean3_maxlabel', 'segment_max',
          'segment_max_backward', 'segment_sum', 'pillar_scatter', 'gather_rows', 'bilinear_gather',
          'bilinear_gather_backward', 'bev_warp', 'rigid_transform', 'chamfer_forward', 'chamfer_backward',
-         'rows_linear', 'rows_wgrad', 'rows_linear_supported']
+         'rows_linear', 'rows_wgrad', 'rows_linear_supported', 'pfn_features']
 
 
 def install(monkeypatch=None):

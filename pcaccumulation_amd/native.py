@@ -43,7 +43,7 @@ EXPORTS = [
     'pcacc_frame_pillars_workspace_bytes', 'pcacc_frame_pillars',
     'pcacc_csr_workspace_bytes', 'pcacc_csr_build', 'pcacc_segment_mean3_maxlabel',
     'pcacc_segment_workspace_bytes', 'pcacc_segment_max', 'pcacc_segment_max_backward', 'pcacc_segment_sum',
-    'pcacc_rows_linear', 'pcacc_rows_wgrad', 'pcacc_pillar_scatter', 'pcacc_gather_rows',
+    'pcacc_pfn_features', 'pcacc_rows_linear', 'pcacc_rows_wgrad', 'pcacc_pillar_scatter', 'pcacc_gather_rows',
     'pcacc_bilinear_gather', 'pcacc_bilinear_gather_backward', 'pcacc_bev_warp', 'pcacc_rigid_transform',
     'pcacc_chamfer_workspace_bytes', 'pcacc_chamfer_forward', 'pcacc_chamfer_backward',
 ]
@@ -322,4 +322,25 @@ def rows_wgrad(dy, x, dy_mask=None, x_relu=False):
     _check(lib().pcacc_rows_wgrad(_dev(dy, torch.float32, 'dy'), _dev(dy_mask, torch.float32, 'dy_mask') if dy_mask is not None else None,
                                   _dev(x, torch.float32, 'x'), 1 if x_relu else 0, _i64(rows), int(k), int(n), _dev(out), _stream()),
            'rows_wgrad')
+    return out
+
+
+def pfn_features(points, p2v, pillar_mean, coords, time_indice, vx, vy, x_offset, y_offset, scale, n_frames):
+    """[n,9] f32 pillar-encoder inputs (models/pillar_encoder.py:98-110); time_indice [n,2] f64 (b,t)."""
+    n = points.shape[0]
+    out = torch.empty((n, 9), dtype=torch.float32, device=points.device)
+    if coords.dtype == torch.float64:
+        is_f64 = 1
+    elif coords.dtype == torch.int32:
+        is_f64 = 0
+    else:
+        raise NativeError('coordinates must be float64 or int32')
+    if time_indice.dtype != torch.float64 or not time_indice.is_contiguous() or time_indice.shape[1] != 2:
+        raise NativeError('time_indice must be a contiguous float64 [n,2] tensor')
+    tcol = ctypes.c_void_p(time_indice.data_ptr() + 8)                   # column 1 of row 0
+    _check(lib().pcacc_pfn_features(_dev(points, torch.float32, 'points'), _dev(p2v, torch.int32, 'p2v'),
+                                    _dev(pillar_mean, torch.float32, 'pillar_mean'), _dev(coords, None, 'coordinates'), is_f64,
+                                    tcol if n else None, _i64(2), _i64(n), ctypes.c_double(vx), ctypes.c_double(vy),
+                                    ctypes.c_double(x_offset), ctypes.c_double(y_offset), ctypes.c_float(scale),
+                                    ctypes.c_float(n_frames), _dev(out), _stream()), 'pfn_features')
     return out

@@ -7,7 +7,7 @@ scatter and bilinear gather run in the HIP kernels behind pcaccumulation_amd.ops
 import torch
 from torch import nn
 
-from . import ops
+from . import native, ops
 from .ops import PillarIndex
 
 
@@ -58,16 +58,15 @@ class PillarFeatureNet(nn.Module):
 
     def point_features(self, raw_points, pidx, coordinates, pillar_mean, time_indice):
         """The 9 inputs of pillar_encoder.py:98-110, in the same arithmetic (f64 coordinates, f32 points)."""
-        p2v = pidx.p2v
-        dist_to_pts_mean = raw_points - ops.gather_rows(pillar_mean, p2v)
-        mapped = ops.gather_rows(coordinates.contiguous(), p2v)           # [N,5] f64 rows of 40 bytes
-        f_center = torch.zeros_like(raw_points[:, :2])
-        f_center[:, 0] = raw_points[:, 0] - (mapped[:, 3] * self.vx + self.x_offset)
-        f_center[:, 1] = raw_points[:, 1] - (mapped[:, 2] * self.vy + self.y_offset)
-        features = torch.cat([raw_points, dist_to_pts_mean, f_center, time_indice[:, 1:2]], dim=-1).float()
-        features[:, :-1] /= self.scale
-        features[:, -1] /= self.n_frames
-        return features
+        coords = coordinates.contiguous()
+        if coords.dtype not in (torch.float64, torch.int32):
+            coords = coords.to(torch.float64)
+        ti = time_indice.contiguous()
+        if ti.dtype != torch.float64:
+            ti = ti.to(torch.float64)
+        return native.pfn_features(raw_points.contiguous(), pidx.p2v, pillar_mean.contiguous(), coords, ti, float(self.vx),
+                                   float(self.vy), float(self.x_offset), float(self.y_offset), float(self.scale),
+                                   float(self.n_frames))
 
     def forward(self, raw_points, point_to_voxel_map, coordinates, pillar_mean, time_indice, pidx=None):
         if pidx is None:                                                  # reference call signature

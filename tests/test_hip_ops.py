@@ -411,3 +411,30 @@ def test_linear_rows_autograd_matches_library(native, dev):
     np.testing.assert_allclose(r1.grad.cpu().numpy(), r2.grad.cpu().numpy(), rtol=1e-3, atol=1e-3)
     np.testing.assert_allclose(gw.cpu().numpy(), lin.weight.grad.cpu().numpy(), rtol=1e-3, atol=2e-2)
     np.testing.assert_allclose(gb.cpu().numpy(), lin.bias.grad.cpu().numpy(), rtol=1e-3, atol=2e-2)
+
+
+def test_pfn_features_vs_oracle_and_pfn_golden(native, dev, golden):
+    """A4: feature build (bit-exact vs the oracle's restatement of pillar_encoder.py:98-110) and the whole pillar encoder
+    against the reference's output."""
+    from pcaccumulation_amd import ops
+    from pcaccumulation_amd.pillar_encoder import PillarFeatureNet
+    from pcaccumulation_amd.synthetic import fill_state_dict_
+    g = golden('segops')
+    cfg, inp = _batch(dev)
+    pe = cfg['pillar_encoder']
+    pts = inp['input_points'].float()
+    p2v = inp['point_to_voxel_map'][:, 0].contiguous()
+    m = inp['coordinates'].shape[0]
+    mean = oracle.segment_mean(pts.numpy(), p2v.numpy().astype(np.int64), m)
+    ref = oracle.pfn_features(pts.numpy(), p2v.numpy().astype(np.int64), inp['coordinates'].numpy(), mean, inp['time_indice'].numpy(),
+                              pe['voxel_size'], pe['pc_range'], pe['n_sweeps'])
+    vx, vy = pe['voxel_size'][0], pe['voxel_size'][1]
+    got = native.pfn_features(pts.to(dev), p2v.to(dev), torch.from_numpy(mean).to(dev), inp['coordinates'].to(dev),
+                              inp['time_indice'].to(dev), vx, vy, vx / 2 + pe['pc_range'][0], vy / 2 + pe['pc_range'][1],
+                              abs(pe['pc_range'][0]), pe['n_sweeps'])
+    assert np.array_equal(got.cpu().numpy(), ref)
+    pfn = fill_state_dict_(PillarFeatureNet(pe)).to(dev).eval()
+    pidx = ops.PillarIndex(inp['coordinates'].to(dev), inp['point_to_voxel_map'].to(dev), 2, [int(v) for v in inp['shape'][0]])
+    with torch.no_grad():
+        out = pfn(pts.to(dev), None, inp['coordinates'].to(dev), torch.from_numpy(mean).to(dev), inp['time_indice'].to(dev), pidx=pidx)
+    np.testing.assert_allclose(out.cpu().numpy(), g['pfn_out'], rtol=1e-4, atol=5e-5)
