@@ -138,6 +138,11 @@ int pcacc_rows_linear(const float *x, const float *in_mask, const float *w, cons
 int pcacc_rows_wgrad(const float *dy, const float *dy_mask, const float *x, int x_relu, int64_t rows, int k, int n,
                      float *dw_aug, void *stream);
 
+/* Sum of rows per index for FEW output rows (m*c <= 8192), no CSR needed: LDS-privatised accumulation.
+ * The per-instance 'sum' / 'mean' poolings of models/tpointnet.py:227,251,283-284 and libs/loss.py:216.
+ *   src [n,c] f32; idx [n] i32 in [0,m) (negative = skip); out [m,c] f32 (zero-filled by the call). */
+int pcacc_scatter_sum_small(const float *src, const int32_t *idx, int64_t n, int c, int m, float *out, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * A5. Pillar scatter into the BEV canvas -- models/pillar_encoder.py:125-174 (scatter_point_pillar).
  * One pass writes every canvas element exactly once (feature row or zeros), so there is no separate

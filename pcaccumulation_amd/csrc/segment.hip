@@ -464,3 +464,45 @@ extern "C" int pcacc_segment_sum(const float *src, int c, const int32_t *seg_off
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Few output rows (instances x frames ~ 100, m*c <= 8192 floats): sums need no CSR at all.  Every workgroup accumulates its
+// slice of the input into an LDS copy of the whole [m,c] output with ds_add_f32 and flushes it with one global atomic per
+// touched element.  (models/tpointnet.py:227,251,283-284 `scatter(..., 'sum' | 'mean')`, libs/loss.py:216.)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void scatter_sum_small_kernel(const float *__restrict__ src, const int32_t *__restrict__ idx,
+                                                                int64_t n_elem, int c, int mc, float *out)
+{
+    extern __shared__ float acc[];
+    for (int j = threadIdx.x; j < mc; j += 256) acc[j] = 0.f;
+    __syncthreads();
+    const int64_t per_block = (n_elem + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = (int64_t)blockIdx.x * per_block, hi = min(n_elem, lo + per_block);
+    for (int64_t e = lo + threadIdx.x; e < hi; e += 256) {
+        const int64_t r = e / c;
+        const int k = (int)(e - r * c);
+        const int s = idx[r];
+        if (s >= 0) atomicAdd(&acc[s * c + k], src[e]);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < mc; j += 256) {
+        const float v = acc[j];
+        if (v != 0.f) atomicAdd(&out[j], v);
+    }
+}
+
+extern "C" int pcacc_scatter_sum_small(const float *src, const int32_t *idx, int64_t n, int c, int m, float *out, void *stream)
+{
+    if (n < 0 || c <= 0 || m <= 0 || (int64_t)m * c > 8192 || !out) return PCACC_E_ARG;
+    hipStream_t s = pcacc_stream(stream);
+    if (hipMemsetAsync(out, 0, (size_t)m * c * sizeof(float), s) != hipSuccess) return PCACC_E_LAUNCH;
+    if (n == 0) return PCACC_OK;
+    if (!src || !idx) return PCACC_E_ARG;
+    const int64_t n_elem = n * c;
+    int grid = (int)((n_elem + 256 * 32 - 1) / (256 * 32));
+    if (grid > PCACC_CUS * 4) grid = PCACC_CUS * 4;
+    if (grid < 1) grid = 1;
+    scatter_sum_small_kernel<<<grid, 256, (size_t)m * c * sizeof(float), s>>>(src, idx, n_elem, c, m * c, out);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}

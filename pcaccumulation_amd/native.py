@@ -42,7 +42,7 @@ EXPORTS = [
     'pcacc_voxelize_workspace_bytes', 'pcacc_voxelize', 'pcacc_cell_index',
     'pcacc_frame_pillars_workspace_bytes', 'pcacc_frame_pillars',
     'pcacc_csr_workspace_bytes', 'pcacc_csr_build', 'pcacc_segment_mean3_maxlabel',
-    'pcacc_segment_workspace_bytes', 'pcacc_segment_max', 'pcacc_segment_max_backward', 'pcacc_segment_sum',
+    'pcacc_segment_workspace_bytes', 'pcacc_segment_max', 'pcacc_segment_max_backward', 'pcacc_segment_sum', 'pcacc_scatter_sum_small',
     'pcacc_pfn_features', 'pcacc_rows_linear', 'pcacc_rows_wgrad', 'pcacc_pillar_scatter', 'pcacc_gather_rows',
     'pcacc_bilinear_gather', 'pcacc_bilinear_gather_backward', 'pcacc_bev_warp', 'pcacc_rigid_transform',
     'pcacc_chamfer_workspace_bytes', 'pcacc_chamfer_forward', 'pcacc_chamfer_backward',
@@ -343,4 +343,13 @@ def pfn_features(points, p2v, pillar_mean, coords, time_indice, vx, vy, x_offset
                                     tcol if n else None, _i64(2), _i64(n), ctypes.c_double(vx), ctypes.c_double(vy),
                                     ctypes.c_double(x_offset), ctypes.c_double(y_offset), ctypes.c_float(scale),
                                     ctypes.c_float(n_frames), _dev(out), _stream()), 'pfn_features')
+    return out
+
+
+def scatter_sum_small(src, idx, m):
+    """out[m,c] = sum of src rows per idx, for m*c <= 8192 (LDS-privatised, no CSR)."""
+    n, c = src.shape
+    out = torch.empty((m, c), dtype=torch.float32, device=src.device)
+    _check(lib().pcacc_scatter_sum_small(_dev(src, torch.float32, 'src'), _dev(idx, torch.int32, 'idx'), _i64(n), int(c), int(m),
+                                         _dev(out), _stream()), 'scatter_sum_small')
     return out

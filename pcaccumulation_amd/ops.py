@@ -182,19 +182,39 @@ def gather_rows(src2d, idx):
 
 
 class ScatterPlan(object):
-    """CSR of an index vector, reusable across several scatter() calls with the same index."""
+    """An index vector prepared for several scatter() calls: int32 copy now, CSR (for 'max') and counts (for 'mean') on demand."""
 
     def __init__(self, index, dim_size=None):
         idx = index.reshape(-1)
         self.m = int(dim_size) if dim_size is not None else (int(idx.max()) + 1 if idx.numel() else 0)
         self.p2v = idx.to(torch.int32).contiguous()
         self.n = int(self.p2v.shape[0])
-        self.seg_offsets, self.order = native.csr_build(self.p2v, self.m)
+        self._csr = None
         self._count = None
+
+    def _build(self):
+        if self._csr is None:
+            self._csr = native.csr_build(self.p2v, self.m)
+        return self._csr
+
+    @property
+    def seg_offsets(self):
+        return self._build()[0]
+
+    @property
+    def order(self):
+        return self._build()[1]
+
+    def small(self, c):
+        return 0 < self.m * c <= 8192
 
     def count(self):
         if self._count is None:
-            self._count = (self.seg_offsets[1:] - self.seg_offsets[:-1]).to(torch.float32)
+            if self.small(1):
+                ones = torch.ones((self.n, 1), dtype=torch.float32, device=self.p2v.device)
+                self._count = native.scatter_sum_small(ones, self.p2v, self.m)[:, 0]
+            else:
+                self._count = (self.seg_offsets[1:] - self.seg_offsets[:-1]).to(torch.float32)
         return self._count
 
 
@@ -203,6 +223,17 @@ class _SegmentSum(torch.autograd.Function):
     def forward(ctx, src, plan):
         ctx.plan = plan
         return native.segment_sum(src, plan.seg_offsets, plan.order, plan.m)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return native.gather_rows(grad.contiguous(), ctx.plan.p2v), None
+
+
+class _ScatterSumSmall(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, plan):
+        ctx.plan = plan
+        return native.scatter_sum_small(src, plan.p2v, plan.m)
 
     @staticmethod
     def backward(ctx, grad):
@@ -233,13 +264,14 @@ def scatter(src, index, dim=0, dim_size=None, reduce='sum', plan=None):
         plan = ScatterPlan(index, dim_size)
     shape_tail = tuple(src.shape[1:])
     x = src.reshape(src.shape[0], -1)
-    x32, c = _pad4(x.to(torch.float32))
-    if reduce == 'max':
-        out = _SegmentMax.apply(x32, plan)[0]
+    c = x.shape[1]
+    if reduce != 'max' and plan.small(c):
+        out = _ScatterSumSmall.apply(x.to(torch.float32).contiguous(), plan)          # few rows: LDS-privatised, no CSR
     else:
-        out = _SegmentSum.apply(x32, plan)
-        if reduce == 'mean':
-            out = out / plan.count().clamp(min=1.0)[:, None]
+        x32, c = _pad4(x.to(torch.float32))
+        out = _SegmentMax.apply(x32, plan)[0] if reduce == 'max' else _SegmentSum.apply(x32, plan)
+    if reduce == 'mean':
+        out = out / plan.count().clamp(min=1.0)[:, None]
     out = out[:, :c].reshape((plan.m,) + shape_tail)
     return out.to(src.dtype) if out.dtype != src.dtype else out
 
