@@ -191,6 +191,21 @@ int pcacc_rigid_transform(const float *points, const int32_t *frame_idx, const f
                           float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * A8. Key-point matching of the ego-motion head, forward pass, fp32, for n_pairs (frame, anchor) pairs at once --
+ * models/egomotion.py:169-192 after the key-point choice: square_distance (toolbox/utils.py:125-144), affinity,
+ * sinkhorn with slack row/column (egomotion.py:100-137), exp * support, soft targets, weighted Kabsch with a 3x3 SVD
+ * and reflection fix (toolbox/register_utils.py:247-317).
+ *   feats_s, feats_t [n_pairs,k,c] f32 (L2-normalised rows); coor_s, coor_t [n_pairs,k,3] f32;
+ *   thr2 [n_pairs] f32 = (duration * max_speed)^2;  params [2] f32 (device) = {softplus(alpha), exp(beta) + 0.02}
+ *   perm [n_pairs,k,k] f32 out;  pose [n_pairs,16] f32 out (row-major 4x4)
+ * Used when no gradient is needed (eval / val / test); training keeps the batched torch formulation for autograd.
+ * ---------------------------------------------------------------------------------------------- */
+int pcacc_sinkhorn_kabsch_workspace_bytes(int n_pairs, int k, size_t *bytes /*host*/);
+int pcacc_sinkhorn_kabsch(const float *feats_s, const float *feats_t, const float *coor_s, const float *coor_t,
+                          const float *thr2, const float *params, int n_pairs, int k, int c, int n_iters,
+                          float *perm, float *pose, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * A12. Chamfer nearest neighbour -- chamfer_distance/chamfer_distance.cu:6-155 (forward kernel and
  * launcher), chamfer_distance.cpp:59-111 (CPU twin), called through
  * chamfer_distance/chamfer_distance.py:9-31.  dist = squared fp32 distance (x*x + y*y) + z*z of

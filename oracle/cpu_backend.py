@@ -185,10 +185,30 @@ def scatter_sum_small(src, idx, m):
     return torch.zeros((m, src.shape[1]), dtype=torch.float32).index_add_(0, idx.long(), src.float())
 
 
+def sinkhorn_kabsch(feats_s, feats_t, coor_s, coor_t, thr2, params, n_iters):
+    P, k, _ = feats_s.shape
+    perms, poses = [], []
+    sp, den = float(params[0]), float(params[1])
+    for p in range(P):
+        f32 = np.float32
+        fs, ft, cs, ct = (_np(t[p]).astype(f32) for t in (feats_s, feats_t, coor_s, coor_t))
+        support = (oracle.square_distance(cs, ct) < f32(thr2[p])).astype(f32)
+        aff = -(oracle.square_distance(fs, ft, normalised=True) - f32(sp)) / f32(den)
+        perm = np.exp(oracle.sinkhorn(aff, n_iters)) * support
+        rowsum = perm.sum(1, keepdims=True)
+        r, t = oracle.kabsch(cs, (perm @ ct) / (rowsum + f32(1e-20)), rowsum[:, 0])
+        pose = np.eye(4, dtype=f32)
+        pose[:3, :3] = r
+        pose[:3, 3] = t[:, 0]
+        perms.append(perm)
+        poses.append(pose)
+    return torch.from_numpy(np.stack(perms)), torch.from_numpy(np.stack(poses))
+
+
 NAMES = ['voxelize', 'cell_index', 'frame_pillars', 'csr_build', 'segment_mean3_maxlabel', 'segment_max',
          'segment_max_backward', 'segment_sum', 'pillar_scatter', 'gather_rows', 'bilinear_gather',
          'bilinear_gather_backward', 'bev_warp', 'rigid_transform', 'chamfer_forward', 'chamfer_backward',
-         'rows_linear', 'rows_wgrad', 'rows_linear_supported', 'pfn_features', 'scatter_sum_small']
+         'rows_linear', 'rows_wgrad', 'rows_linear_supported', 'pfn_features', 'scatter_sum_small', 'sinkhorn_kabsch']
 
 
 def install(monkeypatch=None):

@@ -1,0 +1,323 @@
+// A8: key-point matching for the ego-motion head, forward pass, fp32 -- models/egomotion.py:169-192 (pairwise_ego_motion_
+// estimation after key-point choice), :100-137 (sinkhorn), toolbox/utils.py:125-144 (square_distance) and
+// toolbox/register_utils.py:247-317 (kabsch_transformation_estimation), for P pairs at once.
+//
+// The reference issues ~60 small launches per pair (matmul, pad, 6 x (logsumexp, sub, cat), exp, mul, sums, diag_embed of a
+// 1024x1024 weight matrix, svd, det ...).  Here: 1 affinity kernel (LDS-tiled 64x64 dot products), 2 kernels per Sinkhorn
+// iteration working in place on the padded (k+1)x(k+1) log-matrix (4 MB per pair: L2 / Infinity-Cache resident), 1 row
+// kernel (exp * support, row sums, soft targets) and 1 Kabsch kernel per pair (weighted means, 3x3 covariance by block
+// reduction, 3x3 Jacobi SVD, reflection fix).  Used when no gradient is required (eval / val / test); training keeps the
+// batched torch formulation for autograd.
+#include "common.h"
+
+#define EGO_TILE 64
+
+// ---- 1. affinity = -(max(2 - 2 <fs_i, ft_j>, 1e-12) - softplus(alpha)) * inv_temp, written into the padded matrix ----------
+__global__ __launch_bounds__(256) void ego_affinity_kernel(const float *__restrict__ fs, const float *__restrict__ ft, int k, int c,
+                                                           const float *__restrict__ params, float *__restrict__ la)
+{
+    const float softplus_alpha = params[0], denom = params[1];      // device scalars: no host sync to read alpha / beta
+    __shared__ float As[EGO_TILE][17], Bs[EGO_TILE][17];
+    const int p = blockIdx.z;
+    const int i0 = blockIdx.y * EGO_TILE, j0 = blockIdx.x * EGO_TILE;
+    const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;
+    fs += (int64_t)p * k * c;
+    ft += (int64_t)p * k * c;
+    const int kp = k + 1;
+    la += (int64_t)p * kp * kp;
+    float acc[4][4] = {};
+    for (int c0 = 0; c0 < c; c0 += 16) {
+        for (int e = threadIdx.x; e < EGO_TILE * 16; e += 256) {
+            const int r = e / 16, cc = e % 16;
+            As[r][cc] = (i0 + r < k && c0 + cc < c) ? fs[(int64_t)(i0 + r) * c + c0 + cc] : 0.f;
+            Bs[r][cc] = (j0 + r < k && c0 + cc < c) ? ft[(int64_t)(j0 + r) * c + c0 + cc] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) {
+            float a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a[u] = As[ty * 4 + u][cc]; b[u] = Bs[tx * 4 + u][cc]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[u][v] = fmaf(a[u], b[v], acc[u][v]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int i = i0 + ty * 4 + u, j = j0 + tx * 4 + v;
+            if (i < k && j < k) {
+                const float dist = fmaxf(-2.0f * acc[u][v] + 2.0f, 1e-12f);          // toolbox/utils.py:137-143
+                la[(int64_t)i * kp + j] = -(dist - softplus_alpha) / denom;          // models/egomotion.py:180
+            }
+        }
+}
+
+// slack row / column of the padded matrix = 0 (nn.ZeroPad2d, models/egomotion.py:116-117)
+__global__ __launch_bounds__(256) void ego_pad_kernel(int k, int n_pairs, float *la)
+{
+    const int kp = k + 1;
+    const int64_t total = (int64_t)n_pairs * (2 * kp - 1);
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int p = (int)(e / (2 * kp - 1));
+        const int r = (int)(e % (2 * kp - 1));
+        float *m = la + (int64_t)p * kp * kp;
+        if (r < kp) m[(int64_t)k * kp + r] = 0.f;                // last row
+        else m[(int64_t)(r - kp) * kp + k] = 0.f;               // last column (rows 0..k-1)
+    }
+}
+
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// ---- 2a. row normalisation: rows 0..k-1, logsumexp over ALL k+1 columns (egomotion.py:122-126) -----------------------------
+__global__ __launch_bounds__(256) void ego_sinkhorn_rows_kernel(int k, int n_pairs, float *la)
+{
+    const int kp = k + 1;
+    const int lane = threadIdx.x & 63;
+    const int64_t n_rows = (int64_t)n_pairs * k;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < n_rows; row += (int64_t)gridDim.x * 4) {
+        const int p = (int)(row / k), i = (int)(row % k);
+        float *r = la + (int64_t)p * kp * kp + (int64_t)i * kp;
+        float mx = -__builtin_inff();
+        for (int j = lane; j < kp; j += 64) mx = fmaxf(mx, r[j]);
+        mx = wave_max(mx);
+        float sm = 0.f;
+        for (int j = lane; j < kp; j += 64) sm += expf(r[j] - mx);
+        const float lse = mx + logf(wave_sum(sm));
+        for (int j = lane; j < kp; j += 64) r[j] -= lse;
+    }
+}
+
+// ---- 2b. column normalisation: columns 0..k-1, logsumexp over ALL k+1 rows (egomotion.py:128-132) ---------------------------
+// workgroup = 64 columns x 4 row-quarters; partial (max, sum) combined through LDS
+__global__ __launch_bounds__(256) void ego_sinkhorn_cols_kernel(int k, float *la)
+{
+    __shared__ float smax[4][64], ssum[4][64];
+    const int kp = k + 1;
+    const int p = blockIdx.y;
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    float *m = la + (int64_t)p * kp * kp;
+    const int rows_per = (kp + 3) / 4;
+    const int r_lo = q * rows_per, r_hi = min(kp, r_lo + rows_per);
+    float mx = -__builtin_inff(), sm = 0.f;
+    if (col < k) {
+        for (int i = r_lo; i < r_hi; ++i) mx = fmaxf(mx, m[(int64_t)i * kp + col]);
+        for (int i = r_lo; i < r_hi; ++i) sm += expf(m[(int64_t)i * kp + col] - mx);
+    }
+    smax[q][threadIdx.x & 63] = mx;
+    ssum[q][threadIdx.x & 63] = sm;
+    __syncthreads();
+    float gm = -__builtin_inff();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) gm = fmaxf(gm, smax[u][threadIdx.x & 63]);
+    float gs = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const float pm = smax[u][threadIdx.x & 63];
+        gs += (pm == -__builtin_inff()) ? 0.f : ssum[u][threadIdx.x & 63] * expf(pm - gm);
+    }
+    const float lse = gm + logf(gs);
+    if (col < k)
+        for (int i = r_lo; i < r_hi; ++i) m[(int64_t)i * kp + col] -= lse;
+}
+
+// ---- 3. perm = exp(log_perm) * support; row sums; soft targets (egomotion.py:183-184) -----------------------------------------
+__global__ __launch_bounds__(256) void ego_rows_finish_kernel(const float *__restrict__ la, const float *__restrict__ cs,
+                                                              const float *__restrict__ ct, const float *__restrict__ thr2, int k,
+                                                              int n_pairs, float *__restrict__ perm, float *__restrict__ rowsum,
+                                                              float *__restrict__ wt)
+{
+    const int kp = k + 1;
+    const int lane = threadIdx.x & 63;
+    const int64_t n_rows = (int64_t)n_pairs * k;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < n_rows; row += (int64_t)gridDim.x * 4) {
+        const int p = (int)(row / k), i = (int)(row % k);
+        const float *r = la + (int64_t)p * kp * kp + (int64_t)i * kp;
+        const float *t = ct + (int64_t)p * k * 3;
+        const float sx = cs[row * 3 + 0], sy = cs[row * 3 + 1], sz = cs[row * 3 + 2];
+        const float s2 = sx * sx + sy * sy + sz * sz;
+        const float th = thr2[p];
+        float rs = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
+        for (int j = lane; j < k; j += 64) {
+            const float tx = t[j * 3 + 0], ty = t[j * 3 + 1], tz = t[j * 3 + 2];
+            // square_distance(): -2 <s,t> + |s|^2 + |t|^2, clamped at 1e-12 (toolbox/utils.py:137-143)
+            float d = -2.0f * (sx * tx + sy * ty + sz * tz);
+            d += s2;
+            d += tx * tx + ty * ty + tz * tz;
+            d = fmaxf(d, 1e-12f);
+            const float v = (d < th) ? expf(r[j]) : 0.f;
+            perm[row * k + j] = v;
+            rs += v; ax += v * tx; ay += v * ty; az += v * tz;
+        }
+        rs = wave_sum(rs); ax = wave_sum(ax); ay = wave_sum(ay); az = wave_sum(az);
+        if (lane == 0) {
+            rowsum[row] = rs;
+            const float den = rs + 1e-20f;
+            wt[row * 3 + 0] = ax / den; wt[row * 3 + 1] = ay / den; wt[row * 3 + 2] = az / den;
+        }
+    }
+}
+
+// ---- 4. weighted Kabsch (register_utils.py:268-313), one workgroup per pair -----------------------------------------------------
+__device__ void jacobi_svd3(const double a[3][3], double u[3][3], double s[3], double v[3][3])
+{
+    // one-sided Jacobi on the columns of A: A V = U diag(s)
+    double b[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) { b[i][j] = a[i][j]; v[i][j] = (i == j); }
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                double alpha = 0, beta = 0, gamma = 0;
+                for (int i = 0; i < 3; ++i) { alpha += b[i][p] * b[i][p]; beta += b[i][q] * b[i][q]; gamma += b[i][p] * b[i][q]; }
+                off += gamma * gamma;
+                if (fabs(gamma) < 1e-300) continue;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+                for (int i = 0; i < 3; ++i) {
+                    const double bp = b[i][p], bq = b[i][q];
+                    b[i][p] = c * bp - sn * bq; b[i][q] = sn * bp + c * bq;
+                    const double vp = v[i][p], vq = v[i][q];
+                    v[i][p] = c * vp - sn * vq; v[i][q] = sn * vp + c * vq;
+                }
+            }
+        if (off < 1e-40) break;
+    }
+    for (int j = 0; j < 3; ++j) {
+        double n = 0;
+        for (int i = 0; i < 3; ++i) n += b[i][j] * b[i][j];
+        s[j] = sqrt(n);
+    }
+    // order singular values descending (as LAPACK / torch.svd)
+    for (int x = 0; x < 2; ++x)
+        for (int y = x + 1; y < 3; ++y)
+            if (s[y] > s[x]) {
+                const double ts = s[x]; s[x] = s[y]; s[y] = ts;
+                for (int i = 0; i < 3; ++i) {
+                    const double tb = b[i][x]; b[i][x] = b[i][y]; b[i][y] = tb;
+                    const double tv = v[i][x]; v[i][x] = v[i][y]; v[i][y] = tv;
+                }
+            }
+    for (int j = 0; j < 3; ++j)
+        for (int i = 0; i < 3; ++i) u[i][j] = s[j] > 1e-300 ? b[i][j] / s[j] : (i == j);
+    if (s[2] <= 1e-300 * 1.0 || s[2] < 1e-12 * s[0]) {                 // rank-deficient: complete U with a cross product
+        u[0][2] = u[1][0] * u[2][1] - u[2][0] * u[1][1];
+        u[1][2] = u[2][0] * u[0][1] - u[0][0] * u[2][1];
+        u[2][2] = u[0][0] * u[1][1] - u[1][0] * u[0][1];
+    }
+}
+
+__device__ __forceinline__ double block_sum256(double v, double *red)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void ego_kabsch_kernel(const float *__restrict__ cs, const float *__restrict__ wt,
+                                                         const float *__restrict__ rowsum, int k, float *__restrict__ pose)
+{
+    __shared__ double red[4];
+    const int p = blockIdx.x;
+    const float *x1 = cs + (int64_t)p * k * 3, *x2 = wt + (int64_t)p * k * 3, *w0 = rowsum + (int64_t)p * k;
+    const double eps = 1e-7;
+    double sw = 0;
+    for (int i = threadIdx.x; i < k; i += 256) sw += w0[i];
+    sw = block_sum256(sw, red);
+    const double norm = sw + eps;                                       // weights / (sum + eps), register_utils.py:269-270
+    double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int i = threadIdx.x; i < k; i += 256) {
+        const double w = w0[i] / norm;
+        acc[6] += w;
+        for (int d = 0; d < 3; ++d) { acc[d] += w * x1[i * 3 + d]; acc[3 + d] += w * x2[i * 3 + d]; }
+    }
+    double tot[7];
+    for (int d = 0; d < 7; ++d) tot[d] = block_sum256(acc[d], red);
+    double m1[3], m2[3];
+    for (int d = 0; d < 3; ++d) { m1[d] = tot[d] / (tot[6] + eps); m2[d] = tot[3 + d] / (tot[6] + eps); }      // :284-285
+    double cv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = threadIdx.x; i < k; i += 256) {
+        const double w = w0[i] / norm;
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) cv[a * 3 + b] += (x1[i * 3 + a] - m1[a]) * w * (x2[i * 3 + b] - m2[b]);     // x1c^T W x2c
+    }
+    double cov[3][3];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) cov[a][b] = block_sum256(cv[a * 3 + b], red);
+    if (threadIdx.x == 0) {
+        double u[3][3], s[3], v[3][3];
+        jacobi_svd3(cov, u, s, v);
+        // det(v^T u^T) decides the reflection fix; R = v diag(1,1,det) u^T; t = m2 - R m1   (register_utils.py:306-313)
+        double vu[3][3];
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) { vu[a][b] = 0; for (int c = 0; c < 3; ++c) vu[a][b] += v[c][a] * u[b][c]; }
+        const double det = vu[0][0] * (vu[1][1] * vu[2][2] - vu[1][2] * vu[2][1]) - vu[0][1] * (vu[1][0] * vu[2][2] - vu[1][2] * vu[2][0]) +
+                           vu[0][2] * (vu[1][0] * vu[2][1] - vu[1][1] * vu[2][0]);
+        double R[3][3];
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) R[a][b] = v[a][0] * u[b][0] + v[a][1] * u[b][1] + det * v[a][2] * u[b][2];
+        float *o = pose + (int64_t)p * 16;
+        for (int a = 0; a < 3; ++a) {
+            double t = m2[a];
+            for (int b = 0; b < 3; ++b) { o[a * 4 + b] = (float)R[a][b]; t -= R[a][b] * m1[b]; }
+            o[a * 4 + 3] = (float)t;
+        }
+        o[12] = 0.f; o[13] = 0.f; o[14] = 0.f; o[15] = 1.f;
+    }
+}
+
+extern "C" int pcacc_sinkhorn_kabsch_workspace_bytes(int n_pairs, int k, size_t *bytes)
+{
+    if (!bytes || n_pairs < 0 || k <= 0) return PCACC_E_ARG;
+    *bytes = pcacc_align((size_t)n_pairs * (k + 1) * (k + 1) * 4) + pcacc_align((size_t)n_pairs * k * 4) + pcacc_align((size_t)n_pairs * k * 12);
+    return PCACC_OK;
+}
+
+extern "C" int pcacc_sinkhorn_kabsch(const float *feats_s, const float *feats_t, const float *coor_s, const float *coor_t,
+                                     const float *thr2, const float *params, int n_pairs, int k, int c, int n_iters,
+                                     float *perm, float *pose, void *workspace, size_t workspace_bytes, void *stream)
+{
+    size_t need;
+    if (pcacc_sinkhorn_kabsch_workspace_bytes(n_pairs, k, &need) != PCACC_OK || c <= 0 || n_iters < 0 || n_pairs > 65535) return PCACC_E_ARG;
+    if (n_pairs == 0) return PCACC_OK;
+    if (!feats_s || !feats_t || !coor_s || !coor_t || !thr2 || !params || !perm || !pose) return PCACC_E_ARG;
+    if (!workspace || workspace_bytes < need) return PCACC_E_WORKSPACE;
+    hipStream_t s = pcacc_stream(stream);
+    char *ws = static_cast<char *>(workspace);
+    float *la = reinterpret_cast<float *>(ws); ws += pcacc_align((size_t)n_pairs * (k + 1) * (k + 1) * 4);
+    float *rowsum = reinterpret_cast<float *>(ws); ws += pcacc_align((size_t)n_pairs * k * 4);
+    float *wt = reinterpret_cast<float *>(ws);
+    const int tiles = (k + EGO_TILE - 1) / EGO_TILE;
+    ego_affinity_kernel<<<dim3(tiles, tiles, n_pairs), 256, 0, s>>>(feats_s, feats_t, k, c, params, la);
+    ego_pad_kernel<<<pcacc_grid((int64_t)n_pairs * (2 * k + 1), 256), 256, 0, s>>>(k, n_pairs, la);
+    const int row_grid = pcacc_grid((int64_t)n_pairs * k * 64, 256);
+    for (int it = 0; it < n_iters; ++it) {
+        ego_sinkhorn_rows_kernel<<<row_grid, 256, 0, s>>>(k, n_pairs, la);
+        ego_sinkhorn_cols_kernel<<<dim3((k + 63) / 64, n_pairs), 256, 0, s>>>(k, la);
+    }
+    ego_rows_finish_kernel<<<row_grid, 256, 0, s>>>(la, coor_s, coor_t, thr2, k, n_pairs, perm, rowsum, wt);
+    ego_kabsch_kernel<<<n_pairs, 256, 0, s>>>(coor_s, wt, rowsum, k, pose);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}

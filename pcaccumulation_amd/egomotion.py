@@ -12,7 +12,7 @@ import math
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import native, ops
 
 _EPS = 1e-20                       # toolbox/utils.py:13
 
@@ -196,6 +196,14 @@ class EgoMotionHead(nn.Module):
             feats_t = feats_t / torch.norm(feats_t, p=2, dim=2, keepdim=True)
         thr2 = (torch.tensor(durations, dtype=torch.float32) * self.ego_max_speed) ** 2
         thr2 = thr2.to(dev)
+        if not torch.is_grad_enabled():
+            # eval / val / test: the fused fp32 HIP pipeline (affinity, Sinkhorn, soft targets, Kabsch + 3x3 SVD)
+            params = torch.stack([self.softplus(self.alpha), torch.exp(self.beta) + 0.02]).float().detach()
+            perm, pose_est = native.sinkhorn_kabsch(feats_s.contiguous(), feats_t.contiguous(), coor_s.contiguous().float(),
+                                                    coor_t.contiguous().float(), thr2.contiguous(), params.contiguous(),
+                                                    self.sinkhorn_iter)
+            return self._collect_pairs(sequences, T, perm, pose_est, perm_matrix_list, relative_pose_est_list,
+                                       relative_pose_gt_list, chained_pose_est_list, chained_pose_gt_list)
         support = (square_distance(coor_s, coor_t, normalised=False) < thr2[:, None, None]).float()     # :173-174
         feat_dist = square_distance(feats_s, feats_t, normalised=True)                                   # :177
         affinity = -(feat_dist - self.softplus(self.alpha)) / (torch.exp(self.beta) + 0.02)              # :180
@@ -207,7 +215,14 @@ class EgoMotionHead(nn.Module):
         pose_est = torch.eye(4, device=dev, dtype=t_est.dtype).repeat(P, 1, 1)
         pose_est[:, :3, :3] = R_est
         pose_est[:, :3, 3] = t_est[:, :, 0]
+        return self._collect_pairs(sequences, T, perm, pose_est, perm_matrix_list, relative_pose_est_list, relative_pose_gt_list,
+                                   chained_pose_est_list, chained_pose_gt_list)
 
+    def _collect_pairs(self, sequences, T, perm, pose_est, perm_matrix_list, relative_pose_est_list, relative_pose_gt_list,
+                       chained_pose_est_list, chained_pose_gt_list):
+        """Per-pair bookkeeping of sequence_pose_est_skip (models/egomotion.py:334-355): GT poses, losses, pose lists."""
+        dev = pose_est.device
+        P = pose_est.shape[0]
         identity = torch.eye(4, device=dev)
         total_l1, total_l2, p = 0, 0, 0
         for points_list, feats_list, bg_list, gt in sequences:

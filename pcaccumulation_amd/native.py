@@ -45,7 +45,7 @@ EXPORTS = [
     'pcacc_segment_workspace_bytes', 'pcacc_segment_max', 'pcacc_segment_max_backward', 'pcacc_segment_sum', 'pcacc_scatter_sum_small',
     'pcacc_pfn_features', 'pcacc_rows_linear', 'pcacc_rows_wgrad', 'pcacc_pillar_scatter', 'pcacc_gather_rows',
     'pcacc_bilinear_gather', 'pcacc_bilinear_gather_backward', 'pcacc_bev_warp', 'pcacc_rigid_transform',
-    'pcacc_chamfer_workspace_bytes', 'pcacc_chamfer_forward', 'pcacc_chamfer_backward',
+    'pcacc_sinkhorn_kabsch_workspace_bytes', 'pcacc_sinkhorn_kabsch', 'pcacc_chamfer_workspace_bytes', 'pcacc_chamfer_forward', 'pcacc_chamfer_backward',
 ]
 
 
@@ -353,3 +353,20 @@ def scatter_sum_small(src, idx, m):
     _check(lib().pcacc_scatter_sum_small(_dev(src, torch.float32, 'src'), _dev(idx, torch.int32, 'idx'), _i64(n), int(c), int(m),
                                          _dev(out), _stream()), 'scatter_sum_small')
     return out
+
+
+def sinkhorn_kabsch(feats_s, feats_t, coor_s, coor_t, thr2, params, n_iters):
+    """Forward-only ego-motion matching for P pairs: returns (perm [P,k,k], pose [P,4,4]); see include/pcacc.h (A8)."""
+    P, k, c = feats_s.shape
+    dev = feats_s.device
+    perm = torch.empty((P, k, k), dtype=torch.float32, device=dev)
+    pose = torch.empty((P, 4, 4), dtype=torch.float32, device=dev)
+    need = ctypes.c_size_t(0)
+    _check(lib().pcacc_sinkhorn_kabsch_workspace_bytes(int(P), int(k), ctypes.byref(need)), 'sinkhorn_kabsch_workspace')
+    ws = _ws(need.value, dev)
+    _check(lib().pcacc_sinkhorn_kabsch(_dev(feats_s, torch.float32, 'feats_s'), _dev(feats_t, torch.float32, 'feats_t'),
+                                       _dev(coor_s, torch.float32, 'coor_s'), _dev(coor_t, torch.float32, 'coor_t'),
+                                       _dev(thr2, torch.float32, 'thr2'), _dev(params, torch.float32, 'params'), int(P), int(k), int(c),
+                                       int(n_iters), _dev(perm), _dev(pose), _dev(ws), ctypes.c_size_t(ws.numel()), _stream()),
+           'sinkhorn_kabsch')
+    return perm, pose

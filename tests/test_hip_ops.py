@@ -438,3 +438,46 @@ def test_pfn_features_vs_oracle_and_pfn_golden(native, dev, golden):
     with torch.no_grad():
         out = pfn(pts.to(dev), None, inp['coordinates'].to(dev), torch.from_numpy(mean).to(dev), inp['time_indice'].to(dev), pidx=pidx)
     np.testing.assert_allclose(out.cpu().numpy(), g['pfn_out'], rtol=1e-4, atol=5e-5)
+
+
+# ---------------------------------------------------------------- A8 fused Sinkhorn + Kabsch (forward)
+def test_sinkhorn_kabsch_golden_pair(native, dev, golden):
+    """The reference's pairwise_ego_motion_estimation output (tests/golden/ego.npz) for one pair, k = 64 key points."""
+    g = golden('ego')
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+    fs, ft = g['fs'][g['choice_s']][None], g['ft'][g['choice_t']][None]
+    cs, ct = g['cs'][g['choice_s']][None], g['ct'][g['choice_t']][None]
+    thr2 = torch.tensor([(float(g['duration']) * float(g['max_speed'])) ** 2], device=dev)
+    params = torch.tensor([np.log1p(np.exp(float(g['alpha']))), np.exp(float(g['beta'])) + 0.02], dtype=torch.float32, device=dev)
+    perm, pose = native.sinkhorn_kabsch(t(fs), t(ft), t(cs), t(ct), thr2, params, 3)
+    np.testing.assert_allclose(perm[0].cpu().numpy(), g['perm'][0], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(pose[0].cpu().numpy(), g['pose'], atol=1e-4)
+
+
+def test_sinkhorn_kabsch_full_size_vs_oracle(native, dev):
+    rng = np.random.RandomState(8)
+    P, k, c = 3, 1024, 64
+    fs = rng.randn(P, k, c).astype(np.float32); fs /= np.linalg.norm(fs, axis=2, keepdims=True)
+    ft = rng.randn(P, k, c).astype(np.float32); ft /= np.linalg.norm(ft, axis=2, keepdims=True)
+    ft[:, :700] = fs[:, :700] + 0.05 * rng.randn(P, 700, c).astype(np.float32)        # real correspondences
+    ft /= np.linalg.norm(ft, axis=2, keepdims=True)
+    cs = rng.uniform(-30, 30, (P, k, 3)).astype(np.float32)
+    a = 0.03
+    R = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], np.float32)
+    ct = (cs @ R.T + np.array([0.8, -0.1, 0.0], np.float32)).astype(np.float32)
+    ct[:, 700:] = rng.uniform(-30, 30, (P, k - 700, 3))
+    thr2 = np.array([9.0, 36.0, 81.0], np.float32)
+    params = np.array([np.log1p(np.exp(-5.0)), np.exp(-5.0) + 0.02], np.float32)
+    t = lambda x: torch.from_numpy(x).to(dev)
+    perm, pose = native.sinkhorn_kabsch(t(fs), t(ft), t(cs), t(ct), t(thr2), t(params), 3)
+    for p in range(P):
+        support = (oracle.square_distance(cs[p], ct[p]) < thr2[p]).astype(np.float32)
+        aff = -(oracle.square_distance(fs[p], ft[p], normalised=True) - params[0]) / params[1]
+        ref = np.exp(oracle.sinkhorn(aff, 3)) * support
+        np.testing.assert_allclose(perm[p].cpu().numpy(), ref, rtol=2e-3, atol=1e-6)
+        rowsum = ref.sum(1, keepdims=True)
+        r, tt = oracle.kabsch(cs[p], (ref @ ct[p]) / (rowsum + np.float32(1e-20)), rowsum[:, 0])
+        got = pose[p].cpu().numpy()
+        np.testing.assert_allclose(got[:3, :3], r, atol=1e-4)
+        np.testing.assert_allclose(got[:3, 3], tt[:, 0], atol=2e-3)
+        np.testing.assert_allclose(got[:3, :3], R, atol=2e-2)                              # and it recovers the planted motion
