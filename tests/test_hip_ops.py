@@ -481,3 +481,17 @@ def test_sinkhorn_kabsch_full_size_vs_oracle(native, dev):
         np.testing.assert_allclose(got[:3, :3], r, atol=1e-4)
         np.testing.assert_allclose(got[:3, 3], tt[:, 0], atol=2e-3)
         np.testing.assert_allclose(got[:3, :3], R, atol=2e-2)                              # and it recovers the planted motion
+
+
+def test_pillar_scatter_duplicate_cells_later_wins(native, dev):
+    """Two pillars on one cell (cannot happen after the voxeliser, but scatter_point_pillar defines it): the later row wins,
+    as `canvas[:, indices] = voxels` does in the reference (models/pillar_encoder.py:163)."""
+    coords = np.array([[0, 0, 1, 2, 0], [0, 0, 3, 3, 1], [0, 0, 1, 2, 0], [1, 0, 0, 0, 2]], np.float64)    # rows 0 and 2 collide
+    feats = np.arange(16, dtype=np.float32).reshape(4, 4) + 1
+    shape = [4, 4, 1, 3]
+    cell, c2p = native.cell_index(torch.from_numpy(coords).to(dev), 4, 4, 3, 2)
+    canvas = native.pillar_scatter(torch.from_numpy(feats).to(dev), c2p)
+    got = canvas.view(2, 3, 4, 4, 4).permute(0, 4, 1, 2, 3).cpu().numpy()
+    ref = oracle.scatter_point_pillar(feats, coords, 2, shape)
+    assert np.array_equal(got, ref)
+    assert np.array_equal(got[0, :, 0, 1, 2], feats[2])

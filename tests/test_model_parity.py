@@ -251,3 +251,65 @@ def test_gpu_vs_oracle_backend_ragged_batch(monkeypatch):
               'motionhead.mos_seg.seg_head.3.weight', 'ego_feats_head.seg_head.3.weight'):
         g, c = gpu[2][k], cpu[2][k]
         assert abs(float(g.norm()) - float(c.norm())) < 3e-2 * max(float(c.norm()), 1e-3), k
+
+
+def _no_foreground(dev):
+    """MIN_POINTS gates (models/motionnet.py:11,222,243): with no foreground point at all the STPN and the TubeNet are skipped,
+    mos_est defaults to class 0 / zero offsets, and FuseLoss still returns a finite loss that back-propagates."""
+    from helpers import oracle_voxeliser
+    from pcaccumulation_amd.dataloader import collate_fn
+    from pcaccumulation_amd.synthetic import make_sequence, attach_voxels
+    cfg = default_config('waymo', 'train', n_sweeps=3, xy_range=8)
+    sample = attach_voxels(make_sequence(50, 3, 1200, cfg, n_inst=0), oracle_voxeliser(cfg))
+    assert int(sample['fb_labels'].sum()) == 0
+    inp = _to(collate_fn([sample]), dev)
+    torch.manual_seed(0)
+    model = MotionNet(cfg)
+    fill_state_dict_(model)
+    with torch.no_grad():
+        model.semseg_head.seg_head[3].bias += torch.tensor([1e4, 0.0])            # every pillar predicted background
+    model = model.to(dev).train()
+    out = model(inp)
+    assert int(out['fb_est_per_points'].sum()) == 0
+    assert 'tpointnet_loss_terms' not in out and 'inst_pose_est' not in out
+    assert torch.equal(out['mos_est'].cpu(), torch.tensor([[1.0, 0.0]]).repeat(inp['input_points'].shape[0], 1))
+    assert float(out['offset_est'].abs().sum()) == 0.0
+    assert torch.equal(out['rec_est'], out['transformed_points'])
+    stats = FuseLoss(cfg['loss'])(out, inp)
+    assert torch.isfinite(stats['loss'])
+    stats['loss'].backward()
+    assert model.unet.conv_final.weight.grad is not None and model.motionhead.final_proj[0].weight.grad is None
+
+
+def test_host_logic_no_foreground_gates(double):
+    _no_foreground(double)
+
+
+@pytest.mark.gpu
+def test_gpu_no_foreground_gates():
+    _no_foreground(torch.device('cuda:0'))
+
+
+def test_dropin_import_paths():
+    """the reference's import statements resolve to this package through dropin/."""
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'dropin'))
+    try:
+        for name in ('models', 'models.motionnet', 'models.pillar_encoder', 'libs', 'libs.voxel_generator', 'chamfer_distance',
+                     'chamfer_distance.chamfer_distance'):
+            sys.modules.pop(name, None)
+        mn = importlib.import_module('models.motionnet')
+        pe = importlib.import_module('models.pillar_encoder')
+        vg = importlib.import_module('libs.voxel_generator')
+        cd = importlib.import_module('chamfer_distance.chamfer_distance')
+        assert mn.MotionNet is MotionNet
+        assert all(hasattr(pe, n) for n in ('PillarFeatureNet', 'scatter_point_pillar', 'inverse_scatter_point_pillar', 'temporal_ungrid', 'ungrid'))
+        assert hasattr(vg, 'Voxelization') and hasattr(cd, 'ChamferDistance')
+    finally:
+        sys.path.remove(os.path.join(root, 'dropin'))
+        for name in ('models', 'models.motionnet', 'models.pillar_encoder', 'libs', 'libs.voxel_generator', 'chamfer_distance',
+                     'chamfer_distance.chamfer_distance'):
+            sys.modules.pop(name, None)
