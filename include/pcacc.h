@@ -222,6 +222,28 @@ int pcacc_chamfer_backward(const float *xyz1, const float *xyz2, int b, int n, i
                            const float *grad_dist1, const int32_t *idx1, const float *grad_dist2, const int32_t *idx2,
                            float *grad_xyz1, float *grad_xyz2, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * C1. Test-mode instance clustering -- models/cluster.py:86-111 (Cluster.forward with fb_labels=None),
+ * :52-84 (cluster_per_batch), :23-49 (cluster), :9-13 (voxel_downsample); called from
+ * models/motionnet.py:238.  Replaces the host round trip through torchsparse v1.4.0 sparse_quantize
+ * (README.md:27) and sklearn.cluster.DBSCAN(metric='euclidean') with one set of launches for the whole
+ * batch; same labels, bit for bit (DESIGN.md section 9 has the argument).
+ *   points [n,3] f32   ego-motion-compensated points (results['transformed_points'])
+ *   offset [n,2] f32   predicted centre offsets, added to x,y before clustering (use_offset=True), or NULL
+ *   sel    [n]   u8    1 = predicted moving (mos.argmax(1) == 1)
+ *   batch  [n]   i32   sample index of every point, 0 <= batch < n_batches <= 64
+ *   voxel_size         0.05 with offsets, 0.15 without (cluster.py:76,80)
+ *   eps, min_samples   DBSCAN parameters (cfg.cluster.eps_dbscan, min_samples_dbscan); z is ignored
+ *   min_p_cluster      clusters with fewer down-sampled points are dropped, and a sample with
+ *                      <= min_p_cluster selected points is not clustered at all (cluster.py:38-41,66)
+ *   labels [n]   i64   0 = no instance, 1..K per sample in canonical order (toolbox/utils.py:237-250)
+ * Voxel indices are packed in 19 bits per axis: |coordinate / voxel_size| must stay below 2^18.
+ * ---------------------------------------------------------------------------------------------- */
+int pcacc_cluster_workspace_bytes(int64_t n, size_t *bytes /*host*/);
+int pcacc_cluster(const float *points, const float *offset, const uint8_t *sel, const int32_t *batch, int64_t n,
+                  int32_t n_batches, float voxel_size, double eps, int32_t min_samples, int32_t min_p_cluster,
+                  int64_t *labels, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

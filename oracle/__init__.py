@@ -447,3 +447,114 @@ def scene_flow_epe(rec_est, input_points, time_indice, ego_motion_gt, inst_label
                               inst_labels, np.asarray(inst_motion_gt, np.float64), n_frames)
     err = np.linalg.norm((np.asarray(rec_est, np.float64) - x) - (gt - x), axis=1)
     return err[t > 0]
+
+
+# ------------------------------------------------------------------------------------------------
+# C1  test-mode instance clustering  (models/cluster.py:9-111)
+#
+# Third-party pieces, both absent from /root/reference:
+#   torchsparse v1.4.0 (README.md:27) sparse_quantize(coords, voxel_size=1, return_index, return_inverse):
+#     floor(coords / voxel_size) as int32, ravel hash (row-major over the min-shifted columns), then
+#     np.unique(hash, return_index, return_inverse).  The reference keeps a copy of the same algorithm at
+#     dataset_toolbox/prep_nuscene_waymo_sf/libs/spv_utils.py:7-75.  np.unique sorts the keys, so the kept
+#     points come out in lexicographic (x, y, z) voxel order and each voxel keeps its FIRST point.
+#   scikit-learn DBSCAN (unpinned): fit_predict with metric='euclidean' builds a KD-tree over the float64
+#     copy of X; a point is core when >= min_samples points (itself included) have squared distance
+#     <= eps*eps; clusters are numbered in the order of their smallest core index and a border point takes
+#     the smallest-numbered cluster that has a core point within eps (sklearn/cluster/_dbscan_inner.pyx:
+#     cluster k is expanded completely before cluster k+1 starts).
+# dbscan() below restates that; tests pin it against sklearn.cluster.DBSCAN itself, which IS installed here.
+# ------------------------------------------------------------------------------------------------
+def sparse_quantize(coords):
+    """torchsparse v1.4.0 torchsparse/utils/quantize.py (voxel_size=1): -> (first-occurrence indices, inverse map)."""
+    c = np.floor(np.asarray(coords)).astype(np.int32)
+    c = c - c.min(0)
+    c = c.astype(np.uint64)
+    cmax = c.max(0).astype(np.uint64) + np.uint64(1)
+    h = np.zeros(c.shape[0], np.uint64)
+    for k in range(c.shape[1] - 1):
+        h += c[:, k]
+        h *= cmax[k + 1]
+    h += c[:, -1]
+    _, idx, inv = np.unique(h, return_index=True, return_inverse=True)
+    return idx, inv
+
+
+def voxel_downsample(points, voxel_size):
+    """models/cluster.py:9-13."""
+    return sparse_quantize(np.round(np.asarray(points) / voxel_size))
+
+
+def dbscan(x, eps, min_samples):
+    """sklearn.cluster.DBSCAN(eps, min_samples, metric='euclidean').fit_predict(x), restated (see the block comment)."""
+    x = np.asarray(x, np.float64)
+    n = x.shape[0]
+    r2 = float(eps) * float(eps)
+    nbrs = []
+    for s in range(0, n, 1024):
+        d = np.zeros((min(1024, n - s), n))
+        for k in range(x.shape[1]):                      # sum in column order, like the tree's rdist loop
+            t = x[s:s + 1024, k:k + 1] - x[None, :, k]
+            d = d + t * t
+        nbrs += [np.nonzero(row <= r2)[0] for row in d]
+    core = np.array([len(a) >= min_samples for a in nbrs], bool)
+    labels = np.full(n, -1, np.int64)
+    k = 0
+    for i in range(n):
+        if labels[i] != -1 or not core[i]:
+            continue
+        stack = [i]
+        while stack:
+            v = stack.pop()
+            if labels[v] == -1:
+                labels[v] = k
+                if core[v]:
+                    stack.extend(int(u) for u in nbrs[v] if labels[u] == -1)
+        k += 1
+    return labels
+
+
+def canonicalise_random_indice(indice):
+    """toolbox/utils.py:237-250."""
+    uniq = {v: i for i, v in enumerate(sorted(set(indice)))}
+    return [uniq[v] for v in indice]
+
+
+def cluster_labels(points, eps, min_samples, min_p_cluster, estimator=None):
+    """models/cluster.py:23-49 (inst_labels=None)."""
+    lab = dbscan(points, eps, min_samples) if estimator is None else estimator.fit_predict(points)
+    lab = np.asarray(lab).copy()
+    for u in np.unique(lab).tolist():
+        if (lab == u).sum() < min_p_cluster:
+            lab[lab == u] = -1
+    assert lab.min() <= 0
+    if lab.min() == -1:
+        return np.array(canonicalise_random_indice(lab.tolist()))
+    return np.array(canonicalise_random_indice(lab.tolist())) + 1
+
+
+def cluster_per_batch(mos, offset, points, eps, min_samples, min_p_cluster, use_offset=True, estimator=None):
+    """models/cluster.py:52-84 with fb_labels=None.  mos [N], offset [N,2], points [N,3] (float32)."""
+    mos, offset, points = np.asarray(mos), np.asarray(offset, np.float32), np.asarray(points, np.float32)
+    sel = mos == 1
+    full = np.zeros(mos.shape[0], np.int64)
+    if sel.sum() > min_p_cluster:
+        shifted = points.copy()
+        shifted[:, :2] += offset
+        src = (shifted if use_offset else points)[sel].copy()
+        sub, inv = voxel_downsample(src, 0.05 if use_offset else 0.15)
+        src[:, -1] = 0
+        full[sel] = cluster_labels(src[sub], eps, min_samples, min_p_cluster, estimator)[inv]
+    return full
+
+
+def cluster_forward(points, mos, offset, time_indice, eps, min_samples, min_p_cluster, use_offset=True, estimator=None):
+    """models/cluster.py:86-111: per-sample clustering of the points predicted moving -> inst_labels_est [N] (0 = none)."""
+    b = np.asarray(time_indice)[:, 0]
+    out = []
+    for i in range(int(b.max() + 1)):
+        s = b == i
+        if s.sum():
+            out.append(cluster_per_batch(np.asarray(mos)[s], np.asarray(offset)[s], np.asarray(points)[s], eps,
+                                         min_samples, min_p_cluster, use_offset, estimator))
+    return np.concatenate(out).astype(np.int64)

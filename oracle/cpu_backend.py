@@ -205,10 +205,21 @@ def sinkhorn_kabsch(feats_s, feats_t, coor_s, coor_t, thr2, params, n_iters):
     return torch.from_numpy(np.stack(perms)), torch.from_numpy(np.stack(poses))
 
 
+def cluster(points, offset, sel, batch, n_batches, voxel_size, eps, min_samples, min_p_cluster):
+    use_offset = offset is not None
+    assert abs(voxel_size - (0.05 if use_offset else 0.15)) < 1e-6
+    off = _np(offset) if use_offset else np.zeros((points.shape[0], 2), np.float32)
+    ti = np.stack([_np(batch).astype(np.int64), np.zeros(points.shape[0], np.int64)], 1)
+    lab = np.zeros(points.shape[0], np.int64)
+    if points.shape[0]:
+        lab = oracle.cluster_forward(_np(points), _np(sel).astype(np.int64), off, ti, eps, min_samples, min_p_cluster, use_offset)
+    return torch.from_numpy(lab)
+
+
 NAMES = ['voxelize', 'cell_index', 'frame_pillars', 'csr_build', 'segment_mean3_maxlabel', 'segment_max',
          'segment_max_backward', 'segment_sum', 'pillar_scatter', 'gather_rows', 'bilinear_gather',
          'bilinear_gather_backward', 'bev_warp', 'rigid_transform', 'chamfer_forward', 'chamfer_backward',
-         'rows_linear', 'rows_wgrad', 'rows_linear_supported', 'pfn_features', 'scatter_sum_small', 'sinkhorn_kabsch']
+         'rows_linear', 'rows_wgrad', 'rows_linear_supported', 'pfn_features', 'scatter_sum_small', 'sinkhorn_kabsch', 'cluster']
 
 
 def install(monkeypatch=None):

@@ -185,10 +185,11 @@ class MotionNet(nn.Module):
         if self.mode in ['train', 'val']:
             inst_labels = input_dict['inst_labels'][:, 0].long()
         else:
+            results['_n_batches'] = B                     # spares the cluster step a .max() read-back
             self.cluster(transformed_points, full_mos.argmax(1), full_offset, time_indice, results, use_offset=True)
             inst_labels = results['inst_labels_est']
             rec_mask = inst_labels != 0
-            n_rec = int(rec_mask.sum())
+            n_rec = int(rec_mask.sum())                   # the one extra host sync of test mode
         if n_rec > MIN_POINTS:
             rec_idx = torch.nonzero_static(rec_mask, size=n_rec)[:, 0]
             results['_rec_idx'] = rec_idx

@@ -46,6 +46,7 @@ EXPORTS = [
     'pcacc_pfn_features', 'pcacc_rows_linear', 'pcacc_rows_wgrad', 'pcacc_pillar_scatter', 'pcacc_gather_rows',
     'pcacc_bilinear_gather', 'pcacc_bilinear_gather_backward', 'pcacc_bev_warp', 'pcacc_rigid_transform',
     'pcacc_sinkhorn_kabsch_workspace_bytes', 'pcacc_sinkhorn_kabsch', 'pcacc_chamfer_workspace_bytes', 'pcacc_chamfer_forward', 'pcacc_chamfer_backward',
+    'pcacc_cluster_workspace_bytes', 'pcacc_cluster',
 ]
 
 
@@ -370,3 +371,20 @@ def sinkhorn_kabsch(feats_s, feats_t, coor_s, coor_t, thr2, params, n_iters):
                                        int(n_iters), _dev(perm), _dev(pose), _dev(ws), ctypes.c_size_t(ws.numel()), _stream()),
            'sinkhorn_kabsch')
     return perm, pose
+
+
+def cluster(points, offset, sel, batch, n_batches, voxel_size, eps, min_samples, min_p_cluster):
+    """Instance labels [N] i64 of the selected points, clustered per sample; see include/pcacc.h (C1)."""
+    n = points.shape[0]
+    labels = torch.empty((n,), dtype=torch.int64, device=points.device)
+    if n == 0:
+        return labels
+    need = ctypes.c_size_t(0)
+    _check(lib().pcacc_cluster_workspace_bytes(_i64(n), ctypes.byref(need)), 'cluster_workspace')
+    ws = _ws(need.value, points.device)
+    _check(lib().pcacc_cluster(_dev(points, torch.float32, 'points'),
+                               _dev(offset, torch.float32, 'offset') if offset is not None else None,
+                               _dev(sel, torch.uint8, 'sel'), _dev(batch, torch.int32, 'batch'), _i64(n), int(n_batches),
+                               ctypes.c_float(voxel_size), ctypes.c_double(eps), int(min_samples), int(min_p_cluster),
+                               _dev(labels), _dev(ws), ctypes.c_size_t(ws.numel()), _stream()), 'cluster')
+    return labels

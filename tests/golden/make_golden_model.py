@@ -161,3 +161,46 @@ def gen_model(save, sha):
          epe_sample=epe.numpy()[::64], **d)
     print('waymo val: M=%d, fg ratio %.3f, rot err %.3f, epe %.4f' % (
         int(inp['num_voxels'][0]), float(out['fb_est_per_points'].float().mean()), d['ego_rot_error'], d['epe_mean']))
+
+
+OFFSET_SCALE, MOS_SHIFT = 0.01, 6.0
+
+
+def gen_model_test(save):
+    """misc.mode='test' (B=1, as libs/tester.py runs it): estimated foreground only, DBSCAN instances instead of the
+    ground-truth ones, identity instance-motion 'ground truth' (models/alignnet.py:190-192)."""
+    import numpy as np
+    g = np.load(__file__.replace('make_golden_model.py', 'model_tiny_val.npz'))
+    tweaks = {str(k): v for k, v in zip(g['tweak_keys'], g['tweak_vals'])}
+    cfg_s = default_config('waymo', 'val', n_sweeps=3, xy_range=8)
+    from models.motionnet import MotionNet
+    cfg = dict(cfg_s)
+    cfg['misc'] = dict(cfg['misc'], mode='test')
+    vox = rh.voxeliser(cfg)
+    inp = rh.collate([attach_voxels(make_sequence(20, 3, 1500, cfg), vox)])
+    model = MotionNet(cfg)
+    fill_state_dict_(model)
+    with torch.no_grad():
+        sd = model.state_dict()
+        for k, v in tweaks.items():
+            sd[k] += torch.from_numpy(v)
+        # closed-form weights give offsets of metres and scattered 'moving' points; damp the offset head and push the
+        # motion head towards 'moving' so that DBSCAN finds instances (the test applies the same two edits)
+        sd['motionhead.offset_head.seg_head.3.weight'] *= OFFSET_SCALE
+        sd['motionhead.offset_head.seg_head.3.bias'] *= OFFSET_SCALE
+        sd['motionhead.mos_seg.seg_head.3.bias'] += torch.tensor([0.0, MOS_SHIFT])
+    model.eval()
+    torch.manual_seed(123)
+    with torch.no_grad():
+        out = model(inp)
+    lab = out['inst_labels_est'].numpy()
+    print('tiny test: moving %.3f, instances %d, labelled points %d, inst_l2 %.4f' % (
+        float(out['mos_est'].argmax(1).float().mean()), int(lab.max()), int((lab > 0).sum()), out.get('inst_l2_error', -1)))
+    save('model_tiny_test', seeds=np.array([20]), n_frames=3, pts_per_frame=1500, fwd_seed=123,
+         tweak_keys=np.array(list(tweaks.keys())), tweak_vals=np.stack(list(tweaks.values())),
+         offset_scale=OFFSET_SCALE, mos_shift=MOS_SHIFT, inst_labels_est=lab, mos_est=out['mos_est'].numpy(), offset_est=out['offset_est'].numpy(),
+         rec_est=out['rec_est'].numpy(), transformed_points=out['transformed_points'].numpy(),
+         fb_est_per_points=out['fb_est_per_points'].numpy(), ego_motion_est=out['ego_motion_est'].numpy(),
+         inst_pose_est=out['inst_pose_est'].numpy() if 'inst_pose_est' in out else np.zeros((0, 4, 4), np.float32),
+         inst_l2_error=out.get('inst_l2_error', -1.0), dynamic_inst_l2_error=out.get('dynamic_inst_l2_error', -1.0),
+         ego_rot_error=out['ego_rot_error'], ego_trans_error=out['ego_trans_error'])
