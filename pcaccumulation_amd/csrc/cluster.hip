@@ -7,9 +7,11 @@
 //   voxel down-sampling   key = (sample, vx, vy, vz) packed in 64 bits, stable radix sort -> the kept points come
 //                         out in the order np.unique gives the ravel hash (lexicographic voxel order) and each voxel
 //                         keeps its first (lowest-index) point, like sparse_quantize(return_index, return_inverse).
-//   neighbourhoods        uniform grid with cells slightly wider than eps, second radix sort by cell; a point scans
-//                         the three cell rows around it.  The distance test is the KD-tree's: float64
+//   neighbourhoods        uniform grid with cells 0.7 eps wide, second radix sort by cell; a point scans the 5x5 cells
+//                         around it (5 contiguous runs).  The distance test is the KD-tree's: float64
 //                         dx*dx + dy*dy (summed in that order, no FMA) <= eps*eps, the point itself included.
+//                         Points of one cell are always in range of each other, which bounds the work on dense
+//                         objects: a full cell makes all its points core at once, and one edge joins two cells.
 //   clusters              lock-free union-find over core-core edges (on grid positions, so the candidate loops read
 //                         contiguous memory), then the lowest kept-point index among each component's core points.
 //                         scikit-learn numbers clusters in the order of their lowest core index and finishes cluster k
@@ -31,8 +33,10 @@
 #define CL_INVALID 0xffffffffffffffffull
 #define CL_VBITS 19                       // per-axis voxel field; |coordinate| < 2^18 voxels (13 km at 5 cm)
 #define CL_VBIAS (1 << 18)
-#define CL_GBITS 28                       // per-axis grid-cell field
-#define CL_GBIAS (1 << 27)
+#define CL_GBITS 17                       // per-axis grid-cell field: the grid key is 6 + 2*17 = 40 bits = 5 radix passes
+#define CL_GBIAS (1 << 16)
+#define CL_GSHIFT (2 * CL_GBITS)          // sample index of the grid key
+#define CL_GINVALID ((1ull << (CL_GSHIFT + 6)) - 1)
 #define CL_BSHIFT 57                      // sample index in the top bits: n_batches <= 64
 
 struct ClusterWs {
@@ -40,7 +44,8 @@ struct ClusterWs {
     int *idx_a, *idx_b, *gi_a, *gi_b;
     int *head, *vox;                      // vox[n] = number of kept voxels M
     float *sx, *sy, *gpx, *gpy;           // kept points by voxel rank / by grid order
-    int *row_lo, *row_hi;                 // [3][n] candidate ranges in grid order
+    int *cell_lo, *cell_hi;               // extent of a point's own cell, by grid position
+    int *near_lo, *near_hi, *far_lo, *far_hi;   // [3][n] / [5][n] candidate ranges in grid order
     int *core, *parent, *root_min, *comp, *size, *flag, *rank;   // core/parent/root_min by grid position
     int *chunk;                           // chunk sums scratch
     int *base, *gate;                     // per sample
@@ -69,7 +74,9 @@ static size_t cluster_carve(ClusterWs *w, char *p, int64_t n)
     w->head = (int *)take(n1 * 4);  w->vox = (int *)take(n1 * 4);
     w->sx = (float *)take(n1 * 4);  w->sy = (float *)take(n1 * 4);
     w->gpx = (float *)take(n1 * 4); w->gpy = (float *)take(n1 * 4);
-    w->row_lo = (int *)take(3 * n1 * 4); w->row_hi = (int *)take(3 * n1 * 4);
+    w->cell_lo = (int *)take(n1 * 4); w->cell_hi = (int *)take(n1 * 4);
+    w->near_lo = (int *)take(3 * n1 * 4); w->near_hi = (int *)take(3 * n1 * 4);
+    w->far_lo = (int *)take(5 * n1 * 4); w->far_hi = (int *)take(5 * n1 * 4);
     w->core = (int *)take(n1 * 4); w->parent = (int *)take(n1 * 4); w->root_min = (int *)take(n1 * 4); w->comp = (int *)take(n1 * 4);
     w->size = (int *)take(n1 * 4); w->flag = (int *)take(n1 * 4); w->rank = (int *)take(n1 * 4);
     w->chunk = (int *)take(((size_t)pcacc_chunks(n) + 2) * 4);
@@ -90,7 +97,7 @@ extern "C" int pcacc_cluster_workspace_bytes(int64_t n, size_t *bytes)
 __device__ __forceinline__ uint64_t cl_field(int v, int bias, int bits)
 {
     int64_t t = (int64_t)v + bias;
-    const int64_t hi = (1ll << bits) - 1;
+    const int64_t hi = (1ll << bits) - 2;     // the all-ones pattern is left to the invalid key
     t = t < 0 ? 0 : (t > hi ? hi : t);
     return (uint64_t)t;
 }
@@ -129,7 +136,7 @@ __global__ __launch_bounds__(CL_BLOCK) void cluster_heads(const uint64_t *__rest
 __global__ __launch_bounds__(CL_BLOCK) void cluster_reset(int64_t n, uint64_t *gk, int *gi, int *parent, int *size, int *root_min)
 {
     for (int64_t j = (int64_t)blockIdx.x * CL_BLOCK + threadIdx.x; j < n; j += (int64_t)gridDim.x * CL_BLOCK) {
-        gk[j] = CL_INVALID;                    // slots >= M sort to the end
+        gk[j] = CL_GINVALID;                   // slots >= M sort to the end
         gi[j] = (int)j;
         parent[j] = (int)j;
         size[j] = 0;
@@ -154,7 +161,7 @@ __global__ __launch_bounds__(CL_BLOCK) void cluster_sub_points_fill(const float 
         sy[u] = y;
         const uint64_t b = key[j] >> CL_BSHIFT;
         const int gx = (int)floorf(x / cell), gy = (int)floorf(y / cell);
-        gk[u] = (b << CL_BSHIFT) | (cl_field(gx, CL_GBIAS, CL_GBITS) << CL_GBITS) | cl_field(gy, CL_GBIAS, CL_GBITS);
+        gk[u] = (b << CL_GSHIFT) | (cl_field(gx, CL_GBIAS, CL_GBITS) << CL_GBITS) | cl_field(gy, CL_GBIAS, CL_GBITS);
     }
 }
 
@@ -168,11 +175,15 @@ __device__ __forceinline__ int cl_lower_bound(const uint64_t *a, int n, uint64_t
     return lo;
 }
 
-// grid-ordered coordinates and the three candidate ranges of every kept point
+// Grid-ordered coordinates, the extent of every point's own cell, and its candidate ranges: cells are 0.7 eps wide, so
+// (a) two points of one cell are always within eps of each other and (b) anything within eps lies at most 2 cells away.
+// Row r of `near` covers cells (gx + r-1, gy-1 .. gy+1); row r of `far` covers (gx + CL_ROW_DX[r], gy-2 .. gy+2), own row first.
+__constant__ int CL_ROW_DX[5] = {0, -1, 1, -2, 2};
+
 __global__ __launch_bounds__(CL_BLOCK) void cluster_rows(const uint64_t *__restrict__ gk, const int *__restrict__ g2u,
                                                          const float *__restrict__ sx, const float *__restrict__ sy,
                                                          const int *__restrict__ m_ptr, int64_t n, float *gpx, float *gpy,
-                                                         int *row_lo, int *row_hi)
+                                                         int *cell_lo, int *cell_hi, int *near_lo, int *near_hi, int *far_lo, int *far_hi)
 {
     const int m = *m_ptr;
     for (int k = blockIdx.x * CL_BLOCK + threadIdx.x; k < m; k += gridDim.x * CL_BLOCK) {
@@ -181,13 +192,20 @@ __global__ __launch_bounds__(CL_BLOCK) void cluster_rows(const uint64_t *__restr
         gpy[k] = sy[u];
         const uint64_t key = gk[k];
         const uint64_t gy = key & ((1ull << CL_GBITS) - 1);
-        const uint64_t hi_part = key >> CL_GBITS;                  // (sample, gx)
+        const uint64_t hi_part = key >> CL_GBITS;                  // (sample, gx); the bias keeps gx, gy >= 2
+        cell_lo[k] = cl_lower_bound(gk, m, key);
+        cell_hi[k] = cl_lower_bound(gk, m, key + 1);
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            const uint64_t row = (hi_part + r - 1) << CL_GBITS;    // gx-1, gx, gx+1 (bias keeps gx >= 1)
-            const uint64_t lo_k = row | (gy > 0 ? gy - 1 : 0), hi_k = row | (gy + 1);
-            row_lo[(int64_t)r * n + k] = cl_lower_bound(gk, m, lo_k);
-            row_hi[(int64_t)r * n + k] = cl_lower_bound(gk, m, hi_k + 1);
+            const uint64_t row = (hi_part + r - 1) << CL_GBITS;
+            near_lo[(int64_t)r * n + k] = cl_lower_bound(gk, m, row | (gy - 1));
+            near_hi[(int64_t)r * n + k] = cl_lower_bound(gk, m, (row | (gy + 1)) + 1);
+        }
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            const uint64_t row = (hi_part + CL_ROW_DX[r]) << CL_GBITS;
+            far_lo[(int64_t)r * n + k] = cl_lower_bound(gk, m, row | (gy - 2));
+            far_hi[(int64_t)r * n + k] = cl_lower_bound(gk, m, (row | (gy + 2)) + 1);
         }
     }
 }
@@ -204,29 +222,35 @@ __device__ __forceinline__ bool cl_in_range(float ax, float ay, float bx, float 
 
 // ---- 3. core points (flags kept in GRID order: the candidate loops below then read contiguous memory) ---------------
 __global__ __launch_bounds__(CL_BLOCK) void cluster_core(const float *__restrict__ gpx, const float *__restrict__ gpy,
-                                                         const int *__restrict__ row_lo, const int *__restrict__ row_hi,
+                                                         const int *__restrict__ cell_lo, const int *__restrict__ cell_hi,
+                                                         const int *__restrict__ far_lo, const int *__restrict__ far_hi,
                                                          const int *__restrict__ m_ptr, int64_t n, double r2, int min_samples,
                                                          int *core_g)
 {
     const int m = *m_ptr;
     for (int k = blockIdx.x * CL_BLOCK + threadIdx.x; k < m; k += gridDim.x * CL_BLOCK) {
-        const float x = gpx[k], y = gpy[k];
-        int cnt = 0;
-        for (int r = 0; r < 3; ++r) {
-            const int lo = row_lo[(int64_t)r * n + k], hi = row_hi[(int64_t)r * n + k];
-            for (int c = lo; c < hi; ++c) cnt += cl_in_range(x, y, gpx[c], gpy[c], r2) ? 1 : 0;
+        int cnt = cell_hi[k] - cell_lo[k];                 // the own cell is in range as a whole
+        if (cnt < min_samples) {
+            const float x = gpx[k], y = gpy[k];
+            cnt = 0;
+            for (int r = 0; r < 5 && cnt < min_samples; ++r) {
+                const int lo = far_lo[(int64_t)r * n + k], hi = far_hi[(int64_t)r * n + k];
+                for (int c = lo; c < hi && cnt < min_samples; ++c) cnt += cl_in_range(x, y, gpx[c], gpy[c], r2) ? 1 : 0;
+            }
         }
         core_g[k] = cnt >= min_samples;
     }
 }
 
 // ---- 4. union-find over core-core edges, on grid positions ----------------------------------------------------------------
+__device__ __forceinline__ int uf_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 __device__ __forceinline__ int uf_find(int *parent, int x)
 {
-    int p = __atomic_load_n(&parent[x], __ATOMIC_RELAXED);
+    int p = uf_load(&parent[x]);
     while (p != x) {
-        const int gp = __atomic_load_n(&parent[p], __ATOMIC_RELAXED);
-        if (gp != p) __atomic_store_n(&parent[x], gp, __ATOMIC_RELAXED);      // path halving: gp is an ancestor of x
+        const int gp = uf_load(&parent[p]);
+        if (gp != p) __hip_atomic_store(&parent[x], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // path halving
         x = p;
         p = gp;
     }
@@ -245,70 +269,150 @@ __device__ __forceinline__ int uf_union(int *parent, int a, int b)
     }
 }
 
-__global__ __launch_bounds__(CL_BLOCK) void cluster_union(const float *__restrict__ gpx, const float *__restrict__ gpy,
-                                                          const int *__restrict__ row_lo, const int *__restrict__ row_hi,
-                                                          const int *__restrict__ core_g, const int *__restrict__ m_ptr, int64_t n,
-                                                          double r2, int *parent)
+// 4a. the core points of one cell are mutually in range: hang each under the cell's first core point (no atomics: a point
+//     only writes its own, still untouched, slot)
+__global__ __launch_bounds__(CL_BLOCK) void cluster_link_cell(const int *__restrict__ cell_lo, const int *__restrict__ core_g,
+                                                              const int *__restrict__ m_ptr, int *parent)
+{
+    const int m = *m_ptr;
+    for (int k = blockIdx.x * CL_BLOCK + threadIdx.x; k < m; k += gridDim.x * CL_BLOCK) {
+        if (!core_g[k]) continue;
+        int c = cell_lo[k];
+        while (!core_g[c]) ++c;                                               // stops at k at the latest
+        if (c < k) parent[k] = c;
+    }
+}
+
+// 4b/4c. one edge between two cells joins all their core points, so a cell is left as soon as it is known to be in the
+//     point's set (root check on its first core point) or one in-range core point has been joined.  Launched first over
+//     the 8 adjacent cells, where an in-range partner turns up within a few candidates, then over the full 5x5 block,
+//     where by then almost every cell of a dense object already passes the root check.
+template <int ROWS>
+__global__ __launch_bounds__(CL_BLOCK) void cluster_link(const float *__restrict__ gpx, const float *__restrict__ gpy,
+                                                         const int *__restrict__ cell_hi, const int *__restrict__ row_lo,
+                                                         const int *__restrict__ row_hi, const int *__restrict__ core_g,
+                                                         const int *__restrict__ m_ptr, int64_t n, double r2, int *parent)
 {
     const int m = *m_ptr;
     for (int k = blockIdx.x * CL_BLOCK + threadIdx.x; k < m; k += gridDim.x * CL_BLOCK) {
         if (!core_g[k]) continue;
         const float x = gpx[k], y = gpy[k];
         int rk = uf_find(parent, k);
-        for (int r = 0; r < 3; ++r) {
-            const int lo = row_lo[(int64_t)r * n + k];
-            int hi = row_hi[(int64_t)r * n + k];
-            hi = hi < k ? hi : k;                                              // every edge once: from its larger end
-            for (int c = lo; c < hi; ++c) {
-                if (!core_g[c]) continue;
-                // a dense object's points end up under one root after a few joins: one load settles most pairs
-                if (__atomic_load_n(&parent[c], __ATOMIC_RELAXED) == rk) continue;
-                if (cl_in_range(x, y, gpx[c], gpy[c], r2)) rk = uf_union(parent, rk, c);
+        for (int r = 0; r < ROWS; ++r) {
+            int c = row_lo[(int64_t)r * n + k];
+            const int hi = row_hi[(int64_t)r * n + k];
+            while (c < hi) {
+                if (!core_g[c]) { ++c; continue; }
+                const int end = cell_hi[c];
+                if (uf_find(parent, c) != rk) {
+                    for (int d = c; d < end; ++d) {
+                        if (core_g[d] && cl_in_range(x, y, gpx[d], gpy[d], r2)) {
+                            rk = uf_union(parent, rk, d);
+                            break;
+                        }
+                    }
+                }
+                c = end;
             }
         }
     }
 }
 
-// lowest voxel rank among the core points of every component (scikit-learn numbers clusters by it)
-__global__ __launch_bounds__(CL_BLOCK) void cluster_root_min(const int *__restrict__ g2u, const int *__restrict__ core_g,
-                                                             const int *__restrict__ m_ptr, int *parent, int *root_min)
+// after the joins: every core point directly under its root, so the passes below need one load instead of a walk
+__global__ __launch_bounds__(CL_BLOCK) void cluster_flatten(const int *__restrict__ core_g, const int *__restrict__ m_ptr, int *parent)
 {
     const int m = *m_ptr;
     for (int k = blockIdx.x * CL_BLOCK + threadIdx.x; k < m; k += gridDim.x * CL_BLOCK)
-        if (core_g[k]) atomicMin(&root_min[uf_find(parent, k)], g2u[k]);
+        if (core_g[k]) {
+            const int r = uf_find(parent, k);
+            if (r != k) __hip_atomic_store(&parent[k], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+}
+
+// Neighbouring lanes mostly hold points of the same object: combine their contributions per distinct key inside the wave
+// and issue one atomic per key (a dense object would otherwise send tens of thousands of atomics to one address).
+// Both helpers must be reached by all 64 lanes.
+__device__ __forceinline__ void wave_min_by_key(int *table, int key, int val, bool valid)
+{
+    unsigned long long todo = __ballot(valid);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int v = __shfl(key, leader, 64);
+        const bool mine = valid && key == v;
+        int best = mine ? val : 0x7fffffff;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const int o = __shfl_xor(best, d, 64);
+            best = o < best ? o : best;
+        }
+        if (lane_id() == leader && uf_load(&table[v]) > best) atomicMin(&table[v], best);
+        todo &= ~__ballot(mine);
+    }
+}
+
+__device__ __forceinline__ void wave_count_by_key(int *table, int key, bool valid)
+{
+    unsigned long long todo = __ballot(valid);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int v = __shfl(key, leader, 64);
+        const unsigned long long same = __ballot(valid && key == v);
+        if (lane_id() == leader) atomicAdd(&table[v], (int)__popcll(same));
+        todo &= ~same;
+    }
+}
+
+// lowest voxel rank among the core points of every component (scikit-learn numbers clusters by it)
+__global__ __launch_bounds__(CL_BLOCK) void cluster_root_min(const int *__restrict__ g2u, const int *__restrict__ core_g,
+                                                             const int *__restrict__ m_ptr, const int *__restrict__ parent,
+                                                             int *root_min)
+{
+    const int m = *m_ptr;
+    for (int base = blockIdx.x * CL_BLOCK; base < m; base += gridDim.x * CL_BLOCK) {
+        const int k = base + threadIdx.x;
+        const bool valid = k < m && core_g[k];
+        wave_min_by_key(root_min, valid ? parent[k] : 0, valid ? g2u[k] : 0, valid);
+    }
 }
 
 // ---- 5. component of every kept point (core: its own; border: the lowest among core neighbours; noise: -1) ----------
 __global__ __launch_bounds__(CL_BLOCK) void cluster_assign(const float *__restrict__ gpx, const float *__restrict__ gpy,
-                                                           const int *__restrict__ g2u, const int *__restrict__ row_lo,
-                                                           const int *__restrict__ row_hi, const int *__restrict__ core_g,
-                                                           const int *__restrict__ root_min, const int *__restrict__ m_ptr, int64_t n,
-                                                           double r2, int *parent, int *comp, int *size)
+                                                           const int *__restrict__ g2u, const int *__restrict__ cell_hi,
+                                                           const int *__restrict__ far_lo, const int *__restrict__ far_hi,
+                                                           const int *__restrict__ core_g, const int *__restrict__ root_min,
+                                                           const int *__restrict__ m_ptr, int64_t n, double r2,
+                                                           const int *__restrict__ parent, int *comp, int *size)
 {
     const int m = *m_ptr;
-    for (int k = blockIdx.x * CL_BLOCK + threadIdx.x; k < m; k += gridDim.x * CL_BLOCK) {
+    for (int base = blockIdx.x * CL_BLOCK; base < m; base += gridDim.x * CL_BLOCK) {
+        const int k = base + threadIdx.x;
         int best = 0x7fffffff;
-        if (core_g[k]) {
-            best = root_min[uf_find(parent, k)];
-        } else {
-            const float x = gpx[k], y = gpy[k];
-            for (int r = 0; r < 3; ++r) {
-                const int lo = row_lo[(int64_t)r * n + k], hi = row_hi[(int64_t)r * n + k];
-                for (int c = lo; c < hi; ++c) {
-                    if (core_g[c] && cl_in_range(x, y, gpx[c], gpy[c], r2)) {
-                        const int cand = root_min[uf_find(parent, c)];
-                        best = cand < best ? cand : best;
+        if (k < m) {
+            if (core_g[k]) {
+                best = root_min[parent[k]];
+            } else {
+                const float x = gpx[k], y = gpy[k];
+                for (int r = 0; r < 5; ++r) {
+                    int c = far_lo[(int64_t)r * n + k];
+                    const int hi = far_hi[(int64_t)r * n + k];
+                    while (c < hi) {
+                        if (!core_g[c]) { ++c; continue; }
+                        const int end = cell_hi[c];
+                        for (int d = c; d < end; ++d) {                       // a cell's core points share one component
+                            if (core_g[d] && cl_in_range(x, y, gpx[d], gpy[d], r2)) {
+                                const int cand = root_min[parent[d]];
+                                best = cand < best ? cand : best;
+                                break;
+                            }
+                        }
+                        c = end;
                     }
                 }
             }
+            comp[g2u[k]] = best == 0x7fffffff ? -1 : best;
         }
-        const int u = g2u[k];
-        if (best == 0x7fffffff) {
-            comp[u] = -1;
-        } else {
-            comp[u] = best;
-            atomicAdd(&size[best], 1);        // size[] is only ever touched at a component's lowest core point
-        }
+        // size[] is only ever touched at a component's lowest core point
+        wave_count_by_key(size, best, best != 0x7fffffff);
     }
 }
 
@@ -371,7 +475,7 @@ extern "C" int pcacc_cluster(const float *points, const float *offset, const uin
     if (ws_bytes < cluster_carve(&w, (char *)ws, n)) return PCACC_E_WORKSPACE;
     hipStream_t st = pcacc_stream(stream);
     const int grid = pcacc_grid(n, CL_BLOCK);
-    const float cell = (float)eps * 1.0001f;
+    const float cell = (float)eps * 0.7f;          // see cluster_rows
     const double r2 = eps * eps;
 
     hipLaunchKernelGGL(cluster_voxel_keys, dim3(grid), dim3(CL_BLOCK), 0, st, points, offset, sel, batch, n, n_batches, voxel_size,
@@ -383,18 +487,22 @@ extern "C" int pcacc_cluster(const float *points, const float *offset, const uin
     hipLaunchKernelGGL(cluster_reset, dim3(grid), dim3(CL_BLOCK), 0, st, n, w.gk_a, w.gi_a, w.parent, w.size, w.root_min);
     hipLaunchKernelGGL(cluster_sub_points_fill, dim3(grid), dim3(CL_BLOCK), 0, st, points, offset, w.key_b, w.idx_b, w.head, w.vox, n,
                        cell, w.sx, w.sy, w.gk_a);
-    if (rocprim::radix_sort_pairs(w.sort_tmp, w.sort_tmp_bytes, w.gk_a, w.gk_b, w.gi_a, w.gi_b, (size_t)n, 0, 64, st) != hipSuccess)
+    if (rocprim::radix_sort_pairs(w.sort_tmp, w.sort_tmp_bytes, w.gk_a, w.gk_b, w.gi_a, w.gi_b, (size_t)n, 0, CL_GSHIFT + 6, st) != hipSuccess)
         return PCACC_E_LAUNCH;
     const int *m_ptr = w.vox + n;
-    hipLaunchKernelGGL(cluster_rows, dim3(grid), dim3(CL_BLOCK), 0, st, w.gk_b, w.gi_b, w.sx, w.sy, m_ptr, n, w.gpx, w.gpy, w.row_lo,
-                       w.row_hi);
-    hipLaunchKernelGGL(cluster_core, dim3(grid), dim3(CL_BLOCK), 0, st, w.gpx, w.gpy, w.row_lo, w.row_hi, m_ptr, n, r2, min_samples,
-                       w.core);
-    hipLaunchKernelGGL(cluster_union, dim3(grid), dim3(CL_BLOCK), 0, st, w.gpx, w.gpy, w.row_lo, w.row_hi, w.core, m_ptr, n, r2,
-                       w.parent);
+    hipLaunchKernelGGL(cluster_rows, dim3(grid), dim3(CL_BLOCK), 0, st, w.gk_b, w.gi_b, w.sx, w.sy, m_ptr, n, w.gpx, w.gpy, w.cell_lo,
+                       w.cell_hi, w.near_lo, w.near_hi, w.far_lo, w.far_hi);
+    hipLaunchKernelGGL(cluster_core, dim3(grid), dim3(CL_BLOCK), 0, st, w.gpx, w.gpy, w.cell_lo, w.cell_hi, w.far_lo, w.far_hi, m_ptr, n,
+                       r2, min_samples, w.core);
+    hipLaunchKernelGGL(cluster_link_cell, dim3(grid), dim3(CL_BLOCK), 0, st, w.cell_lo, w.core, m_ptr, w.parent);
+    hipLaunchKernelGGL(cluster_link<3>, dim3(grid), dim3(CL_BLOCK), 0, st, w.gpx, w.gpy, w.cell_hi, w.near_lo, w.near_hi, w.core, m_ptr,
+                       n, r2, w.parent);
+    hipLaunchKernelGGL(cluster_link<5>, dim3(grid), dim3(CL_BLOCK), 0, st, w.gpx, w.gpy, w.cell_hi, w.far_lo, w.far_hi, w.core, m_ptr, n,
+                       r2, w.parent);
+    hipLaunchKernelGGL(cluster_flatten, dim3(grid), dim3(CL_BLOCK), 0, st, w.core, m_ptr, w.parent);
     hipLaunchKernelGGL(cluster_root_min, dim3(grid), dim3(CL_BLOCK), 0, st, w.gi_b, w.core, m_ptr, w.parent, w.root_min);
-    hipLaunchKernelGGL(cluster_assign, dim3(grid), dim3(CL_BLOCK), 0, st, w.gpx, w.gpy, w.gi_b, w.row_lo, w.row_hi, w.core, w.root_min,
-                       m_ptr, n, r2, w.parent, w.comp, w.size);
+    hipLaunchKernelGGL(cluster_assign, dim3(grid), dim3(CL_BLOCK), 0, st, w.gpx, w.gpy, w.gi_b, w.cell_hi, w.far_lo, w.far_hi, w.core,
+                       w.root_min, m_ptr, n, r2, w.parent, w.comp, w.size);
     hipLaunchKernelGGL(cluster_survivors, dim3(grid), dim3(CL_BLOCK), 0, st, w.size, m_ptr, n, min_p_cluster, w.flag);
     cluster_scan(w.flag, n, w.chunk, w.rank, st);                                  // rank[n] = survivors in the whole batch
     hipLaunchKernelGGL(cluster_sample_bases, dim3(1), dim3(64), 0, st, w.key_b, w.vox, w.rank, n, n_batches, min_p_cluster, w.base,

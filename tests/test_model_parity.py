@@ -298,8 +298,8 @@ def test_dropin_import_paths():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, 'dropin'))
     try:
-        for name in ('models', 'models.motionnet', 'models.pillar_encoder', 'libs', 'libs.voxel_generator', 'chamfer_distance',
-                     'chamfer_distance.chamfer_distance'):
+        for name in ('models', 'models.motionnet', 'models.pillar_encoder', 'models.cluster', 'libs', 'libs.voxel_generator',
+                     'chamfer_distance', 'chamfer_distance.chamfer_distance'):
             sys.modules.pop(name, None)
         mn = importlib.import_module('models.motionnet')
         pe = importlib.import_module('models.pillar_encoder')
@@ -308,8 +308,9 @@ def test_dropin_import_paths():
         assert mn.MotionNet is MotionNet
         assert all(hasattr(pe, n) for n in ('PillarFeatureNet', 'scatter_point_pillar', 'inverse_scatter_point_pillar', 'temporal_ungrid', 'ungrid'))
         assert hasattr(vg, 'Voxelization') and hasattr(cd, 'ChamferDistance')
+        assert hasattr(importlib.import_module('models.cluster'), 'Cluster')
     finally:
         sys.path.remove(os.path.join(root, 'dropin'))
-        for name in ('models', 'models.motionnet', 'models.pillar_encoder', 'libs', 'libs.voxel_generator', 'chamfer_distance',
-                     'chamfer_distance.chamfer_distance'):
+        for name in ('models', 'models.motionnet', 'models.pillar_encoder', 'models.cluster', 'libs', 'libs.voxel_generator',
+                     'chamfer_distance', 'chamfer_distance.chamfer_distance'):
             sys.modules.pop(name, None)
