@@ -244,6 +244,26 @@ int pcacc_cluster(const float *points, const float *offset, const uint8_t *sel, 
                   int32_t n_batches, float voxel_size, double eps, int32_t min_samples, int32_t min_p_cluster,
                   int64_t *labels, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * A6/A9. 3x3 convolution + bias + ReLU on the bf16 matrix cores -- the nn.Conv2d(3x3, stride 1, padding 1)
+ * layers of models/unet.py:15-27 (conv3x3), :45-71 (DownConv), :74-113 (UpConv), :196-199 (conv_final),
+ * the STPN backbone models/stpn.py:24-43, and with kt = 3 the Conv3d(3x3x3, padding 1) + ReLU stack of
+ * models/stpn.py:13-22 evaluated on [B*T] frames (frame t reads frames t-1, t, t+1 of its own sample).
+ *   in   [n_img, h, w, c_in]  bf16 channels-last;  out [n_img, h, w, c_out] bf16
+ *   wp   prepared weights, bf16 [kt*9][c_out][c_in] (pcacc_conv3x3_prepare_weights)
+ *   bias [c_out] f32 or NULL;  relu != 0 clamps at 0 before the store
+ *   frames: images per sample (T) when kt = 3, else 1;  n_img % frames == 0
+ *   c_in, c_out multiples of 32.  fp32 accumulation; the result is rounded to bf16 once.
+ * prepare_weights: w f32 [c_out][c_in][kt][3][3] (torch layout) -> wp.  transpose != 0 builds the weights
+ * of the data gradient instead (bf16 [kt*9][c_in][c_out], taps mirrored): dX = conv(dY, wp_T) with the
+ * same entry point and c_in / c_out exchanged.
+ * ---------------------------------------------------------------------------------------------- */
+int pcacc_conv3x3_prepare_weights(const float *w, int32_t c_out, int32_t c_in, int32_t kt, int32_t transpose,
+                                  uint16_t *out, void *stream);
+int pcacc_conv3x3_bf16(const uint16_t *in, const uint16_t *wp, const float *bias, uint16_t *out, int32_t n_img,
+                       int32_t frames, int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t kt, int32_t relu,
+                       void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,7 +46,7 @@ EXPORTS = [
     'pcacc_pfn_features', 'pcacc_rows_linear', 'pcacc_rows_wgrad', 'pcacc_pillar_scatter', 'pcacc_gather_rows',
     'pcacc_bilinear_gather', 'pcacc_bilinear_gather_backward', 'pcacc_bev_warp', 'pcacc_rigid_transform',
     'pcacc_sinkhorn_kabsch_workspace_bytes', 'pcacc_sinkhorn_kabsch', 'pcacc_chamfer_workspace_bytes', 'pcacc_chamfer_forward', 'pcacc_chamfer_backward',
-    'pcacc_cluster_workspace_bytes', 'pcacc_cluster',
+    'pcacc_cluster_workspace_bytes', 'pcacc_cluster', 'pcacc_conv3x3_prepare_weights', 'pcacc_conv3x3_bf16',
 ]
 
 
@@ -388,3 +388,31 @@ def cluster(points, offset, sel, batch, n_batches, voxel_size, eps, min_samples,
                                ctypes.c_float(voxel_size), ctypes.c_double(eps), int(min_samples), int(min_p_cluster),
                                _dev(labels), _dev(ws), ctypes.c_size_t(ws.numel()), _stream()), 'cluster')
     return labels
+
+
+def conv3x3_supported(c_in, c_out):
+    return c_in >= 32 and c_out >= 32 and c_in % 32 == 0 and c_out % 32 == 0
+
+
+def conv3x3_prepare_weights(weight, transpose=False):
+    """weight f32 [O,I,3,3] or [O,I,3,3,3] (contiguous) -> bf16 [kt*9, O', I'] for pcacc_conv3x3_bf16 (A6/A9 in pcacc.h)."""
+    o, i = weight.shape[0], weight.shape[1]
+    kt = 3 if weight.dim() == 5 else 1
+    shape = (kt * 9, i, o) if transpose else (kt * 9, o, i)
+    out = torch.empty(shape, dtype=torch.bfloat16, device=weight.device)
+    _check(lib().pcacc_conv3x3_prepare_weights(_dev(weight, torch.float32, 'weight'), int(o), int(i), kt, 1 if transpose else 0,
+                                               _dev(out), _stream()), 'conv3x3_prepare_weights')
+    return out
+
+
+def conv3x3(x_rows, wp, bias, frames, relu):
+    """x_rows bf16 [n_img,h,w,c_in] contiguous, wp from conv3x3_prepare_weights -> bf16 [n_img,h,w,c_out]."""
+    n_img, h, w, c_in = x_rows.shape
+    taps, c_out, wc_in = wp.shape
+    if wc_in != c_in:
+        raise NativeError('conv3x3: weights prepared for %d input channels, input has %d' % (wc_in, c_in))
+    out = torch.empty((n_img, h, w, c_out), dtype=torch.bfloat16, device=x_rows.device)
+    _check(lib().pcacc_conv3x3_bf16(_dev(x_rows, torch.bfloat16, 'x'), _dev(wp, torch.bfloat16, 'wp'),
+                                    _dev(bias, torch.float32, 'bias') if bias is not None else None, _dev(out), int(n_img), int(frames),
+                                    int(h), int(w), int(c_in), int(c_out), taps // 9, 1 if relu else 0, _stream()), 'conv3x3')
+    return out

@@ -360,3 +360,88 @@ def transform_by_index(points, idx, tsfm):
     """points [N,3], idx [N] (any integer / float dtype holding integers), tsfm [K,4,4] -> [N,3] in points.dtype."""
     out = _TransformByIndex.apply(points.contiguous().float(), idx.to(torch.int32).contiguous(), tsfm.contiguous().float())
     return out if points.dtype == torch.float32 else out.to(points.dtype)
+
+
+class _Conv3x3(torch.autograd.Function):
+    """3x3 (kt=1) / 3x3x3 (kt=3) convolution + bias + ReLU on bf16 channels-last rows [n_img, H, W, C] through the MFMA
+    implicit-GEMM kernel (csrc/conv.hip).  Backward: ReLU mask, data gradient with the same kernel on mirrored /
+    transposed weights, weight and bias gradients with the library's backward-weights kernel (fp32 results)."""
+
+    @staticmethod
+    def forward(ctx, x_rows, weight, bias, frames, relu):
+        w32 = weight.detach().float().contiguous(memory_format=torch.contiguous_format)
+        y = native.conv3x3(x_rows, native.conv3x3_prepare_weights(w32), bias.detach().float() if bias is not None else None,
+                           frames, relu)
+        ctx.save_for_backward(x_rows, weight, y if relu else None)
+        ctx.meta = (frames, relu, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x_rows, weight, y = ctx.saved_tensors
+        frames, relu, has_bias = ctx.meta
+        gy = gy.contiguous()
+        if relu:
+            gy = torch.ops.aten.threshold_backward(gy, y, 0)
+        gx = gw = gb = None
+        kt = 3 if weight.dim() == 5 else 1
+        o, i = weight.shape[0], weight.shape[1]
+        need_w = ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2])
+        lib_dgrad = ctx.needs_input_grad[0] and kt == 1 and not conv3x3_preferred(o, i)      # data gradient: channels exchanged
+        if ctx.needs_input_grad[0] and not lib_dgrad:
+            w32 = weight.detach().float().contiguous(memory_format=torch.contiguous_format)
+            gx = native.conv3x3(gy, native.conv3x3_prepare_weights(w32, transpose=True), None, frames, False)
+        if need_w or lib_dgrad:
+            xin = _stack_frames(x_rows, frames) if kt == 3 else x_rows
+            w2 = weight.detach().permute(0, 2, 1, 3, 4).reshape(o, 3 * i, 3, 3) if kt == 3 else weight.detach()
+            gx2, gw2, gb = torch.ops.aten.convolution_backward(
+                gy.permute(0, 3, 1, 2), xin.permute(0, 3, 1, 2), w2.to(torch.bfloat16).contiguous(memory_format=torch.channels_last),
+                [o] if has_bias else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [lib_dgrad, True, has_bias])
+            if lib_dgrad:
+                gx = gx2.permute(0, 2, 3, 1)
+            gw = gw2.float()
+            if kt == 3:
+                gw = gw.reshape(o, 3, i, 3, 3).permute(0, 2, 1, 3, 4)
+            gw = gw.reshape(weight.shape)
+            gb = gb.float() if has_bias else None
+        return gx, gw, gb, None, None
+
+
+def _stack_frames(rows, frames):
+    """[B*T, H, W, C] -> [B*T, H, W, 3C]: frames t-1, t, t+1 side by side (zeros outside the sequence)."""
+    n, h, w, c = rows.shape
+    r = rows.view(n // frames, frames, h, w, c)
+    prev = torch.nn.functional.pad(r[:, :-1], (0, 0, 0, 0, 0, 0, 1, 0))
+    nxt = torch.nn.functional.pad(r[:, 1:], (0, 0, 0, 0, 0, 0, 0, 1))
+    return torch.cat([prev, r, nxt], dim=-1).view(n, h, w, 3 * c)
+
+
+def conv3x3_preferred(c_in, c_out):
+    """Layer shapes on which the MFMA kernel beats the library today (tools/bench_conv.py, profiles/r01_conv_*): the
+    full-resolution layers with few input channels, i.e. everything that is bound by HBM and LDS rather than by the matrix
+    cores.  Wider layers (K = 9 x 128 and up on small images) stay with the library until the kernel tiles K deeper."""
+    return native.conv3x3_supported(c_in, c_out) and c_in <= 64
+
+
+def conv3x3_available(x, weight):
+    """True when `x` (NCHW view or rows) and the 3x3 weight take the MFMA path: GPU, bf16 compute, supported channel counts."""
+    return (x.is_cuda and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16))
+            and conv3x3_preferred(weight.shape[1], weight.shape[0]))
+
+
+def conv3x3_rows(x_rows, weight, bias, frames=1, relu=False):
+    """x_rows [n_img, H, W, C_in] -> [n_img, H, W, C_out] (bf16).  weight [O,I,3,3] (frames ignored) or [O,I,3,3,3]."""
+    if x_rows.dtype != torch.bfloat16:
+        x_rows = x_rows.to(torch.bfloat16)
+    return _Conv3x3.apply(x_rows.contiguous(), weight, bias, int(frames), bool(relu))
+
+
+def conv3x3(x, conv, relu=False):
+    """`relu?(conv(x))` for an nn.Conv2d(3x3, stride 1, padding 1) on an NCHW tensor; channels-last bf16 inputs on the GPU go
+    through the MFMA kernel, everything else through the library with the same semantics."""
+    if conv3x3_available(x, conv.weight) and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) \
+            and conv.dilation == (1, 1) and conv.groups == 1:
+        y = conv3x3_rows(x.permute(0, 2, 3, 1), conv.weight, conv.bias, 1, relu)
+        return y.permute(0, 3, 1, 2)
+    y = conv(x)
+    return torch.relu(y) if relu else y

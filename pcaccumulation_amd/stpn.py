@@ -55,13 +55,15 @@ class STPN(nn.Module):
         for layer in self.init_conv:
             if not isinstance(layer, nn.Conv3d):
                 continue
-            prev = F.pad(rows[:, :-1], (0, 0, 0, 0, 0, 0, 1, 0))                      # frame t-1 (zeros before frame 0)
-            nxt = F.pad(rows[:, 1:], (0, 0, 0, 0, 0, 0, 0, 1))                        # frame t+1 (zeros after the last)
-            stacked = torch.cat([prev, rows, nxt], dim=-1)                             # [B,T,H,W,3C]
             cin = layer.in_channels
+            if ops.conv3x3_available(rows, layer.weight) and layer.kernel_size == (3, 3, 3) and layer.padding == (1, 1, 1):
+                # bf16 on the GPU: the MFMA kernel reads frames t-1, t, t+1 in place (no channel-stacked copy)
+                y = ops.conv3x3_rows(rows.view(B * T, H, W, cin), layer.weight, layer.bias, frames=T, relu=True)
+                rows = y.view(B, T, H, W, layer.out_channels)
+                continue
+            stacked = ops._stack_frames(rows.view(B * T, H, W, cin), T)                # [B*T,H,W,3C]
             w2 = layer.weight.permute(0, 2, 1, 3, 4).reshape(layer.out_channels, 3 * cin, 3, 3)
-            y = F.conv2d(stacked.view(B * T, H, W, 3 * cin).permute(0, 3, 1, 2), w2, layer.bias, padding=1)
-            y = F.relu(y)
+            y = F.relu(F.conv2d(stacked.permute(0, 3, 1, 2), w2, layer.bias, padding=1))
             rows = y.permute(0, 2, 3, 1).contiguous().view(B, T, H, W, layer.out_channels)
         return rows.max(dim=1)[0].permute(0, 3, 1, 2)                                  # [B,C,H,W], channels_last
 

@@ -10,6 +10,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.nn import init
 
+from . import ops
+
 
 def conv3x3(in_channels, out_channels):
     return nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=True)
@@ -27,7 +29,7 @@ class DownConv(nn.Module):
             self.pool = nn.MaxPool2d(kernel_size=2, stride=2)
 
     def forward(self, x):
-        x = F.relu(self.conv2(F.relu(self.conv1(x))))
+        x = ops.conv3x3(ops.conv3x3(x, self.conv1, relu=True), self.conv2, relu=True)
         return (self.pool(x) if self.pooling else x), x
 
 
@@ -45,7 +47,7 @@ class UpConv(nn.Module):
     def forward(self, from_down, from_up):
         from_up = self.upconv(from_up)
         x = torch.cat((from_up, from_down), 1) if self.merge_mode == 'concat' else from_up + from_down
-        return F.relu(self.conv2(F.relu(self.conv1(x))))
+        return ops.conv3x3(ops.conv3x3(x, self.conv1, relu=True), self.conv2, relu=True)
 
 
 class UNet(nn.Module):
@@ -89,7 +91,7 @@ class UNet(nn.Module):
             skips.append(before_pool)
         for i, module in enumerate(self.up_convs):
             x = module(skips[-(i + 2)], x)
-        return self.conv_final(x)
+        return ops.conv3x3(x, self.conv_final)
 
 
 class SegHead1D(nn.Module):
@@ -117,4 +119,5 @@ class SegHead2D(nn.Module):
             nn.Conv2d(mid, out_channel, kernel_size=kernel_size, stride=stride, padding=padding, bias=bias, groups=groups))
 
     def forward(self, feats):
-        return self.seg_head(feats)
+        conv0, bn, act, conv1 = self.seg_head
+        return conv1(act(bn(ops.conv3x3(feats, conv0))))

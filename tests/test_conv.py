@@ -1,0 +1,105 @@
+"""MFMA 3x3 / 3x3x3 convolution (include/pcacc.h A6/A9) against the library convolution on the same bf16 inputs.
+Tolerance: both sides accumulate bf16 products in fp32 and round the result to bf16 once, so they differ by summation
+order only: one bf16 ulp (2^-8 relative) of the largest term."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from pcaccumulation_amd import native, ops
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device('cuda:0')
+
+
+def _ref_conv(x_rows, w, b, relu):
+    y = F.conv2d(x_rows.float().permute(0, 3, 1, 2), w.to(torch.bfloat16).float(), b, padding=1)
+    y = torch.relu(y) if relu else y
+    return y.permute(0, 2, 3, 1)
+
+
+def _close(a, b, scale):
+    err = (a.float() - b.float()).abs().max().item()
+    assert err <= scale * 2 ** -7, (err, scale)
+
+
+@pytest.mark.parametrize('n,h,w,ci,co,relu', [
+    (2, 16, 32, 32, 32, True), (1, 19, 45, 64, 32, False), (3, 8, 33, 32, 64, True), (1, 24, 64, 96, 32, True),
+    (1, 9, 18, 128, 128, True), (1, 18, 18, 256, 128, False), (1, 7, 5, 128, 256, True), (2, 40, 40, 64, 64, True)])
+def test_conv3x3_forward(n, h, w, ci, co, relu):
+    g = torch.Generator(device='cpu').manual_seed(n * 1000 + ci + co)
+    x = torch.randn(n, h, w, ci, generator=g).to(DEV).to(torch.bfloat16)
+    wt = (torch.randn(co, ci, 3, 3, generator=g) / (3 * ci ** 0.5)).to(DEV)
+    b = torch.randn(co, generator=g).to(DEV)
+    y = ops.conv3x3_rows(x, wt, b, 1, relu)
+    ref = _ref_conv(x, wt, b, relu)
+    assert y.dtype == torch.bfloat16 and y.shape == ref.shape
+    _close(y, ref, ref.abs().max().item())
+
+
+def test_conv3x3_identity_weights_asymmetric():
+    """Centre-tap permutation weights: the output must be the input with channels permuted (catches operand swaps)."""
+    ci = co = 64
+    x = torch.randn(1, 12, 40, ci).to(DEV).to(torch.bfloat16)
+    perm = torch.randperm(ci)
+    wt = torch.zeros(co, ci, 3, 3)
+    wt[torch.arange(co), perm, 1, 1] = 1.0
+    y = ops.conv3x3_rows(x, wt.to(DEV), None, 1, False)
+    assert torch.equal(y, x[..., perm.to(DEV)])
+    wt = torch.zeros(co, ci, 3, 3)
+    wt[torch.arange(co), perm, 0, 2] = 1.0           # tap (dy=-1, dx=+1): shifted copy with zero border
+    y = ops.conv3x3_rows(x, wt.to(DEV), None, 1, False)
+    ref = torch.zeros_like(x)
+    ref[:, 1:, :-1] = x[:, :-1, 1:][..., perm.to(DEV)]
+    assert torch.equal(y, ref)
+
+
+@pytest.mark.parametrize('b,t,h,w,ci,co', [(2, 5, 16, 40, 32, 32), (1, 3, 9, 33, 32, 64)])
+def test_conv3x3x3_forward(b, t, h, w, ci, co):
+    g = torch.Generator(device='cpu').manual_seed(7)
+    x = torch.randn(b * t, h, w, ci, generator=g).to(DEV).to(torch.bfloat16)
+    wt = (torch.randn(co, ci, 3, 3, 3, generator=g) / (5 * ci ** 0.5)).to(DEV)
+    bias = torch.randn(co, generator=g).to(DEV)
+    y = ops.conv3x3_rows(x, wt, bias, t, True)
+    x5 = x.float().view(b, t, h, w, ci).permute(0, 4, 1, 2, 3)
+    ref = torch.relu(F.conv3d(x5, wt.to(torch.bfloat16).float(), bias, padding=1)).permute(0, 2, 3, 4, 1).reshape(b * t, h, w, co)
+    _close(y, ref, ref.abs().max().item())
+
+
+@pytest.mark.parametrize('kt', [1, 3])
+def test_conv3x3_backward(kt):
+    b, t, h, w, ci, co = 2, 3, 12, 36, 32, 64
+    g = torch.Generator(device='cpu').manual_seed(11)
+    x = torch.randn(b * t, h, w, ci, generator=g).to(DEV).to(torch.bfloat16).requires_grad_(True)
+    shape = (co, ci, 3, 3, 3) if kt == 3 else (co, ci, 3, 3)
+    wt = (torch.randn(*shape, generator=g) / (4 * ci ** 0.5)).to(DEV).requires_grad_(True)
+    bias = torch.randn(co, generator=g).to(DEV).requires_grad_(True)
+    gy = torch.randn(b * t, h, w, co, generator=g).to(DEV).to(torch.bfloat16)
+    y = ops.conv3x3_rows(x, wt, bias, t if kt == 3 else 1, True)
+    y.backward(gy)
+    xr = x.detach().float().requires_grad_(True)
+    wr = wt.detach().to(torch.bfloat16).float().requires_grad_(True)
+    br = bias.detach().clone().requires_grad_(True)
+    if kt == 3:
+        x5 = xr.view(b, t, h, w, ci).permute(0, 4, 1, 2, 3)
+        yr = torch.relu(F.conv3d(x5, wr, br, padding=1)).permute(0, 2, 3, 4, 1).reshape(b * t, h, w, co)
+    else:
+        yr = torch.relu(F.conv2d(xr.permute(0, 3, 1, 2), wr, br, padding=1)).permute(0, 2, 3, 1)
+    # use the kernel's own ReLU mask: outputs within a bf16 ulp of zero may differ between the two
+    (yr * (y.detach() > 0)).backward(gy.float())
+    _close(x.grad, xr.grad, xr.grad.abs().max().item())
+    assert (wt.grad - wr.grad).abs().max().item() <= 2e-2 * wr.grad.abs().max().item()
+    assert (bias.grad - br.grad).abs().max().item() <= 2e-2 * br.grad.abs().max().item()
+
+
+def test_conv3x3_module_dispatch():
+    conv = torch.nn.Conv2d(32, 64, 3, padding=1).to(DEV)
+    x = torch.randn(2, 32, 16, 32, device=DEV).to(memory_format=torch.channels_last)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        y = ops.conv3x3(x, conv, relu=True)
+        ref = torch.relu(conv(x))
+    assert y.dtype == torch.bfloat16 and y.shape == ref.shape
+    _close(y, ref, ref.abs().max().item())
+    y32 = ops.conv3x3(x, conv, relu=True)              # fp32, no autocast: library path, fp32 result
+    assert y32.dtype == torch.float32
+    with pytest.raises(native.NativeError):
+        native.conv3x3(torch.zeros(1, 8, 8, 32, dtype=torch.bfloat16), torch.zeros(9, 32, 32, dtype=torch.bfloat16), None, 1, False)
