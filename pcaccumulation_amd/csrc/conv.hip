@@ -15,6 +15,16 @@
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+// two fp32 -> packed bf16 (round to nearest even): v_cvt_pk_bf16_f32 on gfx950
+__device__ __forceinline__ uint32_t cv_pack_bf16(float a, float b)
+{
+    const f32x2_t f = {a, b};
+    const bf16x2_t r = __builtin_convertvector(f, bf16x2_t);
+    return *reinterpret_cast<const uint32_t *>(&r);
+}
 
 #define CV_TH 8
 #define CV_TW 32
@@ -50,6 +60,62 @@ extern "C" int pcacc_conv3x3_prepare_weights(const float *w, int32_t c_out, int3
                        kt, transpose, out);
     PCACC_CHECK_LAUNCH();
     return 0;
+}
+
+// epilogue: lane = pixel lp of the wave's R rows; register quad g holds channels ct*32 + 8g + 4*lh .. +3.
+// Split into pack (bias, ReLU, bf16) and store so that the persistent kernel can hold a finished tile in registers and
+// issue its stores one pass later (loads and stores share the vmcnt counter: a wait for the prefetched patch would
+// otherwise also wait for stores issued just before it).  `bias` points at the wave's first channel (or is NULL).
+template <int R, int CT>
+__device__ __forceinline__ void conv_pack_tile(const f32x16_t (&acc)[R][CT], const float *__restrict__ bias, int relu, int lh,
+                                               uint2 (&pk)[R][CT][4])
+{
+#pragma unroll
+    for (int m = 0; m < R; ++m)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = ct * 32 + 8 * g + 4 * lh;
+                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (bias) bv = *reinterpret_cast<const float4 *>(bias + c);
+                float v[4] = {acc[m][ct][4 * g] + bv.x, acc[m][ct][4 * g + 1] + bv.y, acc[m][ct][4 * g + 2] + bv.z,
+                              acc[m][ct][4 * g + 3] + bv.w};
+                if (relu) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+                }
+                pk[m][ct][g].x = cv_pack_bf16(v[0], v[1]);
+                pk[m][ct][g].y = cv_pack_bf16(v[2], v[3]);
+            }
+}
+
+// `row0` = first of the wave's R rows inside the tile, `co` = its first output channel
+template <int R, int CT>
+__device__ __forceinline__ void conv_store_packed(const uint2 (&pk)[R][CT][4], uint16_t *__restrict__ out, int img, int y0, int x0, int h,
+                                                  int w, int c_out, int co, int row0, int lp, int lh)
+{
+    const int x = x0 + lp;
+#pragma unroll
+    for (int m = 0; m < R; ++m) {
+        const int y = y0 + row0 + m;
+        if (y >= h || x >= w) continue;
+        uint16_t *dst = out + (((int64_t)img * h + y) * w + x) * c_out + co;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) *reinterpret_cast<uint2 *>(dst + ct * 32 + 8 * g + 4 * lh) = pk[m][ct][g];
+    }
+}
+
+template <int CT>
+__device__ __forceinline__ void conv_store_tile(const f32x16_t (&acc)[2][CT], const float *__restrict__ bias, uint16_t *__restrict__ out,
+                                                int img, int y0, int x0, int h, int w, int c_out, int co0, int relu, int wave, int lp,
+                                                int lh)
+{
+    uint2 pk[2][CT][4];
+    conv_pack_tile<2, CT>(acc, bias ? bias + co0 : nullptr, relu, lh, pk);
+    conv_store_packed<2, CT>(pk, out, img, y0, x0, h, w, c_out, co0, 2 * wave, lp, lh);
 }
 
 // ---- the convolution ------------------------------------------------------------------------------------------------------------
@@ -148,31 +214,195 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_mfma_kernel(const uint16_t
         }
     }
 
-    // epilogue: lane = pixel lp of rows 2*wave + m; register quad g holds channels ct*32 + 8g + 4*lh .. +3
-    const int x = x0 + lp;
+    conv_store_tile<CT>(acc, bias, out, img, y0, x0, h, w, c_out, co0, relu, wave, lp, lh);
+}
+
+// All (tap, 16-channel) steps of one pass over a patch, as one straight line of code with the LDS fragment reads issued
+// two steps ahead of the MFMAs that consume them.  `pbase` = patch + (row0*CV_PW + lp)*PS + lh*8; `wbase` = the wave's
+// first weight row of tap 0 + lp*PS + lh*8; consecutive taps are TAP_ROWS rows apart.
+template <int R, int CT, int CS, int TAP_ROWS>
+__device__ __forceinline__ void conv_pass_mfma(f32x16_t (&acc)[R][CT], const uint16_t *pbase, const uint16_t *wbase)
+{
+    constexpr int PS = CS + 8;
+    constexpr int KC = CS / 16;
+    constexpr int STEPS = 9 * KC;
+    constexpr int AHEAD = 2;
+    bf16x8_t fb[AHEAD + 1][R], fa[AHEAD + 1][CT];
+    auto load = [&](int slot, int s) {
+        const int tap = s / KC, kc = s % KC;
+        const uint16_t *p = pbase + ((tap / 3) * CV_PW + tap % 3) * PS + kc * 16;
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int y = y0 + 2 * wave + m;
-        if (y >= h || x >= w) continue;
-        uint16_t *dst = out + (((int64_t)img * h + y) * w + x) * c_out + co0;
+        for (int m = 0; m < R; ++m) fb[slot][m] = *reinterpret_cast<const bf16x8_t *>(p + m * CV_PW * PS);
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
+        for (int ct = 0; ct < CT; ++ct) fa[slot][ct] = *reinterpret_cast<const bf16x8_t *>(wbase + (tap * TAP_ROWS + ct * 32) * PS + kc * 16);
+    };
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c = ct * 32 + 8 * g + 4 * lh;
-                float v[4];
+    for (int s = 0; s < AHEAD && s < STEPS; ++s) load(s, s);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    v[q] = acc[m][ct][4 * g + q] + (bias ? bias[co0 + c + q] : 0.f);
-                    if (relu) v[q] = v[q] > 0.f ? v[q] : 0.f;
-                }
-                uint2 pk;
-                pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-                *reinterpret_cast<uint2 *>(dst + c) = pk;
-            }
-        }
+    for (int s = 0; s < STEPS; ++s) {
+        if (s + AHEAD < STEPS) load((s + AHEAD) % (AHEAD + 1), s + AHEAD);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int m = 0; m < R; ++m)
+                acc[m][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s % (AHEAD + 1)][ct], fb[s % (AHEAD + 1)][m], acc[m][ct], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
+}
+
+// ---- small layers (c_in <= 64): all taps' weights resident in LDS, persistent workgroups, patch prefetch -------------------
+// One pass = one (tile, frame tap): the patch of the NEXT pass is fetched into registers while the matrix cores work on
+// the current one, so global latency is paid once per workgroup instead of once per tap.  Workgroups are dealt to XCDs
+// round-robin by the hardware; each XCD is given a contiguous range of tiles so that the halos are shared in its L2.
+// CT = channel tiles of 32 per workgroup; a wave owns R rows of the 8 x 32 tile and CTW of the CT channel tiles, so the
+// workgroup has (8/R) * (CT/CTW) waves: when LDS leaves room for one workgroup per CU only, 8 waves instead of 4 let one
+// wave's epilogue / staging run under another's MFMAs.
+template <int CT, int CS, int R, int CTW>
+__global__ __launch_bounds__(64 * (8 / R) * (CT / CTW)) void conv3x3_resident_kernel(
+    const uint16_t *__restrict__ in, const uint16_t *__restrict__ wp, const float *__restrict__ bias, uint16_t *__restrict__ out,
+    int n_img, int frames, int h, int w, int c_out, int kt, int relu, int tiles_x, int tiles_y, int co_groups)
+{
+    constexpr int THREADS = 64 * (8 / R) * (CT / CTW);
+    constexpr int PS = CS + 8;
+    constexpr int P_CHUNKS = CV_PH * CV_PW * CS / 8;
+    constexpr int P_PER_THREAD = (P_CHUNKS + THREADS - 1) / THREADS;
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    uint16_t *patch = lds;                                     // [CV_PH * CV_PW][PS]
+    uint16_t *wl = lds + CV_PH * CV_PW * PS;                   // [kt * 9][CT * 32][PS]
+    float *bias_l = reinterpret_cast<float *>(wl + kt * 9 * CT * 32 * PS);   // [CT * 32]
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lp = lane & 31, lh = lane >> 5;
+    const int row0 = (wave % (8 / R)) * R;                     // the wave's rows inside the tile
+    const int cw0 = (wave / (8 / R)) * CTW * 32;               // its first channel inside the workgroup's group
+
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int cog = j % co_groups, slot = j / co_groups;
+    const int slots = (gridDim.x >> 3) / co_groups;
+    const int n_tiles = n_img * tiles_y * tiles_x;
+    const int lo = (int)((int64_t)n_tiles * xcd / 8), hi = (int)((int64_t)n_tiles * (xcd + 1) / 8);
+    const int co0 = cog * CT * 32;
+
+    // weights of this output-channel group, all taps
+    const int w_rows = kt * 9 * CT * 32;
+    for (int c = threadIdx.x; c < w_rows * (CS / 8); c += THREADS) {
+        const int row = c / (CS / 8), c8 = c % (CS / 8);
+        const int tap = row / (CT * 32), r = row % (CT * 32);
+        *reinterpret_cast<uint4 *>(wl + row * PS + c8 * 8) =
+            *reinterpret_cast<const uint4 *>(wp + ((int64_t)tap * c_out + co0 + r) * CS + c8 * 8);
+    }
+    if (threadIdx.x < CT * 32) bias_l[threadIdx.x] = bias ? bias[co0 + threadIdx.x] : 0.f;
+
+    // per-thread constants of its patch pieces: position inside the patch and offset from the patch origin in the image
+    uint4 preg[P_PER_THREAD];
+    int p_off[P_PER_THREAD], p_yx[P_PER_THREAD];
+#pragma unroll
+    for (int q = 0; q < P_PER_THREAD; ++q) {
+        const int c = threadIdx.x + q * THREADS;
+        const int px = c / (CS / 8), c8 = c % (CS / 8);
+        const int py = px / CV_PW, pxx = px % CV_PW;
+        p_yx[q] = c < P_CHUNKS ? (py << 8 | pxx) : (0x7f << 8);                  // row 127 never passes the bounds test
+        p_off[q] = ((py - 1) * w + pxx - 1) * CS + c8 * 8;
+    }
+    auto pass_valid = [&](int tile, int f) {
+        if (kt == 1) return true;
+        const int t_frame = (tile / (tiles_y * tiles_x)) % frames + f - 1;
+        return t_frame >= 0 && t_frame < frames;
+    };
+    auto fetch = [&](int tile, int f) {
+        const int img = tile / (tiles_y * tiles_x) + (kt == 3 ? f - 1 : 0);
+        const int rem = tile % (tiles_y * tiles_x);
+        const int y0 = (rem / tiles_x) * CV_TH, x0 = (rem % tiles_x) * CV_TW;
+        const uint16_t *src = in + ((int64_t)img * h * w + (int64_t)y0 * w + x0) * CS;
+#pragma unroll
+        for (int q = 0; q < P_PER_THREAD; ++q) {
+            const int y = y0 - 1 + (p_yx[q] >> 8), x = x0 - 1 + (p_yx[q] & 0xff);
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if ((unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w) v = *reinterpret_cast<const uint4 *>(src + p_off[q]);
+            preg[q] = v;
+        }
+    };
+    auto store_pending = [&](const uint2 (&pk)[R][CTW][4], int t) {
+        const int img = t / (tiles_y * tiles_x), rem = t % (tiles_y * tiles_x);
+        conv_store_packed<R, CTW>(pk, out, img, (rem / tiles_x) * CV_TH, (rem % tiles_x) * CV_TW, h, w, c_out, co0 + cw0, row0, lp, lh);
+    };
+
+    int tile = lo + slot, f = 0;
+    while (tile < hi && !pass_valid(tile, f)) ++f;             // frame tap 1 (the frame itself) is always valid
+    if (tile < hi) fetch(tile, f);
+
+    f32x16_t acc[R][CTW];
+    uint2 pend[R][CTW][4];                                     // finished tile waiting for its stores
+    int pend_tile = -1;
+    bool fresh = true;
+    while (tile < hi) {
+        __syncthreads();                                       // the previous pass is done with the patch
+#pragma unroll
+        for (int q = 0; q < P_PER_THREAD; ++q) {
+            const int c = threadIdx.x + q * THREADS;
+            if (c < P_CHUNKS) *reinterpret_cast<uint4 *>(patch + (c / (CS / 8)) * PS + (c % (CS / 8)) * 8) = preg[q];
+        }
+        __syncthreads();
+        if (pend_tile >= 0) {
+            store_pending(pend, pend_tile);
+            pend_tile = -1;
+        }
+        int nt = tile, nf = f + 1;
+        while (nt < hi) {
+            if (nf >= kt) { nf = 0; nt += slots; continue; }
+            if (pass_valid(nt, nf)) break;
+            ++nf;
+        }
+        if (nt < hi) fetch(nt, nf);                            // in flight during the MFMAs below
+
+        if (fresh) {
+#pragma unroll
+            for (int m = 0; m < R; ++m)
+#pragma unroll
+                for (int ct = 0; ct < CTW; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][ct][r] = 0.f;
+            fresh = false;
+        }
+        conv_pass_mfma<R, CTW, CS, CT * 32>(acc, patch + (row0 * CV_PW + lp) * PS + lh * 8,
+                                            wl + ((f * 9) * CT * 32 + cw0 + lp) * PS + lh * 8);
+        if (nt != tile) {                                      // last pass of this tile
+            conv_pack_tile<R, CTW>(acc, bias_l + cw0, relu, lh, pend);
+            pend_tile = tile;
+            fresh = true;
+        }
+        tile = nt;
+        f = nf;
+    }
+    if (pend_tile >= 0) store_pending(pend, pend_tile);
+}
+
+template <int CT, int CS, int R, int CTW>
+static int conv_launch_resident(const uint16_t *in, const uint16_t *wp, const float *bias, uint16_t *out, int n_img, int frames, int h,
+                                int w, int c_out, int kt, int relu, hipStream_t st)
+{
+    constexpr int THREADS = 64 * (8 / R) * (CT / CTW);
+    const int tiles_x = (w + CV_TW - 1) / CV_TW, tiles_y = (h + CV_TH - 1) / CV_TH;
+    const int co_groups = c_out / (CT * 32);
+    const size_t lds = (size_t)(CV_PH * CV_PW + kt * 9 * CT * 32) * (CS + 8) * sizeof(uint16_t) + CT * 32 * sizeof(float);
+    auto kern = conv3x3_resident_kernel<CT, CS, R, CTW>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return PCACC_E_LAUNCH;
+    int per_cu = (int)((160 * 1024) / lds);
+    const int by_waves = 16 / (THREADS / 64);                                // keep <= 16 waves per CU: the kernels use ~128+ registers
+    per_cu = per_cu > by_waves ? by_waves : per_cu;
+    per_cu = per_cu < 1 ? 1 : per_cu;
+    const int64_t n_tiles = (int64_t)n_img * tiles_y * tiles_x;
+    if (n_tiles > 0x7fffffff) return PCACC_E_ARG;
+    int64_t slots = (int64_t)PCACC_CUS * per_cu / 8 / co_groups;            // per XCD and channel group
+    const int64_t need = (n_tiles + 7) / 8;
+    if (slots > need) slots = need;
+    if (slots < 1) slots = 1;
+    const unsigned grid = (unsigned)(8 * co_groups * slots);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, st, in, wp, bias, out, n_img, frames, h, w, c_out, kt, relu, tiles_x,
+                       tiles_y, co_groups);
+    PCACC_CHECK_LAUNCH();
+    return 0;
 }
 
 template <int CT, int CS>
@@ -202,6 +432,23 @@ extern "C" int pcacc_conv3x3_bf16(const uint16_t *in, const uint16_t *wp, const 
     if (!in || !wp || !out || n_img < 1 || h < 1 || w < 1 || (kt != 1 && kt != 3) || frames < 1 || n_img % frames) return PCACC_E_ARG;
     if (c_in % 32 || c_out % 32 || c_in < 32 || c_out < 32) return PCACC_E_ARG;
     hipStream_t st = pcacc_stream(stream);
+    if (c_in == 32 || c_in == 64) {
+        // all taps' weights + the patch within 150 KB of LDS: widest channel group that fits
+        for (int ctr = 4; ctr >= 1; ctr >>= 1) {
+            if (c_out % (ctr * 32)) continue;
+            const size_t lds = (size_t)(CV_PH * CV_PW + kt * 9 * ctr * 32) * (c_in + 8) * sizeof(uint16_t) + ctr * 32 * sizeof(float);
+            if (lds > 150 * 1024) continue;
+            const bool alone = lds > 80 * 1024;                    // one workgroup per CU: run it with 8 waves
+#define CV_RES(CTV, CSV, RV, CTWV) \
+    return conv_launch_resident<CTV, CSV, RV, CTWV>(in, wp, bias, out, n_img, frames, h, w, c_out, kt, relu, st)
+            if (c_in == 32 && ctr == 1) { if (alone) CV_RES(1, 32, 1, 1); CV_RES(1, 32, 2, 1); }
+            if (c_in == 32 && ctr == 2) { if (alone) CV_RES(2, 32, 2, 1); CV_RES(2, 32, 2, 2); }
+            if (c_in == 32 && ctr == 4) { CV_RES(4, 32, 2, 2); }
+            if (c_in == 64 && ctr == 1) { if (alone) CV_RES(1, 64, 1, 1); CV_RES(1, 64, 2, 1); }
+            if (c_in == 64 && ctr == 2) { CV_RES(2, 64, 2, 1); }
+#undef CV_RES
+        }
+    }
     const int cs_sel = c_in % 128 == 0 ? 128 : (c_in % 64 == 0 ? 64 : 32);   // input channels per LDS pass
     const int ct = c_out % 128 == 0 ? 4 : (c_out % 64 == 0 ? 2 : 1);
 #define CV_CASE(CTV, CSV) \

@@ -1,0 +1,19 @@
+#!/bin/bash
+mkdir -p gpurun_out/pmc_conv
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA" "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS" "SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VALU" "SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_VALU" "TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum GRBM_GUI_ACTIVE"; do
+  tag=$(echo $set | tr ' ' '_' | cut -c1-40)
+  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmc_conv/$tag -o p -- python3 $R/tools/pmc_conv.py 64 64 288 20 > $R/gpurun_out/pmc_conv/$tag.log 2>&1
+done
+cd $R
+python3 - <<'PY'
+import csv, glob, collections
+agg=collections.defaultdict(list)
+for f in glob.glob('gpurun_out/pmc_conv/*/*counter_collection.csv'):
+    for r in csv.DictReader(open(f)):
+        if 'conv3x3' in r['Kernel_Name']:
+            agg[r['Counter_Name']].append(float(r['Counter_Value']))
+for k,v in sorted(agg.items()):
+    print(k, sum(v)/len(v), len(v))
+PY
