@@ -138,6 +138,21 @@ int pcacc_rows_linear(const float *x, const float *in_mask, const float *w, cons
 int pcacc_rows_wgrad(const float *dy, const float *dy_mask, const float *x, int x_relu, int64_t rows, int k, int n,
                      float *dw_aug, void *stream);
 
+/* bf16 compute mode of the same layers (cfg misc.compute_dtype = bf16): rows stored as bf16, fp32 accumulation.
+ *   pcacc_rows_linear_bf16: x, in_mask, residual, out_mask, y all bf16; k, n in {32, 64, 128}; w, bias f32 (rounded to
+ *     bf16 once per launch); the product runs on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16).
+ *   pcacc_rows_linear_mixed / pcacc_rows_wgrad_mixed: the fp32-arithmetic kernels above with per-tensor element types,
+ *     for the layers at the edges of a bf16 chain (k < 32, n = 2) and for the weight gradients.
+ *     rows_linear dtypes bits: 1 = x, 2 = in_mask, 4 = residual, 8 = out_mask, 16 = y are bf16 (clear = f32);
+ *     rows_wgrad  dtypes bits: 1 = dy, 2 = dy_mask, 4 = x are bf16. */
+int pcacc_rows_linear_bf16(const uint16_t *x, const uint16_t *in_mask, const float *w, const float *bias,
+                           const uint16_t *residual, const uint16_t *out_mask, uint16_t *y, int64_t rows, int32_t k,
+                           int32_t n, int32_t flags, void *stream);
+int pcacc_rows_linear_mixed(const void *x, const void *in_mask, const float *w, const float *bias, const void *residual,
+                            const void *out_mask, void *y, int64_t rows, int k, int n, int flags, int dtypes, void *stream);
+int pcacc_rows_wgrad_mixed(const void *dy, const void *dy_mask, const void *x, int x_relu, int64_t rows, int k, int n,
+                           float *dw_aug, int dtypes, void *stream);
+
 /* Sum of rows per index for FEW output rows (m*c <= 8192), no CSR needed: LDS-privatised accumulation.
  * The per-instance 'sum' / 'mean' poolings of models/tpointnet.py:227,251,283-284 and libs/loss.py:216.
  *   src [n,c] f32; idx [n] i32 in [0,m) (negative = skip); out [m,c] f32 (zero-filled by the call). */

@@ -154,23 +154,24 @@ def rows_linear_supported(k, n):
     return k in (2, 3, 4, 9, 32, 64, 128) and 1 <= n <= 128
 
 
-def rows_linear(x, w, bias=None, residual=None, pre_relu=False, post_relu=False, in_mask=None, out_mask=None):
-    h = torch.relu(x) if pre_relu else x
+def rows_linear(x, w, bias=None, residual=None, pre_relu=False, post_relu=False, in_mask=None, out_mask=None, out_dtype=None):
+    out_dtype = out_dtype or x.dtype
+    h = torch.relu(x.float()) if pre_relu else x.float()
     if in_mask is not None:
         h = h * (in_mask > 0)
     y = torch.nn.functional.linear(h, w, bias)
     if residual is not None:
-        y = y + residual
+        y = y + residual.float()
     if post_relu:
         y = torch.relu(y)
     if out_mask is not None:
         y = y * (out_mask > 0)
-    return y
+    return y.to(out_dtype)
 
 
 def rows_wgrad(dy, x, dy_mask=None, x_relu=False):
-    g = dy * (dy_mask > 0) if dy_mask is not None else dy
-    h = torch.relu(x) if x_relu else x
+    g = dy.float() * (dy_mask > 0) if dy_mask is not None else dy.float()
+    h = torch.relu(x.float()) if x_relu else x.float()
     aug = torch.cat([h, torch.ones(h.shape[0], 1)], dim=1)
     return g.t() @ aug
 

@@ -22,13 +22,52 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // flags
 #define MLP_PRE_RELU 1        // X := max(X, 0) on load
 #define MLP_POST_RELU 2       // Y := max(Y, 0) before the store
+// element types (bit set = bf16, clear = f32) of the five row tensors: the arithmetic is fp32 either way
+#define MLP_X_BF16 1
+#define MLP_INMASK_BF16 2
+#define MLP_RES_BF16 4
+#define MLP_OUTMASK_BF16 8
+#define MLP_Y_BF16 16
+
+typedef __bf16 mlp_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float mlp_f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float4 mlp_ld4(const void *p, bool bf, int64_t i4)
+{
+    if (!bf) return reinterpret_cast<const float4 *>(p)[i4];
+    const uint2 v = reinterpret_cast<const uint2 *>(p)[i4];
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                       __uint_as_float(v.y & 0xffff0000u));
+}
+__device__ __forceinline__ float mlp_ld1(const void *p, bool bf, int64_t i)
+{
+    return bf ? bf16_to_f32(reinterpret_cast<const uint16_t *>(p)[i]) : reinterpret_cast<const float *>(p)[i];
+}
+__device__ __forceinline__ uint32_t mlp_pack2(float a, float b)
+{
+    const mlp_f32x2 f = {a, b};
+    const mlp_bf16x2 r = __builtin_convertvector(f, mlp_bf16x2);
+    return *reinterpret_cast<const uint32_t *>(&r);
+}
+__device__ __forceinline__ void mlp_st4(void *p, bool bf, int64_t i4, float4 v)
+{
+    if (!bf) reinterpret_cast<float4 *>(p)[i4] = v;
+    else reinterpret_cast<uint2 *>(p)[i4] = make_uint2(mlp_pack2(v.x, v.y), mlp_pack2(v.z, v.w));
+}
+__device__ __forceinline__ void mlp_st1(void *p, bool bf, int64_t i, float v)
+{
+    if (!bf) reinterpret_cast<float *>(p)[i] = v;
+    else reinterpret_cast<uint16_t *>(p)[i] = f32_to_bf16(v);
+}
 
 template <int K, int MLP_ROWS>
-__global__ __launch_bounds__(MLP_ROWS) void rows_linear_kernel(const float *__restrict__ X, const float *__restrict__ in_mask,
+__global__ __launch_bounds__(MLP_ROWS) void rows_linear_kernel(const void *__restrict__ X, const void *__restrict__ in_mask,
                                                                const float *__restrict__ W, const float *__restrict__ bias,
-                                                               const float *__restrict__ residual, const float *__restrict__ out_mask,
-                                                               float *__restrict__ Y, int64_t rows, int N, int flags)
+                                                               const void *__restrict__ residual, const void *__restrict__ out_mask,
+                                                               void *__restrict__ Y, int64_t rows, int N, int flags, int dt)
 {
+    const bool x_bf = dt & MLP_X_BF16, im_bf = dt & MLP_INMASK_BF16, r_bf = dt & MLP_RES_BF16, om_bf = dt & MLP_OUTMASK_BF16,
+               y_bf = dt & MLP_Y_BF16;
     extern __shared__ __attribute__((aligned(16))) float tile[];       // MLP_ROWS x (max(K,N)+1)
     const int tid = threadIdx.x;
     const int n_tiles = (int)((rows + MLP_ROWS - 1) / MLP_ROWS);
@@ -40,15 +79,14 @@ __global__ __launch_bounds__(MLP_ROWS) void rows_linear_kernel(const float *__re
         //    rows are moved as float4 (keeps 16-byte alignment, conflict-free for ds_read_b128), +1 float otherwise.
         constexpr int KS = (K % 4 == 0) ? K + 4 : K + 1;
         if (K % 4 == 0) {
-            const float4 *X4 = reinterpret_cast<const float4 *>(X + row0 * K);
-            const float4 *M4 = in_mask ? reinterpret_cast<const float4 *>(in_mask + row0 * K) : nullptr;
+            const int64_t g4 = row0 * K / 4;
             for (int i4 = tid; i4 < MLP_ROWS * K / 4; i4 += MLP_ROWS) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if ((int64_t)i4 * 4 < n_in) {
-                    v = X4[i4];
+                    v = mlp_ld4(X, x_bf, g4 + i4);
                     if (flags & MLP_PRE_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    if (M4) {
-                        const float4 mk = M4[i4];
+                    if (in_mask) {
+                        const float4 mk = mlp_ld4(in_mask, im_bf, g4 + i4);
                         if (!(mk.x > 0.f)) v.x = 0.f;
                         if (!(mk.y > 0.f)) v.y = 0.f;
                         if (!(mk.z > 0.f)) v.z = 0.f;
@@ -62,9 +100,9 @@ __global__ __launch_bounds__(MLP_ROWS) void rows_linear_kernel(const float *__re
             for (int idx = tid; idx < MLP_ROWS * K; idx += MLP_ROWS) {
                 float v = 0.f;
                 if (idx < n_in) {
-                    v = X[row0 * K + idx];
+                    v = mlp_ld1(X, x_bf, row0 * K + idx);
                     if (flags & MLP_PRE_RELU) v = fmaxf(v, 0.f);
-                    if (in_mask && !(in_mask[row0 * K + idx] > 0.f)) v = 0.f;
+                    if (in_mask && !(mlp_ld1(in_mask, im_bf, row0 * K + idx) > 0.f)) v = 0.f;
                 }
                 tile[(idx / K) * KS + (idx % K)] = v;
             }
@@ -114,30 +152,28 @@ __global__ __launch_bounds__(MLP_ROWS) void rows_linear_kernel(const float *__re
         // 3. coalesced store of the output tile (residual / relu / mask applied here)
         const int64_t n_out = min((int64_t)MLP_ROWS, rows - row0) * N;
         if (N % 4 == 0) {
-            float4 *Y4 = reinterpret_cast<float4 *>(Y + row0 * N);
-            const float4 *R4 = residual ? reinterpret_cast<const float4 *>(residual + row0 * N) : nullptr;
-            const float4 *O4 = out_mask ? reinterpret_cast<const float4 *>(out_mask + row0 * N) : nullptr;
+            const int64_t g4 = row0 * N / 4;
             for (int i4 = tid; (int64_t)i4 * 4 < n_out; i4 += MLP_ROWS) {
                 const int e = i4 * 4;
                 float4 v = *reinterpret_cast<const float4 *>(&tile[(e / N) * NS + (e % N)]);
-                if (R4) { const float4 r = R4[i4]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+                if (residual) { const float4 r = mlp_ld4(residual, r_bf, g4 + i4); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
                 if (flags & MLP_POST_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                if (O4) {
-                    const float4 mk = O4[i4];
+                if (out_mask) {
+                    const float4 mk = mlp_ld4(out_mask, om_bf, g4 + i4);
                     if (!(mk.x > 0.f)) v.x = 0.f;
                     if (!(mk.y > 0.f)) v.y = 0.f;
                     if (!(mk.z > 0.f)) v.z = 0.f;
                     if (!(mk.w > 0.f)) v.w = 0.f;
                 }
-                Y4[i4] = v;
+                mlp_st4(Y, y_bf, g4 + i4, v);
             }
         } else {
             for (int idx = tid; idx < n_out; idx += MLP_ROWS) {
                 float v = tile[(idx / N) * NS + (idx % N)];
-                if (residual) v += residual[row0 * N + idx];
+                if (residual) v += mlp_ld1(residual, r_bf, row0 * N + idx);
                 if (flags & MLP_POST_RELU) v = fmaxf(v, 0.f);
-                if (out_mask && !(out_mask[row0 * N + idx] > 0.f)) v = 0.f;
-                Y[row0 * N + idx] = v;
+                if (out_mask && !(mlp_ld1(out_mask, om_bf, row0 * N + idx) > 0.f)) v = 0.f;
+                mlp_st1(Y, y_bf, row0 * N + idx, v);
             }
         }
         __syncthreads();
@@ -146,8 +182,8 @@ __global__ __launch_bounds__(MLP_ROWS) void rows_linear_kernel(const float *__re
 
 static bool mlp_k_supported(int k) { return k == 2 || k == 3 || k == 4 || k == 9 || k == 32 || k == 64 || k == 128; }
 
-extern "C" int pcacc_rows_linear(const float *x, const float *in_mask, const float *w, const float *bias, const float *residual,
-                                 const float *out_mask, float *y, int64_t rows, int k, int n, int flags, void *stream)
+static int rows_linear_any(const void *x, const void *in_mask, const float *w, const float *bias, const void *residual,
+                           const void *out_mask, void *y, int64_t rows, int k, int n, int flags, int dt, void *stream)
 {
     if (rows < 0 || n <= 0 || n > 128 || !mlp_k_supported(k)) return PCACC_E_ARG;
     if (rows == 0) return PCACC_OK;
@@ -161,9 +197,9 @@ extern "C" int pcacc_rows_linear(const float *x, const float *in_mask, const flo
 #define LAUNCH(KK)                                                                                                        \
     do {                                                                                                                  \
         if (tile_rows == 128)                                                                                             \
-            rows_linear_kernel<KK, 128><<<grid, 128, lds, s>>>(x, in_mask, w, bias, residual, out_mask, y, rows, n, flags); \
+            rows_linear_kernel<KK, 128><<<grid, 128, lds, s>>>(x, in_mask, w, bias, residual, out_mask, y, rows, n, flags, dt); \
         else                                                                                                              \
-            rows_linear_kernel<KK, 64><<<grid, 64, lds, s>>>(x, in_mask, w, bias, residual, out_mask, y, rows, n, flags);  \
+            rows_linear_kernel<KK, 64><<<grid, 64, lds, s>>>(x, in_mask, w, bias, residual, out_mask, y, rows, n, flags, dt);  \
     } while (0)
     switch (k) {
         case 2: LAUNCH(2); break;
@@ -178,6 +214,19 @@ extern "C" int pcacc_rows_linear(const float *x, const float *in_mask, const flo
 #undef LAUNCH
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
+}
+
+extern "C" int pcacc_rows_linear(const float *x, const float *in_mask, const float *w, const float *bias, const float *residual,
+                                 const float *out_mask, float *y, int64_t rows, int k, int n, int flags, void *stream)
+{
+    return rows_linear_any(x, in_mask, w, bias, residual, out_mask, y, rows, k, n, flags, 0, stream);
+}
+
+extern "C" int pcacc_rows_linear_mixed(const void *x, const void *in_mask, const float *w, const float *bias, const void *residual,
+                                       const void *out_mask, void *y, int64_t rows, int k, int n, int flags, int dtypes, void *stream)
+{
+    if (dtypes & ~31) return PCACC_E_ARG;
+    return rows_linear_any(x, in_mask, w, bias, residual, out_mask, y, rows, k, n, flags, dtypes, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -195,10 +244,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // common 32/64-wide layers small: 4 workgroups per CU overlap staging and MFMA), 2 for <= 8, 6 for the 128 x 129 case.
 
 template <int WG_ROWS, int WG_MAX_TILES>
-__global__ __launch_bounds__(256) void rows_wgrad_kernel(const float *__restrict__ dY, const float *__restrict__ dy_mask,
-                                                         const float *__restrict__ X, int x_relu, int64_t rows, int K, int N,
-                                                         int k_tiles, int n_tile_total, float *dW)
+__global__ __launch_bounds__(256) void rows_wgrad_kernel(const void *__restrict__ dY, const void *__restrict__ dy_mask,
+                                                         const void *__restrict__ X, int x_relu, int64_t rows, int K, int N,
+                                                         int k_tiles, int n_tile_total, float *dW, int dt)
 {
+    const bool dy_bf = dt & 1, m_bf = dt & 2, x_bf = dt & 4;                 // bf16 flags of dY, dy_mask, X
     extern __shared__ __attribute__((aligned(16))) float lds[];      // [WG_ROWS][NS] dY, then [WG_ROWS][KS] X
     const int NS = N + 4, KS = K + 4;                                // +4: rows stay 16-byte aligned, bank-spread
     float *sdy = lds, *sx = lds + WG_ROWS * NS;
@@ -216,14 +266,13 @@ __global__ __launch_bounds__(256) void rows_wgrad_kernel(const float *__restrict
         const int nrow = (int)min((int64_t)WG_ROWS, rows - row0);
         // stage dY (N floats per row) and X (K floats per row); scalar path when the width is not a multiple of 4
         if ((N & 3) == 0) {
-            const float4 *g = reinterpret_cast<const float4 *>(dY + row0 * N);
-            const float4 *m4 = dy_mask ? reinterpret_cast<const float4 *>(dy_mask + row0 * N) : nullptr;
+            const int64_t g4 = row0 * N / 4;
             for (int i = threadIdx.x; i < WG_ROWS * N / 4; i += 256) {
                 const int e = i * 4, r = e / N, c = e % N;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (r < nrow) {
-                    v = g[i];
-                    if (m4) { const float4 mk = m4[i]; if (!(mk.x > 0.f)) v.x = 0.f; if (!(mk.y > 0.f)) v.y = 0.f; if (!(mk.z > 0.f)) v.z = 0.f; if (!(mk.w > 0.f)) v.w = 0.f; }
+                    v = mlp_ld4(dY, dy_bf, g4 + i);
+                    if (dy_mask) { const float4 mk = mlp_ld4(dy_mask, m_bf, g4 + i); if (!(mk.x > 0.f)) v.x = 0.f; if (!(mk.y > 0.f)) v.y = 0.f; if (!(mk.z > 0.f)) v.z = 0.f; if (!(mk.w > 0.f)) v.w = 0.f; }
                 }
                 *reinterpret_cast<float4 *>(&sdy[r * NS + c]) = v;
             }
@@ -231,17 +280,17 @@ __global__ __launch_bounds__(256) void rows_wgrad_kernel(const float *__restrict
             for (int i = threadIdx.x; i < WG_ROWS * N; i += 256) {
                 const int r = i / N, c = i % N;
                 float v = 0.f;
-                if (r < nrow) { v = dY[row0 * N + i]; if (dy_mask && !(dy_mask[row0 * N + i] > 0.f)) v = 0.f; }
+                if (r < nrow) { v = mlp_ld1(dY, dy_bf, row0 * N + i); if (dy_mask && !(mlp_ld1(dy_mask, m_bf, row0 * N + i) > 0.f)) v = 0.f; }
                 sdy[r * NS + c] = v;
             }
         }
         if ((K & 3) == 0) {
-            const float4 *g = reinterpret_cast<const float4 *>(X + row0 * K);
+            const int64_t g4 = row0 * K / 4;
             for (int i = threadIdx.x; i < WG_ROWS * K / 4; i += 256) {
                 const int e = i * 4, r = e / K, c = e % K;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (r < nrow) {
-                    v = g[i];
+                    v = mlp_ld4(X, x_bf, g4 + i);
                     if (x_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 }
                 *reinterpret_cast<float4 *>(&sx[r * KS + c]) = v;
@@ -250,7 +299,7 @@ __global__ __launch_bounds__(256) void rows_wgrad_kernel(const float *__restrict
             for (int i = threadIdx.x; i < WG_ROWS * K; i += 256) {
                 const int r = i / K, c = i % K;
                 float v = 0.f;
-                if (r < nrow) { v = X[row0 * K + i]; if (x_relu) v = fmaxf(v, 0.f); }
+                if (r < nrow) { v = mlp_ld1(X, x_bf, row0 * K + i); if (x_relu) v = fmaxf(v, 0.f); }
                 sx[r * KS + c] = v;
             }
         }
@@ -289,8 +338,8 @@ __global__ __launch_bounds__(256) void rows_wgrad_kernel(const float *__restrict
     }
 }
 
-extern "C" int pcacc_rows_wgrad(const float *dy, const float *dy_mask, const float *x, int x_relu, int64_t rows, int k, int n,
-                                float *dw_aug, void *stream)
+static int rows_wgrad_any(const void *dy, const void *dy_mask, const void *x, int x_relu, int64_t rows, int k, int n, float *dw_aug,
+                          int dt, void *stream)
 {
     if (rows < 0 || k <= 0 || n <= 0 || k > 128 || n > 128 || !dw_aug) return PCACC_E_ARG;
     hipStream_t s = pcacc_stream(stream);
@@ -306,7 +355,7 @@ extern "C" int pcacc_rows_wgrad(const float *dy, const float *dy_mask, const flo
     int grid = PCACC_CUS * (total <= 4 ? 4 : 2);
     if (grid > n_chunks) grid = (int)n_chunks;
     const size_t lds = (size_t)wg_rows * (n + 4 + k + 4) * sizeof(float);
-#define WG_LAUNCH(R, T) rows_wgrad_kernel<R, T><<<grid, 256, lds, s>>>(dy, dy_mask, x, x_relu, rows, k, n, k_tiles, total, dw_aug)
+#define WG_LAUNCH(R, T) rows_wgrad_kernel<R, T><<<grid, 256, lds, s>>>(dy, dy_mask, x, x_relu, rows, k, n, k_tiles, total, dw_aug, dt)
     if (wg_rows == 96) {
         if (total <= 4) WG_LAUNCH(96, 1);
         else if (total <= 8) WG_LAUNCH(96, 2);
@@ -319,4 +368,17 @@ extern "C" int pcacc_rows_wgrad(const float *dy, const float *dy_mask, const flo
 #undef WG_LAUNCH
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
+}
+
+extern "C" int pcacc_rows_wgrad(const float *dy, const float *dy_mask, const float *x, int x_relu, int64_t rows, int k, int n,
+                                float *dw_aug, void *stream)
+{
+    return rows_wgrad_any(dy, dy_mask, x, x_relu, rows, k, n, dw_aug, 0, stream);
+}
+
+extern "C" int pcacc_rows_wgrad_mixed(const void *dy, const void *dy_mask, const void *x, int x_relu, int64_t rows, int k, int n,
+                                      float *dw_aug, int dtypes, void *stream)
+{
+    if (dtypes & ~7) return PCACC_E_ARG;
+    return rows_wgrad_any(dy, dy_mask, x, x_relu, rows, k, n, dw_aug, dtypes, stream);
 }

@@ -1,0 +1,205 @@
+// Per-point linear layers on the bf16 matrix cores, bf16 rows in and out (the bf16 compute mode of the point MLPs:
+// STPN point heads models/stpn.py:94-102, TubeNet embeddings models/tpointnet.py:176-196, pillar encoder blocks
+// models/pillar_encoder.py:13-55).  Same contract as rows_linear in mlp.hip,
+//     Y = [relu]( [relu|mask](X) @ W^T + b [+ residual] ) [masked],
+// with X, Y, residual and the two masks stored as bf16, W and b as fp32 (rounded to bf16 once per launch), fp32
+// accumulation.  At 128 features the fp32 version is VALU-bound (0.57 ms per 3 M rows); here the multiply is ~5 % of the
+// matrix-core peak and the kernel streams rows at HBM speed with half the bytes.
+//
+// Workgroup = 4 waves, persistent over 128-row tiles.  v_mfma_f32_32x32x16_bf16 with A = 32 output features x 16 k (weights,
+// resident in LDS), B = 16 k x 32 rows (the staged tile): D comes out with lane = row, so the result is written to LDS as
+// 8-byte channel quads and leaves through fully coalesced 16-byte stores, where residual / ReLU / output mask are applied.
+#include "common.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+#define MM_TILE 128
+#define MM_THREADS 256
+#define MM_PRE_RELU 1
+#define MM_POST_RELU 2
+
+__device__ __forceinline__ uint32_t mm_pack_bf16(float a, float b)
+{
+    const f32x2_t f = {a, b};
+    const bf16x2_t r = __builtin_convertvector(f, bf16x2_t);
+    return *reinterpret_cast<const uint32_t *>(&r);
+}
+
+// max(x, 0) on two packed bf16: clear the halves whose sign bit is set
+__device__ __forceinline__ uint32_t mm_relu2(uint32_t v)
+{
+    const uint32_t neg = (v >> 15) & 0x00010001u;
+    return v & ~(neg * 0xffffu);
+}
+
+// keep the halves of v whose mask half is > 0
+__device__ __forceinline__ uint32_t mm_mask2(uint32_t v, uint32_t m)
+{
+    const uint32_t lo = m & 0xffffu, hi = m >> 16;                        // > 0: sign clear, not zero, not NaN
+    const uint32_t lo_ok = (lo != 0 && lo <= 0x7f80u) ? 0x0000ffffu : 0u;
+    const uint32_t hi_ok = (hi != 0 && hi <= 0x7f80u) ? 0xffff0000u : 0u;
+    return v & (lo_ok | hi_ok);
+}
+
+__device__ __forceinline__ uint4 mm_relu8(uint4 v) { return make_uint4(mm_relu2(v.x), mm_relu2(v.y), mm_relu2(v.z), mm_relu2(v.w)); }
+__device__ __forceinline__ uint4 mm_mask8(uint4 v, uint4 m)
+{
+    return make_uint4(mm_mask2(v.x, m.x), mm_mask2(v.y, m.y), mm_mask2(v.z, m.z), mm_mask2(v.w, m.w));
+}
+
+__device__ __forceinline__ float mm_lo(uint32_t v) { return __uint_as_float(v << 16); }
+__device__ __forceinline__ float mm_hi(uint32_t v) { return __uint_as_float(v & 0xffff0000u); }
+
+template <int K, int CT>
+__global__ __launch_bounds__(MM_THREADS) void rows_linear_bf16_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ in_mask,
+                                                                      const float *__restrict__ W, const float *__restrict__ bias,
+                                                                      const uint16_t *__restrict__ residual,
+                                                                      const uint16_t *__restrict__ out_mask, uint16_t *__restrict__ Y,
+                                                                      int64_t rows, int flags)
+{
+    constexpr int N = CT * 32;
+    constexpr int XS = K + 8, YS = N + 8;                      // padded LDS row lengths (elements)
+    constexpr int REGION = MM_TILE * (XS > YS ? XS : YS);      // input tile, later the output tile
+    constexpr int X_CHUNKS = MM_TILE * K / 8;                  // 16-byte pieces of an input tile
+    constexpr int X_PER_THREAD = X_CHUNKS / MM_THREADS;
+    constexpr int Y_CHUNKS = MM_TILE * N / 8;
+    constexpr int Y_PER_THREAD = Y_CHUNKS / MM_THREADS;
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    uint16_t *xs = lds;
+    uint16_t *ws = lds + REGION;                               // [N][XS]
+    float *bias_l = reinterpret_cast<float *>(ws + N * XS);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lp = lane & 31, lh = lane >> 5;
+
+    for (int e = threadIdx.x; e < N * K / 2; e += MM_THREADS) {               // weights: fp32 pairs -> packed bf16
+        const int n = (2 * e) / K, k = (2 * e) % K;
+        const float2 w2 = *reinterpret_cast<const float2 *>(W + (int64_t)n * K + k);
+        *reinterpret_cast<uint32_t *>(ws + n * XS + k) = mm_pack_bf16(w2.x, w2.y);
+    }
+    if (threadIdx.x < N) bias_l[threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
+
+    const int64_t n_tiles = (rows + MM_TILE - 1) / MM_TILE;
+    uint4 xreg[X_PER_THREAD], mreg[X_PER_THREAD];
+    auto fetch = [&](int64_t tile) {
+        const int64_t base = tile * MM_TILE * K;                              // element offset of the tile
+        const int64_t limit = rows * K;
+#pragma unroll
+        for (int q = 0; q < X_PER_THREAD; ++q) {
+            const int64_t e = base + (int64_t)(threadIdx.x + q * MM_THREADS) * 8;
+            uint4 v = make_uint4(0, 0, 0, 0), m = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+            if (e < limit) {
+                v = *reinterpret_cast<const uint4 *>(X + e);
+                if (in_mask) m = *reinterpret_cast<const uint4 *>(in_mask + e);
+            }
+            xreg[q] = v;
+            mreg[q] = m;
+        }
+    };
+
+    int64_t tile = blockIdx.x;
+    if (tile < n_tiles) fetch(tile);
+    for (; tile < n_tiles; tile += gridDim.x) {
+        __syncthreads();                                                      // the previous tile's output left the region
+#pragma unroll
+        for (int q = 0; q < X_PER_THREAD; ++q) {
+            const int c = threadIdx.x + q * MM_THREADS;
+            uint4 v = xreg[q];
+            if (flags & MM_PRE_RELU) v = mm_relu8(v);
+            if (in_mask) v = mm_mask8(v, mreg[q]);
+            *reinterpret_cast<uint4 *>(xs + (c / (K / 8)) * XS + (c % (K / 8)) * 8) = v;
+        }
+        __syncthreads();
+        if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);              // in flight during the MFMAs and the store phase
+
+        f32x16_t acc[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+        const uint16_t *xrow = xs + (wave * 32 + lp) * XS + lh * 8;
+        const uint16_t *wrow = ws + lp * XS + lh * 8;
+#pragma unroll
+        for (int kc = 0; kc < K / 16; ++kc) {
+            const bf16x8_t b = *reinterpret_cast<const bf16x8_t *>(xrow + kc * 16);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const bf16x8_t a = *reinterpret_cast<const bf16x8_t *>(wrow + ct * 32 * XS + kc * 16);
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[ct], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                                      // every wave is done reading the input tile
+        uint16_t *yrow = xs + (wave * 32 + lp) * YS;                          // lane = row; quads of 4 consecutive features
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = ct * 32 + 8 * g + 4 * lh;
+                const float4 bv = *reinterpret_cast<const float4 *>(bias_l + c);
+                uint2 pk;
+                pk.x = mm_pack_bf16(acc[ct][4 * g] + bv.x, acc[ct][4 * g + 1] + bv.y);
+                pk.y = mm_pack_bf16(acc[ct][4 * g + 2] + bv.z, acc[ct][4 * g + 3] + bv.w);
+                *reinterpret_cast<uint2 *>(yrow + c) = pk;
+            }
+        __syncthreads();
+        const int64_t ybase = tile * MM_TILE * N, ylimit = rows * N;
+#pragma unroll
+        for (int q = 0; q < Y_PER_THREAD; ++q) {
+            const int c = threadIdx.x + q * MM_THREADS;
+            const int64_t e = ybase + (int64_t)c * 8;
+            if (e >= ylimit) continue;
+            uint4 v = *reinterpret_cast<const uint4 *>(xs + (c / (N / 8)) * YS + (c % (N / 8)) * 8);
+            if (residual) {
+                const uint4 r = *reinterpret_cast<const uint4 *>(residual + e);
+                v.x = mm_pack_bf16(mm_lo(v.x) + mm_lo(r.x), mm_hi(v.x) + mm_hi(r.x));
+                v.y = mm_pack_bf16(mm_lo(v.y) + mm_lo(r.y), mm_hi(v.y) + mm_hi(r.y));
+                v.z = mm_pack_bf16(mm_lo(v.z) + mm_lo(r.z), mm_hi(v.z) + mm_hi(r.z));
+                v.w = mm_pack_bf16(mm_lo(v.w) + mm_lo(r.w), mm_hi(v.w) + mm_hi(r.w));
+            }
+            if (flags & MM_POST_RELU) v = mm_relu8(v);
+            if (out_mask) v = mm_mask8(v, *reinterpret_cast<const uint4 *>(out_mask + e));
+            *reinterpret_cast<uint4 *>(Y + e) = v;
+        }
+    }
+}
+
+template <int K, int CT>
+static int mm_launch(const uint16_t *x, const uint16_t *in_mask, const float *w, const float *bias, const uint16_t *residual,
+                     const uint16_t *out_mask, uint16_t *y, int64_t rows, int flags, hipStream_t st)
+{
+    constexpr int N = CT * 32;
+    constexpr int XS = K + 8, YS = N + 8;
+    const size_t lds = (size_t)(MM_TILE * (XS > YS ? XS : YS) + N * XS) * sizeof(uint16_t) + N * sizeof(float);
+    auto kern = rows_linear_bf16_kernel<K, CT>;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return PCACC_E_LAUNCH;
+    const int64_t n_tiles = (rows + MM_TILE - 1) / MM_TILE;
+    int per_cu = (int)((160 * 1024) / lds);
+    per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);
+    int64_t grid = (int64_t)PCACC_CUS * per_cu;
+    if (grid > n_tiles) grid = n_tiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(MM_THREADS), lds, st, x, in_mask, w, bias, residual, out_mask, y, rows, flags);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}
+
+extern "C" int pcacc_rows_linear_bf16(const uint16_t *x, const uint16_t *in_mask, const float *w, const float *bias,
+                                      const uint16_t *residual, const uint16_t *out_mask, uint16_t *y, int64_t rows, int32_t k,
+                                      int32_t n, int32_t flags, void *stream)
+{
+    if (rows < 0 || (k != 32 && k != 64 && k != 128) || (n != 32 && n != 64 && n != 128)) return PCACC_E_ARG;
+    if (rows == 0) return PCACC_OK;
+    if (!x || !w || !y) return PCACC_E_ARG;
+    hipStream_t st = pcacc_stream(stream);
+#define MM_CASE(KK, CTV) \
+    if (k == KK && n == CTV * 32) return mm_launch<KK, CTV>(x, in_mask, w, bias, residual, out_mask, y, rows, flags, st)
+    MM_CASE(32, 1); MM_CASE(32, 2); MM_CASE(32, 4);
+    MM_CASE(64, 1); MM_CASE(64, 2); MM_CASE(64, 4);
+    MM_CASE(128, 1); MM_CASE(128, 2); MM_CASE(128, 4);
+#undef MM_CASE
+    return PCACC_E_ARG;
+}

@@ -98,6 +98,7 @@ class MotionNet(nn.Module):
         self.Nx, self.Ny, self.nt = nx, ny, nt
         B, T, Ny, Nx = batch_size, nt, ny, nx
         device = coordinates.device
+        ops.set_point_dtype(self.compute_dtype if device.type == 'cuda' else torch.float32)
         results = dict()
 
         # 0. index structures shared by every irregular op of this forward
@@ -229,8 +230,8 @@ class MotionNet(nn.Module):
         """Per-point part of STPN.forward (models/stpn.py:91-104) on the already computed map."""
         mh = self.motionhead
         ungridded = ops.bilinear_gather(stpn_map, points, batch_idx, abs(self.pc_range[0]), abs(self.pc_range[1]))
-        pos = mh.point_mlp(mh.positional_encoding, points / abs(self.pc_range[0]))
-        enc = mh.point_mlp(mh.final_proj, torch.cat([pos, ungridded], dim=-1))
+        pos = mh.point_mlp(mh.positional_encoding, points / abs(self.pc_range[0]))          # rows in ops.point_dtype()
+        enc = mh.point_mlp(mh.final_proj, torch.cat([pos, ungridded.to(pos.dtype)], dim=-1))
         classes = mh.point_head(mh.mos_seg, enc)
         offset = mh.safe_guard_offset(mh.point_head(mh.offset_head, enc))
         return classes, offset, stpn_map

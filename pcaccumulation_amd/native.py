@@ -47,6 +47,7 @@ EXPORTS = [
     'pcacc_bilinear_gather', 'pcacc_bilinear_gather_backward', 'pcacc_bev_warp', 'pcacc_rigid_transform',
     'pcacc_sinkhorn_kabsch_workspace_bytes', 'pcacc_sinkhorn_kabsch', 'pcacc_chamfer_workspace_bytes', 'pcacc_chamfer_forward', 'pcacc_chamfer_backward',
     'pcacc_cluster_workspace_bytes', 'pcacc_cluster', 'pcacc_conv3x3_prepare_weights', 'pcacc_conv3x3_bf16',
+    'pcacc_rows_linear_bf16', 'pcacc_rows_linear_mixed', 'pcacc_rows_wgrad_mixed',
 ]
 
 
@@ -302,26 +303,48 @@ def rows_linear_supported(k, n):
     return k in ROWS_LINEAR_K and 1 <= n <= 128
 
 
-def rows_linear(x, w, bias=None, residual=None, pre_relu=False, post_relu=False, in_mask=None, out_mask=None):
-    """y = post(pre(x) @ w^T + bias + residual); x [rows,k] f32, w [n,k] f32 (see include/pcacc.h)."""
+def _row_dtype_bit(t, bit, what):
+    if t is None or t.dtype == torch.float32:
+        return 0
+    if t.dtype == torch.bfloat16:
+        return bit
+    raise NativeError('%s must be float32 or bfloat16, got %s' % (what, t.dtype))
+
+
+def rows_linear(x, w, bias=None, residual=None, pre_relu=False, post_relu=False, in_mask=None, out_mask=None, out_dtype=None):
+    """y = post(pre(x) @ w^T + bias + residual); x [rows,k], w [n,k] f32 (see include/pcacc.h).  Row tensors may be f32 or
+    bf16; all-bf16 calls with k, n in {32,64,128} run on the matrix cores, everything else in fp32 arithmetic."""
     rows, k = x.shape
     n = w.shape[0]
-    y = torch.empty((rows, n), dtype=torch.float32, device=x.device)
-    opt = lambda t, what: _dev(t, torch.float32, what) if t is not None else None
-    _check(lib().pcacc_rows_linear(_dev(x, torch.float32, 'x'), opt(in_mask, 'in_mask'), _dev(w, torch.float32, 'w'),
-                                   opt(bias, 'bias'), opt(residual, 'residual'), opt(out_mask, 'out_mask'), _dev(y),
-                                   _i64(rows), int(k), int(n), (1 if pre_relu else 0) | (2 if post_relu else 0), _stream()),
+    out_dtype = out_dtype or x.dtype
+    y = torch.empty((rows, n), dtype=out_dtype, device=x.device)
+    opt = lambda t, what: _dev(t, None, what) if t is not None else None
+    flags = (1 if pre_relu else 0) | (2 if post_relu else 0)
+    tensors = (x, in_mask, residual, out_mask, y)
+    all_bf16 = all(t is None or t.dtype == torch.bfloat16 for t in tensors)
+    if all_bf16 and k in (32, 64, 128) and n in (32, 64, 128):
+        _check(lib().pcacc_rows_linear_bf16(_dev(x, torch.bfloat16, 'x'), opt(in_mask, 'in_mask'), _dev(w, torch.float32, 'w'),
+                                            _dev(bias, torch.float32, 'bias') if bias is not None else None, opt(residual, 'residual'),
+                                            opt(out_mask, 'out_mask'), _dev(y), _i64(rows), int(k), int(n), flags, _stream()),
+               'rows_linear_bf16')
+        return y
+    dt = (_row_dtype_bit(x, 1, 'x') | _row_dtype_bit(in_mask, 2, 'in_mask') | _row_dtype_bit(residual, 4, 'residual')
+          | _row_dtype_bit(out_mask, 8, 'out_mask') | _row_dtype_bit(y, 16, 'y'))
+    _check(lib().pcacc_rows_linear_mixed(_dev(x, None, 'x'), opt(in_mask, 'in_mask'), _dev(w, torch.float32, 'w'),
+                                         _dev(bias, torch.float32, 'bias') if bias is not None else None, opt(residual, 'residual'),
+                                         opt(out_mask, 'out_mask'), _dev(y), _i64(rows), int(k), int(n), flags, dt, _stream()),
            'rows_linear')
     return y
 
 
 def rows_wgrad(dy, x, dy_mask=None, x_relu=False):
-    """[n, k+1] = dYeff^T @ [Xeff | 1]: weight gradient with the bias gradient in the last column."""
+    """[n, k+1] f32 = dYeff^T @ [Xeff | 1]: weight gradient with the bias gradient in the last column (dy, x, dy_mask f32 or bf16)."""
     rows, n = dy.shape
     k = x.shape[1]
     out = torch.empty((n, k + 1), dtype=torch.float32, device=dy.device)
-    _check(lib().pcacc_rows_wgrad(_dev(dy, torch.float32, 'dy'), _dev(dy_mask, torch.float32, 'dy_mask') if dy_mask is not None else None,
-                                  _dev(x, torch.float32, 'x'), 1 if x_relu else 0, _i64(rows), int(k), int(n), _dev(out), _stream()),
+    dt = _row_dtype_bit(dy, 1, 'dy') | _row_dtype_bit(dy_mask, 2, 'dy_mask') | _row_dtype_bit(x, 4, 'x')
+    _check(lib().pcacc_rows_wgrad_mixed(_dev(dy, None, 'dy'), _dev(dy_mask, None, 'dy_mask') if dy_mask is not None else None,
+                                        _dev(x, None, 'x'), 1 if x_relu else 0, _i64(rows), int(k), int(n), _dev(out), dt, _stream()),
            'rows_wgrad')
     return out
 

@@ -282,47 +282,68 @@ MIN_ROWS_FUSED_LINEAR = 2048          # below this a library GEMM launch is as g
 
 class _RowsLinear(torch.autograd.Function):
     """nn.Linear on [rows, k] with optional ReLU on the input, ReLU on the output and a residual add, one HBM pass
-    (pcacc_rows_linear); backward = the same kernel with w^T (masks replay the ReLUs) + the MFMA weight-gradient kernel."""
+    (pcacc_rows_linear*); backward = the same kernel with w^T (masks replay the ReLUs) + the MFMA weight-gradient kernel.
+    Rows may be fp32 or bf16 (bf16 compute mode): the output takes `out_dtype`, gradients take the dtype of what they
+    are the gradient of, weights and their gradients stay fp32."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, pre_relu, post_relu):
+    def forward(ctx, x, weight, bias, residual, pre_relu, post_relu, out_dtype):
         x = x.contiguous()
         w = weight.contiguous()
         res = residual.contiguous() if residual is not None else None
-        y = native.rows_linear(x, w, bias, res, pre_relu, post_relu)
-        ctx.flags = (pre_relu, post_relu, bias is not None, residual is not None)
+        y = native.rows_linear(x, w, bias, res, pre_relu, post_relu, out_dtype=out_dtype)
+        ctx.flags = (pre_relu, post_relu, bias is not None, residual is not None, res.dtype if res is not None else None)
         ctx.save_for_backward(x, w, y if post_relu else None)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, w, y = ctx.saved_tensors
-        pre_relu, post_relu, has_bias, has_res = ctx.flags
+        pre_relu, post_relu, has_bias, has_res, res_dtype = ctx.flags
         gy = gy.contiguous()
         gx = gw = gb = gres = None
         if ctx.needs_input_grad[0]:
-            gx = native.rows_linear(gy, w.t().contiguous(), None, None, False, False, in_mask=y, out_mask=x if pre_relu else None)
+            gx = native.rows_linear(gy, w.t().contiguous(), None, None, False, False, in_mask=y, out_mask=x if pre_relu else None,
+                                    out_dtype=x.dtype)
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             aug = native.rows_wgrad(gy, x, dy_mask=y, x_relu=pre_relu)
             gw = aug[:, :-1]
             gb = aug[:, -1] if has_bias else None
         if has_res and ctx.needs_input_grad[3]:
-            gres = gy if y is None else gy * (y > 0)
-        return gx, gw, gb, gres, None, None
+            gres = (gy if y is None else gy * (y > 0)).to(res_dtype)
+        return gx, gw, gb, gres, None, None, None
 
 
-def linear_rows(x, layer, pre_relu=False, post_relu=False, residual=None):
-    """`layer(relu?(x))` (+ residual, relu?) for an nn.Linear `layer` on a 2-D fp32 `x`.  Large row counts with a supported
-    feature width go through the fused HIP kernels; anything else is the library GEMM with the same semantics."""
+_POINT_DTYPE = torch.float32
+
+
+def set_point_dtype(dtype):
+    """Element type in which the per-point MLP chains keep their activations (MotionNet sets it from cfg misc.compute_dtype):
+    float32 (default, the parity mode) or bfloat16 (half the HBM traffic, products on the bf16 matrix cores)."""
+    global _POINT_DTYPE
+    assert dtype in (torch.float32, torch.bfloat16)
+    _POINT_DTYPE = dtype
+
+
+def point_dtype():
+    return _POINT_DTYPE
+
+
+def linear_rows(x, layer, pre_relu=False, post_relu=False, residual=None, out_dtype=None):
+    """`layer(relu?(x))` (+ residual, relu?) for an nn.Linear `layer` on a 2-D `x`.  Large row counts with a supported
+    feature width go through the fused HIP kernels; anything else is the library GEMM with the same semantics.
+    out_dtype: element type of the result (default: that of x); bf16 rows are only taken on the GPU."""
     k, n = layer.in_features, layer.out_features
-    if x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] >= MIN_ROWS_FUSED_LINEAR and native.rows_linear_supported(k, n) \
-            and not torch.is_autocast_enabled():
-        return _RowsLinear.apply(x, layer.weight, layer.bias, residual, pre_relu, post_relu)
+    out_dtype = out_dtype or x.dtype
+    if x.dim() == 2 and x.dtype in (torch.float32, torch.bfloat16) and x.shape[0] >= MIN_ROWS_FUSED_LINEAR \
+            and native.rows_linear_supported(k, n) and not torch.is_autocast_enabled():
+        return _RowsLinear.apply(x, layer.weight, layer.bias, residual, pre_relu, post_relu, out_dtype)
     h = torch.relu(x) if pre_relu else x
-    y = torch.nn.functional.linear(h, layer.weight, layer.bias)
+    y = torch.nn.functional.linear(h.to(layer.weight.dtype), layer.weight, layer.bias)
     if residual is not None:
         y = y + residual
-    return torch.relu(y) if post_relu else y
+    y = torch.relu(y) if post_relu else y
+    return y.to(out_dtype)
 
 
 class _TransformByIndex(torch.autograd.Function):

@@ -83,9 +83,10 @@ class STPN(nn.Module):
         """nn.Sequential of (Linear, ReLU)* evaluated with the fused row-linear kernels (ReLU folded into the store)."""
         mods = list(seq)
         i = 0
+        pd = ops.point_dtype() if x.is_cuda else x.dtype          # bf16 rows in the bf16 compute mode (GPU only)
         while i < len(mods):
             relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
-            x = ops.linear_rows(x, mods[i], post_relu=relu)
+            x = ops.linear_rows(x, mods[i], post_relu=relu, out_dtype=pd)
             i += 2 if relu else 1
         return x
 
@@ -94,7 +95,7 @@ class STPN(nn.Module):
         """SegHead1D = Linear, BatchNorm1d, ReLU, Linear (models/unet.py:240-245): the two Linear layers are fused row
         kernels, BatchNorm1d (batch statistics over the K points in train mode, trap 16) stays the library op."""
         lin0, bn, _, lin1 = head.seg_head
-        return ops.linear_rows(bn(ops.linear_rows(x, lin0)), lin1, pre_relu=True)
+        return ops.linear_rows(bn(ops.linear_rows(x, lin0)), lin1, pre_relu=True, out_dtype=torch.float32)
 
     def forward(self, x, points, time_indice, pc_range):
         """x [B,C,T,H,W]; points [K,3]; time_indice [K,2] -> (mos logits [K,2], offset [K,2], map [B,64,H,W])."""

@@ -495,3 +495,95 @@ def test_pillar_scatter_duplicate_cells_later_wins(native, dev):
     ref = oracle.scatter_point_pillar(feats, coords, 2, shape)
     assert np.array_equal(got, ref)
     assert np.array_equal(got[0, :, 0, 1, 2], feats[2])
+
+
+# ------------------------------------------------------------------------------------------------ bf16 point MLPs
+@pytest.mark.gpu
+@pytest.mark.parametrize('k,n', [(32, 32), (64, 32), (32, 64), (64, 128), (128, 128), (128, 64), (128, 32)])
+@pytest.mark.parametrize('rows', [5000, 128 * 37 + 3])
+def test_rows_linear_bf16_mfma(k, n, rows):
+    """pcacc_rows_linear_bf16 against fp32 arithmetic on the same bf16-rounded operands: the only differences are the
+    fp32 summation order and the final rounding of y to bf16 (2^-8 relative)."""
+    import torch
+    from pcaccumulation_amd import native
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(k * 1000 + n + rows)
+    x = torch.randn(rows, k, generator=g).to(dev).to(torch.bfloat16)
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).to(dev)
+    b = torch.randn(n, generator=g).to(dev)
+    res = torch.randn(rows, n, generator=g).to(dev).to(torch.bfloat16)
+    im = torch.randn(rows, k, generator=g).to(dev).to(torch.bfloat16)
+    om = torch.randn(rows, n, generator=g).to(dev).to(torch.bfloat16)
+    wq = w.to(torch.bfloat16).float()
+    for pre, post, use_res, use_im, use_om in [(False, False, False, False, False), (True, True, True, False, False),
+                                               (False, False, False, True, True), (True, False, True, True, False)]:
+        y = native.rows_linear(x, w, b, res if use_res else None, pre, post, in_mask=im if use_im else None,
+                               out_mask=om if use_om else None)
+        assert y.dtype == torch.bfloat16
+        h = torch.relu(x.float()) if pre else x.float()
+        if use_im:
+            h = h * (im.float() > 0)
+        ref = (h @ wq.t() + b).to(torch.bfloat16).float()           # the kernel rounds before the residual is added
+        if use_res:
+            ref = ref + res.float()
+        if post:
+            ref = torch.relu(ref)
+        if use_om:
+            ref = ref * (om.float() > 0)
+        err = (y.float() - ref).abs().max().item()
+        assert err <= 2 ** -6 * max(1.0, ref.abs().max().item()), (pre, post, use_res, use_im, use_om, err)
+
+
+@pytest.mark.gpu
+def test_rows_linear_mixed_and_wgrad_dtypes():
+    import torch
+    from pcaccumulation_amd import native
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(5)
+    rows = 7001
+    x32 = torch.randn(rows, 3, generator=g).to(dev)
+    w = torch.randn(32, 3, generator=g).to(dev)
+    b = torch.randn(32, generator=g).to(dev)
+    y = native.rows_linear(x32, w, b, None, False, True, out_dtype=torch.bfloat16)          # f32 in, bf16 out (k = 3)
+    ref = torch.relu(x32 @ w.t() + b)
+    assert y.dtype == torch.bfloat16 and (y.float() - ref).abs().max().item() <= 2 ** -7 * ref.abs().max().item()
+    xb = torch.randn(rows, 128, generator=g).to(dev).to(torch.bfloat16)                    # bf16 in, f32 out (n = 2)
+    w2 = torch.randn(2, 128, generator=g).to(dev) / 11
+    y2 = native.rows_linear(xb, w2, None, None, True, False, out_dtype=torch.float32)
+    ref2 = torch.relu(xb.float()) @ w2.t()
+    assert y2.dtype == torch.float32 and (y2 - ref2).abs().max().item() <= 1e-4 * max(1.0, ref2.abs().max().item())
+    dy = torch.randn(rows, 64, generator=g).to(dev).to(torch.bfloat16)                     # weight gradient from bf16 rows
+    mk = torch.randn(rows, 64, generator=g).to(dev).to(torch.bfloat16)
+    aug = native.rows_wgrad(dy, xb, dy_mask=mk, x_relu=True)
+    geff = dy.float() * (mk.float() > 0)
+    refw = geff.t() @ torch.cat([torch.relu(xb.float()), torch.ones(rows, 1, device=dev)], 1)
+    assert (aug - refw).abs().max().item() <= 1e-3 * refw.abs().max().item()
+
+
+@pytest.mark.gpu
+def test_linear_rows_autograd_bf16():
+    import torch
+    from pcaccumulation_amd import ops
+    dev = torch.device('cuda:0')
+    torch.manual_seed(3)
+    lin0, lin1 = torch.nn.Linear(64, 128).to(dev), torch.nn.Linear(128, 32).to(dev)
+    x = torch.randn(6000, 64, device=dev)
+    xb = x.to(torch.bfloat16).requires_grad_(True)
+    out = ops.linear_rows(ops.linear_rows(xb, lin0, post_relu=True), lin1, pre_relu=False)
+    assert out.dtype == torch.bfloat16
+    gy = torch.randn_like(out)
+    out.backward(gy)
+    # reference with the same rounding points: bf16 operands, fp32 sums, bf16 activations and gradients
+    q = lambda t: t.to(torch.bfloat16).float()
+    w0, w1 = q(lin0.weight.detach()), q(lin1.weight.detach())
+    xf = xb.detach().float()
+    h = q(torch.relu(xf @ w0.t() + lin0.bias.detach()))
+    ref = q(h @ w1.t() + lin1.bias.detach())
+    g1 = q(gy.float() @ w1) * (h > 0)
+    gx = q(g1 @ w0)
+    tol = lambda a, b, r: (a.float() - b).abs().max().item() <= r * b.abs().max().item()
+    assert tol(out, ref, 2 ** -6)
+    assert tol(xb.grad, gx, 2 ** -5)
+    assert tol(lin1.weight.grad, gy.float().t() @ h, 1e-2)
+    assert tol(lin0.weight.grad, g1.t() @ xf, 1e-2)
+    assert tol(lin1.bias.grad, gy.float().sum(0), 1e-2)
