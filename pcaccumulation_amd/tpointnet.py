@@ -11,7 +11,7 @@ import torch.nn.functional as F
 from scipy.spatial.transform import Rotation as R
 
 from .chamfer_distance import ChamferDistance
-from .ops import scatter, ScatterPlan, linear_rows, transform_by_index
+from .ops import scatter, ScatterPlan, linear_rows, transform_by_index, point_dtype
 
 _EPS = 1e-20
 
@@ -124,9 +124,12 @@ def _embed(seq, x):
     """(Linear, ReLU)*, Linear with the fused row-linear kernels."""
     mods = list(seq)
     i = 0
+    pd = point_dtype() if x.is_cuda else x.dtype                  # bf16 rows in the bf16 compute mode (GPU only)
+    if pd != x.dtype and mods[0].in_features >= 32:
+        x = x.to(pd)                                               # wide first layer: take the matrix-core path from the start
     while i < len(mods):
         relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
-        x = linear_rows(x, mods[i], post_relu=relu)
+        x = linear_rows(x, mods[i], post_relu=relu, out_dtype=pd)
         i += 2 if relu else 1
     return x
 
@@ -166,7 +169,7 @@ class TPointNet(BaseModel):
         local = xyz - anchor_centre[inst]
         e_frame = scatter(_embed(self.pos_embed, torch.cat((local, t_idx.unsqueeze(-1) / T), dim=1).float()), slot, dim=0,
                           dim_size=n_slots, reduce='max', plan=per_slot)
-        return e_motion, e_geo, e_frame, anchor_centre, local
+        return e_motion.float(), e_geo.float(), e_frame.float(), anchor_centre, local        # pooled codes: [K*T,128], fp32 from here
 
     def forward(self, input_dict):
         feats_motion, feats_geo = input_dict['mos_feats'], input_dict['frame_feats']
