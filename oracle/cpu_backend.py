@@ -62,11 +62,11 @@ def segment_mean3_maxlabel(points, labels, offs, order, m):
 
 
 def segment_max(src, offs, order, m):
-    out, arg = oracle.segment_max(_np(src), _p2v_from_csr(offs, order), m)
-    return torch.from_numpy(out), torch.from_numpy(arg)
+    out, arg = oracle.segment_max(_np(src.float()), _p2v_from_csr(offs, order), m)
+    return torch.from_numpy(out).to(src.dtype), torch.from_numpy(arg)
 
 
-def segment_max_backward(grad_out, arg, p2v, n):
+def segment_max_backward(grad_out, arg, p2v, n, out_dtype=None):
     seg = p2v.long()
     g = grad_out[seg]
     hit = arg[seg].long() == torch.arange(n)[:, None]

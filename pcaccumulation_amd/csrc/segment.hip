@@ -7,6 +7,24 @@
 // segmented loop: pillars have ~3 points on average (models/motionnet.py:142).
 #include "scan.h"
 
+// rows of 4 channels as float4 (f32) or 4 packed bf16 (8 bytes); the arithmetic is fp32 either way
+typedef __bf16 seg_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float seg_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 seg_ld4(const void *p, bool bf, int64_t i4)
+{
+    if (!bf) return reinterpret_cast<const float4 *>(p)[i4];
+    const uint2 v = reinterpret_cast<const uint2 *>(p)[i4];
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                       __uint_as_float(v.y & 0xffff0000u));
+}
+__device__ __forceinline__ void seg_st4(void *p, bool bf, int64_t i4, float4 v)
+{
+    if (!bf) { reinterpret_cast<float4 *>(p)[i4] = v; return; }
+    const seg_f32x2 a = {v.x, v.y}, b = {v.z, v.w};
+    const seg_bf16x2 ra = __builtin_convertvector(a, seg_bf16x2), rb = __builtin_convertvector(b, seg_bf16x2);
+    reinterpret_cast<uint2 *>(p)[i4] = make_uint2(*reinterpret_cast<const uint32_t *>(&ra), *reinterpret_cast<const uint32_t *>(&rb));
+}
+
 #define CSR_SORT_MAX 64      // pillars with more points keep the (arbitrary) cursor order
 
 __global__ __launch_bounds__(256) void csr_histogram(const int32_t *__restrict__ p2v, int64_t n, int *counts)
@@ -175,9 +193,9 @@ extern "C" int pcacc_segment_mean3_maxlabel(const float *points, const int64_t *
 // owns 4 consecutive channels and streams the pillar's rows as float4 (a row of c floats is contiguous).
 // ---------------------------------------------------------------------------------------------------
 template <int LPP>   // lanes per pillar = c / 4
-__global__ __launch_bounds__(256) void seg_max_kernel(const float4 *__restrict__ src, const int32_t *__restrict__ seg_offsets,
+__global__ __launch_bounds__(256) void seg_max_kernel(const void *__restrict__ src, const int32_t *__restrict__ seg_offsets,
                                                       const int32_t *__restrict__ order, int64_t m,
-                                                      float4 *__restrict__ out, int4 *__restrict__ arg)
+                                                      void *__restrict__ out, int4 *__restrict__ arg, bool bf)
 {
     const int sub = threadIdx.x % LPP;
     const int64_t per_block = 256 / LPP;
@@ -187,7 +205,7 @@ __global__ __launch_bounds__(256) void seg_max_kernel(const float4 *__restrict__
         int4 bi = make_int4(-1, -1, -1, -1);
         for (int k = b; k < e; ++k) {
             const int i = order[k];
-            const float4 v = src[(int64_t)i * LPP + sub];
+            const float4 v = seg_ld4(src, bf, (int64_t)i * LPP + sub);
             // strict '>' in ascending index order, but the lowest INDEX must win even when the cursor
             // order of a >64-point pillar is not sorted: tie-break on the index explicitly.
             if (bi.x < 0 || v.x > best.x || (v.x == best.x && i < bi.x)) { best.x = v.x; bi.x = i; }
@@ -195,7 +213,7 @@ __global__ __launch_bounds__(256) void seg_max_kernel(const float4 *__restrict__
             if (bi.z < 0 || v.z > best.z || (v.z == best.z && i < bi.z)) { best.z = v.z; bi.z = i; }
             if (bi.w < 0 || v.w > best.w || (v.w == best.w && i < bi.w)) { best.w = v.w; bi.w = i; }
         }
-        out[s * LPP + sub] = best;
+        seg_st4(out, bf, s * LPP + sub, best);
         arg[s * LPP + sub] = bi;
     }
 }
@@ -350,23 +368,24 @@ static int seg_two_level(const float *src, int c, const int32_t *seg_offsets, co
     return PCACC_OK;
 }
 
-extern "C" int pcacc_segment_max(const float *src, int c, const int32_t *seg_offsets, const int32_t *order, int64_t n, int64_t m,
-                                 float *out, int32_t *arg, void *workspace, size_t workspace_bytes, void *stream)
+static int segment_max_any(const void *src, int dtype, int c, const int32_t *seg_offsets, const int32_t *order, int64_t n, int64_t m,
+                           void *out, int32_t *arg, void *workspace, size_t workspace_bytes, void *stream)
 {
-    if (m < 0 || n < 0 || c <= 0 || (c % 4) || c > 256) return PCACC_E_ARG;
+    if (m < 0 || n < 0 || c <= 0 || (c % 4) || c > 256 || (dtype != PCACC_F32 && dtype != PCACC_BF16)) return PCACC_E_ARG;
+    const bool bf = dtype == PCACC_BF16;
     if (m > 0 && (!seg_offsets || !out || !arg || (n > 0 && (!src || !order)))) return PCACC_E_ARG;
     if (m == 0) return PCACC_OK;
     hipStream_t s = pcacc_stream(stream);
     if (seg_use_two_level(n, m)) {
-        const int rc = seg_two_level<true>(src, c, seg_offsets, order, n, m, out, arg, workspace, workspace_bytes, s);
+        if (bf) return PCACC_E_ARG;                                  // long segments: f32 rows only
+        const int rc = seg_two_level<true>(reinterpret_cast<const float *>(src), c, seg_offsets, order, n, m,
+                                           reinterpret_cast<float *>(out), arg, workspace, workspace_bytes, s);
         if (rc != PCACC_OK) return rc;
         PCACC_CHECK_LAUNCH();
         return PCACC_OK;
     }
-    const float4 *in4 = reinterpret_cast<const float4 *>(src);
-    float4 *out4 = reinterpret_cast<float4 *>(out);
     int4 *arg4 = reinterpret_cast<int4 *>(arg);
-#define LAUNCH(L) seg_max_kernel<L><<<pcacc_grid(m * L, 256), 256, 0, s>>>(in4, seg_offsets, order, m, out4, arg4)
+#define LAUNCH(L) seg_max_kernel<L><<<pcacc_grid(m * L, 256), 256, 0, s>>>(src, seg_offsets, order, m, out, arg4, bf)
     switch (c / 4) {
         case 1: LAUNCH(1); break;
         case 2: LAUNCH(2); break;
@@ -382,10 +401,22 @@ extern "C" int pcacc_segment_max(const float *src, int c, const int32_t *seg_off
     return PCACC_OK;
 }
 
+extern "C" int pcacc_segment_max(const float *src, int c, const int32_t *seg_offsets, const int32_t *order, int64_t n, int64_t m,
+                                 float *out, int32_t *arg, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return segment_max_any(src, PCACC_F32, c, seg_offsets, order, n, m, out, arg, workspace, workspace_bytes, stream);
+}
+
+extern "C" int pcacc_segment_max_t(const void *src, int dtype, int c, const int32_t *seg_offsets, const int32_t *order, int64_t n,
+                                   int64_t m, void *out, int32_t *arg, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return segment_max_any(src, dtype, c, seg_offsets, order, n, m, out, arg, workspace, workspace_bytes, stream);
+}
+
 // grad_src[i,k] = (arg[p2v[i],k] == i) ? grad_out[p2v[i],k] : 0        (fully coalesced, no atomics)
-__global__ __launch_bounds__(256) void seg_max_bwd_kernel(const float4 *__restrict__ grad_out, const int4 *__restrict__ arg,
+__global__ __launch_bounds__(256) void seg_max_bwd_kernel(const void *__restrict__ grad_out, const int4 *__restrict__ arg,
                                                           const int32_t *__restrict__ p2v, int64_t n, int lpp,
-                                                          float4 *__restrict__ grad_src)
+                                                          void *__restrict__ grad_src, bool bf)
 {
     const int64_t total = n * lpp;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
@@ -393,33 +424,44 @@ __global__ __launch_bounds__(256) void seg_max_bwd_kernel(const float4 *__restri
         const int sub = (int)(e - i * lpp);
         const int64_t s = p2v[i];
         const int4 a = arg[s * lpp + sub];
-        const float4 g = grad_out[s * lpp + sub];
+        const float4 g = seg_ld4(grad_out, bf, s * lpp + sub);
         float4 r;
         r.x = (a.x == (int)i) ? g.x : 0.f;
         r.y = (a.y == (int)i) ? g.y : 0.f;
         r.z = (a.z == (int)i) ? g.z : 0.f;
         r.w = (a.w == (int)i) ? g.w : 0.f;
-        grad_src[e] = r;
+        seg_st4(grad_src, bf, e, r);
     }
+}
+
+static int segment_max_backward_any(const void *grad_out, int dtype, const int32_t *arg, const int32_t *p2v, int64_t n, int c,
+                                    void *grad_src, void *stream)
+{
+    if (n < 0 || c <= 0 || (c % 4) || (dtype != PCACC_F32 && dtype != PCACC_BF16)) return PCACC_E_ARG;
+    if (n > 0 && (!grad_out || !arg || !p2v || !grad_src)) return PCACC_E_ARG;
+    if (n == 0) return PCACC_OK;
+    seg_max_bwd_kernel<<<pcacc_grid(n * (c / 4), 256), 256, 0, pcacc_stream(stream)>>>(
+        grad_out, reinterpret_cast<const int4 *>(arg), p2v, n, c / 4, grad_src, dtype == PCACC_BF16);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
 }
 
 extern "C" int pcacc_segment_max_backward(const float *grad_out, const int32_t *arg, const int32_t *p2v, int64_t n, int c,
                                           float *grad_src, void *stream)
 {
-    if (n < 0 || c <= 0 || (c % 4)) return PCACC_E_ARG;
-    if (n > 0 && (!grad_out || !arg || !p2v || !grad_src)) return PCACC_E_ARG;
-    if (n == 0) return PCACC_OK;
-    seg_max_bwd_kernel<<<pcacc_grid(n * (c / 4), 256), 256, 0, pcacc_stream(stream)>>>(
-        reinterpret_cast<const float4 *>(grad_out), reinterpret_cast<const int4 *>(arg), p2v, n, c / 4,
-        reinterpret_cast<float4 *>(grad_src));
-    PCACC_CHECK_LAUNCH();
-    return PCACC_OK;
+    return segment_max_backward_any(grad_out, PCACC_F32, arg, p2v, n, c, grad_src, stream);
+}
+
+extern "C" int pcacc_segment_max_backward_t(const void *grad_out, int dtype, const int32_t *arg, const int32_t *p2v, int64_t n,
+                                            int c, void *grad_src, void *stream)
+{
+    return segment_max_backward_any(grad_out, dtype, arg, p2v, n, c, grad_src, stream);
 }
 
 // Backward of the [point_to_voxel_map] broadcast (models/pillar_encoder.py:116): per-pillar sum of point rows.
 template <int LPP>
-__global__ __launch_bounds__(256) void seg_sum_kernel(const float4 *__restrict__ src, const int32_t *__restrict__ seg_offsets,
-                                                      const int32_t *__restrict__ order, int64_t m, float4 *__restrict__ out)
+__global__ __launch_bounds__(256) void seg_sum_kernel(const void *__restrict__ src, const int32_t *__restrict__ seg_offsets,
+                                                      const int32_t *__restrict__ order, int64_t m, void *__restrict__ out, bool bf)
 {
     const int sub = threadIdx.x % LPP;
     const int64_t per_block = 256 / LPP;
@@ -427,29 +469,30 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const float4 *__restrict__
         const int b = seg_offsets[s], e = seg_offsets[s + 1];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int k = b; k < e; ++k) {
-            const float4 v = src[(int64_t)order[k] * LPP + sub];
+            const float4 v = seg_ld4(src, bf, (int64_t)order[k] * LPP + sub);
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
-        out[s * LPP + sub] = acc;
+        seg_st4(out, bf, s * LPP + sub, acc);
     }
 }
 
-extern "C" int pcacc_segment_sum(const float *src, int c, const int32_t *seg_offsets, const int32_t *order, int64_t n, int64_t m,
-                                 float *out, void *workspace, size_t workspace_bytes, void *stream)
+static int segment_sum_any(const void *src, int dtype, int c, const int32_t *seg_offsets, const int32_t *order, int64_t n, int64_t m,
+                           void *out, void *workspace, size_t workspace_bytes, void *stream)
 {
-    if (m < 0 || n < 0 || c <= 0 || (c % 4) || c > 256) return PCACC_E_ARG;
+    if (m < 0 || n < 0 || c <= 0 || (c % 4) || c > 256 || (dtype != PCACC_F32 && dtype != PCACC_BF16)) return PCACC_E_ARG;
+    const bool bf = dtype == PCACC_BF16;
     if (m > 0 && (!seg_offsets || !out || (n > 0 && (!src || !order)))) return PCACC_E_ARG;
     if (m == 0) return PCACC_OK;
     hipStream_t s = pcacc_stream(stream);
     if (seg_use_two_level(n, m)) {
-        const int rc = seg_two_level<false>(src, c, seg_offsets, order, n, m, out, nullptr, workspace, workspace_bytes, s);
+        if (bf) return PCACC_E_ARG;                                  // long segments: f32 rows only
+        const int rc = seg_two_level<false>(reinterpret_cast<const float *>(src), c, seg_offsets, order, n, m,
+                                            reinterpret_cast<float *>(out), nullptr, workspace, workspace_bytes, s);
         if (rc != PCACC_OK) return rc;
         PCACC_CHECK_LAUNCH();
         return PCACC_OK;
     }
-    const float4 *in4 = reinterpret_cast<const float4 *>(src);
-    float4 *out4 = reinterpret_cast<float4 *>(out);
-#define LAUNCH(L) seg_sum_kernel<L><<<pcacc_grid(m * L, 256), 256, 0, s>>>(in4, seg_offsets, order, m, out4)
+#define LAUNCH(L) seg_sum_kernel<L><<<pcacc_grid(m * L, 256), 256, 0, s>>>(src, seg_offsets, order, m, out, bf)
     switch (c / 4) {
         case 1: LAUNCH(1); break;
         case 2: LAUNCH(2); break;
@@ -463,6 +506,18 @@ extern "C" int pcacc_segment_sum(const float *src, int c, const int32_t *seg_off
 #undef LAUNCH
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
+}
+
+extern "C" int pcacc_segment_sum(const float *src, int c, const int32_t *seg_offsets, const int32_t *order, int64_t n, int64_t m,
+                                 float *out, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return segment_sum_any(src, PCACC_F32, c, seg_offsets, order, n, m, out, workspace, workspace_bytes, stream);
+}
+
+extern "C" int pcacc_segment_sum_t(const void *src, int dtype, int c, const int32_t *seg_offsets, const int32_t *order, int64_t n,
+                                   int64_t m, void *out, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return segment_sum_any(src, dtype, c, seg_offsets, order, n, m, out, workspace, workspace_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -48,6 +48,7 @@ EXPORTS = [
     'pcacc_sinkhorn_kabsch_workspace_bytes', 'pcacc_sinkhorn_kabsch', 'pcacc_chamfer_workspace_bytes', 'pcacc_chamfer_forward', 'pcacc_chamfer_backward',
     'pcacc_cluster_workspace_bytes', 'pcacc_cluster', 'pcacc_conv3x3_prepare_weights', 'pcacc_conv3x3_bf16',
     'pcacc_rows_linear_bf16', 'pcacc_rows_linear_mixed', 'pcacc_rows_wgrad_mixed',
+    'pcacc_segment_max_t', 'pcacc_segment_max_backward_t', 'pcacc_segment_sum_t',
 ]
 
 
@@ -167,32 +168,48 @@ def _segment_ws(n, m, c, dev):
     return _ws(need.value, dev)
 
 
+def _seg_dtype(t, n, m):
+    """bf16 rows stay bf16 on the short-segment (one lane group per segment) kernels; long segments are reduced in f32."""
+    if t.dtype == torch.bfloat16 and not (m > 0 and n // m > 16):
+        return torch.bfloat16, BF16
+    return torch.float32, F32
+
+
 def segment_max(src, offs, order, m):
+    """Per-segment channel-wise max and arg: [m,c] in src's dtype (f32, or bf16 for short segments) and [m,c] i32."""
     n, c = src.shape
-    out = torch.empty((m, c), dtype=torch.float32, device=src.device)
+    dtype, code = _seg_dtype(src, n, m)
+    src = src if src.dtype == dtype else src.to(dtype)
+    out = torch.empty((m, c), dtype=dtype, device=src.device)
     arg = torch.empty((m, c), dtype=torch.int32, device=src.device)
     ws = _segment_ws(n, m, c, src.device)
-    _check(lib().pcacc_segment_max(_dev(src, torch.float32, 'src'), int(c), _dev(offs, torch.int32), _dev(order, torch.int32),
-                                   _i64(n), _i64(m), _dev(out), _dev(arg), _dev(ws), ctypes.c_size_t(ws.numel()), _stream()),
+    _check(lib().pcacc_segment_max_t(_dev(src, dtype, 'src'), code, int(c), _dev(offs, torch.int32), _dev(order, torch.int32),
+                                     _i64(n), _i64(m), _dev(out), _dev(arg), _dev(ws), ctypes.c_size_t(ws.numel()), _stream()),
            'segment_max')
     return out, arg
 
 
-def segment_max_backward(grad_out, arg, p2v, n):
+def segment_max_backward(grad_out, arg, p2v, n, out_dtype=None):
+    """grad of segment_max w.r.t. its rows: [n,c] in grad_out's dtype (f32 or bf16)."""
     c = grad_out.shape[1]
-    g = torch.empty((n, c), dtype=torch.float32, device=grad_out.device)
-    _check(lib().pcacc_segment_max_backward(_dev(grad_out, torch.float32, 'grad_out'), _dev(arg, torch.int32),
-                                            _dev(p2v, torch.int32), _i64(n), int(c), _dev(g), _stream()),
+    dtype = grad_out.dtype if grad_out.dtype in (torch.float32, torch.bfloat16) else torch.float32
+    grad_out = grad_out if grad_out.dtype == dtype else grad_out.to(dtype)
+    g = torch.empty((n, c), dtype=dtype, device=grad_out.device)
+    _check(lib().pcacc_segment_max_backward_t(_dev(grad_out, dtype, 'grad_out'), BF16 if dtype == torch.bfloat16 else F32,
+                                              _dev(arg, torch.int32), _dev(p2v, torch.int32), _i64(n), int(c), _dev(g), _stream()),
            'segment_max_backward')
     return g
 
 
 def segment_sum(src, offs, order, m):
+    """Per-segment sums, [m,c] in src's dtype (f32, or bf16 for short segments; accumulated in f32)."""
     n, c = src.shape
-    out = torch.empty((m, c), dtype=torch.float32, device=src.device)
+    dtype, code = _seg_dtype(src, n, m)
+    src = src if src.dtype == dtype else src.to(dtype)
+    out = torch.empty((m, c), dtype=dtype, device=src.device)
     ws = _segment_ws(n, m, c, src.device)
-    _check(lib().pcacc_segment_sum(_dev(src, torch.float32, 'src'), int(c), _dev(offs, torch.int32), _dev(order, torch.int32),
-                                   _i64(n), _i64(m), _dev(out), _dev(ws), ctypes.c_size_t(ws.numel()), _stream()), 'segment_sum')
+    _check(lib().pcacc_segment_sum_t(_dev(src, dtype, 'src'), code, int(c), _dev(offs, torch.int32), _dev(order, torch.int32),
+                                     _i64(n), _i64(m), _dev(out), _dev(ws), ctypes.c_size_t(ws.numel()), _stream()), 'segment_sum')
     return out
 
 

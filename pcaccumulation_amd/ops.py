@@ -59,8 +59,11 @@ class _SegmentMax(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, src, pidx):
-        out, arg = native.segment_max(src.contiguous().float(), pidx.seg_offsets, pidx.order, pidx.m)
+        src = src.contiguous()
+        out, arg = native.segment_max(src if src.dtype in (torch.float32, torch.bfloat16) else src.float(), pidx.seg_offsets,
+                                      pidx.order, pidx.m)
         ctx.pidx = pidx
+        ctx.src_dtype = src.dtype
         ctx.save_for_backward(arg)
         ctx.mark_non_differentiable(arg)
         return out, arg
@@ -69,7 +72,8 @@ class _SegmentMax(torch.autograd.Function):
     def backward(ctx, grad_out, _grad_arg):
         (arg,) = ctx.saved_tensors
         pidx = ctx.pidx
-        return native.segment_max_backward(grad_out.contiguous().float(), arg, pidx.p2v, pidx.n), None
+        g = native.segment_max_backward(grad_out.contiguous(), arg, pidx.p2v, pidx.n)
+        return (g if g.dtype == ctx.src_dtype else g.to(ctx.src_dtype)), None
 
 
 def segment_max(src, pidx):
@@ -87,7 +91,9 @@ class _BroadcastToPoints(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad):
         pidx = ctx.pidx
-        return native.segment_sum(grad.contiguous().float(), pidx.seg_offsets, pidx.order, pidx.m), None
+        grad = grad.contiguous()
+        return native.segment_sum(grad if grad.dtype in (torch.float32, torch.bfloat16) else grad.float(), pidx.seg_offsets,
+                                  pidx.order, pidx.m), None
 
 
 def broadcast_to_points(pillar_feats, pidx):

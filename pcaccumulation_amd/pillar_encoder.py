@@ -28,7 +28,8 @@ class ResnetBlockFC(nn.Module):
         nn.init.zeros_(self.fc_1.weight)
 
     def forward(self, x):
-        # fc_1(relu(fc_0(relu(x)))) + shortcut(x): three fused row-linear launches (ReLU on load, residual on store)
+        # fc_1(relu(fc_0(relu(x)))) + shortcut(x): three fused row-linear launches (ReLU on load, residual on store);
+        # rows keep x's element type (bf16 in the bf16 compute mode)
         net = ops.linear_rows(x, self.fc_0, pre_relu=True)
         x_s = ops.linear_rows(x, self.shortcut) if self.shortcut is not None else x
         return ops.linear_rows(net, self.fc_1, pre_relu=True, residual=x_s)
@@ -72,13 +73,14 @@ class PillarFeatureNet(nn.Module):
         if pidx is None:                                                  # reference call signature
             pidx = PillarIndex.from_point_map(point_to_voxel_map, coordinates.shape[0])
         features = self.point_features(raw_points, pidx, coordinates, pillar_mean, time_indice)
-        net = ops.linear_rows(features, self.fc_pos)
+        pd = ops.point_dtype() if features.is_cuda else features.dtype     # bf16 rows in the bf16 compute mode (GPU only)
+        net = ops.linear_rows(features, self.fc_pos, out_dtype=pd)
         net = self.blocks[0](net)
         for block in self.blocks[1:]:
             pooled = ops.broadcast_to_points(ops.segment_max(net, pidx), pidx)
             net = block(torch.cat([net, pooled], dim=1))
         feats = ops.linear_rows(net, self.fc_c)
-        return ops.segment_max(feats, pidx)
+        return ops.segment_max(feats, pidx).float()
 
 
 def _index_for(coords, batch_size, input_shape):

@@ -587,3 +587,26 @@ def test_linear_rows_autograd_bf16():
     assert tol(lin1.weight.grad, gy.float().t() @ h, 1e-2)
     assert tol(lin0.weight.grad, g1.t() @ xf, 1e-2)
     assert tol(lin1.bias.grad, gy.float().sum(0), 1e-2)
+
+
+@pytest.mark.gpu
+def test_segment_ops_bf16():
+    """Short-segment max / max-backward / sum on bf16 rows: max is exact, sums are fp32 sums rounded once."""
+    import numpy as np
+    import torch
+    from pcaccumulation_amd import native, ops
+    dev = torch.device('cuda:0')
+    rng = np.random.RandomState(4)
+    n, m, c = 50000, 9000, 32
+    p2v = torch.from_numpy(rng.randint(0, m, n).astype(np.int32)).to(dev)
+    pidx = ops.PillarIndex.from_point_map(p2v, m)
+    x = torch.randn(n, c, device=dev).to(torch.bfloat16)
+    out, arg = native.segment_max(x, pidx.seg_offsets, pidx.order, m)
+    ref, rarg = native.segment_max(x.float(), pidx.seg_offsets, pidx.order, m)
+    assert out.dtype == torch.bfloat16 and torch.equal(out.float(), ref) and torch.equal(arg, rarg)
+    g = torch.randn(m, c, device=dev).to(torch.bfloat16)
+    gb = native.segment_max_backward(g, arg, pidx.p2v, n)
+    assert gb.dtype == torch.bfloat16 and torch.equal(gb.float(), native.segment_max_backward(g.float(), arg, pidx.p2v, n))
+    s = native.segment_sum(x, pidx.seg_offsets, pidx.order, m)
+    sref = native.segment_sum(x.float(), pidx.seg_offsets, pidx.order, m)
+    assert s.dtype == torch.bfloat16 and (s.float() - sref).abs().max().item() <= 2 ** -7 * sref.abs().max().item()
