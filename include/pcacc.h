@@ -160,6 +160,10 @@ int pcacc_rows_linear_mixed(const void *x, const void *in_mask, const float *w, 
                             const void *out_mask, void *y, int64_t rows, int k, int n, int flags, int dtypes, void *stream);
 int pcacc_rows_wgrad_mixed(const void *dy, const void *dy_mask, const void *x, int x_relu, int64_t rows, int k, int n,
                            float *dw_aug, int dtypes, void *stream);
+/* all-bf16 rows (k, n multiples of 8, <= 128): the same product on the bf16 matrix cores, dw_aug f32 */
+int pcacc_rows_wgrad_bf16_workspace_bytes(int64_t rows, int32_t k, int32_t n, size_t *bytes /*host*/);
+int pcacc_rows_wgrad_bf16(const uint16_t *dy, const uint16_t *dy_mask, const uint16_t *x, int32_t x_relu, int64_t rows,
+                          int32_t k, int32_t n, float *dw_aug, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Sum of rows per index for FEW output rows (m*c <= 8192), no CSR needed: LDS-privatised accumulation.
  * The per-instance 'sum' / 'mean' poolings of models/tpointnet.py:227,251,283-284 and libs/loss.py:216.
@@ -212,6 +216,12 @@ int pcacc_bev_warp(const void *bev, int dtype, int n_batch, int nt, int h, int w
  *   points [n,3] f32; frame_idx [n] i32 = b*nt + t; tsfm [n_frames,16] f32; out [n,3] f32 */
 int pcacc_rigid_transform(const float *points, const int32_t *frame_idx, const float *tsfm, int64_t n,
                           float *out, void *stream);
+
+/* Key-point draws of the ego-motion head -- models/egomotion.py:156-166 (torch.randperm(n)[:k], or arange clamped to n-1
+ * when n <= k).  counts [n_draws] i32 (device): population of every draw; out [n_draws, k] i64: k distinct indices per
+ * draw (keyed Feistel permutation of [0, n) evaluated at 0..k-1), all draws in one launch.  This is the 'device' sampler
+ * (cfg pose_estimation.kpt_sampler); the default sampler reproduces the reference's host RNG stream instead. */
+int pcacc_sample_subsets(const int32_t *counts, int32_t n_draws, int32_t k, uint64_t seed, int64_t *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * A8. Key-point matching of the ego-motion head, forward pass, fp32, for n_pairs (frame, anchor) pairs at once --

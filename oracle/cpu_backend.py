@@ -220,7 +220,7 @@ def cluster(points, offset, sel, batch, n_batches, voxel_size, eps, min_samples,
 NAMES = ['voxelize', 'cell_index', 'frame_pillars', 'csr_build', 'segment_mean3_maxlabel', 'segment_max',
          'segment_max_backward', 'segment_sum', 'pillar_scatter', 'gather_rows', 'bilinear_gather',
          'bilinear_gather_backward', 'bev_warp', 'rigid_transform', 'chamfer_forward', 'chamfer_backward',
-         'rows_linear', 'rows_wgrad', 'rows_linear_supported', 'pfn_features', 'scatter_sum_small', 'sinkhorn_kabsch', 'cluster']
+         'rows_linear', 'rows_wgrad', 'rows_linear_supported', 'pfn_features', 'scatter_sum_small', 'sinkhorn_kabsch', 'cluster', 'sample_subsets']
 
 
 def install(monkeypatch=None):
@@ -231,3 +231,16 @@ def install(monkeypatch=None):
             monkeypatch.setattr(native, name, globals()[name])
         else:
             setattr(native, name, globals()[name])
+
+
+def sample_subsets(counts, k, seed):
+    g = torch.Generator().manual_seed(int(seed) % (2 ** 63))
+    rows = []
+    for n in counts.tolist():
+        if n > k:
+            rows.append(torch.randperm(n, generator=g)[:k])
+        else:
+            c = torch.arange(k)
+            c[n:] = max(n - 1, 0)
+            rows.append(c)
+    return torch.stack(rows)

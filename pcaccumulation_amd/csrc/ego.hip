@@ -321,3 +321,60 @@ extern "C" int pcacc_sinkhorn_kabsch(const float *feats_s, const float *feats_t,
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Key-point draws for the ego-motion head (models/egomotion.py:156-166): k distinct indices out of n, uniformly, for many
+// (n, draw) pairs in ONE launch.  The reference shuffles all n indices on the host (torch.randperm) and keeps the first k;
+// its device twin sorts n random keys, a dozen launches per draw and 32 draws per 4-sample step.  Here draw d evaluates
+// a keyed pseudo-random permutation of [0, n_d) at the points 0..k-1: a 4-round Feistel network on the next even number
+// of bits, cycle-walked back into range (a bijection, so the k outputs are distinct).  n <= k gives 0..n-1 followed by
+// n-1 repeated, like the reference.  This is the 'device' sampler of the throughput runs; parity tests use the
+// reference's host RNG stream.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t kp_mix(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void sample_subsets_kernel(const int32_t *__restrict__ counts, int k, uint64_t seed, int64_t *__restrict__ out)
+{
+    const int d = blockIdx.x;
+    const uint32_t n = (uint32_t)counts[d];
+    int64_t *dst = out + (int64_t)d * k;
+    if (n <= (uint32_t)k) {
+        for (int i = threadIdx.x; i < k; i += 256) dst[i] = n == 0 ? 0 : ((uint32_t)i < n ? i : n - 1);
+        return;
+    }
+    int half = 1;
+    while ((1u << (2 * half)) < n) ++half;                       // 2*half bits cover [0, n)
+    const uint32_t hmask = (1u << half) - 1;
+    uint32_t key[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) key[r] = kp_mix((uint32_t)(seed >> (8 * r)) ^ kp_mix((uint32_t)(seed >> 32) + 0x9e3779b9u * (uint32_t)(d * 4 + r + 1)));
+    for (int i = threadIdx.x; i < k; i += 256) {
+        uint32_t x = (uint32_t)i;
+        do {
+            uint32_t l = x >> half, r = x & hmask;
+#pragma unroll
+            for (int round = 0; round < 4; ++round) {
+                const uint32_t f = kp_mix(r ^ key[round]) & hmask;
+                const uint32_t nl = r;
+                r = l ^ f;
+                l = nl;
+            }
+            x = (l << half) | r;
+        } while (x >= n);
+        dst[i] = x;
+    }
+}
+
+extern "C" int pcacc_sample_subsets(const int32_t *counts, int32_t n_draws, int32_t k, uint64_t seed, int64_t *out, void *stream)
+{
+    if (n_draws < 0 || k <= 0) return PCACC_E_ARG;
+    if (n_draws == 0) return PCACC_OK;
+    if (!counts || !out) return PCACC_E_ARG;
+    sample_subsets_kernel<<<n_draws, 256, 0, pcacc_stream(stream)>>>(counts, k, seed, out);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}

@@ -203,3 +203,164 @@ extern "C" int pcacc_rows_linear_bf16(const uint16_t *x, const uint16_t *in_mask
 #undef MM_CASE
     return PCACC_E_ARG;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight / bias gradient from bf16 rows on the bf16 matrix cores:  dW_aug[n][k] (k in [0,K]; column K = bias gradient)
+//   = sum_r dYeff[r][n] * Xaug[r][k],  Xaug[r][K] = 1,  dYeff = dY masked where dy_mask <= 0,  X optionally ReLU'd.
+// The reduction runs over rows, so both MFMA operands need 8 consecutive ROWS of one column per lane: the tiles are staged
+// row-major (coalesced, masks applied on the way) and the fragments are gathered with 16-bit LDS reads.  That costs 16 LDS
+// reads per MFMA and caps the matrix cores at ~25 % -- still 4x the fp32 MFMA path of mlp.hip, and enough to leave the
+// kernel bound by the HBM stream of dY and X (half the bytes of the fp32 rows).  Row stride = width + 4 elements: the two
+// half-waves of a gather (rows r and r+8) land on disjoint bank halves.
+// Workgroup partials are written to a workspace with plain stores and summed by a second launch: with ~1000 workgroups
+// an atomic per element per workgroup is 17 M same-address atomics for a 128 x 129 gradient, longer than the products.
+// ---------------------------------------------------------------------------------------------------------------------
+#define WG_R 64                    // rows per staged tile
+
+template <int MAX_TILES>
+__global__ __launch_bounds__(256) void rows_wgrad_bf16_kernel(const uint16_t *__restrict__ dY, const uint16_t *__restrict__ dy_mask,
+                                                              const uint16_t *__restrict__ X, int x_relu, int64_t rows, int K, int N,
+                                                              int k_tiles, int n_tile_total, float *partial)
+{
+    extern __shared__ __attribute__((aligned(16))) uint16_t wlds[];
+    const int NS = N + 4, KS = K + 4;
+    uint16_t *sdy = wlds, *sx = wlds + WG_R * NS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lp = lane & 31, lh = lane >> 5;
+    f32x16_t acc[MAX_TILES];
+#pragma unroll
+    for (int t = 0; t < MAX_TILES; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int64_t n_chunks = (rows + WG_R - 1) / WG_R;
+    for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+        const int64_t row0 = ch * WG_R;
+        const int64_t lim_n = (rows - row0) * N, lim_k = (rows - row0) * K;      // elements of this tile that exist
+        for (int i = threadIdx.x; i < WG_R * N / 8; i += 256) {
+            const int e = i * 8, r = e / N, c = e % N;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (e < lim_n) {
+                v = *reinterpret_cast<const uint4 *>(dY + row0 * N + e);
+                if (dy_mask) v = mm_mask8(v, *reinterpret_cast<const uint4 *>(dy_mask + row0 * N + e));
+            }
+            uint2 *dst = reinterpret_cast<uint2 *>(sdy + r * NS + c);
+            dst[0] = make_uint2(v.x, v.y);
+            dst[1] = make_uint2(v.z, v.w);
+        }
+        for (int i = threadIdx.x; i < WG_R * K / 8; i += 256) {
+            const int e = i * 8, r = e / K, c = e % K;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (e < lim_k) {
+                v = *reinterpret_cast<const uint4 *>(X + row0 * K + e);
+                if (x_relu) v = mm_relu8(v);
+            }
+            uint2 *dst = reinterpret_cast<uint2 *>(sx + r * KS + c);
+            dst[0] = make_uint2(v.x, v.y);
+            dst[1] = make_uint2(v.z, v.w);
+        }
+        __syncthreads();
+        const int nrow = (int)min((int64_t)WG_R, rows - row0);
+#pragma unroll
+        for (int t = 0; t < MAX_TILES; ++t) {
+            const int tile = wave + 4 * t;                                       // uniform per wave
+            if (tile < n_tile_total) {
+                const int n = (tile / k_tiles) * 32 + lp;
+                const int k = (tile % k_tiles) * 32 + lp;
+                const bool nv = n < N;
+                const int kind = k < K ? 0 : (k == K ? 1 : 2);                   // data column / ones column (bias) / padding
+                const uint16_t *pa = sdy + (8 * lh) * NS + (nv ? n : 0);
+                const uint16_t *pb = sx + (8 * lh) * KS + (kind == 0 ? k : 0);
+#pragma unroll
+                for (int r0 = 0; r0 < WG_R; r0 += 16) {
+                    uint16_t av[8], bv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        av[j] = nv ? pa[(r0 + j) * NS] : (uint16_t)0;
+                        bv[j] = kind == 0 ? pb[(r0 + j) * KS] : ((kind == 1 && r0 + 8 * lh + j < nrow) ? (uint16_t)0x3f80 : (uint16_t)0);
+                    }
+                    uint4 a4, b4;
+                    a4.x = av[0] | ((uint32_t)av[1] << 16); a4.y = av[2] | ((uint32_t)av[3] << 16);
+                    a4.z = av[4] | ((uint32_t)av[5] << 16); a4.w = av[6] | ((uint32_t)av[7] << 16);
+                    b4.x = bv[0] | ((uint32_t)bv[1] << 16); b4.y = bv[2] | ((uint32_t)bv[3] << 16);
+                    b4.z = bv[4] | ((uint32_t)bv[5] << 16); b4.w = bv[6] | ((uint32_t)bv[7] << 16);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8_t *>(&a4), *reinterpret_cast<bf16x8_t *>(&b4),
+                                                                     acc[t], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const int KA = K + 1;
+    float *mine = partial + (int64_t)blockIdx.x * N * KA;
+#pragma unroll
+    for (int t = 0; t < MAX_TILES; ++t) {
+        const int tile = wave + 4 * t;
+        if (tile < n_tile_total) {
+            const int nb = (tile / k_tiles) * 32, k = (tile % k_tiles) * 32 + lp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = nb + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (n < N && k < KA) mine[(int64_t)n * KA + k] = acc[t][r];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void rows_wgrad_reduce_kernel(const float *__restrict__ partial, int n_parts, int elems, float *out)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= elems) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int p = 0;
+    for (; p + 4 <= n_parts; p += 4) {
+        s0 += partial[(int64_t)p * elems + e];
+        s1 += partial[(int64_t)(p + 1) * elems + e];
+        s2 += partial[(int64_t)(p + 2) * elems + e];
+        s3 += partial[(int64_t)(p + 3) * elems + e];
+    }
+    for (; p < n_parts; ++p) s0 += partial[(int64_t)p * elems + e];
+    out[e] = (s0 + s1) + (s2 + s3);
+}
+
+static int wgrad_bf16_grid(int64_t rows)
+{
+    const int64_t n_chunks = (rows + WG_R - 1) / WG_R;
+    int64_t grid = PCACC_CUS * 4;
+    return (int)(grid > n_chunks ? n_chunks : grid);
+}
+
+extern "C" int pcacc_rows_wgrad_bf16_workspace_bytes(int64_t rows, int32_t k, int32_t n, size_t *bytes)
+{
+    if (!bytes || rows < 0 || k <= 0 || n <= 0) return PCACC_E_ARG;
+    *bytes = (size_t)(rows > 0 ? wgrad_bf16_grid(rows) : 0) * n * (k + 1) * sizeof(float);
+    return PCACC_OK;
+}
+
+extern "C" int pcacc_rows_wgrad_bf16(const uint16_t *dy, const uint16_t *dy_mask, const uint16_t *x, int32_t x_relu, int64_t rows,
+                                     int32_t k, int32_t n, float *dw_aug, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (rows < 0 || k <= 0 || n <= 0 || k > 128 || n > 128 || (k % 8) || (n % 8) || !dw_aug) return PCACC_E_ARG;
+    hipStream_t st = pcacc_stream(stream);
+    if (rows == 0) {
+        if (hipMemsetAsync(dw_aug, 0, (size_t)n * (k + 1) * sizeof(float), st) != hipSuccess) return PCACC_E_LAUNCH;
+        return PCACC_OK;
+    }
+    if (!dy || !x || !workspace) return PCACC_E_ARG;
+    const int k_tiles = (k + 1 + 31) / 32, n_tiles = (n + 31) / 32;
+    const int total = k_tiles * n_tiles;
+    if (total > 24) return PCACC_E_ARG;
+    const int grid = wgrad_bf16_grid(rows);
+    const int elems = n * (k + 1);
+    if (workspace_bytes < (size_t)grid * elems * sizeof(float)) return PCACC_E_WORKSPACE;
+    float *partial = reinterpret_cast<float *>(workspace);
+    const size_t lds = (size_t)WG_R * (n + 4 + k + 4) * sizeof(uint16_t);
+#define WGB(T) rows_wgrad_bf16_kernel<T><<<grid, 256, lds, st>>>(dy, dy_mask, x, x_relu, rows, k, n, k_tiles, total, partial)
+    if (total <= 4) WGB(1);
+    else if (total <= 8) WGB(2);
+    else WGB(6);
+#undef WGB
+    rows_wgrad_reduce_kernel<<<(elems + 255) / 256, 256, 0, st>>>(partial, grid, elems, dw_aug);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}

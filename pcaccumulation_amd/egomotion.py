@@ -175,13 +175,23 @@ class EgoMotionHead(nn.Module):
           bg_list[t] = (bg_idx LongTensor into the frame's pillar list, n_bg int)."""
         dev = sequences[0][0][0].device
         fs, cs, ft, ct, durations = [], [], [], [], []
+        drawn, d = None, 0
+        if self.kpt_sampler == 'device' and dev.type == 'cuda':
+            # every key-point draw of the step in one launch (source, then target, per pair -- the reference's order)
+            counts = [n for _, _, bg_list, _ in sequences for f in range(T - 1) for n in (bg_list[f + 1][1], bg_list[0][1])]
+            seed = int(torch.empty((), dtype=torch.int64).random_())       # host generator: follows torch.manual_seed
+            drawn = native.sample_subsets(torch.tensor(counts, dtype=torch.int32, device=dev), self.ego_n_points, seed)
         for points_list, feats_list, bg_list, _ in sequences:
             a_idx, a_n = bg_list[0]
             for frame_idx in range(T - 1):
                 ref = frame_idx + 1
                 r_idx, r_n = bg_list[ref]
-                choice_s = self._choice(r_n, dev).to(dev)                 # models/egomotion.py:156-166, same order
-                choice_t = self._choice(a_n, dev).to(dev)
+                if drawn is not None:
+                    choice_s, choice_t = drawn[d], drawn[d + 1]
+                    d += 2
+                else:
+                    choice_s = self._choice(r_n, dev).to(dev)             # models/egomotion.py:156-166, same order
+                    choice_t = self._choice(a_n, dev).to(dev)
                 si, ti = r_idx[choice_s], a_idx[choice_t]                   # key-point pillars (indices into the frame lists)
                 fs.append(feats_list[ref](si)); cs.append(points_list[ref][si])
                 ft.append(feats_list[0](ti)); ct.append(points_list[0][ti])

@@ -48,7 +48,7 @@ EXPORTS = [
     'pcacc_sinkhorn_kabsch_workspace_bytes', 'pcacc_sinkhorn_kabsch', 'pcacc_chamfer_workspace_bytes', 'pcacc_chamfer_forward', 'pcacc_chamfer_backward',
     'pcacc_cluster_workspace_bytes', 'pcacc_cluster', 'pcacc_conv3x3_prepare_weights', 'pcacc_conv3x3_bf16',
     'pcacc_rows_linear_bf16', 'pcacc_rows_linear_mixed', 'pcacc_rows_wgrad_mixed',
-    'pcacc_segment_max_t', 'pcacc_segment_max_backward_t', 'pcacc_segment_sum_t',
+    'pcacc_segment_max_t', 'pcacc_segment_max_backward_t', 'pcacc_segment_sum_t', 'pcacc_rows_wgrad_bf16_workspace_bytes', 'pcacc_rows_wgrad_bf16', 'pcacc_sample_subsets',
 ]
 
 
@@ -359,6 +359,14 @@ def rows_wgrad(dy, x, dy_mask=None, x_relu=False):
     rows, n = dy.shape
     k = x.shape[1]
     out = torch.empty((n, k + 1), dtype=torch.float32, device=dy.device)
+    if all(t is None or t.dtype == torch.bfloat16 for t in (dy, dy_mask, x)) and k % 8 == 0 and n % 8 == 0:
+        need = ctypes.c_size_t(0)
+        _check(lib().pcacc_rows_wgrad_bf16_workspace_bytes(_i64(rows), int(k), int(n), ctypes.byref(need)), 'rows_wgrad_bf16_workspace')
+        ws = _ws(need.value, dy.device)
+        _check(lib().pcacc_rows_wgrad_bf16(_dev(dy, torch.bfloat16, 'dy'), _dev(dy_mask, torch.bfloat16, 'dy_mask') if dy_mask is not None else None,
+                                           _dev(x, torch.bfloat16, 'x'), 1 if x_relu else 0, _i64(rows), int(k), int(n), _dev(out),
+                                           _dev(ws), ctypes.c_size_t(ws.numel()), _stream()), 'rows_wgrad_bf16')
+        return out
     dt = _row_dtype_bit(dy, 1, 'dy') | _row_dtype_bit(dy_mask, 2, 'dy_mask') | _row_dtype_bit(x, 4, 'x')
     _check(lib().pcacc_rows_wgrad_mixed(_dev(dy, None, 'dy'), _dev(dy_mask, None, 'dy_mask') if dy_mask is not None else None,
                                         _dev(x, None, 'x'), 1 if x_relu else 0, _i64(rows), int(k), int(n), _dev(out), dt, _stream()),
@@ -455,4 +463,13 @@ def conv3x3(x_rows, wp, bias, frames, relu):
     _check(lib().pcacc_conv3x3_bf16(_dev(x_rows, torch.bfloat16, 'x'), _dev(wp, torch.bfloat16, 'wp'),
                                     _dev(bias, torch.float32, 'bias') if bias is not None else None, _dev(out), int(n_img), int(frames),
                                     int(h), int(w), int(c_in), int(c_out), taps // 9, 1 if relu else 0, _stream()), 'conv3x3')
+    return out
+
+
+def sample_subsets(counts, k, seed):
+    """counts [D] i32 on the device -> [D, k] i64: k distinct indices below counts[d] per row (see include/pcacc.h)."""
+    d = counts.shape[0]
+    out = torch.empty((d, k), dtype=torch.int64, device=counts.device)
+    _check(lib().pcacc_sample_subsets(_dev(counts, torch.int32, 'counts'), int(d), int(k), ctypes.c_uint64(int(seed) & (2 ** 64 - 1)),
+                                      _dev(out), _stream()), 'sample_subsets')
     return out

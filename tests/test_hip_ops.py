@@ -610,3 +610,48 @@ def test_segment_ops_bf16():
     s = native.segment_sum(x, pidx.seg_offsets, pidx.order, m)
     sref = native.segment_sum(x.float(), pidx.seg_offsets, pidx.order, m)
     assert s.dtype == torch.bfloat16 and (s.float() - sref).abs().max().item() <= 2 ** -7 * sref.abs().max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('k,n', [(32, 32), (64, 32), (128, 128), (32, 64), (128, 64), (64, 128)])
+def test_rows_wgrad_bf16_mfma(k, n):
+    import torch
+    from pcaccumulation_amd import native
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(k + 7 * n)
+    for rows in (64 * 50 + 17, 3000):
+        dy = torch.randn(rows, n, generator=g).to(dev).to(torch.bfloat16)
+        x = torch.randn(rows, k, generator=g).to(dev).to(torch.bfloat16)
+        mk = torch.randn(rows, n, generator=g).to(dev).to(torch.bfloat16)
+        for use_mask, relu in ((False, False), (True, True)):
+            aug = native.rows_wgrad(dy, x, dy_mask=mk if use_mask else None, x_relu=relu)
+            geff = dy.float() * (mk.float() > 0) if use_mask else dy.float()
+            xe = torch.relu(x.float()) if relu else x.float()
+            ref = geff.t() @ torch.cat([xe, torch.ones(rows, 1, device=dev)], 1)
+            assert aug.shape == (n, k + 1)
+            assert (aug - ref).abs().max().item() <= 2e-3 * ref.abs().max().item(), (rows, use_mask, relu)
+
+
+@pytest.mark.gpu
+def test_sample_subsets_device_sampler():
+    """k distinct in-range indices per draw; small populations follow the reference's arange-with-clamped-tail rule; the draw is
+    a function of the seed; every index is reachable (coverage over seeds)."""
+    import torch
+    from pcaccumulation_amd import native
+    dev = torch.device('cuda:0')
+    counts = torch.tensor([50000, 1025, 1024, 7, 0, 33000, 2048], dtype=torch.int32, device=dev)
+    a = native.sample_subsets(counts, 1024, 1234).cpu()
+    b = native.sample_subsets(counts, 1024, 1234).cpu()
+    c = native.sample_subsets(counts, 1024, 99).cpu()
+    assert torch.equal(a, b) and not torch.equal(a[0], c[0])
+    for row, n in zip(a, counts.tolist()):
+        if n > 1024:
+            assert row.min() >= 0 and row.max() < n and row.unique().numel() == 1024
+        else:
+            want = torch.arange(1024)
+            want[n:] = max(n - 1, 0)
+            assert torch.equal(row, want)
+    hits = torch.zeros(2048)
+    for s in range(64):
+        hits[native.sample_subsets(counts[6:7], 1024, s).cpu()[0]] += 1
+    assert hits.min() >= 12 and hits.max() <= 52            # 32 expected; binomial(64, 1/2) tails
