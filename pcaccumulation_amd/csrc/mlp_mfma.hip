@@ -307,20 +307,23 @@ __global__ __launch_bounds__(256) void rows_wgrad_bf16_kernel(const uint16_t *__
     }
 }
 
+// out[e] += sum over a slice of the workgroup partials (blockIdx.y = slice); out is zero-filled before the launch
 __global__ __launch_bounds__(256) void rows_wgrad_reduce_kernel(const float *__restrict__ partial, int n_parts, int elems, float *out)
 {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= elems) return;
+    const int per = (n_parts + gridDim.y - 1) / gridDim.y;
+    const int p0 = blockIdx.y * per, p1 = min(n_parts, p0 + per);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int p = 0;
-    for (; p + 4 <= n_parts; p += 4) {
+    int p = p0;
+    for (; p + 4 <= p1; p += 4) {
         s0 += partial[(int64_t)p * elems + e];
         s1 += partial[(int64_t)(p + 1) * elems + e];
         s2 += partial[(int64_t)(p + 2) * elems + e];
         s3 += partial[(int64_t)(p + 3) * elems + e];
     }
-    for (; p < n_parts; ++p) s0 += partial[(int64_t)p * elems + e];
-    out[e] = (s0 + s1) + (s2 + s3);
+    for (; p < p1; ++p) s0 += partial[(int64_t)p * elems + e];
+    if (p1 > p0) atomicAdd(&out[e], (s0 + s1) + (s2 + s3));
 }
 
 static int wgrad_bf16_grid(int64_t rows)
@@ -360,7 +363,9 @@ extern "C" int pcacc_rows_wgrad_bf16(const uint16_t *dy, const uint16_t *dy_mask
     else if (total <= 8) WGB(2);
     else WGB(6);
 #undef WGB
-    rows_wgrad_reduce_kernel<<<(elems + 255) / 256, 256, 0, st>>>(partial, grid, elems, dw_aug);
+    if (hipMemsetAsync(dw_aug, 0, (size_t)elems * sizeof(float), st) != hipSuccess) return PCACC_E_LAUNCH;
+    const int slices = elems >= 8192 ? 16 : 64;                               // ~1000 workgroups in flight either way
+    rows_wgrad_reduce_kernel<<<dim3((elems + 255) / 256, slices), 256, 0, st>>>(partial, grid, elems, dw_aug);
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
 }
