@@ -459,3 +459,165 @@ extern "C" int pcacc_conv3x3_bf16(const uint16_t *in, const uint16_t *wp, const 
 #undef CV_CASE
     return PCACC_E_ARG;
 }
+
+// ---- weight gradient ------------------------------------------------------------------------------------------------------------
+// dW[co][tap][ci] = sum over images and pixels of dY[px][co] * X[px + tap offset][ci]  (zero outside the image), one frame tap per
+// launch (dt: X is read from image n + dt of the same sample, or not at all when that frame does not exist).
+// The reduction runs over pixels, so both MFMA operands are "8 consecutive pixels of one channel" per lane: the dY tile and
+// the X patch are staged channels-last as they come and the fragments are gathered with 16-bit LDS reads (row stride
+// C + 4 elements: the two half-waves of a gather fall on disjoint bank halves).  A wave owns one (co tile, ci tile) pair and
+// all 9 taps, so the dY fragment of a 16-pixel step is gathered once and used by 9 MFMAs.  Workgroups are persistent; their
+// accumulators go to a workspace slot each and a second launch sums the slots (conv_wgrad_reduce_kernel).
+template <int CO_T, int CI_T>
+__global__ __launch_bounds__(CV_THREADS) void conv3x3_wgrad_kernel(const uint16_t *__restrict__ dy, const uint16_t *__restrict__ x,
+                                                                   float *__restrict__ partial, int n_img, int frames, int dt, int h,
+                                                                   int w, int tiles_x, int tiles_y)
+{
+    constexpr int CO = CO_T * 32, CI = CI_T * 32, PAIRS = CO_T * CI_T, GROUPS = 4 / PAIRS;
+    constexpr int YS = CO + 4, XS = CI + 4;
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    uint16_t *sdy = lds;                                       // [CV_TH * CV_TW][YS]
+    uint16_t *sx = lds + CV_TH * CV_TW * YS;                   // [CV_PH * CV_PW][XS]
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lp = lane & 31, lh = lane >> 5;
+    const int pair = wave % PAIRS, grp = wave / PAIRS;
+    const int ct = pair / CI_T, it = pair % CI_T;
+
+    f32x16_t acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    const int n_tiles = n_img * tiles_y * tiles_x;
+    const int lo = (int)((int64_t)n_tiles * xcd / 8), hi = (int)((int64_t)n_tiles * (xcd + 1) / 8);
+    for (int tile = lo + slot; tile < hi; tile += slots) {
+        const int img = tile / (tiles_y * tiles_x), rem = tile % (tiles_y * tiles_x);
+        const int t_frame = img % frames + dt;
+        if (t_frame < 0 || t_frame >= frames) continue;        // uniform
+        const int y0 = (rem / tiles_x) * CV_TH, x0 = (rem % tiles_x) * CV_TW;
+        __syncthreads();                                       // the previous tile's gathers are done
+        const uint16_t *gsrc = dy + (int64_t)img * h * w * CO;
+        for (int c = threadIdx.x; c < CV_TH * CV_TW * CO / 8; c += CV_THREADS) {
+            const int px = c / (CO / 8), c8 = c % (CO / 8);
+            const int yy = y0 + px / CV_TW, xx = x0 + px % CV_TW;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (yy < h && xx < w) v = *reinterpret_cast<const uint4 *>(gsrc + ((int64_t)yy * w + xx) * CO + c8 * 8);
+            uint2 *dst = reinterpret_cast<uint2 *>(sdy + px * YS + c8 * 8);
+            dst[0] = make_uint2(v.x, v.y);
+            dst[1] = make_uint2(v.z, v.w);
+        }
+        const uint16_t *xsrc = x + (int64_t)(img + dt) * h * w * CI;
+        for (int c = threadIdx.x; c < CV_PH * CV_PW * CI / 8; c += CV_THREADS) {
+            const int px = c / (CI / 8), c8 = c % (CI / 8);
+            const int yy = y0 - 1 + px / CV_PW, xx = x0 - 1 + px % CV_PW;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (yy >= 0 && yy < h && xx >= 0 && xx < w) v = *reinterpret_cast<const uint4 *>(xsrc + ((int64_t)yy * w + xx) * CI + c8 * 8);
+            uint2 *dst = reinterpret_cast<uint2 *>(sx + px * XS + c8 * 8);
+            dst[0] = make_uint2(v.x, v.y);
+            dst[1] = make_uint2(v.z, v.w);
+        }
+        __syncthreads();
+        // 16-pixel steps of the tile: step s = row s/2, columns (s%2)*16 ..; this wave's share is every GROUPS-th step
+        for (int s = grp; s < CV_TH * 2; s += GROUPS) {
+            const int ry = s >> 1, xb = (s & 1) * 16 + 8 * lh;
+            const uint16_t *pa = sdy + (ry * CV_TW + xb) * YS + ct * 32 + lp;
+            uint32_t a[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] = (uint32_t)pa[(2 * j) * YS] | ((uint32_t)pa[(2 * j + 1) * YS] << 16);
+            const bf16x8_t af = *reinterpret_cast<const bf16x8_t *>(a);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const uint16_t *pb = sx + ((ry + tap / 3) * CV_PW + xb + tap % 3) * XS + it * 32 + lp;
+                uint32_t b[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[j] = (uint32_t)pb[(2 * j) * XS] | ((uint32_t)pb[(2 * j + 1) * XS] << 16);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, *reinterpret_cast<const bf16x8_t *>(b), acc[tap], 0, 0, 0);
+            }
+        }
+    }
+    // slot of this (workgroup, pixel group): [CO][9][CI]; D has lane = ci, register quads = co
+    float *mine = partial + ((int64_t)blockIdx.x * GROUPS + grp) * CO * 9 * CI;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            mine[((int64_t)co * 9 + tap) * CI + it * 32 + lp] = acc[tap][r];
+        }
+}
+
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__restrict__ partial, int n_parts, int elems, float *out)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= elems) return;
+    const int per = (n_parts + gridDim.y - 1) / gridDim.y;
+    const int p0 = blockIdx.y * per, p1 = min(n_parts, p0 + per);
+    float s0 = 0.f, s1 = 0.f;
+    int p = p0;
+    for (; p + 2 <= p1; p += 2) {
+        s0 += partial[(int64_t)p * elems + e];
+        s1 += partial[(int64_t)(p + 1) * elems + e];
+    }
+    if (p < p1) s0 += partial[(int64_t)p * elems + e];
+    if (p1 > p0) atomicAdd(&out[e], s0 + s1);
+}
+
+static int conv_wgrad_grid(int c_in, int c_out, int64_t n_tiles)
+{
+    const size_t lds = (size_t)(CV_TH * CV_TW * (c_out + 4) + CV_PH * CV_PW * (c_in + 4)) * sizeof(uint16_t);
+    int per_cu = (int)((160 * 1024) / lds);
+    per_cu = per_cu > 3 ? 3 : (per_cu < 1 ? 1 : per_cu);
+    int64_t slots = (int64_t)PCACC_CUS * per_cu / 8;
+    const int64_t need = (n_tiles + 7) / 8;
+    if (slots > need) slots = need;
+    if (slots < 1) slots = 1;
+    return (int)(8 * slots);
+}
+
+extern "C" int pcacc_conv3x3_wgrad_workspace_bytes(int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_out, size_t *bytes)
+{
+    if (!bytes || n_img < 1 || h < 1 || w < 1 || (c_in != 32 && c_in != 64) || (c_out != 32 && c_out != 64)) return PCACC_E_ARG;
+    const int64_t n_tiles = (int64_t)n_img * ((h + CV_TH - 1) / CV_TH) * ((w + CV_TW - 1) / CV_TW);
+    const int groups = 4 / ((c_in / 32) * (c_out / 32));
+    *bytes = (size_t)conv_wgrad_grid(c_in, c_out, n_tiles) * groups * c_out * 9 * c_in * sizeof(float);
+    return 0;
+}
+
+extern "C" int pcacc_conv3x3_wgrad_bf16(const uint16_t *dy, const uint16_t *x, float *dw, int32_t n_img, int32_t frames, int32_t dt,
+                                        int32_t h, int32_t w, int32_t c_in, int32_t c_out, void *workspace, size_t workspace_bytes,
+                                        void *stream)
+{
+    if (!dy || !x || !dw || !workspace || n_img < 1 || h < 1 || w < 1 || frames < 1 || n_img % frames || dt < -1 || dt > 1)
+        return PCACC_E_ARG;
+    if ((c_in != 32 && c_in != 64) || (c_out != 32 && c_out != 64)) return PCACC_E_ARG;
+    hipStream_t st = pcacc_stream(stream);
+    const int tiles_x = (w + CV_TW - 1) / CV_TW, tiles_y = (h + CV_TH - 1) / CV_TH;
+    const int64_t n_tiles = (int64_t)n_img * tiles_y * tiles_x;
+    if (n_tiles > 0x7fffffff) return PCACC_E_ARG;
+    const int grid = conv_wgrad_grid(c_in, c_out, n_tiles);
+    const int groups = 4 / ((c_in / 32) * (c_out / 32));
+    const int elems = c_out * 9 * c_in;
+    if (workspace_bytes < (size_t)grid * groups * elems * sizeof(float)) return PCACC_E_WORKSPACE;
+    const size_t lds = (size_t)(CV_TH * CV_TW * (c_out + 4) + CV_PH * CV_PW * (c_in + 4)) * sizeof(uint16_t);
+    float *partial = reinterpret_cast<float *>(workspace);
+#define CV_WG(COT, CIT)                                                                                                              \
+    do {                                                                                                                             \
+        auto kern = conv3x3_wgrad_kernel<COT, CIT>;                                                                                  \
+        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                   (int)lds) != hipSuccess)                                                          \
+            return PCACC_E_LAUNCH;                                                                                                   \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(CV_THREADS), lds, st, dy, x, partial, n_img, frames, dt, h, w, tiles_x, tiles_y);  \
+    } while (0)
+    if (c_out == 32 && c_in == 32) CV_WG(1, 1);
+    else if (c_out == 32 && c_in == 64) CV_WG(1, 2);
+    else if (c_out == 64 && c_in == 32) CV_WG(2, 1);
+    else CV_WG(2, 2);
+#undef CV_WG
+    if (hipMemsetAsync(dw, 0, (size_t)elems * sizeof(float), st) != hipSuccess) return PCACC_E_LAUNCH;
+    conv_wgrad_reduce_kernel<<<dim3((elems + 255) / 256, 16), 256, 0, st>>>(partial, grid * groups, elems, dw);
+    PCACC_CHECK_LAUNCH();
+    return 0;
+}

@@ -48,7 +48,7 @@ EXPORTS = [
     'pcacc_sinkhorn_kabsch_workspace_bytes', 'pcacc_sinkhorn_kabsch', 'pcacc_chamfer_workspace_bytes', 'pcacc_chamfer_forward', 'pcacc_chamfer_backward',
     'pcacc_cluster_workspace_bytes', 'pcacc_cluster', 'pcacc_conv3x3_prepare_weights', 'pcacc_conv3x3_bf16',
     'pcacc_rows_linear_bf16', 'pcacc_rows_linear_mixed', 'pcacc_rows_wgrad_mixed',
-    'pcacc_segment_max_t', 'pcacc_segment_max_backward_t', 'pcacc_segment_sum_t', 'pcacc_rows_wgrad_bf16_workspace_bytes', 'pcacc_rows_wgrad_bf16', 'pcacc_sample_subsets',
+    'pcacc_segment_max_t', 'pcacc_segment_max_backward_t', 'pcacc_segment_sum_t', 'pcacc_rows_wgrad_bf16_workspace_bytes', 'pcacc_rows_wgrad_bf16', 'pcacc_sample_subsets', 'pcacc_conv3x3_wgrad_workspace_bytes', 'pcacc_conv3x3_wgrad_bf16',
 ]
 
 
@@ -473,3 +473,22 @@ def sample_subsets(counts, k, seed):
     _check(lib().pcacc_sample_subsets(_dev(counts, torch.int32, 'counts'), int(d), int(k), ctypes.c_uint64(int(seed) & (2 ** 64 - 1)),
                                       _dev(out), _stream()), 'sample_subsets')
     return out
+
+
+def conv3x3_wgrad_supported(c_in, c_out):
+    return c_in in (32, 64) and c_out in (32, 64)
+
+
+def conv3x3_wgrad(dy_rows, x_rows, frames=1, dt=0):
+    """dy_rows [n_img,h,w,c_out], x_rows [n_img,h,w,c_in] bf16 -> [c_out, 9, c_in] f32 (frame tap dt of a kt=3 layer)."""
+    n_img, h, w, c_out = dy_rows.shape
+    c_in = x_rows.shape[3]
+    dw = torch.empty((c_out, 9, c_in), dtype=torch.float32, device=dy_rows.device)
+    need = ctypes.c_size_t(0)
+    _check(lib().pcacc_conv3x3_wgrad_workspace_bytes(int(n_img), int(h), int(w), int(c_in), int(c_out), ctypes.byref(need)),
+           'conv3x3_wgrad_workspace')
+    ws = _ws(need.value, dy_rows.device)
+    _check(lib().pcacc_conv3x3_wgrad_bf16(_dev(dy_rows, torch.bfloat16, 'dy'), _dev(x_rows, torch.bfloat16, 'x'), _dev(dw), int(n_img),
+                                          int(frames), int(dt), int(h), int(w), int(c_in), int(c_out), _dev(ws),
+                                          ctypes.c_size_t(ws.numel()), _stream()), 'conv3x3_wgrad')
+    return dw

@@ -418,19 +418,30 @@ class _Conv3x3(torch.autograd.Function):
         if ctx.needs_input_grad[0] and not lib_dgrad:
             w32 = weight.detach().float().contiguous(memory_format=torch.contiguous_format)
             gx = native.conv3x3(gy, native.conv3x3_prepare_weights(w32, transpose=True), None, frames, False)
+        if need_w and native.conv3x3_wgrad_supported(i, o):
+            # weight gradient on the matrix cores too (one launch per frame tap); bias gradient = a column sum of dY
+            if kt == 3:
+                taps = [native.conv3x3_wgrad(gy, x_rows, frames, dt).view(o, 3, 3, i) for dt in (-1, 0, 1)]
+                gw = torch.stack(taps, dim=1).permute(0, 4, 1, 2, 3)                       # [o, i, kt, 3, 3]
+            else:
+                gw = native.conv3x3_wgrad(gy, x_rows).view(o, 3, 3, i).permute(0, 3, 1, 2)
+            gw = gw.to(weight.dtype)
+            gb = gy.sum(dim=(0, 1, 2), dtype=torch.float32) if has_bias and ctx.needs_input_grad[2] else None
+            need_w = False
         if need_w or lib_dgrad:
             xin = _stack_frames(x_rows, frames) if kt == 3 else x_rows
             w2 = weight.detach().permute(0, 2, 1, 3, 4).reshape(o, 3 * i, 3, 3) if kt == 3 else weight.detach()
-            gx2, gw2, gb = torch.ops.aten.convolution_backward(
+            gx2, gw2, gb2 = torch.ops.aten.convolution_backward(
                 gy.permute(0, 3, 1, 2), xin.permute(0, 3, 1, 2), w2.to(torch.bfloat16).contiguous(memory_format=torch.channels_last),
-                [o] if has_bias else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [lib_dgrad, True, has_bias])
+                [o] if has_bias else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [lib_dgrad, need_w, has_bias and need_w])
             if lib_dgrad:
                 gx = gx2.permute(0, 2, 3, 1)
-            gw = gw2.float()
-            if kt == 3:
-                gw = gw.reshape(o, 3, i, 3, 3).permute(0, 2, 1, 3, 4)
-            gw = gw.reshape(weight.shape)
-            gb = gb.float() if has_bias else None
+            if need_w:
+                gw = gw2.float()
+                if kt == 3:
+                    gw = gw.reshape(o, 3, i, 3, 3).permute(0, 2, 1, 3, 4)
+                gw = gw.reshape(weight.shape)
+                gb = gb2.float() if has_bias else None
         return gx, gw, gb, None, None
 
 

@@ -103,3 +103,22 @@ def test_conv3x3_module_dispatch():
     assert y32.dtype == torch.float32
     with pytest.raises(native.NativeError):
         native.conv3x3(torch.zeros(1, 8, 8, 32, dtype=torch.bfloat16), torch.zeros(9, 32, 32, dtype=torch.bfloat16), None, 1, False)
+
+
+@pytest.mark.parametrize('ci,co,kt', [(32, 32, 1), (64, 32, 1), (32, 64, 1), (64, 64, 1), (32, 32, 3)])
+def test_conv3x3_wgrad_kernel(ci, co, kt):
+    """pcacc_conv3x3_wgrad_bf16 against the library's weight gradient on the same bf16 tensors (fp32 sums, different order)."""
+    b, t, h, w = 2, 3, 19, 45
+    g = torch.Generator(device='cpu').manual_seed(ci + 2 * co + kt)
+    x = torch.randn(b * t, h, w, ci, generator=g).to(DEV).to(torch.bfloat16)
+    gy = torch.randn(b * t, h, w, co, generator=g).to(DEV).to(torch.bfloat16)
+    if kt == 1:
+        dw = native.conv3x3_wgrad(gy, x).view(co, 3, 3, ci).permute(0, 3, 1, 2)
+        wr = torch.zeros(co, ci, 3, 3, device=DEV, requires_grad=True)
+        F.conv2d(x.float().permute(0, 3, 1, 2), wr, None, padding=1).backward(gy.float().permute(0, 3, 1, 2))
+    else:
+        dw = torch.stack([native.conv3x3_wgrad(gy, x, t, dt).view(co, 3, 3, ci) for dt in (-1, 0, 1)], 1).permute(0, 4, 1, 2, 3)
+        wr = torch.zeros(co, ci, 3, 3, 3, device=DEV, requires_grad=True)
+        x5 = x.float().view(b, t, h, w, ci).permute(0, 4, 1, 2, 3)
+        F.conv3d(x5, wr, None, padding=1).backward(gy.float().view(b, t, h, w, co).permute(0, 4, 1, 2, 3))
+    assert (dw - wr.grad).abs().max().item() <= 2e-3 * wr.grad.abs().max().item()
