@@ -493,33 +493,66 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_wgrad_kernel(const uint16_
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
     const int n_tiles = n_img * tiles_y * tiles_x;
     const int lo = (int)((int64_t)n_tiles * xcd / 8), hi = (int)((int64_t)n_tiles * (xcd + 1) / 8);
-    for (int tile = lo + slot; tile < hi; tile += slots) {
+
+    // the next tile's dY rows and X patch travel in registers while the current tile is multiplied
+    constexpr int Y_CHUNKS = CV_TH * CV_TW * CO / 8, Y_PER_THREAD = Y_CHUNKS / CV_THREADS;
+    constexpr int X_CHUNKS = CV_PH * CV_PW * CI / 8, X_PER_THREAD = (X_CHUNKS + CV_THREADS - 1) / CV_THREADS;
+    uint4 yreg[Y_PER_THREAD], xreg[X_PER_THREAD];
+    auto tile_valid = [&](int tile) {
+        const int t_frame = (tile / (tiles_y * tiles_x)) % frames + dt;
+        return t_frame >= 0 && t_frame < frames;
+    };
+    auto fetch = [&](int tile) {
         const int img = tile / (tiles_y * tiles_x), rem = tile % (tiles_y * tiles_x);
-        const int t_frame = img % frames + dt;
-        if (t_frame < 0 || t_frame >= frames) continue;        // uniform
         const int y0 = (rem / tiles_x) * CV_TH, x0 = (rem % tiles_x) * CV_TW;
-        __syncthreads();                                       // the previous tile's gathers are done
         const uint16_t *gsrc = dy + (int64_t)img * h * w * CO;
-        for (int c = threadIdx.x; c < CV_TH * CV_TW * CO / 8; c += CV_THREADS) {
+#pragma unroll
+        for (int q = 0; q < Y_PER_THREAD; ++q) {
+            const int c = threadIdx.x + q * CV_THREADS;
             const int px = c / (CO / 8), c8 = c % (CO / 8);
             const int yy = y0 + px / CV_TW, xx = x0 + px % CV_TW;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (yy < h && xx < w) v = *reinterpret_cast<const uint4 *>(gsrc + ((int64_t)yy * w + xx) * CO + c8 * 8);
-            uint2 *dst = reinterpret_cast<uint2 *>(sdy + px * YS + c8 * 8);
-            dst[0] = make_uint2(v.x, v.y);
-            dst[1] = make_uint2(v.z, v.w);
+            yreg[q] = v;
         }
         const uint16_t *xsrc = x + (int64_t)(img + dt) * h * w * CI;
-        for (int c = threadIdx.x; c < CV_PH * CV_PW * CI / 8; c += CV_THREADS) {
+#pragma unroll
+        for (int q = 0; q < X_PER_THREAD; ++q) {
+            const int c = threadIdx.x + q * CV_THREADS;
             const int px = c / (CI / 8), c8 = c % (CI / 8);
             const int yy = y0 - 1 + px / CV_PW, xx = x0 - 1 + px % CV_PW;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (yy >= 0 && yy < h && xx >= 0 && xx < w) v = *reinterpret_cast<const uint4 *>(xsrc + ((int64_t)yy * w + xx) * CI + c8 * 8);
-            uint2 *dst = reinterpret_cast<uint2 *>(sx + px * XS + c8 * 8);
-            dst[0] = make_uint2(v.x, v.y);
-            dst[1] = make_uint2(v.z, v.w);
+            if (c < X_CHUNKS && yy >= 0 && yy < h && xx >= 0 && xx < w)
+                v = *reinterpret_cast<const uint4 *>(xsrc + ((int64_t)yy * w + xx) * CI + c8 * 8);
+            xreg[q] = v;
+        }
+    };
+    int tile = lo + slot;
+    while (tile < hi && !tile_valid(tile)) tile += slots;      // a missing frame contributes nothing
+    if (tile < hi) fetch(tile);
+    while (tile < hi) {
+        __syncthreads();                                       // the previous tile's gathers are done
+#pragma unroll
+        for (int q = 0; q < Y_PER_THREAD; ++q) {
+            const int c = threadIdx.x + q * CV_THREADS;
+            uint2 *dst = reinterpret_cast<uint2 *>(sdy + (c / (CO / 8)) * YS + (c % (CO / 8)) * 8);
+            dst[0] = make_uint2(yreg[q].x, yreg[q].y);
+            dst[1] = make_uint2(yreg[q].z, yreg[q].w);
+        }
+#pragma unroll
+        for (int q = 0; q < X_PER_THREAD; ++q) {
+            const int c = threadIdx.x + q * CV_THREADS;
+            if (c < X_CHUNKS) {
+                uint2 *dst = reinterpret_cast<uint2 *>(sx + (c / (CI / 8)) * XS + (c % (CI / 8)) * 8);
+                dst[0] = make_uint2(xreg[q].x, xreg[q].y);
+                dst[1] = make_uint2(xreg[q].z, xreg[q].w);
+            }
         }
         __syncthreads();
+        int next = tile + slots;
+        while (next < hi && !tile_valid(next)) next += slots;
+        if (next < hi) fetch(next);
+        tile = next;
         // 16-pixel steps of the tile: step s = row s/2, columns (s%2)*16 ..; this wave's share is every GROUPS-th step
         for (int s = grp; s < CV_TH * 2; s += GROUPS) {
             const int ry = s >> 1, xb = (s & 1) * 16 + 8 * lh;

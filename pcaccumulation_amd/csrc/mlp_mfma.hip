@@ -233,33 +233,55 @@ __global__ __launch_bounds__(256) void rows_wgrad_bf16_kernel(const uint16_t *__
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+    // Staging: up to 4 sixteen-byte pieces of dY and of X per thread (64 rows x 128 features), fetched one tile ahead.
     const int64_t n_chunks = (rows + WG_R - 1) / WG_R;
-    for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+    const int ny = WG_R * N / 8, nx = WG_R * K / 8;                              // pieces per tile
+    uint4 yreg[4], mreg[4], xreg[4];
+    auto fetch = [&](int64_t ch) {
         const int64_t row0 = ch * WG_R;
         const int64_t lim_n = (rows - row0) * N, lim_k = (rows - row0) * K;      // elements of this tile that exist
-        for (int i = threadIdx.x; i < WG_R * N / 8; i += 256) {
-            const int e = i * 8, r = e / N, c = e % N;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (e < lim_n) {
-                v = *reinterpret_cast<const uint4 *>(dY + row0 * N + e);
-                if (dy_mask) v = mm_mask8(v, *reinterpret_cast<const uint4 *>(dy_mask + row0 * N + e));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = threadIdx.x + q * 256;
+            uint4 v = make_uint4(0, 0, 0, 0), m = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+            if (i < ny && (int64_t)i * 8 < lim_n) {
+                v = *reinterpret_cast<const uint4 *>(dY + row0 * N + (int64_t)i * 8);
+                if (dy_mask) m = *reinterpret_cast<const uint4 *>(dy_mask + row0 * N + (int64_t)i * 8);
             }
-            uint2 *dst = reinterpret_cast<uint2 *>(sdy + r * NS + c);
-            dst[0] = make_uint2(v.x, v.y);
-            dst[1] = make_uint2(v.z, v.w);
+            yreg[q] = v;
+            mreg[q] = m;
+            uint4 u = make_uint4(0, 0, 0, 0);
+            if (i < nx && (int64_t)i * 8 < lim_k) u = *reinterpret_cast<const uint4 *>(X + row0 * K + (int64_t)i * 8);
+            xreg[q] = u;
         }
-        for (int i = threadIdx.x; i < WG_R * K / 8; i += 256) {
-            const int e = i * 8, r = e / K, c = e % K;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (e < lim_k) {
-                v = *reinterpret_cast<const uint4 *>(X + row0 * K + e);
-                if (x_relu) v = mm_relu8(v);
+    };
+    int64_t ch = blockIdx.x;
+    if (ch < n_chunks) fetch(ch);
+    for (; ch < n_chunks; ch += gridDim.x) {
+        const int64_t row0 = ch * WG_R;
+        __syncthreads();                                                         // the previous tile's gathers are done
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = threadIdx.x + q * 256;
+            if (i < ny) {
+                const int e = i * 8;
+                uint4 v = yreg[q];
+                if (dy_mask) v = mm_mask8(v, mreg[q]);
+                uint2 *dst = reinterpret_cast<uint2 *>(sdy + (e / N) * NS + e % N);
+                dst[0] = make_uint2(v.x, v.y);
+                dst[1] = make_uint2(v.z, v.w);
             }
-            uint2 *dst = reinterpret_cast<uint2 *>(sx + r * KS + c);
-            dst[0] = make_uint2(v.x, v.y);
-            dst[1] = make_uint2(v.z, v.w);
+            if (i < nx) {
+                const int e = i * 8;
+                uint4 v = xreg[q];
+                if (x_relu) v = mm_relu8(v);
+                uint2 *dst = reinterpret_cast<uint2 *>(sx + (e / K) * KS + e % K);
+                dst[0] = make_uint2(v.x, v.y);
+                dst[1] = make_uint2(v.z, v.w);
+            }
         }
         __syncthreads();
+        if (ch + gridDim.x < n_chunks) fetch(ch + gridDim.x);
         const int nrow = (int)min((int64_t)WG_R, rows - row0);
 #pragma unroll
         for (int t = 0; t < MAX_TILES; ++t) {
@@ -289,7 +311,6 @@ __global__ __launch_bounds__(256) void rows_wgrad_bf16_kernel(const uint16_t *__
                 }
             }
         }
-        __syncthreads();
     }
     const int KA = K + 1;
     float *mine = partial + (int64_t)blockIdx.x * N * KA;
