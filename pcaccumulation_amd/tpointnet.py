@@ -4,11 +4,9 @@ Stays plain PyTorch-ROCm (0.6 % of the FLOPs); the pe
 ops.scatter (torch scatter_reduce) on K*T-row outputs.  state_dict keys: `alignment.{geo_embed,motion_embed,
 pos_embed,regressor}.*` under `reconstructor` (appendix B).
 """
-import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
-from scipy.spatial.transform import Rotation as R
 
 from .chamfer_distance import ChamferDistance
 from .ops import scatter, ScatterPlan, linear_rows, transform_by_index, point_dtype
@@ -54,18 +52,42 @@ def batch_quat2mat(pose_est_rep):
     return out
 
 
+def mat2quat(rot):
+    """[N,3,3] rotation matrices -> [N,4] quaternions (x, y, z, w) in float64, on the tensor's device: the branch scheme of
+    scipy.spatial.transform.Rotation.from_matrix(...).as_quat() (largest of the three diagonal entries and the trace decides
+    which component is formed first; ties go to the first), which the reference calls on the host (models/tpointnet.py:62-66).
+    Identical to scipy 1.15 to the last bit on proper rotations and to 2e-8 on float32-rounded ones, which scipy
+    re-orthogonalises first (tests/test_host_logic.py); no device -> host round trip."""
+    m = rot.double()
+    d0, d1, d2 = m[:, 0, 0], m[:, 1, 1], m[:, 2, 2]
+    tr = d0 + d1 + d2
+    choice = torch.stack((d0, d1, d2, tr), dim=1).argmax(dim=1)
+    cands = []
+    for i in range(3):
+        j, k = (i + 1) % 3, (i + 2) % 3
+        q = [None] * 4
+        q[i] = 1 - tr + 2 * m[:, i, i]
+        q[j] = m[:, j, i] + m[:, i, j]
+        q[k] = m[:, k, i] + m[:, i, k]
+        q[3] = m[:, k, j] - m[:, j, k]
+        cands.append(torch.stack(q, dim=1))
+    cands.append(torch.stack((m[:, 2, 1] - m[:, 1, 2], m[:, 0, 2] - m[:, 2, 0], m[:, 1, 0] - m[:, 0, 1], 1 + tr), dim=1))
+    quat = torch.stack(cands, dim=1)[torch.arange(m.size(0), device=m.device), choice]
+    return quat / torch.norm(quat, dim=1, keepdim=True)
+
+
 def batch_mat2quat(pose_gt, centroids):
-    """models/tpointnet.py:43-73: ground-truth poses re-expressed for centred clouds, plus their 7-vector
-    (scipy as_quat on the host, as in the reference)."""
+    """models/tpointnet.py:43-73: ground-truth poses re-expressed for centred clouds, plus their 7-vector (float64, as
+    to_tensor(np.array(...)) yields in the reference)."""
     n_frames = pose_gt.size(1)
     device = pose_gt.device
     tsfm = pose_gt.clone().view(-1, 4, 4)
     cen = centroids.repeat_interleave(n_frames, 0).unsqueeze(2)
     B = tsfm.size(0)
     tsfm[:, :3, 3] += torch.matmul(tsfm[:, :3, :3] - torch.eye(3, device=device)[None].repeat(B, 1, 1), cen).squeeze(2)
-    host = tsfm.detach().cpu().numpy()
-    rep = np.concatenate([R.from_matrix(host[:, :3, :3]).as_quat(), host[:, :3, 3]], axis=1)
-    return tsfm, torch.from_numpy(rep).to(device)        # float64, as to_tensor(np.array(...)) yields in the reference
+    det = tsfm.detach()
+    rep = torch.cat((mat2quat(det[:, :3, :3]), det[:, :3, 3].double()), dim=1)
+    return tsfm, rep
 
 
 def evaluate_pose(pose_est_rep, pose_gt_rep, weights):
