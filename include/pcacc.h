@@ -304,6 +304,11 @@ int pcacc_conv3x3_wgrad_bf16(const uint16_t *dy, const uint16_t *x, float *dw, i
                              int32_t h, int32_t w, int32_t c_in, int32_t c_out, void *workspace, size_t workspace_bytes,
                              void *stream);
 
+/* Host words -> device memory as kernel arguments (asynchronous, unlike a pageable hipMemcpy on the compute stream):
+ * n 32-bit words from host_words to dst, 240 per launch.  For the per-step index tables a host loop of the reference
+ * becomes (sample offsets, per-pair counts, thresholds). */
+int pcacc_upload_words(const uint32_t *host_words, int64_t n, uint32_t *dst, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

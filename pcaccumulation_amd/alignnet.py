@@ -2,6 +2,7 @@
 Plain PyTorch-ROCm; the Open3D ICP refinements (`model.tpointnet_icp`) are off the hot path."""
 import torch
 
+from . import native
 from .ops import scatter
 from .tpointnet import TPointNet, BaseModel, reconstruct_sequence
 
@@ -17,7 +18,7 @@ def update_gt_inst_motion(inst_motion_gt, ego_motion_gt, ego_motion_est):
         K = motion.size(0)
         gt = ego_motion_gt[b][None].repeat(K, 1, 1, 1).view(-1, 4, 4)
         est = ego_motion_est[b][None].repeat(K, 1, 1, 1).view(-1, 4, 4)
-        out.append((motion.view(-1, 4, 4) @ gt @ torch.linalg.inv(est)).view(K, -1, 4, 4))
+        out.append((motion.view(-1, 4, 4) @ gt @ torch.linalg.inv_ex(est)[0]).view(K, -1, 4, 4))   # inv() minus its host sync
     return out
 
 
@@ -44,28 +45,26 @@ class AlignNet(BaseModel):
         per_slot = scatter(ones, slot, dim=0, dim_size=K * T, reduce='sum')
         per_inst = scatter(ones, inst_indice, dim=0, dim_size=K, reduce='sum')
         orphan = (per_slot[::T] == 0) & (per_inst > 0)
-        extra = []
-        if orphan.sum():
-            for k in torch.where(orphan)[0].tolist():
-                first = torch.where(per_slot[k * T:(k + 1) * T] > 0)[0][0]
-                extra.append(torch.where(slot == k * T + first)[0])
-        extra = torch.cat(extra) if extra else None
         alive = per_inst > 0
+        flags = torch.stack((orphan, alive)).cpu()                           # the ONE host sync of this step
+        extra = []
+        for k in torch.where(flags[0])[0].tolist():
+            first = torch.where(per_slot[k * T:(k + 1) * T] > 0)[0][0]
+            extra.append(torch.where(slot == k * T + first)[0])
+        extra = torch.cat(extra) if extra else None
+        alive_idx = torch.where(flags[1])[0]
         relabel = -1 * torch.ones(K).long()
-        relabel[alive.cpu()] = torch.arange(int(alive.sum()))
-        compact = relabel.to(device)[inst_indice]
-        assert compact.min() != -1
-        return extra, inst_motion[alive], compact
+        relabel[alive_idx] = torch.arange(alive_idx.numel())
+        compact = native.upload_small(relabel, torch.int64, device)[inst_indice]   # every point's instance is alive by construction
+        return extra, inst_motion[native.upload_small(alive_idx, torch.int64, device)], compact
 
     def _merge_batch_instances(self, labels, batch_col, motions):
         """Instance ids of sample b are shifted by the number of instances in samples < b (alignnet.py:199-206)."""
-        base = 0
-        for b, m in enumerate(motions):
-            sel = batch_col == b
-            if sel.sum():
-                labels[sel] += base
-                base += m.size(0)
-        return labels, torch.cat(motions)
+        # The reference skips samples without points when it advances the base (`if sel.sum()`); with points sorted by sample and
+        # every sample of a collated batch non-empty this is the running sum of the instance counts, known on the host.
+        sizes = [m.size(0) for m in motions]
+        base = native.upload_small([sum(sizes[:b]) for b in range(len(sizes))], labels.dtype, labels.device)
+        return labels + base[batch_col.long()], torch.cat(motions)
 
     def forward(self, input_dict, results):
         """models/alignnet.py:166-285: iterative per-instance pose regression on the foreground points."""

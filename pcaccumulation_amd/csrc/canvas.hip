@@ -239,3 +239,29 @@ extern "C" int pcacc_gather_rows(const void *src, int row_bytes, const int32_t *
 }
 
 extern "C" const char *pcacc_target(void) { return "gfx950"; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Small host arrays (per-sample counts, label offsets, thresholds: a few dozen words) to device memory as KERNEL ARGUMENTS.
+// A hipMemcpy from pageable host memory on the compute stream waits for everything queued before it -- each
+// `torch.tensor(list, device=...)` in the forward pass was a pipeline drain (20 per step).  A kernel launch carrying the
+// words by value is asynchronous like any other launch.
+// ---------------------------------------------------------------------------------------------------------------------
+struct UploadWords { uint32_t w[240]; };
+
+__global__ void upload_words_kernel(UploadWords words, int n, uint32_t *dst)
+{
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = words.w[threadIdx.x];
+}
+
+extern "C" int pcacc_upload_words(const uint32_t *host_words, int64_t n, uint32_t *dst, void *stream)
+{
+    if (n < 0 || (n > 0 && (!host_words || !dst))) return PCACC_E_ARG;
+    for (int64_t off = 0; off < n; off += 240) {
+        UploadWords words;
+        const int m = (int)((n - off) < 240 ? (n - off) : 240);
+        for (int i = 0; i < m; ++i) words.w[i] = host_words[off + i];
+        upload_words_kernel<<<1, 256, 0, pcacc_stream(stream)>>>(words, m, dst + off);
+    }
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}

@@ -45,7 +45,7 @@ def get_relative_pose_torch(tsfm_src, tsfm_tgt, dataset):
     """toolbox/register_utils.py:184-197: T_tgt^-1 @ T_src (waymo / nuscene branch)."""
     if dataset not in ('waymo', 'nuscene'):
         raise NotImplementedError('only the waymo / nuscene branch of get_relative_pose_torch is on the hot path')
-    return torch.linalg.solve(tsfm_tgt, tsfm_src)
+    return torch.linalg.solve_ex(tsfm_tgt, tsfm_src)[0]          # solve() without the singularity check (a host sync per call)
 
 
 def kabsch_transformation_estimation(x1, x2, weights=None, normalize_w=True, eps=1e-7, best_k=0, w_threshold=0):
@@ -195,7 +195,7 @@ class EgoMotionHead(nn.Module):
             # every key-point draw of the step in one launch (source, then target, per pair -- the reference's order)
             counts = [n for _, _, bg_list, _ in sequences for f in range(T - 1) for n in (bg_list[f + 1][1], bg_list[0][1])]
             seed = int(torch.empty((), dtype=torch.int64).random_())       # host generator: follows torch.manual_seed
-            drawn = native.sample_subsets(torch.tensor(counts, dtype=torch.int32, device=dev), self.ego_n_points, seed)
+            drawn = native.sample_subsets(native.upload_small(counts, torch.int32, dev), self.ego_n_points, seed)
         for points_list, feats_list, bg_list, _ in sequences:
             a_idx, a_n = bg_list[0]
             for frame_idx in range(T - 1):
@@ -219,8 +219,7 @@ class EgoMotionHead(nn.Module):
             # arithmetic on 0.03 % of the data (and of the backward).
             feats_s = feats_s / torch.norm(feats_s, p=2, dim=2, keepdim=True)
             feats_t = feats_t / torch.norm(feats_t, p=2, dim=2, keepdim=True)
-        thr2 = (torch.tensor(durations, dtype=torch.float32) * self.ego_max_speed) ** 2
-        thr2 = thr2.to(dev)
+        thr2 = native.upload_small((torch.tensor(durations, dtype=torch.float32) * self.ego_max_speed) ** 2, torch.float32, dev)
         if not torch.is_grad_enabled():
             # eval / val / test: the fused fp32 HIP pipeline (affinity, Sinkhorn, soft targets, Kabsch + 3x3 SVD)
             params = torch.stack([self.softplus(self.alpha), torch.exp(self.beta) + 0.02]).float().detach()
@@ -274,7 +273,7 @@ class EgoMotionHead(nn.Module):
         # [3, n] x [n, 3] product in its backward (0.23 ms each on MI355X, 16 per step); here the gradient of the pose
         # table is a segment sum.
         pts = torch.cat(ref_pts, dim=0)
-        pair = torch.repeat_interleave(torch.arange(P, device=dev), torch.tensor(lens, device=dev), output_size=pts.shape[0])
+        pair = torch.repeat_interleave(torch.arange(P, device=dev), native.upload_small(lens, torch.int64, dev), output_size=pts.shape[0])
         diff = ops.transform_by_index(pts, pair, pose_est - torch.cat(gt_rows, dim=0).to(pose_est.dtype))
         norms = torch.stack((torch.norm(diff, p=1, dim=1), torch.norm(diff, p=2, dim=1)), dim=1)
         means = ops.scatter(norms, pair, dim=0, dim_size=P, reduce="mean", plan=ops.ScatterPlan(pair, P))

@@ -8,6 +8,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import native
 from .ops import scatter
 from .tpointnet import ego_motion_compensation, reconstruct_sequence
 
@@ -174,15 +175,17 @@ class FuseLoss(nn.Module):
             z = torch.tensor(0., requires_grad=True).to(device)
             return z, torch.tensor(0., requires_grad=True).to(device), 0
         n_frames = ego_motion_gt.size(1)
-        centres = []
-        for b in range(len(bbox_tsfm)):
-            sel = time_indice[:, 0] == b
-            lab, t = inst_labels[sel], time_indice[sel, 1]
-            comp = ego_motion_compensation(input_points[sel], t, ego_motion_gt[b])
-            rec = reconstruct_sequence(comp, t, lab, bbox_tsfm[b].to(device), n_frames)
-            centre = scatter(rec, lab, dim=0, dim_size=bbox_tsfm[b].shape[0], reduce='mean')   # K known on the host: no lab.max() sync
-            centres.append(centre[lab])
-        inst_centers = torch.cat(centres, dim=0)[:, :2]
+        # GT reconstruction and instance centres of all samples at once (the reference loops over samples with boolean masks,
+        # libs/loss.py:216-232: four host syncs per sample): points carry their sample in time_indice[:, 0], so the ego poses
+        # are indexed by b*T+t and the instance tables are concatenated with per-sample label offsets known on the host.
+        sizes = [m.shape[0] for m in bbox_tsfm]
+        base = native.upload_small([sum(sizes[:b]) for b in range(len(sizes))], torch.int64, device)
+        b_idx, t_idx = time_indice[:, 0].long(), time_indice[:, 1].long()
+        lab = inst_labels + base[b_idx]
+        comp = ego_motion_compensation(input_points, b_idx * n_frames + t_idx, ego_motion_gt.reshape(-1, 4, 4))
+        rec = reconstruct_sequence(comp, t_idx, lab, torch.cat([m.to(device) for m in bbox_tsfm], dim=0), n_frames)
+        centre = scatter(rec, lab, dim=0, dim_size=sum(sizes), reduce='mean')       # K known on the host: no lab.max() sync
+        inst_centers = centre[lab][:, :2]
         gt_offset = (inst_centers - predictions['transformed_points'][:, :2])[fb_mask]
         est_offset = predictions['offset_est'][fb_mask]
         offset_norm_loss = torch.abs(gt_offset - est_offset).mean(dim=0).sum()

@@ -48,7 +48,7 @@ EXPORTS = [
     'pcacc_sinkhorn_kabsch_workspace_bytes', 'pcacc_sinkhorn_kabsch', 'pcacc_chamfer_workspace_bytes', 'pcacc_chamfer_forward', 'pcacc_chamfer_backward',
     'pcacc_cluster_workspace_bytes', 'pcacc_cluster', 'pcacc_conv3x3_prepare_weights', 'pcacc_conv3x3_bf16',
     'pcacc_rows_linear_bf16', 'pcacc_rows_linear_mixed', 'pcacc_rows_wgrad_mixed',
-    'pcacc_segment_max_t', 'pcacc_segment_max_backward_t', 'pcacc_segment_sum_t', 'pcacc_rows_wgrad_bf16_workspace_bytes', 'pcacc_rows_wgrad_bf16', 'pcacc_sample_subsets', 'pcacc_conv3x3_wgrad_workspace_bytes', 'pcacc_conv3x3_wgrad_bf16',
+    'pcacc_segment_max_t', 'pcacc_segment_max_backward_t', 'pcacc_segment_sum_t', 'pcacc_rows_wgrad_bf16_workspace_bytes', 'pcacc_rows_wgrad_bf16', 'pcacc_sample_subsets', 'pcacc_conv3x3_wgrad_workspace_bytes', 'pcacc_conv3x3_wgrad_bf16', 'pcacc_upload_words',
 ]
 
 
@@ -492,3 +492,19 @@ def conv3x3_wgrad(dy_rows, x_rows, frames=1, dt=0):
                                           int(frames), int(dt), int(h), int(w), int(c_in), int(c_out), _dev(ws),
                                           ctypes.c_size_t(ws.numel()), _stream()), 'conv3x3_wgrad')
     return dw
+
+
+def upload_small(values, dtype, device):
+    """A small host list / numpy array / CPU tensor -> device tensor of `dtype` without a blocking copy (see pcacc_upload_words).
+    CPU devices get a plain tensor."""
+    host = torch.as_tensor(values, dtype=dtype).contiguous()
+    if device.type != 'cuda':
+        return host
+    out = torch.empty(host.shape, dtype=dtype, device=device)
+    nbytes = host.numel() * host.element_size()
+    if nbytes == 0:
+        return out
+    if nbytes % 4:
+        raise NativeError('upload_small: byte size must be a multiple of 4')
+    _check(lib().pcacc_upload_words(ctypes.c_void_p(host.data_ptr()), _i64(nbytes // 4), _dev(out), _stream()), 'upload_words')
+    return out

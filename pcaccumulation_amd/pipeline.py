@@ -7,15 +7,15 @@ of numba on a DataLoader worker.
 """
 import torch
 
+from . import native
 from .voxel_generator import Voxelization
 
 
 def sample_to_device(sample, device):
     """numpy sample dict (pcaccumulation_amd.synthetic.make_sequence) -> torch tensors on `device`."""
-    out = {}
-    for k, v in sample.items():
-        out[k] = torch.from_numpy(v).to(device) if k != 'inst_motion_gt' else torch.from_numpy(v)
-    return out
+    # everything, including the per-instance motion table (the reference's collate keeps that one as a host list and every
+    # consumer moves it with .to(device), models/alignnet.py:22, libs/loss.py:222: a blocking copy per sample per step)
+    return {k: torch.from_numpy(v).to(device) for k, v in sample.items()}
 
 
 class DeviceBatcher(object):
@@ -49,6 +49,6 @@ class DeviceBatcher(object):
             'sd_labels': cat('sd_labels'), 'inst_labels': cat('inst_labels'), 'fb_labels': cat('fb_labels'),
             'ego_motion_gt': torch.stack([s['ego_motion_gt'] for s in samples], 0),
             'inst_motion_gt': [s['inst_motion_gt'] for s in samples],
-            'coordinates': torch.cat(coords, 0), 'num_voxels': torch.tensor(n_vox, dtype=torch.int64, device=dev),
-            'shape': grid[None].repeat(len(samples), 1).to(dev), 'point_to_voxel_map': torch.cat(p2vs, 0),
+            'coordinates': torch.cat(coords, 0), 'num_voxels': native.upload_small(n_vox, torch.int64, dev),
+            'shape': native.upload_small(grid[None].repeat(len(samples), 1), torch.int64, dev), 'point_to_voxel_map': torch.cat(p2vs, 0),
         }
