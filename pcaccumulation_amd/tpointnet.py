@@ -179,7 +179,7 @@ class TPointNet(BaseModel):
         slot_label = scatter(moving, slot, dim=0, dim_size=n_slots, reduce='max', plan=per_slot)
         label_w = torch.ones_like(slot_label)
         label_w[slot_label == 0] = 0.2
-        ramp = (torch.arange(self.n_frames) + 1).to(device).repeat(n_inst) / self.n_frames
+        ramp = (torch.arange(self.n_frames, device=device) + 1).repeat(n_inst) / self.n_frames
         return enough * label_w * ramp
 
     # -- step 2 ---------------------------------------------------------------------------------------------
