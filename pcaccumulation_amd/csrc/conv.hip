@@ -464,10 +464,13 @@ extern "C" int pcacc_conv3x3_bf16(const uint16_t *in, const uint16_t *wp, const 
 // dW[co][tap][ci] = sum over images and pixels of dY[px][co] * X[px + tap offset][ci]  (zero outside the image), one frame tap per
 // launch (dt: X is read from image n + dt of the same sample, or not at all when that frame does not exist).
 // The reduction runs over pixels, so both MFMA operands are "8 consecutive pixels of one channel" per lane: the dY tile and
-// the X patch are staged channels-last as they come and the fragments are gathered with 16-bit LDS reads (row stride
-// C + 4 elements: the two half-waves of a gather fall on disjoint bank halves).  A wave owns one (co tile, ci tile) pair and
+// the X patch are staged channels-last as they come and the fragments are read with the hardware LDS transpose
+// (ds_read_b64_tr_b16, two per fragment; row stride C + 4 elements).  A wave owns one (co tile, ci tile) pair and
 // all 9 taps, so the dY fragment of a 16-pixel step is gathered once and used by 9 MFMAs.  Workgroups are persistent; their
 // accumulators go to a workspace slot each and a second launch sums the slots (conv_wgrad_reduce_kernel).
+typedef short cv_s16x4 __attribute__((ext_vector_type(4)));
+union cv_frag { bf16x8_t v; cv_s16x4 h[2]; };
+
 template <int CO_T, int CI_T>
 __global__ __launch_bounds__(CV_THREADS) void conv3x3_wgrad_kernel(const uint16_t *__restrict__ dy, const uint16_t *__restrict__ x,
                                                                    float *__restrict__ partial, int n_img, int frames, int dt, int h,
@@ -554,20 +557,23 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_wgrad_kernel(const uint16_
         if (next < hi) fetch(next);
         tile = next;
         // 16-pixel steps of the tile: step s = row s/2, columns (s%2)*16 ..; this wave's share is every GROUPS-th step
+        // fragments through the LDS transpose read (see rows_wgrad_bf16_kernel in mlp_mfma.hip): two ds_read_b64_tr_b16 give a
+        // lane its 8 consecutive pixels of one channel
+        const int tg = lane >> 4, tl = lane & 15;
+        const int tr_row = (tg >> 1) * 8 + (tl >> 2), tr_col = (tg & 1) * 16 + (tl & 3) * 4;
         for (int s = grp; s < CV_TH * 2; s += GROUPS) {
-            const int ry = s >> 1, xb = (s & 1) * 16 + 8 * lh;
-            const uint16_t *pa = sdy + (ry * CV_TW + xb) * YS + ct * 32 + lp;
-            uint32_t a[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) a[j] = (uint32_t)pa[(2 * j) * YS] | ((uint32_t)pa[(2 * j + 1) * YS] << 16);
-            const bf16x8_t af = *reinterpret_cast<const bf16x8_t *>(a);
+            const int ry = s >> 1, xb = (s & 1) * 16;
+            const uint16_t *pa = sdy + (ry * CV_TW + xb + tr_row) * YS + ct * 32 + tr_col;
+            cv_frag af;
+            af.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cv_s16x4 __attribute__((address_space(3))) *)pa);
+            af.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cv_s16x4 __attribute__((address_space(3))) *)(pa + 4 * YS));
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
-                const uint16_t *pb = sx + ((ry + tap / 3) * CV_PW + xb + tap % 3) * XS + it * 32 + lp;
-                uint32_t b[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) b[j] = (uint32_t)pb[(2 * j) * XS] | ((uint32_t)pb[(2 * j + 1) * XS] << 16);
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, *reinterpret_cast<const bf16x8_t *>(b), acc[tap], 0, 0, 0);
+                const uint16_t *pb = sx + ((ry + tap / 3) * CV_PW + xb + tap % 3 + tr_row) * XS + it * 32 + tr_col;
+                cv_frag bf;
+                bf.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cv_s16x4 __attribute__((address_space(3))) *)pb);
+                bf.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cv_s16x4 __attribute__((address_space(3))) *)(pb + 4 * XS));
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.v, bf.v, acc[tap], 0, 0, 0);
             }
         }
     }

@@ -208,14 +208,14 @@ extern "C" int pcacc_rows_linear_bf16(const uint16_t *x, const uint16_t *in_mask
 // Weight / bias gradient from bf16 rows on the bf16 matrix cores:  dW_aug[n][k] (k in [0,K]; column K = bias gradient)
 //   = sum_r dYeff[r][n] * Xaug[r][k],  Xaug[r][K] = 1,  dYeff = dY masked where dy_mask <= 0,  X optionally ReLU'd.
 // The reduction runs over rows, so both MFMA operands need 8 consecutive ROWS of one column per lane: the tiles are staged
-// row-major (coalesced, masks applied on the way) and the fragments are gathered with 16-bit LDS reads.  That costs 16 LDS
-// reads per MFMA and caps the matrix cores at ~25 % -- still 4x the fp32 MFMA path of mlp.hip, and enough to leave the
-// kernel bound by the HBM stream of dY and X (half the bytes of the fp32 rows).  Row stride = width + 4 elements: the two
-// half-waves of a gather (rows r and r+8) land on disjoint bank halves.
+// row-major (coalesced, masks applied on the way) and the fragments come through the hardware transpose read
+// (ds_read_b64_tr_b16, two per fragment) instead of eight 16-bit gathers.  k and n are multiples of 32.
 // Workgroup partials are written to a workspace with plain stores and summed by a second launch: with ~1000 workgroups
 // an atomic per element per workgroup is 17 M same-address atomics for a 128 x 129 gradient, longer than the products.
 // ---------------------------------------------------------------------------------------------------------------------
 #define WG_R 64                    // rows per staged tile
+typedef short wg_s16x4 __attribute__((ext_vector_type(4)));
+union wg_frag { bf16x8_t v; wg_s16x4 h[2]; uint16_t e[8]; };
 
 template <int MAX_TILES>
 __global__ __launch_bounds__(256) void rows_wgrad_bf16_kernel(const uint16_t *__restrict__ dY, const uint16_t *__restrict__ dy_mask,
@@ -283,31 +283,34 @@ __global__ __launch_bounds__(256) void rows_wgrad_bf16_kernel(const uint16_t *__
         __syncthreads();
         if (ch + gridDim.x < n_chunks) fetch(ch + gridDim.x);
         const int nrow = (int)min((int64_t)WG_R, rows - row0);
+        // Fragments through the LDS transpose read: ds_read_b64_tr_b16 hands lane i of a 16-lane group column i of a 4-row x
+        // 16-column block whose 16 four-element pieces the lanes address (piece i = row i>>2, columns 4*(i&3)..+3).  Groups
+        // 0/1 cover columns 0-15 / 16-31 of rows 0-7, groups 2/3 the same columns of rows 8-15: two reads give the lane its
+        // 8 consecutive rows of one column, which is the MFMA operand (k = rows).
+        const int g = lane >> 4, li = lane & 15;
+        const int tr_row = (g >> 1) * 8 + (li >> 2), tr_col = (g & 1) * 16 + (li & 3) * 4;
 #pragma unroll
         for (int t = 0; t < MAX_TILES; ++t) {
             const int tile = wave + 4 * t;                                       // uniform per wave
             if (tile < n_tile_total) {
-                const int n = (tile / k_tiles) * 32 + lp;
-                const int k = (tile % k_tiles) * 32 + lp;
-                const bool nv = n < N;
-                const int kind = k < K ? 0 : (k == K ? 1 : 2);                   // data column / ones column (bias) / padding
-                const uint16_t *pa = sdy + (8 * lh) * NS + (nv ? n : 0);
-                const uint16_t *pb = sx + (8 * lh) * KS + (kind == 0 ? k : 0);
+                const int nt = tile / k_tiles, kt = tile % k_tiles;
+                const bool ones = kt * 32 >= K;                                  // the tile that holds the bias column (k == K)
+                const uint16_t *pa = sdy + tr_row * NS + nt * 32 + tr_col;
+                const uint16_t *pb = sx + tr_row * KS + (ones ? 0 : kt * 32) + tr_col;
 #pragma unroll
                 for (int r0 = 0; r0 < WG_R; r0 += 16) {
-                    uint16_t av[8], bv[8];
+                    wg_frag a, b;
+                    a.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_s16x4 __attribute__((address_space(3))) *)(pa + r0 * NS));
+                    a.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_s16x4 __attribute__((address_space(3))) *)(pa + (r0 + 4) * NS));
+                    if (!ones) {
+                        b.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_s16x4 __attribute__((address_space(3))) *)(pb + r0 * KS));
+                        b.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_s16x4 __attribute__((address_space(3))) *)(pb + (r0 + 4) * KS));
+                    } else {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        av[j] = nv ? pa[(r0 + j) * NS] : (uint16_t)0;
-                        bv[j] = kind == 0 ? pb[(r0 + j) * KS] : ((kind == 1 && r0 + 8 * lh + j < nrow) ? (uint16_t)0x3f80 : (uint16_t)0);
+                        for (int j = 0; j < 8; ++j)
+                            b.e[j] = (kt * 32 + lp == K && r0 + 8 * lh + j < nrow) ? (uint16_t)0x3f80 : (uint16_t)0;
                     }
-                    uint4 a4, b4;
-                    a4.x = av[0] | ((uint32_t)av[1] << 16); a4.y = av[2] | ((uint32_t)av[3] << 16);
-                    a4.z = av[4] | ((uint32_t)av[5] << 16); a4.w = av[6] | ((uint32_t)av[7] << 16);
-                    b4.x = bv[0] | ((uint32_t)bv[1] << 16); b4.y = bv[2] | ((uint32_t)bv[3] << 16);
-                    b4.z = bv[4] | ((uint32_t)bv[5] << 16); b4.w = bv[6] | ((uint32_t)bv[7] << 16);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8_t *>(&a4), *reinterpret_cast<bf16x8_t *>(&b4),
-                                                                     acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc[t], 0, 0, 0);
                 }
             }
         }
@@ -364,7 +367,7 @@ extern "C" int pcacc_rows_wgrad_bf16_workspace_bytes(int64_t rows, int32_t k, in
 extern "C" int pcacc_rows_wgrad_bf16(const uint16_t *dy, const uint16_t *dy_mask, const uint16_t *x, int32_t x_relu, int64_t rows,
                                      int32_t k, int32_t n, float *dw_aug, void *workspace, size_t workspace_bytes, void *stream)
 {
-    if (rows < 0 || k <= 0 || n <= 0 || k > 128 || n > 128 || (k % 8) || (n % 8) || !dw_aug) return PCACC_E_ARG;
+    if (rows < 0 || k <= 0 || n <= 0 || k > 128 || n > 128 || (k % 32) || (n % 32) || !dw_aug) return PCACC_E_ARG;
     hipStream_t st = pcacc_stream(stream);
     if (rows == 0) {
         if (hipMemsetAsync(dw_aug, 0, (size_t)n * (k + 1) * sizeof(float), st) != hipSuccess) return PCACC_E_LAUNCH;

@@ -359,7 +359,7 @@ def rows_wgrad(dy, x, dy_mask=None, x_relu=False):
     rows, n = dy.shape
     k = x.shape[1]
     out = torch.empty((n, k + 1), dtype=torch.float32, device=dy.device)
-    if all(t is None or t.dtype == torch.bfloat16 for t in (dy, dy_mask, x)) and k % 8 == 0 and n % 8 == 0:
+    if all(t is None or t.dtype == torch.bfloat16 for t in (dy, dy_mask, x)) and k % 32 == 0 and n % 32 == 0:
         need = ctypes.c_size_t(0)
         _check(lib().pcacc_rows_wgrad_bf16_workspace_bytes(_i64(rows), int(k), int(n), ctypes.byref(need)), 'rows_wgrad_bf16_workspace')
         ws = _ws(need.value, dy.device)
