@@ -220,7 +220,7 @@ def cluster(points, offset, sel, batch, n_batches, voxel_size, eps, min_samples,
 NAMES = ['voxelize', 'cell_index', 'frame_pillars', 'csr_build', 'segment_mean3_maxlabel', 'segment_max',
          'segment_max_backward', 'segment_sum', 'pillar_scatter', 'gather_rows', 'bilinear_gather',
          'bilinear_gather_backward', 'bev_warp', 'rigid_transform', 'chamfer_forward', 'chamfer_backward',
-         'rows_linear', 'rows_wgrad', 'rows_linear_supported', 'pfn_features', 'scatter_sum_small', 'sinkhorn_kabsch', 'cluster', 'sample_subsets', 'upload_small']
+         'rows_linear', 'rows_wgrad', 'rows_linear_supported', 'pfn_features', 'scatter_sum_small', 'sinkhorn_kabsch', 'cluster', 'sample_subsets', 'upload_small', 'bilinear_gather_backward_sorted']
 
 
 def install(monkeypatch=None):
@@ -248,3 +248,7 @@ def sample_subsets(counts, k, seed):
 
 def upload_small(values, dtype, device):
     return torch.as_tensor(values, dtype=dtype).contiguous()
+
+
+def bilinear_gather_backward_sorted(grad_out, shape, points, map_idx, x_scale, y_scale, out_dtype=torch.float32):
+    return bilinear_gather_backward(grad_out.float(), shape, points, map_idx, x_scale, y_scale).to(out_dtype)

@@ -48,7 +48,7 @@ EXPORTS = [
     'pcacc_sinkhorn_kabsch_workspace_bytes', 'pcacc_sinkhorn_kabsch', 'pcacc_chamfer_workspace_bytes', 'pcacc_chamfer_forward', 'pcacc_chamfer_backward',
     'pcacc_cluster_workspace_bytes', 'pcacc_cluster', 'pcacc_conv3x3_prepare_weights', 'pcacc_conv3x3_bf16',
     'pcacc_rows_linear_bf16', 'pcacc_rows_linear_mixed', 'pcacc_rows_wgrad_mixed',
-    'pcacc_segment_max_t', 'pcacc_segment_max_backward_t', 'pcacc_segment_sum_t', 'pcacc_rows_wgrad_bf16_workspace_bytes', 'pcacc_rows_wgrad_bf16', 'pcacc_sample_subsets', 'pcacc_conv3x3_wgrad_workspace_bytes', 'pcacc_conv3x3_wgrad_bf16', 'pcacc_upload_words',
+    'pcacc_segment_max_t', 'pcacc_segment_max_backward_t', 'pcacc_segment_sum_t', 'pcacc_rows_wgrad_bf16_workspace_bytes', 'pcacc_rows_wgrad_bf16', 'pcacc_sample_subsets', 'pcacc_conv3x3_wgrad_workspace_bytes', 'pcacc_conv3x3_wgrad_bf16', 'pcacc_upload_words', 'pcacc_bilinear_base_cells', 'pcacc_bilinear_gather_backward_sorted',
 ]
 
 
@@ -507,4 +507,25 @@ def upload_small(values, dtype, device):
     if nbytes % 4:
         raise NativeError('upload_small: byte size must be a multiple of 4')
     _check(lib().pcacc_upload_words(ctypes.c_void_p(host.data_ptr()), _i64(nbytes // 4), _dev(out), _stream()), 'upload_words')
+    return out
+
+
+def bilinear_gather_backward_sorted(grad_out, shape, points, map_idx, x_scale, y_scale, out_dtype=torch.float32):
+    """Gradient of bilinear_gather w.r.t. the map, atomic-free (see include/pcacc.h): grad_out [k,c] f32|bf16 ->
+    [n_maps,h,w,c] in out_dtype."""
+    n_maps, h, w, c = shape
+    k = points.shape[0]
+    dev = grad_out.device
+    out = torch.empty((n_maps, h, w, c), dtype=out_dtype, device=dev)
+    if k == 0:
+        return out.zero_()
+    cells = torch.empty((k,), dtype=torch.int32, device=dev)
+    _check(lib().pcacc_bilinear_base_cells(_dev(points, torch.float32, 'points'), _dev(map_idx, torch.int32, 'map_idx'), _i64(k),
+                                           int(n_maps), int(h), int(w), ctypes.c_float(x_scale), ctypes.c_float(y_scale),
+                                           _dev(cells), _stream()), 'bilinear_base_cells')
+    offs, order = csr_build(cells, n_maps * h * w + 1)
+    _check(lib().pcacc_bilinear_gather_backward_sorted(_dev(grad_out, None, 'grad_out'), _dtype_code(grad_out), int(n_maps), int(h),
+                                                       int(w), int(c), _dev(points, torch.float32, 'points'), _dev(offs, torch.int32),
+                                                       _dev(order, torch.int32), ctypes.c_float(x_scale), ctypes.c_float(y_scale),
+                                                       _dev(out), _dtype_code(out), _stream()), 'bilinear_gather_backward_sorted')
     return out

@@ -162,8 +162,14 @@ class _BilinearGather(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         points, map_idx = ctx.saved_tensors
-        g = native.bilinear_gather_backward(grad_out.contiguous().float(), ctx.shape, points, map_idx, *ctx.scales)
-        return g.permute(0, 3, 1, 2).to(ctx.in_dtype), None, None, None, None
+        grad_out = grad_out.contiguous()
+        if grad_out.dtype not in (torch.float32, torch.bfloat16):
+            grad_out = grad_out.float()
+        out_dtype = ctx.in_dtype if ctx.in_dtype in (torch.float32, torch.bfloat16) else torch.float32
+        # sorted, atomic-free reduction (deterministic); writes the map in its own element type
+        g = native.bilinear_gather_backward_sorted(grad_out, ctx.shape, points, map_idx, *ctx.scales, out_dtype=out_dtype)
+        g = g.permute(0, 3, 1, 2)
+        return (g if g.dtype == ctx.in_dtype else g.to(ctx.in_dtype)), None, None, None, None
 
 
 def bilinear_gather(fmap, points, map_idx, x_scale, y_scale):

@@ -120,4 +120,4 @@ class SegHead2D(nn.Module):
 
     def forward(self, feats):
         conv0, bn, act, conv1 = self.seg_head
-        return conv1(act(bn(ops.conv3x3(feats, conv0))))
+        return ops.conv3x3(act(bn(ops.conv3x3(feats, conv0))), conv1)          # library for c_out = 2, MFMA kernel for 64 -> 64

@@ -655,3 +655,30 @@ def test_sample_subsets_device_sampler():
     for s in range(64):
         hits[native.sample_subsets(counts[6:7], 1024, s).cpu()[0]] += 1
     assert hits.min() >= 12 and hits.max() <= 52            # 32 expected; binomial(64, 1/2) tails
+
+
+@pytest.mark.gpu
+def test_bilinear_gather_backward_sorted_matches_atomic():
+    """The sorted, atomic-free map gradient against the atomic kernel (same fp32 products, different summation order) and,
+    in bf16, against its own fp32 result; points outside the map, on the border, and of an invalid map index included."""
+    import torch
+    from pcaccumulation_amd import native
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(21)
+    n_maps, h, w, c, k = 3, 37, 52, 64, 40000
+    pts = (torch.rand(k, 3, generator=g) * 2.4 - 1.2) * 10.0
+    pts[:50] = 10.0                                                       # exactly on / beyond the border
+    idx = torch.randint(0, n_maps, (k,), generator=g).to(torch.int32)
+    idx[100:110] = -1
+    idx[110:120] = n_maps
+    go = torch.randn(k, c, generator=g)
+    pts, idx, go = pts.to(dev), idx.to(dev), go.to(dev)
+    ref = native.bilinear_gather_backward(go, (n_maps, h, w, c), pts, idx, 10.0, 10.0)
+    got = native.bilinear_gather_backward_sorted(go, (n_maps, h, w, c), pts, idx, 10.0, 10.0)
+    assert got.dtype == torch.float32 and (got - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
+    again = native.bilinear_gather_backward_sorted(go, (n_maps, h, w, c), pts, idx, 10.0, 10.0)
+    few = (got != again).any(dim=3).float().mean().item()                 # index-ordered sums: only cells with > 64 points
+    assert few <= 0.05 and (got - again).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())   # (border clamp targets) may reorder
+    got16 = native.bilinear_gather_backward_sorted(go.to(torch.bfloat16), (n_maps, h, w, c), pts, idx, 10.0, 10.0, out_dtype=torch.bfloat16)
+    ref16 = native.bilinear_gather_backward_sorted(go.to(torch.bfloat16).float(), (n_maps, h, w, c), pts, idx, 10.0, 10.0)
+    assert got16.dtype == torch.bfloat16 and (got16.float() - ref16).abs().max().item() <= 2 ** -7 * max(1.0, ref16.abs().max().item())
