@@ -109,12 +109,13 @@ int pcacc_segment_max_backward(const float *grad_out, const int32_t *arg, const 
  * pooling (models/pillar_encoder.py:116).  src [n,c] f32, out [m,c] f32, c % 4 == 0, c <= 256. */
 int pcacc_segment_sum(const float *src, int c, const int32_t *seg_offsets, const int32_t *order, int64_t n, int64_t m,
                       float *out, void *workspace, size_t workspace_bytes, void *stream);
-/* The same three with the element type of the rows as a parameter (PCACC_F32 | PCACC_BF16; reductions in f32, results in
- * the rows' type).  bf16 is for the short segments of the pillar encoder (n/m <= 16); long segments return PCACC_E_ARG. */
+/* The same three with the element type of the rows as a parameter (PCACC_F32 | PCACC_BF16; reductions in f32).  Short
+ * segments (n/m <= 16, the pillar encoder): results in the rows' type.  Long segments (the per-instance poolings): rows in
+ * either type, results always f32.  max_backward: grad_out and grad_src types are independent. */
 int pcacc_segment_max_t(const void *src, int dtype, int c, const int32_t *seg_offsets, const int32_t *order, int64_t n,
                         int64_t m, void *out, int32_t *arg, void *workspace, size_t workspace_bytes, void *stream);
 int pcacc_segment_max_backward_t(const void *grad_out, int dtype, const int32_t *arg, const int32_t *p2v, int64_t n, int c,
-                                 void *grad_src, void *stream);
+                                 void *grad_src, int out_dtype, void *stream);
 int pcacc_segment_sum_t(const void *src, int dtype, int c, const int32_t *seg_offsets, const int32_t *order, int64_t n,
                         int64_t m, void *out, void *workspace, size_t workspace_bytes, void *stream);
 

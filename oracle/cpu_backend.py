@@ -70,7 +70,8 @@ def segment_max_backward(grad_out, arg, p2v, n, out_dtype=None):
     seg = p2v.long()
     g = grad_out[seg]
     hit = arg[seg].long() == torch.arange(n)[:, None]
-    return torch.where(hit, g, torch.zeros_like(g))
+    out = torch.where(hit, g, torch.zeros_like(g))
+    return out.to(out_dtype) if out_dtype is not None else out
 
 
 def segment_sum(src, offs, order, m):

@@ -246,7 +246,7 @@ __device__ __forceinline__ int piece_segment(const int *__restrict__ piece_off, 
 }
 
 template <int LPP, bool IS_MAX>
-__global__ __launch_bounds__(256) void seg_level1(const float4 *__restrict__ src, const int32_t *__restrict__ seg_offsets,
+__global__ __launch_bounds__(256) void seg_level1(const void *__restrict__ src, bool src_bf, const int32_t *__restrict__ seg_offsets,
                                                   const int32_t *__restrict__ order, const int *__restrict__ piece_off, int m,
                                                   float4 *__restrict__ pval, int4 *__restrict__ parg)
 {
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void seg_level1(const float4 *__restrict__ src
         int4 bi = make_int4(-1, -1, -1, -1);
         for (int k = b; k < e; ++k) {
             const int i = order[k];
-            const float4 v = src[(int64_t)i * LPP + sub];
+            const float4 v = seg_ld4(src, src_bf, (int64_t)i * LPP + sub);
             if (IS_MAX) {
                 if (bi.x < 0 || v.x > acc.x || (v.x == acc.x && i < bi.x)) { acc.x = v.x; bi.x = i; }
                 if (bi.y < 0 || v.y > acc.y || (v.y == acc.y && i < bi.y)) { acc.y = v.y; bi.y = i; }
@@ -326,7 +326,7 @@ extern "C" int pcacc_segment_workspace_bytes(int64_t n, int64_t m, int c, size_t
 }
 
 template <bool IS_MAX>
-static int seg_two_level(const float *src, int c, const int32_t *seg_offsets, const int32_t *order, int64_t n, int64_t m,
+static int seg_two_level(const void *src, bool src_bf, int c, const int32_t *seg_offsets, const int32_t *order, int64_t n, int64_t m,
                          float *out, int32_t *arg, void *workspace, size_t workspace_bytes, hipStream_t s)
 {
     size_t need;
@@ -339,7 +339,6 @@ static int seg_two_level(const float *src, int c, const int32_t *seg_offsets, co
     const size_t P = (size_t)seg_max_pieces(n, m);
     float4 *pval = reinterpret_cast<float4 *>(ws); ws += pcacc_align(P * c * 4);
     int4 *parg = reinterpret_cast<int4 *>(ws);
-    const float4 *in4 = reinterpret_cast<const float4 *>(src);
     float4 *out4 = reinterpret_cast<float4 *>(out);
     int4 *arg4 = reinterpret_cast<int4 *>(arg);
     const int chunks = pcacc_chunks(m);
@@ -352,7 +351,7 @@ static int seg_two_level(const float *src, int c, const int32_t *seg_offsets, co
         pval = out4;
     }
 #define LAUNCH2(L)                                                                                                   \
-    seg_level1<L, IS_MAX><<<pcacc_grid((int64_t)P * L, 256), 256, 0, s>>>(in4, seg_offsets, order, piece_off, (int)m, pval, parg); \
+    seg_level1<L, IS_MAX><<<pcacc_grid((int64_t)P * L, 256), 256, 0, s>>>(src, src_bf, seg_offsets, order, piece_off, (int)m, pval, parg); \
     if (IS_MAX) seg_level2<L, IS_MAX><<<pcacc_grid(m * L, 256), 256, 0, s>>>(pval, parg, piece_off, m, out4, arg4)
     switch (c / 4) {
         case 1: LAUNCH2(1); break;
@@ -377,9 +376,9 @@ static int segment_max_any(const void *src, int dtype, int c, const int32_t *seg
     if (m == 0) return PCACC_OK;
     hipStream_t s = pcacc_stream(stream);
     if (seg_use_two_level(n, m)) {
-        if (bf) return PCACC_E_ARG;                                  // long segments: f32 rows only
-        const int rc = seg_two_level<true>(reinterpret_cast<const float *>(src), c, seg_offsets, order, n, m,
-                                           reinterpret_cast<float *>(out), arg, workspace, workspace_bytes, s);
+        // long segments: rows in either type, result always f32 (m is small)
+        const int rc = seg_two_level<true>(src, bf, c, seg_offsets, order, n, m, reinterpret_cast<float *>(out), arg, workspace,
+                                           workspace_bytes, s);
         if (rc != PCACC_OK) return rc;
         PCACC_CHECK_LAUNCH();
         return PCACC_OK;
@@ -416,7 +415,7 @@ extern "C" int pcacc_segment_max_t(const void *src, int dtype, int c, const int3
 // grad_src[i,k] = (arg[p2v[i],k] == i) ? grad_out[p2v[i],k] : 0        (fully coalesced, no atomics)
 __global__ __launch_bounds__(256) void seg_max_bwd_kernel(const void *__restrict__ grad_out, const int4 *__restrict__ arg,
                                                           const int32_t *__restrict__ p2v, int64_t n, int lpp,
-                                                          void *__restrict__ grad_src, bool bf)
+                                                          void *__restrict__ grad_src, bool bf, bool out_bf)
 {
     const int64_t total = n * lpp;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
@@ -430,18 +429,19 @@ __global__ __launch_bounds__(256) void seg_max_bwd_kernel(const void *__restrict
         r.y = (a.y == (int)i) ? g.y : 0.f;
         r.z = (a.z == (int)i) ? g.z : 0.f;
         r.w = (a.w == (int)i) ? g.w : 0.f;
-        seg_st4(grad_src, bf, e, r);
+        seg_st4(grad_src, out_bf, e, r);
     }
 }
 
 static int segment_max_backward_any(const void *grad_out, int dtype, const int32_t *arg, const int32_t *p2v, int64_t n, int c,
-                                    void *grad_src, void *stream)
+                                    void *grad_src, int out_dtype, void *stream)
 {
-    if (n < 0 || c <= 0 || (c % 4) || (dtype != PCACC_F32 && dtype != PCACC_BF16)) return PCACC_E_ARG;
+    if (n < 0 || c <= 0 || (c % 4) || (dtype != PCACC_F32 && dtype != PCACC_BF16) || (out_dtype != PCACC_F32 && out_dtype != PCACC_BF16))
+        return PCACC_E_ARG;
     if (n > 0 && (!grad_out || !arg || !p2v || !grad_src)) return PCACC_E_ARG;
     if (n == 0) return PCACC_OK;
     seg_max_bwd_kernel<<<pcacc_grid(n * (c / 4), 256), 256, 0, pcacc_stream(stream)>>>(
-        grad_out, reinterpret_cast<const int4 *>(arg), p2v, n, c / 4, grad_src, dtype == PCACC_BF16);
+        grad_out, reinterpret_cast<const int4 *>(arg), p2v, n, c / 4, grad_src, dtype == PCACC_BF16, out_dtype == PCACC_BF16);
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
 }
@@ -449,13 +449,13 @@ static int segment_max_backward_any(const void *grad_out, int dtype, const int32
 extern "C" int pcacc_segment_max_backward(const float *grad_out, const int32_t *arg, const int32_t *p2v, int64_t n, int c,
                                           float *grad_src, void *stream)
 {
-    return segment_max_backward_any(grad_out, PCACC_F32, arg, p2v, n, c, grad_src, stream);
+    return segment_max_backward_any(grad_out, PCACC_F32, arg, p2v, n, c, grad_src, PCACC_F32, stream);
 }
 
 extern "C" int pcacc_segment_max_backward_t(const void *grad_out, int dtype, const int32_t *arg, const int32_t *p2v, int64_t n,
-                                            int c, void *grad_src, void *stream)
+                                            int c, void *grad_src, int out_dtype, void *stream)
 {
-    return segment_max_backward_any(grad_out, dtype, arg, p2v, n, c, grad_src, stream);
+    return segment_max_backward_any(grad_out, dtype, arg, p2v, n, c, grad_src, out_dtype, stream);
 }
 
 // Backward of the [point_to_voxel_map] broadcast (models/pillar_encoder.py:116): per-pillar sum of point rows.
@@ -485,9 +485,8 @@ static int segment_sum_any(const void *src, int dtype, int c, const int32_t *seg
     if (m == 0) return PCACC_OK;
     hipStream_t s = pcacc_stream(stream);
     if (seg_use_two_level(n, m)) {
-        if (bf) return PCACC_E_ARG;                                  // long segments: f32 rows only
-        const int rc = seg_two_level<false>(reinterpret_cast<const float *>(src), c, seg_offsets, order, n, m,
-                                            reinterpret_cast<float *>(out), nullptr, workspace, workspace_bytes, s);
+        const int rc = seg_two_level<false>(src, bf, c, seg_offsets, order, n, m, reinterpret_cast<float *>(out), nullptr, workspace,
+                                            workspace_bytes, s);
         if (rc != PCACC_OK) return rc;
         PCACC_CHECK_LAUNCH();
         return PCACC_OK;

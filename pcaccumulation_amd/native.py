@@ -168,47 +168,48 @@ def _segment_ws(n, m, c, dev):
     return _ws(need.value, dev)
 
 
-def _seg_dtype(t, n, m):
-    """bf16 rows stay bf16 on the short-segment (one lane group per segment) kernels; long segments are reduced in f32."""
-    if t.dtype == torch.bfloat16 and not (m > 0 and n // m > 16):
-        return torch.bfloat16, BF16
-    return torch.float32, F32
+def _seg_two_level(n, m):
+    return m > 0 and n // m > 16
 
 
 def segment_max(src, offs, order, m):
-    """Per-segment channel-wise max and arg: [m,c] in src's dtype (f32, or bf16 for short segments) and [m,c] i32."""
+    """Per-segment channel-wise max and arg.  Rows f32 or bf16; [m,c] comes back in the rows' type for short segments and in
+    f32 for long ones (two-level reduction), arg [m,c] i32."""
     n, c = src.shape
-    dtype, code = _seg_dtype(src, n, m)
-    src = src if src.dtype == dtype else src.to(dtype)
-    out = torch.empty((m, c), dtype=dtype, device=src.device)
+    if src.dtype not in (torch.float32, torch.bfloat16):
+        src = src.float()
+    out_dtype = torch.float32 if _seg_two_level(n, m) else src.dtype
+    out = torch.empty((m, c), dtype=out_dtype, device=src.device)
     arg = torch.empty((m, c), dtype=torch.int32, device=src.device)
     ws = _segment_ws(n, m, c, src.device)
-    _check(lib().pcacc_segment_max_t(_dev(src, dtype, 'src'), code, int(c), _dev(offs, torch.int32), _dev(order, torch.int32),
+    _check(lib().pcacc_segment_max_t(_dev(src, None, 'src'), _dtype_code(src), int(c), _dev(offs, torch.int32), _dev(order, torch.int32),
                                      _i64(n), _i64(m), _dev(out), _dev(arg), _dev(ws), ctypes.c_size_t(ws.numel()), _stream()),
            'segment_max')
     return out, arg
 
 
 def segment_max_backward(grad_out, arg, p2v, n, out_dtype=None):
-    """grad of segment_max w.r.t. its rows: [n,c] in grad_out's dtype (f32 or bf16)."""
+    """grad of segment_max w.r.t. its rows: [n,c] in out_dtype (default: grad_out's type); both f32 or bf16."""
     c = grad_out.shape[1]
-    dtype = grad_out.dtype if grad_out.dtype in (torch.float32, torch.bfloat16) else torch.float32
-    grad_out = grad_out if grad_out.dtype == dtype else grad_out.to(dtype)
-    g = torch.empty((n, c), dtype=dtype, device=grad_out.device)
-    _check(lib().pcacc_segment_max_backward_t(_dev(grad_out, dtype, 'grad_out'), BF16 if dtype == torch.bfloat16 else F32,
-                                              _dev(arg, torch.int32), _dev(p2v, torch.int32), _i64(n), int(c), _dev(g), _stream()),
+    if grad_out.dtype not in (torch.float32, torch.bfloat16):
+        grad_out = grad_out.float()
+    out_dtype = out_dtype or grad_out.dtype
+    g = torch.empty((n, c), dtype=out_dtype, device=grad_out.device)
+    _check(lib().pcacc_segment_max_backward_t(_dev(grad_out, None, 'grad_out'), _dtype_code(grad_out), _dev(arg, torch.int32),
+                                              _dev(p2v, torch.int32), _i64(n), int(c), _dev(g), _dtype_code(g), _stream()),
            'segment_max_backward')
     return g
 
 
 def segment_sum(src, offs, order, m):
-    """Per-segment sums, [m,c] in src's dtype (f32, or bf16 for short segments; accumulated in f32)."""
+    """Per-segment sums (accumulated in f32): [m,c] in the rows' type for short segments, f32 for long ones."""
     n, c = src.shape
-    dtype, code = _seg_dtype(src, n, m)
-    src = src if src.dtype == dtype else src.to(dtype)
-    out = torch.empty((m, c), dtype=dtype, device=src.device)
+    if src.dtype not in (torch.float32, torch.bfloat16):
+        src = src.float()
+    out_dtype = torch.float32 if _seg_two_level(n, m) else src.dtype
+    out = torch.empty((m, c), dtype=out_dtype, device=src.device)
     ws = _segment_ws(n, m, c, src.device)
-    _check(lib().pcacc_segment_sum_t(_dev(src, dtype, 'src'), code, int(c), _dev(offs, torch.int32), _dev(order, torch.int32),
+    _check(lib().pcacc_segment_sum_t(_dev(src, None, 'src'), _dtype_code(src), int(c), _dev(offs, torch.int32), _dev(order, torch.int32),
                                      _i64(n), _i64(m), _dev(out), _dev(ws), ctypes.c_size_t(ws.numel()), _stream()), 'segment_sum')
     return out
 

@@ -72,7 +72,8 @@ class _SegmentMax(torch.autograd.Function):
     def backward(ctx, grad_out, _grad_arg):
         (arg,) = ctx.saved_tensors
         pidx = ctx.pidx
-        g = native.segment_max_backward(grad_out.contiguous(), arg, pidx.p2v, pidx.n)
+        out_dtype = ctx.src_dtype if ctx.src_dtype in (torch.float32, torch.bfloat16) else torch.float32
+        g = native.segment_max_backward(grad_out.contiguous(), arg, pidx.p2v, pidx.n, out_dtype=out_dtype)
         return (g if g.dtype == ctx.src_dtype else g.to(ctx.src_dtype)), None
 
 
@@ -279,6 +280,9 @@ def scatter(src, index, dim=0, dim_size=None, reduce='sum', plan=None):
     c = x.shape[1]
     if reduce != 'max' and plan.small(c):
         out = _ScatterSumSmall.apply(x.to(torch.float32).contiguous(), plan)          # few rows: LDS-privatised, no CSR
+    elif reduce == 'max' and x.dtype == torch.bfloat16:
+        xp, c = _pad4(x)                                                              # bf16 rows go in as they are (max is exact)
+        out = _SegmentMax.apply(xp, plan)[0]
     else:
         x32, c = _pad4(x.to(torch.float32))
         out = _SegmentMax.apply(x32, plan)[0] if reduce == 'max' else _SegmentSum.apply(x32, plan)

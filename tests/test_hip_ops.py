@@ -682,3 +682,26 @@ def test_bilinear_gather_backward_sorted_matches_atomic():
     got16 = native.bilinear_gather_backward_sorted(go.to(torch.bfloat16), (n_maps, h, w, c), pts, idx, 10.0, 10.0, out_dtype=torch.bfloat16)
     ref16 = native.bilinear_gather_backward_sorted(go.to(torch.bfloat16).float(), (n_maps, h, w, c), pts, idx, 10.0, 10.0)
     assert got16.dtype == torch.bfloat16 and (got16.float() - ref16).abs().max().item() <= 2 ** -7 * max(1.0, ref16.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_two_level_segment_max_bf16_rows():
+    """Long segments (per-instance poolings): bf16 rows reduced to f32 results, identical to the f32-row reduction; backward writes
+    bf16 rows from an f32 gradient."""
+    import numpy as np
+    import torch
+    from pcaccumulation_amd import native, ops
+    dev = torch.device('cuda:0')
+    rng = np.random.RandomState(9)
+    n, m, c = 60000, 40, 128
+    idx = torch.from_numpy(rng.randint(0, m, n).astype(np.int64)).to(dev)
+    x = torch.randn(n, c, device=dev).to(torch.bfloat16).requires_grad_(True)
+    plan = ops.ScatterPlan(idx, m)
+    out = ops.scatter(x, idx, dim=0, dim_size=m, reduce='max', plan=plan)
+    ref = ops.scatter(x.detach().float(), idx, dim=0, dim_size=m, reduce='max', plan=plan)
+    assert torch.equal(out.float(), ref)
+    g = torch.randn(m, c, device=dev)
+    out.float().backward(g)
+    xr = x.detach().float().requires_grad_(True)
+    ops.scatter(xr, idx, dim=0, dim_size=m, reduce='max', plan=ops.ScatterPlan(idx, m)).backward(g)
+    assert x.grad.dtype == torch.bfloat16 and torch.equal(x.grad.float(), xr.grad.to(torch.bfloat16).float())
