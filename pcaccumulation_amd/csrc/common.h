@@ -37,6 +37,31 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f)
     return (uint16_t)(u >> 16);
 }
 
+// two fp32 -> two packed bf16 (round to nearest even) in one instruction: v_cvt_pk_bf16_f32 on gfx950
+typedef __bf16 pcacc_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float pcacc_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pcacc_pack_bf16x2(float lo, float hi)
+{
+    const pcacc_f32x2 f = {lo, hi};
+    const pcacc_bf16x2 r = __builtin_convertvector(f, pcacc_bf16x2);
+    return *reinterpret_cast<const uint32_t *>(&r);
+}
+// the two halves of a packed pair as fp32
+__device__ __forceinline__ float pcacc_bf16_lo(uint32_t v) { return __uint_as_float(v << 16); }
+__device__ __forceinline__ float pcacc_bf16_hi(uint32_t v) { return __uint_as_float(v & 0xffff0000u); }
+// 4 consecutive channels as float4, from f32 or packed-bf16 rows (index in units of 4 elements)
+__device__ __forceinline__ float4 pcacc_ld4(const void *p, bool bf16, int64_t i4)
+{
+    if (!bf16) return reinterpret_cast<const float4 *>(p)[i4];
+    const uint2 v = reinterpret_cast<const uint2 *>(p)[i4];
+    return make_float4(pcacc_bf16_lo(v.x), pcacc_bf16_hi(v.x), pcacc_bf16_lo(v.y), pcacc_bf16_hi(v.y));
+}
+__device__ __forceinline__ void pcacc_st4(void *p, bool bf16, int64_t i4, float4 v)
+{
+    if (!bf16) reinterpret_cast<float4 *>(p)[i4] = v;
+    else reinterpret_cast<uint2 *>(p)[i4] = make_uint2(pcacc_pack_bf16x2(v.x, v.y), pcacc_pack_bf16x2(v.z, v.w));
+}
+
 // ---- wave64 / block scans ------------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 

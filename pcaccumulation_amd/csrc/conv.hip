@@ -15,17 +15,6 @@
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-
-// two fp32 -> packed bf16 (round to nearest even): v_cvt_pk_bf16_f32 on gfx950
-__device__ __forceinline__ uint32_t cv_pack_bf16(float a, float b)
-{
-    const f32x2_t f = {a, b};
-    const bf16x2_t r = __builtin_convertvector(f, bf16x2_t);
-    return *reinterpret_cast<const uint32_t *>(&r);
-}
-
 #define CV_TH 8
 #define CV_TW 32
 #define CV_PW (CV_TW + 2)
@@ -85,8 +74,8 @@ __device__ __forceinline__ void conv_pack_tile(const f32x16_t (&acc)[R][CT], con
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
                 }
-                pk[m][ct][g].x = cv_pack_bf16(v[0], v[1]);
-                pk[m][ct][g].y = cv_pack_bf16(v[2], v[3]);
+                pk[m][ct][g].x = pcacc_pack_bf16x2(v[0], v[1]);
+                pk[m][ct][g].y = pcacc_pack_bf16x2(v[2], v[3]);
             }
 }
 

@@ -29,30 +29,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define MLP_OUTMASK_BF16 8
 #define MLP_Y_BF16 16
 
-typedef __bf16 mlp_bf16x2 __attribute__((ext_vector_type(2)));
-typedef float mlp_f32x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ float4 mlp_ld4(const void *p, bool bf, int64_t i4)
-{
-    if (!bf) return reinterpret_cast<const float4 *>(p)[i4];
-    const uint2 v = reinterpret_cast<const uint2 *>(p)[i4];
-    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
-                       __uint_as_float(v.y & 0xffff0000u));
-}
 __device__ __forceinline__ float mlp_ld1(const void *p, bool bf, int64_t i)
 {
     return bf ? bf16_to_f32(reinterpret_cast<const uint16_t *>(p)[i]) : reinterpret_cast<const float *>(p)[i];
-}
-__device__ __forceinline__ uint32_t mlp_pack2(float a, float b)
-{
-    const mlp_f32x2 f = {a, b};
-    const mlp_bf16x2 r = __builtin_convertvector(f, mlp_bf16x2);
-    return *reinterpret_cast<const uint32_t *>(&r);
-}
-__device__ __forceinline__ void mlp_st4(void *p, bool bf, int64_t i4, float4 v)
-{
-    if (!bf) reinterpret_cast<float4 *>(p)[i4] = v;
-    else reinterpret_cast<uint2 *>(p)[i4] = make_uint2(mlp_pack2(v.x, v.y), mlp_pack2(v.z, v.w));
 }
 __device__ __forceinline__ void mlp_st1(void *p, bool bf, int64_t i, float v)
 {
@@ -83,10 +62,10 @@ __global__ __launch_bounds__(MLP_ROWS) void rows_linear_kernel(const void *__res
             for (int i4 = tid; i4 < MLP_ROWS * K / 4; i4 += MLP_ROWS) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if ((int64_t)i4 * 4 < n_in) {
-                    v = mlp_ld4(X, x_bf, g4 + i4);
+                    v = pcacc_ld4(X, x_bf, g4 + i4);
                     if (flags & MLP_PRE_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     if (in_mask) {
-                        const float4 mk = mlp_ld4(in_mask, im_bf, g4 + i4);
+                        const float4 mk = pcacc_ld4(in_mask, im_bf, g4 + i4);
                         if (!(mk.x > 0.f)) v.x = 0.f;
                         if (!(mk.y > 0.f)) v.y = 0.f;
                         if (!(mk.z > 0.f)) v.z = 0.f;
@@ -156,16 +135,16 @@ __global__ __launch_bounds__(MLP_ROWS) void rows_linear_kernel(const void *__res
             for (int i4 = tid; (int64_t)i4 * 4 < n_out; i4 += MLP_ROWS) {
                 const int e = i4 * 4;
                 float4 v = *reinterpret_cast<const float4 *>(&tile[(e / N) * NS + (e % N)]);
-                if (residual) { const float4 r = mlp_ld4(residual, r_bf, g4 + i4); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+                if (residual) { const float4 r = pcacc_ld4(residual, r_bf, g4 + i4); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
                 if (flags & MLP_POST_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 if (out_mask) {
-                    const float4 mk = mlp_ld4(out_mask, om_bf, g4 + i4);
+                    const float4 mk = pcacc_ld4(out_mask, om_bf, g4 + i4);
                     if (!(mk.x > 0.f)) v.x = 0.f;
                     if (!(mk.y > 0.f)) v.y = 0.f;
                     if (!(mk.z > 0.f)) v.z = 0.f;
                     if (!(mk.w > 0.f)) v.w = 0.f;
                 }
-                mlp_st4(Y, y_bf, g4 + i4, v);
+                pcacc_st4(Y, y_bf, g4 + i4, v);
             }
         } else {
             for (int idx = tid; idx < n_out; idx += MLP_ROWS) {
@@ -271,8 +250,8 @@ __global__ __launch_bounds__(256) void rows_wgrad_kernel(const void *__restrict_
                 const int e = i * 4, r = e / N, c = e % N;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (r < nrow) {
-                    v = mlp_ld4(dY, dy_bf, g4 + i);
-                    if (dy_mask) { const float4 mk = mlp_ld4(dy_mask, m_bf, g4 + i); if (!(mk.x > 0.f)) v.x = 0.f; if (!(mk.y > 0.f)) v.y = 0.f; if (!(mk.z > 0.f)) v.z = 0.f; if (!(mk.w > 0.f)) v.w = 0.f; }
+                    v = pcacc_ld4(dY, dy_bf, g4 + i);
+                    if (dy_mask) { const float4 mk = pcacc_ld4(dy_mask, m_bf, g4 + i); if (!(mk.x > 0.f)) v.x = 0.f; if (!(mk.y > 0.f)) v.y = 0.f; if (!(mk.z > 0.f)) v.z = 0.f; if (!(mk.w > 0.f)) v.w = 0.f; }
                 }
                 *reinterpret_cast<float4 *>(&sdy[r * NS + c]) = v;
             }
@@ -290,7 +269,7 @@ __global__ __launch_bounds__(256) void rows_wgrad_kernel(const void *__restrict_
                 const int e = i * 4, r = e / K, c = e % K;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (r < nrow) {
-                    v = mlp_ld4(X, x_bf, g4 + i);
+                    v = pcacc_ld4(X, x_bf, g4 + i);
                     if (x_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 }
                 *reinterpret_cast<float4 *>(&sx[r * KS + c]) = v;

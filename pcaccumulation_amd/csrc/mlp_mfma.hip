@@ -12,21 +12,12 @@
 #include "common.h"
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
 #define MM_TILE 128
 #define MM_THREADS 256
 #define MM_PRE_RELU 1
 #define MM_POST_RELU 2
-
-__device__ __forceinline__ uint32_t mm_pack_bf16(float a, float b)
-{
-    const f32x2_t f = {a, b};
-    const bf16x2_t r = __builtin_convertvector(f, bf16x2_t);
-    return *reinterpret_cast<const uint32_t *>(&r);
-}
 
 // max(x, 0) on two packed bf16: clear the halves whose sign bit is set
 __device__ __forceinline__ uint32_t mm_relu2(uint32_t v)
@@ -50,8 +41,6 @@ __device__ __forceinline__ uint4 mm_mask8(uint4 v, uint4 m)
     return make_uint4(mm_mask2(v.x, m.x), mm_mask2(v.y, m.y), mm_mask2(v.z, m.z), mm_mask2(v.w, m.w));
 }
 
-__device__ __forceinline__ float mm_lo(uint32_t v) { return __uint_as_float(v << 16); }
-__device__ __forceinline__ float mm_hi(uint32_t v) { return __uint_as_float(v & 0xffff0000u); }
 
 template <int K, int CT>
 __global__ __launch_bounds__(MM_THREADS) void rows_linear_bf16_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ in_mask,
@@ -78,7 +67,7 @@ __global__ __launch_bounds__(MM_THREADS) void rows_linear_bf16_kernel(const uint
     for (int e = threadIdx.x; e < N * K / 2; e += MM_THREADS) {               // weights: fp32 pairs -> packed bf16
         const int n = (2 * e) / K, k = (2 * e) % K;
         const float2 w2 = *reinterpret_cast<const float2 *>(W + (int64_t)n * K + k);
-        *reinterpret_cast<uint32_t *>(ws + n * XS + k) = mm_pack_bf16(w2.x, w2.y);
+        *reinterpret_cast<uint32_t *>(ws + n * XS + k) = pcacc_pack_bf16x2(w2.x, w2.y);
     }
     if (threadIdx.x < N) bias_l[threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
 
@@ -140,8 +129,8 @@ __global__ __launch_bounds__(MM_THREADS) void rows_linear_bf16_kernel(const uint
                 const int c = ct * 32 + 8 * g + 4 * lh;
                 const float4 bv = *reinterpret_cast<const float4 *>(bias_l + c);
                 uint2 pk;
-                pk.x = mm_pack_bf16(acc[ct][4 * g] + bv.x, acc[ct][4 * g + 1] + bv.y);
-                pk.y = mm_pack_bf16(acc[ct][4 * g + 2] + bv.z, acc[ct][4 * g + 3] + bv.w);
+                pk.x = pcacc_pack_bf16x2(acc[ct][4 * g] + bv.x, acc[ct][4 * g + 1] + bv.y);
+                pk.y = pcacc_pack_bf16x2(acc[ct][4 * g + 2] + bv.z, acc[ct][4 * g + 3] + bv.w);
                 *reinterpret_cast<uint2 *>(yrow + c) = pk;
             }
         __syncthreads();
@@ -154,10 +143,10 @@ __global__ __launch_bounds__(MM_THREADS) void rows_linear_bf16_kernel(const uint
             uint4 v = *reinterpret_cast<const uint4 *>(xs + (c / (N / 8)) * YS + (c % (N / 8)) * 8);
             if (residual) {
                 const uint4 r = *reinterpret_cast<const uint4 *>(residual + e);
-                v.x = mm_pack_bf16(mm_lo(v.x) + mm_lo(r.x), mm_hi(v.x) + mm_hi(r.x));
-                v.y = mm_pack_bf16(mm_lo(v.y) + mm_lo(r.y), mm_hi(v.y) + mm_hi(r.y));
-                v.z = mm_pack_bf16(mm_lo(v.z) + mm_lo(r.z), mm_hi(v.z) + mm_hi(r.z));
-                v.w = mm_pack_bf16(mm_lo(v.w) + mm_lo(r.w), mm_hi(v.w) + mm_hi(r.w));
+                v.x = pcacc_pack_bf16x2(pcacc_bf16_lo(v.x) + pcacc_bf16_lo(r.x), pcacc_bf16_hi(v.x) + pcacc_bf16_hi(r.x));
+                v.y = pcacc_pack_bf16x2(pcacc_bf16_lo(v.y) + pcacc_bf16_lo(r.y), pcacc_bf16_hi(v.y) + pcacc_bf16_hi(r.y));
+                v.z = pcacc_pack_bf16x2(pcacc_bf16_lo(v.z) + pcacc_bf16_lo(r.z), pcacc_bf16_hi(v.z) + pcacc_bf16_hi(r.z));
+                v.w = pcacc_pack_bf16x2(pcacc_bf16_lo(v.w) + pcacc_bf16_lo(r.w), pcacc_bf16_hi(v.w) + pcacc_bf16_hi(r.w));
             }
             if (flags & MM_POST_RELU) v = mm_relu8(v);
             if (out_mask) v = mm_mask8(v, *reinterpret_cast<const uint4 *>(out_mask + e));

@@ -7,23 +7,6 @@
 // segmented loop: pillars have ~3 points on average (models/motionnet.py:142).
 #include "scan.h"
 
-// rows of 4 channels as float4 (f32) or 4 packed bf16 (8 bytes); the arithmetic is fp32 either way
-typedef __bf16 seg_bf16x2 __attribute__((ext_vector_type(2)));
-typedef float seg_f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float4 seg_ld4(const void *p, bool bf, int64_t i4)
-{
-    if (!bf) return reinterpret_cast<const float4 *>(p)[i4];
-    const uint2 v = reinterpret_cast<const uint2 *>(p)[i4];
-    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
-                       __uint_as_float(v.y & 0xffff0000u));
-}
-__device__ __forceinline__ void seg_st4(void *p, bool bf, int64_t i4, float4 v)
-{
-    if (!bf) { reinterpret_cast<float4 *>(p)[i4] = v; return; }
-    const seg_f32x2 a = {v.x, v.y}, b = {v.z, v.w};
-    const seg_bf16x2 ra = __builtin_convertvector(a, seg_bf16x2), rb = __builtin_convertvector(b, seg_bf16x2);
-    reinterpret_cast<uint2 *>(p)[i4] = make_uint2(*reinterpret_cast<const uint32_t *>(&ra), *reinterpret_cast<const uint32_t *>(&rb));
-}
 
 #define CSR_SORT_MAX 64      // pillars with more points keep the (arbitrary) cursor order
 
@@ -205,7 +188,7 @@ __global__ __launch_bounds__(256) void seg_max_kernel(const void *__restrict__ s
         int4 bi = make_int4(-1, -1, -1, -1);
         for (int k = b; k < e; ++k) {
             const int i = order[k];
-            const float4 v = seg_ld4(src, bf, (int64_t)i * LPP + sub);
+            const float4 v = pcacc_ld4(src, bf, (int64_t)i * LPP + sub);
             // strict '>' in ascending index order, but the lowest INDEX must win even when the cursor
             // order of a >64-point pillar is not sorted: tie-break on the index explicitly.
             if (bi.x < 0 || v.x > best.x || (v.x == best.x && i < bi.x)) { best.x = v.x; bi.x = i; }
@@ -213,7 +196,7 @@ __global__ __launch_bounds__(256) void seg_max_kernel(const void *__restrict__ s
             if (bi.z < 0 || v.z > best.z || (v.z == best.z && i < bi.z)) { best.z = v.z; bi.z = i; }
             if (bi.w < 0 || v.w > best.w || (v.w == best.w && i < bi.w)) { best.w = v.w; bi.w = i; }
         }
-        seg_st4(out, bf, s * LPP + sub, best);
+        pcacc_st4(out, bf, s * LPP + sub, best);
         arg[s * LPP + sub] = bi;
     }
 }
@@ -261,7 +244,7 @@ __global__ __launch_bounds__(256) void seg_level1(const void *__restrict__ src, 
         int4 bi = make_int4(-1, -1, -1, -1);
         for (int k = b; k < e; ++k) {
             const int i = order[k];
-            const float4 v = seg_ld4(src, src_bf, (int64_t)i * LPP + sub);
+            const float4 v = pcacc_ld4(src, src_bf, (int64_t)i * LPP + sub);
             if (IS_MAX) {
                 if (bi.x < 0 || v.x > acc.x || (v.x == acc.x && i < bi.x)) { acc.x = v.x; bi.x = i; }
                 if (bi.y < 0 || v.y > acc.y || (v.y == acc.y && i < bi.y)) { acc.y = v.y; bi.y = i; }
@@ -423,13 +406,13 @@ __global__ __launch_bounds__(256) void seg_max_bwd_kernel(const void *__restrict
         const int sub = (int)(e - i * lpp);
         const int64_t s = p2v[i];
         const int4 a = arg[s * lpp + sub];
-        const float4 g = seg_ld4(grad_out, bf, s * lpp + sub);
+        const float4 g = pcacc_ld4(grad_out, bf, s * lpp + sub);
         float4 r;
         r.x = (a.x == (int)i) ? g.x : 0.f;
         r.y = (a.y == (int)i) ? g.y : 0.f;
         r.z = (a.z == (int)i) ? g.z : 0.f;
         r.w = (a.w == (int)i) ? g.w : 0.f;
-        seg_st4(grad_src, out_bf, e, r);
+        pcacc_st4(grad_src, out_bf, e, r);
     }
 }
 
@@ -469,10 +452,10 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const void *__restrict__ s
         const int b = seg_offsets[s], e = seg_offsets[s + 1];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int k = b; k < e; ++k) {
-            const float4 v = seg_ld4(src, bf, (int64_t)order[k] * LPP + sub);
+            const float4 v = pcacc_ld4(src, bf, (int64_t)order[k] * LPP + sub);
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
-        seg_st4(out, bf, s * LPP + sub, acc);
+        pcacc_st4(out, bf, s * LPP + sub, acc);
     }
 }
 
