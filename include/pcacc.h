@@ -314,6 +314,19 @@ int pcacc_conv3x3_wgrad_bf16(const uint16_t *dy, const uint16_t *x, float *dw, i
                              int32_t h, int32_t w, int32_t c_in, int32_t c_out, void *workspace, size_t workspace_bytes,
                              void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * D1. Data step in front of the path -- libs/dataset.py:147-182 (BaseDataset.prep_input before the voxeliser),
+ * :93-104 (apply_data_augmentation), toolbox/register_utils.py:199-206 (apply_tsfm).  One pass over the raw points:
+ *   points [m,3] f64;  tsfm12 [12] f64 on the device = 3x3 rotation (row-major) then translation, or NULL;
+ *   noise [m,3] f64 uniform(0,1) draws or NULL (added as (u - 0.5) * noise_scale);  scale: global factor applied when
+ *   tsfm12 or noise is given;  crop_xy, z_min, z_max: crop box;  remove_ground / ground_z: keep only z > ground_z;
+ *   out_points [m,3] f64: augmented points;  keep [m] u8: 1 where the point passes crop (and ground) tests.
+ * The kept rows are compacted by the caller (stable order); libs/dataset.py:166-181.
+ * ---------------------------------------------------------------------------------------------- */
+int pcacc_prep_points(const double *points, const double *tsfm12, const double *noise, double noise_scale, double scale,
+                      double crop_xy, double z_min, double z_max, int32_t remove_ground, double ground_z, int64_t m,
+                      double *out_points, uint8_t *keep, void *stream);
+
 /* Host words -> device memory as kernel arguments (asynchronous, unlike a pageable hipMemcpy on the compute stream):
  * n 32-bit words from host_words to dst, 240 per launch.  For the per-step index tables a host loop of the reference
  * becomes (sample offsets, per-pair counts, thresholds). */

@@ -558,3 +558,49 @@ def cluster_forward(points, mos, offset, time_indice, eps, min_samples, min_p_cl
             out.append(cluster_per_batch(np.asarray(mos)[s], np.asarray(offset)[s], np.asarray(points)[s], eps,
                                          min_samples, min_p_cluster, use_offset, estimator))
     return np.concatenate(out).astype(np.int64)
+
+
+# ------------------------------------------------------------------------------------------------
+# D1  host data step in front of the path  (libs/dataset.py:93-204: BaseDataset.prep_input)
+# Random numbers come from numpy's global generator in the reference's order (seed it with np.random.seed).
+# ------------------------------------------------------------------------------------------------
+def sample_random_tsfm(rot_aug, shift_range):
+    """libs/dataset.py:106-116: rotation about z by U(0, pi*rot_aug), shift U(-r, r) in x and y."""
+    from scipy.spatial.transform import Rotation
+    euler = [0, 0, np.random.uniform(0, np.pi * rot_aug)]
+    rot = Rotation.from_euler('xyz', euler).as_matrix()
+    shift = [np.random.uniform(-shift_range, shift_range), np.random.uniform(-shift_range, shift_range), 0]
+    tsfm = np.eye(4)
+    tsfm[:3, :3] = rot
+    tsfm[:3, 3] = np.array(shift)
+    return tsfm
+
+
+def update_transformation_after_data_augmentation(aug_tsfm, ego_motion, inst_motion, n_frames):
+    """libs/dataset.py:118-139: T' @ T @ T'^-1 for the ego poses and the instance motions."""
+    a = aug_tsfm[None].repeat(n_frames, 0)
+    ego = a @ ego_motion @ np.linalg.inv(a)
+    im = inst_motion.reshape(-1, 4, 4)
+    a = aug_tsfm[None].repeat(im.shape[0], 0)
+    im = (a @ im @ np.linalg.inv(a)).reshape(-1, n_frames, 4, 4)
+    return ego, im
+
+
+def prep_points(raw_points, sd_labels, fb_labels, inst_labels, time_indice, ego_motion_gt, inst_motion_gt, p, augmentation=True):
+    """libs/dataset.py:147-182 (everything of prep_input before the voxeliser).  p: dict with augment_noise, augment_shift_range,
+    augment_scale_min, augment_scale_max, rot_aug, crop_xy, crop_z_min, crop_z_max, remove_ground, ground_height (+slack), n_frames."""
+    pts = np.asarray(raw_points).copy()
+    if augmentation:
+        tsfm = sample_random_tsfm(p['rot_aug'], p['augment_shift_range'])
+        pts = (tsfm[:3, :3] @ pts.T + tsfm[:3, 3][:, None]).T                                   # apply_tsfm, register_utils.py:199-206
+        pts += (np.random.rand(pts.shape[0], 3) - 0.5) * p['augment_noise']
+        pts = pts * np.random.uniform(p['augment_scale_min'], p['augment_scale_max'])
+        ego_motion_gt, inst_motion_gt = update_transformation_after_data_augmentation(tsfm, ego_motion_gt, inst_motion_gt, p['n_frames'])
+    keep = (np.abs(pts[:, 0]) < p['crop_xy']) & (np.abs(pts[:, 1]) < p['crop_xy']) & (pts[:, 2] < p['crop_z_max']) & (pts[:, 2] > p['crop_z_min'])
+    pts, time_indice, sd_labels, fb_labels, inst_labels = (a[keep] for a in (pts, time_indice, sd_labels, fb_labels, inst_labels))
+    if p['remove_ground']:
+        up = pts[:, 2] > p['ground_height']
+        pts, time_indice, sd_labels, fb_labels, inst_labels = (a[up] for a in (pts, time_indice, sd_labels, fb_labels, inst_labels))
+    return {'input_points': pts, 'num_points': np.array([pts.shape[0]], dtype=np.int64), 'time_indice': time_indice[:, None],
+            'sd_labels': sd_labels[:, None], 'inst_labels': inst_labels[:, None], 'ego_motion_gt': ego_motion_gt,
+            'inst_motion_gt': inst_motion_gt, 'fb_labels': fb_labels[:, None]}

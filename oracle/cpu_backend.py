@@ -221,7 +221,7 @@ def cluster(points, offset, sel, batch, n_batches, voxel_size, eps, min_samples,
 NAMES = ['voxelize', 'cell_index', 'frame_pillars', 'csr_build', 'segment_mean3_maxlabel', 'segment_max',
          'segment_max_backward', 'segment_sum', 'pillar_scatter', 'gather_rows', 'bilinear_gather',
          'bilinear_gather_backward', 'bev_warp', 'rigid_transform', 'chamfer_forward', 'chamfer_backward',
-         'rows_linear', 'rows_wgrad', 'rows_linear_supported', 'pfn_features', 'scatter_sum_small', 'sinkhorn_kabsch', 'cluster', 'sample_subsets', 'upload_small', 'bilinear_gather_backward_sorted']
+         'rows_linear', 'rows_wgrad', 'rows_linear_supported', 'pfn_features', 'scatter_sum_small', 'sinkhorn_kabsch', 'cluster', 'sample_subsets', 'upload_small', 'bilinear_gather_backward_sorted', 'prep_points']
 
 
 def install(monkeypatch=None):
@@ -253,3 +253,18 @@ def upload_small(values, dtype, device):
 
 def bilinear_gather_backward_sorted(grad_out, shape, points, map_idx, x_scale, y_scale, out_dtype=torch.float32):
     return bilinear_gather_backward(grad_out.float(), shape, points, map_idx, x_scale, y_scale).to(out_dtype)
+
+
+def prep_points(points, tsfm12, noise, noise_scale, scale, crop_xy, z_min, z_max, remove_ground, ground_z):
+    p = points.double().numpy().copy()
+    if tsfm12 is not None:
+        t = tsfm12.double().numpy()
+        p = (t[:9].reshape(3, 3) @ p.T + t[9:][:, None]).T
+    if noise is not None:
+        p = p + (noise.double().numpy() - 0.5) * noise_scale
+    if tsfm12 is not None or noise is not None:
+        p = p * scale
+    keep = (np.abs(p[:, 0]) < crop_xy) & (np.abs(p[:, 1]) < crop_xy) & (p[:, 2] < z_max) & (p[:, 2] > z_min)
+    if remove_ground:
+        keep &= p[:, 2] > ground_z
+    return torch.from_numpy(np.ascontiguousarray(p)), torch.from_numpy(keep.astype(np.uint8))

@@ -11,6 +11,8 @@ import copy
 _COMMON = {
     'misc': {'mode': 'val', 'use_gpu': True, 'seed': 42},
     'data': {'max_speed': 20, 'speed_threshold': 0.5, 'ground_slack': 0.3, 'remove_ground': True},
+    'data_aug': {'augment_noise': 0.01, 'augment_shift_range': 0.25, 'augment_scale_min': 0.995, 'augment_scale_max': 1.005,
+                 'rot_aug': 0.5},                                       # configs/default.yaml:44-49
     'cluster': {'cluster_metric': 'euclidean', 'min_p_cluster': 15, 'min_samples_dbscan': 5,
                 'eps_dbscan': 0.4, 'voxel_size': 0.15},
     'pillar_encoder': {'depth': 3, 'num_input_features': 9, 'num_filters': 32},

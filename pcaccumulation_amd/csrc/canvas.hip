@@ -265,3 +265,51 @@ extern "C" int pcacc_upload_words(const uint32_t *host_words, int64_t n, uint32_
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// D1. Host data step in front of the path, on the device (libs/dataset.py:147-182, BaseDataset.prep_input before the
+// voxeliser): augmentation of the raw points (rigid transform about z, uniform noise, global scale) fused with the crop /
+// ground tests into one pass; the caller compacts the kept rows.  float64 like the numpy code it replaces:
+//   p = (R p + t);  p += (u - 0.5) * noise;  p *= scale;
+//   keep = |x| < crop_xy && |y| < crop_xy && z_min < z < z_max && (!remove_ground || z > ground_z)
+// The 3-term products run as an FMA chain (the accumulation order of a K = 3 dgemm), everything else un-fused.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prep_points_kernel(const double *__restrict__ pts, const double *__restrict__ tsfm,
+                                                          const double *__restrict__ noise, double noise_scale, double scale,
+                                                          double crop_xy, double z_min, double z_max, int remove_ground, double ground_z,
+                                                          int64_t m, double *__restrict__ out, uint8_t *__restrict__ keep)
+{
+#pragma clang fp contract(off)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (int64_t)gridDim.x * 256) {
+        double x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+        if (tsfm) {
+            const double nx = fma(tsfm[2], z, fma(tsfm[1], y, tsfm[0] * x)) + tsfm[9];
+            const double ny = fma(tsfm[5], z, fma(tsfm[4], y, tsfm[3] * x)) + tsfm[10];
+            const double nz = fma(tsfm[8], z, fma(tsfm[7], y, tsfm[6] * x)) + tsfm[11];
+            x = nx; y = ny; z = nz;
+        }
+        if (noise) {
+            x = x + (noise[3 * i] - 0.5) * noise_scale;
+            y = y + (noise[3 * i + 1] - 0.5) * noise_scale;
+            z = z + (noise[3 * i + 2] - 0.5) * noise_scale;
+        }
+        if (tsfm || noise) { x = x * scale; y = y * scale; z = z * scale; }
+        out[3 * i] = x; out[3 * i + 1] = y; out[3 * i + 2] = z;
+        bool k = fabs(x) < crop_xy && fabs(y) < crop_xy && z < z_max && z > z_min;
+        if (remove_ground) k = k && z > ground_z;
+        keep[i] = k ? 1 : 0;
+    }
+}
+
+extern "C" int pcacc_prep_points(const double *points, const double *tsfm12, const double *noise, double noise_scale, double scale,
+                                 double crop_xy, double z_min, double z_max, int32_t remove_ground, double ground_z, int64_t m,
+                                 double *out_points, uint8_t *keep, void *stream)
+{
+    if (m < 0) return PCACC_E_ARG;
+    if (m == 0) return PCACC_OK;
+    if (!points || !out_points || !keep) return PCACC_E_ARG;
+    prep_points_kernel<<<pcacc_grid(m, 256), 256, 0, pcacc_stream(stream)>>>(points, tsfm12, noise, noise_scale, scale, crop_xy, z_min,
+                                                                            z_max, remove_ground, ground_z, m, out_points, keep);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}

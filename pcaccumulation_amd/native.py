@@ -48,7 +48,7 @@ EXPORTS = [
     'pcacc_sinkhorn_kabsch_workspace_bytes', 'pcacc_sinkhorn_kabsch', 'pcacc_chamfer_workspace_bytes', 'pcacc_chamfer_forward', 'pcacc_chamfer_backward',
     'pcacc_cluster_workspace_bytes', 'pcacc_cluster', 'pcacc_conv3x3_prepare_weights', 'pcacc_conv3x3_bf16',
     'pcacc_rows_linear_bf16', 'pcacc_rows_linear_mixed', 'pcacc_rows_wgrad_mixed',
-    'pcacc_segment_max_t', 'pcacc_segment_max_backward_t', 'pcacc_segment_sum_t', 'pcacc_rows_wgrad_bf16_workspace_bytes', 'pcacc_rows_wgrad_bf16', 'pcacc_sample_subsets', 'pcacc_conv3x3_wgrad_workspace_bytes', 'pcacc_conv3x3_wgrad_bf16', 'pcacc_upload_words', 'pcacc_bilinear_base_cells', 'pcacc_bilinear_gather_backward_sorted',
+    'pcacc_segment_max_t', 'pcacc_segment_max_backward_t', 'pcacc_segment_sum_t', 'pcacc_rows_wgrad_bf16_workspace_bytes', 'pcacc_rows_wgrad_bf16', 'pcacc_sample_subsets', 'pcacc_conv3x3_wgrad_workspace_bytes', 'pcacc_conv3x3_wgrad_bf16', 'pcacc_upload_words', 'pcacc_bilinear_base_cells', 'pcacc_bilinear_gather_backward_sorted', 'pcacc_prep_points',
 ]
 
 
@@ -530,3 +530,16 @@ def bilinear_gather_backward_sorted(grad_out, shape, points, map_idx, x_scale, y
                                                        _dev(order, torch.int32), ctypes.c_float(x_scale), ctypes.c_float(y_scale),
                                                        _dev(out), _dtype_code(out), _stream()), 'bilinear_gather_backward_sorted')
     return out
+
+
+def prep_points(points, tsfm12, noise, noise_scale, scale, crop_xy, z_min, z_max, remove_ground, ground_z):
+    """points [m,3] f64 -> (augmented points [m,3] f64, keep [m] u8); see include/pcacc.h (D1)."""
+    m = points.shape[0]
+    out = torch.empty_like(points)
+    keep = torch.empty((m,), dtype=torch.uint8, device=points.device)
+    _check(lib().pcacc_prep_points(_dev(points, torch.float64, 'points'), _dev(tsfm12, torch.float64, 'tsfm12') if tsfm12 is not None else None,
+                                   _dev(noise, torch.float64, 'noise') if noise is not None else None, ctypes.c_double(noise_scale),
+                                   ctypes.c_double(scale), ctypes.c_double(crop_xy), ctypes.c_double(z_min), ctypes.c_double(z_max),
+                                   1 if remove_ground else 0, ctypes.c_double(ground_z), _i64(m), _dev(out), _dev(keep), _stream()),
+           'prep_points')
+    return out, keep

@@ -42,3 +42,18 @@ def vox_points(seed, n, cfg, frac_out=0.1):
     p[edge[16:24], 1] = lo[1] + 0.25 * rng.randint(0, int(span[1] / 0.25), 8)
     p[edge[24:], 2] = hi[2]
     return np.concatenate([p, t[:, None]], axis=1).astype(np.float32)
+
+
+def raw_sample(seed, n_frames, ppf, cfg):
+    """A raw sample as BaseDataset.__getitem__ reads it from disk (libs/dataset.py:206-214): float64 points with some beyond
+    the crop box, below the ground threshold and above crop_z_max; per-point labels and frame index as 1-D arrays."""
+    import numpy as np
+    from pcaccumulation_amd.synthetic import make_sequence
+    s = make_sequence(seed, n_frames, ppf, cfg)
+    pts = s['input_points'].astype(np.float64)
+    pts[::7] *= 1.6
+    pts[::5, 2] -= 1.0
+    pts[3::11, 2] += 9.0
+    return {'raw_points': pts, 'time_indice': s['time_indice'][:, 0].astype(np.float64), 'sd_labels': s['sd_labels'][:, 0],
+            'fb_labels': s['fb_labels'][:, 0], 'inst_labels': s['inst_labels'][:, 0], 'ego_motion_gt': s['ego_motion_gt'].astype(np.float64),
+            'inst_motion_gt': s['inst_motion_gt'].astype(np.float64)}
