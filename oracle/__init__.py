@@ -604,3 +604,27 @@ def prep_points(raw_points, sd_labels, fb_labels, inst_labels, time_indice, ego_
     return {'input_points': pts, 'num_points': np.array([pts.shape[0]], dtype=np.int64), 'time_indice': time_indice[:, None],
             'sd_labels': sd_labels[:, None], 'inst_labels': inst_labels[:, None], 'ego_motion_gt': ego_motion_gt,
             'inst_motion_gt': inst_motion_gt, 'fb_labels': fb_labels[:, None]}
+
+
+# ------------------------------------------------------------------------------------------------
+# E1  scene-flow evaluation  (libs/tester.py:58-83; toolbox/sf_eval_utils.py:51-86)
+# ------------------------------------------------------------------------------------------------
+def flow_errors(rec_est, input_points, time_indice, ego_motion_gt, inst_labels, inst_motion_gt, n_frames):
+    """libs/tester.py:58-83: (epe_per_point, relative_error) of the points with t > 0, float32 throughout (the tester's matmul
+    with ego_motion_gt.float() only type-checks for float32 points)."""
+    x = np.asarray(input_points, np.float32)
+    t = np.asarray(time_indice).astype(np.int64)
+    comp = ego_motion_compensation(x, t, np.asarray(ego_motion_gt, np.float32)).astype(np.float32)
+    gt = reconstruct_sequence(comp, t, inst_labels, np.asarray(inst_motion_gt, np.float32), n_frames).astype(np.float32)
+    est_flow, gt_flow = np.asarray(rec_est, np.float32) - x, gt - x
+    epe = np.linalg.norm(est_flow - gt_flow, axis=1)
+    rel = epe / (np.linalg.norm(gt_flow, axis=1) + 1e-20)
+    return epe[t > 0], rel[t > 0]
+
+
+def compute_sf_metrics(epe, rel):
+    """toolbox/sf_eval_utils.py:71-86 (compute_sf_metrics_torch; its numpy twin :51-69 differs only in the median of an even
+    count: np.median averages the two middle values, torch.median returns the lower one)."""
+    return {'EPE3D': float(epe.mean()), 'EPE3D_med': float(np.sort(epe)[(epe.shape[0] - 1) // 2]),
+            'Acc3DS': float(np.logical_or(epe < 0.05, rel < 0.05).mean()), 'Acc3DR': float(np.logical_or(epe < 0.1, rel < 0.1).mean()),
+            'Outlier': float(np.logical_or(epe > 0.3, rel > 0.1).mean()), 'ROutlier': float(np.logical_and(epe > 0.3, rel > 0.3).mean())}
