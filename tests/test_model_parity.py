@@ -314,3 +314,29 @@ def test_dropin_import_paths():
         for name in ('models', 'models.motionnet', 'models.pillar_encoder', 'models.cluster', 'libs', 'libs.voxel_generator',
                      'chamfer_distance', 'chamfer_distance.chamfer_distance'):
             sys.modules.pop(name, None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('compute_dtype', ['fp32', 'bf16'])
+def test_gpu_nuscene_geometry_train_step(compute_dtype):
+    """nuScenes configuration (11 sweeps, configs/nuscene/nuscene.yaml) through the whole path: 3x3x3 stack over 11 frames, 10
+    registration pairs per sample, both compute modes.  No golden vectors for this geometry: shapes and finiteness only."""
+    dev = torch.device('cuda:0')
+    cfg = default_config('nuscene', 'train', xy_range=12)
+    cfg['misc']['compute_dtype'] = compute_dtype
+    T = cfg['voxel_generator']['n_sweeps']
+    # 3000 points per frame: with much sparser frames a registration pair can end up with no supported correspondence at all, and
+    # the SVD of its zero covariance has no gradient -- in the reference too (its training loop skips such steps)
+    inp = _to(make_batch(cfg, [3, 4], T, 3000), dev)
+    torch.manual_seed(0)
+    model = MotionNet(cfg)
+    fill_state_dict_(model)
+    model = model.to(dev).train()
+    model.channels_last_()
+    out = model(inp)
+    stats = FuseLoss(cfg['loss'])(out, inp)
+    stats['loss'].backward()
+    assert out['ego_motion_est'].shape == (2, T, 4, 4) and out['fb_seg_est'].shape[:3] == (2, T, 2)
+    assert out['rec_est'].shape == inp['input_points'].shape and torch.isfinite(out['rec_est']).all()
+    assert torch.isfinite(stats['loss'].detach())
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
