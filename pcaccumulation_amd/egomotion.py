@@ -248,25 +248,27 @@ class EgoMotionHead(nn.Module):
         dev = pose_est.device
         P = pose_est.shape[0]
         identity = torch.eye(4, device=dev)
+        # T_anchor^-1 @ T_ref, T_(t-1)^-1 @ T_t for the GT and for the estimated chain, all samples in three batched solves
+        # (get_relative_pose_torch, register_utils.py:184-197; the reference solves per sample)
+        B = len(sequences)
+        gt_all = torch.stack([seq[3] for seq in sequences])                                     # [B,T,4,4]
+        pose_gt_all = get_relative_pose_torch(gt_all[:, 1:], gt_all[:, 0:1].expand(B, T - 1, 4, 4), self.dataset)
+        rel_gt_all = get_relative_pose_torch(gt_all[:, 1:], gt_all[:, :-1], self.dataset)
+        chain = torch.cat((identity.expand(B, 1, 4, 4), pose_est.view(B, T - 1, 4, 4)), dim=1)
+        rel_est_all = get_relative_pose_torch(chain[:, 1:], chain[:, :-1], self.dataset)
         p = 0
-        gt_rows, ref_pts, lens = [], [], []
-        for points_list, feats_list, bg_list, gt in sequences:
+        ref_pts, lens = [], []
+        for b, (points_list, feats_list, bg_list, gt) in enumerate(sequences):
             for lst in (relative_pose_est_list, relative_pose_gt_list, chained_pose_est_list, chained_pose_gt_list):
                 lst.append(identity)
-            # T_anchor^-1 @ T_ref for all frames at once (get_relative_pose_torch, register_utils.py:184-197)
-            pose_gt_all = get_relative_pose_torch(gt[1:], gt[0:1].expand(T - 1, 4, 4), self.dataset)
-            rel_gt_all = get_relative_pose_torch(gt[1:], gt[:-1], self.dataset)
-            chain = [identity] + [pose_est[p + i] for i in range(T - 1)]
-            rel_est_all = get_relative_pose_torch(torch.stack(chain[1:]), torch.stack(chain[:-1]), self.dataset)
-            gt_rows.append(pose_gt_all)
             for frame_idx in range(T - 1):
                 ref_pts.append(points_list[frame_idx + 1])
                 lens.append(points_list[frame_idx + 1].shape[0])
                 perm_matrix_list.append(perm[p + frame_idx:p + frame_idx + 1])
                 chained_pose_est_list.append(pose_est[p + frame_idx])
-                chained_pose_gt_list.append(pose_gt_all[frame_idx])
-                relative_pose_gt_list.append(rel_gt_all[frame_idx])
-                relative_pose_est_list.append(rel_est_all[frame_idx])
+                chained_pose_gt_list.append(pose_gt_all[b, frame_idx])
+                relative_pose_gt_list.append(rel_gt_all[b, frame_idx])
+                relative_pose_est_list.append(rel_est_all[b, frame_idx])
             p += T - 1
         # pc_est - pc_gt of every reference pillar under its pair's two poses (models/egomotion.py:342-346), all pairs in one
         # indexed-transform launch: x -> (R_est - R_gt) x + (t_est - t_gt).  The reference's per-pair matmul has a
@@ -274,7 +276,7 @@ class EgoMotionHead(nn.Module):
         # table is a segment sum.
         pts = torch.cat(ref_pts, dim=0)
         pair = torch.repeat_interleave(torch.arange(P, device=dev), native.upload_small(lens, torch.int64, dev), output_size=pts.shape[0])
-        diff = ops.transform_by_index(pts, pair, pose_est - torch.cat(gt_rows, dim=0).to(pose_est.dtype))
+        diff = ops.transform_by_index(pts, pair, pose_est - pose_gt_all.reshape(P, 4, 4).to(pose_est.dtype))
         norms = torch.stack((torch.norm(diff, p=1, dim=1), torch.norm(diff, p=2, dim=1)), dim=1)
         means = ops.scatter(norms, pair, dim=0, dim_size=P, reduce="mean", plan=ops.ScatterPlan(pair, P))
         return means[:, 0].sum(), means[:, 1].sum(), P
