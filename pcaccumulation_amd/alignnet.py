@@ -89,9 +89,11 @@ class AlignNet(BaseModel):
         if extra is not None:                                              # stand-in points live in frame 0
             frames = torch.cat((frames, torch.zeros_like(extra).long()))
             take = torch.cat((take, extra))
-        p_labels, cloud = labels[take], start_points[take]
-        net_in = {'frame_feats': input_dict['backbone_feats'][take], 'time_indice': frames, 'inst_labels': p_labels,
-                  'mos_labels': moving[take], 'mos_feats': input_dict['motion_feats'][take]}
+        # without stand-in points `take` is the identity: no gather (and no index_put in its backward) of the feature rows
+        rows = (lambda x: x) if extra is None else (lambda x: x.index_select(0, take))
+        p_labels, cloud = rows(labels), rows(start_points)
+        net_in = {'frame_feats': rows(input_dict['backbone_feats']), 'time_indice': frames, 'inst_labels': p_labels,
+                  'mos_labels': rows(moving), 'mos_feats': rows(input_dict['motion_feats'])}
 
         results['tpointnet_loss_terms'] = dict()
         total = None

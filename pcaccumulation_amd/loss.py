@@ -137,7 +137,8 @@ class FuseLoss(nn.Module):
         if '_fb_idx' in predictions:                                      # index list MotionNet already built (no re-sync)
             fb_idx = predictions['_fb_idx']
             if fb_idx.numel():
-                return self.get_seg_loss(mos_gt[fb_idx], mos_est[fb_idx])
+                # index_select: its backward is an index_add, not the sort-based accumulate of tensor indexing (0.25 ms each)
+                return self.get_seg_loss(mos_gt[fb_idx], mos_est.index_select(0, fb_idx))
             fb_mask = None
         else:
             fb_mask = torch.logical_or(input_dict['fb_labels'][:, 0] == 1, predictions['fb_est_per_points'][:, 0] == 1)
@@ -153,7 +154,7 @@ class FuseLoss(nn.Module):
         gt = predictions['fb_seg_gt'].permute(0, 1, 3, 4, 2).contiguous().view(-1)
         if '_cell' in predictions:                                        # occupied cells = the pillars' cell indices
             cell = predictions['_cell'].long()
-            return self.get_seg_loss(gt[cell], est[cell])
+            return self.get_seg_loss(gt[cell], est.index_select(0, cell))
         mask = predictions['occ_map'].permute(0, 1, 3, 4, 2).contiguous().view(-1) == 1
         return self.get_seg_loss(gt[mask], est[mask])
 
@@ -187,7 +188,7 @@ class FuseLoss(nn.Module):
         centre = scatter(rec, lab, dim=0, dim_size=sum(sizes), reduce='mean')       # K known on the host: no lab.max() sync
         inst_centers = centre[lab][:, :2]
         gt_offset = (inst_centers - predictions['transformed_points'][:, :2])[fb_mask]
-        est_offset = predictions['offset_est'][fb_mask]
+        est_offset = predictions['offset_est'].index_select(0, fb_mask) if fb_mask.dtype == torch.int64 else predictions['offset_est'][fb_mask]
         offset_norm_loss = torch.abs(gt_offset - est_offset).mean(dim=0).sum()
         offset_l2_error = torch.norm(gt_offset - est_offset, p=2, dim=1).mean()       # float after forward()'s single sync
         ngt = gt_offset / (torch.norm(gt_offset, dim=1, p=2).unsqueeze(-1) + _EPS)
