@@ -243,6 +243,17 @@ int pcacc_sample_subsets(const int32_t *counts, int32_t n_draws, int32_t k, uint
  *   perm [n_pairs,k,k] f32 out;  pose [n_pairs,16] f32 out (row-major 4x4)
  * Used when no gradient is needed (eval / val / test); training keeps the batched torch formulation for autograd.
  * ---------------------------------------------------------------------------------------------- */
+/* Sinkhorn normalisation as a differentiable op (training) -- models/egomotion.py:100-137 with add_slack: the [P,k,k]
+ * log-affinity is padded with a zero slack row / column, n_iters x (row, column) log-sum-exp normalisations that leave the
+ * slack row / column themselves un-normalised, result = the un-padded block.  forward records the subtracted
+ * log-sum-exps (lse_rows, lse_cols [n_iters][P][k]); backward replays the half-steps in reverse from log_alpha and those
+ * vectors.  workspace: one padded [P,k+1,k+1] f32 matrix (pcacc_sinkhorn_train_workspace_bytes). */
+int pcacc_sinkhorn_train_workspace_bytes(int n_pairs, int k, size_t *bytes /*host*/);
+int pcacc_sinkhorn_forward(const float *log_alpha, int n_pairs, int k, int n_iters, float *log_perm, float *lse_rows,
+                           float *lse_cols, void *workspace, size_t workspace_bytes, void *stream);
+int pcacc_sinkhorn_backward(const float *grad_log_perm, const float *log_alpha, const float *lse_rows, const float *lse_cols,
+                            int n_pairs, int k, int n_iters, float *grad_log_alpha, void *workspace, size_t workspace_bytes,
+                            void *stream);
 int pcacc_sinkhorn_kabsch_workspace_bytes(int n_pairs, int k, size_t *bytes /*host*/);
 int pcacc_sinkhorn_kabsch(const float *feats_s, const float *feats_t, const float *coor_s, const float *coor_t,
                           const float *thr2, const float *params, int n_pairs, int k, int c, int n_iters,

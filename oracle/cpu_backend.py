@@ -221,7 +221,7 @@ def cluster(points, offset, sel, batch, n_batches, voxel_size, eps, min_samples,
 NAMES = ['voxelize', 'cell_index', 'frame_pillars', 'csr_build', 'segment_mean3_maxlabel', 'segment_max',
          'segment_max_backward', 'segment_sum', 'pillar_scatter', 'gather_rows', 'bilinear_gather',
          'bilinear_gather_backward', 'bev_warp', 'rigid_transform', 'chamfer_forward', 'chamfer_backward',
-         'rows_linear', 'rows_wgrad', 'rows_linear_supported', 'pfn_features', 'scatter_sum_small', 'sinkhorn_kabsch', 'cluster', 'sample_subsets', 'upload_small', 'bilinear_gather_backward_sorted', 'prep_points']
+         'rows_linear', 'rows_wgrad', 'rows_linear_supported', 'pfn_features', 'scatter_sum_small', 'sinkhorn_kabsch', 'cluster', 'sample_subsets', 'upload_small', 'bilinear_gather_backward_sorted', 'prep_points', 'sinkhorn_forward', 'sinkhorn_backward']
 
 
 def install(monkeypatch=None):
@@ -268,3 +268,23 @@ def prep_points(points, tsfm12, noise, noise_scale, scale, crop_xy, z_min, z_max
     if remove_ground:
         keep &= p[:, 2] > ground_z
     return torch.from_numpy(np.ascontiguousarray(p)), torch.from_numpy(keep.astype(np.uint8))
+
+
+def _sinkhorn_ref(log_alpha, n_iters):
+    la = torch.nn.functional.pad(log_alpha, (0, 1, 0, 1))
+    for _ in range(n_iters):
+        la = torch.cat((la[:, :-1, :] - torch.logsumexp(la[:, :-1, :], dim=2, keepdim=True), la[:, -1, None, :]), dim=1)
+        la = torch.cat((la[:, :, :-1] - torch.logsumexp(la[:, :, :-1], dim=1, keepdim=True), la[:, :, -1, None]), dim=2)
+    return la[:, :-1, :-1]
+
+
+def sinkhorn_forward(log_alpha, n_iters):
+    n = torch.tensor([n_iters])                        # rides along in the slot of the recorded vectors
+    return _sinkhorn_ref(log_alpha.detach(), n_iters), n, n
+
+
+def sinkhorn_backward(grad_log_perm, log_alpha, lse_rows, lse_cols):
+    with torch.enable_grad():
+        x = log_alpha.detach().clone().requires_grad_(True)
+        _sinkhorn_ref(x, int(lse_rows[0])).backward(grad_log_perm)
+    return x.grad

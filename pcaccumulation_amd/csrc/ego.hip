@@ -85,7 +85,7 @@ __device__ __forceinline__ float wave_sum(float v)
 }
 
 // ---- 2a. row normalisation: rows 0..k-1, logsumexp over ALL k+1 columns (egomotion.py:122-126) -----------------------------
-__global__ __launch_bounds__(256) void ego_sinkhorn_rows_kernel(int k, int n_pairs, float *la)
+__global__ __launch_bounds__(256) void ego_sinkhorn_rows_kernel(int k, int n_pairs, float *la, float *lse_out = nullptr)
 {
     const int kp = k + 1;
     const int lane = threadIdx.x & 63;
@@ -100,12 +100,13 @@ __global__ __launch_bounds__(256) void ego_sinkhorn_rows_kernel(int k, int n_pai
         for (int j = lane; j < kp; j += 64) sm += expf(r[j] - mx);
         const float lse = mx + logf(wave_sum(sm));
         for (int j = lane; j < kp; j += 64) r[j] -= lse;
+        if (lse_out && lane == 0) lse_out[row] = lse;            // [n_pairs][k]: what the training backward replays
     }
 }
 
 // ---- 2b. column normalisation: columns 0..k-1, logsumexp over ALL k+1 rows (egomotion.py:128-132) ---------------------------
 // workgroup = 64 columns x 4 row-quarters; partial (max, sum) combined through LDS
-__global__ __launch_bounds__(256) void ego_sinkhorn_cols_kernel(int k, float *la)
+__global__ __launch_bounds__(256) void ego_sinkhorn_cols_kernel(int k, float *la, float *lse_out = nullptr)
 {
     __shared__ float smax[4][64], ssum[4][64];
     const int kp = k + 1;
@@ -132,8 +133,10 @@ __global__ __launch_bounds__(256) void ego_sinkhorn_cols_kernel(int k, float *la
         gs += (pm == -__builtin_inff()) ? 0.f : ssum[u][threadIdx.x & 63] * expf(pm - gm);
     }
     const float lse = gm + logf(gs);
-    if (col < k)
+    if (col < k) {
         for (int i = r_lo; i < r_hi; ++i) m[(int64_t)i * kp + col] -= lse;
+        if (lse_out && q == 0) lse_out[(int64_t)p * k + col] = lse;
+    }
 }
 
 // ---- 3. perm = exp(log_perm) * support; row sums; soft targets (egomotion.py:183-184) -----------------------------------------
@@ -318,6 +321,147 @@ extern "C" int pcacc_sinkhorn_kabsch(const float *feats_s, const float *feats_t,
     }
     ego_rows_finish_kernel<<<row_grid, 256, 0, s>>>(la, coor_s, coor_t, thr2, k, n_pairs, perm, rowsum, wt);
     ego_kabsch_kernel<<<n_pairs, 256, 0, s>>>(coor_s, wt, rowsum, k, pose);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Sinkhorn with a backward pass (training): models/egomotion.py:100-137 as a differentiable op of the [P,k,k] affinity.
+// Forward = the in-place row / column kernels above on the padded matrix, recording the log-sum-exp each half-step
+// subtracts.  Every intermediate matrix is then x0 - U[i] - V[j] (U, V = running sums of those vectors, 0 on the slack
+// row / column), so the backward replays the 2*n_iters half-steps in reverse from x0 and the vectors alone:
+//   y = x - lse(x)  =>  dx = dy - exp(y) * sum(dy)      (per normalised row / column; slack row / column: dx = dy)
+// Two launches per iteration, each reading the gradient matrix and x0 and writing the gradient matrix once -- the torch
+// formulation (pad, 12 slices, 6 logsumexp, 6 cats) keeps a dozen [P,1025,1025] intermediates and makes ~20 passes.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ego_copy_in_kernel(const float *__restrict__ x, int k, int n_pairs, float *__restrict__ la)
+{
+    const int kp = k + 1;
+    const int64_t total = (int64_t)n_pairs * kp * kp;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int j = (int)(e % kp), i = (int)((e / kp) % kp);
+        const int64_t p = e / ((int64_t)kp * kp);
+        la[e] = (i < k && j < k) ? x[(p * k + i) * k + j] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void ego_copy_out_kernel(const float *__restrict__ la, int k, int n_pairs, float *__restrict__ out)
+{
+    const int kp = k + 1;
+    const int64_t total = (int64_t)n_pairs * k * k;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int j = (int)(e % k), i = (int)((e / k) % k);
+        const int64_t p = e / ((int64_t)k * k);
+        out[e] = la[(p * kp + i) * kp + j];
+    }
+}
+
+// U[p][i] / V[p][j]: sums of the recorded vectors of the first `nu` row steps / `nv` column steps
+__device__ __forceinline__ float ego_cum(const float *__restrict__ lse, int steps, int64_t stride, int64_t idx)
+{
+    float a = 0.f;
+    for (int t = 0; t < steps; ++t) a += lse[t * stride + idx];
+    return a;
+}
+
+// backward of a row step: rows 0..k-1, all k+1 columns; y[i][j] = x0[i][j] - U_nu[i] - V_nv[j]
+__global__ __launch_bounds__(256) void ego_sinkhorn_rows_bwd_kernel(const float *__restrict__ x0, const float *__restrict__ lse_r,
+                                                                    const float *__restrict__ lse_c, int nu, int nv, int k, int n_pairs,
+                                                                    float *g)
+{
+    const int kp = k + 1;
+    const int lane = threadIdx.x & 63;
+    const int64_t n_rows = (int64_t)n_pairs * k, stride = n_rows;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < n_rows; row += (int64_t)gridDim.x * 4) {
+        const int64_t p = row / k;
+        const int i = (int)(row % k);
+        float *gr = g + (p * kp + i) * kp;
+        const float *xr = x0 + (p * k + i) * k;
+        float sm = 0.f;
+        for (int j = lane; j < kp; j += 64) sm += gr[j];
+        sm = wave_sum(sm);
+        const float u = ego_cum(lse_r, nu, stride, row);
+        for (int j = lane; j < kp; j += 64) {
+            const float y = (j < k ? xr[j] - ego_cum(lse_c, nv, stride, p * k + j) : 0.f) - u;
+            gr[j] -= expf(y) * sm;
+        }
+    }
+}
+
+// backward of a column step: columns 0..k-1, all k+1 rows; same tiling as the forward column kernel
+__global__ __launch_bounds__(256) void ego_sinkhorn_cols_bwd_kernel(const float *__restrict__ x0, const float *__restrict__ lse_r,
+                                                                    const float *__restrict__ lse_c, int nu, int nv, int k, int n_pairs,
+                                                                    float *g)
+{
+    __shared__ float ssum[4][64];
+    const int kp = k + 1;
+    const int64_t p = blockIdx.y, stride = (int64_t)n_pairs * k;
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    float *m = g + p * kp * kp;
+    const int rows_per = (kp + 3) / 4;
+    const int r_lo = q * rows_per, r_hi = min(kp, r_lo + rows_per);
+    float sm = 0.f;
+    if (col < k)
+        for (int i = r_lo; i < r_hi; ++i) sm += m[(int64_t)i * kp + col];
+    ssum[q][threadIdx.x & 63] = sm;
+    __syncthreads();
+    const float tot = ssum[0][threadIdx.x & 63] + ssum[1][threadIdx.x & 63] + ssum[2][threadIdx.x & 63] + ssum[3][threadIdx.x & 63];
+    if (col < k) {
+        const float v = ego_cum(lse_c, nv, stride, p * k + col);
+        for (int i = r_lo; i < r_hi; ++i) {
+            const float y = (i < k ? x0[(p * k + i) * k + col] - ego_cum(lse_r, nu, stride, p * k + i) : 0.f) - v;
+            m[(int64_t)i * kp + col] -= expf(y) * tot;
+        }
+    }
+}
+
+extern "C" int pcacc_sinkhorn_train_workspace_bytes(int n_pairs, int k, size_t *bytes)
+{
+    if (!bytes || n_pairs < 1 || k < 1) return PCACC_E_ARG;
+    *bytes = (size_t)n_pairs * (k + 1) * (k + 1) * sizeof(float);
+    return PCACC_OK;
+}
+
+// log_alpha [P,k,k] -> log_perm [P,k,k]; lse_rows, lse_cols [n_iters][P][k] (saved for the backward)
+extern "C" int pcacc_sinkhorn_forward(const float *log_alpha, int n_pairs, int k, int n_iters, float *log_perm, float *lse_rows,
+                                      float *lse_cols, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!log_alpha || !log_perm || !lse_rows || !lse_cols || !workspace || n_pairs < 1 || k < 1 || n_iters < 0) return PCACC_E_ARG;
+    if (workspace_bytes < (size_t)n_pairs * (k + 1) * (k + 1) * sizeof(float)) return PCACC_E_WORKSPACE;
+    hipStream_t s = pcacc_stream(stream);
+    float *la = reinterpret_cast<float *>(workspace);
+    const int64_t padded = (int64_t)n_pairs * (k + 1) * (k + 1);
+    ego_copy_in_kernel<<<pcacc_grid(padded, 256), 256, 0, s>>>(log_alpha, k, n_pairs, la);
+    const int row_grid = pcacc_grid((int64_t)n_pairs * k * 64, 256);
+    const int64_t stride = (int64_t)n_pairs * k;
+    for (int it = 0; it < n_iters; ++it) {
+        ego_sinkhorn_rows_kernel<<<row_grid, 256, 0, s>>>(k, n_pairs, la, lse_rows + it * stride);
+        ego_sinkhorn_cols_kernel<<<dim3((k + 63) / 64, n_pairs), 256, 0, s>>>(k, la, lse_cols + it * stride);
+    }
+    ego_copy_out_kernel<<<pcacc_grid((int64_t)n_pairs * k * k, 256), 256, 0, s>>>(la, k, n_pairs, log_perm);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}
+
+// grad_log_perm [P,k,k] -> grad_log_alpha [P,k,k]
+extern "C" int pcacc_sinkhorn_backward(const float *grad_log_perm, const float *log_alpha, const float *lse_rows, const float *lse_cols,
+                                       int n_pairs, int k, int n_iters, float *grad_log_alpha, void *workspace, size_t workspace_bytes,
+                                       void *stream)
+{
+    if (!grad_log_perm || !log_alpha || !lse_rows || !lse_cols || !grad_log_alpha || !workspace || n_pairs < 1 || k < 1 || n_iters < 0)
+        return PCACC_E_ARG;
+    if (workspace_bytes < (size_t)n_pairs * (k + 1) * (k + 1) * sizeof(float)) return PCACC_E_WORKSPACE;
+    hipStream_t s = pcacc_stream(stream);
+    float *g = reinterpret_cast<float *>(workspace);
+    const int64_t padded = (int64_t)n_pairs * (k + 1) * (k + 1);
+    ego_copy_in_kernel<<<pcacc_grid(padded, 256), 256, 0, s>>>(grad_log_perm, k, n_pairs, g);
+    const int row_grid = pcacc_grid((int64_t)n_pairs * k * 64, 256);
+    for (int it = n_iters - 1; it >= 0; --it) {
+        // after column step `it`: U = rows 0..it, V = cols 0..it; after row step `it`: U = rows 0..it, V = cols 0..it-1
+        ego_sinkhorn_cols_bwd_kernel<<<dim3((k + 63) / 64, n_pairs), 256, 0, s>>>(log_alpha, lse_rows, lse_cols, it + 1, it + 1, k, n_pairs, g);
+        ego_sinkhorn_rows_bwd_kernel<<<row_grid, 256, 0, s>>>(log_alpha, lse_rows, lse_cols, it + 1, it, k, n_pairs, g);
+    }
+    ego_copy_out_kernel<<<pcacc_grid((int64_t)n_pairs * k * k, 256), 256, 0, s>>>(g, k, n_pairs, grad_log_alpha);
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
 }

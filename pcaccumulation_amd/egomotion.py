@@ -124,6 +124,8 @@ class EgoMotionHead(nn.Module):
 
     def sinkhorn(self, log_alpha, n_iters=5, slack=True):
         """models/egomotion.py:100-137: slack row/column padded with zeros, never normalised themselves."""
+        if slack and log_alpha.dim() == 3:
+            return ops.sinkhorn(log_alpha, n_iters)                         # fused forward / replayed-backward kernels (csrc/ego.hip)
         la = torch.nn.functional.pad(log_alpha, (0, 1, 0, 1))
         for _ in range(n_iters):
             la = torch.cat((la[:, :-1, :] - torch.logsumexp(la[:, :-1, :], dim=2, keepdim=True), la[:, -1, None, :]), dim=1)

@@ -49,6 +49,7 @@ EXPORTS = [
     'pcacc_cluster_workspace_bytes', 'pcacc_cluster', 'pcacc_conv3x3_prepare_weights', 'pcacc_conv3x3_bf16',
     'pcacc_rows_linear_bf16', 'pcacc_rows_linear_mixed', 'pcacc_rows_wgrad_mixed',
     'pcacc_segment_max_t', 'pcacc_segment_max_backward_t', 'pcacc_segment_sum_t', 'pcacc_rows_wgrad_bf16_workspace_bytes', 'pcacc_rows_wgrad_bf16', 'pcacc_sample_subsets', 'pcacc_conv3x3_wgrad_workspace_bytes', 'pcacc_conv3x3_wgrad_bf16', 'pcacc_upload_words', 'pcacc_bilinear_base_cells', 'pcacc_bilinear_gather_backward_sorted', 'pcacc_prep_points',
+    'pcacc_sinkhorn_train_workspace_bytes', 'pcacc_sinkhorn_forward', 'pcacc_sinkhorn_backward',
 ]
 
 
@@ -543,3 +544,33 @@ def prep_points(points, tsfm12, noise, noise_scale, scale, crop_xy, z_min, z_max
                                    1 if remove_ground else 0, ctypes.c_double(ground_z), _i64(m), _dev(out), _dev(keep), _stream()),
            'prep_points')
     return out, keep
+
+
+def _sinkhorn_ws(P, k, dev):
+    need = ctypes.c_size_t(0)
+    _check(lib().pcacc_sinkhorn_train_workspace_bytes(int(P), int(k), ctypes.byref(need)), 'sinkhorn_train_workspace')
+    return _ws(need.value, dev)
+
+
+def sinkhorn_forward(log_alpha, n_iters):
+    """log_alpha [P,k,k] f32 -> (log_perm [P,k,k], lse_rows, lse_cols [n_iters,P,k]); see include/pcacc.h."""
+    P, k, _ = log_alpha.shape
+    dev = log_alpha.device
+    out = torch.empty_like(log_alpha)
+    lr = torch.empty((n_iters, P, k), dtype=torch.float32, device=dev)
+    lc = torch.empty((n_iters, P, k), dtype=torch.float32, device=dev)
+    ws = _sinkhorn_ws(P, k, dev)
+    _check(lib().pcacc_sinkhorn_forward(_dev(log_alpha, torch.float32, 'log_alpha'), int(P), int(k), int(n_iters), _dev(out), _dev(lr),
+                                        _dev(lc), _dev(ws), ctypes.c_size_t(ws.numel()), _stream()), 'sinkhorn_forward')
+    return out, lr, lc
+
+
+def sinkhorn_backward(grad_log_perm, log_alpha, lse_rows, lse_cols):
+    P, k, _ = log_alpha.shape
+    n_iters = lse_rows.shape[0]
+    g = torch.empty_like(log_alpha)
+    ws = _sinkhorn_ws(P, k, log_alpha.device)
+    _check(lib().pcacc_sinkhorn_backward(_dev(grad_log_perm, torch.float32, 'grad'), _dev(log_alpha, torch.float32, 'log_alpha'),
+                                         _dev(lse_rows, torch.float32), _dev(lse_cols, torch.float32), int(P), int(k), int(n_iters),
+                                         _dev(g), _dev(ws), ctypes.c_size_t(ws.numel()), _stream()), 'sinkhorn_backward')
+    return g

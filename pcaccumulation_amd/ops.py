@@ -493,3 +493,24 @@ def conv3x3(x, conv, relu=False):
         return y.permute(0, 3, 1, 2)
     y = conv(x)
     return torch.relu(y) if relu else y
+
+
+class _Sinkhorn(torch.autograd.Function):
+    """Log-domain Sinkhorn with slack (models/egomotion.py:100-137) on [P,k,k] log-affinities: two launches per iteration forward,
+    two backward (csrc/ego.hip); the backward replays the half-steps from the input and the recorded log-sum-exp vectors."""
+
+    @staticmethod
+    def forward(ctx, log_alpha, n_iters):
+        log_alpha = log_alpha.contiguous().float()
+        out, lr, lc = native.sinkhorn_forward(log_alpha, n_iters)
+        ctx.save_for_backward(log_alpha, lr, lc)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        log_alpha, lr, lc = ctx.saved_tensors
+        return native.sinkhorn_backward(grad.contiguous().float(), log_alpha, lr, lc), None
+
+
+def sinkhorn(log_alpha, n_iters):
+    return _Sinkhorn.apply(log_alpha, int(n_iters))

@@ -705,3 +705,31 @@ def test_two_level_segment_max_bf16_rows():
     xr = x.detach().float().requires_grad_(True)
     ops.scatter(xr, idx, dim=0, dim_size=m, reduce='max', plan=ops.ScatterPlan(idx, m)).backward(g)
     assert x.grad.dtype == torch.bfloat16 and torch.equal(x.grad.float(), xr.grad.to(torch.bfloat16).float())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('P,k,iters', [(3, 1024, 3), (2, 300, 5), (1, 64, 1)])
+def test_sinkhorn_forward_backward_kernels(P, k, iters):
+    """Fused Sinkhorn (forward + replayed backward) against autograd through the reference formulation
+    (pad, slice, logsumexp, cat; models/egomotion.py:100-137)."""
+    import torch
+    from pcaccumulation_amd import ops
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(P * 7 + k)
+    x = (torch.randn(P, k, k, generator=g) * 3.0).to(dev)
+    gy = torch.randn(P, k, k, generator=g).to(dev)
+
+    def ref(a):
+        la = torch.nn.functional.pad(a, (0, 1, 0, 1))
+        for _ in range(iters):
+            la = torch.cat((la[:, :-1, :] - torch.logsumexp(la[:, :-1, :], dim=2, keepdim=True), la[:, -1, None, :]), dim=1)
+            la = torch.cat((la[:, :, :-1] - torch.logsumexp(la[:, :, :-1], dim=1, keepdim=True), la[:, :, -1, None]), dim=2)
+        return la[:, :-1, :-1]
+    x1 = x.clone().requires_grad_(True)
+    y1 = ops.sinkhorn(x1, iters)
+    y1.backward(gy)
+    x2 = x.double().requires_grad_(True)
+    y2 = ref(x2)
+    y2.backward(gy.double())
+    assert (y1 - y2.float()).abs().max().item() <= 2e-4
+    assert (x1.grad - x2.grad.float()).abs().max().item() <= 2e-4 * max(1.0, x2.grad.abs().max().item())
