@@ -105,15 +105,17 @@ __global__ __launch_bounds__(256) void ego_sinkhorn_rows_kernel(int k, int n_pai
 }
 
 // ---- 2b. column normalisation: columns 0..k-1, logsumexp over ALL k+1 rows (egomotion.py:128-132) ---------------------------
-// workgroup = 64 columns x 4 row-quarters; partial (max, sum) combined through LDS
-__global__ __launch_bounds__(256) void ego_sinkhorn_cols_kernel(int k, float *la, float *lse_out = nullptr)
+// workgroup = 64 columns x EGO_CG row groups (16 waves: the walk down a column is latency-bound, 4 waves per workgroup left
+// the 16 x P workgroups of this launch 5x slower than the row kernel); partial (max, sum) combined through LDS
+#define EGO_CG 16
+__global__ __launch_bounds__(64 * EGO_CG) void ego_sinkhorn_cols_kernel(int k, float *la, float *lse_out = nullptr)
 {
-    __shared__ float smax[4][64], ssum[4][64];
+    __shared__ float smax[EGO_CG][64], ssum[EGO_CG][64];
     const int kp = k + 1;
     const int p = blockIdx.y;
     const int col = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
     float *m = la + (int64_t)p * kp * kp;
-    const int rows_per = (kp + 3) / 4;
+    const int rows_per = (kp + EGO_CG - 1) / EGO_CG;
     const int r_lo = q * rows_per, r_hi = min(kp, r_lo + rows_per);
     float mx = -__builtin_inff(), sm = 0.f;
     if (col < k) {
@@ -125,10 +127,10 @@ __global__ __launch_bounds__(256) void ego_sinkhorn_cols_kernel(int k, float *la
     __syncthreads();
     float gm = -__builtin_inff();
 #pragma unroll
-    for (int u = 0; u < 4; ++u) gm = fmaxf(gm, smax[u][threadIdx.x & 63]);
+    for (int u = 0; u < EGO_CG; ++u) gm = fmaxf(gm, smax[u][threadIdx.x & 63]);
     float gs = 0.f;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < EGO_CG; ++u) {
         const float pm = smax[u][threadIdx.x & 63];
         gs += (pm == -__builtin_inff()) ? 0.f : ssum[u][threadIdx.x & 63] * expf(pm - gm);
     }
@@ -317,7 +319,7 @@ extern "C" int pcacc_sinkhorn_kabsch(const float *feats_s, const float *feats_t,
     const int row_grid = pcacc_grid((int64_t)n_pairs * k * 64, 256);
     for (int it = 0; it < n_iters; ++it) {
         ego_sinkhorn_rows_kernel<<<row_grid, 256, 0, s>>>(k, n_pairs, la);
-        ego_sinkhorn_cols_kernel<<<dim3((k + 63) / 64, n_pairs), 256, 0, s>>>(k, la);
+        ego_sinkhorn_cols_kernel<<<dim3((k + 63) / 64, n_pairs), 64 * EGO_CG, 0, s>>>(k, la);
     }
     ego_rows_finish_kernel<<<row_grid, 256, 0, s>>>(la, coor_s, coor_t, thr2, k, n_pairs, perm, rowsum, wt);
     ego_kabsch_kernel<<<n_pairs, 256, 0, s>>>(coor_s, wt, rowsum, k, pose);
@@ -389,23 +391,25 @@ __global__ __launch_bounds__(256) void ego_sinkhorn_rows_bwd_kernel(const float 
 }
 
 // backward of a column step: columns 0..k-1, all k+1 rows; same tiling as the forward column kernel
-__global__ __launch_bounds__(256) void ego_sinkhorn_cols_bwd_kernel(const float *__restrict__ x0, const float *__restrict__ lse_r,
+__global__ __launch_bounds__(64 * EGO_CG) void ego_sinkhorn_cols_bwd_kernel(const float *__restrict__ x0, const float *__restrict__ lse_r,
                                                                     const float *__restrict__ lse_c, int nu, int nv, int k, int n_pairs,
                                                                     float *g)
 {
-    __shared__ float ssum[4][64];
+    __shared__ float ssum[EGO_CG][64];
     const int kp = k + 1;
     const int64_t p = blockIdx.y, stride = (int64_t)n_pairs * k;
     const int col = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
     float *m = g + p * kp * kp;
-    const int rows_per = (kp + 3) / 4;
+    const int rows_per = (kp + EGO_CG - 1) / EGO_CG;
     const int r_lo = q * rows_per, r_hi = min(kp, r_lo + rows_per);
     float sm = 0.f;
     if (col < k)
         for (int i = r_lo; i < r_hi; ++i) sm += m[(int64_t)i * kp + col];
     ssum[q][threadIdx.x & 63] = sm;
     __syncthreads();
-    const float tot = ssum[0][threadIdx.x & 63] + ssum[1][threadIdx.x & 63] + ssum[2][threadIdx.x & 63] + ssum[3][threadIdx.x & 63];
+    float tot = 0.f;
+#pragma unroll
+    for (int u = 0; u < EGO_CG; ++u) tot += ssum[u][threadIdx.x & 63];
     if (col < k) {
         const float v = ego_cum(lse_c, nv, stride, p * k + col);
         for (int i = r_lo; i < r_hi; ++i) {
@@ -436,7 +440,7 @@ extern "C" int pcacc_sinkhorn_forward(const float *log_alpha, int n_pairs, int k
     const int64_t stride = (int64_t)n_pairs * k;
     for (int it = 0; it < n_iters; ++it) {
         ego_sinkhorn_rows_kernel<<<row_grid, 256, 0, s>>>(k, n_pairs, la, lse_rows + it * stride);
-        ego_sinkhorn_cols_kernel<<<dim3((k + 63) / 64, n_pairs), 256, 0, s>>>(k, la, lse_cols + it * stride);
+        ego_sinkhorn_cols_kernel<<<dim3((k + 63) / 64, n_pairs), 64 * EGO_CG, 0, s>>>(k, la, lse_cols + it * stride);
     }
     ego_copy_out_kernel<<<pcacc_grid((int64_t)n_pairs * k * k, 256), 256, 0, s>>>(la, k, n_pairs, log_perm);
     PCACC_CHECK_LAUNCH();
@@ -458,7 +462,7 @@ extern "C" int pcacc_sinkhorn_backward(const float *grad_log_perm, const float *
     const int row_grid = pcacc_grid((int64_t)n_pairs * k * 64, 256);
     for (int it = n_iters - 1; it >= 0; --it) {
         // after column step `it`: U = rows 0..it, V = cols 0..it; after row step `it`: U = rows 0..it, V = cols 0..it-1
-        ego_sinkhorn_cols_bwd_kernel<<<dim3((k + 63) / 64, n_pairs), 256, 0, s>>>(log_alpha, lse_rows, lse_cols, it + 1, it + 1, k, n_pairs, g);
+        ego_sinkhorn_cols_bwd_kernel<<<dim3((k + 63) / 64, n_pairs), 64 * EGO_CG, 0, s>>>(log_alpha, lse_rows, lse_cols, it + 1, it + 1, k, n_pairs, g);
         ego_sinkhorn_rows_bwd_kernel<<<row_grid, 256, 0, s>>>(log_alpha, lse_rows, lse_cols, it + 1, it, k, n_pairs, g);
     }
     ego_copy_out_kernel<<<pcacc_grid((int64_t)n_pairs * k * k, 256), 256, 0, s>>>(g, k, n_pairs, grad_log_alpha);
