@@ -317,7 +317,8 @@ int pcacc_conv3x3_prepare_weights(const float *w, int32_t c_out, int32_t c_in, i
 int pcacc_conv3x3_bf16(const uint16_t *in, const uint16_t *wp, const float *bias, uint16_t *out, int32_t n_img,
                        int32_t frames, int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t kt, int32_t relu,
                        void *stream);
-/* Weight gradient of the same layers (c_in, c_out in {32, 64}): dw [c_out][9][c_in] f32 = sum over images and pixels of
+/* Weight gradient of the same layers (c_in, c_out in {32, 64}): dw = [c_out][9][c_in] f32 followed by [c_out] f32 (bias
+ * gradient = sum of dy over the images and pixels this launch visits; complete for dt = 0);  dw[co][tap][ci] = sum of
  * dy[n][px][co] * x[n + dt][px + tap offset][ci]; dt in {-1, 0, 1} selects the frame tap of a kt = 3 layer (0 for kt = 1),
  * frames as above.  bf16 MFMA with fp32 accumulation; per-workgroup partials in `workspace`, summed by a second launch. */
 int pcacc_conv3x3_wgrad_workspace_bytes(int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_out, size_t *bytes /*host*/);

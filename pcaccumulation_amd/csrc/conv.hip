@@ -481,6 +481,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_wgrad_kernel(const uint16_
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bsum = 0.f;
 
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
     const int n_tiles = n_img * tiles_y * tiles_x;
@@ -556,6 +557,12 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_wgrad_kernel(const uint16_
             cv_frag af;
             af.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cv_s16x4 __attribute__((address_space(3))) *)pa);
             af.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cv_s16x4 __attribute__((address_space(3))) *)(pa + 4 * YS));
+            if (it == 0) {                                     // bias gradient = column sums of dY: the fragment is at hand
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bsum += bf16_to_f32((uint16_t)af.h[j][q]);
+            }
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const uint16_t *pb = sx + ((ry + tap / 3) * CV_PW + xb + tap % 3 + tr_row) * XS + it * 32 + tr_col;
@@ -566,8 +573,8 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_wgrad_kernel(const uint16_
             }
         }
     }
-    // slot of this (workgroup, pixel group): [CO][9][CI]; D has lane = ci, register quads = co
-    float *mine = partial + ((int64_t)blockIdx.x * GROUPS + grp) * CO * 9 * CI;
+    // slot of this (workgroup, pixel group): [CO][9][CI] then [CO] bias sums; D has lane = ci, register quads = co
+    float *mine = partial + ((int64_t)blockIdx.x * GROUPS + grp) * (CO * 9 * CI + CO);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
@@ -575,6 +582,8 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_wgrad_kernel(const uint16_
             const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             mine[((int64_t)co * 9 + tap) * CI + it * 32 + lp] = acc[tap][r];
         }
+    bsum += __shfl_xor(bsum, 32, 64);                          // the two half-waves hold pixels 0-7 / 8-15 of the same channel
+    if (it == 0 && lh == 0) mine[CO * 9 * CI + ct * 32 + lp] = bsum;
 }
 
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__restrict__ partial, int n_parts, int elems, float *out)
@@ -610,7 +619,7 @@ extern "C" int pcacc_conv3x3_wgrad_workspace_bytes(int32_t n_img, int32_t h, int
     if (!bytes || n_img < 1 || h < 1 || w < 1 || (c_in != 32 && c_in != 64) || (c_out != 32 && c_out != 64)) return PCACC_E_ARG;
     const int64_t n_tiles = (int64_t)n_img * ((h + CV_TH - 1) / CV_TH) * ((w + CV_TW - 1) / CV_TW);
     const int groups = 4 / ((c_in / 32) * (c_out / 32));
-    *bytes = (size_t)conv_wgrad_grid(c_in, c_out, n_tiles) * groups * c_out * 9 * c_in * sizeof(float);
+    *bytes = (size_t)conv_wgrad_grid(c_in, c_out, n_tiles) * groups * (c_out * 9 * c_in + c_out) * sizeof(float);
     return 0;
 }
 
@@ -627,7 +636,7 @@ extern "C" int pcacc_conv3x3_wgrad_bf16(const uint16_t *dy, const uint16_t *x, f
     if (n_tiles > 0x7fffffff) return PCACC_E_ARG;
     const int grid = conv_wgrad_grid(c_in, c_out, n_tiles);
     const int groups = 4 / ((c_in / 32) * (c_out / 32));
-    const int elems = c_out * 9 * c_in;
+    const int elems = c_out * 9 * c_in + c_out;                 // weight gradient, then the bias gradient
     if (workspace_bytes < (size_t)grid * groups * elems * sizeof(float)) return PCACC_E_WORKSPACE;
     const size_t lds = (size_t)(CV_TH * CV_TW * (c_out + 4) + CV_PH * CV_PW * (c_in + 4)) * sizeof(uint16_t);
     float *partial = reinterpret_cast<float *>(workspace);

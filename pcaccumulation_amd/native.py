@@ -482,10 +482,11 @@ def conv3x3_wgrad_supported(c_in, c_out):
 
 
 def conv3x3_wgrad(dy_rows, x_rows, frames=1, dt=0):
-    """dy_rows [n_img,h,w,c_out], x_rows [n_img,h,w,c_in] bf16 -> [c_out, 9, c_in] f32 (frame tap dt of a kt=3 layer)."""
+    """dy_rows [n_img,h,w,c_out], x_rows [n_img,h,w,c_in] bf16 -> (dw [c_out, 9, c_in] f32, db [c_out] f32) for frame tap dt of a
+    kt=3 layer (db is the full bias gradient for dt = 0)."""
     n_img, h, w, c_out = dy_rows.shape
     c_in = x_rows.shape[3]
-    dw = torch.empty((c_out, 9, c_in), dtype=torch.float32, device=dy_rows.device)
+    dw = torch.empty((c_out * 9 * c_in + c_out,), dtype=torch.float32, device=dy_rows.device)
     need = ctypes.c_size_t(0)
     _check(lib().pcacc_conv3x3_wgrad_workspace_bytes(int(n_img), int(h), int(w), int(c_in), int(c_out), ctypes.byref(need)),
            'conv3x3_wgrad_workspace')
@@ -493,7 +494,7 @@ def conv3x3_wgrad(dy_rows, x_rows, frames=1, dt=0):
     _check(lib().pcacc_conv3x3_wgrad_bf16(_dev(dy_rows, torch.bfloat16, 'dy'), _dev(x_rows, torch.bfloat16, 'x'), _dev(dw), int(n_img),
                                           int(frames), int(dt), int(h), int(w), int(c_in), int(c_out), _dev(ws),
                                           ctypes.c_size_t(ws.numel()), _stream()), 'conv3x3_wgrad')
-    return dw
+    return dw[:c_out * 9 * c_in].view(c_out, 9, c_in), dw[c_out * 9 * c_in:]
 
 
 def upload_small(values, dtype, device):

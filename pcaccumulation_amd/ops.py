@@ -431,12 +431,14 @@ class _Conv3x3(torch.autograd.Function):
         if need_w and native.conv3x3_wgrad_supported(i, o):
             # weight gradient on the matrix cores too (one launch per frame tap); bias gradient = a column sum of dY
             if kt == 3:
-                taps = [native.conv3x3_wgrad(gy, x_rows, frames, dt).view(o, 3, 3, i) for dt in (-1, 0, 1)]
-                gw = torch.stack(taps, dim=1).permute(0, 4, 1, 2, 3)                       # [o, i, kt, 3, 3]
+                parts = [native.conv3x3_wgrad(gy, x_rows, frames, dt) for dt in (-1, 0, 1)]
+                gw = torch.stack([p[0].view(o, 3, 3, i) for p in parts], dim=1).permute(0, 4, 1, 2, 3)    # [o, i, kt, 3, 3]
+                gb = parts[1][1]                                                           # dt = 0 visits every frame
             else:
-                gw = native.conv3x3_wgrad(gy, x_rows).view(o, 3, 3, i).permute(0, 3, 1, 2)
+                gw, gb = native.conv3x3_wgrad(gy, x_rows)
+                gw = gw.view(o, 3, 3, i).permute(0, 3, 1, 2)
             gw = gw.to(weight.dtype)
-            gb = gy.sum(dim=(0, 1, 2), dtype=torch.float32) if has_bias and ctx.needs_input_grad[2] else None
+            gb = gb.clone() if has_bias and ctx.needs_input_grad[2] else None
             need_w = False
         if need_w or lib_dgrad:
             xin = _stack_frames(x_rows, frames) if kt == 3 else x_rows

@@ -113,12 +113,17 @@ def test_conv3x3_wgrad_kernel(ci, co, kt):
     x = torch.randn(b * t, h, w, ci, generator=g).to(DEV).to(torch.bfloat16)
     gy = torch.randn(b * t, h, w, co, generator=g).to(DEV).to(torch.bfloat16)
     if kt == 1:
-        dw = native.conv3x3_wgrad(gy, x).view(co, 3, 3, ci).permute(0, 3, 1, 2)
+        dw, db = native.conv3x3_wgrad(gy, x)
+        dw = dw.view(co, 3, 3, ci).permute(0, 3, 1, 2)
         wr = torch.zeros(co, ci, 3, 3, device=DEV, requires_grad=True)
         F.conv2d(x.float().permute(0, 3, 1, 2), wr, None, padding=1).backward(gy.float().permute(0, 3, 1, 2))
     else:
-        dw = torch.stack([native.conv3x3_wgrad(gy, x, t, dt).view(co, 3, 3, ci) for dt in (-1, 0, 1)], 1).permute(0, 4, 1, 2, 3)
+        parts = [native.conv3x3_wgrad(gy, x, t, dt) for dt in (-1, 0, 1)]
+        dw = torch.stack([p[0].view(co, 3, 3, ci) for p in parts], 1).permute(0, 4, 1, 2, 3)
+        db = parts[1][1]
         wr = torch.zeros(co, ci, 3, 3, 3, device=DEV, requires_grad=True)
         x5 = x.float().view(b, t, h, w, ci).permute(0, 4, 1, 2, 3)
         F.conv3d(x5, wr, None, padding=1).backward(gy.float().view(b, t, h, w, co).permute(0, 4, 1, 2, 3))
     assert (dw - wr.grad).abs().max().item() <= 2e-3 * wr.grad.abs().max().item()
+    ref_b = gy.float().sum(dim=(0, 1, 2))
+    assert (db - ref_b).abs().max().item() <= 1e-3 * max(1.0, ref_b.abs().max().item())
