@@ -14,16 +14,40 @@ from .ops import scatter, ScatterPlan, linear_rows, transform_by_index, point_dt
 _EPS = 1e-20
 
 
+_CONST = {}
+
+
+def _const(name, device, build):
+    """Small constant tables (built once per device) that turn the per-entry formulas below into one gather or one product."""
+    key = (name, str(device))
+    if key not in _CONST:
+        _CONST[key] = build().to(device)
+    return _CONST[key]
+
+
+def _quat_products_to_pose():
+    """[20,16] table: row = product q_a*q_b (a*4+b, order x,y,z,w), then the translation (3) and a one; column = entry of the
+    row-major 4x4 pose. Rotation block as toolbox/se3_utils.py:44-64, translation in the last column, last row (0,0,0,1)."""
+    x, y, z, w = 0, 1, 2, 3
+    rot = {(0, 0): [(w, w, 1), (x, x, 1), (y, y, -1), (z, z, -1)], (0, 1): [(x, y, 2), (w, z, -2)], (0, 2): [(w, y, 2), (x, z, 2)],
+           (1, 0): [(w, z, 2), (x, y, 2)], (1, 1): [(w, w, 1), (x, x, -1), (y, y, 1), (z, z, -1)], (1, 2): [(y, z, 2), (w, x, -2)],
+           (2, 0): [(x, z, 2), (w, y, -2)], (2, 1): [(w, x, 2), (y, z, 2)], (2, 2): [(w, w, 1), (x, x, -1), (y, y, -1), (z, z, 1)]}
+    table = torch.zeros(20, 16)
+    for (r, c), terms in rot.items():
+        for a, b, coef in terms:
+            table[a * 4 + b, r * 4 + c] += coef
+    for r in range(3):
+        table[16 + r, r * 4 + 3] = 1
+    table[19, 15] = 1
+    return table
+
+
 def quat2mat(quat):
-    """toolbox/se3_utils.py:44-64: [x,y,z,w] quaternion (scipy order) -> [B,3,3]."""
-    x, y, z, w = quat[:, 0], quat[:, 1], quat[:, 2], quat[:, 3]
-    B = quat.size(0)
-    w2, x2, y2, z2 = w.pow(2), x.pow(2), y.pow(2), z.pow(2)
-    wx, wy, wz = w * x, w * y, w * z
-    xy, xz, yz = x * y, x * z, y * z
-    return torch.stack([w2 + x2 - y2 - z2, 2 * xy - 2 * wz, 2 * wy + 2 * xz,
-                        2 * wz + 2 * xy, w2 - x2 + y2 - z2, 2 * yz - 2 * wx,
-                        2 * xz - 2 * wy, 2 * wx + 2 * yz, w2 - x2 - y2 + z2], dim=1).reshape(B, 3, 3)
+    """toolbox/se3_utils.py:44-64: [x,y,z,w] quaternion (scipy order) -> [B,3,3]. The nine entries are sums of products
+    q_a*q_b: one outer product and one [B,16]x[16,9] product instead of ~40 element-wise launches."""
+    table = _const('q2m', quat.device, _quat_products_to_pose)[:16].reshape(16, 4, 4)[:, :3, :3].reshape(16, 9)
+    outer = (quat[:, :, None] * quat[:, None, :]).reshape(-1, 16)
+    return (outer @ table.to(quat.dtype)).reshape(-1, 3, 3)
 
 
 def apply_tsfm(src, tsfm):
@@ -44,12 +68,29 @@ def ego_motion_compensation(points, time_indice, tsfm):
 
 
 def batch_quat2mat(pose_est_rep):
-    """models/tpointnet.py:20-40: [N,7] (quat xyzw, trans) -> [N,4,4]; the quaternion is normalised first."""
+    """models/tpointnet.py:20-40: [N,7] (quat xyzw, trans) -> [N,4,4]; the quaternion is normalised first. Rotation, translation
+    and the constant row come out of one product with the table above."""
     quat = F.normalize(pose_est_rep[:, :4], p=2, dim=1)
-    out = torch.eye(4, device=pose_est_rep.device)[None].repeat(pose_est_rep.size(0), 1, 1)
-    out[:, :3, :3] = quat2mat(quat)
-    out[:, :3, 3] = pose_est_rep[:, 4:]
-    return out
+    n = pose_est_rep.size(0)
+    outer = (quat[:, :, None] * quat[:, None, :]).reshape(n, 16)
+    terms = torch.cat((outer, pose_est_rep[:, 4:], torch.ones_like(pose_est_rep[:, :1])), dim=1)
+    return (terms @ _const('q2m', pose_est_rep.device, _quat_products_to_pose).to(terms.dtype)).reshape(n, 4, 4)
+
+
+def _mat2quat_tables():
+    """Index tables for mat2quat: candidate c (0..2: component c formed first, 3: w first), component e -> the two entries of
+    the row-major 3x3 matrix that are added (sign +1) or subtracted (sign -1); the component formed first is marked instead."""
+    first, second, sign, lead = torch.zeros(16, dtype=torch.long), torch.zeros(16, dtype=torch.long), torch.zeros(16), torch.zeros(16, dtype=torch.long)
+    is_lead = torch.zeros(16, dtype=torch.bool)
+    for i in range(3):
+        j, k = (i + 1) % 3, (i + 2) % 3
+        is_lead[i * 4 + i] = True; lead[i * 4 + i] = i
+        for e, (a, b, sg) in ((j, (j * 3 + i, i * 3 + j, 1.0)), (k, (k * 3 + i, i * 3 + k, 1.0)), (3, (k * 3 + j, j * 3 + k, -1.0))):
+            first[i * 4 + e], second[i * 4 + e], sign[i * 4 + e] = a, b, sg
+    for e, (a, b) in enumerate(((2 * 3 + 1, 1 * 3 + 2), (0 * 3 + 2, 2 * 3 + 0), (1 * 3 + 0, 0 * 3 + 1))):
+        first[12 + e], second[12 + e], sign[12 + e] = a, b, -1.0
+    is_lead[15] = True; lead[15] = 3
+    return first, second, sign.double(), lead, is_lead
 
 
 def mat2quat(rot):
@@ -58,21 +99,19 @@ def mat2quat(rot):
     which component is formed first; ties go to the first), which the reference calls on the host (models/tpointnet.py:62-66).
     Identical to scipy 1.15 to the last bit on proper rotations and to 2e-8 on float32-rounded ones, which scipy
     re-orthogonalises first (tests/test_host_logic.py); no device -> host round trip."""
-    m = rot.double()
-    d0, d1, d2 = m[:, 0, 0], m[:, 1, 1], m[:, 2, 2]
-    tr = d0 + d1 + d2
-    choice = torch.stack((d0, d1, d2, tr), dim=1).argmax(dim=1)
-    cands = []
-    for i in range(3):
-        j, k = (i + 1) % 3, (i + 2) % 3
-        q = [None] * 4
-        q[i] = 1 - tr + 2 * m[:, i, i]
-        q[j] = m[:, j, i] + m[:, i, j]
-        q[k] = m[:, k, i] + m[:, i, k]
-        q[3] = m[:, k, j] - m[:, j, k]
-        cands.append(torch.stack(q, dim=1))
-    cands.append(torch.stack((m[:, 2, 1] - m[:, 1, 2], m[:, 0, 2] - m[:, 2, 0], m[:, 1, 0] - m[:, 0, 1], 1 + tr), dim=1))
-    quat = torch.stack(cands, dim=1)[torch.arange(m.size(0), device=m.device), choice]
+    dev = rot.device
+    first = _const('m2q_first', dev, lambda: _mat2quat_tables()[0])
+    second = _const('m2q_second', dev, lambda: _mat2quat_tables()[1])
+    sign = _const('m2q_sign', dev, lambda: _mat2quat_tables()[2])
+    lead = _const('m2q_lead', dev, lambda: _mat2quat_tables()[3])
+    is_lead = _const('m2q_is_lead', dev, lambda: _mat2quat_tables()[4])
+    m = rot.double().reshape(-1, 9)
+    diag = m[:, 0::4]
+    tr = (m[:, 0] + m[:, 4] + m[:, 8])[:, None]
+    leading = torch.cat((1 - tr + 2 * diag, 1 + tr), dim=1)                         # the component formed first, per candidate
+    cands = torch.where(is_lead, leading[:, lead], m[:, first] + sign * m[:, second]).reshape(-1, 4, 4)
+    choice = torch.cat((diag, tr), dim=1).argmax(dim=1)
+    quat = cands.gather(1, choice[:, None, None].expand(-1, 1, 4))[:, 0]
     return quat / torch.norm(quat, dim=1, keepdim=True)
 
 
