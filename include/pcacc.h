@@ -339,6 +339,48 @@ int pcacc_prep_points(const double *points, const double *tsfm12, const double *
                       double crop_xy, double z_min, double z_max, int32_t remove_ground, double ground_z, int64_t m,
                       double *out_points, uint8_t *keep, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * L1. Two-class segmentation loss on selected rows -- libs/loss.py:110-137 (FuseLoss.get_seg_loss: weighted cross entropy
+ * with the class weights of :90-108, Lovasz-Softmax of libs/lovasz_softmax.py:56-94, IoU counters of compute_iou :17-50),
+ * as called on the occupied pillars (:167-191) and on the foreground points (:140-165).
+ *   logits: f32 or bf16 (PCACC_F32 | PCACC_BF16), row i at [i][2] (plane = 0) or as planes [i / plane][2][i % plane]
+ *           (an NCHW head output read in place, plane = H*W);  labels [n_total] i64 (0, 1, or -1 = ignored by the cross
+ *           entropy and background of both classes in the Lovasz term, as in the reference);  rows [n] i64 = the selected
+ *           rows (NULL: rows 0..n-1)
+ *   out_loss [2] f32 = (cross entropy, Lovasz);  out_metric [4][2] f64 = intersection, union, predicted, labelled per
+ *   class, each / 1e3;  lovasz_grad [2][n] f32 and saved [8] f32 are what backward needs (the Jaccard gradient of each
+ *   row's rank per class; the class weights, their sum over the rows and the share of each present class)
+ *   backward: grad_bce, grad_lovasz = device scalars (NULL = 0);  grad_logits has the layout and type of logits over all
+ *   n_total rows (rows outside the selection get 0).  Equal errors are ranked by row index.
+ * ---------------------------------------------------------------------------------------------- */
+int pcacc_seg_loss_workspace_bytes(int64_t n, size_t *bytes /*host*/);
+int pcacc_seg_loss_forward(const void *logits, int logits_dtype, int64_t plane, const int64_t *labels, const int64_t *rows,
+                           int64_t n, float *out_loss, double *out_metric, float *lovasz_grad, float *saved,
+                           void *workspace, size_t workspace_bytes, void *stream);
+int pcacc_seg_loss_backward(const void *logits, int logits_dtype, int64_t plane, const int64_t *labels, const int64_t *rows,
+                            int64_t n, int64_t n_total, const float *lovasz_grad, const float *saved, const float *grad_bce,
+                            const float *grad_lovasz, void *grad_logits, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * L2. Offset loss -- libs/loss.py:194-250 (FuseLoss.get_offset_loss): every point is reconstructed with the ground truth
+ * (toolbox/register_utils.py:59-93: ego pose of its frame, then the motion of its instance), the instance centres are the
+ * means of the reconstructed points per instance, and the selected (foreground) rows compare the offset to their centre
+ * with the estimate.
+ *   points [n,3] f32;  time_indice [n,2] i64 (sample, frame);  inst_labels [n] i64 (per sample);  label_base [B] i64 =
+ *   first row of each sample in inst_motion;  ego_motion [B,T,16] f32;  inst_motion [k,T,16] f32 (all samples
+ *   concatenated);  transformed_points [n,3] f32;  offset_est [n,2] f32;  rows [m] i64 (NULL: all rows)
+ *   out [3] f32 = (L1 term, direction term, mean L2 error);  offset_gt [m,2] f32 = predictions['offset_gt'] (:246)
+ *   backward: grad_norm / grad_dir = device scalars (NULL = 0);  grad_est [n,2] f32 (0 outside the selection).
+ * ---------------------------------------------------------------------------------------------- */
+int pcacc_offset_loss_workspace_bytes(int64_t m, int64_t k, size_t *bytes /*host*/);
+int pcacc_offset_loss_forward(const float *points, const int64_t *time_indice, const int64_t *inst_labels,
+                              const int64_t *label_base, const float *ego_motion, const float *inst_motion, int32_t n_frames,
+                              int64_t n, int64_t k, const float *transformed_points, const float *offset_est,
+                              const int64_t *rows, int64_t m, float *out, float *offset_gt, void *workspace,
+                              size_t workspace_bytes, void *stream);
+int pcacc_offset_loss_backward(const float *offset_gt, const float *offset_est, const int64_t *rows, int64_t m, int64_t n,
+                               const float *grad_norm, const float *grad_dir, float *grad_est, void *stream);
+
 /* Host words -> device memory as kernel arguments (asynchronous, unlike a pageable hipMemcpy on the compute stream):
  * n 32-bit words from host_words to dst, 240 per launch.  For the per-step index tables a host loop of the reference
  * becomes (sample offsets, per-pair counts, thresholds). */

@@ -628,3 +628,104 @@ def compute_sf_metrics(epe, rel):
     return {'EPE3D': float(epe.mean()), 'EPE3D_med': float(np.sort(epe)[(epe.shape[0] - 1) // 2]),
             'Acc3DS': float(np.logical_or(epe < 0.05, rel < 0.05).mean()), 'Acc3DR': float(np.logical_or(epe < 0.1, rel < 0.1).mean()),
             'Outlier': float(np.logical_or(epe > 0.3, rel > 0.1).mean()), 'ROutlier': float(np.logical_and(epe > 0.3, rel > 0.3).mean())}
+
+
+# ------------------------------------------------------------------------------------------------
+# L1/L2  loss terms on the path's tensors  (libs/loss.py:90-137,194-250; libs/lovasz_softmax.py:56-94)
+# ------------------------------------------------------------------------------------------------
+def ce_weights(labels, n_classes=2, max_weights=50.0):
+    """libs/loss.py:90-108 ('sqrt_inv_freq'): float32 counts + 1e-20, sqrt(total / count) clamped to [0, 50]."""
+    counts = np.array([float((labels == c).sum()) + 1e-20 for c in range(n_classes)], np.float32)
+    with np.errstate(over='ignore'):
+        return np.clip(np.sqrt(counts.sum() / counts), 0, max_weights).astype(np.float32)
+
+
+def lovasz_grad(fg_sorted):
+    """libs/lovasz_softmax.py:56-68 (float32 cumulative sums, as the reference's .float().cumsum)."""
+    fg_sorted = fg_sorted.astype(np.float32)
+    gts = fg_sorted.sum(dtype=np.float32)
+    inter = gts - np.cumsum(fg_sorted, dtype=np.float32)
+    union = gts + np.cumsum(1 - fg_sorted, dtype=np.float32)
+    jac = (1.0 - inter / union).astype(np.float32)
+    jac[1:] = jac[1:] - jac[:-1]
+    return jac
+
+
+def seg_loss(logits, labels, n_classes=2, ignore_index=-1):
+    """libs/loss.py:110-137: weighted cross entropy (ignore_index rows dropped, weights from the label frequencies), Lovasz-Softmax
+    over the classes that are present (libs/lovasz_softmax.py:71-94, rows with the ignore label count as background of every
+    class, as in the reference which passes no ignore value), the IoU counters of compute_iou, and the gradients of the two loss
+    terms w.r.t. the logits (the Lovasz gradient vector is a constant, lovasz_softmax.py:92).  Ties between equal errors are
+    ordered by row index (stable sort); the loss value does not depend on that choice, the (sub)gradient does."""
+    z = np.asarray(logits, np.float32)
+    y = np.asarray(labels).astype(np.int64)
+    n = z.shape[0]
+    m = z.max(1, keepdims=True)
+    ez = np.exp(z - m)
+    p = (ez / ez.sum(1, keepdims=True)).astype(np.float32)
+    logp = (z - m) - np.log(ez.sum(1, keepdims=True))
+    w = ce_weights(y, n_classes)
+    keep = y != ignore_index
+    safe = np.where(keep, y, 0)
+    wi = w[safe] * keep
+    wsum = wi.sum(dtype=np.float64)
+    bce = -(wi * logp[np.arange(n), safe]).sum(dtype=np.float64) / wsum
+    onehot = np.zeros_like(p)
+    onehot[np.arange(n), safe] = 1
+    grad_bce = (wi[:, None] * (p - onehot) / wsum).astype(np.float32)
+    losses, dprob = [], np.zeros_like(p, dtype=np.float64)
+    present = [c for c in range(n_classes) if (y == c).any()]
+    for c in present:
+        fg = (y == c).astype(np.float32)
+        err = np.abs(fg - p[:, c])
+        perm = np.argsort(-err, kind='stable')
+        g = lovasz_grad(fg[perm])
+        losses.append(np.dot(err[perm].astype(np.float64), g.astype(np.float64)))
+        by_row = np.empty(n, np.float32)
+        by_row[perm] = g
+        dprob[:, c] = by_row * -np.sign(fg - p[:, c]) / len(present)
+    lovasz = float(np.mean(losses)) if losses else 0.0
+    grad_lov = (p * (dprob - (dprob * p).sum(1, keepdims=True))).astype(np.float32)
+    pred = (z[:, 1] > z[:, 0]).astype(np.int64) if n_classes == 2 else z.argmax(1)
+    return {'bce_loss': float(bce), 'lovasz_loss': lovasz, 'metric': compute_iou(pred, y, n_classes, ignore_index),
+            'grad_bce': grad_bce, 'grad_lovasz': grad_lov}
+
+
+def offset_loss(input_points, time_indice, inst_labels, fb_labels, ego_motion_gt, inst_motion_gt, transformed_points, offset_est):
+    """libs/loss.py:194-250: ground-truth reconstruction per sample (ego compensation, then the instance motions), instance
+    centres = mean of the reconstructed points per label, offsets of the foreground points to their centre (x, y) against the
+    estimate: L1 term (mean per coordinate, summed), direction term (1 - cosine with 1e-20 in the norms), mean L2 error; plus
+    the gradients of the first two w.r.t. offset_est and the ground-truth offsets (predictions['offset_gt'])."""
+    pts = np.asarray(input_points, np.float32)
+    tidx = np.asarray(time_indice).astype(np.int64)
+    lab = np.asarray(inst_labels).reshape(-1).astype(np.int64)
+    ego = np.asarray(ego_motion_gt, np.float32)
+    n_frames = ego.shape[1]
+    centres = np.zeros((pts.shape[0], 2), np.float32)
+    for b in range(len(inst_motion_gt)):
+        sel = tidx[:, 0] == b
+        comp = ego_motion_compensation(pts[sel], tidx[sel, 1], ego[b]).astype(np.float32)
+        rec = reconstruct_sequence(comp, tidx[sel, 1], lab[sel], np.asarray(inst_motion_gt[b], np.float32), n_frames).astype(np.float32)
+        k = int(lab[sel].max()) + 1
+        sums = np.zeros((k, 3), np.float64)
+        np.add.at(sums, lab[sel], rec)
+        cnt = np.maximum(np.bincount(lab[sel], minlength=k), 1)[:, None]
+        centres[sel] = (sums / cnt).astype(np.float32)[lab[sel]][:, :2]
+    fb = np.asarray(fb_labels).reshape(-1) == 1
+    gt = (centres - np.asarray(transformed_points, np.float32)[:, :2])[fb]
+    est = np.asarray(offset_est, np.float32)[fb]
+    m = gt.shape[0]
+    diff = (gt - est).astype(np.float64)
+    norm_loss = np.abs(diff).mean(0).sum()
+    l2 = np.linalg.norm(diff, axis=1).mean()
+    gn, en = np.linalg.norm(gt.astype(np.float64), axis=1, keepdims=True), np.linalg.norm(est.astype(np.float64), axis=1, keepdims=True)
+    ngt, nest = gt / (gn + 1e-20), est / (en + 1e-20)
+    dir_loss = (1 - (ngt * nest).sum(1)).mean()
+    grad_norm, grad_dir = np.zeros((pts.shape[0], 2), np.float32), np.zeros((pts.shape[0], 2), np.float32)
+    grad_norm[fb] = -np.sign(diff) / m
+    with np.errstate(invalid='ignore', divide='ignore'):
+        d_norm = np.where(en > 0, est / en, 0.0)                       # torch.norm's backward at 0 is 0
+        g = ngt / (en + 1e-20) - (ngt * est).sum(1, keepdims=True) / (en + 1e-20) ** 2 * d_norm
+    grad_dir[fb] = -g / m
+    return {'offset_norm_loss': float(norm_loss), 'offset_dir_loss': float(dir_loss), 'offset_l2_error': float(l2),
+            'offset_gt': gt, 'grad_norm': grad_norm, 'grad_dir': grad_dir}

@@ -221,7 +221,8 @@ def cluster(points, offset, sel, batch, n_batches, voxel_size, eps, min_samples,
 NAMES = ['voxelize', 'cell_index', 'frame_pillars', 'csr_build', 'segment_mean3_maxlabel', 'segment_max',
          'segment_max_backward', 'segment_sum', 'pillar_scatter', 'gather_rows', 'bilinear_gather',
          'bilinear_gather_backward', 'bev_warp', 'rigid_transform', 'chamfer_forward', 'chamfer_backward',
-         'rows_linear', 'rows_wgrad', 'rows_linear_supported', 'pfn_features', 'scatter_sum_small', 'sinkhorn_kabsch', 'cluster', 'sample_subsets', 'upload_small', 'bilinear_gather_backward_sorted', 'prep_points', 'sinkhorn_forward', 'sinkhorn_backward']
+         'rows_linear', 'rows_wgrad', 'rows_linear_supported', 'pfn_features', 'scatter_sum_small', 'sinkhorn_kabsch', 'cluster', 'sample_subsets', 'upload_small', 'bilinear_gather_backward_sorted', 'prep_points', 'sinkhorn_forward', 'sinkhorn_backward',
+         'seg_loss_forward', 'seg_loss_backward', 'offset_loss_forward', 'offset_loss_backward']
 
 
 def install(monkeypatch=None):
@@ -288,3 +289,55 @@ def sinkhorn_backward(grad_log_perm, log_alpha, lse_rows, lse_cols):
         x = log_alpha.detach().clone().requires_grad_(True)
         _sinkhorn_ref(x, int(lse_rows[0])).backward(grad_log_perm)
     return x.grad
+
+
+def _seg_rows(logits, plane, rows, n):
+    """The selected [n,2] logit rows of either layout (see include/pcacc.h L1) and their flat positions."""
+    flat = logits.detach().reshape(-1)
+    i = rows if rows is not None else torch.arange(n)
+    a = (i // plane) * 2 * plane + i % plane if plane > 0 else i * 2
+    step = plane if plane > 0 else 1
+    return torch.stack((flat[a], flat[a + step]), 1).float(), a, step
+
+
+def seg_loss_forward(logits, plane, labels, rows, n):
+    z, _, _ = _seg_rows(logits, plane, rows, n)
+    y = labels[rows] if rows is not None else labels[:n]
+    r = oracle.seg_loss(_np(z), _np(y))
+    metric = np.stack([r['metric'][k] for k in ('intersection', 'union', 'pred_positives', 'gt_positives')])
+    grads = torch.from_numpy(np.stack([r['grad_bce'], r['grad_lovasz']]))      # rides along in the slot of the Jaccard gradients
+    return torch.tensor([r['bce_loss'], r['lovasz_loss']], dtype=torch.float32), torch.from_numpy(metric), grads, torch.zeros(8)
+
+
+def seg_loss_backward(logits, plane, labels, rows, n, lovasz_grad, saved, grad_bce, grad_lovasz):
+    _, a, step = _seg_rows(logits, plane, rows, n)
+    gb = grad_bce if grad_bce is not None else 0.0
+    gl = grad_lovasz if grad_lovasz is not None else 0.0
+    g = (lovasz_grad[0] * gb + lovasz_grad[1] * gl).to(logits.dtype)
+    out = torch.zeros(logits.numel(), dtype=logits.dtype)
+    out[a] = g[:, 0]
+    out[a + step] = g[:, 1]
+    return out.reshape(logits.shape)
+
+
+def offset_loss_forward(points, time_indice, inst_labels, label_base, ego_motion, inst_motion, n_frames, transformed_points, offset_est, rows):
+    n = points.shape[0]
+    fb = np.zeros(n, np.int64)
+    fb[_np(rows) if rows is not None else slice(None)] = 1
+    base = _np(label_base).tolist() + [inst_motion.shape[0]]
+    motions = [_np(inst_motion)[base[b]:base[b + 1]] for b in range(len(base) - 1)]
+    r = oracle.offset_loss(_np(points), _np(time_indice), _np(inst_labels), fb, _np(ego_motion), motions, _np(transformed_points), _np(offset_est))
+    return (torch.tensor([r['offset_norm_loss'], r['offset_dir_loss'], r['offset_l2_error']], dtype=torch.float32),
+            torch.from_numpy(r['offset_gt'].astype(np.float32)))
+
+
+def offset_loss_backward(offset_gt, offset_est, rows, grad_norm, grad_dir):
+    est = offset_est.detach().clone().requires_grad_(True)
+    with torch.enable_grad():
+        e = est[rows] if rows is not None else est
+        norm = torch.abs(offset_gt - e).mean(dim=0).sum()
+        ngt = offset_gt / (torch.norm(offset_gt, dim=1, p=2).unsqueeze(-1) + 1e-20)
+        nest = e / (torch.norm(e, dim=1, p=2).unsqueeze(-1) + 1e-20)
+        dirl = (1 - (ngt * nest).sum(-1)).mean()
+        total = norm * (grad_norm if grad_norm is not None else 0.0) + dirl * (grad_dir if grad_dir is not None else 0.0)
+    return torch.autograd.grad(total, est)[0]

@@ -1,15 +1,16 @@
 """Training loss and the IoU bookkeeping that defines `mos_iou`: host mirror of libs/loss.py (FuseLoss,
 compute_iou), libs/lovasz_softmax.py (Lovasz-Softmax, Berman et al. 2018, MIT) and libs/outlier_loss.py.
 
-Needed so that BASELINE.json's "fwd+bwd" metric runs end to end; plain PyTorch-ROCm (SURVEY.md 8f rank 3 lists
-fused loss kernels as a later row).  The cluster-evaluation hook (test mode only) is not carried over.
+Needed so that BASELINE.json's "fwd+bwd" metric runs end to end.  The terms that read the path's large tensors -- the two
+segmentation losses (cross entropy + Lovasz + IoU counters) and the offset loss -- are fused HIP passes (SURVEY.md 8f rank 3,
+csrc/loss.hip, ops.seg_loss / ops.offset_loss); the rest is a handful of scalar operations.  The cluster-evaluation hook (test
+mode only) is not carried over.
 """
 import numpy as np
 import torch
 import torch.nn as nn
 
-from . import native
-from .ops import scatter
+from . import native, ops
 from .tpointnet import ego_motion_compensation, reconstruct_sequence
 
 _EPS = 1e-20
@@ -30,18 +31,6 @@ def compute_iou(predictions, gt, n_class, ignore_index):
         union.append(n_pred + n_gt - i)
     return {'intersection': np.array(inter), 'union': np.array(union),
             'pred_positives': np.array(pred_pos), 'gt_positives': np.array(gt_pos)}
-
-
-def _iou_counts(predictions, gt, n_class, ignore_index):
-    """The four count vectors of compute_iou as ONE device tensor [4, n_kept] (intersection, union, pred+, gt+), / 1e3."""
-    rows = []
-    for idx in range(n_class):
-        if idx == ignore_index:
-            continue
-        sel_gt, sel_pred = gt == idx, predictions == idx
-        n_pred, n_gt, inter = sel_pred.sum(), sel_gt.sum(), (sel_gt & sel_pred).sum()
-        rows.append(torch.stack([inter, n_pred + n_gt - inter, n_pred, n_gt]))
-    return torch.stack(rows, dim=1).double() / 1e3
 
 
 def _metric_dict(t):
@@ -108,6 +97,7 @@ class FuseLoss(nn.Module):
         self.n_classes = 2
         self.ignore_index = -1
         self.softmax = nn.Softmax(dim=1)
+        self._w_cache = {}
         for k, v in config.items():
             if k.startswith('w_') or k == 'obj_gamma':
                 setattr(self, k, v)
@@ -117,85 +107,66 @@ class FuseLoss(nn.Module):
         counts = torch.stack([(gt_label == c).sum() for c in range(self.n_classes)]).to(torch.float32) + _EPS
         return torch.clamp(torch.sqrt(counts.sum() / counts), 0, max_weights)
 
-    def get_seg_loss(self, gt, est):
-        """libs/loss.py:110-137."""
-        # CrossEntropyLoss(weight, ignore_index) written out: sum_i w[y_i] * (-log p_i[y_i]) / sum_i w[y_i] over kept rows.
-        # (the library's weighted nll reduction is a single-workgroup kernel: 0.6 ms forward + 0.7 ms backward per call)
-        w = self.get_ce_weights(gt)
-        keep = gt != self.ignore_index
-        safe = torch.where(keep, gt, torch.zeros_like(gt))
-        picked = torch.log_softmax(est, dim=1).gather(1, safe[:, None])[:, 0]
-        wi = w[safe] * keep
-        ce = -(wi * picked).sum() / wi.sum()
-        stats = {'bce_loss': ce, 'lovasz_loss': self.lovasz_loss(self.softmax(est), gt)}
-        stats['metric'] = _iou_counts(est.argmax(1), gt, self.n_classes, self.ignore_index)    # device tensor, see forward()
-        return stats
+    def _weights(self, device, *names):
+        """Loss weights as a device vector (built once): the kernels return their terms as one tensor and the weighted sum is
+        one dot product."""
+        key = (str(device),) + names
+        if key not in self._w_cache:
+            self._w_cache[key] = native.upload_small([float(getattr(self, n)) if n else 0.0 for n in names], torch.float32, device)
+        return self._w_cache[key]
+
+    def get_seg_loss(self, gt, est, rows=None):
+        """libs/loss.py:110-137 on rows `rows` of est / gt (all rows when None): one fused pass (csrc/loss.hip, L1) for the
+        weighted cross entropy (class weights of :90-108), the Lovasz-Softmax term and compute_iou's counters.  'terms' is the
+        differentiable [2] tensor (cross entropy, Lovasz); 'metric' stays on the device until forward()'s single transfer."""
+        terms, metric = ops.seg_loss(est, gt, rows)
+        return {'terms': terms, 'bce_loss': terms.detach()[0], 'lovasz_loss': terms.detach()[1], 'metric': metric}
+
+    def _empty_seg(self, device):
+        zero = {k: np.zeros(2) for k in ('intersection', 'union', 'pred_positives', 'gt_positives')}
+        z = torch.zeros(2, device=device, requires_grad=True)
+        return {'metric': zero, 'terms': z, 'bce_loss': z.detach()[0], 'lovasz_loss': z.detach()[1]}
 
     def get_mos_loss(self, predictions, input_dict):
         """libs/loss.py:140-165: supervised on points that are foreground in GT or in the estimate."""
-        mos_gt, mos_est = input_dict['sd_labels'][:, 0].long(), predictions['mos_est']
+        mos_gt, mos_est = input_dict['sd_labels'][:, 0], predictions['mos_est']
         if '_fb_idx' in predictions:                                      # index list MotionNet already built (no re-sync)
             fb_idx = predictions['_fb_idx']
-            if fb_idx.numel():
-                # index_select: its backward is an index_add, not the sort-based accumulate of tensor indexing (0.25 ms each)
-                return self.get_seg_loss(mos_gt[fb_idx], mos_est.index_select(0, fb_idx))
-            fb_mask = None
         else:
-            fb_mask = torch.logical_or(input_dict['fb_labels'][:, 0] == 1, predictions['fb_est_per_points'][:, 0] == 1)
-        if fb_mask is not None and fb_mask.sum():
-            return self.get_seg_loss(mos_gt[fb_mask], mos_est[fb_mask])
-        zero = {k: np.zeros(2) for k in ('intersection', 'union', 'pred_positives', 'gt_positives')}
-        return {'metric': zero, 'bce_loss': torch.tensor(0., requires_grad=True).to(mos_gt.device),
-                'lovasz_loss': torch.tensor(0., requires_grad=True).to(mos_gt.device)}
+            fb_idx = torch.nonzero(torch.logical_or(input_dict['fb_labels'][:, 0] == 1, predictions['fb_est_per_points'][:, 0] == 1))[:, 0]
+        if fb_idx.numel():
+            return self.get_seg_loss(mos_gt, mos_est, fb_idx)
+        return self._empty_seg(mos_est.device)
 
     def get_fb_loss(self, predictions):
-        """libs/loss.py:167-191: only occupied pillars are supervised."""
-        est = predictions['fb_seg_est'].permute(0, 1, 3, 4, 2).contiguous().view(-1, 2)
-        gt = predictions['fb_seg_gt'].permute(0, 1, 3, 4, 2).contiguous().view(-1)
+        """libs/loss.py:167-191: only occupied pillars are supervised.  The [B,T,2,H,W] head output is read in place (no
+        permute copy); rows = the cell index of every occupied pillar."""
+        est, gt = predictions['fb_seg_est'], predictions['fb_seg_gt']
         if '_cell' in predictions:                                        # occupied cells = the pillars' cell indices
-            cell = predictions['_cell'].long()
-            return self.get_seg_loss(gt[cell], est.index_select(0, cell))
-        mask = predictions['occ_map'].permute(0, 1, 3, 4, 2).contiguous().view(-1) == 1
-        return self.get_seg_loss(gt[mask], est[mask])
+            return self.get_seg_loss(gt, est, predictions['_cell'])
+        return self.get_seg_loss(gt, est, torch.nonzero(predictions['occ_map'].reshape(-1) == 1)[:, 0])
 
     def get_offset_loss(self, input_dict, predictions):
-        """libs/loss.py:194-250."""
+        """libs/loss.py:194-250: one fused pass (csrc/loss.hip, L2).  GT reconstruction and instance centres of all samples at
+        once (the reference loops over samples with boolean masks, :216-232: four host syncs per sample): points carry their
+        sample in time_indice[:, 0], the instance tables are concatenated with per-sample label offsets known on the host."""
         input_points = input_dict['input_points']
-        time_indice = input_dict['time_indice']
-        ego_motion_gt = input_dict['ego_motion_gt']
-        inst_labels = input_dict['inst_labels'][:, 0].long()
         bbox_tsfm = input_dict['inst_motion_gt']
         device = input_points.device
         if '_rec_idx' in predictions:
-            fb_mask = predictions['_rec_idx']                              # index list of the GT-foreground points
-            empty = fb_mask.numel() == 0
+            rows = predictions['_rec_idx']                                 # index list of the GT-foreground points
         else:
-            fb_mask = input_dict['fb_labels'][:, 0] == 1
-            empty = not fb_mask.sum()
-        if empty:
-            z = torch.tensor(0., requires_grad=True).to(device)
-            return z, torch.tensor(0., requires_grad=True).to(device), 0
-        n_frames = ego_motion_gt.size(1)
-        # GT reconstruction and instance centres of all samples at once (the reference loops over samples with boolean masks,
-        # libs/loss.py:216-232: four host syncs per sample): points carry their sample in time_indice[:, 0], so the ego poses
-        # are indexed by b*T+t and the instance tables are concatenated with per-sample label offsets known on the host.
+            rows = torch.nonzero(input_dict['fb_labels'][:, 0] == 1)[:, 0]
+        if rows.numel() == 0:
+            z = torch.zeros(3, device=device, requires_grad=True)
+            return z, None
         sizes = [m.shape[0] for m in bbox_tsfm]
         base = native.upload_small([sum(sizes[:b]) for b in range(len(sizes))], torch.int64, device)
-        b_idx, t_idx = time_indice[:, 0].long(), time_indice[:, 1].long()
-        lab = inst_labels + base[b_idx]
-        comp = ego_motion_compensation(input_points, b_idx * n_frames + t_idx, ego_motion_gt.reshape(-1, 4, 4))
-        rec = reconstruct_sequence(comp, t_idx, lab, torch.cat([m.to(device) for m in bbox_tsfm], dim=0), n_frames)
-        centre = scatter(rec, lab, dim=0, dim_size=sum(sizes), reduce='mean')       # K known on the host: no lab.max() sync
-        inst_centers = centre[lab][:, :2]
-        gt_offset = (inst_centers - predictions['transformed_points'][:, :2])[fb_mask]
-        est_offset = predictions['offset_est'].index_select(0, fb_mask) if fb_mask.dtype == torch.int64 else predictions['offset_est'][fb_mask]
-        offset_norm_loss = torch.abs(gt_offset - est_offset).mean(dim=0).sum()
-        offset_l2_error = torch.norm(gt_offset - est_offset, p=2, dim=1).mean()       # float after forward()'s single sync
-        ngt = gt_offset / (torch.norm(gt_offset, dim=1, p=2).unsqueeze(-1) + _EPS)
-        nest = est_offset / (torch.norm(est_offset, dim=1, p=2).unsqueeze(-1) + _EPS)
-        offset_dir_loss = (1 - (ngt * nest).sum(-1)).mean()
+        out, gt_offset = ops.offset_loss(predictions['offset_est'], input_points, input_dict['time_indice'], input_dict['inst_labels'][:, 0], base,
+                                         input_dict['ego_motion_gt'], torch.cat([m.to(device) for m in bbox_tsfm], dim=0),
+                                         predictions['transformed_points'], rows)
         predictions['offset_gt'] = gt_offset
-        return offset_norm_loss, offset_dir_loss, offset_l2_error
+        return out, gt_offset
 
     def get_tpointnet_loss(self, predictions):
         """libs/loss.py:253-263."""
@@ -220,17 +191,19 @@ class FuseLoss(nn.Module):
         total = total + perm_loss
         stats['perm_loss'] = perm_loss
         fb = self.get_fb_loss(predictions)
-        fb_loss = self.w_fb_bce_loss * fb['bce_loss'] + self.w_fb_lovasz_loss * fb['lovasz_loss']
+        dev = total.device
+        fb_loss = torch.dot(fb['terms'], self._weights(dev, 'w_fb_bce_loss', 'w_fb_lovasz_loss'))
         total = total + fb_loss
         stats['fb_loss'], stats['fb_metric'] = fb_loss, fb['metric']
         mos = self.get_mos_loss(predictions, input_dict)
-        mos_loss = self.w_mos_bce_loss * mos['bce_loss'] + self.w_mos_lovasz_loss * mos['lovasz_loss']
+        mos_loss = torch.dot(mos['terms'], self._weights(dev, 'w_mos_bce_loss', 'w_mos_lovasz_loss'))
         total = total + mos_loss
         stats['mos_loss'], stats['mos_metric'] = mos_loss, mos['metric']
-        o_norm, o_dir, o_l2 = self.get_offset_loss(input_dict, predictions)
-        offset_loss = o_dir * self.w_offset_dir_loss + o_norm * self.w_offset_norm_loss
+        off, _ = self.get_offset_loss(input_dict, predictions)
+        offset_loss = torch.dot(off, self._weights(dev, 'w_offset_norm_loss', 'w_offset_dir_loss', None))
         total = total + offset_loss
-        stats.update(offset_loss=offset_loss, offset_l1_loss=o_norm, offset_dir_loss=o_dir, offset_l2_error=o_l2)
+        off = off.detach()
+        stats.update(offset_loss=offset_loss, offset_l1_loss=off[0], offset_dir_loss=off[1], offset_l2_error=off[2])
         if 'tpointnet_loss_terms' in predictions:
             obj_loss = self.get_tpointnet_loss(predictions) * self.w_obj_loss
             total = total + obj_loss

@@ -50,6 +50,8 @@ EXPORTS = [
     'pcacc_rows_linear_bf16', 'pcacc_rows_linear_mixed', 'pcacc_rows_wgrad_mixed',
     'pcacc_segment_max_t', 'pcacc_segment_max_backward_t', 'pcacc_segment_sum_t', 'pcacc_rows_wgrad_bf16_workspace_bytes', 'pcacc_rows_wgrad_bf16', 'pcacc_sample_subsets', 'pcacc_conv3x3_wgrad_workspace_bytes', 'pcacc_conv3x3_wgrad_bf16', 'pcacc_upload_words', 'pcacc_bilinear_base_cells', 'pcacc_bilinear_gather_backward_sorted', 'pcacc_prep_points',
     'pcacc_sinkhorn_train_workspace_bytes', 'pcacc_sinkhorn_forward', 'pcacc_sinkhorn_backward',
+    'pcacc_seg_loss_workspace_bytes', 'pcacc_seg_loss_forward', 'pcacc_seg_loss_backward',
+    'pcacc_offset_loss_workspace_bytes', 'pcacc_offset_loss_forward', 'pcacc_offset_loss_backward',
 ]
 
 
@@ -575,3 +577,65 @@ def sinkhorn_backward(grad_log_perm, log_alpha, lse_rows, lse_cols):
                                          _dev(lse_rows, torch.float32), _dev(lse_cols, torch.float32), int(P), int(k), int(n_iters),
                                          _dev(g), _dev(ws), ctypes.c_size_t(ws.numel()), _stream()), 'sinkhorn_backward')
     return g
+
+
+# ---------------------------------------------------------------------------------------------------
+def _opt(t, dtype, what):
+    return _dev(t, dtype, what) if t is not None else None
+
+
+def seg_loss_forward(logits, plane, labels, rows, n):
+    """L1 (include/pcacc.h): logits = the whole f32 / bf16 logit tensor ([n_total,2] rows when plane == 0, NCHW planes of
+    `plane` cells otherwise), labels [n_total] i64, rows [n] i64 or None.  Returns (loss [2] f32 = cross entropy, Lovasz;
+    metric [4,2] f64; lovasz_grad [2,n] f32; saved [8] f32) -- the last two are for seg_loss_backward."""
+    dev = logits.device
+    loss = torch.empty((2,), dtype=torch.float32, device=dev)
+    metric = torch.empty((4, 2), dtype=torch.float64, device=dev)
+    lov = torch.empty((2, n), dtype=torch.float32, device=dev)
+    saved = torch.zeros((8,), dtype=torch.float32, device=dev)
+    need = ctypes.c_size_t(0)
+    _check(lib().pcacc_seg_loss_workspace_bytes(_i64(n), ctypes.byref(need)), 'seg_loss_workspace')
+    ws = _ws(need.value, dev)
+    _check(lib().pcacc_seg_loss_forward(_dev(logits, None, 'logits'), _dtype_code(logits), _i64(plane), _dev(labels, torch.int64, 'labels'),
+                                        _opt(rows, torch.int64, 'rows'), _i64(n), _dev(loss), _dev(metric), _dev(lov), _dev(saved), _dev(ws),
+                                        ctypes.c_size_t(ws.numel()), _stream()), 'seg_loss_forward')
+    return loss, metric, lov, saved
+
+
+def seg_loss_backward(logits, plane, labels, rows, n, lovasz_grad, saved, grad_bce, grad_lovasz):
+    """Gradient of grad_bce * cross entropy + grad_lovasz * Lovasz w.r.t. the whole logit tensor (0 outside the rows)."""
+    grad = torch.empty_like(logits)
+    _check(lib().pcacc_seg_loss_backward(_dev(logits, None, 'logits'), _dtype_code(logits), _i64(plane), _dev(labels, torch.int64, 'labels'),
+                                         _opt(rows, torch.int64, 'rows'), _i64(n), _i64(logits.numel() // 2), _dev(lovasz_grad, torch.float32),
+                                         _dev(saved, torch.float32), _opt(grad_bce, torch.float32, 'grad_bce'),
+                                         _opt(grad_lovasz, torch.float32, 'grad_lovasz'), _dev(grad), _stream()), 'seg_loss_backward')
+    return grad
+
+
+def offset_loss_forward(points, time_indice, inst_labels, label_base, ego_motion, inst_motion, n_frames, transformed_points, offset_est, rows):
+    """L2 (include/pcacc.h): returns (out [3] f32 = L1 term, direction term, mean L2 error; offset_gt [m,2] f32)."""
+    dev = points.device
+    n, k = points.shape[0], inst_motion.shape[0]
+    m = rows.shape[0] if rows is not None else n
+    out = torch.empty((3,), dtype=torch.float32, device=dev)
+    gt = torch.empty((m, 2), dtype=torch.float32, device=dev)
+    need = ctypes.c_size_t(0)
+    _check(lib().pcacc_offset_loss_workspace_bytes(_i64(m), _i64(k), ctypes.byref(need)), 'offset_loss_workspace')
+    ws = _ws(need.value, dev)
+    _check(lib().pcacc_offset_loss_forward(_dev(points, torch.float32, 'points'), _dev(time_indice, torch.int64, 'time_indice'),
+                                           _dev(inst_labels, torch.int64, 'inst_labels'), _dev(label_base, torch.int64, 'label_base'),
+                                           _dev(ego_motion, torch.float32, 'ego_motion'), _dev(inst_motion, torch.float32, 'inst_motion'),
+                                           int(n_frames), _i64(n), _i64(k), _dev(transformed_points, torch.float32, 'transformed_points'),
+                                           _dev(offset_est, torch.float32, 'offset_est'), _opt(rows, torch.int64, 'rows'), _i64(m), _dev(out),
+                                           _dev(gt), _dev(ws), ctypes.c_size_t(ws.numel()), _stream()), 'offset_loss_forward')
+    return out, gt
+
+
+def offset_loss_backward(offset_gt, offset_est, rows, grad_norm, grad_dir):
+    grad = torch.empty_like(offset_est)
+    m = offset_gt.shape[0]
+    _check(lib().pcacc_offset_loss_backward(_dev(offset_gt, torch.float32), _dev(offset_est, torch.float32, 'offset_est'),
+                                            _opt(rows, torch.int64, 'rows'), _i64(m), _i64(offset_est.shape[0]),
+                                            _opt(grad_norm, torch.float32, 'grad_norm'), _opt(grad_dir, torch.float32, 'grad_dir'), _dev(grad),
+                                            _stream()), 'offset_loss_backward')
+    return grad

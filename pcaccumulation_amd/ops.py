@@ -516,3 +516,72 @@ class _Sinkhorn(torch.autograd.Function):
 
 def sinkhorn(log_alpha, n_iters):
     return _Sinkhorn.apply(log_alpha, int(n_iters))
+
+
+# ---------------------------------------------------------------------------------------------------
+class _SegLoss(torch.autograd.Function):
+    """L1 (csrc/loss.hip): weighted cross entropy + Lovasz-Softmax + IoU counters of libs/loss.py:110-137 on the selected rows of
+    a two-class logit tensor, read in place ([n,2] rows or an NCHW head output).  Returns (terms [2] = cross entropy, Lovasz;
+    metric [4,2] f64 = compute_iou's counters)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, rows, plane):
+        n = rows.shape[0] if rows is not None else logits.numel() // 2
+        terms, metric, lov, saved = native.seg_loss_forward(logits, plane, labels, rows, n)
+        ctx.save_for_backward(logits, labels, rows, lov, saved)
+        ctx.plane, ctx.n = plane, n
+        ctx.mark_non_differentiable(metric)
+        return terms, metric
+
+    @staticmethod
+    def backward(ctx, grad_terms, _):
+        logits, labels, rows, lov, saved = ctx.saved_tensors
+        g = grad_terms.contiguous().float()
+        return native.seg_loss_backward(logits, ctx.plane, labels, rows, ctx.n, lov, saved, g[0:1], g[1:2]), None, None, None
+
+
+def seg_loss(logits, labels, rows=None):
+    """logits [n,2] or [..., 2, H, W] (f32 / bf16), labels with one entry per row (any integer type, flattened), rows = int64
+    indices of the supervised rows or None for all.  -> (terms [2], metric [4,2])."""
+    if logits.dim() >= 3 and not logits.is_contiguous() and logits.movedim(-3, -1).is_contiguous():
+        logits = logits.movedim(-3, -1).reshape(-1, 2)                           # channels-last head output: already rows
+    if logits.dim() >= 3:
+        plane = logits.shape[-1] * logits.shape[-2]
+        assert logits.shape[-3] == 2
+    else:
+        plane = 0
+        assert logits.dim() == 2 and logits.shape[1] == 2
+    if logits.dtype not in (torch.float32, torch.bfloat16):
+        logits = logits.float()
+    labels = labels.reshape(-1)
+    if labels.dtype != torch.int64:
+        labels = labels.long()
+    if rows is not None and rows.dtype != torch.int64:
+        rows = rows.long()
+    return _SegLoss.apply(logits.contiguous(), labels.contiguous(), rows, plane)
+
+
+class _OffsetLoss(torch.autograd.Function):
+    """L2 (csrc/loss.hip): libs/loss.py:194-250 in three launches; gradient w.r.t. the estimated offsets only (the ground truth and
+    the ego-compensated points carry none, models/motionnet.py:207-209)."""
+
+    @staticmethod
+    def forward(ctx, offset_est, points, time_indice, inst_labels, label_base, ego_motion, inst_motion, transformed_points, rows):
+        out, gt = native.offset_loss_forward(points, time_indice, inst_labels, label_base, ego_motion, inst_motion, ego_motion.shape[1],
+                                             transformed_points, offset_est, rows)
+        ctx.save_for_backward(gt, offset_est, rows)
+        ctx.mark_non_differentiable(gt)
+        return out, gt
+
+    @staticmethod
+    def backward(ctx, grad_out, _):
+        gt, est, rows = ctx.saved_tensors
+        g = grad_out.contiguous().float()
+        return (native.offset_loss_backward(gt, est, rows, g[0:1], g[1:2]),) + (None,) * 8
+
+
+def offset_loss(offset_est, points, time_indice, inst_labels, label_base, ego_motion, inst_motion, transformed_points, rows):
+    """-> (out [3] = L1 term, direction term, mean L2 error; offset_gt [m,2])."""
+    f = lambda t: t.detach().float().contiguous()
+    return _OffsetLoss.apply(offset_est.float().contiguous(), f(points), time_indice.long().contiguous(), inst_labels.long().contiguous(),
+                             label_base, f(ego_motion), f(inst_motion), f(transformed_points), rows)

@@ -185,3 +185,32 @@ def test_chamfer_against_live_reference_build_when_present():
     got = oracle.chamfer_forward(a, b)
     for r, o in zip(ref, got):
         assert np.array_equal(r.numpy(), o)
+
+
+def _offset_args(g, p):
+    return (g[p + 'input_points'], g[p + 'time_indice'], g[p + 'inst_labels'], g[p + 'fb_labels'], g[p + 'ego_motion_gt'],
+            [g[p + 'inst_motion_gt_%d' % b] for b in range(int(g[p + 'n_samples']))], g[p + 'transformed_points'], g[p + 'offset_est'])
+
+
+def test_loss_terms(golden):
+    """L1/L2: the oracle's segmentation and offset losses against the reference's own FuseLoss.get_seg_loss /
+    get_offset_loss and the gradients its autograd produced (tests/golden/make_golden_loss.py).  fp32 reductions: 1e-6 relative
+    on the values; gradients to 1e-3 of their largest entry (ties between equal errors pick a sub-gradient)."""
+    g = golden('loss')
+    for name in g['seg_names']:
+        r = oracle.seg_loss(g['seg_%s_logits' % name], g['seg_%s_labels' % name])
+        assert abs(r['bce_loss'] - g['seg_%s_bce' % name]) < 2e-6 * max(1, abs(g['seg_%s_bce' % name])), name
+        assert abs(r['lovasz_loss'] - g['seg_%s_lovasz' % name]) < 1e-6, name
+        m = np.stack([r['metric'][k] for k in ('intersection', 'union', 'pred_positives', 'gt_positives')])
+        np.testing.assert_allclose(m, g['seg_%s_metric' % name], rtol=0, atol=1e-12)
+        for k in ('grad_bce', 'grad_lovasz'):
+            want = g['seg_%s_%s' % (name, k)]
+            assert np.abs(r[k] - want).max() <= 1e-3 * np.abs(want).max() + 1e-12, (name, k)
+    for ci in range(2):
+        p = 'off%d_' % ci
+        r = oracle.offset_loss(*_offset_args(g, p))
+        assert abs(r['offset_norm_loss'] - g[p + 'norm']) < 1e-5 and abs(r['offset_dir_loss'] - g[p + 'dir']) < 1e-6
+        assert abs(r['offset_l2_error'] - g[p + 'l2']) < 1e-5
+        np.testing.assert_allclose(r['offset_gt'], g[p + 'offset_gt'], atol=1e-5)
+        np.testing.assert_allclose(r['grad_norm'], g[p + 'grad_norm'], atol=1e-9)
+        np.testing.assert_allclose(r['grad_dir'], g[p + 'grad_dir'], atol=1e-8)
