@@ -381,6 +381,14 @@ int pcacc_offset_loss_forward(const float *points, const int64_t *time_indice, c
 int pcacc_offset_loss_backward(const float *offset_gt, const float *offset_est, const int64_t *rows, int64_t m, int64_t n,
                                const float *grad_norm, const float *grad_dir, float *grad_est, void *stream);
 
+/* A9. Max over the frames of a map stack -- models/stpn.py:83 (`torch.max(x, dim=2)` between the temporal convolutions and the
+ * U-Net): x [n_seq, frames, plane] f32 or bf16 (plane = H*W*C contiguous elements, a multiple of 4 / 8), out [n_seq, plane],
+ * arg [n_seq, plane] u8 = the winning frame (lowest on ties; a NaN wins).  backward: grad_x[s,t,p] = arg[s,p] == t ? grad_out[s,p] : 0,
+ * every element written. */
+int pcacc_frames_max(const void *x, int dtype, int64_t n_seq, int32_t frames, int64_t plane, void *out, uint8_t *arg, void *stream);
+int pcacc_frames_max_backward(const void *grad_out, const uint8_t *arg, int dtype, int64_t n_seq, int32_t frames, int64_t plane,
+                              void *grad_x, void *stream);
+
 /* Host words -> device memory as kernel arguments (asynchronous, unlike a pageable hipMemcpy on the compute stream):
  * n 32-bit words from host_words to dst, 240 per launch.  For the per-step index tables a host loop of the reference
  * becomes (sample offsets, per-pair counts, thresholds). */

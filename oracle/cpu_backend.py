@@ -222,7 +222,7 @@ NAMES = ['voxelize', 'cell_index', 'frame_pillars', 'csr_build', 'segment_mean3_
          'segment_max_backward', 'segment_sum', 'pillar_scatter', 'gather_rows', 'bilinear_gather',
          'bilinear_gather_backward', 'bev_warp', 'rigid_transform', 'chamfer_forward', 'chamfer_backward',
          'rows_linear', 'rows_wgrad', 'rows_linear_supported', 'pfn_features', 'scatter_sum_small', 'sinkhorn_kabsch', 'cluster', 'sample_subsets', 'upload_small', 'bilinear_gather_backward_sorted', 'prep_points', 'sinkhorn_forward', 'sinkhorn_backward',
-         'seg_loss_forward', 'seg_loss_backward', 'offset_loss_forward', 'offset_loss_backward']
+         'seg_loss_forward', 'seg_loss_backward', 'offset_loss_forward', 'offset_loss_backward', 'frames_max', 'frames_max_backward']
 
 
 def install(monkeypatch=None):
@@ -341,3 +341,16 @@ def offset_loss_backward(offset_gt, offset_est, rows, grad_norm, grad_dir):
         dirl = (1 - (ngt * nest).sum(-1)).mean()
         total = norm * (grad_norm if grad_norm is not None else 0.0) + dirl * (grad_dir if grad_dir is not None else 0.0)
     return torch.autograd.grad(total, est)[0]
+
+
+def frames_max(x):
+    """models/stpn.py:83: max over the frame axis; the winning frame is the lowest index attaining it."""
+    v = x.detach().float()
+    out = v.max(dim=1)[0]
+    arg = (v == out.unsqueeze(1)).to(torch.uint8).argmax(dim=1).to(torch.uint8)
+    return out.to(x.dtype), arg
+
+
+def frames_max_backward(grad_out, arg, frames):
+    t = torch.arange(frames).view((1, frames) + (1,) * (grad_out.dim() - 1))
+    return torch.where(arg.unsqueeze(1).long() == t, grad_out.unsqueeze(1), torch.zeros((), dtype=grad_out.dtype))

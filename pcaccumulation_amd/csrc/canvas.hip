@@ -313,3 +313,115 @@ extern "C" int pcacc_prep_points(const double *points, const double *tsfm12, con
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// A9. Max over the T frames of a [S,T,P] map stack (models/stpn.py:83 `torch.max(x, dim=2)` after the temporal convs), rows of
+// P = H*W*C contiguous elements, f32 or bf16.  One streaming pass: 16 bytes per lane and frame, the winning frame (lowest t on
+// ties) kept as one byte per element for the backward pass, which writes the whole gradient (zeros included) in one pass.
+// The library reduction walks this layout at ~0.2 TB/s.
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool BF>
+__global__ __launch_bounds__(256) void frames_max_kernel(const void *__restrict__ x, int64_t n_seq, int frames, int64_t plane_vec,
+                                                         void *__restrict__ out, uint8_t *__restrict__ arg)
+{
+    constexpr int V = BF ? 8 : 4;
+    const int64_t total = n_seq * plane_vec;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t s = e / plane_vec, p = e - s * plane_vec;
+        float best[V];
+        uint8_t who[V];
+        for (int t = 0; t < frames; ++t) {
+            const uint4 raw = reinterpret_cast<const uint4 *>(x)[(s * frames + t) * plane_vec + p];
+            float v[V];
+            if (BF) {
+                v[0] = pcacc_bf16_lo(raw.x), v[1] = pcacc_bf16_hi(raw.x), v[2] = pcacc_bf16_lo(raw.y), v[3] = pcacc_bf16_hi(raw.y);
+                v[V - 4] = pcacc_bf16_lo(raw.z), v[V - 3] = pcacc_bf16_hi(raw.z), v[V - 2] = pcacc_bf16_lo(raw.w), v[V - 1] = pcacc_bf16_hi(raw.w);
+            } else {
+                v[0] = __uint_as_float(raw.x), v[1] = __uint_as_float(raw.y), v[2] = __uint_as_float(raw.z), v[3] = __uint_as_float(raw.w);
+            }
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const bool take = t == 0 || v[k] > best[k] || (v[k] != v[k] && best[k] == best[k]);   // NaN propagates like torch.max
+                best[k] = take ? v[k] : best[k];
+                who[k] = take ? (uint8_t)t : who[k];
+            }
+        }
+        if (BF) {
+            reinterpret_cast<uint4 *>(out)[e] = make_uint4(pcacc_pack_bf16x2(best[0], best[1]), pcacc_pack_bf16x2(best[2], best[3]),
+                                                           pcacc_pack_bf16x2(best[V - 4], best[V - 3]), pcacc_pack_bf16x2(best[V - 2], best[V - 1]));
+            reinterpret_cast<uint2 *>(arg)[e] = make_uint2(who[0] | who[1] << 8 | who[2] << 16 | who[3] << 24,
+                                                           who[V - 4] | who[V - 3] << 8 | who[V - 2] << 16 | who[V - 1] << 24);
+        } else {
+            reinterpret_cast<float4 *>(out)[e] = make_float4(best[0], best[1], best[2], best[3]);
+            reinterpret_cast<uint32_t *>(arg)[e] = who[0] | who[1] << 8 | who[2] << 16 | who[3] << 24;
+        }
+    }
+}
+
+template <bool BF>
+__global__ __launch_bounds__(256) void frames_max_bwd_kernel(const void *__restrict__ grad_out, const uint8_t *__restrict__ arg, int64_t n_seq,
+                                                             int frames, int64_t plane_vec, void *__restrict__ grad_x)
+{
+    const int64_t total = n_seq * plane_vec;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t s = e / plane_vec, p = e - s * plane_vec;
+        const uint4 g = reinterpret_cast<const uint4 *>(grad_out)[e];
+        uint32_t w0, w1 = 0;
+        if (BF) {
+            const uint2 a = reinterpret_cast<const uint2 *>(arg)[e];
+            w0 = a.x, w1 = a.y;
+        } else {
+            w0 = reinterpret_cast<const uint32_t *>(arg)[e];
+        }
+        for (int t = 0; t < frames; ++t) {
+            uint4 o;
+            if (BF) {
+                const uint32_t m0 = ((w0 & 0xff) == (uint32_t)t ? 0xffffu : 0u) | (((w0 >> 8) & 0xff) == (uint32_t)t ? 0xffff0000u : 0u);
+                const uint32_t m1 = (((w0 >> 16) & 0xff) == (uint32_t)t ? 0xffffu : 0u) | ((w0 >> 24) == (uint32_t)t ? 0xffff0000u : 0u);
+                const uint32_t m2 = ((w1 & 0xff) == (uint32_t)t ? 0xffffu : 0u) | (((w1 >> 8) & 0xff) == (uint32_t)t ? 0xffff0000u : 0u);
+                const uint32_t m3 = (((w1 >> 16) & 0xff) == (uint32_t)t ? 0xffffu : 0u) | ((w1 >> 24) == (uint32_t)t ? 0xffff0000u : 0u);
+                o = make_uint4(g.x & m0, g.y & m1, g.z & m2, g.w & m3);
+            } else {
+                o = make_uint4((w0 & 0xff) == (uint32_t)t ? g.x : 0u, ((w0 >> 8) & 0xff) == (uint32_t)t ? g.y : 0u,
+                               ((w0 >> 16) & 0xff) == (uint32_t)t ? g.z : 0u, (w0 >> 24) == (uint32_t)t ? g.w : 0u);
+            }
+            reinterpret_cast<uint4 *>(grad_x)[(s * frames + t) * plane_vec + p] = o;
+        }
+    }
+}
+
+static int frames_max_args(int dtype, int64_t n_seq, int frames, int64_t plane, int64_t *plane_vec)
+{
+    if (dtype != PCACC_F32 && dtype != PCACC_BF16) return PCACC_E_ARG;
+    const int v = dtype == PCACC_BF16 ? 8 : 4;
+    if (n_seq < 0 || frames <= 0 || frames > 255 || plane <= 0 || plane % v) return PCACC_E_ARG;
+    *plane_vec = plane / v;
+    return PCACC_OK;
+}
+
+extern "C" int pcacc_frames_max(const void *x, int dtype, int64_t n_seq, int32_t frames, int64_t plane, void *out, uint8_t *arg, void *stream)
+{
+    int64_t pv;
+    if (frames_max_args(dtype, n_seq, frames, plane, &pv) != PCACC_OK) return PCACC_E_ARG;
+    if (n_seq == 0) return PCACC_OK;
+    if (!x || !out || !arg) return PCACC_E_ARG;
+    const int grid = pcacc_grid(n_seq * pv, 256, PCACC_CUS * 16);
+    if (dtype == PCACC_BF16) frames_max_kernel<true><<<grid, 256, 0, pcacc_stream(stream)>>>(x, n_seq, frames, pv, out, arg);
+    else frames_max_kernel<false><<<grid, 256, 0, pcacc_stream(stream)>>>(x, n_seq, frames, pv, out, arg);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}
+
+extern "C" int pcacc_frames_max_backward(const void *grad_out, const uint8_t *arg, int dtype, int64_t n_seq, int32_t frames, int64_t plane,
+                                         void *grad_x, void *stream)
+{
+    int64_t pv;
+    if (frames_max_args(dtype, n_seq, frames, plane, &pv) != PCACC_OK) return PCACC_E_ARG;
+    if (n_seq == 0) return PCACC_OK;
+    if (!grad_out || !arg || !grad_x) return PCACC_E_ARG;
+    const int grid = pcacc_grid(n_seq * pv, 256, PCACC_CUS * 16);
+    if (dtype == PCACC_BF16) frames_max_bwd_kernel<true><<<grid, 256, 0, pcacc_stream(stream)>>>(grad_out, arg, n_seq, frames, pv, grad_x);
+    else frames_max_bwd_kernel<false><<<grid, 256, 0, pcacc_stream(stream)>>>(grad_out, arg, n_seq, frames, pv, grad_x);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}

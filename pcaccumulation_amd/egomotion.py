@@ -78,6 +78,12 @@ def kabsch_transformation_estimation(x1, x2, weights=None, normalize_w=True, eps
     return rotation, translation, res, False
 
 
+class PermList(list):
+    """results['perm_matrix']: the per-pair [1,k,k] matrices of the reference (models/egomotion.py:352), plus the [P,k,k] tensor
+    they are slices of when one batched solve produced them all (`stacked`), so that the outlier loss is two reductions."""
+    stacked = None
+
+
 class _RowRef(object):
     """Rows `index` of a 2-D `source`, not gathered yet: the key-point features of all pairs are fetched with ONE index op,
     so the backward is one index_put into one zero map instead of 32 maps of [n_cells, C] summed pairwise (5 ms per step)."""
@@ -260,6 +266,8 @@ class EgoMotionHead(nn.Module):
         rel_est_all = get_relative_pose_torch(chain[:, 1:], chain[:, :-1], self.dataset)
         p = 0
         ref_pts, lens = [], []
+        if isinstance(perm_matrix_list, PermList):
+            perm_matrix_list.stacked = perm if len(perm_matrix_list) == 0 else None     # all pairs of this forward as one tensor
         for b, (points_list, feats_list, bg_list, gt) in enumerate(sequences):
             for lst in (relative_pose_est_list, relative_pose_gt_list, chained_pose_est_list, chained_pose_gt_list):
                 lst.append(identity)
@@ -312,7 +320,7 @@ class EgoMotionHead(nn.Module):
         B, T = pidx.batch_size, pidx.nt
         sp = pidx.frame_pillars()[0].long()
         cells = pidx.cell.long()
-        perm_l, rel_est, rel_gt, ch_est, ch_gt = [], [], [], [], []
+        perm_l, rel_est, rel_gt, ch_est, ch_gt = PermList(), [], [], [], []
         sequences, bg_start = [], 0
         for b in range(B):
             points_list, getters, bg_list = [], [], []
@@ -332,7 +340,7 @@ class EgoMotionHead(nn.Module):
     def forward(self, bev_feats, fb_est, occ_map, pts_mean_map, ego_motion_gt, input_points, fb_est_per_point, time_indice, results):
         """Reference signature (models/egomotion.py:387-469): dense [B,T,C,Ny,Nx] maps in, results dict filled."""
         B, T, C, Ny, Nx = bev_feats.size()
-        perm_l, rel_est, rel_gt, ch_est, ch_gt = [], [], [], [], []
+        perm_l, rel_est, rel_gt, ch_est, ch_gt = PermList(), [], [], [], []
         sequences = []
         for b in range(B):
             points_list, feats_list, bg_list = [], [], []

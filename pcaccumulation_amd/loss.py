@@ -84,6 +84,9 @@ class OutlierLoss(object):
     """libs/outlier_loss.py: mean mass missing from the rows and columns of each permutation matrix."""
 
     def __call__(self, perm_matrix):
+        stacked = getattr(perm_matrix, 'stacked', None)
+        if stacked is not None:                                            # equal-sized pairs: the means of the concatenations
+            return torch.mean(1.0 - torch.sum(stacked, dim=1)) + torch.mean(1.0 - torch.sum(stacked, dim=2))
         ref = torch.cat([1.0 - torch.sum(p, dim=1) for p in perm_matrix], 1)
         src = torch.cat([1.0 - torch.sum(p, dim=2) for p in perm_matrix], 0)
         return torch.mean(ref) + torch.mean(src)

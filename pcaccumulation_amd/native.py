@@ -52,6 +52,7 @@ EXPORTS = [
     'pcacc_sinkhorn_train_workspace_bytes', 'pcacc_sinkhorn_forward', 'pcacc_sinkhorn_backward',
     'pcacc_seg_loss_workspace_bytes', 'pcacc_seg_loss_forward', 'pcacc_seg_loss_backward',
     'pcacc_offset_loss_workspace_bytes', 'pcacc_offset_loss_forward', 'pcacc_offset_loss_backward',
+    'pcacc_frames_max', 'pcacc_frames_max_backward',
 ]
 
 
@@ -639,3 +640,22 @@ def offset_loss_backward(offset_gt, offset_est, rows, grad_norm, grad_dir):
                                             _opt(grad_norm, torch.float32, 'grad_norm'), _opt(grad_dir, torch.float32, 'grad_dir'), _dev(grad),
                                             _stream()), 'offset_loss_backward')
     return grad
+
+
+def frames_max(x):
+    """x [S,T,...] f32 / bf16 contiguous -> (max over T [S,...], winning frame u8 [S,...]); include/pcacc.h A9."""
+    S, T = x.shape[0], x.shape[1]
+    plane = x[0, 0].numel()
+    out = torch.empty((S,) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
+    arg = torch.empty((S,) + tuple(x.shape[2:]), dtype=torch.uint8, device=x.device)
+    _check(lib().pcacc_frames_max(_dev(x, None, 'x'), _dtype_code(x), _i64(S), int(T), _i64(plane), _dev(out), _dev(arg), _stream()), 'frames_max')
+    return out, arg
+
+
+def frames_max_backward(grad_out, arg, frames):
+    S = grad_out.shape[0]
+    plane = grad_out[0].numel()
+    g = torch.empty((S, frames) + tuple(grad_out.shape[1:]), dtype=grad_out.dtype, device=grad_out.device)
+    _check(lib().pcacc_frames_max_backward(_dev(grad_out, None, 'grad_out'), _dev(arg, torch.uint8), _dtype_code(grad_out), _i64(S), int(frames),
+                                           _i64(plane), _dev(g), _stream()), 'frames_max_backward')
+    return g

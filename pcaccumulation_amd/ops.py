@@ -585,3 +585,24 @@ def offset_loss(offset_est, points, time_indice, inst_labels, label_base, ego_mo
     f = lambda t: t.detach().float().contiguous()
     return _OffsetLoss.apply(offset_est.float().contiguous(), f(points), time_indice.long().contiguous(), inst_labels.long().contiguous(),
                              label_base, f(ego_motion), f(inst_motion), f(transformed_points), rows)
+
+
+class _FramesMax(torch.autograd.Function):
+    """A9: max over the frame axis of [S,T,...] rows in one streaming pass each way (csrc/canvas.hip)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        out, arg = native.frames_max(x)
+        ctx.save_for_backward(arg)
+        ctx.frames = x.shape[1]
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        arg, = ctx.saved_tensors
+        return native.frames_max_backward(grad.contiguous(), arg, ctx.frames)
+
+
+def frames_max(x):
+    """torch.max(x, dim=1)[0] for a contiguous f32 / bf16 [S,T,...] stack (models/stpn.py:83)."""
+    return _FramesMax.apply(x.contiguous())

@@ -65,7 +65,7 @@ class STPN(nn.Module):
             w2 = layer.weight.permute(0, 2, 1, 3, 4).reshape(layer.out_channels, 3 * cin, 3, 3)
             y = F.relu(F.conv2d(stacked.permute(0, 3, 1, 2), w2, layer.bias, padding=1))
             rows = y.permute(0, 2, 3, 1).contiguous().view(B, T, H, W, layer.out_channels)
-        return rows.max(dim=1)[0].permute(0, 3, 1, 2)                                  # [B,C,H,W], channels_last
+        return ops.frames_max(rows).permute(0, 3, 1, 2)                                # [B,C,H,W], channels_last
 
     def backbone(self, x):
         """[B, C, T, H, W] -> [B, 64, H, W]: temporal conv stack, max over T, U-Net (models/stpn.py:82-92)."""

@@ -733,3 +733,25 @@ def test_sinkhorn_forward_backward_kernels(P, k, iters):
     y2.backward(gy.double())
     assert (y1 - y2.float()).abs().max().item() <= 2e-4
     assert (x1.grad - x2.grad.float()).abs().max().item() <= 2e-4 * max(1.0, x2.grad.abs().max().item())
+
+
+# ---------------------------------------------------------------- A9 frame max
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_frames_max_is_torch_max(native, dev, dtype):
+    """models/stpn.py:83: values bit-exact; the gradient goes to the lowest frame attaining the maximum (post-ReLU zeros tie)."""
+    from pcaccumulation_amd import ops
+    torch.manual_seed(3)
+    x = torch.relu(torch.randn(3, 5, 12, 10, 32, device=dev)).to(dtype)
+    x[0, :, 0, 0, :4] = float('nan')
+    xr = x.clone().requires_grad_(True)
+    out = ops.frames_max(xr)
+    want = x.float().max(dim=1)[0]
+    assert out.dtype == dtype and torch.equal(torch.nan_to_num(out.float(), nan=-1.0), torch.nan_to_num(want, nan=-1.0))
+    g = torch.randn_like(out)
+    out.backward(g)
+    xf = torch.nan_to_num(x.float(), nan=float('inf'))
+    first = (xf == xf.max(dim=1, keepdim=True)[0]).to(torch.uint8).argmax(dim=1)
+    ref = torch.zeros_like(x).scatter_(1, first.unsqueeze(1), g.unsqueeze(1))
+    assert torch.equal(xr.grad, ref)
+    with pytest.raises(native.NativeError):
+        native.frames_max(torch.zeros(2, 3, 5, device=dev))                     # rows must be a multiple of 16 bytes

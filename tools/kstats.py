@@ -7,7 +7,7 @@ def cat(name):
     if name.startswith('Cijk'): return 'hipblaslt_gemm'
     if 'igemm' in name or name.startswith('_ZN2ck') or 'ck::' in name or 'naive_conv' in name or 'SubTensorOp' in name or 'batched_transpose' in name or 'gridwise' in name.lower() or 'MIOpen' in name: return 'miopen_conv'
     if 'BatchNorm' in name or 'batch_norm' in name: return 'batchnorm'
-    if any(k in name for k in ['seg_', 'csr_', 'vox_', 'pillar_', 'gather_rows', 'bilinear', 'bev_warp', 'rigid_', 'scan_chunk', 'chunk_', 'cell_index', 'fp_', 'rows_linear', 'rows_wgrad', 'chamfer', 'conv3x3', 'conv_', 'cluster_', 'sinkhorn', 'kabsch', 'affinity', 'sample_subsets', 'upload_words', 'prep_points', 'pfn_', 'scatter_sum_small']): return 'pcacc_hip'
+    if any(k in name for k in ['seg_', 'csr_', 'vox_', 'pillar_', 'gather_rows', 'bilinear', 'bev_warp', 'rigid_', 'scan_chunk', 'chunk_', 'cell_index', 'fp_', 'rows_linear', 'rows_wgrad', 'chamfer', 'conv3x3', 'conv_', 'cluster_', 'sinkhorn', 'kabsch', 'affinity', 'sample_subsets', 'upload_words', 'prep_points', 'pfn_', 'scatter_sum_small', 'offset_']): return 'pcacc_hip'
     if 'rocclr' in name: return 'memcpy/memset'
     if 'at::native' in name or 'rocprim' in name or 'indexing' in name: return 'torch_misc'
     return 'other'
