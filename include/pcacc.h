@@ -165,6 +165,18 @@ int pcacc_rows_wgrad_mixed(const void *dy, const void *dy_mask, const void *x, i
 int pcacc_rows_wgrad_bf16_workspace_bytes(int64_t rows, int32_t k, int32_t n, size_t *bytes /*host*/);
 int pcacc_rows_wgrad_bf16(const uint16_t *dy, const uint16_t *dy_mask, const uint16_t *x, int32_t x_relu, int64_t rows,
                           int32_t k, int32_t n, float *dw_aug, void *workspace, size_t workspace_bytes, void *stream);
+/* The two kernels above on rows made of two pieces -- models/pillar_encoder.py:116-118 feeds every PFN block
+ * cat(point row, pooled row of the point's pillar): x[row] = cat(xa[row] (ka columns), xb[b_index[row]] (k - ka columns)), read
+ * in place (no gather, no concatenation; b_index NULL: xb[row]).  Forward: pcacc_rows_linear_cat_bf16 with y2 = NULL.
+ * Backward-data: xa = the output gradient (xb NULL), w = W^T; the [rows,n] result leaves as y [rows,na] and y2 [rows,n-na],
+ * masked where the forward input cat(out_mask_a[row], out_mask_b[b_index[row]]) was <= 0 (out_mask_* NULL: no mask). */
+int pcacc_rows_linear_cat_bf16(const uint16_t *xa, const uint16_t *xb, const int32_t *b_index, int32_t ka, const uint16_t *in_mask,
+                               const float *w, const float *bias, const uint16_t *residual, const uint16_t *out_mask_a,
+                               const uint16_t *out_mask_b, uint16_t *y, uint16_t *y2, int32_t na, int64_t rows, int32_t k,
+                               int32_t n, int32_t flags, void *stream);
+int pcacc_rows_wgrad_cat_bf16(const uint16_t *dy, const uint16_t *dy_mask, const uint16_t *xa, const uint16_t *xb,
+                              const int32_t *b_index, int32_t ka, int32_t x_relu, int64_t rows, int32_t k, int32_t n,
+                              float *dw_aug, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Sum of rows per index for FEW output rows (m*c <= 8192), no CSR needed: LDS-privatised accumulation.
  * The per-instance 'sum' / 'mean' poolings of models/tpointnet.py:227,251,283-284 and libs/loss.py:216.
@@ -254,6 +266,12 @@ int pcacc_sinkhorn_forward(const float *log_alpha, int n_pairs, int k, int n_ite
 int pcacc_sinkhorn_backward(const float *grad_log_perm, const float *log_alpha, const float *lse_rows, const float *lse_cols,
                             int n_pairs, int k, int n_iters, float *grad_log_alpha, void *workspace, size_t workspace_bytes,
                             void *stream);
+/* Batched 3x3 SVD of the Kabsch solve in the training path -- toolbox/register_utils.py:293 (`torch.svd(cov_mat)`):
+ * a [n,3,3] f32 = u diag(s) v^T, s descending, no status word read back on the host.  backward: grad_a from the gradients of
+ * u, s, v (any of them NULL = 0), closed form for distinct singular values. */
+int pcacc_svd3(const float *a, int64_t n, float *u, float *s, float *v, void *stream);
+int pcacc_svd3_backward(const float *u, const float *s, const float *v, const float *grad_u, const float *grad_s,
+                        const float *grad_v, int64_t n, float *grad_a, void *stream);
 int pcacc_sinkhorn_kabsch_workspace_bytes(int n_pairs, int k, size_t *bytes /*host*/);
 int pcacc_sinkhorn_kabsch(const float *feats_s, const float *feats_t, const float *coor_s, const float *coor_t,
                           const float *thr2, const float *params, int n_pairs, int k, int c, int n_iters,

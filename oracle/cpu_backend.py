@@ -222,7 +222,7 @@ NAMES = ['voxelize', 'cell_index', 'frame_pillars', 'csr_build', 'segment_mean3_
          'segment_max_backward', 'segment_sum', 'pillar_scatter', 'gather_rows', 'bilinear_gather',
          'bilinear_gather_backward', 'bev_warp', 'rigid_transform', 'chamfer_forward', 'chamfer_backward',
          'rows_linear', 'rows_wgrad', 'rows_linear_supported', 'pfn_features', 'scatter_sum_small', 'sinkhorn_kabsch', 'cluster', 'sample_subsets', 'upload_small', 'bilinear_gather_backward_sorted', 'prep_points', 'sinkhorn_forward', 'sinkhorn_backward',
-         'seg_loss_forward', 'seg_loss_backward', 'offset_loss_forward', 'offset_loss_backward', 'frames_max', 'frames_max_backward']
+         'seg_loss_forward', 'seg_loss_backward', 'offset_loss_forward', 'offset_loss_backward', 'frames_max', 'frames_max_backward', 'svd3', 'svd3_backward']
 
 
 def install(monkeypatch=None):
@@ -354,3 +354,26 @@ def frames_max(x):
 def frames_max_backward(grad_out, arg, frames):
     t = torch.arange(frames).view((1, frames) + (1,) * (grad_out.dim() - 1))
     return torch.where(arg.unsqueeze(1).long() == t, grad_out.unsqueeze(1), torch.zeros((), dtype=grad_out.dtype))
+
+
+def svd3(a):
+    """toolbox/register_utils.py:293: the library SVD the reference calls."""
+    u, s, v = torch.svd(a.detach())
+    return u.contiguous(), s.contiguous(), v.contiguous()
+
+
+def svd3_backward(u, s, v, gu, gs, gv):
+    """Gradient of a = u diag(s) v^T through the library's own SVD derivative."""
+    a = ((u * s[:, None, :]) @ v.transpose(1, 2)).detach().requires_grad_(True)
+    with torch.enable_grad():
+        uu, ss, vv = torch.svd(a)
+        # the decomposition of the rebuilt matrix may differ from (u, v) by a sign per column: align the incoming gradients
+        sign = torch.sign((uu * u).sum(dim=1, keepdim=True))
+        total = 0
+        if gu is not None:
+            total = total + (uu * sign * gu).sum()
+        if gv is not None:
+            total = total + (vv * sign * gv).sum()
+        if gs is not None:
+            total = total + (ss * gs).sum()
+    return torch.autograd.grad(total, a)[0]

@@ -34,19 +34,30 @@ class AlignNet(BaseModel):
         if self.refine_with_icp:
             raise NotImplementedError('model.tpointnet_icp (Open3D ICP) is off the hot path (configs/default.yaml:117)')
 
-    def padding(self, inst_indice, time_indice, inst_motion):
+    @staticmethod
+    def padding_flags(inst_indice, time_indice, K, T, weights=None):
+        """(orphan, alive) per instance as one [2,K] device tensor: alive = has points, orphan = has points but none in the anchor
+        frame (models/alignnet.py:121-140).  `weights` restricts the count to a subset (1 = counted) so that MotionNet can
+        evaluate the flags on all points before its one host sync of the forward."""
+        slot = (inst_indice * T + time_indice).long()
+        ones = torch.ones(slot.size(0), device=slot.device) if weights is None else weights.float()
+        per_slot = scatter(ones, slot, dim=0, dim_size=K * T, reduce='sum')
+        per_inst = per_slot.view(K, T).sum(dim=1)
+        return torch.stack(((per_slot[::T] == 0) & (per_inst > 0), per_inst > 0)), per_slot, slot
+
+    def padding(self, inst_indice, time_indice, inst_motion, flags=None):
         """models/alignnet.py:115-163.  Returns (extra point indices or None, motions of the non-empty instances,
         compacted instance label per point).  Instances that have points but none in the anchor frame get the points of
-        their first populated frame appended as frame-0 stand-ins."""
+        their first populated frame appended as frame-0 stand-ins.  `flags` = padding_flags already on the host."""
         device = inst_indice.device
         K, T = inst_motion.size(0), inst_motion.size(1)
-        slot = (inst_indice * T + time_indice).long()
-        ones = torch.ones(slot.size(0), device=device)
-        per_slot = scatter(ones, slot, dim=0, dim_size=K * T, reduce='sum')
-        per_inst = scatter(ones, inst_indice, dim=0, dim_size=K, reduce='sum')
-        orphan = (per_slot[::T] == 0) & (per_inst > 0)
-        alive = per_inst > 0
-        flags = torch.stack((orphan, alive)).cpu()                           # the ONE host sync of this step
+        if flags is None:
+            dev_flags, per_slot, slot = self.padding_flags(inst_indice, time_indice, K, T)
+            flags = dev_flags.cpu()                                          # the ONE host sync of this step
+        else:
+            per_slot = slot = None
+        if bool(flags[0].any()) and slot is None:                            # rare: an instance without anchor-frame points
+            _, per_slot, slot = self.padding_flags(inst_indice, time_indice, K, T)
         extra = []
         for k in torch.where(flags[0])[0].tolist():
             first = torch.where(per_slot[k * T:(k + 1) * T] > 0)[0][0]
@@ -80,7 +91,7 @@ class AlignNet(BaseModel):
         # GT instance motion relative to the ESTIMATED ego motion, all samples merged into one instance table
         labels, remaining = self._merge_batch_instances(
             labels, tcol[:, 0], update_gt_inst_motion(gt_list, input_dict['ego_motion_gt'], input_dict['ego_motion_est']))
-        extra, remaining, labels = self.padding(labels, tcol[:, 1], remaining)
+        extra, remaining, labels = self.padding(labels, tcol[:, 1], remaining, input_dict.get('_pad_flags'))
         gt_motion = remaining.clone()
         K, T = remaining.size(0), remaining.size(1)
 

@@ -526,3 +526,87 @@ extern "C" int pcacc_sample_subsets(const int32_t *counts, int32_t n_draws, int3
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Batched 3x3 SVD as a differentiable op (toolbox/register_utils.py:293 `torch.svd(cov_mat)` inside the Kabsch solve of the
+// training path).  The library call checks its status word on the host -- two queue drains per step in front of the small
+// launches of the ego head.  One lane per matrix: one-sided Jacobi in float64 (the routine of the fused eval kernel above),
+// a = u diag(s) v^T with s descending; the backward pass is the closed form for a square matrix with distinct singular values,
+//   ga = u [ (skew(u^T gu) / E) diag(s) + diag(s) (skew(v^T gv) / E) + diag(gs) ] v^T,   E_ij = s_j^2 - s_i^2,  skew(x) = x - x^T.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void svd3_kernel(const float *__restrict__ a, int64_t n, float *__restrict__ u, float *__restrict__ s,
+                                                  float *__restrict__ v)
+{
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    double am[3][3], um[3][3], sm[3], vm[3][3];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) am[r][c] = a[i * 9 + r * 3 + c];
+    jacobi_svd3(am, um, sm, vm);
+    for (int r = 0; r < 3; ++r) {
+        s[i * 3 + r] = (float)sm[r];
+        for (int c = 0; c < 3; ++c) {
+            u[i * 9 + r * 3 + c] = (float)um[r][c];
+            v[i * 9 + r * 3 + c] = (float)vm[r][c];
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void svd3_bwd_kernel(const float *__restrict__ u, const float *__restrict__ s, const float *__restrict__ v,
+                                                      const float *__restrict__ gu, const float *__restrict__ gs, const float *__restrict__ gv,
+                                                      int64_t n, float *__restrict__ ga)
+{
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    double U[3][3], V[3][3], S[3], GU[3][3], GV[3][3], inner[3][3];
+    for (int r = 0; r < 3; ++r) {
+        S[r] = s[i * 3 + r];
+        for (int c = 0; c < 3; ++c) {
+            U[r][c] = u[i * 9 + r * 3 + c];
+            V[r][c] = v[i * 9 + r * 3 + c];
+            GU[r][c] = gu ? gu[i * 9 + r * 3 + c] : 0.0;
+            GV[r][c] = gv ? gv[i * 9 + r * 3 + c] : 0.0;
+        }
+    }
+    double ku[3][3], kv[3][3];                                                 // u^T gu, v^T gv
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            double x = 0, y = 0;
+            for (int k = 0; k < 3; ++k) { x += U[k][r] * GU[k][c]; y += V[k][r] * GV[k][c]; }
+            ku[r][c] = x, kv[r][c] = y;
+        }
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            if (r == c) { inner[r][c] = gs ? gs[i * 3 + r] : 0.0; continue; }
+            const double e = S[c] * S[c] - S[r] * S[r];
+            inner[r][c] = (ku[r][c] - ku[c][r]) / e * S[c] + S[r] * (kv[r][c] - kv[c][r]) / e;
+        }
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            double x = 0;
+            for (int k = 0; k < 3; ++k)
+                for (int l = 0; l < 3; ++l) x += U[r][k] * inner[k][l] * V[c][l];
+            ga[i * 9 + r * 3 + c] = (float)x;
+        }
+}
+
+extern "C" int pcacc_svd3(const float *a, int64_t n, float *u, float *s, float *v, void *stream)
+{
+    if (n < 0) return PCACC_E_ARG;
+    if (n == 0) return PCACC_OK;
+    if (!a || !u || !s || !v) return PCACC_E_ARG;
+    svd3_kernel<<<(unsigned)((n + 63) / 64), 64, 0, pcacc_stream(stream)>>>(a, n, u, s, v);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}
+
+extern "C" int pcacc_svd3_backward(const float *u, const float *s, const float *v, const float *grad_u, const float *grad_s, const float *grad_v,
+                                   int64_t n, float *grad_a, void *stream)
+{
+    if (n < 0) return PCACC_E_ARG;
+    if (n == 0) return PCACC_OK;
+    if (!u || !s || !v || !grad_a) return PCACC_E_ARG;
+    svd3_bwd_kernel<<<(unsigned)((n + 63) / 64), 64, 0, pcacc_stream(stream)>>>(u, s, v, grad_u, grad_s, grad_v, n, grad_a);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}

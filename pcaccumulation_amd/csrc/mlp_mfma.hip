@@ -42,12 +42,28 @@ __device__ __forceinline__ uint4 mm_mask8(uint4 v, uint4 m)
 }
 
 
+// A row made of two pieces ("virtual concatenation"): columns [0,ka) from a[row], columns [ka,K) from b[idx[row]] (idx == NULL:
+// b[row]).  b == NULL: the plain contiguous [rows,K] layout of `a`.  Lets the PFN blocks consume cat(point row, pooled
+// pillar row) (models/pillar_encoder.py:116-118) without materialising the gather or the concatenation.
+struct RowPieces {
+    const uint16_t *b;
+    const int32_t *idx;
+    int ka;
+};
+__device__ __forceinline__ const uint16_t *row_piece(const uint16_t *a, const RowPieces &s, int K, int64_t row, int col)
+{
+    if (!s.b) return a + row * K + col;
+    if (col < s.ka) return a + row * s.ka + col;
+    return s.b + (s.idx ? (int64_t)s.idx[row] : row) * (K - s.ka) + (col - s.ka);
+}
+
 template <int K, int CT>
 __global__ __launch_bounds__(MM_THREADS) void rows_linear_bf16_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ in_mask,
                                                                       const float *__restrict__ W, const float *__restrict__ bias,
                                                                       const uint16_t *__restrict__ residual,
                                                                       const uint16_t *__restrict__ out_mask, uint16_t *__restrict__ Y,
-                                                                      int64_t rows, int flags)
+                                                                      int64_t rows, int flags, RowPieces xs2, RowPieces ms2,
+                                                                      uint16_t *__restrict__ Y2, int na)
 {
     constexpr int N = CT * 32;
     constexpr int XS = K + 8, YS = N + 8;                      // padded LDS row lengths (elements)
@@ -81,7 +97,7 @@ __global__ __launch_bounds__(MM_THREADS) void rows_linear_bf16_kernel(const uint
             const int64_t e = base + (int64_t)(threadIdx.x + q * MM_THREADS) * 8;
             uint4 v = make_uint4(0, 0, 0, 0), m = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
             if (e < limit) {
-                v = *reinterpret_cast<const uint4 *>(X + e);
+                v = *reinterpret_cast<const uint4 *>(row_piece(X, xs2, K, e / K, (int)(e % K)));
                 if (in_mask) m = *reinterpret_cast<const uint4 *>(in_mask + e);
             }
             xreg[q] = v;
@@ -149,15 +165,20 @@ __global__ __launch_bounds__(MM_THREADS) void rows_linear_bf16_kernel(const uint
                 v.w = pcacc_pack_bf16x2(pcacc_bf16_lo(v.w) + pcacc_bf16_lo(r.w), pcacc_bf16_hi(v.w) + pcacc_bf16_hi(r.w));
             }
             if (flags & MM_POST_RELU) v = mm_relu8(v);
-            if (out_mask) v = mm_mask8(v, *reinterpret_cast<const uint4 *>(out_mask + e));
-            *reinterpret_cast<uint4 *>(Y + e) = v;
+            const int64_t row = e / N;
+            const int col = (int)(e % N);
+            if (out_mask) v = mm_mask8(v, *reinterpret_cast<const uint4 *>(row_piece(out_mask, ms2, N, row, col)));
+            if (!Y2) *reinterpret_cast<uint4 *>(Y + e) = v;
+            else if (col < na) *reinterpret_cast<uint4 *>(Y + row * na + col) = v;
+            else *reinterpret_cast<uint4 *>(Y2 + row * (N - na) + (col - na)) = v;
         }
     }
 }
 
 template <int K, int CT>
 static int mm_launch(const uint16_t *x, const uint16_t *in_mask, const float *w, const float *bias, const uint16_t *residual,
-                     const uint16_t *out_mask, uint16_t *y, int64_t rows, int flags, hipStream_t st)
+                     const uint16_t *out_mask, uint16_t *y, int64_t rows, int flags, hipStream_t st, RowPieces xs2 = RowPieces{nullptr, nullptr, 0},
+                     RowPieces ms2 = RowPieces{nullptr, nullptr, 0}, uint16_t *y2 = nullptr, int na = 0)
 {
     constexpr int N = CT * 32;
     constexpr int XS = K + 8, YS = N + 8;
@@ -171,7 +192,7 @@ static int mm_launch(const uint16_t *x, const uint16_t *in_mask, const float *w,
     per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);
     int64_t grid = (int64_t)PCACC_CUS * per_cu;
     if (grid > n_tiles) grid = n_tiles;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(MM_THREADS), lds, st, x, in_mask, w, bias, residual, out_mask, y, rows, flags);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(MM_THREADS), lds, st, x, in_mask, w, bias, residual, out_mask, y, rows, flags, xs2, ms2, y2, na);
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
 }
@@ -186,6 +207,31 @@ extern "C" int pcacc_rows_linear_bf16(const uint16_t *x, const uint16_t *in_mask
     hipStream_t st = pcacc_stream(stream);
 #define MM_CASE(KK, CTV) \
     if (k == KK && n == CTV * 32) return mm_launch<KK, CTV>(x, in_mask, w, bias, residual, out_mask, y, rows, flags, st)
+    MM_CASE(32, 1); MM_CASE(32, 2); MM_CASE(32, 4);
+    MM_CASE(64, 1); MM_CASE(64, 2); MM_CASE(64, 4);
+    MM_CASE(128, 1); MM_CASE(128, 2); MM_CASE(128, 4);
+#undef MM_CASE
+    return PCACC_E_ARG;
+}
+
+// The same layer on rows made of two pieces (see RowPieces).  Forward: x = cat(xa [rows,ka], xb[b_index] [.,k-ka]).  Backward-data
+// (w = W^T, x = the output gradient, xb = NULL): the [rows,n] result leaves as y [rows,na] and y2 [rows,n-na], masked where the
+// forward input cat(out_mask_a, out_mask_b[b_index]) was <= 0.
+extern "C" int pcacc_rows_linear_cat_bf16(const uint16_t *xa, const uint16_t *xb, const int32_t *b_index, int32_t ka, const uint16_t *in_mask,
+                                          const float *w, const float *bias, const uint16_t *residual, const uint16_t *out_mask_a,
+                                          const uint16_t *out_mask_b, uint16_t *y, uint16_t *y2, int32_t na, int64_t rows, int32_t k, int32_t n,
+                                          int32_t flags, void *stream)
+{
+    if (rows < 0 || (k != 32 && k != 64 && k != 128) || (n != 32 && n != 64 && n != 128)) return PCACC_E_ARG;
+    if (xb && (ka <= 0 || ka >= k || ka % 8)) return PCACC_E_ARG;
+    if (y2 && (na <= 0 || na >= n || na % 8)) return PCACC_E_ARG;
+    if (out_mask_b && (!out_mask_a || !y2)) return PCACC_E_ARG;
+    if (rows == 0) return PCACC_OK;
+    if (!xa || !w || !y) return PCACC_E_ARG;
+    hipStream_t st = pcacc_stream(stream);
+    const RowPieces xs2{xb, b_index, ka}, ms2{out_mask_b, b_index, na};
+#define MM_CASE(KK, CTV) \
+    if (k == KK && n == CTV * 32) return mm_launch<KK, CTV>(xa, in_mask, w, bias, residual, out_mask_a, y, rows, flags, st, xs2, ms2, y2, na)
     MM_CASE(32, 1); MM_CASE(32, 2); MM_CASE(32, 4);
     MM_CASE(64, 1); MM_CASE(64, 2); MM_CASE(64, 4);
     MM_CASE(128, 1); MM_CASE(128, 2); MM_CASE(128, 4);
@@ -209,7 +255,7 @@ union wg_frag { bf16x8_t v; wg_s16x4 h[2]; uint16_t e[8]; };
 template <int MAX_TILES>
 __global__ __launch_bounds__(256) void rows_wgrad_bf16_kernel(const uint16_t *__restrict__ dY, const uint16_t *__restrict__ dy_mask,
                                                               const uint16_t *__restrict__ X, int x_relu, int64_t rows, int K, int N,
-                                                              int k_tiles, int n_tile_total, float *partial)
+                                                              int k_tiles, int n_tile_total, float *partial, RowPieces xs2)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t wlds[];
     const int NS = N + 4, KS = K + 4;
@@ -240,7 +286,7 @@ __global__ __launch_bounds__(256) void rows_wgrad_bf16_kernel(const uint16_t *__
             yreg[q] = v;
             mreg[q] = m;
             uint4 u = make_uint4(0, 0, 0, 0);
-            if (i < nx && (int64_t)i * 8 < lim_k) u = *reinterpret_cast<const uint4 *>(X + row0 * K + (int64_t)i * 8);
+            if (i < nx && (int64_t)i * 8 < lim_k) u = *reinterpret_cast<const uint4 *>(row_piece(X, xs2, K, row0 + (i * 8) / K, (i * 8) % K));
             xreg[q] = u;
         }
     };
@@ -353,8 +399,8 @@ extern "C" int pcacc_rows_wgrad_bf16_workspace_bytes(int64_t rows, int32_t k, in
     return PCACC_OK;
 }
 
-extern "C" int pcacc_rows_wgrad_bf16(const uint16_t *dy, const uint16_t *dy_mask, const uint16_t *x, int32_t x_relu, int64_t rows,
-                                     int32_t k, int32_t n, float *dw_aug, void *workspace, size_t workspace_bytes, void *stream)
+static int rows_wgrad_bf16_any(const uint16_t *dy, const uint16_t *dy_mask, const uint16_t *x, RowPieces xs2, int32_t x_relu, int64_t rows,
+                               int32_t k, int32_t n, float *dw_aug, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (rows < 0 || k <= 0 || n <= 0 || k > 128 || n > 128 || (k % 32) || (n % 32) || !dw_aug) return PCACC_E_ARG;
     hipStream_t st = pcacc_stream(stream);
@@ -371,7 +417,7 @@ extern "C" int pcacc_rows_wgrad_bf16(const uint16_t *dy, const uint16_t *dy_mask
     if (workspace_bytes < (size_t)grid * elems * sizeof(float)) return PCACC_E_WORKSPACE;
     float *partial = reinterpret_cast<float *>(workspace);
     const size_t lds = (size_t)WG_R * (n + 4 + k + 4) * sizeof(uint16_t);
-#define WGB(T) rows_wgrad_bf16_kernel<T><<<grid, 256, lds, st>>>(dy, dy_mask, x, x_relu, rows, k, n, k_tiles, total, partial)
+#define WGB(T) rows_wgrad_bf16_kernel<T><<<grid, 256, lds, st>>>(dy, dy_mask, x, x_relu, rows, k, n, k_tiles, total, partial, xs2)
     if (total <= 4) WGB(1);
     else if (total <= 8) WGB(2);
     else WGB(6);
@@ -381,4 +427,19 @@ extern "C" int pcacc_rows_wgrad_bf16(const uint16_t *dy, const uint16_t *dy_mask
     rows_wgrad_reduce_kernel<<<dim3((elems + 255) / 256, slices), 256, 0, st>>>(partial, grid, elems, dw_aug);
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
+}
+
+extern "C" int pcacc_rows_wgrad_bf16(const uint16_t *dy, const uint16_t *dy_mask, const uint16_t *x, int32_t x_relu, int64_t rows,
+                                     int32_t k, int32_t n, float *dw_aug, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return rows_wgrad_bf16_any(dy, dy_mask, x, RowPieces{nullptr, nullptr, 0}, x_relu, rows, k, n, dw_aug, workspace, workspace_bytes, stream);
+}
+
+// x = cat(xa [rows,ka], xb[b_index] [.,k-ka]) (see RowPieces); workspace as pcacc_rows_wgrad_bf16_workspace_bytes(rows, k, n)
+extern "C" int pcacc_rows_wgrad_cat_bf16(const uint16_t *dy, const uint16_t *dy_mask, const uint16_t *xa, const uint16_t *xb,
+                                         const int32_t *b_index, int32_t ka, int32_t x_relu, int64_t rows, int32_t k, int32_t n,
+                                         float *dw_aug, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!xb || ka <= 0 || ka >= k || ka % 8) return PCACC_E_ARG;
+    return rows_wgrad_bf16_any(dy, dy_mask, xa, RowPieces{xb, b_index, ka}, x_relu, rows, k, n, dw_aug, workspace, workspace_bytes, stream);
 }

@@ -64,7 +64,8 @@ def kabsch_transformation_estimation(x1, x2, weights=None, normalize_w=True, eps
     # diag_embed(w) @ x2c == w * x2c exactly (the dropped terms are +0): no 1024x1024 dense weight matrix
     cov_mat = torch.matmul(x1_centered.transpose(1, 2), weights * x2_centered)
     try:
-        u, s, v = torch.svd(cov_mat)
+        # 3x3 Jacobi kernel on the GPU (no status word read back: torch.svd drains the launch queue twice per call)
+        u, s, v = ops.svd3(cov_mat) if cov_mat.shape[-2:] == (3, 3) and cov_mat.dim() == 3 else torch.svd(cov_mat)
     except Exception:                                                  # register_utils.py:295-304
         r = torch.eye(3, device=x1.device).repeat(x1_mean.shape[0], 1, 1)
         t = torch.zeros((x1_mean.shape[0], 3, 1), device=x1.device)

@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 from . import native, ops
+from .lazy import HostCopy, LazyDict, LazyValue, raw
 from .tpointnet import ego_motion_compensation, reconstruct_sequence
 
 _EPS = 1e-20
@@ -183,13 +184,13 @@ class FuseLoss(nn.Module):
 
     def forward(self, predictions, input_dict):
         """libs/loss.py:280-327."""
-        stats = dict()
+        stats = LazyDict()
         ego = self.w_pose_l1_loss * predictions['ego_l1_loss']
         total = ego
         stats['ego_l1_loss'] = ego
         stats['ego_l2_loss'] = predictions['ego_l2_loss']
-        stats['ego_rot_error'] = predictions['ego_rot_error']
-        stats['ego_trans_error'] = predictions['ego_trans_error']
+        stats['ego_rot_error'] = raw(predictions, 'ego_rot_error')            # still in flight (lazy.py): carried along unread
+        stats['ego_trans_error'] = raw(predictions, 'ego_trans_error')
         perm_loss = self.outlier_loss(predictions['perm_matrix']) * self.w_perm_loss
         total = total + perm_loss
         stats['perm_loss'] = perm_loss
@@ -211,24 +212,20 @@ class FuseLoss(nn.Module):
             obj_loss = self.get_tpointnet_loss(predictions) * self.w_obj_loss
             total = total + obj_loss
             stats['obj_loss'] = obj_loss
-            stats['inst_l2_error'] = predictions['inst_l2_error']
-            stats['dynamic_inst_l2_error'] = predictions['dynamic_inst_l2_error']
+            stats['inst_l2_error'] = raw(predictions, 'inst_l2_error')
+            stats['dynamic_inst_l2_error'] = raw(predictions, 'dynamic_inst_l2_error')
         stats['loss'] = total
-        # one device->host transfer for everything the reference reads with .item() (loss.py:30-35, 226)
-        pend = [('fb_metric', None), ('mos_metric', None), ('offset_l2_error', None)]
-        flat = [stats['fb_metric'].reshape(-1) if torch.is_tensor(stats['fb_metric']) else None,
-                stats['mos_metric'].reshape(-1) if torch.is_tensor(stats['mos_metric']) else None,
-                stats['offset_l2_error'].detach().double().reshape(1) if torch.is_tensor(stats['offset_l2_error']) else None]
-        live = [f for f in flat if f is not None]
-        if live:
-            host = torch.cat(live).cpu().numpy()
+        # one asynchronous device->host transfer for everything the reference reads with .item() (loss.py:30-35, 226); the
+        # values materialise when they are first read from `stats` (lazy.py), i.e. after the backward pass has been queued
+        pend = [k for k in ('fb_metric', 'mos_metric', 'offset_l2_error') if torch.is_tensor(dict.__getitem__(stats, k))]
+        if pend:
+            flat = [dict.__getitem__(stats, k).detach().double().reshape(-1) for k in pend]
+            copy = HostCopy(torch.cat(flat))
             off = 0
-            for (key, _), f in zip(pend, flat):
-                if f is None:
-                    continue
-                vals = host[off:off + f.numel()]
+            for k, f in zip(pend, flat):
+                conv = (lambda v: float(v[0])) if k == 'offset_l2_error' else (lambda v: _metric_dict(v.reshape(4, -1)))
+                stats[k] = LazyValue(copy, off, off + f.numel(), conv)
                 off += f.numel()
-                stats[key] = float(vals[0]) if key == 'offset_l2_error' else _metric_dict(vals.reshape(4, -1))
         return stats
 
 

@@ -17,10 +17,11 @@ import contextlib
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import native, ops
 from .alignnet import AlignNet
 from .cluster import Cluster
 from .egomotion import EgoMotionHead
+from .lazy import LazyDict, lazy_scalars
 from .ops import PillarIndex
 from .pillar_encoder import PillarFeatureNet, temporal_ungrid
 from .stpn import STPN
@@ -99,7 +100,7 @@ class MotionNet(nn.Module):
         B, T, Ny, Nx = batch_size, nt, ny, nx
         device = coordinates.device
         ops.set_point_dtype(self.compute_dtype if device.type == 'cuda' else torch.float32)
-        results = dict()
+        results = LazyDict()
 
         # 0. index structures shared by every irregular op of this forward
         pidx = PillarIndex(coordinates, input_dict['point_to_voxel_map'], B, self.grid)
@@ -142,12 +143,23 @@ class MotionNet(nn.Module):
         sorted_pillars, frame_offsets_dev = pidx.frame_pillars()
         bg_flag_sorted = ops.gather_rows(fb_est_pillar, sorted_pillars)[:, 0] == 0           # cell order, per frame
         bg_cum = torch.cat([torch.zeros(1, dtype=torch.int64, device=device), torch.cumsum(bg_flag_sorted, 0)])
+        pad_flags = None
+        if rec_mask is not None:
+            # TubeNet's instance bookkeeping (alignnet.py:121-140) depends on the input labels only: its flags ride along with the
+            # sizes instead of costing a second queue drain in front of the ~700 small launches of the TubeNet
+            counts = [m.size(0) for m in input_dict['inst_motion_gt']]
+            base = native.upload_small([sum(counts[:b]) for b in range(len(counts))], torch.int64, device)
+            merged = input_dict['inst_labels'][:, 0].long() + base[time_indice[:, 0].long()]
+            pad_flags = AlignNet.padding_flags(merged, time_indice[:, 1].long(), sum(counts), T, weights=rec_mask)[0]
         sizes = torch.cat([frame_offsets_dev.long(), bg_cum[frame_offsets_dev.long()], fb_mask.sum()[None],
-                           (rec_mask.sum() if rec_mask is not None else fb_mask.sum())[None]]).cpu().tolist()
+                           (rec_mask.sum() if rec_mask is not None else fb_mask.sum())[None]]
+                          + ([pad_flags.reshape(-1).long()] if pad_flags is not None else [])).cpu().tolist()
         nf = B * T + 1
         frame_offsets, bg_at = sizes[:nf], sizes[nf:2 * nf]
         bg_counts = [bg_at[i + 1] - bg_at[i] for i in range(B * T)]
         n_fb, n_rec = int(sizes[2 * nf]), int(sizes[2 * nf + 1])
+        if pad_flags is not None:
+            pad_flags = torch.tensor(sizes[2 * nf + 2:], dtype=torch.bool).view(2, -1)
         bg_sorted_idx = torch.nonzero_static(bg_flag_sorted, size=bg_at[-1])[:, 0]
         fb_idx = torch.nonzero_static(fb_mask, size=n_fb)[:, 0]
         results['_fb_idx'], results['_cell'] = fb_idx, pidx.cell                                # reused by FuseLoss (no re-sync)
@@ -209,6 +221,7 @@ class MotionNet(nn.Module):
                 'mos_labels': input_dict['sd_labels'][rec_idx, 0].long(),
                 'ego_motion_est': results['ego_motion_est'],
                 'ego_motion_gt': results['ego_motion_gt'],
+                '_pad_flags': pad_flags if self.mode in ['train', 'val'] else None,
             }
             self.reconstructor(reconstructor_input, results)
             results['rec_est'] = results['rec_est'].index_copy(0, rec_idx, results['sub_rec_est'])
@@ -218,12 +231,11 @@ class MotionNet(nn.Module):
     @staticmethod
     def _resolve_scalars(results):
         """Python floats for the scalar results the reference produces with .item() (egomotion.py:456, alignnet.py:280-281):
-        one device->host transfer for all of them."""
+        one asynchronous device->host transfer for all of them, waited for when a value is first read (lazy.py)."""
         keys = [k for k in ('ego_rot_error', 'ego_trans_error', 'inst_l2_error', 'dynamic_inst_l2_error')
-                if k in results and torch.is_tensor(results[k])]
+                if k in results and torch.is_tensor(dict.__getitem__(results, k))]
         if keys:
-            vals = torch.stack([results[k].detach().float().reshape(()) for k in keys]).cpu().tolist()
-            for k, v in zip(keys, vals):
+            for k, v in zip(keys, lazy_scalars([dict.__getitem__(results, k) for k in keys])):
                 results[k] = v
 
     def _stpn_heads(self, stpn_map, points, batch_idx):

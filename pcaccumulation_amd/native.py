@@ -52,7 +52,8 @@ EXPORTS = [
     'pcacc_sinkhorn_train_workspace_bytes', 'pcacc_sinkhorn_forward', 'pcacc_sinkhorn_backward',
     'pcacc_seg_loss_workspace_bytes', 'pcacc_seg_loss_forward', 'pcacc_seg_loss_backward',
     'pcacc_offset_loss_workspace_bytes', 'pcacc_offset_loss_forward', 'pcacc_offset_loss_backward',
-    'pcacc_frames_max', 'pcacc_frames_max_backward',
+    'pcacc_frames_max', 'pcacc_frames_max_backward', 'pcacc_rows_linear_cat_bf16', 'pcacc_rows_wgrad_cat_bf16',
+    'pcacc_svd3', 'pcacc_svd3_backward',
 ]
 
 
@@ -659,3 +660,67 @@ def frames_max_backward(grad_out, arg, frames):
     _check(lib().pcacc_frames_max_backward(_dev(grad_out, None, 'grad_out'), _dev(arg, torch.uint8), _dtype_code(grad_out), _i64(S), int(frames),
                                            _i64(plane), _dev(g), _stream()), 'frames_max_backward')
     return g
+
+
+def rows_linear_cat_supported(ka, kb, n):
+    """Two-piece rows are a bf16 matrix-core path only (include/pcacc.h: pcacc_rows_linear_cat_bf16)."""
+    return (ka + kb) in (32, 64, 128) and n in (32, 64, 128) and ka % 8 == 0 and kb % 8 == 0
+
+
+def rows_linear_cat(xa, xb, b_index, w, bias=None, residual=None, pre_relu=False, post_relu=False):
+    """y = post(pre(cat(xa, xb[b_index])) @ w^T + bias + residual), bf16 rows, the concatenation read in place."""
+    rows, ka = xa.shape
+    k, n = ka + xb.shape[1], w.shape[0]
+    y = torch.empty((rows, n), dtype=torch.bfloat16, device=xa.device)
+    flags = (1 if pre_relu else 0) | (2 if post_relu else 0)
+    _check(lib().pcacc_rows_linear_cat_bf16(_dev(xa, torch.bfloat16, 'xa'), _dev(xb, torch.bfloat16, 'xb'), _opt(b_index, torch.int32, 'b_index'),
+                                            int(ka), None, _dev(w, torch.float32, 'w'), _opt(bias, torch.float32, 'bias'),
+                                            _opt(residual, torch.bfloat16, 'residual'), None, None, _dev(y), None, 0, _i64(rows), int(k), int(n),
+                                            flags, _stream()), 'rows_linear_cat')
+    return y
+
+
+def rows_linear_cat_backward(gy, w_t, dy_mask, xa, xb, b_index, pre_relu):
+    """(d xa [rows,ka], d of the gathered xb rows [rows,kb]) = split of (gy masked where dy_mask <= 0) @ w_t^T, each masked where the
+    forward input was <= 0 when pre_relu.  w_t = W^T [k,n] f32."""
+    rows, n = gy.shape
+    ka, kb = xa.shape[1], xb.shape[1]
+    ga = torch.empty((rows, ka), dtype=torch.bfloat16, device=gy.device)
+    gb = torch.empty((rows, kb), dtype=torch.bfloat16, device=gy.device)
+    _check(lib().pcacc_rows_linear_cat_bf16(_dev(gy, torch.bfloat16, 'gy'), None, _opt(b_index, torch.int32, 'b_index'), 0,
+                                            _opt(dy_mask, torch.bfloat16, 'dy_mask'), _dev(w_t, torch.float32, 'w_t'), None, None,
+                                            _dev(xa, torch.bfloat16, 'xa') if pre_relu else None, _dev(xb, torch.bfloat16, 'xb') if pre_relu else None,
+                                            _dev(ga), _dev(gb), int(ka), _i64(rows), int(n), int(ka + kb), 0, _stream()), 'rows_linear_cat_backward')
+    return ga, gb
+
+
+def rows_wgrad_cat(dy, xa, xb, b_index, dy_mask=None, x_relu=False):
+    """[n, k+1] f32 weight (+ bias) gradient for x = cat(xa, xb[b_index]), bf16 rows."""
+    rows, n = dy.shape
+    ka = xa.shape[1]
+    k = ka + xb.shape[1]
+    out = torch.empty((n, k + 1), dtype=torch.float32, device=dy.device)
+    need = ctypes.c_size_t(0)
+    _check(lib().pcacc_rows_wgrad_bf16_workspace_bytes(_i64(rows), int(k), int(n), ctypes.byref(need)), 'rows_wgrad_bf16_workspace')
+    ws = _ws(need.value, dy.device)
+    _check(lib().pcacc_rows_wgrad_cat_bf16(_dev(dy, torch.bfloat16, 'dy'), _opt(dy_mask, torch.bfloat16, 'dy_mask'), _dev(xa, torch.bfloat16, 'xa'),
+                                           _dev(xb, torch.bfloat16, 'xb'), _opt(b_index, torch.int32, 'b_index'), int(ka), 1 if x_relu else 0,
+                                           _i64(rows), int(k), int(n), _dev(out), _dev(ws), ctypes.c_size_t(ws.numel()), _stream()), 'rows_wgrad_cat')
+    return out
+
+
+def svd3(a):
+    """a [n,3,3] f32 -> (u [n,3,3], s [n,3], v [n,3,3]) with a = u diag(s) v^T (include/pcacc.h: pcacc_svd3)."""
+    n = a.shape[0]
+    u, v = torch.empty_like(a), torch.empty_like(a)
+    s = torch.empty((n, 3), dtype=torch.float32, device=a.device)
+    _check(lib().pcacc_svd3(_dev(a, torch.float32, 'a'), _i64(n), _dev(u), _dev(s), _dev(v), _stream()), 'svd3')
+    return u, s, v
+
+
+def svd3_backward(u, s, v, gu, gs, gv):
+    ga = torch.empty_like(u)
+    _check(lib().pcacc_svd3_backward(_dev(u, torch.float32), _dev(s, torch.float32), _dev(v, torch.float32), _opt(gu, torch.float32, 'grad_u'),
+                                     _opt(gs, torch.float32, 'grad_s'), _opt(gv, torch.float32, 'grad_v'), _i64(u.shape[0]), _dev(ga), _stream()),
+           'svd3_backward')
+    return ga

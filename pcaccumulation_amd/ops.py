@@ -330,6 +330,53 @@ class _RowsLinear(torch.autograd.Function):
         return gx, gw, gb, gres, None, None, None
 
 
+class _RowsLinearCat(torch.autograd.Function):
+    """_RowsLinear on x = cat(xa, pooled[p2v]) without materialising the gather or the concatenation (bf16 rows on the GPU;
+    pcacc_rows_linear_cat_bf16): the PFN blocks' input (models/pillar_encoder.py:116-118).  Backward: the data gradient leaves
+    the kernel already split; the pooled half is summed over each pillar's points (CSR segment sum)."""
+
+    @staticmethod
+    def forward(ctx, xa, pooled, pidx, weight, bias, residual, pre_relu, post_relu):
+        xa, pooled, w = xa.contiguous(), pooled.contiguous(), weight.contiguous()
+        res = residual.contiguous() if residual is not None else None
+        y = native.rows_linear_cat(xa, pooled, pidx.p2v, w, bias, res, pre_relu, post_relu)
+        ctx.pidx = pidx
+        ctx.flags = (pre_relu, post_relu, bias is not None, residual is not None)
+        ctx.save_for_backward(xa, pooled, w, y if post_relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xa, pooled, w, y = ctx.saved_tensors
+        pre_relu, post_relu, has_bias, has_res = ctx.flags
+        pidx = ctx.pidx
+        gy = gy.contiguous()
+        ga = gp = gw = gb = gres = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            ga, gb_rows = native.rows_linear_cat_backward(gy, w.t().contiguous(), y, xa, pooled, pidx.p2v, pre_relu)
+            if ctx.needs_input_grad[1]:
+                gp = native.segment_sum(gb_rows, pidx.seg_offsets, pidx.order, pidx.m).to(pooled.dtype)
+        if ctx.needs_input_grad[3] or (has_bias and ctx.needs_input_grad[4]):
+            aug = native.rows_wgrad_cat(gy, xa, pooled, pidx.p2v, dy_mask=y, x_relu=pre_relu)
+            gw = aug[:, :-1]
+            gb = aug[:, -1] if has_bias else None
+        if has_res and ctx.needs_input_grad[5]:
+            gres = gy if y is None else gy * (y > 0)
+        return ga, gp, None, gw, gb, gres, None, None
+
+
+def linear_rows_cat_available(xa, pooled, layer):
+    """bf16 point rows on the GPU with widths the matrix-core kernel takes; otherwise callers concatenate (parity mode, CPU)."""
+    return (xa.is_cuda and xa.dtype == torch.bfloat16 and pooled.dtype == torch.bfloat16 and xa.shape[0] >= MIN_ROWS_FUSED_LINEAR
+            and layer.in_features == xa.shape[1] + pooled.shape[1]
+            and native.rows_linear_cat_supported(xa.shape[1], pooled.shape[1], layer.out_features) and not torch.is_autocast_enabled())
+
+
+def linear_rows_cat(xa, pooled, pidx, layer, pre_relu=False, post_relu=False, residual=None):
+    """`layer(relu?(cat(xa, pooled[pidx.p2v])))` (+ residual, relu?) -- see _RowsLinearCat."""
+    return _RowsLinearCat.apply(xa, pooled, pidx, layer.weight, layer.bias, residual, pre_relu, post_relu)
+
+
 _POINT_DTYPE = torch.float32
 
 
@@ -606,3 +653,24 @@ class _FramesMax(torch.autograd.Function):
 def frames_max(x):
     """torch.max(x, dim=1)[0] for a contiguous f32 / bf16 [S,T,...] stack (models/stpn.py:83)."""
     return _FramesMax.apply(x.contiguous())
+
+
+class _Svd3(torch.autograd.Function):
+    """torch.svd for [n,3,3] matrices without the host-side status check (csrc/ego.hip: Jacobi in float64, closed-form backward)."""
+
+    @staticmethod
+    def forward(ctx, a):
+        u, s, v = native.svd3(a.contiguous().float())
+        ctx.save_for_backward(u, s, v)
+        return u, s, v
+
+    @staticmethod
+    def backward(ctx, gu, gs, gv):
+        u, s, v = ctx.saved_tensors
+        c = lambda g: g.contiguous().float() if g is not None else None
+        return native.svd3_backward(u, s, v, c(gu), c(gs), c(gv))
+
+
+def svd3(a):
+    """(u, s, v) with a = u diag(s) v^T, as torch.svd (toolbox/register_utils.py:293)."""
+    return _Svd3.apply(a)

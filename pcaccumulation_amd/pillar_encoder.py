@@ -34,6 +34,15 @@ class ResnetBlockFC(nn.Module):
         x_s = ops.linear_rows(x, self.shortcut) if self.shortcut is not None else x
         return ops.linear_rows(net, self.fc_1, pre_relu=True, residual=x_s)
 
+    def forward_pooled(self, x, pooled, pidx):
+        """forward(cat(x, pooled[point_to_voxel_map])) (models/pillar_encoder.py:116-118) with the gather and the concatenation
+        folded into the two layers that read them (bf16 rows on the GPU); the same arithmetic otherwise."""
+        if self.shortcut is None or not ops.linear_rows_cat_available(x, pooled, self.fc_0):
+            return self.forward(torch.cat([x, ops.broadcast_to_points(pooled, pidx)], dim=1))
+        net = ops.linear_rows_cat(x, pooled, pidx, self.fc_0, pre_relu=True)
+        x_s = ops.linear_rows_cat(x, pooled, pidx, self.shortcut)
+        return ops.linear_rows(net, self.fc_1, pre_relu=True, residual=x_s)
+
 
 class PillarFeatureNet(nn.Module):
     """models/pillar_encoder.py:59-122."""
@@ -77,8 +86,7 @@ class PillarFeatureNet(nn.Module):
         net = ops.linear_rows(features, self.fc_pos, out_dtype=pd)
         net = self.blocks[0](net)
         for block in self.blocks[1:]:
-            pooled = ops.broadcast_to_points(ops.segment_max(net, pidx), pidx)
-            net = block(torch.cat([net, pooled], dim=1))
+            net = block.forward_pooled(net, ops.segment_max(net, pidx), pidx)
         feats = ops.linear_rows(net, self.fc_c)
         return ops.segment_max(feats, pidx).float()
 

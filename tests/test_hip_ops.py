@@ -755,3 +755,64 @@ def test_frames_max_is_torch_max(native, dev, dtype):
     assert torch.equal(xr.grad, ref)
     with pytest.raises(native.NativeError):
         native.frames_max(torch.zeros(2, 3, 5, device=dev))                     # rows must be a multiple of 16 bytes
+
+
+def test_pfn_block_on_two_piece_rows(native, dev):
+    """ResnetBlockFC.forward_pooled (gather + concatenation folded into the row kernels, include/pcacc.h
+    pcacc_rows_linear_cat_bf16) against the same block on the materialised cat(x, pooled[p2v]): identical output (same products,
+    same order), gradients to bf16 rounding of the sums that are formed in a different order."""
+    from pcaccumulation_amd import ops
+    from pcaccumulation_amd.ops import PillarIndex
+    from pcaccumulation_amd.pillar_encoder import ResnetBlockFC
+    torch.manual_seed(1)
+    n, m = 50_000, 9_000
+    p2v = torch.randint(0, m, (n,), device=dev, dtype=torch.int32)
+    p2v[:m] = torch.arange(m, device=dev, dtype=torch.int32)
+    pidx = PillarIndex.from_point_map(p2v, m)
+    block = ResnetBlockFC(64, 32).to(dev)
+    torch.nn.init.normal_(block.fc_1.weight, std=0.2)
+    x = torch.randn(n, 32, device=dev).bfloat16()
+    pooled = torch.randn(m, 32, device=dev).bfloat16()
+    g = torch.randn(n, 32, device=dev).bfloat16()
+    outs = []
+    for fused in (True, False):
+        xr, pr = x.clone().requires_grad_(True), pooled.clone().requires_grad_(True)
+        block.zero_grad()
+        y = block.forward_pooled(xr, pr, pidx) if fused else block(torch.cat([xr, ops.broadcast_to_points(pr, pidx)], dim=1))
+        y.backward(g)
+        outs.append((y.detach().float(), xr.grad.float(), pr.grad.float(), [p.grad.clone() for p in block.parameters()]))
+    assert ops.linear_rows_cat_available(x, pooled, block.fc_0)
+    (y1, gx1, gp1, gw1), (y0, gx0, gp0, gw0) = outs
+    assert torch.equal(y1, y0)
+    assert (gx1 - gx0).abs().max() <= 2e-2 * gx0.abs().max()
+    assert (gp1 - gp0).abs().max() <= 2e-2 * gp0.abs().max()
+    for a, b in zip(gw1, gw0):
+        assert (a - b).abs().max() <= 1e-3 * b.abs().max() + 1e-6
+
+
+def test_svd3_matches_library_and_its_gradient(native, dev):
+    """toolbox/register_utils.py:293-313: the Kabsch rotation v diag(1,1,det) u^T and translation built from the 3x3 SVD kernel,
+    and their gradient w.r.t. the covariance, against torch.svd + autograd (float64 on the CPU).  fp32 storage: 1e-5."""
+    from pcaccumulation_amd import ops
+    torch.manual_seed(4)
+    a = torch.randn(64, 3, 3)
+    a[0] = torch.diag(torch.tensor([3.0, 2.0, 1.0]))
+    a[1] = -a[1].abs()                                                            # a reflection case (det < 0)
+
+    def rot(u, v):
+        det = torch.det(v @ u.transpose(1, 2))
+        d = torch.diag_embed(torch.cat((torch.ones((det.shape[0], 2), dtype=u.dtype, device=u.device), det.unsqueeze(1)), 1))
+        return v @ d @ u.transpose(1, 2)
+    ad = a.to(dev).requires_grad_(True)
+    u, s, v = ops.svd3(ad)
+    rebuilt = (u * s[:, None, :]) @ v.transpose(1, 2)
+    assert (rebuilt - ad).abs().max() < 1e-5 and (s[:, :-1] >= s[:, 1:]).all()
+    g = torch.randn(64, 3, 3)
+    (rot(u, v) * g.to(dev)).sum().backward()
+    ar = a.double().requires_grad_(True)
+    ur, sr, vr = torch.svd(ar)
+    (rot(ur, vr) * g.double()).sum().backward()
+    assert (s.detach().cpu().double() - sr.detach()).abs().max() < 1e-5
+    assert (rot(u, v).detach().cpu().double() - rot(ur, vr).detach()).abs().max() < 1e-5
+    scale = ar.grad.abs().amax(dim=(1, 2), keepdim=True)
+    assert ((ad.grad.cpu().double() - ar.grad).abs() / scale).max() < 1e-3         # fp32 u, s, v feed a 1/(s_j^2 - s_i^2) formula
