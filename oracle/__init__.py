@@ -1,7 +1,8 @@
 """oracle -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
 
 CPU restatement (plain C for loop-shaped integer work, numpy fp32 for the rest) of the algorithms on
-the PCAccumulation hot path.  Every function cites the
+the PCAccumulation hot path and of the section 8f rows built on top of it
+(C1 clustering, D1 data step, E1 evaluation, L1/L2 loss terms).  Every function cites the
 reference file:line it follows (paths relative to /root/reference).
 
 Who may import this package: tests/, __graft_entry__.smoke(), and the cpu_baseline leg of bench.py --
