@@ -188,7 +188,7 @@ class EgoMotionHead(nn.Module):
         return points_list, getters, bg, gt
 
     def _estimate_pairs(self, sequences, T, perm_matrix_list, relative_pose_est_list, relative_pose_gt_list,
-                        chained_pose_est_list, chained_pose_gt_list, normalise=False):
+                        chained_pose_est_list, chained_pose_gt_list, normalise=False, flat=None):
         """All (T-1) registrations of all batch elements in ONE batched Sinkhorn / Kabsch evaluation
         ([P,1024,1024] instead of P sequential [1,1024,1024] problems: the reference issues ~60 tiny launches and
         several host syncs per pair).  Key points are still drawn pair by pair in the reference's
@@ -205,7 +205,20 @@ class EgoMotionHead(nn.Module):
             counts = [n for _, _, bg_list, _ in sequences for f in range(T - 1) for n in (bg_list[f + 1][1], bg_list[0][1])]
             seed = int(torch.empty((), dtype=torch.int64).random_())       # host generator: follows torch.manual_seed
             drawn = native.sample_subsets(native.upload_small(counts, torch.int32, dev), self.ego_n_points, seed)
-        for points_list, feats_list, bg_list, _ in sequences:
+        if drawn is not None and flat is not None:
+            # pillar-level inputs + device sampler: the key points of all pairs in five gathers.  Entry e = (pair, source | target)
+            # draws positions in the background list of its frame; bg_sorted_idx holds positions in the cell-ordered pillar list.
+            frames = [f for b in range(len(sequences)) for t in range(1, T) for f in (b * T + t, b * T)]
+            offs = native.upload_small([flat['bg_at'][f] for f in frames], torch.int64, dev)
+            pillar = flat['sp'][flat['bg_sorted_idx'][offs[:, None] + drawn.long()]]              # [2P,k] pillar ids
+            coor = flat['pillar_mean'][pillar]                                                    # [2P,k,3]
+            feats = flat['geo_rows'][flat['cells'][pillar]].float()                               # [2P,k,C], one index op
+            feats_s, feats_t, coor_s, coor_t = feats[0::2], feats[1::2], coor[0::2], coor[1::2]
+            durations = [(frame_idx + 1) / self.frequence for _ in sequences for frame_idx in range(T - 1)]
+            sequences_loop = []
+        else:
+            sequences_loop = sequences
+        for points_list, feats_list, bg_list, _ in sequences_loop:
             a_idx, a_n = bg_list[0]
             for frame_idx in range(T - 1):
                 ref = frame_idx + 1
@@ -220,8 +233,9 @@ class EgoMotionHead(nn.Module):
                 fs.append(feats_list[ref](si)); cs.append(points_list[ref][si])
                 ft.append(feats_list[0](ti)); ct.append(points_list[0][ti])
                 durations.append((frame_idx + 1) / self.frequence)
-        feats_s, feats_t = _stack_rows(fs).float(), _stack_rows(ft).float()  # [P,k,C]
-        coor_s, coor_t = torch.stack(cs), torch.stack(ct)                    # [P,k,3]
+        if sequences_loop:
+            feats_s, feats_t = _stack_rows(fs).float(), _stack_rows(ft).float()  # [P,k,C]
+            coor_s, coor_t = torch.stack(cs), torch.stack(ct)                    # [P,k,3]
         if normalise:
             # models/motionnet.py:199 divides the WHOLE [B*T,64,Ny,Nx] map by its per-cell L2 norm (no epsilon); only the
             # 2*P*1024 key-point rows are ever read, and the norm is per cell, so normalising the gathered rows is the same
@@ -322,20 +336,29 @@ class EgoMotionHead(nn.Module):
         sp = pidx.frame_pillars()[0].long()
         cells = pidx.cell.long()
         perm_l, rel_est, rel_gt, ch_est, ch_gt = PermList(), [], [], [], []
-        sequences, bg_start = [], 0
+        sequences, bg_start, bg_at = [], 0, []
+        # all key points in five gathers (_estimate_pairs); flat_keypoints = False keeps the per-pair loop (tests compare the two)
+        fast = self.kpt_sampler == 'device' and geo_rows.is_cuda and getattr(self, 'flat_keypoints', True)
+        mean_sorted = pillar_mean[sp]                                        # xyz of every pillar in frame / cell order: one gather
         for b in range(B):
             points_list, getters, bg_list = [], [], []
             for t in range(T):
                 f = b * T + t
                 lo, hi = frame_offsets[f], frame_offsets[f + 1]
-                ids = sp[lo:hi]                                              # pillar ids of this frame, cell order
-                points_list.append(pillar_mean[ids])
-                getters.append(lambda i, ids=ids: _RowRef(geo_rows, cells[ids[i]]))
+                points_list.append(mean_sorted[lo:hi])
                 n_bg = bg_counts[f]
-                bg_list.append((bg_sorted_idx[bg_start:bg_start + n_bg] - lo, n_bg))
+                bg_at.append(bg_start)
+                if fast:
+                    bg_list.append((None, n_bg))
+                    getters.append(None)
+                else:
+                    ids = sp[lo:hi]                                          # pillar ids of this frame, cell order
+                    getters.append(lambda i, ids=ids: _RowRef(geo_rows, cells[ids[i]]))
+                    bg_list.append((bg_sorted_idx[bg_start:bg_start + n_bg] - lo, n_bg))
                 bg_start += n_bg
             sequences.append((points_list, getters, bg_list, ego_motion_gt[b]))
-        total_l1, total_l2, count = self._estimate_pairs(sequences, T, perm_l, rel_est, rel_gt, ch_est, ch_gt, normalise=True)
+        flat = dict(sp=sp, cells=cells, geo_rows=geo_rows, pillar_mean=pillar_mean, bg_sorted_idx=bg_sorted_idx, bg_at=bg_at) if fast else None
+        total_l1, total_l2, count = self._estimate_pairs(sequences, T, perm_l, rel_est, rel_gt, ch_est, ch_gt, normalise=True, flat=flat)
         self._finish(B, T, total_l1, total_l2, count, perm_l, ch_est, ch_gt, results)
 
     def forward(self, bev_feats, fb_est, occ_map, pts_mean_map, ego_motion_gt, input_points, fb_est_per_point, time_indice, results):

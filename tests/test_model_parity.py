@@ -340,3 +340,42 @@ def test_gpu_nuscene_geometry_train_step(compute_dtype):
     assert out['rec_est'].shape == inp['input_points'].shape and torch.isfinite(out['rec_est']).all()
     assert torch.isfinite(stats['loss'].detach())
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
+@pytest.mark.gpu
+def test_gpu_device_sampler_flat_keypoint_gather():
+    """Throughput configuration (pose_estimation.kpt_sampler = 'device'): gathering the key points of all pairs with five flat
+    index ops gives what the per-pair loop gives for the same draws -- poses, permutation matrices, loss and the gradient
+    reaching the ego feature head."""
+    from helpers import oracle_voxeliser
+    from pcaccumulation_amd.dataloader import collate_fn
+    from pcaccumulation_amd.synthetic import make_sequence, attach_voxels
+    cfg = default_config('waymo', 'train', n_sweeps=5, xy_range=8)
+    cfg['pose_estimation']['kpt_sampler'] = 'device'
+    vox = oracle_voxeliser(cfg)
+    inp = collate_fn([attach_voxels(make_sequence(50, 5, 1500, cfg), vox), attach_voxels(make_sequence(51, 5, 900, cfg), vox)])
+    dev = torch.device('cuda:0')
+    outs = []
+    for flat in (True, False):
+        torch.manual_seed(5)
+        model = MotionNet(cfg)
+        fill_state_dict_(model)
+        with torch.no_grad():
+            model.semseg_head.seg_head[3].bias += torch.tensor([17.0, 0.0])
+        model = model.to(dev).train()
+        model.channels_last_()
+        model.ego_motion_head.flat_keypoints = flat
+        batch = _to(inp, dev)
+        torch.manual_seed(6)
+        out = model(batch)
+        stats = FuseLoss(cfg['loss'])(out, batch)
+        stats['loss'].backward()
+        g = model.ego_feats_head.seg_head[0].weight.grad if hasattr(model.ego_feats_head, 'seg_head') else next(model.ego_feats_head.parameters()).grad
+        outs.append((out['ego_motion_est'].detach().cpu(), torch.cat([p.detach() for p in out['perm_matrix']]).cpu(), float(stats['loss']), g.detach().cpu().clone()))
+    (pose1, perm1, loss1, g1), (pose0, perm0, loss0, g0) = outs
+    # same draws, same rows; the stacked operands are strided views in one case and fresh tensors in the other, so the batched
+    # products may run in another order: fp32 rounding only
+    assert (pose1 - pose0).abs().max() < 1e-5, (pose1 - pose0).abs().max()
+    assert (perm1 - perm0).abs().max() < 1e-5, (perm1 - perm0).abs().max()
+    assert abs(loss1 - loss0) <= 1e-5 * abs(loss0), (loss1, loss0)
+    assert (g1 - g0).abs().max() <= 5e-3 * g0.abs().max(), ((g1 - g0).abs().max(), g0.abs().max())   # bf16 conv backward, atomic row sums

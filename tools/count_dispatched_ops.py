@@ -1,3 +1,5 @@
+"""Dispatched (non-view) aten ops of one stage per source line of the package, or of a whole train step by op name (forward and
+backward).  Development aid.  Usage: python tools/count_dispatched_ops.py tubenet|ego|loss|forward|step"""
 import os, sys, collections, traceback
 sys.path.insert(0, '/root/repo')
 import torch, bench
@@ -24,7 +26,22 @@ class Count(TorchDispatchMode):
                     per_line['%s:%d' % (os.path.basename(fr.filename), fr.lineno)] += 1
                     break
         return func(*args, **(kwargs or {}))
-target = {'tubenet': (model.reconstructor, 'forward'), 'ego': (model.ego_motion_head, 'forward_pillars')}[stage] if stage != 'loss' else None
+per_name = collections.Counter()
+class CountNames(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        shapes = [tuple(a.shape) for a in args if torch.is_tensor(a)][:2]
+        per_name['%s %s' % (func, shapes)] += 1
+        return func(*args, **(kwargs or {}))
+if stage == 'step':
+    with CountNames():
+        bench.train_step(model, opt, loss_fn, batcher, scenes, None, 1.0)
+    skip = ('view', 'permute', 'select', 'slice', 'expand', 'unsqueeze', 'squeeze', 'detach', 'alias', 'aten.t.', 'transpose', 'as_strided', 'sym_', 'reshape')
+    rows = [(v, k) for k, v in per_name.items() if not any(s in k for s in skip)]
+    print('total', sum(v for v, _ in rows))
+    for v, k in sorted(rows, reverse=True)[:90]:
+        print('%4d  %s' % (v, k[:150]))
+    sys.exit(0)
+target = {'tubenet': (model.reconstructor, 'forward'), 'ego': (model.ego_motion_head, 'forward_pillars'), 'forward': (model, 'forward')}[stage] if stage != 'loss' else None
 if target:
     orig = getattr(*target)
     def wrapped(*a, **k):
