@@ -456,7 +456,7 @@ extern "C" int pcacc_conv3x3_bf16(const uint16_t *in, const uint16_t *wp, const 
 // the X patch are staged channels-last as they come and the fragments are read with the hardware LDS transpose
 // (ds_read_b64_tr_b16, two per fragment; row stride C + 4 elements).  A wave owns one (co tile, ci tile) pair and
 // all 9 taps, so the dY fragment of a 16-pixel step is gathered once and used by 9 MFMAs.  Workgroups are persistent; their
-// accumulators go to a workspace slot each and a second launch sums the slots (conv_wgrad_reduce_kernel).
+// accumulators are folded into one workspace slot per workgroup and a second launch sums the slots (conv_wgrad_reduce_kernel).
 typedef short cv_s16x4 __attribute__((ext_vector_type(4)));
 union cv_frag { bf16x8_t v; cv_s16x4 h[2]; };
 
@@ -573,8 +573,46 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_wgrad_kernel(const uint16_
             }
         }
     }
-    // slot of this (workgroup, pixel group): [CO][9][CI] then [CO] bias sums; D has lane = ci, register quads = co
-    float *mine = partial + ((int64_t)blockIdx.x * GROUPS + grp) * (CO * 9 * CI + CO);
+    // The pixel groups of a workgroup hold partial sums of the same (co, ci) tiles: fold them into group 0 through the staging
+    // LDS (free now), a few taps at a time, so that the workspace holds one slot per workgroup instead of one per wave
+    // (32x32 layers: 113 MB of partials per launch became 28 MB, for this kernel's stores and for the reduce launch's loads).
+    if (GROUPS > 1) {
+        constexpr int LDS_FLOATS = (CV_TH * CV_TW * YS + CV_PH * CV_PW * XS) / 2;
+        constexpr int T_FIT = LDS_FLOATS / (PAIRS * 1024), T_STEP = T_FIT > 9 ? 9 : T_FIT;
+        static_assert(T_STEP >= 1, "staging LDS too small for the accumulator exchange");
+        float *red = reinterpret_cast<float *>(lds);
+#pragma unroll
+        for (int g = 1; g < GROUPS; ++g) {
+#pragma unroll
+            for (int t0 = 0; t0 < 9; t0 += T_STEP) {
+                __syncthreads();
+                if (grp == g) {
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap)
+                        if (tap >= t0 && tap < t0 + T_STEP)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) red[((pair * T_STEP + (tap - t0)) * 16 + r) * 64 + lane] = acc[tap][r];
+                }
+                __syncthreads();
+                if (grp == 0) {
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap)
+                        if (tap >= t0 && tap < t0 + T_STEP)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[tap][r] += red[((pair * T_STEP + (tap - t0)) * 16 + r) * 64 + lane];
+                }
+            }
+        }
+        __syncthreads();
+        if (grp > 0) red[((grp - 1) * PAIRS + pair) * 64 + lane] = bsum;
+        __syncthreads();
+        if (grp == 0)
+#pragma unroll
+            for (int g = 1; g < GROUPS; ++g) bsum += red[((g - 1) * PAIRS + pair) * 64 + lane];
+    }
+    if (grp != 0) return;
+    // slot of this workgroup: [CO][9][CI] then [CO] bias sums; D has lane = ci, register quads = co
+    float *mine = partial + (int64_t)blockIdx.x * (CO * 9 * CI + CO);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
@@ -618,8 +656,7 @@ extern "C" int pcacc_conv3x3_wgrad_workspace_bytes(int32_t n_img, int32_t h, int
 {
     if (!bytes || n_img < 1 || h < 1 || w < 1 || (c_in != 32 && c_in != 64) || (c_out != 32 && c_out != 64)) return PCACC_E_ARG;
     const int64_t n_tiles = (int64_t)n_img * ((h + CV_TH - 1) / CV_TH) * ((w + CV_TW - 1) / CV_TW);
-    const int groups = 4 / ((c_in / 32) * (c_out / 32));
-    *bytes = (size_t)conv_wgrad_grid(c_in, c_out, n_tiles) * groups * (c_out * 9 * c_in + c_out) * sizeof(float);
+    *bytes = (size_t)conv_wgrad_grid(c_in, c_out, n_tiles) * (c_out * 9 * c_in + c_out) * sizeof(float);
     return 0;
 }
 
@@ -635,9 +672,8 @@ extern "C" int pcacc_conv3x3_wgrad_bf16(const uint16_t *dy, const uint16_t *x, f
     const int64_t n_tiles = (int64_t)n_img * tiles_y * tiles_x;
     if (n_tiles > 0x7fffffff) return PCACC_E_ARG;
     const int grid = conv_wgrad_grid(c_in, c_out, n_tiles);
-    const int groups = 4 / ((c_in / 32) * (c_out / 32));
     const int elems = c_out * 9 * c_in + c_out;                 // weight gradient, then the bias gradient
-    if (workspace_bytes < (size_t)grid * groups * elems * sizeof(float)) return PCACC_E_WORKSPACE;
+    if (workspace_bytes < (size_t)grid * elems * sizeof(float)) return PCACC_E_WORKSPACE;
     const size_t lds = (size_t)(CV_TH * CV_TW * (c_out + 4) + CV_PH * CV_PW * (c_in + 4)) * sizeof(uint16_t);
     float *partial = reinterpret_cast<float *>(workspace);
 #define CV_WG(COT, CIT)                                                                                                              \
@@ -654,7 +690,7 @@ extern "C" int pcacc_conv3x3_wgrad_bf16(const uint16_t *dy, const uint16_t *x, f
     else CV_WG(2, 2);
 #undef CV_WG
     if (hipMemsetAsync(dw, 0, (size_t)elems * sizeof(float), st) != hipSuccess) return PCACC_E_LAUNCH;
-    conv_wgrad_reduce_kernel<<<dim3((elems + 255) / 256, 16), 256, 0, st>>>(partial, grid * groups, elems, dw);
+    conv_wgrad_reduce_kernel<<<dim3((elems + 255) / 256, 16), 256, 0, st>>>(partial, grid, elems, dw);
     PCACC_CHECK_LAUNCH();
     return 0;
 }

@@ -272,6 +272,17 @@ __global__ __launch_bounds__(256) void rows_wgrad_bf16_kernel(const uint16_t *__
     const int64_t n_chunks = (rows + WG_R - 1) / WG_R;
     const int ny = WG_R * N / 8, nx = WG_R * K / 8;                              // pieces per tile
     uint4 yreg[4], mreg[4], xreg[4];
+    const int kshift = __ffs(K) - 1;                                           // two-piece rows: K is a power of two
+    int prow[4] = {0, 0, 0, 0};                                                // rows of the second piece for the NEXT fetch: the index
+    auto fetch_rows = [&](int64_t ch) {                                        // load and the row load it feeds are a tile apart
+        if (!xs2.b) return;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = threadIdx.x + q * 256;
+            const int64_t row = ch * WG_R + ((i * 8) >> kshift);
+            prow[q] = (i < nx && row < rows && ch < n_chunks) ? (xs2.idx ? xs2.idx[row] : (int)row) : 0;
+        }
+    };
     auto fetch = [&](int64_t ch) {
         const int64_t row0 = ch * WG_R;
         const int64_t lim_n = (rows - row0) * N, lim_k = (rows - row0) * K;      // elements of this tile that exist
@@ -286,12 +297,21 @@ __global__ __launch_bounds__(256) void rows_wgrad_bf16_kernel(const uint16_t *__
             yreg[q] = v;
             mreg[q] = m;
             uint4 u = make_uint4(0, 0, 0, 0);
-            if (i < nx && (int64_t)i * 8 < lim_k) u = *reinterpret_cast<const uint4 *>(row_piece(X, xs2, K, row0 + (i * 8) / K, (i * 8) % K));
+            if (i < nx && (int64_t)i * 8 < lim_k) {
+                const int col = (i * 8) & (K - 1);
+                const uint16_t *src = X + row0 * K + (int64_t)i * 8;
+                if (xs2.b)                                                       // two-piece rows: the gathered row's index was
+                    src = col < xs2.ka ? X + (row0 + ((i * 8) >> kshift)) * xs2.ka + col   // fetched one tile earlier (prow)
+                                       : xs2.b + (int64_t)prow[q] * (K - xs2.ka) + (col - xs2.ka);
+                u = *reinterpret_cast<const uint4 *>(src);
+            }
             xreg[q] = u;
         }
     };
     int64_t ch = blockIdx.x;
+    fetch_rows(ch);
     if (ch < n_chunks) fetch(ch);
+    fetch_rows(ch + gridDim.x);
     for (; ch < n_chunks; ch += gridDim.x) {
         const int64_t row0 = ch * WG_R;
         __syncthreads();                                                         // the previous tile's gathers are done
@@ -317,6 +337,7 @@ __global__ __launch_bounds__(256) void rows_wgrad_bf16_kernel(const uint16_t *__
         }
         __syncthreads();
         if (ch + gridDim.x < n_chunks) fetch(ch + gridDim.x);
+        fetch_rows(ch + 2 * (int64_t)gridDim.x);
         const int nrow = (int)min((int64_t)WG_R, rows - row0);
         // Fragments through the LDS transpose read: ds_read_b64_tr_b16 hands lane i of a 16-lane group column i of a 4-row x
         // 16-column block whose 16 four-element pieces the lanes address (piece i = row i>>2, columns 4*(i&3)..+3).  Groups
@@ -440,6 +461,6 @@ extern "C" int pcacc_rows_wgrad_cat_bf16(const uint16_t *dy, const uint16_t *dy_
                                          const int32_t *b_index, int32_t ka, int32_t x_relu, int64_t rows, int32_t k, int32_t n,
                                          float *dw_aug, void *workspace, size_t workspace_bytes, void *stream)
 {
-    if (!xb || ka <= 0 || ka >= k || ka % 8) return PCACC_E_ARG;
+    if (!xb || ka <= 0 || ka >= k || ka % 8 || (k & (k - 1))) return PCACC_E_ARG;
     return rows_wgrad_bf16_any(dy, dy_mask, xa, RowPieces{xb, b_index, ka}, x_relu, rows, k, n, dw_aug, workspace, workspace_bytes, stream);
 }
