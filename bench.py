@@ -49,8 +49,27 @@ def build(cfg, device, seed=0):
     return model, opt, FuseLoss(cfg['loss'])
 
 
+class BatchFeed(object):
+    """One batch ahead: next() hands out the batch whose voxelisation was queued (on a side stream) during the previous step
+    and queues the following one -- every step still voxelises and collates exactly one batch."""
+
+    def __init__(self, batcher, batch_of, ahead):
+        self.batcher, self.batch_of, self.ahead, self.i = batcher, batch_of, ahead, 0
+        self.pending = batcher.start(batch_of(0), side_stream=True) if ahead else None
+
+    def next(self):
+        if not self.ahead:
+            inp = self.batcher(self.batch_of(self.i))
+            self.i += 1
+            return inp
+        inp = self.batcher.finish(self.pending)
+        self.i += 1
+        self.pending = self.batcher.start(self.batch_of(self.i), side_stream=True)
+        return inp
+
+
 def train_step(model, opt, loss_fn, batcher, scenes, allreduce, clip):
-    inp = batcher(scenes)
+    inp = scenes.next() if isinstance(scenes, BatchFeed) else batcher(scenes)
     out = model(inp)
     stats = loss_fn(out, inp)
     stats['loss'].backward()
@@ -100,6 +119,7 @@ def main():
     ap.add_argument('--batch', type=int, default=4, help='sequences per GPU per step (reference default: train.batch_size = 4, configs/default.yaml:33)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-prefetch', action='store_true', help='voxelise each batch at the start of its own step instead of one step ahead on a side stream')
     args = ap.parse_args()
 
     # PCACC_DIST_BACKEND=gloo lets the N > 1 path be exercised on a box with fewer GPUs than ranks (ranks then share
@@ -130,15 +150,16 @@ def main():
     clip = cfg['train']['grad_clip']
 
     torch.manual_seed(1234 + rank)
+    feed = BatchFeed(batcher, batch_of, not args.no_prefetch)
     for i in range(args.warmup):
-        train_step(model, opt, loss_fn, batcher, batch_of(i), allreduce, clip)
+        train_step(model, opt, loss_fn, batcher, feed, allreduce, clip)
 
     native.scatter_timer = []
     pdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        train_step(model, opt, loss_fn, batcher, batch_of(i), allreduce, clip)
+        train_step(model, opt, loss_fn, batcher, feed, allreduce, clip)
     torch.cuda.synchronize()
     pdist.barrier()
     dt = pdist.max_over_ranks(time.perf_counter() - t0, device)

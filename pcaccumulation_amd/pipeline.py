@@ -18,37 +18,83 @@ def sample_to_device(sample, device):
     return {k: torch.from_numpy(v).to(device) for k, v in sample.items()}
 
 
+class _Pending(object):
+    """A batch whose voxelisation has been launched: everything that does not depend on the voxel counts is already queued."""
+    __slots__ = ('samples', 'launched', 'static', 'tis', 'counts', 'event', 'stream', 'device')
+
+
 class DeviceBatcher(object):
+    """`batcher(samples)` = voxelise + collate now.  `start(samples)` / `finish(pending)` split the same work so that a training
+    loop can queue the voxelisation of batch i+1 on a side stream while batch i trains (the DataLoader workers' role in the
+    reference, libs/dataset.py:183-199): the voxel counts come back through pinned memory and an event, so finish() does not
+    drain the compute stream -- the first of the three host stalls of a step otherwise."""
+
     def __init__(self, cfg):
         self.voxeliser = Voxelization(cfg['voxel_generator'])
+        self._side = None
 
-    def __call__(self, samples):
-        vox = self.voxeliser
-        dev = samples[0]['input_points'].device
-        coords, p2vs, tis, n_vox = [], [], [], []
-        offset = 0
-        launched = []
-        for s in samples:                                                # launch every voxelisation, then ONE host sync
+    def _launch(self, p):
+        vox, samples, dev = self.voxeliser, p.samples, p.device
+        p.launched = []
+        for s in samples:                                                # launch every voxelisation, then ONE read-back
             pts4 = torch.cat((s['input_points'].float(), s['time_indice'].float()), dim=1)
-            launched.append(vox.voxelize_launch(pts4))
-        counts = torch.cat([l[2] for l in launched]).cpu().tolist()
+            p.launched.append(vox.voxelize_launch(pts4))
+        counts = torch.cat([l[2] for l in p.launched])
+        p.tis = [torch.cat((torch.full((s['time_indice'].shape[0], 1), float(b), dtype=torch.float64, device=dev),
+                            s['time_indice'].double()), dim=1) for b, s in enumerate(samples)]
+        cat = lambda key: torch.cat([s[key] for s in samples], dim=0)
+        p.static = {'input_points': cat('input_points'), 'num_points': cat('num_points'), 'time_indice': torch.cat(p.tis, 0),
+                    'sd_labels': cat('sd_labels'), 'inst_labels': cat('inst_labels'), 'fb_labels': cat('fb_labels'),
+                    'ego_motion_gt': torch.stack([s['ego_motion_gt'] for s in samples], 0)}
+        return counts
+
+    def start(self, samples, side_stream=False):
+        p = _Pending()
+        p.samples, p.device = samples, samples[0]['input_points'].device
+        p.stream = p.event = None
+        if side_stream and p.device.type == 'cuda':
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=p.device)
+            p.stream = self._side
+            with torch.cuda.stream(p.stream):
+                counts = self._launch(p)
+                p.counts = torch.empty(counts.shape, dtype=counts.dtype, pin_memory=True)
+                p.counts.copy_(counts, non_blocking=True)
+                p.event = torch.cuda.Event()
+                p.event.record(p.stream)
+        else:
+            p.counts = self._launch(p)
+        return p
+
+    def finish(self, p):
+        vox, samples, dev = self.voxeliser, p.samples, p.device
+        if p.event is not None:
+            p.event.synchronize()                                        # long past when the batch was started a step ago
+            main = torch.cuda.current_stream(dev)
+            main.wait_event(p.event)
+            for t in [x for l in p.launched for x in l[:2]] + list(p.static.values()):
+                t.record_stream(main)                                    # allocated on the side stream, consumed on this one
+            counts = p.counts.tolist()
+        else:
+            counts = p.counts.cpu().tolist()
+        coords, p2vs, n_vox = [], [], []
+        offset = 0
         for b, s in enumerate(samples):
-            t = s['time_indice']
             m = int(counts[b])
-            c, p2v = launched[b][0][:m], launched[b][1]
+            c, p2v = p.launched[b][0][:m], p.launched[b][1]
             bcol = torch.full((m, 1), float(b), dtype=torch.float64, device=dev)
             coords.append(torch.cat((bcol, c.double()), dim=1))
-            tis.append(torch.cat((torch.full((t.shape[0], 1), float(b), dtype=torch.float64, device=dev), t.double()), dim=1))
             p2vs.append((p2v + offset)[:, None])
             n_vox.append(m)
             offset += m
-        cat = lambda key: torch.cat([s[key] for s in samples], dim=0)
         grid = torch.tensor(list(vox.grid_size) + [vox.n_sweeps], dtype=torch.int64)
-        return {
-            'input_points': cat('input_points'), 'num_points': cat('num_points'), 'time_indice': torch.cat(tis, 0),
-            'sd_labels': cat('sd_labels'), 'inst_labels': cat('inst_labels'), 'fb_labels': cat('fb_labels'),
-            'ego_motion_gt': torch.stack([s['ego_motion_gt'] for s in samples], 0),
+        out = dict(p.static)
+        out.update({
             'inst_motion_gt': [s['inst_motion_gt'] for s in samples],
             'coordinates': torch.cat(coords, 0), 'num_voxels': native.upload_small(n_vox, torch.int64, dev),
             'shape': native.upload_small(grid[None].repeat(len(samples), 1), torch.int64, dev), 'point_to_voxel_map': torch.cat(p2vs, 0),
-        }
+        })
+        return out
+
+    def __call__(self, samples):
+        return self.finish(self.start(samples))

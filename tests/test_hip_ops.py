@@ -816,3 +816,23 @@ def test_svd3_matches_library_and_its_gradient(native, dev):
     assert (rot(u, v).detach().cpu().double() - rot(ur, vr).detach()).abs().max() < 1e-5
     scale = ar.grad.abs().amax(dim=(1, 2), keepdim=True)
     assert ((ad.grad.cpu().double() - ar.grad).abs() / scale).max() < 1e-3         # fp32 u, s, v feed a 1/(s_j^2 - s_i^2) formula
+
+
+def test_batcher_side_stream_start_finish_equals_call(native, dev):
+    """DeviceBatcher.start(side_stream=True) / finish() (voxelisation queued a step ahead, counts through pinned memory) hands
+    the model the same input dictionary as the one-shot call -- every tensor bit-identical."""
+    from pcaccumulation_amd.pipeline import DeviceBatcher, sample_to_device
+    from pcaccumulation_amd.synthetic import make_sequence
+    cfg = default_config('waymo', 'train', n_sweeps=3, xy_range=8)
+    samples = [sample_to_device(make_sequence(70 + i, 3, 1200 + 300 * i, cfg), dev) for i in range(3)]
+    batcher = DeviceBatcher(cfg)
+    want = batcher(samples)
+    pend = [batcher.start(samples, side_stream=True) for _ in range(3)]          # several in flight, consumed in order
+    for p in pend:
+        got = batcher.finish(p)
+        assert set(got) == set(want)
+        for k, v in want.items():
+            if torch.is_tensor(v):
+                assert v.dtype == got[k].dtype and torch.equal(v, got[k]), k
+            else:
+                assert len(v) == len(got[k]) and all(torch.equal(a, b) for a, b in zip(v, got[k])), k
