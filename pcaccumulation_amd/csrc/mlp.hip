@@ -159,6 +159,126 @@ __global__ __launch_bounds__(MLP_ROWS) void rows_linear_kernel(const void *__res
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The edges of the point chains: few inputs (the 9 pillar-encoder features, 2/3-d positional encodings, and the backward-data
+// pass of the 2-output heads: k <= 9) or few outputs (the 2-output heads: n <= 4).  One row per lane wastes the machine there
+// (a 64-lane workgroup per 33 KB of LDS: 0.5-1.3 TB/s); these are plain streaming kernels instead.
+//   few inputs : one lane per (row, 8 consecutive outputs); the row's k inputs come through L1 (the n/8 lanes of a row are
+//                adjacent), the weights from LDS; 16- or 32-byte stores.  Same fp32 FMA order over k as rows_linear_kernel.
+//   few outputs: k/8 lanes per row, each 8 consecutive inputs (16- or 32-byte loads), partial dot products folded with
+//                xor-shuffles inside the lane group.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void rows_linear_fewk_kernel(const void *__restrict__ X, const void *__restrict__ in_mask,
+                                                               const float *__restrict__ W, const float *__restrict__ bias,
+                                                               const void *__restrict__ residual, const void *__restrict__ out_mask,
+                                                               void *__restrict__ Y, int64_t rows, int N, int flags, int dt)
+{
+    const bool x_bf = dt & MLP_X_BF16, im_bf = dt & MLP_INMASK_BF16, r_bf = dt & MLP_RES_BF16, om_bf = dt & MLP_OUTMASK_BF16,
+               y_bf = dt & MLP_Y_BF16;
+    __shared__ float wl[128 * K + 128];
+    for (int i = threadIdx.x; i < N * K; i += 256) wl[i] = W[i];
+    for (int i = threadIdx.x; i < N; i += 256) wl[128 * K + i] = bias ? bias[i] : 0.f;
+    __syncthreads();
+    const int groups = N / 8;
+    const int64_t total = rows * groups;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t row = e / groups;
+        const int n0 = (int)(e - row * groups) * 8;
+        float x[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float v = mlp_ld1(X, x_bf, row * K + k);
+            if (flags & MLP_PRE_RELU) v = fmaxf(v, 0.f);
+            if (in_mask && !(mlp_ld1(in_mask, im_bf, row * K + k) > 0.f)) v = 0.f;
+            x[k] = v;
+        }
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            acc[j] = wl[128 * K + n0 + j];
+#pragma unroll
+            for (int k = 0; k < K; ++k) acc[j] = fmaf(x[k], wl[(n0 + j) * K + k], acc[j]);
+        }
+        const int64_t g4 = (row * N + n0) / 4;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float4 v = make_float4(acc[4 * h], acc[4 * h + 1], acc[4 * h + 2], acc[4 * h + 3]);
+            if (residual) { const float4 r = pcacc_ld4(residual, r_bf, g4 + h); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+            if (flags & MLP_POST_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (out_mask) {
+                const float4 mk = pcacc_ld4(out_mask, om_bf, g4 + h);
+                if (!(mk.x > 0.f)) v.x = 0.f;
+                if (!(mk.y > 0.f)) v.y = 0.f;
+                if (!(mk.z > 0.f)) v.z = 0.f;
+                if (!(mk.w > 0.f)) v.w = 0.f;
+            }
+            pcacc_st4(Y, y_bf, g4 + h, v);
+        }
+    }
+}
+
+template <int K, int N>
+__global__ __launch_bounds__(256) void rows_linear_fewn_kernel(const void *__restrict__ X, const void *__restrict__ in_mask,
+                                                               const float *__restrict__ W, const float *__restrict__ bias,
+                                                               const void *__restrict__ residual, const void *__restrict__ out_mask,
+                                                               void *__restrict__ Y, int64_t rows, int flags, int dt)
+{
+    const bool x_bf = dt & MLP_X_BF16, im_bf = dt & MLP_INMASK_BF16, r_bf = dt & MLP_RES_BF16, om_bf = dt & MLP_OUTMASK_BF16,
+               y_bf = dt & MLP_Y_BF16;
+    constexpr int LANES = K / 8;                                   // lanes per row (4, 8 or 16)
+    const int sub = threadIdx.x % LANES;
+    float w[N][8];
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) w[j][c] = W[j * K + sub * 8 + c];
+    const int64_t total = rows * LANES;
+    const int64_t padded = (total + 255) / 256 * 256;              // whole waves stay in the loop: the shuffles need all lanes
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < padded; e += (int64_t)gridDim.x * 256) {
+        const int64_t row = e / LANES;
+        const bool live = row < rows;
+        float x[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live) {
+                const int64_t g4 = (row * K + sub * 8) / 4 + h;
+                v = pcacc_ld4(X, x_bf, g4);
+                if (flags & MLP_PRE_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (in_mask) {
+                    const float4 mk = pcacc_ld4(in_mask, im_bf, g4);
+                    if (!(mk.x > 0.f)) v.x = 0.f;
+                    if (!(mk.y > 0.f)) v.y = 0.f;
+                    if (!(mk.z > 0.f)) v.z = 0.f;
+                    if (!(mk.w > 0.f)) v.w = 0.f;
+                }
+            }
+            x[4 * h] = v.x, x[4 * h + 1] = v.y, x[4 * h + 2] = v.z, x[4 * h + 3] = v.w;
+        }
+        float acc[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            float a = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) a = fmaf(x[c], w[j][c], a);
+#pragma unroll
+            for (int d = LANES / 2; d; d >>= 1) a += __shfl_xor(a, d, 64);
+            acc[j] = a;
+        }
+        if (live && sub == 0) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                float v = acc[j] + (bias ? bias[j] : 0.f);
+                if (residual) v += mlp_ld1(residual, r_bf, row * N + j);
+                if (flags & MLP_POST_RELU) v = fmaxf(v, 0.f);
+                if (out_mask && !(mlp_ld1(out_mask, om_bf, row * N + j) > 0.f)) v = 0.f;
+                mlp_st1(Y, y_bf, row * N + j, v);
+            }
+        }
+    }
+}
+
 static bool mlp_k_supported(int k) { return k == 2 || k == 3 || k == 4 || k == 9 || k == 32 || k == 64 || k == 128; }
 
 static int rows_linear_any(const void *x, const void *in_mask, const float *w, const float *bias, const void *residual,
@@ -168,6 +288,26 @@ static int rows_linear_any(const void *x, const void *in_mask, const float *w, c
     if (rows == 0) return PCACC_OK;
     if (!x || !w || !y) return PCACC_E_ARG;
     hipStream_t s = pcacc_stream(stream);
+    if (k <= 9 && n % 8 == 0) {                                    // few inputs: lane per (row, 8 outputs)
+        const int grid = pcacc_grid(rows * (n / 8), 256, PCACC_CUS * 16);
+#define FEWK(KK) rows_linear_fewk_kernel<KK><<<grid, 256, 0, s>>>(x, in_mask, w, bias, residual, out_mask, y, rows, n, flags, dt)
+        if (k == 2) FEWK(2);
+        else if (k == 3) FEWK(3);
+        else if (k == 4) FEWK(4);
+        else FEWK(9);
+#undef FEWK
+        PCACC_CHECK_LAUNCH();
+        return PCACC_OK;
+    }
+    if (n <= 2 && k >= 32) {                                       // few outputs: k/8 lanes per row
+        const int grid = pcacc_grid(rows * (k / 8), 256, PCACC_CUS * 16);
+#define FEWN(KK, NN) rows_linear_fewn_kernel<KK, NN><<<grid, 256, 0, s>>>(x, in_mask, w, bias, residual, out_mask, y, rows, flags, dt)
+        if (n == 1) { if (k == 32) FEWN(32, 1); else if (k == 64) FEWN(64, 1); else FEWN(128, 1); }
+        else { if (k == 32) FEWN(32, 2); else if (k == 64) FEWN(64, 2); else FEWN(128, 2); }
+#undef FEWN
+        PCACC_CHECK_LAUNCH();
+        return PCACC_OK;
+    }
     const int feat = k > n ? k : n;
     const int tile_rows = feat <= 64 ? 128 : 64;
     const int n_tiles = (int)((rows + tile_rows - 1) / tile_rows);

@@ -358,7 +358,7 @@ def test_chamfer_golden_from_reference_cpp(native, dev, golden):
 
 
 # ---------------------------------------------------------------- A4 MLP part: fused per-point linear layers
-@pytest.mark.parametrize('k,n', [(9, 64), (64, 32), (32, 32), (3, 32), (32, 64), (128, 128), (128, 2), (4, 32), (64, 128), (2, 7)])
+@pytest.mark.parametrize('k,n', [(9, 64), (64, 32), (32, 32), (3, 32), (32, 64), (128, 128), (128, 2), (4, 32), (64, 128), (2, 7), (2, 128), (64, 2)])
 def test_rows_linear_and_wgrad_vs_torch(native, dev, k, n):
     rng = np.random.RandomState(k * 131 + n)
     rows = 5000 + k                                            # not a multiple of the tile size
