@@ -56,6 +56,9 @@ class DeviceBatcher(object):
             if self._side is None:
                 self._side = torch.cuda.Stream(device=p.device)
             p.stream = self._side
+            # the side stream starts where the compute stream stands NOW in queue order (the host may be many launches ahead of
+            # the GPU): the copies then overlap what is queued after this point, not the kernels queued before it
+            p.stream.wait_event(torch.cuda.current_stream(p.device).record_event())
             with torch.cuda.stream(p.stream):
                 counts = self._launch(p)
                 p.counts = torch.empty(counts.shape, dtype=counts.dtype, pin_memory=True)
