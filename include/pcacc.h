@@ -407,6 +407,19 @@ int pcacc_frames_max(const void *x, int dtype, int64_t n_seq, int32_t frames, in
 int pcacc_frames_max_backward(const void *grad_out, const uint8_t *arg, int dtype, int64_t n_seq, int32_t frames, int64_t plane,
                               void *grad_x, void *stream);
 
+/* A10 point heads: nn.BatchNorm1d in training mode over [rows, c] rows -- models/unet.py:240-245 (SegHead1D: Linear, BatchNorm1d,
+ * ReLU, Linear on the K foreground points; batch statistics over the rows).  x, y: f32 or bf16 (PCACC_F32 | PCACC_BF16), c a
+ * multiple of 4 / 8 with 256 % (c / 4 | 8) == 0, c <= 256;  gamma, beta [c] f32 or NULL;  running_mean / running_var [c] f32
+ * updated in place when given (momentum; unbiased variance, as torch);  save_mean, save_invstd [c] f32 out (for backward).
+ * backward: grad_x in the type of x, grad_gamma / grad_beta [c] f32. */
+int pcacc_bn_rows_workspace_bytes(int64_t rows, int32_t c, size_t *bytes /*host*/);
+int pcacc_bn_rows_forward(const void *x, int dtype, int64_t rows, int32_t c, const float *gamma, const float *beta, float eps,
+                          float momentum, float *running_mean, float *running_var, void *y, float *save_mean,
+                          float *save_invstd, void *workspace, size_t workspace_bytes, void *stream);
+int pcacc_bn_rows_backward(const void *grad_y, const void *x, int dtype, int64_t rows, int32_t c, const float *gamma,
+                           const float *save_mean, const float *save_invstd, void *grad_x, float *grad_gamma, float *grad_beta,
+                           void *workspace, size_t workspace_bytes, void *stream);
+
 /* Host words -> device memory as kernel arguments (asynchronous, unlike a pageable hipMemcpy on the compute stream):
  * n 32-bit words from host_words to dst, 240 per launch.  For the per-step index tables a host loop of the reference
  * becomes (sample offsets, per-pair counts, thresholds). */

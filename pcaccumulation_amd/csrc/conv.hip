@@ -573,34 +573,33 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_wgrad_kernel(const uint16_
             }
         }
     }
-    // The pixel groups of a workgroup hold partial sums of the same (co, ci) tiles: fold them into group 0 through the staging
-    // LDS (free now), a few taps at a time, so that the workspace holds one slot per workgroup instead of one per wave
-    // (32x32 layers: 113 MB of partials per launch became 28 MB, for this kernel's stores and for the reduce launch's loads).
+    // The pixel groups of a workgroup hold partial sums of the same (co, ci) tiles: fold them through the staging LDS (free now)
+    // so that the workspace holds one slot per workgroup instead of one per wave (32x32 layers: 113 MB of partials per launch
+    // became 28 MB, for this kernel's stores and for the reduce launch's loads).  Tap t of a pair is owned by pixel group
+    // t % GROUPS: in round r every wave hands the taps owned by group (grp + r) % GROUPS to that group, so each tap travels once
+    // per round, the adds and the final stores are spread over all waves.
     if (GROUPS > 1) {
         constexpr int LDS_FLOATS = (CV_TH * CV_TW * YS + CV_PH * CV_PW * XS) / 2;
         constexpr int T_FIT = LDS_FLOATS / (PAIRS * 1024), T_STEP = T_FIT > 9 ? 9 : T_FIT;
         static_assert(T_STEP >= 1, "staging LDS too small for the accumulator exchange");
         float *red = reinterpret_cast<float *>(lds);
 #pragma unroll
-        for (int g = 1; g < GROUPS; ++g) {
+        for (int r = 1; r < GROUPS; ++r) {
+            const int to = (grp + r) % GROUPS;
 #pragma unroll
             for (int t0 = 0; t0 < 9; t0 += T_STEP) {
                 __syncthreads();
-                if (grp == g) {
 #pragma unroll
-                    for (int tap = 0; tap < 9; ++tap)
-                        if (tap >= t0 && tap < t0 + T_STEP)
+                for (int tap = 0; tap < 9; ++tap)
+                    if (tap >= t0 && tap < t0 + T_STEP && tap % GROUPS == to)
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) red[((pair * T_STEP + (tap - t0)) * 16 + r) * 64 + lane] = acc[tap][r];
-                }
+                        for (int q = 0; q < 16; ++q) red[((pair * T_STEP + (tap - t0)) * 16 + q) * 64 + lane] = acc[tap][q];
                 __syncthreads();
-                if (grp == 0) {
 #pragma unroll
-                    for (int tap = 0; tap < 9; ++tap)
-                        if (tap >= t0 && tap < t0 + T_STEP)
+                for (int tap = 0; tap < 9; ++tap)
+                    if (tap >= t0 && tap < t0 + T_STEP && tap % GROUPS == grp)
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) acc[tap][r] += red[((pair * T_STEP + (tap - t0)) * 16 + r) * 64 + lane];
-                }
+                        for (int q = 0; q < 16; ++q) acc[tap][q] += red[((pair * T_STEP + (tap - t0)) * 16 + q) * 64 + lane];
             }
         }
         __syncthreads();
@@ -610,16 +609,17 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_wgrad_kernel(const uint16_
 #pragma unroll
             for (int g = 1; g < GROUPS; ++g) bsum += red[((g - 1) * PAIRS + pair) * 64 + lane];
     }
-    if (grp != 0) return;
     // slot of this workgroup: [CO][9][CI] then [CO] bias sums; D has lane = ci, register quads = co
     float *mine = partial + (int64_t)blockIdx.x * (CO * 9 * CI + CO);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
+        if (tap % GROUPS == grp)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            mine[((int64_t)co * 9 + tap) * CI + it * 32 + lp] = acc[tap][r];
-        }
+            for (int r = 0; r < 16; ++r) {
+                const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                mine[((int64_t)co * 9 + tap) * CI + it * 32 + lp] = acc[tap][r];
+            }
+    if (grp != 0) return;
     bsum += __shfl_xor(bsum, 32, 64);                          // the two half-waves hold pixels 0-7 / 8-15 of the same channel
     if (it == 0 && lh == 0) mine[CO * 9 * CI + ct * 32 + lp] = bsum;
 }

@@ -53,7 +53,7 @@ EXPORTS = [
     'pcacc_seg_loss_workspace_bytes', 'pcacc_seg_loss_forward', 'pcacc_seg_loss_backward',
     'pcacc_offset_loss_workspace_bytes', 'pcacc_offset_loss_forward', 'pcacc_offset_loss_backward',
     'pcacc_frames_max', 'pcacc_frames_max_backward', 'pcacc_rows_linear_cat_bf16', 'pcacc_rows_wgrad_cat_bf16',
-    'pcacc_svd3', 'pcacc_svd3_backward',
+    'pcacc_svd3', 'pcacc_svd3_backward', 'pcacc_bn_rows_workspace_bytes', 'pcacc_bn_rows_forward', 'pcacc_bn_rows_backward',
 ]
 
 
@@ -724,3 +724,45 @@ def svd3_backward(u, s, v, gu, gs, gv):
                                      _opt(gs, torch.float32, 'grad_s'), _opt(gv, torch.float32, 'grad_v'), _i64(u.shape[0]), _dev(ga), _stream()),
            'svd3_backward')
     return ga
+
+
+def bn_rows_supported(x):
+    c = x.shape[1] if x.dim() == 2 else 0
+    v = 8 if x.dtype == torch.bfloat16 else 4
+    return x.dim() == 2 and x.dtype in (torch.float32, torch.bfloat16) and x.shape[0] >= 1 and 0 < c <= 256 and c % v == 0 and 256 % (c // v) == 0
+
+
+def _bn_ws(rows, c, dev):
+    need = ctypes.c_size_t(0)
+    _check(lib().pcacc_bn_rows_workspace_bytes(_i64(rows), int(c), ctypes.byref(need)), 'bn_rows_workspace')
+    return _ws(need.value, dev)
+
+
+def bn_rows_forward(x, gamma, beta, eps, momentum, running_mean, running_var):
+    """Training-mode BatchNorm1d over the rows of x [rows,c] (include/pcacc.h): -> (y like x, save_mean [c], save_invstd [c]);
+    running_mean / running_var (f32, or None) are updated in place."""
+    rows, c = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty((c,), dtype=torch.float32, device=x.device)
+    invstd = torch.empty((c,), dtype=torch.float32, device=x.device)
+    ws = _bn_ws(rows, c, x.device)
+    _check(lib().pcacc_bn_rows_forward(_dev(x, None, 'x'), _dtype_code(x), _i64(rows), int(c), _opt(gamma, torch.float32, 'gamma'),
+                                       _opt(beta, torch.float32, 'beta'), ctypes.c_float(eps), ctypes.c_float(momentum),
+                                       _opt(running_mean, torch.float32, 'running_mean'), _opt(running_var, torch.float32, 'running_var'),
+                                       _dev(y), _dev(mean), _dev(invstd), _dev(ws), ctypes.c_size_t(ws.numel()), _stream()), 'bn_rows_forward')
+    return y, mean, invstd
+
+
+def bn_rows_backward(grad_y, x, gamma, save_mean, save_invstd):
+    """-> (grad_x like x, grad_gamma [c] f32, grad_beta [c] f32)."""
+    rows, c = x.shape
+    gx = torch.empty_like(x)
+    gg = torch.empty((c,), dtype=torch.float32, device=x.device)
+    gb = torch.empty((c,), dtype=torch.float32, device=x.device)
+    ws = _bn_ws(rows, c, x.device)
+    if grad_y.dtype != x.dtype:
+        raise NativeError('bn_rows_backward: grad_y must have the type of x')
+    _check(lib().pcacc_bn_rows_backward(_dev(grad_y, None, 'grad_y'), _dev(x, None, 'x'), _dtype_code(x), _i64(rows), int(c),
+                                        _opt(gamma, torch.float32, 'gamma'), _dev(save_mean, torch.float32), _dev(save_invstd, torch.float32),
+                                        _dev(gx), _dev(gg), _dev(gb), _dev(ws), ctypes.c_size_t(ws.numel()), _stream()), 'bn_rows_backward')
+    return gx, gg, gb

@@ -674,3 +674,33 @@ class _Svd3(torch.autograd.Function):
 def svd3(a):
     """(u, s, v) with a = u diag(s) v^T, as torch.svd (toolbox/register_utils.py:293)."""
     return _Svd3.apply(a)
+
+
+class _BatchNormRows(torch.autograd.Function):
+    """Training-mode nn.BatchNorm1d on [rows, c] rows (models/unet.py:240-245) in four streaming passes (csrc/bn.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, momentum, running_mean, running_var):
+        x = x.contiguous()
+        y, mean, invstd = native.bn_rows_forward(x, gamma, beta, eps, momentum, running_mean, running_var)
+        ctx.save_for_backward(x, gamma, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, gamma, mean, invstd = ctx.saved_tensors
+        gx, gg, gb = native.bn_rows_backward(gy.contiguous().to(x.dtype), x, gamma, mean, invstd)
+        return gx, (gg if gamma is not None else None), (gb if gamma is not None else None), None, None, None, None
+
+
+def batch_norm_rows(x, bn):
+    """`bn(x)` for an nn.BatchNorm1d `bn` on 2-D rows.  Training mode on the GPU with a momentum and f32 affine parameters runs
+    the fused passes (running statistics and num_batches_tracked updated as the module does); everything else is the module."""
+    if not (bn.training and x.is_cuda and x.dim() == 2 and bn.momentum is not None and native.bn_rows_supported(x)
+            and x.shape[0] >= MIN_ROWS_FUSED_LINEAR and not torch.is_autocast_enabled()
+            and (bn.weight is None or bn.weight.dtype == torch.float32)):
+        return bn(x)
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+    return _BatchNormRows.apply(x, bn.weight, bn.bias, float(bn.eps), float(bn.momentum), rm, rv)

@@ -93,9 +93,9 @@ class STPN(nn.Module):
     @staticmethod
     def point_head(head, x):
         """SegHead1D = Linear, BatchNorm1d, ReLU, Linear (models/unet.py:240-245): the two Linear layers are fused row
-        kernels, BatchNorm1d (batch statistics over the K points in train mode, trap 16) stays the library op."""
+        kernels, BatchNorm1d (batch statistics over the K points in train mode, trap 16) four streaming passes (ops.batch_norm_rows)."""
         lin0, bn, _, lin1 = head.seg_head
-        return ops.linear_rows(bn(ops.linear_rows(x, lin0)), lin1, pre_relu=True, out_dtype=torch.float32)
+        return ops.linear_rows(ops.batch_norm_rows(ops.linear_rows(x, lin0), bn), lin1, pre_relu=True, out_dtype=torch.float32)
 
     def forward(self, x, points, time_indice, pc_range):
         """x [B,C,T,H,W]; points [K,3]; time_indice [K,2] -> (mos logits [K,2], offset [K,2], map [B,64,H,W])."""

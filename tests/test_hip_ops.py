@@ -836,3 +836,36 @@ def test_batcher_side_stream_start_finish_equals_call(native, dev):
                 assert v.dtype == got[k].dtype and torch.equal(v, got[k]), k
             else:
                 assert len(v) == len(got[k]) and all(torch.equal(a, b) for a, b in zip(v, got[k])), k
+
+
+@pytest.mark.parametrize('dtype,c', [(torch.float32, 128), (torch.bfloat16, 128), (torch.bfloat16, 64), (torch.float32, 32)])
+def test_batch_norm_rows_is_batchnorm1d(native, dev, dtype, c):
+    """models/unet.py:240-245: training-mode BatchNorm1d over K rows (trap 16) -- output, input / affine gradients, running
+    statistics and the batch counter against nn.BatchNorm1d fed float32 values of the same rows."""
+    from pcaccumulation_amd import ops
+    torch.manual_seed(7)
+    rows = 30_011
+    x = (torch.randn(rows, c, device=dev) * torch.linspace(0.5, 3.0, c, device=dev) + torch.linspace(-2.0, 2.0, c, device=dev)).to(dtype)
+    g = torch.randn(rows, c, device=dev).to(dtype)
+    mine, ref = torch.nn.BatchNorm1d(c).to(dev), torch.nn.BatchNorm1d(c).to(dev)
+    with torch.no_grad():
+        for bn in (mine, ref):
+            bn.weight.copy_(torch.linspace(0.5, 1.5, c))
+            bn.bias.copy_(torch.linspace(-1.0, 1.0, c))
+    xm = x.clone().requires_grad_(True)
+    ym = ops.batch_norm_rows(xm, mine)
+    ym.backward(g)
+    xr = x.float().clone().requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(g.float())
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    assert ym.dtype == dtype and (ym.float() - yr).abs().max() <= tol * yr.abs().max()
+    assert (xm.grad.float() - xr.grad).abs().max() <= tol * xr.grad.abs().max()
+    assert (mine.weight.grad - ref.weight.grad).abs().max() <= 1e-3 * ref.weight.grad.abs().max()
+    assert (mine.bias.grad - ref.bias.grad).abs().max() <= 1e-3 * ref.bias.grad.abs().max()
+    assert torch.allclose(mine.running_mean, ref.running_mean, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(mine.running_var, ref.running_var, rtol=1e-4, atol=1e-5)
+    assert int(mine.num_batches_tracked) == int(ref.num_batches_tracked) == 1
+    mine.eval()
+    ref.eval()
+    assert torch.allclose(ops.batch_norm_rows(x, mine).float(), ref(x.float()), rtol=tol, atol=tol)      # eval: the module itself
