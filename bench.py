@@ -127,6 +127,7 @@ def main():
     ap.add_argument('--batch', type=int, default=4, help='sequences per GPU per step (reference default: train.batch_size = 4, configs/default.yaml:33)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-miopen-find', action='store_true', help='library convolutions through the immediate-mode heuristic instead of the find-db')
     ap.add_argument('--no-prefetch', action='store_true', help='voxelise each batch at the start of its own step instead of one step ahead on a side stream')
     args = ap.parse_args()
 
@@ -143,6 +144,11 @@ def main():
     device = torch.device('cuda', local_rank % n_dev)
     torch.cuda.set_device(device)
     native.lib()
+    if not args.no_miopen_find:
+        # MIOpen find mode for the layers that stay with the library (c_in >= 128): the applicable solvers are benchmarked once
+        # per layer shape and the choice is kept in the user find-db (.miopen_cache/, travels with the repo); the immediate-mode
+        # heuristic picks kernels that are ~1.5 ms per step slower in total
+        torch.backends.cudnn.benchmark = True
 
     cfg = default_config('waymo', 'train', n_sweeps=T_FRAMES)
     cfg['misc']['compute_dtype'] = args.dtype

@@ -379,3 +379,46 @@ def test_gpu_device_sampler_flat_keypoint_gather():
     assert (perm1 - perm0).abs().max() < 1e-4, (perm1 - perm0).abs().max()
     assert abs(loss1 - loss0) <= 1e-4 * abs(loss0), (loss1, loss0)
     assert (g1 - g0).abs().max() <= 2e-2 * g0.abs().max(), ((g1 - g0).abs().max(), g0.abs().max())   # bf16 conv backward, atomic row sums
+
+
+@pytest.mark.gpu
+def test_gpu_library_conv_find_mode_is_the_same_step():
+    """bench.py lets MIOpen pick the solver of the c_in >= 128 layers by measurement (torch.backends.cudnn.benchmark): same
+    library, other kernels.  One bf16 train step with and without it: loss within 1e-3, U-Net bottleneck and head gradients
+    pointing the same way (cosine > 0.98)."""
+    from helpers import oracle_voxeliser
+    from pcaccumulation_amd.dataloader import collate_fn
+    from pcaccumulation_amd.synthetic import make_sequence, attach_voxels
+    cfg = default_config('waymo', 'train', n_sweeps=3, xy_range=8)
+    cfg['misc']['compute_dtype'] = 'bf16'
+    vox = oracle_voxeliser(cfg)
+    inp = collate_fn([attach_voxels(make_sequence(60, 3, 1500, cfg), vox), attach_voxels(make_sequence(61, 3, 1100, cfg), vox)])
+    dev = torch.device('cuda:0')
+    outs = []
+    before = torch.backends.cudnn.benchmark
+    try:
+        for find in (False, True):
+            torch.backends.cudnn.benchmark = find
+            torch.manual_seed(5)
+            model = MotionNet(cfg)
+            fill_state_dict_(model)
+            with torch.no_grad():
+                model.semseg_head.seg_head[3].bias += torch.tensor([17.0, 0.0])
+            model = model.to(dev).train()
+            model.channels_last_()
+            batch = _to(inp, dev)
+            torch.manual_seed(6)
+            out = model(batch)
+            stats = FuseLoss(cfg['loss'])(out, batch)
+            stats['loss'].backward()
+            grads = {k: p.grad.detach().float().cpu().clone() for k, p in model.named_parameters()
+                     if p.grad is not None and p.dim() == 4 and (k.startswith('unet.down_convs.3') or k.startswith('semseg_head'))}   # conv weights (a bias in front of a BatchNorm has a zero gradient: rounding noise only)
+            outs.append((float(stats['loss']), grads))
+    finally:
+        torch.backends.cudnn.benchmark = before
+    (l0, g0), (l1, g1) = outs
+    assert abs(l1 - l0) <= 1e-3 * abs(l0), (l0, l1)
+    assert g0 and set(g0) == set(g1)
+    for k in g0:                                   # bf16 sums in another order, and a few ReLU / arg-max decisions downstream of them
+        cos = torch.nn.functional.cosine_similarity(g1[k].reshape(-1), g0[k].reshape(-1), dim=0)
+        assert cos > 0.98, (k, float(cos))
