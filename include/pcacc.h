@@ -214,12 +214,15 @@ int pcacc_bilinear_gather_backward(const float *grad_out, int n_maps, int h, int
 /* The same gradient without atomics (index-ordered sums): pcacc_bilinear_base_cells writes, per point, the cell of its
  * upper-left tap (n_maps*h*w for points of no map); after pcacc_csr_build over those keys (m = n_maps*h*w + 1),
  * pcacc_bilinear_gather_backward_sorted sums, per map cell, the contributions of the four neighbouring base cells in
- * index order.  grad_out [k,c] and grad_fmap [n_maps,h,w,c] may each be f32 or bf16 (PCACC_F32 | PCACC_BF16). */
+ * index order (two launches: tap weights and gradient rows laid out in CSR order, then the per-cell sums over consecutive
+ * rows; workspace = those two tables).  grad_out [k,c] and grad_fmap [n_maps,h,w,c] may each be f32 or bf16. */
 int pcacc_bilinear_base_cells(const float *points, const int32_t *map_idx, int64_t k, int n_maps, int h, int w,
                               float x_scale, float y_scale, int32_t *cell, void *stream);
+int pcacc_bilinear_sorted_workspace_bytes(int64_t k, int c, int grad_dtype, size_t *bytes /*host*/);
 int pcacc_bilinear_gather_backward_sorted(const void *grad_out, int grad_dtype, int n_maps, int h, int w, int c,
-                                          const float *points, const int32_t *seg_offsets, const int32_t *order,
-                                          float x_scale, float y_scale, void *grad_fmap, int out_dtype, void *stream);
+                                          const float *points, const int32_t *seg_offsets, const int32_t *order, int64_t k,
+                                          float x_scale, float y_scale, void *grad_fmap, int out_dtype, void *workspace,
+                                          size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * A9. Ego-motion BEV warp -- models/motionnet.py:45-80 (get_transformed_grid) + :82-114 (warp_feats).

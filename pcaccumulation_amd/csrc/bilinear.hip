@@ -190,11 +190,33 @@ __global__ __launch_bounds__(256) void bilinear_base_cell_kernel(const float *__
     }
 }
 
+// Step 1 of the sorted backward: per point in CSR order, its four tap weights (0 where the tap is outside the map) and its
+// gradient row -- so that the per-cell loops below read consecutive rows with no dependent index loads and no divisions.
+template <int G_BF16>
+__global__ __launch_bounds__(256) void bilinear_sorted_prep_kernel(const void *__restrict__ grad_out, int c, int h, int w,
+                                                                   const float *__restrict__ pts, const int32_t *__restrict__ order,
+                                                                   int64_t k, float xs, float ys, float4 *__restrict__ wts,
+                                                                   void *__restrict__ g_sorted)
+{
+    const int lpp = c / 4;
+    const int64_t total = k * lpp;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t q = e / lpp;
+        const int ch = (int)(e - q * lpp) * 4;
+        const int64_t i = order[q];
+        store4<G_BF16>(g_sorted, q * c + ch, load4<G_BF16>(grad_out, i * c + ch));
+        if (ch == 0) {
+            const Taps t = make_taps<true>(__fdiv_rn(pts[i * 3 + 0], xs), __fdiv_rn(pts[i * 3 + 1], ys), w, h);
+            wts[q] = make_float4((t.vy0 && t.vx0) ? t.w00 : 0.f, (t.vy0 && t.vx1) ? t.w01 : 0.f, (t.vy1 && t.vx0) ? t.w10 : 0.f,
+                                 (t.vy1 && t.vx1) ? t.w11 : 0.f);
+        }
+    }
+}
+
 template <int G_BF16, int OUT_BF16>
-__global__ __launch_bounds__(256) void bilinear_gather_bwd_sorted_kernel(const void *__restrict__ grad_out, int n_maps, int h, int w, int c,
-                                                                         const float *__restrict__ pts,
+__global__ __launch_bounds__(256) void bilinear_gather_bwd_sorted_kernel(const void *__restrict__ g_sorted, const float4 *__restrict__ wts,
+                                                                         int n_maps, int h, int w, int c,
                                                                          const int32_t *__restrict__ seg_offsets,
-                                                                         const int32_t *__restrict__ order, float xs, float ys,
                                                                          void *__restrict__ grad_fmap)
 {
     const int lpp = c / 4;
@@ -211,12 +233,10 @@ __global__ __launch_bounds__(256) void bilinear_gather_bwd_sorted_kernel(const v
             const int64_t base = cell - (int64_t)ty * w - tx;
             const int b = seg_offsets[base], en = seg_offsets[base + 1];
             for (int q = b; q < en; ++q) {
-                const int64_t i = order[q];
-                const Taps t = make_taps<true>(__fdiv_rn(pts[i * 3 + 0], xs), __fdiv_rn(pts[i * 3 + 1], ys), w, h);
-                const bool valid = (ty ? t.vy1 : t.vy0) && (tx ? t.vx1 : t.vx0);
-                if (!valid) continue;
-                const float wt = ty ? (tx ? t.w11 : t.w10) : (tx ? t.w01 : t.w00);
-                const float4 g = load4<G_BF16>(grad_out, i * c + ch);
+                const float4 w4 = wts[q];
+                const float wt = tap == 0 ? w4.x : tap == 1 ? w4.y : tap == 2 ? w4.z : w4.w;
+                if (wt == 0.f) continue;                                         // outside the map (or an exact zero weight)
+                const float4 g = load4<G_BF16>(g_sorted, (int64_t)q * c + ch);
                 acc.x += wt * g.x; acc.y += wt * g.y; acc.z += wt * g.z; acc.w += wt * g.w;
             }
         }
@@ -235,16 +255,35 @@ extern "C" int pcacc_bilinear_base_cells(const float *points, const int32_t *map
     return PCACC_OK;
 }
 
-extern "C" int pcacc_bilinear_gather_backward_sorted(const void *grad_out, int grad_dtype, int n_maps, int h, int w, int c,
-                                                     const float *points, const int32_t *seg_offsets, const int32_t *order,
-                                                     float x_scale, float y_scale, void *grad_fmap, int out_dtype, void *stream)
+extern "C" int pcacc_bilinear_sorted_workspace_bytes(int64_t k, int c, int grad_dtype, size_t *bytes)
 {
-    if (n_maps <= 0 || h <= 0 || w <= 0 || c <= 0 || (c % 4)) return PCACC_E_ARG;
+    if (!bytes || k < 0 || c <= 0 || (c % 4) || (grad_dtype != PCACC_F32 && grad_dtype != PCACC_BF16)) return PCACC_E_ARG;
+    *bytes = pcacc_align((size_t)k * 16) + pcacc_align((size_t)k * c * (grad_dtype == PCACC_BF16 ? 2 : 4));
+    return PCACC_OK;
+}
+
+extern "C" int pcacc_bilinear_gather_backward_sorted(const void *grad_out, int grad_dtype, int n_maps, int h, int w, int c,
+                                                     const float *points, const int32_t *seg_offsets, const int32_t *order, int64_t k,
+                                                     float x_scale, float y_scale, void *grad_fmap, int out_dtype, void *workspace,
+                                                     size_t workspace_bytes, void *stream)
+{
+    if (n_maps <= 0 || h <= 0 || w <= 0 || c <= 0 || (c % 4) || k < 0) return PCACC_E_ARG;
     if ((grad_dtype != PCACC_F32 && grad_dtype != PCACC_BF16) || (out_dtype != PCACC_F32 && out_dtype != PCACC_BF16)) return PCACC_E_ARG;
-    if (!grad_out || !points || !seg_offsets || !order || !grad_fmap) return PCACC_E_ARG;
+    if (!grad_out || !points || !seg_offsets || !order || !grad_fmap || !workspace) return PCACC_E_ARG;
+    size_t need = 0;
+    pcacc_bilinear_sorted_workspace_bytes(k, c, grad_dtype, &need);
+    if (workspace_bytes < need) return PCACC_E_WORKSPACE;
     hipStream_t s = pcacc_stream(stream);
-    const int grid = pcacc_grid((int64_t)n_maps * h * w * (c / 4), 256);
-#define BGS(GB, OB) bilinear_gather_bwd_sorted_kernel<GB, OB><<<grid, 256, 0, s>>>(grad_out, n_maps, h, w, c, points, seg_offsets, order, x_scale, y_scale, grad_fmap)
+    float4 *wts = reinterpret_cast<float4 *>(workspace);
+    void *g_sorted = static_cast<char *>(workspace) + pcacc_align((size_t)k * 16);
+    if (k > 0) {
+        const int pgrid = pcacc_grid(k * (c / 4), 256);
+        if (grad_dtype == PCACC_BF16) bilinear_sorted_prep_kernel<1><<<pgrid, 256, 0, s>>>(grad_out, c, h, w, points, order, k, x_scale, y_scale, wts, g_sorted);
+        else bilinear_sorted_prep_kernel<0><<<pgrid, 256, 0, s>>>(grad_out, c, h, w, points, order, k, x_scale, y_scale, wts, g_sorted);
+    }
+    // many short workgroups: the per-cell loops are as long as the cell is crowded, a fine grid evens that out
+    const int grid = pcacc_grid((int64_t)n_maps * h * w * (c / 4), 256, PCACC_CUS * 64);
+#define BGS(GB, OB) bilinear_gather_bwd_sorted_kernel<GB, OB><<<grid, 256, 0, s>>>(g_sorted, wts, n_maps, h, w, c, seg_offsets, grad_fmap)
     if (grad_dtype == PCACC_BF16) { if (out_dtype == PCACC_BF16) BGS(1, 1); else BGS(1, 0); }
     else { if (out_dtype == PCACC_BF16) BGS(0, 1); else BGS(0, 0); }
 #undef BGS

@@ -48,7 +48,7 @@ EXPORTS = [
     'pcacc_sinkhorn_kabsch_workspace_bytes', 'pcacc_sinkhorn_kabsch', 'pcacc_chamfer_workspace_bytes', 'pcacc_chamfer_forward', 'pcacc_chamfer_backward',
     'pcacc_cluster_workspace_bytes', 'pcacc_cluster', 'pcacc_conv3x3_prepare_weights', 'pcacc_conv3x3_bf16',
     'pcacc_rows_linear_bf16', 'pcacc_rows_linear_mixed', 'pcacc_rows_wgrad_mixed',
-    'pcacc_segment_max_t', 'pcacc_segment_max_backward_t', 'pcacc_segment_sum_t', 'pcacc_rows_wgrad_bf16_workspace_bytes', 'pcacc_rows_wgrad_bf16', 'pcacc_sample_subsets', 'pcacc_conv3x3_wgrad_workspace_bytes', 'pcacc_conv3x3_wgrad_bf16', 'pcacc_upload_words', 'pcacc_bilinear_base_cells', 'pcacc_bilinear_gather_backward_sorted', 'pcacc_prep_points',
+    'pcacc_segment_max_t', 'pcacc_segment_max_backward_t', 'pcacc_segment_sum_t', 'pcacc_rows_wgrad_bf16_workspace_bytes', 'pcacc_rows_wgrad_bf16', 'pcacc_sample_subsets', 'pcacc_conv3x3_wgrad_workspace_bytes', 'pcacc_conv3x3_wgrad_bf16', 'pcacc_upload_words', 'pcacc_bilinear_base_cells', 'pcacc_bilinear_sorted_workspace_bytes', 'pcacc_bilinear_gather_backward_sorted', 'pcacc_prep_points',
     'pcacc_sinkhorn_train_workspace_bytes', 'pcacc_sinkhorn_forward', 'pcacc_sinkhorn_backward',
     'pcacc_seg_loss_workspace_bytes', 'pcacc_seg_loss_forward', 'pcacc_seg_loss_backward',
     'pcacc_offset_loss_workspace_bytes', 'pcacc_offset_loss_forward', 'pcacc_offset_loss_backward',
@@ -531,10 +531,14 @@ def bilinear_gather_backward_sorted(grad_out, shape, points, map_idx, x_scale, y
                                            int(n_maps), int(h), int(w), ctypes.c_float(x_scale), ctypes.c_float(y_scale),
                                            _dev(cells), _stream()), 'bilinear_base_cells')
     offs, order = csr_build(cells, n_maps * h * w + 1)
+    need = ctypes.c_size_t(0)
+    _check(lib().pcacc_bilinear_sorted_workspace_bytes(_i64(k), int(c), _dtype_code(grad_out), ctypes.byref(need)), 'bilinear_sorted_workspace')
+    ws = _ws(need.value, dev)
     _check(lib().pcacc_bilinear_gather_backward_sorted(_dev(grad_out, None, 'grad_out'), _dtype_code(grad_out), int(n_maps), int(h),
                                                        int(w), int(c), _dev(points, torch.float32, 'points'), _dev(offs, torch.int32),
-                                                       _dev(order, torch.int32), ctypes.c_float(x_scale), ctypes.c_float(y_scale),
-                                                       _dev(out), _dtype_code(out), _stream()), 'bilinear_gather_backward_sorted')
+                                                       _dev(order, torch.int32), _i64(k), ctypes.c_float(x_scale), ctypes.c_float(y_scale),
+                                                       _dev(out), _dtype_code(out), _dev(ws), ctypes.c_size_t(ws.numel()), _stream()),
+           'bilinear_gather_backward_sorted')
     return out
 
 
