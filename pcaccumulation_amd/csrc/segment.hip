@@ -186,15 +186,28 @@ __global__ __launch_bounds__(256) void seg_max_kernel(const void *__restrict__ s
         const int b = seg_offsets[s], e = seg_offsets[s + 1];
         float4 best = make_float4(0.f, 0.f, 0.f, 0.f);
         int4 bi = make_int4(-1, -1, -1, -1);
-        for (int k = b; k < e; ++k) {
-            const int i = order[k];
-            const float4 v = pcacc_ld4(src, bf, (int64_t)i * LPP + sub);
-            // strict '>' in ascending index order, but the lowest INDEX must win even when the cursor
-            // order of a >64-point pillar is not sorted: tie-break on the index explicitly.
-            if (bi.x < 0 || v.x > best.x || (v.x == best.x && i < bi.x)) { best.x = v.x; bi.x = i; }
-            if (bi.y < 0 || v.y > best.y || (v.y == best.y && i < bi.y)) { best.y = v.y; bi.y = i; }
-            if (bi.z < 0 || v.z > best.z || (v.z == best.z && i < bi.z)) { best.z = v.z; bi.z = i; }
-            if (bi.w < 0 || v.w > best.w || (v.w == best.w && i < bi.w)) { best.w = v.w; bi.w = i; }
+        // four rows in flight: the index loads of a chunk go out together, then the four row loads (a pillar holds ~3 points,
+        // so most segments are one chunk: two memory latencies instead of two per point)
+        for (int k0 = b; k0 < e; k0 += 4) {
+            int idx[4];
+            float4 rows[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) idx[j] = k0 + j < e ? order[k0 + j] : -1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                rows[j] = idx[j] >= 0 ? pcacc_ld4(src, bf, (int64_t)idx[j] * LPP + sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = idx[j];
+                if (i < 0) continue;
+                const float4 v = rows[j];
+                // strict '>' in ascending index order, but the lowest INDEX must win even when the cursor
+                // order of a >64-point pillar is not sorted: tie-break on the index explicitly.
+                if (bi.x < 0 || v.x > best.x || (v.x == best.x && i < bi.x)) { best.x = v.x; bi.x = i; }
+                if (bi.y < 0 || v.y > best.y || (v.y == best.y && i < bi.y)) { best.y = v.y; bi.y = i; }
+                if (bi.z < 0 || v.z > best.z || (v.z == best.z && i < bi.z)) { best.z = v.z; bi.z = i; }
+                if (bi.w < 0 || v.w > best.w || (v.w == best.w && i < bi.w)) { best.w = v.w; bi.w = i; }
+            }
         }
         pcacc_st4(out, bf, s * LPP + sub, best);
         arg[s * LPP + sub] = bi;
@@ -451,9 +464,17 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const void *__restrict__ s
     for (int64_t s = (int64_t)blockIdx.x * per_block + threadIdx.x / LPP; s < m; s += (int64_t)gridDim.x * per_block) {
         const int b = seg_offsets[s], e = seg_offsets[s + 1];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int k = b; k < e; ++k) {
-            const float4 v = pcacc_ld4(src, bf, (int64_t)order[k] * LPP + sub);
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        for (int k0 = b; k0 < e; k0 += 4) {                               // four rows in flight (see seg_max_kernel); same sum order
+            int idx[4];
+            float4 rows[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) idx[j] = k0 + j < e ? order[k0 + j] : -1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                rows[j] = idx[j] >= 0 ? pcacc_ld4(src, bf, (int64_t)idx[j] * LPP + sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (idx[j] >= 0) { acc.x += rows[j].x; acc.y += rows[j].y; acc.z += rows[j].z; acc.w += rows[j].w; }
         }
         pcacc_st4(out, bf, s * LPP + sub, acc);
     }
