@@ -191,6 +191,13 @@ int pcacc_scatter_sum_small(const float *src, const int32_t *idx, int64_t n, int
  * ---------------------------------------------------------------------------------------------- */
 int pcacc_pillar_scatter(const float *feats, const int32_t *cell2pillar, int64_t n_cells, int c,
                          void *canvas, int dtype, void *stream);
+/* The same launch with two events attached to the dispatch (bench.py's roofline object): after the stream has been
+ * synchronised, pcacc_timer_elapsed_us(start, stop) is the kernel's own begin-to-end time, as a kernel trace reports it. */
+int pcacc_pillar_scatter_timed(const float *feats, const int32_t *cell2pillar, int64_t n_cells, int c, void *canvas, int dtype,
+                               void *start_event, void *stop_event, void *stream);
+int pcacc_timer_create(void **start_event, void **stop_event);
+int pcacc_timer_elapsed_us(void *start_event, void *stop_event, float *us);
+int pcacc_timer_destroy(void *start_event, void *stop_event);
 
 /* A6 and the backward of A5: row gather out[i,:] = src[idx[i],:] for rows of row_bytes bytes
  * (row_bytes % 4 == 0).  Replaces models/pillar_encoder.py:177-204 (inverse_scatter_point_pillar)

@@ -7,6 +7,8 @@
 // streaming pass that writes every canvas byte exactly once, in 16-byte pieces, 1 KiB per wave store:
 //   HBM traffic = canvas bytes (write) + 4 B/cell (table) + one feature row per occupied cell (read)
 // which is the algorithmic minimum (SURVEY.md 8d "pillar scatter").
+#include <hip/hip_ext.h>
+
 #include "scan.h"
 
 // ---- coordinates [m,5] = (b,z,y,x,t) -> linear cell index + inverse table ----------------------------
@@ -167,30 +169,73 @@ __global__ __launch_bounds__(256) void pillar_scatter_scalar(const float *__rest
     }
 }
 
-extern "C" int pcacc_pillar_scatter(const float *feats, const int32_t *cell2pillar, int64_t n_cells, int c,
-                                    void *canvas, int dtype, void *stream)
+// start / stop: optional hipEvents attached to the dispatch itself (hipExtLaunchKernelGGL): their elapsed time is the kernel's own
+// begin-to-end interval, the quantity a kernel trace reports -- an event pair recorded around the launch also contains the
+// queue's event-processing time (4-5 us on this stack), which is 10 % of this kernel.
+static int pillar_scatter_launch(const float *feats, const int32_t *cell2pillar, int64_t n_cells, int c, void *canvas, int dtype,
+                                 hipEvent_t start, hipEvent_t stop, hipStream_t s)
 {
     if (n_cells < 0 || c <= 0 || !cell2pillar || !canvas || (dtype != PCACC_F32 && dtype != PCACC_BF16)) return PCACC_E_ARG;
     if (n_cells == 0) return PCACC_OK;
-    hipStream_t s = pcacc_stream(stream);
     const bool vec = dtype == PCACC_F32 ? (c % 4 == 0) : (c % 8 == 0);
+    int64_t n;
+    int width;
+    const void *fn;
     if (vec) {
-        const int ppc = c / 4;
-        if (dtype == PCACC_F32) {
-            const int64_t n = n_cells * ppc;
-            pillar_scatter_vec4<0><<<pcacc_grid(n, 256), 256, 0, s>>>(reinterpret_cast<const float4 *>(feats), cell2pillar, n,
-                                                                       ppc, canvas);
-        } else {
-            const int64_t n = n_cells * (ppc / 2);
-            pillar_scatter_vec4<1><<<pcacc_grid(n, 256), 256, 0, s>>>(reinterpret_cast<const float4 *>(feats), cell2pillar, n,
-                                                                       ppc, canvas);
-        }
+        width = c / 4;
+        n = dtype == PCACC_F32 ? n_cells * width : n_cells * (width / 2);
+        fn = dtype == PCACC_F32 ? reinterpret_cast<const void *>(pillar_scatter_vec4<0>) : reinterpret_cast<const void *>(pillar_scatter_vec4<1>);
     } else {
-        const int64_t n = n_cells * c;
-        if (dtype == PCACC_F32) pillar_scatter_scalar<0><<<pcacc_grid(n, 256), 256, 0, s>>>(feats, cell2pillar, n, c, canvas);
-        else pillar_scatter_scalar<1><<<pcacc_grid(n, 256), 256, 0, s>>>(feats, cell2pillar, n, c, canvas);
+        width = c;
+        n = n_cells * c;
+        fn = dtype == PCACC_F32 ? reinterpret_cast<const void *>(pillar_scatter_scalar<0>) : reinterpret_cast<const void *>(pillar_scatter_scalar<1>);
     }
+    // both kernel families take (features, cell2pillar, n, width, canvas)
+    void *args[] = {(void *)&feats, (void *)&cell2pillar, (void *)&n, (void *)&width, (void *)&canvas};
+    if (hipExtLaunchKernel(fn, dim3(pcacc_grid(n, 256)), dim3(256), args, 0, s, start, stop, 0) != hipSuccess) return PCACC_E_LAUNCH;
     PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}
+
+extern "C" int pcacc_pillar_scatter(const float *feats, const int32_t *cell2pillar, int64_t n_cells, int c,
+                                    void *canvas, int dtype, void *stream)
+{
+    return pillar_scatter_launch(feats, cell2pillar, n_cells, c, canvas, dtype, nullptr, nullptr, pcacc_stream(stream));
+}
+
+extern "C" int pcacc_pillar_scatter_timed(const float *feats, const int32_t *cell2pillar, int64_t n_cells, int c, void *canvas, int dtype,
+                                          void *start_event, void *stop_event, void *stream)
+{
+    if (!start_event || !stop_event) return PCACC_E_ARG;
+    return pillar_scatter_launch(feats, cell2pillar, n_cells, c, canvas, dtype, reinterpret_cast<hipEvent_t>(start_event),
+                                 reinterpret_cast<hipEvent_t>(stop_event), pcacc_stream(stream));
+}
+
+extern "C" int pcacc_timer_create(void **start_event, void **stop_event)
+{
+    if (!start_event || !stop_event) return PCACC_E_ARG;
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess) return PCACC_E_LAUNCH;
+    if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return PCACC_E_LAUNCH; }
+    *start_event = a;
+    *stop_event = b;
+    return PCACC_OK;
+}
+
+extern "C" int pcacc_timer_elapsed_us(void *start_event, void *stop_event, float *us)
+{
+    if (!start_event || !stop_event || !us) return PCACC_E_ARG;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, reinterpret_cast<hipEvent_t>(start_event), reinterpret_cast<hipEvent_t>(stop_event)) != hipSuccess)
+        return PCACC_E_LAUNCH;
+    *us = ms * 1e3f;
+    return PCACC_OK;
+}
+
+extern "C" int pcacc_timer_destroy(void *start_event, void *stop_event)
+{
+    if (start_event) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(start_event));
+    if (stop_event) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(stop_event));
     return PCACC_OK;
 }
 

@@ -53,6 +53,7 @@ EXPORTS = [
     'pcacc_seg_loss_workspace_bytes', 'pcacc_seg_loss_forward', 'pcacc_seg_loss_backward',
     'pcacc_offset_loss_workspace_bytes', 'pcacc_offset_loss_forward', 'pcacc_offset_loss_backward',
     'pcacc_frames_max', 'pcacc_frames_max_backward', 'pcacc_rows_linear_cat_bf16', 'pcacc_rows_wgrad_cat_bf16',
+    'pcacc_pillar_scatter_timed', 'pcacc_timer_create', 'pcacc_timer_elapsed_us', 'pcacc_timer_destroy',
     'pcacc_svd3', 'pcacc_svd3_backward', 'pcacc_bn_rows_workspace_bytes', 'pcacc_bn_rows_forward', 'pcacc_bn_rows_backward',
 ]
 
@@ -219,9 +220,28 @@ def segment_sum(src, offs, order, m):
     return out
 
 
-# bench.py sets this to a list to time the dominant kernel live: (start, end, n_cells, c, m, dtype) per launch,
-# HIP events recorded on the stream the kernel is launched on, only for canvases of >= 32 channels.
+# bench.py sets this to a list to time the dominant kernel live: (KernelTimer, n_cells, c, m, dtype) per launch, only for
+# canvases of >= 32 channels.  The two events are attached to the dispatch (pcacc_pillar_scatter_timed).
 scatter_timer = None
+
+
+class KernelTimer(object):
+    """A pair of HIP events for one dispatch; elapsed_us() after the stream has been synchronised."""
+
+    def __init__(self):
+        self.start, self.stop = ctypes.c_void_p(), ctypes.c_void_p()
+        _check(lib().pcacc_timer_create(ctypes.byref(self.start), ctypes.byref(self.stop)), 'timer_create')
+
+    def elapsed_us(self):
+        us = ctypes.c_float(0.0)
+        _check(lib().pcacc_timer_elapsed_us(self.start, self.stop, ctypes.byref(us)), 'timer_elapsed_us')
+        return us.value
+
+    def __del__(self):
+        try:
+            lib().pcacc_timer_destroy(self.start, self.stop)
+        except Exception:
+            pass
 
 
 def pillar_scatter(feats, cell2pillar, out_dtype=torch.float32):
@@ -229,15 +249,14 @@ def pillar_scatter(feats, cell2pillar, out_dtype=torch.float32):
     c = feats.shape[1]
     n_cells = cell2pillar.numel()
     canvas = torch.empty((n_cells, c), dtype=out_dtype, device=feats.device)
-    timed = scatter_timer is not None and c >= 32
-    if timed:
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
+    if scatter_timer is not None and c >= 32:
+        t = KernelTimer()
+        _check(lib().pcacc_pillar_scatter_timed(_dev(feats, torch.float32, 'feats'), _dev(cell2pillar, torch.int32), _i64(n_cells),
+                                                int(c), _dev(canvas), _dtype_code(canvas), t.start, t.stop, _stream()), 'pillar_scatter')
+        scatter_timer.append((t, n_cells, c, feats.shape[0], out_dtype))
+        return canvas
     _check(lib().pcacc_pillar_scatter(_dev(feats, torch.float32, 'feats'), _dev(cell2pillar, torch.int32), _i64(n_cells),
                                       int(c), _dev(canvas), _dtype_code(canvas), _stream()), 'pillar_scatter')
-    if timed:
-        ev1.record()
-        scatter_timer.append((ev0, ev1, n_cells, c, feats.shape[0], out_dtype))
     return canvas
 
 

@@ -869,3 +869,24 @@ def test_batch_norm_rows_is_batchnorm1d(native, dev, dtype, c):
     mine.eval()
     ref.eval()
     assert torch.allclose(ops.batch_norm_rows(x, mine).float(), ref(x.float()), rtol=tol, atol=tol)      # eval: the module itself
+
+
+def test_pillar_scatter_timed_launch(native, dev):
+    """pcacc_pillar_scatter_timed (bench.py's roofline probe): the same canvas as the plain launch, and a dispatch time that is
+    positive and of the order the byte count allows (5 MB at < 8 TB/s: between 0.6 us and 1 ms)."""
+    torch.manual_seed(0)
+    m, n_cells, c = 20_000, 80_000, 32
+    feats = torch.randn(m, c, device=dev)
+    c2p = torch.full((n_cells,), -1, dtype=torch.int32, device=dev)
+    c2p[torch.randperm(n_cells, device=dev)[:m]] = torch.arange(m, dtype=torch.int32, device=dev)
+    want = native.pillar_scatter(feats, c2p, torch.bfloat16)
+    native.scatter_timer = []
+    try:
+        got = native.pillar_scatter(feats, c2p, torch.bfloat16)
+        torch.cuda.synchronize()
+        (timer, nc, cc, mm, dt), = native.scatter_timer
+    finally:
+        native.scatter_timer = None
+    assert torch.equal(got, want) and (nc, cc, mm, dt) == (n_cells, c, m, torch.bfloat16)
+    us = timer.elapsed_us()
+    assert 0.6 < us < 1000.0, us
