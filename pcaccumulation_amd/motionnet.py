@@ -56,6 +56,8 @@ class MotionNet(nn.Module):
         self.reconstructor = AlignNet(cfg)
         self.grid = grid_shape(cfg)
         self.compute_dtype = {'fp32': torch.float32, 'bf16': torch.bfloat16}[cfg['misc'].get('compute_dtype', 'fp32')]
+        # pillars renumbered in canvas-cell order inside forward() (ops.PillarIndex); False keeps the voxeliser's numbering
+        self.cell_ordered_pillars = bool(cfg['misc'].get('cell_ordered_pillars', True))
 
     # ------------------------------------------------------------------------------------------------
     def channels_last_(self):
@@ -103,7 +105,8 @@ class MotionNet(nn.Module):
         results = LazyDict()
 
         # 0. index structures shared by every irregular op of this forward
-        pidx = PillarIndex(coordinates, input_dict['point_to_voxel_map'], B, self.grid)
+        pidx = PillarIndex(coordinates, input_dict['point_to_voxel_map'], B, self.grid, cell_order=self.cell_ordered_pillars)
+        coordinates = pidx.coordinates                                         # rows in the numbering pidx uses from here on
         assert pidx.n == input_points.size(0)
         batch_idx = time_indice[:, 0].to(torch.int32).contiguous()
         frame_idx = (time_indice[:, 0] * T + time_indice[:, 1]).to(torch.int32).contiguous()

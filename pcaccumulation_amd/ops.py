@@ -15,7 +15,12 @@ class PillarIndex(object):
     pillar lists in ascending cell order.  Built once per forward (the reference recomputes the index
     arithmetic inside every scatter call, models/pillar_encoder.py:144-170, 193-203)."""
 
-    def __init__(self, coordinates, point_to_voxel_map, batch_size, input_shape):
+    def __init__(self, coordinates, point_to_voxel_map, batch_size, input_shape, cell_order=False):
+        """cell_order=True renumbers the pillars in ascending cell order for everything built here (`coordinates`, `p2v`, `cell`,
+        `cell2pillar`, the CSR; `perm[new id] = id in the caller's numbering`): the voxeliser numbers pillars in first-touch
+        order of the points (libs/voxel_generator.py:41-58), i.e. randomly with respect to the canvas, which turns every
+        pillar <-> canvas transfer (pillar scatter, its backward, the inverse scatter) into random row accesses; in cell
+        order they stream.  Nothing per-pillar leaves MotionNet.forward, so the renumbering is invisible outside."""
         nx, ny, nz, nt = (int(v) for v in input_shape[:4])
         self.nx, self.ny, self.nt, self.batch_size = nx, ny, nt, int(batch_size)
         self.m = int(coordinates.shape[0])
@@ -25,14 +30,26 @@ class PillarIndex(object):
         if coords.dtype not in (torch.float64, torch.int32):
             coords = coords.to(torch.float64)
         self.cell, self.cell2pillar = native.cell_index(coords, nx, ny, nt, self.batch_size)
-        if point_to_voxel_map is not None:
-            p2v = point_to_voxel_map
-            if p2v.dim() == 2:
-                p2v = p2v[:, 0]
-            self.p2v = p2v.to(torch.int32).contiguous()
+        self.coordinates, self.perm, self._frames = coordinates, None, None
+        p2v = point_to_voxel_map
+        if p2v is not None:
+            p2v = (p2v[:, 0] if p2v.dim() == 2 else p2v).to(torch.int32)
+        if cell_order and self.m > 0:
+            sp, offs = native.frame_pillars(self.cell2pillar, self.cells_per_frame, self.m)     # caller's ids in cell order
+            spl = sp.long()
+            rank = torch.empty(self.m, dtype=torch.int32, device=sp.device)
+            rank[spl] = torch.arange(self.m, dtype=torch.int32, device=sp.device)
+            self.perm = sp
+            self.cell = self.cell[spl].contiguous()                          # ascending
+            self.cell2pillar = torch.where(self.cell2pillar >= 0, rank[self.cell2pillar.clamp(min=0).long()], self.cell2pillar)
+            self.coordinates = coordinates[spl]
+            self._frames = (torch.arange(self.m, dtype=torch.int32, device=sp.device), offs)
+            if p2v is not None:
+                p2v = rank[p2v.long()]
+        if p2v is not None:
+            self.p2v = p2v.contiguous()
             self.n = int(self.p2v.shape[0])
             self.seg_offsets, self.order = native.csr_build(self.p2v, self.m)
-        self._frames = None
 
     @classmethod
     def from_point_map(cls, point_to_voxel_map, m):
