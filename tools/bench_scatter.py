@@ -12,12 +12,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pcaccumulation_amd import native  # noqa: E402
 
 
-def run(c2p, feats, n=50):
+def run(c2p, feats, n=50, flush=None):
     for _ in range(5):
         native.pillar_scatter(feats, c2p, torch.bfloat16)
     native.scatter_timer = []
     try:
         for _ in range(n):
+            if flush is not None:
+                flush.add_(1.0)                                # 1 GiB read + written in between: nothing of the table stays cached
             native.pillar_scatter(feats, c2p, torch.bfloat16)
         torch.cuda.synchronize()
         us = sorted(t.elapsed_us() for t, *_ in native.scatter_timer)
@@ -40,10 +42,11 @@ def main():
             c2p[occupied.sort().values] = torch.arange(m, dtype=torch.int32, device=dev)
         else:
             c2p[occupied] = ids
-        us = run(c2p, feats)
-        med = us[len(us) // 2]
-        print(json.dumps({'case': name, 'launches': len(us), 'median_us': round(med, 2), 'min_us': round(us[0], 2), 'max_us': round(us[-1], 2),
-                          'algorithmic_MB': round(alg / 1e6, 1), 'GBps': round(alg / med / 1e3, 1), 'frac_of_8TBps': round(alg / med / 1e3 / 8000, 3)}))
+        for flush in (None, torch.zeros(256 * 1024 * 1024, device=dev)):
+            us = run(c2p, feats, flush=flush)
+            med = us[len(us) // 2]
+            print(json.dumps({'case': name + (', caches flushed between launches' if flush is not None else ', back to back'), 'launches': len(us), 'median_us': round(med, 2), 'min_us': round(us[0], 2), 'max_us': round(us[-1], 2),
+                              'algorithmic_MB': round(alg / 1e6, 1), 'GBps': round(alg / med / 1e3, 1), 'frac_of_8TBps': round(alg / med / 1e3 / 8000, 3)}))
 
 
 if __name__ == '__main__':
