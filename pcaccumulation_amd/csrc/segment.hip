@@ -255,16 +255,27 @@ __global__ __launch_bounds__(256) void seg_level1(const void *__restrict__ src, 
         const int e = min(b + SEG_PIECE, seg_offsets[s + 1]);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         int4 bi = make_int4(-1, -1, -1, -1);
-        for (int k = b; k < e; ++k) {
-            const int i = order[k];
-            const float4 v = pcacc_ld4(src, src_bf, (int64_t)i * LPP + sub);
-            if (IS_MAX) {
-                if (bi.x < 0 || v.x > acc.x || (v.x == acc.x && i < bi.x)) { acc.x = v.x; bi.x = i; }
-                if (bi.y < 0 || v.y > acc.y || (v.y == acc.y && i < bi.y)) { acc.y = v.y; bi.y = i; }
-                if (bi.z < 0 || v.z > acc.z || (v.z == acc.z && i < bi.z)) { acc.z = v.z; bi.z = i; }
-                if (bi.w < 0 || v.w > acc.w || (v.w == acc.w && i < bi.w)) { acc.w = v.w; bi.w = i; }
-            } else {
-                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        for (int k0 = b; k0 < e; k0 += 4) {                               // four rows in flight (see seg_max_kernel); same order
+            int idx[4];
+            float4 rows[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) idx[j] = k0 + j < e ? order[k0 + j] : -1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                rows[j] = idx[j] >= 0 ? pcacc_ld4(src, src_bf, (int64_t)idx[j] * LPP + sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = idx[j];
+                if (i < 0) continue;
+                const float4 v = rows[j];
+                if (IS_MAX) {
+                    if (bi.x < 0 || v.x > acc.x || (v.x == acc.x && i < bi.x)) { acc.x = v.x; bi.x = i; }
+                    if (bi.y < 0 || v.y > acc.y || (v.y == acc.y && i < bi.y)) { acc.y = v.y; bi.y = i; }
+                    if (bi.z < 0 || v.z > acc.z || (v.z == acc.z && i < bi.z)) { acc.z = v.z; bi.z = i; }
+                    if (bi.w < 0 || v.w > acc.w || (v.w == acc.w && i < bi.w)) { acc.w = v.w; bi.w = i; }
+                } else {
+                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                }
             }
         }
         if (IS_MAX) {
