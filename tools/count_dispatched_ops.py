@@ -20,7 +20,10 @@ per_line = collections.Counter()
 class Count(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         name = str(func)
-        if not any(s in name for s in ('view', 'permute', 'select', 'slice', 'expand', 'unsqueeze', 'squeeze', 'detach', 'alias', 't.default', 'transpose', 'as_strided', 'size', 'stride', 'numel', 'is_', 'sym_')):
+        only = os.environ.get('PCACC_COUNT_ONLY')
+        if only and only not in name:
+            return func(*args, **(kwargs or {}))
+        if only or not any(s in name for s in ('view', 'permute', 'select', 'slice', 'expand', 'unsqueeze', 'squeeze', 'detach', 'alias', 'aten.t.default', 'transpose', 'as_strided', 'size', 'stride', 'numel', 'is_', 'sym_')):
             for fr in reversed(traceback.extract_stack(limit=14)):
                 if 'pcaccumulation_amd' in fr.filename:
                     per_line['%s:%d' % (os.path.basename(fr.filename), fr.lineno)] += 1
