@@ -19,3 +19,25 @@ def test_mat2quat_is_scipy():
     want32 = R.from_matrix(mats.astype(np.float32).astype(np.float64)).as_quat()
     # scipy re-orthogonalises matrices that are only orthogonal to float32 precision: agreement to that precision
     assert np.abs(got32 - want32).max() < 1e-7
+
+
+def test_lazy_results_behave_like_the_reference_dict():
+    """pcaccumulation_amd/lazy.py: scalar results are copied to the host asynchronously and become the reference's Python numbers
+    on first read -- through every way a trainer reads a dict -- while raw() carries an entry along unread."""
+    from pcaccumulation_amd.lazy import HostCopy, LazyDict, LazyValue, lazy_scalars, raw
+    a, b = lazy_scalars([torch.tensor(1.5), torch.tensor(2.5, dtype=torch.float64)])
+    d = LazyDict(loss=torch.tensor(3.0), rot=a, trans=b)
+    assert isinstance(d.raw('rot'), LazyValue) and isinstance(raw(d, 'rot'), LazyValue)
+    other = LazyDict(rot=d.raw('rot'))                                        # carried along, still unread
+    assert isinstance(dict.__getitem__(other, 'rot'), LazyValue)
+    assert d['rot'] == 1.5 and isinstance(d['rot'], float) and not isinstance(dict.__getitem__(d, 'rot'), LazyValue)
+    assert other['rot'] == 1.5
+    assert d.get('trans') == 2.5 and d.get('missing', 7) == 7
+    copy = HostCopy(torch.arange(8, dtype=torch.float64))
+    m = LazyDict(metric=LazyValue(copy, 0, 8, lambda v: {'intersection': v[:2], 'union': v[2:4]}), plain=4)
+    items = dict(m.items())
+    assert items['plain'] == 4 and np.array_equal(items['metric']['union'], [2.0, 3.0])
+    assert list(LazyDict(x=LazyValue(copy, 1, 2, lambda v: float(v[0]))).values()) == [1.0]
+    p = LazyDict(x=LazyValue(copy, 3, 4, lambda v: float(v[0])))
+    assert p.pop('x') == 3.0 and 'x' not in p and p.pop('x', None) is None
+    assert raw({'k': 1}, 'k') == 1                                            # plain dicts pass through
