@@ -195,6 +195,11 @@ int pcacc_pillar_scatter(const float *feats, const int32_t *cell2pillar, int64_t
  * synchronised, pcacc_timer_elapsed_us(start, stop) is the kernel's own begin-to-end time, as a kernel trace reports it. */
 int pcacc_pillar_scatter_timed(const float *feats, const int32_t *cell2pillar, int64_t n_cells, int c, void *canvas, int dtype,
                                void *start_event, void *stop_event, void *stream);
+/* Typed form: feats [m,c] of `feats_dtype` (PCACC_F32, or PCACC_BF16 with a PCACC_BF16 canvas and c % 8 == 0: the bf16 compute mode,
+ * where the pillar encoder's last pooling leaves bf16 rows and the kernel moves exactly SURVEY.md 8d's bytes with s = 2:
+ * c*2*n_cells written, c*2*m + 4*n_cells read).  start_event / stop_event: both NULL, or the two events of pcacc_timer_create. */
+int pcacc_pillar_scatter_t(const void *feats, int feats_dtype, const int32_t *cell2pillar, int64_t n_cells, int c, void *canvas,
+                           int dtype, void *start_event, void *stop_event, void *stream);
 int pcacc_timer_create(void **start_event, void **stop_event);
 int pcacc_timer_elapsed_us(void *start_event, void *stop_event, float *us);
 int pcacc_timer_destroy(void *start_event, void *stop_event);

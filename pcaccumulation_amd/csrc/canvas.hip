@@ -154,6 +154,26 @@ __global__ __launch_bounds__(256) void pillar_scatter_vec4(const float4 *__restr
     }
 }
 
+// bf16 feature rows -> bf16 canvas (the bf16 compute mode: the pillar encoder's last pooling already emits bf16 rows, so the kernel
+// moves C*2 B per occupied cell in and C*2 B per cell out -- SURVEY.md 8d's bytes with s = 2 on both sides, no fp32 [M,C] table in
+// between).  Two 16-byte pieces per lane and iteration, table words first, then the two row pieces, then the two stores.
+__global__ __launch_bounds__(256) void pillar_scatter_rows16(const uint4 *__restrict__ feats, const int32_t *__restrict__ c2p,
+                                                             int64_t n_pieces, int ppc /*16-byte pieces per cell*/, uint4 *__restrict__ canvas)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t e0 = (int64_t)blockIdx.x * 256 + threadIdx.x; e0 < n_pieces; e0 += 2 * stride) {
+        const int64_t e1 = e0 + stride;
+        const bool two = e1 < n_pieces;
+        const int64_t cell0 = e0 / ppc, cell1 = two ? e1 / ppc : cell0;
+        const int p0 = c2p[cell0], p1 = two ? c2p[cell1] : -1;
+        uint4 o0 = make_uint4(0u, 0u, 0u, 0u), o1 = o0;
+        if (p0 >= 0) o0 = feats[(int64_t)p0 * ppc + (e0 - cell0 * ppc)];
+        if (p1 >= 0) o1 = feats[(int64_t)p1 * ppc + (e1 - cell1 * ppc)];
+        canvas[e0] = o0;
+        if (two) canvas[e1] = o1;
+    }
+}
+
 // narrow canvases (C = 1, 2, 3: occupancy, labels, pillar means) -- one element per lane
 template <int OUT_BF16>
 __global__ __launch_bounds__(256) void pillar_scatter_scalar(const float *__restrict__ feats, const int32_t *__restrict__ c2p,
@@ -172,16 +192,20 @@ __global__ __launch_bounds__(256) void pillar_scatter_scalar(const float *__rest
 // start / stop: optional hipEvents attached to the dispatch itself (hipExtLaunchKernelGGL): their elapsed time is the kernel's own
 // begin-to-end interval, the quantity a kernel trace reports -- an event pair recorded around the launch also contains the
 // queue's event-processing time (4-5 us on this stack), which is 10 % of this kernel.
-static int pillar_scatter_launch(const float *feats, const int32_t *cell2pillar, int64_t n_cells, int c, void *canvas, int dtype,
-                                 hipEvent_t start, hipEvent_t stop, hipStream_t s)
+static int pillar_scatter_launch(const void *feats, int feats_dtype, const int32_t *cell2pillar, int64_t n_cells, int c, void *canvas,
+                                 int dtype, hipEvent_t start, hipEvent_t stop, hipStream_t s)
 {
     if (n_cells < 0 || c <= 0 || !cell2pillar || !canvas || (dtype != PCACC_F32 && dtype != PCACC_BF16)) return PCACC_E_ARG;
+    if (feats_dtype != PCACC_F32 && !(feats_dtype == PCACC_BF16 && dtype == PCACC_BF16 && c % 8 == 0)) return PCACC_E_ARG;
     if (n_cells == 0) return PCACC_OK;
-    const bool vec = dtype == PCACC_F32 ? (c % 4 == 0) : (c % 8 == 0);
     int64_t n;
     int width;
     const void *fn;
-    if (vec) {
+    if (feats_dtype == PCACC_BF16) {
+        width = c / 8;
+        n = n_cells * width;
+        fn = reinterpret_cast<const void *>(pillar_scatter_rows16);
+    } else if (dtype == PCACC_F32 ? (c % 4 == 0) : (c % 8 == 0)) {
         width = c / 4;
         n = dtype == PCACC_F32 ? n_cells * width : n_cells * (width / 2);
         fn = dtype == PCACC_F32 ? reinterpret_cast<const void *>(pillar_scatter_vec4<0>) : reinterpret_cast<const void *>(pillar_scatter_vec4<1>);
@@ -190,9 +214,10 @@ static int pillar_scatter_launch(const float *feats, const int32_t *cell2pillar,
         n = n_cells * c;
         fn = dtype == PCACC_F32 ? reinterpret_cast<const void *>(pillar_scatter_scalar<0>) : reinterpret_cast<const void *>(pillar_scatter_scalar<1>);
     }
-    // both kernel families take (features, cell2pillar, n, width, canvas)
+    // all kernel families take (features, cell2pillar, n, width, canvas)
     void *args[] = {(void *)&feats, (void *)&cell2pillar, (void *)&n, (void *)&width, (void *)&canvas};
-    if (hipExtLaunchKernel(fn, dim3(pcacc_grid(n, 256)), dim3(256), args, 0, s, start, stop, 0) != hipSuccess) return PCACC_E_LAUNCH;
+    const int64_t items = feats_dtype == PCACC_BF16 ? (n + 1) / 2 : n;
+    if (hipExtLaunchKernel(fn, dim3(pcacc_grid(items, 256)), dim3(256), args, 0, s, start, stop, 0) != hipSuccess) return PCACC_E_LAUNCH;
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
 }
@@ -200,14 +225,22 @@ static int pillar_scatter_launch(const float *feats, const int32_t *cell2pillar,
 extern "C" int pcacc_pillar_scatter(const float *feats, const int32_t *cell2pillar, int64_t n_cells, int c,
                                     void *canvas, int dtype, void *stream)
 {
-    return pillar_scatter_launch(feats, cell2pillar, n_cells, c, canvas, dtype, nullptr, nullptr, pcacc_stream(stream));
+    return pillar_scatter_launch(feats, PCACC_F32, cell2pillar, n_cells, c, canvas, dtype, nullptr, nullptr, pcacc_stream(stream));
 }
 
 extern "C" int pcacc_pillar_scatter_timed(const float *feats, const int32_t *cell2pillar, int64_t n_cells, int c, void *canvas, int dtype,
                                           void *start_event, void *stop_event, void *stream)
 {
     if (!start_event || !stop_event) return PCACC_E_ARG;
-    return pillar_scatter_launch(feats, cell2pillar, n_cells, c, canvas, dtype, reinterpret_cast<hipEvent_t>(start_event),
+    return pillar_scatter_launch(feats, PCACC_F32, cell2pillar, n_cells, c, canvas, dtype, reinterpret_cast<hipEvent_t>(start_event),
+                                 reinterpret_cast<hipEvent_t>(stop_event), pcacc_stream(stream));
+}
+
+extern "C" int pcacc_pillar_scatter_t(const void *feats, int feats_dtype, const int32_t *cell2pillar, int64_t n_cells, int c, void *canvas,
+                                      int dtype, void *start_event, void *stop_event, void *stream)
+{
+    if ((start_event == nullptr) != (stop_event == nullptr)) return PCACC_E_ARG;
+    return pillar_scatter_launch(feats, feats_dtype, cell2pillar, n_cells, c, canvas, dtype, reinterpret_cast<hipEvent_t>(start_event),
                                  reinterpret_cast<hipEvent_t>(stop_event), pcacc_stream(stream));
 }
 

@@ -118,7 +118,7 @@ class MotionNet(nn.Module):
         results['occ_map'] = occ.view(B, T, 1, Ny, Nx)
 
         # 1. pillar encoder -> BEV canvas (channels-last, one streaming pass)
-        input_features = self.pillar_encoder(input_points, None, coordinates, pillar_mean, time_indice, pidx=pidx)
+        input_features = self.pillar_encoder(input_points, None, coordinates, pillar_mean, time_indice, pidx=pidx, keep_dtype=True)
         canvas = ops.pillar_scatter(input_features, pidx, self.compute_dtype)
         bev = ops.canvas_as_nchw(canvas, pidx)                                 # [B*T, C, Ny, Nx]
 

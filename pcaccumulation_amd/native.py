@@ -53,7 +53,7 @@ EXPORTS = [
     'pcacc_seg_loss_workspace_bytes', 'pcacc_seg_loss_forward', 'pcacc_seg_loss_backward',
     'pcacc_offset_loss_workspace_bytes', 'pcacc_offset_loss_forward', 'pcacc_offset_loss_backward',
     'pcacc_frames_max', 'pcacc_frames_max_backward', 'pcacc_rows_linear_cat_bf16', 'pcacc_rows_wgrad_cat_bf16',
-    'pcacc_pillar_scatter_timed', 'pcacc_timer_create', 'pcacc_timer_elapsed_us', 'pcacc_timer_destroy',
+    'pcacc_pillar_scatter_timed', 'pcacc_pillar_scatter_t', 'pcacc_timer_create', 'pcacc_timer_elapsed_us', 'pcacc_timer_destroy',
     'pcacc_svd3', 'pcacc_svd3_backward', 'pcacc_bn_rows_workspace_bytes', 'pcacc_bn_rows_forward', 'pcacc_bn_rows_backward',
 ]
 
@@ -245,18 +245,17 @@ class KernelTimer(object):
 
 
 def pillar_scatter(feats, cell2pillar, out_dtype=torch.float32):
-    """feats [m,c] f32 -> canvas [n_cells, c] (channels-last) of out_dtype."""
+    """feats [m,c] f32 (or bf16 with a bf16 canvas: rows copied as they are) -> canvas [n_cells, c] (channels-last) of out_dtype."""
     c = feats.shape[1]
     n_cells = cell2pillar.numel()
     canvas = torch.empty((n_cells, c), dtype=out_dtype, device=feats.device)
+    t = None
     if scatter_timer is not None and c >= 32:
         t = KernelTimer()
-        _check(lib().pcacc_pillar_scatter_timed(_dev(feats, torch.float32, 'feats'), _dev(cell2pillar, torch.int32), _i64(n_cells),
-                                                int(c), _dev(canvas), _dtype_code(canvas), t.start, t.stop, _stream()), 'pillar_scatter')
-        scatter_timer.append((t, n_cells, c, feats.shape[0], out_dtype))
-        return canvas
-    _check(lib().pcacc_pillar_scatter(_dev(feats, torch.float32, 'feats'), _dev(cell2pillar, torch.int32), _i64(n_cells),
-                                      int(c), _dev(canvas), _dtype_code(canvas), _stream()), 'pillar_scatter')
+        scatter_timer.append((t, n_cells, c, feats.shape[0], out_dtype, feats.dtype))
+    _check(lib().pcacc_pillar_scatter_t(_dev(feats, None, 'feats'), _dtype_code(feats), _dev(cell2pillar, torch.int32), _i64(n_cells),
+                                        int(c), _dev(canvas), _dtype_code(canvas), t.start if t else None, t.stop if t else None,
+                                        _stream()), 'pillar_scatter')
     return canvas
 
 

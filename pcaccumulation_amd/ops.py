@@ -128,17 +128,22 @@ def segment_mean3_maxlabel(points, labels, pidx):
 
 
 class _PillarScatter(torch.autograd.Function):
-    """scatter_point_pillar (models/pillar_encoder.py:125-174) into a channels-last canvas [n_cells, C]."""
+    """scatter_point_pillar (models/pillar_encoder.py:125-174) into a channels-last canvas [n_cells, C].  bf16 rows go into a bf16
+    canvas as they are (bf16 compute mode: no fp32 [M,C] table between the pillar encoder and the canvas); everything else is read
+    as fp32.  The gradient comes back in the element type of `feats`."""
 
     @staticmethod
     def forward(ctx, feats, pidx, out_dtype):
-        ctx.pidx = pidx
-        return native.pillar_scatter(feats.contiguous().float(), pidx.cell2pillar, out_dtype)
+        ctx.pidx, ctx.in_dtype = pidx, feats.dtype
+        feats = feats.contiguous()
+        if not (feats.dtype == torch.bfloat16 and out_dtype == torch.bfloat16 and feats.shape[1] % 8 == 0):
+            feats = feats.float()
+        return native.pillar_scatter(feats, pidx.cell2pillar, out_dtype)
 
     @staticmethod
     def backward(ctx, grad_canvas):
         g = native.gather_rows(grad_canvas.contiguous(), ctx.pidx.cell)
-        return g.float(), None, None
+        return (g if g.dtype == ctx.in_dtype else g.to(ctx.in_dtype)), None, None
 
 
 def pillar_scatter(feats, pidx, out_dtype=torch.float32):

@@ -78,7 +78,9 @@ class PillarFeatureNet(nn.Module):
                                    float(self.vy), float(self.x_offset), float(self.y_offset), float(self.scale),
                                    float(self.n_frames))
 
-    def forward(self, raw_points, point_to_voxel_map, coordinates, pillar_mean, time_indice, pidx=None):
+    def forward(self, raw_points, point_to_voxel_map, coordinates, pillar_mean, time_indice, pidx=None, keep_dtype=False):
+        """keep_dtype: return the pooled rows in the element type of the point rows (bf16 in the bf16 compute mode; MotionNet feeds
+        them to the canvas fill as they are) instead of the reference's float32."""
         if pidx is None:                                                  # reference call signature
             pidx = PillarIndex.from_point_map(point_to_voxel_map, coordinates.shape[0])
         features = self.point_features(raw_points, pidx, coordinates, pillar_mean, time_indice)
@@ -88,7 +90,8 @@ class PillarFeatureNet(nn.Module):
         for block in self.blocks[1:]:
             net = block.forward_pooled(net, ops.segment_max(net, pidx), pidx)
         feats = ops.linear_rows(net, self.fc_c)
-        return ops.segment_max(feats, pidx).float()
+        pooled = ops.segment_max(feats, pidx)
+        return pooled if keep_dtype else pooled.float()
 
 
 def _index_for(coords, batch_size, input_shape):
@@ -102,7 +105,7 @@ def scatter_point_pillar(voxel_features, coords, batch_size, input_shape, pidx=N
         pidx = _index_for(coords, batch_size, input_shape)
     src = voxel_features
     out_dtype = src.dtype if src.dtype in (torch.float32, torch.bfloat16) else torch.float32
-    canvas = ops.pillar_scatter(src.float(), pidx, out_dtype)
+    canvas = ops.pillar_scatter(src, pidx, out_dtype)
     out = ops.canvas_as_reference(canvas, pidx)
     return out if src.dtype == out.dtype else out.to(src.dtype)
 

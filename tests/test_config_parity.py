@@ -1,0 +1,204 @@
+"""Whole-model parity at BASELINE.json's full config sizes (c2, c3, c4, c5, and the reference's own 11-sweep nuScenes shape): the
+product MotionNet (+ FuseLoss, + backward for the train configs) on cuda:0 against golden vectors the REFERENCE produced on the
+same seeded inputs and closed-form weights (tests/golden/make_golden_configs.py, reference imported in the build container).
+
+fp32 compute: north_star's tolerance -- mos_iou, ego rotation / translation error and scene-flow EPE within 1e-3, integer voxel
+structure bit-exact (digest of `coordinates` and `point_to_voxel_map` as collate hands them to the model).
+bf16 compute (the benchmarked precision): the same golden vectors with the bound BF16_TOL below, see DESIGN.md section 4 for where
+the numbers come from (measured on these five configs, `gpurun_out/bf16_deltas.jsonl` when PCACC_DUMP_DELTAS is set).
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_batch
+from pcaccumulation_amd.config import default_config
+from pcaccumulation_amd.loss import FuseLoss, scene_flow_epe
+from pcaccumulation_amd.motionnet import MotionNet
+from pcaccumulation_amd.synthetic import fill_state_dict_
+
+CONFIGS = ['c2', 'c3', 'c4', 'c5', 'nus11']
+FP32_TOL = dict(ego=1e-3, iou=1e-3, epe=1e-3)
+# bf16 canvas + bf16 conv stacks + bf16 point rows against the reference's fp32 run.  ego: degrees / metres; iou: absolute;
+# epe: metres, relative to the reference's EPE when that is larger than 1 m (random-weight poses are metres off).
+BF16_TOL = dict(ego=5e-2, iou=2e-2, epe=5e-2)
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _run(g, compute_dtype):
+    dev = torch.device('cuda:0')
+    T, ppf, mode = int(g['n_frames']), int(g['pts_per_frame']), str(g['mode'])
+    cfg = default_config(str(g['dataset']), mode, n_sweeps=T)
+    cfg['misc']['compute_dtype'] = compute_dtype
+    inp = make_batch(cfg, [int(s) for s in g['seeds']], T, ppf)
+    # integer voxel structure at full size: bit-exact with what the reference's voxeliser + collate_fn produced
+    assert _sha(inp['coordinates'].numpy()) == str(g['coordinates_sha'])
+    assert _sha(inp['point_to_voxel_map'].numpy()) == str(g['p2v_sha'])
+    assert np.array_equal(inp['num_voxels'].numpy(), g['num_voxels'])
+    model = MotionNet(cfg)
+    fill_state_dict_(model)
+    with torch.no_grad():
+        sd = model.state_dict()
+        for k, v in zip(g['tweak_keys'], g['tweak_vals']):
+            sd[str(k)] += torch.from_numpy(v)
+    train = mode == 'train'
+    model = model.to(dev).train(train).channels_last_()
+    inp = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}
+    loss_fn = FuseLoss(cfg['loss'])
+    torch.manual_seed(int(g['fwd_seed']))
+    if train:
+        out = model(inp)
+        stats = loss_fn(out, inp)
+        stats['loss'].backward()
+    else:
+        with torch.no_grad():
+            out = model(inp)
+            stats = loss_fn(out, inp)
+    return model, inp, out, stats, T
+
+
+def _metrics(g, inp, out, stats, T):
+    i, u = stats['mos_metric']['intersection'], stats['mos_metric']['union']
+    sel = inp['time_indice'][:, 0] == 0
+    s0 = {k: inp[k][sel] for k in ('input_points', 'time_indice', 'inst_labels')}
+    s0['input_points'] = s0['input_points'].float()
+    s0['ego_motion_gt'], s0['inst_motion_gt'] = inp['ego_motion_gt'], inp['inst_motion_gt']
+    epe = scene_flow_epe({'rec_est': out['rec_est'][sel].detach()}, s0, T)
+    got = dict(ego_rot_error=float(out['ego_rot_error']), ego_trans_error=float(out['ego_trans_error']),
+               mos_iou=float((i / (u + 1e-20)).mean()), epe_mean=float(epe.mean()))
+    ref = {k: float(g[k]) for k in got}
+    return got, ref
+
+
+def _dump(name, compute_dtype, got, ref, extra):
+    if os.environ.get('PCACC_DUMP_DELTAS'):
+        os.makedirs('gpurun_out', exist_ok=True)
+        with open('gpurun_out/bf16_deltas.jsonl', 'a') as f:
+            f.write(json.dumps(dict(config=name, dtype=compute_dtype, got=got, ref=ref, **extra)) + '\n')
+
+
+def _check(name, compute_dtype, golden):
+    g = golden('model_' + name)
+    model, inp, out, stats, T = _run(g, compute_dtype)
+    got, ref = _metrics(g, inp, out, stats, T)
+    idx = torch.from_numpy(g['sample_idx']).cuda()
+    flips = float((out['fb_est_per_points'][idx].cpu().numpy() != g['fb_est_per_points']).mean())
+    extra = dict(fb_flips=flips, fb_est_sum=int(out['fb_est_per_points'].sum()), fb_est_sum_ref=int(g['fb_est_sum']))
+    if str(g['mode']) == 'train':
+        extra.update(loss=float(stats['loss']), loss_ref=float(g['loss']))
+    _dump(name, compute_dtype, got, ref, extra)
+    tol = FP32_TOL if compute_dtype == 'fp32' else BF16_TOL
+    assert abs(got['ego_rot_error'] - ref['ego_rot_error']) < tol['ego'], (got, ref)
+    assert abs(got['ego_trans_error'] - ref['ego_trans_error']) < tol['ego'], (got, ref)
+    assert abs(got['mos_iou'] - ref['mos_iou']) < tol['iou'], (got, ref)
+    epe_tol = tol['epe'] * (max(1.0, ref['epe_mean']) if compute_dtype == 'bf16' else 1.0)
+    assert abs(got['epe_mean'] - ref['epe_mean']) < epe_tol, (got, ref)
+    return g, model, out, stats, flips
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', CONFIGS)
+def test_gpu_config_fp32(name, golden):
+    g, model, out, stats, flips = _check(name, 'fp32', golden)
+    idx = torch.from_numpy(g['sample_idx']).cuda()
+    assert flips < 2e-3
+    assert abs(int(out['fb_est_per_points'].sum()) - int(g['fb_est_sum'])) <= 0.002 * max(int(g['fb_est_sum']), 1000)
+    np.testing.assert_allclose(out['transformed_points'][idx].detach().cpu().numpy(), g['transformed_points'], atol=5e-3)
+    np.testing.assert_allclose(out['fb_seg_est'][0, :, :, ::8, ::8].detach().cpu().numpy(), g['fb_seg_est_sample'], rtol=2e-3, atol=2e-3)
+    if str(g['mode']) == 'train':
+        assert abs(float(stats['loss']) - float(g['loss'])) < 5e-3 * abs(float(g['loss']))
+        grads = dict(model.named_parameters())
+        names = [str(n) for n in g['grad_names']]
+        assert names == list(grads.keys())
+        loose = ('motionhead.init_conv', 'motionhead.down_convs', 'motionhead.up_convs')     # see test_model_parity._assert_tiny_train
+        bad = []
+        for n, ref in zip(names, g['grad_norms']):
+            got = float(grads[n].grad.norm()) if grads[n].grad is not None else 0.0
+            if abs(got - ref) > (3e-2 if n.startswith(loose) else 2.5e-2) * max(abs(ref), 1e-3):
+                bad.append((n, got, float(ref)))
+        assert not bad, bad[:8]
+        np.testing.assert_allclose(model.semseg_head.seg_head[1].running_mean.detach().cpu().numpy(), g['bn_running_mean'],
+                                   rtol=5e-2, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', CONFIGS)
+def test_gpu_config_bf16(name, golden):
+    g, model, out, stats, flips = _check(name, 'bf16', golden)
+    assert flips < 2e-2
+    if str(g['mode']) == 'train':
+        assert abs(float(stats['loss']) - float(g['loss'])) < 2e-2 * abs(float(g['loss']))
+        assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
+def _trained_tiny_model(steps=150):
+    """The fp32 product trained for a few Adam steps on tiny synthetic scenes (default initialisation, seed 0): weights that were
+    neither filled by formula nor shifted to put a decision boundary through the bulk of the logits."""
+    dev = torch.device('cuda:0')
+    cfg = default_config('waymo', 'train', n_sweeps=3, xy_range=8)
+    torch.manual_seed(0)
+    model = MotionNet(cfg).to(dev).train().channels_last_()
+    opt = torch.optim.Adam(model.parameters(), lr=cfg['Adam']['learning_rate'])
+    loss_fn = FuseLoss(cfg['loss'])
+    for step in range(steps):
+        inp = make_batch(cfg, [1000 + 2 * step, 1001 + 2 * step], 3, 1500)
+        inp = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}
+        torch.manual_seed(step)
+        out = model(inp)
+        loss = loss_fn(out, inp)['loss']
+        opt.zero_grad(set_to_none=True)
+        if not bool(torch.isfinite(loss.detach())):
+            continue
+        loss.backward()
+        if not all(bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.grad is not None):
+            continue                                            # libs/trainer.py:222-227 skips such steps too
+        torch.nn.utils.clip_grad_norm_(model.parameters(), cfg['train']['grad_clip'])
+        opt.step()
+    return cfg, model
+
+
+@pytest.mark.gpu
+def test_gpu_bf16_against_fp32_on_trained_weights():
+    """The bf16 bound on weights without engineered near-ties: 150 Adam steps of the fp32 product (itself pinned to the reference
+    at 1e-3 by the fp32 tests above), then the frozen model evaluated in fp32 and in bf16 on eight held-out scenes."""
+    dev = torch.device('cuda:0')
+    cfg, model = _trained_tiny_model()
+    model.eval()
+    cfg16 = default_config('waymo', 'train', n_sweeps=3, xy_range=8)
+    cfg16['misc']['compute_dtype'] = 'bf16'
+    model16 = MotionNet(cfg16).to(dev).channels_last_()
+    model16.load_state_dict(model.state_dict())
+    model16.eval()
+    loss_fn = FuseLoss(cfg['loss'])
+    rows = {'fp32': [], 'bf16': []}
+    for seed in range(5000, 5008):
+        inp = make_batch(cfg, [seed], 3, 1500)
+        inp = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}
+        for tag, m in (('fp32', model), ('bf16', model16)):
+            torch.manual_seed(seed)
+            with torch.no_grad():
+                out = m(inp)
+                stats = loss_fn(out, inp)
+            got, _ = _metrics({k: 0.0 for k in ('ego_rot_error', 'ego_trans_error', 'mos_iou', 'epe_mean')}, inp, out, stats, 3)
+            got['fb_est'] = out['fb_est_per_points'].clone()
+            got['mos_i'], got['mos_u'] = stats['mos_metric']['intersection'], stats['mos_metric']['union']
+            rows[tag].append(got)
+    d = lambda k: max(abs(a[k] - b[k]) for a, b in zip(rows['fp32'], rows['bf16']))
+    flips = max(float((a['fb_est'] != b['fb_est']).float().mean()) for a, b in zip(rows['fp32'], rows['bf16']))
+    # mos_iou as the reference aggregates it over a validation set (toolbox/metrics.py:43-60): counters summed over the scenes
+    agg = {t: float((sum(r['mos_i'] for r in rows[t]) / (sum(r['mos_u'] for r in rows[t]) + 1e-20)).mean()) for t in rows}
+    res = dict(rot=d('ego_rot_error'), trans=d('ego_trans_error'), mos_iou_scene=d('mos_iou'), epe=d('epe_mean'), fb_flips=flips,
+               mos_iou_set=abs(agg['fp32'] - agg['bf16']), fp32_rot=float(np.mean([r['ego_rot_error'] for r in rows['fp32']])),
+               fp32_epe=float(np.mean([r['epe_mean'] for r in rows['fp32']])), fp32_mos_iou=agg['fp32'])
+    _dump('trained_tiny', 'bf16-vs-fp32', res, {}, {})
+    assert res['rot'] < BF16_TOL['ego'] and res['trans'] < BF16_TOL['ego'], res
+    assert res['mos_iou_set'] < BF16_TOL['iou'], res
+    assert res['epe'] < BF16_TOL['epe'], res
+    assert flips < 2e-2, res

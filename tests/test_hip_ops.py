@@ -176,6 +176,11 @@ def test_pillar_scatter_and_gather_golden(native, dev, golden):
     dense = torch.zeros((c2p.numel(), 8), dtype=torch.bfloat16)
     dense[cell.cpu().long()] = ref
     assert torch.equal(cb.cpu(), dense)
+    # bf16 rows -> bf16 canvas (bf16 compute mode): the rows are copied as they are
+    cbb = native.pillar_scatter(ref.to(dev), c2p, torch.bfloat16)
+    assert torch.equal(cbb.cpu(), dense)
+    with pytest.raises(Exception):                                                    # bf16 rows into an f32 canvas: not a path
+        native.pillar_scatter(ref.to(dev), c2p, torch.float32)
     # narrow canvases (occupancy, 3-channel means)
     for c in (1, 3):
         f = torch.from_numpy(np.random.RandomState(c).randn(cell.numel(), c).astype(np.float32))
@@ -211,6 +216,17 @@ def test_pillar_scatter_full_size_roundtrip(native, dev):
         assert torch.equal(native.gather_rows(cv, cell), feats.to(dt))
         assert float(cv.float().abs().sum(1).gt(0).sum()) <= occ.size
         assert abs(float(cv.double().sum()) - float(feats.to(dt).double().sum())) < 1e-3
+    # bf16 rows in (what the bf16 compute mode feeds): bit-identical canvas to the f32 -> bf16 launch on pre-rounded rows, odd
+    # piece counts (the kernel moves two pieces per lane and iteration)
+    f16 = feats.to(torch.bfloat16)
+    assert torch.equal(native.pillar_scatter(f16, c2p, torch.bfloat16), native.pillar_scatter(f16.float(), c2p, torch.bfloat16))
+    for cells, c in ((7, 8), (1, 32), (333, 24)):
+        t = torch.full((cells,), -1, dtype=torch.int32, device=dev)
+        t[::2] = torch.arange((cells + 1) // 2, dtype=torch.int32, device=dev)
+        f = torch.randn((cells + 1) // 2, c, device=dev).to(torch.bfloat16)
+        want = torch.zeros(cells, c, dtype=torch.bfloat16, device=dev)
+        want[::2] = f
+        assert torch.equal(native.pillar_scatter(f, t, torch.bfloat16), want)
 
 
 # ---------------------------------------------------------------- A11
@@ -884,9 +900,12 @@ def test_pillar_scatter_timed_launch(native, dev):
     try:
         got = native.pillar_scatter(feats, c2p, torch.bfloat16)
         torch.cuda.synchronize()
-        (timer, nc, cc, mm, dt), = native.scatter_timer
+        (timer, nc, cc, mm, dt, fdt), = native.scatter_timer
+        got16 = native.pillar_scatter(feats.to(torch.bfloat16), c2p, torch.bfloat16)
+        torch.cuda.synchronize()
+        assert native.scatter_timer[1][5] == torch.bfloat16 and 0.6 < native.scatter_timer[1][0].elapsed_us() < 1000.0
     finally:
         native.scatter_timer = None
-    assert torch.equal(got, want) and (nc, cc, mm, dt) == (n_cells, c, m, torch.bfloat16)
+    assert torch.equal(got, want) and torch.equal(got16, want) and (nc, cc, mm, dt, fdt) == (n_cells, c, m, torch.bfloat16, torch.float32)
     us = timer.elapsed_us()
     assert 0.6 < us < 1000.0, us

@@ -1,5 +1,5 @@
 """The pillar-scatter launch of bench.py's roofline object in isolation: the canvas of a 4-sequence step (20 x 288 x 288 cells,
-32 channels, bf16) filled from 1.17 M feature rows, timed with events attached to the dispatch, 50 launches back to back --
+32 channels, bf16) filled from 1.17 M bf16 feature rows, timed with events attached to the dispatch, 50 launches back to back --
 first with the features in pillar-id order as the model has them (random with respect to the cells on uniform synthetic
 input), then with pillar ids in cell order (sequential reads).  Usage: python tools/bench_scatter.py"""
 import json
@@ -13,6 +13,7 @@ from pcaccumulation_amd import native  # noqa: E402
 
 
 def run(c2p, feats, n=50, flush=None):
+    """feats: bf16 rows (the bf16 compute mode) or f32 rows (converted on the way)."""
     for _ in range(5):
         native.pillar_scatter(feats, c2p, torch.bfloat16)
     native.scatter_timer = []
@@ -22,7 +23,7 @@ def run(c2p, feats, n=50, flush=None):
                 flush.add_(1.0)                                # 1 GiB read + written in between: nothing of the table stays cached
             native.pillar_scatter(feats, c2p, torch.bfloat16)
         torch.cuda.synchronize()
-        us = sorted(t.elapsed_us() for t, *_ in native.scatter_timer)
+        us = sorted(t[0].elapsed_us() for t in native.scatter_timer)
     finally:
         native.scatter_timer = None
     return us
@@ -32,9 +33,9 @@ def main():
     dev = torch.device('cuda:0')
     torch.manual_seed(0)
     n_cells, m, c = 20 * 288 * 288, 1_169_433, 32
-    feats = torch.randn(m, c, device=dev)
+    feats = torch.randn(m, c, device=dev).to(torch.bfloat16)
     occupied = torch.randperm(n_cells, device=dev)[:m]
-    alg = n_cells * c * 2 + m * c * 4 + 4 * m
+    alg = n_cells * c * 2 + m * c * 2 + 4 * m               # SURVEY 8d with s = 2
     for name, ids in (('pillar ids in first-touch (random) order', torch.arange(m, dtype=torch.int32, device=dev)),
                       ('pillar ids in cell order', None)):
         c2p = torch.full((n_cells,), -1, dtype=torch.int32, device=dev)
