@@ -6,13 +6,15 @@
 
 A step = one pass of the hot path over one synthetic 5-frame x 160k-point sequence per GPU (BASELINE config
 c3 shape): GPU voxelisation + collate layout -> MotionNet forward (bf16 canvas / conv stacks, fp32 ego head)
--> FuseLoss -> backward -> flat gradient all-reduce (N > 1) -> grad clip -> Adam step.  Inputs (raw points,
+-> FuseLoss -> backward into a flat gradient buffer (N > 1: bucketed all-reduce overlapped with backward) -> non-finite check
+-> grad clip -> Adam step (pdist.DataParallelStep, the cadence of libs/trainer.py:165-237).  Inputs (raw points,
 labels, poses) are resident in HBM before the timed region.  Scenes are independent, so ranks run different
 scenes and the only collective is the gradient all-reduce: weak scaling.
 
 Extra objects on the JSON line: `roofline` for the pillar-scatter kernel (the kernel BASELINE.json's north_star
 names), timed live with HIP events on the launch stream inside the timed region; `cpu_baseline`: the same step
-on the host cores with the oracle-backed CPU backend (rank 0, N = 1 only).
+on the host cores with the oracle-backed CPU backend (rank 0, N = 1 only); `matched_accuracy`: the same step with fp32 compute,
+the precision at which the path matches the reference within 1e-3 (N = 1 only).
 """
 import argparse
 import json
@@ -149,6 +151,7 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--iter-size', type=int, default=1, help='micro-steps per optimizer step (gradient accumulation; the all-reduce fires on the last one; reference yaml: 2)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-fp32-leg', action='store_true', help='skip the fp32 (matched-accuracy) timing of the same step that follows the bf16 run at N = 1')
     ap.add_argument('--no-miopen-find', action='store_true', help='library convolutions through the immediate-mode heuristic instead of the find-db')
     ap.add_argument('--no-prefetch', action='store_true', help='voxelise each batch at the start of its own step instead of one step ahead on a side stream')
     args = ap.parse_args()
@@ -203,6 +206,31 @@ def main():
     if stepper.skipped:
         raise SystemExit('bench: %d optimizer step(s) were skipped (rank %d: %r)' % (stepper.skipped, rank, stepper.last_error))
 
+    # The same step with fp32 compute: the precision at which the path matches the reference within north_star's 1e-3
+    # (tests/test_config_parity.py::test_gpu_config_fp32); bf16 is bounded in DESIGN.md section 4.  N = 1 only, a few steps.
+    fp32_leg = None
+    if world == 1 and args.dtype == 'bf16' and not args.no_fp32_leg:
+        del stepper, model, opt
+        torch.cuda.empty_cache()
+        cfg32 = json.loads(json.dumps(cfg))
+        cfg32['misc']['compute_dtype'] = 'fp32'
+        m32, o32, l32 = build(cfg32, device)
+        st32 = pdist.DataParallelStep(m32, o32, l32, iter_size=args.iter_size, grad_clip=cfg['train']['grad_clip'])
+        feed32 = BatchFeed(batcher, batch_of, not args.no_prefetch)
+        k32 = max(2, min(args.steps, 5))
+        for i in range(2):
+            train_step(st32, batcher, feed32)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(k32):
+            train_step(st32, batcher, feed32)
+        torch.cuda.synchronize()
+        dt32 = time.perf_counter() - t1
+        fp32_leg = {'dtype': 'fp32', 'value': args.batch * T_FRAMES * k32 / dt32, 'unit': 'LiDAR-frames/s', 'ms_per_step': dt32 / k32 * 1e3,
+                    'steps': k32, 'note': 'same step, fp32 compute: the mode whose mos_iou / ego errors / EPE match the reference within '
+                                          '1e-3 on c2-c5 (tests/test_config_parity.py); bf16 bound: DESIGN.md section 4'}
+        del st32, m32, o32
+
     if rank == 0:
         frames = world * args.batch * T_FRAMES * args.steps
         s = 2 if args.dtype == 'bf16' else 4
@@ -215,12 +243,12 @@ def main():
         # per element of the activation dtype
         alg = [nc * c * s + m * c * s + 4 * m for _, nc, c, m, *_ in timer]
         achieved = (sum(alg) / len(alg)) / (sum(durs) / len(durs)) / 1e9 if durs else 0.0
-        # HBM traffic of the same kernel from the committed PMC passes (profiles/r01_pmc_scatter_summary.json):
-        # measured bytes / algorithmic bytes at c3 size, applied to this run's per-launch algorithmic bytes
+        # HBM traffic of the same kernel from the committed PMC passes (profiles/r02_pmc_scatter_summary.json, taken at this
+        # launch's size: 4 sequences): measured bytes / algorithmic bytes, applied to this run's per-launch algorithmic bytes
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_scatter_summary.json')))
-            key = 'pillar_scatter_vec4<1> (bf16 canvas)' if args.dtype == 'bf16' else 'pillar_scatter_vec4<0> (fp32 canvas)'
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_scatter_summary.json')))
+            key = 'pillar_scatter_rows16' if args.dtype == 'bf16' else 'pillar_scatter_vec4<0>'
             traffic = pmc[key]['traffic_over_algorithmic'] * (sum(alg) / len(alg)) if alg else None
         except Exception:
             traffic = None
@@ -233,13 +261,15 @@ def main():
                                    % (T_FRAMES, args.pts_per_frame, args.batch),
                        'frames_per_sequence': T_FRAMES, 'pts_per_frame': args.pts_per_frame, 'sequences_per_gpu': args.batch, 'iter_size': args.iter_size,
                        'parallelism': 'dp%d' % world},
-            'roofline': {'kernel': 'pillar_scatter_vec4 (BEV canvas fill)', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
+            'roofline': {'kernel': 'pillar_scatter_rows16 (BEV canvas fill, bf16 rows -> bf16 canvas)' if args.dtype == 'bf16' else 'pillar_scatter_vec4<0> (BEV canvas fill)', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
-                         'traffic_source': 'PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_scatter_summary.json',
+                         'traffic_source': 'PMC FETCH_SIZE x2 + WRITE_SIZE (calibrated on a 128 MiB copy), profiles/r02_pmc_scatter_summary.json',
                          'launches_timed': len(durs), 'avg_launch_us': (sum(durs) / len(durs) * 1e6) if durs else None,
                          'timing': 'HIP events attached to each dispatch (hipExtLaunchKernel start/stop)',
                          'algorithmic_bytes_per_launch': (sum(alg) / len(alg)) if alg else None},
         }
+        if fp32_leg is not None:
+            line['matched_accuracy'] = fp32_leg
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line['cpu_baseline'] = cpu_baseline(cfg, args.pts_per_frame)

@@ -27,10 +27,11 @@ _LIB = None
 
 
 def build(force=False):
+    """libpcacc_oracle.so = csrc/pcacc_oracle.c (scalar restatements) + csrc/pcacc_twin.c (the OpenMP CPU twin of the C ABI)."""
     so = os.path.join(_HERE, 'libpcacc_oracle.so')
-    src = os.path.join(_HERE, 'csrc', 'pcacc_oracle.c')
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(['gcc', '-O2', '-ffp-contract=off', '-fPIC', '-shared', '-o', so, src, '-lm'])
+    srcs = [os.path.join(_HERE, 'csrc', f) for f in ('pcacc_oracle.c', 'pcacc_twin.c')]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
+        subprocess.check_call(['gcc', '-O2', '-ffp-contract=off', '-fopenmp', '-fPIC', '-shared', '-o', so] + srcs + ['-lm'])
     return so
 
 

@@ -10,6 +10,7 @@ import numpy as np
 import torch
 
 import oracle
+from oracle import twin
 
 
 def _np(t):
@@ -25,11 +26,8 @@ def voxelize(points, voxel_size, pc_range, grid, nt, max_voxels):
 
 
 def cell_index(coords, nx, ny, nt, n_batch):
-    c = _np(coords).astype(np.int64)
-    cell = ((c[:, 0] * nt + c[:, 4]) * ny + c[:, 2]) * nx + c[:, 3]
-    c2p = np.full(n_batch * nt * ny * nx, -1, np.int32)
-    c2p[cell] = np.arange(c.shape[0], dtype=np.int32)
-    return torch.from_numpy(cell.astype(np.int32)), torch.from_numpy(c2p)
+    cell, c2p = twin.cell_index(_np(coords), nx, ny, nt, n_batch)
+    return torch.from_numpy(cell), torch.from_numpy(c2p)
 
 
 def frame_pillars(cell2pillar, cells_per_frame, m):
@@ -40,9 +38,7 @@ def frame_pillars(cell2pillar, cells_per_frame, m):
 
 
 def csr_build(p2v, m):
-    p = _np(p2v)
-    order = np.argsort(p, kind='stable').astype(np.int32)
-    offs = np.concatenate([[0], np.cumsum(np.bincount(p, minlength=m))]).astype(np.int32)
+    offs, order = twin.csr_build(_np(p2v), m)
     return torch.from_numpy(offs), torch.from_numpy(order)
 
 
@@ -55,57 +51,34 @@ def _p2v_from_csr(offs, order):
 
 
 def segment_mean3_maxlabel(points, labels, offs, order, m):
-    p2v = _p2v_from_csr(offs, order)
-    mean = torch.from_numpy(oracle.segment_mean(_np(points), p2v, m))
-    lab = torch.from_numpy(oracle.segment_max_label(_np(labels), p2v, m)[:, 0].copy()) if labels is not None else None
-    return mean, lab
+    mean, lab = twin.segment_mean3_maxlabel(_np(points), _np(labels) if labels is not None else None, _np(offs), _np(order), m)
+    return torch.from_numpy(mean), (torch.from_numpy(lab) if lab is not None else None)
 
 
 def segment_max(src, offs, order, m):
-    out, arg = oracle.segment_max(_np(src.float()), _p2v_from_csr(offs, order), m)
+    out, arg = twin.segment_max(_np(src.float()), _np(offs), _np(order), m)
     return torch.from_numpy(out).to(src.dtype), torch.from_numpy(arg)
 
 
 def segment_max_backward(grad_out, arg, p2v, n, out_dtype=None):
-    seg = p2v.long()
-    g = grad_out[seg]
-    hit = arg[seg].long() == torch.arange(n)[:, None]
-    out = torch.where(hit, g, torch.zeros_like(g))
-    return out.to(out_dtype) if out_dtype is not None else out
+    out = torch.from_numpy(twin.segment_max_backward(_np(grad_out.float()), _np(arg), _np(p2v), n))
+    return out.to(out_dtype) if out_dtype is not None else out.to(grad_out.dtype)
 
 
 def segment_sum(src, offs, order, m):
-    p2v = torch.from_numpy(_p2v_from_csr(offs, order))
-    return torch.zeros((m, src.shape[1]), dtype=torch.float32).index_add_(0, p2v, src.float())
+    return torch.from_numpy(twin.segment_sum(_np(src.float()), _np(offs), _np(order), m))
 
 
 def pillar_scatter(feats, cell2pillar, out_dtype=torch.float32):
-    c2p = cell2pillar.long()
-    canvas = torch.zeros((c2p.numel(), feats.shape[1]), dtype=torch.float32)
-    occ = c2p >= 0
-    canvas[occ] = feats.detach().float()[c2p[occ]]
-    return canvas.to(out_dtype)
+    return torch.from_numpy(twin.pillar_scatter(_np(feats.float()), _np(cell2pillar))).to(out_dtype)
 
 
 def gather_rows(src, idx):
-    i = idx.long()
-    out = src[i.clamp(min=0)]
-    out[i < 0] = 0
-    return out
+    return torch.from_numpy(twin.gather_rows(_np(src), _np(idx)))
 
 
 def bilinear_gather(fmap, points, map_idx, x_scale, y_scale):
-    fm = np.transpose(_np(fmap.float()), (0, 3, 1, 2))
-    pts = _np(points)
-    u = pts[:, 0] / np.float32(x_scale)
-    v = pts[:, 1] / np.float32(y_scale)
-    mi = _np(map_idx)
-    out = np.zeros((pts.shape[0], fm.shape[1]), np.float32)
-    for b in range(fm.shape[0]):
-        sel = mi == b
-        if sel.any():
-            out[sel] = oracle._grid_sample(fm[b], u[sel], v[sel], 'border')
-    return torch.from_numpy(out)
+    return torch.from_numpy(twin.bilinear_gather(_np(fmap.float()), _np(points), _np(map_idx), x_scale, y_scale))
 
 
 def bilinear_gather_backward(grad_out, shape, points, map_idx, x_scale, y_scale):
@@ -126,21 +99,11 @@ def bilinear_gather_backward(grad_out, shape, points, map_idx, x_scale, y_scale)
 
 
 def bev_warp(bev, inv_pose, x_reso, y_reso, x_min, y_min):
-    b_, t_, h, w, c = bev.shape
-    src = np.transpose(_np(bev.float()), (0, 1, 4, 2, 3))
-    out = np.empty_like(src)
-    ip = _np(inv_pose)
-    for b in range(b_):
-        out[b, 0] = src[b, t_ - 1]
-        for t in range(1, t_):
-            gx, gy = oracle.get_transformed_grid(ip[b, t], h, w, x_reso, y_reso, x_min, y_min)
-            out[b, t] = oracle._grid_sample(src[b, t], gx, gy, 'zeros').T.reshape(c, h, w)
-    return torch.from_numpy(np.ascontiguousarray(np.transpose(out, (0, 1, 3, 4, 2)))).to(bev.dtype)
+    return torch.from_numpy(twin.bev_warp(_np(bev.float()), _np(inv_pose), x_reso, y_reso, x_min, y_min)).to(bev.dtype)
 
 
 def rigid_transform(points, frame_idx, tsfm):
-    tr = tsfm.view(-1, 4, 4)[frame_idx.long()]
-    return (torch.matmul(tr[:, :3, :3], points[:, :, None])[:, :, 0] + tr[:, :3, 3]).float()
+    return torch.from_numpy(twin.rigid_transform(_np(points), _np(frame_idx), _np(tsfm)))
 
 
 def chamfer_forward(xyz1, xyz2):
@@ -178,9 +141,8 @@ def rows_wgrad(dy, x, dy_mask=None, x_relu=False):
 
 
 def pfn_features(points, p2v, pillar_mean, coords, time_indice, vx, vy, x_offset, y_offset, scale, n_frames):
-    f = oracle.pfn_features(_np(points), _np(p2v).astype(np.int64), _np(coords), _np(pillar_mean), _np(time_indice),
-                            [vx, vy], [-scale, -scale], n_frames)
-    return torch.from_numpy(f)
+    return torch.from_numpy(twin.pfn_features(_np(points), _np(p2v), _np(pillar_mean), _np(coords), _np(time_indice), vx, vy, x_offset,
+                                              y_offset, scale, n_frames))
 
 
 def scatter_sum_small(src, idx, m):

@@ -95,7 +95,7 @@ class BucketedGradReducer(object):
             if off - start > 0 and (off - start + p.numel()) * p.element_size() > bucket_bytes:
                 self.buckets.append((start, off))
                 start = off
-            self.views[i] = self.flat[off:off + p.numel()].view_as(p)
+            self.views[i] = self._view_like(p, off)
             self.bucket_of[i] = len(self.buckets)
             off += p.numel()
         self.buckets.append((start, off))
@@ -111,6 +111,18 @@ class BucketedGradReducer(object):
         for i, p in enumerate(self.params):
             p.grad = self.views[i]
             p.register_post_accumulate_grad_hook(self._make_hook(i))
+
+    def _view_like(self, p, off):
+        """A view of the flat buffer with the shape AND strides of `p` (conv weights are kept channels-last, MotionNet.channels_last_;
+        the fused optimizer kernels require gradients in the layout of their parameters)."""
+        try:
+            if p.is_contiguous():
+                return self.flat[off:off + p.numel()].view_as(p)
+            if torch.ops.aten.is_non_overlapping_and_dense(p):
+                return self.flat.as_strided(p.shape, p.stride(), off)
+        except (RuntimeError, AttributeError):
+            pass
+        return self.flat[off:off + p.numel()].view_as(p)
 
     # ------------------------------------------------------------------------------------------------
     def _make_hook(self, i):

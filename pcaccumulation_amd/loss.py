@@ -134,8 +134,8 @@ class FuseLoss(nn.Module):
     def get_mos_loss(self, predictions, input_dict):
         """libs/loss.py:140-165: supervised on points that are foreground in GT or in the estimate."""
         mos_gt, mos_est = input_dict['sd_labels'][:, 0], predictions['mos_est']
-        if '_fb_idx' in predictions:                                      # index list MotionNet already built (no re-sync)
-            fb_idx = predictions['_fb_idx']
+        if '_mos_idx' in predictions:                                     # index list MotionNet already built (train / val: no re-sync)
+            fb_idx = predictions['_mos_idx']
         else:
             fb_idx = torch.nonzero(torch.logical_or(input_dict['fb_labels'][:, 0] == 1, predictions['fb_est_per_points'][:, 0] == 1))[:, 0]
         if fb_idx.numel():
@@ -157,8 +157,8 @@ class FuseLoss(nn.Module):
         input_points = input_dict['input_points']
         bbox_tsfm = input_dict['inst_motion_gt']
         device = input_points.device
-        if '_rec_idx' in predictions:
-            rows = predictions['_rec_idx']                                 # index list of the GT-foreground points
+        if '_gtfg_idx' in predictions:
+            rows = predictions['_gtfg_idx']                                # index list of the GT-foreground points (train / val)
         else:
             rows = torch.nonzero(input_dict['fb_labels'][:, 0] == 1)[:, 0]
         if rows.numel() == 0:

@@ -165,7 +165,11 @@ class MotionNet(nn.Module):
             pad_flags = torch.tensor(sizes[2 * nf + 2:], dtype=torch.bool).view(2, -1)
         bg_sorted_idx = torch.nonzero_static(bg_flag_sorted, size=bg_at[-1])[:, 0]
         fb_idx = torch.nonzero_static(fb_mask, size=n_fb)[:, 0]
-        results['_fb_idx'], results['_cell'] = fb_idx, pidx.cell                                # reused by FuseLoss (no re-sync)
+        results['_fb_idx'], results['_cell'] = fb_idx, pidx.cell
+        if self.mode in ['train', 'val']:
+            # FuseLoss.get_mos_loss supervises GT-or-estimated foreground in EVERY mode (libs/loss.py:145-147): only in train / val is
+            # that this forward's mask, so only then is the index list handed over (no re-sync); in test mode the loss rebuilds it
+            results['_mos_idx'] = fb_idx
 
         # 4. ego motion (fp32).  The per-cell L2 normalisation of motionnet.py:199 (no epsilon, trap 7) is applied to the
         #    gathered key-point rows inside the head instead of to the whole map.
@@ -209,6 +213,8 @@ class MotionNet(nn.Module):
         if n_rec > MIN_POINTS:
             rec_idx = torch.nonzero_static(rec_mask, size=n_rec)[:, 0]
             results['_rec_idx'] = rec_idx
+            if self.mode in ['train', 'val']:
+                results['_gtfg_idx'] = rec_idx            # = nonzero(fb_labels == 1), what FuseLoss.get_offset_loss supervises (libs/loss.py:199)
             # mos_feats exists whenever rec_mask passes in train/val (fb_mask is a superset of rec_mask)
             backbone_feats = ops.bilinear_gather(bev_feats, input_points[rec_idx], frame_idx[rec_idx],
                                                  abs(self.pc_range[0]), abs(self.pc_range[1]))       # temporal_ungrid

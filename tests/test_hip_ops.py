@@ -909,3 +909,62 @@ def test_pillar_scatter_timed_launch(native, dev):
     assert torch.equal(got, want) and torch.equal(got16, want) and (nc, cc, mm, dt, fdt) == (n_cells, c, m, torch.bfloat16, torch.float32)
     us = timer.elapsed_us()
     assert 0.6 < us < 1000.0, us
+
+
+def test_hip_against_cpu_twin_full_size(native, dev):
+    """The HIP library against the CPU twin of the same C ABI (oracle/csrc/pcacc_twin.c) on raw buffers at c3 size (800 k points):
+    index structures and arg-max routing bit-exact, fp32 reductions bit-exact where the summation order is defined (CSR order),
+    sampling kernels within fp32 rounding."""
+    from oracle import twin
+    cfg = default_config('waymo', 'val')
+    vg = cfg['voxel_generator']
+    inp = make_batch(cfg, [77], 5, 160000)
+    nx, ny, nz, nt = (int(v) for v in inp['shape'][0])
+    coords, p2v = inp['coordinates'].numpy(), inp['point_to_voxel_map'][:, 0].numpy()
+    m, n = coords.shape[0], p2v.shape[0]
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    cell, c2p = native.cell_index(d(coords), nx, ny, nt, 1)
+    tcell, tc2p = twin.cell_index(coords, nx, ny, nt, 1)
+    assert np.array_equal(cell.cpu().numpy(), tcell) and np.array_equal(c2p.cpu().numpy(), tc2p)
+    offs, order = native.csr_build(d(p2v), m)
+    toffs, torder = twin.csr_build(p2v, m)
+    assert np.array_equal(offs.cpu().numpy(), toffs) and np.array_equal(order.cpu().numpy(), torder)
+    pts = inp['input_points'].numpy().astype(np.float32)
+    mean, lab = native.segment_mean3_maxlabel(d(pts), d(inp['fb_labels'][:, 0].numpy()), offs, order, m)
+    tmean, tlab = twin.segment_mean3_maxlabel(pts, inp['fb_labels'][:, 0].numpy(), toffs, torder, m)
+    assert np.array_equal(mean.cpu().numpy(), tmean) and np.array_equal(lab.cpu().numpy(), tlab)
+    rng = np.random.RandomState(0)
+    src = rng.randn(n, 32).astype(np.float32)
+    out, arg = native.segment_max(d(src), offs, order, m)
+    tout, targ = twin.segment_max(src, toffs, torder, m)
+    assert np.array_equal(out.cpu().numpy(), tout) and np.array_equal(arg.cpu().numpy(), targ)
+    assert np.array_equal(native.segment_sum(d(src), offs, order, m).cpu().numpy(), twin.segment_sum(src, toffs, torder, m))
+    g = rng.randn(m, 32).astype(np.float32)
+    assert np.array_equal(native.segment_max_backward(d(g), arg, d(p2v), n).cpu().numpy(), twin.segment_max_backward(g, targ, p2v, n))
+    vx, vy = vg['voxel_size'][0], vg['voxel_size'][1]
+    args = (vx, vy, vx / 2 + vg['range'][0], vy / 2 + vg['range'][1], abs(vg['range'][0]), nt)
+    f = native.pfn_features(d(pts), d(p2v), mean, d(coords), d(inp['time_indice'].numpy()), *(float(a) for a in args))
+    assert np.array_equal(f.cpu().numpy(), twin.pfn_features(pts, p2v, tmean, coords, inp['time_indice'].numpy(), *args))
+    feats = rng.randn(m, 32).astype(np.float32)
+    canvas = native.pillar_scatter(d(feats), c2p)
+    tcanvas = twin.pillar_scatter(feats, tc2p)
+    assert np.array_equal(canvas.cpu().numpy(), tcanvas)
+    assert np.array_equal(native.gather_rows(canvas, cell).cpu().numpy(), twin.gather_rows(tcanvas, tcell))
+    fmap = tcanvas.reshape(nt, ny, nx, 32)
+    midx = inp['time_indice'][:, 1].numpy().astype(np.int32)
+    bg = native.bilinear_gather(d(fmap), d(pts), d(midx), 36.0, 36.0)
+    np.testing.assert_allclose(bg.cpu().numpy(), twin.bilinear_gather(fmap, pts, midx, 36.0, 36.0), rtol=0, atol=2e-5)
+    pose = np.tile(np.eye(4, dtype=np.float32), (1, nt, 1, 1))
+    for t in range(1, nt):
+        a = 0.01 * t
+        pose[0, t, :2, :2] = [[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]
+        pose[0, t, :2, 3] = [0.9 * t, 0.05 * t]
+    bev = fmap.reshape(1, nt, ny, nx, 32)
+    w = native.bev_warp(d(bev), d(pose), vx, vy, float(vg['range'][0]), float(vg['range'][1]))
+    np.testing.assert_allclose(w.cpu().numpy(), twin.bev_warp(bev, pose, vx, vy, vg['range'][0], vg['range'][1]), rtol=0, atol=2e-5)
+    tp = native.rigid_transform(d(pts), d(midx), d(pose.reshape(-1, 16)))
+    np.testing.assert_allclose(tp.cpu().numpy(), twin.rigid_transform(pts, midx, pose.reshape(-1, 16)), rtol=0, atol=4e-6)
+    x = rng.randn(2, 5, 64, 64, 8).astype(np.float32)
+    fm_out, fm_arg = native.frames_max(d(x))
+    tfo, tfa = twin.frames_max(x)
+    assert np.array_equal(fm_out.cpu().numpy(), tfo) and np.array_equal(fm_arg.cpu().numpy().reshape(tfa.shape), tfa)

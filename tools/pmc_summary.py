@@ -26,7 +26,7 @@ def collect(path, counter):
         for frag in KERNELS:
             if frag in name:
                 key = frag
-        if key is None and 'vectorized_elementwise_kernel' in name and 'direct_copy' in name and int(r['Grid_Size']) >= 32 * 1024 * 1024 // 16:
+        if key is None and 'copyBuffer' in name and float(r['Counter_Value']) > 32 * 1024:      # dst.copy_(src): the 128 MiB device copy
             key = 'copy'
         if key:
             out.setdefault(key, []).append(float(r['Counter_Value']))
