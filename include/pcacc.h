@@ -354,6 +354,13 @@ int pcacc_conv3x3_bf16(const uint16_t *in, const uint16_t *wp, const float *bias
  * gradient = sum of dy over the images and pixels this launch visits; complete for dt = 0);  dw[co][tap][ci] = sum of
  * dy[n][px][co] * x[n + dt][px + tap offset][ci]; dt in {-1, 0, 1} selects the frame tap of a kt = 3 layer (0 for kt = 1),
  * frames as above.  bf16 MFMA with fp32 accumulation; per-workgroup partials in `workspace`, summed by a second launch. */
+/* The deep layers (c_in >= 128 in steps of 64, c_out in steps of 64, kt = 1: the 128..512-channel layers of models/unet.py:45-113 and
+ * models/stpn.py:24-43 on 18^2 .. 144^2 images): tiles of 32 consecutive pixels of a strip instead of 8 x 32 image tiles, the strip's
+ * input patch resident in LDS per channel slice, weight tiles double buffered.  pcacc_conv3x3_bf16 routes such shapes here itself;
+ * pcacc_conv3x3_deep_supported tells whether a shape qualifies (1) or not (0). */
+int pcacc_conv3x3_deep_supported(int32_t h, int32_t w, int32_t c_in, int32_t c_out);
+int pcacc_conv3x3_deep_bf16(const uint16_t *in, const uint16_t *wp, const float *bias, uint16_t *out, int32_t n_img, int32_t h,
+                            int32_t w, int32_t c_in, int32_t c_out, int32_t relu, void *stream);
 int pcacc_conv3x3_wgrad_workspace_bytes(int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_out, size_t *bytes /*host*/);
 int pcacc_conv3x3_wgrad_bf16(const uint16_t *dy, const uint16_t *x, float *dw, int32_t n_img, int32_t frames, int32_t dt,
                              int32_t h, int32_t w, int32_t c_in, int32_t c_out, void *workspace, size_t workspace_bytes,

@@ -438,6 +438,9 @@ extern "C" int pcacc_conv3x3_bf16(const uint16_t *in, const uint16_t *wp, const 
 #undef CV_RES
         }
     }
+    // deep layers on small images: strips of consecutive pixels, K-deep tiling (conv_deep.hip)
+    if (kt == 1 && pcacc_conv3x3_deep_supported(h, w, c_in, c_out))
+        return pcacc_conv3x3_deep_bf16(in, wp, bias, out, n_img, h, w, c_in, c_out, relu, stream);
     const int cs_sel = c_in % 128 == 0 ? 128 : (c_in % 64 == 0 ? 64 : 32);   // input channels per LDS pass
     const int ct = c_out % 128 == 0 ? 4 : (c_out % 64 == 0 ? 2 : 1);
 #define CV_CASE(CTV, CSV) \

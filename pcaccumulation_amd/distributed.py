@@ -68,48 +68,53 @@ def _reachable_parameters(loss):
 
 
 class BucketedGradReducer(object):
-    """Mean of the gradients of `params` across ranks: flat buffer, reverse-order buckets, all-reduces overlapped with backward.
+    """Mean of the gradients of `params` across ranks: reverse-order buckets of one flat buffer, all-reduces overlapped with backward.
 
-        reducer.zero()                          # start of an accumulation window (replaces optimizer.zero_grad)
+        reducer.zero()                          # start of an accumulation window (= optimizer.zero_grad(set_to_none=True))
         for each micro-step of the window:
             reducer.prepare(loss, sync=last)    # sync=True on the window's last micro-step only
-            loss.backward()                     # hooks launch ready buckets (sync steps)
-        reducer.finish()                        # wait for the collectives (current stream waits; the host does not)
-        ok = reducer.agree(ok)                  # all ranks ok?  + per-parameter "any rank has a gradient"
-        with reducer.sparse_grads(): clip; optimizer.step()
+            loss.backward()                     # hooks copy finished buckets into the flat buffer and launch their all-reduce
+        reducer.finish()                        # the current stream waits for the collectives (the host does not); .grad = views
+        flag = reducer.agree(ok)                # device tensor: 1 iff every rank reports ok
 
-    With one rank everything degenerates to the flat buffer (still one memset instead of 195 `grad = None`)."""
+    Autograd keeps producing ordinary gradient tensors (no read-modify-write into a zeroed buffer: the first accumulation of a
+    window just adopts the incoming tensor); when the last expected gradient of a bucket has arrived, ONE multi-tensor copy moves
+    the bucket's gradients into its slice of the flat buffer and the slice's all-reduce is launched.  After finish() every
+    parameter's `.grad` is its (averaged) view.  With one rank nothing is copied or reduced at all."""
 
     def __init__(self, params, bucket_bytes=8 << 20):
         self.params = [p for p in params if p.requires_grad]
+        self.world = world_size()
         dev, dtype = self.params[0].device, self.params[0].dtype
         order = list(reversed(range(len(self.params))))
         self.numel = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(self.numel, dtype=dtype, device=dev)
+        self.flat = torch.zeros(self.numel if self.world > 1 else 0, dtype=dtype, device=dev)
         self.views = [None] * len(self.params)
         self.bucket_of = [0] * len(self.params)
+        self.members = [[]]                                  # parameter indices per bucket
         self.buckets = []                                    # (start, end) element ranges of the flat buffer
         off = start = 0
         for i in order:
             p = self.params[i]
             if off - start > 0 and (off - start + p.numel()) * p.element_size() > bucket_bytes:
                 self.buckets.append((start, off))
+                self.members.append([])
                 start = off
-            self.views[i] = self._view_like(p, off)
+            if self.world > 1:
+                self.views[i] = self._view_like(p, off)
             self.bucket_of[i] = len(self.buckets)
+            self.members[-1].append(i)
             off += p.numel()
         self.buckets.append((start, off))
-        self.index = {id(p): i for i, p in enumerate(self.params)}
         self.touched = [False] * len(self.params)
-        self._expected = [0] * len(self.buckets)
+        self._expected = [True] * len(self.params)
         self._pending = [0] * len(self.buckets)
         self._next = len(self.buckets)                       # nothing to launch until prepare(sync=True)
         self._works = []
         self._sync = False
         self._callback_queued = False
-        self._absent = None
+        self._mask = None
         for i, p in enumerate(self.params):
-            p.grad = self.views[i]
             p.register_post_accumulate_grad_hook(self._make_hook(i))
 
     def _view_like(self, p, off):
@@ -127,13 +132,8 @@ class BucketedGradReducer(object):
     # ------------------------------------------------------------------------------------------------
     def _make_hook(self, i):
         def hook(param):
-            g = param.grad
-            if g is None or g.data_ptr() != self.views[i].data_ptr():     # somebody replaced the view (zero_grad(set_to_none)):
-                if g is not None:                                          # fold what autograd wrote back into the buffer
-                    self.views[i].add_(g)
-                param.grad = self.views[i]
             self.touched[i] = True
-            if self._sync:
+            if self._sync and self.world > 1:
                 if not self._callback_queued:                # the rest of the buckets go out when this backward ends
                     torch.autograd.Variable._execution_engine.queue_callback(self._launch_all)
                     self._callback_queued = True
@@ -144,11 +144,24 @@ class BucketedGradReducer(object):
         return hook
 
     def _launch(self, b):
+        """Bucket b: gradients that exist -> their views (one multi-tensor copy), views nobody wrote -> zero, then the all-reduce."""
         s, e = self.buckets[b]
-        if world_size() > 1:
-            avg = dist.get_backend() == 'nccl'
-            work = dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=True)
-            self._works.append((work, b, avg))
+        src, dst, zero = [], [], []
+        for i in self.members[b]:
+            g = self.params[i].grad
+            if self.touched[i] and g is not None:
+                if g.data_ptr() != self.views[i].data_ptr():
+                    src.append(g)
+                    dst.append(self.views[i])
+            else:
+                zero.append(self.views[i])
+        if src:
+            torch._foreach_copy_(dst, src)
+        if zero:
+            torch._foreach_zero_(zero)
+        avg = dist.get_backend() == 'nccl'
+        work = dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=True)
+        self._works.append((work, b, avg))
 
     def _launch_ready(self):
         while self._next < len(self.buckets) and self._pending[self._next] <= 0:
@@ -162,10 +175,9 @@ class BucketedGradReducer(object):
 
     # ------------------------------------------------------------------------------------------------
     def zero(self):
-        """Start of an accumulation window: one memset; every .grad is (again) its view."""
-        self.flat.zero_()
-        for i, p in enumerate(self.params):
-            p.grad = self.views[i]
+        """Start of an accumulation window: gradients dropped (autograd adopts the next ones instead of adding into old memory)."""
+        for p in self.params:
+            p.grad = None
         self.touched = [False] * len(self.params)
 
     def prepare(self, loss, sync=True):
@@ -173,63 +185,72 @@ class BucketedGradReducer(object):
         self._sync = bool(sync)
         self._callback_queued = False
         self._works = []
-        if not self._sync:
-            self._next = len(self.buckets)
+        self._next = len(self.buckets)
+        if not self._sync or self.world == 1:
             return
         self._next = 0
-        reach = _reachable_parameters(loss) if (loss is not None and world_size() > 1) else None
+        reach = _reachable_parameters(loss) if loss is not None else None
         self._pending = [0] * len(self.buckets)
         for i, p in enumerate(self.params):
             if reach is None or id(p) in reach:
                 self._pending[self.bucket_of[i]] += 1
-        self._launch_ready()                                  # leading buckets nobody will write (skipped branches)
+        self._launch_ready()                                  # leading buckets this backward cannot write (skipped branches)
 
     def flush(self):
         """A rank whose forward / backward raised still issues every collective of the step (in order), so the others do not hang."""
-        if self._sync:
+        if self._sync and self.world > 1:
             self._launch_all()
 
     def finish(self):
-        """After backward: every bucket is out; the current stream waits for them (no host block with RCCL)."""
-        if not self._sync:
+        """After backward: every bucket is out; the current stream waits for them (no host block with RCCL); `.grad` of every
+        parameter becomes its averaged view."""
+        if not self._sync or self.world == 1:
+            self._sync = False
             return
         self._launch_all()
-        ws = world_size()
         for work, b, averaged in self._works:
             work.wait()
             if not averaged:
                 s, e = self.buckets[b]
-                self.flat[s:e].div_(ws)
+                self.flat[s:e].div_(self.world)
         self._works = []
         self._sync = False
+        for i, p in enumerate(self.params):
+            p.grad = self.views[i]
 
-    def agree(self, ok=True, check_finite=False):
-        """True iff every rank reports ok (and, with check_finite, every reduced gradient is finite: validate_gradient of
-        toolbox/utils.py:147-157 on the buffer all ranks share); also settles which parameters received a gradient on ANY rank.
-        One MIN all-reduce of 1 + n_params int32 and ONE read-back: the step's agreement point."""
-        flags = [1 if ok else 0] + [0 if t else 1 for t in self.touched]          # MIN(absent) == 0 <=> somebody has it
-        if world_size() > 1 or check_finite:
-            t = torch.tensor(flags, dtype=torch.int32).to(self.flat.device)
-            if check_finite:
-                t[0] = torch.minimum(t[0], torch.isfinite(self.flat).all().to(torch.int32))
-            if world_size() > 1:
-                dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            flags = t.cpu().tolist()
-        self._absent = [bool(f) for f in flags[1:]]
-        return bool(flags[0])
+    def agree(self, ok=True):
+        """-> device tensor [1] int32: 1 iff every rank reports ok.  The same MIN all-reduce carries, per parameter, "no rank produced a
+        gradient"; it is read back on the host only by ranks that lack a gradient themselves (a skipped branch -- otherwise the
+        answer is known to be "somebody did"), so the common step has no host synchronisation at all."""
+        dev = self.params[0].device
+        if self.world == 1:
+            self._mask = None
+            return torch.full((1,), 1 if ok else 0, dtype=torch.int32, device=dev)
+        flags = torch.tensor([1 if ok else 0] + [0 if t else 1 for t in self.touched], dtype=torch.int32)
+        t = flags.to(dev, non_blocking=True)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        self._mask = t[1:] if not all(self.touched) else None
+        return t[:1]
 
     class _Sparse(object):
         def __init__(self, reducer):
             self.r = reducer
 
         def __enter__(self):
-            for p, absent in zip(self.r.params, self.r._absent or []):
-                if absent:
-                    p.grad = None                             # as in a single process: Adam / clip skip parameters without a gradient
+            r = self.r
+            if r.world == 1:
+                return                                        # untouched parameters already have .grad = None
+            if r._mask is not None:                           # this rank skipped a branch: did every other rank skip it too?
+                absent = r._mask.cpu().tolist()
+                for p, a in zip(r.params, absent):
+                    if a:
+                        p.grad = None                         # as in a single process: Adam / clip skip parameters without a gradient
 
         def __exit__(self, *exc):
-            for i, p in enumerate(self.r.params):
-                p.grad = self.r.views[i]
+            r = self.r
+            if r.world > 1 and r._mask is not None:
+                for i, p in enumerate(r.params):
+                    p.grad = r.views[i]
             return False
 
     def sparse_grads(self):
@@ -239,9 +260,13 @@ class BucketedGradReducer(object):
 
 class DataParallelStep(object):
     """The per-batch body and the every-`iter_size` block of the reference's training loop (libs/trainer.py:165-196, 214-237) for
-    N ranks: forward, `loss / iter_size` backward into the flat buffer (all-reduce overlapped on the window's last micro-step),
-    then -- once per window -- agreement, non-finite check (toolbox/utils.py:147-157), clip, optimizer step, zero.
-    Exceptions inside forward / loss / backward are caught like the reference does (the step is then skipped on EVERY rank)."""
+    N ranks: forward, `loss / iter_size` backward (bucketed all-reduce overlapped on the window's last micro-step), then -- once per
+    window -- agreement across ranks, non-finite check (toolbox/utils.py:147-157), clip, optimizer step, zero.
+    Exceptions inside forward / loss / backward are caught like the reference does (the step is then skipped on EVERY rank).
+    No host synchronisation in the common step: "skip" is a device flag (every rank ok AND the clipped-norm finite, which all ranks
+    compute from the same averaged gradients) handed to the fused optimizer as its `found_inf` input, the mechanism torch's AMP
+    GradScaler uses; `skipped` counts on the device (read it with skipped_steps()).  Optimizers without that input (CPU tests)
+    read the flag on the host."""
 
     def __init__(self, model, optimizer, loss_fn, iter_size=1, grad_clip=1.0, check_finite=True, catch=True, reducer=None):
         self.model, self.optimizer, self.loss_fn = model, optimizer, loss_fn
@@ -249,8 +274,16 @@ class DataParallelStep(object):
         self.reducer = reducer if reducer is not None else BucketedGradReducer(model.parameters())
         self.micro = 0
         self.ok = True
-        self.skipped = 0
         self.last_error = None
+        self._skipped = torch.zeros(1, dtype=torch.float32, device=self.reducer.params[0].device)
+        self._device_skip = bool(getattr(optimizer, '_step_supports_amp_scaling', False))
+
+    def skipped_steps(self):
+        return int(self._skipped.item())
+
+    @property
+    def skipped(self):
+        return self.skipped_steps()
 
     def __call__(self, inp, after_forward=None):
         """One micro-step on `inp`.  Returns the loss stats (None when this rank's forward failed)."""
@@ -281,13 +314,24 @@ class DataParallelStep(object):
         if last:
             self.micro = 0
             r.finish()
-            if r.agree(self.ok, check_finite=self.check_finite):
-                with r.sparse_grads():
+            flag = r.agree(self.ok)
+            with r.sparse_grads():
+                grads = [p.grad for p in r.params if p.grad is not None]
+                bad = (flag == 0).to(torch.float32).reshape(())
+                if grads and (self.grad_clip is not None or self.check_finite):
+                    norm = torch.nn.utils.get_total_norm(grads, 2.0, False, None)
+                    if self.check_finite:                     # inf / nan anywhere makes the norm non-finite
+                        bad = torch.maximum(bad, (~torch.isfinite(norm)).to(torch.float32).reshape(()))
                     if self.grad_clip is not None:
-                        torch.nn.utils.clip_grad_norm_(self.reducer.params, self.grad_clip)
+                        torch.nn.utils.clip_grads_with_norm_(r.params, self.grad_clip, norm, None)
+                self._skipped += bad
+                if not grads:
+                    pass
+                elif self._device_skip:
+                    self.optimizer.grad_scale, self.optimizer.found_inf = None, bad
                     self.optimizer.step()
-            else:
-                self.skipped += 1
+                elif not bool(bad.item()):
+                    self.optimizer.step()
         return stats
 
 

@@ -54,7 +54,7 @@ EXPORTS = [
     'pcacc_offset_loss_workspace_bytes', 'pcacc_offset_loss_forward', 'pcacc_offset_loss_backward',
     'pcacc_frames_max', 'pcacc_frames_max_backward', 'pcacc_rows_linear_cat_bf16', 'pcacc_rows_wgrad_cat_bf16',
     'pcacc_pillar_scatter_timed', 'pcacc_pillar_scatter_t', 'pcacc_timer_create', 'pcacc_timer_elapsed_us', 'pcacc_timer_destroy',
-    'pcacc_svd3', 'pcacc_svd3_backward', 'pcacc_bn_rows_workspace_bytes', 'pcacc_bn_rows_forward', 'pcacc_bn_rows_backward',
+    'pcacc_svd3', 'pcacc_svd3_backward', 'pcacc_conv3x3_deep_supported', 'pcacc_conv3x3_deep_bf16', 'pcacc_bn_rows_workspace_bytes', 'pcacc_bn_rows_forward', 'pcacc_bn_rows_backward',
 ]
 
 
@@ -464,6 +464,11 @@ def cluster(points, offset, sel, batch, n_batches, voxel_size, eps, min_samples,
 
 def conv3x3_supported(c_in, c_out):
     return c_in >= 32 and c_out >= 32 and c_in % 32 == 0 and c_out % 32 == 0
+
+
+def conv3x3_deep_supported(h, w, c_in, c_out):
+    """True for the layer shapes the strip kernel of csrc/conv_deep.hip takes (c_in >= 128, small images)."""
+    return bool(lib().pcacc_conv3x3_deep_supported(int(h), int(w), int(c_in), int(c_out)))
 
 
 def conv3x3_prepare_weights(weight, transpose=False):

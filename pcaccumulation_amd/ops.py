@@ -493,7 +493,7 @@ class _Conv3x3(torch.autograd.Function):
         kt = 3 if weight.dim() == 5 else 1
         o, i = weight.shape[0], weight.shape[1]
         need_w = ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2])
-        lib_dgrad = ctx.needs_input_grad[0] and kt == 1 and not conv3x3_preferred(o, i)      # data gradient: channels exchanged
+        lib_dgrad = ctx.needs_input_grad[0] and kt == 1 and not conv3x3_preferred(o, i, x_rows.shape[1], x_rows.shape[2])   # data gradient: channels exchanged
         if ctx.needs_input_grad[0] and not lib_dgrad:
             w32 = weight.detach().float().contiguous(memory_format=torch.contiguous_format)
             gx = native.conv3x3(gy, native.conv3x3_prepare_weights(w32, transpose=True), None, frames, False)
@@ -535,17 +535,21 @@ def _stack_frames(rows, frames):
     return torch.cat([prev, r, nxt], dim=-1).view(n, h, w, 3 * c)
 
 
-def conv3x3_preferred(c_in, c_out):
-    """Layer shapes on which the MFMA kernel beats the library today (tools/bench_conv.py, profiles/r01_conv_*): the
-    full-resolution layers with few input channels, i.e. everything that is bound by HBM and LDS rather than by the matrix
-    cores.  Wider layers (K = 9 x 128 and up on small images) stay with the library until the kernel tiles K deeper."""
-    return native.conv3x3_supported(c_in, c_out) and c_in <= 64
+def conv3x3_preferred(c_in, c_out, h=None, w=None):
+    """Layer shapes the hand-written kernels take: everything with c_in <= 64 (weights resident in LDS, csrc/conv.hip -- the layers
+    bound by HBM and LDS rather than by the matrix cores) and, given the image size, the deep layers on small images (c_in >= 128,
+    strips of consecutive pixels with K-deep tiling, csrc/conv_deep.hip)."""
+    if not native.conv3x3_supported(c_in, c_out):
+        return False
+    if c_in <= 64:
+        return True
+    return h is not None and native.conv3x3_deep_supported(h, w, c_in, c_out)
 
 
 def conv3x3_available(x, weight):
-    """True when `x` (NCHW view or rows) and the 3x3 weight take the MFMA path: GPU, bf16 compute, supported channel counts."""
+    """True when `x` (NCHW view) and the 3x3 weight take the MFMA path: GPU, bf16 compute, supported channel counts."""
     return (x.is_cuda and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16))
-            and conv3x3_preferred(weight.shape[1], weight.shape[0]))
+            and conv3x3_preferred(weight.shape[1], weight.shape[0], x.shape[-2], x.shape[-1]))
 
 
 def conv3x3_rows(x_rows, weight, bias, frames=1, relu=False):

@@ -49,7 +49,7 @@ def toy(rank, world, out):
         red.prepare(loss, sync=(micro == 1))
         loss.backward()
     red.finish()
-    ok = red.agree(True, check_finite=True)
+    ok = bool(red.agree(True).item())
     res['bucketed'] = {k: p.grad.clone() for k, p in net.named_parameters()}
     with red.sparse_grads():
         res['none_inside'] = [k for k, p in net.named_parameters() if p.grad is None]

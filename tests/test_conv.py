@@ -24,7 +24,11 @@ def _close(a, b, scale):
 
 @pytest.mark.parametrize('n,h,w,ci,co,relu', [
     (2, 16, 32, 32, 32, True), (1, 19, 45, 64, 32, False), (3, 8, 33, 32, 64, True), (1, 24, 64, 96, 32, True),
-    (1, 9, 18, 128, 128, True), (1, 18, 18, 256, 128, False), (1, 7, 5, 128, 256, True), (2, 40, 40, 64, 64, True)])
+    (1, 9, 18, 128, 128, True), (1, 18, 18, 256, 128, False), (1, 7, 5, 128, 256, True), (2, 40, 40, 64, 64, True),
+    # the deep layers of the two U-Nets (csrc/conv_deep.hip): strips of consecutive pixels, ragged last strips, 64-channel groups
+    (3, 18, 18, 512, 512, True), (2, 36, 36, 256, 256, True), (1, 72, 72, 128, 128, False), (2, 36, 36, 512, 256, True),
+    (1, 18, 18, 256, 512, False), (2, 20, 144, 128, 64, True), (1, 5, 288, 128, 64, True), (1, 19, 37, 128, 192, False),
+    (1, 72, 72, 256, 128, True), (1, 3, 400, 128, 128, True)])
 def test_conv3x3_forward(n, h, w, ci, co, relu):
     g = torch.Generator(device='cpu').manual_seed(n * 1000 + ci + co)
     x = torch.randn(n, h, w, ci, generator=g).to(DEV).to(torch.bfloat16)
@@ -127,3 +131,26 @@ def test_conv3x3_wgrad_kernel(ci, co, kt):
     assert (dw - wr.grad).abs().max().item() <= 2e-3 * wr.grad.abs().max().item()
     ref_b = gy.float().sum(dim=(0, 1, 2))
     assert (db - ref_b).abs().max().item() <= 1e-3 * max(1.0, ref_b.abs().max().item())
+
+
+@pytest.mark.parametrize('n,h,w,ci,co', [(2, 18, 18, 256, 128), (1, 36, 36, 128, 256), (2, 9, 72, 128, 128)])
+def test_conv3x3_backward_deep(n, h, w, ci, co):
+    """Deep layers: forward and data gradient through the strip kernel (csrc/conv_deep.hip; the data gradient is the same kernel on
+    mirrored / transposed weights, here with c_in and c_out exchanged), weight gradient as the layer currently takes it."""
+    g = torch.Generator(device='cpu').manual_seed(n + ci + co)
+    x = torch.randn(n, h, w, ci, generator=g).to(DEV).to(torch.bfloat16).requires_grad_(True)
+    wt = (torch.randn(co, ci, 3, 3, generator=g) / (4 * ci ** 0.5)).to(DEV).requires_grad_(True)
+    bias = torch.randn(co, generator=g).to(DEV).requires_grad_(True)
+    gy = torch.randn(n, h, w, co, generator=g).to(DEV).to(torch.bfloat16)
+    assert native.conv3x3_deep_supported(h, w, ci, co) and native.conv3x3_deep_supported(h, w, co, ci)
+    y = ops.conv3x3_rows(x, wt, bias, 1, True)
+    y.backward(gy)
+    xr = x.detach().float().requires_grad_(True)
+    wr = wt.detach().to(torch.bfloat16).float().requires_grad_(True)
+    br = bias.detach().clone().requires_grad_(True)
+    yr = torch.relu(F.conv2d(xr.permute(0, 3, 1, 2), wr, br, padding=1)).permute(0, 2, 3, 1)
+    _close(y, yr, yr.abs().max().item())
+    (yr * (y.detach() > 0)).backward(gy.float())
+    _close(x.grad, xr.grad, xr.grad.abs().max().item())
+    assert (wt.grad - wr.grad).abs().max().item() <= 2e-2 * wr.grad.abs().max().item()
+    assert (bias.grad - br.grad).abs().max().item() <= 2e-2 * br.grad.abs().max().item()
