@@ -361,6 +361,13 @@ int pcacc_conv3x3_bf16(const uint16_t *in, const uint16_t *wp, const float *bias
 int pcacc_conv3x3_deep_supported(int32_t h, int32_t w, int32_t c_in, int32_t c_out);
 int pcacc_conv3x3_deep_bf16(const uint16_t *in, const uint16_t *wp, const float *bias, uint16_t *out, int32_t n_img, int32_t h,
                             int32_t w, int32_t c_in, int32_t c_out, int32_t relu, void *stream);
+/* Weight gradient of the same deep layers (c_in, c_out multiples of 64, at least one of them > 64; kt = 1): dw [c_out][9][c_in] f32 and
+ * db [c_out] f32 = bias gradient, from dy [n_img,h,w,c_out] and x [n_img,h,w,c_in] (bf16, channels-last).  64 x 64 blocks of the weight
+ * tensor per workgroup, strips of consecutive pixels, per-workgroup partial slots in the workspace + a reduce launch. */
+int pcacc_conv3x3_wgrad_deep_supported(int32_t h, int32_t w, int32_t c_in, int32_t c_out);
+int pcacc_conv3x3_wgrad_deep_workspace_bytes(int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_out, size_t *bytes /*host*/);
+int pcacc_conv3x3_wgrad_deep_bf16(const uint16_t *dy, const uint16_t *x, float *dw, float *db, int32_t n_img, int32_t h, int32_t w,
+                                  int32_t c_in, int32_t c_out, void *workspace, size_t workspace_bytes, void *stream);
 int pcacc_conv3x3_wgrad_workspace_bytes(int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_out, size_t *bytes /*host*/);
 int pcacc_conv3x3_wgrad_bf16(const uint16_t *dy, const uint16_t *x, float *dw, int32_t n_img, int32_t frames, int32_t dt,
                              int32_t h, int32_t w, int32_t c_in, int32_t c_out, void *workspace, size_t workspace_bytes,

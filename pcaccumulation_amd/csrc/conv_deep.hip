@@ -48,7 +48,6 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_strip_kernel(const uint16_
     const int lp = lane & 31, lh = lane >> 5;
     const int mg = wave % MG, ng = wave / MG;
     const int n_px = rows * w;
-    const int n_mt = (n_px + 31) >> 5;
 
     // the lane's pixels: LDS offset of the top-left tap of their 3x3 windows, image position for the store
     int poff[MT], pyx[MT];
@@ -60,10 +59,6 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_strip_kernel(const uint16_
         poff[j] = ok ? (y * pw + x) * PS : 0;
         pyx[j] = ok ? ((y0 + y) << 16 | x) : -1;
     }
-    int mt_count = 0;                                          // wave-uniform: tiles of this wave that exist in the strip
-#pragma unroll
-    for (int j = 0; j < MT; ++j) mt_count += (mg + MG * j) < n_mt;
-
     f32x16_t acc[MT][2];
 #pragma unroll
     for (int j = 0; j < MT; ++j)
@@ -89,10 +84,11 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_strip_kernel(const uint16_
         for (int q = 0; q < CD_PCH; ++q) {
             const int py = pinfo[q] >> 20, pxx = (pinfo[q] >> 8) & 0xfff, c8 = pinfo[q] & 0xff;
             const int y = y0 - 1 + py, x = pxx - 1;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if ((unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w)
-                v = *reinterpret_cast<const uint4 *>(img_in + ((int64_t)y * w + x) * c_in + cs * CS + c8 * 8);
-            preg[q] = v;
+            // always load (from a clamped position), then select: a load under a lane mask would cost a branch and an early wait
+            const bool ok = (unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w;
+            const int yc = min(max(y, 0), h - 1), xc = min(max(x, 0), w - 1);
+            const uint4 v = *reinterpret_cast<const uint4 *>(img_in + ((int64_t)yc * w + xc) * c_in + cs * CS + c8 * 8);
+            preg[q] = ok ? v : make_uint4(0, 0, 0, 0);
         }
     };
     auto write_patch = [&]() {
@@ -109,8 +105,8 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_strip_kernel(const uint16_
         const uint16_t *src = wp + ((int64_t)tap * c_out + co0) * c_in + cs * CS;
 #pragma unroll
         for (int q = 0; q < W_PER; ++q) {
-            const int c = threadIdx.x + q * CD_THREADS;
-            if (c < W_CHUNKS) wreg[q] = *reinterpret_cast<const uint4 *>(src + (int64_t)(c / C8) * c_in + (c % C8) * 8);
+            const int c = (W_CHUNKS % CD_THREADS) ? min(threadIdx.x + q * CD_THREADS, W_CHUNKS - 1) : threadIdx.x + q * CD_THREADS;
+            wreg[q] = *reinterpret_cast<const uint4 *>(src + (int64_t)(c / C8) * c_in + (c % C8) * 8);   // clamped, never masked
         }
     };
     auto write_w = [&](int buf) {
@@ -138,19 +134,23 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_strip_kernel(const uint16_
             __syncthreads();                                   // buffer `buf` (and, at tap 0, the patch) is visible
             const uint16_t *wb = wbuf + buf * WROWS * PS + (ng * 64 + lp) * PS + lh * 8;
             const int toff = ((tap / 3) * pw + tap % 3) * PS + lh * 8;
+            constexpr int KC = CS / 16;
+            bf16x8_t fa[2][2], fb[2][MT];
+            auto load = [&](int slot, int kc) {
 #pragma unroll
-            for (int kc = 0; kc < CS / 16; ++kc) {
-                bf16x8_t a[2], b[MT];
+                for (int n = 0; n < 2; ++n) fa[slot][n] = *reinterpret_cast<const bf16x8_t *>(wb + n * 32 * PS + kc * 16);
 #pragma unroll
-                for (int n = 0; n < 2; ++n) a[n] = *reinterpret_cast<const bf16x8_t *>(wb + n * 32 * PS + kc * 16);
+                for (int j = 0; j < MT; ++j) fb[slot][j] = *reinterpret_cast<const bf16x8_t *>(patch + poff[j] + toff + kc * 16);
+            };
+            load(0, 0);
 #pragma unroll
-                for (int j = 0; j < MT; ++j) b[j] = *reinterpret_cast<const bf16x8_t *>(patch + poff[j] + toff + kc * 16);
+            for (int kc = 0; kc < KC; ++kc) {
+                if (kc + 1 < KC) load((kc + 1) & 1, kc + 1);   // fragments of the next step in flight under this step's MFMAs
 #pragma unroll
                 for (int j = 0; j < MT; ++j)
-                    if (j < mt_count) {
 #pragma unroll
-                        for (int n = 0; n < 2; ++n) acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[n], b[j], acc[j][n], 0, 0, 0);
-                    }
+                    for (int n = 0; n < 2; ++n)
+                        acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kc & 1][n], fb[kc & 1][j], acc[j][n], 0, 0, 0);
             }
             if (tap < 8) write_w(buf ^ 1);                     // the other buffer: its last readers passed the barrier above
             if (tap < 8) buf ^= 1;
@@ -251,4 +251,231 @@ extern "C" int pcacc_conv3x3_deep_bf16(const uint16_t *in, const uint16_t *wp, c
     }
     return wide ? conv_strip_launch<32, 1>(in, wp, bias, out, n_img, h, w, c_in, c_out, relu, st)
                 : conv_strip_launch<64, 1>(in, wp, bias, out, n_img, h, w, c_in, c_out, relu, st);
+}
+
+// ---- weight gradient of the deep layers ---------------------------------------------------------------------------------------------
+// dW[co][tap][ci] = sum over images and pixels of dY[px][co] * X[px + tap offset][ci]: M = co, N = (tap, ci), K = pixels.  The
+// reduction runs over pixels, so both MFMA operands are "8 consecutive pixels of one channel" per lane: the dY rows and the X patch of
+// a strip are staged channels-last as they come and the fragments are read with the hardware LDS transpose (ds_read_b64_tr_b16,
+// the scheme of conv3x3_wgrad_kernel in conv.hip; row stride C + 4 elements).  Here a workgroup owns one 64 x 64 (co, ci) block
+// of the weight tensor and every `slots`-th strip: 8 waves = 4 (co tile, ci tile) pairs x 2 tap groups (taps 0-4 / 5-8), up to 5
+// accumulators per wave, so a dY fragment is read once per 4-5 MFMAs and no wave shares an output element with another.  Pixels of
+// a strip are consecutive in row-major order; a per-strip LDS table maps a pixel to the patch row of its top-left tap (no
+// divisions in the loop).  One partial slot per workgroup goes to the workspace, a second launch sums the slots.
+typedef short cd_s16x4 __attribute__((ext_vector_type(4)));
+union cd_frag { bf16x8_t v; cd_s16x4 h[2]; };
+#define CDW_MAXP 256                                       // pixels per strip
+#define CDW_PCH 11                                         // staged 16-byte pieces (dY rows + X patch) a thread carries
+
+__global__ __launch_bounds__(CD_THREADS) void conv3x3_wgrad_strip_kernel(const uint16_t *__restrict__ dy, const uint16_t *__restrict__ x,
+                                                                         float *__restrict__ partial, int n_img, int h, int w, int c_in,
+                                                                         int c_out, int rows, int strips, int ci_blocks, int slots)
+{
+    constexpr int CO = 64, CI = 64, PAIRS = 4, TG = 5;        // TG = taps of the first tap group
+    constexpr int YS = CO + 4, XS = CI + 4;
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    const int pw = w + 2, pp = (rows + 2) * pw;
+    const int n_px = rows * w, n_steps = (n_px + 15) >> 4, py_rows = n_steps * 16;
+    uint16_t *sdy = lds;                                       // [py_rows][YS]   (rows >= n_px are zero)
+    uint16_t *sx = sdy + (size_t)py_rows * YS;                 // [pp][XS]
+    uint16_t *ptab = sx + (size_t)pp * XS;                     // [py_rows] patch row of the pixel's top-left tap
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lp = lane & 31, lh = lane >> 5;
+    const int pair = wave % PAIRS, grp = wave / PAIRS;
+    const int ct = pair >> 1, it = pair & 1;
+    const int block = blockIdx.x / slots, slot = blockIdx.x % slots;
+    const int co0 = (block / ci_blocks) * CO, ci0 = (block % ci_blocks) * CI;
+
+    for (int q = threadIdx.x; q < py_rows; q += CD_THREADS) ptab[q] = q < n_px ? (uint16_t)((q / w) * pw + q % w) : 0;
+
+    const int tap0 = grp * TG, n_tap = grp ? 9 - TG : TG;      // this wave's taps (wave-uniform)
+    f32x16_t acc[TG];
+#pragma unroll
+    for (int t = 0; t < TG; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bsum = 0.f;
+
+    // staged pieces of this thread: first the dY rows (py_rows * 8 pieces), then the X patch (pp * 8 pieces)
+    const int y_chunks = py_rows * (CO / 8), n_chunks = y_chunks + pp * (CI / 8);
+    uint4 sreg[CDW_PCH];
+    auto fetch = [&](int job) {
+        const int img = job / strips, y0 = (job % strips) * rows;
+        const uint16_t *ysrc = dy + (int64_t)img * h * w * c_out + co0;
+        const uint16_t *xsrc = x + (int64_t)img * h * w * c_in + ci0;
+#pragma unroll
+        for (int q = 0; q < CDW_PCH; ++q) {
+            const int c = threadIdx.x + q * CD_THREADS;
+            // one unconditional load per piece from a clamped address, zero selected afterwards (no lane-masked loads: they cost a
+            // branch each and make the compiler wait for the data on the spot)
+            const bool is_y = c < y_chunks;
+            const int e = is_y ? c : min(c, n_chunks - 1) - y_chunks;
+            const int px = e >> 3, c8 = e & 7;
+            const int yy = is_y ? y0 + px / w : y0 - 1 + px / pw;
+            const int xx = is_y ? px % w : px % pw - 1;
+            const bool ok = c < n_chunks && (unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w && (!is_y || px < n_px);
+            const int64_t pos = (int64_t)min(max(yy, 0), h - 1) * w + min(max(xx, 0), w - 1);
+            const uint16_t *src = is_y ? ysrc + pos * c_out + c8 * 8 : xsrc + pos * c_in + c8 * 8;
+            uint4 v = *reinterpret_cast<const uint4 *>(src);
+            if (!ok) v = make_uint4(0, 0, 0, 0);
+            sreg[q] = v;
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int q = 0; q < CDW_PCH; ++q) {
+            const int c = threadIdx.x + q * CD_THREADS;
+            if (c >= n_chunks) continue;
+            uint2 *dst = c < y_chunks ? reinterpret_cast<uint2 *>(sdy + (c >> 3) * YS + (c & 7) * 8)
+                                      : reinterpret_cast<uint2 *>(sx + ((c - y_chunks) >> 3) * XS + ((c - y_chunks) & 7) * 8);
+            dst[0] = make_uint2(sreg[q].x, sreg[q].y);
+            dst[1] = make_uint2(sreg[q].z, sreg[q].w);
+        }
+    };
+
+    const int n_jobs = n_img * strips;
+    const int tg = lane >> 4, tl = lane & 15;
+    const int tr_row = (tg >> 1) * 8 + (tl >> 2), tr_col = (tg & 1) * 16 + (tl & 3) * 4;
+    int job = slot;
+    if (job < n_jobs) fetch(job);
+    while (job < n_jobs) {
+        __syncthreads();                                       // the previous strip's fragment reads are done
+        stage();
+        __syncthreads();
+        const int next = job + slots;
+        if (next < n_jobs) fetch(next);
+        job = next;
+        for (int s = 0; s < n_steps; ++s) {
+            const int r0 = s * 16 + tr_row;
+            const uint16_t *pa = sdy + r0 * YS + ct * 32 + tr_col;
+            cd_frag af;
+            af.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cd_s16x4 __attribute__((address_space(3))) *)pa);
+            af.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cd_s16x4 __attribute__((address_space(3))) *)(pa + 4 * YS));
+            if (it == 0 && grp == 0) {                         // bias gradient = column sums of dY: the fragment is at hand
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bsum += bf16_to_f32((uint16_t)af.h[j][q]);
+            }
+            const int p0 = ptab[r0], p1 = ptab[r0 + 4];
+            const uint16_t *pb0 = sx + p0 * XS + it * 32 + tr_col, *pb1 = sx + p1 * XS + it * 32 + tr_col;
+#pragma unroll
+            for (int t = 0; t < TG; ++t) {
+                if (t >= n_tap) continue;
+                const int tap = tap0 + t;
+                const int toff = ((tap / 3) * pw + tap % 3) * XS;
+                cd_frag bf;
+                bf.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cd_s16x4 __attribute__((address_space(3))) *)(pb0 + toff));
+                bf.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cd_s16x4 __attribute__((address_space(3))) *)(pb1 + toff));
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.v, bf.v, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    // slot of this workgroup: [CO][9][CI] then [CO] bias sums; D has lane = ci, register quads = co
+    float *mine = partial + (int64_t)blockIdx.x * (CO * 9 * CI + CO);
+#pragma unroll
+    for (int t = 0; t < TG; ++t)
+        if (t < n_tap)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                mine[((int64_t)co * 9 + tap0 + t) * CI + it * 32 + lp] = acc[t][r];
+            }
+    if (grp != 0) return;
+    bsum += __shfl_xor(bsum, 32, 64);                          // the two half-waves hold pixels 0-7 / 8-15 of the same channel
+    if (it == 0 && lh == 0) mine[CO * 9 * CI + ct * 32 + lp] = bsum;
+}
+
+// out[co][tap][ci] (full tensor) and db[co] from the per-workgroup slots: one thread per output element, its block's slots summed
+__global__ __launch_bounds__(256) void conv_wgrad_strip_reduce_kernel(const float *__restrict__ partial, int slots, int c_in, int c_out,
+                                                                      int ci_blocks, float *__restrict__ dw, float *__restrict__ db)
+{
+    constexpr int CO = 64, CI = 64, SLOT = CO * 9 * CI + CO;
+    const int64_t n_w = (int64_t)c_out * 9 * c_in;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < n_w) {
+        const int ci = (int)(e % c_in), tap = (int)((e / c_in) % 9), co = (int)(e / ((int64_t)9 * c_in));
+        const int block = (co / CO) * ci_blocks + ci / CI;
+        const float *src = partial + (int64_t)block * slots * SLOT + ((int64_t)(co % CO) * 9 + tap) * CI + ci % CI;
+        float s0 = 0.f, s1 = 0.f;
+        int p = 0;
+        for (; p + 2 <= slots; p += 2) {
+            s0 += src[(int64_t)p * SLOT];
+            s1 += src[(int64_t)(p + 1) * SLOT];
+        }
+        if (p < slots) s0 += src[(int64_t)p * SLOT];
+        dw[e] = s0 + s1;
+    } else if (e < n_w + c_out) {
+        const int co = (int)(e - n_w);
+        const float *src = partial + (int64_t)((co / CO) * ci_blocks) * slots * SLOT + CO * 9 * CI + co % CO;   // ci block 0 carries the bias sums
+        float s = 0.f;
+        for (int p = 0; p < slots; ++p) s += src[(int64_t)p * SLOT];
+        db[co] = s;
+    }
+}
+
+// strip height for the weight gradient: least padded work (strips x 16-pixel steps) among the heights whose staging fits
+static int conv_wgrad_strip_rows(int h, int w, size_t *lds_bytes)
+{
+    int best = 0;
+    int64_t best_cost = 0;
+    for (int rows = 1; rows <= h && rows * w <= CDW_MAXP; ++rows) {
+        const int pp = (rows + 2) * (w + 2), py_rows = (rows * w + 15) / 16 * 16;
+        const size_t lds = ((size_t)py_rows * 68 + (size_t)pp * 68 + py_rows) * sizeof(uint16_t);
+        if ((py_rows + pp) * 8 > CD_THREADS * CDW_PCH || lds > 150 * 1024) continue;
+        const int64_t cost = (int64_t)((h + rows - 1) / rows) * py_rows;
+        if (!best || cost <= best_cost) { best = rows; best_cost = cost; *lds_bytes = lds; }
+    }
+    return best;
+}
+
+static int conv_wgrad_strip_slots(int n_img, int strips, int blocks)
+{
+    int slots = (PCACC_CUS + blocks - 1) / blocks;             // one workgroup per CU (the staging LDS allows no more)
+    const int jobs = n_img * strips;
+    if (slots > jobs) slots = jobs;
+    return slots < 1 ? 1 : slots;
+}
+
+extern "C" int pcacc_conv3x3_wgrad_deep_supported(int32_t h, int32_t w, int32_t c_in, int32_t c_out)
+{
+    size_t lds;
+    return c_in >= 64 && c_out >= 64 && c_in % 64 == 0 && c_out % 64 == 0 && (c_in > 64 || c_out > 64) && h >= 1 && w >= 1 &&
+           conv_wgrad_strip_rows(h, w, &lds) >= 1;
+}
+
+extern "C" int pcacc_conv3x3_wgrad_deep_workspace_bytes(int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_out, size_t *bytes)
+{
+    size_t lds;
+    if (!bytes || n_img < 1 || !pcacc_conv3x3_wgrad_deep_supported(h, w, c_in, c_out)) return PCACC_E_ARG;
+    const int rows = conv_wgrad_strip_rows(h, w, &lds);
+    const int blocks = (c_out / 64) * (c_in / 64);
+    *bytes = (size_t)blocks * conv_wgrad_strip_slots(n_img, (h + rows - 1) / rows, blocks) * (64 * 9 * 64 + 64) * sizeof(float);
+    return 0;
+}
+
+extern "C" int pcacc_conv3x3_wgrad_deep_bf16(const uint16_t *dy, const uint16_t *x, float *dw, float *db, int32_t n_img, int32_t h,
+                                             int32_t w, int32_t c_in, int32_t c_out, void *workspace, size_t workspace_bytes,
+                                             void *stream)
+{
+    size_t lds = 0, need = 0;
+    if (!dy || !x || !dw || !db || !workspace || pcacc_conv3x3_wgrad_deep_workspace_bytes(n_img, h, w, c_in, c_out, &need) != 0)
+        return PCACC_E_ARG;
+    if (workspace_bytes < need) return PCACC_E_WORKSPACE;
+    hipStream_t st = pcacc_stream(stream);
+    const int rows = conv_wgrad_strip_rows(h, w, &lds);
+    const int strips = (h + rows - 1) / rows, ci_blocks = c_in / 64, blocks = (c_out / 64) * ci_blocks;
+    const int slots = conv_wgrad_strip_slots(n_img, strips, blocks);
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_wgrad_strip_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+        return PCACC_E_LAUNCH;
+    float *partial = static_cast<float *>(workspace);
+    hipLaunchKernelGGL(conv3x3_wgrad_strip_kernel, dim3(blocks * slots), dim3(CD_THREADS), lds, st, dy, x, partial, n_img, h, w, c_in, c_out,
+                       rows, strips, ci_blocks, slots);
+    const int64_t elems = (int64_t)c_out * 9 * c_in + c_out;
+    hipLaunchKernelGGL(conv_wgrad_strip_reduce_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, partial, slots, c_in, c_out,
+                       ci_blocks, dw, db);
+    PCACC_CHECK_LAUNCH();
+    return 0;
 }

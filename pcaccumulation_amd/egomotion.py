@@ -126,8 +126,19 @@ class EgoMotionHead(nn.Module):
         #              1.8 ms each on the host, 32 of them per 4-sequence step).
         self.kpt_sampler = pe.get('kpt_sampler', 'reference')
         self.seq_pose = pe['seq_pose']
-        if self.seq_pose != 'skip':
-            raise NotImplementedError("pose_estimation.seq_pose='%s': only 'skip' (configs/default.yaml:83) is built" % self.seq_pose)
+        if self.seq_pose not in ('skip', 'chain', 'full'):
+            raise NotImplementedError("pose_estimation.seq_pose='%s' (models/egomotion.py:53-61 knows skip / chain / full)" % self.seq_pose)
+
+    def _pair_plan(self, T):
+        """(source frame, target frame, duration) of every registration of one sequence, in the order the reference runs them:
+        skip  (models/egomotion.py:309-357): every frame t >= 1 against the anchor frame 0;
+        chain (:255-307): frame t + 1 against frame t;
+        full  (:195-252): every pair (anchor, anchor + gap), gap-major."""
+        if self.seq_pose == 'skip':
+            return [(t, 0, t / self.frequence) for t in range(1, T)]
+        if self.seq_pose == 'chain':
+            return [(t + 1, t, 1.0 / self.frequence) for t in range(T - 1)]
+        return [(a + gap, a, gap / self.frequence) for gap in range(1, T) for a in range(T - 1) if a + gap < T]
 
     def sinkhorn(self, log_alpha, n_iters=5, slack=True):
         """models/egomotion.py:100-137: slack row/column padded with zeros, never normalised themselves."""
@@ -173,9 +184,24 @@ class EgoMotionHead(nn.Module):
                                relative_pose_est_list, relative_pose_gt_list, chained_pose_est_list, chained_pose_gt_list):
         """models/egomotion.py:309-357 for ONE batch element: every frame t >= 1 is registered against the anchor
         frame 0.  Kept with the reference's signature; it runs the batched estimator on this element's pairs."""
-        seq = self._sequence_from_masks(points_list, feats_list, bg_mask_list, c_ego_motion_gt)
-        return self._estimate_pairs([seq], T, perm_matrix_list, relative_pose_est_list, relative_pose_gt_list,
-                                    chained_pose_est_list, chained_pose_gt_list)
+        return self._sequence_pose_est('skip', points_list, feats_list, bg_mask_list, c_ego_motion_gt, T, perm_matrix_list,
+                                       relative_pose_est_list, relative_pose_gt_list, chained_pose_est_list, chained_pose_gt_list)
+
+    def sequence_pose_est_chain(self, *args):
+        """models/egomotion.py:255-307: frame t + 1 against frame t, poses chained."""
+        return self._sequence_pose_est('chain', *args)
+
+    def sequence_pose_est_full(self, *args):
+        """models/egomotion.py:195-252: all pairs; the pairs against frame 0 give the sequence poses."""
+        return self._sequence_pose_est('full', *args)
+
+    def _sequence_pose_est(self, mode, points_list, feats_list, bg_mask_list, c_ego_motion_gt, T, *lists):
+        keep, self.seq_pose = self.seq_pose, mode
+        try:
+            seq = self._sequence_from_masks(points_list, feats_list, bg_mask_list, c_ego_motion_gt)
+            return self._estimate_pairs([seq], T, *lists)
+        finally:
+            self.seq_pose = keep
 
     @staticmethod
     def _sequence_from_masks(points_list, feats_list, bg_mask_list, gt):
@@ -198,30 +224,30 @@ class EgoMotionHead(nn.Module):
           points_list[t] = xyz of all occupied pillars, feats_list[t] = callable(idx)-> features of pillars `idx` of frame t,
           bg_list[t] = (bg_idx LongTensor into the frame's pillar list, n_bg int)."""
         dev = sequences[0][0][0].device
+        plan = self._pair_plan(T)
         fs, cs, ft, ct, durations = [], [], [], [], []
         drawn, d = None, 0
         if self.kpt_sampler == 'device' and dev.type == 'cuda':
             # every key-point draw of the step in one launch (source, then target, per pair -- the reference's order)
-            counts = [n for _, _, bg_list, _ in sequences for f in range(T - 1) for n in (bg_list[f + 1][1], bg_list[0][1])]
+            counts = [n for _, _, bg_list, _ in sequences for src, tgt, _ in plan for n in (bg_list[src][1], bg_list[tgt][1])]
             seed = int(torch.empty((), dtype=torch.int64).random_())       # host generator: follows torch.manual_seed
             drawn = native.sample_subsets(native.upload_small(counts, torch.int32, dev), self.ego_n_points, seed)
         if drawn is not None and flat is not None:
             # pillar-level inputs + device sampler: the key points of all pairs in five gathers.  Entry e = (pair, source | target)
             # draws positions in the background list of its frame; bg_sorted_idx holds positions in the cell-ordered pillar list.
-            frames = [f for b in range(len(sequences)) for t in range(1, T) for f in (b * T + t, b * T)]
+            frames = [f for b in range(len(sequences)) for src, tgt, _ in plan for f in (b * T + src, b * T + tgt)]
             offs = native.upload_small([flat['bg_at'][f] for f in frames], torch.int64, dev)
             pillar = flat['sp'][flat['bg_sorted_idx'][offs[:, None] + drawn.long()]]              # [2P,k] pillar ids
             coor = flat['pillar_mean'][pillar]                                                    # [2P,k,3]
             feats = flat['geo_rows'][flat['cells'][pillar]].float()                               # [2P,k,C], one index op
             feats_s, feats_t, coor_s, coor_t = feats[0::2], feats[1::2], coor[0::2], coor[1::2]
-            durations = [(frame_idx + 1) / self.frequence for _ in sequences for frame_idx in range(T - 1)]
+            durations = [dur for _ in sequences for _, _, dur in plan]
             sequences_loop = []
         else:
             sequences_loop = sequences
         for points_list, feats_list, bg_list, _ in sequences_loop:
-            a_idx, a_n = bg_list[0]
-            for frame_idx in range(T - 1):
-                ref = frame_idx + 1
+            for ref, anchor, dur in plan:
+                a_idx, a_n = bg_list[anchor]
                 r_idx, r_n = bg_list[ref]
                 if drawn is not None:
                     choice_s, choice_t = drawn[d], drawn[d + 1]
@@ -231,8 +257,8 @@ class EgoMotionHead(nn.Module):
                     choice_t = self._choice(a_n, dev).to(dev)
                 si, ti = r_idx[choice_s], a_idx[choice_t]                   # key-point pillars (indices into the frame lists)
                 fs.append(feats_list[ref](si)); cs.append(points_list[ref][si])
-                ft.append(feats_list[0](ti)); ct.append(points_list[0][ti])
-                durations.append((frame_idx + 1) / self.frequence)
+                ft.append(feats_list[anchor](ti)); ct.append(points_list[anchor][ti])
+                durations.append(dur)
         if sequences_loop:
             feats_s, feats_t = _stack_rows(fs).float(), _stack_rows(ft).float()  # [P,k,C]
             coor_s, coor_t = torch.stack(cs), torch.stack(ct)                    # [P,k,3]
@@ -268,6 +294,9 @@ class EgoMotionHead(nn.Module):
     def _collect_pairs(self, sequences, T, perm, pose_est, perm_matrix_list, relative_pose_est_list, relative_pose_gt_list,
                        chained_pose_est_list, chained_pose_gt_list):
         """Per-pair bookkeeping of sequence_pose_est_skip (models/egomotion.py:334-355): GT poses, losses, pose lists."""
+        if self.seq_pose != 'skip':
+            return self._collect_pairs_general(sequences, T, perm, pose_est, perm_matrix_list, relative_pose_est_list,
+                                               relative_pose_gt_list, chained_pose_est_list, chained_pose_gt_list)
         dev = pose_est.device
         P = pose_est.shape[0]
         identity = torch.eye(4, device=dev)
@@ -299,6 +328,51 @@ class EgoMotionHead(nn.Module):
         # indexed-transform launch: x -> (R_est - R_gt) x + (t_est - t_gt).  The reference's per-pair matmul has a
         # [3, n] x [n, 3] product in its backward (0.23 ms each on MI355X, 16 per step); here the gradient of the pose
         # table is a segment sum.
+        pts = torch.cat(ref_pts, dim=0)
+        pair = torch.repeat_interleave(torch.arange(P, device=dev), native.upload_small(lens, torch.int64, dev), output_size=pts.shape[0])
+        diff = ops.transform_by_index(pts, pair, pose_est - pose_gt_all.reshape(P, 4, 4).to(pose_est.dtype))
+        norms = torch.stack((torch.norm(diff, p=1, dim=1), torch.norm(diff, p=2, dim=1)), dim=1)
+        means = ops.scatter(norms, pair, dim=0, dim_size=P, reduce="mean", plan=ops.ScatterPlan(pair, P))
+        return means[:, 0].sum(), means[:, 1].sum(), P
+
+    def _collect_pairs_general(self, sequences, T, perm, pose_est, perm_matrix_list, relative_pose_est_list, relative_pose_gt_list,
+                               chained_pose_est_list, chained_pose_gt_list):
+        """The bookkeeping of sequence_pose_est_chain (models/egomotion.py:255-307) and sequence_pose_est_full (:195-252) on the
+        batched solve: ground-truth poses of every pair, the chained / relative pose lists, the point-wise L1 / L2 losses over all
+        pillars of each pair's source frame."""
+        dev = pose_est.device
+        plan = self._pair_plan(T)
+        n_pairs, B = len(plan), len(sequences)
+        P = pose_est.shape[0]
+        identity = torch.eye(4, device=dev)
+        src = torch.tensor([p[0] for p in plan], device=dev)
+        tgt = torch.tensor([p[1] for p in plan], device=dev)
+        gt_all = torch.stack([seq[3] for seq in sequences])                                     # [B,T,4,4]
+        pose_gt_all = get_relative_pose_torch(gt_all[:, src], gt_all[:, tgt], self.dataset)     # [B,n_pairs,4,4]
+        to_anchor_gt = get_relative_pose_torch(gt_all[:, 1:], gt_all[:, 0:1].expand(B, T - 1, 4, 4), self.dataset)
+        rel_gt = get_relative_pose_torch(gt_all[:, 1:], gt_all[:, :-1], self.dataset)
+        ref_pts, lens = [], []
+        for b, (points_list, feats_list, bg_list, gt) in enumerate(sequences):
+            for lst in (relative_pose_est_list, relative_pose_gt_list, chained_pose_est_list, chained_pose_gt_list):
+                lst.append(identity)
+            chained = identity
+            for j, (s, a, _) in enumerate(plan):
+                p = b * n_pairs + j
+                ref_pts.append(points_list[s])
+                lens.append(points_list[s].shape[0])
+                if self.seq_pose == 'chain':
+                    perm_matrix_list.append(perm[p:p + 1])
+                    relative_pose_est_list.append(pose_est[p])
+                    chained = chained @ pose_est[p]
+                    chained_pose_est_list.append(chained)
+                    relative_pose_gt_list.append(pose_gt_all[b, j])
+                    chained_pose_gt_list.append(to_anchor_gt[b, s - 1])
+                elif a == 0:                                                # 'full': the pairs against frame 0 carry the sequence pose
+                    chained_pose_est_list.append(pose_est[p])
+                    chained_pose_gt_list.append(pose_gt_all[b, j])
+                    relative_pose_gt_list.append(rel_gt[b, s - 1])
+                    relative_pose_est_list.append(get_relative_pose_torch(chained_pose_est_list[-1], chained_pose_est_list[-2], self.dataset))
+                    perm_matrix_list.append(perm[p:p + 1])
         pts = torch.cat(ref_pts, dim=0)
         pair = torch.repeat_interleave(torch.arange(P, device=dev), native.upload_small(lens, torch.int64, dev), output_size=pts.shape[0])
         diff = ops.transform_by_index(pts, pair, pose_est - pose_gt_all.reshape(P, 4, 4).to(pose_est.dtype))

@@ -54,7 +54,8 @@ EXPORTS = [
     'pcacc_offset_loss_workspace_bytes', 'pcacc_offset_loss_forward', 'pcacc_offset_loss_backward',
     'pcacc_frames_max', 'pcacc_frames_max_backward', 'pcacc_rows_linear_cat_bf16', 'pcacc_rows_wgrad_cat_bf16',
     'pcacc_pillar_scatter_timed', 'pcacc_pillar_scatter_t', 'pcacc_timer_create', 'pcacc_timer_elapsed_us', 'pcacc_timer_destroy',
-    'pcacc_svd3', 'pcacc_svd3_backward', 'pcacc_conv3x3_deep_supported', 'pcacc_conv3x3_deep_bf16', 'pcacc_bn_rows_workspace_bytes', 'pcacc_bn_rows_forward', 'pcacc_bn_rows_backward',
+    'pcacc_svd3', 'pcacc_svd3_backward', 'pcacc_conv3x3_deep_supported', 'pcacc_conv3x3_deep_bf16',
+    'pcacc_conv3x3_wgrad_deep_supported', 'pcacc_conv3x3_wgrad_deep_workspace_bytes', 'pcacc_conv3x3_wgrad_deep_bf16', 'pcacc_bn_rows_workspace_bytes', 'pcacc_bn_rows_forward', 'pcacc_bn_rows_backward',
 ]
 
 
@@ -522,6 +523,26 @@ def conv3x3_wgrad(dy_rows, x_rows, frames=1, dt=0):
                                           int(frames), int(dt), int(h), int(w), int(c_in), int(c_out), _dev(ws),
                                           ctypes.c_size_t(ws.numel()), _stream()), 'conv3x3_wgrad')
     return dw[:c_out * 9 * c_in].view(c_out, 9, c_in), dw[c_out * 9 * c_in:]
+
+
+def conv3x3_wgrad_deep_supported(h, w, c_in, c_out):
+    return bool(lib().pcacc_conv3x3_wgrad_deep_supported(int(h), int(w), int(c_in), int(c_out)))
+
+
+def conv3x3_wgrad_deep(dy_rows, x_rows):
+    """dy_rows [n_img,h,w,c_out], x_rows [n_img,h,w,c_in] bf16 -> (dw [c_out, 9, c_in] f32, db [c_out] f32); csrc/conv_deep.hip."""
+    n_img, h, w, c_out = dy_rows.shape
+    c_in = x_rows.shape[3]
+    dw = torch.empty((c_out, 9, c_in), dtype=torch.float32, device=dy_rows.device)
+    db = torch.empty((c_out,), dtype=torch.float32, device=dy_rows.device)
+    need = ctypes.c_size_t(0)
+    _check(lib().pcacc_conv3x3_wgrad_deep_workspace_bytes(int(n_img), int(h), int(w), int(c_in), int(c_out), ctypes.byref(need)),
+           'conv3x3_wgrad_deep_workspace')
+    ws = _ws(need.value, dy_rows.device)
+    _check(lib().pcacc_conv3x3_wgrad_deep_bf16(_dev(dy_rows, torch.bfloat16, 'dy'), _dev(x_rows, torch.bfloat16, 'x'), _dev(dw), _dev(db),
+                                               int(n_img), int(h), int(w), int(c_in), int(c_out), _dev(ws), ctypes.c_size_t(ws.numel()),
+                                               _stream()), 'conv3x3_wgrad_deep')
+    return dw, db
 
 
 def upload_small(values, dtype, device):

@@ -509,6 +509,11 @@ class _Conv3x3(torch.autograd.Function):
             gw = gw.to(weight.dtype)
             gb = gb.clone() if has_bias and ctx.needs_input_grad[2] else None
             need_w = False
+        elif need_w and kt == 1 and native.conv3x3_wgrad_deep_supported(x_rows.shape[1], x_rows.shape[2], i, o):
+            gw, gb = native.conv3x3_wgrad_deep(gy, x_rows)                                 # deep layers: 64 x 64 weight blocks, strips
+            gw = gw.view(o, 3, 3, i).permute(0, 3, 1, 2).to(weight.dtype)
+            gb = gb if has_bias and ctx.needs_input_grad[2] else None
+            need_w = False
         if need_w or lib_dgrad:
             xin = _stack_frames(x_rows, frames) if kt == 3 else x_rows
             w2 = weight.detach().permute(0, 2, 1, 3, 4).reshape(o, 3 * i, 3, 3) if kt == 3 else weight.detach()

@@ -57,3 +57,29 @@ def raw_sample(seed, n_frames, ppf, cfg):
     return {'raw_points': pts, 'time_indice': s['time_indice'][:, 0].astype(np.float64), 'sd_labels': s['sd_labels'][:, 0],
             'fb_labels': s['fb_labels'][:, 0], 'inst_labels': s['inst_labels'][:, 0], 'ego_motion_gt': s['ego_motion_gt'].astype(np.float64),
             'inst_motion_gt': s['inst_motion_gt'].astype(np.float64)}
+
+
+def flow_error_scenes(root, n_scenes=3, seed=0):
+    """A results folder as SegTrainer.test leaves it (libs/tester.py:95-107): <root>/<scene>/flow_error.npz with the reference's
+    keys and narrow dtypes; errors spread around the 0.05 / 0.1 / 0.3 thresholds; the last scene has no moving point and no
+    static foreground, and stores its frame index run-length coded ('length', toolbox/evaluation.py:37-46)."""
+    import os
+    rng = np.random.RandomState(seed)
+    for s in range(n_scenes):
+        n = 4000 + 777 * s
+        t = np.sort(rng.randint(1, 5, n)).astype(np.int8)
+        fb = rng.rand(n) < 0.2
+        sd = fb & (rng.rand(n) < 0.5)
+        if s == n_scenes - 1:
+            fb[:] = False
+            sd[:] = False
+        epe = np.abs(rng.randn(n) * 0.15).astype(np.float16)
+        rel = np.abs(rng.randn(n) * 0.2).astype(np.float16)
+        d = os.path.join(root, 'scene_%03d' % s)
+        os.makedirs(d, exist_ok=True)
+        if s == n_scenes - 1:
+            vals, counts = np.unique(t, return_counts=True)
+            np.savez_compressed(os.path.join(d, 'flow_error'), fb_label=fb, sd_label=sd, epe_per_point=epe, relative_error=rel,
+                                time_indice=vals.astype(np.int8), length=counts.astype(np.int64))
+        else:
+            np.savez_compressed(os.path.join(d, 'flow_error'), fb_label=fb, sd_label=sd, epe_per_point=epe, relative_error=rel, time_indice=t)

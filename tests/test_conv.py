@@ -154,3 +154,20 @@ def test_conv3x3_backward_deep(n, h, w, ci, co):
     _close(x.grad, xr.grad, xr.grad.abs().max().item())
     assert (wt.grad - wr.grad).abs().max().item() <= 2e-2 * wr.grad.abs().max().item()
     assert (bias.grad - br.grad).abs().max().item() <= 2e-2 * br.grad.abs().max().item()
+
+
+@pytest.mark.parametrize('n,h,w,ci,co', [(3, 18, 18, 256, 128), (2, 36, 36, 128, 256), (1, 72, 72, 128, 128), (5, 18, 18, 512, 512),
+                                         (2, 20, 144, 128, 64), (1, 19, 37, 64, 192), (2, 7, 5, 128, 128)])
+def test_conv3x3_wgrad_deep_kernel(n, h, w, ci, co):
+    """pcacc_conv3x3_wgrad_deep_bf16 against the library's weight gradient on the same bf16 tensors (fp32 sums, different order)."""
+    g = torch.Generator(device='cpu').manual_seed(ci + 2 * co + n)
+    x = torch.randn(n, h, w, ci, generator=g).to(DEV).to(torch.bfloat16)
+    gy = torch.randn(n, h, w, co, generator=g).to(DEV).to(torch.bfloat16)
+    assert native.conv3x3_wgrad_deep_supported(h, w, ci, co)
+    dw, db = native.conv3x3_wgrad_deep(gy, x)
+    dw = dw.view(co, 3, 3, ci).permute(0, 3, 1, 2)
+    wr = torch.zeros(co, ci, 3, 3, device=DEV, requires_grad=True)
+    F.conv2d(x.float().permute(0, 3, 1, 2), wr, None, padding=1).backward(gy.float().permute(0, 3, 1, 2))
+    assert (dw - wr.grad).abs().max().item() <= 2e-3 * wr.grad.abs().max().item()
+    ref_b = gy.float().sum(dim=(0, 1, 2))
+    assert (db - ref_b).abs().max().item() <= 1e-3 * max(1.0, ref_b.abs().max().item())

@@ -70,3 +70,64 @@ def test_flow_errors_cpu(golden, monkeypatch, tmp_path):
 @pytest.mark.gpu
 def test_flow_errors_gpu(golden):
     _check(golden, torch.device('cuda:0'))
+
+
+def _flat_meters(meters, prefix=''):
+    out = {}
+    for k, v in meters.items():
+        if isinstance(v, dict):
+            out.update(_flat_meters(v, prefix + k + '/'))
+        else:
+            out[prefix + k] = [float(v.avg), float(v.sum), int(v.count)]
+    return out
+
+
+def _collect(golden, tmp_path, dev):
+    """collect_results (toolbox/evaluation.py:20-98) against the reference's own run on the same three synthetic scenes
+    (tests/golden/make_golden_collect.py): running meters, per-scene dictionaries, sampled dynamic errors, the three files."""
+    import json
+    import pickle
+    from helpers import flow_error_scenes
+    from pcaccumulation_amd.evaluation import collect_results
+    g = golden('collect')
+    src, dst = str(tmp_path / 'results'), str(tmp_path / 'metrics')
+    flow_error_scenes(src)
+    meters, scenes = collect_results(src, dst, 'waymo', device=dev)
+    want = json.loads(str(g['static']))
+    got = _flat_meters(meters)
+    assert set(got) == set(want)
+    for k, (avg, total, count) in want.items():
+        assert got[k][2] == count, k
+        assert abs(got[k][0] - avg) <= 1e-6 * max(1.0, abs(avg)) and abs(got[k][1] - total) <= 1e-6 * max(1.0, abs(total)), k
+    ws = json.loads(str(g['scene']))
+    assert set(scenes) == set(ws)
+
+    def same(a, b, path):
+        if isinstance(b, dict):
+            assert set(a) == set(b), path
+            for k in b:
+                same(a[k], b[k], path + '/' + k)
+        elif isinstance(b, list):
+            same(a[0], b[0], path)
+            assert a[1] == b[1], path
+        elif b != b:                                           # an empty selection: the mean of nothing is NaN in the reference too
+            assert a != a, path
+        else:
+            assert abs(a - b) <= 1e-6 * max(1.0, abs(b)), path
+    same(scenes, ws, '')
+    dyn = torch.load(str(tmp_path / 'metrics' / 'dynamic_dict.pth'))
+    assert dyn['relative_error'].dtype == torch.float32
+    assert np.array_equal(np.sort(dyn['relative_error'].numpy()), g['dyn_rel_sorted'])
+    assert np.array_equal(np.sort(dyn['epe_per_point'].numpy()), g['dyn_epe_sorted'])
+    static = pickle.load(open(str(tmp_path / 'metrics' / 'static_stats.pkl'), 'rb'))
+    assert abs(static['static_BG']['EPE3D'].avg - want['static_BG/EPE3D'][0]) < 1e-6            # what toolbox/evaluation.py:113 prints
+    assert 'static_FG' in static and 'Dynamic' not in pickle.load(open(str(tmp_path / 'metrics' / 'scene_stats.pkl'), 'rb'))['scene_002']
+
+
+def test_collect_results_cpu(golden, tmp_path):
+    _collect(golden, tmp_path, 'cpu')
+
+
+@pytest.mark.gpu
+def test_collect_results_gpu(golden, tmp_path):
+    _collect(golden, tmp_path, 'cuda:0')

@@ -422,3 +422,39 @@ def test_gpu_library_conv_find_mode_is_the_same_step():
     for k in g0:                                   # bf16 sums in another order, and a few ReLU / arg-max decisions downstream of them
         cos = torch.nn.functional.cosine_similarity(g1[k].reshape(-1), g0[k].reshape(-1), dim=0)
         assert cos > 0.98, (k, float(cos))
+
+
+def _seq_pose(dev, golden, mode):
+    """pose_estimation.seq_pose = chain / full (models/egomotion.py:195-307) on the tiny validation scene against the reference."""
+    g, gs = golden('model_tiny_val'), golden('seqpose')
+    cfg = default_config('waymo', 'val', n_sweeps=3, xy_range=8)
+    cfg['pose_estimation']['seq_pose'] = mode
+    model, inp = _build(g, cfg, dev, train=False)
+    loss_fn = FuseLoss(cfg['loss'])
+    torch.manual_seed(int(g['fwd_seed']))
+    with torch.no_grad():
+        out = model(inp)
+        stats = loss_fn(out, inp)
+    c = lambda t: t.detach().float().cpu().numpy()
+    np.testing.assert_allclose(c(out['ego_motion_est']), gs[mode + '_ego_motion_est'], atol=5e-3)
+    np.testing.assert_allclose(c(out['ego_motion_gt']), gs[mode + '_ego_motion_gt'], atol=1e-5)
+    assert abs(out['ego_rot_error'] - float(gs[mode + '_ego_rot_error'])) < 1e-3
+    assert abs(out['ego_trans_error'] - float(gs[mode + '_ego_trans_error'])) < 1e-3
+    assert abs(float(out['ego_l1_loss']) - float(gs[mode + '_ego_l1_loss'])) < 1e-3 * max(1.0, float(gs[mode + '_ego_l1_loss']))
+    assert abs(float(out['ego_l2_loss']) - float(gs[mode + '_ego_l2_loss'])) < 1e-3 * max(1.0, float(gs[mode + '_ego_l2_loss']))
+    assert len(out['perm_matrix']) == int(gs[mode + '_n_perm'])
+    np.testing.assert_allclose(np.stack([c(p.sum(2)[0]) for p in out['perm_matrix']]), gs[mode + '_perm_rowsum'], atol=5e-3)
+    assert abs(float(stats['perm_loss']) - float(gs[mode + '_perm_loss'])) < 1e-3 * max(1.0, abs(float(gs[mode + '_perm_loss'])))
+    i, u = stats['mos_metric']['intersection'], stats['mos_metric']['union']
+    assert abs(float((i / (u + 1e-20)).mean()) - float(gs[mode + '_mos_iou'])) < 1e-3
+
+
+@pytest.mark.parametrize('mode', ['chain', 'full'])
+def test_host_logic_seq_pose_modes(double, golden, mode):
+    _seq_pose(double, golden, mode)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['chain', 'full'])
+def test_gpu_seq_pose_modes(golden, mode):
+    _seq_pose(torch.device('cuda:0'), golden, mode)

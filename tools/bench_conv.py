@@ -39,7 +39,10 @@ def main():
         ('unet up 64->32 @288', B * T, 1, 288, 288, 64, 32, 1), ('ego head 32->64 @288', B * T, 1, 288, 288, 32, 64, 1),
         ('ego head 64->64 @288', B * T, 1, 288, 288, 64, 64, 1), ('stpn temporal 3x32->32 @288', B * T, T, 288, 288, 32, 32, 3),
         ('stpn 32->64 @288', B, 1, 288, 288, 32, 64, 1), ('stpn 64->64 @288', B, 1, 288, 288, 64, 64, 1),
-        ('stpn up 128->64 @288', B, 1, 288, 288, 128, 64, 1), ('stpn 256->128 @72', B, 1, 72, 72, 256, 128, 1)]
+        ('stpn up 128->64 @288', B, 1, 288, 288, 128, 64, 1), ('stpn 256->128 @72', B, 1, 72, 72, 256, 128, 1),
+        ('unet up 512->256 @36', B * T, 1, 36, 36, 512, 256, 1), ('unet up 256->128 @72', B * T, 1, 72, 72, 256, 128, 1),
+        ('unet up 128->64 @144', B * T, 1, 144, 144, 128, 64, 1), ('unet 256->512 @18', B * T, 1, 18, 18, 256, 512, 1),
+        ('stpn 128->128 @36', B, 1, 36, 36, 128, 128, 1), ('stpn 256->256 @18', B, 1, 18, 18, 256, 256, 1)]
     for name, n, frames, h, w, ci, co, kt in shapes:
         x = torch.randn(n, h, w, ci, device=dev).to(torch.bfloat16)
         wshape = (co, ci, 3, 3, 3) if kt == 3 else (co, ci, 3, 3)
@@ -60,6 +63,14 @@ def main():
                 w2 = wt.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
                 t_l = timeit(lambda: torch.relu_(F.conv2d(xs, w2, bias.to(torch.bfloat16), padding=1)))
             row['lib_us'] = round(t_l, 1)
+        if kt == 1 and native.conv3x3_wgrad_deep_supported(h, w, ci, co):
+            gy = torch.randn(n, h, w, co, device=dev).to(torch.bfloat16)
+            row['wgrad_us'] = round(timeit(lambda: native.conv3x3_wgrad_deep(gy, x)), 1)
+            row['wgrad_TFLOPs'] = round(flops / row['wgrad_us'] / 1e6, 1)
+            if a.lib:
+                w2 = wt.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+                row['lib_wgrad_us'] = round(timeit(lambda: torch.ops.aten.convolution_backward(
+                    gy.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2), w2, [co], [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, True])), 1)
         print(json.dumps(row), flush=True)
 
 
