@@ -347,6 +347,10 @@ int pcacc_cluster(const float *points, const float *offset, const uint8_t *sel, 
  * ---------------------------------------------------------------------------------------------- */
 int pcacc_conv3x3_prepare_weights(const float *w, int32_t c_out, int32_t c_in, int32_t kt, int32_t transpose,
                                   uint16_t *out, void *stream);
+/* Both prepared forms of one weight tensor in one launch (out_fwd = transpose 0, out_bwd = transpose 1 of the entry point above), the fp32
+ * weight read through `strides` (host array, in elements: o, i, [t,] y, x -- contiguous or channels-last storage). */
+int pcacc_conv3x3_prepare_weights_pair(const float *w, int32_t c_out, int32_t c_in, int32_t kt, const int64_t *strides /*host*/,
+                                       uint16_t *out_fwd, uint16_t *out_bwd, void *stream);
 int pcacc_conv3x3_bf16(const uint16_t *in, const uint16_t *wp, const float *bias, uint16_t *out, int32_t n_img,
                        int32_t frames, int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t kt, int32_t relu,
                        void *stream);
@@ -359,15 +363,24 @@ int pcacc_conv3x3_bf16(const uint16_t *in, const uint16_t *wp, const float *bias
  * input patch resident in LDS per channel slice, weight tiles double buffered.  pcacc_conv3x3_bf16 routes such shapes here itself;
  * pcacc_conv3x3_deep_supported tells whether a shape qualifies (1) or not (0). */
 int pcacc_conv3x3_deep_supported(int32_t h, int32_t w, int32_t c_in, int32_t c_out);
-int pcacc_conv3x3_deep_bf16(const uint16_t *in, const uint16_t *wp, const float *bias, uint16_t *out, int32_t n_img, int32_t h,
-                            int32_t w, int32_t c_in, int32_t c_out, int32_t relu, void *stream);
+int pcacc_conv3x3_deep_bf16(const uint16_t *in, const uint16_t *in_mask, const uint16_t *wp, const float *bias, uint16_t *out, int32_t n_img,
+                            int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t relu, void *stream);
+/* ReLU backward fused into the consumers of the gradient: `in_mask` / `dy_mask` (NULL = none) is the forward OUTPUT of the ReLU layer
+ * whose gradient `in` / `dy` is, same shape; elements where it is not > 0 are read as zero (aten::threshold_backward on the fly, no
+ * separate pass over the gradient map). */
+int pcacc_conv3x3_masked_bf16(const uint16_t *in, const uint16_t *in_mask, const uint16_t *wp, const float *bias, uint16_t *out,
+                              int32_t n_img, int32_t frames, int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t kt,
+                              int32_t relu, void *stream);
+int pcacc_conv3x3_wgrad_masked_bf16(const uint16_t *dy, const uint16_t *dy_mask, const uint16_t *x, float *dw, int32_t n_img,
+                                    int32_t frames, int32_t dt, int32_t h, int32_t w, int32_t c_in, int32_t c_out, void *workspace,
+                                    size_t workspace_bytes, void *stream);
 /* Weight gradient of the same deep layers (c_in, c_out multiples of 64, at least one of them > 64; kt = 1): dw [c_out][9][c_in] f32 and
  * db [c_out] f32 = bias gradient, from dy [n_img,h,w,c_out] and x [n_img,h,w,c_in] (bf16, channels-last).  64 x 64 blocks of the weight
  * tensor per workgroup, strips of consecutive pixels, per-workgroup partial slots in the workspace + a reduce launch. */
 int pcacc_conv3x3_wgrad_deep_supported(int32_t h, int32_t w, int32_t c_in, int32_t c_out);
 int pcacc_conv3x3_wgrad_deep_workspace_bytes(int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_out, size_t *bytes /*host*/);
-int pcacc_conv3x3_wgrad_deep_bf16(const uint16_t *dy, const uint16_t *x, float *dw, float *db, int32_t n_img, int32_t h, int32_t w,
-                                  int32_t c_in, int32_t c_out, void *workspace, size_t workspace_bytes, void *stream);
+int pcacc_conv3x3_wgrad_deep_bf16(const uint16_t *dy, const uint16_t *dy_mask, const uint16_t *x, float *dw, float *db, int32_t n_img,
+                                  int32_t h, int32_t w, int32_t c_in, int32_t c_out, void *workspace, size_t workspace_bytes, void *stream);
 int pcacc_conv3x3_wgrad_workspace_bytes(int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_out, size_t *bytes /*host*/);
 int pcacc_conv3x3_wgrad_bf16(const uint16_t *dy, const uint16_t *x, float *dw, int32_t n_img, int32_t frames, int32_t dt,
                              int32_t h, int32_t w, int32_t c_in, int32_t c_out, void *workspace, size_t workspace_bytes,

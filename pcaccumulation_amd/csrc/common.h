@@ -62,6 +62,19 @@ __device__ __forceinline__ void pcacc_st4(void *p, bool bf16, int64_t i4, float4
     else reinterpret_cast<uint2 *>(p)[i4] = make_uint2(pcacc_pack_bf16x2(v.x, v.y), pcacc_pack_bf16x2(v.z, v.w));
 }
 
+// ReLU backward on the fly: eight packed bf16 gradients, zeroed where the forward output y (same positions) is not > 0 -- what
+// aten::threshold_backward(grad, y, 0) computes, fused into the staging of the kernels that consume the gradient.
+__device__ __forceinline__ uint32_t pcacc_relu_mask2(uint32_t g, uint32_t y)
+{
+    const uint32_t lo = ((int32_t)(y << 16) > 0) ? 0x0000ffffu : 0u;
+    const uint32_t hi = ((int32_t)(y & 0xffff0000u) > 0) ? 0xffff0000u : 0u;
+    return g & (lo | hi);
+}
+__device__ __forceinline__ uint4 pcacc_relu_mask8(uint4 g, uint4 y)
+{
+    return make_uint4(pcacc_relu_mask2(g.x, y.x), pcacc_relu_mask2(g.y, y.y), pcacc_relu_mask2(g.z, y.z), pcacc_relu_mask2(g.w, y.w));
+}
+
 // ---- wave64 / block scans ------------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 

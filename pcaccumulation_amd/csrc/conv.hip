@@ -51,6 +51,42 @@ extern "C" int pcacc_conv3x3_prepare_weights(const float *w, int32_t c_out, int3
     return 0;
 }
 
+// Both prepared forms (forward, and mirrored / transposed for the data gradient) of one fp32 weight tensor in ONE launch, read through its
+// strides (contiguous or channels-last storage alike): a training step needs both, and the weight only changes at the optimizer step.
+struct ConvWStrides { int64_t o, i, t, y, x; };
+
+__global__ __launch_bounds__(256) void conv_prepare_weights_pair_kernel(const float *__restrict__ w, int o, int i, int kt, ConvWStrides st,
+                                                                        uint16_t *__restrict__ out_fwd, uint16_t *__restrict__ out_bwd)
+{
+    const int taps = kt * 9;
+    const int64_t total = (int64_t)taps * o * i;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < 2 * total; e += (int64_t)gridDim.x * 256) {
+        const bool transpose = e >= total;
+        const int64_t r = transpose ? e - total : e;
+        const int op = transpose ? i : o, ip = transpose ? o : i;
+        const int ci = (int)(r % ip);
+        const int co = (int)((r / ip) % op);
+        const int tap = (int)(r / ((int64_t)ip * op));
+        const int src_tap = transpose ? (taps - 1 - tap) : tap;
+        const int so = transpose ? ci : co, si = transpose ? co : ci;
+        const int ft = src_tap / 9, fy = (src_tap % 9) / 3, fx = src_tap % 3;
+        const uint16_t v = f32_to_bf16(w[so * st.o + si * st.i + ft * st.t + fy * st.y + fx * st.x]);
+        (transpose ? out_bwd : out_fwd)[r] = v;
+    }
+}
+
+extern "C" int pcacc_conv3x3_prepare_weights_pair(const float *w, int32_t c_out, int32_t c_in, int32_t kt, const int64_t *strides,
+                                                  uint16_t *out_fwd, uint16_t *out_bwd, void *stream)
+{
+    if (!w || !out_fwd || !out_bwd || !strides || c_out < 1 || c_in < 1 || (kt != 1 && kt != 3)) return PCACC_E_ARG;
+    const ConvWStrides st = {strides[0], strides[1], kt == 3 ? strides[2] : 0, strides[kt == 3 ? 3 : 2], strides[kt == 3 ? 4 : 3]};
+    const int64_t total = 2 * (int64_t)kt * 9 * c_out * c_in;
+    hipLaunchKernelGGL(conv_prepare_weights_pair_kernel, dim3(pcacc_grid(total, 256)), dim3(256), 0, pcacc_stream(stream), w, c_out, c_in, kt,
+                       st, out_fwd, out_bwd);
+    PCACC_CHECK_LAUNCH();
+    return 0;
+}
+
 // epilogue: lane = pixel lp of the wave's R rows; register quad g holds channels ct*32 + 8g + 4*lh .. +3.
 // Split into pack (bias, ReLU, bf16) and store so that the persistent kernel can hold a finished tile in registers and
 // issue its stores one pass later (loads and stores share the vmcnt counter: a wait for the prefetched patch would
@@ -110,7 +146,8 @@ __device__ __forceinline__ void conv_store_tile(const f32x16_t (&acc)[2][CT], co
 // ---- the convolution ------------------------------------------------------------------------------------------------------------
 // CT = output-channel tiles of 32 per workgroup (1, 2 or 4); CS = input channels resident in LDS at a time (32, 64, 128).
 template <int CT, int CS>
-__global__ __launch_bounds__(CV_THREADS) void conv3x3_mfma_kernel(const uint16_t *__restrict__ in, const uint16_t *__restrict__ wp,
+__global__ __launch_bounds__(CV_THREADS) void conv3x3_mfma_kernel(const uint16_t *__restrict__ in, const uint16_t *__restrict__ in_mask,
+                                                                  const uint16_t *__restrict__ wp,
                                                                   const float *__restrict__ bias, uint16_t *__restrict__ out,
                                                                   int n_img, int frames, int h, int w, int c_in, int c_out, int kt,
                                                                   int relu, int tiles_x, int tiles_y, int co_groups)
@@ -150,6 +187,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_mfma_kernel(const uint16_t
         const int dt = kt == 3 ? f - 1 : 0;
         if (t_frame + dt < 0 || t_frame + dt >= frames) continue;               // uniform: a missing frame contributes zeros
         const uint16_t *src = in + (int64_t)(img + dt) * h * w * c_in;
+        const uint16_t *msrc = in_mask ? in_mask + (int64_t)(img + dt) * h * w * c_in : nullptr;
         for (int cs = 0; cs < n_slices; ++cs) {
             __syncthreads();                                                     // the previous pass is done with the patch
             for (int c = threadIdx.x; c < P_CHUNKS; c += CV_THREADS) {
@@ -157,8 +195,10 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_mfma_kernel(const uint16_t
                 const int py = px / CV_PW, pxx = px % CV_PW;
                 const int y = y0 - 1 + py, x = x0 - 1 + pxx;
                 uint4 v = make_uint4(0, 0, 0, 0);
-                if (y >= 0 && y < h && x >= 0 && x < w)
+                if (y >= 0 && y < h && x >= 0 && x < w) {
                     v = *reinterpret_cast<const uint4 *>(src + ((int64_t)y * w + x) * c_in + cs * CS + c8 * 8);
+                    if (msrc) v = pcacc_relu_mask8(v, *reinterpret_cast<const uint4 *>(msrc + ((int64_t)y * w + x) * c_in + cs * CS + c8 * 8));
+                }
                 *reinterpret_cast<uint4 *>(patch + px * PS + c8 * 8) = v;
             }
             const uint16_t *wsrc = wp + ((int64_t)f * 9 * c_out + co0) * c_in + cs * CS;   // tap 0 of this frame tap
@@ -248,7 +288,8 @@ __device__ __forceinline__ void conv_pass_mfma(f32x16_t (&acc)[R][CT], const uin
 // wave's epilogue / staging run under another's MFMAs.
 template <int CT, int CS, int R, int CTW>
 __global__ __launch_bounds__(64 * (8 / R) * (CT / CTW)) void conv3x3_resident_kernel(
-    const uint16_t *__restrict__ in, const uint16_t *__restrict__ wp, const float *__restrict__ bias, uint16_t *__restrict__ out,
+    const uint16_t *__restrict__ in, const uint16_t *__restrict__ in_mask, const uint16_t *__restrict__ wp, const float *__restrict__ bias,
+    uint16_t *__restrict__ out,
     int n_img, int frames, int h, int w, int c_out, int kt, int relu, int tiles_x, int tiles_y, int co_groups)
 {
     constexpr int THREADS = 64 * (8 / R) * (CT / CTW);
@@ -302,12 +343,16 @@ __global__ __launch_bounds__(64 * (8 / R) * (CT / CTW)) void conv3x3_resident_ke
         const int img = tile / (tiles_y * tiles_x) + (kt == 3 ? f - 1 : 0);
         const int rem = tile % (tiles_y * tiles_x);
         const int y0 = (rem / tiles_x) * CV_TH, x0 = (rem % tiles_x) * CV_TW;
-        const uint16_t *src = in + ((int64_t)img * h * w + (int64_t)y0 * w + x0) * CS;
+        const int64_t origin = ((int64_t)img * h * w + (int64_t)y0 * w + x0) * CS;
+        const uint16_t *src = in + origin;
 #pragma unroll
         for (int q = 0; q < P_PER_THREAD; ++q) {
             const int y = y0 - 1 + (p_yx[q] >> 8), x = x0 - 1 + (p_yx[q] & 0xff);
             uint4 v = make_uint4(0, 0, 0, 0);
-            if ((unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w) v = *reinterpret_cast<const uint4 *>(src + p_off[q]);
+            if ((unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w) {
+                v = *reinterpret_cast<const uint4 *>(src + p_off[q]);
+                if (in_mask) v = pcacc_relu_mask8(v, *reinterpret_cast<const uint4 *>(in_mask + origin + p_off[q]));   // uniform branch
+            }
             preg[q] = v;
         }
     };
@@ -367,8 +412,8 @@ __global__ __launch_bounds__(64 * (8 / R) * (CT / CTW)) void conv3x3_resident_ke
 }
 
 template <int CT, int CS, int R, int CTW>
-static int conv_launch_resident(const uint16_t *in, const uint16_t *wp, const float *bias, uint16_t *out, int n_img, int frames, int h,
-                                int w, int c_out, int kt, int relu, hipStream_t st)
+static int conv_launch_resident(const uint16_t *in, const uint16_t *in_mask, const uint16_t *wp, const float *bias, uint16_t *out, int n_img,
+                                int frames, int h, int w, int c_out, int kt, int relu, hipStream_t st)
 {
     constexpr int THREADS = 64 * (8 / R) * (CT / CTW);
     const int tiles_x = (w + CV_TW - 1) / CV_TW, tiles_y = (h + CV_TH - 1) / CV_TH;
@@ -388,15 +433,15 @@ static int conv_launch_resident(const uint16_t *in, const uint16_t *wp, const fl
     if (slots > need) slots = need;
     if (slots < 1) slots = 1;
     const unsigned grid = (unsigned)(8 * co_groups * slots);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, st, in, wp, bias, out, n_img, frames, h, w, c_out, kt, relu, tiles_x,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, st, in, in_mask, wp, bias, out, n_img, frames, h, w, c_out, kt, relu, tiles_x,
                        tiles_y, co_groups);
     PCACC_CHECK_LAUNCH();
     return 0;
 }
 
 template <int CT, int CS>
-static int conv_launch(const uint16_t *in, const uint16_t *wp, const float *bias, uint16_t *out, int n_img, int frames, int h, int w,
-                       int c_in, int c_out, int kt, int relu, hipStream_t st)
+static int conv_launch(const uint16_t *in, const uint16_t *in_mask, const uint16_t *wp, const float *bias, uint16_t *out, int n_img, int frames,
+                       int h, int w, int c_in, int c_out, int kt, int relu, hipStream_t st)
 {
     const int tiles_x = (w + CV_TW - 1) / CV_TW, tiles_y = (h + CV_TH - 1) / CV_TH;
     const int co_groups = c_out / (CT * 32);
@@ -408,8 +453,8 @@ static int conv_launch(const uint16_t *in, const uint16_t *wp, const float *bias
     }
     const int64_t blocks = (int64_t)n_img * tiles_y * tiles_x * co_groups;
     if (blocks > 0x7fffffff) return PCACC_E_ARG;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(CV_THREADS), lds, st, in, wp, bias, out, n_img, frames, h, w, c_in, c_out, kt,
-                       relu, tiles_x, tiles_y, co_groups);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(CV_THREADS), lds, st, in, in_mask, wp, bias, out, n_img, frames, h, w, c_in, c_out,
+                       kt, relu, tiles_x, tiles_y, co_groups);
     PCACC_CHECK_LAUNCH();
     return 0;
 }
@@ -417,6 +462,13 @@ static int conv_launch(const uint16_t *in, const uint16_t *wp, const float *bias
 extern "C" int pcacc_conv3x3_bf16(const uint16_t *in, const uint16_t *wp, const float *bias, uint16_t *out, int32_t n_img,
                                   int32_t frames, int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t kt, int32_t relu,
                                   void *stream)
+{
+    return pcacc_conv3x3_masked_bf16(in, nullptr, wp, bias, out, n_img, frames, h, w, c_in, c_out, kt, relu, stream);
+}
+
+extern "C" int pcacc_conv3x3_masked_bf16(const uint16_t *in, const uint16_t *in_mask, const uint16_t *wp, const float *bias, uint16_t *out,
+                                         int32_t n_img, int32_t frames, int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t kt,
+                                         int32_t relu, void *stream)
 {
     if (!in || !wp || !out || n_img < 1 || h < 1 || w < 1 || (kt != 1 && kt != 3) || frames < 1 || n_img % frames) return PCACC_E_ARG;
     if (c_in % 32 || c_out % 32 || c_in < 32 || c_out < 32) return PCACC_E_ARG;
@@ -429,7 +481,7 @@ extern "C" int pcacc_conv3x3_bf16(const uint16_t *in, const uint16_t *wp, const 
             if (lds > 150 * 1024) continue;
             const bool alone = lds > 80 * 1024;                    // one workgroup per CU: run it with 8 waves
 #define CV_RES(CTV, CSV, RV, CTWV) \
-    return conv_launch_resident<CTV, CSV, RV, CTWV>(in, wp, bias, out, n_img, frames, h, w, c_out, kt, relu, st)
+    return conv_launch_resident<CTV, CSV, RV, CTWV>(in, in_mask, wp, bias, out, n_img, frames, h, w, c_out, kt, relu, st)
             if (c_in == 32 && ctr == 1) { if (alone) CV_RES(1, 32, 1, 1); CV_RES(1, 32, 2, 1); }
             if (c_in == 32 && ctr == 2) { if (alone) CV_RES(2, 32, 2, 1); CV_RES(2, 32, 2, 2); }
             if (c_in == 32 && ctr == 4) { CV_RES(4, 32, 2, 2); }
@@ -440,11 +492,11 @@ extern "C" int pcacc_conv3x3_bf16(const uint16_t *in, const uint16_t *wp, const 
     }
     // deep layers on small images: strips of consecutive pixels, K-deep tiling (conv_deep.hip)
     if (kt == 1 && pcacc_conv3x3_deep_supported(h, w, c_in, c_out))
-        return pcacc_conv3x3_deep_bf16(in, wp, bias, out, n_img, h, w, c_in, c_out, relu, stream);
+        return pcacc_conv3x3_deep_bf16(in, in_mask, wp, bias, out, n_img, h, w, c_in, c_out, relu, stream);
     const int cs_sel = c_in % 128 == 0 ? 128 : (c_in % 64 == 0 ? 64 : 32);   // input channels per LDS pass
     const int ct = c_out % 128 == 0 ? 4 : (c_out % 64 == 0 ? 2 : 1);
 #define CV_CASE(CTV, CSV) \
-    if (ct == CTV && cs_sel == CSV) return conv_launch<CTV, CSV>(in, wp, bias, out, n_img, frames, h, w, c_in, c_out, kt, relu, st)
+    if (ct == CTV && cs_sel == CSV) return conv_launch<CTV, CSV>(in, in_mask, wp, bias, out, n_img, frames, h, w, c_in, c_out, kt, relu, st)
     CV_CASE(1, 32); CV_CASE(2, 32); CV_CASE(4, 32);
     CV_CASE(1, 64); CV_CASE(2, 64); CV_CASE(4, 64);
     CV_CASE(1, 128); CV_CASE(2, 128); CV_CASE(4, 128);
@@ -464,8 +516,8 @@ typedef short cv_s16x4 __attribute__((ext_vector_type(4)));
 union cv_frag { bf16x8_t v; cv_s16x4 h[2]; };
 
 template <int CO_T, int CI_T>
-__global__ __launch_bounds__(CV_THREADS) void conv3x3_wgrad_kernel(const uint16_t *__restrict__ dy, const uint16_t *__restrict__ x,
-                                                                   float *__restrict__ partial, int n_img, int frames, int dt, int h,
+__global__ __launch_bounds__(CV_THREADS) void conv3x3_wgrad_kernel(const uint16_t *__restrict__ dy, const uint16_t *__restrict__ dy_mask,
+                                                                   const uint16_t *__restrict__ x, float *__restrict__ partial, int n_img, int frames, int dt, int h,
                                                                    int w, int tiles_x, int tiles_y)
 {
     constexpr int CO = CO_T * 32, CI = CI_T * 32, PAIRS = CO_T * CI_T, GROUPS = 4 / PAIRS;
@@ -508,7 +560,10 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_wgrad_kernel(const uint16_
             const int px = c / (CO / 8), c8 = c % (CO / 8);
             const int yy = y0 + px / CV_TW, xx = x0 + px % CV_TW;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (yy < h && xx < w) v = *reinterpret_cast<const uint4 *>(gsrc + ((int64_t)yy * w + xx) * CO + c8 * 8);
+            if (yy < h && xx < w) {
+                v = *reinterpret_cast<const uint4 *>(gsrc + ((int64_t)yy * w + xx) * CO + c8 * 8);
+                if (dy_mask) v = pcacc_relu_mask8(v, *reinterpret_cast<const uint4 *>(dy_mask + (int64_t)img * h * w * CO + ((int64_t)yy * w + xx) * CO + c8 * 8));
+            }
             yreg[q] = v;
         }
         const uint16_t *xsrc = x + (int64_t)(img + dt) * h * w * CI;
@@ -667,6 +722,13 @@ extern "C" int pcacc_conv3x3_wgrad_bf16(const uint16_t *dy, const uint16_t *x, f
                                         int32_t h, int32_t w, int32_t c_in, int32_t c_out, void *workspace, size_t workspace_bytes,
                                         void *stream)
 {
+    return pcacc_conv3x3_wgrad_masked_bf16(dy, nullptr, x, dw, n_img, frames, dt, h, w, c_in, c_out, workspace, workspace_bytes, stream);
+}
+
+extern "C" int pcacc_conv3x3_wgrad_masked_bf16(const uint16_t *dy, const uint16_t *dy_mask, const uint16_t *x, float *dw, int32_t n_img,
+                                               int32_t frames, int32_t dt, int32_t h, int32_t w, int32_t c_in, int32_t c_out,
+                                               void *workspace, size_t workspace_bytes, void *stream)
+{
     if (!dy || !x || !dw || !workspace || n_img < 1 || h < 1 || w < 1 || frames < 1 || n_img % frames || dt < -1 || dt > 1)
         return PCACC_E_ARG;
     if ((c_in != 32 && c_in != 64) || (c_out != 32 && c_out != 64)) return PCACC_E_ARG;
@@ -685,7 +747,7 @@ extern "C" int pcacc_conv3x3_wgrad_bf16(const uint16_t *dy, const uint16_t *x, f
         if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                                    (int)lds) != hipSuccess)                                                          \
             return PCACC_E_LAUNCH;                                                                                                   \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(CV_THREADS), lds, st, dy, x, partial, n_img, frames, dt, h, w, tiles_x, tiles_y);  \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(CV_THREADS), lds, st, dy, dy_mask, x, partial, n_img, frames, dt, h, w, tiles_x, tiles_y);  \
     } while (0)
     if (c_out == 32 && c_in == 32) CV_WG(1, 1);
     else if (c_out == 32 && c_in == 64) CV_WG(1, 2);

@@ -22,7 +22,8 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 #define CD_PCH 10                              // patch pieces (16 B) a thread carries per channel slice
 
 template <int CS, int NG>
-__global__ __launch_bounds__(CD_THREADS) void conv3x3_strip_kernel(const uint16_t *__restrict__ in, const uint16_t *__restrict__ wp,
+__global__ __launch_bounds__(CD_THREADS) void conv3x3_strip_kernel(const uint16_t *__restrict__ in, const uint16_t *__restrict__ in_mask,
+                                                                   const uint16_t *__restrict__ wp,
                                                                    const float *__restrict__ bias, uint16_t *__restrict__ out, int n_img,
                                                                    int h, int w, int c_in, int c_out, int relu, int rows, int strips,
                                                                    int co_groups)
@@ -87,7 +88,9 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_strip_kernel(const uint16_
             // always load (from a clamped position), then select: a load under a lane mask would cost a branch and an early wait
             const bool ok = (unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w;
             const int yc = min(max(y, 0), h - 1), xc = min(max(x, 0), w - 1);
-            const uint4 v = *reinterpret_cast<const uint4 *>(img_in + ((int64_t)yc * w + xc) * c_in + cs * CS + c8 * 8);
+            const int64_t off = ((int64_t)yc * w + xc) * c_in + cs * CS + c8 * 8;
+            uint4 v = *reinterpret_cast<const uint4 *>(img_in + off);
+            if (in_mask) v = pcacc_relu_mask8(v, *reinterpret_cast<const uint4 *>(in_mask + (int64_t)img * h * w * c_in + off));   // uniform
             preg[q] = ok ? v : make_uint4(0, 0, 0, 0);
         }
     };
@@ -204,8 +207,8 @@ static int conv_strip_rows(int h, int w, size_t *lds_bytes)
 }
 
 template <int CS, int NG>
-static int conv_strip_launch(const uint16_t *in, const uint16_t *wp, const float *bias, uint16_t *out, int n_img, int h, int w, int c_in,
-                             int c_out, int relu, hipStream_t st)
+static int conv_strip_launch(const uint16_t *in, const uint16_t *in_mask, const uint16_t *wp, const float *bias, uint16_t *out, int n_img, int h,
+                             int w, int c_in, int c_out, int relu, hipStream_t st)
 {
     size_t lds = 0;
     const int rows = conv_strip_rows<CS, NG>(h, w, &lds);
@@ -216,8 +219,8 @@ static int conv_strip_launch(const uint16_t *in, const uint16_t *wp, const float
         return PCACC_E_LAUNCH;
     const int64_t blocks = (int64_t)n_img * strips * co_groups;
     if (blocks > 0x7fffffff) return PCACC_E_ARG;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(CD_THREADS), lds, st, in, wp, bias, out, n_img, h, w, c_in, c_out, relu, rows,
-                       strips, co_groups);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(CD_THREADS), lds, st, in, in_mask, wp, bias, out, n_img, h, w, c_in, c_out, relu,
+                       rows, strips, co_groups);
     PCACC_CHECK_LAUNCH();
     return 0;
 }
@@ -232,8 +235,8 @@ extern "C" int pcacc_conv3x3_deep_supported(int32_t h, int32_t w, int32_t c_in, 
     return (c_out % 128 == 0 ? conv_strip_rows<32, 2>(h, w, &lds) : conv_strip_rows<32, 1>(h, w, &lds)) >= 1;
 }
 
-extern "C" int pcacc_conv3x3_deep_bf16(const uint16_t *in, const uint16_t *wp, const float *bias, uint16_t *out, int32_t n_img, int32_t h,
-                                       int32_t w, int32_t c_in, int32_t c_out, int32_t relu, void *stream)
+extern "C" int pcacc_conv3x3_deep_bf16(const uint16_t *in, const uint16_t *in_mask, const uint16_t *wp, const float *bias, uint16_t *out,
+                                       int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t relu, void *stream)
 {
     if (!in || !wp || !out || n_img < 1 || !pcacc_conv3x3_deep_supported(h, w, c_in, c_out)) return PCACC_E_ARG;
     hipStream_t st = pcacc_stream(stream);
@@ -244,13 +247,13 @@ extern "C" int pcacc_conv3x3_deep_bf16(const uint16_t *in, const uint16_t *wp, c
         const int rows = wide ? conv_strip_rows<32, 2>(h, w, &lds) : conv_strip_rows<64, 2>(h, w, &lds);
         const int64_t blocks = (int64_t)n_img * ((h + rows - 1) / rows) * (c_out / 128);
         if (blocks * 2 <= PCACC_CUS)
-            return wide ? conv_strip_launch<32, 1>(in, wp, bias, out, n_img, h, w, c_in, c_out, relu, st)
-                        : conv_strip_launch<64, 1>(in, wp, bias, out, n_img, h, w, c_in, c_out, relu, st);
-        return wide ? conv_strip_launch<32, 2>(in, wp, bias, out, n_img, h, w, c_in, c_out, relu, st)
-                    : conv_strip_launch<64, 2>(in, wp, bias, out, n_img, h, w, c_in, c_out, relu, st);
+            return wide ? conv_strip_launch<32, 1>(in, in_mask, wp, bias, out, n_img, h, w, c_in, c_out, relu, st)
+                        : conv_strip_launch<64, 1>(in, in_mask, wp, bias, out, n_img, h, w, c_in, c_out, relu, st);
+        return wide ? conv_strip_launch<32, 2>(in, in_mask, wp, bias, out, n_img, h, w, c_in, c_out, relu, st)
+                    : conv_strip_launch<64, 2>(in, in_mask, wp, bias, out, n_img, h, w, c_in, c_out, relu, st);
     }
-    return wide ? conv_strip_launch<32, 1>(in, wp, bias, out, n_img, h, w, c_in, c_out, relu, st)
-                : conv_strip_launch<64, 1>(in, wp, bias, out, n_img, h, w, c_in, c_out, relu, st);
+    return wide ? conv_strip_launch<32, 1>(in, in_mask, wp, bias, out, n_img, h, w, c_in, c_out, relu, st)
+                : conv_strip_launch<64, 1>(in, in_mask, wp, bias, out, n_img, h, w, c_in, c_out, relu, st);
 }
 
 // ---- weight gradient of the deep layers ---------------------------------------------------------------------------------------------
@@ -267,7 +270,8 @@ union cd_frag { bf16x8_t v; cd_s16x4 h[2]; };
 #define CDW_MAXP 256                                       // pixels per strip
 #define CDW_PCH 11                                         // staged 16-byte pieces (dY rows + X patch) a thread carries
 
-__global__ __launch_bounds__(CD_THREADS) void conv3x3_wgrad_strip_kernel(const uint16_t *__restrict__ dy, const uint16_t *__restrict__ x,
+__global__ __launch_bounds__(CD_THREADS) void conv3x3_wgrad_strip_kernel(const uint16_t *__restrict__ dy, const uint16_t *__restrict__ dy_mask,
+                                                                         const uint16_t *__restrict__ x,
                                                                          float *__restrict__ partial, int n_img, int h, int w, int c_in,
                                                                          int c_out, int rows, int strips, int ci_blocks, int slots)
 {
@@ -318,6 +322,7 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_wgrad_strip_kernel(const u
             const int64_t pos = (int64_t)min(max(yy, 0), h - 1) * w + min(max(xx, 0), w - 1);
             const uint16_t *src = is_y ? ysrc + pos * c_out + c8 * 8 : xsrc + pos * c_in + c8 * 8;
             uint4 v = *reinterpret_cast<const uint4 *>(src);
+            if (dy_mask && is_y) v = pcacc_relu_mask8(v, *reinterpret_cast<const uint4 *>(dy_mask + (src - dy)));
             if (!ok) v = make_uint4(0, 0, 0, 0);
             sreg[q] = v;
         }
@@ -455,9 +460,9 @@ extern "C" int pcacc_conv3x3_wgrad_deep_workspace_bytes(int32_t n_img, int32_t h
     return 0;
 }
 
-extern "C" int pcacc_conv3x3_wgrad_deep_bf16(const uint16_t *dy, const uint16_t *x, float *dw, float *db, int32_t n_img, int32_t h,
-                                             int32_t w, int32_t c_in, int32_t c_out, void *workspace, size_t workspace_bytes,
-                                             void *stream)
+extern "C" int pcacc_conv3x3_wgrad_deep_bf16(const uint16_t *dy, const uint16_t *dy_mask, const uint16_t *x, float *dw, float *db,
+                                             int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_out, void *workspace,
+                                             size_t workspace_bytes, void *stream)
 {
     size_t lds = 0, need = 0;
     if (!dy || !x || !dw || !db || !workspace || pcacc_conv3x3_wgrad_deep_workspace_bytes(n_img, h, w, c_in, c_out, &need) != 0)
@@ -471,7 +476,7 @@ extern "C" int pcacc_conv3x3_wgrad_deep_bf16(const uint16_t *dy, const uint16_t 
                             (int)lds) != hipSuccess)
         return PCACC_E_LAUNCH;
     float *partial = static_cast<float *>(workspace);
-    hipLaunchKernelGGL(conv3x3_wgrad_strip_kernel, dim3(blocks * slots), dim3(CD_THREADS), lds, st, dy, x, partial, n_img, h, w, c_in, c_out,
+    hipLaunchKernelGGL(conv3x3_wgrad_strip_kernel, dim3(blocks * slots), dim3(CD_THREADS), lds, st, dy, dy_mask, x, partial, n_img, h, w, c_in, c_out,
                        rows, strips, ci_blocks, slots);
     const int64_t elems = (int64_t)c_out * 9 * c_in + c_out;
     hipLaunchKernelGGL(conv_wgrad_strip_reduce_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, partial, slots, c_in, c_out,

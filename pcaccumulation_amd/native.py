@@ -54,7 +54,8 @@ EXPORTS = [
     'pcacc_offset_loss_workspace_bytes', 'pcacc_offset_loss_forward', 'pcacc_offset_loss_backward',
     'pcacc_frames_max', 'pcacc_frames_max_backward', 'pcacc_rows_linear_cat_bf16', 'pcacc_rows_wgrad_cat_bf16',
     'pcacc_pillar_scatter_timed', 'pcacc_pillar_scatter_t', 'pcacc_timer_create', 'pcacc_timer_elapsed_us', 'pcacc_timer_destroy',
-    'pcacc_svd3', 'pcacc_svd3_backward', 'pcacc_conv3x3_deep_supported', 'pcacc_conv3x3_deep_bf16',
+    'pcacc_svd3', 'pcacc_svd3_backward', 'pcacc_conv3x3_deep_supported', 'pcacc_conv3x3_deep_bf16', 'pcacc_conv3x3_prepare_weights_pair',
+    'pcacc_conv3x3_masked_bf16', 'pcacc_conv3x3_wgrad_masked_bf16',
     'pcacc_conv3x3_wgrad_deep_supported', 'pcacc_conv3x3_wgrad_deep_workspace_bytes', 'pcacc_conv3x3_wgrad_deep_bf16', 'pcacc_bn_rows_workspace_bytes', 'pcacc_bn_rows_forward', 'pcacc_bn_rows_backward',
 ]
 
@@ -483,16 +484,36 @@ def conv3x3_prepare_weights(weight, transpose=False):
     return out
 
 
-def conv3x3(x_rows, wp, bias, frames, relu):
-    """x_rows bf16 [n_img,h,w,c_in] contiguous, wp from conv3x3_prepare_weights -> bf16 [n_img,h,w,c_out]."""
+def conv3x3_prepare_weights_pair(weight):
+    """weight f32 [O,I,3,3] / [O,I,3,3,3] in ANY dense storage order -> (forward form bf16 [kt*9,O,I], data-gradient form bf16 [kt*9,I,O]),
+    one launch (pcacc_conv3x3_prepare_weights_pair)."""
+    o, i = weight.shape[0], weight.shape[1]
+    kt = 3 if weight.dim() == 5 else 1
+    fwd = torch.empty((kt * 9, o, i), dtype=torch.bfloat16, device=weight.device)
+    bwd = torch.empty((kt * 9, i, o), dtype=torch.bfloat16, device=weight.device)
+    strides = (ctypes.c_int64 * weight.dim())(*weight.stride())
+    if not weight.is_cuda or weight.dtype != torch.float32:
+        raise NativeError('conv3x3_prepare_weights_pair: weight must be a float32 GPU tensor')
+    _check(lib().pcacc_conv3x3_prepare_weights_pair(ctypes.c_void_p(weight.data_ptr()), int(o), int(i), kt, strides, _dev(fwd), _dev(bwd),
+                                                    _stream()), 'conv3x3_prepare_weights_pair')
+    return fwd, bwd
+
+
+def conv3x3(x_rows, wp, bias, frames, relu, mask=None):
+    """x_rows bf16 [n_img,h,w,c_in] contiguous, wp from conv3x3_prepare_weights -> bf16 [n_img,h,w,c_out].
+    mask (same shape as x_rows): x_rows is the gradient of a ReLU layer whose forward output is `mask`; elements where mask <= 0 are
+    read as zero (ReLU backward fused into the staging)."""
     n_img, h, w, c_in = x_rows.shape
     taps, c_out, wc_in = wp.shape
     if wc_in != c_in:
         raise NativeError('conv3x3: weights prepared for %d input channels, input has %d' % (wc_in, c_in))
     out = torch.empty((n_img, h, w, c_out), dtype=torch.bfloat16, device=x_rows.device)
-    _check(lib().pcacc_conv3x3_bf16(_dev(x_rows, torch.bfloat16, 'x'), _dev(wp, torch.bfloat16, 'wp'),
-                                    _dev(bias, torch.float32, 'bias') if bias is not None else None, _dev(out), int(n_img), int(frames),
-                                    int(h), int(w), int(c_in), int(c_out), taps // 9, 1 if relu else 0, _stream()), 'conv3x3')
+    if mask is not None and mask.shape != x_rows.shape:
+        raise NativeError('conv3x3: mask shape %s != input shape %s' % (tuple(mask.shape), tuple(x_rows.shape)))
+    _check(lib().pcacc_conv3x3_masked_bf16(_dev(x_rows, torch.bfloat16, 'x'), _dev(mask, torch.bfloat16, 'mask') if mask is not None else None,
+                                           _dev(wp, torch.bfloat16, 'wp'), _dev(bias, torch.float32, 'bias') if bias is not None else None,
+                                           _dev(out), int(n_img), int(frames), int(h), int(w), int(c_in), int(c_out), taps // 9,
+                                           1 if relu else 0, _stream()), 'conv3x3')
     return out
 
 
@@ -509,7 +530,7 @@ def conv3x3_wgrad_supported(c_in, c_out):
     return c_in in (32, 64) and c_out in (32, 64)
 
 
-def conv3x3_wgrad(dy_rows, x_rows, frames=1, dt=0):
+def conv3x3_wgrad(dy_rows, x_rows, frames=1, dt=0, mask=None):
     """dy_rows [n_img,h,w,c_out], x_rows [n_img,h,w,c_in] bf16 -> (dw [c_out, 9, c_in] f32, db [c_out] f32) for frame tap dt of a
     kt=3 layer (db is the full bias gradient for dt = 0)."""
     n_img, h, w, c_out = dy_rows.shape
@@ -519,9 +540,9 @@ def conv3x3_wgrad(dy_rows, x_rows, frames=1, dt=0):
     _check(lib().pcacc_conv3x3_wgrad_workspace_bytes(int(n_img), int(h), int(w), int(c_in), int(c_out), ctypes.byref(need)),
            'conv3x3_wgrad_workspace')
     ws = _ws(need.value, dy_rows.device)
-    _check(lib().pcacc_conv3x3_wgrad_bf16(_dev(dy_rows, torch.bfloat16, 'dy'), _dev(x_rows, torch.bfloat16, 'x'), _dev(dw), int(n_img),
-                                          int(frames), int(dt), int(h), int(w), int(c_in), int(c_out), _dev(ws),
-                                          ctypes.c_size_t(ws.numel()), _stream()), 'conv3x3_wgrad')
+    _check(lib().pcacc_conv3x3_wgrad_masked_bf16(_dev(dy_rows, torch.bfloat16, 'dy'), _dev(mask, torch.bfloat16, 'mask') if mask is not None else None,
+                                                 _dev(x_rows, torch.bfloat16, 'x'), _dev(dw), int(n_img), int(frames), int(dt), int(h), int(w),
+                                                 int(c_in), int(c_out), _dev(ws), ctypes.c_size_t(ws.numel()), _stream()), 'conv3x3_wgrad')
     return dw[:c_out * 9 * c_in].view(c_out, 9, c_in), dw[c_out * 9 * c_in:]
 
 
@@ -529,7 +550,7 @@ def conv3x3_wgrad_deep_supported(h, w, c_in, c_out):
     return bool(lib().pcacc_conv3x3_wgrad_deep_supported(int(h), int(w), int(c_in), int(c_out)))
 
 
-def conv3x3_wgrad_deep(dy_rows, x_rows):
+def conv3x3_wgrad_deep(dy_rows, x_rows, mask=None):
     """dy_rows [n_img,h,w,c_out], x_rows [n_img,h,w,c_in] bf16 -> (dw [c_out, 9, c_in] f32, db [c_out] f32); csrc/conv_deep.hip."""
     n_img, h, w, c_out = dy_rows.shape
     c_in = x_rows.shape[3]
@@ -539,7 +560,8 @@ def conv3x3_wgrad_deep(dy_rows, x_rows):
     _check(lib().pcacc_conv3x3_wgrad_deep_workspace_bytes(int(n_img), int(h), int(w), int(c_in), int(c_out), ctypes.byref(need)),
            'conv3x3_wgrad_deep_workspace')
     ws = _ws(need.value, dy_rows.device)
-    _check(lib().pcacc_conv3x3_wgrad_deep_bf16(_dev(dy_rows, torch.bfloat16, 'dy'), _dev(x_rows, torch.bfloat16, 'x'), _dev(dw), _dev(db),
+    _check(lib().pcacc_conv3x3_wgrad_deep_bf16(_dev(dy_rows, torch.bfloat16, 'dy'), _dev(mask, torch.bfloat16, 'mask') if mask is not None else None,
+                                               _dev(x_rows, torch.bfloat16, 'x'), _dev(dw), _dev(db),
                                                int(n_img), int(h), int(w), int(c_in), int(c_out), _dev(ws), ctypes.c_size_t(ws.numel()),
                                                _stream()), 'conv3x3_wgrad_deep')
     return dw, db

@@ -4,6 +4,8 @@ Layout convention: BEV canvases and feature maps are channels-last i
 channels is the 2-D tensor [n_cells, C] with n_cells = B*T*ny*nx in (b, t, y, x) order; viewed as
 [B*T, C, ny, nx] it is a torch channels_last tensor, as [B, C, T, ny, nx] a channels_last_3d one.
 """
+import weakref
+
 import torch
 
 from . import native
@@ -468,6 +470,27 @@ def transform_by_index(points, idx, tsfm):
     return out if points.dtype == torch.float32 else out.to(points.dtype)
 
 
+_PREPARED = {}
+
+
+def prepared_conv_weights(weight):
+    """(forward form, data-gradient form) of a 3x3 / 3x3x3 weight for the MFMA kernels, prepared once per weight VERSION: the
+    forward of a training step and its backward share one launch, evaluation passes reuse the forms until the optimizer (or a
+    load_state_dict) writes the parameter again."""
+    key = id(weight)
+    hit = _PREPARED.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == (weight._version, weight.data_ptr()):
+        return hit[2], hit[3]
+    w = weight.detach()
+    if w.dtype != torch.float32:
+        w = w.float()
+    fwd, bwd = native.conv3x3_prepare_weights_pair(w)
+    if len(_PREPARED) > 4096:
+        _PREPARED.clear()
+    _PREPARED[key] = (weakref.ref(weight), (weight._version, weight.data_ptr()), fwd, bwd)
+    return fwd, bwd
+
+
 class _Conv3x3(torch.autograd.Function):
     """3x3 (kt=1) / 3x3x3 (kt=3) convolution + bias + ReLU on bf16 channels-last rows [n_img, H, W, C] through the MFMA
     implicit-GEMM kernel (csrc/conv.hip).  Backward: ReLU mask, data gradient with the same kernel on mirrored /
@@ -475,9 +498,7 @@ class _Conv3x3(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x_rows, weight, bias, frames, relu):
-        w32 = weight.detach().float().contiguous(memory_format=torch.contiguous_format)
-        y = native.conv3x3(x_rows, native.conv3x3_prepare_weights(w32), bias.detach().float() if bias is not None else None,
-                           frames, relu)
+        y = native.conv3x3(x_rows, prepared_conv_weights(weight)[0], bias.detach().float() if bias is not None else None, frames, relu)
         ctx.save_for_backward(x_rows, weight, y if relu else None)
         ctx.meta = (frames, relu, bias is not None)
         return y
@@ -487,30 +508,34 @@ class _Conv3x3(torch.autograd.Function):
         x_rows, weight, y = ctx.saved_tensors
         frames, relu, has_bias = ctx.meta
         gy = gy.contiguous()
-        if relu:
-            gy = torch.ops.aten.threshold_backward(gy, y, 0)
         gx = gw = gb = None
         kt = 3 if weight.dim() == 5 else 1
         o, i = weight.shape[0], weight.shape[1]
+        h, w = x_rows.shape[1], x_rows.shape[2]
         need_w = ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2])
-        lib_dgrad = ctx.needs_input_grad[0] and kt == 1 and not conv3x3_preferred(o, i, x_rows.shape[1], x_rows.shape[2])   # data gradient: channels exchanged
+        lib_dgrad = ctx.needs_input_grad[0] and kt == 1 and not conv3x3_preferred(o, i, h, w)      # data gradient: channels exchanged
+        own_w = need_w and (native.conv3x3_wgrad_supported(i, o) or (kt == 1 and native.conv3x3_wgrad_deep_supported(h, w, i, o)))
+        # ReLU backward: the hand-written kernels zero the gradient where the forward output is <= 0 while they stage it (mask = y);
+        # only a library fallback needs the masked gradient as a tensor of its own
+        mask = y if relu else None
+        if relu and (lib_dgrad or (need_w and not own_w)):
+            gy, mask = torch.ops.aten.threshold_backward(gy, y, 0), None
         if ctx.needs_input_grad[0] and not lib_dgrad:
-            w32 = weight.detach().float().contiguous(memory_format=torch.contiguous_format)
-            gx = native.conv3x3(gy, native.conv3x3_prepare_weights(w32, transpose=True), None, frames, False)
+            gx = native.conv3x3(gy, prepared_conv_weights(weight)[1], None, frames, False, mask=mask)
         if need_w and native.conv3x3_wgrad_supported(i, o):
             # weight gradient on the matrix cores too (one launch per frame tap); bias gradient = a column sum of dY
             if kt == 3:
-                parts = [native.conv3x3_wgrad(gy, x_rows, frames, dt) for dt in (-1, 0, 1)]
+                parts = [native.conv3x3_wgrad(gy, x_rows, frames, dt, mask=mask) for dt in (-1, 0, 1)]
                 gw = torch.stack([p[0].view(o, 3, 3, i) for p in parts], dim=1).permute(0, 4, 1, 2, 3)    # [o, i, kt, 3, 3]
                 gb = parts[1][1]                                                           # dt = 0 visits every frame
             else:
-                gw, gb = native.conv3x3_wgrad(gy, x_rows)
+                gw, gb = native.conv3x3_wgrad(gy, x_rows, mask=mask)
                 gw = gw.view(o, 3, 3, i).permute(0, 3, 1, 2)
             gw = gw.to(weight.dtype)
             gb = gb.clone() if has_bias and ctx.needs_input_grad[2] else None
             need_w = False
-        elif need_w and kt == 1 and native.conv3x3_wgrad_deep_supported(x_rows.shape[1], x_rows.shape[2], i, o):
-            gw, gb = native.conv3x3_wgrad_deep(gy, x_rows)                                 # deep layers: 64 x 64 weight blocks, strips
+        elif need_w and own_w:
+            gw, gb = native.conv3x3_wgrad_deep(gy, x_rows, mask=mask)                      # deep layers: 64 x 64 weight blocks, strips
             gw = gw.view(o, 3, 3, i).permute(0, 3, 1, 2).to(weight.dtype)
             gb = gb if has_bias and ctx.needs_input_grad[2] else None
             need_w = False

@@ -130,7 +130,8 @@ def test_gpu_config_fp32(name, golden):
         bad = []
         for n, ref in zip(names, g['grad_norms']):
             got = float(grads[n].grad.norm()) if grads[n].grad is not None else 0.0
-            if abs(got - ref) > (3e-2 if n.startswith(loose) else 2.5e-2) * max(abs(ref), 1e-3):
+            # floor 1e-2: a conv bias in front of a BatchNorm has a mathematically zero gradient -- both sides hold rounding noise there
+            if abs(got - ref) > (3e-2 if n.startswith(loose) else 2.5e-2) * max(abs(ref), 1e-2):
                 bad.append((n, got, float(ref)))
         assert not bad, bad[:8]
         np.testing.assert_allclose(model.semseg_head.seg_head[1].running_mean.detach().cpu().numpy(), g['bn_running_mean'],

@@ -171,3 +171,20 @@ def test_conv3x3_wgrad_deep_kernel(n, h, w, ci, co):
     assert (dw - wr.grad).abs().max().item() <= 2e-3 * wr.grad.abs().max().item()
     ref_b = gy.float().sum(dim=(0, 1, 2))
     assert (db - ref_b).abs().max().item() <= 1e-3 * max(1.0, ref_b.abs().max().item())
+
+
+@pytest.mark.parametrize('shape', [(64, 32, 3, 3), (128, 256, 3, 3), (32, 32, 3, 3, 3)])
+def test_conv3x3_prepare_weights_pair_and_cache(shape):
+    """One launch for both prepared forms, any dense storage order; ops.prepared_conv_weights re-prepares when the weight is written."""
+    w = torch.randn(*shape, device=DEV)
+    want = native.conv3x3_prepare_weights(w), native.conv3x3_prepare_weights(w, transpose=True)
+    for wt in (w, w.contiguous(memory_format=torch.channels_last if w.dim() == 4 else torch.channels_last_3d)):
+        fwd, bwd = native.conv3x3_prepare_weights_pair(wt)
+        assert torch.equal(fwd, want[0]) and torch.equal(bwd, want[1])
+    p = torch.nn.Parameter(w.clone())
+    a = ops.prepared_conv_weights(p)
+    assert ops.prepared_conv_weights(p)[0] is a[0]                       # cached
+    with torch.no_grad():
+        p.mul_(2.0)                                                      # what an optimizer step does: a new version
+    b = ops.prepared_conv_weights(p)
+    assert b[0] is not a[0] and torch.equal(b[0], native.conv3x3_prepare_weights(p.detach().contiguous()))
