@@ -15,13 +15,16 @@
 //     weights (1.2 MB at 512 input channels) in its 4 MB L2.
 #include "common.h"
 
+#include <cstdio>
+#include <cstdlib>
+
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
 #define CD_THREADS 512
 #define CD_PCH 10                              // patch pieces (16 B) a thread carries per channel slice
 
-template <int CS, int NG>
+template <int CS, int NG, int MT>
 __global__ __launch_bounds__(CD_THREADS) void conv3x3_strip_kernel(const uint16_t *__restrict__ in, const uint16_t *__restrict__ in_mask,
                                                                    const uint16_t *__restrict__ wp,
                                                                    const float *__restrict__ bias, uint16_t *__restrict__ out, int n_img,
@@ -29,8 +32,7 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_strip_kernel(const uint16_
                                                                    int co_groups)
 {
     constexpr int PS = CS + 8;                                 // padded LDS row (elements): conflict-free 16-byte fragment reads
-    constexpr int MG = NG == 2 ? 4 : 8;                        // waves along the pixel dimension
-    constexpr int MT = NG == 2 ? 3 : 2;                        // 32-pixel tiles per wave
+    constexpr int MG = NG == 2 ? 4 : 8;                        // waves along the pixel dimension; MT = 32-pixel tiles per wave
     constexpr int WROWS = NG * 64;                             // weight rows (output channels) per workgroup
     constexpr int C8 = CS / 8;
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
@@ -101,65 +103,86 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_strip_kernel(const uint16_
             if (c < n_chunks) *reinterpret_cast<uint4 *>(patch + (c / C8) * PS + (c % C8) * 8) = preg[q];
         }
     };
-    // weight tile of (tap, slice): WROWS rows of CS elements = WROWS * C8 pieces, <= 2 per thread
+    // weight tile of (tap, slice): WROWS rows of CS elements = WROWS * C8 pieces, <= 2 per thread.  Tiles are requested TWO taps
+    // ahead into alternating register sets (plain loads stay in flight across the barriers) and written to the other LDS buffer
+    // one tap ahead: a tap of few MFMAs (small MT) does not wait for an L2 round trip.
     constexpr int W_CHUNKS = WROWS * C8, W_PER = (W_CHUNKS + CD_THREADS - 1) / CD_THREADS;
-    uint4 wreg[W_PER];
-    auto fetch_w = [&](int tap, int cs) {
+    uint4 wreg[2][W_PER];
+    const int n_slices = c_in / CS, n_taps = n_slices * 9;
+    auto fetch_w = [&](int set, int g) {                       // g = linear tap index: slice g / 9, tap g % 9
+        const int cs = g / 9, tap = g - cs * 9;
         const uint16_t *src = wp + ((int64_t)tap * c_out + co0) * c_in + cs * CS;
 #pragma unroll
         for (int q = 0; q < W_PER; ++q) {
             const int c = (W_CHUNKS % CD_THREADS) ? min(threadIdx.x + q * CD_THREADS, W_CHUNKS - 1) : threadIdx.x + q * CD_THREADS;
-            wreg[q] = *reinterpret_cast<const uint4 *>(src + (int64_t)(c / C8) * c_in + (c % C8) * 8);   // clamped, never masked
+            wreg[set][q] = *reinterpret_cast<const uint4 *>(src + (int64_t)(c / C8) * c_in + (c % C8) * 8);   // clamped, never masked
         }
     };
-    auto write_w = [&](int buf) {
-        uint16_t *dst = wbuf + buf * WROWS * PS;
+    auto write_w = [&](uint16_t *dst, int set) {
 #pragma unroll
         for (int q = 0; q < W_PER; ++q) {
             const int c = threadIdx.x + q * CD_THREADS;
-            if (c < W_CHUNKS) *reinterpret_cast<uint4 *>(dst + (c / C8) * PS + (c % C8) * 8) = wreg[q];
+            if (c < W_CHUNKS) *reinterpret_cast<uint4 *>(dst + (c / C8) * PS + (c % C8) * 8) = wreg[set][q];
         }
     };
 
-    const int n_slices = c_in / CS;
     fetch_patch(0);
     fetch_w(0, 0);
-    int buf = 0;
+    if (n_taps > 1) fetch_w(1, 1);
+    uint16_t *wb0 = wbuf, *wb1 = wbuf + WROWS * PS;             // buffer of the even / odd taps of the current slice
+    write_w(wb0, 0);                                           // tap 0 (nobody reads LDS yet)
     for (int cs = 0; cs < n_slices; ++cs) {
-        __syncthreads();                                       // every wave is done with the previous slice's patch and weight tiles
+        __syncthreads();                                       // every wave is done with the previous slice's patch
         write_patch();
-        write_w(buf);
+#ifndef CD_EXP_NOPATCHPF
         if (cs + 1 < n_slices) fetch_patch(cs + 1);            // in flight during the nine taps below
+#endif
+#pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            // the next weight tile: tap + 1 of this slice, or tap 0 of the next one
-            const bool more = tap < 8 || cs + 1 < n_slices;
-            if (more) fetch_w(tap < 8 ? tap + 1 : 0, tap < 8 ? cs : cs + 1);
-            __syncthreads();                                   // buffer `buf` (and, at tap 0, the patch) is visible
-            const uint16_t *wb = wbuf + buf * WROWS * PS + (ng * 64 + lp) * PS + lh * 8;
+            const int g = cs * 9 + tap;
+            uint16_t *cur = (tap & 1) ? wb1 : wb0, *other = (tap & 1) ? wb0 : wb1;
+#ifndef CD_EXP_NOBARRIER
+            __syncthreads();                                   // buffer `cur` (and, at tap 0, the patch) is visible
+#endif
+#ifndef CD_EXP_NOWFETCH
+            if (g + 2 < n_taps) fetch_w(tap & 1, g + 2);       // set (tap & 1) held tap g: already in LDS
+#endif
+            const uint16_t *wb = cur + (ng * 64 + lp) * PS + lh * 8;
             const int toff = ((tap / 3) * pw + tap % 3) * PS + lh * 8;
             constexpr int KC = CS / 16;
-            bf16x8_t fa[2][2], fb[2][MT];
+            constexpr int FB = MT >= 3 ? 1 : 2;                // fragment sets: the 3-tile waves have no registers for a second one
+            bf16x8_t fa[FB][2], fb[FB][MT];
             auto load = [&](int slot, int kc) {
 #pragma unroll
                 for (int n = 0; n < 2; ++n) fa[slot][n] = *reinterpret_cast<const bf16x8_t *>(wb + n * 32 * PS + kc * 16);
 #pragma unroll
                 for (int j = 0; j < MT; ++j) fb[slot][j] = *reinterpret_cast<const bf16x8_t *>(patch + poff[j] + toff + kc * 16);
             };
-            load(0, 0);
+            if (FB == 2) load(0, 0);
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc) {
-                if (kc + 1 < KC) load((kc + 1) & 1, kc + 1);   // fragments of the next step in flight under this step's MFMAs
+                if (FB == 1) load(0, kc);
+                else if (kc + 1 < KC) load((kc + 1) & 1, kc + 1);   // fragments of the next step in flight under this step's MFMAs
 #pragma unroll
                 for (int j = 0; j < MT; ++j)
 #pragma unroll
                     for (int n = 0; n < 2; ++n)
-                        acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kc & 1][n], fb[kc & 1][j], acc[j][n], 0, 0, 0);
+#ifndef CD_EXP_NOMFMA
+                        acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kc & (FB - 1)][n], fb[kc & (FB - 1)][j], acc[j][n], 0, 0, 0);
+#else
+                        acc[j][n][0] += (float)fa[kc & (FB - 1)][n][0] * (float)fb[kc & (FB - 1)][j][0];
+#endif
             }
-            if (tap < 8) write_w(buf ^ 1);                     // the other buffer: its last readers passed the barrier above
-            if (tap < 8) buf ^= 1;
+#ifndef CD_EXP_NOWWRITE
+            if (g + 1 < n_taps) write_w(other, (tap + 1) & 1);   // tap g + 1 (requested two taps ago) into the buffer tap g - 1 used
+#endif
         }
-        // tap 0 of the next slice is in wreg; it is written after the barrier at the top of the loop (the patch changes there too)
-        buf ^= 1;
+        // nine taps per slice: the next slice's tap 0 sits in register set 1 / goes to the odd buffer -- swap the roles (a few moves)
+        {
+            uint16_t *t = wb0; wb0 = wb1; wb1 = t;
+#pragma unroll
+            for (int q = 0; q < W_PER; ++q) { const uint4 v = wreg[0][q]; wreg[0][q] = wreg[1][q]; wreg[1][q] = v; }
+        }
     }
 
     // epilogue: lane = pixel, register quad g of tile n = channels n*32 + 8g + 4*lh .. +3 of this wave's 64
@@ -185,75 +208,96 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_strip_kernel(const uint16_
     }
 }
 
-// rows of the strip for an image width: as many as the wave layout covers (32 * MT * MG pixels), the thread-carried patch pieces
-// allow, and LDS holds next to the two weight buffers
-template <int CS, int NG>
-static int conv_strip_rows(int h, int w, size_t *lds_bytes)
+// Tiling of a layer: NG (64-channel groups per workgroup: 2 -> 4 pixel groups of waves, 1 -> 8), MT (32-pixel tiles per wave) and the
+// strip height.  Every wave runs MT x 2 accumulator tiles over the whole K, so a workgroup's time goes with MT; the launch takes
+// ceil(blocks / 256 CUs) rounds of it (LDS leaves one workgroup per CU).  Pick the cheapest rounds x MT; among equals the larger MT
+// (the weight tiles staged per tap are shared by more work), then fewer padded tiles.
+struct ConvStripPlan { int cs, ng, mt, rows, strips, co_groups; size_t lds; int64_t blocks; };
+
+static bool conv_strip_fits(int cs, int ng, int rows, int w, size_t *lds)
 {
-    constexpr int PS = CS + 8;
-    const int max_px = NG == 2 ? 384 : 512;
-    int rows = max_px / w;
-    if (rows > h) rows = h;
-    while (rows >= 1) {
-        const int pp = (rows + 2) * (w + 2);
-        const size_t lds = ((size_t)pp + 2 * NG * 64) * PS * sizeof(uint16_t);
-        if (pp * (CS / 8) <= CD_THREADS * CD_PCH && lds <= 160 * 1024) {
-            *lds_bytes = lds;
-            return rows;
-        }
-        --rows;
-    }
-    return 0;
+    const int pp = (rows + 2) * (w + 2);
+    *lds = ((size_t)pp + 2 * ng * 64) * (cs + 8) * sizeof(uint16_t);
+    return pp * (cs / 8) <= CD_THREADS * CD_PCH && *lds <= 160 * 1024;
 }
 
-template <int CS, int NG>
-static int conv_strip_launch(const uint16_t *in, const uint16_t *in_mask, const uint16_t *wp, const float *bias, uint16_t *out, int n_img, int h,
-                             int w, int c_in, int c_out, int relu, hipStream_t st)
+static bool conv_strip_plan(int n_img, int h, int w, int c_in, int c_out, ConvStripPlan *best)
 {
-    size_t lds = 0;
-    const int rows = conv_strip_rows<CS, NG>(h, w, &lds);
-    if (rows < 1) return PCACC_E_ARG;
-    const int strips = (h + rows - 1) / rows, co_groups = c_out / (NG * 64);
-    auto kern = conv3x3_strip_kernel<CS, NG>;
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (c_in < 128 || c_in % 64 || c_out < 64 || c_out % 64 || h < 1 || w < 1) return false;
+    bool found = false;
+    int64_t best_cost = 0, best_waste = 0;
+    for (int ng = 2; ng >= 1; --ng) {
+        if (c_out % (64 * ng)) continue;
+        const int mg = ng == 2 ? 4 : 8;
+        for (int mt = 3; mt >= 1; --mt) {
+            if (ng == 1 && mt > 2) continue;                   // instantiated: NG = 2 with MT 1..3, NG = 1 with MT 1..2
+            int rows = mg * mt * 32 / w;
+            if (rows > h) rows = h;
+            for (int cs = 64; cs >= 32; cs -= 32) {
+                size_t lds;
+                int r = rows;
+                while (r >= 1 && !conv_strip_fits(cs, ng, r, w, &lds)) --r;
+                if (r < 1) continue;
+                const int strips = (h + r - 1) / r;            // balance the strips: the same count with the least height
+                r = (h + strips - 1) / strips;
+                if (!conv_strip_fits(cs, ng, r, w, &lds)) continue;
+                const int tiles = (r * w + 31) / 32;
+                if (mt > 1 && tiles <= mg * (mt - 1)) break;   // a smaller MT covers this strip
+                const int64_t blocks = (int64_t)n_img * strips * (c_out / (64 * ng));
+                const int64_t rounds = (blocks + PCACC_CUS - 1) / PCACC_CUS;
+                // a tap of one tile per wave is bound by its weight tile's arrival, not by its 8 MFMAs: price it like 1.5 tiles
+                const int64_t cost = rounds * (mt == 1 ? 3 : 2 * mt) * (cs == 64 ? 16 : 17);   // 32-channel slices: twice the barriers
+                const int64_t waste = (int64_t)mg * mt * 32 * strips - (int64_t)h * w;
+                if (!found || cost < best_cost || (cost == best_cost && mt > best->mt) ||
+                    (cost == best_cost && mt == best->mt && waste < best_waste)) {
+                    found = true;
+                    best_cost = cost;
+                    best_waste = waste;
+                    *best = ConvStripPlan{cs, ng, mt, r, strips, c_out / (64 * ng), lds, blocks};
+                }
+                break;                                         // the widest slice that fits is the one to use for this (ng, mt)
+            }
+        }
+    }
+    return found;
+}
+
+template <int CS, int NG, int MT>
+static int conv_strip_launch(const ConvStripPlan &p, const uint16_t *in, const uint16_t *in_mask, const uint16_t *wp, const float *bias,
+                             uint16_t *out, int n_img, int h, int w, int c_in, int c_out, int relu, hipStream_t st)
+{
+    auto kern = conv3x3_strip_kernel<CS, NG, MT>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds) != hipSuccess)
         return PCACC_E_LAUNCH;
-    const int64_t blocks = (int64_t)n_img * strips * co_groups;
-    if (blocks > 0x7fffffff) return PCACC_E_ARG;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(CD_THREADS), lds, st, in, in_mask, wp, bias, out, n_img, h, w, c_in, c_out, relu,
-                       rows, strips, co_groups);
+    if (p.blocks > 0x7fffffff) return PCACC_E_ARG;
+    hipLaunchKernelGGL(kern, dim3((unsigned)p.blocks), dim3(CD_THREADS), p.lds, st, in, in_mask, wp, bias, out, n_img, h, w, c_in, c_out, relu,
+                       p.rows, p.strips, p.co_groups);
     PCACC_CHECK_LAUNCH();
     return 0;
 }
 
 // Which layers take this kernel: deep K (c_in >= 128 in steps of 64), output channels in groups of 64, images narrow enough for a
-// strip of >= 1 row (W <= 510).  conv.hip keeps the c_in <= 64 layers (weights resident in LDS) and the 3x3x3 stack.
+// strip of >= 1 row.  conv.hip keeps the c_in <= 64 layers (weights resident in LDS) and the 3x3x3 stack.
 extern "C" int pcacc_conv3x3_deep_supported(int32_t h, int32_t w, int32_t c_in, int32_t c_out)
 {
-    size_t lds;
-    if (c_in < 128 || c_in % 64 || c_out < 64 || c_out % 64 || h < 1 || w < 1) return 0;
-    if (w <= 384 / 2) return (c_out % 128 == 0 ? conv_strip_rows<64, 2>(h, w, &lds) : conv_strip_rows<64, 1>(h, w, &lds)) >= 1;
-    return (c_out % 128 == 0 ? conv_strip_rows<32, 2>(h, w, &lds) : conv_strip_rows<32, 1>(h, w, &lds)) >= 1;
+    ConvStripPlan p;
+    return conv_strip_plan(1, h, w, c_in, c_out, &p) ? 1 : 0;
 }
 
 extern "C" int pcacc_conv3x3_deep_bf16(const uint16_t *in, const uint16_t *in_mask, const uint16_t *wp, const float *bias, uint16_t *out,
                                        int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t relu, void *stream)
 {
-    if (!in || !wp || !out || n_img < 1 || !pcacc_conv3x3_deep_supported(h, w, c_in, c_out)) return PCACC_E_ARG;
+    ConvStripPlan p;
+    if (!in || !wp || !out || n_img < 1 || !conv_strip_plan(n_img, h, w, c_in, c_out, &p)) return PCACC_E_ARG;
+    if (getenv("PCACC_CONV_PLAN")) fprintf(stderr, "conv plan %dx%d %d->%d n=%d: cs=%d ng=%d mt=%d rows=%d blocks=%lld\n", h, w, c_in, c_out, n_img, p.cs, p.ng, p.mt, p.rows, (long long)p.blocks);
     hipStream_t st = pcacc_stream(stream);
-    const bool wide = w > 384 / 2;                             // one-row strips of wide images: 32-channel slices keep the patch in LDS
-    if (c_out % 128 == 0) {
-        // few, large workgroups leave CUs idle on the smallest layers: halve the channel group when that fills more of the chip
-        size_t lds;
-        const int rows = wide ? conv_strip_rows<32, 2>(h, w, &lds) : conv_strip_rows<64, 2>(h, w, &lds);
-        const int64_t blocks = (int64_t)n_img * ((h + rows - 1) / rows) * (c_out / 128);
-        if (blocks * 2 <= PCACC_CUS)
-            return wide ? conv_strip_launch<32, 1>(in, in_mask, wp, bias, out, n_img, h, w, c_in, c_out, relu, st)
-                        : conv_strip_launch<64, 1>(in, in_mask, wp, bias, out, n_img, h, w, c_in, c_out, relu, st);
-        return wide ? conv_strip_launch<32, 2>(in, in_mask, wp, bias, out, n_img, h, w, c_in, c_out, relu, st)
-                    : conv_strip_launch<64, 2>(in, in_mask, wp, bias, out, n_img, h, w, c_in, c_out, relu, st);
-    }
-    return wide ? conv_strip_launch<32, 1>(in, in_mask, wp, bias, out, n_img, h, w, c_in, c_out, relu, st)
-                : conv_strip_launch<64, 1>(in, in_mask, wp, bias, out, n_img, h, w, c_in, c_out, relu, st);
+#define CD_CASE(CSV, NGV, MTV) \
+    if (p.cs == CSV && p.ng == NGV && p.mt == MTV) \
+        return conv_strip_launch<CSV, NGV, MTV>(p, in, in_mask, wp, bias, out, n_img, h, w, c_in, c_out, relu, st)
+    CD_CASE(64, 2, 1); CD_CASE(64, 2, 2); CD_CASE(64, 2, 3); CD_CASE(64, 1, 1); CD_CASE(64, 1, 2);
+    CD_CASE(32, 2, 1); CD_CASE(32, 2, 2); CD_CASE(32, 2, 3); CD_CASE(32, 1, 1); CD_CASE(32, 1, 2);
+#undef CD_CASE
+    return PCACC_E_ARG;
 }
 
 // ---- weight gradient of the deep layers ---------------------------------------------------------------------------------------------
