@@ -367,13 +367,11 @@ int pcacc_conv3x3_deep_bf16(const uint16_t *in, const uint16_t *in_mask, const u
                             int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t relu, void *stream);
 /* ReLU backward fused into the consumers of the gradient: `in_mask` / `dy_mask` (NULL = none) is the forward OUTPUT of the ReLU layer
  * whose gradient `in` / `dy` is, same shape; elements where it is not > 0 are read as zero (aten::threshold_backward on the fly, no
- * separate pass over the gradient map). */
+ * separate pass over the gradient map).  Deep layers only (pcacc_conv3x3_deep_supported / pcacc_conv3x3_wgrad_deep_supported): they
+ * are MFMA-bound, the second read is free; PCACC_E_ARG for a mask on any other shape. */
 int pcacc_conv3x3_masked_bf16(const uint16_t *in, const uint16_t *in_mask, const uint16_t *wp, const float *bias, uint16_t *out,
                               int32_t n_img, int32_t frames, int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t kt,
                               int32_t relu, void *stream);
-int pcacc_conv3x3_wgrad_masked_bf16(const uint16_t *dy, const uint16_t *dy_mask, const uint16_t *x, float *dw, int32_t n_img,
-                                    int32_t frames, int32_t dt, int32_t h, int32_t w, int32_t c_in, int32_t c_out, void *workspace,
-                                    size_t workspace_bytes, void *stream);
 /* Weight gradient of the same deep layers (c_in, c_out multiples of 64, at least one of them > 64; kt = 1): dw [c_out][9][c_in] f32 and
  * db [c_out] f32 = bias gradient, from dy [n_img,h,w,c_out] and x [n_img,h,w,c_in] (bf16, channels-last).  64 x 64 blocks of the weight
  * tensor per workgroup, strips of consecutive pixels, per-workgroup partial slots in the workspace + a reduce launch. */

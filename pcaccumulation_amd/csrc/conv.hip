@@ -146,8 +146,7 @@ __device__ __forceinline__ void conv_store_tile(const f32x16_t (&acc)[2][CT], co
 // ---- the convolution ------------------------------------------------------------------------------------------------------------
 // CT = output-channel tiles of 32 per workgroup (1, 2 or 4); CS = input channels resident in LDS at a time (32, 64, 128).
 template <int CT, int CS>
-__global__ __launch_bounds__(CV_THREADS) void conv3x3_mfma_kernel(const uint16_t *__restrict__ in, const uint16_t *__restrict__ in_mask,
-                                                                  const uint16_t *__restrict__ wp,
+__global__ __launch_bounds__(CV_THREADS) void conv3x3_mfma_kernel(const uint16_t *__restrict__ in, const uint16_t *__restrict__ wp,
                                                                   const float *__restrict__ bias, uint16_t *__restrict__ out,
                                                                   int n_img, int frames, int h, int w, int c_in, int c_out, int kt,
                                                                   int relu, int tiles_x, int tiles_y, int co_groups)
@@ -187,7 +186,6 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_mfma_kernel(const uint16_t
         const int dt = kt == 3 ? f - 1 : 0;
         if (t_frame + dt < 0 || t_frame + dt >= frames) continue;               // uniform: a missing frame contributes zeros
         const uint16_t *src = in + (int64_t)(img + dt) * h * w * c_in;
-        const uint16_t *msrc = in_mask ? in_mask + (int64_t)(img + dt) * h * w * c_in : nullptr;
         for (int cs = 0; cs < n_slices; ++cs) {
             __syncthreads();                                                     // the previous pass is done with the patch
             for (int c = threadIdx.x; c < P_CHUNKS; c += CV_THREADS) {
@@ -195,10 +193,8 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_mfma_kernel(const uint16_t
                 const int py = px / CV_PW, pxx = px % CV_PW;
                 const int y = y0 - 1 + py, x = x0 - 1 + pxx;
                 uint4 v = make_uint4(0, 0, 0, 0);
-                if (y >= 0 && y < h && x >= 0 && x < w) {
+                if (y >= 0 && y < h && x >= 0 && x < w)
                     v = *reinterpret_cast<const uint4 *>(src + ((int64_t)y * w + x) * c_in + cs * CS + c8 * 8);
-                    if (msrc) v = pcacc_relu_mask8(v, *reinterpret_cast<const uint4 *>(msrc + ((int64_t)y * w + x) * c_in + cs * CS + c8 * 8));
-                }
                 *reinterpret_cast<uint4 *>(patch + px * PS + c8 * 8) = v;
             }
             const uint16_t *wsrc = wp + ((int64_t)f * 9 * c_out + co0) * c_in + cs * CS;   // tap 0 of this frame tap
@@ -288,8 +284,7 @@ __device__ __forceinline__ void conv_pass_mfma(f32x16_t (&acc)[R][CT], const uin
 // wave's epilogue / staging run under another's MFMAs.
 template <int CT, int CS, int R, int CTW>
 __global__ __launch_bounds__(64 * (8 / R) * (CT / CTW)) void conv3x3_resident_kernel(
-    const uint16_t *__restrict__ in, const uint16_t *__restrict__ in_mask, const uint16_t *__restrict__ wp, const float *__restrict__ bias,
-    uint16_t *__restrict__ out,
+    const uint16_t *__restrict__ in, const uint16_t *__restrict__ wp, const float *__restrict__ bias, uint16_t *__restrict__ out,
     int n_img, int frames, int h, int w, int c_out, int kt, int relu, int tiles_x, int tiles_y, int co_groups)
 {
     constexpr int THREADS = 64 * (8 / R) * (CT / CTW);
@@ -343,16 +338,12 @@ __global__ __launch_bounds__(64 * (8 / R) * (CT / CTW)) void conv3x3_resident_ke
         const int img = tile / (tiles_y * tiles_x) + (kt == 3 ? f - 1 : 0);
         const int rem = tile % (tiles_y * tiles_x);
         const int y0 = (rem / tiles_x) * CV_TH, x0 = (rem % tiles_x) * CV_TW;
-        const int64_t origin = ((int64_t)img * h * w + (int64_t)y0 * w + x0) * CS;
-        const uint16_t *src = in + origin;
+        const uint16_t *src = in + ((int64_t)img * h * w + (int64_t)y0 * w + x0) * CS;
 #pragma unroll
         for (int q = 0; q < P_PER_THREAD; ++q) {
             const int y = y0 - 1 + (p_yx[q] >> 8), x = x0 - 1 + (p_yx[q] & 0xff);
             uint4 v = make_uint4(0, 0, 0, 0);
-            if ((unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w) {
-                v = *reinterpret_cast<const uint4 *>(src + p_off[q]);
-                if (in_mask) v = pcacc_relu_mask8(v, *reinterpret_cast<const uint4 *>(in_mask + origin + p_off[q]));   // uniform branch
-            }
+            if ((unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w) v = *reinterpret_cast<const uint4 *>(src + p_off[q]);
             preg[q] = v;
         }
     };
@@ -412,8 +403,8 @@ __global__ __launch_bounds__(64 * (8 / R) * (CT / CTW)) void conv3x3_resident_ke
 }
 
 template <int CT, int CS, int R, int CTW>
-static int conv_launch_resident(const uint16_t *in, const uint16_t *in_mask, const uint16_t *wp, const float *bias, uint16_t *out, int n_img,
-                                int frames, int h, int w, int c_out, int kt, int relu, hipStream_t st)
+static int conv_launch_resident(const uint16_t *in, const uint16_t *wp, const float *bias, uint16_t *out, int n_img, int frames, int h,
+                                int w, int c_out, int kt, int relu, hipStream_t st)
 {
     constexpr int THREADS = 64 * (8 / R) * (CT / CTW);
     const int tiles_x = (w + CV_TW - 1) / CV_TW, tiles_y = (h + CV_TH - 1) / CV_TH;
@@ -433,15 +424,15 @@ static int conv_launch_resident(const uint16_t *in, const uint16_t *in_mask, con
     if (slots > need) slots = need;
     if (slots < 1) slots = 1;
     const unsigned grid = (unsigned)(8 * co_groups * slots);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, st, in, in_mask, wp, bias, out, n_img, frames, h, w, c_out, kt, relu, tiles_x,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, st, in, wp, bias, out, n_img, frames, h, w, c_out, kt, relu, tiles_x,
                        tiles_y, co_groups);
     PCACC_CHECK_LAUNCH();
     return 0;
 }
 
 template <int CT, int CS>
-static int conv_launch(const uint16_t *in, const uint16_t *in_mask, const uint16_t *wp, const float *bias, uint16_t *out, int n_img, int frames,
-                       int h, int w, int c_in, int c_out, int kt, int relu, hipStream_t st)
+static int conv_launch(const uint16_t *in, const uint16_t *wp, const float *bias, uint16_t *out, int n_img, int frames, int h, int w,
+                       int c_in, int c_out, int kt, int relu, hipStream_t st)
 {
     const int tiles_x = (w + CV_TW - 1) / CV_TW, tiles_y = (h + CV_TH - 1) / CV_TH;
     const int co_groups = c_out / (CT * 32);
@@ -453,8 +444,8 @@ static int conv_launch(const uint16_t *in, const uint16_t *in_mask, const uint16
     }
     const int64_t blocks = (int64_t)n_img * tiles_y * tiles_x * co_groups;
     if (blocks > 0x7fffffff) return PCACC_E_ARG;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(CV_THREADS), lds, st, in, in_mask, wp, bias, out, n_img, frames, h, w, c_in, c_out,
-                       kt, relu, tiles_x, tiles_y, co_groups);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(CV_THREADS), lds, st, in, wp, bias, out, n_img, frames, h, w, c_in, c_out, kt,
+                       relu, tiles_x, tiles_y, co_groups);
     PCACC_CHECK_LAUNCH();
     return 0;
 }
@@ -462,13 +453,6 @@ static int conv_launch(const uint16_t *in, const uint16_t *in_mask, const uint16
 extern "C" int pcacc_conv3x3_bf16(const uint16_t *in, const uint16_t *wp, const float *bias, uint16_t *out, int32_t n_img,
                                   int32_t frames, int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t kt, int32_t relu,
                                   void *stream)
-{
-    return pcacc_conv3x3_masked_bf16(in, nullptr, wp, bias, out, n_img, frames, h, w, c_in, c_out, kt, relu, stream);
-}
-
-extern "C" int pcacc_conv3x3_masked_bf16(const uint16_t *in, const uint16_t *in_mask, const uint16_t *wp, const float *bias, uint16_t *out,
-                                         int32_t n_img, int32_t frames, int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t kt,
-                                         int32_t relu, void *stream)
 {
     if (!in || !wp || !out || n_img < 1 || h < 1 || w < 1 || (kt != 1 && kt != 3) || frames < 1 || n_img % frames) return PCACC_E_ARG;
     if (c_in % 32 || c_out % 32 || c_in < 32 || c_out < 32) return PCACC_E_ARG;
@@ -481,7 +465,7 @@ extern "C" int pcacc_conv3x3_masked_bf16(const uint16_t *in, const uint16_t *in_
             if (lds > 150 * 1024) continue;
             const bool alone = lds > 80 * 1024;                    // one workgroup per CU: run it with 8 waves
 #define CV_RES(CTV, CSV, RV, CTWV) \
-    return conv_launch_resident<CTV, CSV, RV, CTWV>(in, in_mask, wp, bias, out, n_img, frames, h, w, c_out, kt, relu, st)
+    return conv_launch_resident<CTV, CSV, RV, CTWV>(in, wp, bias, out, n_img, frames, h, w, c_out, kt, relu, st)
             if (c_in == 32 && ctr == 1) { if (alone) CV_RES(1, 32, 1, 1); CV_RES(1, 32, 2, 1); }
             if (c_in == 32 && ctr == 2) { if (alone) CV_RES(2, 32, 2, 1); CV_RES(2, 32, 2, 2); }
             if (c_in == 32 && ctr == 4) { CV_RES(4, 32, 2, 2); }
@@ -492,16 +476,27 @@ extern "C" int pcacc_conv3x3_masked_bf16(const uint16_t *in, const uint16_t *in_
     }
     // deep layers on small images: strips of consecutive pixels, K-deep tiling (conv_deep.hip)
     if (kt == 1 && pcacc_conv3x3_deep_supported(h, w, c_in, c_out))
-        return pcacc_conv3x3_deep_bf16(in, in_mask, wp, bias, out, n_img, h, w, c_in, c_out, relu, stream);
+        return pcacc_conv3x3_deep_bf16(in, nullptr, wp, bias, out, n_img, h, w, c_in, c_out, relu, stream);
     const int cs_sel = c_in % 128 == 0 ? 128 : (c_in % 64 == 0 ? 64 : 32);   // input channels per LDS pass
     const int ct = c_out % 128 == 0 ? 4 : (c_out % 64 == 0 ? 2 : 1);
 #define CV_CASE(CTV, CSV) \
-    if (ct == CTV && cs_sel == CSV) return conv_launch<CTV, CSV>(in, in_mask, wp, bias, out, n_img, frames, h, w, c_in, c_out, kt, relu, st)
+    if (ct == CTV && cs_sel == CSV) return conv_launch<CTV, CSV>(in, wp, bias, out, n_img, frames, h, w, c_in, c_out, kt, relu, st)
     CV_CASE(1, 32); CV_CASE(2, 32); CV_CASE(4, 32);
     CV_CASE(1, 64); CV_CASE(2, 64); CV_CASE(4, 64);
     CV_CASE(1, 128); CV_CASE(2, 128); CV_CASE(4, 128);
 #undef CV_CASE
     return PCACC_E_ARG;
+}
+
+// ReLU backward fused into the consumer of the gradient: only the deep (MFMA-bound) layers take it, where the second read is free.
+// The c_in <= 64 layers are HBM-bound: reading the mask next to the gradient in both consumers costs what the separate pass costs.
+extern "C" int pcacc_conv3x3_masked_bf16(const uint16_t *in, const uint16_t *in_mask, const uint16_t *wp, const float *bias, uint16_t *out,
+                                         int32_t n_img, int32_t frames, int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t kt,
+                                         int32_t relu, void *stream)
+{
+    if (!in_mask) return pcacc_conv3x3_bf16(in, wp, bias, out, n_img, frames, h, w, c_in, c_out, kt, relu, stream);
+    if (kt != 1 || !pcacc_conv3x3_deep_supported(h, w, c_in, c_out)) return PCACC_E_ARG;
+    return pcacc_conv3x3_deep_bf16(in, in_mask, wp, bias, out, n_img, h, w, c_in, c_out, relu, stream);
 }
 
 // ---- weight gradient ------------------------------------------------------------------------------------------------------------
@@ -516,8 +511,8 @@ typedef short cv_s16x4 __attribute__((ext_vector_type(4)));
 union cv_frag { bf16x8_t v; cv_s16x4 h[2]; };
 
 template <int CO_T, int CI_T>
-__global__ __launch_bounds__(CV_THREADS) void conv3x3_wgrad_kernel(const uint16_t *__restrict__ dy, const uint16_t *__restrict__ dy_mask,
-                                                                   const uint16_t *__restrict__ x, float *__restrict__ partial, int n_img, int frames, int dt, int h,
+__global__ __launch_bounds__(CV_THREADS) void conv3x3_wgrad_kernel(const uint16_t *__restrict__ dy, const uint16_t *__restrict__ x,
+                                                                   float *__restrict__ partial, int n_img, int frames, int dt, int h,
                                                                    int w, int tiles_x, int tiles_y)
 {
     constexpr int CO = CO_T * 32, CI = CI_T * 32, PAIRS = CO_T * CI_T, GROUPS = 4 / PAIRS;
@@ -560,10 +555,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_wgrad_kernel(const uint16_
             const int px = c / (CO / 8), c8 = c % (CO / 8);
             const int yy = y0 + px / CV_TW, xx = x0 + px % CV_TW;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (yy < h && xx < w) {
-                v = *reinterpret_cast<const uint4 *>(gsrc + ((int64_t)yy * w + xx) * CO + c8 * 8);
-                if (dy_mask) v = pcacc_relu_mask8(v, *reinterpret_cast<const uint4 *>(dy_mask + (int64_t)img * h * w * CO + ((int64_t)yy * w + xx) * CO + c8 * 8));
-            }
+            if (yy < h && xx < w) v = *reinterpret_cast<const uint4 *>(gsrc + ((int64_t)yy * w + xx) * CO + c8 * 8);
             yreg[q] = v;
         }
         const uint16_t *xsrc = x + (int64_t)(img + dt) * h * w * CI;
@@ -722,13 +714,6 @@ extern "C" int pcacc_conv3x3_wgrad_bf16(const uint16_t *dy, const uint16_t *x, f
                                         int32_t h, int32_t w, int32_t c_in, int32_t c_out, void *workspace, size_t workspace_bytes,
                                         void *stream)
 {
-    return pcacc_conv3x3_wgrad_masked_bf16(dy, nullptr, x, dw, n_img, frames, dt, h, w, c_in, c_out, workspace, workspace_bytes, stream);
-}
-
-extern "C" int pcacc_conv3x3_wgrad_masked_bf16(const uint16_t *dy, const uint16_t *dy_mask, const uint16_t *x, float *dw, int32_t n_img,
-                                               int32_t frames, int32_t dt, int32_t h, int32_t w, int32_t c_in, int32_t c_out,
-                                               void *workspace, size_t workspace_bytes, void *stream)
-{
     if (!dy || !x || !dw || !workspace || n_img < 1 || h < 1 || w < 1 || frames < 1 || n_img % frames || dt < -1 || dt > 1)
         return PCACC_E_ARG;
     if ((c_in != 32 && c_in != 64) || (c_out != 32 && c_out != 64)) return PCACC_E_ARG;
@@ -747,7 +732,7 @@ extern "C" int pcacc_conv3x3_wgrad_masked_bf16(const uint16_t *dy, const uint16_
         if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                                    (int)lds) != hipSuccess)                                                          \
             return PCACC_E_LAUNCH;                                                                                                   \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(CV_THREADS), lds, st, dy, dy_mask, x, partial, n_img, frames, dt, h, w, tiles_x, tiles_y);  \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(CV_THREADS), lds, st, dy, x, partial, n_img, frames, dt, h, w, tiles_x, tiles_y);  \
     } while (0)
     if (c_out == 32 && c_in == 32) CV_WG(1, 1);
     else if (c_out == 32 && c_in == 64) CV_WG(1, 2);

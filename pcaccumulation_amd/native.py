@@ -55,7 +55,7 @@ EXPORTS = [
     'pcacc_frames_max', 'pcacc_frames_max_backward', 'pcacc_rows_linear_cat_bf16', 'pcacc_rows_wgrad_cat_bf16',
     'pcacc_pillar_scatter_timed', 'pcacc_pillar_scatter_t', 'pcacc_timer_create', 'pcacc_timer_elapsed_us', 'pcacc_timer_destroy',
     'pcacc_svd3', 'pcacc_svd3_backward', 'pcacc_conv3x3_deep_supported', 'pcacc_conv3x3_deep_bf16', 'pcacc_conv3x3_prepare_weights_pair',
-    'pcacc_conv3x3_masked_bf16', 'pcacc_conv3x3_wgrad_masked_bf16',
+    'pcacc_conv3x3_masked_bf16',
     'pcacc_conv3x3_wgrad_deep_supported', 'pcacc_conv3x3_wgrad_deep_workspace_bytes', 'pcacc_conv3x3_wgrad_deep_bf16', 'pcacc_bn_rows_workspace_bytes', 'pcacc_bn_rows_forward', 'pcacc_bn_rows_backward',
 ]
 
@@ -530,7 +530,7 @@ def conv3x3_wgrad_supported(c_in, c_out):
     return c_in in (32, 64) and c_out in (32, 64)
 
 
-def conv3x3_wgrad(dy_rows, x_rows, frames=1, dt=0, mask=None):
+def conv3x3_wgrad(dy_rows, x_rows, frames=1, dt=0):
     """dy_rows [n_img,h,w,c_out], x_rows [n_img,h,w,c_in] bf16 -> (dw [c_out, 9, c_in] f32, db [c_out] f32) for frame tap dt of a
     kt=3 layer (db is the full bias gradient for dt = 0)."""
     n_img, h, w, c_out = dy_rows.shape
@@ -540,9 +540,9 @@ def conv3x3_wgrad(dy_rows, x_rows, frames=1, dt=0, mask=None):
     _check(lib().pcacc_conv3x3_wgrad_workspace_bytes(int(n_img), int(h), int(w), int(c_in), int(c_out), ctypes.byref(need)),
            'conv3x3_wgrad_workspace')
     ws = _ws(need.value, dy_rows.device)
-    _check(lib().pcacc_conv3x3_wgrad_masked_bf16(_dev(dy_rows, torch.bfloat16, 'dy'), _dev(mask, torch.bfloat16, 'mask') if mask is not None else None,
-                                                 _dev(x_rows, torch.bfloat16, 'x'), _dev(dw), int(n_img), int(frames), int(dt), int(h), int(w),
-                                                 int(c_in), int(c_out), _dev(ws), ctypes.c_size_t(ws.numel()), _stream()), 'conv3x3_wgrad')
+    _check(lib().pcacc_conv3x3_wgrad_bf16(_dev(dy_rows, torch.bfloat16, 'dy'), _dev(x_rows, torch.bfloat16, 'x'), _dev(dw), int(n_img),
+                                          int(frames), int(dt), int(h), int(w), int(c_in), int(c_out), _dev(ws),
+                                          ctypes.c_size_t(ws.numel()), _stream()), 'conv3x3_wgrad')
     return dw[:c_out * 9 * c_in].view(c_out, 9, c_in), dw[c_out * 9 * c_in:]
 
 

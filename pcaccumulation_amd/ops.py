@@ -514,27 +514,28 @@ class _Conv3x3(torch.autograd.Function):
         h, w = x_rows.shape[1], x_rows.shape[2]
         need_w = ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2])
         lib_dgrad = ctx.needs_input_grad[0] and kt == 1 and not conv3x3_preferred(o, i, h, w)      # data gradient: channels exchanged
-        own_w = need_w and (native.conv3x3_wgrad_supported(i, o) or (kt == 1 and native.conv3x3_wgrad_deep_supported(h, w, i, o)))
-        # ReLU backward: the hand-written kernels zero the gradient where the forward output is <= 0 while they stage it (mask = y);
-        # only a library fallback needs the masked gradient as a tensor of its own
-        mask = y if relu else None
-        if relu and (lib_dgrad or (need_w and not own_w)):
-            gy, mask = torch.ops.aten.threshold_backward(gy, y, 0), None
+        deep_w = need_w and kt == 1 and not native.conv3x3_wgrad_supported(i, o) and native.conv3x3_wgrad_deep_supported(h, w, i, o)
+        deep_d = ctx.needs_input_grad[0] and kt == 1 and o > 64 and native.conv3x3_deep_supported(h, w, o, i)
+        # ReLU backward: the deep (MFMA-bound) kernels zero the gradient where the forward output is <= 0 while they stage it
+        # (mask = y: the second read is free there); every other consumer gets the masked gradient as a tensor of its own
+        mask = y if relu and (deep_w or not need_w) and (deep_d or not ctx.needs_input_grad[0]) else None
+        if relu and mask is None:
+            gy = torch.ops.aten.threshold_backward(gy, y, 0)
         if ctx.needs_input_grad[0] and not lib_dgrad:
             gx = native.conv3x3(gy, prepared_conv_weights(weight)[1], None, frames, False, mask=mask)
         if need_w and native.conv3x3_wgrad_supported(i, o):
             # weight gradient on the matrix cores too (one launch per frame tap); bias gradient = a column sum of dY
             if kt == 3:
-                parts = [native.conv3x3_wgrad(gy, x_rows, frames, dt, mask=mask) for dt in (-1, 0, 1)]
+                parts = [native.conv3x3_wgrad(gy, x_rows, frames, dt) for dt in (-1, 0, 1)]
                 gw = torch.stack([p[0].view(o, 3, 3, i) for p in parts], dim=1).permute(0, 4, 1, 2, 3)    # [o, i, kt, 3, 3]
                 gb = parts[1][1]                                                           # dt = 0 visits every frame
             else:
-                gw, gb = native.conv3x3_wgrad(gy, x_rows, mask=mask)
+                gw, gb = native.conv3x3_wgrad(gy, x_rows)
                 gw = gw.view(o, 3, 3, i).permute(0, 3, 1, 2)
             gw = gw.to(weight.dtype)
             gb = gb.clone() if has_bias and ctx.needs_input_grad[2] else None
             need_w = False
-        elif need_w and own_w:
+        elif deep_w:
             gw, gb = native.conv3x3_wgrad_deep(gy, x_rows, mask=mask)                      # deep layers: 64 x 64 weight blocks, strips
             gw = gw.view(o, 3, 3, i).permute(0, 3, 1, 2).to(weight.dtype)
             gb = gb if has_bias and ctx.needs_input_grad[2] else None
