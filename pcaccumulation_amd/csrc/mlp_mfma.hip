@@ -248,14 +248,16 @@ extern "C" int pcacc_rows_linear_cat_bf16(const uint16_t *xa, const uint16_t *xb
 // Workgroup partials are written to a workspace with plain stores and summed by a second launch: with ~1000 workgroups
 // an atomic per element per workgroup is 17 M same-address atomics for a 128 x 129 gradient, longer than the products.
 // ---------------------------------------------------------------------------------------------------------------------
-#define WG_R 64                    // rows per staged tile
+// Rows per staged tile: 64 for the widest layers (128 features each side: 4 sixteen-byte pieces of dY and of X per thread), more for the
+// narrow ones so that every thread still has 4 + 4 pieces in flight and a barrier pair is paid per 128 / 256 rows instead of per 64
+// (the 32 -> 32 layers of the pillar encoder ran 49 tile iterations of 8 MFMAs each per workgroup: barrier-bound at 3.6 TB/s).
 typedef short wg_s16x4 __attribute__((ext_vector_type(4)));
 union wg_frag { bf16x8_t v; wg_s16x4 h[2]; uint16_t e[8]; };
 
-template <int MAX_TILES>
+template <int MAX_TILES, int WG_R>
 __global__ __launch_bounds__(256) void rows_wgrad_bf16_kernel(const uint16_t *__restrict__ dY, const uint16_t *__restrict__ dy_mask,
                                                               const uint16_t *__restrict__ X, int x_relu, int64_t rows, int K, int N,
-                                                              int k_tiles, int n_tile_total, float *partial, RowPieces xs2)
+                                                              int k_tiles, int n_tile_total, int tiles_par, float *partial, RowPieces xs2)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t wlds[];
     const int NS = N + 4, KS = K + 4;
@@ -345,16 +347,19 @@ __global__ __launch_bounds__(256) void rows_wgrad_bf16_kernel(const uint16_t *__
         // 8 consecutive rows of one column, which is the MFMA operand (k = rows).
         const int g = lane >> 4, li = lane & 15;
         const int tr_row = (g >> 1) * 8 + (li >> 2), tr_col = (g & 1) * 16 + (li & 3) * 4;
+        // few output tiles (tiles_par = 1 or 2 of them in parallel): the waves split the rows of the staged tile instead of idling
+        // (row group = wave / tiles_par; every group keeps its own partial slot)
+        const int rgroups = 4 / tiles_par, rgrp = wave / tiles_par;
+        const int r_lo = rgrp * (WG_R / rgroups), r_hi = r_lo + WG_R / rgroups;
 #pragma unroll
         for (int t = 0; t < MAX_TILES; ++t) {
-            const int tile = wave + 4 * t;                                       // uniform per wave
+            const int tile = wave % tiles_par + tiles_par * t;                   // uniform per wave
             if (tile < n_tile_total) {
                 const int nt = tile / k_tiles, kt = tile % k_tiles;
                 const bool ones = kt * 32 >= K;                                  // the tile that holds the bias column (k == K)
                 const uint16_t *pa = sdy + tr_row * NS + nt * 32 + tr_col;
                 const uint16_t *pb = sx + tr_row * KS + (ones ? 0 : kt * 32) + tr_col;
-#pragma unroll
-                for (int r0 = 0; r0 < WG_R; r0 += 16) {
+                for (int r0 = r_lo; r0 < r_hi; r0 += 16) {
                     wg_frag a, b;
                     a.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_s16x4 __attribute__((address_space(3))) *)(pa + r0 * NS));
                     a.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_s16x4 __attribute__((address_space(3))) *)(pa + (r0 + 4) * NS));
@@ -372,10 +377,10 @@ __global__ __launch_bounds__(256) void rows_wgrad_bf16_kernel(const uint16_t *__
         }
     }
     const int KA = K + 1;
-    float *mine = partial + (int64_t)blockIdx.x * N * KA;
+    float *mine = partial + ((int64_t)blockIdx.x * (4 / tiles_par) + wave / tiles_par) * N * KA;
 #pragma unroll
     for (int t = 0; t < MAX_TILES; ++t) {
-        const int tile = wave + 4 * t;
+        const int tile = wave % tiles_par + tiles_par * t;
         if (tile < n_tile_total) {
             const int nb = (tile / k_tiles) * 32, k = (tile % k_tiles) * 32 + lp;
 #pragma unroll
@@ -406,9 +411,12 @@ __global__ __launch_bounds__(256) void rows_wgrad_reduce_kernel(const float *__r
     if (p1 > p0) atomicAdd(&out[e], (s0 + s1) + (s2 + s3));
 }
 
-static int wgrad_bf16_grid(int64_t rows)
+static int wgrad_bf16_tile_rows(int k, int n) { return k + n <= 64 ? 256 : (k + n <= 128 ? 128 : 64); }
+static int wgrad_bf16_tiles_par(int total) { return total <= 1 ? 1 : (total <= 2 ? 2 : 4); }
+
+static int wgrad_bf16_grid(int64_t rows, int tile_rows)
 {
-    const int64_t n_chunks = (rows + WG_R - 1) / WG_R;
+    const int64_t n_chunks = (rows + tile_rows - 1) / tile_rows;
     int64_t grid = PCACC_CUS * 4;
     return (int)(grid > n_chunks ? n_chunks : grid);
 }
@@ -416,7 +424,8 @@ static int wgrad_bf16_grid(int64_t rows)
 extern "C" int pcacc_rows_wgrad_bf16_workspace_bytes(int64_t rows, int32_t k, int32_t n, size_t *bytes)
 {
     if (!bytes || rows < 0 || k <= 0 || n <= 0) return PCACC_E_ARG;
-    *bytes = (size_t)(rows > 0 ? wgrad_bf16_grid(rows) : 0) * n * (k + 1) * sizeof(float);
+    const int total = ((k + 1 + 31) / 32) * ((n + 31) / 32);
+    *bytes = (size_t)(rows > 0 ? wgrad_bf16_grid(rows, wgrad_bf16_tile_rows(k, n)) : 0) * (4 / wgrad_bf16_tiles_par(total)) * n * (k + 1) * sizeof(float);
     return PCACC_OK;
 }
 
@@ -433,19 +442,20 @@ static int rows_wgrad_bf16_any(const uint16_t *dy, const uint16_t *dy_mask, cons
     const int k_tiles = (k + 1 + 31) / 32, n_tiles = (n + 31) / 32;
     const int total = k_tiles * n_tiles;
     if (total > 24) return PCACC_E_ARG;
-    const int grid = wgrad_bf16_grid(rows);
+    const int tile_rows = wgrad_bf16_tile_rows(k, n), tiles_par = wgrad_bf16_tiles_par(total), parts_per_wg = 4 / tiles_par;
+    const int grid = wgrad_bf16_grid(rows, tile_rows);
     const int elems = n * (k + 1);
-    if (workspace_bytes < (size_t)grid * elems * sizeof(float)) return PCACC_E_WORKSPACE;
+    if (workspace_bytes < (size_t)grid * parts_per_wg * elems * sizeof(float)) return PCACC_E_WORKSPACE;
     float *partial = reinterpret_cast<float *>(workspace);
-    const size_t lds = (size_t)WG_R * (n + 4 + k + 4) * sizeof(uint16_t);
-#define WGB(T) rows_wgrad_bf16_kernel<T><<<grid, 256, lds, st>>>(dy, dy_mask, x, x_relu, rows, k, n, k_tiles, total, partial, xs2)
-    if (total <= 4) WGB(1);
-    else if (total <= 8) WGB(2);
-    else WGB(6);
+    const size_t lds = (size_t)tile_rows * (n + 4 + k + 4) * sizeof(uint16_t);
+#define WGB(T, R) rows_wgrad_bf16_kernel<T, R><<<grid, 256, lds, st>>>(dy, dy_mask, x, x_relu, rows, k, n, k_tiles, total, tiles_par, partial, xs2)
+    if (total <= 4) { if (tile_rows == 256) WGB(1, 256); else if (tile_rows == 128) WGB(1, 128); else WGB(1, 64); }
+    else if (total <= 8) { if (tile_rows == 128) WGB(2, 128); else WGB(2, 64); }
+    else WGB(6, 64);
 #undef WGB
     if (hipMemsetAsync(dw_aug, 0, (size_t)elems * sizeof(float), st) != hipSuccess) return PCACC_E_LAUNCH;
     const int slices = elems >= 8192 ? 16 : 64;                               // ~1000 workgroups in flight either way
-    rows_wgrad_reduce_kernel<<<dim3((elems + 255) / 256, slices), 256, 0, st>>>(partial, grid, elems, dw_aug);
+    rows_wgrad_reduce_kernel<<<dim3((elems + 255) / 256, slices), 256, 0, st>>>(partial, grid * parts_per_wg, elems, dw_aug);
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
 }
