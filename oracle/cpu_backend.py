@@ -34,7 +34,9 @@ def frame_pillars(cell2pillar, cells_per_frame, m):
     c2p = _np(cell2pillar)
     occ = c2p >= 0
     offs = np.concatenate([[0], np.cumsum(occ.reshape(-1, cells_per_frame).sum(1))]).astype(np.int32)
-    return torch.from_numpy(c2p[occ].astype(np.int32)), torch.from_numpy(offs)
+    sp = np.zeros(m, np.int32)                                 # like the HIP binding: [m], entries beyond the occupied-cell count are 0
+    sp[:int(occ.sum())] = c2p[occ]
+    return torch.from_numpy(sp), torch.from_numpy(offs)
 
 
 def csr_build(p2v, m):

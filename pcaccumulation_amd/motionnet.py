@@ -21,7 +21,7 @@ from . import native, ops
 from .alignnet import AlignNet
 from .cluster import Cluster
 from .egomotion import EgoMotionHead
-from .lazy import LazyDict, lazy_scalars
+from .lazy import HostCopy, LazyDict, lazy_scalars
 from .ops import PillarIndex
 from .pillar_encoder import PillarFeatureNet, temporal_ungrid
 from .stpn import STPN
@@ -126,7 +126,6 @@ class MotionNet(nn.Module):
         with self._dense():
             bev_feats = self.unet(bev)
             fb_seg = self.semseg_head(bev_feats)
-            geometric_feats = self.ego_feats_head(bev_feats)
         fb_seg = fb_seg.float()
         results['fb_seg_est'] = fb_seg.view(B, T, 2, Ny, Nx)
         fb_est = (fb_seg[:, 1] > fb_seg[:, 0]).long()                          # argmax, ties -> 0 (motionnet.py:190)
@@ -154,11 +153,20 @@ class MotionNet(nn.Module):
             base = native.upload_small([sum(counts[:b]) for b in range(len(counts))], torch.int64, device)
             merged = input_dict['inst_labels'][:, 0].long() + base[time_indice[:, 0].long()]
             pad_flags = AlignNet.padding_flags(merged, time_indice[:, 1].long(), sum(counts), T, weights=rec_mask)[0]
-        sizes = torch.cat([frame_offsets_dev.long(), bg_cum[frame_offsets_dev.long()], fb_mask.sum()[None],
-                           (rec_mask.sum() if rec_mask is not None else fb_mask.sum())[None]]
-                          + ([pad_flags.reshape(-1).long()] if pad_flags is not None else [])).cpu().tolist()
+        sizes = HostCopy(torch.cat([frame_offsets_dev.long(), bg_cum[frame_offsets_dev.long()], fb_mask.sum()[None],
+                                    (rec_mask.sum() if rec_mask is not None else fb_mask.sum())[None]]
+                                   + ([pad_flags.reshape(-1).long()] if pad_flags is not None else [])))
+        # The ego feature head (two full-resolution convolutions, needed by the ego head only) is queued between the request for the
+        # sizes and the wait for them: the GPU still has work when the host wakes up and starts issuing the ego head's small launches.
+        with self._dense():
+            geometric_feats = self.ego_feats_head(bev_feats)
+        sizes = sizes.numpy().tolist()
         nf = B * T + 1
         frame_offsets, bg_at = sizes[:nf], sizes[nf:2 * nf]
+        if self.cell_ordered_pillars and frame_offsets[-1] != pidx.m:
+            raise ValueError('coordinates: %d pillars but %d occupied cells (duplicate or out-of-range rows); the cell-ordered pillar '
+                             'numbering needs one cell per pillar -- set misc.cell_ordered_pillars = False for such input'
+                             % (pidx.m, frame_offsets[-1]))
         bg_counts = [bg_at[i + 1] - bg_at[i] for i in range(B * T)]
         n_fb, n_rec = int(sizes[2 * nf]), int(sizes[2 * nf + 1])
         if pad_flags is not None:

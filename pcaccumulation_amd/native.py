@@ -135,7 +135,7 @@ def cell_index(coords, nx, ny, nt, n_batch):
 def frame_pillars(cell2pillar, cells_per_frame, m):
     dev = cell2pillar.device
     n_cells = cell2pillar.numel()
-    sorted_p = torch.empty((m,), dtype=torch.int32, device=dev)
+    sorted_p = torch.zeros((m,), dtype=torch.int32, device=dev)      # entries beyond the occupied-cell count (duplicate cells) stay valid ids
     offs = torch.empty((n_cells // cells_per_frame + 1,), dtype=torch.int32, device=dev)
     need = ctypes.c_size_t(0)
     _check(lib().pcacc_frame_pillars_workspace_bytes(_i64(n_cells), ctypes.byref(need)), 'frame_pillars_workspace')

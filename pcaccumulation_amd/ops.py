@@ -19,7 +19,9 @@ class PillarIndex(object):
 
     def __init__(self, coordinates, point_to_voxel_map, batch_size, input_shape, cell_order=False):
         """cell_order=True renumbers the pillars in ascending cell order for everything built here (`coordinates`, `p2v`, `cell`,
-        `cell2pillar`, the CSR; `perm[new id] = id in the caller's numbering`): the voxeliser numbers pillars in first-touch
+        `cell2pillar`, the CSR; `perm[new id] = id in the caller's numbering`).  Precondition: every pillar owns one in-range cell (what
+        the voxeliser guarantees; duplicate or out-of-range rows in `coordinates` would leave ids without a rank) -- MotionNet.forward
+        checks the occupied-cell count against m at its one host sync and raises.  The voxeliser numbers pillars in first-touch
         order of the points (libs/voxel_generator.py:41-58), i.e. randomly with respect to the canvas, which turns every
         pillar <-> canvas transfer (pillar scatter, its backward, the inverse scatter) into random row accesses; in cell
         order they stream.  Nothing per-pillar leaves MotionNet.forward, so the renumbering is invisible outside."""
@@ -39,7 +41,7 @@ class PillarIndex(object):
         if cell_order and self.m > 0:
             sp, offs = native.frame_pillars(self.cell2pillar, self.cells_per_frame, self.m)     # caller's ids in cell order
             spl = sp.long()
-            rank = torch.empty(self.m, dtype=torch.int32, device=sp.device)
+            rank = torch.full((self.m,), -1, dtype=torch.int32, device=sp.device)   # pillars that own no cell keep -1 (see check below)
             rank[spl] = torch.arange(self.m, dtype=torch.int32, device=sp.device)
             self.perm = sp
             self.cell = self.cell[spl].contiguous()                          # ascending

@@ -149,7 +149,26 @@ def _tiny_test_model(dev, golden):
     torch.manual_seed(int(g['fwd_seed']))
     with torch.no_grad():
         out = model(inp)
+    _assert_test_mode_mos_metric(cfg, out, inp, golden)
     return g, out
+
+
+def _assert_test_mode_mos_metric(cfg, out, inp, golden):
+    """SegTrainer.test calls FuseLoss.get_mos_loss on test-mode predictions (libs/tester.py:87); it supervises the points that are
+    foreground in the ground truth OR in the estimate (libs/loss.py:145-147) although the test-mode forward decodes the estimated
+    foreground only -- the index list the forward hands over must not be mistaken for that set."""
+    from pcaccumulation_amd.loss import FuseLoss
+    gl = golden('model_tiny_test_loss')
+    assert int(gl['n_union']) > int(gl['n_est'])                             # the two sets differ on this scene
+    assert '_mos_idx' not in out and '_gtfg_idx' not in out
+    with torch.no_grad():
+        mos = FuseLoss(cfg['loss']).get_mos_loss(out, inp)
+    metric = mos['metric']
+    if torch.is_tensor(metric):
+        metric = {k: metric[i].cpu().numpy() for i, k in enumerate(('intersection', 'union', 'pred_positives', 'gt_positives'))}
+    for k in ('intersection', 'union', 'pred_positives', 'gt_positives'):
+        np.testing.assert_allclose(np.asarray(metric[k], np.float64), gl['mos_' + k], atol=2.5e-3)     # counts / 1e3: a couple of points
+    assert abs(float(mos['bce_loss']) - float(gl['bce_loss'])) < 2e-2 * max(1.0, float(gl['bce_loss']))
 
 
 def _assert_tiny_test(g, out):

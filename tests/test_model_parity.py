@@ -458,3 +458,15 @@ def test_host_logic_seq_pose_modes(double, golden, mode):
 @pytest.mark.parametrize('mode', ['chain', 'full'])
 def test_gpu_seq_pose_modes(golden, mode):
     _seq_pose(torch.device('cuda:0'), golden, mode)
+
+
+def test_host_logic_duplicate_pillars_are_reported(double):
+    """ops.PillarIndex(cell_order=True) needs one cell per pillar: a duplicated coordinate row is reported at the
+    forward's host sync instead of turning into out-of-range gathers."""
+    cfg = default_config('waymo', 'val', n_sweeps=3, xy_range=8)
+    inp = make_batch(cfg, [5], 3, 600)
+    inp['coordinates'][1] = inp['coordinates'][0]
+    model = MotionNet(cfg)
+    fill_state_dict_(model)
+    with torch.no_grad(), pytest.raises(ValueError, match='occupied cells'):
+        model.eval()(inp)
