@@ -93,7 +93,7 @@ def _median(xs):
     return xs[len(xs) // 2] if len(xs) % 2 else 0.5 * (xs[len(xs) // 2 - 1] + xs[len(xs) // 2])
 
 
-def cpu_baseline(cfg, pts_per_frame, budget_s=75.0):
+def cpu_baseline(cfg, pts_per_frame, budget_s=110.0):
     """The same workload on the host cores: product host code + oracle CPU backend (kind 'port'), fp32, one sequence, all host
     threads.  SURVEY 8d: warm second call, 5 repeats, median -- bounded by `budget_s` of CPU work, so the (3x heavier) train step
     gets as many warm repeats as fit (at least one) and the eval forward, the figure the survey timed the reference itself at

@@ -27,10 +27,10 @@ FP32_TOL = dict(ego=1e-3, iou=1e-3, epe=1e-3)
 # (1) On trained weights, against the fp32 product (itself pinned to the reference at 1e-3 above): the bound DESIGN.md section 4 quotes.
 #     Eight held-out scenes; metrics as a validation run reports them (means / summed IoU counters over the scenes) and the worst
 #     single scene.  Measured over repeated runs (the 150 training steps are not bit-reproducible: atomic row sums): worst scene
-#     rotation 0.03-0.20 deg, translation 0.006-0.012 m, EPE 0.004-0.013 m; set-level mos_iou 1e-4-5e-4; foreground flips
-#     0.15-0.3 %.  A flipped pillar changes a frame's background count and with it the key-point draw (torch.randperm(n)), so one
+#     rotation 0.03-0.26 deg, translation 0.006-0.012 m, EPE 0.004-0.013 m; set level: rotation 0.03 deg, translation 1e-3 m, EPE
+#     2e-3 m, mos_iou 1e-4-1e-3; foreground flips 0.02-0.3 %.  A flipped pillar changes a frame's background count and with it the key-point draw (torch.randperm(n)), so one
 #     scene's pose can move by a tenth of a degree while the set mean moves by hundredths.
-BF16_TRAINED_TOL = dict(ego=0.1, ego_scene=0.5, iou=2e-3, epe=3e-2, flips=6e-3)
+BF16_TRAINED_TOL = dict(ego=0.1, ego_scene=0.5, iou=4e-3, epe=3e-2, flips=6e-3)
 # (2) Against the reference's fp32 golden vectors on closed-form (random) weights: bf16 rounding flips 0.1-0.3 % of the foreground
 #     decisions, the background pillar count of a frame changes, torch.randperm(n) (models/egomotion.py:157) draws a different
 #     key-point set and the noise-driven pose of a random-weight model moves by tenths of a degree / up to a metre.  These

@@ -1,0 +1,57 @@
+#!/usr/bin/env python
+"""profiles/rNN_pmc_kernels_summary.json from the counter files of tools/gpu_pmc_kernels.sh (one rocprofv3 --pmc run per counter set).
+Per kernel (mean over its launches): duration, MFMA busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs),
+achieved TFLOP/s from the algorithmic FLOPs, LDS bank-conflict share = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, HBM bytes
+(FETCH_SIZE x2 per MI355X_MICROARCH.md's gfx950 correction + WRITE_SIZE, KiB units).
+Usage: pmc_kernels_summary.py <dir with one sub-directory per counter set> out.json"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+csv.field_size_limit(1 << 30)
+KERNELS = {  # name fragment -> (label, algorithmic FLOPs per launch, algorithmic HBM bytes per launch)
+    'conv3x3_resident_kernel': ('conv 64->64 @288^2 x20 (resident weights)', 2.0 * 20 * 288 * 288 * 64 * 64 * 9, 20 * 288 * 288 * 128 * 2),
+    'conv3x3_strip_kernel': ('conv 256->256 @36^2 x20 (deep, strips)', 2.0 * 20 * 36 * 36 * 256 * 256 * 9, 20 * 36 * 36 * 512 * 2 + 9 * 256 * 256 * 2),
+    'conv3x3_wgrad_kernel': ('conv wgrad 32x32 @288^2 x20', 2.0 * 20 * 288 * 288 * 32 * 32 * 9, 20 * 288 * 288 * 64 * 2),
+    'conv3x3_wgrad_strip_kernel': ('conv wgrad 256x256 @36^2 x20 (deep)', 2.0 * 20 * 36 * 36 * 256 * 256 * 9, 20 * 36 * 36 * 512 * 2),
+    'rows_wgrad_bf16_kernel': ('rows wgrad 32x32, 3.2 M rows', 2.0 * 3.2e6 * 32 * 33, 3.2e6 * 64 * 2),
+    'rows_linear_bf16_kernel': ('rows linear 64->32, 3.2 M rows', 2.0 * 3.2e6 * 64 * 32, 3.2e6 * 96 * 2),
+}
+
+
+def main():
+    root, out = sys.argv[1], sys.argv[2]
+    vals = collections.defaultdict(lambda: collections.defaultdict(list))
+    durs = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(root, '*', '*counter_collection.csv')) + glob.glob(os.path.join(root, '*', '*', '*counter_collection.csv')):
+        for r in csv.DictReader(open(f)):
+            for frag in sorted(KERNELS, key=len, reverse=True):
+                if frag in r['Kernel_Name']:
+                    vals[frag][r['Counter_Name']].append(float(r['Counter_Value']))
+                    durs[frag].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+                    break
+    res = {'source': 'rocprofv3 --pmc (one counter set per run, --kernel-trace) on tools/pmc_kernels.py; durations are those of the counter runs '
+                     '(clocks sit lower under counter collection than in a plain run)'}
+    for frag, (label, flops, hbm) in KERNELS.items():
+        if frag not in vals:
+            continue
+        c = {k: sum(v) / len(v) for k, v in vals[frag].items()}
+        us = sum(durs[frag]) / len(durs[frag])
+        row = {'what': label, 'avg_us_under_pmc': round(us, 1), 'TFLOPs': round(flops / us / 1e6, 1), 'counters': {k: round(v, 1) for k, v in sorted(c.items())}}
+        if 'SQ_VALU_MFMA_BUSY_CYCLES' in c and 'GRBM_GUI_ACTIVE' in c:
+            row['mfma_busy_frac'] = round(c['SQ_VALU_MFMA_BUSY_CYCLES'] / (c['GRBM_GUI_ACTIVE'] * 1024), 4)
+        if 'SQ_LDS_BANK_CONFLICT' in c and c.get('SQ_LDS_IDX_ACTIVE'):
+            row['lds_conflict_share'] = round(c['SQ_LDS_BANK_CONFLICT'] / c['SQ_LDS_IDX_ACTIVE'], 4)
+        if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
+            row['hbm_bytes'] = round((2 * c['FETCH_SIZE'] + c['WRITE_SIZE']) * 1024)
+            row['hbm_over_algorithmic'] = round(row['hbm_bytes'] / hbm, 3)
+        res[frag] = row
+    json.dump(res, open(out, 'w'), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == '__main__':
+    main()
