@@ -75,6 +75,16 @@ __device__ __forceinline__ uint4 pcacc_relu_mask8(uint4 g, uint4 y)
     return make_uint4(pcacc_relu_mask2(g.x, y.x), pcacc_relu_mask2(g.y, y.y), pcacc_relu_mask2(g.z, y.z), pcacc_relu_mask2(g.w, y.w));
 }
 
+// Row stride (elements) of a channels-last bf16 LDS tile of `c` channels that is read with ds_read_b64_tr_b16: a 32-lane half of the
+// instruction addresses 4 consecutive rows x 16 dwords (two 16-lane groups, 8 pieces of 8 bytes each), so the read is bank-conflict
+// free iff the four row starts fall on the four 16-dword quarters of the 64 banks: stride = 16 or 48 dwords (mod 64).  The C + 4
+// padding used before made rows 0 / 2 and 1 / 3 overlap: SQ_LDS_BANK_CONFLICT = 41-50 % of the LDS cycles of the weight-gradient
+// kernels (profiles/r02_pmc_kernels_v1_summary.json).  32 channels need no padding at all.
+__host__ __device__ constexpr int pcacc_tr_stride(int c)
+{
+    return c == 32 ? 32 : (c == 64 ? 96 : (c == 96 ? 96 : (c == 128 ? 160 : c + 4)));
+}
+
 // ---- wave64 / block scans ------------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 

@@ -516,7 +516,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_wgrad_kernel(const uint16_
                                                                    int w, int tiles_x, int tiles_y)
 {
     constexpr int CO = CO_T * 32, CI = CI_T * 32, PAIRS = CO_T * CI_T, GROUPS = 4 / PAIRS;
-    constexpr int YS = CO + 4, XS = CI + 4;
+    constexpr int YS = pcacc_tr_stride(CO), XS = pcacc_tr_stride(CI);
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     uint16_t *sdy = lds;                                       // [CV_TH * CV_TW][YS]
     uint16_t *sx = lds + CV_TH * CV_TW * YS;                   // [CV_PH * CV_PW][XS]
@@ -692,7 +692,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__r
 
 static int conv_wgrad_grid(int c_in, int c_out, int64_t n_tiles)
 {
-    const size_t lds = (size_t)(CV_TH * CV_TW * (c_out + 4) + CV_PH * CV_PW * (c_in + 4)) * sizeof(uint16_t);
+    const size_t lds = (size_t)(CV_TH * CV_TW * pcacc_tr_stride(c_out) + CV_PH * CV_PW * pcacc_tr_stride(c_in)) * sizeof(uint16_t);
     int per_cu = (int)((160 * 1024) / lds);
     per_cu = per_cu > 3 ? 3 : (per_cu < 1 ? 1 : per_cu);
     int64_t slots = (int64_t)PCACC_CUS * per_cu / 8;
@@ -724,7 +724,7 @@ extern "C" int pcacc_conv3x3_wgrad_bf16(const uint16_t *dy, const uint16_t *x, f
     const int grid = conv_wgrad_grid(c_in, c_out, n_tiles);
     const int elems = c_out * 9 * c_in + c_out;                 // weight gradient, then the bias gradient
     if (workspace_bytes < (size_t)grid * elems * sizeof(float)) return PCACC_E_WORKSPACE;
-    const size_t lds = (size_t)(CV_TH * CV_TW * (c_out + 4) + CV_PH * CV_PW * (c_in + 4)) * sizeof(uint16_t);
+    const size_t lds = (size_t)(CV_TH * CV_TW * pcacc_tr_stride(c_out) + CV_PH * CV_PW * pcacc_tr_stride(c_in)) * sizeof(uint16_t);
     float *partial = reinterpret_cast<float *>(workspace);
 #define CV_WG(COT, CIT)                                                                                                              \
     do {                                                                                                                             \

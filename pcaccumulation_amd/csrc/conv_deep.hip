@@ -320,7 +320,7 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_wgrad_strip_kernel(const u
                                                                          int c_out, int rows, int strips, int ci_blocks, int slots)
 {
     constexpr int CO = 64, CI = 64, PAIRS = 4, TG = 5;        // TG = taps of the first tap group
-    constexpr int YS = CO + 4, XS = CI + 4;
+    constexpr int YS = pcacc_tr_stride(CO), XS = pcacc_tr_stride(CI);
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     const int pw = w + 2, pp = (rows + 2) * pw;
     const int n_px = rows * w, n_steps = (n_px + 15) >> 4, py_rows = n_steps * 16;
@@ -471,7 +471,7 @@ static int conv_wgrad_strip_rows(int h, int w, size_t *lds_bytes)
     int64_t best_cost = 0;
     for (int rows = 1; rows <= h && rows * w <= CDW_MAXP; ++rows) {
         const int pp = (rows + 2) * (w + 2), py_rows = (rows * w + 15) / 16 * 16;
-        const size_t lds = ((size_t)py_rows * 68 + (size_t)pp * 68 + py_rows) * sizeof(uint16_t);
+        const size_t lds = ((size_t)py_rows * pcacc_tr_stride(64) + (size_t)pp * pcacc_tr_stride(64) + py_rows) * sizeof(uint16_t);
         if ((py_rows + pp) * 8 > CD_THREADS * CDW_PCH || lds > 150 * 1024) continue;
         const int64_t cost = (int64_t)((h + rows - 1) / rows) * py_rows;
         if (!best || cost <= best_cost) { best = rows; best_cost = cost; *lds_bytes = lds; }

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void rows_wgrad_bf16_kernel(const uint16_t *__
                                                               int k_tiles, int n_tile_total, int tiles_par, float *partial, RowPieces xs2)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t wlds[];
-    const int NS = N + 4, KS = K + 4;
+    const int NS = pcacc_tr_stride(N), KS = pcacc_tr_stride(K);
     uint16_t *sdy = wlds, *sx = wlds + WG_R * NS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lp = lane & 31, lh = lane >> 5;
@@ -447,7 +447,7 @@ static int rows_wgrad_bf16_any(const uint16_t *dy, const uint16_t *dy_mask, cons
     const int elems = n * (k + 1);
     if (workspace_bytes < (size_t)grid * parts_per_wg * elems * sizeof(float)) return PCACC_E_WORKSPACE;
     float *partial = reinterpret_cast<float *>(workspace);
-    const size_t lds = (size_t)tile_rows * (n + 4 + k + 4) * sizeof(uint16_t);
+    const size_t lds = (size_t)tile_rows * (pcacc_tr_stride(n) + pcacc_tr_stride(k)) * sizeof(uint16_t);
 #define WGB(T, R) rows_wgrad_bf16_kernel<T, R><<<grid, 256, lds, st>>>(dy, dy_mask, x, x_relu, rows, k, n, k_tiles, total, tiles_par, partial, xs2)
     if (total <= 4) { if (tile_rows == 256) WGB(1, 256); else if (tile_rows == 128) WGB(1, 128); else WGB(1, 64); }
     else if (total <= 8) { if (tile_rows == 128) WGB(2, 128); else WGB(2, 64); }

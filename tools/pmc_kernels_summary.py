@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """profiles/rNN_pmc_kernels_summary.json from the counter files of tools/gpu_pmc_kernels.sh (one rocprofv3 --pmc run per counter set).
-Per kernel (mean over its launches): duration, MFMA busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs),
+Per kernel (mean over its launches): duration, MFMA busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs),
 achieved TFLOP/s from the algorithmic FLOPs, LDS bank-conflict share = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, HBM bytes
 (FETCH_SIZE x2 per MI355X_MICROARCH.md's gfx950 correction + WRITE_SIZE, KiB units).
 Usage: pmc_kernels_summary.py <dir with one sub-directory per counter set> out.json"""
@@ -42,7 +42,7 @@ def main():
         us = sum(durs[frag]) / len(durs[frag])
         row = {'what': label, 'avg_us_under_pmc': round(us, 1), 'TFLOPs': round(flops / us / 1e6, 1), 'counters': {k: round(v, 1) for k, v in sorted(c.items())}}
         if 'SQ_VALU_MFMA_BUSY_CYCLES' in c and 'GRBM_GUI_ACTIVE' in c:
-            row['mfma_busy_frac'] = round(c['SQ_VALU_MFMA_BUSY_CYCLES'] / (c['GRBM_GUI_ACTIVE'] * 1024), 4)
+            row["mfma_busy_frac"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8 * 1024), 4)   # GRBM_GUI_ACTIVE is summed over the 8 XCDs
         if 'SQ_LDS_BANK_CONFLICT' in c and c.get('SQ_LDS_IDX_ACTIVE'):
             row['lds_conflict_share'] = round(c['SQ_LDS_BANK_CONFLICT'] / c['SQ_LDS_IDX_ACTIVE'], 4)
         if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
