@@ -268,8 +268,13 @@ class DataParallelStep(object):
     GradScaler uses; `skipped` counts on the device (read it with skipped_steps()).  Optimizers without that input (CPU tests)
     read the flag on the host."""
 
-    def __init__(self, model, optimizer, loss_fn, iter_size=1, grad_clip=1.0, check_finite=True, catch=True, reducer=None):
+    def __init__(self, model, optimizer, loss_fn, iter_size=1, grad_clip=1.0, check_finite=True, catch=True, reducer=None, pipelined=None):
         self.model, self.optimizer, self.loss_fn = model, optimizer, loss_fn
+        # pipelined: back-propagate the loss terms of the lower half of the model (pillar encoder, U-Net, heads, ego head) as soon as
+        # the ego head has run, before the motion heads and the TubeNet are even issued (MotionNet.after_ego, FuseLoss.early_terms);
+        # default: whenever model and loss offer the two hooks
+        can = hasattr(model, 'after_ego') and hasattr(loss_fn, 'early_terms')
+        self.pipelined = can if pipelined is None else (bool(pipelined) and can)
         self.iter_size, self.grad_clip, self.check_finite, self.catch = int(iter_size), grad_clip, check_finite, catch
         self.reducer = reducer if reducer is not None else BucketedGradReducer(model.parameters())
         self.micro = 0
@@ -293,11 +298,25 @@ class DataParallelStep(object):
             self.ok = True
         last = self.micro == self.iter_size - 1
         stats, prepared = None, False
+        early = []
+
+        def early_backward(results):
+            e = self.loss_fn.early_terms(results)
+            loss_e = e['loss_early'] / self.iter_size if self.iter_size > 1 else e['loss_early']
+            r.prepare(loss_e, sync=False)                     # accumulate only: the collectives go out with the second pass
+            loss_e.backward()
+            early.append(e)
         try:
-            out = self.model(inp)
+            if self.pipelined:
+                self.model.after_ego = early_backward
+            try:
+                out = self.model(inp)
+            finally:
+                if self.pipelined:
+                    self.model.after_ego = None
             if after_forward is not None:
                 after_forward()
-            stats = self.loss_fn(out, inp)
+            stats = self.loss_fn(out, inp, early=early[0]) if early else self.loss_fn(out, inp)
             loss = stats['loss'] / self.iter_size if self.iter_size > 1 else stats['loss']
             r.prepare(loss, sync=last)
             prepared = True

@@ -182,23 +182,41 @@ class FuseLoss(nn.Module):
             n_th += 1
         return total
 
-    def forward(self, predictions, input_dict):
-        """libs/loss.py:280-327."""
+    def early_terms(self, predictions):
+        """The terms of forward() that only need the ego head, the fg/bg head and what lies below them (ego pose loss, permutation
+        loss, fg/bg segmentation): available as soon as MotionNet's ego head has run, i.e. BEFORE the motion branch and the TubeNet.
+        A training step can back-propagate them right there (DataParallelStep, `pipelined`): the backward of the pillar encoder and
+        the U-Net -- most of the step's GPU work -- is then queued in front of the TubeNet's hundreds of small launches, which the
+        host issues while the GPU is busy instead of starving it.  Returns a LazyDict with these stats and 'loss_early'."""
         stats = LazyDict()
         ego = self.w_pose_l1_loss * predictions['ego_l1_loss']
         total = ego
         stats['ego_l1_loss'] = ego
         stats['ego_l2_loss'] = predictions['ego_l2_loss']
-        stats['ego_rot_error'] = raw(predictions, 'ego_rot_error')            # still in flight (lazy.py): carried along unread
-        stats['ego_trans_error'] = raw(predictions, 'ego_trans_error')
         perm_loss = self.outlier_loss(predictions['perm_matrix']) * self.w_perm_loss
         total = total + perm_loss
         stats['perm_loss'] = perm_loss
         fb = self.get_fb_loss(predictions)
-        dev = total.device
-        fb_loss = torch.dot(fb['terms'], self._weights(dev, 'w_fb_bce_loss', 'w_fb_lovasz_loss'))
+        fb_loss = torch.dot(fb['terms'], self._weights(total.device, 'w_fb_bce_loss', 'w_fb_lovasz_loss'))
         total = total + fb_loss
         stats['fb_loss'], stats['fb_metric'] = fb_loss, fb['metric']
+        stats['loss_early'] = total
+        return stats
+
+    def forward(self, predictions, input_dict, early=None):
+        """libs/loss.py:280-327.  `early`: the result of early_terms() when those terms were already evaluated (and possibly
+        back-propagated) -- they enter the total as constants then."""
+        if early is None:
+            early = self.early_terms(predictions)
+            total = early['loss_early']
+        else:
+            total = early['loss_early'].detach()
+        stats = LazyDict()
+        for k in ('ego_l1_loss', 'ego_l2_loss', 'perm_loss', 'fb_loss', 'fb_metric'):
+            stats[k] = raw(early, k)
+        stats['ego_rot_error'] = raw(predictions, 'ego_rot_error')            # still in flight (lazy.py): carried along unread
+        stats['ego_trans_error'] = raw(predictions, 'ego_trans_error')
+        dev = total.device
         mos = self.get_mos_loss(predictions, input_dict)
         mos_loss = torch.dot(mos['terms'], self._weights(dev, 'w_mos_bce_loss', 'w_mos_lovasz_loss'))
         total = total + mos_loss

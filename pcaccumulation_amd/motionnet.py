@@ -58,6 +58,7 @@ class MotionNet(nn.Module):
         self.compute_dtype = {'fp32': torch.float32, 'bf16': torch.bfloat16}[cfg['misc'].get('compute_dtype', 'fp32')]
         # pillars renumbered in canvas-cell order inside forward() (ops.PillarIndex); False keeps the voxeliser's numbering
         self.cell_ordered_pillars = bool(cfg['misc'].get('cell_ordered_pillars', True))
+        self.after_ego = None                    # optional callable(results), see forward()
 
     # ------------------------------------------------------------------------------------------------
     def channels_last_(self):
@@ -183,6 +184,12 @@ class MotionNet(nn.Module):
         #    gathered key-point rows inside the head instead of to the whole map.
         self.ego_motion_head.forward_pillars(ops.nchw_as_rows(geometric_feats), pillar_mean, pidx, ego_motion_gt, results,
                                              frame_offsets, bg_sorted_idx, bg_counts)
+        # Everything below works on detached features and poses (motionnet.py:205-209): the graph of the pillar encoder, the
+        # U-Net, the two heads and the ego head is complete here.  A training step may hook in (`after_ego`) to evaluate the loss terms
+        # that live on it and back-propagate them now (FuseLoss.early_terms, distributed.DataParallelStep): the largest kernels of
+        # the step are then queued in front of the ~800 small launches of the motion heads and the TubeNet.
+        if self.after_ego is not None:
+            self.after_ego(results)
 
         # 5. motion segmentation on ego-motion-compensated features
         pose_est = results['ego_motion_est'].float().detach()
@@ -236,7 +243,7 @@ class MotionNet(nn.Module):
                 'motion_feats': motion_feats,
                 'inst_motion_gt': input_dict['inst_motion_gt'],
                 'mos_labels': input_dict['sd_labels'][rec_idx, 0].long(),
-                'ego_motion_est': results['ego_motion_est'],
+                'ego_motion_est': results['ego_motion_est'].detach(),     # alignnet.py:240 detaches what is derived from it
                 'ego_motion_gt': results['ego_motion_gt'],
                 '_pad_flags': pad_flags if self.mode in ['train', 'val'] else None,
             }

@@ -14,7 +14,9 @@ cfg['misc']['compute_dtype'] = 'bf16'; cfg['pose_estimation']['kpt_sampler'] = '
 model, opt, loss_fn = bench.build(cfg, dev)
 batcher = DeviceBatcher(cfg)
 scenes = [sample_to_device(make_sequence(i, 5, 160000, cfg), dev) for i in range(4)]
-bench.train_step(model, opt, loss_fn, batcher, scenes, None, 1.0)
+from pcaccumulation_amd import distributed as pdist
+stepper = pdist.DataParallelStep(model, opt, loss_fn, iter_size=1, grad_clip=1.0)
+bench.train_step(stepper, batcher, scenes)
 inp = batcher(scenes)
 per_line = collections.Counter()
 class Count(TorchDispatchMode):
@@ -37,7 +39,7 @@ class CountNames(TorchDispatchMode):
         return func(*args, **(kwargs or {}))
 if stage == 'step':
     with CountNames():
-        bench.train_step(model, opt, loss_fn, batcher, scenes, None, 1.0)
+        bench.train_step(stepper, batcher, scenes)
     skip = ('view', 'permute', 'select', 'slice', 'expand', 'unsqueeze', 'squeeze', 'detach', 'alias', 'aten.t.', 'transpose', 'as_strided', 'sym_', 'reshape')
     rows = [(v, k) for k, v in per_name.items() if not any(s in k for s in skip)]
     print('total', sum(v for v, _ in rows))
