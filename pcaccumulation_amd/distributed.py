@@ -77,6 +77,14 @@ class BucketedGradReducer(object):
         reducer.finish()                        # the current stream waits for the collectives (the host does not); .grad = views
         flag = reducer.agree(ok)                # device tensor: 1 iff every rank reports ok
 
+    Two-pass micro-steps (DataParallelStep.pipelined: one backward in the middle of the forward, one at its end): set_early(params)
+    names the parameters only the first pass can reach; their buckets form the head of the launch sequence and go out during the
+    first backward -- overlapped with the rest of the forward -- the others during the second:
+        reducer.begin(sync); reducer.prepare(loss_a, part='early'); loss_a.backward(); ...
+        reducer.prepare(loss_b, part='rest'); loss_b.backward(); reducer.finish()
+    The split is static (a property of the model, not of this batch's graph), so every rank issues the same collectives in the same
+    order whatever branches its forward took.
+
     Autograd keeps producing ordinary gradient tensors (no read-modify-write into a zeroed buffer: the first accumulation of a
     window just adopts the incoming tensor); when the last expected gradient of a bucket has arrived, ONE multi-tensor copy moves
     the bucket's gradients into its slice of the flat buffer and the slice's all-reduce is launched.  After finish() every
@@ -107,9 +115,11 @@ class BucketedGradReducer(object):
             off += p.numel()
         self.buckets.append((start, off))
         self.touched = [False] * len(self.params)
-        self._expected = [True] * len(self.params)
         self._pending = [0] * len(self.buckets)
-        self._next = len(self.buckets)                       # nothing to launch until prepare(sync=True)
+        self._seq = list(range(len(self.buckets)))           # launch sequence (bucket ids); set_early() moves the early ones first
+        self._n_early = 0
+        self._next = self._limit = len(self._seq)            # position in _seq; nothing to launch until begin(sync=True)
+        self._launched = [False] * len(self.buckets)
         self._works = []
         self._sync = False
         self._callback_queued = False
@@ -146,6 +156,7 @@ class BucketedGradReducer(object):
     def _launch(self, b):
         """Bucket b: gradients that exist -> their views (one multi-tensor copy), views nobody wrote -> zero, then the all-reduce."""
         s, e = self.buckets[b]
+        self._launched[b] = True
         src, dst, zero = [], [], []
         for i in self.members[b]:
             g = self.params[i].grad
@@ -164,14 +175,24 @@ class BucketedGradReducer(object):
         self._works.append((work, b, avg))
 
     def _launch_ready(self):
-        while self._next < len(self.buckets) and self._pending[self._next] <= 0:
-            self._launch(self._next)
+        while self._next < self._limit and self._pending[self._seq[self._next]] <= 0:
+            self._launch(self._seq[self._next])
             self._next += 1
 
     def _launch_all(self):
-        while self._next < len(self.buckets):
-            self._launch(self._next)
+        while self._next < self._limit:
+            self._launch(self._seq[self._next])
             self._next += 1
+
+    def set_early(self, params):
+        """Buckets made of `params` only (parameters that a first, early backward pass reaches and a second never does) move to the
+        head of the launch sequence.  Must be the same call on every rank."""
+        ids = set(id(p) for p in params)
+        early = [b for b, m in enumerate(self.members) if all(id(self.params[i]) in ids for i in m)]
+        chosen = set(early)
+        self._seq = early + [b for b in range(len(self.buckets)) if b not in chosen]
+        self._n_early = len(early)
+        return self._n_early
 
     # ------------------------------------------------------------------------------------------------
     def zero(self):
@@ -180,25 +201,38 @@ class BucketedGradReducer(object):
             p.grad = None
         self.touched = [False] * len(self.params)
 
-    def prepare(self, loss, sync=True):
-        """Before `loss.backward()`.  sync=False: accumulate only (a micro-step that is not the window's last)."""
+    def begin(self, sync=True):
+        """Start of a micro-step.  sync=False: accumulate only (a micro-step that is not the window's last)."""
         self._sync = bool(sync)
-        self._callback_queued = False
         self._works = []
-        self._next = len(self.buckets)
+        self._launched = [False] * len(self.buckets)
+        self._next = 0 if (self._sync and self.world > 1) else len(self._seq)
+        self._limit = self._next
+
+    def prepare(self, loss, sync=None, part=None):
+        """Before `loss.backward()`.  `sync` given: begin(sync) first (the one-pass form).  part = 'early': only the buckets of
+        set_early() may go out during this backward; 'rest' / None: every bucket not yet out."""
+        if sync is not None:
+            self.begin(sync)
+        self._callback_queued = False
         if not self._sync or self.world == 1:
             return
-        self._next = 0
+        self._limit = self._n_early if part == 'early' else len(self._seq)
         reach = _reachable_parameters(loss) if loss is not None else None
         self._pending = [0] * len(self.buckets)
         for i, p in enumerate(self.params):
             if reach is None or id(p) in reach:
-                self._pending[self.bucket_of[i]] += 1
+                b = self.bucket_of[i]
+                if self._launched[b] and reach is not None:
+                    raise RuntimeError('BucketedGradReducer: a parameter of a bucket that was reduced in the early pass is reachable '
+                                       'from the second loss (set_early() names parameters the second pass must not touch)')
+                self._pending[b] += 1
         self._launch_ready()                                  # leading buckets this backward cannot write (skipped branches)
 
     def flush(self):
         """A rank whose forward / backward raised still issues every collective of the step (in order), so the others do not hang."""
         if self._sync and self.world > 1:
+            self._limit = len(self._seq)
             self._launch_all()
 
     def finish(self):
@@ -207,6 +241,7 @@ class BucketedGradReducer(object):
         if not self._sync or self.world == 1:
             self._sync = False
             return
+        self._limit = len(self._seq)
         self._launch_all()
         for work, b, averaged in self._works:
             work.wait()
@@ -277,6 +312,8 @@ class DataParallelStep(object):
         self.pipelined = can if pipelined is None else (bool(pipelined) and can)
         self.iter_size, self.grad_clip, self.check_finite, self.catch = int(iter_size), grad_clip, check_finite, catch
         self.reducer = reducer if reducer is not None else BucketedGradReducer(model.parameters())
+        if self.pipelined and hasattr(model, 'early_parameters'):
+            self.reducer.set_early(model.early_parameters())
         self.micro = 0
         self.ok = True
         self.last_error = None
@@ -297,15 +334,16 @@ class DataParallelStep(object):
             r.zero()
             self.ok = True
         last = self.micro == self.iter_size - 1
-        stats, prepared = None, False
+        stats = None
         early = []
 
         def early_backward(results):
             e = self.loss_fn.early_terms(results)
             loss_e = e['loss_early'] / self.iter_size if self.iter_size > 1 else e['loss_early']
-            r.prepare(loss_e, sync=False)                     # accumulate only: the collectives go out with the second pass
+            r.prepare(loss_e, part='early')                   # the lower half's buckets go out now, under the rest of the forward
             loss_e.backward()
             early.append(e)
+        r.begin(sync=last)
         try:
             if self.pipelined:
                 self.model.after_ego = early_backward
@@ -318,16 +356,13 @@ class DataParallelStep(object):
                 after_forward()
             stats = self.loss_fn(out, inp, early=early[0]) if early else self.loss_fn(out, inp)
             loss = stats['loss'] / self.iter_size if self.iter_size > 1 else stats['loss']
-            r.prepare(loss, sync=last)
-            prepared = True
+            r.prepare(loss, part='rest')
             loss.backward()
         except Exception as e:                                # noqa: BLE001 -- libs/trainer.py:234-235
             if not self.catch:
                 raise
             self.ok, self.last_error = False, e
             if last:
-                if not prepared:
-                    r.prepare(None, sync=True)
                 r.flush()                                     # the other ranks are waiting in these collectives
         self.micro += 1
         if last:

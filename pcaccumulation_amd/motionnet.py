@@ -61,6 +61,11 @@ class MotionNet(nn.Module):
         self.after_ego = None                    # optional callable(results), see forward()
 
     # ------------------------------------------------------------------------------------------------
+    def early_parameters(self):
+        """The parameters whose whole gradient comes from the loss terms of FuseLoss.early_terms (see `after_ego` in forward())."""
+        mods = (self.pillar_encoder, self.unet, self.semseg_head, self.ego_feats_head, self.ego_motion_head)
+        return [p for m in mods for p in m.parameters()]
+
     def channels_last_(self):
         """Store conv weights in the layout the channels-last activations want (no state_dict change)."""
         for m in self.modules():

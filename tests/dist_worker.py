@@ -71,6 +71,36 @@ def toy(rank, world, out):
     step({'x': toy_input(rank, 0), 'fail': False})
     res['stepped'] = not bool(torch.equal(before, net.a.weight.detach()))
     res['a_after'] = net.a.weight.detach().clone()
+    # (4) two backward passes per micro-step: the buckets of set_early() go out during the first, the others during the second
+    torch.manual_seed(0)
+    net = Net()
+    red = pdist.BucketedGradReducer(net.parameters(), bucket_bytes=64 * 1024)
+    res['n_early'] = red.set_early(list(net.d.parameters()))
+    res['seq'] = list(red._seq)
+    red.zero()
+    red.begin(sync=True)
+    y = net.a(toy_input(rank, 0))
+    loss_a = net.d(y.detach().repeat(1, 100)).sum() * 1e-3
+    red.prepare(loss_a, part='early')
+    loss_a.backward()
+    res['out_after_first'] = list(red._launched)
+    loss_b = net.b(y).sum() if rank == 0 else y.sum()
+    red.prepare(loss_b, part='rest')
+    loss_b.backward()
+    red.finish()
+    res['two_pass'] = {k: p.grad.clone() for k, p in net.named_parameters()}
+    # a second loss that reaches an already reduced bucket is refused (its gradient would be lost)
+    red.zero()
+    red.begin(sync=True)
+    loss_a = net.d(toy_input(rank, 0).repeat(1, 75)).sum()
+    red.prepare(loss_a, part='early')
+    loss_a.backward()
+    try:
+        red.prepare(net.d(toy_input(rank, 0).repeat(1, 75)).sum(), part='rest')
+        res['refused'] = False
+    except RuntimeError:
+        res['refused'] = True
+    red.finish()
     torch.save(res, out)
 
 
@@ -114,7 +144,7 @@ def motionnet(rank, world, out):
     grads = {k: p.grad.clone() for k, p in model.named_parameters()}
     touched = {k: t for (k, _), t in zip(model.named_parameters(), step.reducer.touched)}
     torch.save({'grads': grads, 'touched': touched, 'loss': float(stats['loss']), 'skipped': step.skipped,
-                'n_buckets': len(step.reducer.buckets)}, out)
+                'n_buckets': len(step.reducer.buckets), 'n_early': step.reducer._n_early, 'seq': list(step.reducer._seq)}, out)
 
 
 def main():

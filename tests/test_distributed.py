@@ -64,6 +64,24 @@ def test_gradient_reduction_two_gloo_ranks(tmp_path):
         # rank 1 raised in its forward: nobody hangs, nobody steps; the next (healthy) step is taken by both
         assert g['skipped'] == 1 and g['unchanged'] and g['stepped']
     assert torch.equal(got[0]['a_after'], got[1]['a_after'])
+    # two-pass micro-step: `d`'s bucket(s) lead the sequence and are out after the first backward, nothing else is
+    def two_pass_reference():
+        grads = []
+        for rank in range(2):
+            torch.manual_seed(0)
+            net = Net()
+            y = net.a(toy_input(rank, 0))
+            (net.d(y.detach().repeat(1, 100)).sum() * 1e-3 + (net.b(y).sum() if rank == 0 else y.sum())).backward()
+            grads.append({k: p.grad for k, p in net.named_parameters()})
+        return {k: sum((g[k] if g[k] is not None else 0) for g in grads) / 2 for k in grads[0]}
+    ref3 = two_pass_reference()
+    for rank, g in enumerate(got):
+        assert g['n_early'] >= 1 and g['seq'] == got[0]['seq'] and g['refused']
+        early = set(g['seq'][:g['n_early']])
+        assert [b for b, out in enumerate(g['out_after_first']) if out] == sorted(early)
+        for k in ref3:
+            want = ref3[k] if torch.is_tensor(ref3[k]) else torch.zeros_like(g['two_pass'][k])
+            assert torch.allclose(g['two_pass'][k], want, atol=1e-6), (rank, k)
 
 
 def test_motionnet_data_dependent_branches_two_gloo_ranks(tmp_path):
@@ -75,6 +93,8 @@ def test_motionnet_data_dependent_branches_two_gloo_ranks(tmp_path):
     from pcaccumulation_amd.loss import FuseLoss
     got = _launch('motionnet', tmp_path, 600)
     assert got[0]['n_buckets'] >= 4 and got[0]['skipped'] == got[1]['skipped'] == 0
+    # the early backward's buckets (pillar encoder ... ego head) lead the launch sequence, identically on both ranks
+    assert got[0]['n_early'] >= 2 and got[0]['seq'] == got[1]['seq'] and got[0]['seq'][0] > 0
     assert got[0]['touched']['motionhead.final_proj.0.weight'] and not got[1]['touched']['motionhead.final_proj.0.weight']
     assert got[0]['touched']['reconstructor.alignment.regressor.0.weight'] and not got[1]['touched']['reconstructor.alignment.regressor.0.weight']
 
