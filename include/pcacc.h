@@ -460,6 +460,41 @@ int pcacc_bn_rows_backward(const void *grad_y, const void *x, int dtype, int64_t
                            const float *save_mean, const float *save_invstd, void *grad_x, float *grad_gamma, float *grad_beta,
                            void *workspace, size_t workspace_bytes, void *stream);
 
+/* TubeNet slot algebra -- models/tpointnet.py:249-305 (TPointNet.forward after the pooled embeddings) and the refinement loop of
+ * models/alignnet.py:236-263, per refinement iteration.  A slot s = k * n_frames + t is instance k in frame t; slot [n] i32 is the
+ * slot of every foreground point; slot_centre [S,3] the per-slot centroids (the anchor frame's row k * n_frames is the one used).
+ *  rows           rows [n,4] = (xyz - centre of the instance's anchor frame, t / n_frames): input of the positional embedding
+ *                 (tpointnet.py:246-251).
+ *  code           code [S,4c] = (geo[k], motion[k], frame[s], frame[k * n_frames]) (tpointnet.py:259-262); backward: the three gradients.
+ *  pose_forward   pose_vec [S,7] (quaternion xyzw, translation) -> pose_c / gt_c [S,12] (R row-major, t): estimated pose and ground truth
+ *                 `remaining` [S,4,4] re-expressed for the centred cloud (batch_quat2mat / batch_mat2quat, tpointnet.py:20-73);
+ *                 loss_rt [2] f64 = weighted means of |q_gt - q| and |t_gt - t| (evaluate_pose, :76-94; q_gt by scipy's branch scheme
+ *                 in f64); step [S,4,4] = the un-centred pose, frame 0 = identity (:291-296); remaining_out = remaining @ step^-1 and
+ *                 total_out = step @ total_in (alignnet.py:257-263; total_in NULL = identity); wsum [1] = sum(weights) + 1e-20.
+ *  gap_forward    pp [n,4] = (|est - gt|_2, |est - gt|_1, 0, 0) of the centred point under the two poses (tpointnet.py:276-281).
+ *  finish         l12 [2] = sum_s weights[s] * slot_sums[s][0|1] / max(count[s], 1) / wsum (tpointnet.py:282-286).
+ *  gap_backward   grad_rows16 [n,16]: per point gradient of (grad_l1 * l12[0] + grad_l2 * l12[1]) w.r.t. pose_c of its slot (12 + 4 zeros);
+ *                 their per-slot sums are grad_pose [S,stride] of
+ *  pose_backward  grad_vec [S,7], including the loss_rt terms (grad_rot, grad_trans f64 scalars; NULL = 0).
+ * The slot-level kernels run in one workgroup each. */
+int pcacc_tube_rows(const float *xyz, const int32_t *slot, const float *slot_centre, int64_t n, int32_t n_frames, float *rows, void *stream);
+int pcacc_tube_code(const float *geo, const float *motion, const float *frame, int64_t n_inst, int32_t n_frames, int32_t c, float *code,
+                    void *stream);
+int pcacc_tube_code_backward(const float *grad_code, int64_t n_inst, int32_t n_frames, int32_t c, float *grad_geo, float *grad_motion,
+                             float *grad_frame, void *stream);
+int pcacc_tube_pose_forward(const float *pose_vec, const float *remaining, const float *total_in, const float *slot_centre,
+                            const float *weights, int32_t n_slots, int32_t n_frames, float *pose_c, float *gt_c, float *step,
+                            float *remaining_out, float *total_out, double *loss_rt, float *wsum, void *stream);
+int pcacc_tube_gap_forward(const float *rows, const int32_t *slot, const float *pose_c, const float *gt_c, int64_t n, float *pp, void *stream);
+int pcacc_tube_finish(const float *slot_sums, int32_t stride, const float *count, const float *weights, const float *wsum, int32_t n_slots,
+                      float *l12, void *stream);
+int pcacc_tube_gap_backward(const float *rows, const int32_t *slot, const float *pose_c, const float *gt_c, const float *weights,
+                            const float *count, const float *wsum, const float *grad_l1, const float *grad_l2, int64_t n,
+                            float *grad_rows16, void *stream);
+int pcacc_tube_pose_backward(const float *pose_vec, const float *remaining, const float *slot_centre, const float *weights, const float *wsum,
+                             const float *grad_pose, int32_t stride, const double *grad_rot, const double *grad_trans, int32_t n_slots,
+                             int32_t n_frames, float *grad_vec, void *stream);
+
 /* Host words -> device memory as kernel arguments (asynchronous, unlike a pageable hipMemcpy on the compute stream):
  * n 32-bit words from host_words to dst, 240 per launch.  For the per-step index tables a host loop of the reference
  * becomes (sample offsets, per-pair counts, thresholds). */

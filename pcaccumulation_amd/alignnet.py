@@ -92,7 +92,7 @@ class AlignNet(BaseModel):
         labels, remaining = self._merge_batch_instances(
             labels, tcol[:, 0], update_gt_inst_motion(gt_list, input_dict['ego_motion_gt'], input_dict['ego_motion_est']))
         extra, remaining, labels = self.padding(labels, tcol[:, 1], remaining, input_dict.get('_pad_flags'))
-        gt_motion = remaining.clone()
+        gt_motion = remaining
         K, T = remaining.size(0), remaining.size(1)
 
         take = torch.arange(n_pts, device=device).long()
@@ -108,20 +108,19 @@ class AlignNet(BaseModel):
 
         results['tpointnet_loss_terms'] = dict()
         total = None
+        net_in['inst_motion_gt'] = remaining
+        shared = self.alignment.shared_terms(net_in)                       # what the iterations have in common, once
         for it in range(self.n_iterations):
             net_in['points'] = cloud.detach()
             net_in['inst_motion_gt'] = remaining.detach()
-            out = self.alignment(net_in)
+            net_in['total'] = total
+            out = self.alignment(net_in, shared)
             results['tpointnet_loss_terms'][f'{it}_th'] = out
             step = out['inst_est_motion']                                  # [K,T,4,4]
             cloud = reconstruct_sequence(cloud, frames, p_labels, step, T)
-            # what is left of the GT motion after this step: remaining <- remaining @ step^-1 (alignnet.py:259-263)
-            rem, stp = remaining.view(-1, 4, 4), step.view(-1, 4, 4)
-            rem[:, :3, :3] = torch.matmul(rem[:, :3, :3], stp[:, :3, :3].transpose(1, 2))
-            rem[:, :3, 3] = rem[:, :3, 3] - torch.matmul(rem[:, :3, :3], stp[:, :3, 3].unsqueeze(-1)).squeeze(-1)
-            remaining = rem.view(K, T, 4, 4)
-            total = stp if total is None else torch.matmul(stp, total)
-        total = total.view(K, T, 4, 4)
+            # what is left of the GT motion after this step (remaining <- remaining @ step^-1) and the composed estimate
+            # (total <- step @ total), alignnet.py:257-263: both come out of the slot kernel
+            remaining, total = out['remaining'], out['total']
 
         src = input_dict['transformed_points']
         moved_est = reconstruct_sequence(src, tcol[:, 1], labels, total, T)

@@ -57,6 +57,8 @@ EXPORTS = [
     'pcacc_svd3', 'pcacc_svd3_backward', 'pcacc_conv3x3_deep_supported', 'pcacc_conv3x3_deep_bf16', 'pcacc_conv3x3_prepare_weights_pair',
     'pcacc_conv3x3_masked_bf16',
     'pcacc_conv3x3_wgrad_deep_supported', 'pcacc_conv3x3_wgrad_deep_workspace_bytes', 'pcacc_conv3x3_wgrad_deep_bf16', 'pcacc_bn_rows_workspace_bytes', 'pcacc_bn_rows_forward', 'pcacc_bn_rows_backward',
+    'pcacc_tube_rows', 'pcacc_tube_code', 'pcacc_tube_code_backward', 'pcacc_tube_pose_forward', 'pcacc_tube_gap_forward', 'pcacc_tube_finish',
+    'pcacc_tube_gap_backward', 'pcacc_tube_pose_backward',
 ]
 
 
@@ -836,3 +838,83 @@ def bn_rows_backward(grad_y, x, gamma, save_mean, save_invstd):
                                         _opt(gamma, torch.float32, 'gamma'), _dev(save_mean, torch.float32), _dev(save_invstd, torch.float32),
                                         _dev(gx), _dev(gg), _dev(gb), _dev(ws), ctypes.c_size_t(ws.numel()), _stream()), 'bn_rows_backward')
     return gx, gg, gb
+
+
+# ---- TubeNet slot algebra (include/pcacc.h: pcacc_tube_*) ---------------------------------------------------------------------------
+def tube_rows(xyz, slot, slot_centre, n_frames):
+    """rows [n,4] f32 = (xyz - centre of the instance's anchor frame, t / n_frames)."""
+    n = xyz.shape[0]
+    rows = torch.empty((n, 4), dtype=torch.float32, device=xyz.device)
+    _check(lib().pcacc_tube_rows(_dev(xyz, torch.float32, 'xyz'), _dev(slot, torch.int32, 'slot'), _dev(slot_centre, torch.float32, 'slot_centre'),
+                                 _i64(n), int(n_frames), _dev(rows), _stream()), 'tube_rows')
+    return rows
+
+
+def tube_code(geo, motion, frame, n_frames):
+    n_inst, c = geo.shape
+    code = torch.empty((n_inst * n_frames, 4 * c), dtype=torch.float32, device=geo.device)
+    _check(lib().pcacc_tube_code(_dev(geo, torch.float32, 'geo'), _dev(motion, torch.float32, 'motion'), _dev(frame, torch.float32, 'frame'),
+                                 _i64(n_inst), int(n_frames), int(c), _dev(code), _stream()), 'tube_code')
+    return code
+
+
+def tube_code_backward(grad_code, n_inst, n_frames, c):
+    dev = grad_code.device
+    g_geo = torch.empty((n_inst, c), dtype=torch.float32, device=dev)
+    g_motion = torch.empty((n_inst, c), dtype=torch.float32, device=dev)
+    g_frame = torch.empty((n_inst * n_frames, c), dtype=torch.float32, device=dev)
+    _check(lib().pcacc_tube_code_backward(_dev(grad_code, torch.float32, 'grad_code'), _i64(n_inst), int(n_frames), int(c), _dev(g_geo),
+                                          _dev(g_motion), _dev(g_frame), _stream()), 'tube_code_backward')
+    return g_geo, g_motion, g_frame
+
+
+def tube_pose_forward(pose_vec, remaining, total, slot_centre, weights, n_frames):
+    """-> pose_c [S,12], gt_c [S,12], step [S,4,4], remaining_out [S,4,4], total_out [S,4,4], loss_rt [2] f64, wsum [1]."""
+    s = pose_vec.shape[0]
+    dev = pose_vec.device
+    f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    pose_c, gt_c, step, rem_out, total_out, wsum = f(s, 12), f(s, 12), f(s, 4, 4), f(s, 4, 4), f(s, 4, 4), f(1)
+    loss_rt = torch.empty((2,), dtype=torch.float64, device=dev)
+    _check(lib().pcacc_tube_pose_forward(_dev(pose_vec, torch.float32, 'pose_vec'), _dev(remaining, torch.float32, 'remaining'),
+                                         _opt(total, torch.float32, 'total'), _dev(slot_centre, torch.float32, 'slot_centre'),
+                                         _dev(weights, torch.float32, 'weights'), int(s), int(n_frames), _dev(pose_c), _dev(gt_c), _dev(step),
+                                         _dev(rem_out), _dev(total_out), _dev(loss_rt), _dev(wsum), _stream()), 'tube_pose_forward')
+    return pose_c, gt_c, step, rem_out, total_out, loss_rt, wsum
+
+
+def tube_gap_forward(rows, slot, pose_c, gt_c):
+    n = rows.shape[0]
+    pp = torch.empty((n, 4), dtype=torch.float32, device=rows.device)
+    _check(lib().pcacc_tube_gap_forward(_dev(rows, torch.float32, 'rows'), _dev(slot, torch.int32, 'slot'), _dev(pose_c, torch.float32, 'pose_c'),
+                                        _dev(gt_c, torch.float32, 'gt_c'), _i64(n), _dev(pp), _stream()), 'tube_gap_forward')
+    return pp
+
+
+def tube_finish(slot_sums, count, weights, wsum):
+    l12 = torch.empty((2,), dtype=torch.float32, device=slot_sums.device)
+    _check(lib().pcacc_tube_finish(_dev(slot_sums, torch.float32, 'slot_sums'), int(slot_sums.shape[1]), _dev(count, torch.float32, 'count'),
+                                   _dev(weights, torch.float32, 'weights'), _dev(wsum, torch.float32, 'wsum'), int(slot_sums.shape[0]),
+                                   _dev(l12), _stream()), 'tube_finish')
+    return l12
+
+
+def tube_gap_backward(rows, slot, pose_c, gt_c, weights, count, wsum, grad_l1, grad_l2):
+    n = rows.shape[0]
+    g16 = torch.empty((n, 16), dtype=torch.float32, device=rows.device)
+    _check(lib().pcacc_tube_gap_backward(_dev(rows, torch.float32, 'rows'), _dev(slot, torch.int32, 'slot'), _dev(pose_c, torch.float32, 'pose_c'),
+                                         _dev(gt_c, torch.float32, 'gt_c'), _dev(weights, torch.float32, 'weights'),
+                                         _dev(count, torch.float32, 'count'), _dev(wsum, torch.float32, 'wsum'),
+                                         _opt(grad_l1, torch.float32, 'grad_l1'), _opt(grad_l2, torch.float32, 'grad_l2'), _i64(n), _dev(g16),
+                                         _stream()), 'tube_gap_backward')
+    return g16
+
+
+def tube_pose_backward(pose_vec, remaining, slot_centre, weights, wsum, grad_pose, grad_rot, grad_trans, n_frames):
+    s = pose_vec.shape[0]
+    g_vec = torch.empty((s, 7), dtype=torch.float32, device=pose_vec.device)
+    _check(lib().pcacc_tube_pose_backward(_dev(pose_vec, torch.float32, 'pose_vec'), _dev(remaining, torch.float32, 'remaining'),
+                                          _dev(slot_centre, torch.float32, 'slot_centre'), _dev(weights, torch.float32, 'weights'),
+                                          _dev(wsum, torch.float32, 'wsum'), _dev(grad_pose, torch.float32, 'grad_pose'), int(grad_pose.shape[1]),
+                                          _opt(grad_rot, torch.float64, 'grad_rot'), _opt(grad_trans, torch.float64, 'grad_trans'), int(s),
+                                          int(n_frames), _dev(g_vec), _stream()), 'tube_pose_backward')
+    return g_vec

@@ -472,6 +472,73 @@ def transform_by_index(points, idx, tsfm):
     return out if points.dtype == torch.float32 else out.to(points.dtype)
 
 
+# ---- TubeNet slot algebra (csrc/tube.hip) -------------------------------------------------------------------------------------------
+def _plan_sum(x, plan):
+    """Per-slot sums of [N,c] f32 rows (c = 4 or 16: a width the segment kernels are instantiated for)."""
+    if plan.small(x.shape[1]):
+        return native.scatter_sum_small(x, plan.p2v, plan.m)
+    return native.segment_sum(x, plan.seg_offsets, plan.order, plan.m)
+
+
+def tube_rows(xyz, plan, slot_centre, n_frames):
+    """[N,4] f32 rows of the TubeNet's positional embedding: point minus the centroid of its instance in the anchor frame, and
+    t / n_frames (models/tpointnet.py:246-251).  No gradient: AlignNet hands the points over detached (models/alignnet.py:239)."""
+    return native.tube_rows(xyz.detach().contiguous().float(), plan.p2v, slot_centre.detach().contiguous().float(), n_frames)
+
+
+class _TubeCode(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, geo, motion, frame, n_frames):
+        ctx.dims = (geo.shape[0], n_frames, geo.shape[1])
+        return native.tube_code(geo.contiguous(), motion.contiguous(), frame.contiguous(), n_frames)
+
+    @staticmethod
+    def backward(ctx, grad):
+        g_geo, g_motion, g_frame = native.tube_code_backward(grad.contiguous(), *ctx.dims)
+        return g_geo, g_motion, g_frame, None
+
+
+def tube_code(geo, motion, frame, n_frames):
+    """Regressor input rows [K*T, 4c]: (geometry code, motion code) of the instance, frame code of the slot, frame code of the
+    instance's anchor frame (models/tpointnet.py:259-262) -- one gather instead of three repeat_interleave and a cat."""
+    return _TubeCode.apply(geo.float(), motion.float(), frame.float(), int(n_frames))
+
+
+class _TubePose(torch.autograd.Function):
+    """Everything of TPointNet.forward behind the regressor, and the bookkeeping of AlignNet's loop (csrc/tube.hip)."""
+
+    @staticmethod
+    def forward(ctx, pose_vec, rows, plan, remaining, total, slot_centre, weights, n_frames):
+        pose_vec = pose_vec.contiguous().float()
+        remaining = remaining.detach().contiguous().float().view(-1, 4, 4)
+        total = total.detach().contiguous().float().view(-1, 4, 4) if total is not None else None
+        pose_c, gt_c, step, rem_out, total_out, loss_rt, wsum = native.tube_pose_forward(pose_vec, remaining, total, slot_centre, weights, n_frames)
+        count = plan.count()
+        l12 = native.tube_finish(_plan_sum(native.tube_gap_forward(rows, plan.p2v, pose_c, gt_c), plan), count, weights, wsum)
+        ctx.save_for_backward(pose_vec, rows, remaining, slot_centre, weights, pose_c, gt_c, count, wsum)
+        ctx.plan, ctx.n_frames = plan, n_frames
+        ctx.mark_non_differentiable(step, rem_out, total_out)
+        return l12[0], l12[1], loss_rt[0], loss_rt[1], step, rem_out, total_out
+
+    @staticmethod
+    def backward(ctx, g_l1, g_l2, g_rot, g_trans, *unused):
+        pose_vec, rows, remaining, slot_centre, weights, pose_c, gt_c, count, wsum = ctx.saved_tensors
+        plan = ctx.plan
+        c = lambda g, dt: g.contiguous().to(dt) if g is not None else None
+        g16 = native.tube_gap_backward(rows, plan.p2v, pose_c, gt_c, weights, count, wsum, c(g_l1, torch.float32), c(g_l2, torch.float32))
+        g_vec = native.tube_pose_backward(pose_vec, remaining, slot_centre, weights, wsum, _plan_sum(g16, plan), c(g_rot, torch.float64),
+                                          c(g_trans, torch.float64), ctx.n_frames)
+        return g_vec, None, None, None, None, None, None, None
+
+
+def tube_pose(pose_vec, rows, plan, remaining, total, slot_centre, weights, n_frames):
+    """pose_vec [K*T,7] -> (l1_loss, l2_loss, rot_loss, trans_loss, step [K*T,4,4], remaining' [K*T,4,4], total' [K*T,4,4]):
+    models/tpointnet.py:264-296 and models/alignnet.py:257-263.  Only pose_vec receives a gradient (the reference's other inputs
+    are detached or constant); the three pose tables come back without one -- no loss term reads them (libs/loss.py:253-263)."""
+    return _TubePose.apply(pose_vec, rows, plan, remaining, total, slot_centre.detach().contiguous().float(), weights.detach().contiguous().float(),
+                           int(n_frames))
+
+
 _PREPARED = {}
 
 

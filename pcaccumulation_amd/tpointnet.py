@@ -9,7 +9,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .chamfer_distance import ChamferDistance
-from .ops import scatter, ScatterPlan, linear_rows, transform_by_index, point_dtype
+from .ops import scatter, ScatterPlan, linear_rows, transform_by_index, point_dtype, tube_rows, tube_code, tube_pose
 
 _EPS = 1e-20
 
@@ -222,55 +222,50 @@ class TPointNet(BaseModel):
         return enough * label_w * ramp
 
     # -- step 2 ---------------------------------------------------------------------------------------------
-    def _embeddings(self, feats_motion, feats_geo, xyz, t_idx, inst, slot, per_inst, per_slot, n_inst, n_slots, T):
-        e_motion = scatter(_embed(self.motion_embed, feats_motion), inst, dim=0, dim_size=n_inst, reduce='max', plan=per_inst)
-        e_geo = scatter(_embed(self.geo_embed, feats_geo), inst, dim=0, dim_size=n_inst, reduce='max', plan=per_inst)
-        slot_centre = scatter(xyz, slot, dim=0, dim_size=n_slots, reduce='mean', plan=per_slot)
-        anchor_centre = slot_centre[::T]                                   # centroid of each instance in frame 0
-        local = xyz - anchor_centre[inst]
-        e_frame = scatter(_embed(self.pos_embed, torch.cat((local, t_idx.unsqueeze(-1) / T), dim=1).float()), slot, dim=0,
-                          dim_size=n_slots, reduce='max', plan=per_slot)
-        return e_motion.float(), e_geo.float(), e_frame.float(), anchor_centre, local        # pooled codes: [K*T,128], fp32 from here
-
-    def forward(self, input_dict):
+    def shared_terms(self, input_dict):
+        """Everything of forward() that the refinement iterations of AlignNet have in common: the reference recomputes it in every
+        iteration (models/alignnet.py:236-247 hands the same labels and features to models/tpointnet.py:200-262 each time), but
+        instance / frame indices, the slot weights and the pooled motion and geometry codes depend only on labels, features and
+        weights -- none of which moves between iterations.  Computed once; the gradients of all iterations meet in one graph."""
         feats_motion, feats_geo = input_dict['mos_feats'], input_dict['frame_feats']
-        xyz = input_dict['points']
         t_idx, inst = input_dict['time_indice'], input_dict['inst_labels']
-        gt_motion = input_dict['inst_motion_gt']
-        n_inst, T = gt_motion.size(0), gt_motion.size(1)
+        n_inst, T = input_dict['inst_motion_gt'].size(0), input_dict['inst_motion_gt'].size(1)
         n_slots = n_inst * T
-        device = feats_motion.device
         slot = (inst * T + t_idx).long()                                   # flat (instance, frame) index of every point
         per_slot = ScatterPlan(slot, n_slots)                              # one CSR per index vector, shared below
         per_inst = ScatterPlan(inst, n_inst)
+        weights = self._frame_weights(slot, per_slot, input_dict['mos_labels'], n_inst, n_slots, feats_motion.device)
+        e_motion = scatter(_embed(self.motion_embed, feats_motion), inst, dim=0, dim_size=n_inst, reduce='max', plan=per_inst)
+        e_geo = scatter(_embed(self.geo_embed, feats_geo), inst, dim=0, dim_size=n_inst, reduce='max', plan=per_inst)
+        return {'slot': slot, 'per_slot': per_slot, 'per_inst': per_inst, 'weights': weights,
+                'e_motion': e_motion.float(), 'e_geo': e_geo.float()}     # pooled codes: [K,128], fp32 from here
 
-        weights = self._frame_weights(slot, per_slot, input_dict['mos_labels'], n_inst, n_slots, device)
-        e_motion, e_geo, e_frame, anchor_centre, local = self._embeddings(feats_motion, feats_geo, xyz, t_idx, inst, slot,
-                                                                          per_inst, per_slot, n_inst, n_slots, T)
+    def _frame_embedding(self, xyz, slot, per_slot, n_slots, T):
+        slot_centre = scatter(xyz, slot, dim=0, dim_size=n_slots, reduce='mean', plan=per_slot)      # row k*T: the anchor frame's centroid
+        rows = tube_rows(xyz, per_slot, slot_centre, T)                                              # (xyz - anchor centre, t / T)
+        e_frame = scatter(_embed(self.pos_embed, rows), slot, dim=0, dim_size=n_slots, reduce='max', plan=per_slot)
+        return e_frame.float(), slot_centre, rows                           # [K*T,128]
+
+    def forward(self, input_dict, shared=None):
+        """models/tpointnet.py:200-305.  Beyond the reference's keys the result carries the two running pose tables of AlignNet's loop
+        ('remaining' = inst_motion_gt @ step^-1, 'total' = step @ input_dict['total'], models/alignnet.py:257-263): the slot kernel
+        that builds the poses updates them on the way."""
+        xyz = input_dict['points']
+        gt_motion = input_dict['inst_motion_gt']
+        n_inst, T = gt_motion.size(0), gt_motion.size(1)
+        n_slots = n_inst * T
+        if shared is None:
+            shared = self.shared_terms(input_dict)
+        slot, per_slot, weights = shared['slot'], shared['per_slot'], shared['weights']
+        e_frame, slot_centre, rows = self._frame_embedding(xyz, slot, per_slot, n_slots, T)
 
         # step 3: one 7-vector (quaternion xyzw + translation) per slot from [geometry | motion | frame | anchor frame]
-        code = torch.cat((e_geo.repeat_interleave(T, 0), e_motion.repeat_interleave(T, 0), e_frame,
-                          e_frame[::T].repeat_interleave(T, 0)), dim=1)
-        pose_vec = self.regressor(code)
-        pose_mat = batch_quat2mat(pose_vec)
+        pose_vec = self.regressor(tube_code(shared['e_geo'], shared['e_motion'], e_frame, T))
 
-        # step 4: losses on the centred clouds (the reference's l1 / l2 names are swapped, tpointnet.py:281-282; kept)
-        gt_mat, gt_vec = batch_mat2quat(gt_motion, anchor_centre)
-        moved_est = reconstruct_sequence(local, t_idx, inst, pose_mat.view(n_inst, T, 4, 4), T)
-        moved_gt = reconstruct_sequence(local, t_idx, inst, gt_mat.view(n_inst, T, 4, 4), T)
-        gap = moved_est - moved_gt
-        slot_l1 = scatter(torch.norm(gap, p=2, dim=1), slot, dim=0, dim_size=n_slots, reduce='mean', plan=per_slot)
-        slot_l2 = scatter(torch.norm(gap, p=1, dim=1), slot, dim=0, dim_size=n_slots, reduce='mean', plan=per_slot)
-        wsum = weights.sum() + _EPS
-        l1_loss = (slot_l1 * weights).sum() / wsum
-        l2_loss = (slot_l2 * weights).sum() / wsum
-        rot_loss, trans_loss = evaluate_pose(pose_vec, gt_vec, weights)
-
-        # undo the centring (t += (I - R) c) and pin frame 0 to the identity (tpointnet.py:291-296)
-        centre = anchor_centre.repeat_interleave(T, 0).unsqueeze(-1)
-        eye3 = torch.eye(3, device=device)[None].repeat(n_slots, 1, 1)
-        pose_mat[:, :3, 3] += torch.matmul(eye3 - pose_mat[:, :3, :3], centre).squeeze(2)
-        pose_mat = pose_mat.view(n_inst, T, 4, 4)
-        pose_mat[:, 0] = torch.eye(4, device=device)[None].repeat(n_inst, 1, 1)
+        # step 4: poses, losses on the centred clouds (the reference's l1 / l2 names are swapped, tpointnet.py:281-282; kept),
+        # un-centring (t += (I - R) c) with frame 0 pinned to the identity (tpointnet.py:291-296)
+        l1_loss, l2_loss, rot_loss, trans_loss, step, remaining, total = tube_pose(
+            pose_vec, rows, per_slot, gt_motion, input_dict.get('total'), slot_centre, weights, T)
+        shape = (n_inst, T, 4, 4)
         return {'l1_loss': l1_loss, 'l2_loss': l2_loss, 'rot_loss': rot_loss, 'trans_loss': trans_loss,
-                'inst_est_motion': pose_mat}
+                'inst_est_motion': step.view(shape), 'remaining': remaining.view(shape), 'total': total.view(shape)}

@@ -17,7 +17,9 @@ model, opt, loss_fn = bench.build(cfg, dev)
 batcher = DeviceBatcher(cfg)
 scenes = [sample_to_device(make_sequence(i, 5, 160000, cfg), dev) for i in range(4)]
 for it in range(2):
-    bench.train_step(model, opt, loss_fn, batcher, scenes, None, 1.0)
+    inp = batcher(scenes)
+    loss_fn(model(inp), inp)['loss'].backward()
+    opt.zero_grad(set_to_none=True)
 
 
 def report(prof):
