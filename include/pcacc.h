@@ -460,6 +460,15 @@ int pcacc_bn_rows_backward(const void *grad_y, const void *x, int dtype, int64_t
                            const float *save_mean, const float *save_invstd, void *grad_x, float *grad_gamma, float *grad_beta,
                            void *workspace, size_t workspace_bytes, void *stream);
 
+/* Weight gradient of a row-linear layer with few inputs (k in {1,2,3,4,9}, n in {32,64,128}: first layers of the point chains) or few
+ * outputs (n in {1,2,3,4,9}, k in {32,64,128}: the heads) -- same result and operand conventions as pcacc_rows_wgrad_mixed
+ * (dw_aug [n, k+1] f32, bias gradient in the last column; dtypes bit 0 dY, bit 1 dy_mask, bit 2 X set = bf16), streamed at HBM speed
+ * instead of padded into 32 x 32 matrix-core tiles; summed in a fixed order through workspace partials (no atomics). */
+int pcacc_rows_wgrad_few_supported(int32_t k, int32_t n);
+int pcacc_rows_wgrad_few_workspace_bytes(int64_t rows, int32_t k, int32_t n, size_t *bytes /*host*/);
+int pcacc_rows_wgrad_few(const void *dy, const void *dy_mask, const void *x, int32_t x_relu, int64_t rows, int32_t k, int32_t n,
+                         float *dw_aug, int32_t dtypes, void *workspace, size_t workspace_bytes, void *stream);
+
 /* TubeNet slot algebra -- models/tpointnet.py:249-305 (TPointNet.forward after the pooled embeddings) and the refinement loop of
  * models/alignnet.py:236-263, per refinement iteration.  A slot s = k * n_frames + t is instance k in frame t; slot [n] i32 is the
  * slot of every foreground point; slot_centre [S,3] the per-slot centroids (the anchor frame's row k * n_frames is the one used).

@@ -168,52 +168,87 @@ __global__ __launch_bounds__(MLP_ROWS) void rows_linear_kernel(const void *__res
 //   few outputs: k/8 lanes per row, each 8 consecutive inputs (16- or 32-byte loads), partial dot products folded with
 //                xor-shuffles inside the lane group.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int K>
+// Few inputs, G = N / 8 lanes per row (a power of two <= 16): a lane owns 8 output columns for the whole launch -- their 8 x K weights
+// and biases live in registers -- and walks the rows.  The K inputs of a row are loaded once by the row's lanes (lane g takes elements
+// g, g + G, ...: one coalesced load instruction per wave covers 64 / G rows) and handed round with wave shuffles: no LDS staging, no
+// barrier, two rows in flight per lane.  (r02: the former version -- K global loads of 4 bytes per lane and 8 x K weight reads from LDS --
+// ran the 3.2 M x 9 -> 64 layer of the pillar encoder in 297 us, address-unit- and LDS-bound; the HBM floor is 65 us.)
+#define FEW_U 4                     // rows in flight per lane in the few-feature streaming kernels
+template <int K, int G>
 __global__ __launch_bounds__(256) void rows_linear_fewk_kernel(const void *__restrict__ X, const void *__restrict__ in_mask,
                                                                const float *__restrict__ W, const float *__restrict__ bias,
                                                                const void *__restrict__ residual, const void *__restrict__ out_mask,
-                                                               void *__restrict__ Y, int64_t rows, int N, int flags, int dt)
+                                                               void *__restrict__ Y, int64_t rows, int flags, int dt)
 {
     const bool x_bf = dt & MLP_X_BF16, im_bf = dt & MLP_INMASK_BF16, r_bf = dt & MLP_RES_BF16, om_bf = dt & MLP_OUTMASK_BF16,
                y_bf = dt & MLP_Y_BF16;
-    __shared__ float wl[128 * K + 128];
-    for (int i = threadIdx.x; i < N * K; i += 256) wl[i] = W[i];
-    for (int i = threadIdx.x; i < N; i += 256) wl[128 * K + i] = bias ? bias[i] : 0.f;
-    __syncthreads();
-    const int groups = N / 8;
-    const int64_t total = rows * groups;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int64_t row = e / groups;
-        const int n0 = (int)(e - row * groups) * 8;
-        float x[K];
+    constexpr int N = 8 * G, RB = 256 / G, NL = (K + G - 1) / G;      // rows per workgroup pass, loads per lane and row
+    const int g = threadIdx.x % G, rsub = threadIdx.x / G;
+    const int lane = threadIdx.x & 63, rowbase = lane - g;
+    const int n0 = g * 8;
+    float w[8][K], b[8];
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            float v = mlp_ld1(X, x_bf, row * K + k);
-            if (flags & MLP_PRE_RELU) v = fmaxf(v, 0.f);
-            if (in_mask && !(mlp_ld1(in_mask, im_bf, row * K + k) > 0.f)) v = 0.f;
-            x[k] = v;
-        }
-        float acc[8];
+    for (int j = 0; j < 8; ++j) {
+        b[j] = bias ? bias[n0 + j] : 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            acc[j] = wl[128 * K + n0 + j];
+        for (int k = 0; k < K; ++k) w[j][k] = W[(n0 + j) * K + k];
+    }
+    const int64_t stride = (int64_t)gridDim.x * RB;
+    for (int64_t r0 = (int64_t)blockIdx.x * RB + rsub; r0 < rows; r0 += FEW_U * stride) {      // the lanes of a row share r0: the shuffles below stay inside the row
+        float part[FEW_U][NL];
 #pragma unroll
-            for (int k = 0; k < K; ++k) acc[j] = fmaf(x[k], wl[(n0 + j) * K + k], acc[j]);
-        }
-        const int64_t g4 = (row * N + n0) / 4;
+        for (int u = 0; u < FEW_U; ++u) {
+            const int64_t row = r0 + u * stride;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            float4 v = make_float4(acc[4 * h], acc[4 * h + 1], acc[4 * h + 2], acc[4 * h + 3]);
-            if (residual) { const float4 r = pcacc_ld4(residual, r_bf, g4 + h); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
-            if (flags & MLP_POST_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            if (out_mask) {
-                const float4 mk = pcacc_ld4(out_mask, om_bf, g4 + h);
-                if (!(mk.x > 0.f)) v.x = 0.f;
-                if (!(mk.y > 0.f)) v.y = 0.f;
-                if (!(mk.z > 0.f)) v.z = 0.f;
-                if (!(mk.w > 0.f)) v.w = 0.f;
+            for (int l = 0; l < NL; ++l) {
+                const int k = g + l * G;
+                float v = 0.f;
+                if (row < rows && k < K) {
+                    v = mlp_ld1(X, x_bf, row * K + k);
+                    if (flags & MLP_PRE_RELU) v = fmaxf(v, 0.f);
+                    if (in_mask && !(mlp_ld1(in_mask, im_bf, row * K + k) > 0.f)) v = 0.f;
+                }
+                part[u][l] = v;
             }
-            pcacc_st4(Y, y_bf, g4 + h, v);
+        }
+#pragma unroll
+        for (int u = 0; u < FEW_U; ++u) {
+            const int64_t row = r0 + u * stride;
+            float x[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) x[k] = __shfl(part[u][k / G], rowbase + (k % G), 64);
+            if (row >= rows) continue;
+            float acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                acc[j] = b[j];
+#pragma unroll
+                for (int k = 0; k < K; ++k) acc[j] = fmaf(x[k], w[j][k], acc[j]);
+            }
+            const int64_t g4 = (row * N + n0) / 4;
+            if (y_bf && !residual && !out_mask) {                     // the common case: one 16-byte store of 8 bf16
+                if (flags & MLP_POST_RELU) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = fmaxf(acc[j], 0.f);
+                }
+                reinterpret_cast<uint4 *>(Y)[g4 / 2] = make_uint4(pcacc_pack_bf16x2(acc[0], acc[1]), pcacc_pack_bf16x2(acc[2], acc[3]),
+                                                                 pcacc_pack_bf16x2(acc[4], acc[5]), pcacc_pack_bf16x2(acc[6], acc[7]));
+                continue;
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float4 v = make_float4(acc[4 * h], acc[4 * h + 1], acc[4 * h + 2], acc[4 * h + 3]);
+                if (residual) { const float4 r = pcacc_ld4(residual, r_bf, g4 + h); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+                if (flags & MLP_POST_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (out_mask) {
+                    const float4 mk = pcacc_ld4(out_mask, om_bf, g4 + h);
+                    if (!(mk.x > 0.f)) v.x = 0.f;
+                    if (!(mk.y > 0.f)) v.y = 0.f;
+                    if (!(mk.z > 0.f)) v.z = 0.f;
+                    if (!(mk.w > 0.f)) v.w = 0.f;
+                }
+                pcacc_st4(Y, y_bf, g4 + h, v);
+            }
         }
     }
 }
@@ -288,13 +323,16 @@ static int rows_linear_any(const void *x, const void *in_mask, const float *w, c
     if (rows == 0) return PCACC_OK;
     if (!x || !w || !y) return PCACC_E_ARG;
     hipStream_t s = pcacc_stream(stream);
-    if (k <= 9 && n % 8 == 0) {                                    // few inputs: lane per (row, 8 outputs)
-        const int grid = pcacc_grid(rows * (n / 8), 256, PCACC_CUS * 16);
-#define FEWK(KK) rows_linear_fewk_kernel<KK><<<grid, 256, 0, s>>>(x, in_mask, w, bias, residual, out_mask, y, rows, n, flags, dt)
-        if (k == 2) FEWK(2);
-        else if (k == 3) FEWK(3);
-        else if (k == 4) FEWK(4);
-        else FEWK(9);
+    if (k <= 9 && (n == 8 || n == 16 || n == 32 || n == 64 || n == 128)) {   // few inputs: lane per (row, 8 outputs)
+        const int grid = pcacc_grid(rows * (n / 8), 256 * FEW_U, PCACC_CUS * 8);
+#define FEWK(KK, GG) rows_linear_fewk_kernel<KK, GG><<<grid, 256, 0, s>>>(x, in_mask, w, bias, residual, out_mask, y, rows, flags, dt)
+#define FEWK_G(KK) do { switch (n) { case 8: FEWK(KK, 1); break; case 16: FEWK(KK, 2); break; case 32: FEWK(KK, 4); break; \
+                                     case 64: FEWK(KK, 8); break; default: FEWK(KK, 16); break; } } while (0)
+        if (k == 2) FEWK_G(2);
+        else if (k == 3) FEWK_G(3);
+        else if (k == 4) FEWK_G(4);
+        else FEWK_G(9);
+#undef FEWK_G
 #undef FEWK
         PCACC_CHECK_LAUNCH();
         return PCACC_OK;
@@ -455,6 +493,196 @@ __global__ __launch_bounds__(256) void rows_wgrad_kernel(const void *__restrict_
             }
         }
     }
+}
+
+// One of the two operands has only a few features (the 9 / 4 / 3 / 2 inputs of a first layer, or the 1 / 2 outputs of a head):
+// the 32 x 32 MFMA tiles above are mostly padding there and the kernel is LDS-bound at 0.3-1.1 TB/s.  Streamed instead: the WIDE
+// operand (C = 32 / 64 / 128 features, rows of C4N = C / 4 lanes, 8- or 16-byte loads) against the NARROW one (F <= 9 features: the
+// lanes of a row load one element each and hand them round with wave shuffles); each lane keeps its 4 x F partial products, the
+// column sums of its 4 wide features and the sums of the narrow features.  Folded over the lanes of a wave that own the same
+// columns (xor-shuffles) and over the 4 waves (LDS); workgroup partials go to the workspace and a second kernel adds them up in
+// a fixed order (fp32 atomics on the ~10^3 output words from ~10^3 workgroups serialise in L2: 1.3 ms measured).
+//   wide = dY, narrow = X (few inputs) : dW[n][k] = P[n][k], bias column = wide sums
+//   wide = X, narrow = dY (few outputs): dW[n][k] = P[k][n], bias column = narrow sums
+#define FEW_WU 2                    // (4 rows in flight cost the weight-gradient kernel half its occupancy: 500 us instead of 308)
+template <int F, int C4N>
+__global__ __launch_bounds__(256) void rows_wgrad_few_kernel(const void *__restrict__ wide, const void *__restrict__ wide_mask, int wide_relu,
+                                                             const void *__restrict__ narrow, const void *__restrict__ narrow_mask,
+                                                             int narrow_relu, int64_t rows, int wide_is_dy, int flags_bf,
+                                                             float *__restrict__ partial)
+{
+    const bool w_bf = flags_bf & 1, wm_bf = flags_bf & 2, n_bf = flags_bf & 4, nm_bf = flags_bf & 8;
+    constexpr int V = 4 * F + 4 + F;                                   // values a lane accumulates
+    constexpr int C = 4 * C4N, RB = 256 / C4N, NL = (F + C4N - 1) / C4N;
+    __shared__ float red[4 * C4N * V];
+    const int c4 = threadIdx.x % C4N, rsub = threadIdx.x / C4N;
+    const int lane = threadIdx.x & 63, rowbase = lane - c4;
+    float acc[F][4], wsum[4] = {0.f, 0.f, 0.f, 0.f}, ssum[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) { ssum[f] = 0.f; acc[f][0] = acc[f][1] = acc[f][2] = acc[f][3] = 0.f; }
+    const int64_t stride = (int64_t)gridDim.x * RB;
+    for (int64_t r0 = (int64_t)blockIdx.x * RB + rsub; r0 < rows; r0 += FEW_WU * stride) {       // the lanes of a row share r0
+        float4 w[FEW_WU];
+        float part[FEW_WU][NL];
+#pragma unroll
+        for (int u = 0; u < FEW_WU; ++u) {
+            const int64_t row = r0 + u * stride;
+            w[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < rows) {
+                w[u] = pcacc_ld4(wide, w_bf, row * C4N + c4);
+                if (wide_relu) { w[u].x = fmaxf(w[u].x, 0.f); w[u].y = fmaxf(w[u].y, 0.f); w[u].z = fmaxf(w[u].z, 0.f); w[u].w = fmaxf(w[u].w, 0.f); }
+                if (wide_mask) {
+                    const float4 mk = pcacc_ld4(wide_mask, wm_bf, row * C4N + c4);
+                    if (!(mk.x > 0.f)) w[u].x = 0.f;
+                    if (!(mk.y > 0.f)) w[u].y = 0.f;
+                    if (!(mk.z > 0.f)) w[u].z = 0.f;
+                    if (!(mk.w > 0.f)) w[u].w = 0.f;
+                }
+            }
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                const int f = c4 + l * C4N;
+                float v = 0.f;
+                if (row < rows && f < F) {
+                    v = mlp_ld1(narrow, n_bf, row * F + f);
+                    if (narrow_relu) v = fmaxf(v, 0.f);
+                    if (narrow_mask && !(mlp_ld1(narrow_mask, nm_bf, row * F + f) > 0.f)) v = 0.f;
+                }
+                part[u][l] = v;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < FEW_WU; ++u) {
+            wsum[0] += w[u].x; wsum[1] += w[u].y; wsum[2] += w[u].z; wsum[3] += w[u].w;
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                const float v = __shfl(part[u][f / C4N], rowbase + (f % C4N), 64);
+                ssum[f] += v;
+                acc[f][0] = fmaf(v, w[u].x, acc[f][0]);
+                acc[f][1] = fmaf(v, w[u].y, acc[f][1]);
+                acc[f][2] = fmaf(v, w[u].z, acc[f][2]);
+                acc[f][3] = fmaf(v, w[u].w, acc[f][3]);
+            }
+        }
+    }
+    // lanes c4, c4 + C4N, ... of a wave own the same columns
+    float vals[V];
+#pragma unroll
+    for (int f = 0; f < F; ++f) { vals[4 * f] = acc[f][0]; vals[4 * f + 1] = acc[f][1]; vals[4 * f + 2] = acc[f][2]; vals[4 * f + 3] = acc[f][3]; vals[4 * F + 4 + f] = ssum[f]; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vals[4 * F + j] = wsum[j];
+#pragma unroll
+    for (int d = C4N; d < 64; d <<= 1)
+#pragma unroll
+        for (int i = 0; i < V; ++i) vals[i] += __shfl_xor(vals[i], d, 64);
+    const int wave = threadIdx.x >> 6;
+    if (lane < C4N)
+#pragma unroll
+        for (int i = 0; i < V; ++i) red[(wave * C4N + lane) * V + i] = vals[i];
+    __syncthreads();
+    if (threadIdx.x < C4N) {
+#pragma unroll
+        for (int i = 0; i < V; ++i)
+            vals[i] = (red[threadIdx.x * V + i] + red[(C4N + threadIdx.x) * V + i]) + (red[(2 * C4N + threadIdx.x) * V + i] + red[(3 * C4N + threadIdx.x) * V + i]);
+        if (wide_is_dy) {                                              // dW [C][F + 1]
+            float *out = partial + (int64_t)blockIdx.x * C * (F + 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float *o = out + (c4 * 4 + j) * (F + 1);
+#pragma unroll
+                for (int f = 0; f < F; ++f) o[f] = vals[4 * f + j];
+                o[F] = vals[4 * F + j];
+            }
+        } else {                                                       // dW [F][C + 1]
+            float *out = partial + (int64_t)blockIdx.x * F * (C + 1);
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                float *o = out + f * (C + 1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[c4 * 4 + j] = vals[4 * f + j];
+                if (c4 == 0) o[C] = vals[4 * F + 4 + f];
+            }
+        }
+    }
+}
+
+// out[e] = sum over the workgroup partials, in index order: 64 elements x 4 slices per workgroup
+__global__ __launch_bounds__(256) void rows_wgrad_few_reduce_kernel(const float *__restrict__ partial, int n_parts, int elems, float *__restrict__ out)
+{
+    __shared__ float red[256];
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+    float s0 = 0.f, s1 = 0.f;
+    if (e < elems) {
+        int p = slice;
+        for (; p + 4 < n_parts; p += 8) {
+            s0 += partial[(int64_t)p * elems + e];
+            s1 += partial[(int64_t)(p + 4) * elems + e];
+        }
+        if (p < n_parts) s0 += partial[(int64_t)p * elems + e];
+    }
+    red[threadIdx.x] = s0 + s1;
+    __syncthreads();
+    if (slice == 0 && e < elems) out[e] = (red[threadIdx.x] + red[64 + threadIdx.x]) + (red[128 + threadIdx.x] + red[192 + threadIdx.x]);
+}
+
+static bool wgrad_few_width(int c) { return c == 32 || c == 64 || c == 128; }
+static bool wgrad_few_feats(int f) { return f == 1 || f == 2 || f == 3 || f == 4 || f == 9; }
+static int wgrad_few_grid(int64_t rows, int c)
+{
+    const int rb = 256 / (c / 4);
+    const int64_t tiles = (rows + FEW_WU * rb - 1) / (FEW_WU * rb);
+    return (int)(tiles < PCACC_CUS * 4 ? (tiles < 1 ? 1 : tiles) : PCACC_CUS * 4);
+}
+
+extern "C" int pcacc_rows_wgrad_few_supported(int32_t k, int32_t n)
+{
+    return ((wgrad_few_feats(k) && wgrad_few_width(n)) || (wgrad_few_feats(n) && wgrad_few_width(k))) ? 1 : 0;
+}
+
+extern "C" int pcacc_rows_wgrad_few_workspace_bytes(int64_t rows, int32_t k, int32_t n, size_t *bytes)
+{
+    if (!bytes || rows < 0 || !pcacc_rows_wgrad_few_supported(k, n)) return PCACC_E_ARG;
+    const bool few_in = wgrad_few_feats(k) && wgrad_few_width(n);
+    *bytes = (size_t)wgrad_few_grid(rows, few_in ? n : k) * n * (k + 1) * sizeof(float);
+    return PCACC_OK;
+}
+
+extern "C" int pcacc_rows_wgrad_few(const void *dy, const void *dy_mask, const void *x, int32_t x_relu, int64_t rows, int32_t k, int32_t n,
+                                    float *dw_aug, int32_t dt, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (rows < 0 || !dw_aug || (dt & ~7) || !pcacc_rows_wgrad_few_supported(k, n)) return PCACC_E_ARG;
+    hipStream_t s = pcacc_stream(stream);
+    const int elems = n * (k + 1);
+    if (rows == 0) {
+        if (hipMemsetAsync(dw_aug, 0, (size_t)elems * sizeof(float), s) != hipSuccess) return PCACC_E_LAUNCH;
+        return PCACC_OK;
+    }
+    if (!dy || !x || !workspace) return PCACC_E_ARG;
+    const bool few_in = wgrad_few_feats(k) && wgrad_few_width(n);
+    const int c = few_in ? n : k, f = few_in ? k : n;
+    const int grid = wgrad_few_grid(rows, c);
+    if (workspace_bytes < (size_t)grid * elems * sizeof(float)) return PCACC_E_WORKSPACE;
+    float *partial = reinterpret_cast<float *>(workspace);
+    // bf16 flags: wide, wide mask, narrow, narrow mask (dt: bit 0 dY, bit 1 dy_mask, bit 2 X)
+    const int fb = few_in ? (dt & 7) : (((dt & 4) ? 1 : 0) | ((dt & 1) ? 4 : 0) | ((dt & 2) ? 8 : 0));
+#define WG_FEW(FF, CC)                                                                                                                     \
+    do {                                                                                                                                   \
+        if (few_in) rows_wgrad_few_kernel<FF, CC><<<grid, 256, 0, s>>>(dy, dy_mask, 0, x, nullptr, x_relu, rows, 1, fb, partial);          \
+        else rows_wgrad_few_kernel<FF, CC><<<grid, 256, 0, s>>>(x, nullptr, x_relu, dy, dy_mask, 0, rows, 0, fb, partial);                 \
+    } while (0)
+#define WG_FEW_C(FF) do { if (c == 32) WG_FEW(FF, 8); else if (c == 64) WG_FEW(FF, 16); else WG_FEW(FF, 32); } while (0)
+    switch (f) {
+        case 1: WG_FEW_C(1); break;
+        case 2: WG_FEW_C(2); break;
+        case 3: WG_FEW_C(3); break;
+        case 4: WG_FEW_C(4); break;
+        default: WG_FEW_C(9); break;
+    }
+#undef WG_FEW_C
+#undef WG_FEW
+    rows_wgrad_few_reduce_kernel<<<(elems + 63) / 64, 256, 0, s>>>(partial, grid, elems, dw_aug);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
 }
 
 static int rows_wgrad_any(const void *dy, const void *dy_mask, const void *x, int x_relu, int64_t rows, int k, int n, float *dw_aug,

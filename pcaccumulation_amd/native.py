@@ -58,7 +58,7 @@ EXPORTS = [
     'pcacc_conv3x3_masked_bf16',
     'pcacc_conv3x3_wgrad_deep_supported', 'pcacc_conv3x3_wgrad_deep_workspace_bytes', 'pcacc_conv3x3_wgrad_deep_bf16', 'pcacc_bn_rows_workspace_bytes', 'pcacc_bn_rows_forward', 'pcacc_bn_rows_backward',
     'pcacc_tube_rows', 'pcacc_tube_code', 'pcacc_tube_code_backward', 'pcacc_tube_pose_forward', 'pcacc_tube_gap_forward', 'pcacc_tube_finish',
-    'pcacc_tube_gap_backward', 'pcacc_tube_pose_backward',
+    'pcacc_tube_gap_backward', 'pcacc_tube_pose_backward', 'pcacc_rows_wgrad_few_supported', 'pcacc_rows_wgrad_few_workspace_bytes', 'pcacc_rows_wgrad_few',
 ]
 
 
@@ -396,6 +396,14 @@ def rows_wgrad(dy, x, dy_mask=None, x_relu=False):
                                            _dev(ws), ctypes.c_size_t(ws.numel()), _stream()), 'rows_wgrad_bf16')
         return out
     dt = _row_dtype_bit(dy, 1, 'dy') | _row_dtype_bit(dy_mask, 2, 'dy_mask') | _row_dtype_bit(x, 4, 'x')
+    if lib().pcacc_rows_wgrad_few_supported(int(k), int(n)):
+        need = ctypes.c_size_t(0)
+        _check(lib().pcacc_rows_wgrad_few_workspace_bytes(_i64(rows), int(k), int(n), ctypes.byref(need)), 'rows_wgrad_few_workspace')
+        ws = _ws(need.value, dy.device)
+        _check(lib().pcacc_rows_wgrad_few(_dev(dy, None, 'dy'), _dev(dy_mask, None, 'dy_mask') if dy_mask is not None else None, _dev(x, None, 'x'),
+                                          1 if x_relu else 0, _i64(rows), int(k), int(n), _dev(out), dt, _dev(ws), ctypes.c_size_t(ws.numel()),
+                                          _stream()), 'rows_wgrad_few')
+        return out
     _check(lib().pcacc_rows_wgrad_mixed(_dev(dy, None, 'dy'), _dev(dy_mask, None, 'dy_mask') if dy_mask is not None else None,
                                         _dev(x, None, 'x'), 1 if x_relu else 0, _i64(rows), int(k), int(n), _dev(out), dt, _stream()),
            'rows_wgrad')

@@ -577,6 +577,55 @@ def test_rows_linear_mixed_and_wgrad_dtypes():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('c,f,rows', [(64, 9, 70001), (32, 4, 5003), (32, 3, 255), (128, 2, 9001), (64, 1, 4097), (128, 9, 1)])
+def test_rows_wgrad_few_features_mixed_dtypes(c, f, rows):
+    """The streamed weight gradient for first layers (few inputs) and heads (few outputs) at the dtypes of the bf16 step: bf16
+    gradient / activation rows against f32 ones, with the ReLU mask and the pre-ReLU flag."""
+    import torch
+    from pcaccumulation_amd import native
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(c * 10 + f)
+    wide = torch.randn(rows, c, generator=g).to(dev).to(torch.bfloat16)
+    mk = torch.randn(rows, c, generator=g).to(dev).to(torch.bfloat16)
+    narrow = torch.randn(rows, f, generator=g).to(dev)
+    ones = torch.ones(rows, 1, device=dev, dtype=torch.float64)
+    # few inputs: dy = wide (masked), x = narrow (pre-ReLU)
+    aug = native.rows_wgrad(wide, narrow, dy_mask=mk, x_relu=True)
+    geff = (wide.float() * (mk.float() > 0)).double()
+    ref = geff.t() @ torch.cat([torch.relu(narrow).double(), ones], 1)
+    assert aug.shape == (c, f + 1) and (aug.double() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+    # few outputs: dy = narrow (f32, masked), x = wide (bf16, pre-ReLU)
+    nm = torch.randn(rows, f, generator=g).to(dev)
+    aug = native.rows_wgrad(narrow, wide, dy_mask=nm, x_relu=True)
+    ref = (narrow * (nm > 0)).double().t() @ torch.cat([torch.relu(wide.float()).double(), ones], 1)
+    assert aug.shape == (f, c + 1) and (aug.double() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_csr_order_for_all_segment_lengths():
+    """Ascending point index inside every segment for lengths 0..64 (register network up to 8, wave-wide bitonic network up to
+    64), whatever order the cursor fill left; longer segments keep the fill's order but hold the right members."""
+    import torch
+    from pcaccumulation_amd import native
+    rng = np.random.RandomState(3)
+    lengths = np.concatenate([np.arange(0, 70), rng.randint(0, 12, 3000), rng.randint(9, 65, 300), [200, 1000]])
+    rng.shuffle(lengths)
+    m = len(lengths)
+    p2v = np.repeat(np.arange(m), lengths).astype(np.int32)
+    rng.shuffle(p2v)
+    offs, order = native.csr_build(torch.from_numpy(p2v).cuda(), m)
+    offs, order = offs.cpu().numpy(), order.cpu().numpy()
+    assert np.array_equal(np.diff(offs), lengths)
+    want = np.argsort(p2v, kind='stable')
+    for s in range(m):
+        a, b = offs[s], offs[s + 1]
+        if lengths[s] <= 64:
+            assert np.array_equal(order[a:b], want[a:b]), (s, lengths[s])
+        else:
+            assert np.array_equal(np.sort(order[a:b]), want[a:b])
+
+
+@pytest.mark.gpu
 def test_linear_rows_autograd_bf16():
     import torch
     from pcaccumulation_amd import ops
