@@ -460,6 +460,16 @@ int pcacc_bn_rows_backward(const void *grad_y, const void *x, int dtype, int64_t
                            const float *save_mean, const float *save_invstd, void *grad_x, float *grad_gamma, float *grad_beta,
                            void *workspace, size_t workspace_bytes, void *stream);
 
+/* Tail of a U-Net encoder stage -- models/unet.py:60-71 (DownConv: ... conv, ReLU, 2x2 max-pool; returns the pooled map and the map
+ * before the pool).  Channels-last bf16 maps [n_img, h, w, c], c a multiple of 8.
+ *  maxpool2x2                out [n_img, h/2, w/2, c]: nn.MaxPool2d(2, 2) (floor mode; NaN propagates), no index map.
+ *  pool_skip_relu_backward   grad_y = (un-pool(grad_pooled) + grad_skip) where y > 0, else 0: the gradient of the stage's ReLU input
+ *                            from the gradients of its two consumers in one pass (the window's first maximum in scan order takes
+ *                            the pooled gradient, as the library's forward picks it); either gradient may be NULL (= 0). */
+int pcacc_maxpool2x2_bf16(const uint16_t *x, int64_t n_img, int32_t h, int32_t w, int32_t c, uint16_t *out, void *stream);
+int pcacc_pool_skip_relu_backward_bf16(const uint16_t *y, const uint16_t *grad_pooled, const uint16_t *grad_skip, int64_t n_img, int32_t h,
+                                       int32_t w, int32_t c, uint16_t *grad_y, void *stream);
+
 /* Weight gradient of a row-linear layer with few inputs (k in {1,2,3,4,9}, n in {32,64,128}: first layers of the point chains) or few
  * outputs (n in {1,2,3,4,9}, k in {32,64,128}: the heads) -- same result and operand conventions as pcacc_rows_wgrad_mixed
  * (dw_aug [n, k+1] f32, bias gradient in the last column; dtypes bit 0 dY, bit 1 dy_mask, bit 2 X set = bf16), streamed at HBM speed

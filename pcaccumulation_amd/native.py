@@ -59,6 +59,7 @@ EXPORTS = [
     'pcacc_conv3x3_wgrad_deep_supported', 'pcacc_conv3x3_wgrad_deep_workspace_bytes', 'pcacc_conv3x3_wgrad_deep_bf16', 'pcacc_bn_rows_workspace_bytes', 'pcacc_bn_rows_forward', 'pcacc_bn_rows_backward',
     'pcacc_tube_rows', 'pcacc_tube_code', 'pcacc_tube_code_backward', 'pcacc_tube_pose_forward', 'pcacc_tube_gap_forward', 'pcacc_tube_finish',
     'pcacc_tube_gap_backward', 'pcacc_tube_pose_backward', 'pcacc_rows_wgrad_few_supported', 'pcacc_rows_wgrad_few_workspace_bytes', 'pcacc_rows_wgrad_few',
+    'pcacc_maxpool2x2_bf16', 'pcacc_pool_skip_relu_backward_bf16',
 ]
 
 
@@ -926,3 +927,22 @@ def tube_pose_backward(pose_vec, remaining, slot_centre, weights, wsum, grad_pos
                                           _opt(grad_rot, torch.float64, 'grad_rot'), _opt(grad_trans, torch.float64, 'grad_trans'), int(s),
                                           int(n_frames), _dev(g_vec), _stream()), 'tube_pose_backward')
     return g_vec
+
+
+# ---- tail of a U-Net encoder stage (include/pcacc.h: pcacc_maxpool2x2_bf16, pcacc_pool_skip_relu_backward_bf16) -----------------------
+def maxpool2x2(x_rows):
+    """[n_img, h, w, c] bf16 channels-last -> [n_img, h/2, w/2, c]."""
+    n, h, w, c = x_rows.shape
+    out = torch.empty((n, h // 2, w // 2, c), dtype=torch.bfloat16, device=x_rows.device)
+    _check(lib().pcacc_maxpool2x2_bf16(_dev(x_rows, torch.bfloat16, 'x'), _i64(n), int(h), int(w), int(c), _dev(out), _stream()), 'maxpool2x2')
+    return out
+
+
+def pool_skip_relu_backward(y_rows, grad_pooled, grad_skip):
+    """(un-pool(grad_pooled) + grad_skip) * (y > 0) in one pass; either gradient may be None."""
+    n, h, w, c = y_rows.shape
+    out = torch.empty_like(y_rows)
+    _check(lib().pcacc_pool_skip_relu_backward_bf16(_dev(y_rows, torch.bfloat16, 'y'), _opt(grad_pooled, torch.bfloat16, 'grad_pooled'),
+                                                    _opt(grad_skip, torch.bfloat16, 'grad_skip'), _i64(n), int(h), int(w), int(c), _dev(out),
+                                                    _stream()), 'pool_skip_relu_backward')
+    return out

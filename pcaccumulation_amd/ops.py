@@ -566,10 +566,11 @@ class _Conv3x3(torch.autograd.Function):
     transposed weights, weight and bias gradients with the library's backward-weights kernel (fp32 results)."""
 
     @staticmethod
-    def forward(ctx, x_rows, weight, bias, frames, relu):
+    def forward(ctx, x_rows, weight, bias, frames, relu, premasked=False):
         y = native.conv3x3(x_rows, prepared_conv_weights(weight)[0], bias.detach().float() if bias is not None else None, frames, relu)
-        ctx.save_for_backward(x_rows, weight, y if relu else None)
-        ctx.meta = (frames, relu, bias is not None)
+        # premasked: every consumer of y hands back a gradient that is already zero where y <= 0 (pool_skip below): no ReLU pass here
+        ctx.save_for_backward(x_rows, weight, y if relu and not premasked else None)
+        ctx.meta = (frames, relu and not premasked, bias is not None)
         return y
 
     @staticmethod
@@ -623,7 +624,7 @@ class _Conv3x3(torch.autograd.Function):
                     gw = gw.reshape(o, 3, i, 3, 3).permute(0, 2, 1, 3, 4)
                 gw = gw.reshape(weight.shape)
                 gb = gb2.float() if has_bias else None
-        return gx, gw, gb, None, None
+        return gx, gw, gb, None, None, None
 
 
 def _stack_frames(rows, frames):
@@ -652,22 +653,51 @@ def conv3x3_available(x, weight):
             and conv3x3_preferred(weight.shape[1], weight.shape[0], x.shape[-2], x.shape[-1]))
 
 
-def conv3x3_rows(x_rows, weight, bias, frames=1, relu=False):
+def conv3x3_rows(x_rows, weight, bias, frames=1, relu=False, premasked=False):
     """x_rows [n_img, H, W, C_in] -> [n_img, H, W, C_out] (bf16).  weight [O,I,3,3] (frames ignored) or [O,I,3,3,3]."""
     if x_rows.dtype != torch.bfloat16:
         x_rows = x_rows.to(torch.bfloat16)
-    return _Conv3x3.apply(x_rows.contiguous(), weight, bias, int(frames), bool(relu))
+    return _Conv3x3.apply(x_rows.contiguous(), weight, bias, int(frames), bool(relu), bool(premasked))
+
+
+def conv3x3_native(x, conv):
+    """True when conv3x3(x, conv) takes the MFMA kernels (GPU, bf16 compute, plain 3x3 / stride 1 / padding 1, supported widths)."""
+    return conv3x3_available(x, conv.weight) and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) \
+        and conv.dilation == (1, 1) and conv.groups == 1
 
 
 def conv3x3(x, conv, relu=False):
     """`relu?(conv(x))` for an nn.Conv2d(3x3, stride 1, padding 1) on an NCHW tensor; channels-last bf16 inputs on the GPU go
     through the MFMA kernel, everything else through the library with the same semantics."""
-    if conv3x3_available(x, conv.weight) and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) \
-            and conv.dilation == (1, 1) and conv.groups == 1:
+    if conv3x3_native(x, conv):
         y = conv3x3_rows(x.permute(0, 2, 3, 1), conv.weight, conv.bias, 1, relu)
         return y.permute(0, 3, 1, 2)
     y = conv(x)
     return torch.relu(y) if relu else y
+
+
+class _PoolSkip(torch.autograd.Function):
+    """y [n, H, W, C] bf16 rows = a ReLU output -> (2x2 max-pool of y, y).  Backward: ONE pass that un-pools the first gradient, adds
+    the second and zeroes the sum where y <= 0 (csrc/pool.hip) -- in place of max_pool2d_backward + add + threshold_backward."""
+
+    @staticmethod
+    def forward(ctx, y_rows):
+        ctx.save_for_backward(y_rows)
+        return native.maxpool2x2(y_rows), y_rows.view_as(y_rows)
+
+    @staticmethod
+    def backward(ctx, g_pool, g_skip):
+        y_rows, = ctx.saved_tensors
+        c = lambda g: g.contiguous().to(torch.bfloat16) if g is not None else None
+        return native.pool_skip_relu_backward(y_rows, c(g_pool), c(g_skip))
+
+
+def conv3x3_relu_pool(x, conv):
+    """(max_pool2d(y, 2), y) with y = relu(conv(x)) -- the tail of models/unet.py:60-71 -- when conv3x3_native(x, conv) and the
+    channel count suits the pooling kernel; the ReLU's backward is folded into the pooling's (one pass, see _PoolSkip)."""
+    y = conv3x3_rows(x.permute(0, 2, 3, 1), conv.weight, conv.bias, 1, True, premasked=True)
+    pooled, skip = _PoolSkip.apply(y)
+    return pooled.permute(0, 3, 1, 2), skip.permute(0, 3, 1, 2)
 
 
 class _Sinkhorn(torch.autograd.Function):

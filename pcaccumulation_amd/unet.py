@@ -29,7 +29,10 @@ class DownConv(nn.Module):
             self.pool = nn.MaxPool2d(kernel_size=2, stride=2)
 
     def forward(self, x):
-        x = ops.conv3x3(ops.conv3x3(x, self.conv1, relu=True), self.conv2, relu=True)
+        x = ops.conv3x3(x, self.conv1, relu=True)
+        if self.pooling and ops.conv3x3_native(x, self.conv2) and self.out_channels % 8 == 0:
+            return ops.conv3x3_relu_pool(x, self.conv2)            # second conv + ReLU + pool, their backward in one pass (csrc/pool.hip)
+        x = ops.conv3x3(x, self.conv2, relu=True)
         return (self.pool(x) if self.pooling else x), x
 
 
