@@ -460,6 +460,20 @@ int pcacc_bn_rows_backward(const void *grad_y, const void *x, int dtype, int64_t
                            const float *save_mean, const float *save_invstd, void *grad_x, float *grad_gamma, float *grad_beta,
                            void *workspace, size_t workspace_bytes, void *stream);
 
+/* A ResnetBlockFC of the pillar encoder -- models/pillar_encoder.py:13-55 with size_in 64, size_h 32, size_out 32 and the linear
+ * shortcut (the blocks of PillarFeatureNet, :76-78) -- fused over bf16 point rows:
+ *     h = relu(x) w0^T + b0,   out = relu(h) w1^T + b1 + x ws^T          w0, ws [32,64], w1 [32,32], b0, b1 [32] f32
+ * x [rows,64] = `xa` when pooled == NULL, else cat(xa[row] [32], pooled[p2v[row]] [32]) (models/pillar_encoder.py:116-118).
+ * forward: out [rows,32], relu_h [rows,32] (kept for the backward; may be NULL).
+ * backward: grad_xa [rows,64] (pooled == NULL) or grad_xa [rows,32] + grad_xb [rows,32] (per point: the caller sums it over each
+ * pillar's points); grad_params [5184] f32 = d w1 [32,32] | d b1 [32] | d ws [32,64] | d w0 [32,64] | d b0 [32]. */
+int pcacc_pfn_block_forward(const uint16_t *xa, const uint16_t *pooled, const int32_t *p2v, const float *w0, const float *b0,
+                            const float *ws, const float *w1, const float *b1, uint16_t *out, uint16_t *relu_h, int64_t rows, void *stream);
+int pcacc_pfn_block_backward_workspace_bytes(int64_t rows, size_t *bytes /*host*/);
+int pcacc_pfn_block_backward(const uint16_t *xa, const uint16_t *pooled, const int32_t *p2v, const uint16_t *relu_h,
+                             const uint16_t *grad_out, const float *w0, const float *ws, const float *w1, uint16_t *grad_xa,
+                             uint16_t *grad_xb, float *grad_params, int64_t rows, void *workspace, size_t workspace_bytes, void *stream);
+
 /* Tail of a U-Net encoder stage -- models/unet.py:60-71 (DownConv: ... conv, ReLU, 2x2 max-pool; returns the pooled map and the map
  * before the pool).  Channels-last bf16 maps [n_img, h, w, c], c a multiple of 8.
  *  maxpool2x2                out [n_img, h/2, w/2, c]: nn.MaxPool2d(2, 2) (floor mode; NaN propagates), no index map.

@@ -60,6 +60,7 @@ EXPORTS = [
     'pcacc_tube_rows', 'pcacc_tube_code', 'pcacc_tube_code_backward', 'pcacc_tube_pose_forward', 'pcacc_tube_gap_forward', 'pcacc_tube_finish',
     'pcacc_tube_gap_backward', 'pcacc_tube_pose_backward', 'pcacc_rows_wgrad_few_supported', 'pcacc_rows_wgrad_few_workspace_bytes', 'pcacc_rows_wgrad_few',
     'pcacc_maxpool2x2_bf16', 'pcacc_pool_skip_relu_backward_bf16',
+    'pcacc_pfn_block_forward', 'pcacc_pfn_block_backward_workspace_bytes', 'pcacc_pfn_block_backward',
 ]
 
 
@@ -946,3 +947,39 @@ def pool_skip_relu_backward(y_rows, grad_pooled, grad_skip):
                                                     _opt(grad_skip, torch.bfloat16, 'grad_skip'), _i64(n), int(h), int(w), int(c), _dev(out),
                                                     _stream()), 'pool_skip_relu_backward')
     return out
+
+
+# ---- fused ResnetBlockFC of the pillar encoder (include/pcacc.h: pcacc_pfn_block_*) ---------------------------------------------------
+PFN_BLOCK_SLICES = {'w1': (0, 1024, (32, 32)), 'b1': (1024, 1056, (32,)), 'ws': (1056, 3104, (32, 64)), 'w0': (3104, 5152, (32, 64)),
+                    'b0': (5152, 5184, (32,))}
+
+
+def pfn_block_forward(xa, pooled, p2v, w0, b0, ws, w1, b1):
+    """-> (out [rows,32] bf16, relu(h) [rows,32] bf16)."""
+    rows = xa.shape[0]
+    out = torch.empty((rows, 32), dtype=torch.bfloat16, device=xa.device)
+    hr = torch.empty((rows, 32), dtype=torch.bfloat16, device=xa.device)
+    _check(lib().pcacc_pfn_block_forward(_dev(xa, torch.bfloat16, 'xa'), _opt(pooled, torch.bfloat16, 'pooled'), _opt(p2v, torch.int32, 'p2v'),
+                                         _dev(w0, torch.float32, 'w0'), _opt(b0, torch.float32, 'b0'), _dev(ws, torch.float32, 'ws'),
+                                         _dev(w1, torch.float32, 'w1'), _opt(b1, torch.float32, 'b1'), _dev(out), _dev(hr), _i64(rows),
+                                         _stream()), 'pfn_block_forward')
+    return out, hr
+
+
+def pfn_block_backward(xa, pooled, p2v, hr, grad_out, w0, ws, w1):
+    """-> (grad_xa, grad_xb rows or None, grad_params [5184] f32; PFN_BLOCK_SLICES names its parts)."""
+    rows = xa.shape[0]
+    dev = xa.device
+    two = pooled is not None
+    gxa = torch.empty((rows, 32 if two else 64), dtype=torch.bfloat16, device=dev)
+    gxb = torch.empty((rows, 32), dtype=torch.bfloat16, device=dev) if two else None
+    gp = torch.empty((5184,), dtype=torch.float32, device=dev)
+    need = ctypes.c_size_t(0)
+    _check(lib().pcacc_pfn_block_backward_workspace_bytes(_i64(rows), ctypes.byref(need)), 'pfn_block_backward_workspace')
+    ws_buf = _ws(need.value, dev)
+    _check(lib().pcacc_pfn_block_backward(_dev(xa, torch.bfloat16, 'xa'), _opt(pooled, torch.bfloat16, 'pooled'), _opt(p2v, torch.int32, 'p2v'),
+                                          _dev(hr, torch.bfloat16, 'relu_h'), _dev(grad_out, torch.bfloat16, 'grad_out'),
+                                          _dev(w0, torch.float32, 'w0'), _dev(ws, torch.float32, 'ws'), _dev(w1, torch.float32, 'w1'),
+                                          _dev(gxa), _opt(gxb, torch.bfloat16, 'grad_xb'), _dev(gp), _i64(rows), _dev(ws_buf),
+                                          ctypes.c_size_t(ws_buf.numel()), _stream()), 'pfn_block_backward')
+    return gxa, gxb, gp

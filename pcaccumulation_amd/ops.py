@@ -403,6 +403,48 @@ def linear_rows_cat(xa, pooled, pidx, layer, pre_relu=False, post_relu=False, re
     return _RowsLinearCat.apply(xa, pooled, pidx, layer.weight, layer.bias, residual, pre_relu, post_relu)
 
 
+class _PfnBlock(torch.autograd.Function):
+    """ResnetBlockFC(64, 32) on bf16 point rows as one kernel each way (csrc/pfn_block.hip); x = xa [rows,64], or
+    cat(xa [rows,32], pooled[pidx.p2v]) without materialising gather or concatenation.  The pooled half of the data gradient is
+    summed over each pillar's points (CSR segment sum), as in _RowsLinearCat."""
+
+    @staticmethod
+    def forward(ctx, xa, pooled, pidx, w0, b0, ws, w1, b1):
+        xa = xa.contiguous()
+        pooled = pooled.contiguous() if pooled is not None else None
+        w0, ws, w1 = w0.contiguous(), ws.contiguous(), w1.contiguous()
+        out, hr = native.pfn_block_forward(xa, pooled, pidx.p2v if pooled is not None else None, w0, b0, ws, w1, b1)
+        ctx.pidx = pidx
+        ctx.save_for_backward(xa, pooled, hr, w0, ws, w1)
+        ctx.has_bias = (b0 is not None, b1 is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xa, pooled, hr, w0, ws, w1 = ctx.saved_tensors
+        pidx = ctx.pidx
+        gxa, gxb, gp = native.pfn_block_backward(xa, pooled, pidx.p2v if pooled is not None else None, hr, g.contiguous(), w0, ws, w1)
+        gpool = None
+        if pooled is not None and ctx.needs_input_grad[1]:
+            gpool = native.segment_sum(gxb, pidx.seg_offsets, pidx.order, pidx.m).to(pooled.dtype)
+        part = lambda name: gp[native.PFN_BLOCK_SLICES[name][0]:native.PFN_BLOCK_SLICES[name][1]].view(native.PFN_BLOCK_SLICES[name][2])
+        return (gxa, gpool, None, part('w0'), part('b0') if ctx.has_bias[0] else None, part('ws'), part('w1'),
+                part('b1') if ctx.has_bias[1] else None)
+
+
+def pfn_block_available(block, x, pooled=None):
+    """The fused block takes bf16 rows on the GPU, the encoder's widths (64 -> 32 -> 32 with a shortcut) and fp32 parameters."""
+    width = x.shape[1] + (pooled.shape[1] if pooled is not None else 0)
+    return (x.is_cuda and x.dtype == torch.bfloat16 and (pooled is None or (pooled.dtype == torch.bfloat16 and x.shape[1] == 32 and pooled.shape[1] == 32))
+            and x.shape[0] >= MIN_ROWS_FUSED_LINEAR and width == 64 and block.size_in == 64 and block.size_h == 32 and block.size_out == 32
+            and block.shortcut is not None and block.fc_0.weight.dtype == torch.float32 and not torch.is_autocast_enabled())
+
+
+def pfn_block(block, x, pooled=None, pidx=None):
+    """block(x) or block(cat(x, pooled[pidx.p2v])) for a pillar_encoder.ResnetBlockFC -- see _PfnBlock."""
+    return _PfnBlock.apply(x, pooled, pidx, block.fc_0.weight, block.fc_0.bias, block.shortcut.weight, block.fc_1.weight, block.fc_1.bias)
+
+
 _POINT_DTYPE = torch.float32
 
 

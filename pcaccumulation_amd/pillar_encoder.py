@@ -28,8 +28,10 @@ class ResnetBlockFC(nn.Module):
         nn.init.zeros_(self.fc_1.weight)
 
     def forward(self, x):
-        # fc_1(relu(fc_0(relu(x)))) + shortcut(x): three fused row-linear launches (ReLU on load, residual on store);
-        # rows keep x's element type (bf16 in the bf16 compute mode)
+        # fc_1(relu(fc_0(relu(x)))) + shortcut(x): one kernel for the encoder's block shape on bf16 rows (csrc/pfn_block.hip), else
+        # three fused row-linear launches (ReLU on load, residual on store); rows keep x's element type
+        if ops.pfn_block_available(self, x):
+            return ops.pfn_block(self, x)
         net = ops.linear_rows(x, self.fc_0, pre_relu=True)
         x_s = ops.linear_rows(x, self.shortcut) if self.shortcut is not None else x
         return ops.linear_rows(net, self.fc_1, pre_relu=True, residual=x_s)
@@ -37,6 +39,8 @@ class ResnetBlockFC(nn.Module):
     def forward_pooled(self, x, pooled, pidx):
         """forward(cat(x, pooled[point_to_voxel_map])) (models/pillar_encoder.py:116-118) with the gather and the concatenation
         folded into the two layers that read them (bf16 rows on the GPU); the same arithmetic otherwise."""
+        if ops.pfn_block_available(self, x, pooled):
+            return ops.pfn_block(self, x, pooled, pidx)
         if self.shortcut is None or not ops.linear_rows_cat_available(x, pooled, self.fc_0):
             return self.forward(torch.cat([x, ops.broadcast_to_points(pooled, pidx)], dim=1))
         net = ops.linear_rows_cat(x, pooled, pidx, self.fc_0, pre_relu=True)

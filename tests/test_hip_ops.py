@@ -1017,3 +1017,57 @@ def test_hip_against_cpu_twin_full_size(native, dev):
     fm_out, fm_arg = native.frames_max(d(x))
     tfo, tfa = twin.frames_max(x)
     assert np.array_equal(fm_out.cpu().numpy(), tfo) and np.array_equal(fm_arg.cpu().numpy().reshape(tfa.shape), tfa)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rows,pooled', [(5000, False), (70001, True), (2049, False), (4099, True)])
+def test_pfn_block_fused_matches_row_layers(rows, pooled):
+    """csrc/pfn_block.hip (one kernel per direction for a ResnetBlockFC(64, 32) on bf16 rows) against the same block evaluated with
+    the three row-linear launches it replaces: outputs within one bf16 rounding of each other (the fused kernel keeps the shortcut
+    in fp32 until the final rounding), gradients of the input pieces and of all five parameters to bf16 accumulation accuracy."""
+    import torch
+    from pcaccumulation_amd import ops
+    from pcaccumulation_amd.pillar_encoder import ResnetBlockFC
+    dev = torch.device('cuda:0')
+    torch.manual_seed(rows)
+    block = ResnetBlockFC(64, 32).to(dev)
+    with torch.no_grad():
+        block.fc_1.weight.normal_(0, 0.2)                          # the reference zero-initialises it: give the second layer work
+    m = max(rows // 3, 1)
+    g = torch.Generator().manual_seed(1)
+    xa = torch.randn(rows, 32 if pooled else 64, generator=g).to(dev).to(torch.bfloat16).requires_grad_(True)
+    pl = torch.randn(m, 32, generator=g).to(dev).to(torch.bfloat16).requires_grad_(True) if pooled else None
+    p2v = torch.randint(0, m, (rows,), generator=g).to(dev)
+    pidx = ops.PillarIndex.from_point_map(p2v, m) if pooled else None
+    gy = torch.randn(rows, 32, generator=g).to(dev).to(torch.bfloat16)
+
+    def run(fused):
+        for t in (xa, pl):
+            if t is not None:
+                t.grad = None
+        block.zero_grad()
+        if fused:
+            assert ops.pfn_block_available(block, xa, pl)
+            y = ops.pfn_block(block, xa, pl, pidx)
+        elif pooled:
+            net = ops.linear_rows_cat(xa, pl, pidx, block.fc_0, pre_relu=True)
+            y = ops.linear_rows(net, block.fc_1, pre_relu=True, residual=ops.linear_rows_cat(xa, pl, pidx, block.shortcut))
+        else:
+            y = ops.linear_rows(ops.linear_rows(xa, block.fc_0, pre_relu=True), block.fc_1, pre_relu=True, residual=ops.linear_rows(xa, block.shortcut))
+        y.backward(gy)
+        grads = [xa.grad.float()] + ([pl.grad.float()] if pooled else []) + [p.grad.float().clone() for p in block.parameters()]
+        return y.detach().float(), grads
+
+    y_f, g_f = run(True)
+    y_u, g_u = run(False)
+    # fp64 reference of the block on the bf16 inputs
+    x64 = (torch.cat([xa, pl[p2v]], 1) if pooled else xa).detach().double()
+    w = {k: v.detach().double() for k, v in block.state_dict().items()}
+    ref = torch.relu(torch.relu(x64) @ w['fc_0.weight'].t() + w['fc_0.bias']) @ w['fc_1.weight'].t() + w['fc_1.bias'] + x64 @ w['shortcut.weight'].t()
+    scale = float(ref.abs().max())
+    assert float((y_f.double() - ref).abs().max()) <= 2.5 * 2 ** -8 * scale
+    assert float((y_f.double() - ref).abs().max()) <= 1.05 * float((y_u.double() - ref).abs().max()) + 2 ** -9 * scale
+    for a, b in zip(g_f, g_u):
+        assert a.shape == b.shape
+        tol = 3e-2 * float(b.abs().max()) + 1e-6
+        assert float((a - b).abs().max()) <= tol, (tuple(a.shape), float((a - b).abs().max()), float(b.abs().max()))
