@@ -504,9 +504,12 @@ extern "C" int pcacc_conv3x3_masked_bf16(const uint16_t *in, const uint16_t *in_
 // launch (dt: X is read from image n + dt of the same sample, or not at all when that frame does not exist).
 // The reduction runs over pixels, so both MFMA operands are "8 consecutive pixels of one channel" per lane: the dY tile and
 // the X patch are staged channels-last as they come and the fragments are read with the hardware LDS transpose
-// (ds_read_b64_tr_b16, two per fragment; row stride C + 4 elements).  A wave owns one (co tile, ci tile) pair and
-// all 9 taps, so the dY fragment of a 16-pixel step is gathered once and used by 9 MFMAs.  Workgroups are persistent; their
-// accumulators are folded into one workspace slot per workgroup and a second launch sums the slots (conv_wgrad_reduce_kernel).
+// (ds_read_b64_tr_b16, two per fragment; row stride pcacc_tr_stride(C) elements).  A wave owns one (co tile, ci tile) pair and one
+// of TG = 4 / pairs TAP GROUPS (taps t with t % TG == group: 3 | 2 | 2 | 2 taps at 32 x 32 channels, 5 | 4 at 32 x 64, all 9 at
+// 64 x 64) over ALL 16-pixel steps of the tile: 48 / 80 accumulator registers instead of 144, so two or three workgroups share a CU
+// and one wave's LDS latency hides behind another's MFMAs (r02: with every wave holding all 9 taps of a quarter of the pixels the
+// kernel ran one wave per SIMD -- 310 registers -- at 15 % matrix-pipe utilisation, and its accumulators had to be folded through
+// LDS at the end).  Workgroups are persistent; one workspace slot per workgroup, a second launch sums the slots.
 typedef short cv_s16x4 __attribute__((ext_vector_type(4)));
 union cv_frag { bf16x8_t v; cv_s16x4 h[2]; };
 
@@ -515,7 +518,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_wgrad_kernel(const uint16_
                                                                    float *__restrict__ partial, int n_img, int frames, int dt, int h,
                                                                    int w, int tiles_x, int tiles_y)
 {
-    constexpr int CO = CO_T * 32, CI = CI_T * 32, PAIRS = CO_T * CI_T, GROUPS = 4 / PAIRS;
+    constexpr int CO = CO_T * 32, CI = CI_T * 32, PAIRS = CO_T * CI_T, TG = 4 / PAIRS, NT = (9 + TG - 1) / TG;
     constexpr int YS = pcacc_tr_stride(CO), XS = pcacc_tr_stride(CI);
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     uint16_t *sdy = lds;                                       // [CV_TH * CV_TW][YS]
@@ -526,9 +529,9 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_wgrad_kernel(const uint16_
     const int pair = wave % PAIRS, grp = wave / PAIRS;
     const int ct = pair / CI_T, it = pair % CI_T;
 
-    f32x16_t acc[9];
+    f32x16_t acc[NT];                                          // local tap j = tap grp + j * TG
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     float bsum = 0.f;
@@ -601,74 +604,43 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_wgrad_kernel(const uint16_
         // lane its 8 consecutive pixels of one channel
         const int tg = lane >> 4, tl = lane & 15;
         const int tr_row = (tg >> 1) * 8 + (tl >> 2), tr_col = (tg & 1) * 16 + (tl & 3) * 4;
-        for (int s = grp; s < CV_TH * 2; s += GROUPS) {
+        for (int s = 0; s < CV_TH * 2; ++s) {
             const int ry = s >> 1, xb = (s & 1) * 16;
             const uint16_t *pa = sdy + (ry * CV_TW + xb + tr_row) * YS + ct * 32 + tr_col;
             cv_frag af;
             af.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cv_s16x4 __attribute__((address_space(3))) *)pa);
             af.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cv_s16x4 __attribute__((address_space(3))) *)(pa + 4 * YS));
-            if (it == 0) {                                     // bias gradient = column sums of dY: the fragment is at hand
+            if (it == 0 && grp == 0) {                         // bias gradient = column sums of dY: the fragment is at hand
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) bsum += bf16_to_f32((uint16_t)af.h[j][q]);
             }
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const uint16_t *pb = sx + ((ry + tap / 3) * CV_PW + xb + tap % 3 + tr_row) * XS + it * 32 + tr_col;
-                cv_frag bf;
-                bf.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cv_s16x4 __attribute__((address_space(3))) *)pb);
-                bf.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cv_s16x4 __attribute__((address_space(3))) *)(pb + 4 * XS));
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.v, bf.v, acc[tap], 0, 0, 0);
+            for (int j = 0; j < NT; ++j) {
+                const int tap = grp + j * TG;                  // uniform per wave
+                if (tap < 9) {
+                    const uint16_t *pb = sx + ((ry + tap / 3) * CV_PW + xb + tap % 3 + tr_row) * XS + it * 32 + tr_col;
+                    cv_frag bf;
+                    bf.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cv_s16x4 __attribute__((address_space(3))) *)pb);
+                    bf.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cv_s16x4 __attribute__((address_space(3))) *)(pb + 4 * XS));
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.v, bf.v, acc[j], 0, 0, 0);
+                }
             }
         }
-    }
-    // The pixel groups of a workgroup hold partial sums of the same (co, ci) tiles: fold them through the staging LDS (free now)
-    // so that the workspace holds one slot per workgroup instead of one per wave (32x32 layers: 113 MB of partials per launch
-    // became 28 MB, for this kernel's stores and for the reduce launch's loads).  Tap t of a pair is owned by pixel group
-    // t % GROUPS: in round r every wave hands the taps owned by group (grp + r) % GROUPS to that group, so each tap travels once
-    // per round, the adds and the final stores are spread over all waves.
-    if (GROUPS > 1) {
-        constexpr int LDS_FLOATS = (CV_TH * CV_TW * YS + CV_PH * CV_PW * XS) / 2;
-        constexpr int T_FIT = LDS_FLOATS / (PAIRS * 1024), T_STEP = T_FIT > 9 ? 9 : T_FIT;
-        static_assert(T_STEP >= 1, "staging LDS too small for the accumulator exchange");
-        float *red = reinterpret_cast<float *>(lds);
-#pragma unroll
-        for (int r = 1; r < GROUPS; ++r) {
-            const int to = (grp + r) % GROUPS;
-#pragma unroll
-            for (int t0 = 0; t0 < 9; t0 += T_STEP) {
-                __syncthreads();
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap)
-                    if (tap >= t0 && tap < t0 + T_STEP && tap % GROUPS == to)
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) red[((pair * T_STEP + (tap - t0)) * 16 + q) * 64 + lane] = acc[tap][q];
-                __syncthreads();
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap)
-                    if (tap >= t0 && tap < t0 + T_STEP && tap % GROUPS == grp)
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) acc[tap][q] += red[((pair * T_STEP + (tap - t0)) * 16 + q) * 64 + lane];
-            }
-        }
-        __syncthreads();
-        if (grp > 0) red[((grp - 1) * PAIRS + pair) * 64 + lane] = bsum;
-        __syncthreads();
-        if (grp == 0)
-#pragma unroll
-            for (int g = 1; g < GROUPS; ++g) bsum += red[((g - 1) * PAIRS + pair) * 64 + lane];
     }
     // slot of this workgroup: [CO][9][CI] then [CO] bias sums; D has lane = ci, register quads = co
     float *mine = partial + (int64_t)blockIdx.x * (CO * 9 * CI + CO);
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
-        if (tap % GROUPS == grp)
+    for (int j = 0; j < NT; ++j) {
+        const int tap = grp + j * TG;
+        if (tap < 9)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                mine[((int64_t)co * 9 + tap) * CI + it * 32 + lp] = acc[tap][r];
+                mine[((int64_t)co * 9 + tap) * CI + it * 32 + lp] = acc[j][r];
             }
+    }
     if (grp != 0) return;
     bsum += __shfl_xor(bsum, 32, 64);                          // the two half-waves hold pixels 0-7 / 8-15 of the same channel
     if (it == 0 && lh == 0) mine[CO * 9 * CI + ct * 32 + lp] = bsum;
