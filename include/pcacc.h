@@ -161,7 +161,9 @@ int pcacc_rows_linear_mixed(const void *x, const void *in_mask, const float *w, 
                             const void *out_mask, void *y, int64_t rows, int k, int n, int flags, int dtypes, void *stream);
 int pcacc_rows_wgrad_mixed(const void *dy, const void *dy_mask, const void *x, int x_relu, int64_t rows, int k, int n,
                            float *dw_aug, int dtypes, void *stream);
-/* all-bf16 rows (k, n multiples of 32, <= 128): the same product on the bf16 matrix cores, dw_aug f32 */
+/* all-bf16 rows (k, n multiples of 32, <= 128): the same product on the bf16 matrix cores, dw_aug f32.
+ * x_relu is a flags word here, in pcacc_rows_wgrad_cat_bf16 and in pcacc_rows_wgrad_few: bit 0 = ReLU on X; bit 1 = split result layout:
+ * dw_aug holds dW [n,k] followed by the bias gradients [n], each contiguous (what an optimizer wants), instead of [n,k+1] rows. */
 int pcacc_rows_wgrad_bf16_workspace_bytes(int64_t rows, int32_t k, int32_t n, size_t *bytes /*host*/);
 int pcacc_rows_wgrad_bf16(const uint16_t *dy, const uint16_t *dy_mask, const uint16_t *x, int32_t x_relu, int64_t rows,
                           int32_t k, int32_t n, float *dw_aug, void *workspace, size_t workspace_bytes, void *stream);

@@ -135,11 +135,12 @@ def rows_linear(x, w, bias=None, residual=None, pre_relu=False, post_relu=False,
     return y.to(out_dtype)
 
 
-def rows_wgrad(dy, x, dy_mask=None, x_relu=False):
+def rows_wgrad(dy, x, dy_mask=None, x_relu=False, split=False):
     g = dy.float() * (dy_mask > 0) if dy_mask is not None else dy.float()
     h = torch.relu(x.float()) if x_relu else x.float()
     aug = torch.cat([h, torch.ones(h.shape[0], 1)], dim=1)
-    return g.t() @ aug
+    out = g.t() @ aug
+    return (out[:, :-1].contiguous(), out[:, -1].contiguous()) if split else out
 
 
 def pfn_features(points, p2v, pillar_mean, coords, time_indice, vx, vy, x_offset, y_offset, scale, n_frames):

@@ -516,9 +516,11 @@ union cv_frag { bf16x8_t v; cv_s16x4 h[2]; };
 template <int CO_T, int CI_T>
 __global__ __launch_bounds__(CV_THREADS) void conv3x3_wgrad_kernel(const uint16_t *__restrict__ dy, const uint16_t *__restrict__ x,
                                                                    float *__restrict__ partial, int n_img, int frames, int dt, int h,
-                                                                   int w, int tiles_x, int tiles_y)
+                                                                   int w, int tiles_x, int tiles_y, float *__restrict__ dw_zero)
 {
     constexpr int CO = CO_T * 32, CI = CI_T * 32, PAIRS = CO_T * CI_T, TG = 4 / PAIRS, NT = (9 + TG - 1) / TG;
+    if (blockIdx.x == 0)                                       // the reduce launch that follows adds into dW: cleared here, not by a memset
+        for (int e = threadIdx.x; e < CO * 9 * CI + CO; e += CV_THREADS) dw_zero[e] = 0.f;
     constexpr int YS = pcacc_tr_stride(CO), XS = pcacc_tr_stride(CI);
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     uint16_t *sdy = lds;                                       // [CV_TH * CV_TW][YS]
@@ -704,14 +706,13 @@ extern "C" int pcacc_conv3x3_wgrad_bf16(const uint16_t *dy, const uint16_t *x, f
         if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                                    (int)lds) != hipSuccess)                                                          \
             return PCACC_E_LAUNCH;                                                                                                   \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(CV_THREADS), lds, st, dy, x, partial, n_img, frames, dt, h, w, tiles_x, tiles_y);  \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(CV_THREADS), lds, st, dy, x, partial, n_img, frames, dt, h, w, tiles_x, tiles_y, dw); \
     } while (0)
     if (c_out == 32 && c_in == 32) CV_WG(1, 1);
     else if (c_out == 32 && c_in == 64) CV_WG(1, 2);
     else if (c_out == 64 && c_in == 32) CV_WG(2, 1);
     else CV_WG(2, 2);
 #undef CV_WG
-    if (hipMemsetAsync(dw, 0, (size_t)elems * sizeof(float), st) != hipSuccess) return PCACC_E_LAUNCH;
     conv_wgrad_reduce_kernel<<<dim3((elems + 255) / 256, 16), 256, 0, st>>>(partial, grid, elems, dw);
     PCACC_CHECK_LAUNCH();
     return 0;

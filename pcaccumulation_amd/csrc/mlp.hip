@@ -607,7 +607,8 @@ __global__ __launch_bounds__(256) void rows_wgrad_few_kernel(const void *__restr
 }
 
 // out[e] = sum over the workgroup partials, in index order: 64 elements x 4 slices per workgroup
-__global__ __launch_bounds__(256) void rows_wgrad_few_reduce_kernel(const float *__restrict__ partial, int n_parts, int elems, float *__restrict__ out)
+__global__ __launch_bounds__(256) void rows_wgrad_few_reduce_kernel(const float *__restrict__ partial, int n_parts, int elems, float *__restrict__ out,
+                                                                    int split_k)
 {
     __shared__ float red[256];
     const int e = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
@@ -622,7 +623,14 @@ __global__ __launch_bounds__(256) void rows_wgrad_few_reduce_kernel(const float 
     }
     red[threadIdx.x] = s0 + s1;
     __syncthreads();
-    if (slice == 0 && e < elems) out[e] = (red[threadIdx.x] + red[64 + threadIdx.x]) + (red[128 + threadIdx.x] + red[192 + threadIdx.x]);
+    if (slice == 0 && e < elems) {
+        int o = e;
+        if (split_k > 0) {                                                    // dW [n][k] then the bias gradients [n], both contiguous
+            const int row = e / (split_k + 1), col = e % (split_k + 1);
+            o = col < split_k ? row * split_k + col : (elems / (split_k + 1)) * split_k + row;
+        }
+        out[o] = (red[threadIdx.x] + red[64 + threadIdx.x]) + (red[128 + threadIdx.x] + red[192 + threadIdx.x]);
+    }
 }
 
 static bool wgrad_few_width(int c) { return c == 32 || c == 64 || c == 128; }
@@ -651,6 +659,8 @@ extern "C" int pcacc_rows_wgrad_few(const void *dy, const void *dy_mask, const v
                                     float *dw_aug, int32_t dt, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (rows < 0 || !dw_aug || (dt & ~7) || !pcacc_rows_wgrad_few_supported(k, n)) return PCACC_E_ARG;
+    const int split_k = (x_relu & 2) ? k : 0;                                 // flags: bit 0 = ReLU on X, bit 1 = split result layout
+    x_relu &= 1;
     hipStream_t s = pcacc_stream(stream);
     const int elems = n * (k + 1);
     if (rows == 0) {
@@ -680,7 +690,7 @@ extern "C" int pcacc_rows_wgrad_few(const void *dy, const void *dy_mask, const v
     }
 #undef WG_FEW_C
 #undef WG_FEW
-    rows_wgrad_few_reduce_kernel<<<(elems + 63) / 64, 256, 0, s>>>(partial, grid, elems, dw_aug);
+    rows_wgrad_few_reduce_kernel<<<(elems + 63) / 64, 256, 0, s>>>(partial, grid, elems, dw_aug, split_k);
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
 }

@@ -257,9 +257,12 @@ union wg_frag { bf16x8_t v; wg_s16x4 h[2]; uint16_t e[8]; };
 template <int MAX_TILES, int WG_R>
 __global__ __launch_bounds__(256) void rows_wgrad_bf16_kernel(const uint16_t *__restrict__ dY, const uint16_t *__restrict__ dy_mask,
                                                               const uint16_t *__restrict__ X, int x_relu, int64_t rows, int K, int N,
-                                                              int k_tiles, int n_tile_total, int tiles_par, float *partial, RowPieces xs2)
+                                                              int k_tiles, int n_tile_total, int tiles_par, float *partial, RowPieces xs2,
+                                                              float *__restrict__ dw_zero)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t wlds[];
+    if (blockIdx.x == 0)                                                       // the reduce launch adds into dW: cleared here, not by a memset
+        for (int e = threadIdx.x; e < N * (K + 1); e += 256) dw_zero[e] = 0.f;
     const int NS = pcacc_tr_stride(N), KS = pcacc_tr_stride(K);
     uint16_t *sdy = wlds, *sx = wlds + WG_R * NS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -393,7 +396,8 @@ __global__ __launch_bounds__(256) void rows_wgrad_bf16_kernel(const uint16_t *__
 }
 
 // out[e] += sum over a slice of the workgroup partials (blockIdx.y = slice); out is zero-filled before the launch
-__global__ __launch_bounds__(256) void rows_wgrad_reduce_kernel(const float *__restrict__ partial, int n_parts, int elems, float *out)
+// split_k > 0: the [n][split_k + 1] result is written as dW [n][split_k] followed by the bias gradients [n], both contiguous
+__global__ __launch_bounds__(256) void rows_wgrad_reduce_kernel(const float *__restrict__ partial, int n_parts, int elems, float *out, int split_k)
 {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= elems) return;
@@ -408,7 +412,12 @@ __global__ __launch_bounds__(256) void rows_wgrad_reduce_kernel(const float *__r
         s3 += partial[(int64_t)(p + 3) * elems + e];
     }
     for (; p < p1; ++p) s0 += partial[(int64_t)p * elems + e];
-    if (p1 > p0) atomicAdd(&out[e], (s0 + s1) + (s2 + s3));
+    int o = e;
+    if (split_k > 0) {
+        const int row = e / (split_k + 1), col = e % (split_k + 1);
+        o = col < split_k ? row * split_k + col : (elems / (split_k + 1)) * split_k + row;
+    }
+    if (p1 > p0) atomicAdd(&out[o], (s0 + s1) + (s2 + s3));
 }
 
 static int wgrad_bf16_tile_rows(int k, int n) { return k + n <= 64 ? 256 : (k + n <= 128 ? 128 : 64); }
@@ -433,6 +442,8 @@ static int rows_wgrad_bf16_any(const uint16_t *dy, const uint16_t *dy_mask, cons
                                int32_t k, int32_t n, float *dw_aug, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (rows < 0 || k <= 0 || n <= 0 || k > 128 || n > 128 || (k % 32) || (n % 32) || !dw_aug) return PCACC_E_ARG;
+    const int split_k = (x_relu & 2) ? k : 0;                                 // flags: bit 0 = ReLU on X, bit 1 = split result layout
+    x_relu &= 1;
     hipStream_t st = pcacc_stream(stream);
     if (rows == 0) {
         if (hipMemsetAsync(dw_aug, 0, (size_t)n * (k + 1) * sizeof(float), st) != hipSuccess) return PCACC_E_LAUNCH;
@@ -448,14 +459,13 @@ static int rows_wgrad_bf16_any(const uint16_t *dy, const uint16_t *dy_mask, cons
     if (workspace_bytes < (size_t)grid * parts_per_wg * elems * sizeof(float)) return PCACC_E_WORKSPACE;
     float *partial = reinterpret_cast<float *>(workspace);
     const size_t lds = (size_t)tile_rows * (pcacc_tr_stride(n) + pcacc_tr_stride(k)) * sizeof(uint16_t);
-#define WGB(T, R) rows_wgrad_bf16_kernel<T, R><<<grid, 256, lds, st>>>(dy, dy_mask, x, x_relu, rows, k, n, k_tiles, total, tiles_par, partial, xs2)
+#define WGB(T, R) rows_wgrad_bf16_kernel<T, R><<<grid, 256, lds, st>>>(dy, dy_mask, x, x_relu, rows, k, n, k_tiles, total, tiles_par, partial, xs2, dw_aug)
     if (total <= 4) { if (tile_rows == 256) WGB(1, 256); else if (tile_rows == 128) WGB(1, 128); else WGB(1, 64); }
     else if (total <= 8) { if (tile_rows == 128) WGB(2, 128); else WGB(2, 64); }
     else WGB(6, 64);
 #undef WGB
-    if (hipMemsetAsync(dw_aug, 0, (size_t)elems * sizeof(float), st) != hipSuccess) return PCACC_E_LAUNCH;
     const int slices = elems >= 8192 ? 16 : 64;                               // ~1000 workgroups in flight either way
-    rows_wgrad_reduce_kernel<<<dim3((elems + 255) / 256, slices), 256, 0, st>>>(partial, grid * parts_per_wg, elems, dw_aug);
+    rows_wgrad_reduce_kernel<<<dim3((elems + 255) / 256, slices), 256, 0, st>>>(partial, grid * parts_per_wg, elems, dw_aug, split_k);
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
 }

@@ -186,8 +186,10 @@ __global__ __launch_bounds__(PB_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                                                                    const uint16_t *__restrict__ gout, const float *__restrict__ W0,
                                                                    const float *__restrict__ Ws, const float *__restrict__ W1,
                                                                    uint16_t *__restrict__ gxa, uint16_t *__restrict__ gxb,
-                                                                   float *__restrict__ partial, int64_t rows)
+                                                                   float *__restrict__ partial, int64_t rows, float *__restrict__ gp_zero)
 {
+    if (blockIdx.x == 0)                                                      // the reduce launch adds into the parameter gradients
+        for (int e = threadIdx.x; e < PB_PARTIAL; e += PB_THREADS) gp_zero[e] = 0.f;
     // row strides (elements): 96 / 32 keep the transpose reads conflict-free (pcacc_tr_stride); OS = the d(x) tile
     constexpr int XS = 96, GS = 32, WS = 40, OS = 72;
     __shared__ __attribute__((aligned(16))) uint16_t xs[PB_TILE * XS];                    // x
@@ -414,14 +416,16 @@ extern "C" int pcacc_pfn_block_backward(const uint16_t *xa, const uint16_t *pool
 {
     if (rows < 0 || !grad_params || (pooled && (!p2v || !grad_xb)) || (!pooled && grad_xb)) return PCACC_E_ARG;
     hipStream_t s = pcacc_stream(stream);
-    if (hipMemsetAsync(grad_params, 0, PB_PARTIAL * sizeof(float), s) != hipSuccess) return PCACC_E_LAUNCH;
-    if (rows == 0) return PCACC_OK;
+    if (rows == 0) {
+        if (hipMemsetAsync(grad_params, 0, PB_PARTIAL * sizeof(float), s) != hipSuccess) return PCACC_E_LAUNCH;
+        return PCACC_OK;
+    }
     if (!xa || !relu_h || !grad_out || !w0 || !ws || !w1 || !grad_xa || !workspace) return PCACC_E_ARG;
     const int grid = pb_grid(rows, 2);
     if (workspace_bytes < (size_t)grid * 4 * PB_PARTIAL * sizeof(float)) return PCACC_E_WORKSPACE;
     float *partial = reinterpret_cast<float *>(workspace);
-    if (pooled) pfn_block_bwd_kernel<true><<<grid, PB_THREADS, 0, s>>>(xa, PbPieces{pooled, p2v}, relu_h, grad_out, w0, ws, w1, grad_xa, grad_xb, partial, rows);
-    else pfn_block_bwd_kernel<false><<<grid, PB_THREADS, 0, s>>>(xa, PbPieces{pooled, p2v}, relu_h, grad_out, w0, ws, w1, grad_xa, grad_xb, partial, rows);
+    if (pooled) pfn_block_bwd_kernel<true><<<grid, PB_THREADS, 0, s>>>(xa, PbPieces{pooled, p2v}, relu_h, grad_out, w0, ws, w1, grad_xa, grad_xb, partial, rows, grad_params);
+    else pfn_block_bwd_kernel<false><<<grid, PB_THREADS, 0, s>>>(xa, PbPieces{pooled, p2v}, relu_h, grad_out, w0, ws, w1, grad_xa, grad_xb, partial, rows, grad_params);
     pfn_block_reduce_kernel<<<dim3((PB_PARTIAL + 255) / 256, 32), 256, 0, s>>>(partial, grid * 4, grad_params);
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;

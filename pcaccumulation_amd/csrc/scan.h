@@ -62,8 +62,9 @@ static __global__ __launch_bounds__(256) void chunk_sums_i32(const int *in, int6
 }
 
 // out[i] = exclusive prefix sum of in[0..i); out[n] = total when write_total.
+// clear_in: the input is zeroed behind the scan (a histogram that becomes the cursor array of the fill pass: saves a memset launch)
 static __global__ __launch_bounds__(256) void chunk_scan_i32(const int *in, int64_t n, const int *chunk_offsets,
-                                                      int *out, int write_total)
+                                                      int *out, int write_total, int *clear_in = nullptr)
 {
     __shared__ int lds[4];
     const int64_t base = (int64_t)blockIdx.x * PCACC_CHUNK;
@@ -74,6 +75,7 @@ static __global__ __launch_bounds__(256) void chunk_scan_i32(const int *in, int6
         int tot;
         const int excl = block256_exclusive_scan(v, lds, &tot);
         if (i < n) out[i] = carry + excl;
+        if (clear_in && i < n) clear_in[i] = 0;
         if (write_total && i == n - 1) out[n] = carry + excl + v;
         carry += tot;
     }

@@ -140,8 +140,10 @@ extern "C" int pcacc_csr_build(const int32_t *p2v, int64_t n, int64_t m, int32_t
     char *ws = static_cast<char *>(workspace);
     int *counts = reinterpret_cast<int *>(ws);
     int *sums = reinterpret_cast<int *>(ws + pcacc_align((size_t)(m + 1) * 4));
-    if (hipMemsetAsync(seg_offsets, 0, (size_t)(m + 1) * 4, s) != hipSuccess) return PCACC_E_LAUNCH;
-    if (m == 0 || n == 0) return PCACC_OK;
+    if (m == 0 || n == 0) {                                   // no points: every segment is empty
+        if (hipMemsetAsync(seg_offsets, 0, (size_t)(m + 1) * 4, s) != hipSuccess) return PCACC_E_LAUNCH;
+        return PCACC_OK;
+    }
     if (hipMemsetAsync(counts, 0, (size_t)(m + 1) * 4, s) != hipSuccess) return PCACC_E_LAUNCH;
     const int chunks = pcacc_chunks(m);
     const bool small = m <= CSR_SMALL_M;
@@ -149,8 +151,7 @@ extern "C" int pcacc_csr_build(const int32_t *p2v, int64_t n, int64_t m, int32_t
     else csr_histogram<<<pcacc_grid(n, 256), 256, 0, s>>>(p2v, n, counts);
     chunk_sums_i32<<<chunks, 256, 0, s>>>(counts, m, sums);
     scan_chunk_sums<<<1, 1024, 0, s>>>(sums, chunks, nullptr, -1);
-    chunk_scan_i32<<<chunks, 256, 0, s>>>(counts, m, sums, seg_offsets, 1);
-    if (hipMemsetAsync(counts, 0, (size_t)m * 4, s) != hipSuccess) return PCACC_E_LAUNCH;
+    chunk_scan_i32<<<chunks, 256, 0, s>>>(counts, m, sums, seg_offsets, 1, counts);      // counts -> cursors (zeroed behind the scan)
     if (small) csr_fill_small<<<pcacc_chunks(n), 256, 0, s>>>(p2v, n, (int)m, seg_offsets, counts, order);
     else csr_fill<<<pcacc_grid(n, 256), 256, 0, s>>>(p2v, n, seg_offsets, counts, order);
     csr_sort_segments<<<pcacc_grid(m, 256), 256, 0, s>>>(seg_offsets, m, order);

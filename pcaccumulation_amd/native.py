@@ -384,32 +384,44 @@ def rows_linear(x, w, bias=None, residual=None, pre_relu=False, post_relu=False,
     return y
 
 
-def rows_wgrad(dy, x, dy_mask=None, x_relu=False):
-    """[n, k+1] f32 = dYeff^T @ [Xeff | 1]: weight gradient with the bias gradient in the last column (dy, x, dy_mask f32 or bf16)."""
+def _split_aug(out, n, k, split, native_split):
+    """split: (dW [n,k], db [n]); contiguous views of `out` when the kernel wrote the split layout, slices of the [n,k+1] rows otherwise."""
+    if not split:
+        return out
+    if native_split:
+        flat = out.view(-1)
+        return flat[:n * k].view(n, k), flat[n * k:]
+    return out[:, :-1], out[:, -1]
+
+
+def rows_wgrad(dy, x, dy_mask=None, x_relu=False, split=False):
+    """[n, k+1] f32 = dYeff^T @ [Xeff | 1]: weight gradient with the bias gradient in the last column (dy, x, dy_mask f32 or bf16).
+    split=True: (dW [n,k], db [n]) -- contiguous tensors where the kernel can write them so (no copy when autograd adopts them)."""
     rows, n = dy.shape
     k = x.shape[1]
     out = torch.empty((n, k + 1), dtype=torch.float32, device=dy.device)
+    flags = (1 if x_relu else 0) | (2 if split else 0)
     if all(t is None or t.dtype == torch.bfloat16 for t in (dy, dy_mask, x)) and k % 32 == 0 and n % 32 == 0:
         need = ctypes.c_size_t(0)
         _check(lib().pcacc_rows_wgrad_bf16_workspace_bytes(_i64(rows), int(k), int(n), ctypes.byref(need)), 'rows_wgrad_bf16_workspace')
         ws = _ws(need.value, dy.device)
         _check(lib().pcacc_rows_wgrad_bf16(_dev(dy, torch.bfloat16, 'dy'), _dev(dy_mask, torch.bfloat16, 'dy_mask') if dy_mask is not None else None,
-                                           _dev(x, torch.bfloat16, 'x'), 1 if x_relu else 0, _i64(rows), int(k), int(n), _dev(out),
+                                           _dev(x, torch.bfloat16, 'x'), flags, _i64(rows), int(k), int(n), _dev(out),
                                            _dev(ws), ctypes.c_size_t(ws.numel()), _stream()), 'rows_wgrad_bf16')
-        return out
+        return _split_aug(out, n, k, split, True)
     dt = _row_dtype_bit(dy, 1, 'dy') | _row_dtype_bit(dy_mask, 2, 'dy_mask') | _row_dtype_bit(x, 4, 'x')
     if lib().pcacc_rows_wgrad_few_supported(int(k), int(n)):
         need = ctypes.c_size_t(0)
         _check(lib().pcacc_rows_wgrad_few_workspace_bytes(_i64(rows), int(k), int(n), ctypes.byref(need)), 'rows_wgrad_few_workspace')
         ws = _ws(need.value, dy.device)
         _check(lib().pcacc_rows_wgrad_few(_dev(dy, None, 'dy'), _dev(dy_mask, None, 'dy_mask') if dy_mask is not None else None, _dev(x, None, 'x'),
-                                          1 if x_relu else 0, _i64(rows), int(k), int(n), _dev(out), dt, _dev(ws), ctypes.c_size_t(ws.numel()),
+                                          flags, _i64(rows), int(k), int(n), _dev(out), dt, _dev(ws), ctypes.c_size_t(ws.numel()),
                                           _stream()), 'rows_wgrad_few')
-        return out
+        return _split_aug(out, n, k, split, rows > 0)
     _check(lib().pcacc_rows_wgrad_mixed(_dev(dy, None, 'dy'), _dev(dy_mask, None, 'dy_mask') if dy_mask is not None else None,
                                         _dev(x, None, 'x'), 1 if x_relu else 0, _i64(rows), int(k), int(n), _dev(out), dt, _stream()),
            'rows_wgrad')
-    return out
+    return _split_aug(out, n, k, split, False)
 
 
 def pfn_features(points, p2v, pillar_mean, coords, time_indice, vx, vy, x_offset, y_offset, scale, n_frames):
@@ -776,8 +788,8 @@ def rows_linear_cat_backward(gy, w_t, dy_mask, xa, xb, b_index, pre_relu):
     return ga, gb
 
 
-def rows_wgrad_cat(dy, xa, xb, b_index, dy_mask=None, x_relu=False):
-    """[n, k+1] f32 weight (+ bias) gradient for x = cat(xa, xb[b_index]), bf16 rows."""
+def rows_wgrad_cat(dy, xa, xb, b_index, dy_mask=None, x_relu=False, split=False):
+    """[n, k+1] f32 weight (+ bias) gradient for x = cat(xa, xb[b_index]), bf16 rows (split: see rows_wgrad)."""
     rows, n = dy.shape
     ka = xa.shape[1]
     k = ka + xb.shape[1]
@@ -786,9 +798,10 @@ def rows_wgrad_cat(dy, xa, xb, b_index, dy_mask=None, x_relu=False):
     _check(lib().pcacc_rows_wgrad_bf16_workspace_bytes(_i64(rows), int(k), int(n), ctypes.byref(need)), 'rows_wgrad_bf16_workspace')
     ws = _ws(need.value, dy.device)
     _check(lib().pcacc_rows_wgrad_cat_bf16(_dev(dy, torch.bfloat16, 'dy'), _opt(dy_mask, torch.bfloat16, 'dy_mask'), _dev(xa, torch.bfloat16, 'xa'),
-                                           _dev(xb, torch.bfloat16, 'xb'), _opt(b_index, torch.int32, 'b_index'), int(ka), 1 if x_relu else 0,
+                                           _dev(xb, torch.bfloat16, 'xb'), _opt(b_index, torch.int32, 'b_index'), int(ka),
+                                           (1 if x_relu else 0) | (2 if split else 0),
                                            _i64(rows), int(k), int(n), _dev(out), _dev(ws), ctypes.c_size_t(ws.numel()), _stream()), 'rows_wgrad_cat')
-    return out
+    return _split_aug(out, n, k, split, rows > 0)
 
 
 def svd3(a):

@@ -348,9 +348,8 @@ class _RowsLinear(torch.autograd.Function):
             gx = native.rows_linear(gy, w.t().contiguous(), None, None, False, False, in_mask=y, out_mask=x if pre_relu else None,
                                     out_dtype=x.dtype)
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
-            aug = native.rows_wgrad(gy, x, dy_mask=y, x_relu=pre_relu)
-            gw = aug[:, :-1]
-            gb = aug[:, -1] if has_bias else None
+            gw, gb = native.rows_wgrad(gy, x, dy_mask=y, x_relu=pre_relu, split=True)     # contiguous: autograd adopts them without a copy
+            gb = gb if has_bias else None
         if has_res and ctx.needs_input_grad[3]:
             gres = (gy if y is None else gy * (y > 0)).to(res_dtype)
         return gx, gw, gb, gres, None, None, None
@@ -383,9 +382,8 @@ class _RowsLinearCat(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 gp = native.segment_sum(gb_rows, pidx.seg_offsets, pidx.order, pidx.m).to(pooled.dtype)
         if ctx.needs_input_grad[3] or (has_bias and ctx.needs_input_grad[4]):
-            aug = native.rows_wgrad_cat(gy, xa, pooled, pidx.p2v, dy_mask=y, x_relu=pre_relu)
-            gw = aug[:, :-1]
-            gb = aug[:, -1] if has_bias else None
+            gw, gb = native.rows_wgrad_cat(gy, xa, pooled, pidx.p2v, dy_mask=y, x_relu=pre_relu, split=True)
+            gb = gb if has_bias else None
         if has_res and ctx.needs_input_grad[5]:
             gres = gy if y is None else gy * (y > 0)
         return ga, gp, None, gw, gb, gres, None, None

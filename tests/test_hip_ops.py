@@ -591,6 +591,8 @@ def test_rows_wgrad_few_features_mixed_dtypes(c, f, rows):
     ones = torch.ones(rows, 1, device=dev, dtype=torch.float64)
     # few inputs: dy = wide (masked), x = narrow (pre-ReLU)
     aug = native.rows_wgrad(wide, narrow, dy_mask=mk, x_relu=True)
+    gw, gb = native.rows_wgrad(wide, narrow, dy_mask=mk, x_relu=True, split=True)          # the layout autograd adopts without a copy
+    assert gw.is_contiguous() and gb.is_contiguous() and torch.equal(gw, aug[:, :-1]) and torch.equal(gb, aug[:, -1])
     geff = (wide.float() * (mk.float() > 0)).double()
     ref = geff.t() @ torch.cat([torch.relu(narrow).double(), ones], 1)
     assert aug.shape == (c, f + 1) and (aug.double() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
@@ -690,6 +692,9 @@ def test_rows_wgrad_bf16_mfma(k, n):
         mk = torch.randn(rows, n, generator=g).to(dev).to(torch.bfloat16)
         for use_mask, relu in ((False, False), (True, True)):
             aug = native.rows_wgrad(dy, x, dy_mask=mk if use_mask else None, x_relu=relu)
+            gw, gb = native.rows_wgrad(dy, x, dy_mask=mk if use_mask else None, x_relu=relu, split=True)
+            assert gw.is_contiguous() and gb.is_contiguous() and gw.shape == (n, k) and gb.shape == (n,)
+            assert torch.allclose(gw, aug[:, :-1], rtol=1e-5, atol=1e-5 * float(aug.abs().max())) and torch.allclose(gb, aug[:, -1], rtol=1e-5, atol=1e-4)
             geff = dy.float() * (mk.float() > 0) if use_mask else dy.float()
             xe = torch.relu(x.float()) if relu else x.float()
             ref = geff.t() @ torch.cat([xe, torch.ones(rows, 1, device=dev)], 1)
