@@ -171,6 +171,7 @@ def main():
     ap.add_argument('--no-fp32-leg', action='store_true', help='skip the fp32 (matched-accuracy) timing of the same step that follows the bf16 run at N = 1')
     ap.add_argument('--no-miopen-find', action='store_true', help='library convolutions through the immediate-mode heuristic instead of the find-db')
     ap.add_argument('--no-pipeline', action='store_true', help='one backward at the end of the forward instead of the early backward of the ego / fb / perm terms (DataParallelStep.pipelined)')
+    ap.add_argument('--one-stream', action='store_true', help='motion heads and TubeNet on the main stream behind the early backward instead of beside it on a second stream')
     ap.add_argument('--no-prefetch', action='store_true', help='voxelise each batch at the start of its own step instead of one step ahead on a side stream')
     args = ap.parse_args()
 
@@ -205,7 +206,7 @@ def main():
     def batch_of(i):
         return [scenes[(i * args.batch + j) % n_scenes] for j in range(args.batch)]
     stepper = pdist.DataParallelStep(model, opt, loss_fn, iter_size=args.iter_size, grad_clip=cfg['train']['grad_clip'],
-                                     pipelined=not args.no_pipeline)
+                                     pipelined=not args.no_pipeline, two_streams=not args.one_stream)
 
     torch.manual_seed(1234 + rank)
     feed = BatchFeed(batcher, batch_of, not args.no_prefetch)
@@ -236,7 +237,7 @@ def main():
         cfg32['misc']['compute_dtype'] = 'fp32'
         m32, o32, l32 = build(cfg32, device)
         st32 = pdist.DataParallelStep(m32, o32, l32, iter_size=args.iter_size, grad_clip=cfg['train']['grad_clip'],
-                                      pipelined=not args.no_pipeline)
+                                      pipelined=not args.no_pipeline, two_streams=not args.one_stream)
         feed32 = BatchFeed(batcher, batch_of, not args.no_prefetch)
         k32 = max(2, min(args.steps, 5))
         for i in range(2):

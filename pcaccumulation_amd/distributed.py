@@ -25,6 +25,8 @@ Design for MotionNet on an 8 x MI355X node:
 """
 import os
 
+import contextlib
+
 import torch
 import torch.distributed as dist
 
@@ -303,17 +305,22 @@ class DataParallelStep(object):
     GradScaler uses; `skipped` counts on the device (read it with skipped_steps()).  Optimizers without that input (CPU tests)
     read the flag on the host."""
 
-    def __init__(self, model, optimizer, loss_fn, iter_size=1, grad_clip=1.0, check_finite=True, catch=True, reducer=None, pipelined=None):
+    def __init__(self, model, optimizer, loss_fn, iter_size=1, grad_clip=1.0, check_finite=True, catch=True, reducer=None, pipelined=None, two_streams=True):
         self.model, self.optimizer, self.loss_fn = model, optimizer, loss_fn
         # pipelined: back-propagate the loss terms of the lower half of the model (pillar encoder, U-Net, heads, ego head) as soon as
         # the ego head has run, before the motion heads and the TubeNet are even issued (MotionNet.after_ego, FuseLoss.early_terms);
         # default: whenever model and loss offer the two hooks
         can = hasattr(model, 'after_ego') and hasattr(loss_fn, 'early_terms')
         self.pipelined = can if pipelined is None else (bool(pipelined) and can)
+        # two_streams: the rest of the forward, its loss terms and their backward run on a side stream while the early backward
+        # occupies the main one (MotionNet.side_stream); joined before the clip / optimizer block
+        self._two_streams = bool(two_streams)
         self.iter_size, self.grad_clip, self.check_finite, self.catch = int(iter_size), grad_clip, check_finite, catch
         self.reducer = reducer if reducer is not None else BucketedGradReducer(model.parameters())
         if self.pipelined and hasattr(model, 'early_parameters'):
             self.reducer.set_early(model.early_parameters())
+        dev = self.reducer.params[0].device
+        self.side = torch.cuda.Stream(device=dev) if (self.pipelined and self._two_streams and dev.type == 'cuda' and hasattr(model, 'side_stream')) else None
         self.micro = 0
         self.ok = True
         self.last_error = None
@@ -339,6 +346,9 @@ class DataParallelStep(object):
 
         def early_backward(results):
             e = self.loss_fn.early_terms(results)
+            if self.side is not None:                         # the side stream reads these terms (statistics, total loss) -- not the backward below
+                self._early_ready = torch.cuda.Event()
+                self._early_ready.record()
             loss_e = e['loss_early'] / self.iter_size if self.iter_size > 1 else e['loss_early']
             r.prepare(loss_e, part='early')                   # the lower half's buckets go out now, under the rest of the forward
             loss_e.backward()
@@ -347,17 +357,27 @@ class DataParallelStep(object):
         try:
             if self.pipelined:
                 self.model.after_ego = early_backward
+                self.model.side_stream = self.side
             try:
                 out = self.model(inp)
             finally:
                 if self.pipelined:
                     self.model.after_ego = None
+                    self.model.side_stream = None
             if after_forward is not None:
                 after_forward()
-            stats = self.loss_fn(out, inp, early=early[0]) if early else self.loss_fn(out, inp)
-            loss = stats['loss'] / self.iter_size if self.iter_size > 1 else stats['loss']
-            r.prepare(loss, part='rest')
-            loss.backward()
+            two = self.side is not None and bool(early)
+            if two:
+                from .motionnet import share_with_stream
+                share_with_stream(self.side, early[0], inp)
+                self.side.wait_event(self._early_ready)
+            with (torch.cuda.stream(self.side) if two else contextlib.nullcontext()):
+                stats = self.loss_fn(out, inp, early=early[0]) if early else self.loss_fn(out, inp)
+                loss = stats['loss'] / self.iter_size if self.iter_size > 1 else stats['loss']
+                r.prepare(loss, part='rest')
+                loss.backward()
+            if two:
+                torch.cuda.current_stream().wait_stream(self.side)     # join: clip / optimizer read the gradients of both halves
         except Exception as e:                                # noqa: BLE001 -- libs/trainer.py:234-235
             if not self.catch:
                 raise

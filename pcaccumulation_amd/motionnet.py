@@ -30,6 +30,18 @@ from .unet import SegHead2D, UNet
 MIN_POINTS = 15                          # models/motionnet.py:11
 
 
+def share_with_stream(stream, *objs):
+    """Tensor.record_stream(stream) for every CUDA tensor in `objs` (dicts, lists and tuples are walked)."""
+    for o in objs:
+        if torch.is_tensor(o):
+            if o.is_cuda:
+                o.record_stream(stream)
+        elif isinstance(o, dict):
+            share_with_stream(stream, *[dict.__getitem__(o, k) for k in o])
+        elif isinstance(o, (list, tuple)):
+            share_with_stream(stream, *o)
+
+
 def grid_shape(cfg):
     """[nx, ny, nz, nt] as Voxelization computes it (libs/voxel_generator.py:123-125, fp32 round)."""
     vg = cfg['voxel_generator']
@@ -59,6 +71,7 @@ class MotionNet(nn.Module):
         # pillars renumbered in canvas-cell order inside forward() (ops.PillarIndex); False keeps the voxeliser's numbering
         self.cell_ordered_pillars = bool(cfg['misc'].get('cell_ordered_pillars', True))
         self.after_ego = None                    # optional callable(results), see forward()
+        self.side_stream = None                  # optional torch.cuda.Stream for stages 5-6 while after_ego's backward runs
 
     # ------------------------------------------------------------------------------------------------
     def early_parameters(self):
@@ -193,69 +206,87 @@ class MotionNet(nn.Module):
         # U-Net, the two heads and the ego head is complete here.  A training step may hook in (`after_ego`) to evaluate the loss terms
         # that live on it and back-propagate them now (FuseLoss.early_terms, distributed.DataParallelStep): the largest kernels of
         # the step are then queued in front of the ~800 small launches of the motion heads and the TubeNet.
+        fork = None
         if self.after_ego is not None:
+            if self.side_stream is not None and input_points.is_cuda:
+                fork = torch.cuda.Event()
+                fork.record()                                  # the side stream joins HERE: in front of the backward the hook queues
             self.after_ego(results)
 
-        # 5. motion segmentation on ego-motion-compensated features
-        pose_est = results['ego_motion_est'].float().detach()
-        bev_feats = bev_feats.detach()
-        C = bev_feats.size(1)
-        bev_cl = bev_feats.permute(0, 2, 3, 1).contiguous().view(B, T, Ny, Nx, C)
-        warped = ops.bev_warp(bev_cl, torch.linalg.inv_ex(pose_est)[0], self.resolution[0], self.resolution[1],
-                              self.pc_range[0], self.pc_range[1])
-        warped_feats = warped.permute(0, 4, 1, 2, 3)                           # [B,C,T,H,W], channels_last_3d memory
-        transformed_points = ops.rigid_transform(input_points, frame_idx, pose_est)
-        results['transformed_points'] = transformed_points
+        # Stages 5 and 6 read detached tensors only: with a side stream set (training steps that back-propagate the early terms in the
+        # hook above) they run there, concurrently with that backward on the main stream -- their hundreds of small kernels fill the
+        # gaps the large ones leave instead of queueing behind them.  The caller joins the streams (DataParallelStep).
+        def upper():
+            nonlocal bev_feats, rec_mask, n_rec
+            # 5. motion segmentation on ego-motion-compensated features
+            pose_est = results['ego_motion_est'].float().detach()
+            bev_feats = bev_feats.detach()
+            C = bev_feats.size(1)
+            bev_cl = bev_feats.permute(0, 2, 3, 1).contiguous().view(B, T, Ny, Nx, C)
+            warped = ops.bev_warp(bev_cl, torch.linalg.inv_ex(pose_est)[0], self.resolution[0], self.resolution[1],
+                                  self.pc_range[0], self.pc_range[1])
+            warped_feats = warped.permute(0, 4, 1, 2, 3)                           # [B,C,T,H,W], channels_last_3d memory
+            transformed_points = ops.rigid_transform(input_points, frame_idx, pose_est)
+            results['transformed_points'] = transformed_points
 
-        full_mos = torch.zeros(transformed_points.size(0), 2, device=device)
-        full_offset = torch.zeros(transformed_points.size(0), 2, device=device)
-        full_mos[:, 0] = 1
-        mos_feats = None
-        if n_fb > MIN_POINTS:
-            with self._dense():
-                stpn_map = self.motionhead.backbone(warped_feats)
-            mos, offset, mos_feats = self._stpn_heads(stpn_map, transformed_points[fb_idx], batch_idx[fb_idx])
-            full_mos = full_mos.index_copy(0, fb_idx, mos)
-            full_offset = full_offset.index_copy(0, fb_idx, offset)
-        results['mos_est'] = full_mos
-        results['offset_est'] = full_offset
-        results['rec_est'] = transformed_points.clone()
+            full_mos = torch.zeros(transformed_points.size(0), 2, device=device)
+            full_offset = torch.zeros(transformed_points.size(0), 2, device=device)
+            full_mos[:, 0] = 1
+            mos_feats = None
+            if n_fb > MIN_POINTS:
+                with self._dense():
+                    stpn_map = self.motionhead.backbone(warped_feats)
+                mos, offset, mos_feats = self._stpn_heads(stpn_map, transformed_points[fb_idx], batch_idx[fb_idx])
+                full_mos = full_mos.index_copy(0, fb_idx, mos)
+                full_offset = full_offset.index_copy(0, fb_idx, offset)
+            results['mos_est'] = full_mos
+            results['offset_est'] = full_offset
+            results['rec_est'] = transformed_points.clone()
 
-        # 6. TubeNet
-        if self.mode in ['train', 'val']:
-            inst_labels = input_dict['inst_labels'][:, 0].long()
-        else:
-            results['_n_batches'] = B                     # spares the cluster step a .max() read-back
-            self.cluster(transformed_points, full_mos.argmax(1), full_offset, time_indice, results, use_offset=True)
-            inst_labels = results['inst_labels_est']
-            rec_mask = inst_labels != 0
-            n_rec = int(rec_mask.sum())                   # the one extra host sync of test mode
-        if n_rec > MIN_POINTS:
-            rec_idx = torch.nonzero_static(rec_mask, size=n_rec)[:, 0]
-            results['_rec_idx'] = rec_idx
+            # 6. TubeNet
             if self.mode in ['train', 'val']:
-                results['_gtfg_idx'] = rec_idx            # = nonzero(fb_labels == 1), what FuseLoss.get_offset_loss supervises (libs/loss.py:199)
-            # mos_feats exists whenever rec_mask passes in train/val (fb_mask is a superset of rec_mask)
-            backbone_feats = ops.bilinear_gather(bev_feats, input_points[rec_idx], frame_idx[rec_idx],
-                                                 abs(self.pc_range[0]), abs(self.pc_range[1]))       # temporal_ungrid
-            motion_feats = ops.bilinear_gather(mos_feats, transformed_points[rec_idx], batch_idx[rec_idx],
-                                               abs(self.pc_range[0]), abs(self.pc_range[1]))          # ungrid
-            reconstructor_input = {
-                'inst_labels': inst_labels[rec_idx],
-                'time_indice': time_indice[rec_idx],
-                'transformed_points': transformed_points[rec_idx],
-                'backbone_feats': backbone_feats,
-                'motion_feats': motion_feats,
-                'inst_motion_gt': input_dict['inst_motion_gt'],
-                'mos_labels': input_dict['sd_labels'][rec_idx, 0].long(),
-                'ego_motion_est': results['ego_motion_est'].detach(),     # alignnet.py:240 detaches what is derived from it
-                'ego_motion_gt': results['ego_motion_gt'],
-                '_pad_flags': pad_flags if self.mode in ['train', 'val'] else None,
-            }
-            self.reconstructor(reconstructor_input, results)
-            results['rec_est'] = results['rec_est'].index_copy(0, rec_idx, results['sub_rec_est'])
-        self._resolve_scalars(results)
-        return results
+                inst_labels = input_dict['inst_labels'][:, 0].long()
+            else:
+                results['_n_batches'] = B                     # spares the cluster step a .max() read-back
+                self.cluster(transformed_points, full_mos.argmax(1), full_offset, time_indice, results, use_offset=True)
+                inst_labels = results['inst_labels_est']
+                rec_mask = inst_labels != 0
+                n_rec = int(rec_mask.sum())                   # the one extra host sync of test mode
+            if n_rec > MIN_POINTS:
+                rec_idx = torch.nonzero_static(rec_mask, size=n_rec)[:, 0]
+                results['_rec_idx'] = rec_idx
+                if self.mode in ['train', 'val']:
+                    results['_gtfg_idx'] = rec_idx            # = nonzero(fb_labels == 1), what FuseLoss.get_offset_loss supervises (libs/loss.py:199)
+                # mos_feats exists whenever rec_mask passes in train/val (fb_mask is a superset of rec_mask)
+                backbone_feats = ops.bilinear_gather(bev_feats, input_points[rec_idx], frame_idx[rec_idx],
+                                                     abs(self.pc_range[0]), abs(self.pc_range[1]))       # temporal_ungrid
+                motion_feats = ops.bilinear_gather(mos_feats, transformed_points[rec_idx], batch_idx[rec_idx],
+                                                   abs(self.pc_range[0]), abs(self.pc_range[1]))          # ungrid
+                reconstructor_input = {
+                    'inst_labels': inst_labels[rec_idx],
+                    'time_indice': time_indice[rec_idx],
+                    'transformed_points': transformed_points[rec_idx],
+                    'backbone_feats': backbone_feats,
+                    'motion_feats': motion_feats,
+                    'inst_motion_gt': input_dict['inst_motion_gt'],
+                    'mos_labels': input_dict['sd_labels'][rec_idx, 0].long(),
+                    'ego_motion_est': results['ego_motion_est'].detach(),     # alignnet.py:240 detaches what is derived from it
+                    'ego_motion_gt': results['ego_motion_gt'],
+                    '_pad_flags': pad_flags if self.mode in ['train', 'val'] else None,
+                }
+                self.reconstructor(reconstructor_input, results)
+                results['rec_est'] = results['rec_est'].index_copy(0, rec_idx, results['sub_rec_est'])
+            self._resolve_scalars(results)
+            return results
+
+        if fork is None:
+            return upper()
+        # what stages 5-6 read was allocated on the main stream: tell the caching allocator that the side stream uses it too, or a
+        # block could be handed out again on the main stream (the early backward allocates there) while a side-stream kernel reads it
+        share_with_stream(self.side_stream, input_dict, results, bev_feats, input_points, frame_idx, batch_idx, time_indice, fb_idx, rec_mask)
+        self.side_stream.wait_event(fork)
+        with torch.cuda.stream(self.side_stream):
+            return upper()
 
     @staticmethod
     def _resolve_scalars(results):

@@ -112,27 +112,36 @@ def _check(name, compute_dtype, golden):
     _dump(name, compute_dtype, got, ref, extra)
     tol = FP32_TOL if compute_dtype == 'fp32' else BF16_TOL
     bounds = dict(ego_rot_error=tol['ego'], ego_trans_error=tol['ego'], mos_iou=tol['iou'], epe_mean=tol['epe'])
+    ensemble_loss = False
     outside = [k for k in bounds if not abs(got[k] - ref[k]) < bounds[k]]
     if outside and compute_dtype == 'bf16' and 'mos_iou' not in outside:
-        draws = {'fp32': [ref], 'bf16': [got]}
+        train = str(g['mode']) == 'train'
+        draws = {'fp32': [dict(ref, loss=float(g['loss'])) if train else ref], 'bf16': [dict(got, loss=float(stats['loss'])) if train else got]}
         for off in range(1, 6):
             for dt in ('fp32', 'bf16'):
                 _, inp2, out2, stats2, _ = _run(g, dt, seed_offset=off)
-                draws[dt].append(_metrics(g, inp2, out2, stats2, T)[0])
+                m = _metrics(g, inp2, out2, stats2, T)[0]
+                if train:
+                    m['loss'] = float(stats2['loss'])
+                draws[dt].append(m)
                 del inp2, out2, stats2
         _dump(name, 'seed-ensembles', got, ref, draws)
         for k in outside:
             m32, m16 = (float(np.mean([d[k] for d in draws[dt]])) for dt in ('fp32', 'bf16'))
             assert abs(m16 - m32) < bounds[k], (k, m16, m32, draws)
         outside = []
+        if train:                                              # the ego terms of the loss follow the draw too: compare the means
+            l32, l16 = (float(np.mean([d['loss'] for d in draws[dt]])) for dt in ('fp32', 'bf16'))
+            assert abs(l16 - l32) < 5e-2 * abs(l32), (l16, l32, draws)
+            ensemble_loss = True
     assert not outside, (outside, got, ref)
-    return g, model, out, stats, flips
+    return g, model, out, stats, (flips, ensemble_loss)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('name', CONFIGS)
 def test_gpu_config_fp32(name, golden):
-    g, model, out, stats, flips = _check(name, 'fp32', golden)
+    g, model, out, stats, (flips, _) = _check(name, 'fp32', golden)
     idx = torch.from_numpy(g['sample_idx']).cuda()
     assert flips < 2e-3
     assert abs(int(out['fb_est_per_points'].sum()) - int(g['fb_est_sum'])) <= 0.002 * max(int(g['fb_est_sum']), 1000)
@@ -160,10 +169,11 @@ def test_gpu_config_fp32(name, golden):
 @pytest.mark.gpu
 @pytest.mark.parametrize('name', CONFIGS)
 def test_gpu_config_bf16(name, golden):
-    g, model, out, stats, flips = _check(name, 'bf16', golden)
+    g, model, out, stats, (flips, ensemble_loss) = _check(name, 'bf16', golden)
     assert flips < 1e-2
     if str(g['mode']) == 'train':
-        assert abs(float(stats['loss']) - float(g['loss'])) < 5e-2 * abs(float(g['loss']))
+        if not ensemble_loss:                                  # (a tail draw of the pose was compared through the seed ensembles, loss included)
+            assert abs(float(stats['loss']) - float(g['loss'])) < 5e-2 * abs(float(g['loss']))
         assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
 
 
