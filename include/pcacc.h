@@ -486,6 +486,10 @@ int pcacc_maxpool2x2_bf16(const uint16_t *x, int64_t n_img, int32_t h, int32_t w
 int pcacc_pool_skip_relu_backward_bf16(const uint16_t *y, const uint16_t *grad_pooled, const uint16_t *grad_skip, int64_t n_img, int32_t h,
                                        int32_t w, int32_t c, uint16_t *grad_y, void *stream);
 
+/* Batched inverse of n 4x4 f32 matrices (the pose tables: torch.linalg.inv at models/motionnet.py:100 and models/alignnet.py:33),
+ * Gauss-Jordan with partial pivoting, one launch; a singular matrix yields inf / nan entries (no status word). */
+int pcacc_inv4x4(const float *m, int64_t n, float *out, void *stream);
+
 /* Weight gradient of a row-linear layer with few inputs (k in {1,2,3,4,9}, n in {32,64,128}: first layers of the point chains) or few
  * outputs (n in {1,2,3,4,9}, k in {32,64,128}: the heads) -- same result and operand conventions as pcacc_rows_wgrad_mixed
  * (dw_aug [n, k+1] f32, bias gradient in the last column; dtypes bit 0 dY, bit 1 dy_mask, bit 2 X set = bf16), streamed at HBM speed

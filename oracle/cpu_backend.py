@@ -274,12 +274,17 @@ def tube_pose_backward(pose_vec, remaining, slot_centre, weights, wsum, grad_pos
     return torch.autograd.grad(obj, pv)[0]
 
 
+def inv4x4(m):
+    """torch.linalg.inv of the pose tables (models/motionnet.py:100, models/alignnet.py:33)."""
+    return torch.linalg.inv(m.float())
+
+
 NAMES = ['voxelize', 'cell_index', 'frame_pillars', 'csr_build', 'segment_mean3_maxlabel', 'segment_max',
          'segment_max_backward', 'segment_sum', 'pillar_scatter', 'gather_rows', 'bilinear_gather',
          'bilinear_gather_backward', 'bev_warp', 'rigid_transform', 'chamfer_forward', 'chamfer_backward',
          'rows_linear', 'rows_wgrad', 'rows_linear_supported', 'pfn_features', 'scatter_sum_small', 'sinkhorn_kabsch', 'cluster', 'sample_subsets', 'upload_small', 'bilinear_gather_backward_sorted', 'prep_points', 'sinkhorn_forward', 'sinkhorn_backward',
          'seg_loss_forward', 'seg_loss_backward', 'offset_loss_forward', 'offset_loss_backward', 'frames_max', 'frames_max_backward', 'svd3', 'svd3_backward',
-         'tube_rows', 'tube_code', 'tube_code_backward', 'tube_pose_forward', 'tube_gap_forward', 'tube_finish', 'tube_gap_backward', 'tube_pose_backward']
+         'tube_rows', 'tube_code', 'tube_code_backward', 'tube_pose_forward', 'tube_gap_forward', 'tube_finish', 'tube_gap_backward', 'tube_pose_backward', 'inv4x4']
 
 
 def install(monkeypatch=None):

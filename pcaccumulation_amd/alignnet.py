@@ -10,16 +10,23 @@ _EPS = 1e-20
 
 
 def update_gt_inst_motion(inst_motion_gt, ego_motion_gt, ego_motion_est):
-    """models/alignnet.py:9-38: GT instance motion expressed relative to the ESTIMATED ego motion."""
+    """models/alignnet.py:9-38: GT instance motion expressed relative to the ESTIMATED ego motion, per sample
+    `motion @ ego_gt @ inv(ego_est)` -- evaluated for all samples at once (one inverse launch, two batched products over the
+    concatenated instance table) and handed back as the reference's list of per-sample views."""
     device = ego_motion_gt.device
-    out = []
-    for b, motion in enumerate(inst_motion_gt):
-        motion = motion.to(device).float()
-        K = motion.size(0)
-        gt = ego_motion_gt[b][None].repeat(K, 1, 1, 1).view(-1, 4, 4)
-        est = ego_motion_est[b][None].repeat(K, 1, 1, 1).view(-1, 4, 4)
-        out.append((motion.view(-1, 4, 4) @ gt @ torch.linalg.inv_ex(est)[0]).view(K, -1, 4, 4))   # inv() minus its host sync
-    return out
+    sizes = [m.size(0) for m in inst_motion_gt]
+    T = ego_motion_gt.size(1)
+    if sum(sizes) == 0:
+        return [m.to(device).float().view(0, T, 4, 4) for m in inst_motion_gt]
+    motion = torch.cat([m.to(device).float() for m in inst_motion_gt], dim=0) if len(sizes) > 1 else inst_motion_gt[0].to(device).float()
+    est_inv = native.inv4x4(ego_motion_est.detach().float())                   # inv() minus its host sync and its dozen launches
+    if len(sizes) > 1:
+        sample = native.upload_small([b for b, k in enumerate(sizes) for _ in range(k)], torch.int64, device)
+        gt, inv = ego_motion_gt.float().index_select(0, sample), est_inv.index_select(0, sample)          # [K, T, 4, 4]
+    else:
+        gt, inv = ego_motion_gt.float().expand(sizes[0], -1, -1, -1), est_inv.expand(sizes[0], -1, -1, -1)
+    out = torch.matmul(torch.matmul(motion, gt), inv)                          # the reference's association: (motion @ gt) @ inv
+    return list(out.split(sizes, dim=0))
 
 
 class AlignNet(BaseModel):

@@ -254,15 +254,15 @@ extern "C" int pcacc_rows_linear_cat_bf16(const uint16_t *xa, const uint16_t *xb
 typedef short wg_s16x4 __attribute__((ext_vector_type(4)));
 union wg_frag { bf16x8_t v; wg_s16x4 h[2]; uint16_t e[8]; };
 
-template <int MAX_TILES, int WG_R>
-__global__ __launch_bounds__(256) void rows_wgrad_bf16_kernel(const uint16_t *__restrict__ dY, const uint16_t *__restrict__ dy_mask,
+template <int MAX_TILES, int WG_R, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void rows_wgrad_bf16_kernel(const uint16_t *__restrict__ dY, const uint16_t *__restrict__ dy_mask,
                                                               const uint16_t *__restrict__ X, int x_relu, int64_t rows, int K, int N,
                                                               int k_tiles, int n_tile_total, int tiles_par, float *partial, RowPieces xs2,
                                                               float *__restrict__ dw_zero)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t wlds[];
     if (blockIdx.x == 0)                                                       // the reduce launch adds into dW: cleared here, not by a memset
-        for (int e = threadIdx.x; e < N * (K + 1); e += 256) dw_zero[e] = 0.f;
+        for (int e = threadIdx.x; e < N * (K + 1); e += NW * 64) dw_zero[e] = 0.f;
     const int NS = pcacc_tr_stride(N), KS = pcacc_tr_stride(K);
     uint16_t *sdy = wlds, *sx = wlds + WG_R * NS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -276,14 +276,15 @@ __global__ __launch_bounds__(256) void rows_wgrad_bf16_kernel(const uint16_t *__
     // Staging: up to 4 sixteen-byte pieces of dY and of X per thread (64 rows x 128 features), fetched one tile ahead.
     const int64_t n_chunks = (rows + WG_R - 1) / WG_R;
     const int ny = WG_R * N / 8, nx = WG_R * K / 8;                              // pieces per tile
-    uint4 yreg[4], mreg[4], xreg[4];
+    constexpr int PIECES = 16 / NW;                                            // 16-byte pieces of dY and of X per thread and tile
+    uint4 yreg[PIECES], mreg[PIECES], xreg[PIECES];
     const int kshift = __ffs(K) - 1;                                           // two-piece rows: K is a power of two
-    int prow[4] = {0, 0, 0, 0};                                                // rows of the second piece for the NEXT fetch: the index
+    int prow[PIECES] = {};                                                // rows of the second piece for the NEXT fetch: the index
     auto fetch_rows = [&](int64_t ch) {                                        // load and the row load it feeds are a tile apart
         if (!xs2.b) return;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = threadIdx.x + q * 256;
+        for (int q = 0; q < PIECES; ++q) {
+            const int i = threadIdx.x + q * NW * 64;
             const int64_t row = ch * WG_R + ((i * 8) >> kshift);
             prow[q] = (i < nx && row < rows && ch < n_chunks) ? (xs2.idx ? xs2.idx[row] : (int)row) : 0;
         }
@@ -292,8 +293,8 @@ __global__ __launch_bounds__(256) void rows_wgrad_bf16_kernel(const uint16_t *__
         const int64_t row0 = ch * WG_R;
         const int64_t lim_n = (rows - row0) * N, lim_k = (rows - row0) * K;      // elements of this tile that exist
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = threadIdx.x + q * 256;
+        for (int q = 0; q < PIECES; ++q) {
+            const int i = threadIdx.x + q * NW * 64;
             uint4 v = make_uint4(0, 0, 0, 0), m = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
             if (i < ny && (int64_t)i * 8 < lim_n) {
                 v = *reinterpret_cast<const uint4 *>(dY + row0 * N + (int64_t)i * 8);
@@ -321,8 +322,8 @@ __global__ __launch_bounds__(256) void rows_wgrad_bf16_kernel(const uint16_t *__
         const int64_t row0 = ch * WG_R;
         __syncthreads();                                                         // the previous tile's gathers are done
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = threadIdx.x + q * 256;
+        for (int q = 0; q < PIECES; ++q) {
+            const int i = threadIdx.x + q * NW * 64;
             if (i < ny) {
                 const int e = i * 8;
                 uint4 v = yreg[q];
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(256) void rows_wgrad_bf16_kernel(const uint16_t *__
         const int tr_row = (g >> 1) * 8 + (li >> 2), tr_col = (g & 1) * 16 + (li & 3) * 4;
         // few output tiles (tiles_par = 1 or 2 of them in parallel): the waves split the rows of the staged tile instead of idling
         // (row group = wave / tiles_par; every group keeps its own partial slot)
-        const int rgroups = 4 / tiles_par, rgrp = wave / tiles_par;
+        const int rgroups = NW / tiles_par, rgrp = wave / tiles_par;
         const int r_lo = rgrp * (WG_R / rgroups), r_hi = r_lo + WG_R / rgroups;
 #pragma unroll
         for (int t = 0; t < MAX_TILES; ++t) {
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(256) void rows_wgrad_bf16_kernel(const uint16_t *__
         }
     }
     const int KA = K + 1;
-    float *mine = partial + ((int64_t)blockIdx.x * (4 / tiles_par) + wave / tiles_par) * N * KA;
+    float *mine = partial + ((int64_t)blockIdx.x * (NW / tiles_par) + wave / tiles_par) * N * KA;
 #pragma unroll
     for (int t = 0; t < MAX_TILES; ++t) {
         const int tile = wave % tiles_par + tiles_par * t;
@@ -421,7 +422,8 @@ __global__ __launch_bounds__(256) void rows_wgrad_reduce_kernel(const float *__r
 }
 
 static int wgrad_bf16_tile_rows(int k, int n) { return k + n <= 64 ? 256 : (k + n <= 128 ? 128 : 64); }
-static int wgrad_bf16_tiles_par(int total) { return total <= 1 ? 1 : (total <= 2 ? 2 : 4); }
+static int wgrad_bf16_waves(int total) { return total > 12 ? 8 : 4; }       // 20 tiles (128 x 129): 8 waves x 3 accumulators, 2 workgroups per CU
+static int wgrad_bf16_tiles_par(int total) { return total <= 1 ? 1 : (total <= 2 ? 2 : (total > 12 ? 8 : 4)); }
 
 static int wgrad_bf16_grid(int64_t rows, int tile_rows)
 {
@@ -434,7 +436,7 @@ extern "C" int pcacc_rows_wgrad_bf16_workspace_bytes(int64_t rows, int32_t k, in
 {
     if (!bytes || rows < 0 || k <= 0 || n <= 0) return PCACC_E_ARG;
     const int total = ((k + 1 + 31) / 32) * ((n + 31) / 32);
-    *bytes = (size_t)(rows > 0 ? wgrad_bf16_grid(rows, wgrad_bf16_tile_rows(k, n)) : 0) * (4 / wgrad_bf16_tiles_par(total)) * n * (k + 1) * sizeof(float);
+    *bytes = (size_t)(rows > 0 ? wgrad_bf16_grid(rows, wgrad_bf16_tile_rows(k, n)) : 0) * (wgrad_bf16_waves(total) / wgrad_bf16_tiles_par(total)) * n * (k + 1) * sizeof(float);
     return PCACC_OK;
 }
 
@@ -453,7 +455,7 @@ static int rows_wgrad_bf16_any(const uint16_t *dy, const uint16_t *dy_mask, cons
     const int k_tiles = (k + 1 + 31) / 32, n_tiles = (n + 31) / 32;
     const int total = k_tiles * n_tiles;
     if (total > 24) return PCACC_E_ARG;
-    const int tile_rows = wgrad_bf16_tile_rows(k, n), tiles_par = wgrad_bf16_tiles_par(total), parts_per_wg = 4 / tiles_par;
+    const int tile_rows = wgrad_bf16_tile_rows(k, n), tiles_par = wgrad_bf16_tiles_par(total), parts_per_wg = wgrad_bf16_waves(total) / tiles_par;
     const int grid = wgrad_bf16_grid(rows, tile_rows);
     const int elems = n * (k + 1);
     if (workspace_bytes < (size_t)grid * parts_per_wg * elems * sizeof(float)) return PCACC_E_WORKSPACE;
@@ -462,7 +464,8 @@ static int rows_wgrad_bf16_any(const uint16_t *dy, const uint16_t *dy_mask, cons
 #define WGB(T, R) rows_wgrad_bf16_kernel<T, R><<<grid, 256, lds, st>>>(dy, dy_mask, x, x_relu, rows, k, n, k_tiles, total, tiles_par, partial, xs2, dw_aug)
     if (total <= 4) { if (tile_rows == 256) WGB(1, 256); else if (tile_rows == 128) WGB(1, 128); else WGB(1, 64); }
     else if (total <= 8) { if (tile_rows == 128) WGB(2, 128); else WGB(2, 64); }
-    else WGB(6, 64);
+    else if (total <= 12) WGB(3, 64);
+    else rows_wgrad_bf16_kernel<3, 64, 8><<<grid, 512, lds, st>>>(dy, dy_mask, x, x_relu, rows, k, n, k_tiles, total, tiles_par, partial, xs2, dw_aug);
 #undef WGB
     const int slices = elems >= 8192 ? 16 : 64;                               // ~1000 workgroups in flight either way
     rows_wgrad_reduce_kernel<<<dim3((elems + 255) / 256, slices), 256, 0, st>>>(partial, grid * parts_per_wg, elems, dw_aug, split_k);

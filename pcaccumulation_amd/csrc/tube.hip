@@ -502,3 +502,56 @@ extern "C" int pcacc_tube_pose_backward(const float *pose_vec, const float *rema
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Batched inverse of 4x4 matrices (torch.linalg.inv of the pose tables: models/motionnet.py:100, models/alignnet.py:33), one lane
+// per matrix: Gauss-Jordan with partial pivoting in registers.  The library call is a dozen launches (LU factorisation, pivot
+// swaps, triangular solves) for a [B*T] batch of 20.
+__global__ void inv4x4_kernel(const float *__restrict__ m, int64_t n, float *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a[4][8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { a[r][c] = m[i * 16 + r * 4 + c]; a[r][4 + c] = r == c ? 1.f : 0.f; }
+#pragma unroll
+    for (int col = 0; col < 4; ++col) {
+        int piv = col;
+        float best = fabsf(a[col][col]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r > col && fabsf(a[r][col]) > best) { best = fabsf(a[r][col]); piv = r; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r > col && r == piv) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) { const float t = a[col][c]; a[col][c] = a[r][c]; a[r][c] = t; }
+            }
+        const float inv = 1.f / a[col][col];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) a[col][c] *= inv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r != col) {
+                const float f = a[r][col];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) a[r][c] -= f * a[col][c];
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) out[i * 16 + r * 4 + c] = a[r][4 + c];
+}
+
+extern "C" int pcacc_inv4x4(const float *m, int64_t n, float *out, void *stream)
+{
+    if (n < 0) return PCACC_E_ARG;
+    if (n == 0) return PCACC_OK;
+    if (!m || !out) return PCACC_E_ARG;
+    inv4x4_kernel<<<(unsigned)((n + 63) / 64), 64, 0, pcacc_stream(stream)>>>(m, n, out);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}

@@ -223,7 +223,7 @@ class MotionNet(nn.Module):
             bev_feats = bev_feats.detach()
             C = bev_feats.size(1)
             bev_cl = bev_feats.permute(0, 2, 3, 1).contiguous().view(B, T, Ny, Nx, C)
-            warped = ops.bev_warp(bev_cl, torch.linalg.inv_ex(pose_est)[0], self.resolution[0], self.resolution[1],
+            warped = ops.bev_warp(bev_cl, native.inv4x4(pose_est), self.resolution[0], self.resolution[1],
                                   self.pc_range[0], self.pc_range[1])
             warped_feats = warped.permute(0, 4, 1, 2, 3)                           # [B,C,T,H,W], channels_last_3d memory
             transformed_points = ops.rigid_transform(input_points, frame_idx, pose_est)

@@ -60,7 +60,7 @@ EXPORTS = [
     'pcacc_tube_rows', 'pcacc_tube_code', 'pcacc_tube_code_backward', 'pcacc_tube_pose_forward', 'pcacc_tube_gap_forward', 'pcacc_tube_finish',
     'pcacc_tube_gap_backward', 'pcacc_tube_pose_backward', 'pcacc_rows_wgrad_few_supported', 'pcacc_rows_wgrad_few_workspace_bytes', 'pcacc_rows_wgrad_few',
     'pcacc_maxpool2x2_bf16', 'pcacc_pool_skip_relu_backward_bf16',
-    'pcacc_pfn_block_forward', 'pcacc_pfn_block_backward_workspace_bytes', 'pcacc_pfn_block_backward',
+    'pcacc_pfn_block_forward', 'pcacc_pfn_block_backward_workspace_bytes', 'pcacc_pfn_block_backward', 'pcacc_inv4x4',
 ]
 
 
@@ -996,3 +996,11 @@ def pfn_block_backward(xa, pooled, p2v, hr, grad_out, w0, ws, w1):
                                           _dev(gxa), _opt(gxb, torch.bfloat16, 'grad_xb'), _dev(gp), _i64(rows), _dev(ws_buf),
                                           ctypes.c_size_t(ws_buf.numel()), _stream()), 'pfn_block_backward')
     return gxa, gxb, gp
+
+
+def inv4x4(m):
+    """[..., 4, 4] f32 -> inverses, one launch (include/pcacc.h: pcacc_inv4x4)."""
+    x = m.contiguous().float()
+    out = torch.empty_like(x)
+    _check(lib().pcacc_inv4x4(_dev(x, torch.float32, 'm'), _i64(x.numel() // 16), _dev(out), _stream()), 'inv4x4')
+    return out

@@ -175,3 +175,37 @@ def test_tube_restatement_matches_reference_formulation():
     assert np.allclose(l12.numpy(), [float(l1), float(l2)], rtol=1e-5)
     assert np.allclose(loss_rt.numpy(), [float(rot), float(trans)], rtol=1e-12)
     assert torch.allclose(torch.matmul(rem_out, step), c['rem'], atol=1e-5) and torch.allclose(total_out, torch.matmul(step, c['total']))
+
+
+@pytest.mark.gpu
+def test_inv4x4_and_update_gt_inst_motion():
+    """pcacc_inv4x4 against torch.linalg.inv on rigid and on general (pivoting) matrices; update_gt_inst_motion evaluated for all
+    samples at once against the reference's per-sample loop (models/alignnet.py:9-38)."""
+    from pcaccumulation_amd import native
+    from pcaccumulation_amd.alignnet import update_gt_inst_motion
+    rng = np.random.RandomState(0)
+    rigid = np.tile(np.eye(4, dtype=np.float32), (40, 1, 1))
+    rigid[:, :3, :3] = _rotations(rng, 40)
+    rigid[:, :3, 3] = rng.randn(40, 3) * 5
+    general = rng.randn(25, 4, 4).astype(np.float32)
+    general[::5, 0, 0] = 0.0                                  # forces a row exchange
+    for m in (rigid, general):
+        t = torch.from_numpy(m).cuda()
+        got = native.inv4x4(t)
+        want = torch.linalg.inv(t.double())
+        # accuracy of an fp32 inverse scales with the matrix's condition number (one of the random matrices has inverse entries
+        # of 3e3): the yardstick is the fp32 library inverse this call replaces, both measured against float64, matrix by matrix
+        err = (got.double() - want).abs().amax(dim=(1, 2))
+        err_lib = (torch.linalg.inv(t).double() - want).abs().amax(dim=(1, 2))
+        scale = want.abs().amax(dim=(1, 2))
+        assert bool((err <= 4 * err_lib + 1e-6 * scale).all()), (err / scale).max().item()
+    assert float((native.inv4x4(torch.from_numpy(rigid).cuda()).double() - torch.linalg.inv(torch.from_numpy(rigid).cuda().double())).abs().max()) <= 2e-5
+    B, T = 3, 5
+    ego_gt = torch.from_numpy(rigid[:B * T].reshape(B, T, 4, 4)).cuda()
+    ego_est = torch.from_numpy(rigid[B * T:2 * B * T].reshape(B, T, 4, 4)).cuda()
+    motions = [torch.from_numpy(np.tile(rigid[30 + b][None, None], (k, T, 1, 1)) * 1.0) for b, k in enumerate((4, 0, 7))]
+    got = update_gt_inst_motion(motions, ego_gt, ego_est)
+    assert [g.shape[0] for g in got] == [4, 0, 7]
+    for b, m in enumerate(motions):
+        want = m.cuda().float().view(-1, T, 4, 4) @ ego_gt[b][None] @ torch.linalg.inv(ego_est[b])[None]
+        assert got[b].shape == want.shape and torch.allclose(got[b], want, rtol=1e-5, atol=1e-4)
