@@ -334,7 +334,7 @@ class DataParallelStep(object):
     def skipped(self):
         return self.skipped_steps()
 
-    def __call__(self, inp, after_forward=None):
+    def __call__(self, inp, after_forward=None, after_backward=None):
         """One micro-step on `inp`.  Returns the loss stats (None when this rank's forward failed)."""
         r = self.reducer
         if self.micro == 0:
@@ -384,6 +384,8 @@ class DataParallelStep(object):
             self.ok, self.last_error = False, e
             if last:
                 r.flush()                                     # the other ranks are waiting in these collectives
+        if after_backward is not None:                        # every launch of this micro-step's forward and backward is issued;
+            after_backward()                                  # outside the try: a data-pipeline error is not a skipped model step
         self.micro += 1
         if last:
             self.micro = 0

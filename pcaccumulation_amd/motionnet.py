@@ -31,7 +31,7 @@ MIN_POINTS = 15                          # models/motionnet.py:11
 
 
 def share_with_stream(stream, *objs):
-    """Tensor.record_stream(stream) for every CUDA tensor in `objs` (dicts, lists and tuples are walked)."""
+    """Tensor.record_stream(stream) for every CUDA tensor in `objs` (dicts, lists, tuples and PreparedInputs are walked)."""
     for o in objs:
         if torch.is_tensor(o):
             if o.is_cuda:
@@ -40,6 +40,31 @@ def share_with_stream(stream, *objs):
             share_with_stream(stream, *[dict.__getitem__(o, k) for k in o])
         elif isinstance(o, (list, tuple)):
             share_with_stream(stream, *o)
+        elif isinstance(o, PreparedInputs):
+            share_with_stream(stream, *o.tensors())
+
+
+class PreparedInputs(object):
+    """What MotionNet.forward derives from the batch alone (no weights involved): the pillar index with its CSR, the per-point
+    frame / sample indices, per-pillar means and labels, the occupancy and label maps and the pillar encoder's 9 point features.
+    A data pipeline can build it while the previous step is still on the GPU (MotionNet.prepare_inputs; bench.py does, on the
+    stream that voxelises the next batch) and hand it over as input_dict['_prepared']."""
+
+    FIELDS = ('pidx', 'batch_idx', 'frame_idx', 'pillar_mean', 'fb_labels_sub', 'occ_map', 'fb_seg_gt', 'features')
+
+    def __init__(self, **kw):
+        for k in self.FIELDS:
+            setattr(self, k, kw[k])
+
+    def tensors(self):
+        out = [getattr(self, k) for k in self.FIELDS[1:]]
+        out += [v for v in vars(self.pidx).values() if torch.is_tensor(v)]
+        out += [t for v in vars(self.pidx).values() if isinstance(v, (tuple, list)) for t in v if torch.is_tensor(t)]
+        return [t for t in out if torch.is_tensor(t)]
+
+    def matches(self, input_dict):
+        return (self.pidx.m == input_dict['coordinates'].shape[0] and self.pidx.n == input_dict['input_points'].shape[0]
+                and self.features.device == input_dict['input_points'].device)
 
 
 def grid_shape(cfg):
@@ -108,6 +133,27 @@ class MotionNet(nn.Module):
         return ops.rigid_transform(points, frame_idx, transformation)
 
     # ------------------------------------------------------------------------------------------------
+    def prepare_inputs(self, input_dict):
+        """The weight-independent head of forward(): see PreparedInputs.  (models/motionnet.py:150-166 and the feature build of
+        models/pillar_encoder.py:98-110.)"""
+        input_points = input_dict['input_points'].float()
+        time_indice = input_dict['time_indice']
+        fb_labels = input_dict['fb_labels']
+        coordinates = input_dict['coordinates']
+        B = input_dict['num_voxels'].size(0)
+        nx, ny, nz, nt = self.grid
+        device = coordinates.device
+        pidx = PillarIndex(coordinates, input_dict['point_to_voxel_map'], B, self.grid, cell_order=self.cell_ordered_pillars)
+        assert pidx.n == input_points.size(0)
+        batch_idx = time_indice[:, 0].to(torch.int32).contiguous()
+        frame_idx = (time_indice[:, 0] * nt + time_indice[:, 1]).to(torch.int32).contiguous()
+        pillar_mean, fb_labels_sub = ops.segment_mean3_maxlabel(input_points, fb_labels, pidx)   # motionnet.py:159-160
+        occ = ops.pillar_scatter(torch.ones((pidx.m, 1), device=device), pidx)
+        fb_map = ops.pillar_scatter(fb_labels_sub.float().unsqueeze(1), pidx)
+        features = self.pillar_encoder.point_features(input_points, pidx, pidx.coordinates, pillar_mean, time_indice)
+        return PreparedInputs(pidx=pidx, batch_idx=batch_idx, frame_idx=frame_idx, pillar_mean=pillar_mean, fb_labels_sub=fb_labels_sub,
+                              occ_map=occ.view(B, nt, 1, ny, nx), fb_seg_gt=fb_map.view(B, nt, 1, ny, nx).to(fb_labels.dtype), features=features)
+
     def forward(self, input_dict):
         input_points = input_dict['input_points'].float()                    # [N,3]
         time_indice = input_dict['time_indice']                                # [N,2] f64 (b,t)
@@ -123,21 +169,18 @@ class MotionNet(nn.Module):
         ops.set_point_dtype(self.compute_dtype if device.type == 'cuda' else torch.float32)
         results = LazyDict()
 
-        # 0. index structures shared by every irregular op of this forward
-        pidx = PillarIndex(coordinates, input_dict['point_to_voxel_map'], B, self.grid, cell_order=self.cell_ordered_pillars)
+        # 0. index structures shared by every irregular op of this forward, and everything else that follows from the batch alone
+        prep = input_dict.get('_prepared')
+        if prep is None or not prep.matches(input_dict):
+            prep = self.prepare_inputs(input_dict)
+        pidx, batch_idx, frame_idx = prep.pidx, prep.batch_idx, prep.frame_idx
         coordinates = pidx.coordinates                                         # rows in the numbering pidx uses from here on
-        assert pidx.n == input_points.size(0)
-        batch_idx = time_indice[:, 0].to(torch.int32).contiguous()
-        frame_idx = (time_indice[:, 0] * T + time_indice[:, 1]).to(torch.int32).contiguous()
-
-        pillar_mean, fb_labels_sub = ops.segment_mean3_maxlabel(input_points, fb_labels, pidx)   # motionnet.py:159-160
-        occ = ops.pillar_scatter(torch.ones((pidx.m, 1), device=device), pidx)
-        fb_map = ops.pillar_scatter(fb_labels_sub.float().unsqueeze(1), pidx)
-        results['fb_seg_gt'] = fb_map.view(B, T, 1, Ny, Nx).to(fb_labels.dtype)
-        results['occ_map'] = occ.view(B, T, 1, Ny, Nx)
+        pillar_mean = prep.pillar_mean
+        results['fb_seg_gt'], results['occ_map'] = prep.fb_seg_gt, prep.occ_map
 
         # 1. pillar encoder -> BEV canvas (channels-last, one streaming pass)
-        input_features = self.pillar_encoder(input_points, None, coordinates, pillar_mean, time_indice, pidx=pidx, keep_dtype=True)
+        input_features = self.pillar_encoder(input_points, None, coordinates, pillar_mean, time_indice, pidx=pidx, keep_dtype=True,
+                                             features=prep.features)
         canvas = ops.pillar_scatter(input_features, pidx, self.compute_dtype)
         bev = ops.canvas_as_nchw(canvas, pidx)                                 # [B*T, C, Ny, Nx]
 

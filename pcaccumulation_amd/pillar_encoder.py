@@ -82,12 +82,14 @@ class PillarFeatureNet(nn.Module):
                                    float(self.vy), float(self.x_offset), float(self.y_offset), float(self.scale),
                                    float(self.n_frames))
 
-    def forward(self, raw_points, point_to_voxel_map, coordinates, pillar_mean, time_indice, pidx=None, keep_dtype=False):
+    def forward(self, raw_points, point_to_voxel_map, coordinates, pillar_mean, time_indice, pidx=None, keep_dtype=False, features=None):
         """keep_dtype: return the pooled rows in the element type of the point rows (bf16 in the bf16 compute mode; MotionNet feeds
-        them to the canvas fill as they are) instead of the reference's float32."""
+        them to the canvas fill as they are) instead of the reference's float32.  features: the 9 inputs per point when the caller
+        built them ahead of time (point_features depends on the batch only, MotionNet.prepare_inputs)."""
         if pidx is None:                                                  # reference call signature
             pidx = PillarIndex.from_point_map(point_to_voxel_map, coordinates.shape[0])
-        features = self.point_features(raw_points, pidx, coordinates, pillar_mean, time_indice)
+        if features is None:
+            features = self.point_features(raw_points, pidx, coordinates, pillar_mean, time_indice)
         pd = ops.point_dtype() if features.is_cuda else features.dtype     # bf16 rows in the bf16 compute mode (GPU only)
         net = ops.linear_rows(features, self.fc_pos, out_dtype=pd)
         net = self.blocks[0](net)

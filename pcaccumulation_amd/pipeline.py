@@ -20,7 +20,7 @@ def sample_to_device(sample, device):
 
 class _Pending(object):
     """A batch whose voxelisation has been launched: everything that does not depend on the voxel counts is already queued."""
-    __slots__ = ('samples', 'launched', 'static', 'tis', 'counts', 'event', 'stream', 'device')
+    __slots__ = ('samples', 'launched', 'static', 'tis', 'counts', 'event', 'stream', 'device', 'ready', 'result')
 
 
 class DeviceBatcher(object):
@@ -51,7 +51,7 @@ class DeviceBatcher(object):
     def start(self, samples, side_stream=False):
         p = _Pending()
         p.samples, p.device = samples, samples[0]['input_points'].device
-        p.stream = p.event = None
+        p.stream = p.event = p.ready = p.result = None
         if side_stream and p.device.type == 'cuda':
             if self._side is None:
                 self._side = torch.cuda.Stream(device=p.device)
@@ -69,17 +69,9 @@ class DeviceBatcher(object):
             p.counts = self._launch(p)
         return p
 
-    def finish(self, p):
+    def _collate(self, p, counts):
+        """The batch dict of the reference's collate_fn from the launched voxelisations and their pillar counts."""
         vox, samples, dev = self.voxeliser, p.samples, p.device
-        if p.event is not None:
-            p.event.synchronize()                                        # long past when the batch was started a step ago
-            main = torch.cuda.current_stream(dev)
-            main.wait_event(p.event)
-            for t in [x for l in p.launched for x in l[:2]] + list(p.static.values()):
-                t.record_stream(main)                                    # allocated on the side stream, consumed on this one
-            counts = p.counts.tolist()
-        else:
-            counts = p.counts.cpu().tolist()
         coords, p2vs, n_vox = [], [], []
         offset = 0
         for b, s in enumerate(samples):
@@ -98,6 +90,41 @@ class DeviceBatcher(object):
             'shape': native.upload_small(grid[None].repeat(len(samples), 1), torch.int64, dev), 'point_to_voxel_map': torch.cat(p2vs, 0),
         })
         return out
+
+    def finish_early(self, p, prepare=None):
+        """Collate the pending batch -- and run `prepare(batch)` (MotionNet.prepare_inputs: pillar index, CSR, per-pillar means,
+        point features -- everything the forward derives from the batch alone) -- on the side stream the voxelisation ran on, while
+        the current step is still on the GPU.  Call it once the host has issued the step's launches (the pillar counts have long
+        arrived by then); finish() then only joins the streams."""
+        if p.event is None or p.result is not None:
+            return
+        p.event.synchronize()
+        with torch.cuda.stream(p.stream):
+            out = self._collate(p, p.counts.tolist())
+            if prepare is not None:
+                out['_prepared'] = prepare(out)
+            p.ready = torch.cuda.Event()
+            p.ready.record(p.stream)
+        p.result = out
+
+    def finish(self, p):
+        dev = p.device
+        if p.result is not None:                                         # collated (and prepared) ahead of time on the side stream
+            from .motionnet import share_with_stream
+            main = torch.cuda.current_stream(dev)
+            main.wait_event(p.ready)
+            share_with_stream(main, p.result, [x for l in p.launched for x in l[:2]])     # allocated there, consumed here
+            return p.result
+        if p.event is not None:
+            p.event.synchronize()                                        # long past when the batch was started a step ago
+            main = torch.cuda.current_stream(dev)
+            main.wait_event(p.event)
+            for t in [x for l in p.launched for x in l[:2]] + list(p.static.values()):
+                t.record_stream(main)                                    # allocated on the side stream, consumed on this one
+            counts = p.counts.tolist()
+        else:
+            counts = p.counts.cpu().tolist()
+        return self._collate(p, counts)
 
     def __call__(self, samples):
         return self.finish(self.start(samples))
