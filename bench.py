@@ -176,6 +176,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fp32-leg', action='store_true', help='skip the fp32 (matched-accuracy) timing of the same step that follows the bf16 run at N = 1')
     ap.add_argument('--no-miopen-find', action='store_true', help='library convolutions through the immediate-mode heuristic instead of the find-db')
+    ap.add_argument('--pipeline', action='store_true', help='force the staged step (default: staged with a second stream at N = 1, one backward at N > 1)')
     ap.add_argument('--no-pipeline', action='store_true', help='one backward at the end of the forward instead of the early backward of the ego / fb / perm terms (DataParallelStep.pipelined)')
     ap.add_argument('--one-stream', action='store_true', help='motion heads and TubeNet on the main stream behind the early backward instead of beside it on a second stream')
     ap.add_argument('--prepare-ahead', action='store_true', help='build the pillar index / CSR / point features of the next batch on the prefetch stream during the current step (MotionNet.prepare_inputs) instead of inside its own forward; measured neutral: 29.16 vs 29.22 ms over 8 interleaved runs each, sd 0.5')
@@ -213,7 +214,7 @@ def main():
     def batch_of(i):
         return [scenes[(i * args.batch + j) % n_scenes] for j in range(args.batch)]
     stepper = pdist.DataParallelStep(model, opt, loss_fn, iter_size=args.iter_size, grad_clip=cfg['train']['grad_clip'],
-                                     pipelined=not args.no_pipeline, two_streams=not args.one_stream)
+                                     pipelined=False if args.no_pipeline else (True if args.pipeline else None), two_streams=not args.one_stream)
 
     torch.manual_seed(1234 + rank)
     feed = BatchFeed(batcher, batch_of, not args.no_prefetch, prepare=model.prepare_inputs if args.prepare_ahead else None)
@@ -244,7 +245,7 @@ def main():
         cfg32['misc']['compute_dtype'] = 'fp32'
         m32, o32, l32 = build(cfg32, device)
         st32 = pdist.DataParallelStep(m32, o32, l32, iter_size=args.iter_size, grad_clip=cfg['train']['grad_clip'],
-                                      pipelined=not args.no_pipeline, two_streams=not args.one_stream)
+                                      pipelined=False if args.no_pipeline else (True if args.pipeline else None), two_streams=not args.one_stream)
         feed32 = BatchFeed(batcher, batch_of, not args.no_prefetch, prepare=m32.prepare_inputs if args.prepare_ahead else None)
         k32 = max(2, min(args.steps, 5))
         for i in range(2):

@@ -311,7 +311,10 @@ class DataParallelStep(object):
         # the ego head has run, before the motion heads and the TubeNet are even issued (MotionNet.after_ego, FuseLoss.early_terms);
         # default: whenever model and loss offer the two hooks
         can = hasattr(model, 'after_ego') and hasattr(loss_fn, 'early_terms')
-        self.pipelined = can if pipelined is None else (bool(pipelined) and can)
+        # default: staged only where it can use the second stream (one process, see below).  On ONE stream the staged step no longer
+        # pays: 30.4 ms against 30.0 ms unstaged at N = 1 (4 interleaved runs each, sd 0.3), 92 ms against 76 ms with two gloo ranks on
+        # one GPU -- it won 1.9 ms only while ~800 tiny launches behind the forward's host sync left the GPU idle.
+        self.pipelined = (can and world_size() == 1) if pipelined is None else (bool(pipelined) and can)
         # two_streams: the rest of the forward, its loss terms and their backward run on a side stream while the early backward
         # occupies the main one (MotionNet.side_stream); joined before the clip / optimizer block
         self._two_streams = bool(two_streams)
@@ -320,7 +323,13 @@ class DataParallelStep(object):
         if self.pipelined and hasattr(model, 'early_parameters'):
             self.reducer.set_early(model.early_parameters())
         dev = self.reducer.params[0].device
-        self.side = torch.cuda.Stream(device=dev) if (self.pipelined and self._two_streams and dev.type == 'cuda' and hasattr(model, 'side_stream')) else None
+        # Second stream only without a process group.  With N > 1 the collectives draw further streams from the pool, HIP folds all of
+        # them onto a few hardware queues, and together with a data pipeline that host-waits on its own prefetch stream the step
+        # collapsed: two gloo ranks sharing one MI355X took 1.4-2.9 s per step (75 ms with the prefetch off, 94 ms with one stream;
+        # 70 ms / 418 ms with GPU_MAX_HW_QUEUES = 2 / 16 -- the dependence on the queue count is measured, the exact mechanism is not,
+        # and RCCL could not be tried with two ranks on one GPU).  One stream is the safe choice there.
+        self.side = torch.cuda.Stream(device=dev) if (self.pipelined and self._two_streams and dev.type == 'cuda' and world_size() == 1
+                                                      and hasattr(model, 'side_stream')) else None
         self.micro = 0
         self.ok = True
         self.last_error = None

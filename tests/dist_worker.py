@@ -138,7 +138,7 @@ def motionnet(rank, world, out):
     cfg = default_config('waymo', 'train', n_sweeps=3, xy_range=8)
     model = motionnet_model(cfg)
     opt = torch.optim.SGD(model.parameters(), lr=0.0)                         # the step runs, the weights stay: gradients are the output
-    step = pdist.DataParallelStep(model, opt, FuseLoss(cfg['loss']), iter_size=1, grad_clip=None, catch=False)
+    step = pdist.DataParallelStep(model, opt, FuseLoss(cfg['loss']), iter_size=1, grad_clip=None, catch=False, pipelined=True)   # staged: still supported with N > 1
     torch.manual_seed(100 + rank)
     stats = step(motionnet_batch(cfg, rank))
     grads = {k: p.grad.clone() for k, p in model.named_parameters()}
