@@ -283,7 +283,8 @@ __device__ __forceinline__ void conv_pass_mfma(f32x16_t (&acc)[R][CT], const uin
 // workgroup has (8/R) * (CT/CTW) waves: when LDS leaves room for one workgroup per CU only, 8 waves instead of 4 let one
 // wave's epilogue / staging run under another's MFMAs.
 template <int CT, int CS, int R, int CTW>
-__global__ __launch_bounds__(64 * (8 / R) * (CT / CTW)) void conv3x3_resident_kernel(
+__global__ __launch_bounds__(64 * (8 / R) * (CT / CTW)) __attribute__((amdgpu_waves_per_eu((CT == 1 && CS == 32 && R == 2) ? 3 : 1, (CT == 1 && CS == 32 && R == 2) ? 3 : 8)))
+void conv3x3_resident_kernel(
     const uint16_t *__restrict__ in, const uint16_t *__restrict__ wp, const float *__restrict__ bias, uint16_t *__restrict__ out,
     int n_img, int frames, int h, int w, int c_out, int kt, int relu, int tiles_x, int tiles_y, int co_groups)
 {
