@@ -64,6 +64,7 @@ def toy(rank, world, out):
                 raise RuntimeError('injected')
             return net(inp['x'], True)
     step = pdist.DataParallelStep(Boom(), opt, lambda o, i: {'loss': o}, iter_size=1, grad_clip=1.0, reducer=red)
+    res['plain_by_default'] = (not step.pipelined) and step.side is None          # N > 1: one stream, one backward unless asked
     before = net.a.weight.detach().clone()
     step({'x': toy_input(rank, 0), 'fail': rank == 1})
     res['skipped'] = step.skipped

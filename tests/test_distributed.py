@@ -62,7 +62,7 @@ def test_gradient_reduction_two_gloo_ranks(tmp_path):
         # a parameter no rank produced a gradient for is None for the optimizer (single-process semantics), a view again afterwards
         assert g['none_inside'] == ['c.weight', 'c.bias'] and g['none_after'] == [] and g['ok2'] is True
         # rank 1 raised in its forward: nobody hangs, nobody steps; the next (healthy) step is taken by both
-        assert g['skipped'] == 1 and g['unchanged'] and g['stepped']
+        assert g['skipped'] == 1 and g['unchanged'] and g['stepped'] and g['plain_by_default']
     assert torch.equal(got[0]['a_after'], got[1]['a_after'])
     # two-pass micro-step: `d`'s bucket(s) lead the sequence and are out after the first backward, nothing else is
     def two_pass_reference():
