@@ -30,7 +30,17 @@ FP32_TOL = dict(ego=1e-3, iou=1e-3, epe=1e-3)
 #     rotation 0.03-0.26 deg, translation 0.006-0.012 m, EPE 0.004-0.013 m; set level: rotation 0.03 deg, translation 1e-3 m, EPE
 #     2e-3 m, mos_iou 1e-4-1e-3; foreground flips 0.02-0.3 %.  A flipped pillar changes a frame's background count and with it the key-point draw (torch.randperm(n)), so one
 #     scene's pose can move by a tenth of a degree while the set mean moves by hundredths.
-BF16_TRAINED_TOL = dict(ego=0.1, ego_scene=0.5, iou=4e-3, epe=3e-2, flips=6e-3)
+#     Over 8 repeats of the test (every repeat trains a slightly different model; tools/gpu_trained_spread.sh) with EIGHT held-out scenes the
+#     worst single scene's rotation difference was heavy-tailed (0.006 ... 0.22, 0.25 deg) and the test failed about once in a dozen
+#     full-suite runs: a maximum over scenes is the statistic of the one scene whose key-point draw changed.  Hence 32 scenes, the
+#     set means a validation run would report, the MEDIAN over scenes for the tight per-scene claim, and the maximum only as a
+#     no-blow-up bound (the bound of check (2) below).
+#     Measured over 10 repeats with 32 scenes (tools/gpu_trained_spread.sh, worst of the ten): set level rotation 0.020 deg, translation
+#     0.0033 m, EPE 0.0027 m, mos_iou 0.0013; median scene rotation 0.005 ... 0.108 deg (it depends on which model the training
+#     produced), translation 0.013 m, EPE 0.0072 m, flipped decisions 0.33 %; worst scene rotation 0.38 deg, translation 0.036 m, EPE
+#     0.023 m, flips 0.58 %.  Every bound below leaves at least a factor 2 over those.
+BF16_TRAINED_TOL = dict(ego=0.1, rot_median=0.25, trans_median=0.05, ego_worst=1.5, iou=4e-3, epe=3e-2, epe_median=2e-2,
+                        flips_median=8e-3, flips_worst=2e-2)
 # (2) Against the reference's fp32 golden vectors on closed-form (random) weights: bf16 rounding flips 0.1-0.3 % of the foreground
 #     decisions, the background pillar count of a frame changes, torch.randperm(n) (models/egomotion.py:157) draws a different
 #     key-point set and the noise-driven pose of a random-weight model moves by tenths of a degree / up to a metre.  These
@@ -217,7 +227,7 @@ def test_gpu_bf16_against_fp32_on_trained_weights():
     model16.eval()
     loss_fn = FuseLoss(cfg['loss'])
     rows = {'fp32': [], 'bf16': []}
-    for seed in range(5000, 5008):
+    for seed in range(5000, 5032):
         inp = make_batch(cfg, [seed], 3, 1500)
         inp = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}
         for tag, m in (('fp32', model), ('bf16', model16)):
@@ -229,19 +239,24 @@ def test_gpu_bf16_against_fp32_on_trained_weights():
             got['fb_est'] = out['fb_est_per_points'].clone()
             got['mos_i'], got['mos_u'] = stats['mos_metric']['intersection'], stats['mos_metric']['union']
             rows[tag].append(got)
-    d = lambda k: max(abs(a[k] - b[k]) for a, b in zip(rows['fp32'], rows['bf16']))
+    per_scene = lambda k: np.array([abs(a[k] - b[k]) for a, b in zip(rows['fp32'], rows['bf16'])])
     ds = lambda k: abs(float(np.mean([a[k] for a in rows['fp32']])) - float(np.mean([b[k] for b in rows['bf16']])))   # as a validation set reports it
-    flips = max(float((a['fb_est'] != b['fb_est']).float().mean()) for a, b in zip(rows['fp32'], rows['bf16']))
+    flips = np.array([float((a['fb_est'] != b['fb_est']).float().mean()) for a, b in zip(rows['fp32'], rows['bf16'])])
     # mos_iou as the reference aggregates it over a validation set (toolbox/metrics.py:43-60): counters summed over the scenes
     agg = {t: float((sum(r['mos_i'] for r in rows[t]) / (sum(r['mos_u'] for r in rows[t]) + 1e-20)).mean()) for t in rows}
-    res = dict(rot=d('ego_rot_error'), trans=d('ego_trans_error'), mos_iou_scene=d('mos_iou'), epe=d('epe_mean'), fb_flips=flips,
+    rot, trans, epe = per_scene('ego_rot_error'), per_scene('ego_trans_error'), per_scene('epe_mean')
+    res = dict(rot=float(rot.max()), trans=float(trans.max()), mos_iou_scene=float(per_scene('mos_iou').max()), epe=float(epe.max()),
+               fb_flips=float(flips.max()), rot_median=float(np.median(rot)), trans_median=float(np.median(trans)),
+               epe_median=float(np.median(epe)), flips_median=float(np.median(flips)),
                rot_set=ds('ego_rot_error'), trans_set=ds('ego_trans_error'), epe_set=ds('epe_mean'),
                mos_iou_set=abs(agg['fp32'] - agg['bf16']), fp32_rot=float(np.mean([r['ego_rot_error'] for r in rows['fp32']])),
-               fp32_epe=float(np.mean([r['epe_mean'] for r in rows['fp32']])), fp32_mos_iou=agg['fp32'])
+               fp32_epe=float(np.mean([r['epe_mean'] for r in rows['fp32']])), fp32_mos_iou=agg['fp32'], n_scenes=len(rot))
     _dump('trained_tiny', 'bf16-vs-fp32', res, {}, {})
     tol = BF16_TRAINED_TOL
     assert res['rot_set'] < tol['ego'] and res['trans_set'] < tol['ego'], res          # validation-set means (what the reference logs)
     assert res['mos_iou_set'] < tol['iou'], res
     assert res['epe_set'] < tol['epe'], res
-    assert res['rot'] < tol['ego_scene'] and res['trans'] < tol['ego_scene'] and res['epe'] < tol['ego_scene'], res   # worst single scene
-    assert flips < tol['flips'], res
+    assert res['rot_median'] < tol['rot_median'] and res['trans_median'] < tol['trans_median'] and res['epe_median'] < tol['epe_median'], res
+    assert res['flips_median'] < tol['flips_median'], res
+    assert res['rot'] < tol['ego_worst'] and res['trans'] < tol['ego_worst'] and res['epe'] < tol['ego_worst'], res   # no scene blows up
+    assert res['fb_flips'] < tol['flips_worst'], res
