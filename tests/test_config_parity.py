@@ -35,12 +35,13 @@ FP32_TOL = dict(ego=1e-3, iou=1e-3, epe=1e-3)
 #     full-suite runs: a maximum over scenes is the statistic of the one scene whose key-point draw changed.  Hence 32 scenes, the
 #     set means a validation run would report, the MEDIAN over scenes for the tight per-scene claim, and the maximum only as a
 #     no-blow-up bound (the bound of check (2) below).
-#     Measured over 10 repeats with 32 scenes (tools/gpu_trained_spread.sh, worst of the ten): set level rotation 0.020 deg, translation
-#     0.0033 m, EPE 0.0027 m, mos_iou 0.0013; median scene rotation 0.005 ... 0.108 deg (it depends on which model the training
-#     produced), translation 0.013 m, EPE 0.0072 m, flipped decisions 0.33 %; worst scene rotation 0.38 deg, translation 0.036 m, EPE
-#     0.023 m, flips 0.58 %.  Every bound below leaves at least a factor 2 over those.
-BF16_TRAINED_TOL = dict(ego=0.1, rot_median=0.25, trans_median=0.05, ego_worst=1.5, iou=4e-3, epe=3e-2, epe_median=2e-2,
-                        flips_median=8e-3, flips_worst=2e-2)
+#     Measured over 22 repeats with 32 scenes (tools/gpu_trained_spread.sh; worst of the 22): set level rotation 0.032 deg, translation
+#     0.0033 m, EPE 0.0032 m, mos_iou 0.0030; median scene rotation 0.005 ... 0.142 deg (it depends on which model the training
+#     produced), translation 0.013 m, EPE 0.011 m, flipped decisions 0.33 %; worst scene rotation 0.82 deg, translation 0.045 m, EPE
+#     0.039 m, flips 0.58 %.  The tail over trained instances is heavy: bounds first taken at 2x the worst of ten repeats were
+#     approached to within 1.3x by the next twelve (mos_iou 0.0013 -> 0.0030), so they sit at about 3x the worst of all 22.
+BF16_TRAINED_TOL = dict(ego=0.1, rot_median=0.4, trans_median=0.05, ego_worst=2.5, iou=1e-2, epe=3e-2, epe_median=3e-2,
+                        flips_median=1e-2, flips_worst=2e-2)
 # (2) Against the reference's fp32 golden vectors on closed-form (random) weights: bf16 rounding flips 0.1-0.3 % of the foreground
 #     decisions, the background pillar count of a frame changes, torch.randperm(n) (models/egomotion.py:157) draws a different
 #     key-point set and the noise-driven pose of a random-weight model moves by tenths of a degree / up to a metre.  These
