@@ -384,7 +384,10 @@ class DataParallelStep(object):
                 stats = self.loss_fn(out, inp, early=early[0]) if early else self.loss_fn(out, inp)
                 loss = stats['loss'] / self.iter_size if self.iter_size > 1 else stats['loss']
                 r.prepare(loss, part='rest')
-                loss.backward()
+                # after an early backward the rest of the loss may be constants only (motion heads and TubeNet both skipped on a batch
+                # with 0 < n_fb <= MIN_POINTS): the early gradients are the step's gradients then, as in the unstaged path
+                if loss.requires_grad or not early:
+                    loss.backward()
             if two:
                 torch.cuda.current_stream().wait_stream(self.side)     # join: clip / optimizer read the gradients of both halves
         except Exception as e:                                # noqa: BLE001 -- libs/trainer.py:234-235

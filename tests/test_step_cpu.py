@@ -1,0 +1,39 @@
+"""distributed.DataParallelStep on the oracle-backed CPU backend (test infrastructure): the staged step on a batch whose motion heads
+and TubeNet are both skipped (0 < n_fb <= MIN_POINTS) -- the second-pass loss is then constants only and has no graph; the early
+gradients (ego / fb / perm terms) are the step's gradients and the optimizer step must still be taken, as the unstaged path and the
+reference (libs/trainer.py:176-179) do.  ADVICE round 2."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+import dist_worker  # noqa: E402
+from oracle import cpu_backend  # noqa: E402
+from pcaccumulation_amd import distributed as pdist  # noqa: E402
+from pcaccumulation_amd import motionnet as mn  # noqa: E402
+from pcaccumulation_amd.config import default_config  # noqa: E402
+from pcaccumulation_amd.loss import FuseLoss  # noqa: E402
+
+
+def test_pipelined_step_with_few_foreground_points_still_steps(monkeypatch):
+    cpu_backend.install(monkeypatch)
+    if True:
+        cfg = default_config('waymo', 'train', n_sweeps=3, xy_range=8)
+        inp = dist_worker.motionnet_batch(cfg, 0)
+        monkeypatch.setattr(mn, 'MIN_POINTS', 10 ** 9)                  # every foreground count is "few": STPN heads and TubeNet skipped
+        got = {}
+        for pipelined in (False, True):
+            model = dist_worker.motionnet_model(cfg)
+            opt = torch.optim.SGD(model.parameters(), lr=0.0)
+            step = pdist.DataParallelStep(model, opt, FuseLoss(cfg['loss']), iter_size=1, grad_clip=None, catch=False, pipelined=pipelined)
+            assert step.pipelined == pipelined
+            torch.manual_seed(100)
+            stats = step(inp)
+            assert step.ok and step.skipped == 0, step.last_error
+            got[pipelined] = (float(stats['loss']), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+        assert got[True][1].keys() == got[False][1].keys() and len(got[True][1]) > 0
+        assert abs(got[True][0] - got[False][0]) <= 1e-5 * abs(got[False][0])
+        for k, g in got[False][1].items():
+            assert torch.allclose(got[True][1][k], g, rtol=1e-4, atol=1e-6 * float(g.abs().max()) + 1e-12), k
