@@ -1,0 +1,702 @@
+// 3x3 (and 3x3x3 over frames) convolution at fp32 accuracy on the bf16 matrix cores ("fp32x3" compute mode): fp32 channels-last in
+// and out, every product formed from bf16 hi / lo halves,
+//
+//     x = x_hi + x_lo (+ 2^-18 |x|),  w = w_hi + w_lo:   w x  ~=  w_hi x_lo + w_lo x_hi + w_hi x_hi      (w_lo x_lo <= 2^-18 |w x| dropped)
+//
+// three v_mfma_f32_32x32x16_bf16 per fragment pair, fp32 accumulation: relative error ~4e-6 per product against 4e-3 for plain
+// bf16 operands, at a third of the bf16 rate = 5x the fp32 MFMA rate (v_mfma_f32_32x32x2_f32 runs at 1/16).  This is the mode in which
+// the dense stacks (models/unet.py:11-20,45-113, models/stpn.py:13-43 -- fp32 convolutions in the reference) meet north_star's 1e-3
+// on hand-written kernels; the fp32 mode used the library's fp32 convolutions for that (98.8 ms per step, 43 ms of it MIOpen).
+//
+// One kernel family covers every layer (c_in, c_out multiples of 32; forward, and on mirrored / transposed weights the data
+// gradient):
+//   * tile = rows x bw pixels at (y0, x0) of one image; M-tiles are 32 consecutive pixels of the tile in row-major order (the strip
+//     scheme of conv_deep.hip with a band width: a 288-wide image is cut into 32-wide bands, an 18-wide one is taken whole); every
+//     lane keeps the LDS offset of its pixels' 3x3 windows, a tap adds a constant.
+//   * K runs over (frame tap, CS-channel slice, 3x3 tap).  The slice's input patch is converted to hi / lo while it is staged
+//     (two bf16 LDS planes, rows padded by 8 elements: conflict-free 16-byte fragment reads); the next slice's patch travels in
+//     registers as fp32 during the MFMAs.  The ReLU backward of the layer whose gradient is being consumed is applied while staging
+//     (in_mask = that layer's output).
+//   * weight tiles ([hi | lo] x [WROWS output channels] x [CS]) per tap are double buffered in LDS and requested two taps ahead
+//     (conv_deep.hip's scheme): one barrier per tap, 3 x the MFMAs of the bf16 kernel between two barriers.
+//   * 8 waves = MG pixel groups x NGW channel groups; a wave owns MT pixel tiles x NW channel tiles.  LDS fragment reads per MFMA:
+//     (2 NW + 2 MT) / (3 NW MT) = 0.67 at 2 x 2 -- the split turns the LDS-bound 32/64-channel layers of the bf16 kernels into
+//     matrix-pipe-bound ones.
+#include "common.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+#define CSP_THREADS 512
+#define CSP_PCH 6                              // 8-channel patch chunks (two float4) a thread carries per slice
+#define CSP_LDS_MAX (160 * 1024)
+
+// eight fp32 -> eight bf16 hi + eight bf16 lo (round to nearest even both times)
+__device__ __forceinline__ void csp_split8(const float4 &a, const float4 &b, uint4 &hi, uint4 &lo)
+{
+    hi.x = pcacc_pack_bf16x2(a.x, a.y);
+    hi.y = pcacc_pack_bf16x2(a.z, a.w);
+    hi.z = pcacc_pack_bf16x2(b.x, b.y);
+    hi.w = pcacc_pack_bf16x2(b.z, b.w);
+    lo.x = pcacc_pack_bf16x2(a.x - pcacc_bf16_lo(hi.x), a.y - pcacc_bf16_hi(hi.x));
+    lo.y = pcacc_pack_bf16x2(a.z - pcacc_bf16_lo(hi.y), a.w - pcacc_bf16_hi(hi.y));
+    lo.z = pcacc_pack_bf16x2(b.x - pcacc_bf16_lo(hi.z), b.y - pcacc_bf16_hi(hi.z));
+    lo.w = pcacc_pack_bf16x2(b.z - pcacc_bf16_lo(hi.w), b.w - pcacc_bf16_hi(hi.w));
+}
+
+__device__ __forceinline__ float4 csp_relu_mask4(float4 g, float4 y)
+{
+    return make_float4(y.x > 0.f ? g.x : 0.f, y.y > 0.f ? g.y : 0.f, y.z > 0.f ? g.z : 0.f, y.w > 0.f ? g.w : 0.f);
+}
+
+// ---- weight preparation: fp32 [O][I][KT][3][3] read through its strides -> bf16 [2 = hi, lo][KT*9][O'][I'] ------------------------
+// forward form (O' = O, I' = I) and data-gradient form (O' = I, I' = O, taps and frame taps mirrored) in one launch.
+struct CspWStrides { int64_t o, i, t, y, x; };
+
+__global__ __launch_bounds__(256) void conv_split_prepare_kernel(const float *__restrict__ w, int o, int i, int kt, CspWStrides st,
+                                                                 uint16_t *__restrict__ out_fwd, uint16_t *__restrict__ out_bwd)
+{
+    const int taps = kt * 9;
+    const int64_t total = (int64_t)taps * o * i;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < 2 * total; e += (int64_t)gridDim.x * 256) {
+        const bool transpose = e >= total;
+        const int64_t r = transpose ? e - total : e;
+        const int op = transpose ? i : o, ip = transpose ? o : i;
+        const int ci = (int)(r % ip);
+        const int co = (int)((r / ip) % op);
+        const int tap = (int)(r / ((int64_t)ip * op));
+        const int src_tap = transpose ? (taps - 1 - tap) : tap;
+        const int so = transpose ? ci : co, si = transpose ? co : ci;
+        const int ft = src_tap / 9, fy = (src_tap % 9) / 3, fx = src_tap % 3;
+        const float v = w[so * st.o + si * st.i + ft * st.t + fy * st.y + fx * st.x];
+        const uint16_t hi = f32_to_bf16(v);
+        const uint16_t lo = f32_to_bf16(v - bf16_to_f32(hi));
+        uint16_t *dst = transpose ? out_bwd : out_fwd;
+        dst[r] = hi;
+        dst[total + r] = lo;
+    }
+}
+
+extern "C" int pcacc_conv3x3_split_prepare_weights(const float *w, int32_t c_out, int32_t c_in, int32_t kt, const int64_t *strides,
+                                                   uint16_t *out_fwd, uint16_t *out_bwd, void *stream)
+{
+    if (!w || !out_fwd || !out_bwd || !strides || c_out < 1 || c_in < 1 || (kt != 1 && kt != 3)) return PCACC_E_ARG;
+    const CspWStrides st = {strides[0], strides[1], kt == 3 ? strides[2] : 0, strides[kt == 3 ? 3 : 2], strides[kt == 3 ? 4 : 3]};
+    const int64_t total = 2 * (int64_t)kt * 9 * c_out * c_in;
+    hipLaunchKernelGGL(conv_split_prepare_kernel, dim3(pcacc_grid(total, 256)), dim3(256), 0, pcacc_stream(stream), w, c_out, c_in, kt, st,
+                       out_fwd, out_bwd);
+    PCACC_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- forward / data gradient --------------------------------------------------------------------------------------------------------
+template <int CS, int NW, int NGW, int MT>
+__global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float *__restrict__ in, const float *__restrict__ in_mask,
+                                                                    const uint16_t *__restrict__ wp, const float *__restrict__ bias,
+                                                                    float *__restrict__ out, int n_img, int frames, int h, int w, int c_in,
+                                                                    int c_out, int kt, int relu, int rows, int bw, int tiles_y, int tiles_x,
+                                                                    int co_groups)
+{
+    constexpr int PS = CS + 8;                                 // padded LDS row (elements)
+    constexpr int MG = 8 / NGW;                                // waves along the pixel dimension
+    constexpr int WROWS = 32 * NW * NGW;                       // output channels per workgroup
+    constexpr int C8 = CS / 8;
+    constexpr int WPL = WROWS * PS;                            // one weight plane of one buffer
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    const int pw = bw + 2, pp = (rows + 2) * pw;
+    const int plane = pp * PS;
+    uint16_t *patch = lds;                                     // [2 = hi, lo][pp][PS]
+    uint16_t *wbuf = lds + 2 * (size_t)plane;                  // [2 buffers][2 = hi, lo][WROWS][PS]
+
+    int bid = blockIdx.x;
+    const int cog = bid % co_groups; bid /= co_groups;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int img = bid / tiles_y;
+    const int y0 = ty * rows, x0 = tx * bw;
+    const int co0 = cog * WROWS;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lp = lane & 31, lh = lane >> 5;
+    const int mg = wave % MG, ngw = wave / MG;
+    const int n_px = rows * bw;
+
+    // frame taps that exist for this image (uniform): a missing frame contributes zeros
+    const int t_frame = img % frames;
+    const int f_lo = (kt == 3 && t_frame == 0) ? 1 : 0;
+    const int f_hi = kt == 3 ? (t_frame == frames - 1 ? 1 : 2) : 0;
+    const int nc = c_in / CS;
+    const int s0 = f_lo * nc, n_slices = (f_hi - f_lo + 1) * nc, n_taps = n_slices * 9;
+
+    // the lane's pixels: LDS offset of the top-left tap of their 3x3 windows, image position for the store
+    int poff[MT], pyx[MT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        const int q = (mg + MG * j) * 32 + lp;
+        const int y = q / bw, x = q - y * bw;
+        const bool ok = q < n_px && y0 + y < h && x0 + x < w;
+        poff[j] = ok ? (y * pw + x) * PS : 0;
+        pyx[j] = ok ? ((y0 + y) << 16 | (x0 + x)) : -1;
+    }
+    f32x16_t acc[MT][NW];
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+        for (int n = 0; n < NW; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][n][r] = 0.f;
+
+    // patch chunks (8 channels) of this thread: position packed as py << 20 | px << 8 | c8 (0x7ff rows never pass the bounds test)
+    const int n_chunks = pp * C8;
+    int pinfo[CSP_PCH];
+    float4 preg[CSP_PCH][2];
+#pragma unroll
+    for (int q = 0; q < CSP_PCH; ++q) {
+        const int c = threadIdx.x + q * CSP_THREADS;
+        const int px = c / C8, c8 = c - px * C8;
+        const int py = px / pw, pxx = px - py * pw;
+        pinfo[q] = c < n_chunks ? (py << 20 | pxx << 8 | c8) : (0x7ff << 20);
+    }
+    auto fetch_patch = [&](int sl) {                           // sl = index into the valid slices
+        const int s = s0 + sl, f = s / nc, cs = s - f * nc;
+        const int64_t img_off = (int64_t)(img + (kt == 3 ? f - 1 : 0)) * h * w * c_in;
+#pragma unroll
+        for (int q = 0; q < CSP_PCH; ++q) {
+            const int py = pinfo[q] >> 20, pxx = (pinfo[q] >> 8) & 0xfff, c8 = pinfo[q] & 0xff;
+            const int y = y0 - 1 + py, x = x0 - 1 + pxx;
+            // always load (from a clamped position), then select: a load under a lane mask costs a branch and an early wait
+            const bool ok = (unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w;
+            const int yc = min(max(y, 0), h - 1), xc = min(max(x, 0), w - 1);
+            const int64_t off = img_off + ((int64_t)yc * w + xc) * c_in + cs * CS + c8 * 8;
+            float4 a = *reinterpret_cast<const float4 *>(in + off), b = *reinterpret_cast<const float4 *>(in + off + 4);
+            if (in_mask) {                                     // uniform
+                a = csp_relu_mask4(a, *reinterpret_cast<const float4 *>(in_mask + off));
+                b = csp_relu_mask4(b, *reinterpret_cast<const float4 *>(in_mask + off + 4));
+            }
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            preg[q][0] = ok ? a : z;
+            preg[q][1] = ok ? b : z;
+        }
+    };
+    auto write_patch = [&]() {
+#pragma unroll
+        for (int q = 0; q < CSP_PCH; ++q) {
+            const int c = threadIdx.x + q * CSP_THREADS;
+            if (c < n_chunks) {
+                uint4 hi, lo;
+                csp_split8(preg[q][0], preg[q][1], hi, lo);
+                uint16_t *dst = patch + (c / C8) * PS + (c % C8) * 8;
+                *reinterpret_cast<uint4 *>(dst) = hi;
+                *reinterpret_cast<uint4 *>(dst + plane) = lo;
+            }
+        }
+    };
+    // weight tile of (slice, tap): 2 planes x WROWS rows x CS elements.  Requested TWO taps ahead into alternating register sets, written
+    // to the other LDS buffer one tap ahead.
+    constexpr int W_CH_PLANE = WROWS * C8, W_CHUNKS = 2 * W_CH_PLANE, W_PER = (W_CHUNKS + CSP_THREADS - 1) / CSP_THREADS;
+    const int64_t w_plane = (int64_t)kt * 9 * c_out * c_in;    // elements of one prepared plane
+    uint4 wreg[2][W_PER];
+    auto fetch_w = [&](int set, int g) {                       // g = linear tap index over the valid slices
+        const int sl = g / 9, tap = g - sl * 9;
+        const int s = s0 + sl, f = s / nc, cs = s - f * nc;
+        const uint16_t *src = wp + ((int64_t)(f * 9 + tap) * c_out + co0) * c_in + cs * CS;
+#pragma unroll
+        for (int q = 0; q < W_PER; ++q) {
+            const int c = (W_CHUNKS % CSP_THREADS) ? min((int)threadIdx.x + q * CSP_THREADS, W_CHUNKS - 1) : threadIdx.x + q * CSP_THREADS;
+            const int p = c / W_CH_PLANE, r = c - p * W_CH_PLANE;
+            wreg[set][q] = *reinterpret_cast<const uint4 *>(src + p * w_plane + (int64_t)(r / C8) * c_in + (r % C8) * 8);   // clamped, never masked
+        }
+    };
+    auto write_w = [&](uint16_t *dst, int set) {
+#pragma unroll
+        for (int q = 0; q < W_PER; ++q) {
+            const int c = threadIdx.x + q * CSP_THREADS;
+            if (c < W_CHUNKS) {
+                const int p = c / W_CH_PLANE, r = c - p * W_CH_PLANE;
+                *reinterpret_cast<uint4 *>(dst + p * WPL + (r / C8) * PS + (r % C8) * 8) = wreg[set][q];
+            }
+        }
+    };
+
+    fetch_patch(0);
+    fetch_w(0, 0);
+    if (n_taps > 1) fetch_w(1, 1);
+    uint16_t *wb0 = wbuf, *wb1 = wbuf + 2 * WPL;               // buffer of the even / odd taps of the current slice
+    write_w(wb0, 0);                                           // tap 0 (nobody reads LDS yet)
+    for (int sl = 0; sl < n_slices; ++sl) {
+        __syncthreads();                                       // every wave is done with the previous slice's patch
+        write_patch();
+        if (sl + 1 < n_slices) fetch_patch(sl + 1);            // in flight during the nine taps below
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int g = sl * 9 + tap;
+            uint16_t *cur = (tap & 1) ? wb1 : wb0, *other = (tap & 1) ? wb0 : wb1;
+            __syncthreads();                                   // buffer `cur` (and, at tap 0, the patch) is visible
+            if (g + 2 < n_taps) fetch_w(tap & 1, g + 2);       // set (tap & 1) held tap g: already in LDS
+            const uint16_t *wa = cur + (ngw * NW * 32 + lp) * PS + lh * 8;
+            const int toff = ((tap / 3) * pw + tap % 3) * PS + lh * 8;
+            constexpr int KC = CS / 16;
+            constexpr int FB = (MT * NW >= 6 || MT >= 3) ? 1 : 2;   // fragment sets: the widest waves have no registers for a second one
+            bf16x8_t ah[FB][NW], al[FB][NW], bh[FB][MT], bl[FB][MT];
+            auto load = [&](int slot, int kc) {
+#pragma unroll
+                for (int n = 0; n < NW; ++n) {
+                    ah[slot][n] = *reinterpret_cast<const bf16x8_t *>(wa + n * 32 * PS + kc * 16);
+                    al[slot][n] = *reinterpret_cast<const bf16x8_t *>(wa + WPL + n * 32 * PS + kc * 16);
+                }
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    bh[slot][j] = *reinterpret_cast<const bf16x8_t *>(patch + poff[j] + toff + kc * 16);
+                    bl[slot][j] = *reinterpret_cast<const bf16x8_t *>(patch + plane + poff[j] + toff + kc * 16);
+                }
+            };
+            if (FB == 2) load(0, 0);
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+                if (FB == 1) load(0, kc);
+                else if (kc + 1 < KC) load((kc + 1) & 1, kc + 1);   // fragments of the next step in flight under this step's MFMAs
+                constexpr int M = FB - 1;
+                // small terms first; consecutive MFMAs go to different accumulators
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+#pragma unroll
+                    for (int n = 0; n < NW; ++n)
+                        acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kc & M][n], bl[kc & M][j], acc[j][n], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+#pragma unroll
+                    for (int n = 0; n < NW; ++n)
+                        acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[kc & M][n], bh[kc & M][j], acc[j][n], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+#pragma unroll
+                    for (int n = 0; n < NW; ++n)
+                        acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kc & M][n], bh[kc & M][j], acc[j][n], 0, 0, 0);
+            }
+            if (g + 1 < n_taps) write_w(other, (tap + 1) & 1);   // tap g + 1 (requested two taps ago) into the buffer tap g - 1 used
+        }
+        // nine taps per slice: the next slice's tap 0 sits in register set 1 / goes to the odd buffer -- swap the roles (a few moves)
+        {
+            uint16_t *t = wb0; wb0 = wb1; wb1 = t;
+#pragma unroll
+            for (int q = 0; q < W_PER; ++q) { const uint4 v = wreg[0][q]; wreg[0][q] = wreg[1][q]; wreg[1][q] = v; }
+        }
+    }
+
+    // epilogue: lane = pixel, register quad g of tile n = channels n*32 + 8g + 4*lh .. +3 of this wave's NW * 32
+    const int cw0 = co0 + ngw * NW * 32;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        if (pyx[j] < 0) continue;
+        float *dst = out + (((int64_t)img * h + (pyx[j] >> 16)) * w + (pyx[j] & 0xffff)) * c_out + cw0;
+#pragma unroll
+        for (int n = 0; n < NW; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = n * 32 + 8 * g + 4 * lh;
+                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (bias) bv = *reinterpret_cast<const float4 *>(bias + cw0 + c);
+                float4 v = make_float4(acc[j][n][4 * g] + bv.x, acc[j][n][4 * g + 1] + bv.y, acc[j][n][4 * g + 2] + bv.z, acc[j][n][4 * g + 3] + bv.w);
+                if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                *reinterpret_cast<float4 *>(dst + c) = v;
+            }
+    }
+}
+
+// Tiling of a layer: (NW, NGW) by the output width, MT, slice width, tile = rows x bw.  A workgroup's time goes with its MFMA count
+// (3 per fragment pair) plus a per-tap cost for the barrier and the weight tile; the launch takes ceil(blocks / 256 CUs) rounds of it
+// (LDS leaves one workgroup per CU).
+struct ConvSplitPlan { int cs, nw, ngw, mt, rows, bw, tiles_y, tiles_x, co_groups; size_t lds; int64_t blocks; };
+
+static bool conv_split_fits(int cs, int wrows, int rows, int bw, size_t *lds)
+{
+    const int64_t pp = (int64_t)(rows + 2) * (bw + 2);
+    *lds = (size_t)(2 * pp + 4 * wrows) * (cs + 8) * sizeof(uint16_t);
+    return pp * (cs / 8) <= CSP_THREADS * CSP_PCH && *lds <= CSP_LDS_MAX && rows + 2 < 0x7ff && bw + 2 < 0xfff;
+}
+
+static bool conv_split_plan(int n_img, int h, int w, int c_in, int c_out, int kt, ConvSplitPlan *best)
+{
+    if (c_in < 32 || c_in % 32 || c_out < 32 || c_out % 32 || h < 1 || w < 1 || h > 32767 || w > 32767) return false;
+    bool found = false;
+    int64_t best_cost = 0, best_waste = 0;
+    static const int shapes[3][2] = {{2, 2}, {2, 1}, {1, 1}};
+    for (int si = 0; si < 3; ++si) {
+        const int nw = shapes[si][0], ngw = shapes[si][1];
+        const int wrows = 32 * nw * ngw, mg = 8 / ngw;
+        if (c_out % wrows) continue;
+        for (int mt = 3; mt >= 1; --mt) {
+            if (nw == 2 && mt == 3) continue;                  // instantiated: (2,2) and (2,1) x MT 1..2 (MT = 3 spills), (1,1) x MT 1..3
+            const int cap = mg * mt * 32;
+            for (int cs = 64; cs >= 32; cs -= 32) {
+                if (c_in % cs) continue;
+                // band widths: the whole row when it fits a tile, else bands of about 32 / 64 / 96 pixels (balanced over the row)
+                for (int bi = 0; bi < 4; ++bi) {
+                    int bw = bi == 0 ? w : 32 * bi;
+                    if (bi > 0 && bw >= w) continue;
+                    if (bw > cap) continue;
+                    const int tiles_x = (w + bw - 1) / bw;
+                    bw = (w + tiles_x - 1) / tiles_x;
+                    int r = cap / bw;
+                    if (r > h) r = h;
+                    size_t lds;
+                    while (r >= 1 && !conv_split_fits(cs, wrows, r, bw, &lds)) --r;
+                    if (r < 1) continue;
+                    const int tiles_y = (h + r - 1) / r;
+                    r = (h + tiles_y - 1) / tiles_y;               // balance: the same count with the least height
+                    if (!conv_split_fits(cs, wrows, r, bw, &lds)) continue;
+                    const int tiles = (r * bw + 31) / 32;
+                    if (mt > 1 && tiles <= mg * (mt - 1)) continue;   // a smaller MT covers this tile
+                    const int64_t blocks = (int64_t)n_img * tiles_y * tiles_x * (c_out / wrows);
+                    const int64_t rounds = (blocks + PCACC_CUS - 1) / PCACC_CUS;
+                    // per (slice, tap): 3 MFMAs per fragment pair and 16 k, ~6 MFMA times for the barrier / weight tile; per slice: the patch
+                    const int64_t per_slice = 9 * ((int64_t)(cs / 16) * 3 * nw * mt + 6) + (int64_t)(r + 2) * (bw + 2) * cs / 1024;
+                    const int64_t cost = rounds * per_slice * (c_in / cs);
+                    const int64_t waste = (int64_t)mg * mt * 32 * tiles_y * tiles_x - (int64_t)h * w;
+                    if (!found || cost < best_cost || (cost == best_cost && waste < best_waste)) {
+                        found = true;
+                        best_cost = cost;
+                        best_waste = waste;
+                        *best = ConvSplitPlan{cs, nw, ngw, mt, r, bw, tiles_y, tiles_x, c_out / wrows, lds, blocks};
+                    }
+                }
+            }
+        }
+    }
+    (void)kt;
+    return found;
+}
+
+template <int CS, int NW, int NGW, int MT>
+static int conv_split_launch(const ConvSplitPlan &p, const float *in, const float *in_mask, const uint16_t *wp, const float *bias, float *out,
+                             int n_img, int frames, int h, int w, int c_in, int c_out, int kt, int relu, hipStream_t st)
+{
+    auto kern = conv3x3_split_kernel<CS, NW, NGW, MT>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds) != hipSuccess)
+        return PCACC_E_LAUNCH;
+    if (p.blocks > 0x7fffffff) return PCACC_E_ARG;
+    hipLaunchKernelGGL(kern, dim3((unsigned)p.blocks), dim3(CSP_THREADS), p.lds, st, in, in_mask, wp, bias, out, n_img, frames, h, w, c_in,
+                       c_out, kt, relu, p.rows, p.bw, p.tiles_y, p.tiles_x, p.co_groups);
+    PCACC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pcacc_conv3x3_split_supported(int32_t h, int32_t w, int32_t c_in, int32_t c_out)
+{
+    ConvSplitPlan p;
+    return conv_split_plan(1, h, w, c_in, c_out, 1, &p) ? 1 : 0;
+}
+
+extern "C" int pcacc_conv3x3_split(const float *in, const float *in_mask, const uint16_t *wp, const float *bias, float *out, int32_t n_img,
+                                   int32_t frames, int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t kt, int32_t relu, void *stream)
+{
+    ConvSplitPlan p;
+    if (!in || !wp || !out || n_img < 1 || (kt != 1 && kt != 3) || frames < 1 || n_img % frames ||
+        !conv_split_plan(n_img, h, w, c_in, c_out, kt, &p))
+        return PCACC_E_ARG;
+    if (getenv("PCACC_CONV_PLAN"))
+        fprintf(stderr, "split conv plan %dx%d %d->%d kt=%d n=%d: cs=%d nw=%d ngw=%d mt=%d rows=%d bw=%d blocks=%lld lds=%zu\n", h, w, c_in, c_out,
+                kt, n_img, p.cs, p.nw, p.ngw, p.mt, p.rows, p.bw, (long long)p.blocks, p.lds);
+    hipStream_t st = pcacc_stream(stream);
+#define CSP_CASE(CSV, NWV, NGWV, MTV)                                          \
+    if (p.cs == CSV && p.nw == NWV && p.ngw == NGWV && p.mt == MTV)            \
+        return conv_split_launch<CSV, NWV, NGWV, MTV>(p, in, in_mask, wp, bias, out, n_img, frames, h, w, c_in, c_out, kt, relu, st)
+    CSP_CASE(64, 2, 2, 1); CSP_CASE(64, 2, 2, 2); CSP_CASE(64, 2, 1, 1); CSP_CASE(64, 2, 1, 2);
+    CSP_CASE(64, 1, 1, 1); CSP_CASE(64, 1, 1, 2); CSP_CASE(64, 1, 1, 3);
+    CSP_CASE(32, 2, 2, 1); CSP_CASE(32, 2, 2, 2); CSP_CASE(32, 2, 1, 1); CSP_CASE(32, 2, 1, 2);
+    CSP_CASE(32, 1, 1, 1); CSP_CASE(32, 1, 1, 2); CSP_CASE(32, 1, 1, 3);
+#undef CSP_CASE
+    return PCACC_E_ARG;
+}
+
+// ---- weight gradient ------------------------------------------------------------------------------------------------------------------
+// dW[co][tap][ci] = sum over images and pixels of dY[px][co] * X[px + tap offset][ci]: M = co, N = (tap, ci), K = pixels, one frame tap
+// per launch (dt).  The scheme of conv3x3_wgrad_strip_kernel (conv_deep.hip) on split operands: a workgroup owns one (CO x CI) block of
+// the weight tensor (CO, CI = 32 or 64) and every `slots`-th tile (rows x bw pixels); the fp32 dY rows and the X patch are split into
+// hi / lo planes while they are staged channels-last, the fragments ("8 consecutive pixels of one channel") come through the LDS
+// transpose read; 8 waves = (co tile, ci tile) pairs x tap groups; three MFMAs per fragment pair.  The ReLU backward of dY is applied
+// while staging (dy_mask = the layer's forward output).  One partial slot per workgroup, a second launch sums the slots.
+typedef short csp_s16x4 __attribute__((ext_vector_type(4)));
+union csp_frag { bf16x8_t v; csp_s16x4 h[2]; };
+#define CSW_PCH 6                                          // staged 8-channel chunks (dY rows + X patch) a thread carries
+
+__device__ __forceinline__ bf16x8_t csp_tr_frag(const uint16_t *p, int stride4)
+{
+    csp_frag f;
+    f.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((csp_s16x4 __attribute__((address_space(3))) *)p);
+    f.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((csp_s16x4 __attribute__((address_space(3))) *)(p + stride4));
+    return f.v;
+}
+
+template <int CO_T, int CI_T>
+__global__ __launch_bounds__(CSP_THREADS) void conv3x3_wgrad_split_kernel(const float *__restrict__ dy, const float *__restrict__ dy_mask,
+                                                                          const float *__restrict__ x, float *__restrict__ partial,
+                                                                          int n_img, int frames, int dt, int h, int w, int c_in, int c_out,
+                                                                          int rows, int bw, int tiles_y, int tiles_x, int ci_blocks, int slots)
+{
+    constexpr int CO = CO_T * 32, CI = CI_T * 32, PAIRS = CO_T * CI_T, G = 8 / PAIRS, NT = (9 + G - 1) / G;
+    constexpr int YS = pcacc_tr_stride(CO), XS = pcacc_tr_stride(CI);
+    constexpr int SLOT = CO * 9 * CI + CO;
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    const int pw = bw + 2, pp = (rows + 2) * pw;
+    const int n_px = rows * bw, n_steps = (n_px + 15) >> 4, py_rows = n_steps * 16;
+    const int yplane = py_rows * YS, xplane = pp * XS;
+    uint16_t *sdy = lds;                                       // [2][py_rows][YS]   (rows >= n_px are zero)
+    uint16_t *sx = sdy + 2 * (size_t)yplane;                   // [2][pp][XS]
+    uint16_t *ptab = sx + 2 * (size_t)xplane;                  // [py_rows] patch row of the pixel's top-left tap
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lp = lane & 31, lh = lane >> 5;
+    const int pair = wave % PAIRS, grp = wave / PAIRS;
+    const int ct = pair / CI_T, it = pair % CI_T;
+    const int block = blockIdx.x / slots, slot = blockIdx.x % slots;
+    const int co0 = (block / ci_blocks) * CO, ci0 = (block % ci_blocks) * CI;
+
+    for (int q = threadIdx.x; q < py_rows; q += CSP_THREADS) ptab[q] = q < n_px ? (uint16_t)((q / bw) * pw + q % bw) : 0;
+
+    f32x16_t acc[NT];                                          // local tap j = tap grp + j * G
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bsum = 0.f;
+
+    // staged chunks of this thread: first the dY rows (py_rows * CO / 8 chunks), then the X patch (pp * CI / 8 chunks)
+    constexpr int YC8 = CO / 8, XC8 = CI / 8;
+    const int y_chunks = py_rows * YC8, n_chunks = y_chunks + pp * XC8;
+    float4 sreg[CSW_PCH][2];
+    const int tiles = tiles_y * tiles_x;
+    auto job_valid = [&](int job) {
+        const int t_frame = (job / tiles) % frames + dt;
+        return t_frame >= 0 && t_frame < frames;
+    };
+    auto fetch = [&](int job) {
+        const int img = job / tiles, rem = job - img * tiles;
+        const int y0 = (rem / tiles_x) * rows, x0 = (rem % tiles_x) * bw;
+        const float *ysrc = dy + (int64_t)img * h * w * c_out + co0;
+        const float *msrc = dy_mask ? dy_mask + (int64_t)img * h * w * c_out + co0 : nullptr;
+        const float *xsrc = x + (int64_t)(img + dt) * h * w * c_in + ci0;
+#pragma unroll
+        for (int q = 0; q < CSW_PCH; ++q) {
+            const int c = threadIdx.x + q * CSP_THREADS;
+            // one unconditional load per chunk from a clamped address, zero selected afterwards
+            const bool is_y = c < y_chunks;
+            const int e = is_y ? c : min(c, n_chunks - 1) - y_chunks;
+            const int px = is_y ? e / YC8 : e / XC8, c8 = is_y ? e % YC8 : e % XC8;
+            const int yy = is_y ? y0 + px / bw : y0 - 1 + px / pw;
+            const int xx = is_y ? x0 + px % bw : x0 - 1 + px % pw;
+            const bool ok = c < n_chunks && (unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w && (!is_y || px < n_px);
+            const int64_t pos = (int64_t)min(max(yy, 0), h - 1) * w + min(max(xx, 0), w - 1);
+            const float *src = is_y ? ysrc + pos * c_out + c8 * 8 : xsrc + pos * c_in + c8 * 8;
+            float4 a = *reinterpret_cast<const float4 *>(src), b = *reinterpret_cast<const float4 *>(src + 4);
+            if (msrc && is_y) {
+                const float *m = msrc + pos * c_out + c8 * 8;
+                a = csp_relu_mask4(a, *reinterpret_cast<const float4 *>(m));
+                b = csp_relu_mask4(b, *reinterpret_cast<const float4 *>(m + 4));
+            }
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            sreg[q][0] = ok ? a : z;
+            sreg[q][1] = ok ? b : z;
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int q = 0; q < CSW_PCH; ++q) {
+            const int c = threadIdx.x + q * CSP_THREADS;
+            if (c >= n_chunks) continue;
+            uint4 hi, lo;
+            csp_split8(sreg[q][0], sreg[q][1], hi, lo);
+            const bool is_y = c < y_chunks;
+            const int e = is_y ? c : c - y_chunks;
+            uint16_t *dst = is_y ? sdy + (e / YC8) * YS + (e % YC8) * 8 : sx + (e / XC8) * XS + (e % XC8) * 8;
+            const int pl = is_y ? yplane : xplane;
+            // 8-byte stores: the transposed-read row strides are multiples of 8 bytes only
+            reinterpret_cast<uint2 *>(dst)[0] = make_uint2(hi.x, hi.y);
+            reinterpret_cast<uint2 *>(dst)[1] = make_uint2(hi.z, hi.w);
+            reinterpret_cast<uint2 *>(dst + pl)[0] = make_uint2(lo.x, lo.y);
+            reinterpret_cast<uint2 *>(dst + pl)[1] = make_uint2(lo.z, lo.w);
+        }
+    };
+
+    const int n_jobs = n_img * tiles;
+    const int tg = lane >> 4, tl = lane & 15;
+    const int tr_row = (tg >> 1) * 8 + (tl >> 2), tr_col = (tg & 1) * 16 + (tl & 3) * 4;
+    int job = slot;
+    while (job < n_jobs && !job_valid(job)) job += slots;      // a missing frame contributes nothing
+    if (job < n_jobs) fetch(job);
+    while (job < n_jobs) {
+        __syncthreads();                                       // the previous tile's fragment reads are done
+        stage();
+        __syncthreads();
+        int next = job + slots;
+        while (next < n_jobs && !job_valid(next)) next += slots;
+        if (next < n_jobs) fetch(next);
+        job = next;
+        for (int s = 0; s < n_steps; ++s) {
+            const int r0 = s * 16 + tr_row;
+            const uint16_t *pa = sdy + r0 * YS + ct * 32 + tr_col;
+            csp_frag ah, al;
+            ah.v = csp_tr_frag(pa, 4 * YS);
+            al.v = csp_tr_frag(pa + yplane, 4 * YS);
+            if (it == 0 && grp == 0) {                         // bias gradient = column sums of dY: the fragments are at hand
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bsum += bf16_to_f32((uint16_t)ah.h[j][q]) + bf16_to_f32((uint16_t)al.h[j][q]);
+            }
+            const int p0 = ptab[r0], p1 = ptab[r0 + 4];
+            const uint16_t *pb0 = sx + p0 * XS + it * 32 + tr_col, *pb1 = sx + p1 * XS + it * 32 + tr_col;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int tap = grp + j * G;                   // uniform per wave
+                if (tap < 9) {
+                    const int toff = ((tap / 3) * pw + tap % 3) * XS;
+                    csp_frag bh, bl;
+                    bh.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((csp_s16x4 __attribute__((address_space(3))) *)(pb0 + toff));
+                    bh.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((csp_s16x4 __attribute__((address_space(3))) *)(pb1 + toff));
+                    bl.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((csp_s16x4 __attribute__((address_space(3))) *)(pb0 + xplane + toff));
+                    bl.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((csp_s16x4 __attribute__((address_space(3))) *)(pb1 + xplane + toff));
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bl.v, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.v, bh.v, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bh.v, acc[j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // slot of this workgroup: [CO][9][CI] then [CO] bias sums; D has lane = ci, register quads = co
+    float *mine = partial + (int64_t)blockIdx.x * SLOT;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int tap = grp + j * G;
+        if (tap < 9)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                mine[((int64_t)co * 9 + tap) * CI + it * 32 + lp] = acc[j][r];
+            }
+    }
+    if (grp != 0) return;
+    bsum += __shfl_xor(bsum, 32, 64);                          // the two half-waves hold pixels 0-7 / 8-15 of the same channel
+    if (it == 0 && lh == 0) mine[CO * 9 * CI + ct * 32 + lp] = bsum;
+}
+
+// out[co][tap][ci] (full tensor) and db[co] from the per-workgroup slots: one thread per output element, its block's slots summed
+__global__ __launch_bounds__(256) void conv_wgrad_split_reduce_kernel(const float *__restrict__ partial, int slots, int c_in, int c_out,
+                                                                      int cob, int cib, float *__restrict__ dw, float *__restrict__ db)
+{
+    const int slot_elems = cob * 9 * cib + cob, ci_blocks = c_in / cib;
+    const int64_t n_w = (int64_t)c_out * 9 * c_in;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < n_w) {
+        const int ci = (int)(e % c_in), tap = (int)((e / c_in) % 9), co = (int)(e / ((int64_t)9 * c_in));
+        const int block = (co / cob) * ci_blocks + ci / cib;
+        const float *src = partial + (int64_t)block * slots * slot_elems + ((int64_t)(co % cob) * 9 + tap) * cib + ci % cib;
+        float s0 = 0.f, s1 = 0.f;
+        int p = 0;
+        for (; p + 2 <= slots; p += 2) {
+            s0 += src[(int64_t)p * slot_elems];
+            s1 += src[(int64_t)(p + 1) * slot_elems];
+        }
+        if (p < slots) s0 += src[(int64_t)p * slot_elems];
+        dw[e] = s0 + s1;
+    } else if (e < n_w + c_out && db) {
+        const int co = (int)(e - n_w);
+        const float *src = partial + (int64_t)((co / cob) * ci_blocks) * slots * slot_elems + cob * 9 * cib + co % cob;   // ci block 0 carries the bias sums
+        float s = 0.f;
+        for (int p = 0; p < slots; ++p) s += src[(int64_t)p * slot_elems];
+        db[co] = s;
+    }
+}
+
+struct ConvSplitWPlan { int cob, cib, rows, bw, tiles_y, tiles_x, blocks, slots; size_t lds; };
+
+static bool conv_wsplit_fits(int cob, int cib, int rows, int bw, size_t *lds)
+{
+    const int pp = (rows + 2) * (bw + 2), py_rows = (rows * bw + 15) / 16 * 16;
+    *lds = ((size_t)2 * py_rows * pcacc_tr_stride(cob) + (size_t)2 * pp * pcacc_tr_stride(cib) + py_rows) * sizeof(uint16_t);
+    return py_rows * (cob / 8) + pp * (cib / 8) <= CSP_THREADS * CSW_PCH && *lds <= 150 * 1024 && pp < 65536;
+}
+
+static bool conv_wsplit_plan(int n_img, int h, int w, int c_in, int c_out, ConvSplitWPlan *best)
+{
+    if (c_in < 32 || c_in % 32 || c_out < 32 || c_out % 32 || h < 1 || w < 1 || n_img < 1) return false;
+    const int cob = c_out % 64 == 0 ? 64 : 32, cib = c_in % 64 == 0 ? 64 : 32;
+    bool found = false;
+    int64_t best_cost = 0;
+    // band widths: the whole row, or bands of about 16 / 32 / 64 pixels; rows as many as fit.  Cost = padded 16-pixel steps (MFMA work)
+    // plus the staged pixels (halo included) weighted by the share of a step they cost.
+    for (int bi = 0; bi < 4; ++bi) {
+        int bw = bi == 0 ? w : 16 << (bi - 1);
+        if (bi > 0 && bw >= w) continue;
+        const int tiles_x = (w + bw - 1) / bw;
+        bw = (w + tiles_x - 1) / tiles_x;
+        int best_r = 0;
+        size_t lds = 0, l;
+        for (int r = 1; r <= h; ++r) {
+            if (!conv_wsplit_fits(cob, cib, r, bw, &l)) break;
+            best_r = r;
+            lds = l;
+        }
+        if (!best_r) continue;
+        const int tiles_y = (h + best_r - 1) / best_r;
+        const int r = (h + tiles_y - 1) / tiles_y;
+        if (!conv_wsplit_fits(cob, cib, r, bw, &lds)) continue;
+        const int64_t steps = (int64_t)tiles_y * tiles_x * ((r * bw + 15) / 16);
+        const int64_t staged = (int64_t)tiles_y * tiles_x * ((int64_t)(r + 2) * (bw + 2) + r * bw);
+        const int64_t cost = steps * 16 * 4 + staged;
+        if (!found || cost < best_cost) {
+            found = true;
+            best_cost = cost;
+            const int blocks = (c_out / cob) * (c_in / cib);
+            int slots = (PCACC_CUS + blocks - 1) / blocks;         // one workgroup per CU (the staging LDS allows no more)
+            const int64_t jobs = (int64_t)n_img * tiles_y * tiles_x;
+            if (slots > jobs) slots = (int)jobs;
+            *best = ConvSplitWPlan{cob, cib, r, bw, tiles_y, tiles_x, blocks, slots < 1 ? 1 : slots, lds};
+        }
+    }
+    return found;
+}
+
+extern "C" int pcacc_conv3x3_wgrad_split_workspace_bytes(int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_out, size_t *bytes)
+{
+    ConvSplitWPlan p;
+    if (!bytes || !conv_wsplit_plan(n_img, h, w, c_in, c_out, &p)) return PCACC_E_ARG;
+    *bytes = (size_t)p.blocks * p.slots * (p.cob * 9 * p.cib + p.cob) * sizeof(float);
+    return 0;
+}
+
+extern "C" int pcacc_conv3x3_wgrad_split(const float *dy, const float *dy_mask, const float *x, float *dw, float *db, int32_t n_img,
+                                         int32_t frames, int32_t dt, int32_t h, int32_t w, int32_t c_in, int32_t c_out, void *workspace,
+                                         size_t workspace_bytes, void *stream)
+{
+    ConvSplitWPlan p;
+    if (!dy || !x || !dw || !workspace || frames < 1 || n_img < 1 || n_img % frames || dt < -1 || dt > 1 ||
+        !conv_wsplit_plan(n_img, h, w, c_in, c_out, &p))
+        return PCACC_E_ARG;
+    if ((int64_t)n_img * p.tiles_y * p.tiles_x > 0x7fffffff) return PCACC_E_ARG;
+    const size_t need = (size_t)p.blocks * p.slots * (p.cob * 9 * p.cib + p.cob) * sizeof(float);
+    if (workspace_bytes < need) return PCACC_E_WORKSPACE;
+    hipStream_t st = pcacc_stream(stream);
+    float *partial = static_cast<float *>(workspace);
+    if (getenv("PCACC_CONV_PLAN"))
+        fprintf(stderr, "split wgrad plan %dx%d %d->%d n=%d: block %dx%d rows=%d bw=%d blocks=%d slots=%d lds=%zu\n", h, w, c_in, c_out, n_img,
+                p.cob, p.cib, p.rows, p.bw, p.blocks, p.slots, p.lds);
+#define CSW_CASE(COT, CIT)                                                                                                              \
+    if (p.cob == COT * 32 && p.cib == CIT * 32) {                                                                                       \
+        auto kern = conv3x3_wgrad_split_kernel<COT, CIT>;                                                                               \
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds) != hipSuccess) \
+            return PCACC_E_LAUNCH;                                                                                                      \
+        hipLaunchKernelGGL(kern, dim3(p.blocks * p.slots), dim3(CSP_THREADS), p.lds, st, dy, dy_mask, x, partial, n_img, frames, dt, h, w, \
+                           c_in, c_out, p.rows, p.bw, p.tiles_y, p.tiles_x, c_in / p.cib, p.slots);                                     \
+    }
+    CSW_CASE(1, 1) else CSW_CASE(1, 2) else CSW_CASE(2, 1) else CSW_CASE(2, 2) else return PCACC_E_ARG;
+#undef CSW_CASE
+    const int64_t elems = (int64_t)c_out * 9 * c_in + c_out;
+    hipLaunchKernelGGL(conv_wgrad_split_reduce_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, partial, p.slots, c_in, c_out,
+                       p.cob, p.cib, dw, db);
+    PCACC_CHECK_LAUNCH();
+    return 0;
+}

@@ -9,8 +9,8 @@ gathers, BEV warp and the per-point transform are single launches of the gfx950 
 (all batch elements and frames at once -- the reference loops over batch and frame in Python,
 models/pillar_encoder.py:144,193, models/motionnet.py:97-135), on channels-last canvases.
 
-cfg['misc']['compute_dtype'] ('fp32' default | 'bf16'): element type of the BEV canvas and of the conv stacks
-(autocast).  Sinkhorn / Kabsch / normalisation / grid arithmetic always stay fp32.
+cfg['misc']['compute_dtype'] ('fp32' default | 'bf16' | 'fp32x3'): element type of the BEV canvas and of the conv stacks
+(autocast for bf16; 'fp32x3' = fp32 tensors with split-bf16 MFMA products, the fast mode that matches the reference to 1e-3).  Sinkhorn / Kabsch / normalisation / grid arithmetic always stay fp32.
 """
 import contextlib
 
@@ -92,7 +92,9 @@ class MotionNet(nn.Module):
         self.mode = cfg['misc']['mode']
         self.reconstructor = AlignNet(cfg)
         self.grid = grid_shape(cfg)
-        self.compute_dtype = {'fp32': torch.float32, 'bf16': torch.bfloat16}[cfg['misc'].get('compute_dtype', 'fp32')]
+        # 'fp32x3': fp32 tensors, products of the dense stacks / wide row layers on the bf16 matrix cores from hi / lo halves (ops.set_split)
+        self.compute_mode = cfg['misc'].get('compute_dtype', 'fp32')
+        self.compute_dtype = {'fp32': torch.float32, 'fp32x3': torch.float32, 'bf16': torch.bfloat16}[self.compute_mode]
         # pillars renumbered in canvas-cell order inside forward() (ops.PillarIndex); False keeps the voxeliser's numbering
         self.cell_ordered_pillars = bool(cfg['misc'].get('cell_ordered_pillars', True))
         self.after_ego = None                    # optional callable(results), see forward()
@@ -167,6 +169,7 @@ class MotionNet(nn.Module):
         B, T, Ny, Nx = batch_size, nt, ny, nx
         device = coordinates.device
         ops.set_point_dtype(self.compute_dtype if device.type == 'cuda' else torch.float32)
+        ops.set_split(self.compute_mode == 'fp32x3' and device.type == 'cuda')
         results = LazyDict()
 
         # 0. index structures shared by every irregular op of this forward, and everything else that follows from the batch alone

@@ -61,6 +61,8 @@ EXPORTS = [
     'pcacc_tube_gap_backward', 'pcacc_tube_pose_backward', 'pcacc_rows_wgrad_few_supported', 'pcacc_rows_wgrad_few_workspace_bytes', 'pcacc_rows_wgrad_few',
     'pcacc_maxpool2x2_bf16', 'pcacc_pool_skip_relu_backward_bf16',
     'pcacc_pfn_block_forward', 'pcacc_pfn_block_backward_workspace_bytes', 'pcacc_pfn_block_backward', 'pcacc_inv4x4',
+    'pcacc_conv3x3_split_prepare_weights', 'pcacc_conv3x3_split_supported', 'pcacc_conv3x3_split', 'pcacc_conv3x3_wgrad_split_workspace_bytes',
+    'pcacc_conv3x3_wgrad_split',
 ]
 
 
@@ -588,6 +590,60 @@ def conv3x3_wgrad_deep(dy_rows, x_rows, mask=None):
                                                _dev(x_rows, torch.bfloat16, 'x'), _dev(dw), _dev(db),
                                                int(n_img), int(h), int(w), int(c_in), int(c_out), _dev(ws), ctypes.c_size_t(ws.numel()),
                                                _stream()), 'conv3x3_wgrad_deep')
+    return dw, db
+
+
+# ---- fp32x3: the same layers at fp32 accuracy, split-bf16 products on the matrix cores (csrc/conv_split.hip) -------------------------------
+def conv3x3_split_supported(h, w, c_in, c_out):
+    return bool(lib().pcacc_conv3x3_split_supported(int(h), int(w), int(c_in), int(c_out)))
+
+
+def conv3x3_split_prepare_weights(weight):
+    """weight f32 [O,I,3,3] / [O,I,3,3,3] in ANY dense storage order -> (forward form bf16 [2,kt*9,O,I], data-gradient form bf16
+    [2,kt*9,I,O]); plane 0 = hi, plane 1 = lo (weight - hi)."""
+    o, i = weight.shape[0], weight.shape[1]
+    kt = 3 if weight.dim() == 5 else 1
+    if not weight.is_cuda or weight.dtype != torch.float32:
+        raise NativeError('conv3x3_split_prepare_weights: weight must be a float32 GPU tensor')
+    fwd = torch.empty((2, kt * 9, o, i), dtype=torch.bfloat16, device=weight.device)
+    bwd = torch.empty((2, kt * 9, i, o), dtype=torch.bfloat16, device=weight.device)
+    strides = (ctypes.c_int64 * weight.dim())(*weight.stride())
+    _check(lib().pcacc_conv3x3_split_prepare_weights(ctypes.c_void_p(weight.data_ptr()), int(o), int(i), kt, strides, _dev(fwd), _dev(bwd),
+                                                     _stream()), 'conv3x3_split_prepare_weights')
+    return fwd, bwd
+
+
+def conv3x3_split(x_rows, wp, bias, frames, relu, mask=None):
+    """x_rows f32 [n_img,h,w,c_in] contiguous, wp from conv3x3_split_prepare_weights -> f32 [n_img,h,w,c_out]; mask as in conv3x3 (f32)."""
+    n_img, h, w, c_in = x_rows.shape
+    _, taps, c_out, wc_in = wp.shape
+    if wc_in != c_in:
+        raise NativeError('conv3x3_split: weights prepared for %d input channels, input has %d' % (wc_in, c_in))
+    if mask is not None and mask.shape != x_rows.shape:
+        raise NativeError('conv3x3_split: mask shape %s != input shape %s' % (tuple(mask.shape), tuple(x_rows.shape)))
+    out = torch.empty((n_img, h, w, c_out), dtype=torch.float32, device=x_rows.device)
+    _check(lib().pcacc_conv3x3_split(_dev(x_rows, torch.float32, 'x'), _dev(mask, torch.float32, 'mask') if mask is not None else None,
+                                     _dev(wp, torch.bfloat16, 'wp'), _dev(bias, torch.float32, 'bias') if bias is not None else None,
+                                     _dev(out), int(n_img), int(frames), int(h), int(w), int(c_in), int(c_out), taps // 9,
+                                     1 if relu else 0, _stream()), 'conv3x3_split')
+    return out
+
+
+def conv3x3_wgrad_split(dy_rows, x_rows, frames=1, dt=0, mask=None):
+    """dy_rows [n_img,h,w,c_out], x_rows [n_img,h,w,c_in] f32 -> (dw [c_out, 9, c_in] f32, db [c_out] f32) for frame tap dt (db is the
+    full bias gradient for dt = 0); mask = forward output of the ReLU layer whose gradient dy_rows is (None: no ReLU)."""
+    n_img, h, w, c_out = dy_rows.shape
+    c_in = x_rows.shape[3]
+    dw = torch.empty((c_out, 9, c_in), dtype=torch.float32, device=dy_rows.device)
+    db = torch.empty((c_out,), dtype=torch.float32, device=dy_rows.device)
+    need = ctypes.c_size_t(0)
+    _check(lib().pcacc_conv3x3_wgrad_split_workspace_bytes(int(n_img), int(h), int(w), int(c_in), int(c_out), ctypes.byref(need)),
+           'conv3x3_wgrad_split_workspace')
+    ws = _ws(need.value, dy_rows.device)
+    _check(lib().pcacc_conv3x3_wgrad_split(_dev(dy_rows, torch.float32, 'dy'), _dev(mask, torch.float32, 'mask') if mask is not None else None,
+                                           _dev(x_rows, torch.float32, 'x'), _dev(dw), _dev(db), int(n_img), int(frames), int(dt),
+                                           int(h), int(w), int(c_in), int(c_out), _dev(ws), ctypes.c_size_t(ws.numel()), _stream()),
+           'conv3x3_wgrad_split')
     return dw, db
 
 

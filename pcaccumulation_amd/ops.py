@@ -458,6 +458,21 @@ def point_dtype():
     return _POINT_DTYPE
 
 
+_SPLIT = False
+
+
+def set_split(flag):
+    """fp32x3 compute mode (MotionNet sets it from cfg misc.compute_dtype == 'fp32x3'): fp32 tensors everywhere, the dense 3x3 stacks and
+    the wide per-point linear layers form their products on the bf16 matrix cores from hi / lo halves (csrc/conv_split.hip) instead
+    of calling the library's fp32 convolutions / the fp32 vector kernels."""
+    global _SPLIT
+    _SPLIT = bool(flag)
+
+
+def split_mode():
+    return _SPLIT
+
+
 def linear_rows(x, layer, pre_relu=False, post_relu=False, residual=None, out_dtype=None):
     """`layer(relu?(x))` (+ residual, relu?) for an nn.Linear `layer` on a 2-D `x`.  Large row counts with a supported
     feature width go through the fused HIP kernels; anything else is the library GEMM with the same semantics.
@@ -667,6 +682,62 @@ class _Conv3x3(torch.autograd.Function):
         return gx, gw, gb, None, None, None
 
 
+_PREPARED_SPLIT = {}
+
+
+def prepared_conv_weights_split(weight):
+    """(forward form, data-gradient form) of a 3x3 / 3x3x3 weight as bf16 hi / lo planes (fp32x3 mode), once per weight version."""
+    key = id(weight)
+    hit = _PREPARED_SPLIT.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == (weight._version, weight.data_ptr()):
+        return hit[2], hit[3]
+    w = weight.detach()
+    if w.dtype != torch.float32:
+        w = w.float()
+    fwd, bwd = native.conv3x3_split_prepare_weights(w)
+    if len(_PREPARED_SPLIT) > 4096:
+        _PREPARED_SPLIT.clear()
+    _PREPARED_SPLIT[key] = (weakref.ref(weight), (weight._version, weight.data_ptr()), fwd, bwd)
+    return fwd, bwd
+
+
+class _Conv3x3Split(torch.autograd.Function):
+    """3x3 (kt=1) / 3x3x3 (kt=3) convolution + bias + ReLU on fp32 channels-last rows [n_img, H, W, C] at fp32 accuracy on the bf16
+    matrix cores (csrc/conv_split.hip).  Backward: data gradient = the same kernel on mirrored / transposed weights, weight and bias
+    gradients by the split weight-gradient kernel; both read the gradient through the ReLU mask (the forward output) while staging."""
+
+    @staticmethod
+    def forward(ctx, x_rows, weight, bias, frames, relu):
+        y = native.conv3x3_split(x_rows, prepared_conv_weights_split(weight)[0], bias.detach().float() if bias is not None else None, frames, relu)
+        ctx.save_for_backward(x_rows, weight, y if relu else None)
+        ctx.meta = (frames, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x_rows, weight, y = ctx.saved_tensors
+        frames, has_bias = ctx.meta
+        gy = gy.contiguous()
+        if gy.dtype != torch.float32:
+            gy = gy.float()
+        gx = gw = gb = None
+        kt = 3 if weight.dim() == 5 else 1
+        o, i = weight.shape[0], weight.shape[1]
+        if ctx.needs_input_grad[0]:
+            gx = native.conv3x3_split(gy, prepared_conv_weights_split(weight)[1], None, frames, False, mask=y)
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            if kt == 3:
+                parts = [native.conv3x3_wgrad_split(gy, x_rows, frames, dt, mask=y) for dt in (-1, 0, 1)]
+                gw = torch.stack([p[0].view(o, 3, 3, i) for p in parts], dim=1).permute(0, 4, 1, 2, 3)    # [o, i, kt, 3, 3]
+                gb = parts[1][1]                                                           # dt = 0 visits every frame
+            else:
+                gw, gb = native.conv3x3_wgrad_split(gy, x_rows, mask=y)
+                gw = gw.view(o, 3, 3, i).permute(0, 3, 1, 2)
+            gw = gw.to(weight.dtype)
+            gb = gb if has_bias and ctx.needs_input_grad[2] else None
+        return gx, gw, gb, None, None
+
+
 def _stack_frames(rows, frames):
     """[B*T, H, W, C] -> [B*T, H, W, 3C]: frames t-1, t, t+1 side by side (zeros outside the sequence)."""
     n, h, w, c = rows.shape
@@ -688,22 +759,32 @@ def conv3x3_preferred(c_in, c_out, h=None, w=None):
 
 
 def conv3x3_available(x, weight):
-    """True when `x` (NCHW view) and the 3x3 weight take the MFMA path: GPU, bf16 compute, supported channel counts."""
-    return (x.is_cuda and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16))
-            and conv3x3_preferred(weight.shape[1], weight.shape[0], x.shape[-2], x.shape[-1]))
+    """'bf16' / 'split' when `x` (NCHW view) and the 3x3 weight take an MFMA path, else None (falsy): GPU, supported channel counts, and
+    bf16 compute (bf16 kernels) or fp32 rows in the fp32x3 mode (split-bf16 kernels, csrc/conv_split.hip)."""
+    if not x.is_cuda:
+        return None
+    if x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16):
+        return 'bf16' if conv3x3_preferred(weight.shape[1], weight.shape[0], x.shape[-2], x.shape[-1]) else None
+    if _SPLIT and x.dtype == torch.float32 and weight.dtype == torch.float32 \
+            and native.conv3x3_split_supported(x.shape[-2], x.shape[-1], weight.shape[1], weight.shape[0]):
+        return 'split'
+    return None
 
 
 def conv3x3_rows(x_rows, weight, bias, frames=1, relu=False, premasked=False):
-    """x_rows [n_img, H, W, C_in] -> [n_img, H, W, C_out] (bf16).  weight [O,I,3,3] (frames ignored) or [O,I,3,3,3]."""
+    """x_rows [n_img, H, W, C_in] -> [n_img, H, W, C_out] (bf16; f32 in the fp32x3 mode).  weight [O,I,3,3] (frames ignored) or [O,I,3,3,3]."""
+    if _SPLIT and x_rows.dtype == torch.float32 and not torch.is_autocast_enabled():
+        return _Conv3x3Split.apply(x_rows.contiguous(), weight, bias, int(frames), bool(relu))
     if x_rows.dtype != torch.bfloat16:
         x_rows = x_rows.to(torch.bfloat16)
     return _Conv3x3.apply(x_rows.contiguous(), weight, bias, int(frames), bool(relu), bool(premasked))
 
 
 def conv3x3_native(x, conv):
-    """True when conv3x3(x, conv) takes the MFMA kernels (GPU, bf16 compute, plain 3x3 / stride 1 / padding 1, supported widths)."""
-    return conv3x3_available(x, conv.weight) and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) \
-        and conv.dilation == (1, 1) and conv.groups == 1
+    """'bf16' / 'split' when conv3x3(x, conv) takes the MFMA kernels (plain 3x3 / stride 1 / padding 1, see conv3x3_available), else None."""
+    if conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1:
+        return conv3x3_available(x, conv.weight)
+    return None
 
 
 def conv3x3(x, conv, relu=False):

@@ -56,8 +56,9 @@ class STPN(nn.Module):
             if not isinstance(layer, nn.Conv3d):
                 continue
             cin = layer.in_channels
-            if ops.conv3x3_available(rows, layer.weight) and layer.kernel_size == (3, 3, 3) and layer.padding == (1, 1, 1):
-                # bf16 on the GPU: the MFMA kernel reads frames t-1, t, t+1 in place (no channel-stacked copy)
+            if ops.conv3x3_available(rows.view(B * T, H, W, cin).permute(0, 3, 1, 2), layer.weight) and layer.kernel_size == (3, 3, 3) \
+                    and layer.padding == (1, 1, 1):
+                # bf16 / fp32x3 on the GPU: the MFMA kernels read frames t-1, t, t+1 in place (no channel-stacked copy)
                 y = ops.conv3x3_rows(rows.view(B * T, H, W, cin), layer.weight, layer.bias, frames=T, relu=True)
                 rows = y.view(B, T, H, W, layer.out_channels)
                 continue

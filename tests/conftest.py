@@ -25,9 +25,11 @@ def golden():
 @pytest.fixture(autouse=True)
 def _fp32_point_rows():
     """MotionNet.forward records its compute dtype in pcaccumulation_amd.ops (the element type of the per-point MLP rows); tests that
-    call sub-modules directly must not inherit the bf16 mode of whichever model ran before them."""
+    call sub-modules directly must not inherit the bf16 / fp32x3 mode of whichever model ran before them."""
     import torch
     from pcaccumulation_amd import ops
     ops.set_point_dtype(torch.float32)
+    ops.set_split(False)
     yield
     ops.set_point_dtype(torch.float32)
+    ops.set_split(False)

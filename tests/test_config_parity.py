@@ -53,6 +53,18 @@ BF16_TRAINED_TOL = dict(ego=0.1, rot_median=0.4, trans_median=0.05, ego_worst=2.
 #     MEANS over six forward seeds (other key-point draws, same scene and weights) of the bf16 and of the fp32 product -- the latter
 #     pinned to the reference at 1e-3 above -- have to agree within the bound.
 BF16_TOL = dict(ego=1.5, iou=5e-2, epe=1.5)
+# Per-parameter gradient norms of the train configs against the reference's (not part of north_star's tolerance; a consistency check of
+# the backward pass), as (STPN backbone [+ TubeNet], everything else).  The losses of this model are ill-conditioned functions of the
+# feature maps: the ego terms go through Sinkhorn and an SVD on soft correspondences, the fg/bg term through a BatchNorm2d that cancels
+# most of the incoming gradient, the STPN / TubeNet gradients are routed by arg-max over near-tied frames / points.  Measured on c5
+# (tools/exp_x3_vs_fp32_terms.py, profiles/r03_x3_vs_fp32_terms.txt): forward maps of the two modes agree to 2e-5 relative, the
+# gradient TENSORS of the early parameters to 1e-3 (fb_loss), 2e-2 (perm_loss), 8e-2 (ego terms); and fp32 itself with 1e-5 relative
+# noise on the U-Net output moves the STPN gradient norms by 4.2 % on c3 (tools/exp_gradnorm_sensitivity.py,
+# profiles/r03_gradnorm_sensitivity.txt).  fp32: library fp32 convolutions differ from the reference's by 1e-6 -> 2.5 % / 3 % hold.
+# fp32x3: products carry 4e-6 relative error (the reference itself runs its convolutions in TF32, 5e-4, on the Ampere GPUs it was
+# written for: torch.backends.cudnn.allow_tf32 defaults to True) -> measured worst 6.1 % (c3, TubeNet positional embedding), 4.3 %
+# (STPN), 3.3 % (c5, U-Net); bounds pre-declared at <= 2x that.
+GRAD_TOL = {'fp32': (3e-2, 2.5e-2), 'fp32x3': (1e-1, 6e-2)}
 
 
 def _sha(a):
@@ -121,7 +133,7 @@ def _check(name, compute_dtype, golden):
     if str(g['mode']) == 'train':
         extra.update(loss=float(stats['loss']), loss_ref=float(g['loss']))
     _dump(name, compute_dtype, got, ref, extra)
-    tol = FP32_TOL if compute_dtype == 'fp32' else BF16_TOL
+    tol = FP32_TOL if compute_dtype in ('fp32', 'fp32x3') else BF16_TOL
     bounds = dict(ego_rot_error=tol['ego'], ego_trans_error=tol['ego'], mos_iou=tol['iou'], epe_mean=tol['epe'])
     ensemble_loss = False
     outside = [k for k in bounds if not abs(got[k] - ref[k]) < bounds[k]]
@@ -151,8 +163,11 @@ def _check(name, compute_dtype, golden):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('name', CONFIGS)
-def test_gpu_config_fp32(name, golden):
-    g, model, out, stats, (flips, _) = _check(name, 'fp32', golden)
+@pytest.mark.parametrize('mode', ['fp32', 'fp32x3'])
+def test_gpu_config_fp32(name, mode, golden):
+    """north_star's 1e-3 in both fp32-accurate modes: 'fp32' (library fp32 convolutions, fp32 vector row kernels) and 'fp32x3' (the
+    hand-written split-bf16 MFMA kernels of csrc/conv_split.hip: the matched-accuracy figure of bench.py)."""
+    g, model, out, stats, (flips, _) = _check(name, mode, golden)
     idx = torch.from_numpy(g['sample_idx']).cuda()
     assert flips < 2e-3
     assert abs(int(out['fb_est_per_points'].sum()) - int(g['fb_est_sum'])) <= 0.002 * max(int(g['fb_est_sum']), 1000)
@@ -166,11 +181,14 @@ def test_gpu_config_fp32(name, golden):
         names = [str(n) for n in g['grad_names']]
         assert names == list(grads.keys())
         loose = ('motionhead.init_conv', 'motionhead.down_convs', 'motionhead.up_convs')     # see test_model_parity._assert_tiny_train
+        tol_loose, tol_rest = GRAD_TOL[mode]
+        if mode == 'fp32x3':
+            loose = loose + ('reconstructor.',)
         bad = []
         for n, ref in zip(names, g['grad_norms']):
             got = float(grads[n].grad.norm()) if grads[n].grad is not None else 0.0
             # floor 1e-2: a conv bias in front of a BatchNorm has a mathematically zero gradient -- both sides hold rounding noise there
-            if abs(got - ref) > (3e-2 if n.startswith(loose) else 2.5e-2) * max(abs(ref), 1e-2):
+            if abs(got - ref) > (tol_loose if n.startswith(loose) else tol_rest) * max(abs(ref), 1e-2):
                 bad.append((n, got, float(ref)))
         assert not bad, bad[:8]
         np.testing.assert_allclose(model.semseg_head.seg_head[1].running_mean.detach().cpu().numpy(), g['bn_running_mean'],

@@ -1,0 +1,148 @@
+"""fp32x3 convolution (include/pcacc.h "A6/A9 at fp32 accuracy", csrc/conv_split.hip): fp32 rows in / out, products formed on the bf16
+matrix cores from hi / lo halves.  Reference: the same convolution in float64.  Tolerance: the split keeps 16+ significant bits per
+factor (relative error <= 3 * 2^-18 per product); against the float64 result of K-term sums with random signs that is a few 1e-6 of the
+typical term magnitude -- asserted at 2e-5 of the largest output, 250x tighter than bf16 operands (2^-8) and within 10x of what the
+fp32 library convolution itself shows against float64 (asserted alongside, so the bound is not vacuous)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from pcaccumulation_amd import native, ops
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device('cuda:0')
+TOL = 2e-5
+
+
+@pytest.fixture(autouse=True)
+def _split_mode():
+    ops.set_split(True)
+    yield
+    ops.set_split(False)
+
+
+def _ref64(x_rows, w, b, relu, frames=1):
+    x = x_rows.double()
+    if w.dim() == 5:
+        n, h, ww, ci = x.shape
+        x5 = x.view(n // frames, frames, h, ww, ci).permute(0, 4, 1, 2, 3)
+        y = F.conv3d(x5, w.double(), b.double() if b is not None else None, padding=1).permute(0, 2, 3, 4, 1).reshape(n, h, ww, -1)
+    else:
+        y = F.conv2d(x.permute(0, 3, 1, 2), w.double(), b.double() if b is not None else None, padding=1).permute(0, 2, 3, 1)
+    return torch.relu(y) if relu else y
+
+
+def _rel(a, ref):
+    return ((a.double() - ref).abs().max() / ref.abs().max()).item()
+
+
+SHAPES = [
+    # (n, h, w, c_in, c_out, relu): every (NW, NGW) shape of the kernel, both slice widths, bands and whole rows, ragged tiles
+    (2, 16, 32, 32, 32, True), (1, 19, 45, 64, 32, False), (3, 8, 33, 32, 64, True), (1, 24, 64, 96, 32, True),
+    (1, 9, 18, 128, 128, True), (1, 18, 18, 256, 128, False), (1, 7, 5, 128, 256, True), (2, 40, 40, 64, 64, True),
+    (3, 18, 18, 512, 512, True), (2, 36, 36, 256, 256, True), (1, 72, 72, 128, 128, False), (2, 36, 36, 512, 256, True),
+    (1, 18, 18, 256, 512, False), (2, 20, 144, 128, 64, True), (1, 5, 288, 128, 64, True), (1, 19, 37, 128, 192, False),
+    (1, 72, 72, 256, 128, True), (1, 3, 400, 128, 128, True), (1, 288, 288, 32, 32, True), (1, 144, 144, 64, 64, True),
+    (1, 1, 1, 32, 32, False), (1, 2, 700, 64, 96, True)]
+
+
+@pytest.mark.parametrize('n,h,w,ci,co,relu', SHAPES)
+def test_conv3x3_split_forward(n, h, w, ci, co, relu):
+    g = torch.Generator(device='cpu').manual_seed(n * 1000 + ci + co)
+    x = torch.randn(n, h, w, ci, generator=g).to(DEV)
+    wt = (torch.randn(co, ci, 3, 3, generator=g) / (3 * ci ** 0.5)).to(DEV)
+    b = torch.randn(co, generator=g).to(DEV)
+    assert native.conv3x3_split_supported(h, w, ci, co)
+    y = ops.conv3x3_rows(x, wt, b, 1, relu)
+    ref = _ref64(x, wt, b, relu)
+    assert y.dtype == torch.float32 and y.shape == ref.shape
+    err = _rel(y, ref)
+    lib = _rel(torch.relu(F.conv2d(x.permute(0, 3, 1, 2), wt, b, padding=1)).permute(0, 2, 3, 1) if relu
+               else F.conv2d(x.permute(0, 3, 1, 2), wt, b, padding=1).permute(0, 2, 3, 1), ref)
+    assert err <= TOL, (err, lib)
+    assert err <= max(50 * lib, 5e-6), (err, lib)                # fp32-like: within 50x of the fp32 library's own deviation from float64
+
+
+def test_conv3x3_split_identity_weights_asymmetric():
+    """Centre-tap / shifted permutation weights: the output must reproduce the input (hi + lo) to fp32 rounding -- catches operand swaps
+    and a dropped lo plane (which would leave a 2^-9 relative error)."""
+    ci = co = 64
+    x = torch.randn(1, 12, 40, ci).to(DEV)
+    perm = torch.randperm(ci)
+    wt = torch.zeros(co, ci, 3, 3)
+    wt[torch.arange(co), perm, 1, 1] = 1.0
+    y = ops.conv3x3_rows(x, wt.to(DEV), None, 1, False)
+    ref = x[..., perm.to(DEV)]
+    assert (y - ref).abs().max().item() <= 2 ** -16 * ref.abs().max().item()
+    wt = torch.zeros(co, ci, 3, 3)
+    wt[torch.arange(co), perm, 0, 2] = 1.0           # tap (dy=-1, dx=+1): shifted copy with zero border
+    y = ops.conv3x3_rows(x, wt.to(DEV), None, 1, False)
+    ref = torch.zeros_like(x)
+    ref[:, 1:, :-1] = x[:, :-1, 1:][..., perm.to(DEV)]
+    assert (y - ref).abs().max().item() <= 2 ** -16 * x.abs().max().item()
+    assert torch.equal(y[:, 0], torch.zeros_like(y[:, 0])) and torch.equal(y[:, :, -1], torch.zeros_like(y[:, :, -1]))
+
+
+@pytest.mark.parametrize('b,t,h,w,ci,co', [(2, 5, 16, 40, 32, 32), (1, 3, 9, 33, 32, 64), (1, 1, 8, 8, 32, 32), (1, 2, 36, 36, 64, 128)])
+def test_conv3x3x3_split_forward(b, t, h, w, ci, co):
+    g = torch.Generator(device='cpu').manual_seed(7)
+    x = torch.randn(b * t, h, w, ci, generator=g).to(DEV)
+    wt = (torch.randn(co, ci, 3, 3, 3, generator=g) / (5 * ci ** 0.5)).to(DEV)
+    bias = torch.randn(co, generator=g).to(DEV)
+    y = ops.conv3x3_rows(x, wt, bias, t, True)
+    ref = _ref64(x, wt, bias, True, frames=t)
+    assert _rel(y, ref) <= TOL
+
+
+@pytest.mark.parametrize('kt,ci,co,h,w', [(1, 32, 64, 12, 36), (3, 32, 32, 12, 36), (1, 64, 64, 19, 45), (1, 32, 32, 33, 70), (1, 128, 64, 18, 18),
+                                          (1, 256, 128, 9, 20), (3, 32, 64, 7, 33), (1, 64, 32, 40, 40)])
+def test_conv3x3_split_backward(kt, ci, co, h, w):
+    b, t = 2, 3
+    g = torch.Generator(device='cpu').manual_seed(11 + ci + co)
+    x = torch.randn(b * t, h, w, ci, generator=g).to(DEV).requires_grad_(True)
+    shape = (co, ci, 3, 3, 3) if kt == 3 else (co, ci, 3, 3)
+    wt = (torch.randn(*shape, generator=g) / (4 * ci ** 0.5)).to(DEV).requires_grad_(True)
+    bias = torch.randn(co, generator=g).to(DEV).requires_grad_(True)
+    gy = torch.randn(b * t, h, w, co, generator=g).to(DEV)
+    y = ops.conv3x3_rows(x, wt, bias, t if kt == 3 else 1, True)
+    y.backward(gy)
+    xr = x.detach().double().requires_grad_(True)
+    wr = wt.detach().double().requires_grad_(True)
+    br = bias.detach().double().requires_grad_(True)
+    if kt == 3:
+        x5 = xr.view(b, t, h, w, ci).permute(0, 4, 1, 2, 3)
+        yr = F.conv3d(x5, wr, br, padding=1).permute(0, 2, 3, 4, 1).reshape(b * t, h, w, co)
+    else:
+        yr = F.conv2d(xr.permute(0, 3, 1, 2), wr, br, padding=1).permute(0, 2, 3, 1)
+    # the kernel's own ReLU mask: outputs within rounding of zero may differ between the two
+    (yr * (y.detach() > 0)).backward(gy.double())
+    assert _rel(x.grad, xr.grad) <= TOL
+    assert _rel(wt.grad, wr.grad) <= TOL
+    assert _rel(bias.grad, br.grad) <= TOL
+
+
+def test_conv3x3_split_module_dispatch_and_mode_switch():
+    conv = torch.nn.Conv2d(32, 64, 3, padding=1).to(DEV)
+    x = torch.randn(2, 32, 16, 32, device=DEV).to(memory_format=torch.channels_last)
+    assert ops.conv3x3_native(x, conv) == 'split'
+    y = ops.conv3x3(x, conv, relu=True)
+    ref = torch.relu(F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1))
+    assert y.dtype == torch.float32 and _rel(y, ref) <= TOL
+    ops.set_split(False)
+    assert ops.conv3x3_native(x, conv) is None                    # plain fp32 mode: the library
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        assert ops.conv3x3_native(x, conv) == 'bf16'
+    with pytest.raises(native.NativeError):
+        native.conv3x3_split(torch.zeros(1, 8, 8, 32), torch.zeros(2, 9, 32, 32, dtype=torch.bfloat16), None, 1, False)
+
+
+def test_conv3x3_split_weights_follow_parameter_updates():
+    """The prepared hi / lo planes are cached per weight version: an optimizer step must invalidate them."""
+    conv = torch.nn.Conv2d(32, 32, 3, padding=1).to(DEV)
+    x = torch.randn(1, 32, 8, 32, device=DEV).to(memory_format=torch.channels_last)
+    y0 = ops.conv3x3(x, conv)
+    with torch.no_grad():
+        conv.weight.mul_(2.0)
+    y1 = ops.conv3x3(x, conv)
+    ref = F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1)
+    assert _rel(y1, ref) <= TOL and not torch.allclose(y0, y1)
