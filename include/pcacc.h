@@ -383,27 +383,32 @@ int pcacc_conv3x3_wgrad_deep_bf16(const uint16_t *dy, const uint16_t *dy_mask, c
                                   int32_t h, int32_t w, int32_t c_in, int32_t c_out, void *workspace, size_t workspace_bytes, void *stream);
 /* ------------------------------------------------------------------------------------------------
  * A6/A9 at fp32 accuracy ("fp32x3" compute mode): the same layers -- fp32 convolutions in the reference, models/unet.py:11-20,45-113,
- * models/stpn.py:13-43 -- on fp32 channels-last maps, every product formed on the bf16 matrix cores from hi / lo halves
- * (w_hi x_lo + w_lo x_hi + w_hi x_hi, fp32 accumulation; relative error ~4e-6 per product).  One kernel family for all layers
- * (c_in, c_out multiples of 32; kt = 1 or 3): tiles of rows x band-width pixels, hi / lo planes of the patch and of the per-tap
- * weight tiles in LDS (csrc/conv_split.hip).
+ * models/stpn.py:13-43 -- on fp32 channels-last maps, every product formed on the 16-bit matrix cores from fp16 hi / lo halves of
+ * power-of-two scaled operands (w_hi x_lo + w_lo x_hi + w_hi x_hi, fp32 accumulation; 22 significant bits per factor, relative error
+ * ~3e-7 per product).  One kernel family for all layers (c_in, c_out multiples of 32; kt = 1 or 3): tiles of rows x band-width pixels,
+ * hi / lo planes of the patch and of the per-tap weight tiles in LDS (csrc/conv_split.hip).
+ *   absmax256: parts[256] f32 <- partial maxima of |x| over n f32 elements (x 16-byte aligned; a NaN gives +inf).  Every consumer below
+ *       takes such an array for each fp32 tensor it splits and derives the tensor's scale from it (no host round trip).
  *   prepare_weights: w f32 [c_out][c_in][kt][3][3] read through `strides` (host, elements: o, i, [t,] y, x) ->
- *       out_fwd bf16 [2 = hi, lo][kt*9][c_out][c_in] and out_bwd bf16 [2][kt*9][c_in][c_out] (taps mirrored: data gradient)
- *   split:  in [n_img,h,w,c_in] f32 -> out [n_img,h,w,c_out] f32; in_mask (NULL = none): same shape as `in`, elements of `in` are read as
- *       zero where in_mask <= 0 (ReLU backward of the layer whose gradient `in` is, fused into the staging); bias / relu / frames / kt
- *       as pcacc_conv3x3_bf16
+ *       out_fwd fp16 [2 = hi, lo][kt*9][c_out][c_in] + scale_fwd f32 [c_out]; out_bwd fp16 [2][kt*9][c_in][c_out] (taps mirrored:
+ *       data gradient) + scale_bwd f32 [c_in]; scale = 1 / (power-of-two scale of that output-channel row)
+ *   split:  in [n_img,h,w,c_in] f32 (+ in_amax) -> out [n_img,h,w,c_out] f32; in_mask (NULL = none): same shape as `in`, elements of `in`
+ *       are read as zero where in_mask <= 0 (ReLU backward of the layer whose gradient `in` is, fused into the staging); wp / wscale from
+ *       prepare_weights; bias / relu / frames / kt as pcacc_conv3x3_bf16
  *   wgrad_split: dw [c_out][9][c_in] f32, db [c_out] f32 (NULL = not wanted; complete for dt = 0) from dy [n_img,h,w,c_out] f32
- *       (dy_mask as in_mask) and x [n_img,h,w,c_in] f32; dt / frames as pcacc_conv3x3_wgrad_bf16
+ *       (dy_mask as in_mask) and x [n_img,h,w,c_in] f32 with their absmax256 arrays; dt / frames as pcacc_conv3x3_wgrad_bf16
  * ---------------------------------------------------------------------------------------------- */
+int pcacc_absmax256(const float *x, int64_t n, float *parts, void *stream);
 int pcacc_conv3x3_split_prepare_weights(const float *w, int32_t c_out, int32_t c_in, int32_t kt, const int64_t *strides /*host*/,
-                                        uint16_t *out_fwd, uint16_t *out_bwd, void *stream);
+                                        uint16_t *out_fwd, float *scale_fwd, uint16_t *out_bwd, float *scale_bwd, void *stream);
 int pcacc_conv3x3_split_supported(int32_t h, int32_t w, int32_t c_in, int32_t c_out);
-int pcacc_conv3x3_split(const float *in, const float *in_mask, const uint16_t *wp, const float *bias, float *out, int32_t n_img,
-                        int32_t frames, int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t kt, int32_t relu, void *stream);
+int pcacc_conv3x3_split(const float *in, const float *in_amax, const float *in_mask, const uint16_t *wp, const float *wscale,
+                        const float *bias, float *out, int32_t n_img, int32_t frames, int32_t h, int32_t w, int32_t c_in, int32_t c_out,
+                        int32_t kt, int32_t relu, void *stream);
 int pcacc_conv3x3_wgrad_split_workspace_bytes(int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_out, size_t *bytes /*host*/);
-int pcacc_conv3x3_wgrad_split(const float *dy, const float *dy_mask, const float *x, float *dw, float *db, int32_t n_img, int32_t frames,
-                              int32_t dt, int32_t h, int32_t w, int32_t c_in, int32_t c_out, void *workspace, size_t workspace_bytes,
-                              void *stream);
+int pcacc_conv3x3_wgrad_split(const float *dy, const float *dy_amax, const float *dy_mask, const float *x, const float *x_amax, float *dw,
+                              float *db, int32_t n_img, int32_t frames, int32_t dt, int32_t h, int32_t w, int32_t c_in, int32_t c_out,
+                              void *workspace, size_t workspace_bytes, void *stream);
 int pcacc_conv3x3_wgrad_workspace_bytes(int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_out, size_t *bytes /*host*/);
 int pcacc_conv3x3_wgrad_bf16(const uint16_t *dy, const uint16_t *x, float *dw, int32_t n_img, int32_t frames, int32_t dt,
                              int32_t h, int32_t w, int32_t c_in, int32_t c_out, void *workspace, size_t workspace_bytes,

@@ -1,20 +1,26 @@
-// 3x3 (and 3x3x3 over frames) convolution at fp32 accuracy on the bf16 matrix cores ("fp32x3" compute mode): fp32 channels-last in
-// and out, every product formed from bf16 hi / lo halves,
+// 3x3 (and 3x3x3 over frames) convolution at fp32 accuracy on the 16-bit matrix cores ("fp32x3" compute mode): fp32 channels-last in
+// and out, every product formed from fp16 hi / lo halves of SCALED operands,
 //
-//     x = x_hi + x_lo (+ 2^-18 |x|),  w = w_hi + w_lo:   w x  ~=  w_hi x_lo + w_lo x_hi + w_hi x_hi      (w_lo x_lo <= 2^-18 |w x| dropped)
+//     s x = x_hi + x_lo (+ 2^-22 s|x|),  t w = w_hi + w_lo:   (t w)(s x)  ~=  w_hi x_lo + w_lo x_hi + w_hi x_hi      (w_lo x_lo <= 2^-22 dropped)
 //
-// three v_mfma_f32_32x32x16_bf16 per fragment pair, fp32 accumulation: relative error ~4e-6 per product against 4e-3 for plain
-// bf16 operands, at a third of the bf16 rate = 5x the fp32 MFMA rate (v_mfma_f32_32x32x2_f32 runs at 1/16).  This is the mode in which
-// the dense stacks (models/unet.py:11-20,45-113, models/stpn.py:13-43 -- fp32 convolutions in the reference) meet north_star's 1e-3
-// on hand-written kernels; the fp32 mode used the library's fp32 convolutions for that (98.8 ms per step, 43 ms of it MIOpen).
+// three v_mfma_f32_32x32x16_f16 per fragment pair, fp32 accumulation, result divided by s t.  fp16 carries 11 significant bits, so hi + lo
+// keep 22 (fp32 has 24): relative error ~3e-7 per product -- the first version of this file split into bf16 halves (8 + 8 bits, 4e-6
+// per product, 2e-5 after the U-Net) and left the c4 scene-flow EPE 1.04e-3 from the reference and the gradient norms of the
+// ill-conditioned loss terms up to 6 % off (profiles/r03_gradnorm_sensitivity.txt).  fp16's narrow exponent range is handled by
+// power-of-two scales: s per input TENSOR (from its absolute maximum, pcacc_absmax256: the scaled maximum lands in [2^13, 2^14)), t per
+// output-channel row of the weights (fixed when the weights are prepared).  Elements far below the tensor's maximum lose relative, not
+// absolute precision (their lo half becomes subnormal): errors stay below 2^-22 of the LARGEST operand, which is what a sum needs.
+// Rate: a third of the fp16 / bf16 matrix rate = 5x the fp32 MFMA rate (v_mfma_f32_32x32x2_f32 runs at 1/16).  This is the mode in
+// which the dense stacks (models/unet.py:11-20,45-113, models/stpn.py:13-43 -- fp32 convolutions in the reference) meet north_star's
+// 1e-3 on hand-written kernels; the fp32 mode used the library's fp32 convolutions for that (98.8 ms per step, 43 ms of it MIOpen).
 //
 // One kernel family covers every layer (c_in, c_out multiples of 32; forward, and on mirrored / transposed weights the data
 // gradient):
 //   * tile = rows x bw pixels at (y0, x0) of one image; M-tiles are 32 consecutive pixels of the tile in row-major order (the strip
 //     scheme of conv_deep.hip with a band width: a 288-wide image is cut into 32-wide bands, an 18-wide one is taken whole); every
 //     lane keeps the LDS offset of its pixels' 3x3 windows, a tap adds a constant.
-//   * K runs over (frame tap, CS-channel slice, 3x3 tap).  The slice's input patch is converted to hi / lo while it is staged
-//     (two bf16 LDS planes, rows padded by 8 elements: conflict-free 16-byte fragment reads); the next slice's patch travels in
+//   * K runs over (frame tap, CS-channel slice, 3x3 tap).  The slice's input patch is scaled and converted to hi / lo while it is
+//     staged (two fp16 LDS planes, rows padded by 8 elements: conflict-free 16-byte fragment reads); the next slice's patch travels in
 //     registers as fp32 during the MFMAs.  The ReLU backward of the layer whose gradient is being consumed is applied while staging
 //     (in_mask = that layer's output).
 //   * weight tiles ([hi | lo] x [WROWS output channels] x [CS]) per tap are double buffered in LDS and requested two taps ahead
@@ -27,24 +33,91 @@
 #include <cstdio>
 #include <cstdlib>
 
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
 #define CSP_THREADS 512
 #define CSP_PCH 6                              // 8-channel patch chunks (two float4) a thread carries per slice
 #define CSP_LDS_MAX (160 * 1024)
+#define CSP_AMAX_PARTS 256                     // partial maxima pcacc_absmax256 leaves for its consumers
 
-// eight fp32 -> eight bf16 hi + eight bf16 lo (round to nearest even both times)
-__device__ __forceinline__ void csp_split8(const float4 &a, const float4 &b, uint4 &hi, uint4 &lo)
+// ---- absolute maximum of a tensor: 256 partial maxima, every one always written (no initialisation, no second launch); the consumers
+// reduce the 256 values themselves (csp_scale_from_parts) ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void absmax256_kernel(const float *__restrict__ x, int64_t n, float *__restrict__ parts)
 {
-    hi.x = pcacc_pack_bf16x2(a.x, a.y);
-    hi.y = pcacc_pack_bf16x2(a.z, a.w);
-    hi.z = pcacc_pack_bf16x2(b.x, b.y);
-    hi.w = pcacc_pack_bf16x2(b.z, b.w);
-    lo.x = pcacc_pack_bf16x2(a.x - pcacc_bf16_lo(hi.x), a.y - pcacc_bf16_hi(hi.x));
-    lo.y = pcacc_pack_bf16x2(a.z - pcacc_bf16_lo(hi.y), a.w - pcacc_bf16_hi(hi.y));
-    lo.z = pcacc_pack_bf16x2(b.x - pcacc_bf16_lo(hi.z), b.y - pcacc_bf16_hi(hi.z));
-    lo.w = pcacc_pack_bf16x2(b.z - pcacc_bf16_lo(hi.w), b.w - pcacc_bf16_hi(hi.w));
+    float m = 0.f;
+    const int64_t n4 = n >> 2;
+    const float4 *x4 = reinterpret_cast<const float4 *>(x);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = x4[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));     // fmaxf drops NaN: see the note below
+        if (!(v.x == v.x && v.y == v.y && v.z == v.z && v.w == v.w)) m = __builtin_inff();       // a NaN must poison the result, like fp32 would
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const float v = x[(n4 << 2) + threadIdx.x];
+        m = fmaxf(m, fabsf(v));
+        if (v != v) m = __builtin_inff();
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+    __shared__ float sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) parts[blockIdx.x] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+}
+
+extern "C" int pcacc_absmax256(const float *x, int64_t n, float *parts, void *stream)
+{
+    if (!x || !parts || n < 0 || (reinterpret_cast<uintptr_t>(x) & 15)) return PCACC_E_ARG;
+    hipLaunchKernelGGL(absmax256_kernel, dim3(CSP_AMAX_PARTS), dim3(256), 0, pcacc_stream(stream), x, n, parts);
+    PCACC_CHECK_LAUNCH();
+    return 0;
+}
+
+// power-of-two scale that puts a tensor's absolute maximum into [2^13, 2^14) (fp16 overflows at 65504); 1 for an all-zero tensor.
+// A non-finite maximum gives scale 1: the non-finite element then reaches the output as inf / NaN, as it would in fp32 arithmetic.
+__device__ __forceinline__ float csp_scale_of(float amax)
+{
+    if (!(amax > 0.f) || !(amax < __builtin_inff())) return 1.f;
+    int k;
+    frexpf(amax, &k);                                         // amax = m 2^k, m in [0.5, 1)
+    return ldexpf(1.f, 14 - k);
+}
+
+// every lane reduces the 256 partial maxima (wave-uniform result, no LDS, no barrier)
+__device__ __forceinline__ float csp_scale_from_parts(const float *__restrict__ parts)
+{
+    const int lane = threadIdx.x & 63;
+    float m = fmaxf(fmaxf(parts[lane], parts[lane + 64]), fmaxf(parts[lane + 128], parts[lane + 192]));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+    return csp_scale_of(m);
+}
+
+__device__ __forceinline__ uint32_t csp_pack_f16x2(float a, float b)
+{
+    const pcacc_f32x2 f = {a, b};
+    const f16x2_t r = __builtin_convertvector(f, f16x2_t);    // round to nearest even
+    return *reinterpret_cast<const uint32_t *>(&r);
+}
+__device__ __forceinline__ pcacc_f32x2 csp_unpack_f16x2(uint32_t v)
+{
+    return __builtin_convertvector(*reinterpret_cast<const f16x2_t *>(&v), pcacc_f32x2);
+}
+__device__ __forceinline__ void csp_split2(float a, float b, uint32_t &hi, uint32_t &lo)
+{
+    hi = csp_pack_f16x2(a, b);
+    const pcacc_f32x2 back = csp_unpack_f16x2(hi);
+    lo = csp_pack_f16x2(a - back[0], b - back[1]);           // exact differences (Sterbenz); an inf hi gives NaN here, as it should
+}
+// eight fp32, scaled by s -> eight fp16 hi + eight fp16 lo (round to nearest even both times)
+__device__ __forceinline__ void csp_split8(const float4 &a, const float4 &b, float s, uint4 &hi, uint4 &lo)
+{
+    csp_split2(a.x * s, a.y * s, hi.x, lo.x);
+    csp_split2(a.z * s, a.w * s, hi.y, lo.y);
+    csp_split2(b.x * s, b.y * s, hi.z, lo.z);
+    csp_split2(b.z * s, b.w * s, hi.w, lo.w);
 }
 
 __device__ __forceinline__ float4 csp_relu_mask4(float4 g, float4 y)
@@ -52,50 +125,70 @@ __device__ __forceinline__ float4 csp_relu_mask4(float4 g, float4 y)
     return make_float4(y.x > 0.f ? g.x : 0.f, y.y > 0.f ? g.y : 0.f, y.z > 0.f ? g.z : 0.f, y.w > 0.f ? g.w : 0.f);
 }
 
-// ---- weight preparation: fp32 [O][I][KT][3][3] read through its strides -> bf16 [2 = hi, lo][KT*9][O'][I'] ------------------------
-// forward form (O' = O, I' = I) and data-gradient form (O' = I, I' = O, taps and frame taps mirrored) in one launch.
+// ---- weight preparation: fp32 [O][I][KT][3][3] read through its strides -> fp16 [2 = hi, lo][KT*9][O'][I'] + fp32 [O'] ----------------
+// forward form (O' = O, I' = I) and data-gradient form (O' = I, I' = O, taps and frame taps mirrored) in one launch: one workgroup per
+// output-channel row of either form -- the row's absolute maximum fixes its scale t (scaled maximum in [2^13, 2^14)), 1 / t goes to
+// the scale vector the convolution's epilogue multiplies with.
 struct CspWStrides { int64_t o, i, t, y, x; };
 
 __global__ __launch_bounds__(256) void conv_split_prepare_kernel(const float *__restrict__ w, int o, int i, int kt, CspWStrides st,
-                                                                 uint16_t *__restrict__ out_fwd, uint16_t *__restrict__ out_bwd)
+                                                                 uint16_t *__restrict__ out_fwd, float *__restrict__ inv_fwd,
+                                                                 uint16_t *__restrict__ out_bwd, float *__restrict__ inv_bwd)
 {
     const int taps = kt * 9;
+    const bool transpose = (int)blockIdx.x >= o;
+    const int row = transpose ? blockIdx.x - o : blockIdx.x;     // output channel of this form
+    const int op = transpose ? i : o, ip = transpose ? o : i;
     const int64_t total = (int64_t)taps * o * i;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < 2 * total; e += (int64_t)gridDim.x * 256) {
-        const bool transpose = e >= total;
-        const int64_t r = transpose ? e - total : e;
-        const int op = transpose ? i : o, ip = transpose ? o : i;
-        const int ci = (int)(r % ip);
-        const int co = (int)((r / ip) % op);
-        const int tap = (int)(r / ((int64_t)ip * op));
+    const int n = taps * ip;                                      // elements of the row: (tap, input channel of this form)
+    auto src = [&](int e) {
+        const int tap = e / ip, ci = e - tap * ip;
         const int src_tap = transpose ? (taps - 1 - tap) : tap;
-        const int so = transpose ? ci : co, si = transpose ? co : ci;
+        const int so = transpose ? ci : row, si = transpose ? row : ci;
         const int ft = src_tap / 9, fy = (src_tap % 9) / 3, fx = src_tap % 3;
-        const float v = w[so * st.o + si * st.i + ft * st.t + fy * st.y + fx * st.x];
-        const uint16_t hi = f32_to_bf16(v);
-        const uint16_t lo = f32_to_bf16(v - bf16_to_f32(hi));
-        uint16_t *dst = transpose ? out_bwd : out_fwd;
-        dst[r] = hi;
-        dst[total + r] = lo;
+        return w[so * st.o + si * st.i + ft * st.t + fy * st.y + fx * st.x];
+    };
+    float m = 0.f;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const float v = src(e);
+        m = fmaxf(m, fabsf(v));
+        if (v != v) m = __builtin_inff();
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+    __shared__ float sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    const float t = csp_scale_of(fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3])));
+    if (threadIdx.x == 0) (transpose ? inv_bwd : inv_fwd)[row] = 1.f / t;
+    uint16_t *dst = transpose ? out_bwd : out_fwd;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const int tap = e / ip, ci = e - tap * ip;
+        const float v = src(e) * t;
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        const int64_t r = ((int64_t)tap * op + row) * ip + ci;
+        dst[r] = *reinterpret_cast<const uint16_t *>(&hi);
+        dst[total + r] = *reinterpret_cast<const uint16_t *>(&lo);
     }
 }
 
 extern "C" int pcacc_conv3x3_split_prepare_weights(const float *w, int32_t c_out, int32_t c_in, int32_t kt, const int64_t *strides,
-                                                   uint16_t *out_fwd, uint16_t *out_bwd, void *stream)
+                                                   uint16_t *out_fwd, float *scale_fwd, uint16_t *out_bwd, float *scale_bwd, void *stream)
 {
-    if (!w || !out_fwd || !out_bwd || !strides || c_out < 1 || c_in < 1 || (kt != 1 && kt != 3)) return PCACC_E_ARG;
+    if (!w || !out_fwd || !out_bwd || !scale_fwd || !scale_bwd || !strides || c_out < 1 || c_in < 1 || (kt != 1 && kt != 3)) return PCACC_E_ARG;
     const CspWStrides st = {strides[0], strides[1], kt == 3 ? strides[2] : 0, strides[kt == 3 ? 3 : 2], strides[kt == 3 ? 4 : 3]};
-    const int64_t total = 2 * (int64_t)kt * 9 * c_out * c_in;
-    hipLaunchKernelGGL(conv_split_prepare_kernel, dim3(pcacc_grid(total, 256)), dim3(256), 0, pcacc_stream(stream), w, c_out, c_in, kt, st,
-                       out_fwd, out_bwd);
+    hipLaunchKernelGGL(conv_split_prepare_kernel, dim3(c_out + c_in), dim3(256), 0, pcacc_stream(stream), w, c_out, c_in, kt, st, out_fwd,
+                       scale_fwd, out_bwd, scale_bwd);
     PCACC_CHECK_LAUNCH();
     return 0;
 }
 
 // ---- forward / data gradient --------------------------------------------------------------------------------------------------------
 template <int CS, int NW, int NGW, int MT>
-__global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float *__restrict__ in, const float *__restrict__ in_mask,
-                                                                    const uint16_t *__restrict__ wp, const float *__restrict__ bias,
+__global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float *__restrict__ in, const float *__restrict__ in_amax,
+                                                                    const float *__restrict__ in_mask, const uint16_t *__restrict__ wp,
+                                                                    const float *__restrict__ wscale, const float *__restrict__ bias,
                                                                     float *__restrict__ out, int n_img, int frames, int h, int w, int c_in,
                                                                     int c_out, int kt, int relu, int rows, int bw, int tiles_y, int tiles_x,
                                                                     int co_groups)
@@ -123,6 +216,7 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float 
     const int lp = lane & 31, lh = lane >> 5;
     const int mg = wave % MG, ngw = wave / MG;
     const int n_px = rows * bw;
+    const float sx = csp_scale_from_parts(in_amax);            // power-of-two scale of the input tensor
 
     // frame taps that exist for this image (uniform): a missing frame contributes zeros
     const int t_frame = img % frames;
@@ -187,7 +281,7 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float 
             const int c = threadIdx.x + q * CSP_THREADS;
             if (c < n_chunks) {
                 uint4 hi, lo;
-                csp_split8(preg[q][0], preg[q][1], hi, lo);
+                csp_split8(preg[q][0], preg[q][1], sx, hi, lo);
                 uint16_t *dst = patch + (c / C8) * PS + (c % C8) * 8;
                 *reinterpret_cast<uint4 *>(dst) = hi;
                 *reinterpret_cast<uint4 *>(dst + plane) = lo;
@@ -240,17 +334,17 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float 
             const int toff = ((tap / 3) * pw + tap % 3) * PS + lh * 8;
             constexpr int KC = CS / 16;
             constexpr int FB = (MT * NW >= 6 || MT >= 3) ? 1 : 2;   // fragment sets: the widest waves have no registers for a second one
-            bf16x8_t ah[FB][NW], al[FB][NW], bh[FB][MT], bl[FB][MT];
+            f16x8_t ah[FB][NW], al[FB][NW], bh[FB][MT], bl[FB][MT];
             auto load = [&](int slot, int kc) {
 #pragma unroll
                 for (int n = 0; n < NW; ++n) {
-                    ah[slot][n] = *reinterpret_cast<const bf16x8_t *>(wa + n * 32 * PS + kc * 16);
-                    al[slot][n] = *reinterpret_cast<const bf16x8_t *>(wa + WPL + n * 32 * PS + kc * 16);
+                    ah[slot][n] = *reinterpret_cast<const f16x8_t *>(wa + n * 32 * PS + kc * 16);
+                    al[slot][n] = *reinterpret_cast<const f16x8_t *>(wa + WPL + n * 32 * PS + kc * 16);
                 }
 #pragma unroll
                 for (int j = 0; j < MT; ++j) {
-                    bh[slot][j] = *reinterpret_cast<const bf16x8_t *>(patch + poff[j] + toff + kc * 16);
-                    bl[slot][j] = *reinterpret_cast<const bf16x8_t *>(patch + plane + poff[j] + toff + kc * 16);
+                    bh[slot][j] = *reinterpret_cast<const f16x8_t *>(patch + poff[j] + toff + kc * 16);
+                    bl[slot][j] = *reinterpret_cast<const f16x8_t *>(patch + plane + poff[j] + toff + kc * 16);
                 }
             };
             if (FB == 2) load(0, 0);
@@ -264,17 +358,17 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float 
                 for (int j = 0; j < MT; ++j)
 #pragma unroll
                     for (int n = 0; n < NW; ++n)
-                        acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kc & M][n], bl[kc & M][j], acc[j][n], 0, 0, 0);
+                        acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kc & M][n], bl[kc & M][j], acc[j][n], 0, 0, 0);
 #pragma unroll
                 for (int j = 0; j < MT; ++j)
 #pragma unroll
                     for (int n = 0; n < NW; ++n)
-                        acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[kc & M][n], bh[kc & M][j], acc[j][n], 0, 0, 0);
+                        acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[kc & M][n], bh[kc & M][j], acc[j][n], 0, 0, 0);
 #pragma unroll
                 for (int j = 0; j < MT; ++j)
 #pragma unroll
                     for (int n = 0; n < NW; ++n)
-                        acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kc & M][n], bh[kc & M][j], acc[j][n], 0, 0, 0);
+                        acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kc & M][n], bh[kc & M][j], acc[j][n], 0, 0, 0);
             }
             if (g + 1 < n_taps) write_w(other, (tap + 1) & 1);   // tap g + 1 (requested two taps ago) into the buffer tap g - 1 used
         }
@@ -288,6 +382,7 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float 
 
     // epilogue: lane = pixel, register quad g of tile n = channels n*32 + 8g + 4*lh .. +3 of this wave's NW * 32
     const int cw0 = co0 + ngw * NW * 32;
+    const float inv_sx = 1.f / sx;
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
         if (pyx[j] < 0) continue;
@@ -299,7 +394,10 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float 
                 const int c = n * 32 + 8 * g + 4 * lh;
                 float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (bias) bv = *reinterpret_cast<const float4 *>(bias + cw0 + c);
-                float4 v = make_float4(acc[j][n][4 * g] + bv.x, acc[j][n][4 * g + 1] + bv.y, acc[j][n][4 * g + 2] + bv.z, acc[j][n][4 * g + 3] + bv.w);
+                float4 sc = *reinterpret_cast<const float4 *>(wscale + cw0 + c);          // 1 / t per output channel
+                sc = make_float4(sc.x * inv_sx, sc.y * inv_sx, sc.z * inv_sx, sc.w * inv_sx);
+                float4 v = make_float4(acc[j][n][4 * g] * sc.x + bv.x, acc[j][n][4 * g + 1] * sc.y + bv.y, acc[j][n][4 * g + 2] * sc.z + bv.z,
+                                       acc[j][n][4 * g + 3] * sc.w + bv.w);
                 if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
                 *reinterpret_cast<float4 *>(dst + c) = v;
             }
@@ -371,15 +469,16 @@ static bool conv_split_plan(int n_img, int h, int w, int c_in, int c_out, int kt
 }
 
 template <int CS, int NW, int NGW, int MT>
-static int conv_split_launch(const ConvSplitPlan &p, const float *in, const float *in_mask, const uint16_t *wp, const float *bias, float *out,
-                             int n_img, int frames, int h, int w, int c_in, int c_out, int kt, int relu, hipStream_t st)
+static int conv_split_launch(const ConvSplitPlan &p, const float *in, const float *in_amax, const float *in_mask, const uint16_t *wp,
+                             const float *wscale, const float *bias, float *out, int n_img, int frames, int h, int w, int c_in, int c_out,
+                             int kt, int relu, hipStream_t st)
 {
     auto kern = conv3x3_split_kernel<CS, NW, NGW, MT>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds) != hipSuccess)
         return PCACC_E_LAUNCH;
     if (p.blocks > 0x7fffffff) return PCACC_E_ARG;
-    hipLaunchKernelGGL(kern, dim3((unsigned)p.blocks), dim3(CSP_THREADS), p.lds, st, in, in_mask, wp, bias, out, n_img, frames, h, w, c_in,
-                       c_out, kt, relu, p.rows, p.bw, p.tiles_y, p.tiles_x, p.co_groups);
+    hipLaunchKernelGGL(kern, dim3((unsigned)p.blocks), dim3(CSP_THREADS), p.lds, st, in, in_amax, in_mask, wp, wscale, bias, out, n_img, frames,
+                       h, w, c_in, c_out, kt, relu, p.rows, p.bw, p.tiles_y, p.tiles_x, p.co_groups);
     PCACC_CHECK_LAUNCH();
     return 0;
 }
@@ -390,11 +489,12 @@ extern "C" int pcacc_conv3x3_split_supported(int32_t h, int32_t w, int32_t c_in,
     return conv_split_plan(1, h, w, c_in, c_out, 1, &p) ? 1 : 0;
 }
 
-extern "C" int pcacc_conv3x3_split(const float *in, const float *in_mask, const uint16_t *wp, const float *bias, float *out, int32_t n_img,
-                                   int32_t frames, int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t kt, int32_t relu, void *stream)
+extern "C" int pcacc_conv3x3_split(const float *in, const float *in_amax, const float *in_mask, const uint16_t *wp, const float *wscale,
+                                   const float *bias, float *out, int32_t n_img, int32_t frames, int32_t h, int32_t w, int32_t c_in,
+                                   int32_t c_out, int32_t kt, int32_t relu, void *stream)
 {
     ConvSplitPlan p;
-    if (!in || !wp || !out || n_img < 1 || (kt != 1 && kt != 3) || frames < 1 || n_img % frames ||
+    if (!in || !in_amax || !wp || !wscale || !out || n_img < 1 || (kt != 1 && kt != 3) || frames < 1 || n_img % frames ||
         !conv_split_plan(n_img, h, w, c_in, c_out, kt, &p))
         return PCACC_E_ARG;
     if (getenv("PCACC_CONV_PLAN"))
@@ -403,7 +503,7 @@ extern "C" int pcacc_conv3x3_split(const float *in, const float *in_mask, const 
     hipStream_t st = pcacc_stream(stream);
 #define CSP_CASE(CSV, NWV, NGWV, MTV)                                          \
     if (p.cs == CSV && p.nw == NWV && p.ngw == NGWV && p.mt == MTV)            \
-        return conv_split_launch<CSV, NWV, NGWV, MTV>(p, in, in_mask, wp, bias, out, n_img, frames, h, w, c_in, c_out, kt, relu, st)
+        return conv_split_launch<CSV, NWV, NGWV, MTV>(p, in, in_amax, in_mask, wp, wscale, bias, out, n_img, frames, h, w, c_in, c_out, kt, relu, st)
     CSP_CASE(64, 2, 2, 1); CSP_CASE(64, 2, 2, 2); CSP_CASE(64, 2, 1, 1); CSP_CASE(64, 2, 1, 2);
     CSP_CASE(64, 1, 1, 1); CSP_CASE(64, 1, 1, 2); CSP_CASE(64, 1, 1, 3);
     CSP_CASE(32, 2, 2, 1); CSP_CASE(32, 2, 2, 2); CSP_CASE(32, 2, 1, 1); CSP_CASE(32, 2, 1, 2);
@@ -416,14 +516,14 @@ extern "C" int pcacc_conv3x3_split(const float *in, const float *in_mask, const 
 // dW[co][tap][ci] = sum over images and pixels of dY[px][co] * X[px + tap offset][ci]: M = co, N = (tap, ci), K = pixels, one frame tap
 // per launch (dt).  The scheme of conv3x3_wgrad_strip_kernel (conv_deep.hip) on split operands: a workgroup owns one (CO x CI) block of
 // the weight tensor (CO, CI = 32 or 64) and every `slots`-th tile (rows x bw pixels); the fp32 dY rows and the X patch are split into
-// hi / lo planes while they are staged channels-last, the fragments ("8 consecutive pixels of one channel") come through the LDS
+// scaled hi / lo planes while they are staged channels-last, the fragments ("8 consecutive pixels of one channel") come through the LDS
 // transpose read; 8 waves = (co tile, ci tile) pairs x tap groups; three MFMAs per fragment pair.  The ReLU backward of dY is applied
 // while staging (dy_mask = the layer's forward output).  One partial slot per workgroup, a second launch sums the slots.
 typedef short csp_s16x4 __attribute__((ext_vector_type(4)));
-union csp_frag { bf16x8_t v; csp_s16x4 h[2]; };
+union csp_frag { f16x8_t v; csp_s16x4 h[2]; };
 #define CSW_PCH 6                                          // staged 8-channel chunks (dY rows + X patch) a thread carries
 
-__device__ __forceinline__ bf16x8_t csp_tr_frag(const uint16_t *p, int stride4)
+__device__ __forceinline__ f16x8_t csp_tr_frag(const uint16_t *p, int stride4)
 {
     csp_frag f;
     f.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((csp_s16x4 __attribute__((address_space(3))) *)p);
@@ -432,8 +532,9 @@ __device__ __forceinline__ bf16x8_t csp_tr_frag(const uint16_t *p, int stride4)
 }
 
 template <int CO_T, int CI_T>
-__global__ __launch_bounds__(CSP_THREADS) void conv3x3_wgrad_split_kernel(const float *__restrict__ dy, const float *__restrict__ dy_mask,
-                                                                          const float *__restrict__ x, float *__restrict__ partial,
+__global__ __launch_bounds__(CSP_THREADS) void conv3x3_wgrad_split_kernel(const float *__restrict__ dy, const float *__restrict__ dy_amax,
+                                                                          const float *__restrict__ dy_mask, const float *__restrict__ x,
+                                                                          const float *__restrict__ x_amax, float *__restrict__ partial,
                                                                           int n_img, int frames, int dt, int h, int w, int c_in, int c_out,
                                                                           int rows, int bw, int tiles_y, int tiles_x, int ci_blocks, int slots)
 {
@@ -454,6 +555,7 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_wgrad_split_kernel(const 
     const int ct = pair / CI_T, it = pair % CI_T;
     const int block = blockIdx.x / slots, slot = blockIdx.x % slots;
     const int co0 = (block / ci_blocks) * CO, ci0 = (block % ci_blocks) * CI;
+    const float sy = csp_scale_from_parts(dy_amax), sxs = csp_scale_from_parts(x_amax);   // the reduce launch divides by sy * sxs
 
     for (int q = threadIdx.x; q < py_rows; q += CSP_THREADS) ptab[q] = q < n_px ? (uint16_t)((q / bw) * pw + q % bw) : 0;
 
@@ -508,8 +610,8 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_wgrad_split_kernel(const 
             const int c = threadIdx.x + q * CSP_THREADS;
             if (c >= n_chunks) continue;
             uint4 hi, lo;
-            csp_split8(sreg[q][0], sreg[q][1], hi, lo);
             const bool is_y = c < y_chunks;
+            csp_split8(sreg[q][0], sreg[q][1], is_y ? sy : sxs, hi, lo);
             const int e = is_y ? c : c - y_chunks;
             uint16_t *dst = is_y ? sdy + (e / YC8) * YS + (e % YC8) * 8 : sx + (e / XC8) * XS + (e % XC8) * 8;
             const int pl = is_y ? yplane : xplane;
@@ -545,7 +647,7 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_wgrad_split_kernel(const 
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) bsum += bf16_to_f32((uint16_t)ah.h[j][q]) + bf16_to_f32((uint16_t)al.h[j][q]);
+                    for (int q = 0; q < 4; ++q) bsum += (float)ah.v[4 * j + q] + (float)al.v[4 * j + q];
             }
             const int p0 = ptab[r0], p1 = ptab[r0 + 4];
             const uint16_t *pb0 = sx + p0 * XS + it * 32 + tr_col, *pb1 = sx + p1 * XS + it * 32 + tr_col;
@@ -559,9 +661,9 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_wgrad_split_kernel(const 
                     bh.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((csp_s16x4 __attribute__((address_space(3))) *)(pb1 + toff));
                     bl.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((csp_s16x4 __attribute__((address_space(3))) *)(pb0 + xplane + toff));
                     bl.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((csp_s16x4 __attribute__((address_space(3))) *)(pb1 + xplane + toff));
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bl.v, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.v, bh.v, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bh.v, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, bl.v, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.v, bh.v, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, bh.v, acc[j], 0, 0, 0);
                 }
             }
         }
@@ -585,8 +687,11 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_wgrad_split_kernel(const 
 
 // out[co][tap][ci] (full tensor) and db[co] from the per-workgroup slots: one thread per output element, its block's slots summed
 __global__ __launch_bounds__(256) void conv_wgrad_split_reduce_kernel(const float *__restrict__ partial, int slots, int c_in, int c_out,
-                                                                      int cob, int cib, float *__restrict__ dw, float *__restrict__ db)
+                                                                      int cob, int cib, const float *__restrict__ dy_amax,
+                                                                      const float *__restrict__ x_amax, float *__restrict__ dw,
+                                                                      float *__restrict__ db)
 {
+    const float inv_y = 1.f / csp_scale_from_parts(dy_amax), inv_yx = inv_y / csp_scale_from_parts(x_amax);
     const int slot_elems = cob * 9 * cib + cob, ci_blocks = c_in / cib;
     const int64_t n_w = (int64_t)c_out * 9 * c_in;
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -601,13 +706,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_reduce_kernel(const floa
             s1 += src[(int64_t)(p + 1) * slot_elems];
         }
         if (p < slots) s0 += src[(int64_t)p * slot_elems];
-        dw[e] = s0 + s1;
+        dw[e] = (s0 + s1) * inv_yx;
     } else if (e < n_w + c_out && db) {
         const int co = (int)(e - n_w);
         const float *src = partial + (int64_t)((co / cob) * ci_blocks) * slots * slot_elems + cob * 9 * cib + co % cob;   // ci block 0 carries the bias sums
         float s = 0.f;
         for (int p = 0; p < slots; ++p) s += src[(int64_t)p * slot_elems];
-        db[co] = s;
+        db[co] = s * inv_y;
     }
 }
 
@@ -668,12 +773,12 @@ extern "C" int pcacc_conv3x3_wgrad_split_workspace_bytes(int32_t n_img, int32_t 
     return 0;
 }
 
-extern "C" int pcacc_conv3x3_wgrad_split(const float *dy, const float *dy_mask, const float *x, float *dw, float *db, int32_t n_img,
-                                         int32_t frames, int32_t dt, int32_t h, int32_t w, int32_t c_in, int32_t c_out, void *workspace,
-                                         size_t workspace_bytes, void *stream)
+extern "C" int pcacc_conv3x3_wgrad_split(const float *dy, const float *dy_amax, const float *dy_mask, const float *x, const float *x_amax,
+                                         float *dw, float *db, int32_t n_img, int32_t frames, int32_t dt, int32_t h, int32_t w, int32_t c_in,
+                                         int32_t c_out, void *workspace, size_t workspace_bytes, void *stream)
 {
     ConvSplitWPlan p;
-    if (!dy || !x || !dw || !workspace || frames < 1 || n_img < 1 || n_img % frames || dt < -1 || dt > 1 ||
+    if (!dy || !dy_amax || !x || !x_amax || !dw || !workspace || frames < 1 || n_img < 1 || n_img % frames || dt < -1 || dt > 1 ||
         !conv_wsplit_plan(n_img, h, w, c_in, c_out, &p))
         return PCACC_E_ARG;
     if ((int64_t)n_img * p.tiles_y * p.tiles_x > 0x7fffffff) return PCACC_E_ARG;
@@ -689,14 +794,14 @@ extern "C" int pcacc_conv3x3_wgrad_split(const float *dy, const float *dy_mask, 
         auto kern = conv3x3_wgrad_split_kernel<COT, CIT>;                                                                               \
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds) != hipSuccess) \
             return PCACC_E_LAUNCH;                                                                                                      \
-        hipLaunchKernelGGL(kern, dim3(p.blocks * p.slots), dim3(CSP_THREADS), p.lds, st, dy, dy_mask, x, partial, n_img, frames, dt, h, w, \
+        hipLaunchKernelGGL(kern, dim3(p.blocks * p.slots), dim3(CSP_THREADS), p.lds, st, dy, dy_amax, dy_mask, x, x_amax, partial, n_img, frames, dt, h, w, \
                            c_in, c_out, p.rows, p.bw, p.tiles_y, p.tiles_x, c_in / p.cib, p.slots);                                     \
     }
     CSW_CASE(1, 1) else CSW_CASE(1, 2) else CSW_CASE(2, 1) else CSW_CASE(2, 2) else return PCACC_E_ARG;
 #undef CSW_CASE
     const int64_t elems = (int64_t)c_out * 9 * c_in + c_out;
     hipLaunchKernelGGL(conv_wgrad_split_reduce_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, partial, p.slots, c_in, c_out,
-                       p.cob, p.cib, dw, db);
+                       p.cob, p.cib, dy_amax, x_amax, dw, db);
     PCACC_CHECK_LAUNCH();
     return 0;
 }

@@ -62,7 +62,7 @@ EXPORTS = [
     'pcacc_maxpool2x2_bf16', 'pcacc_pool_skip_relu_backward_bf16',
     'pcacc_pfn_block_forward', 'pcacc_pfn_block_backward_workspace_bytes', 'pcacc_pfn_block_backward', 'pcacc_inv4x4',
     'pcacc_conv3x3_split_prepare_weights', 'pcacc_conv3x3_split_supported', 'pcacc_conv3x3_split', 'pcacc_conv3x3_wgrad_split_workspace_bytes',
-    'pcacc_conv3x3_wgrad_split',
+    'pcacc_conv3x3_wgrad_split', 'pcacc_absmax256',
 ]
 
 
@@ -593,55 +593,75 @@ def conv3x3_wgrad_deep(dy_rows, x_rows, mask=None):
     return dw, db
 
 
-# ---- fp32x3: the same layers at fp32 accuracy, split-bf16 products on the matrix cores (csrc/conv_split.hip) -------------------------------
+# ---- fp32x3: the same layers at fp32 accuracy, scaled fp16 hi / lo products on the matrix cores (csrc/conv_split.hip) ---------------------
+def absmax256(t):
+    """256 partial maxima of |t| (f32, contiguous or any dense layout) on the device: what the fp32x3 kernels derive a tensor's scale from."""
+    out = torch.empty((256,), dtype=torch.float32, device=t.device)
+    if not t.is_cuda or t.dtype != torch.float32:
+        raise NativeError('absmax256: float32 GPU tensor expected, got %s on %s' % (t.dtype, t.device))
+    _check(lib().pcacc_absmax256(ctypes.c_void_p(t.data_ptr()), _i64(t.numel()), _dev(out), _stream()), 'absmax256')
+    return out
+
+
 def conv3x3_split_supported(h, w, c_in, c_out):
     return bool(lib().pcacc_conv3x3_split_supported(int(h), int(w), int(c_in), int(c_out)))
 
 
 def conv3x3_split_prepare_weights(weight):
-    """weight f32 [O,I,3,3] / [O,I,3,3,3] in ANY dense storage order -> (forward form bf16 [2,kt*9,O,I], data-gradient form bf16
-    [2,kt*9,I,O]); plane 0 = hi, plane 1 = lo (weight - hi)."""
+    """weight f32 [O,I,3,3] / [O,I,3,3,3] in ANY dense storage order -> ((planes fp16 [2,kt*9,O,I], scale f32 [O]), (planes fp16
+    [2,kt*9,I,O], scale f32 [I])): forward and data-gradient form; plane 0 = hi, plane 1 = lo of the row-scaled weight, scale = 1 / row scale."""
     o, i = weight.shape[0], weight.shape[1]
     kt = 3 if weight.dim() == 5 else 1
     if not weight.is_cuda or weight.dtype != torch.float32:
         raise NativeError('conv3x3_split_prepare_weights: weight must be a float32 GPU tensor')
-    fwd = torch.empty((2, kt * 9, o, i), dtype=torch.bfloat16, device=weight.device)
-    bwd = torch.empty((2, kt * 9, i, o), dtype=torch.bfloat16, device=weight.device)
+    fwd = torch.empty((2, kt * 9, o, i), dtype=torch.float16, device=weight.device)
+    bwd = torch.empty((2, kt * 9, i, o), dtype=torch.float16, device=weight.device)
+    sf = torch.empty((o,), dtype=torch.float32, device=weight.device)
+    sb = torch.empty((i,), dtype=torch.float32, device=weight.device)
     strides = (ctypes.c_int64 * weight.dim())(*weight.stride())
-    _check(lib().pcacc_conv3x3_split_prepare_weights(ctypes.c_void_p(weight.data_ptr()), int(o), int(i), kt, strides, _dev(fwd), _dev(bwd),
-                                                     _stream()), 'conv3x3_split_prepare_weights')
-    return fwd, bwd
+    _check(lib().pcacc_conv3x3_split_prepare_weights(ctypes.c_void_p(weight.data_ptr()), int(o), int(i), kt, strides, _dev(fwd), _dev(sf),
+                                                     _dev(bwd), _dev(sb), _stream()), 'conv3x3_split_prepare_weights')
+    return (fwd, sf), (bwd, sb)
 
 
-def conv3x3_split(x_rows, wp, bias, frames, relu, mask=None):
-    """x_rows f32 [n_img,h,w,c_in] contiguous, wp from conv3x3_split_prepare_weights -> f32 [n_img,h,w,c_out]; mask as in conv3x3 (f32)."""
+def conv3x3_split(x_rows, wps, bias, frames, relu, mask=None, amax=None):
+    """x_rows f32 [n_img,h,w,c_in] contiguous, wps = (planes, scale) from conv3x3_split_prepare_weights -> f32 [n_img,h,w,c_out]; mask as in
+    conv3x3 (f32); amax = absmax256(x_rows) when the caller has it already."""
+    wp, wscale = wps
     n_img, h, w, c_in = x_rows.shape
     _, taps, c_out, wc_in = wp.shape
     if wc_in != c_in:
         raise NativeError('conv3x3_split: weights prepared for %d input channels, input has %d' % (wc_in, c_in))
     if mask is not None and mask.shape != x_rows.shape:
         raise NativeError('conv3x3_split: mask shape %s != input shape %s' % (tuple(mask.shape), tuple(x_rows.shape)))
+    xp = _dev(x_rows, torch.float32, 'x')
+    if amax is None:
+        amax = absmax256(x_rows)
     out = torch.empty((n_img, h, w, c_out), dtype=torch.float32, device=x_rows.device)
-    _check(lib().pcacc_conv3x3_split(_dev(x_rows, torch.float32, 'x'), _dev(mask, torch.float32, 'mask') if mask is not None else None,
-                                     _dev(wp, torch.bfloat16, 'wp'), _dev(bias, torch.float32, 'bias') if bias is not None else None,
+    _check(lib().pcacc_conv3x3_split(xp, _dev(amax, torch.float32, 'amax'), _dev(mask, torch.float32, 'mask') if mask is not None else None,
+                                     _dev(wp, torch.float16, 'wp'), _dev(wscale, torch.float32, 'wscale'),
+                                     _dev(bias, torch.float32, 'bias') if bias is not None else None,
                                      _dev(out), int(n_img), int(frames), int(h), int(w), int(c_in), int(c_out), taps // 9,
                                      1 if relu else 0, _stream()), 'conv3x3_split')
     return out
 
 
-def conv3x3_wgrad_split(dy_rows, x_rows, frames=1, dt=0, mask=None):
+def conv3x3_wgrad_split(dy_rows, x_rows, frames=1, dt=0, mask=None, dy_amax=None, x_amax=None):
     """dy_rows [n_img,h,w,c_out], x_rows [n_img,h,w,c_in] f32 -> (dw [c_out, 9, c_in] f32, db [c_out] f32) for frame tap dt (db is the
     full bias gradient for dt = 0); mask = forward output of the ReLU layer whose gradient dy_rows is (None: no ReLU)."""
     n_img, h, w, c_out = dy_rows.shape
     c_in = x_rows.shape[3]
+    dyp, xp = _dev(dy_rows, torch.float32, 'dy'), _dev(x_rows, torch.float32, 'x')
+    dy_amax = absmax256(dy_rows) if dy_amax is None else dy_amax
+    x_amax = absmax256(x_rows) if x_amax is None else x_amax
     dw = torch.empty((c_out, 9, c_in), dtype=torch.float32, device=dy_rows.device)
     db = torch.empty((c_out,), dtype=torch.float32, device=dy_rows.device)
     need = ctypes.c_size_t(0)
     _check(lib().pcacc_conv3x3_wgrad_split_workspace_bytes(int(n_img), int(h), int(w), int(c_in), int(c_out), ctypes.byref(need)),
            'conv3x3_wgrad_split_workspace')
     ws = _ws(need.value, dy_rows.device)
-    _check(lib().pcacc_conv3x3_wgrad_split(_dev(dy_rows, torch.float32, 'dy'), _dev(mask, torch.float32, 'mask') if mask is not None else None,
-                                           _dev(x_rows, torch.float32, 'x'), _dev(dw), _dev(db), int(n_img), int(frames), int(dt),
+    _check(lib().pcacc_conv3x3_wgrad_split(dyp, _dev(dy_amax, torch.float32, 'dy_amax'), _dev(mask, torch.float32, 'mask') if mask is not None else None,
+                                           xp, _dev(x_amax, torch.float32, 'x_amax'), _dev(dw), _dev(db), int(n_img), int(frames), int(dt),
                                            int(h), int(w), int(c_in), int(c_out), _dev(ws), ctypes.c_size_t(ws.numel()), _stream()),
            'conv3x3_wgrad_split')
     return dw, db

@@ -686,7 +686,7 @@ _PREPARED_SPLIT = {}
 
 
 def prepared_conv_weights_split(weight):
-    """(forward form, data-gradient form) of a 3x3 / 3x3x3 weight as bf16 hi / lo planes (fp32x3 mode), once per weight version."""
+    """(forward form, data-gradient form) of a 3x3 / 3x3x3 weight as fp16 hi / lo planes + row scales (fp32x3 mode), once per weight version."""
     key = id(weight)
     hit = _PREPARED_SPLIT.get(key)
     if hit is not None and hit[0]() is weight and hit[1] == (weight._version, weight.data_ptr()):
@@ -702,20 +702,24 @@ def prepared_conv_weights_split(weight):
 
 
 class _Conv3x3Split(torch.autograd.Function):
-    """3x3 (kt=1) / 3x3x3 (kt=3) convolution + bias + ReLU on fp32 channels-last rows [n_img, H, W, C] at fp32 accuracy on the bf16
+    """3x3 (kt=1) / 3x3x3 (kt=3) convolution + bias + ReLU on fp32 channels-last rows [n_img, H, W, C] at fp32 accuracy on the 16-bit
     matrix cores (csrc/conv_split.hip).  Backward: data gradient = the same kernel on mirrored / transposed weights, weight and bias
-    gradients by the split weight-gradient kernel; both read the gradient through the ReLU mask (the forward output) while staging."""
+    gradients by the split weight-gradient kernel; both read the gradient through the ReLU mask (the forward output) while staging.
+    The absolute maxima the kernels scale their operands by are taken once per tensor (x in forward, reused by the weight gradient;
+    the incoming gradient once for both backward kernels)."""
 
     @staticmethod
     def forward(ctx, x_rows, weight, bias, frames, relu):
-        y = native.conv3x3_split(x_rows, prepared_conv_weights_split(weight)[0], bias.detach().float() if bias is not None else None, frames, relu)
-        ctx.save_for_backward(x_rows, weight, y if relu else None)
+        x_amax = native.absmax256(x_rows)
+        y = native.conv3x3_split(x_rows, prepared_conv_weights_split(weight)[0], bias.detach().float() if bias is not None else None, frames, relu,
+                                 amax=x_amax)
+        ctx.save_for_backward(x_rows, weight, y if relu else None, x_amax)
         ctx.meta = (frames, bias is not None)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x_rows, weight, y = ctx.saved_tensors
+        x_rows, weight, y, x_amax = ctx.saved_tensors
         frames, has_bias = ctx.meta
         gy = gy.contiguous()
         if gy.dtype != torch.float32:
@@ -723,15 +727,16 @@ class _Conv3x3Split(torch.autograd.Function):
         gx = gw = gb = None
         kt = 3 if weight.dim() == 5 else 1
         o, i = weight.shape[0], weight.shape[1]
+        g_amax = native.absmax256(gy)                          # of the unmasked gradient: an upper bound is all the scale needs
         if ctx.needs_input_grad[0]:
-            gx = native.conv3x3_split(gy, prepared_conv_weights_split(weight)[1], None, frames, False, mask=y)
+            gx = native.conv3x3_split(gy, prepared_conv_weights_split(weight)[1], None, frames, False, mask=y, amax=g_amax)
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             if kt == 3:
-                parts = [native.conv3x3_wgrad_split(gy, x_rows, frames, dt, mask=y) for dt in (-1, 0, 1)]
+                parts = [native.conv3x3_wgrad_split(gy, x_rows, frames, dt, mask=y, dy_amax=g_amax, x_amax=x_amax) for dt in (-1, 0, 1)]
                 gw = torch.stack([p[0].view(o, 3, 3, i) for p in parts], dim=1).permute(0, 4, 1, 2, 3)    # [o, i, kt, 3, 3]
                 gb = parts[1][1]                                                           # dt = 0 visits every frame
             else:
-                gw, gb = native.conv3x3_wgrad_split(gy, x_rows, mask=y)
+                gw, gb = native.conv3x3_wgrad_split(gy, x_rows, mask=y, dy_amax=g_amax, x_amax=x_amax)
                 gw = gw.view(o, 3, 3, i).permute(0, 3, 1, 2)
             gw = gw.to(weight.dtype)
             gb = gb if has_bias and ctx.needs_input_grad[2] else None

@@ -54,17 +54,15 @@ BF16_TRAINED_TOL = dict(ego=0.1, rot_median=0.4, trans_median=0.05, ego_worst=2.
 #     pinned to the reference at 1e-3 above -- have to agree within the bound.
 BF16_TOL = dict(ego=1.5, iou=5e-2, epe=1.5)
 # Per-parameter gradient norms of the train configs against the reference's (not part of north_star's tolerance; a consistency check of
-# the backward pass), as (STPN backbone [+ TubeNet], everything else).  The losses of this model are ill-conditioned functions of the
-# feature maps: the ego terms go through Sinkhorn and an SVD on soft correspondences, the fg/bg term through a BatchNorm2d that cancels
-# most of the incoming gradient, the STPN / TubeNet gradients are routed by arg-max over near-tied frames / points.  Measured on c5
-# (tools/exp_x3_vs_fp32_terms.py, profiles/r03_x3_vs_fp32_terms.txt): forward maps of the two modes agree to 2e-5 relative, the
-# gradient TENSORS of the early parameters to 1e-3 (fb_loss), 2e-2 (perm_loss), 8e-2 (ego terms); and fp32 itself with 1e-5 relative
-# noise on the U-Net output moves the STPN gradient norms by 4.2 % on c3 (tools/exp_gradnorm_sensitivity.py,
-# profiles/r03_gradnorm_sensitivity.txt).  fp32: library fp32 convolutions differ from the reference's by 1e-6 -> 2.5 % / 3 % hold.
-# fp32x3: products carry 4e-6 relative error (the reference itself runs its convolutions in TF32, 5e-4, on the Ampere GPUs it was
-# written for: torch.backends.cudnn.allow_tf32 defaults to True) -> measured worst 6.1 % (c3, TubeNet positional embedding), 4.3 %
-# (STPN), 3.3 % (c5, U-Net); bounds pre-declared at <= 2x that.
-GRAD_TOL = {'fp32': (3e-2, 2.5e-2), 'fp32x3': (1e-1, 6e-2)}
+# the backward pass), as (STPN backbone, everything else).  The losses of this model are ill-conditioned functions of the feature maps:
+# the ego terms go through Sinkhorn and an SVD on soft correspondences, the fg/bg term through a BatchNorm2d that cancels most of the
+# incoming gradient, the STPN / TubeNet gradients are routed by arg-max over near-tied frames / points.  Measured with the first,
+# bf16 hi / lo version of the fp32x3 kernels (4e-6 per product; tools/exp_x3_vs_fp32_terms.py, profiles/r03_x3_vs_fp32_terms.txt): forward
+# maps agreed with the fp32 mode to 2e-5, the gradient TENSORS of the early parameters to 1e-3 (fb_loss), 2e-2 (perm_loss), 8e-2 (ego
+# terms), gradient norms up to 6 % off; fp32 itself with 1e-5 relative noise on the U-Net output moves the STPN gradient norms by 4.2 %
+# (tools/exp_gradnorm_sensitivity.py, profiles/r03_gradnorm_sensitivity.txt).  That is why the kernels split into scaled fp16 halves
+# (22 bits, 3e-7 per product): the fp32 bounds then hold in both modes.
+GRAD_TOL = {'fp32': (3e-2, 2.5e-2), 'fp32x3': (3e-2, 2.5e-2)}
 
 
 def _sha(a):
@@ -182,8 +180,6 @@ def test_gpu_config_fp32(name, mode, golden):
         assert names == list(grads.keys())
         loose = ('motionhead.init_conv', 'motionhead.down_convs', 'motionhead.up_convs')     # see test_model_parity._assert_tiny_train
         tol_loose, tol_rest = GRAD_TOL[mode]
-        if mode == 'fp32x3':
-            loose = loose + ('reconstructor.',)
         bad = []
         for n, ref in zip(names, g['grad_norms']):
             got = float(grads[n].grad.norm()) if grads[n].grad is not None else 0.0

@@ -1,8 +1,9 @@
-"""fp32x3 convolution (include/pcacc.h "A6/A9 at fp32 accuracy", csrc/conv_split.hip): fp32 rows in / out, products formed on the bf16
-matrix cores from hi / lo halves.  Reference: the same convolution in float64.  Tolerance: the split keeps 16+ significant bits per
-factor (relative error <= 3 * 2^-18 per product); against the float64 result of K-term sums with random signs that is a few 1e-6 of the
-typical term magnitude -- asserted at 2e-5 of the largest output, 250x tighter than bf16 operands (2^-8) and within 10x of what the
-fp32 library convolution itself shows against float64 (asserted alongside, so the bound is not vacuous)."""
+"""fp32x3 convolution (include/pcacc.h "A6/A9 at fp32 accuracy", csrc/conv_split.hip): fp32 rows in / out, products formed on the 16-bit
+matrix cores from fp16 hi / lo halves of power-of-two scaled operands.  Reference: the same convolution in float64.  Tolerance: hi + lo
+keep 22 significant bits per factor (fp32: 24), the accumulation is fp32 on both sides -- asserted at 3e-6 of the largest output
+(bf16 operands: 4e-3; the bf16 hi / lo split this file started with: 4e-6 per layer) and within 10x of what the fp32 library
+convolution itself shows against float64 (so the bound is not vacuous).  Dynamic range: tensors of magnitude 1e-8 .. 1e+8, a single
+outlier 1e4 x the rest, non-finite values."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -11,7 +12,7 @@ from pcaccumulation_amd import native, ops
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device('cuda:0')
-TOL = 2e-5
+TOL = 3e-6
 
 
 @pytest.fixture(autouse=True)
@@ -60,12 +61,12 @@ def test_conv3x3_split_forward(n, h, w, ci, co, relu):
     lib = _rel(torch.relu(F.conv2d(x.permute(0, 3, 1, 2), wt, b, padding=1)).permute(0, 2, 3, 1) if relu
                else F.conv2d(x.permute(0, 3, 1, 2), wt, b, padding=1).permute(0, 2, 3, 1), ref)
     assert err <= TOL, (err, lib)
-    assert err <= max(50 * lib, 5e-6), (err, lib)                # fp32-like: within 50x of the fp32 library's own deviation from float64
+    assert err <= max(10 * lib, 2e-6), (err, lib)                # fp32-like: within 10x of the fp32 library's own deviation from float64
 
 
 def test_conv3x3_split_identity_weights_asymmetric():
     """Centre-tap / shifted permutation weights: the output must reproduce the input (hi + lo) to fp32 rounding -- catches operand swaps
-    and a dropped lo plane (which would leave a 2^-9 relative error)."""
+    and a dropped lo plane (which would leave a 2^-11 relative error)."""
     ci = co = 64
     x = torch.randn(1, 12, 40, ci).to(DEV)
     perm = torch.randperm(ci)
@@ -73,13 +74,13 @@ def test_conv3x3_split_identity_weights_asymmetric():
     wt[torch.arange(co), perm, 1, 1] = 1.0
     y = ops.conv3x3_rows(x, wt.to(DEV), None, 1, False)
     ref = x[..., perm.to(DEV)]
-    assert (y - ref).abs().max().item() <= 2 ** -16 * ref.abs().max().item()
+    assert (y - ref).abs().max().item() <= 2 ** -21 * ref.abs().max().item()
     wt = torch.zeros(co, ci, 3, 3)
     wt[torch.arange(co), perm, 0, 2] = 1.0           # tap (dy=-1, dx=+1): shifted copy with zero border
     y = ops.conv3x3_rows(x, wt.to(DEV), None, 1, False)
     ref = torch.zeros_like(x)
     ref[:, 1:, :-1] = x[:, :-1, 1:][..., perm.to(DEV)]
-    assert (y - ref).abs().max().item() <= 2 ** -16 * x.abs().max().item()
+    assert (y - ref).abs().max().item() <= 2 ** -21 * x.abs().max().item()
     assert torch.equal(y[:, 0], torch.zeros_like(y[:, 0])) and torch.equal(y[:, :, -1], torch.zeros_like(y[:, :, -1]))
 
 
@@ -133,7 +134,7 @@ def test_conv3x3_split_module_dispatch_and_mode_switch():
     with torch.autocast('cuda', dtype=torch.bfloat16):
         assert ops.conv3x3_native(x, conv) == 'bf16'
     with pytest.raises(native.NativeError):
-        native.conv3x3_split(torch.zeros(1, 8, 8, 32), torch.zeros(2, 9, 32, 32, dtype=torch.bfloat16), None, 1, False)
+        native.conv3x3_split(torch.zeros(1, 8, 8, 32), (torch.zeros(2, 9, 32, 32, dtype=torch.float16), torch.zeros(32)), None, 1, False)
 
 
 def test_conv3x3_split_weights_follow_parameter_updates():
@@ -146,3 +147,50 @@ def test_conv3x3_split_weights_follow_parameter_updates():
     y1 = ops.conv3x3(x, conv)
     ref = F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1)
     assert _rel(y1, ref) <= TOL and not torch.allclose(y0, y1)
+
+
+def test_absmax256():
+    for n in (1, 3, 4, 1000, 12345, 1 << 20):
+        x = torch.randn(n, device=DEV) * 3
+        assert float(native.absmax256(x).max()) == float(x.abs().max())
+    x = torch.zeros(4096, device=DEV)
+    assert float(native.absmax256(x).max()) == 0.0
+    x[77] = float('nan')
+    assert float(native.absmax256(x).max()) == float('inf')        # a NaN poisons the maximum (fmaxf alone would drop it)
+    x[77] = -float('inf')
+    assert float(native.absmax256(x).max()) == float('inf')
+
+
+@pytest.mark.parametrize('scale_x,scale_w', [(1e-8, 1.0), (1e8, 1e-6), (1.0, 1e5), (3e-5, 7e3)])
+def test_conv3x3_split_dynamic_range(scale_x, scale_w):
+    """Gradient-sized and huge operands: the per-tensor / per-row power-of-two scales keep the relative accuracy."""
+    g = torch.Generator(device='cpu').manual_seed(3)
+    x = (torch.randn(2, 20, 40, 64, generator=g) * scale_x).to(DEV).requires_grad_(True)
+    wt = (torch.randn(64, 64, 3, 3, generator=g) / 24 * scale_w).to(DEV).requires_grad_(True)
+    gy = (torch.randn(2, 20, 40, 64, generator=g) * scale_x).to(DEV)
+    y = ops.conv3x3_rows(x, wt, None, 1, False)
+    y.backward(gy)
+    xr, wr = x.detach().double().requires_grad_(True), wt.detach().double().requires_grad_(True)
+    yr = F.conv2d(xr.permute(0, 3, 1, 2), wr, None, padding=1).permute(0, 2, 3, 1)
+    yr.backward(gy.double())
+    assert _rel(y, yr.detach()) <= TOL and _rel(x.grad, xr.grad) <= TOL and _rel(wt.grad, wr.grad) <= TOL
+
+
+def test_conv3x3_split_outlier_and_nonfinite():
+    g = torch.Generator(device='cpu').manual_seed(4)
+    x = torch.randn(1, 16, 32, 32, generator=g).to(DEV)
+    x[0, 5, 7, 3] = 1e4                                           # one element 1e4 x the rest: the others keep >= 2^-22 * 1e4 absolute accuracy
+    wt = (torch.randn(32, 32, 3, 3, generator=g) / 17).to(DEV)
+    y = ops.conv3x3_rows(x, wt, None, 1, False)
+    ref = _ref64(x, wt, None, False)
+    far = torch.ones_like(ref, dtype=torch.bool)
+    far[0, 3:8, 5:10] = False                                     # outputs the outlier does not reach: errors relative to THEIR size
+    assert _rel(y, ref) <= TOL
+    assert float((y.double() - ref)[far].abs().max()) <= 2 ** -22 * 1e4 * 9 * 32 * float(wt.abs().max())
+    x[0, 2, 2, 0] = float('nan')
+    y = ops.conv3x3_rows(x, wt, None, 1, False)
+    assert not torch.isfinite(y).all()                            # a non-finite input reaches the output, as in fp32 arithmetic
+    x[0, 2, 2, 0] = float('inf')
+    assert not torch.isfinite(ops.conv3x3_rows(x, wt, None, 1, False)).all()
+    z = torch.zeros(1, 8, 8, 32, device=DEV)
+    assert torch.equal(ops.conv3x3_rows(z, wt, None, 1, False), torch.zeros(1, 8, 8, 32, device=DEV))     # all-zero tensor: scale 1
