@@ -409,6 +409,24 @@ int pcacc_conv3x3_wgrad_split_workspace_bytes(int32_t n_img, int32_t h, int32_t 
 int pcacc_conv3x3_wgrad_split(const float *dy, const float *dy_amax, const float *dy_mask, const float *x, const float *x_amax, float *dw,
                               float *db, int32_t n_img, int32_t frames, int32_t dt, int32_t h, int32_t w, int32_t c_in, int32_t c_out,
                               void *workspace, size_t workspace_bytes, void *stream);
+/* The per-point linear layers in the fp32x3 mode (csrc/mlp_split.hip): the contracts of pcacc_rows_linear_bf16 / _cat_bf16 /
+ * pcacc_rows_wgrad_bf16 / _cat_bf16 above on fp32 rows (x, masks, residual, y all f32; k, n in {32, 64, 128}), products from scaled
+ * fp16 hi / lo halves as in pcacc_conv3x3_split; every fp32 row tensor that is split comes with its pcacc_absmax256 array
+ * (x_amax; two-piece rows: one per piece; dy_amax), the weight matrix is scaled per output row inside the kernel.  nn.Linear of
+ * models/pillar_encoder.py:13-55,113-122, models/stpn.py:94-102, models/tpointnet.py:176-196 (fp32 in the reference). */
+int pcacc_rows_linear_split(const float *x, const float *x_amax, const float *in_mask, const float *w, const float *bias,
+                            const float *residual, const float *out_mask, float *y, int64_t rows, int32_t k, int32_t n, int32_t flags,
+                            void *stream);
+int pcacc_rows_linear_cat_split(const float *xa, const float *xa_amax, const float *xb, const float *xb_amax, const int32_t *b_index,
+                                int32_t ka, const float *in_mask, const float *w, const float *bias, const float *residual,
+                                const float *out_mask_a, const float *out_mask_b, float *y, float *y2, int32_t na, int64_t rows, int32_t k,
+                                int32_t n, int32_t flags, void *stream);
+int pcacc_rows_wgrad_split_workspace_bytes(int64_t rows, int32_t k, int32_t n, size_t *bytes /*host*/);
+int pcacc_rows_wgrad_split(const float *dy, const float *dy_amax, const float *dy_mask, const float *x, const float *x_amax, int32_t x_relu,
+                           int64_t rows, int32_t k, int32_t n, float *dw_aug, void *workspace, size_t workspace_bytes, void *stream);
+int pcacc_rows_wgrad_cat_split(const float *dy, const float *dy_amax, const float *dy_mask, const float *xa, const float *xa_amax,
+                               const float *xb, const float *xb_amax, const int32_t *b_index, int32_t ka, int32_t x_relu, int64_t rows,
+                               int32_t k, int32_t n, float *dw_aug, void *workspace, size_t workspace_bytes, void *stream);
 int pcacc_conv3x3_wgrad_workspace_bytes(int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_out, size_t *bytes /*host*/);
 int pcacc_conv3x3_wgrad_bf16(const uint16_t *dy, const uint16_t *x, float *dw, int32_t n_img, int32_t frames, int32_t dt,
                              int32_t h, int32_t w, int32_t c_in, int32_t c_out, void *workspace, size_t workspace_bytes,

@@ -63,6 +63,8 @@ EXPORTS = [
     'pcacc_pfn_block_forward', 'pcacc_pfn_block_backward_workspace_bytes', 'pcacc_pfn_block_backward', 'pcacc_inv4x4',
     'pcacc_conv3x3_split_prepare_weights', 'pcacc_conv3x3_split_supported', 'pcacc_conv3x3_split', 'pcacc_conv3x3_wgrad_split_workspace_bytes',
     'pcacc_conv3x3_wgrad_split', 'pcacc_absmax256',
+    'pcacc_rows_linear_split', 'pcacc_rows_linear_cat_split', 'pcacc_rows_wgrad_split_workspace_bytes', 'pcacc_rows_wgrad_split',
+    'pcacc_rows_wgrad_cat_split',
 ]
 
 
@@ -665,6 +667,85 @@ def conv3x3_wgrad_split(dy_rows, x_rows, frames=1, dt=0, mask=None, dy_amax=None
                                            int(h), int(w), int(c_in), int(c_out), _dev(ws), ctypes.c_size_t(ws.numel()), _stream()),
            'conv3x3_wgrad_split')
     return dw, db
+
+
+def rows_split_supported(k, n):
+    """Widths the fp32x3 row kernels take (csrc/mlp_split.hip)."""
+    return k in (32, 64, 128) and n in (32, 64, 128)
+
+
+def rows_linear_split(x, x_amax, w, bias=None, residual=None, pre_relu=False, post_relu=False, in_mask=None, out_mask=None):
+    """rows_linear on f32 rows at fp32 accuracy on the matrix cores; x_amax = absmax256(x) (of the tensor before ReLU / mask: an upper bound
+    is what the scale needs)."""
+    rows, k = x.shape
+    n = w.shape[0]
+    y = torch.empty((rows, n), dtype=torch.float32, device=x.device)
+    flags = (1 if pre_relu else 0) | (2 if post_relu else 0)
+    _check(lib().pcacc_rows_linear_split(_dev(x, torch.float32, 'x'), _dev(x_amax, torch.float32, 'x_amax'), _opt(in_mask, torch.float32, 'in_mask'),
+                                         _dev(w, torch.float32, 'w'), _opt(bias, torch.float32, 'bias'), _opt(residual, torch.float32, 'residual'),
+                                         _opt(out_mask, torch.float32, 'out_mask'), _dev(y), _i64(rows), int(k), int(n), flags, _stream()),
+           'rows_linear_split')
+    return y
+
+
+def rows_wgrad_split(dy, dy_amax, x, x_amax, dy_mask=None, x_relu=False, split=False):
+    """rows_wgrad on f32 rows at fp32 accuracy on the matrix cores (split: (dW [n,k], db [n]) contiguous)."""
+    rows, n = dy.shape
+    k = x.shape[1]
+    out = torch.empty((n, k + 1), dtype=torch.float32, device=dy.device)
+    need = ctypes.c_size_t(0)
+    _check(lib().pcacc_rows_wgrad_split_workspace_bytes(_i64(rows), int(k), int(n), ctypes.byref(need)), 'rows_wgrad_split_workspace')
+    ws = _ws(need.value, dy.device)
+    _check(lib().pcacc_rows_wgrad_split(_dev(dy, torch.float32, 'dy'), _dev(dy_amax, torch.float32, 'dy_amax'), _opt(dy_mask, torch.float32, 'dy_mask'),
+                                        _dev(x, torch.float32, 'x'), _dev(x_amax, torch.float32, 'x_amax'), (1 if x_relu else 0) | (2 if split else 0),
+                                        _i64(rows), int(k), int(n), _dev(out), _dev(ws), ctypes.c_size_t(ws.numel()), _stream()), 'rows_wgrad_split')
+    return _split_aug(out, n, k, split, rows > 0)
+
+
+def rows_linear_cat_split(xa, xa_amax, xb, xb_amax, b_index, w, bias=None, residual=None, pre_relu=False, post_relu=False):
+    """y = post(pre(cat(xa, xb[b_index])) @ w^T + bias + residual), f32 rows, the concatenation read in place (fp32x3)."""
+    rows, ka = xa.shape
+    k, n = ka + xb.shape[1], w.shape[0]
+    y = torch.empty((rows, n), dtype=torch.float32, device=xa.device)
+    flags = (1 if pre_relu else 0) | (2 if post_relu else 0)
+    _check(lib().pcacc_rows_linear_cat_split(_dev(xa, torch.float32, 'xa'), _dev(xa_amax, torch.float32, 'xa_amax'), _dev(xb, torch.float32, 'xb'),
+                                             _dev(xb_amax, torch.float32, 'xb_amax'), _opt(b_index, torch.int32, 'b_index'), int(ka), None,
+                                             _dev(w, torch.float32, 'w'), _opt(bias, torch.float32, 'bias'), _opt(residual, torch.float32, 'residual'),
+                                             None, None, _dev(y), None, 0, _i64(rows), int(k), int(n), flags, _stream()), 'rows_linear_cat_split')
+    return y
+
+
+def rows_linear_cat_backward_split(gy, gy_amax, w_t, dy_mask, xa, xb, b_index, pre_relu):
+    """(d xa [rows,ka], d of the gathered xb rows [rows,kb]) = split of (gy masked where dy_mask <= 0) @ w_t^T, each masked where the
+    forward input was <= 0 when pre_relu; f32 rows (fp32x3)."""
+    rows, n = gy.shape
+    ka, kb = xa.shape[1], xb.shape[1]
+    ga = torch.empty((rows, ka), dtype=torch.float32, device=gy.device)
+    gb = torch.empty((rows, kb), dtype=torch.float32, device=gy.device)
+    _check(lib().pcacc_rows_linear_cat_split(_dev(gy, torch.float32, 'gy'), _dev(gy_amax, torch.float32, 'gy_amax'), None, None,
+                                             _opt(b_index, torch.int32, 'b_index'), 0, _opt(dy_mask, torch.float32, 'dy_mask'),
+                                             _dev(w_t, torch.float32, 'w_t'), None, None,
+                                             _dev(xa, torch.float32, 'xa') if pre_relu else None, _dev(xb, torch.float32, 'xb') if pre_relu else None,
+                                             _dev(ga), _dev(gb), int(ka), _i64(rows), int(n), int(ka + kb), 0, _stream()),
+           'rows_linear_cat_backward_split')
+    return ga, gb
+
+
+def rows_wgrad_cat_split(dy, dy_amax, xa, xa_amax, xb, xb_amax, b_index, dy_mask=None, x_relu=False, split=False):
+    """[n, k+1] f32 weight (+ bias) gradient for x = cat(xa, xb[b_index]), f32 rows (fp32x3; split: see rows_wgrad)."""
+    rows, n = dy.shape
+    ka = xa.shape[1]
+    k = ka + xb.shape[1]
+    out = torch.empty((n, k + 1), dtype=torch.float32, device=dy.device)
+    need = ctypes.c_size_t(0)
+    _check(lib().pcacc_rows_wgrad_split_workspace_bytes(_i64(rows), int(k), int(n), ctypes.byref(need)), 'rows_wgrad_split_workspace')
+    ws = _ws(need.value, dy.device)
+    _check(lib().pcacc_rows_wgrad_cat_split(_dev(dy, torch.float32, 'dy'), _dev(dy_amax, torch.float32, 'dy_amax'), _opt(dy_mask, torch.float32, 'dy_mask'),
+                                            _dev(xa, torch.float32, 'xa'), _dev(xa_amax, torch.float32, 'xa_amax'), _dev(xb, torch.float32, 'xb'),
+                                            _dev(xb_amax, torch.float32, 'xb_amax'), _opt(b_index, torch.int32, 'b_index'), int(ka),
+                                            (1 if x_relu else 0) | (2 if split else 0), _i64(rows), int(k), int(n), _dev(out), _dev(ws),
+                                            ctypes.c_size_t(ws.numel()), _stream()), 'rows_wgrad_cat_split')
+    return _split_aug(out, n, k, split, rows > 0)
 
 
 def upload_small(values, dtype, device):

@@ -326,63 +326,95 @@ class _RowsLinear(torch.autograd.Function):
     """nn.Linear on [rows, k] with optional ReLU on the input, ReLU on the output and a residual add, one HBM pass
     (pcacc_rows_linear*); backward = the same kernel with w^T (masks replay the ReLUs) + the MFMA weight-gradient kernel.
     Rows may be fp32 or bf16 (bf16 compute mode): the output takes `out_dtype`, gradients take the dtype of what they
-    are the gradient of, weights and their gradients stay fp32."""
+    are the gradient of, weights and their gradients stay fp32.  fp32x3 mode (ops.set_split) with all-fp32 rows and widths in
+    {32, 64, 128}: the split-fp16 matrix-core kernels of csrc/mlp_split.hip, absolute maxima taken once per tensor."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual, pre_relu, post_relu, out_dtype):
         x = x.contiguous()
         w = weight.contiguous()
         res = residual.contiguous() if residual is not None else None
-        y = native.rows_linear(x, w, bias, res, pre_relu, post_relu, out_dtype=out_dtype)
-        ctx.flags = (pre_relu, post_relu, bias is not None, residual is not None, res.dtype if res is not None else None)
-        ctx.save_for_backward(x, w, y if post_relu else None)
+        k, n = w.shape[1], w.shape[0]
+        split = (_SPLIT and x.dtype == torch.float32 and out_dtype == torch.float32 and native.rows_split_supported(k, n)
+                 and w.dtype == torch.float32 and (res is None or res.dtype == torch.float32))
+        x_amax = None
+        if split:
+            x_amax = native.absmax256(x)
+            y = native.rows_linear_split(x, x_amax, w, bias, res, pre_relu, post_relu)
+        else:
+            y = native.rows_linear(x, w, bias, res, pre_relu, post_relu, out_dtype=out_dtype)
+        ctx.flags = (pre_relu, post_relu, bias is not None, residual is not None, res.dtype if res is not None else None, split)
+        ctx.save_for_backward(x, w, y if post_relu else None, x_amax)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, w, y = ctx.saved_tensors
-        pre_relu, post_relu, has_bias, has_res, res_dtype = ctx.flags
+        x, w, y, x_amax = ctx.saved_tensors
+        pre_relu, post_relu, has_bias, has_res, res_dtype, split = ctx.flags
         gy = gy.contiguous()
         gx = gw = gb = gres = None
-        if ctx.needs_input_grad[0]:
-            gx = native.rows_linear(gy, w.t().contiguous(), None, None, False, False, in_mask=y, out_mask=x if pre_relu else None,
-                                    out_dtype=x.dtype)
-        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
-            gw, gb = native.rows_wgrad(gy, x, dy_mask=y, x_relu=pre_relu, split=True)     # contiguous: autograd adopts them without a copy
-            gb = gb if has_bias else None
+        if split:
+            if gy.dtype != torch.float32:
+                gy = gy.float()
+            g_amax = native.absmax256(gy)
+            if ctx.needs_input_grad[0]:
+                gx = native.rows_linear_split(gy, g_amax, w.t().contiguous(), None, None, False, False, in_mask=y, out_mask=x if pre_relu else None)
+            if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+                gw, gb = native.rows_wgrad_split(gy, g_amax, x, x_amax, dy_mask=y, x_relu=pre_relu, split=True)
+                gb = gb if has_bias else None
+        else:
+            if ctx.needs_input_grad[0]:
+                gx = native.rows_linear(gy, w.t().contiguous(), None, None, False, False, in_mask=y, out_mask=x if pre_relu else None,
+                                        out_dtype=x.dtype)
+            if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+                gw, gb = native.rows_wgrad(gy, x, dy_mask=y, x_relu=pre_relu, split=True)     # contiguous: autograd adopts them without a copy
+                gb = gb if has_bias else None
         if has_res and ctx.needs_input_grad[3]:
             gres = (gy if y is None else gy * (y > 0)).to(res_dtype)
         return gx, gw, gb, gres, None, None, None
 
 
 class _RowsLinearCat(torch.autograd.Function):
-    """_RowsLinear on x = cat(xa, pooled[p2v]) without materialising the gather or the concatenation (bf16 rows on the GPU;
-    pcacc_rows_linear_cat_bf16): the PFN blocks' input (models/pillar_encoder.py:116-118).  Backward: the data gradient leaves
-    the kernel already split; the pooled half is summed over each pillar's points (CSR segment sum)."""
+    """_RowsLinear on x = cat(xa, pooled[p2v]) without materialising the gather or the concatenation (bf16 rows, or fp32 rows in the
+    fp32x3 mode, on the GPU; pcacc_rows_linear_cat_bf16 / _cat_split): the PFN blocks' input (models/pillar_encoder.py:116-118).
+    Backward: the data gradient leaves the kernel already split; the pooled half is summed over each pillar's points (CSR segment sum)."""
 
     @staticmethod
     def forward(ctx, xa, pooled, pidx, weight, bias, residual, pre_relu, post_relu):
         xa, pooled, w = xa.contiguous(), pooled.contiguous(), weight.contiguous()
         res = residual.contiguous() if residual is not None else None
-        y = native.rows_linear_cat(xa, pooled, pidx.p2v, w, bias, res, pre_relu, post_relu)
+        split = xa.dtype == torch.float32
+        amax = (None, None)
+        if split:
+            amax = (native.absmax256(xa), native.absmax256(pooled))
+            y = native.rows_linear_cat_split(xa, amax[0], pooled, amax[1], pidx.p2v, w, bias, res, pre_relu, post_relu)
+        else:
+            y = native.rows_linear_cat(xa, pooled, pidx.p2v, w, bias, res, pre_relu, post_relu)
         ctx.pidx = pidx
-        ctx.flags = (pre_relu, post_relu, bias is not None, residual is not None)
-        ctx.save_for_backward(xa, pooled, w, y if post_relu else None)
+        ctx.flags = (pre_relu, post_relu, bias is not None, residual is not None, split)
+        ctx.save_for_backward(xa, pooled, w, y if post_relu else None, amax[0], amax[1])
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        xa, pooled, w, y = ctx.saved_tensors
-        pre_relu, post_relu, has_bias, has_res = ctx.flags
+        xa, pooled, w, y, a_amax, p_amax = ctx.saved_tensors
+        pre_relu, post_relu, has_bias, has_res, split = ctx.flags
         pidx = ctx.pidx
         gy = gy.contiguous()
         ga = gp = gw = gb = gres = None
+        g_amax = native.absmax256(gy) if split else None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            ga, gb_rows = native.rows_linear_cat_backward(gy, w.t().contiguous(), y, xa, pooled, pidx.p2v, pre_relu)
+            if split:
+                ga, gb_rows = native.rows_linear_cat_backward_split(gy, g_amax, w.t().contiguous(), y, xa, pooled, pidx.p2v, pre_relu)
+            else:
+                ga, gb_rows = native.rows_linear_cat_backward(gy, w.t().contiguous(), y, xa, pooled, pidx.p2v, pre_relu)
             if ctx.needs_input_grad[1]:
                 gp = native.segment_sum(gb_rows, pidx.seg_offsets, pidx.order, pidx.m).to(pooled.dtype)
         if ctx.needs_input_grad[3] or (has_bias and ctx.needs_input_grad[4]):
-            gw, gb = native.rows_wgrad_cat(gy, xa, pooled, pidx.p2v, dy_mask=y, x_relu=pre_relu, split=True)
+            if split:
+                gw, gb = native.rows_wgrad_cat_split(gy, g_amax, xa, a_amax, pooled, p_amax, pidx.p2v, dy_mask=y, x_relu=pre_relu, split=True)
+            else:
+                gw, gb = native.rows_wgrad_cat(gy, xa, pooled, pidx.p2v, dy_mask=y, x_relu=pre_relu, split=True)
             gb = gb if has_bias else None
         if has_res and ctx.needs_input_grad[5]:
             gres = gy if y is None else gy * (y > 0)
@@ -390,8 +422,10 @@ class _RowsLinearCat(torch.autograd.Function):
 
 
 def linear_rows_cat_available(xa, pooled, layer):
-    """bf16 point rows on the GPU with widths the matrix-core kernel takes; otherwise callers concatenate (parity mode, CPU)."""
-    return (xa.is_cuda and xa.dtype == torch.bfloat16 and pooled.dtype == torch.bfloat16 and xa.shape[0] >= MIN_ROWS_FUSED_LINEAR
+    """bf16 point rows (or fp32 rows in the fp32x3 mode) on the GPU with widths the matrix-core kernels take; otherwise callers concatenate
+    (parity mode, CPU)."""
+    return (xa.is_cuda and xa.dtype == pooled.dtype and (xa.dtype == torch.bfloat16 or (_SPLIT and xa.dtype == torch.float32 and layer.weight.dtype == torch.float32))
+            and xa.shape[0] >= MIN_ROWS_FUSED_LINEAR
             and layer.in_features == xa.shape[1] + pooled.shape[1]
             and native.rows_linear_cat_supported(xa.shape[1], pooled.shape[1], layer.out_features) and not torch.is_autocast_enabled())
 

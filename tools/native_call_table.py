@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Every call into libpcacc_hip.so during one training step: shapes, event-timed duration, bytes of its tensor arguments and
 results (an upper bound of the algorithmic traffic: every operand once) and the resulting GB/s.  Shows which calls sit far from
-the 8 TB/s HBM roofline at their real shapes.  Development aid.  Usage: python tools/native_call_table.py [min_us]"""
+the 8 TB/s HBM roofline at their real shapes.  Development aid.  Usage: [PCACC_DTYPE=bf16|fp32|fp32x3] python tools/native_call_table.py [min_us]"""
 import os, sys, collections, types
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -14,7 +14,7 @@ from pcaccumulation_amd.synthetic import make_sequence
 min_us = float(sys.argv[1]) if len(sys.argv) > 1 else 20.0
 dev = torch.device('cuda:0')
 cfg = default_config('waymo', 'train', n_sweeps=5)
-cfg['misc']['compute_dtype'] = 'bf16'; cfg['pose_estimation']['kpt_sampler'] = 'device'
+cfg['misc']['compute_dtype'] = os.environ.get('PCACC_DTYPE', 'bf16'); cfg['pose_estimation']['kpt_sampler'] = 'device'
 model, opt, loss_fn = bench.build(cfg, dev)
 batcher = DeviceBatcher(cfg)
 scenes = [sample_to_device(make_sequence(i, 5, 160000, cfg), dev) for i in range(4)]
