@@ -394,7 +394,8 @@ int pcacc_conv3x3_wgrad_deep_bf16(const uint16_t *dy, const uint16_t *dy_mask, c
  *       data gradient) + scale_bwd f32 [c_in]; scale = 1 / (power-of-two scale of that output-channel row)
  *   split:  in [n_img,h,w,c_in] f32 (+ in_amax) -> out [n_img,h,w,c_out] f32; in_mask (NULL = none): same shape as `in`, elements of `in`
  *       are read as zero where in_mask <= 0 (ReLU backward of the layer whose gradient `in` is, fused into the staging); wp / wscale from
- *       prepare_weights; bias / relu / frames / kt as pcacc_conv3x3_bf16
+ *       prepare_weights; bias / relu / frames / kt as pcacc_conv3x3_bf16; out_amax (NULL = not wanted): 256 f32 slots, ZEROED by the caller,
+ *       receive partial maxima of |out| -- an absmax256 array of the result for the kernel that consumes it
  *   wgrad_split: dw [c_out][9][c_in] f32, db [c_out] f32 (NULL = not wanted; complete for dt = 0) from dy [n_img,h,w,c_out] f32
  *       (dy_mask as in_mask) and x [n_img,h,w,c_in] f32 with their absmax256 arrays; dt / frames as pcacc_conv3x3_wgrad_bf16
  * ---------------------------------------------------------------------------------------------- */
@@ -403,8 +404,8 @@ int pcacc_conv3x3_split_prepare_weights(const float *w, int32_t c_out, int32_t c
                                         uint16_t *out_fwd, float *scale_fwd, uint16_t *out_bwd, float *scale_bwd, void *stream);
 int pcacc_conv3x3_split_supported(int32_t h, int32_t w, int32_t c_in, int32_t c_out);
 int pcacc_conv3x3_split(const float *in, const float *in_amax, const float *in_mask, const uint16_t *wp, const float *wscale,
-                        const float *bias, float *out, int32_t n_img, int32_t frames, int32_t h, int32_t w, int32_t c_in, int32_t c_out,
-                        int32_t kt, int32_t relu, void *stream);
+                        const float *bias, float *out, float *out_amax, int32_t n_img, int32_t frames, int32_t h, int32_t w, int32_t c_in,
+                        int32_t c_out, int32_t kt, int32_t relu, void *stream);
 int pcacc_conv3x3_wgrad_split_workspace_bytes(int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_out, size_t *bytes /*host*/);
 int pcacc_conv3x3_wgrad_split(const float *dy, const float *dy_amax, const float *dy_mask, const float *x, const float *x_amax, float *dw,
                               float *db, int32_t n_img, int32_t frames, int32_t dt, int32_t h, int32_t w, int32_t c_in, int32_t c_out,
@@ -412,15 +413,16 @@ int pcacc_conv3x3_wgrad_split(const float *dy, const float *dy_amax, const float
 /* The per-point linear layers in the fp32x3 mode (csrc/mlp_split.hip): the contracts of pcacc_rows_linear_bf16 / _cat_bf16 /
  * pcacc_rows_wgrad_bf16 / _cat_bf16 above on fp32 rows (x, masks, residual, y all f32; k, n in {32, 64, 128}), products from scaled
  * fp16 hi / lo halves as in pcacc_conv3x3_split; every fp32 row tensor that is split comes with its pcacc_absmax256 array
- * (x_amax; two-piece rows: one per piece; dy_amax), the weight matrix is scaled per output row inside the kernel.  nn.Linear of
+ * (x_amax; two-piece rows: one per piece; dy_amax), the weight matrix is scaled per output row inside the kernel; y_amax (NULL = not
+ * wanted; 256 f32 slots zeroed by the caller) receives partial maxima of |y| (of y and y2 together), as out_amax above.  nn.Linear of
  * models/pillar_encoder.py:13-55,113-122, models/stpn.py:94-102, models/tpointnet.py:176-196 (fp32 in the reference). */
 int pcacc_rows_linear_split(const float *x, const float *x_amax, const float *in_mask, const float *w, const float *bias,
-                            const float *residual, const float *out_mask, float *y, int64_t rows, int32_t k, int32_t n, int32_t flags,
-                            void *stream);
+                            const float *residual, const float *out_mask, float *y, float *y_amax, int64_t rows, int32_t k, int32_t n,
+                            int32_t flags, void *stream);
 int pcacc_rows_linear_cat_split(const float *xa, const float *xa_amax, const float *xb, const float *xb_amax, const int32_t *b_index,
                                 int32_t ka, const float *in_mask, const float *w, const float *bias, const float *residual,
-                                const float *out_mask_a, const float *out_mask_b, float *y, float *y2, int32_t na, int64_t rows, int32_t k,
-                                int32_t n, int32_t flags, void *stream);
+                                const float *out_mask_a, const float *out_mask_b, float *y, float *y2, int32_t na, float *y_amax, int64_t rows,
+                                int32_t k, int32_t n, int32_t flags, void *stream);
 int pcacc_rows_wgrad_split_workspace_bytes(int64_t rows, int32_t k, int32_t n, size_t *bytes /*host*/);
 int pcacc_rows_wgrad_split(const float *dy, const float *dy_amax, const float *dy_mask, const float *x, const float *x_amax, int32_t x_relu,
                            int64_t rows, int32_t k, int32_t n, float *dw_aug, void *workspace, size_t workspace_bytes, void *stream);

@@ -44,33 +44,50 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
 // ---- absolute maximum of a tensor: 256 partial maxima, every one always written (no initialisation, no second launch); the consumers
 // reduce the 256 values themselves (csp_scale_from_parts) ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void absmax256_kernel(const float *__restrict__ x, int64_t n, float *__restrict__ parts)
+#define CSP_AMAX_THREADS 1024
+__global__ __launch_bounds__(CSP_AMAX_THREADS) void absmax256_kernel(const float *__restrict__ x, int64_t n, float *__restrict__ parts)
 {
-    float m = 0.f;
+    // 256 workgroups x 1024 threads x 4 independent 16-byte loads per iteration = 16 MB in flight: an HBM stream (the first version,
+    // one load per thread of 256 x 256, ran at 1.9 TB/s and cost 10 ms of a 58 ms step)
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+    bool bad = false;
     const int64_t n4 = n >> 2;
     const float4 *x4 = reinterpret_cast<const float4 *>(x);
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        const float4 v = x4[i];
-        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));     // fmaxf drops NaN: see the note below
-        if (!(v.x == v.x && v.y == v.y && v.z == v.z && v.w == v.w)) m = __builtin_inff();       // a NaN must poison the result, like fp32 would
+    const int64_t stride = (int64_t)gridDim.x * CSP_AMAX_THREADS;
+    int64_t i = (int64_t)blockIdx.x * CSP_AMAX_THREADS + threadIdx.x;
+    auto fold = [&](float &m, const float4 &v) {
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));        // fmaxf drops NaN ...
+        bad |= !(v.x == v.x && v.y == v.y && v.z == v.z && v.w == v.w);                            // ... but a NaN must poison the result
+    };
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const float4 a = x4[i], b = x4[i + stride], c = x4[i + 2 * stride], d = x4[i + 3 * stride];
+        fold(m0, a); fold(m1, b); fold(m2, c); fold(m3, d);
     }
+    for (; i < n4; i += stride) fold(m0, x4[i]);
+    float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const float v = x[(n4 << 2) + threadIdx.x];
         m = fmaxf(m, fabsf(v));
-        if (v != v) m = __builtin_inff();
+        bad |= v != v;
     }
+    if (bad) m = __builtin_inff();
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
-    __shared__ float sm[4];
+    __shared__ float sm[CSP_AMAX_THREADS / 64];
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) parts[blockIdx.x] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    if (threadIdx.x == 0) {
+        float r = sm[0];
+#pragma unroll
+        for (int w = 1; w < CSP_AMAX_THREADS / 64; ++w) r = fmaxf(r, sm[w]);
+        parts[blockIdx.x] = r;
+    }
 }
 
 extern "C" int pcacc_absmax256(const float *x, int64_t n, float *parts, void *stream)
 {
     if (!x || !parts || n < 0 || (reinterpret_cast<uintptr_t>(x) & 15)) return PCACC_E_ARG;
-    hipLaunchKernelGGL(absmax256_kernel, dim3(CSP_AMAX_PARTS), dim3(256), 0, pcacc_stream(stream), x, n, parts);
+    hipLaunchKernelGGL(absmax256_kernel, dim3(CSP_AMAX_PARTS), dim3(CSP_AMAX_THREADS), 0, pcacc_stream(stream), x, n, parts);
     PCACC_CHECK_LAUNCH();
     return 0;
 }
@@ -189,9 +206,9 @@ template <int CS, int NW, int NGW, int MT>
 __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float *__restrict__ in, const float *__restrict__ in_amax,
                                                                     const float *__restrict__ in_mask, const uint16_t *__restrict__ wp,
                                                                     const float *__restrict__ wscale, const float *__restrict__ bias,
-                                                                    float *__restrict__ out, int n_img, int frames, int h, int w, int c_in,
-                                                                    int c_out, int kt, int relu, int rows, int bw, int tiles_y, int tiles_x,
-                                                                    int co_groups)
+                                                                    float *__restrict__ out, float *__restrict__ out_amax, int n_img, int frames,
+                                                                    int h, int w, int c_in, int c_out, int kt, int relu, int rows, int bw,
+                                                                    int tiles_y, int tiles_x, int co_groups)
 {
     constexpr int PS = CS + 8;                                 // padded LDS row (elements)
     constexpr int MG = 8 / NGW;                                // waves along the pixel dimension
@@ -383,6 +400,7 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float 
     // epilogue: lane = pixel, register quad g of tile n = channels n*32 + 8g + 4*lh .. +3 of this wave's NW * 32
     const int cw0 = co0 + ngw * NW * 32;
     const float inv_sx = 1.f / sx;
+    float omax = 0.f;                                          // |output| maximum of this lane (NaN -> inf), for the consumer's scale
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
         if (pyx[j] < 0) continue;
@@ -400,7 +418,14 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float 
                                        acc[j][n][4 * g + 3] * sc.w + bv.w);
                 if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
                 *reinterpret_cast<float4 *>(dst + c) = v;
+                omax = fmaxf(fmaxf(omax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                if (!(v.x == v.x && v.y == v.y && v.z == v.z && v.w == v.w)) omax = __builtin_inff();
             }
+    }
+    if (out_amax) {                                            // uniform: one atomic per wave into one of 256 slots (zeroed by the caller)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) omax = fmaxf(omax, __shfl_xor(omax, d, 64));
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned *>(out_amax) + (blockIdx.x & (CSP_AMAX_PARTS - 1)), __float_as_uint(omax));
     }
 }
 
@@ -470,15 +495,15 @@ static bool conv_split_plan(int n_img, int h, int w, int c_in, int c_out, int kt
 
 template <int CS, int NW, int NGW, int MT>
 static int conv_split_launch(const ConvSplitPlan &p, const float *in, const float *in_amax, const float *in_mask, const uint16_t *wp,
-                             const float *wscale, const float *bias, float *out, int n_img, int frames, int h, int w, int c_in, int c_out,
-                             int kt, int relu, hipStream_t st)
+                             const float *wscale, const float *bias, float *out, float *out_amax, int n_img, int frames, int h, int w, int c_in,
+                             int c_out, int kt, int relu, hipStream_t st)
 {
     auto kern = conv3x3_split_kernel<CS, NW, NGW, MT>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds) != hipSuccess)
         return PCACC_E_LAUNCH;
     if (p.blocks > 0x7fffffff) return PCACC_E_ARG;
-    hipLaunchKernelGGL(kern, dim3((unsigned)p.blocks), dim3(CSP_THREADS), p.lds, st, in, in_amax, in_mask, wp, wscale, bias, out, n_img, frames,
-                       h, w, c_in, c_out, kt, relu, p.rows, p.bw, p.tiles_y, p.tiles_x, p.co_groups);
+    hipLaunchKernelGGL(kern, dim3((unsigned)p.blocks), dim3(CSP_THREADS), p.lds, st, in, in_amax, in_mask, wp, wscale, bias, out, out_amax, n_img,
+                       frames, h, w, c_in, c_out, kt, relu, p.rows, p.bw, p.tiles_y, p.tiles_x, p.co_groups);
     PCACC_CHECK_LAUNCH();
     return 0;
 }
@@ -490,8 +515,8 @@ extern "C" int pcacc_conv3x3_split_supported(int32_t h, int32_t w, int32_t c_in,
 }
 
 extern "C" int pcacc_conv3x3_split(const float *in, const float *in_amax, const float *in_mask, const uint16_t *wp, const float *wscale,
-                                   const float *bias, float *out, int32_t n_img, int32_t frames, int32_t h, int32_t w, int32_t c_in,
-                                   int32_t c_out, int32_t kt, int32_t relu, void *stream)
+                                   const float *bias, float *out, float *out_amax, int32_t n_img, int32_t frames, int32_t h, int32_t w,
+                                   int32_t c_in, int32_t c_out, int32_t kt, int32_t relu, void *stream)
 {
     ConvSplitPlan p;
     if (!in || !in_amax || !wp || !wscale || !out || n_img < 1 || (kt != 1 && kt != 3) || frames < 1 || n_img % frames ||
@@ -503,7 +528,7 @@ extern "C" int pcacc_conv3x3_split(const float *in, const float *in_amax, const 
     hipStream_t st = pcacc_stream(stream);
 #define CSP_CASE(CSV, NWV, NGWV, MTV)                                          \
     if (p.cs == CSV && p.nw == NWV && p.ngw == NGWV && p.mt == MTV)            \
-        return conv_split_launch<CSV, NWV, NGWV, MTV>(p, in, in_amax, in_mask, wp, wscale, bias, out, n_img, frames, h, w, c_in, c_out, kt, relu, st)
+        return conv_split_launch<CSV, NWV, NGWV, MTV>(p, in, in_amax, in_mask, wp, wscale, bias, out, out_amax, n_img, frames, h, w, c_in, c_out, kt, relu, st)
     CSP_CASE(64, 2, 2, 1); CSP_CASE(64, 2, 2, 2); CSP_CASE(64, 2, 1, 1); CSP_CASE(64, 2, 1, 2);
     CSP_CASE(64, 1, 1, 1); CSP_CASE(64, 1, 1, 2); CSP_CASE(64, 1, 1, 3);
     CSP_CASE(32, 2, 2, 1); CSP_CASE(32, 2, 2, 2); CSP_CASE(32, 2, 1, 1); CSP_CASE(32, 2, 1, 2);
@@ -538,7 +563,9 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_wgrad_split_kernel(const 
                                                                           int n_img, int frames, int dt, int h, int w, int c_in, int c_out,
                                                                           int rows, int bw, int tiles_y, int tiles_x, int ci_blocks, int slots)
 {
-    constexpr int CO = CO_T * 32, CI = CI_T * 32, PAIRS = CO_T * CI_T, G = 8 / PAIRS, NT = (9 + G - 1) / G;
+    // 32 x 32 blocks: one (co, ci) pair -- the 8 waves are 2 halves of the 16-pixel steps x 4 tap groups (3 | 2 | 2 | 2 taps) and each half
+    // keeps its own partial slot; with 8 tap groups (2 | 1 x 7 taps) wave 0 did twice the work of the others.
+    constexpr int CO = CO_T * 32, CI = CI_T * 32, PAIRS = CO_T * CI_T, HALVES = PAIRS == 1 ? 2 : 1, G = 8 / (PAIRS * HALVES), NT = (9 + G - 1) / G;
     constexpr int YS = pcacc_tr_stride(CO), XS = pcacc_tr_stride(CI);
     constexpr int SLOT = CO * 9 * CI + CO;
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
@@ -551,7 +578,7 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_wgrad_split_kernel(const 
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lp = lane & 31, lh = lane >> 5;
-    const int pair = wave % PAIRS, grp = wave / PAIRS;
+    const int pair = wave % PAIRS, grp = (wave / PAIRS) % G, half = wave / (PAIRS * G);
     const int ct = pair / CI_T, it = pair % CI_T;
     const int block = blockIdx.x / slots, slot = blockIdx.x % slots;
     const int co0 = (block / ci_blocks) * CO, ci0 = (block % ci_blocks) * CI;
@@ -637,7 +664,7 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_wgrad_split_kernel(const 
         while (next < n_jobs && !job_valid(next)) next += slots;
         if (next < n_jobs) fetch(next);
         job = next;
-        for (int s = 0; s < n_steps; ++s) {
+        for (int s = half; s < n_steps; s += HALVES) {
             const int r0 = s * 16 + tr_row;
             const uint16_t *pa = sdy + r0 * YS + ct * 32 + tr_col;
             csp_frag ah, al;
@@ -669,7 +696,7 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_wgrad_split_kernel(const 
         }
     }
     // slot of this workgroup: [CO][9][CI] then [CO] bias sums; D has lane = ci, register quads = co
-    float *mine = partial + (int64_t)blockIdx.x * SLOT;
+    float *mine = partial + ((int64_t)blockIdx.x * HALVES + half) * SLOT;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int tap = grp + j * G;
@@ -685,7 +712,9 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_wgrad_split_kernel(const 
     if (it == 0 && lh == 0) mine[CO * 9 * CI + ct * 32 + lp] = bsum;
 }
 
-// out[co][tap][ci] (full tensor) and db[co] from the per-workgroup slots: one thread per output element, its block's slots summed
+// out[co][tap][ci] (full tensor) and db[co] from the per-workgroup slots, scales removed.  A workgroup = 64 output elements x 4 slot groups
+// (wave g sums the slots p = g, g + 4, ...), combined through LDS in a fixed order: the 32 x 32 layers have 9 248 elements and 256 slots --
+// with one thread per element the launch was 37 workgroups walking 256 partials each (40 us, 2 ms per step over 52 launches).
 __global__ __launch_bounds__(256) void conv_wgrad_split_reduce_kernel(const float *__restrict__ partial, int slots, int c_in, int c_out,
                                                                       int cob, int cib, const float *__restrict__ dy_amax,
                                                                       const float *__restrict__ x_amax, float *__restrict__ dw,
@@ -694,25 +723,35 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_reduce_kernel(const floa
     const float inv_y = 1.f / csp_scale_from_parts(dy_amax), inv_yx = inv_y / csp_scale_from_parts(x_amax);
     const int slot_elems = cob * 9 * cib + cob, ci_blocks = c_in / cib;
     const int64_t n_w = (int64_t)c_out * 9 * c_in;
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t e = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int grp = threadIdx.x >> 6;
+    __shared__ float sm[4][64];
+    float s = 0.f;
+    const float *src = nullptr;
     if (e < n_w) {
         const int ci = (int)(e % c_in), tap = (int)((e / c_in) % 9), co = (int)(e / ((int64_t)9 * c_in));
         const int block = (co / cob) * ci_blocks + ci / cib;
-        const float *src = partial + (int64_t)block * slots * slot_elems + ((int64_t)(co % cob) * 9 + tap) * cib + ci % cib;
+        src = partial + (int64_t)block * slots * slot_elems + ((int64_t)(co % cob) * 9 + tap) * cib + ci % cib;
+    } else if (e < n_w + c_out) {
+        const int co = (int)(e - n_w);
+        src = partial + (int64_t)((co / cob) * ci_blocks) * slots * slot_elems + cob * 9 * cib + co % cob;   // ci block 0 carries the bias sums
+    }
+    if (src) {
         float s0 = 0.f, s1 = 0.f;
-        int p = 0;
-        for (; p + 2 <= slots; p += 2) {
+        int p = grp;
+        for (; p + 4 < slots; p += 8) {
             s0 += src[(int64_t)p * slot_elems];
-            s1 += src[(int64_t)(p + 1) * slot_elems];
+            s1 += src[(int64_t)(p + 4) * slot_elems];
         }
         if (p < slots) s0 += src[(int64_t)p * slot_elems];
-        dw[e] = (s0 + s1) * inv_yx;
-    } else if (e < n_w + c_out && db) {
-        const int co = (int)(e - n_w);
-        const float *src = partial + (int64_t)((co / cob) * ci_blocks) * slots * slot_elems + cob * 9 * cib + co % cob;   // ci block 0 carries the bias sums
-        float s = 0.f;
-        for (int p = 0; p < slots; ++p) s += src[(int64_t)p * slot_elems];
-        db[co] = s * inv_y;
+        s = s0 + s1;
+    }
+    sm[grp][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (grp == 0 && src) {
+        const float t = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+        if (e < n_w) dw[e] = t * inv_yx;
+        else if (db) db[e - n_w] = t * inv_y;
     }
 }
 
@@ -765,11 +804,13 @@ static bool conv_wsplit_plan(int n_img, int h, int w, int c_in, int c_out, ConvS
     return found;
 }
 
+static int conv_wsplit_halves(const ConvSplitWPlan &p) { return (p.cob == 32 && p.cib == 32) ? 2 : 1; }   // partial slots per workgroup
+
 extern "C" int pcacc_conv3x3_wgrad_split_workspace_bytes(int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_out, size_t *bytes)
 {
     ConvSplitWPlan p;
     if (!bytes || !conv_wsplit_plan(n_img, h, w, c_in, c_out, &p)) return PCACC_E_ARG;
-    *bytes = (size_t)p.blocks * p.slots * (p.cob * 9 * p.cib + p.cob) * sizeof(float);
+    *bytes = (size_t)p.blocks * p.slots * conv_wsplit_halves(p) * (p.cob * 9 * p.cib + p.cob) * sizeof(float);
     return 0;
 }
 
@@ -782,7 +823,7 @@ extern "C" int pcacc_conv3x3_wgrad_split(const float *dy, const float *dy_amax, 
         !conv_wsplit_plan(n_img, h, w, c_in, c_out, &p))
         return PCACC_E_ARG;
     if ((int64_t)n_img * p.tiles_y * p.tiles_x > 0x7fffffff) return PCACC_E_ARG;
-    const size_t need = (size_t)p.blocks * p.slots * (p.cob * 9 * p.cib + p.cob) * sizeof(float);
+    const size_t need = (size_t)p.blocks * p.slots * conv_wsplit_halves(p) * (p.cob * 9 * p.cib + p.cob) * sizeof(float);
     if (workspace_bytes < need) return PCACC_E_WORKSPACE;
     hipStream_t st = pcacc_stream(stream);
     float *partial = static_cast<float *>(workspace);
@@ -800,8 +841,8 @@ extern "C" int pcacc_conv3x3_wgrad_split(const float *dy, const float *dy_amax, 
     CSW_CASE(1, 1) else CSW_CASE(1, 2) else CSW_CASE(2, 1) else CSW_CASE(2, 2) else return PCACC_E_ARG;
 #undef CSW_CASE
     const int64_t elems = (int64_t)c_out * 9 * c_in + c_out;
-    hipLaunchKernelGGL(conv_wgrad_split_reduce_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, partial, p.slots, c_in, c_out,
-                       p.cob, p.cib, dy_amax, x_amax, dw, db);
+    hipLaunchKernelGGL(conv_wgrad_split_reduce_kernel, dim3((unsigned)((elems + 63) / 64)), dim3(256), 0, st, partial, p.slots * conv_wsplit_halves(p), c_in,
+                       c_out, p.cob, p.cib, dy_amax, x_amax, dw, db);
     PCACC_CHECK_LAUNCH();
     return 0;
 }

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(MS_THREADS) void rows_linear_split_kernel(const flo
                                                                        const float *__restrict__ W, const float *__restrict__ bias,
                                                                        const float *__restrict__ residual, const float *__restrict__ out_mask,
                                                                        float *__restrict__ Y, int64_t rows, int flags, MsPieces xs2, MsPieces ms2,
-                                                                       float *__restrict__ Y2, int na)
+                                                                       float *__restrict__ Y2, int na, float *__restrict__ y_amax)
 {
     constexpr int N = CT * 32;
     constexpr int XS = K + 8;                                  // padded LDS row (elements) of the 16-bit planes
@@ -158,6 +158,7 @@ __global__ __launch_bounds__(MS_THREADS) void rows_linear_split_kernel(const flo
         }
     };
 
+    float omax = 0.f;                                                         // |output| maximum of this thread (NaN -> inf)
     int64_t tile = blockIdx.x;
     if (tile < n_tiles) fetch(tile);
     for (; tile < n_tiles; tile += gridDim.x) {
@@ -222,10 +223,17 @@ __global__ __launch_bounds__(MS_THREADS) void rows_linear_split_kernel(const flo
             const int64_t row = e / N;
             const int col = (int)(e % N);
             if (out_mask) v = ms_mask4(v, *reinterpret_cast<const float4 *>(ms_piece(out_mask, ms2, N, row, col)));
+            omax = fmaxf(fmaxf(omax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+            if (!(v.x == v.x && v.y == v.y && v.z == v.z && v.w == v.w)) omax = __builtin_inff();
             if (!Y2) *reinterpret_cast<float4 *>(Y + e) = v;
             else if (col < na) *reinterpret_cast<float4 *>(Y + row * na + col) = v;
             else *reinterpret_cast<float4 *>(Y2 + row * (N - na) + (col - na)) = v;
         }
+    }
+    if (y_amax) {                                                             // uniform: the result's maximum for its consumer's scale --
+#pragma unroll                                                                // one atomic per wave into one of 256 slots (zeroed by the caller)
+        for (int d = 32; d >= 1; d >>= 1) omax = fmaxf(omax, __shfl_xor(omax, d, 64));
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned *>(y_amax) + (blockIdx.x & 255), __float_as_uint(omax));
     }
 }
 
@@ -240,7 +248,7 @@ static size_t ms_linear_lds()
 template <int K, int CT>
 static int ms_launch(const float *x, const float *x_amax, const float *x_amax2, const float *in_mask, const float *w, const float *bias,
                      const float *residual, const float *out_mask, float *y, int64_t rows, int flags, hipStream_t st, MsPieces xs2, MsPieces ms2,
-                     float *y2, int na)
+                     float *y2, int na, float *y_amax)
 {
     const size_t lds = ms_linear_lds<K, CT>();
     auto kern = rows_linear_split_kernel<K, CT>;
@@ -253,17 +261,17 @@ static int ms_launch(const float *x, const float *x_amax, const float *x_amax2, 
     int64_t grid = (int64_t)PCACC_CUS * per_cu;
     if (grid > n_tiles) grid = n_tiles;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(MS_THREADS), lds, st, x, x_amax, x_amax2, in_mask, w, bias, residual, out_mask, y, rows, flags,
-                       xs2, ms2, y2, na);
+                       xs2, ms2, y2, na, y_amax);
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
 }
 
 static int ms_dispatch(const float *x, const float *x_amax, const float *x_amax2, const float *in_mask, const float *w, const float *bias,
                        const float *residual, const float *out_mask, float *y, int64_t rows, int k, int n, int flags, hipStream_t st,
-                       MsPieces xs2, MsPieces ms2, float *y2, int na)
+                       MsPieces xs2, MsPieces ms2, float *y2, int na, float *y_amax)
 {
 #define MS_CASE(KK, CTV) \
-    if (k == KK && n == CTV * 32) return ms_launch<KK, CTV>(x, x_amax, x_amax2, in_mask, w, bias, residual, out_mask, y, rows, flags, st, xs2, ms2, y2, na)
+    if (k == KK && n == CTV * 32) return ms_launch<KK, CTV>(x, x_amax, x_amax2, in_mask, w, bias, residual, out_mask, y, rows, flags, st, xs2, ms2, y2, na, y_amax)
     MS_CASE(32, 1); MS_CASE(32, 2); MS_CASE(32, 4);
     MS_CASE(64, 1); MS_CASE(64, 2); MS_CASE(64, 4);
     MS_CASE(128, 1); MS_CASE(128, 2); MS_CASE(128, 4);
@@ -272,14 +280,14 @@ static int ms_dispatch(const float *x, const float *x_amax, const float *x_amax2
 }
 
 extern "C" int pcacc_rows_linear_split(const float *x, const float *x_amax, const float *in_mask, const float *w, const float *bias,
-                                       const float *residual, const float *out_mask, float *y, int64_t rows, int32_t k, int32_t n,
+                                       const float *residual, const float *out_mask, float *y, float *y_amax, int64_t rows, int32_t k, int32_t n,
                                        int32_t flags, void *stream)
 {
     if (rows < 0 || (k != 32 && k != 64 && k != 128) || (n != 32 && n != 64 && n != 128)) return PCACC_E_ARG;
     if (rows == 0) return PCACC_OK;
     if (!x || !x_amax || !w || !y) return PCACC_E_ARG;
     const MsPieces none{nullptr, nullptr, 0};
-    return ms_dispatch(x, x_amax, nullptr, in_mask, w, bias, residual, out_mask, y, rows, k, n, flags, pcacc_stream(stream), none, none, nullptr, 0);
+    return ms_dispatch(x, x_amax, nullptr, in_mask, w, bias, residual, out_mask, y, rows, k, n, flags, pcacc_stream(stream), none, none, nullptr, 0, y_amax);
 }
 
 // The same layer on rows made of two pieces (see MsPieces; the fp32 twin of pcacc_rows_linear_cat_bf16).  Forward: x = cat(xa [rows,ka],
@@ -287,8 +295,8 @@ extern "C" int pcacc_rows_linear_split(const float *x, const float *x_amax, cons
 // y2 [rows,n-na], masked where the forward input cat(out_mask_a, out_mask_b[b_index]) was <= 0.
 extern "C" int pcacc_rows_linear_cat_split(const float *xa, const float *xa_amax, const float *xb, const float *xb_amax, const int32_t *b_index,
                                            int32_t ka, const float *in_mask, const float *w, const float *bias, const float *residual,
-                                           const float *out_mask_a, const float *out_mask_b, float *y, float *y2, int32_t na, int64_t rows,
-                                           int32_t k, int32_t n, int32_t flags, void *stream)
+                                           const float *out_mask_a, const float *out_mask_b, float *y, float *y2, int32_t na, float *y_amax,
+                                           int64_t rows, int32_t k, int32_t n, int32_t flags, void *stream)
 {
     if (rows < 0 || (k != 32 && k != 64 && k != 128) || (n != 32 && n != 64 && n != 128)) return PCACC_E_ARG;
     if (xb && (ka <= 0 || ka >= k || ka % 8 || !xb_amax)) return PCACC_E_ARG;
@@ -298,7 +306,7 @@ extern "C" int pcacc_rows_linear_cat_split(const float *xa, const float *xa_amax
     if (!xa || !xa_amax || !w || !y) return PCACC_E_ARG;
     const MsPieces xs2{xb, b_index, ka}, ms2{out_mask_b, b_index, na};
     return ms_dispatch(xa, xa_amax, xb ? xb_amax : nullptr, in_mask, w, bias, residual, out_mask_a, y, rows, k, n, flags, pcacc_stream(stream), xs2,
-                       ms2, y2, na);
+                       ms2, y2, na, y_amax);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------

@@ -601,8 +601,26 @@ def absmax256(t):
     out = torch.empty((256,), dtype=torch.float32, device=t.device)
     if not t.is_cuda or t.dtype != torch.float32:
         raise NativeError('absmax256: float32 GPU tensor expected, got %s on %s' % (t.dtype, t.device))
+    if not (t.is_contiguous() or torch.ops.aten.is_non_overlapping_and_dense(t)):
+        t = t.contiguous()                                     # the kernel walks the storage: it must hold exactly the tensor's elements
     _check(lib().pcacc_absmax256(ctypes.c_void_p(t.data_ptr()), _i64(t.numel()), _dev(out), _stream()), 'absmax256')
     return out
+
+
+_ZERO_POOL = {}
+
+
+def _zero256(device):
+    """A zeroed [256] f32 array for a kernel's output maxima: rows of a [128, 256] block cleared by ONE fill launch (a torch.zeros per
+    kernel call was ~100 fill launches per step).  A row is handed out once; the block lives as long as any of its rows."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0)
+    blk = _ZERO_POOL.get(key)
+    if blk is None or blk[1] >= blk[0].shape[0]:
+        blk = [torch.zeros((128, 256), dtype=torch.float32, device=device), 0]
+        _ZERO_POOL[key] = blk
+    row = blk[0][blk[1]]
+    blk[1] += 1
+    return row
 
 
 def conv3x3_split_supported(h, w, c_in, c_out):
@@ -626,9 +644,10 @@ def conv3x3_split_prepare_weights(weight):
     return (fwd, sf), (bwd, sb)
 
 
-def conv3x3_split(x_rows, wps, bias, frames, relu, mask=None, amax=None):
+def conv3x3_split(x_rows, wps, bias, frames, relu, mask=None, amax=None, want_amax=False):
     """x_rows f32 [n_img,h,w,c_in] contiguous, wps = (planes, scale) from conv3x3_split_prepare_weights -> f32 [n_img,h,w,c_out]; mask as in
-    conv3x3 (f32); amax = absmax256(x_rows) when the caller has it already."""
+    conv3x3 (f32); amax = absmax256(x_rows) when the caller has it already.  want_amax: -> (out, absmax256 array of out), the maxima
+    collected by the kernel's epilogue."""
     wp, wscale = wps
     n_img, h, w, c_in = x_rows.shape
     _, taps, c_out, wc_in = wp.shape
@@ -640,12 +659,13 @@ def conv3x3_split(x_rows, wps, bias, frames, relu, mask=None, amax=None):
     if amax is None:
         amax = absmax256(x_rows)
     out = torch.empty((n_img, h, w, c_out), dtype=torch.float32, device=x_rows.device)
+    out_amax = _zero256(x_rows.device) if want_amax else None
     _check(lib().pcacc_conv3x3_split(xp, _dev(amax, torch.float32, 'amax'), _dev(mask, torch.float32, 'mask') if mask is not None else None,
                                      _dev(wp, torch.float16, 'wp'), _dev(wscale, torch.float32, 'wscale'),
                                      _dev(bias, torch.float32, 'bias') if bias is not None else None,
-                                     _dev(out), int(n_img), int(frames), int(h), int(w), int(c_in), int(c_out), taps // 9,
-                                     1 if relu else 0, _stream()), 'conv3x3_split')
-    return out
+                                     _dev(out), _dev(out_amax) if want_amax else None, int(n_img), int(frames), int(h), int(w), int(c_in), int(c_out),
+                                     taps // 9, 1 if relu else 0, _stream()), 'conv3x3_split')
+    return (out, out_amax) if want_amax else out
 
 
 def conv3x3_wgrad_split(dy_rows, x_rows, frames=1, dt=0, mask=None, dy_amax=None, x_amax=None):
@@ -674,18 +694,19 @@ def rows_split_supported(k, n):
     return k in (32, 64, 128) and n in (32, 64, 128)
 
 
-def rows_linear_split(x, x_amax, w, bias=None, residual=None, pre_relu=False, post_relu=False, in_mask=None, out_mask=None):
+def rows_linear_split(x, x_amax, w, bias=None, residual=None, pre_relu=False, post_relu=False, in_mask=None, out_mask=None, want_amax=False):
     """rows_linear on f32 rows at fp32 accuracy on the matrix cores; x_amax = absmax256(x) (of the tensor before ReLU / mask: an upper bound
-    is what the scale needs)."""
+    is what the scale needs).  want_amax: -> (y, absmax256 array of y) from the kernel's store phase."""
     rows, k = x.shape
     n = w.shape[0]
     y = torch.empty((rows, n), dtype=torch.float32, device=x.device)
+    y_amax = _zero256(x.device) if want_amax else None
     flags = (1 if pre_relu else 0) | (2 if post_relu else 0)
     _check(lib().pcacc_rows_linear_split(_dev(x, torch.float32, 'x'), _dev(x_amax, torch.float32, 'x_amax'), _opt(in_mask, torch.float32, 'in_mask'),
                                          _dev(w, torch.float32, 'w'), _opt(bias, torch.float32, 'bias'), _opt(residual, torch.float32, 'residual'),
-                                         _opt(out_mask, torch.float32, 'out_mask'), _dev(y), _i64(rows), int(k), int(n), flags, _stream()),
-           'rows_linear_split')
-    return y
+                                         _opt(out_mask, torch.float32, 'out_mask'), _dev(y), _opt(y_amax, torch.float32, 'y_amax'), _i64(rows), int(k),
+                                         int(n), flags, _stream()), 'rows_linear_split')
+    return (y, y_amax) if want_amax else y
 
 
 def rows_wgrad_split(dy, dy_amax, x, x_amax, dy_mask=None, x_relu=False, split=False):
@@ -702,17 +723,19 @@ def rows_wgrad_split(dy, dy_amax, x, x_amax, dy_mask=None, x_relu=False, split=F
     return _split_aug(out, n, k, split, rows > 0)
 
 
-def rows_linear_cat_split(xa, xa_amax, xb, xb_amax, b_index, w, bias=None, residual=None, pre_relu=False, post_relu=False):
+def rows_linear_cat_split(xa, xa_amax, xb, xb_amax, b_index, w, bias=None, residual=None, pre_relu=False, post_relu=False, want_amax=False):
     """y = post(pre(cat(xa, xb[b_index])) @ w^T + bias + residual), f32 rows, the concatenation read in place (fp32x3)."""
     rows, ka = xa.shape
     k, n = ka + xb.shape[1], w.shape[0]
     y = torch.empty((rows, n), dtype=torch.float32, device=xa.device)
+    y_amax = _zero256(xa.device) if want_amax else None
     flags = (1 if pre_relu else 0) | (2 if post_relu else 0)
     _check(lib().pcacc_rows_linear_cat_split(_dev(xa, torch.float32, 'xa'), _dev(xa_amax, torch.float32, 'xa_amax'), _dev(xb, torch.float32, 'xb'),
                                              _dev(xb_amax, torch.float32, 'xb_amax'), _opt(b_index, torch.int32, 'b_index'), int(ka), None,
                                              _dev(w, torch.float32, 'w'), _opt(bias, torch.float32, 'bias'), _opt(residual, torch.float32, 'residual'),
-                                             None, None, _dev(y), None, 0, _i64(rows), int(k), int(n), flags, _stream()), 'rows_linear_cat_split')
-    return y
+                                             None, None, _dev(y), None, 0, _opt(y_amax, torch.float32, 'y_amax'), _i64(rows), int(k), int(n), flags,
+                                             _stream()), 'rows_linear_cat_split')
+    return (y, y_amax) if want_amax else y
 
 
 def rows_linear_cat_backward_split(gy, gy_amax, w_t, dy_mask, xa, xb, b_index, pre_relu):
@@ -722,13 +745,14 @@ def rows_linear_cat_backward_split(gy, gy_amax, w_t, dy_mask, xa, xb, b_index, p
     ka, kb = xa.shape[1], xb.shape[1]
     ga = torch.empty((rows, ka), dtype=torch.float32, device=gy.device)
     gb = torch.empty((rows, kb), dtype=torch.float32, device=gy.device)
+    g_amax = _zero256(gy.device)                                               # of both pieces together: an upper bound for either
     _check(lib().pcacc_rows_linear_cat_split(_dev(gy, torch.float32, 'gy'), _dev(gy_amax, torch.float32, 'gy_amax'), None, None,
                                              _opt(b_index, torch.int32, 'b_index'), 0, _opt(dy_mask, torch.float32, 'dy_mask'),
                                              _dev(w_t, torch.float32, 'w_t'), None, None,
                                              _dev(xa, torch.float32, 'xa') if pre_relu else None, _dev(xb, torch.float32, 'xb') if pre_relu else None,
-                                             _dev(ga), _dev(gb), int(ka), _i64(rows), int(n), int(ka + kb), 0, _stream()),
+                                             _dev(ga), _dev(gb), int(ka), _dev(g_amax), _i64(rows), int(n), int(ka + kb), 0, _stream()),
            'rows_linear_cat_backward_split')
-    return ga, gb
+    return ga, gb, g_amax
 
 
 def rows_wgrad_cat_split(dy, dy_amax, xa, xa_amax, xb, xb_amax, b_index, dy_mask=None, x_relu=False, split=False):

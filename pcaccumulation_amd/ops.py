@@ -339,8 +339,9 @@ class _RowsLinear(torch.autograd.Function):
                  and w.dtype == torch.float32 and (res is None or res.dtype == torch.float32))
         x_amax = None
         if split:
-            x_amax = native.absmax256(x)
-            y = native.rows_linear_split(x, x_amax, w, bias, res, pre_relu, post_relu)
+            x_amax = amax_of(x)
+            y, y_amax = native.rows_linear_split(x, x_amax, w, bias, res, pre_relu, post_relu, want_amax=True)
+            set_amax_tag(y, y_amax)
         else:
             y = native.rows_linear(x, w, bias, res, pre_relu, post_relu, out_dtype=out_dtype)
         ctx.flags = (pre_relu, post_relu, bias is not None, residual is not None, res.dtype if res is not None else None, split)
@@ -356,9 +357,11 @@ class _RowsLinear(torch.autograd.Function):
         if split:
             if gy.dtype != torch.float32:
                 gy = gy.float()
-            g_amax = native.absmax256(gy)
+            g_amax = amax_of(gy)
             if ctx.needs_input_grad[0]:
-                gx = native.rows_linear_split(gy, g_amax, w.t().contiguous(), None, None, False, False, in_mask=y, out_mask=x if pre_relu else None)
+                gx, gx_amax = native.rows_linear_split(gy, g_amax, w.t().contiguous(), None, None, False, False, in_mask=y,
+                                                       out_mask=x if pre_relu else None, want_amax=True)
+                set_amax_tag(gx, gx_amax)
             if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
                 gw, gb = native.rows_wgrad_split(gy, g_amax, x, x_amax, dy_mask=y, x_relu=pre_relu, split=True)
                 gb = gb if has_bias else None
@@ -371,6 +374,8 @@ class _RowsLinear(torch.autograd.Function):
                 gb = gb if has_bias else None
         if has_res and ctx.needs_input_grad[3]:
             gres = (gy if y is None else gy * (y > 0)).to(res_dtype)
+            if split:
+                carry_amax(gy, gres)                           # gy itself, or gy with some elements zeroed
         return gx, gw, gb, gres, None, None, None
 
 
@@ -386,8 +391,9 @@ class _RowsLinearCat(torch.autograd.Function):
         split = xa.dtype == torch.float32
         amax = (None, None)
         if split:
-            amax = (native.absmax256(xa), native.absmax256(pooled))
-            y = native.rows_linear_cat_split(xa, amax[0], pooled, amax[1], pidx.p2v, w, bias, res, pre_relu, post_relu)
+            amax = (amax_of(xa), amax_of(pooled))
+            y, y_amax = native.rows_linear_cat_split(xa, amax[0], pooled, amax[1], pidx.p2v, w, bias, res, pre_relu, post_relu, want_amax=True)
+            set_amax_tag(y, y_amax)
         else:
             y = native.rows_linear_cat(xa, pooled, pidx.p2v, w, bias, res, pre_relu, post_relu)
         ctx.pidx = pidx
@@ -402,10 +408,11 @@ class _RowsLinearCat(torch.autograd.Function):
         pidx = ctx.pidx
         gy = gy.contiguous()
         ga = gp = gw = gb = gres = None
-        g_amax = native.absmax256(gy) if split else None
+        g_amax = amax_of(gy) if split else None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             if split:
-                ga, gb_rows = native.rows_linear_cat_backward_split(gy, g_amax, w.t().contiguous(), y, xa, pooled, pidx.p2v, pre_relu)
+                ga, gb_rows, gab_amax = native.rows_linear_cat_backward_split(gy, g_amax, w.t().contiguous(), y, xa, pooled, pidx.p2v, pre_relu)
+                set_amax_tag(ga, gab_amax)
             else:
                 ga, gb_rows = native.rows_linear_cat_backward(gy, w.t().contiguous(), y, xa, pooled, pidx.p2v, pre_relu)
             if ctx.needs_input_grad[1]:
@@ -418,6 +425,8 @@ class _RowsLinearCat(torch.autograd.Function):
             gb = gb if has_bias else None
         if has_res and ctx.needs_input_grad[5]:
             gres = gy if y is None else gy * (y > 0)
+            if split:
+                carry_amax(gy, gres)
         return ga, gp, None, gw, gb, gres, None, None
 
 
@@ -505,6 +514,36 @@ def set_split(flag):
 
 def split_mode():
     return _SPLIT
+
+
+# ---- absolute maxima of the fp32 tensors the fp32x3 kernels split (their power-of-two scales) ----------------------------------------
+# The kernels that produce a tensor collect its maximum in their store phase; the array rides on the tensor OBJECT as `_pcacc_amax` together
+# with the tensor's version counter (an in-place write invalidates it) and is picked up by the next split kernel that reads the tensor --
+# forward chains (layer to layer) and backward chains (a data gradient handed on by autograd) alike.  Anything else costs one
+# pcacc_absmax256 pass, remembered the same way (a tensor read by two layers is measured once).  Upper bounds are as good as the exact
+# maximum up to a bit of precision per factor two, so pure re-arrangements and maxima (views, pooling) may pass the tag on.
+def amax_tag(t):
+    a = getattr(t, '_pcacc_amax', None)
+    return a[0] if a is not None and a[1] == t._version else None
+
+
+def set_amax_tag(t, parts):
+    if parts is not None:
+        t._pcacc_amax = (parts, t._version)
+    return t
+
+
+def carry_amax(src, dst):
+    """dst holds a subset / re-arrangement / maxima of src's elements: src's bound holds for it."""
+    return set_amax_tag(dst, amax_tag(src))
+
+
+def amax_of(t):
+    a = amax_tag(t)
+    if a is None:
+        a = native.absmax256(t)
+        set_amax_tag(t, a)
+    return a
 
 
 def linear_rows(x, layer, pre_relu=False, post_relu=False, residual=None, out_dtype=None):
@@ -744,9 +783,10 @@ class _Conv3x3Split(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x_rows, weight, bias, frames, relu):
-        x_amax = native.absmax256(x_rows)
-        y = native.conv3x3_split(x_rows, prepared_conv_weights_split(weight)[0], bias.detach().float() if bias is not None else None, frames, relu,
-                                 amax=x_amax)
+        x_amax = amax_of(x_rows)
+        y, y_amax = native.conv3x3_split(x_rows, prepared_conv_weights_split(weight)[0], bias.detach().float() if bias is not None else None, frames,
+                                         relu, amax=x_amax, want_amax=True)
+        set_amax_tag(y, y_amax)
         ctx.save_for_backward(x_rows, weight, y if relu else None, x_amax)
         ctx.meta = (frames, bias is not None)
         return y
@@ -761,9 +801,10 @@ class _Conv3x3Split(torch.autograd.Function):
         gx = gw = gb = None
         kt = 3 if weight.dim() == 5 else 1
         o, i = weight.shape[0], weight.shape[1]
-        g_amax = native.absmax256(gy)                          # of the unmasked gradient: an upper bound is all the scale needs
+        g_amax = amax_of(gy)                                   # of the unmasked gradient: an upper bound is all the scale needs
         if ctx.needs_input_grad[0]:
-            gx = native.conv3x3_split(gy, prepared_conv_weights_split(weight)[1], None, frames, False, mask=y, amax=g_amax)
+            gx, gx_amax = native.conv3x3_split(gy, prepared_conv_weights_split(weight)[1], None, frames, False, mask=y, amax=g_amax, want_amax=True)
+            set_amax_tag(gx, gx_amax)
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             if kt == 3:
                 parts = [native.conv3x3_wgrad_split(gy, x_rows, frames, dt, mask=y, dy_amax=g_amax, x_amax=x_amax) for dt in (-1, 0, 1)]
@@ -813,7 +854,10 @@ def conv3x3_available(x, weight):
 def conv3x3_rows(x_rows, weight, bias, frames=1, relu=False, premasked=False):
     """x_rows [n_img, H, W, C_in] -> [n_img, H, W, C_out] (bf16; f32 in the fp32x3 mode).  weight [O,I,3,3] (frames ignored) or [O,I,3,3,3]."""
     if _SPLIT and x_rows.dtype == torch.float32 and not torch.is_autocast_enabled():
-        return _Conv3x3Split.apply(x_rows.contiguous(), weight, bias, int(frames), bool(relu))
+        xc = x_rows.contiguous()
+        if xc is not x_rows:
+            carry_amax(x_rows, xc)
+        return _Conv3x3Split.apply(xc, weight, bias, int(frames), bool(relu))
     if x_rows.dtype != torch.bfloat16:
         x_rows = x_rows.to(torch.bfloat16)
     return _Conv3x3.apply(x_rows.contiguous(), weight, bias, int(frames), bool(relu), bool(premasked))
@@ -829,9 +873,13 @@ def conv3x3_native(x, conv):
 def conv3x3(x, conv, relu=False):
     """`relu?(conv(x))` for an nn.Conv2d(3x3, stride 1, padding 1) on an NCHW tensor; channels-last bf16 inputs on the GPU go
     through the MFMA kernel, everything else through the library with the same semantics."""
-    if conv3x3_native(x, conv):
-        y = conv3x3_rows(x.permute(0, 2, 3, 1), conv.weight, conv.bias, 1, relu)
-        return y.permute(0, 3, 1, 2)
+    mode = conv3x3_native(x, conv)
+    if mode:
+        xr = x.permute(0, 2, 3, 1)
+        if mode == 'split' and xr.is_contiguous():
+            set_amax_tag(xr, amax_of(x))                       # measured (or inherited) on the caller's tensor: its next reader finds it there
+        y = conv3x3_rows(xr, conv.weight, conv.bias, 1, relu)
+        return carry_amax(y, y.permute(0, 3, 1, 2))
     y = conv(x)
     return torch.relu(y) if relu else y
 

@@ -94,7 +94,7 @@ class PillarFeatureNet(nn.Module):
         net = ops.linear_rows(features, self.fc_pos, out_dtype=pd)
         net = self.blocks[0](net)
         for block in self.blocks[1:]:
-            net = block.forward_pooled(net, ops.segment_max(net, pidx), pidx)
+            net = block.forward_pooled(net, ops.carry_amax(net, ops.segment_max(net, pidx)), pidx)      # maxima of net's rows: net's bound holds
         feats = ops.linear_rows(net, self.fc_c)
         pooled = ops.segment_max(feats, pidx)
         return pooled if keep_dtype else pooled.float()

@@ -59,8 +59,8 @@ class STPN(nn.Module):
             if ops.conv3x3_available(rows.view(B * T, H, W, cin).permute(0, 3, 1, 2), layer.weight) and layer.kernel_size == (3, 3, 3) \
                     and layer.padding == (1, 1, 1):
                 # bf16 / fp32x3 on the GPU: the MFMA kernels read frames t-1, t, t+1 in place (no channel-stacked copy)
-                y = ops.conv3x3_rows(rows.view(B * T, H, W, cin), layer.weight, layer.bias, frames=T, relu=True)
-                rows = y.view(B, T, H, W, layer.out_channels)
+                y = ops.conv3x3_rows(ops.carry_amax(rows, rows.view(B * T, H, W, cin)), layer.weight, layer.bias, frames=T, relu=True)
+                rows = ops.carry_amax(y, y.view(B, T, H, W, layer.out_channels))
                 continue
             stacked = ops._stack_frames(rows.view(B * T, H, W, cin), T)                # [B*T,H,W,3C]
             w2 = layer.weight.permute(0, 2, 1, 3, 4).reshape(layer.out_channels, 3 * cin, 3, 3)

@@ -159,6 +159,9 @@ def test_absmax256():
     assert float(native.absmax256(x).max()) == float('inf')        # a NaN poisons the maximum (fmaxf alone would drop it)
     x[77] = -float('inf')
     assert float(native.absmax256(x).max()) == float('inf')
+    y = torch.randn(64, 64, device=DEV)
+    y[0, 63] = 100.0
+    assert float(native.absmax256(y[:, :32]).max()) == float(y[:, :32].abs().max())     # a strided view is measured on its own elements
 
 
 @pytest.mark.parametrize('scale_x,scale_w', [(1e-8, 1.0), (1e8, 1e-6), (1.0, 1e5), (3e-5, 7e3)])
@@ -194,3 +197,18 @@ def test_conv3x3_split_outlier_and_nonfinite():
     assert not torch.isfinite(ops.conv3x3_rows(x, wt, None, 1, False)).all()
     z = torch.zeros(1, 8, 8, 32, device=DEV)
     assert torch.equal(ops.conv3x3_rows(z, wt, None, 1, False), torch.zeros(1, 8, 8, 32, device=DEV))     # all-zero tensor: scale 1
+
+
+def test_split_kernels_report_their_output_maximum_and_tags_follow_the_tensor():
+    x = torch.randn(2, 24, 40, 32, device=DEV)
+    wt = torch.randn(64, 32, 3, 3, device=DEV) / 17
+    wps = native.conv3x3_split_prepare_weights(wt)[0]
+    y, y_amax = native.conv3x3_split(x, wps, None, 1, True, want_amax=True)
+    assert float(y_amax.max()) == float(y.abs().max())
+    conv = torch.nn.Conv2d(32, 32, 3, padding=1).to(DEV)
+    xn = x.permute(0, 3, 1, 2)
+    a = ops.conv3x3(xn, conv, relu=True)
+    assert ops.amax_tag(xn) is not None and float(ops.amax_tag(xn).max()) == float(x.abs().max())       # measured once, remembered on the tensor
+    assert ops.amax_tag(a) is not None and float(ops.amax_tag(a).max()) == float(a.abs().max())          # produced by the kernel, carried through the permute
+    a.add_(1.0)
+    assert ops.amax_tag(a) is None                                                                        # an in-place write invalidates the tag

@@ -112,6 +112,8 @@ def test_rows_split_dynamic_range(scale):
     w = (torch.randn(n, k, generator=g) / 8).to(DEV)
     w[3] *= 1e4                                                                    # one output row far larger than the rest: per-row scales
     y = native.rows_linear_split(x, native.absmax256(x), w)
+    y2, y_amax = native.rows_linear_split(x, native.absmax256(x), w, want_amax=True)
+    assert torch.equal(y, y2) and float(y_amax.max()) == float(y.abs().max())
     assert _rel(y[:, :3], x.double() @ w[:3].double().t()) <= TOL and _rel(y, x.double() @ w.double().t()) <= TOL
     gw, gb = native.rows_wgrad_split(dy, native.absmax256(dy), x, native.absmax256(x), split=True)
     assert _rel(gw, dy.double().t() @ x.double()) <= TOL and _rel(gb, dy.double().sum(0)) <= TOL
