@@ -99,7 +99,7 @@ def _median(xs):
     return xs[len(xs) // 2] if len(xs) % 2 else 0.5 * (xs[len(xs) // 2 - 1] + xs[len(xs) // 2])
 
 
-def cpu_baseline(cfg, pts_per_frame, budget_s=110.0):
+def cpu_baseline(cfg, pts_per_frame, budget_s=170.0):
     """The same workload on the host cores: product host code + oracle CPU backend (kind 'port'), fp32, one sequence, all host
     threads.  SURVEY 8d: warm second call, 5 repeats, median -- bounded by `budget_s` of CPU work, so the (3x heavier) train step
     gets as many warm repeats as fit (at least one) and the eval forward, the figure the survey timed the reference itself at
@@ -130,7 +130,7 @@ def cpu_baseline(cfg, pts_per_frame, budget_s=110.0):
     # (128 threads on the GPU box's EPYC host ran the forward 2.5x slower than 8 cores of the build container); probe once
     cores = os.cpu_count() or threads
     best = (None, float('inf'))
-    for n in sorted({min(c, cores) for c in (8, 16, 32, 64, cores)}):
+    for n in sorted({min(c, cores) for c in (8, 16, 32)}):             # three probes (all threads of the GPU box's host ran 2.5x slower than 16)
         torch.set_num_threads(n)
         os.environ['OMP_NUM_THREADS'] = str(n)
         t = fwd()
@@ -143,7 +143,7 @@ def cpu_baseline(cfg, pts_per_frame, budget_s=110.0):
         ctypes.CDLL('libgomp.so.1').omp_set_num_threads(threads)       # the twin's OpenMP runtime
     except OSError:
         pass
-    f_times = [fwd() for _ in range(5)]
+    f_times = [fwd() for _ in range(3)]
     model.train()
     stepper = pdist.DataParallelStep(model, opt, loss_fn, iter_size=1, grad_clip=cfg['train']['grad_clip'], catch=False)
 
@@ -161,7 +161,110 @@ def cpu_baseline(cfg, pts_per_frame, budget_s=110.0):
             'sample': 'train step (fwd + loss + bwd + Adam) on one %dx%d-point sequence, fp32: warm, median of %d (%.2f s; cold first step '
                       '%.2f s)' % (T_FRAMES, pts_per_frame, len(s_times), dt, cold),
             'forward_only': {'value': T_FRAMES / fdt, 'unit': 'LiDAR-frames/s',
-                             'sample': 'eval forward on the same sequence: warm, median of 5 (%.2f s)' % fdt}}
+                             'sample': 'eval forward on the same sequence: warm, median of 3 (%.2f s)' % fdt}}
+
+
+def step_model(stepper, batcher, feed):
+    """One extra, untimed training step with every call into libpcacc_hip.so instrumented: algorithmic bytes (every tensor operand and
+    result once -- tools/native_call_table.py's model) and algorithmic FLOPs of the GEMM-shaped calls (convolutions, row-linear layers,
+    their weight gradients: 2 x multiply-adds of the mathematical operation, whatever the kernel spends on it -- the fp32x3 kernels
+    issue 3 MFMAs per product).  Torch / library kernels are not in the model (their share of GPU time: profiles/)."""
+    import types
+    tot = {'bytes': 0.0, 'flops': 0.0, 'calls': 0}
+
+    def tensors(obj):
+        if torch.is_tensor(obj):
+            yield obj
+        elif isinstance(obj, (list, tuple)):
+            for o in obj:
+                yield from tensors(o)
+
+    def flops_of(name, a, k):
+        try:
+            if name in ('conv3x3', 'conv3x3_split'):
+                x, wp = a[0], a[1]
+                wp = wp[0] if isinstance(wp, (tuple, list)) else wp
+                taps, co, ci = wp.shape[-3], wp.shape[-2], wp.shape[-1]
+                return 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * ci * co * taps
+            if name in ('conv3x3_wgrad', 'conv3x3_wgrad_deep', 'conv3x3_wgrad_split'):
+                dy, x = a[0], a[1]
+                return 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * x.shape[3] * 9
+            if name in ('rows_linear', 'rows_linear_split'):
+                x, w = a[0], (a[2] if name == 'rows_linear_split' else a[1])
+                return 2.0 * x.shape[0] * w.shape[0] * w.shape[1]
+            if name in ('rows_linear_cat', 'rows_linear_cat_split'):
+                w = a[5] if name.endswith('split') else a[3]
+                return 2.0 * a[0].shape[0] * w.shape[0] * w.shape[1]
+            if name in ('rows_linear_cat_backward', 'rows_linear_cat_backward_split'):
+                w = a[2] if name.endswith('split') else a[1]
+                return 2.0 * a[0].shape[0] * w.shape[0] * w.shape[1]
+            if name in ('rows_wgrad', 'rows_wgrad_split'):
+                dy, x = a[0], (a[2] if name == 'rows_wgrad_split' else a[1])
+                return 2.0 * dy.shape[0] * dy.shape[1] * x.shape[1]
+            if name in ('rows_wgrad_cat', 'rows_wgrad_cat_split'):
+                dy = a[0]
+                kk = (a[2].shape[1] + a[4].shape[1]) if name.endswith('split') else (a[1].shape[1] + a[2].shape[1])
+                return 2.0 * dy.shape[0] * dy.shape[1] * kk
+            if name == 'pfn_block_forward':
+                return 2.0 * a[0].shape[0] * (64 * 32 * 2 + 32 * 32)
+            if name == 'pfn_block_backward':
+                return 2.0 * a[0].shape[0] * (64 * 32 * 2 + 32 * 32) * 2
+            if name in ('chamfer_forward',):
+                return 8.0 * a[0].shape[0] * a[1].shape[0] * 2
+        except Exception:
+            return 0.0
+        return 0.0
+
+    def wrap(name, fn):
+        def w(*a, **k):
+            r = fn(*a, **k)
+            ins = list(tensors(a)) + list(tensors(list(k.values())))
+            tot['bytes'] += sum(t.numel() * t.element_size() for t in ins + list(tensors(r)))
+            tot['flops'] += flops_of(name, a, k)
+            tot['calls'] += 1
+            return r
+        return w
+    saved = {}
+    for name, fn in list(vars(native).items()):
+        if isinstance(fn, types.FunctionType) and not name.startswith('_') and name not in ('lib', 'upload_small') and not name.endswith('_supported'):
+            saved[name] = fn
+            setattr(native, name, wrap(name, fn))
+    try:
+        train_step(stepper, batcher, feed)
+        torch.cuda.synchronize()
+    finally:
+        for name, fn in saved.items():
+            setattr(native, name, fn)
+    return tot
+
+
+def scatter_flushed(dtype, batch, pillars):
+    """The pillar-scatter launch of the roofline object with cold caches: 1 GiB read and written between launches (the in-step launch
+    follows the pillar encoder's last layers and finds part of its feature table in the 256 MB Infinity Cache)."""
+    dev = torch.device('cuda')
+    n_cells, c = batch * T_FRAMES * 288 * 288, 32
+    m = int(min(pillars, n_cells))
+    rows_dtype = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    feats = torch.randn(m, c, device=dev).to(rows_dtype)
+    c2p = torch.full((n_cells,), -1, dtype=torch.int32, device=dev)
+    c2p[torch.randperm(n_cells, device=dev)[:m].sort().values] = torch.arange(m, dtype=torch.int32, device=dev)     # pillar ids in cell order, as the model numbers them
+    flush = torch.zeros(256 * 1024 * 1024, device=dev)
+    for _ in range(3):
+        native.pillar_scatter(feats, c2p, rows_dtype)
+    native.scatter_timer = []
+    try:
+        for _ in range(12):
+            flush.add_(1.0)
+            native.pillar_scatter(feats, c2p, rows_dtype)
+        torch.cuda.synchronize()
+        us = sorted(t[0].elapsed_us() for t in native.scatter_timer)
+    finally:
+        native.scatter_timer = None
+    s = 2 if dtype == 'bf16' else 4
+    alg = n_cells * c * s + m * c * s + 4 * m
+    med = us[len(us) // 2]
+    return {'frac': alg / med / 1e3 / HBM_PEAK_GBPS, 'achieved': alg / med / 1e3, 'median_launch_us': med, 'launches': len(us),
+            'note': 'same launch size, 1 GiB streamed between launches (cold L2 / Infinity Cache)'}
 
 
 def main():
@@ -173,7 +276,9 @@ def main():
     ap.add_argument('--batch', type=int, default=4, help='sequences per GPU per step (reference default: train.batch_size = 4, configs/default.yaml:33)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32', 'fp32x3'])
     ap.add_argument('--iter-size', type=int, default=1, help='micro-steps per optimizer step (gradient accumulation; the all-reduce fires on the last one; reference yaml: 2)')
+    ap.add_argument('--points', default='uniform', choices=['uniform', 'lidar'], help="synthetic point distribution: 'uniform' (BASELINE.json: synthetic; the headline) or 'lidar' = 1/r range density, 64 beams, scan-ordered within a frame (SURVEY 8d; synthetic.make_sequence(mode='lidar_scan'))")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-step-model', action='store_true', help='skip the instrumented extra step behind roofline_step and the cold-cache scatter launches')
     ap.add_argument('--no-fp32-leg', action='store_true', help='skip the fp32 (matched-accuracy) timing of the same step that follows the bf16 run at N = 1')
     ap.add_argument('--no-miopen-find', action='store_true', help='library convolutions through the immediate-mode heuristic instead of the find-db')
     ap.add_argument('--pipeline', action='store_true', help='force the staged step (default: staged with a second stream at N = 1, one backward at N > 1)')
@@ -209,7 +314,8 @@ def main():
     model, opt, loss_fn = build(cfg, device)
     batcher = DeviceBatcher(cfg)
     n_scenes = 2 * args.batch
-    scenes = [sample_to_device(make_sequence(1000 * rank + i, T_FRAMES, args.pts_per_frame, cfg), device) for i in range(n_scenes)]
+    mode = 'lidar_scan' if args.points == 'lidar' else 'uniform'
+    scenes = [sample_to_device(make_sequence(1000 * rank + i, T_FRAMES, args.pts_per_frame, cfg, mode=mode), device) for i in range(n_scenes)]
 
     def batch_of(i):
         return [scenes[(i * args.batch + j) % n_scenes] for j in range(args.batch)]
@@ -233,11 +339,18 @@ def main():
     timer, native.scatter_timer = native.scatter_timer, None
     if stepper.skipped:
         raise SystemExit('bench: %d optimizer step(s) were skipped (rank %d: %r)' % (stepper.skipped, rank, stepper.last_error))
+    model_tot = flushed = None
+    if rank == 0 and not args.no_step_model:
+        try:
+            model_tot = step_model(stepper, batcher, feed)
+            flushed = scatter_flushed(args.dtype, args.batch, sum(t[3] for t in timer) / max(len(timer), 1)) if timer else None
+        except Exception as e:                                         # diagnostics must never take the bench line down
+            model_tot, flushed = {'error': repr(e)}, None
 
     # The same step with fp32 compute: the precision at which the path matches the reference within north_star's 1e-3
     # (tests/test_config_parity.py::test_gpu_config_fp32); bf16 is bounded in DESIGN.md section 4.  N = 1 only, a few steps.
     fp32_leg = None
-    if world == 1 and args.dtype == 'bf16' and not args.no_fp32_leg:        # TODO-check: k32 steps
+    if world == 1 and args.dtype == 'bf16' and not args.no_fp32_leg:
         del stepper, model, opt
         torch.cuda.empty_cache()
         torch.backends.cudnn.benchmark = False      # library convolutions of this leg through the immediate-mode heuristic: no minutes of find runs for the fp32 shapes
@@ -247,8 +360,8 @@ def main():
         st32 = pdist.DataParallelStep(m32, o32, l32, iter_size=args.iter_size, grad_clip=cfg['train']['grad_clip'],
                                       pipelined=False if args.no_pipeline else (True if args.pipeline else None), two_streams=not args.one_stream)
         feed32 = BatchFeed(batcher, batch_of, not args.no_prefetch, prepare=m32.prepare_inputs if args.prepare_ahead else None)
-        k32 = max(2, min(args.steps, 5))
-        for i in range(2):
+        k32 = args.steps
+        for i in range(args.warmup):
             train_step(st32, batcher, feed32)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -257,7 +370,7 @@ def main():
         torch.cuda.synchronize()
         dt32 = time.perf_counter() - t1
         fp32_leg = {'dtype': 'fp32x3', 'value': args.batch * T_FRAMES * k32 / dt32, 'unit': 'LiDAR-frames/s', 'ms_per_step': dt32 / k32 * 1e3,
-                    'steps': k32, 'note': 'same step in the fp32x3 mode (fp32 tensors, split-bf16 products on the matrix cores, hand-written '
+                    'steps': k32, 'warmup': args.warmup, 'note': 'same step in the fp32x3 mode (fp32 tensors, split-bf16 products on the matrix cores, hand-written '
                                           'kernels): mos_iou / ego errors / EPE match the reference within 1e-3 on c2-c5 + nus11 '
                                           '(tests/test_config_parity.py::test_gpu_config_fp32[fp32x3-*]); bf16 bound: DESIGN.md section 4'}
         del st32, m32, o32
@@ -287,18 +400,38 @@ def main():
             'metric': 'LiDAR-frames/sec (5-frame seq, 160k pts) fwd+bwd', 'value': frames / dt, 'unit': 'LiDAR-frames/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': 'c3 shape: Waymo geometry 288x288x%d, %d pts/frame uniform synthetic, %d sequences per GPU per step, '
+            'config': {'workload': 'c3 shape: Waymo geometry 288x288x%d, %d pts/frame %s synthetic, %d sequences per GPU per step, '
                                    'train step = GPU voxelise + MotionNet fwd + FuseLoss + bwd + bucketed grad all-reduce (overlapped) + clip + Adam'
-                                   % (T_FRAMES, args.pts_per_frame, args.batch),
+                                   % (T_FRAMES, args.pts_per_frame, 'uniform' if args.points == 'uniform' else 'LiDAR-distributed (1/r, 64 beams, scan order)',
+                                      args.batch),
                        'frames_per_sequence': T_FRAMES, 'pts_per_frame': args.pts_per_frame, 'sequences_per_gpu': args.batch, 'iter_size': args.iter_size,
-                       'parallelism': 'dp%d' % world},
+                       'points': args.points, 'parallelism': 'dp%d' % world,
+                       'kpt_sampler': "device: the ego head's 1024 key points per frame are drawn by pcacc_sample_subsets (keyed Feistel permutation, one "
+                                      "launch) instead of the reference's host torch.randperm stream (models/egomotion.py:157) -- same uniform "
+                                      "distribution over subsets, different draw; the parity tests use the host stream",
+                       'step_variant': ('staged (early backward of the ego / fb / perm terms)' + (' + second stream' if stepper.side is not None else ''))
+                                       if stepper.pipelined else 'one backward'},
+            'distributed': {'world_size': world, 'backend': (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
+                            'device': str(device), 'ranks_per_device': max(1, world // n_dev) if world > n_dev else 1},
             'roofline': {'kernel': 'pillar_scatter_rows16 (BEV canvas fill, bf16 rows -> bf16 canvas)' if args.dtype == 'bf16' else 'pillar_scatter_vec4<0> (BEV canvas fill)', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
                          'traffic_source': 'PMC FETCH_SIZE x2 + WRITE_SIZE (calibrated on a 128 MiB copy), profiles/r02_pmc_scatter_summary.json',
                          'launches_timed': len(durs), 'avg_launch_us': (sum(durs) / len(durs) * 1e6) if durs else None,
                          'timing': 'HIP events attached to each dispatch (hipExtLaunchKernel start/stop)',
-                         'algorithmic_bytes_per_launch': (sum(alg) / len(alg)) if alg else None},
+                         'algorithmic_bytes_per_launch': (sum(alg) / len(alg)) if alg else None,
+                         'cold_cache': flushed},
         }
+        if model_tot is not None and 'error' not in model_tot:
+            step_s = dt / args.steps
+            line['roofline_step'] = {
+                'flops_per_step': model_tot['flops'], 'bytes_per_step': model_tot['bytes'], 'native_calls_per_step': model_tot['calls'],
+                'mfma': {'achieved': model_tot['flops'] / step_s / 1e12, 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': model_tot['flops'] / step_s / 1e12 / 2500.0},
+                'hbm': {'achieved': model_tot['bytes'] / step_s / 1e9, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': model_tot['bytes'] / step_s / 1e9 / HBM_PEAK_GBPS},
+                'model': 'whole step: algorithmic FLOPs of the GEMM-shaped native calls (3x3 / 3x3x3 convolutions, per-point linear layers, their '
+                         'weight gradients; 2 x MACs of the operation) and algorithmic bytes of ALL native calls (every tensor operand and result '
+                         'once), both divided by the measured step time; torch / library kernels are outside the model'}
+        elif model_tot is not None:
+            line['roofline_step'] = model_tot
         if fp32_leg is not None:
             line['matched_accuracy'] = fp32_leg
         if world == 1 and not args.no_cpu_baseline:

@@ -429,6 +429,311 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float 
     }
 }
 
+// ---- the narrow layers (c_in, c_out <= 64) on full-resolution maps: persistent workgroups, a slice's nine weight tiles resident ----------
+// These layers move the most pixels (20 x 288^2) with the fewest MFMAs per pixel; in the kernel above they paid a barrier per tap for 12
+// MFMAs per wave, and -- one slice per tile, one tile per workgroup -- nothing overlapped a tile's global loads with another's math.
+// Here a workgroup walks tiles (stride = workgroups per channel group); a pass = (tile, slice): the NEXT pass's patch travels in
+// registers during the current pass's MFMAs, the nine tap tiles of the pass's slice sit in LDS (re-staged only when the slice changes:
+// never for a one-slice layer), and the 9 x CS/16 steps of a pass run without a barrier, fragment reads two steps ahead of their MFMAs.
+// 8 waves along the pixels (NGW = 1); a wave owns MT pixel tiles x NW channel tiles.
+#define CSR_WPT 9                               // 16-byte weight pieces a thread carries for the next slice (9 taps x 64 rows x 32 ch x 2 planes / 512)
+
+template <int CS, int NW, int MT, int PCH>
+__global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_res_kernel(const float *__restrict__ in, const float *__restrict__ in_amax,
+                                                                        const float *__restrict__ in_mask, const uint16_t *__restrict__ wp,
+                                                                        const float *__restrict__ wscale, const float *__restrict__ bias,
+                                                                        float *__restrict__ out, float *__restrict__ out_amax, int n_img, int frames,
+                                                                        int h, int w, int c_in, int c_out, int kt, int relu, int rows, int bw,
+                                                                        int tiles_y, int tiles_x, int co_groups, int slots)
+{
+    constexpr int PS = CS + 8;
+    constexpr int WROWS = 32 * NW;
+    constexpr int C8 = CS / 8;
+    constexpr int WPL = 9 * WROWS * PS;                        // one weight plane (nine taps)
+    constexpr int KC = CS / 16, STEPS = 9 * KC, AHEAD = 1;
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    const int pw = bw + 2, pp = (rows + 2) * pw;
+    const int plane = pp * PS;
+    uint16_t *patch = lds;                                     // [2 = hi, lo][pp][PS]
+    uint16_t *wl = lds + 2 * (size_t)plane;                    // [2 = hi, lo][9][WROWS][PS]
+
+    const int cog = blockIdx.x % co_groups, slot = blockIdx.x / co_groups;
+    const int co0 = cog * WROWS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lp = lane & 31, lh = lane >> 5;
+    const int n_px = rows * bw;
+    const int nc = c_in / CS;
+    const int tiles_img = tiles_y * tiles_x, n_tiles = n_img * tiles_img;
+    const float sx = csp_scale_from_parts(in_amax);
+    const float inv_sx = 1.f / sx;
+
+    // slices of a tile that exist: frame taps f_lo .. f_hi (a missing frame contributes zeros), all channel slices of each
+    auto first_slice = [&](int tile) { return (kt == 3 && (tile / tiles_img) % frames == 0) ? nc : 0; };
+    auto end_slice = [&](int tile) { return kt == 3 ? ((tile / tiles_img) % frames == frames - 1 ? 2 * nc : 3 * nc) : nc; };
+
+    // patch chunks (8 channels) of this thread: position packed as py << 20 | px << 8 | c8
+    const int n_chunks = pp * C8;
+    int pinfo[PCH];                                            // PCH: patch chunks a thread carries (3 .. 6 by configuration: registers)
+    float4 preg[PCH][2];
+#pragma unroll
+    for (int q = 0; q < PCH; ++q) {
+        const int c = threadIdx.x + q * CSP_THREADS;
+        const int px = c / C8, c8 = c - px * C8;
+        const int py = px / pw, pxx = px - py * pw;
+        pinfo[q] = c < n_chunks ? (py << 20 | pxx << 8 | c8) : (0x7ff << 20);
+    }
+    auto fetch_patch = [&](int tile, int s) __attribute__((always_inline)) {
+        const int img = tile / tiles_img, rem = tile - img * tiles_img;
+        const int y0 = (rem / tiles_x) * rows, x0 = (rem % tiles_x) * bw;
+        const int f = s / nc, cs = s - f * nc;
+        const int64_t img_off = (int64_t)(img + (kt == 3 ? f - 1 : 0)) * h * w * c_in;
+#pragma unroll
+        for (int q = 0; q < PCH; ++q) {
+            const int py = pinfo[q] >> 20, pxx = (pinfo[q] >> 8) & 0xfff, c8 = pinfo[q] & 0xff;
+            const int y = y0 - 1 + py, x = x0 - 1 + pxx;
+            const bool ok = (unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w;
+            const int yc = min(max(y, 0), h - 1), xc = min(max(x, 0), w - 1);
+            const int64_t off = img_off + ((int64_t)yc * w + xc) * c_in + cs * CS + c8 * 8;
+            float4 a = *reinterpret_cast<const float4 *>(in + off), b = *reinterpret_cast<const float4 *>(in + off + 4);
+            if (in_mask) {                                     // uniform
+                a = csp_relu_mask4(a, *reinterpret_cast<const float4 *>(in_mask + off));
+                b = csp_relu_mask4(b, *reinterpret_cast<const float4 *>(in_mask + off + 4));
+            }
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            preg[q][0] = ok ? a : z;
+            preg[q][1] = ok ? b : z;
+        }
+    };
+    auto write_patch = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < PCH; ++q) {
+            const int c = threadIdx.x + q * CSP_THREADS;
+            if (c < n_chunks) {
+                uint4 hi, lo;
+                csp_split8(preg[q][0], preg[q][1], sx, hi, lo);
+                uint16_t *dst = patch + (c / C8) * PS + (c % C8) * 8;
+                *reinterpret_cast<uint4 *>(dst) = hi;
+                *reinterpret_cast<uint4 *>(dst + plane) = lo;
+            }
+        }
+    };
+    // the nine tap tiles of slice s, both planes: 2 x 9 x WROWS rows of CS elements
+    constexpr int W_ROWS_ALL = 2 * 9 * WROWS, W_CHUNKS = W_ROWS_ALL * C8, W_PER = (W_CHUNKS + CSP_THREADS - 1) / CSP_THREADS;
+    static_assert(W_PER <= CSR_WPT, "weight pieces per thread");
+    const int64_t w_plane = (int64_t)kt * 9 * c_out * c_in;
+    typedef uint32_t wvec_t __attribute__((ext_vector_type(4 * W_PER)));      // one SSA value, not an array: as `uint4 wreg[W_PER]` it stayed in scratch memory
+    wvec_t wreg;
+    auto fetch_w = [&](int s) __attribute__((always_inline)) {
+        const int f = s / nc, cs = s - f * nc;
+#pragma unroll
+        for (int q = 0; q < W_PER; ++q) {
+            const int c = min((int)threadIdx.x + q * CSP_THREADS, W_CHUNKS - 1);
+            const int row = c / C8, c8 = c - row * C8;         // row = (plane, tap, r)
+            const int pl = row / (9 * WROWS), tr = row - pl * 9 * WROWS;
+            const int tap = tr / WROWS, r = tr - tap * WROWS;
+            const uint4 v = *reinterpret_cast<const uint4 *>(wp + pl * w_plane + ((int64_t)(f * 9 + tap) * c_out + co0 + r) * c_in + cs * CS + c8 * 8);
+            wreg[4 * q] = v.x; wreg[4 * q + 1] = v.y; wreg[4 * q + 2] = v.z; wreg[4 * q + 3] = v.w;
+        }
+    };
+    auto write_w = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < W_PER; ++q) {
+            const int c = threadIdx.x + q * CSP_THREADS;
+            if (c < W_CHUNKS) *reinterpret_cast<uint4 *>(wl + (c / C8) * PS + (c % C8) * 8) = make_uint4(wreg[4 * q], wreg[4 * q + 1], wreg[4 * q + 2], wreg[4 * q + 3]);
+        }
+    };
+
+    float omax = 0.f;
+    int tile = slot;
+    if (tile >= n_tiles) return;
+    int s = first_slice(tile);
+    fetch_patch(tile, s);
+    fetch_w(s);
+    f32x16_t acc[MT][NW];
+    while (tile < n_tiles) {
+        if (s == first_slice(tile)) {
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+#pragma unroll
+                for (int n = 0; n < NW; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[j][n][r] = 0.f;
+        }
+        __syncthreads();                                       // the previous pass is done with the patch and the weight tiles
+        write_patch();
+        write_w();                                             // unconditionally (46 - 92 KB of LDS writes against ~1 MB of fragment reads per pass):
+        __syncthreads();                                       // under a condition the compiler keeps the pieces in scratch memory
+        // the next pass: its patch and its weight tiles in flight during this pass's MFMAs
+        int nt = tile, ns = s + 1;
+        if (ns >= end_slice(tile)) { nt = tile + slots; ns = nt < n_tiles ? first_slice(nt) : s; }
+        if (nt < n_tiles) fetch_patch(nt, ns);
+        fetch_w(ns);
+
+        // the lane's pixels of this tile
+        const int img = tile / tiles_img, rem = tile - img * tiles_img;
+        const int y0 = (rem / tiles_x) * rows, x0 = (rem % tiles_x) * bw;
+        int poff[MT], pyx[MT];
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int q = (wave + 8 * j) * 32 + lp;
+            const int y = q / bw, x = q - y * bw;
+            const bool ok = q < n_px && y0 + y < h && x0 + x < w;
+            poff[j] = ok ? (y * pw + x) * PS : 0;
+            pyx[j] = ok ? ((y0 + y) << 16 | (x0 + x)) : -1;
+        }
+        {
+            f16x8_t ah[AHEAD + 1][NW], al[AHEAD + 1][NW], bh[AHEAD + 1][MT], bl[AHEAD + 1][MT];
+            const uint16_t *wa = wl + lp * PS + lh * 8;
+            auto load = [&](int slt, int st) __attribute__((always_inline)) {
+                const int tap = st / KC, kc = st - tap * KC;
+                const int toff = ((tap / 3) * pw + tap % 3) * PS + lh * 8 + kc * 16;
+#pragma unroll
+                for (int n = 0; n < NW; ++n) {
+                    ah[slt][n] = *reinterpret_cast<const f16x8_t *>(wa + (tap * WROWS + n * 32) * PS + kc * 16);
+                    al[slt][n] = *reinterpret_cast<const f16x8_t *>(wa + WPL + (tap * WROWS + n * 32) * PS + kc * 16);
+                }
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    bh[slt][j] = *reinterpret_cast<const f16x8_t *>(patch + poff[j] + toff);
+                    bl[slt][j] = *reinterpret_cast<const f16x8_t *>(patch + plane + poff[j] + toff);
+                }
+            };
+#pragma unroll
+            for (int st = 0; st < AHEAD && st < STEPS; ++st) load(st, st);
+#pragma unroll
+            for (int st = 0; st < STEPS; ++st) {
+                if (st + AHEAD < STEPS) load((st + AHEAD) % (AHEAD + 1), st + AHEAD);
+                constexpr int DUMMY = 0; (void)DUMMY;
+                const int c = st % (AHEAD + 1);
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+#pragma unroll
+                    for (int n = 0; n < NW; ++n) acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[c][n], bl[c][j], acc[j][n], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+#pragma unroll
+                    for (int n = 0; n < NW; ++n) acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[c][n], bh[c][j], acc[j][n], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+#pragma unroll
+                    for (int n = 0; n < NW; ++n) acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[c][n], bh[c][j], acc[j][n], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (nt != tile) {                                      // last slice of this tile: scales off, bias, ReLU, store
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                if (pyx[j] < 0) continue;
+                float *dst = out + (((int64_t)img * h + (pyx[j] >> 16)) * w + (pyx[j] & 0xffff)) * c_out + co0;
+#pragma unroll
+                for (int n = 0; n < NW; ++n)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int c = n * 32 + 8 * g + 4 * lh;
+                        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (bias) bv = *reinterpret_cast<const float4 *>(bias + co0 + c);
+                        float4 sc = *reinterpret_cast<const float4 *>(wscale + co0 + c);
+                        sc = make_float4(sc.x * inv_sx, sc.y * inv_sx, sc.z * inv_sx, sc.w * inv_sx);
+                        float4 v = make_float4(acc[j][n][4 * g] * sc.x + bv.x, acc[j][n][4 * g + 1] * sc.y + bv.y, acc[j][n][4 * g + 2] * sc.z + bv.z,
+                                               acc[j][n][4 * g + 3] * sc.w + bv.w);
+                        if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                        *reinterpret_cast<float4 *>(dst + c) = v;
+                        omax = fmaxf(fmaxf(omax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                        if (!(v.x == v.x && v.y == v.y && v.z == v.z && v.w == v.w)) omax = __builtin_inff();
+                    }
+            }
+        }
+        tile = nt;
+        s = ns;
+    }
+    if (out_amax) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) omax = fmaxf(omax, __shfl_xor(omax, d, 64));
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned *>(out_amax) + (blockIdx.x & (CSP_AMAX_PARTS - 1)), __float_as_uint(omax));
+    }
+}
+
+struct ConvResPlan { int cs, nw, mt, rows, bw, tiles_y, tiles_x, co_groups, slots; size_t lds; };
+
+// the four configurations that fit 160 KB of LDS with a slice's nine tap tiles resident: (CS, NW, MT) -> patch chunks per thread
+static int conv_res_pch(int cs, int nw, int mt)
+{
+    if (cs == 32 && mt == 1) return 3;                         // 32 -> 32 / 64, 256-pixel tiles
+    if (cs == 32 && nw == 1 && mt == 2) return 5;              // 32 -> 32, 512-pixel tiles
+    if (cs == 64 && nw == 1 && mt == 1) return 6;              // 64 -> 32
+    return 0;
+}
+
+static bool conv_res_fits(int cs, int nw, int mt, int rows, int bw, size_t *lds)
+{
+    const int64_t pp = (int64_t)(rows + 2) * (bw + 2);
+    const int wrows = 32 * nw, pch = conv_res_pch(cs, nw, mt);
+    *lds = (size_t)(2 * pp + 2 * 9 * wrows) * (cs + 8) * sizeof(uint16_t);
+    return pch > 0 && pp * (cs / 8) <= CSP_THREADS * pch && *lds <= CSP_LDS_MAX && 2 * 9 * wrows * (cs / 8) <= CSP_THREADS * CSR_WPT &&
+           rows + 2 < 0x7ff && bw + 2 < 0xfff;
+}
+
+// c_in, c_out in {32, 64} on maps of at least a few thousand pixels (below that the launch is latency, not throughput)
+static bool conv_res_plan(int n_img, int h, int w, int c_in, int c_out, ConvResPlan *best)
+{
+    const char *e = getenv("PCACC_CONV_RES");                 // "0": never, "2": whatever the size (tests)
+    if ((c_in != 32 && c_in != 64) || (c_out != 32 && c_out != 64) || (e && e[0] == '0')) return false;
+    if ((int64_t)n_img * h * w < 200000 && !(e && e[0] == '2')) return false;
+    const int nw = c_out / 32;
+    bool found = false;
+    int64_t best_cost = 0;
+    for (int mt = 2; mt >= 1; --mt) {
+        const int cap = 8 * mt * 32;
+        for (int cs = 64; cs >= 32; cs -= 32) {
+            if (c_in % cs || !conv_res_pch(cs, nw, mt)) continue;
+            for (int bi = 0; bi < 4; ++bi) {
+                int bw = bi == 0 ? w : 32 * bi;
+                if (bi > 0 && bw >= w) continue;
+                if (bw > cap) continue;
+                const int tiles_x = (w + bw - 1) / bw;
+                bw = (w + tiles_x - 1) / tiles_x;
+                int r = cap / bw;
+                if (r > h) r = h;
+                size_t lds;
+                while (r >= 1 && !conv_res_fits(cs, nw, mt, r, bw, &lds)) --r;
+                if (r < 1) continue;
+                const int tiles_y = (h + r - 1) / r;
+                r = (h + tiles_y - 1) / tiles_y;
+                if (!conv_res_fits(cs, nw, mt, r, bw, &lds)) continue;
+                const int tiles = (r * bw + 31) / 32;
+                if (mt > 1 && tiles <= 8 * (mt - 1)) continue;
+                // per tile: MFMAs of all slices (3 per fragment pair), one barrier pair + staging per slice; padded pixel tiles are wasted MFMAs
+                const int64_t per_tile = (int64_t)(c_in / cs) * (9 * (cs / 16) * 3 * nw * mt + 12 + (int64_t)(r + 2) * (bw + 2) * cs / 512 +
+                                                                 9 * 32 * nw * cs / 512);
+                const int64_t cost = per_tile * tiles_y * tiles_x;
+                if (!found || cost < best_cost) {
+                    found = true;
+                    best_cost = cost;
+                    int64_t slots = PCACC_CUS;
+                    const int64_t n_tiles = (int64_t)n_img * tiles_y * tiles_x;
+                    if (slots > n_tiles) slots = n_tiles;
+                    *best = ConvResPlan{cs, nw, mt, r, bw, tiles_y, tiles_x, 1, (int)slots, lds};
+                }
+            }
+        }
+    }
+    return found;
+}
+
+template <int CS, int NW, int MT, int PCH>
+static int conv_res_launch(const ConvResPlan &p, const float *in, const float *in_amax, const float *in_mask, const uint16_t *wp,
+                           const float *wscale, const float *bias, float *out, float *out_amax, int n_img, int frames, int h, int w, int c_in,
+                           int c_out, int kt, int relu, hipStream_t st)
+{
+    auto kern = conv3x3_split_res_kernel<CS, NW, MT, PCH>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds) != hipSuccess)
+        return PCACC_E_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.co_groups * p.slots)), dim3(CSP_THREADS), p.lds, st, in, in_amax, in_mask, wp, wscale, bias, out, out_amax,
+                       n_img, frames, h, w, c_in, c_out, kt, relu, p.rows, p.bw, p.tiles_y, p.tiles_x, p.co_groups, p.slots);
+    PCACC_CHECK_LAUNCH();
+    return 0;
+}
+
 // Tiling of a layer: (NW, NGW) by the output width, MT, slice width, tile = rows x bw.  A workgroup's time goes with its MFMA count
 // (3 per fragment pair) plus a per-tap cost for the barrier and the weight tile; the launch takes ceil(blocks / 256 CUs) rounds of it
 // (LDS leaves one workgroup per CU).
@@ -522,10 +827,21 @@ extern "C" int pcacc_conv3x3_split(const float *in, const float *in_amax, const 
     if (!in || !in_amax || !wp || !wscale || !out || n_img < 1 || (kt != 1 && kt != 3) || frames < 1 || n_img % frames ||
         !conv_split_plan(n_img, h, w, c_in, c_out, kt, &p))
         return PCACC_E_ARG;
+    hipStream_t st = pcacc_stream(stream);
+    ConvResPlan rp;
+    if (conv_res_plan(n_img, h, w, c_in, c_out, &rp)) {
+        if (getenv("PCACC_CONV_PLAN"))
+            fprintf(stderr, "split conv plan (resident) %dx%d %d->%d kt=%d n=%d: cs=%d nw=%d mt=%d rows=%d bw=%d slots=%d lds=%zu\n", h, w, c_in, c_out,
+                    kt, n_img, rp.cs, rp.nw, rp.mt, rp.rows, rp.bw, rp.slots, rp.lds);
+#define CSR_CASE(CSV, NWV, MTV, PCHV)                                          \
+    if (rp.cs == CSV && rp.nw == NWV && rp.mt == MTV)                          \
+        return conv_res_launch<CSV, NWV, MTV, PCHV>(rp, in, in_amax, in_mask, wp, wscale, bias, out, out_amax, n_img, frames, h, w, c_in, c_out, kt, relu, st)
+        CSR_CASE(32, 1, 1, 3); CSR_CASE(32, 2, 1, 3); CSR_CASE(32, 1, 2, 5); CSR_CASE(64, 1, 1, 6);
+#undef CSR_CASE
+    }
     if (getenv("PCACC_CONV_PLAN"))
         fprintf(stderr, "split conv plan %dx%d %d->%d kt=%d n=%d: cs=%d nw=%d ngw=%d mt=%d rows=%d bw=%d blocks=%lld lds=%zu\n", h, w, c_in, c_out,
                 kt, n_img, p.cs, p.nw, p.ngw, p.mt, p.rows, p.bw, (long long)p.blocks, p.lds);
-    hipStream_t st = pcacc_stream(stream);
 #define CSP_CASE(CSV, NWV, NGWV, MTV)                                          \
     if (p.cs == CSV && p.nw == NWV && p.ngw == NGWV && p.mt == MTV)            \
         return conv_split_launch<CSV, NWV, NGWV, MTV>(p, in, in_amax, in_mask, wp, wscale, bias, out, out_amax, n_img, frames, h, w, c_in, c_out, kt, relu, st)

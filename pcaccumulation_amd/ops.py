@@ -1068,3 +1068,24 @@ def batch_norm_rows(x, bn):
         bn.num_batches_tracked.add_(1)
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
     return _BatchNormRows.apply(x, bn.weight, bn.bias, float(bn.eps), float(bn.momentum), rm, rv)
+
+
+def batch_norm_nchw(x, bn):
+    """`bn(x)` for an nn.BatchNorm2d on a channels-last NCHW tensor (models/unet.py:259-277, the two SegHead2D): training mode on the GPU
+    runs the streaming passes of csrc/bn.hip on the [N*H*W, C] rows the memory already is (f32 or bf16 rows, statistics in fp32 /
+    float64 as the module's); everything else is the module (library)."""
+    if not (bn.training and x.is_cuda and x.dim() == 4 and bn.momentum is not None and x.dtype in (torch.float32, torch.bfloat16)
+            and (bn.weight is None or bn.weight.dtype == torch.float32)):
+        return bn(x)
+    rows = x.permute(0, 2, 3, 1)
+    if not rows.is_contiguous():
+        return bn(x)
+    n, h, w, c = rows.shape
+    rows = rows.reshape(n * h * w, c)
+    if not native.bn_rows_supported(rows) or rows.shape[0] < MIN_ROWS_FUSED_LINEAR:
+        return bn(x)
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+    y = _BatchNormRows.apply(rows, bn.weight, bn.bias, float(bn.eps), float(bn.momentum), rm, rv)
+    return y.view(n, h, w, c).permute(0, 3, 1, 2)

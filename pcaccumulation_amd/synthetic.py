@@ -67,10 +67,14 @@ def make_sequence(seed, n_frames, pts_per_frame, cfg, mode='uniform', n_inst=20,
         if mode == 'uniform':
             bg = np.stack([rng.uniform(-crop, crop, n_bg), rng.uniform(-crop, crop, n_bg),
                            rng.uniform(z_lo, z_hi, n_bg)], axis=1)
-        elif mode == 'lidar':
+        elif mode in ('lidar', 'lidar_scan'):
             r = 2.0 * (45.0 / 2.0) ** rng.uniform(0, 1, n_bg)          # density ~ 1/r
             az = rng.uniform(0, 2 * np.pi, n_bg)
-            elev = np.deg2rad(np.linspace(-17.6, 2.4, 64))[rng.randint(0, 64, n_bg)]
+            beam = rng.randint(0, 64, n_bg)
+            elev = np.deg2rad(np.linspace(-17.6, 2.4, 64))[beam]
+            if mode == 'lidar_scan':                                   # the order a spinning sensor delivers: beam by beam, by azimuth
+                order = np.lexsort((az, beam))
+                r, az, elev = r[order], az[order], elev[order]
             bg = np.stack([r * np.cos(az), r * np.sin(az), 1.8 + r * np.tan(elev)], axis=1)
             bg[:, 0] = np.clip(bg[:, 0], -crop, crop)
             bg[:, 1] = np.clip(bg[:, 1], -crop, crop)

@@ -123,4 +123,4 @@ class SegHead2D(nn.Module):
 
     def forward(self, feats):
         conv0, bn, act, conv1 = self.seg_head
-        return ops.conv3x3(act(bn(ops.conv3x3(feats, conv0))), conv1)          # library for c_out = 2, MFMA kernel for 64 -> 64
+        return ops.conv3x3(act(ops.batch_norm_nchw(ops.conv3x3(feats, conv0), bn)), conv1)          # library for c_out = 2, MFMA kernel for 64 -> 64

@@ -105,6 +105,48 @@ def toy(rank, world, out):
     torch.save(res, out)
 
 
+class Branchy(torch.nn.Module):
+    """Four heads over a shared trunk; which heads run depends on the input (a rank-dependent set), like MotionNet's STPN / TubeNet
+    branches (models/motionnet.py:222,243)."""
+
+    def __init__(self):
+        super().__init__()
+        self.trunk = torch.nn.Linear(6, 16)
+        self.heads = torch.nn.ModuleList([torch.nn.Linear(16, 120) for _ in range(4)])      # 120 x 16 floats: a bucket each at 8 KB buckets
+
+    def forward(self, inp):
+        y = torch.tanh(self.trunk(inp['x']))
+        out = y.sum() * 0.1
+        for i, h in enumerate(self.heads):
+            if inp['use'][i]:
+                out = out + h(y).pow(2).mean() * (i + 1)
+        return out
+
+
+def branchy_input(rank, step):
+    g = torch.Generator().manual_seed(1000 + 17 * rank + step)
+    # rank r skips head r (and rank 3 additionally head 0); on step 1 nobody runs head 2 at all
+    use = [i != rank and not (rank == 3 and i == 0) and not (step == 1 and i == 2) for i in range(4)]
+    return {'x': torch.randn(5, 6, generator=g), 'use': use}
+
+
+def branchy(rank, world, out):
+    """DataParallelStep over `world` ranks with a rank-dependent set of skipped branches: two optimizer steps, iter_size 2."""
+    from pcaccumulation_amd import distributed as pdist
+    torch.manual_seed(0)
+    net = Branchy()
+    opt = torch.optim.SGD(net.parameters(), lr=0.05)
+    red = pdist.BucketedGradReducer(net.parameters(), bucket_bytes=8 * 1024)
+    step = pdist.DataParallelStep(net, opt, lambda o, i: {'loss': o}, iter_size=2, grad_clip=None, reducer=red, catch=False)
+    grads = []
+    for s in range(2):
+        for micro in range(2):
+            step(branchy_input(rank, 2 * s + micro))
+        grads.append({k: (p.grad.clone() if p.grad is not None else None) for k, p in net.named_parameters()})
+    torch.save({'params': {k: p.detach().clone() for k, p in net.named_parameters()}, 'grads': grads, 'skipped': step.skipped,
+                'n_buckets': len(red.buckets)}, out)
+
+
 def motionnet_batch(cfg, rank):
     """rank 0: an ordinary tiny scene; rank 1: a scene without any foreground point (STPN and TubeNet are skipped there)."""
     from helpers import oracle_voxeliser
@@ -155,7 +197,7 @@ def main():
     from pcaccumulation_amd import distributed as pdist
     r, w, _ = pdist.init_from_env(backend='gloo')
     assert (r, w) == (rank, world)
-    {'toy': toy, 'motionnet': motionnet}[mode](rank, world, out)
+    {'toy': toy, 'motionnet': motionnet, 'branchy': branchy}[mode](rank, world, out)
     pdist.barrier()
     torch.distributed.destroy_process_group()
 

@@ -212,3 +212,31 @@ def test_split_kernels_report_their_output_maximum_and_tags_follow_the_tensor():
     assert ops.amax_tag(a) is not None and float(ops.amax_tag(a).max()) == float(a.abs().max())          # produced by the kernel, carried through the permute
     a.add_(1.0)
     assert ops.amax_tag(a) is None                                                                        # an in-place write invalidates the tag
+
+
+@pytest.mark.parametrize('n,t,h,w,ci,co,kt', [(2, 1, 16, 32, 32, 32, 1), (1, 1, 19, 45, 64, 32, 1), (3, 1, 8, 33, 32, 64, 1), (2, 1, 40, 40, 64, 64, 1),
+                                              (6, 3, 12, 36, 32, 32, 3), (4, 2, 33, 70, 32, 64, 3), (2, 1, 100, 70, 32, 32, 1), (5, 5, 9, 9, 64, 64, 3),
+                                              (1, 1, 1, 1, 32, 32, 1), (2, 2, 3, 300, 64, 32, 3)])
+def test_conv3x3_split_resident_kernel(n, t, h, w, ci, co, kt, monkeypatch):
+    """The persistent kernel of the narrow layers (weights of a slice resident in LDS, patches prefetched across tiles), forced on at
+    test sizes: forward and masked data gradient against float64, and bit-equal maxima reporting."""
+    monkeypatch.setenv('PCACC_CONV_RES', '2')
+    g = torch.Generator(device='cpu').manual_seed(n + h + w + ci + co)
+    x = torch.randn(n, h, w, ci, generator=g).to(DEV).requires_grad_(True)
+    shape = (co, ci, 3, 3, 3) if kt == 3 else (co, ci, 3, 3)
+    wt = (torch.randn(*shape, generator=g) / (4 * ci ** 0.5)).to(DEV).requires_grad_(True)
+    bias = torch.randn(co, generator=g).to(DEV).requires_grad_(True)
+    gy = torch.randn(n, h, w, co, generator=g).to(DEV)
+    y = ops.conv3x3_rows(x, wt, bias, t if kt == 3 else 1, True)
+    y.backward(gy)
+    xr, wr, br = (v.detach().double().requires_grad_(True) for v in (x, wt, bias))
+    if kt == 3:
+        yr = F.conv3d(xr.view(n // t, t, h, w, ci).permute(0, 4, 1, 2, 3), wr, br, padding=1).permute(0, 2, 3, 4, 1).reshape(n, h, w, co)
+    else:
+        yr = F.conv2d(xr.permute(0, 3, 1, 2), wr, br, padding=1).permute(0, 2, 3, 1)
+    (yr * (y.detach() > 0)).backward(gy.double())
+    assert _rel(y, torch.relu(yr.detach())) <= TOL and _rel(x.grad, xr.grad) <= TOL and _rel(wt.grad, wr.grad) <= TOL
+    assert float(ops.amax_tag(y).max()) == float(y.abs().max())
+    monkeypatch.setenv('PCACC_CONV_RES', '0')
+    y0 = ops.conv3x3_rows(x.detach(), wt.detach(), bias.detach(), t if kt == 3 else 1, True)
+    assert _rel(y0, y.detach()) <= 1e-6                        # the two kernels sum in different orders

