@@ -202,13 +202,21 @@ extern "C" int pcacc_conv3x3_split_prepare_weights(const float *w, int32_t c_out
 }
 
 // ---- forward / data gradient --------------------------------------------------------------------------------------------------------
-template <int CS, int NW, int NGW, int MT>
+// TAPS = 9: the 3x3 (x kt frames) convolution.  TAPS = 1: a 1x1 product on the same tiles, the two halves of nn.ConvTranspose2d(kernel 2, stride 2)
+// (models/unet.py:22-30,101-113):  mode CSP_UP  -- out[n, 2y+a, 2x+b, co] = bias[co] + sum_ci in[n,y,x,ci] W[ci,co,a,b]: prepared rows co' = (a, b, co),
+// the epilogue scatters a pixel's 4 c_up results to its 2 x 2 output pixels;  mode CSP_S2D -- its data gradient: input channel k' = (a, b, co) of
+// pixel (y, x) is dy[n, 2y+a, 2x+b, co] (read in place while staging), c_in' = 4 c_up.
+#define CSP_PLAIN 0
+#define CSP_UP 1
+#define CSP_S2D 2
+
+template <int CS, int NW, int NGW, int MT, int TAPS>
 __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float *__restrict__ in, const float *__restrict__ in_amax,
                                                                     const float *__restrict__ in_mask, const uint16_t *__restrict__ wp,
                                                                     const float *__restrict__ wscale, const float *__restrict__ bias,
                                                                     float *__restrict__ out, float *__restrict__ out_amax, int n_img, int frames,
                                                                     int h, int w, int c_in, int c_out, int kt, int relu, int rows, int bw,
-                                                                    int tiles_y, int tiles_x, int co_groups)
+                                                                    int tiles_y, int tiles_x, int co_groups, int mode, int c_up)
 {
     constexpr int PS = CS + 8;                                 // padded LDS row (elements)
     constexpr int MG = 8 / NGW;                                // waves along the pixel dimension
@@ -240,7 +248,7 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float 
     const int f_lo = (kt == 3 && t_frame == 0) ? 1 : 0;
     const int f_hi = kt == 3 ? (t_frame == frames - 1 ? 1 : 2) : 0;
     const int nc = c_in / CS;
-    const int s0 = f_lo * nc, n_slices = (f_hi - f_lo + 1) * nc, n_taps = n_slices * 9;
+    const int s0 = f_lo * nc, n_slices = (f_hi - f_lo + 1) * nc, n_taps = n_slices * TAPS;
 
     // the lane's pixels: LDS offset of the top-left tap of their 3x3 windows, image position for the store
     int poff[MT], pyx[MT];
@@ -274,6 +282,8 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float 
     auto fetch_patch = [&](int sl) {                           // sl = index into the valid slices
         const int s = s0 + sl, f = s / nc, cs = s - f * nc;
         const int64_t img_off = (int64_t)(img + (kt == 3 ? f - 1 : 0)) * h * w * c_in;
+        // space-to-depth source (CSP_S2D): the slice's channels (a, b, ch ..) live in pixel (2y + a, 2x + b) of the [2h, 2w, c_up] map
+        const int ab = mode == CSP_S2D ? (cs * CS) / c_up : 0, ch0 = mode == CSP_S2D ? (cs * CS) % c_up : 0;
 #pragma unroll
         for (int q = 0; q < CSP_PCH; ++q) {
             const int py = pinfo[q] >> 20, pxx = (pinfo[q] >> 8) & 0xfff, c8 = pinfo[q] & 0xff;
@@ -281,7 +291,9 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float 
             // always load (from a clamped position), then select: a load under a lane mask costs a branch and an early wait
             const bool ok = (unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w;
             const int yc = min(max(y, 0), h - 1), xc = min(max(x, 0), w - 1);
-            const int64_t off = img_off + ((int64_t)yc * w + xc) * c_in + cs * CS + c8 * 8;
+            const int64_t off = mode == CSP_S2D
+                                    ? (((int64_t)img * 2 * h + 2 * yc + (ab >> 1)) * 2 * w + 2 * xc + (ab & 1)) * c_up + ch0 + c8 * 8
+                                    : img_off + ((int64_t)yc * w + xc) * c_in + cs * CS + c8 * 8;
             float4 a = *reinterpret_cast<const float4 *>(in + off), b = *reinterpret_cast<const float4 *>(in + off + 4);
             if (in_mask) {                                     // uniform
                 a = csp_relu_mask4(a, *reinterpret_cast<const float4 *>(in_mask + off));
@@ -308,12 +320,12 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float 
     // weight tile of (slice, tap): 2 planes x WROWS rows x CS elements.  Requested TWO taps ahead into alternating register sets, written
     // to the other LDS buffer one tap ahead.
     constexpr int W_CH_PLANE = WROWS * C8, W_CHUNKS = 2 * W_CH_PLANE, W_PER = (W_CHUNKS + CSP_THREADS - 1) / CSP_THREADS;
-    const int64_t w_plane = (int64_t)kt * 9 * c_out * c_in;    // elements of one prepared plane
+    const int64_t w_plane = (int64_t)kt * TAPS * c_out * c_in; // elements of one prepared plane
     uint4 wreg[2][W_PER];
     auto fetch_w = [&](int set, int g) {                       // g = linear tap index over the valid slices
-        const int sl = g / 9, tap = g - sl * 9;
+        const int sl = g / TAPS, tap = g - sl * TAPS;
         const int s = s0 + sl, f = s / nc, cs = s - f * nc;
-        const uint16_t *src = wp + ((int64_t)(f * 9 + tap) * c_out + co0) * c_in + cs * CS;
+        const uint16_t *src = wp + ((int64_t)(f * TAPS + tap) * c_out + co0) * c_in + cs * CS;
 #pragma unroll
         for (int q = 0; q < W_PER; ++q) {
             const int c = (W_CHUNKS % CSP_THREADS) ? min((int)threadIdx.x + q * CSP_THREADS, W_CHUNKS - 1) : threadIdx.x + q * CSP_THREADS;
@@ -342,13 +354,13 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float 
         write_patch();
         if (sl + 1 < n_slices) fetch_patch(sl + 1);            // in flight during the nine taps below
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int g = sl * 9 + tap;
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int g = sl * TAPS + tap;
             uint16_t *cur = (tap & 1) ? wb1 : wb0, *other = (tap & 1) ? wb0 : wb1;
             __syncthreads();                                   // buffer `cur` (and, at tap 0, the patch) is visible
             if (g + 2 < n_taps) fetch_w(tap & 1, g + 2);       // set (tap & 1) held tap g: already in LDS
             const uint16_t *wa = cur + (ngw * NW * 32 + lp) * PS + lh * 8;
-            const int toff = ((tap / 3) * pw + tap % 3) * PS + lh * 8;
+            const int toff = (TAPS == 1 ? pw + 1 : (tap / 3) * pw + tap % 3) * PS + lh * 8;     // one tap: the pixel itself
             constexpr int KC = CS / 16;
             constexpr int FB = (MT * NW >= 6 || MT >= 3) ? 1 : 2;   // fragment sets: the widest waves have no registers for a second one
             f16x8_t ah[FB][NW], al[FB][NW], bh[FB][MT], bl[FB][MT];
@@ -389,7 +401,7 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float 
             }
             if (g + 1 < n_taps) write_w(other, (tap + 1) & 1);   // tap g + 1 (requested two taps ago) into the buffer tap g - 1 used
         }
-        // nine taps per slice: the next slice's tap 0 sits in register set 1 / goes to the odd buffer -- swap the roles (a few moves)
+        // nine taps (or one) per slice -- an odd number: the next slice's tap 0 sits in register set 1 / goes to the odd buffer: swap the roles
         {
             uint16_t *t = wb0; wb0 = wb1; wb1 = t;
 #pragma unroll
@@ -411,7 +423,13 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float 
             for (int g = 0; g < 4; ++g) {
                 const int c = n * 32 + 8 * g + 4 * lh;
                 float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (bias) bv = *reinterpret_cast<const float4 *>(bias + cw0 + c);
+                int cb = cw0 + c;                              // bias index; CSP_UP: channel (a, b, co) -> pixel (2y + a, 2x + b), channel co
+                if (mode == CSP_UP) {
+                    const int ab2 = cb / c_up;
+                    cb -= ab2 * c_up;
+                    dst = out + (((int64_t)img * 2 * h + 2 * (pyx[j] >> 16) + (ab2 >> 1)) * 2 * w + 2 * (pyx[j] & 0xffff) + (ab2 & 1)) * c_up + cb - c;
+                }
+                if (bias) bv = *reinterpret_cast<const float4 *>(bias + cb);
                 float4 sc = *reinterpret_cast<const float4 *>(wscale + cw0 + c);          // 1 / t per output channel
                 sc = make_float4(sc.x * inv_sx, sc.y * inv_sx, sc.z * inv_sx, sc.w * inv_sx);
                 float4 v = make_float4(acc[j][n][4 * g] * sc.x + bv.x, acc[j][n][4 * g + 1] * sc.y + bv.y, acc[j][n][4 * g + 2] * sc.z + bv.z,
@@ -746,7 +764,7 @@ static bool conv_split_fits(int cs, int wrows, int rows, int bw, size_t *lds)
     return pp * (cs / 8) <= CSP_THREADS * CSP_PCH && *lds <= CSP_LDS_MAX && rows + 2 < 0x7ff && bw + 2 < 0xfff;
 }
 
-static bool conv_split_plan(int n_img, int h, int w, int c_in, int c_out, int kt, ConvSplitPlan *best)
+static bool conv_split_plan(int n_img, int h, int w, int c_in, int c_out, int kt, ConvSplitPlan *best, int taps = 9, int cs_must_divide = 0)
 {
     if (c_in < 32 || c_in % 32 || c_out < 32 || c_out % 32 || h < 1 || w < 1 || h > 32767 || w > 32767) return false;
     bool found = false;
@@ -760,7 +778,7 @@ static bool conv_split_plan(int n_img, int h, int w, int c_in, int c_out, int kt
             if (nw == 2 && mt == 3) continue;                  // instantiated: (2,2) and (2,1) x MT 1..2 (MT = 3 spills), (1,1) x MT 1..3
             const int cap = mg * mt * 32;
             for (int cs = 64; cs >= 32; cs -= 32) {
-                if (c_in % cs) continue;
+                if (c_in % cs || (cs_must_divide && cs_must_divide % cs)) continue;
                 // band widths: the whole row when it fits a tile, else bands of about 32 / 64 / 96 pixels (balanced over the row)
                 for (int bi = 0; bi < 4; ++bi) {
                     int bw = bi == 0 ? w : 32 * bi;
@@ -781,7 +799,7 @@ static bool conv_split_plan(int n_img, int h, int w, int c_in, int c_out, int kt
                     const int64_t blocks = (int64_t)n_img * tiles_y * tiles_x * (c_out / wrows);
                     const int64_t rounds = (blocks + PCACC_CUS - 1) / PCACC_CUS;
                     // per (slice, tap): 3 MFMAs per fragment pair and 16 k, ~6 MFMA times for the barrier / weight tile; per slice: the patch
-                    const int64_t per_slice = 9 * ((int64_t)(cs / 16) * 3 * nw * mt + 6) + (int64_t)(r + 2) * (bw + 2) * cs / 1024;
+                    const int64_t per_slice = taps * ((int64_t)(cs / 16) * 3 * nw * mt + 6) + (int64_t)(r + 2) * (bw + 2) * cs / 1024;
                     const int64_t cost = rounds * per_slice * (c_in / cs);
                     const int64_t waste = (int64_t)mg * mt * 32 * tiles_y * tiles_x - (int64_t)h * w;
                     if (!found || cost < best_cost || (cost == best_cost && waste < best_waste)) {
@@ -798,17 +816,17 @@ static bool conv_split_plan(int n_img, int h, int w, int c_in, int c_out, int kt
     return found;
 }
 
-template <int CS, int NW, int NGW, int MT>
+template <int CS, int NW, int NGW, int MT, int TAPS = 9>
 static int conv_split_launch(const ConvSplitPlan &p, const float *in, const float *in_amax, const float *in_mask, const uint16_t *wp,
                              const float *wscale, const float *bias, float *out, float *out_amax, int n_img, int frames, int h, int w, int c_in,
-                             int c_out, int kt, int relu, hipStream_t st)
+                             int c_out, int kt, int relu, hipStream_t st, int mode = CSP_PLAIN, int c_up = 0)
 {
-    auto kern = conv3x3_split_kernel<CS, NW, NGW, MT>;
+    auto kern = conv3x3_split_kernel<CS, NW, NGW, MT, TAPS>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds) != hipSuccess)
         return PCACC_E_LAUNCH;
     if (p.blocks > 0x7fffffff) return PCACC_E_ARG;
     hipLaunchKernelGGL(kern, dim3((unsigned)p.blocks), dim3(CSP_THREADS), p.lds, st, in, in_amax, in_mask, wp, wscale, bias, out, out_amax, n_img,
-                       frames, h, w, c_in, c_out, kt, relu, p.rows, p.bw, p.tiles_y, p.tiles_x, p.co_groups);
+                       frames, h, w, c_in, c_out, kt, relu, p.rows, p.bw, p.tiles_y, p.tiles_x, p.co_groups, mode, c_up);
     PCACC_CHECK_LAUNCH();
     return 0;
 }
@@ -872,18 +890,21 @@ __device__ __forceinline__ f16x8_t csp_tr_frag(const uint16_t *p, int stride4)
     return f.v;
 }
 
-template <int CO_T, int CI_T>
+template <int CO_T, int CI_T, int TAPS>
 __global__ __launch_bounds__(CSP_THREADS) void conv3x3_wgrad_split_kernel(const float *__restrict__ dy, const float *__restrict__ dy_amax,
                                                                           const float *__restrict__ dy_mask, const float *__restrict__ x,
                                                                           const float *__restrict__ x_amax, float *__restrict__ partial,
                                                                           int n_img, int frames, int dt, int h, int w, int c_in, int c_out,
-                                                                          int rows, int bw, int tiles_y, int tiles_x, int ci_blocks, int slots)
+                                                                          int rows, int bw, int tiles_y, int tiles_x, int ci_blocks, int slots, int c_up)
 {
     // 32 x 32 blocks: one (co, ci) pair -- the 8 waves are 2 halves of the 16-pixel steps x 4 tap groups (3 | 2 | 2 | 2 taps) and each half
     // keeps its own partial slot; with 8 tap groups (2 | 1 x 7 taps) wave 0 did twice the work of the others.
-    constexpr int CO = CO_T * 32, CI = CI_T * 32, PAIRS = CO_T * CI_T, HALVES = PAIRS == 1 ? 2 : 1, G = 8 / (PAIRS * HALVES), NT = (9 + G - 1) / G;
+    // TAPS = 1 (the 2x2 transposed convolution: dW'[(a,b,co)][ci] = sum dy[2y+a,2x+b,co] x[y,x,ci], c_up > 0: dY read space-to-depth): no taps
+    // to share out -- all waves of a pair split the pixel steps.
+    constexpr int CO = CO_T * 32, CI = CI_T * 32, PAIRS = CO_T * CI_T, HALVES = TAPS == 1 ? 8 / PAIRS : (PAIRS == 1 ? 2 : 1), G = 8 / (PAIRS * HALVES),
+                  NT = (TAPS + G - 1) / G;
     constexpr int YS = pcacc_tr_stride(CO), XS = pcacc_tr_stride(CI);
-    constexpr int SLOT = CO * 9 * CI + CO;
+    constexpr int SLOT = CO * TAPS * CI + CO;
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     const int pw = bw + 2, pp = (rows + 2) * pw;
     const int n_px = rows * bw, n_steps = (n_px + 15) >> 4, py_rows = n_steps * 16;
@@ -923,6 +944,7 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_wgrad_split_kernel(const 
         const int y0 = (rem / tiles_x) * rows, x0 = (rem % tiles_x) * bw;
         const float *ysrc = dy + (int64_t)img * h * w * c_out + co0;
         const float *msrc = dy_mask ? dy_mask + (int64_t)img * h * w * c_out + co0 : nullptr;
+        const int ab = c_up ? co0 / c_up : 0, ch0 = c_up ? co0 % c_up : 0;      // space-to-depth: this block's channels sit in pixel (2y+a, 2x+b)
         const float *xsrc = x + (int64_t)(img + dt) * h * w * c_in + ci0;
 #pragma unroll
         for (int q = 0; q < CSW_PCH; ++q) {
@@ -936,6 +958,10 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_wgrad_split_kernel(const 
             const bool ok = c < n_chunks && (unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w && (!is_y || px < n_px);
             const int64_t pos = (int64_t)min(max(yy, 0), h - 1) * w + min(max(xx, 0), w - 1);
             const float *src = is_y ? ysrc + pos * c_out + c8 * 8 : xsrc + pos * c_in + c8 * 8;
+            if (c_up && is_y) {
+                const int yc = min(max(yy, 0), h - 1), xc = min(max(xx, 0), w - 1);
+                src = dy + (((int64_t)img * 2 * h + 2 * yc + (ab >> 1)) * 2 * w + 2 * xc + (ab & 1)) * c_up + ch0 + c8 * 8;
+            }
             float4 a = *reinterpret_cast<const float4 *>(src), b = *reinterpret_cast<const float4 *>(src + 4);
             if (msrc && is_y) {
                 const float *m = msrc + pos * c_out + c8 * 8;
@@ -997,8 +1023,8 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_wgrad_split_kernel(const 
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int tap = grp + j * G;                   // uniform per wave
-                if (tap < 9) {
-                    const int toff = ((tap / 3) * pw + tap % 3) * XS;
+                if (tap < TAPS) {
+                    const int toff = (TAPS == 1 ? pw + 1 : (tap / 3) * pw + tap % 3) * XS;
                     csp_frag bh, bl;
                     bh.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((csp_s16x4 __attribute__((address_space(3))) *)(pb0 + toff));
                     bh.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((csp_s16x4 __attribute__((address_space(3))) *)(pb1 + toff));
@@ -1016,41 +1042,41 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_wgrad_split_kernel(const 
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int tap = grp + j * G;
-        if (tap < 9)
+        if (tap < TAPS)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                mine[((int64_t)co * 9 + tap) * CI + it * 32 + lp] = acc[j][r];
+                mine[((int64_t)co * TAPS + tap) * CI + it * 32 + lp] = acc[j][r];
             }
     }
     if (grp != 0) return;
     bsum += __shfl_xor(bsum, 32, 64);                          // the two half-waves hold pixels 0-7 / 8-15 of the same channel
-    if (it == 0 && lh == 0) mine[CO * 9 * CI + ct * 32 + lp] = bsum;
+    if (it == 0 && lh == 0) mine[CO * TAPS * CI + ct * 32 + lp] = bsum;
 }
 
 // out[co][tap][ci] (full tensor) and db[co] from the per-workgroup slots, scales removed.  A workgroup = 64 output elements x 4 slot groups
 // (wave g sums the slots p = g, g + 4, ...), combined through LDS in a fixed order: the 32 x 32 layers have 9 248 elements and 256 slots --
 // with one thread per element the launch was 37 workgroups walking 256 partials each (40 us, 2 ms per step over 52 launches).
 __global__ __launch_bounds__(256) void conv_wgrad_split_reduce_kernel(const float *__restrict__ partial, int slots, int c_in, int c_out,
-                                                                      int cob, int cib, const float *__restrict__ dy_amax,
+                                                                      int cob, int cib, int taps, const float *__restrict__ dy_amax,
                                                                       const float *__restrict__ x_amax, float *__restrict__ dw,
                                                                       float *__restrict__ db)
 {
     const float inv_y = 1.f / csp_scale_from_parts(dy_amax), inv_yx = inv_y / csp_scale_from_parts(x_amax);
-    const int slot_elems = cob * 9 * cib + cob, ci_blocks = c_in / cib;
-    const int64_t n_w = (int64_t)c_out * 9 * c_in;
+    const int slot_elems = cob * taps * cib + cob, ci_blocks = c_in / cib;
+    const int64_t n_w = (int64_t)c_out * taps * c_in;
     const int64_t e = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
     const int grp = threadIdx.x >> 6;
     __shared__ float sm[4][64];
     float s = 0.f;
     const float *src = nullptr;
     if (e < n_w) {
-        const int ci = (int)(e % c_in), tap = (int)((e / c_in) % 9), co = (int)(e / ((int64_t)9 * c_in));
+        const int ci = (int)(e % c_in), tap = (int)((e / c_in) % taps), co = (int)(e / ((int64_t)taps * c_in));
         const int block = (co / cob) * ci_blocks + ci / cib;
-        src = partial + (int64_t)block * slots * slot_elems + ((int64_t)(co % cob) * 9 + tap) * cib + ci % cib;
+        src = partial + (int64_t)block * slots * slot_elems + ((int64_t)(co % cob) * taps + tap) * cib + ci % cib;
     } else if (e < n_w + c_out) {
         const int co = (int)(e - n_w);
-        src = partial + (int64_t)((co / cob) * ci_blocks) * slots * slot_elems + cob * 9 * cib + co % cob;   // ci block 0 carries the bias sums
+        src = partial + (int64_t)((co / cob) * ci_blocks) * slots * slot_elems + cob * taps * cib + co % cob;   // ci block 0 carries the bias sums
     }
     if (src) {
         float s0 = 0.f, s1 = 0.f;
@@ -1080,10 +1106,10 @@ static bool conv_wsplit_fits(int cob, int cib, int rows, int bw, size_t *lds)
     return py_rows * (cob / 8) + pp * (cib / 8) <= CSP_THREADS * CSW_PCH && *lds <= 150 * 1024 && pp < 65536;
 }
 
-static bool conv_wsplit_plan(int n_img, int h, int w, int c_in, int c_out, ConvSplitWPlan *best)
+static bool conv_wsplit_plan(int n_img, int h, int w, int c_in, int c_out, ConvSplitWPlan *best, int co_group = 0)
 {
     if (c_in < 32 || c_in % 32 || c_out < 32 || c_out % 32 || h < 1 || w < 1 || n_img < 1) return false;
-    const int cob = c_out % 64 == 0 ? 64 : 32, cib = c_in % 64 == 0 ? 64 : 32;
+    const int cob = (co_group ? co_group : c_out) % 64 == 0 ? 64 : 32, cib = c_in % 64 == 0 ? 64 : 32;     // co_group: channels per (a, b) group
     bool found = false;
     int64_t best_cost = 0;
     // band widths: the whole row, or bands of about 16 / 32 / 64 pixels; rows as many as fit.  Cost = padded 16-pixel steps (MFMA work)
@@ -1120,7 +1146,11 @@ static bool conv_wsplit_plan(int n_img, int h, int w, int c_in, int c_out, ConvS
     return found;
 }
 
-static int conv_wsplit_halves(const ConvSplitWPlan &p) { return (p.cob == 32 && p.cib == 32) ? 2 : 1; }   // partial slots per workgroup
+static int conv_wsplit_halves(const ConvSplitWPlan &p, int taps = 9)      // partial slots per workgroup
+{
+    const int pairs = (p.cob / 32) * (p.cib / 32);
+    return taps == 1 ? 8 / pairs : (pairs == 1 ? 2 : 1);
+}
 
 extern "C" int pcacc_conv3x3_wgrad_split_workspace_bytes(int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_out, size_t *bytes)
 {
@@ -1148,17 +1178,142 @@ extern "C" int pcacc_conv3x3_wgrad_split(const float *dy, const float *dy_amax, 
                 p.cob, p.cib, p.rows, p.bw, p.blocks, p.slots, p.lds);
 #define CSW_CASE(COT, CIT)                                                                                                              \
     if (p.cob == COT * 32 && p.cib == CIT * 32) {                                                                                       \
-        auto kern = conv3x3_wgrad_split_kernel<COT, CIT>;                                                                               \
+        auto kern = conv3x3_wgrad_split_kernel<COT, CIT, 9>;                                                                            \
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds) != hipSuccess) \
             return PCACC_E_LAUNCH;                                                                                                      \
         hipLaunchKernelGGL(kern, dim3(p.blocks * p.slots), dim3(CSP_THREADS), p.lds, st, dy, dy_amax, dy_mask, x, x_amax, partial, n_img, frames, dt, h, w, \
-                           c_in, c_out, p.rows, p.bw, p.tiles_y, p.tiles_x, c_in / p.cib, p.slots);                                     \
+                           c_in, c_out, p.rows, p.bw, p.tiles_y, p.tiles_x, c_in / p.cib, p.slots, 0);                                  \
     }
     CSW_CASE(1, 1) else CSW_CASE(1, 2) else CSW_CASE(2, 1) else CSW_CASE(2, 2) else return PCACC_E_ARG;
 #undef CSW_CASE
     const int64_t elems = (int64_t)c_out * 9 * c_in + c_out;
     hipLaunchKernelGGL(conv_wgrad_split_reduce_kernel, dim3((unsigned)((elems + 63) / 64)), dim3(256), 0, st, partial, p.slots * conv_wsplit_halves(p), c_in,
-                       c_out, p.cob, p.cib, dy_amax, x_amax, dw, db);
+                       c_out, p.cob, p.cib, 9, dy_amax, x_amax, dw, db);
+    PCACC_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- nn.ConvTranspose2d(kernel 2, stride 2) of the two decoders (models/unet.py:22-30,101-113) on the kernels above ------------------
+// weights: w f32 [c_in][c_up][2][2] (torch layout, read through `strides`: elements i, o, y, x) ->
+//   forward form      fp16 [2][1][4 c_up][c_in]  rows co' = (a, b, co)      + 1 / row scale [4 c_up]
+//   data-gradient form fp16 [2][1][c_in][4 c_up]  columns k' = (a, b, co)    + 1 / row scale [c_in]
+__global__ __launch_bounds__(256) void upconv_split_prepare_kernel(const float *__restrict__ w, int c_in, int c_up, int64_t si, int64_t so, int64_t sy,
+                                                                   int64_t sx, uint16_t *__restrict__ out_fwd, float *__restrict__ inv_fwd,
+                                                                   uint16_t *__restrict__ out_bwd, float *__restrict__ inv_bwd)
+{
+    const int n4 = 4 * c_up;
+    const bool bwd = (int)blockIdx.x >= n4;
+    const int row = bwd ? blockIdx.x - n4 : blockIdx.x;
+    const int n = bwd ? n4 : c_in;                             // elements of the row
+    const int64_t total = (int64_t)n4 * c_in;
+    auto src = [&](int e) {
+        const int cop = bwd ? e : row, ci = bwd ? row : e;     // co' = (ab, co)
+        const int ab = cop / c_up, co = cop - ab * c_up;
+        return w[ci * si + co * so + (ab >> 1) * sy + (ab & 1) * sx];
+    };
+    float m = 0.f;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const float v = src(e);
+        m = fmaxf(m, fabsf(v));
+        if (v != v) m = __builtin_inff();
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+    __shared__ float sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    const float t = csp_scale_of(fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3])));
+    if (threadIdx.x == 0) (bwd ? inv_bwd : inv_fwd)[row] = 1.f / t;
+    uint16_t *dst = (bwd ? out_bwd : out_fwd) + (int64_t)row * n;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const float v = src(e) * t;
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        dst[e] = *reinterpret_cast<const uint16_t *>(&hi);
+        dst[total + e] = *reinterpret_cast<const uint16_t *>(&lo);
+    }
+}
+
+extern "C" int pcacc_upconv2x2_split_prepare_weights(const float *w, int32_t c_in, int32_t c_up, const int64_t *strides, uint16_t *out_fwd,
+                                                     float *scale_fwd, uint16_t *out_bwd, float *scale_bwd, void *stream)
+{
+    if (!w || !strides || !out_fwd || !scale_fwd || !out_bwd || !scale_bwd || c_in < 1 || c_up < 1) return PCACC_E_ARG;
+    hipLaunchKernelGGL(upconv_split_prepare_kernel, dim3(4 * c_up + c_in), dim3(256), 0, pcacc_stream(stream), w, c_in, c_up, strides[0], strides[1],
+                       strides[2], strides[3], out_fwd, scale_fwd, out_bwd, scale_bwd);
+    PCACC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pcacc_upconv2x2_split_supported(int32_t h, int32_t w, int32_t c_in, int32_t c_up)
+{
+    ConvSplitPlan p;
+    ConvSplitWPlan q;
+    return c_up % 32 == 0 && conv_split_plan(1, h, w, c_in, 4 * c_up, 1, &p, 1) && conv_split_plan(1, h, w, 4 * c_up, c_in, 1, &p, 1, c_up) &&
+           conv_wsplit_plan(1, h, w, c_in, 4 * c_up, &q, c_up);
+}
+
+// direction 0: out [n, 2h, 2w, c_up] = upconv(in [n, h, w, c_in]) + bias;  direction 1: out [n, h, w, c_in] = data gradient of in = dy [n, 2h, 2w, c_up]
+// (h, w = the SMALL map's size in both directions; wp / wscale: the matching form of prepare_weights; bias NULL for direction 1)
+extern "C" int pcacc_upconv2x2_split(const float *in, const float *in_amax, const uint16_t *wp, const float *wscale, const float *bias, float *out,
+                                     float *out_amax, int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_up, int32_t direction,
+                                     void *stream)
+{
+    if (!in || !in_amax || !wp || !wscale || !out || n_img < 1 || c_up < 32 || c_up % 32 || (direction != 0 && direction != 1)) return PCACC_E_ARG;
+    const int k_in = direction ? 4 * c_up : c_in, k_out = direction ? c_in : 4 * c_up;
+    ConvSplitPlan p;
+    if (!conv_split_plan(n_img, h, w, k_in, k_out, 1, &p, 1, direction ? c_up : 0)) return PCACC_E_ARG;
+    if (getenv("PCACC_CONV_PLAN"))
+        fprintf(stderr, "upconv plan dir %d %dx%d %d->%d n=%d: cs=%d nw=%d ngw=%d mt=%d rows=%d bw=%d blocks=%lld lds=%zu\n", direction, h, w, k_in, k_out,
+                n_img, p.cs, p.nw, p.ngw, p.mt, p.rows, p.bw, (long long)p.blocks, p.lds);
+    hipStream_t st = pcacc_stream(stream);
+    const int mode = direction ? CSP_S2D : CSP_UP;
+#define CSU_CASE(CSV, NWV, NGWV, MTV)                                          \
+    if (p.cs == CSV && p.nw == NWV && p.ngw == NGWV && p.mt == MTV)            \
+        return conv_split_launch<CSV, NWV, NGWV, MTV, 1>(p, in, in_amax, nullptr, wp, wscale, bias, out, out_amax, n_img, 1, h, w, k_in, k_out, 1, 0, st, mode, c_up)
+    CSU_CASE(64, 2, 2, 1); CSU_CASE(64, 2, 2, 2); CSU_CASE(64, 2, 1, 1); CSU_CASE(64, 2, 1, 2);
+    CSU_CASE(64, 1, 1, 1); CSU_CASE(64, 1, 1, 2); CSU_CASE(64, 1, 1, 3);
+    CSU_CASE(32, 2, 2, 1); CSU_CASE(32, 2, 2, 2); CSU_CASE(32, 2, 1, 1); CSU_CASE(32, 2, 1, 2);
+    CSU_CASE(32, 1, 1, 1); CSU_CASE(32, 1, 1, 2); CSU_CASE(32, 1, 1, 3);
+#undef CSU_CASE
+    return PCACC_E_ARG;
+}
+
+extern "C" int pcacc_upconv2x2_wgrad_split_workspace_bytes(int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_up, size_t *bytes)
+{
+    ConvSplitWPlan p;
+    if (!bytes || c_up < 32 || c_up % 32 || !conv_wsplit_plan(n_img, h, w, c_in, 4 * c_up, &p, c_up)) return PCACC_E_ARG;
+    *bytes = (size_t)p.blocks * p.slots * conv_wsplit_halves(p, 1) * (p.cob * p.cib + p.cob) * sizeof(float);
+    return 0;
+}
+
+// dw [4 c_up][c_in] f32 (row (a, b, co): the caller permutes to the module's [c_in][c_up][2][2]) and db4 [4 c_up] f32 (per (a, b, co) sums of dy: the
+// caller adds the four groups) from dy [n, 2h, 2w, c_up] and x [n, h, w, c_in]
+extern "C" int pcacc_upconv2x2_wgrad_split(const float *dy, const float *dy_amax, const float *x, const float *x_amax, float *dw, float *db4,
+                                           int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_up, void *workspace, size_t workspace_bytes,
+                                           void *stream)
+{
+    ConvSplitWPlan p;
+    if (!dy || !dy_amax || !x || !x_amax || !dw || !workspace || c_up < 32 || c_up % 32 || !conv_wsplit_plan(n_img, h, w, c_in, 4 * c_up, &p, c_up))
+        return PCACC_E_ARG;
+    const int halves = conv_wsplit_halves(p, 1);
+    const size_t need = (size_t)p.blocks * p.slots * halves * (p.cob * p.cib + p.cob) * sizeof(float);
+    if (workspace_bytes < need) return PCACC_E_WORKSPACE;
+    hipStream_t st = pcacc_stream(stream);
+    float *partial = static_cast<float *>(workspace);
+    const int c_out = 4 * c_up;
+#define CSUW_CASE(COT, CIT)                                                                                                             \
+    if (p.cob == COT * 32 && p.cib == CIT * 32) {                                                                                       \
+        auto kern = conv3x3_wgrad_split_kernel<COT, CIT, 1>;                                                                            \
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds) != hipSuccess) \
+            return PCACC_E_LAUNCH;                                                                                                      \
+        hipLaunchKernelGGL(kern, dim3(p.blocks * p.slots), dim3(CSP_THREADS), p.lds, st, dy, dy_amax, nullptr, x, x_amax, partial, n_img, 1, 0, h, w, \
+                           c_in, c_out, p.rows, p.bw, p.tiles_y, p.tiles_x, c_in / p.cib, p.slots, c_up);                               \
+    }
+    CSUW_CASE(1, 1) else CSUW_CASE(1, 2) else CSUW_CASE(2, 1) else CSUW_CASE(2, 2) else return PCACC_E_ARG;
+#undef CSUW_CASE
+    const int64_t elems = (int64_t)c_out * c_in + c_out;
+    hipLaunchKernelGGL(conv_wgrad_split_reduce_kernel, dim3((unsigned)((elems + 63) / 64)), dim3(256), 0, st, partial, p.slots * halves, c_in, c_out,
+                       p.cob, p.cib, 1, dy_amax, x_amax, dw, db4);
     PCACC_CHECK_LAUNCH();
     return 0;
 }

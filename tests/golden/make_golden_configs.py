@@ -8,7 +8,7 @@
     c5  nuScenes geometry,                                       T = 5,  80 k points / frame, B = 4, train step (loss + backward)
     nus11  nuScenes configuration as the reference ships it (configs/nuscene/nuscene.yaml:7-9: 11 sweeps), 30 k points / frame, val
 
-    python tests/golden/make_golden_configs.py c2 c3 c4 c5 nus11
+    python tests/golden/make_golden_configs.py c2 c3 c4 c5 nus11 c3_lidar
 
 Inputs are regenerated from seeds by pcaccumulation_amd.synthetic (byte-stable numpy RandomState); weights are the closed-form
 fill of synthetic.fill_state_dict_ plus two stored head-bias offsets (the foreground one placed in a gap of the logit
@@ -41,6 +41,9 @@ CONFIGS = {
     'c4': ('waymo', 10, 200000, (33,), 'val', 324),
     'c5': ('nuscene', 5, 80000, (34, 35, 36, 37), 'train', 325),
     'nus11': ('nuscene', 11, 30000, (38,), 'val', 326),
+    # c3 on LiDAR-distributed points (1/r range density, 64 beams, scan order within a frame -- synthetic mode 'lidar_scan'):
+    # crowded pillars near the sensor, ~3 points per pillar on average, long CSR segments
+    'c3_lidar': ('waymo', 5, 160000, (39,), 'train', 327, 'lidar_scan'),
 }
 
 
@@ -58,7 +61,7 @@ def _gap_threshold(d, lo=0.90, hi=0.97):
     return float(0.5 * (v[a + j] + v[a + j + 1])), float(gaps[j]), 1.0 - (a + j + 1) / v.numel()
 
 
-def _probe(cfg, seeds, T, ppf, fwd_seed, train):
+def _probe(cfg, seeds, T, ppf, fwd_seed, train, points='uniform'):
     """The two head-bias offsets (make_golden_model._tweak_biases) with a gap-seeking foreground threshold; train configs are probed
     in train() mode (BatchNorm batch statistics, as the step itself normalises), no gradients."""
     from models.motionnet import MotionNet
@@ -66,7 +69,7 @@ def _probe(cfg, seeds, T, ppf, fwd_seed, train):
     cfg = dict(cfg)
     cfg['misc'] = dict(cfg['misc'], mode='train' if train else 'val')
     vox = rh.voxeliser(cfg)
-    inp = rh.collate([attach_voxels(make_sequence(s, T, ppf, cfg), vox) for s in seeds])
+    inp = rh.collate([attach_voxels(make_sequence(s, T, ppf, cfg, mode=points), vox) for s in seeds])
     model = MotionNet(cfg)
     fill_state_dict_(model)
     model.train(train)
@@ -90,13 +93,14 @@ def _probe(cfg, seeds, T, ppf, fwd_seed, train):
 
 
 def gen(name):
-    dataset, T, ppf, seeds, mode, fwd_seed = CONFIGS[name]
+    dataset, T, ppf, seeds, mode, fwd_seed = CONFIGS[name][:6]
+    points = CONFIGS[name][6] if len(CONFIGS[name]) > 6 else 'uniform'
     cfg = default_config(dataset, mode, n_sweeps=T)
     t0 = time.time()
     train = mode == 'train'
     # the two head-bias offsets are found with probe forwards (_probe) and then applied to a freshly built model for the run
-    tweaks, gap = _probe(cfg, seeds, T, ppf, fwd_seed, train)
-    model, inp, out, stats, _ = _run(cfg, seeds, T, ppf, mode, fwd_seed, train=train, tweaks=tweaks)
+    tweaks, gap = _probe(cfg, seeds, T, ppf, fwd_seed, train, points)
+    model, inp, out, stats, _ = _run(cfg, seeds, T, ppf, mode, fwd_seed, train=train, tweaks=tweaks, points=points)
     d, epe = _common(out, stats, inp, T)
     n = inp['input_points'].shape[0]
     idx = np.linspace(0, n - 1, 2048).astype(np.int64)
@@ -111,7 +115,7 @@ def gen(name):
                      bn_running_mean=model.semseg_head.seg_head[1].running_mean.numpy())
     fb = out['fb_est_per_points']
     save('model_%s' % name, config=name, dataset=dataset, mode=mode, seeds=np.array(seeds), n_frames=T, pts_per_frame=ppf,
-         fwd_seed=fwd_seed, tweak_keys=np.array(list(tweaks.keys())), tweak_vals=np.stack(list(tweaks.values())),
+         fwd_seed=fwd_seed, points=points, tweak_keys=np.array(list(tweaks.keys())), tweak_vals=np.stack(list(tweaks.values())),
          sample_idx=idx, mos_est=det(out['mos_est'])[idx], offset_est=det(out['offset_est'])[idx], rec_est=det(out['rec_est'])[idx],
          transformed_points=det(out['transformed_points'])[idx], fb_est_per_points=fb.numpy()[idx], fb_est_sum=int(fb.sum()),
          mos1_sum=int(out['mos_est'].argmax(1).sum()),

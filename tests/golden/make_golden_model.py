@@ -47,13 +47,13 @@ def _epe(out, inp, n_frames):
     return err[t > 0]
 
 
-def _run(cfg, seeds, n_frames, ppf, mode, fwd_seed, train, tweaks=None):
+def _run(cfg, seeds, n_frames, ppf, mode, fwd_seed, train, tweaks=None, points='uniform'):
     from models.motionnet import MotionNet
     from libs.loss import FuseLoss
     cfg = dict(cfg)
     cfg['misc'] = dict(cfg['misc'], mode=mode)
     vox = rh.voxeliser(cfg)
-    inp = rh.collate([attach_voxels(make_sequence(s, n_frames, ppf, cfg), vox) for s in seeds])
+    inp = rh.collate([attach_voxels(make_sequence(s, n_frames, ppf, cfg, mode=points), vox) for s in seeds])
     model = MotionNet(cfg)
     fill_state_dict_(model)
     if tweaks is None:
