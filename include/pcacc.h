@@ -410,6 +410,35 @@ int pcacc_conv3x3_wgrad_split_workspace_bytes(int32_t n_img, int32_t h, int32_t 
 int pcacc_conv3x3_wgrad_split(const float *dy, const float *dy_amax, const float *dy_mask, const float *x, const float *x_amax, float *dw,
                               float *db, int32_t n_img, int32_t frames, int32_t dt, int32_t h, int32_t w, int32_t c_in, int32_t c_out,
                               void *workspace, size_t workspace_bytes, void *stream);
+/* nn.ConvTranspose2d(kernel 2, stride 2) of the two decoders (models/unet.py:22-30,101-113) in the fp32x3 mode: a 1-tap product on the
+ * tiles of pcacc_conv3x3_split whose epilogue scatters a pixel's 4 c_up results to its 2 x 2 output pixels (direction 0), its data
+ * gradient reading dy space-to-depth (direction 1), and the weight gradient on pcacc_conv3x3_wgrad_split's kernel.  c_in, c_up
+ * multiples of 32; h, w = the small map's size.
+ *   prepare_weights: w f32 [c_in][c_up][2][2] through `strides` (host, elements: i, o, y, x) -> out_fwd fp16 [2][4 c_up][c_in] (rows
+ *       (a, b, co)) + scale_fwd [4 c_up], out_bwd fp16 [2][c_in][4 c_up] + scale_bwd [c_in]
+ *   upconv2x2_split: direction 0: in [n,h,w,c_in] -> out [n,2h,2w,c_up] (+ bias [c_up]); direction 1: in = dy [n,2h,2w,c_up] -> out
+ *       [n,h,w,c_in]; in_amax / out_amax as pcacc_conv3x3_split
+ *   wgrad: dw [4 c_up][c_in] f32 (row (a, b, co)), db4 [4 c_up] f32 (sums of dy per (a, b, co); the bias gradient is the sum of the four groups) */
+int pcacc_upconv2x2_split_prepare_weights(const float *w, int32_t c_in, int32_t c_up, const int64_t *strides /*host*/, uint16_t *out_fwd,
+                                          float *scale_fwd, uint16_t *out_bwd, float *scale_bwd, void *stream);
+int pcacc_upconv2x2_split_supported(int32_t h, int32_t w, int32_t c_in, int32_t c_up);
+int pcacc_upconv2x2_split(const float *in, const float *in_amax, const uint16_t *wp, const float *wscale, const float *bias, float *out,
+                          float *out_amax, int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_up, int32_t direction, void *stream);
+int pcacc_upconv2x2_wgrad_split_workspace_bytes(int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_up, size_t *bytes /*host*/);
+int pcacc_upconv2x2_wgrad_split(const float *dy, const float *dy_amax, const float *x, const float *x_amax, float *dw, float *db4, int32_t n_img,
+                                int32_t h, int32_t w, int32_t c_in, int32_t c_up, void *workspace, size_t workspace_bytes, void *stream);
+/* The last convolution of a SegHead2D -- models/unet.py:259-277: Conv2d(mid, 2, 3, padding 1), the fg / bg logits -- c_in = 32 or 64,
+ * c_out <= 4: exact fp32 arithmetic on f32 (dtype 0) or bf16 (1) channels-last rows, streamed (csrc/head_conv.hip; matrix-core tiles
+ * would be 94 % padding).  w f32 [c_out][c_in][3][3] read through `w_strides` (host, elements: o, i, y, x).
+ *   forward: y [n,h,w,c_out] f32 = conv(x) + bias;  dgrad: dx [n,h,w,c_in] (f32 / bf16) from dy [n,h,w,c_out] f32;
+ *   wgrad: dw [c_out][c_in][3][3] f32 contiguous, db [c_out] f32 or NULL (both cleared by the call). */
+int pcacc_head_conv3x3_supported(int32_t c_in, int32_t c_out);
+int pcacc_head_conv3x3_forward(const void *x, int32_t x_dtype, const float *w, const int64_t *w_strides /*host*/, const float *bias, float *y,
+                               int32_t n_img, int32_t h, int32_t wd, int32_t c_in, int32_t c_out, void *stream);
+int pcacc_head_conv3x3_dgrad(const float *dy, const float *w, const int64_t *w_strides /*host*/, void *dx, int32_t dx_dtype, int32_t n_img,
+                             int32_t h, int32_t wd, int32_t c_in, int32_t c_out, void *stream);
+int pcacc_head_conv3x3_wgrad(const float *dy, const void *x, int32_t x_dtype, float *dw, float *db, int32_t n_img, int32_t h, int32_t wd,
+                             int32_t c_in, int32_t c_out, void *stream);
 /* The per-point linear layers in the fp32x3 mode (csrc/mlp_split.hip): the contracts of pcacc_rows_linear_bf16 / _cat_bf16 /
  * pcacc_rows_wgrad_bf16 / _cat_bf16 above on fp32 rows (x, masks, residual, y all f32; k, n in {32, 64, 128}), products from scaled
  * fp16 hi / lo halves as in pcacc_conv3x3_split; every fp32 row tensor that is split comes with its pcacc_absmax256 array

@@ -64,7 +64,9 @@ EXPORTS = [
     'pcacc_conv3x3_split_prepare_weights', 'pcacc_conv3x3_split_supported', 'pcacc_conv3x3_split', 'pcacc_conv3x3_wgrad_split_workspace_bytes',
     'pcacc_conv3x3_wgrad_split', 'pcacc_absmax256',
     'pcacc_rows_linear_split', 'pcacc_rows_linear_cat_split', 'pcacc_rows_wgrad_split_workspace_bytes', 'pcacc_rows_wgrad_split',
-    'pcacc_rows_wgrad_cat_split',
+    'pcacc_rows_wgrad_cat_split', 'pcacc_upconv2x2_split_prepare_weights', 'pcacc_upconv2x2_split_supported', 'pcacc_upconv2x2_split',
+    'pcacc_upconv2x2_wgrad_split_workspace_bytes', 'pcacc_upconv2x2_wgrad_split',
+    'pcacc_head_conv3x3_supported', 'pcacc_head_conv3x3_forward', 'pcacc_head_conv3x3_dgrad', 'pcacc_head_conv3x3_wgrad',
 ]
 
 
@@ -686,6 +688,96 @@ def conv3x3_wgrad_split(dy_rows, x_rows, frames=1, dt=0, mask=None, dy_amax=None
                                            xp, _dev(x_amax, torch.float32, 'x_amax'), _dev(dw), _dev(db), int(n_img), int(frames), int(dt),
                                            int(h), int(w), int(c_in), int(c_out), _dev(ws), ctypes.c_size_t(ws.numel()), _stream()),
            'conv3x3_wgrad_split')
+    return dw, db
+
+
+def upconv2x2_split_supported(h, w, c_in, c_up):
+    return bool(lib().pcacc_upconv2x2_split_supported(int(h), int(w), int(c_in), int(c_up)))
+
+
+def upconv2x2_split_prepare_weights(weight):
+    """nn.ConvTranspose2d(k=2, s=2).weight f32 [c_in, c_up, 2, 2] (any dense layout) -> ((planes fp16 [2, 4 c_up, c_in], scale [4 c_up]),
+    (planes fp16 [2, c_in, 4 c_up], scale [c_in])): forward and data-gradient form."""
+    ci, cu = weight.shape[0], weight.shape[1]
+    if not weight.is_cuda or weight.dtype != torch.float32 or tuple(weight.shape[2:]) != (2, 2):
+        raise NativeError('upconv2x2_split_prepare_weights: float32 GPU weight [c_in, c_up, 2, 2] expected')
+    fwd = torch.empty((2, 4 * cu, ci), dtype=torch.float16, device=weight.device)
+    bwd = torch.empty((2, ci, 4 * cu), dtype=torch.float16, device=weight.device)
+    sf = torch.empty((4 * cu,), dtype=torch.float32, device=weight.device)
+    sb = torch.empty((ci,), dtype=torch.float32, device=weight.device)
+    strides = (ctypes.c_int64 * 4)(*weight.stride())
+    _check(lib().pcacc_upconv2x2_split_prepare_weights(ctypes.c_void_p(weight.data_ptr()), int(ci), int(cu), strides, _dev(fwd), _dev(sf), _dev(bwd),
+                                                       _dev(sb), _stream()), 'upconv2x2_split_prepare_weights')
+    return (fwd, sf), (bwd, sb)
+
+
+def upconv2x2_split(x_rows, amax, wps, bias, direction):
+    """direction 0: x_rows f32 [n,h,w,c_in] -> ([n,2h,2w,c_up], its absmax256 array); direction 1: x_rows = dy [n,2h,2w,c_up] -> ([n,h,w,c_in], amax)."""
+    wp, wscale = wps
+    n = x_rows.shape[0]
+    if direction == 0:
+        h, w, c_in = x_rows.shape[1:]
+        c_up = wp.shape[1] // 4
+        out = torch.empty((n, 2 * h, 2 * w, c_up), dtype=torch.float32, device=x_rows.device)
+    else:
+        h, w, c_up = x_rows.shape[1] // 2, x_rows.shape[2] // 2, x_rows.shape[3]
+        c_in = wp.shape[1]
+        out = torch.empty((n, h, w, c_in), dtype=torch.float32, device=x_rows.device)
+    out_amax = _zero256(x_rows.device)
+    _check(lib().pcacc_upconv2x2_split(_dev(x_rows, torch.float32, 'x'), _dev(amax, torch.float32, 'amax'), _dev(wp, torch.float16, 'wp'),
+                                       _dev(wscale, torch.float32, 'wscale'), _opt(bias, torch.float32, 'bias'), _dev(out), _dev(out_amax), int(n),
+                                       int(h), int(w), int(c_in), int(c_up), int(direction), _stream()), 'upconv2x2_split')
+    return out, out_amax
+
+
+def upconv2x2_wgrad_split(dy_rows, dy_amax, x_rows, x_amax):
+    """dy [n,2h,2w,c_up], x [n,h,w,c_in] f32 -> (dw [c_in, c_up, 2, 2] f32 (a permuted view), db [c_up] f32)."""
+    n, h, w, c_in = x_rows.shape
+    c_up = dy_rows.shape[3]
+    dw = torch.empty((4 * c_up, c_in), dtype=torch.float32, device=x_rows.device)
+    db4 = torch.empty((4 * c_up,), dtype=torch.float32, device=x_rows.device)
+    need = ctypes.c_size_t(0)
+    _check(lib().pcacc_upconv2x2_wgrad_split_workspace_bytes(int(n), int(h), int(w), int(c_in), int(c_up), ctypes.byref(need)), 'upconv2x2_wgrad_workspace')
+    ws = _ws(need.value, x_rows.device)
+    _check(lib().pcacc_upconv2x2_wgrad_split(_dev(dy_rows, torch.float32, 'dy'), _dev(dy_amax, torch.float32, 'dy_amax'), _dev(x_rows, torch.float32, 'x'),
+                                             _dev(x_amax, torch.float32, 'x_amax'), _dev(dw), _dev(db4), int(n), int(h), int(w), int(c_in), int(c_up),
+                                             _dev(ws), ctypes.c_size_t(ws.numel()), _stream()), 'upconv2x2_wgrad_split')
+    return dw.view(2, 2, c_up, c_in).permute(3, 2, 0, 1), db4.view(4, c_up).sum(0)
+
+
+def head_conv3x3_supported(c_in, c_out):
+    return bool(lib().pcacc_head_conv3x3_supported(int(c_in), int(c_out)))
+
+
+def head_conv3x3_forward(x_rows, weight, bias):
+    """x_rows [n,h,w,c_in] f32 / bf16, weight f32 [c_out,c_in,3,3] (any dense layout), c_out <= 4 -> y [n,h,w,c_out] f32."""
+    n, h, w, c_in = x_rows.shape
+    c_out = weight.shape[0]
+    y = torch.empty((n, h, w, c_out), dtype=torch.float32, device=x_rows.device)
+    strides = (ctypes.c_int64 * 4)(*weight.stride())
+    _check(lib().pcacc_head_conv3x3_forward(_dev(x_rows, None, 'x'), _dtype_code(x_rows), ctypes.c_void_p(weight.data_ptr()), strides,
+                                            _opt(bias, torch.float32, 'bias'), _dev(y), int(n), int(h), int(w), int(c_in), int(c_out), _stream()),
+           'head_conv3x3_forward')
+    return y
+
+
+def head_conv3x3_dgrad(dy_rows, weight, c_in, out_dtype):
+    n, h, w, c_out = dy_rows.shape
+    dx = torch.empty((n, h, w, c_in), dtype=out_dtype, device=dy_rows.device)
+    strides = (ctypes.c_int64 * 4)(*weight.stride())
+    _check(lib().pcacc_head_conv3x3_dgrad(_dev(dy_rows, torch.float32, 'dy'), ctypes.c_void_p(weight.data_ptr()), strides, _dev(dx), _dtype_code(dx),
+                                          int(n), int(h), int(w), int(c_in), int(c_out), _stream()), 'head_conv3x3_dgrad')
+    return dx
+
+
+def head_conv3x3_wgrad(dy_rows, x_rows, want_bias=True):
+    n, h, w, c_out = dy_rows.shape
+    c_in = x_rows.shape[3]
+    dw = torch.empty((c_out, c_in, 3, 3), dtype=torch.float32, device=dy_rows.device)
+    db = torch.empty((c_out,), dtype=torch.float32, device=dy_rows.device) if want_bias else None
+    _check(lib().pcacc_head_conv3x3_wgrad(_dev(dy_rows, torch.float32, 'dy'), _dev(x_rows, None, 'x'), _dtype_code(x_rows), _dev(dw),
+                                          _dev(db) if db is not None else None, int(n), int(h), int(w), int(c_in), int(c_out), _stream()),
+           'head_conv3x3_wgrad')
     return dw, db
 
 

@@ -818,6 +818,95 @@ class _Conv3x3Split(torch.autograd.Function):
         return gx, gw, gb, None, None
 
 
+_PREPARED_UP = {}
+
+
+def prepared_upconv_weights_split(weight):
+    key = id(weight)
+    hit = _PREPARED_UP.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == (weight._version, weight.data_ptr()):
+        return hit[2], hit[3]
+    fwd, bwd = native.upconv2x2_split_prepare_weights(weight.detach())
+    if len(_PREPARED_UP) > 4096:
+        _PREPARED_UP.clear()
+    _PREPARED_UP[key] = (weakref.ref(weight), (weight._version, weight.data_ptr()), fwd, bwd)
+    return fwd, bwd
+
+
+class _UpConv2x2Split(torch.autograd.Function):
+    """nn.ConvTranspose2d(kernel 2, stride 2) on fp32 channels-last rows in the fp32x3 mode (csrc/conv_split.hip, 1-tap kernels):
+    [n,h,w,c_in] -> [n,2h,2w,c_up]."""
+
+    @staticmethod
+    def forward(ctx, x_rows, weight, bias):
+        x_amax = amax_of(x_rows)
+        y, y_amax = native.upconv2x2_split(x_rows, x_amax, prepared_upconv_weights_split(weight)[0], bias.detach() if bias is not None else None, 0)
+        set_amax_tag(y, y_amax)
+        ctx.save_for_backward(x_rows, weight, x_amax)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x_rows, weight, x_amax = ctx.saved_tensors
+        gy = gy.contiguous()
+        if gy.dtype != torch.float32:
+            gy = gy.float()
+        g_amax = amax_of(gy)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx, gx_amax = native.upconv2x2_split(gy, g_amax, prepared_upconv_weights_split(weight)[1], None, 1)
+            set_amax_tag(gx, gx_amax)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw, gb = native.upconv2x2_wgrad_split(gy, g_amax, x_rows, x_amax)
+            gw = gw.to(weight.dtype)
+            gb = gb if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
+def upconv2x2(x, conv):
+    """`conv(x)` for the decoders' nn.ConvTranspose2d(kernel 2, stride 2) (models/unet.py:22-30): fp32 channels-last maps in the fp32x3 mode
+    run the split kernels, everything else the module (library)."""
+    if (_SPLIT and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled() and conv.kernel_size == (2, 2) and conv.stride == (2, 2)
+            and conv.padding == (0, 0) and conv.output_padding == (0, 0) and conv.groups == 1 and conv.dilation == (1, 1)
+            and conv.weight.dtype == torch.float32 and native.upconv2x2_split_supported(x.shape[-2], x.shape[-1], conv.in_channels, conv.out_channels)):
+        xr = x.permute(0, 2, 3, 1)
+        if xr.is_contiguous():
+            set_amax_tag(xr, amax_of(x))
+            y = _UpConv2x2Split.apply(xr, conv.weight, conv.bias)
+            return carry_amax(y, y.permute(0, 3, 1, 2))
+    return conv(x)
+
+
+class _HeadConv3x3(torch.autograd.Function):
+    """Conv2d(c_in, c_out <= 4, 3, padding 1) on channels-last rows [n,H,W,c_in] (f32 or bf16) -> f32 logits (csrc/head_conv.hip): the fg / bg
+    head's last layer (models/unet.py:259-277), exact fp32 arithmetic in every compute mode."""
+
+    @staticmethod
+    def forward(ctx, x_rows, weight, bias):
+        ctx.save_for_backward(x_rows, weight)
+        ctx.has_bias = bias is not None
+        return native.head_conv3x3_forward(x_rows, weight.detach(), bias.detach() if bias is not None else None)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x_rows, weight = ctx.saved_tensors
+        gy = gy.contiguous().float()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = native.head_conv3x3_dgrad(gy, weight.detach(), x_rows.shape[3], x_rows.dtype)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw, gb = native.head_conv3x3_wgrad(gy, x_rows, want_bias=ctx.has_bias)
+            gw = gw.to(weight.dtype)
+        return gx, gw, gb
+
+
+def head_conv3x3_available(x, conv):
+    return (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16) and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+            and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.weight.dtype == torch.float32
+            and native.head_conv3x3_supported(conv.in_channels, conv.out_channels) and x.permute(0, 2, 3, 1).is_contiguous())
+
+
 def _stack_frames(rows, frames):
     """[B*T, H, W, C] -> [B*T, H, W, 3C]: frames t-1, t, t+1 side by side (zeros outside the sequence)."""
     n, h, w, c = rows.shape
@@ -873,6 +962,8 @@ def conv3x3_native(x, conv):
 def conv3x3(x, conv, relu=False):
     """`relu?(conv(x))` for an nn.Conv2d(3x3, stride 1, padding 1) on an NCHW tensor; channels-last bf16 inputs on the GPU go
     through the MFMA kernel, everything else through the library with the same semantics."""
+    if not relu and head_conv3x3_available(x, conv):            # c_out <= 4: the streamed fp32 kernels, f32 logits out
+        return _HeadConv3x3.apply(x.permute(0, 2, 3, 1), conv.weight, conv.bias).permute(0, 3, 1, 2)
     mode = conv3x3_native(x, conv)
     if mode:
         xr = x.permute(0, 2, 3, 1)

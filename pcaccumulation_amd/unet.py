@@ -48,7 +48,7 @@ class UpConv(nn.Module):
         self.conv2 = conv3x3(out_channels, out_channels)
 
     def forward(self, from_down, from_up):
-        from_up = self.upconv(from_up)
+        from_up = ops.upconv2x2(from_up, self.upconv)                   # fp32x3 mode: the 1-tap split kernels; else the library
         x = torch.cat((from_up, from_down), 1) if self.merge_mode == 'concat' else from_up + from_down
         return ops.conv3x3(ops.conv3x3(x, self.conv1, relu=True), self.conv2, relu=True)
 

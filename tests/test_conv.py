@@ -233,3 +233,28 @@ def test_down_conv_fused_tail_matches_separate_ops():
     for a, b in zip(got, want):
         assert a.shape == b.shape
         assert torch.allclose(a.float(), b.float(), rtol=1e-3, atol=1e-3 * float(b.float().abs().max())), float((a.float() - b.float()).abs().max())
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('n,h,w,ci,co', [(2, 37, 53, 32, 2), (1, 16, 16, 64, 2), (3, 9, 70, 32, 4), (1, 1, 1, 32, 1), (1, 288, 288, 32, 2)])
+def test_head_conv3x3(n, h, w, ci, co, dtype):
+    """Conv2d(c_in, c_out <= 4, 3, padding 1) -- the fg / bg head's last layer (models/unet.py:259-277) -- on the streamed fp32 kernels of
+    csrc/head_conv.hip: logits, input gradient, weight and bias gradients against the same layer in float64 on the same (f32 / bf16) input."""
+    g = torch.Generator(device='cpu').manual_seed(h + w + ci + co)
+    conv = torch.nn.Conv2d(ci, co, 3, padding=1).to(DEV)
+    conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
+    x = torch.randn(n, ci, h, w, generator=g).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    gy = torch.randn(n, co, h, w, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    assert ops.head_conv3x3_available(x, conv)
+    y = ops.conv3x3(x, conv)
+    assert y.dtype == torch.float32 and y.shape == (n, co, h, w)
+    y.backward(gy)
+    c64 = torch.nn.Conv2d(ci, co, 3, padding=1).to(DEV).double()
+    c64.load_state_dict({k: v.double() for k, v in conv.state_dict().items()})
+    xr = x.detach().double().requires_grad_(True)
+    yr = c64(xr)
+    yr.backward(gy.double())
+    rel = lambda a, b: float((a.double() - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    assert rel(y, yr.detach()) <= 2e-6
+    assert rel(x.grad, xr.grad) <= (2e-6 if dtype == torch.float32 else 8e-3)            # bf16 gradient: rounded once on store
+    assert rel(conv.weight.grad, c64.weight.grad) <= 2e-5 and rel(conv.bias.grad, c64.bias.grad) <= 2e-5      # fp32 sums over n*h*w pixels, atomics

@@ -240,3 +240,32 @@ def test_conv3x3_split_resident_kernel(n, t, h, w, ci, co, kt, monkeypatch):
     monkeypatch.setenv('PCACC_CONV_RES', '0')
     y0 = ops.conv3x3_rows(x.detach(), wt.detach(), bias.detach(), t if kt == 3 else 1, True)
     assert _rel(y0, y.detach()) <= 1e-6                        # the two kernels sum in different orders
+
+
+@pytest.mark.parametrize('n,h,w,ci,cu', [(2, 18, 18, 512, 256), (1, 9, 20, 64, 32), (3, 36, 36, 256, 128), (1, 72, 72, 128, 64), (2, 33, 7, 64, 64),
+                                         (1, 144, 144, 64, 32), (1, 5, 5, 128, 128)])
+def test_upconv2x2_split(n, h, w, ci, cu):
+    """nn.ConvTranspose2d(kernel 2, stride 2) (models/unet.py:22-30) in the fp32x3 mode: forward, data gradient, weight and bias
+    gradients against the module in float64."""
+    g = torch.Generator(device='cpu').manual_seed(ci + cu + h)
+    conv = torch.nn.ConvTranspose2d(ci, cu, kernel_size=2, stride=2).to(DEV)
+    conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
+    x = torch.randn(n, ci, h, w, generator=g).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    gy = torch.randn(n, cu, 2 * h, 2 * w, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    calls = []
+    orig = native.upconv2x2_split
+    native.upconv2x2_split = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        y = ops.upconv2x2(x, conv)
+        y.backward(gy)
+    finally:
+        native.upconv2x2_split = orig
+    assert len(calls) == 2 and y.shape == (n, cu, 2 * h, 2 * w)
+    c64 = torch.nn.ConvTranspose2d(ci, cu, kernel_size=2, stride=2).to(DEV).double()
+    c64.load_state_dict({k: v.double() for k, v in conv.state_dict().items()})
+    xr = x.detach().double().requires_grad_(True)
+    yr = c64(xr)
+    yr.backward(gy.double())
+    assert _rel(y, yr.detach()) <= TOL and _rel(x.grad, xr.grad) <= TOL
+    assert _rel(conv.weight.grad, c64.weight.grad) <= TOL and _rel(conv.bias.grad, c64.bias.grad) <= TOL
+    assert float(ops.amax_tag(y).max()) == float(y.abs().max())
