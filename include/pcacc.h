@@ -431,14 +431,15 @@ int pcacc_upconv2x2_wgrad_split(const float *dy, const float *dy_amax, const flo
  * c_out <= 4: exact fp32 arithmetic on f32 (dtype 0) or bf16 (1) channels-last rows, streamed (csrc/head_conv.hip; matrix-core tiles
  * would be 94 % padding).  w f32 [c_out][c_in][3][3] read through `w_strides` (host, elements: o, i, y, x).
  *   forward: y [n,h,w,c_out] f32 = conv(x) + bias;  dgrad: dx [n,h,w,c_in] (f32 / bf16) from dy [n,h,w,c_out] f32;
- *   wgrad: dw [c_out][c_in][3][3] f32 contiguous, db [c_out] f32 or NULL (both cleared by the call). */
+ *   wgrad: dw [c_out][c_in][3][3] f32 contiguous, db [c_out] f32 or NULL; per-workgroup partials in `workspace`, summed in a fixed order. */
 int pcacc_head_conv3x3_supported(int32_t c_in, int32_t c_out);
 int pcacc_head_conv3x3_forward(const void *x, int32_t x_dtype, const float *w, const int64_t *w_strides /*host*/, const float *bias, float *y,
                                int32_t n_img, int32_t h, int32_t wd, int32_t c_in, int32_t c_out, void *stream);
 int pcacc_head_conv3x3_dgrad(const float *dy, const float *w, const int64_t *w_strides /*host*/, void *dx, int32_t dx_dtype, int32_t n_img,
                              int32_t h, int32_t wd, int32_t c_in, int32_t c_out, void *stream);
+int pcacc_head_conv3x3_wgrad_workspace_bytes(int32_t n_img, int32_t h, int32_t wd, int32_t c_in, int32_t c_out, size_t *bytes /*host*/);
 int pcacc_head_conv3x3_wgrad(const float *dy, const void *x, int32_t x_dtype, float *dw, float *db, int32_t n_img, int32_t h, int32_t wd,
-                             int32_t c_in, int32_t c_out, void *stream);
+                             int32_t c_in, int32_t c_out, void *workspace, size_t workspace_bytes, void *stream);
 /* The per-point linear layers in the fp32x3 mode (csrc/mlp_split.hip): the contracts of pcacc_rows_linear_bf16 / _cat_bf16 /
  * pcacc_rows_wgrad_bf16 / _cat_bf16 above on fp32 rows (x, masks, residual, y all f32; k, n in {32, 64, 128}), products from scaled
  * fp16 hi / lo halves as in pcacc_conv3x3_split; every fp32 row tensor that is split comes with its pcacc_absmax256 array

@@ -184,8 +184,8 @@ class MotionNet(nn.Module):
         # 1. pillar encoder -> BEV canvas (channels-last, one streaming pass)
         input_features = self.pillar_encoder(input_points, None, coordinates, pillar_mean, time_indice, pidx=pidx, keep_dtype=True,
                                              features=prep.features)
-        canvas = ops.pillar_scatter(input_features, pidx, self.compute_dtype)
-        bev = ops.canvas_as_nchw(canvas, pidx)                                 # [B*T, C, Ny, Nx]
+        canvas = ops.carry_amax(input_features, ops.pillar_scatter(input_features, pidx, self.compute_dtype))     # rows or zeros
+        bev = ops.carry_amax(canvas, ops.canvas_as_nchw(canvas, pidx))         # [B*T, C, Ny, Nx]
 
         # 2. backbone + 3. fg/bg head
         with self._dense():
@@ -271,7 +271,8 @@ class MotionNet(nn.Module):
             bev_cl = bev_feats.permute(0, 2, 3, 1).contiguous().view(B, T, Ny, Nx, C)
             warped = ops.bev_warp(bev_cl, native.inv4x4(pose_est), self.resolution[0], self.resolution[1],
                                   self.pc_range[0], self.pc_range[1])
-            warped_feats = warped.permute(0, 4, 1, 2, 3)                           # [B,C,T,H,W], channels_last_3d memory
+            ops.carry_amax(bev_feats, warped)                                      # convex combinations of bev_feats' cells (or zero)
+            warped_feats = ops.carry_amax(warped, warped.permute(0, 4, 1, 2, 3))   # [B,C,T,H,W], channels_last_3d memory
             transformed_points = ops.rigid_transform(input_points, frame_idx, pose_est)
             results['transformed_points'] = transformed_points
 

@@ -67,6 +67,7 @@ EXPORTS = [
     'pcacc_rows_wgrad_cat_split', 'pcacc_upconv2x2_split_prepare_weights', 'pcacc_upconv2x2_split_supported', 'pcacc_upconv2x2_split',
     'pcacc_upconv2x2_wgrad_split_workspace_bytes', 'pcacc_upconv2x2_wgrad_split',
     'pcacc_head_conv3x3_supported', 'pcacc_head_conv3x3_forward', 'pcacc_head_conv3x3_dgrad', 'pcacc_head_conv3x3_wgrad',
+    'pcacc_head_conv3x3_wgrad_workspace_bytes',
 ]
 
 
@@ -775,9 +776,12 @@ def head_conv3x3_wgrad(dy_rows, x_rows, want_bias=True):
     c_in = x_rows.shape[3]
     dw = torch.empty((c_out, c_in, 3, 3), dtype=torch.float32, device=dy_rows.device)
     db = torch.empty((c_out,), dtype=torch.float32, device=dy_rows.device) if want_bias else None
+    need = ctypes.c_size_t(0)
+    _check(lib().pcacc_head_conv3x3_wgrad_workspace_bytes(int(n), int(h), int(w), int(c_in), int(c_out), ctypes.byref(need)), 'head_conv3x3_wgrad_workspace')
+    ws = _ws(need.value, dy_rows.device)
     _check(lib().pcacc_head_conv3x3_wgrad(_dev(dy_rows, torch.float32, 'dy'), _dev(x_rows, None, 'x'), _dtype_code(x_rows), _dev(dw),
-                                          _dev(db) if db is not None else None, int(n), int(h), int(w), int(c_in), int(c_out), _stream()),
-           'head_conv3x3_wgrad')
+                                          _dev(db) if db is not None else None, int(n), int(h), int(w), int(c_in), int(c_out), _dev(ws),
+                                          ctypes.c_size_t(ws.numel()), _stream()), 'head_conv3x3_wgrad')
     return dw, db
 
 

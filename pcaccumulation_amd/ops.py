@@ -538,6 +538,18 @@ def carry_amax(src, dst):
     return set_amax_tag(dst, amax_tag(src))
 
 
+def merge_amax(dst, *srcs):
+    """dst is made of the elements of `srcs` (a concatenation): the element-wise maximum of their arrays bounds it (one 256-element launch
+    instead of a pass over dst).  No tag when a source has none."""
+    tags = [amax_tag(t) for t in srcs]
+    if _SPLIT and tags and all(t is not None for t in tags):
+        m = tags[0]
+        for t in tags[1:]:
+            m = torch.maximum(m, t)
+        set_amax_tag(dst, m)
+    return dst
+
+
 def amax_of(t):
     a = amax_tag(t)
     if a is None:

@@ -96,7 +96,7 @@ class PillarFeatureNet(nn.Module):
         for block in self.blocks[1:]:
             net = block.forward_pooled(net, ops.carry_amax(net, ops.segment_max(net, pidx)), pidx)      # maxima of net's rows: net's bound holds
         feats = ops.linear_rows(net, self.fc_c)
-        pooled = ops.segment_max(feats, pidx)
+        pooled = ops.carry_amax(feats, ops.segment_max(feats, pidx))
         return pooled if keep_dtype else pooled.float()
 
 

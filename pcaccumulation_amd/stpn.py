@@ -51,7 +51,7 @@ class STPN(nn.Module):
         the work lands on the channels-last implicit-GEMM conv kernels instead of the batched-GEMM Conv3d
         backward-weights path, which took 48 ms per layer on MI355X (profiles/r01_*)."""
         B, C, T, H, W = x.shape
-        rows = x.permute(0, 2, 3, 4, 1).contiguous()                               # [B,T,H,W,C]; free for warp output
+        rows = ops.carry_amax(x, x.permute(0, 2, 3, 4, 1).contiguous())            # [B,T,H,W,C]; free for warp output
         for layer in self.init_conv:
             if not isinstance(layer, nn.Conv3d):
                 continue
@@ -66,7 +66,8 @@ class STPN(nn.Module):
             w2 = layer.weight.permute(0, 2, 1, 3, 4).reshape(layer.out_channels, 3 * cin, 3, 3)
             y = F.relu(F.conv2d(stacked.permute(0, 3, 1, 2), w2, layer.bias, padding=1))
             rows = y.permute(0, 2, 3, 1).contiguous().view(B, T, H, W, layer.out_channels)
-        return ops.frames_max(rows).permute(0, 3, 1, 2)                                # [B,C,H,W], channels_last
+        out = ops.carry_amax(rows, ops.frames_max(rows))                               # maxima over frames: the stack's bound holds
+        return ops.carry_amax(out, out.permute(0, 3, 1, 2))                            # [B,C,H,W], channels_last
 
     def backbone(self, x):
         """[B, C, T, H, W] -> [B, 64, H, W]: temporal conv stack, max over T, U-Net (models/stpn.py:82-92)."""

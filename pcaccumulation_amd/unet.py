@@ -33,7 +33,7 @@ class DownConv(nn.Module):
         if self.pooling and ops.conv3x3_native(x, self.conv2) == 'bf16' and self.out_channels % 8 == 0:
             return ops.conv3x3_relu_pool(x, self.conv2)            # second conv + ReLU + pool, their backward in one pass (csrc/pool.hip)
         x = ops.conv3x3(x, self.conv2, relu=True)
-        return (self.pool(x) if self.pooling else x), x
+        return (ops.carry_amax(x, self.pool(x)) if self.pooling else x), x          # window maxima of x: x's bound holds (fp32x3 scales)
 
 
 class UpConv(nn.Module):
@@ -49,7 +49,7 @@ class UpConv(nn.Module):
 
     def forward(self, from_down, from_up):
         from_up = ops.upconv2x2(from_up, self.upconv)                   # fp32x3 mode: the 1-tap split kernels; else the library
-        x = torch.cat((from_up, from_down), 1) if self.merge_mode == 'concat' else from_up + from_down
+        x = ops.merge_amax(torch.cat((from_up, from_down), 1), from_up, from_down) if self.merge_mode == 'concat' else from_up + from_down
         return ops.conv3x3(ops.conv3x3(x, self.conv1, relu=True), self.conv2, relu=True)
 
 
