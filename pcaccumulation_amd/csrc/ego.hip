@@ -533,6 +533,117 @@ __global__ __launch_bounds__(256) void ego_sinkhorn_finish_ro_kernel(const float
     }
 }
 
+// ---- backward in vector form --------------------------------------------------------------------------------------------------------
+// Undoing a half-step subtracts a rank-one term weighted by that step's normalised matrix P_s = exp(x0 - U_s[i] - V_s[j]):
+//   column step:  g -= P_s * c_s[j]   (c_s = current column sums of g over all k+1 rows),      row step:  g -= P_s * r_s[i].
+// So the gradient matrix never has to be rewritten: dx0 = G - sum_s P_s (c_s[j] | r_s[i]) on the real block, and the sums obey vector
+// recurrences -- a column of P_s (slack row included) sums to 1, so a column step zeroes the column sums and changes the row sums by
+// -sum_j P_s[i][j] c_s[j]; a row step zeroes the row sums and changes the column sums by -sum_i P_s[i][j] r_s[i]: ONE read-only pass
+// over x0 per half-step (a matrix-vector product), two passes for the sums of G, one final pass (read G and x0, write dx0) -- 10
+// passes of 64 MB at 16 x 1024^2 instead of 26 read-modify-write passes over the padded gradient matrix.  k % 4 == 0.
+__global__ __launch_bounds__(256) void sk_rowsum_kernel(const float *__restrict__ G, int k, int n_pairs, float *__restrict__ R)
+{
+    const int lane = threadIdx.x & 63, k4 = k >> 2;
+    const int64_t n_rows = (int64_t)n_pairs * k;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < n_rows; row += (int64_t)gridDim.x * 4) {
+        const float4 *gr = reinterpret_cast<const float4 *>(G + row * k);
+        float sm = 0.f;
+        for (int j = lane; j < k4; j += 64) { const float4 a = gr[j]; sm += (a.x + a.y) + (a.z + a.w); }
+        sm = wave_sum(sm);
+        if (lane == 0) R[row] = sm;
+    }
+}
+
+// column sums of G (W == NULL) or the column-side matrix-vector product of a row step:
+//   out[j] = sum_i G[i][j]                                         |  out[j] = -exp(-V[j]) sum_i exp(x0[i][j] - U[i]) W[i]
+// 64 columns x 16 row groups per workgroup, partial sums combined through LDS (the tiling of ego_sinkhorn_cols_ro_kernel)
+__global__ __launch_bounds__(256) void sk_cols_kernel(const float *__restrict__ M, const float *__restrict__ lse_r, const float *__restrict__ lse_c,
+                                                      int nu, int nv, const float *__restrict__ W, int k, int n_pairs, float *__restrict__ out)
+{
+    __shared__ float ssum[16][64];
+    const int p = blockIdx.y;
+    const int c4 = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int col = blockIdx.x * 64 + c4 * 4;
+    const float *m = M + (int64_t)p * k * k;
+    const int64_t stride = (int64_t)n_pairs * k;
+    float sm[4] = {0.f, 0.f, 0.f, 0.f};
+    if (col < k) {
+        float4 vj = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (W) {
+            vj.x = ego_cum(lse_c, nv, stride, (int64_t)p * k + col);     vj.y = ego_cum(lse_c, nv, stride, (int64_t)p * k + col + 1);
+            vj.z = ego_cum(lse_c, nv, stride, (int64_t)p * k + col + 2); vj.w = ego_cum(lse_c, nv, stride, (int64_t)p * k + col + 3);
+        }
+        for (int i = rg; i < k; i += 16) {
+            const float4 a = *reinterpret_cast<const float4 *>(m + (int64_t)i * k + col);
+            if (W) {
+                const float ui = ego_cum(lse_r, nu, stride, (int64_t)p * k + i), wi = W[(int64_t)p * k + i];
+                sm[0] += wi * expf(a.x - ui - vj.x); sm[1] += wi * expf(a.y - ui - vj.y);
+                sm[2] += wi * expf(a.z - ui - vj.z); sm[3] += wi * expf(a.w - ui - vj.w);
+            } else {
+                sm[0] += a.x; sm[1] += a.y; sm[2] += a.z; sm[3] += a.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ssum[rg][c4 * 4 + q] = sm[q];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int c = blockIdx.x * 64 + threadIdx.x;
+        if (c < k) {
+            float t = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) t += ssum[g][threadIdx.x];
+            out[(int64_t)p * k + c] = W ? -t : t;
+        }
+    }
+}
+
+// row-side matrix-vector product of a column step: out[i] = Rin[i] - exp(-U[i]) sum_j exp(x0[i][j] - V[j]) C[j]   (Rin == NULL: 0)
+__global__ __launch_bounds__(256) void sk_rows_kernel(const float *__restrict__ x0, const float *__restrict__ lse_r, const float *__restrict__ lse_c,
+                                                      int nu, int nv, const float *__restrict__ C, const float *__restrict__ Rin, int k, int n_pairs,
+                                                      float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t n_rows = (int64_t)n_pairs * k, stride = n_rows;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < n_rows; row += (int64_t)gridDim.x * 4) {
+        const int64_t p = row / k;
+        const float *xr = x0 + row * k;
+        const float u = ego_cum(lse_r, nu, stride, row);
+        float sm = 0.f;
+        for (int j = lane; j < k; j += 64) sm += C[p * k + j] * expf(xr[j] - u - ego_cum(lse_c, nv, stride, p * k + j));
+        sm = wave_sum(sm);
+        if (lane == 0) out[row] = (Rin ? Rin[row] : 0.f) - sm;
+    }
+}
+
+// dx0[i][j] = G[i][j] - sum_it ( Wc[it][j] exp(x0 - U_{it+1}[i] - V_{it+1}[j]) + Wr[it][i] exp(x0 - U_{it+1}[i] - V_it[j]) )
+__global__ __launch_bounds__(256) void sk_final_kernel(const float4 *__restrict__ G, const float4 *__restrict__ x0, const float *__restrict__ lse_r,
+                                                       const float *__restrict__ lse_c, const float *__restrict__ Wc, const float *__restrict__ Wr,
+                                                       int n_iters, int k, int n_pairs, int64_t total4, float4 *__restrict__ out)
+{
+    const int k4 = k >> 2;
+    const int64_t stride = (int64_t)n_pairs * k;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total4; e += (int64_t)gridDim.x * 256) {
+        const int64_t row = e / k4;                                          // p * k + i
+        const int j4 = (int)(e % k4);
+        const int64_t col0 = (row / k) * k + (int64_t)j4 * 4;               // p * k + j
+        const float4 a = x0[e];
+        float4 acc = G[e];
+        float u = 0.f;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                          // V_it
+        for (int it = 0; it < n_iters; ++it) {
+            u += lse_r[it * stride + row];                                   // U_{it+1}
+            const float wr = Wr[it * stride + row];
+            acc.x -= wr * expf(a.x - u - v.x); acc.y -= wr * expf(a.y - u - v.y); acc.z -= wr * expf(a.z - u - v.z); acc.w -= wr * expf(a.w - u - v.w);
+            const float4 l = *reinterpret_cast<const float4 *>(lse_c + it * stride + col0);
+            v = make_float4(v.x + l.x, v.y + l.y, v.z + l.z, v.w + l.w);    // V_{it+1}
+            const float4 wc = *reinterpret_cast<const float4 *>(Wc + it * stride + col0);
+            acc.x -= wc.x * expf(a.x - u - v.x); acc.y -= wc.y * expf(a.y - u - v.y); acc.z -= wc.z * expf(a.z - u - v.z); acc.w -= wc.w * expf(a.w - u - v.w);
+        }
+        out[e] = acc;
+    }
+}
+
 extern "C" int pcacc_sinkhorn_train_workspace_bytes(int n_pairs, int k, size_t *bytes)
 {
     if (!bytes || n_pairs < 1 || k < 1) return PCACC_E_ARG;
@@ -586,8 +697,31 @@ extern "C" int pcacc_sinkhorn_backward(const float *grad_log_perm, const float *
     hipStream_t s = pcacc_stream(stream);
     float *g = reinterpret_cast<float *>(workspace);
     const int64_t padded = (int64_t)n_pairs * (k + 1) * (k + 1);
-    ego_copy_in_kernel<<<pcacc_grid(padded, 256), 256, 0, s>>>(grad_log_perm, k, n_pairs, g);
     const int row_grid = pcacc_grid((int64_t)n_pairs * k * 64, 256);
+    const int64_t stride = (int64_t)n_pairs * k;
+    if (k % 4 == 0 && n_iters >= 1 && (int64_t)(2 * n_iters + 1) * stride <= padded) {
+        // vector form (see above): Wc[it] / Wr[it] = the column / row sums each half-step subtracts with, R0 = row sums of G
+        float *Wc = g, *Wr = g + (int64_t)n_iters * stride, *R0 = g + (int64_t)2 * n_iters * stride;
+        const dim3 cgrid((k + 63) / 64, n_pairs);
+        sk_rowsum_kernel<<<row_grid, 256, 0, s>>>(grad_log_perm, k, n_pairs, R0);
+        sk_cols_kernel<<<cgrid, 256, 0, s>>>(grad_log_perm, nullptr, nullptr, 0, 0, nullptr, k, n_pairs, Wc + (int64_t)(n_iters - 1) * stride);
+        for (int it = n_iters - 1; it >= 0; --it) {
+            // column step `it` (P = exp(x0 - U_{it+1} - V_{it+1})): the row sums it leaves = what row step `it` subtracts with
+            sk_rows_kernel<<<row_grid, 256, 0, s>>>(log_alpha, lse_rows, lse_cols, it + 1, it + 1, Wc + (int64_t)it * stride,
+                                                    it == n_iters - 1 ? R0 : nullptr, k, n_pairs, Wr + (int64_t)it * stride);
+            // row step `it` (P = exp(x0 - U_{it+1} - V_it)): the column sums it leaves = what column step `it - 1` subtracts with
+            if (it > 0)
+                sk_cols_kernel<<<cgrid, 256, 0, s>>>(log_alpha, lse_rows, lse_cols, it + 1, it, Wr + (int64_t)it * stride, k, n_pairs,
+                                                     Wc + (int64_t)(it - 1) * stride);
+        }
+        const int64_t total4 = stride * (k / 4);
+        sk_final_kernel<<<pcacc_grid(total4, 256), 256, 0, s>>>(reinterpret_cast<const float4 *>(grad_log_perm), reinterpret_cast<const float4 *>(log_alpha),
+                                                                lse_rows, lse_cols, Wc, Wr, n_iters, k, n_pairs, total4,
+                                                                reinterpret_cast<float4 *>(grad_log_alpha));
+        PCACC_CHECK_LAUNCH();
+        return PCACC_OK;
+    }
+    ego_copy_in_kernel<<<pcacc_grid(padded, 256), 256, 0, s>>>(grad_log_perm, k, n_pairs, g);
     for (int it = n_iters - 1; it >= 0; --it) {
         // after column step `it`: U = rows 0..it, V = cols 0..it; after row step `it`: U = rows 0..it, V = cols 0..it-1
         ego_sinkhorn_cols_bwd_kernel<<<dim3((k + 63) / 64, n_pairs), 64 * EGO_CG, 0, s>>>(log_alpha, lse_rows, lse_cols, it + 1, it + 1, k, n_pairs, g);

@@ -30,7 +30,8 @@ __global__ __launch_bounds__(HC_THREADS) void head_conv_fwd_kernel(const void *_
     const int l = threadIdx.x % LPP, slot = threadIdx.x / LPP;
     const int64_t n_px = (int64_t)n_img * h * wd;
     for (int64_t px = (int64_t)blockIdx.x * PPB + slot; px < n_px; px += (int64_t)gridDim.x * PPB) {
-        const int xx = (int)(px % wd), yy = (int)((px / wd) % h);
+        const unsigned pq = (unsigned)px / (unsigned)wd;                 // 32-bit: n_img * h * w < 2^31 (checked by the host)
+        const int xx = (int)((unsigned)px - pq * (unsigned)wd), yy = (int)(pq % (unsigned)h);
         float acc[COM];
 #pragma unroll
         for (int c = 0; c < COM; ++c) acc[c] = 0.f;
@@ -79,7 +80,8 @@ __global__ __launch_bounds__(HC_THREADS) void head_conv_dgrad_kernel(const float
     const int l = threadIdx.x % LPP, slot = threadIdx.x / LPP;
     const int64_t n_px = (int64_t)n_img * h * wd;
     for (int64_t px = (int64_t)blockIdx.x * PPB + slot; px < n_px; px += (int64_t)gridDim.x * PPB) {
-        const int xx = (int)(px % wd), yy = (int)((px / wd) % h);
+        const unsigned pq = (unsigned)px / (unsigned)wd;                 // 32-bit: n_img * h * w < 2^31 (checked by the host)
+        const int xx = (int)((unsigned)px - pq * (unsigned)wd), yy = (int)(pq % (unsigned)h);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         float gv[9][COM];
 #pragma unroll
@@ -121,7 +123,8 @@ __global__ __launch_bounds__(HC_THREADS) void head_conv_wgrad_kernel(const float
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[t][c][q] = 0.f;
     for (int64_t px = (int64_t)blockIdx.x * PPB + slot; px < n_px; px += (int64_t)gridDim.x * PPB) {
-        const int xx = (int)(px % wd), yy = (int)((px / wd) % h);
+        const unsigned pq = (unsigned)px / (unsigned)wd;                 // 32-bit: n_img * h * w < 2^31 (checked by the host)
+        const int xx = (int)((unsigned)px - pq * (unsigned)wd), yy = (int)(pq % (unsigned)h);
         float g[COM];
         float4 v[9];
 #pragma unroll
@@ -207,7 +210,10 @@ __global__ __launch_bounds__(256) void head_conv_wgrad_reduce_kernel(const float
     }
 }
 
-static bool hc_ok(int n_img, int h, int w, int c_in, int c_out) { return n_img >= 1 && h >= 1 && w >= 1 && (c_in == 32 || c_in == 64) && c_out >= 1 && c_out <= HC_MAXCO; }
+static bool hc_ok(int n_img, int h, int w, int c_in, int c_out)
+{
+    return n_img >= 1 && h >= 1 && w >= 1 && (int64_t)n_img * h * w < 0x7fffffffLL && (c_in == 32 || c_in == 64) && c_out >= 1 && c_out <= HC_MAXCO;
+}
 
 extern "C" int pcacc_head_conv3x3_supported(int32_t c_in, int32_t c_out) { return hc_ok(1, 1, 1, c_in, c_out) ? 1 : 0; }
 
