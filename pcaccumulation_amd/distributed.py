@@ -328,7 +328,8 @@ class DataParallelStep(object):
         # collapsed: two gloo ranks sharing one MI355X took 1.4-2.9 s per step (75 ms with the prefetch off, 94 ms with one stream;
         # 70 ms / 418 ms with GPU_MAX_HW_QUEUES = 2 / 16 -- the dependence on the queue count is measured, the exact mechanism is not,
         # and RCCL could not be tried with two ranks on one GPU).  One stream is the safe choice there.
-        self.side = torch.cuda.Stream(device=dev) if (self.pipelined and self._two_streams and dev.type == 'cuda' and world_size() == 1
+        allow = world_size() == 1 or os.environ.get('PCACC_TWO_STREAMS_DIST') == '1'      # opt-in with a process group (see above)
+        self.side = torch.cuda.Stream(device=dev) if (self.pipelined and self._two_streams and dev.type == 'cuda' and allow
                                                       and hasattr(model, 'side_stream')) else None
         self.micro = 0
         self.ok = True

@@ -47,5 +47,32 @@ x64 = bf(rows, 64)
 w = torch.randn(32, 64, device=dev) / 8
 for _ in range(3):
     native.rows_linear(x64, w, None, None, False, True, out_dtype=torch.bfloat16)
+# ---- fp32x3 kernels (round 3): fp32 operands, scaled fp16 hi / lo products
+f32 = lambda *shape: torch.randn(*shape, device=dev)
+
+
+def conv_split(n, h, ci, co, kt=1, frames=1):
+    x, gy = f32(n, h, h, ci), f32(n, h, h, co)
+    w = torch.randn(*((co, ci, 3, 3, 3) if kt == 3 else (co, ci, 3, 3)), device=dev) / (3 * (ci * kt) ** 0.5)
+    b = torch.randn(co, device=dev)
+    wf, wb = native.conv3x3_split_prepare_weights(w)
+    ax, ag = native.absmax256(x), native.absmax256(gy)
+    for _ in range(3):
+        native.conv3x3_split(x, wf, b, frames, True, amax=ax)
+    for _ in range(3):
+        native.conv3x3_wgrad_split(gy, x, frames, 0, dy_amax=ag, x_amax=ax)
+
+
+conv_split(20, 288, 32, 32)               # conv3x3_split_res_kernel<32,1,2,5> + conv3x3_wgrad_split_kernel<1,1,9>
+conv_split(20, 36, 256, 256)              # conv3x3_split_kernel<64,2,2,2,9> + conv3x3_wgrad_split_kernel<2,2,9>
+xr, dyr = f32(rows, 32), f32(rows, 32)
+ar, ad = native.absmax256(xr), native.absmax256(dyr)
+w32 = torch.randn(32, 32, device=dev) / 6
+for _ in range(3):
+    native.rows_linear_split(xr, ar, w32, None, None, False, True)
+for _ in range(3):
+    native.rows_wgrad_split(dyr, ad, xr, ar)
+for _ in range(3):
+    native.absmax256(xr)
 torch.cuda.synchronize()
 print('done')

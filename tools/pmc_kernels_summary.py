@@ -19,6 +19,14 @@ KERNELS = {  # name fragment -> (label, algorithmic FLOPs per launch, algorithmi
     'conv3x3_wgrad_strip_kernel': ('conv wgrad 256x256 @36^2 x20 (deep)', 2.0 * 20 * 36 * 36 * 256 * 256 * 9, 20 * 36 * 36 * 512 * 2),
     'rows_wgrad_bf16_kernel': ('rows wgrad 32x32, 3.2 M rows', 2.0 * 3.2e6 * 32 * 33, 3.2e6 * 64 * 2),
     'rows_linear_bf16_kernel': ('rows linear 64->32, 3.2 M rows', 2.0 * 3.2e6 * 64 * 32, 3.2e6 * 96 * 2),
+    # fp32x3 (round 3): algorithmic FLOPs of the operation (the kernels issue 3 MFMAs per product: MFMA busy / 3 is the algorithmic share)
+    'conv3x3_split_res_kernel': ('fp32x3 conv 32->32 @288^2 x20 (resident, persistent)', 2.0 * 20 * 288 * 288 * 32 * 32 * 9, 20 * 288 * 288 * 64 * 4),
+    'conv3x3_split_kernel': ('fp32x3 conv 256->256 @36^2 x20 (streaming)', 2.0 * 20 * 36 * 36 * 256 * 256 * 9, 20 * 36 * 36 * 512 * 4 + 9 * 256 * 256 * 4),
+    'conv3x3_wgrad_split_kernel<1, 1': ('fp32x3 conv wgrad 32x32 @288^2 x20', 2.0 * 20 * 288 * 288 * 32 * 32 * 9, 20 * 288 * 288 * 64 * 4),
+    'conv3x3_wgrad_split_kernel<2, 2': ('fp32x3 conv wgrad 256x256 @36^2 x20', 2.0 * 20 * 36 * 36 * 256 * 256 * 9, 20 * 36 * 36 * 512 * 4),
+    'rows_linear_split_kernel': ('fp32x3 rows linear 32->32, 3.2 M rows', 2.0 * 3.2e6 * 32 * 32, 3.2e6 * 64 * 4),
+    'rows_wgrad_split_kernel': ('fp32x3 rows wgrad 32x32, 3.2 M rows', 2.0 * 3.2e6 * 32 * 33, 3.2e6 * 64 * 4),
+    'absmax256_kernel': ('absmax of 3.2 M x 32 f32', 3.2e6 * 32, 3.2e6 * 32 * 4),
 }
 
 
