@@ -554,6 +554,22 @@ int pcacc_pfn_block_backward(const uint16_t *xa, const uint16_t *pooled, const i
                              const uint16_t *grad_out, const float *w0, const float *ws, const float *w1, uint16_t *grad_xa,
                              uint16_t *grad_xb, float *grad_params, int64_t rows, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The same block on fp32 point rows at fp32 accuracy (compute mode fp32x3: products on the matrix cores from scaled fp16 hi / lo
+ * halves, csrc/pfn_block_split.hip).  *_amax arguments are pcacc_absmax256 arrays of the tensor they follow (inputs), or 256 zeroed
+ * slots the kernel's store phase fills (outputs; may be NULL).
+ * forward: out, relu_h [rows,32] f32; xmask [rows] u64 / hmask [rows] u32: bit c set where x[row][c] > 0 / h[row][c] > 0 -- all the
+ * data-gradient kernel needs of x and h.
+ * dgrad: grad_xa [rows,64] (grad_xb == NULL) or grad_xa [rows,32] + grad_xb [rows,32]; grad_h [rows,32] = d(h), the operand of fc_0's
+ * weight gradient.  The three weight gradients are pcacc_rows_wgrad_split / _cat_split calls on (grad_out, relu_h), (grad_out, x)
+ * and (grad_h, relu(x)). */
+int pcacc_pfn_block_split_forward(const float *xa, const float *xa_amax, const float *pooled, const float *pooled_amax, const int32_t *p2v,
+                                  const float *w0, const float *b0, const float *ws, const float *w1, const float *b1, float *out,
+                                  float *relu_h, uint64_t *xmask, uint32_t *hmask, float *out_amax, float *hr_amax, int64_t rows,
+                                  void *stream);
+int pcacc_pfn_block_split_dgrad(const float *grad_out, const float *grad_out_amax, const uint64_t *xmask, const uint32_t *hmask,
+                                const float *w0, const float *ws, const float *w1, float *grad_xa, float *grad_xb, float *grad_h,
+                                float *gx_amax, float *dh_amax, int64_t rows, void *stream);
+
 /* Tail of a U-Net encoder stage -- models/unet.py:60-71 (DownConv: ... conv, ReLU, 2x2 max-pool; returns the pooled map and the map
  * before the pool).  Channels-last bf16 maps [n_img, h, w, c], c a multiple of 8.
  *  maxpool2x2                out [n_img, h/2, w/2, c]: nn.MaxPool2d(2, 2) (floor mode; NaN propagates), no index map.

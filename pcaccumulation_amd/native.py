@@ -60,7 +60,7 @@ EXPORTS = [
     'pcacc_tube_rows', 'pcacc_tube_code', 'pcacc_tube_code_backward', 'pcacc_tube_pose_forward', 'pcacc_tube_gap_forward', 'pcacc_tube_finish',
     'pcacc_tube_gap_backward', 'pcacc_tube_pose_backward', 'pcacc_rows_wgrad_few_supported', 'pcacc_rows_wgrad_few_workspace_bytes', 'pcacc_rows_wgrad_few',
     'pcacc_maxpool2x2_bf16', 'pcacc_pool_skip_relu_backward_bf16',
-    'pcacc_pfn_block_forward', 'pcacc_pfn_block_backward_workspace_bytes', 'pcacc_pfn_block_backward', 'pcacc_inv4x4',
+    'pcacc_pfn_block_forward', 'pcacc_pfn_block_backward_workspace_bytes', 'pcacc_pfn_block_backward', 'pcacc_pfn_block_split_forward', 'pcacc_pfn_block_split_dgrad', 'pcacc_inv4x4',
     'pcacc_conv3x3_split_prepare_weights', 'pcacc_conv3x3_split_supported', 'pcacc_conv3x3_split', 'pcacc_conv3x3_wgrad_split_workspace_bytes',
     'pcacc_conv3x3_wgrad_split', 'pcacc_absmax256',
     'pcacc_rows_linear_split', 'pcacc_rows_linear_cat_split', 'pcacc_rows_wgrad_split_workspace_bytes', 'pcacc_rows_wgrad_split',
@@ -1273,6 +1273,39 @@ def pfn_block_backward(xa, pooled, p2v, hr, grad_out, w0, ws, w1):
                                           _dev(gxa), _opt(gxb, torch.bfloat16, 'grad_xb'), _dev(gp), _i64(rows), _dev(ws_buf),
                                           ctypes.c_size_t(ws_buf.numel()), _stream()), 'pfn_block_backward')
     return gxa, gxb, gp
+
+
+def pfn_block_split_forward(xa, xa_amax, pooled, pooled_amax, p2v, w0, b0, ws, w1, b1):
+    """The block on f32 rows (fp32x3) -> (out, relu(h) [rows,32] f32, xmask [rows] i64, hmask [rows] i32, out_amax, hr_amax)."""
+    rows = xa.shape[0]
+    dev = xa.device
+    out = torch.empty((rows, 32), dtype=torch.float32, device=dev)
+    hr = torch.empty((rows, 32), dtype=torch.float32, device=dev)
+    xmask = torch.empty((rows,), dtype=torch.int64, device=dev)
+    hmask = torch.empty((rows,), dtype=torch.int32, device=dev)
+    out_amax, hr_amax = _zero256(dev), _zero256(dev)
+    _check(lib().pcacc_pfn_block_split_forward(_dev(xa, torch.float32, 'xa'), _dev(xa_amax, torch.float32, 'xa_amax'), _opt(pooled, torch.float32, 'pooled'),
+                                               _opt(pooled_amax, torch.float32, 'pooled_amax'), _opt(p2v, torch.int32, 'p2v'),
+                                               _dev(w0, torch.float32, 'w0'), _opt(b0, torch.float32, 'b0'), _dev(ws, torch.float32, 'ws'),
+                                               _dev(w1, torch.float32, 'w1'), _opt(b1, torch.float32, 'b1'), _dev(out), _dev(hr), _dev(xmask),
+                                               _dev(hmask), _dev(out_amax), _dev(hr_amax), _i64(rows), _stream()), 'pfn_block_split_forward')
+    return out, hr, xmask, hmask, out_amax, hr_amax
+
+
+def pfn_block_split_dgrad(grad_out, grad_out_amax, xmask, hmask, w0, ws, w1, two_pieces):
+    """-> (grad_xa, grad_xb rows or None, d(h) [rows,32], amax of the d(x) pieces together, amax of d(h))."""
+    rows = grad_out.shape[0]
+    dev = grad_out.device
+    gxa = torch.empty((rows, 32 if two_pieces else 64), dtype=torch.float32, device=dev)
+    gxb = torch.empty((rows, 32), dtype=torch.float32, device=dev) if two_pieces else None
+    dh = torch.empty((rows, 32), dtype=torch.float32, device=dev)
+    gx_amax, dh_amax = _zero256(dev), _zero256(dev)
+    _check(lib().pcacc_pfn_block_split_dgrad(_dev(grad_out, torch.float32, 'grad_out'), _dev(grad_out_amax, torch.float32, 'grad_out_amax'),
+                                             _dev(xmask, torch.int64, 'xmask'), _dev(hmask, torch.int32, 'hmask'), _dev(w0, torch.float32, 'w0'),
+                                             _dev(ws, torch.float32, 'ws'), _dev(w1, torch.float32, 'w1'), _dev(gxa),
+                                             _opt(gxb, torch.float32, 'grad_xb'), _dev(dh), _dev(gx_amax), _dev(dh_amax), _i64(rows), _stream()),
+           'pfn_block_split_dgrad')
+    return gxa, gxb, dh, gx_amax, dh_amax
 
 
 def inv4x4(m):

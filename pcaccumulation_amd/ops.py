@@ -473,17 +473,60 @@ class _PfnBlock(torch.autograd.Function):
                 part('b1') if ctx.has_bias[1] else None)
 
 
+class _PfnBlockSplit(torch.autograd.Function):
+    """_PfnBlock on fp32 rows in the fp32x3 mode (csrc/pfn_block_split.hip): one kernel forward; backward = one data-gradient kernel
+    (reads d(out) and two sign masks) + the three weight gradients on the row weight-gradient kernels."""
+
+    @staticmethod
+    def forward(ctx, xa, pooled, pidx, w0, b0, ws, w1, b1):
+        xa = xa.contiguous()
+        pooled = pooled.contiguous() if pooled is not None else None
+        w0, ws, w1 = w0.contiguous(), ws.contiguous(), w1.contiguous()
+        a_amax = amax_of(xa)
+        p_amax = amax_of(pooled) if pooled is not None else None
+        out, hr, xmask, hmask, out_amax, hr_amax = native.pfn_block_split_forward(xa, a_amax, pooled, p_amax, pidx.p2v if pooled is not None else None,
+                                                                                  w0, b0, ws, w1, b1)
+        set_amax_tag(out, out_amax)
+        ctx.pidx = pidx
+        ctx.save_for_backward(xa, pooled, hr, xmask, hmask, w0, ws, w1, a_amax, p_amax, hr_amax)
+        ctx.has_bias = (b0 is not None, b1 is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xa, pooled, hr, xmask, hmask, w0, ws, w1, a_amax, p_amax, hr_amax = ctx.saved_tensors
+        pidx = ctx.pidx
+        g = g.contiguous()
+        g_amax = amax_of(g)
+        gxa, gxb, dh, gx_amax, dh_amax = native.pfn_block_split_dgrad(g, g_amax, xmask, hmask, w0, ws, w1, pooled is not None)
+        set_amax_tag(gxa, gx_amax)
+        gpool = None
+        if pooled is not None and ctx.needs_input_grad[1]:
+            gpool = native.segment_sum(gxb, pidx.seg_offsets, pidx.order, pidx.m).to(pooled.dtype)
+        gw1, gb1 = native.rows_wgrad_split(g, g_amax, hr, hr_amax, split=True)
+        if pooled is not None:
+            gws, _ = native.rows_wgrad_cat_split(g, g_amax, xa, a_amax, pooled, p_amax, pidx.p2v, split=True)
+            gw0, gb0 = native.rows_wgrad_cat_split(dh, dh_amax, xa, a_amax, pooled, p_amax, pidx.p2v, x_relu=True, split=True)
+        else:
+            gws, _ = native.rows_wgrad_split(g, g_amax, xa, a_amax, split=True)
+            gw0, gb0 = native.rows_wgrad_split(dh, dh_amax, xa, a_amax, x_relu=True, split=True)
+        return gxa, gpool, None, gw0, gb0 if ctx.has_bias[0] else None, gws, gw1, gb1 if ctx.has_bias[1] else None
+
+
 def pfn_block_available(block, x, pooled=None):
-    """The fused block takes bf16 rows on the GPU, the encoder's widths (64 -> 32 -> 32 with a shortcut) and fp32 parameters."""
+    """The fused block takes bf16 rows (or fp32 rows in the fp32x3 mode) on the GPU, the encoder's widths (64 -> 32 -> 32 with a shortcut)
+    and fp32 parameters."""
     width = x.shape[1] + (pooled.shape[1] if pooled is not None else 0)
-    return (x.is_cuda and x.dtype == torch.bfloat16 and (pooled is None or (pooled.dtype == torch.bfloat16 and x.shape[1] == 32 and pooled.shape[1] == 32))
+    dtype_ok = x.dtype == torch.bfloat16 or (_SPLIT and x.dtype == torch.float32)
+    return (x.is_cuda and dtype_ok and (pooled is None or (pooled.dtype == x.dtype and x.shape[1] == 32 and pooled.shape[1] == 32))
             and x.shape[0] >= MIN_ROWS_FUSED_LINEAR and width == 64 and block.size_in == 64 and block.size_h == 32 and block.size_out == 32
             and block.shortcut is not None and block.fc_0.weight.dtype == torch.float32 and not torch.is_autocast_enabled())
 
 
 def pfn_block(block, x, pooled=None, pidx=None):
-    """block(x) or block(cat(x, pooled[pidx.p2v])) for a pillar_encoder.ResnetBlockFC -- see _PfnBlock."""
-    return _PfnBlock.apply(x, pooled, pidx, block.fc_0.weight, block.fc_0.bias, block.shortcut.weight, block.fc_1.weight, block.fc_1.bias)
+    """block(x) or block(cat(x, pooled[pidx.p2v])) for a pillar_encoder.ResnetBlockFC -- see _PfnBlock / _PfnBlockSplit."""
+    fn = _PfnBlockSplit if x.dtype == torch.float32 else _PfnBlock
+    return fn.apply(x, pooled, pidx, block.fc_0.weight, block.fc_0.bias, block.shortcut.weight, block.fc_1.weight, block.fc_1.bias)
 
 
 _POINT_DTYPE = torch.float32

@@ -118,3 +118,74 @@ def test_rows_split_dynamic_range(scale):
     gw, gb = native.rows_wgrad_split(dy, native.absmax256(dy), x, native.absmax256(x), split=True)
     assert _rel(gw, dy.double().t() @ x.double()) <= TOL and _rel(gb, dy.double().sum(0)) <= TOL
     assert torch.equal(native.rows_wgrad_split(dy[:0], native.absmax256(dy), x[:0], native.absmax256(x)), torch.zeros(n, k + 1, device=DEV))
+
+
+@pytest.mark.parametrize('two_piece,n', [(False, 4096), (False, 33333), (True, 50_001), (True, 2177)])
+def test_pfn_block_split_fused_kernels(two_piece, n):
+    """The fused fp32x3 block (csrc/pfn_block_split.hip: one forward kernel, one data-gradient kernel, sign masks instead of x and h)
+    against float64 autograd of models/pillar_encoder.py:45-55 -- rows not a multiple of the 128-row tile, both input forms, rows of very
+    different magnitude (the intermediates are scaled per wave)."""
+    from pcaccumulation_amd.pillar_encoder import ResnetBlockFC
+    torch.manual_seed(3 + n)
+    m = max(n // 6, 1)
+    block = ResnetBlockFC(64, 32).to(DEV)
+    torch.nn.init.normal_(block.fc_1.weight, std=0.2)
+    row_scale = torch.ones(n, 1, device=DEV)
+    row_scale[n // 2:] = 1e-3                                                      # whole waves of small rows next to waves of large ones
+    calls = []
+    orig_f, orig_d = native.pfn_block_split_forward, native.pfn_block_split_dgrad
+    native.pfn_block_split_forward = lambda *a, **k: (calls.append('f'), orig_f(*a, **k))[1]
+    native.pfn_block_split_dgrad = lambda *a, **k: (calls.append('d'), orig_d(*a, **k))[1]
+    try:
+        if two_piece:
+            p2v = torch.randint(0, m, (n,), device=DEV, dtype=torch.int32)
+            p2v[:m] = torch.arange(m, device=DEV, dtype=torch.int32)
+            pidx = PillarIndex.from_point_map(p2v, m)
+            x = (torch.randn(n, 32, device=DEV) * row_scale).requires_grad_(True)
+            pooled = (torch.randn(m, 32, device=DEV) * 7).requires_grad_(True)
+            y = block.forward_pooled(x, pooled, pidx)
+        else:
+            x = (torch.randn(n, 64, device=DEV) * row_scale).requires_grad_(True)
+            pooled = None
+            y = block(x)
+        g = torch.randn(n, 32, device=DEV) * row_scale
+        y.backward(g)
+    finally:
+        native.pfn_block_split_forward, native.pfn_block_split_dgrad = orig_f, orig_d
+    assert calls == ['f', 'd'], 'fp32x3 mode: the block runs on its fused kernels'
+    assert float(ops.amax_of(y.detach()).max()) == float(y.detach().abs().max()), 'the store phase reports the output maximum'
+    b64 = ResnetBlockFC(64, 32).to(DEV).double()
+    b64.load_state_dict({k: v.double() for k, v in block.state_dict().items()})
+    xr = x.detach().double().requires_grad_(True)
+    pr = pooled.detach().double().requires_grad_(True) if two_piece else None
+    cat = torch.cat([xr, pr[p2v.long()]], dim=1) if two_piece else xr
+    net = torch.nn.functional.linear(torch.relu(cat), b64.fc_0.weight, b64.fc_0.bias)
+    yr = torch.nn.functional.linear(torch.relu(net), b64.fc_1.weight, b64.fc_1.bias) + torch.nn.functional.linear(cat, b64.shortcut.weight)
+    yr.backward(g.double())
+    assert _rel(y.detach(), yr.detach()) <= TOL
+    half = n // 2                                                                  # the small rows are held to their own magnitude
+    assert _rel(y.detach()[half:] - block.fc_1.bias, yr.detach()[half:] - b64.fc_1.bias) <= 2e-4   # bias 0.1 next to 1e-3 rows: fp32 rounding of the sum
+    assert _rel(x.grad, xr.grad) <= 4 * TOL and _rel(x.grad[half:], xr.grad[half:]) <= 4 * TOL
+    if two_piece:
+        assert _rel(pooled.grad, pr.grad) <= 4 * TOL
+    for a, p in zip(block.parameters(), b64.parameters()):
+        assert _rel(a.grad, p.grad) <= 4 * TOL
+
+
+def test_pfn_block_split_matches_unfused_masks():
+    """xmask / hmask are exactly the signs the unfused layers would use (x > 0, h > 0), nonfinite input propagates."""
+    torch.manual_seed(9)
+    n = 1000
+    x = torch.randn(n, 64, device=DEV)
+    x[5, 7] = 0.0
+    w0, ws, w1 = torch.randn(32, 64, device=DEV) / 8, torch.randn(32, 64, device=DEV) / 8, torch.randn(32, 32, device=DEV) / 6
+    b0, b1 = torch.randn(32, device=DEV), torch.randn(32, device=DEV)
+    out, hr, xmask, hmask, out_amax, hr_amax = native.pfn_block_split_forward(x, native.absmax256(x), None, None, None, w0, b0, ws, w1, b1)
+    bits = torch.arange(64, device=DEV)
+    assert torch.equal(((xmask[:, None] >> bits) & 1).bool(), x > 0)
+    assert torch.equal(((hmask[:, None].long() >> bits[:32]) & 1).bool(), hr > 0)
+    h64 = torch.relu(x.double()) @ w0.double().t() + b0.double()
+    assert _rel(hr, torch.relu(h64)) <= TOL and float(hr_amax.max()) == float(hr.max())
+    x[17, 3] = float('nan')
+    out2 = native.pfn_block_split_forward(x, native.absmax256(x), None, None, None, w0, b0, ws, w1, b1)[0]
+    assert torch.isnan(out2[17]).all()
