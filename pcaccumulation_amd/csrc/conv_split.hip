@@ -454,9 +454,12 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float 
 // registers during the current pass's MFMAs, the nine tap tiles of the pass's slice sit in LDS (re-staged only when the slice changes:
 // never for a one-slice layer), and the 9 x CS/16 steps of a pass run without a barrier, fragment reads two steps ahead of their MFMAs.
 // 8 waves along the pixels (NGW = 1); a wave owns MT pixel tiles x NW channel tiles.
+#ifndef CSR_EXP
+#define CSR_EXP 0                               // phase knock-outs for tools/exp_conv_res_phases.sh (1 MFMA loop, 2 patch staging, 4 stores, 8 patch loads, 16 weight staging)
+#endif
 #define CSR_WPT 9                               // 16-byte weight pieces a thread carries for the next slice (9 taps x 64 rows x 32 ch x 2 planes / 512)
 
-template <int CS, int NW, int MT, int PCH>
+template <int CS, int NW, int MT, int PCH, bool RESTAGE>
 __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_res_kernel(const float *__restrict__ in, const float *__restrict__ in_amax,
                                                                         const float *__restrict__ in_mask, const uint16_t *__restrict__ wp,
                                                                         const float *__restrict__ wscale, const float *__restrict__ bias,
@@ -567,7 +570,26 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_res_kernel(const fl
     int s = first_slice(tile);
     fetch_patch(tile, s);
     fetch_w(s);
+    if (!RESTAGE) write_w();                                   // a one-slice layer (RESTAGE false): its nine tap tiles are staged once; the first pass's barriers publish them
     f32x16_t acc[MT][NW];
+    // a finished tile's values wait in registers and leave one pass later, right after the next patch loads are issued: the wait for those
+    // loads at the top of a pass (vmcnt counts stores too) then finds the stores a whole MFMA phase old instead of just issued -- as
+    // written before, load burst, MFMA phase and store burst took turns (57 + 53 + 71 us of a 181 us layer, measured by knocking each out)
+    constexpr bool DEFER = !RESTAGE;
+    float4 pend[MT][NW][4];
+    int pend_pyx[MT], pend_img = 0;
+    bool have_pend = false;
+    auto flush = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            if (pend_pyx[j] < 0) continue;
+            float *dst = out + (((int64_t)pend_img * h + (pend_pyx[j] >> 16)) * w + (pend_pyx[j] & 0xffff)) * c_out + co0;
+#pragma unroll
+            for (int n = 0; n < NW; ++n)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) *reinterpret_cast<float4 *>(dst + n * 32 + 8 * g + 4 * lh) = pend[j][n][g];
+        }
+    };
     while (tile < n_tiles) {
         if (s == first_slice(tile)) {
 #pragma unroll
@@ -578,14 +600,16 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_res_kernel(const fl
                     for (int r = 0; r < 16; ++r) acc[j][n][r] = 0.f;
         }
         __syncthreads();                                       // the previous pass is done with the patch and the weight tiles
-        write_patch();
-        write_w();                                             // unconditionally (46 - 92 KB of LDS writes against ~1 MB of fragment reads per pass):
+        if (!(CSR_EXP & 2)) write_patch();
+        if (RESTAGE && !(CSR_EXP & 16)) write_w();             // unconditionally (46 - 92 KB of LDS writes against ~1 MB of fragment reads per pass):
         __syncthreads();                                       // under a condition the compiler keeps the pieces in scratch memory
         // the next pass: its patch and its weight tiles in flight during this pass's MFMAs
         int nt = tile, ns = s + 1;
         if (ns >= end_slice(tile)) { nt = tile + slots; ns = nt < n_tiles ? first_slice(nt) : s; }
-        if (nt < n_tiles) fetch_patch(nt, ns);
-        fetch_w(ns);
+        if (nt < n_tiles && !(CSR_EXP & 8)) fetch_patch(nt, ns);
+        if (RESTAGE && !(CSR_EXP & 16)) fetch_w(ns);
+        if (have_pend && !(CSR_EXP & 4)) flush();
+        have_pend = false;
 
         // the lane's pixels of this tile
         const int img = tile / tiles_img, rem = tile - img * tiles_img;
@@ -599,7 +623,7 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_res_kernel(const fl
             poff[j] = ok ? (y * pw + x) * PS : 0;
             pyx[j] = ok ? ((y0 + y) << 16 | (x0 + x)) : -1;
         }
-        {
+        if (!(CSR_EXP & 1)) {
             f16x8_t ah[AHEAD + 1][NW], al[AHEAD + 1][NW], bh[AHEAD + 1][MT], bl[AHEAD + 1][MT];
             const uint16_t *wa = wl + lp * PS + lh * 8;
             auto load = [&](int slt, int st) __attribute__((always_inline)) {
@@ -638,11 +662,11 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_res_kernel(const fl
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (nt != tile) {                                      // last slice of this tile: scales off, bias, ReLU, store
+        if (nt != tile) {                                      // last slice of this tile: scales off, bias, ReLU -> the pending registers
+            pend_img = img;
 #pragma unroll
             for (int j = 0; j < MT; ++j) {
-                if (pyx[j] < 0) continue;
-                float *dst = out + (((int64_t)img * h + (pyx[j] >> 16)) * w + (pyx[j] & 0xffff)) * c_out + co0;
+                pend_pyx[j] = pyx[j];
 #pragma unroll
                 for (int n = 0; n < NW; ++n)
 #pragma unroll
@@ -655,15 +679,23 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_res_kernel(const fl
                         float4 v = make_float4(acc[j][n][4 * g] * sc.x + bv.x, acc[j][n][4 * g + 1] * sc.y + bv.y, acc[j][n][4 * g + 2] * sc.z + bv.z,
                                                acc[j][n][4 * g + 3] * sc.w + bv.w);
                         if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-                        *reinterpret_cast<float4 *>(dst + c) = v;
-                        omax = fmaxf(fmaxf(omax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-                        if (!(v.x == v.x && v.y == v.y && v.z == v.z && v.w == v.w)) omax = __builtin_inff();
+                        pend[j][n][g] = v;
+                        if (pyx[j] >= 0) {
+                            omax = fmaxf(fmaxf(omax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                            if (!(v.x == v.x && v.y == v.y && v.z == v.z && v.w == v.w)) omax = __builtin_inff();
+                        }
                     }
+            }
+            have_pend = true;
+            if (!DEFER) {                                      // the re-staging variants have no registers to spare for the delay
+                if (!(CSR_EXP & 4)) flush();
+                have_pend = false;
             }
         }
         tile = nt;
         s = ns;
     }
+    if (have_pend && !(CSR_EXP & 4)) flush();
     if (out_amax) {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) omax = fmaxf(omax, __shfl_xor(omax, d, 64));
@@ -738,12 +770,12 @@ static bool conv_res_plan(int n_img, int h, int w, int c_in, int c_out, ConvResP
     return found;
 }
 
-template <int CS, int NW, int MT, int PCH>
+template <int CS, int NW, int MT, int PCH, bool RESTAGE>
 static int conv_res_launch(const ConvResPlan &p, const float *in, const float *in_amax, const float *in_mask, const uint16_t *wp,
                            const float *wscale, const float *bias, float *out, float *out_amax, int n_img, int frames, int h, int w, int c_in,
                            int c_out, int kt, int relu, hipStream_t st)
 {
-    auto kern = conv3x3_split_res_kernel<CS, NW, MT, PCH>;
+    auto kern = conv3x3_split_res_kernel<CS, NW, MT, PCH, RESTAGE>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds) != hipSuccess)
         return PCACC_E_LAUNCH;
     hipLaunchKernelGGL(kern, dim3((unsigned)(p.co_groups * p.slots)), dim3(CSP_THREADS), p.lds, st, in, in_amax, in_mask, wp, wscale, bias, out, out_amax,
@@ -851,9 +883,11 @@ extern "C" int pcacc_conv3x3_split(const float *in, const float *in_amax, const 
         if (getenv("PCACC_CONV_PLAN"))
             fprintf(stderr, "split conv plan (resident) %dx%d %d->%d kt=%d n=%d: cs=%d nw=%d mt=%d rows=%d bw=%d slots=%d lds=%zu\n", h, w, c_in, c_out,
                     kt, n_img, rp.cs, rp.nw, rp.mt, rp.rows, rp.bw, rp.slots, rp.lds);
+        const bool restage = kt == 3 || c_in != rp.cs;         // more than one (frame tap, channel slice) per tile
 #define CSR_CASE(CSV, NWV, MTV, PCHV)                                          \
     if (rp.cs == CSV && rp.nw == NWV && rp.mt == MTV)                          \
-        return conv_res_launch<CSV, NWV, MTV, PCHV>(rp, in, in_amax, in_mask, wp, wscale, bias, out, out_amax, n_img, frames, h, w, c_in, c_out, kt, relu, st)
+        return restage ? conv_res_launch<CSV, NWV, MTV, PCHV, true>(rp, in, in_amax, in_mask, wp, wscale, bias, out, out_amax, n_img, frames, h, w, c_in, c_out, kt, relu, st) \
+                       : conv_res_launch<CSV, NWV, MTV, PCHV, false>(rp, in, in_amax, in_mask, wp, wscale, bias, out, out_amax, n_img, frames, h, w, c_in, c_out, kt, relu, st)
         CSR_CASE(32, 1, 1, 3); CSR_CASE(32, 2, 1, 3); CSR_CASE(32, 1, 2, 5); CSR_CASE(64, 1, 1, 6);
 #undef CSR_CASE
     }

@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libpcacc_hip.so')
+LIB_PATH = os.environ.get('PCACC_LIB') or os.path.join(_HERE, 'csrc', 'libpcacc_hip.so')   # PCACC_LIB: experiment builds (tools/)
 
 F32, BF16 = 0, 1
 _ERR = {-1: 'PCACC_E_ARG', -2: 'PCACC_E_WORKSPACE', -3: 'PCACC_E_LAUNCH'}

@@ -11,14 +11,16 @@ from torch.profiler import profile, ProfilerActivity
 
 dev = torch.device('cuda:0')
 cfg = default_config('waymo', 'train', n_sweeps=5)
-cfg['misc']['compute_dtype'] = 'bf16'; cfg['pose_estimation']['kpt_sampler'] = 'device'
+cfg['misc']['compute_dtype'] = os.environ.get('PCACC_DTYPE', 'bf16'); cfg['pose_estimation']['kpt_sampler'] = 'device'
+from pcaccumulation_amd import distributed as pdist
 model, opt, loss_fn = bench.build(cfg, dev)
+stepper = pdist.DataParallelStep(model, opt, loss_fn, iter_size=1, grad_clip=cfg['train']['grad_clip'], catch=False)
 batcher = DeviceBatcher(cfg)
 scenes = [sample_to_device(make_sequence(i, 5, 160000, cfg), dev) for i in range(4)]
-for it in range(2):
-    bench.train_step(model, opt, loss_fn, batcher, scenes, None, 1.0)
+for it in range(3):
+    bench.train_step(stepper, batcher, scenes)
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
-    bench.train_step(model, opt, loss_fn, batcher, scenes, None, 1.0)
+    bench.train_step(stepper, batcher, scenes)
     torch.cuda.synchronize()
 rows = []
 for e in prof.key_averages(group_by_input_shape=True):
