@@ -118,6 +118,11 @@ int pcacc_segment_max_backward_t(const void *grad_out, int dtype, const int32_t 
                                  void *grad_src, int out_dtype, void *stream);
 int pcacc_segment_sum_t(const void *src, int dtype, int c, const int32_t *seg_offsets, const int32_t *order, int64_t n,
                         int64_t m, void *out, void *workspace, size_t workspace_bytes, void *stream);
+/* max_backward added into grad_src (in/out): the rows' gradient from their other consumer is already there -- the pooled PFN blocks,
+ * models/pillar_encoder.py:116-118, where `net` feeds both the max-pool and the concatenation.  out_amax: 256 zeroed f32 slots that
+ * receive the largest magnitude of the sums (pcacc_absmax256 layout), or NULL. */
+int pcacc_segment_max_backward_acc(const void *grad_out, int dtype, const int32_t *arg, const int32_t *p2v, int64_t n, int c,
+                                   void *grad_src, int out_dtype, float *out_amax, void *stream);
 
 /* A4 (feature build). The nine per-point inputs of the pillar encoder -- models/pillar_encoder.py:98-110:
  * [xyz, xyz - pillar_mean, xy - pillar_centre, t], first eight divided by `scale` (= |x_min|), t by n_frames.

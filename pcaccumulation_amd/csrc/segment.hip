@@ -451,11 +451,15 @@ extern "C" int pcacc_segment_max_t(const void *src, int dtype, int c, const int3
 }
 
 // grad_src[i,k] = (arg[p2v[i],k] == i) ? grad_out[p2v[i],k] : 0        (fully coalesced, no atomics)
+// ACC: added to what grad_src holds (the rows' gradient from their other consumer: one pass instead of a dense result plus autograd's
+// add of the two), with the largest magnitude of the sums into out_amax (256 zeroed slots; may be NULL)
+template <bool ACC>
 __global__ __launch_bounds__(256) void seg_max_bwd_kernel(const void *__restrict__ grad_out, const int4 *__restrict__ arg,
                                                           const int32_t *__restrict__ p2v, int64_t n, int lpp,
-                                                          void *__restrict__ grad_src, bool bf, bool out_bf)
+                                                          void *__restrict__ grad_src, bool bf, bool out_bf, float *__restrict__ out_amax)
 {
     const int64_t total = n * lpp;
+    float mx = 0.f;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int64_t i = e / lpp;
         const int sub = (int)(e - i * lpp);
@@ -467,19 +471,34 @@ __global__ __launch_bounds__(256) void seg_max_bwd_kernel(const void *__restrict
         r.y = (a.y == (int)i) ? g.y : 0.f;
         r.z = (a.z == (int)i) ? g.z : 0.f;
         r.w = (a.w == (int)i) ? g.w : 0.f;
+        if (ACC) {
+            const float4 o = pcacc_ld4(grad_src, out_bf, e);
+            r = make_float4(o.x + r.x, o.y + r.y, o.z + r.z, o.w + r.w);
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
+            if (!(r.x == r.x && r.y == r.y && r.z == r.z && r.w == r.w)) mx = __builtin_inff();
+        }
         pcacc_st4(grad_src, out_bf, e, r);
+    }
+    if (ACC && out_amax) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+        if (lane_id() == 0) atomicMax(reinterpret_cast<unsigned *>(out_amax) + (blockIdx.x & 255), __float_as_uint(mx));
     }
 }
 
 static int segment_max_backward_any(const void *grad_out, int dtype, const int32_t *arg, const int32_t *p2v, int64_t n, int c,
-                                    void *grad_src, int out_dtype, void *stream)
+                                    void *grad_src, int out_dtype, void *stream, bool accumulate = false, float *out_amax = nullptr)
 {
     if (n < 0 || c <= 0 || (c % 4) || (dtype != PCACC_F32 && dtype != PCACC_BF16) || (out_dtype != PCACC_F32 && out_dtype != PCACC_BF16))
         return PCACC_E_ARG;
     if (n > 0 && (!grad_out || !arg || !p2v || !grad_src)) return PCACC_E_ARG;
     if (n == 0) return PCACC_OK;
-    seg_max_bwd_kernel<<<pcacc_grid(n * (c / 4), 256), 256, 0, pcacc_stream(stream)>>>(
-        grad_out, reinterpret_cast<const int4 *>(arg), p2v, n, c / 4, grad_src, dtype == PCACC_BF16, out_dtype == PCACC_BF16);
+    if (accumulate)
+        seg_max_bwd_kernel<true><<<pcacc_grid(n * (c / 4), 256), 256, 0, pcacc_stream(stream)>>>(
+            grad_out, reinterpret_cast<const int4 *>(arg), p2v, n, c / 4, grad_src, dtype == PCACC_BF16, out_dtype == PCACC_BF16, out_amax);
+    else
+        seg_max_bwd_kernel<false><<<pcacc_grid(n * (c / 4), 256), 256, 0, pcacc_stream(stream)>>>(
+            grad_out, reinterpret_cast<const int4 *>(arg), p2v, n, c / 4, grad_src, dtype == PCACC_BF16, out_dtype == PCACC_BF16, nullptr);
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
 }
@@ -494,6 +513,12 @@ extern "C" int pcacc_segment_max_backward_t(const void *grad_out, int dtype, con
                                             int c, void *grad_src, int out_dtype, void *stream)
 {
     return segment_max_backward_any(grad_out, dtype, arg, p2v, n, c, grad_src, out_dtype, stream);
+}
+
+extern "C" int pcacc_segment_max_backward_acc(const void *grad_out, int dtype, const int32_t *arg, const int32_t *p2v, int64_t n, int c,
+                                              void *grad_src, int out_dtype, float *out_amax, void *stream)
+{
+    return segment_max_backward_any(grad_out, dtype, arg, p2v, n, c, grad_src, out_dtype, stream, true, out_amax);
 }
 
 // Backward of the [point_to_voxel_map] broadcast (models/pillar_encoder.py:116): per-pillar sum of point rows.

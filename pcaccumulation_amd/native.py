@@ -48,7 +48,7 @@ EXPORTS = [
     'pcacc_sinkhorn_kabsch_workspace_bytes', 'pcacc_sinkhorn_kabsch', 'pcacc_chamfer_workspace_bytes', 'pcacc_chamfer_forward', 'pcacc_chamfer_backward',
     'pcacc_cluster_workspace_bytes', 'pcacc_cluster', 'pcacc_conv3x3_prepare_weights', 'pcacc_conv3x3_bf16',
     'pcacc_rows_linear_bf16', 'pcacc_rows_linear_mixed', 'pcacc_rows_wgrad_mixed',
-    'pcacc_segment_max_t', 'pcacc_segment_max_backward_t', 'pcacc_segment_sum_t', 'pcacc_rows_wgrad_bf16_workspace_bytes', 'pcacc_rows_wgrad_bf16', 'pcacc_sample_subsets', 'pcacc_conv3x3_wgrad_workspace_bytes', 'pcacc_conv3x3_wgrad_bf16', 'pcacc_upload_words', 'pcacc_bilinear_base_cells', 'pcacc_bilinear_sorted_workspace_bytes', 'pcacc_bilinear_gather_backward_sorted', 'pcacc_prep_points',
+    'pcacc_segment_max_t', 'pcacc_segment_max_backward_t', 'pcacc_segment_max_backward_acc', 'pcacc_segment_sum_t', 'pcacc_rows_wgrad_bf16_workspace_bytes', 'pcacc_rows_wgrad_bf16', 'pcacc_sample_subsets', 'pcacc_conv3x3_wgrad_workspace_bytes', 'pcacc_conv3x3_wgrad_bf16', 'pcacc_upload_words', 'pcacc_bilinear_base_cells', 'pcacc_bilinear_sorted_workspace_bytes', 'pcacc_bilinear_gather_backward_sorted', 'pcacc_prep_points',
     'pcacc_sinkhorn_train_workspace_bytes', 'pcacc_sinkhorn_forward', 'pcacc_sinkhorn_backward',
     'pcacc_seg_loss_workspace_bytes', 'pcacc_seg_loss_forward', 'pcacc_seg_loss_backward',
     'pcacc_offset_loss_workspace_bytes', 'pcacc_offset_loss_forward', 'pcacc_offset_loss_backward',
@@ -218,6 +218,18 @@ def segment_max_backward(grad_out, arg, p2v, n, out_dtype=None):
                                               _dev(p2v, torch.int32), _i64(n), int(c), _dev(g), _dtype_code(g), _stream()),
            'segment_max_backward')
     return g
+
+
+def segment_max_backward_acc(grad_out, arg, p2v, grad_src, want_amax=False):
+    """grad_src [n,c] += grad of segment_max w.r.t. its rows, in place (f32 / bf16 each); want_amax: -> absmax256 array of the sums."""
+    n, c = grad_src.shape
+    if grad_out.dtype not in (torch.float32, torch.bfloat16):
+        grad_out = grad_out.float()
+    amax = _zero256(grad_src.device) if want_amax else None
+    _check(lib().pcacc_segment_max_backward_acc(_dev(grad_out, None, 'grad_out'), _dtype_code(grad_out), _dev(arg, torch.int32), _dev(p2v, torch.int32),
+                                                _i64(n), int(c), _dev(grad_src, None, 'grad_src'), _dtype_code(grad_src),
+                                                _dev(amax) if want_amax else None, _stream()), 'segment_max_backward_acc')
+    return amax
 
 
 def segment_sum(src, offs, order, m):

@@ -6,6 +6,8 @@ channels is the 2-D tensor [n_cells, C] with n_cells = B*T*ny*nx in (b, t, y, x)
 """
 import weakref
 
+import os
+
 import torch
 
 from . import native
@@ -447,30 +449,41 @@ def linear_rows_cat(xa, pooled, pidx, layer, pre_relu=False, post_relu=False, re
 class _PfnBlock(torch.autograd.Function):
     """ResnetBlockFC(64, 32) on bf16 point rows as one kernel each way (csrc/pfn_block.hip); x = xa [rows,64], or
     cat(xa [rows,32], pooled[pidx.p2v]) without materialising gather or concatenation.  The pooled half of the data gradient is
-    summed over each pillar's points (CSR segment sum), as in _RowsLinearCat."""
+    summed over each pillar's points (CSR segment sum), as in _RowsLinearCat.
+    pool=True: pooled = segment_max(xa) is taken here too (models/pillar_encoder.py:116-118 as one autograd node): xa's gradient
+    through the max-pool is added into its direct gradient in one pass (pcacc_segment_max_backward_acc) instead of a dense
+    max-pool gradient plus autograd's sum of the two."""
 
     @staticmethod
-    def forward(ctx, xa, pooled, pidx, w0, b0, ws, w1, b1):
+    def forward(ctx, xa, pooled, pidx, w0, b0, ws, w1, b1, pool=False):
         xa = xa.contiguous()
+        arg = None
+        if pool:
+            pooled, arg = native.segment_max(xa, pidx.seg_offsets, pidx.order, pidx.m)
         pooled = pooled.contiguous() if pooled is not None else None
         w0, ws, w1 = w0.contiguous(), ws.contiguous(), w1.contiguous()
         out, hr = native.pfn_block_forward(xa, pooled, pidx.p2v if pooled is not None else None, w0, b0, ws, w1, b1)
         ctx.pidx = pidx
-        ctx.save_for_backward(xa, pooled, hr, w0, ws, w1)
+        ctx.save_for_backward(xa, pooled, hr, w0, ws, w1, arg)
         ctx.has_bias = (b0 is not None, b1 is not None)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        xa, pooled, hr, w0, ws, w1 = ctx.saved_tensors
+        xa, pooled, hr, w0, ws, w1, arg = ctx.saved_tensors
         pidx = ctx.pidx
         gxa, gxb, gp = native.pfn_block_backward(xa, pooled, pidx.p2v if pooled is not None else None, hr, g.contiguous(), w0, ws, w1)
         gpool = None
-        if pooled is not None and ctx.needs_input_grad[1]:
-            gpool = native.segment_sum(gxb, pidx.seg_offsets, pidx.order, pidx.m).to(pooled.dtype)
+        if pooled is not None and (arg is not None or ctx.needs_input_grad[1]):
+            gpool = native.segment_sum(gxb, pidx.seg_offsets, pidx.order, pidx.m)
+            if arg is not None:
+                native.segment_max_backward_acc(gpool, arg, pidx.p2v, gxa)
+                gpool = None
+            else:
+                gpool = gpool.to(pooled.dtype)
         part = lambda name: gp[native.PFN_BLOCK_SLICES[name][0]:native.PFN_BLOCK_SLICES[name][1]].view(native.PFN_BLOCK_SLICES[name][2])
         return (gxa, gpool, None, part('w0'), part('b0') if ctx.has_bias[0] else None, part('ws'), part('w1'),
-                part('b1') if ctx.has_bias[1] else None)
+                part('b1') if ctx.has_bias[1] else None, None)
 
 
 class _PfnBlockSplit(torch.autograd.Function):
@@ -478,31 +491,41 @@ class _PfnBlockSplit(torch.autograd.Function):
     (reads d(out) and two sign masks) + the three weight gradients on the row weight-gradient kernels."""
 
     @staticmethod
-    def forward(ctx, xa, pooled, pidx, w0, b0, ws, w1, b1):
+    def forward(ctx, xa, pooled, pidx, w0, b0, ws, w1, b1, pool=False):
         xa = xa.contiguous()
-        pooled = pooled.contiguous() if pooled is not None else None
-        w0, ws, w1 = w0.contiguous(), ws.contiguous(), w1.contiguous()
         a_amax = amax_of(xa)
-        p_amax = amax_of(pooled) if pooled is not None else None
+        arg = None
+        if pool:
+            pooled, arg = native.segment_max(xa, pidx.seg_offsets, pidx.order, pidx.m)
+            p_amax = a_amax                                                   # maxima of xa's rows: its bound holds
+        else:
+            pooled = pooled.contiguous() if pooled is not None else None
+            p_amax = amax_of(pooled) if pooled is not None else None
+        w0, ws, w1 = w0.contiguous(), ws.contiguous(), w1.contiguous()
         out, hr, xmask, hmask, out_amax, hr_amax = native.pfn_block_split_forward(xa, a_amax, pooled, p_amax, pidx.p2v if pooled is not None else None,
                                                                                   w0, b0, ws, w1, b1)
         set_amax_tag(out, out_amax)
         ctx.pidx = pidx
-        ctx.save_for_backward(xa, pooled, hr, xmask, hmask, w0, ws, w1, a_amax, p_amax, hr_amax)
+        ctx.save_for_backward(xa, pooled, hr, xmask, hmask, w0, ws, w1, a_amax, p_amax, hr_amax, arg)
         ctx.has_bias = (b0 is not None, b1 is not None)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        xa, pooled, hr, xmask, hmask, w0, ws, w1, a_amax, p_amax, hr_amax = ctx.saved_tensors
+        xa, pooled, hr, xmask, hmask, w0, ws, w1, a_amax, p_amax, hr_amax, arg = ctx.saved_tensors
         pidx = ctx.pidx
         g = g.contiguous()
         g_amax = amax_of(g)
         gxa, gxb, dh, gx_amax, dh_amax = native.pfn_block_split_dgrad(g, g_amax, xmask, hmask, w0, ws, w1, pooled is not None)
-        set_amax_tag(gxa, gx_amax)
         gpool = None
-        if pooled is not None and ctx.needs_input_grad[1]:
-            gpool = native.segment_sum(gxb, pidx.seg_offsets, pidx.order, pidx.m).to(pooled.dtype)
+        if pooled is not None and (arg is not None or ctx.needs_input_grad[1]):
+            gpool = native.segment_sum(gxb, pidx.seg_offsets, pidx.order, pidx.m)
+            if arg is not None:
+                gx_amax = native.segment_max_backward_acc(gpool, arg, pidx.p2v, gxa, want_amax=True)
+                gpool = None
+            else:
+                gpool = gpool.to(pooled.dtype)
+        set_amax_tag(gxa, gx_amax)
         gw1, gb1 = native.rows_wgrad_split(g, g_amax, hr, hr_amax, split=True)
         if pooled is not None:
             gws, _ = native.rows_wgrad_cat_split(g, g_amax, xa, a_amax, pooled, p_amax, pidx.p2v, split=True)
@@ -510,7 +533,7 @@ class _PfnBlockSplit(torch.autograd.Function):
         else:
             gws, _ = native.rows_wgrad_split(g, g_amax, xa, a_amax, split=True)
             gw0, gb0 = native.rows_wgrad_split(dh, dh_amax, xa, a_amax, x_relu=True, split=True)
-        return gxa, gpool, None, gw0, gb0 if ctx.has_bias[0] else None, gws, gw1, gb1 if ctx.has_bias[1] else None
+        return gxa, gpool, None, gw0, gb0 if ctx.has_bias[0] else None, gws, gw1, gb1 if ctx.has_bias[1] else None, None
 
 
 def pfn_block_available(block, x, pooled=None):
@@ -523,10 +546,18 @@ def pfn_block_available(block, x, pooled=None):
             and block.shortcut is not None and block.fc_0.weight.dtype == torch.float32 and not torch.is_autocast_enabled())
 
 
-def pfn_block(block, x, pooled=None, pidx=None):
-    """block(x) or block(cat(x, pooled[pidx.p2v])) for a pillar_encoder.ResnetBlockFC -- see _PfnBlock / _PfnBlockSplit."""
+def pfn_block(block, x, pooled=None, pidx=None, pool=False):
+    """block(x) or block(cat(x, pooled[pidx.p2v])) for a pillar_encoder.ResnetBlockFC -- see _PfnBlock / _PfnBlockSplit.
+    pool=True: pooled = segment_max(x, pidx), taken inside the same autograd node."""
     fn = _PfnBlockSplit if x.dtype == torch.float32 else _PfnBlock
-    return fn.apply(x, pooled, pidx, block.fc_0.weight, block.fc_0.bias, block.shortcut.weight, block.fc_1.weight, block.fc_1.bias)
+    return fn.apply(x, pooled, pidx, block.fc_0.weight, block.fc_0.bias, block.shortcut.weight, block.fc_1.weight, block.fc_1.bias, pool)
+
+
+def pfn_pool_block_available(block, x, pidx):
+    """block(cat(x, segment_max(x)[p2v])) as one node: the fused block's conditions with a [m, 32] pooled half in the rows' type
+    (short segments: native.segment_max keeps the type)."""
+    return (x.shape[1] == 32 and x.is_cuda and not native._seg_two_level(x.shape[0], pidx.m) and os.environ.get('PCACC_PFN_POOL_NODE', '1') != '0'
+            and pfn_block_available(block, x, torch.empty((0, 32), dtype=x.dtype, device=x.device)))
 
 
 _POINT_DTYPE = torch.float32

@@ -94,7 +94,10 @@ class PillarFeatureNet(nn.Module):
         net = ops.linear_rows(features, self.fc_pos, out_dtype=pd)
         net = self.blocks[0](net)
         for block in self.blocks[1:]:
-            net = block.forward_pooled(net, ops.carry_amax(net, ops.segment_max(net, pidx)), pidx)      # maxima of net's rows: net's bound holds
+            if ops.pfn_pool_block_available(block, net, pidx):
+                net = ops.pfn_block(block, net, None, pidx, pool=True)       # max-pool, broadcast, concatenation and block: one autograd node
+            else:
+                net = block.forward_pooled(net, ops.carry_amax(net, ops.segment_max(net, pidx)), pidx)      # maxima of net's rows: net's bound holds
         feats = ops.linear_rows(net, self.fc_c)
         pooled = ops.carry_amax(feats, ops.segment_max(feats, pidx))
         return pooled if keep_dtype else pooled.float()

@@ -189,3 +189,37 @@ def test_pfn_block_split_matches_unfused_masks():
     x[17, 3] = float('nan')
     out2 = native.pfn_block_split_forward(x, native.absmax256(x), None, None, None, w0, b0, ws, w1, b1)[0]
     assert torch.isnan(out2[17]).all()
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_pfn_pool_block_is_pool_then_block(dtype):
+    """models/pillar_encoder.py:116-118 as one autograd node (max-pool + broadcast + concatenation + block; the max-pool's gradient added
+    into the rows' direct gradient by pcacc_segment_max_backward_acc) == the same three steps as separate nodes, bit for bit
+    in the output and the data gradient."""
+    from pcaccumulation_amd.pillar_encoder import ResnetBlockFC
+    torch.manual_seed(11)
+    n, m = 60_001, 9_000
+    p2v = torch.randint(0, m, (n,), device=DEV, dtype=torch.int32)
+    p2v[:m] = torch.arange(m, device=DEV, dtype=torch.int32)
+    pidx = PillarIndex.from_point_map(p2v, m)
+    block = ResnetBlockFC(64, 32).to(DEV)
+    torch.nn.init.normal_(block.fc_1.weight, std=0.2)
+    ops.set_split(dtype == torch.float32)
+    x0 = torch.randn(n, 32, device=DEV).to(dtype)
+    g = torch.randn(n, 32, device=DEV).to(dtype)
+    res = []
+    for fused in (True, False):
+        x = x0.clone().requires_grad_(True)
+        block.zero_grad()
+        assert ops.pfn_pool_block_available(block, x, pidx)
+        if fused:
+            y = ops.pfn_block(block, x, None, pidx, pool=True)
+        else:
+            y = block.forward_pooled(x, ops.carry_amax(x, ops.segment_max(x, pidx)), pidx)
+        y.backward(g)
+        res.append((y.detach().clone(), x.grad.clone(), [p.grad.clone() for p in block.parameters()]))
+        if dtype == torch.float32:
+            assert float(ops.amax_of(x.grad).max()) >= float(x.grad.abs().max()) if not fused else float(ops.amax_of(x.grad).max()) == float(x.grad.abs().max())
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for a, b in zip(res[0][2], res[1][2]):                                         # weight gradients: slices summed by atomics
+        assert _rel(a, b) <= 1e-5
