@@ -354,7 +354,7 @@ class _RowsLinear(torch.autograd.Function):
     def backward(ctx, gy):
         x, w, y, x_amax = ctx.saved_tensors
         pre_relu, post_relu, has_bias, has_res, res_dtype, split = ctx.flags
-        gy = gy.contiguous()
+        gy = dense(gy)
         gx = gw = gb = gres = None
         if split:
             if gy.dtype != torch.float32:
@@ -408,7 +408,7 @@ class _RowsLinearCat(torch.autograd.Function):
         xa, pooled, w, y, a_amax, p_amax = ctx.saved_tensors
         pre_relu, post_relu, has_bias, has_res, split = ctx.flags
         pidx = ctx.pidx
-        gy = gy.contiguous()
+        gy = dense(gy)
         ga = gp = gw = gb = gres = None
         g_amax = amax_of(gy) if split else None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
@@ -514,7 +514,7 @@ class _PfnBlockSplit(torch.autograd.Function):
     def backward(ctx, g):
         xa, pooled, hr, xmask, hmask, w0, ws, w1, a_amax, p_amax, hr_amax, arg = ctx.saved_tensors
         pidx = ctx.pidx
-        g = g.contiguous()
+        g = dense(g)
         g_amax = amax_of(g)
         gxa, gxb, dh, gx_amax, dh_amax = native.pfn_block_split_dgrad(g, g_amax, xmask, hmask, w0, ws, w1, pooled is not None)
         gpool = None
@@ -598,7 +598,20 @@ def split_mode():
 # maximum up to a bit of precision per factor two, so pure re-arrangements and maxima (views, pooling) may pass the tag on.
 def amax_tag(t):
     a = getattr(t, '_pcacc_amax', None)
-    return a[0] if a is not None and a[1] == t._version else None
+    if a is not None and a[1] == t._version:
+        return a[0]
+    b = t._base                                               # a view (autograd's PermuteBackward / ViewBackward hand on views of the tensor a
+    if b is not None:                                         # kernel produced): the base's bound holds for any part of it; one version counter
+        a = getattr(b, '_pcacc_amax', None)
+        if a is not None and a[1] == b._version:
+            return a[0]
+    return None
+
+
+def dense(t):
+    """t.contiguous(), the tag kept when that is a copy."""
+    c = t.contiguous()
+    return c if c is t else carry_amax(t, c)
 
 
 def set_amax_tag(t, parts):
@@ -881,7 +894,7 @@ class _Conv3x3Split(torch.autograd.Function):
     def backward(ctx, gy):
         x_rows, weight, y, x_amax = ctx.saved_tensors
         frames, has_bias = ctx.meta
-        gy = gy.contiguous()
+        gy = dense(gy)
         if gy.dtype != torch.float32:
             gy = gy.float()
         gx = gw = gb = None
@@ -935,7 +948,7 @@ class _UpConv2x2Split(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x_rows, weight, x_amax = ctx.saved_tensors
-        gy = gy.contiguous()
+        gy = dense(gy)
         if gy.dtype != torch.float32:
             gy = gy.float()
         g_amax = amax_of(gy)
