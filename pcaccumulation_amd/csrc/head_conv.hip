@@ -15,91 +15,134 @@
 
 __device__ __forceinline__ float4 hc_ld4(const void *p, int bf16, int64_t i4) { return pcacc_ld4(p, bf16 != 0, i4); }
 
-template <int CI, int COM>
-__global__ __launch_bounds__(HC_THREADS) void head_conv_fwd_kernel(const void *__restrict__ x, int x_bf16, const float *__restrict__ w,
-                                                                   const float *__restrict__ bias, float *__restrict__ y, int n_img, int h,
-                                                                   int wd, int co, int64_t ws_o, int64_t ws_i, int64_t ws_y, int64_t ws_x)
+// forward / weight gradient: a workgroup walks 8 x 32-pixel tiles; a tile's input patch (10 x 34 pixels, converted to f32) is staged in LDS
+// once -- read straight from global memory, every input row went through L1 three times and through L2 about three times (the rows above
+// and below belong to other workgroups): 252 us forward / 240 us weight gradient for a 212 MB map.
+#define HC_TR 8
+#define HC_TC 32
+#define HC_PW (HC_TC + 2)
+#define HC_PH (HC_TR + 2)
+
+struct HcTile { int img, y0, x0; };
+__device__ __forceinline__ HcTile hc_tile(int t, int tiles_y, int tiles_x)
 {
-    constexpr int LPP = CI / 4, PPB = HC_THREADS / LPP;        // lanes per pixel, pixels per workgroup
-    __shared__ float wl[9][CI][COM];                      // [tap][ci][co]
-    for (int e = threadIdx.x; e < 9 * CI * COM; e += HC_THREADS) {
-        const int c = e % COM, ci = (e / COM) % CI, tap = e / (COM * CI);
-        wl[tap][ci][c] = c < co ? w[c * ws_o + ci * ws_i + (tap / 3) * ws_y + (tap % 3) * ws_x] : 0.f;
-    }
-    __syncthreads();
-    const int l = threadIdx.x % LPP, slot = threadIdx.x / LPP;
-    const int64_t n_px = (int64_t)n_img * h * wd;
-    for (int64_t px = (int64_t)blockIdx.x * PPB + slot; px < n_px; px += (int64_t)gridDim.x * PPB) {
-        const unsigned pq = (unsigned)px / (unsigned)wd;                 // 32-bit: n_img * h * w < 2^31 (checked by the host)
-        const int xx = (int)((unsigned)px - pq * (unsigned)wd), yy = (int)(pq % (unsigned)h);
-        float acc[COM];
-#pragma unroll
-        for (int c = 0; c < COM; ++c) acc[c] = 0.f;
-        float4 v[9];
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            // always load (from the pixel itself when the neighbour is outside), then select: loads under a branch are issued and
-            // waited for one at a time (9 serial memory latencies per pixel: 185 us for this launch, 743 us for the weight gradient)
-            const int y2 = yy + tap / 3 - 1, x2 = xx + tap % 3 - 1;
-            const bool ok = (unsigned)y2 < (unsigned)h && (unsigned)x2 < (unsigned)wd;
-            v[tap] = hc_ld4(x, x_bf16, (ok ? px + (int64_t)(tap / 3 - 1) * wd + (tap % 3 - 1) : px) * LPP + l);
-            if (!ok) v[tap] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const float *wt = &wl[tap][4 * l][0];
-#pragma unroll
-            for (int c = 0; c < COM; ++c)
-                acc[c] += v[tap].x * wt[c] + v[tap].y * wt[COM + c] + v[tap].z * wt[2 * COM + c] + v[tap].w * wt[3 * COM + c];
-        }
-#pragma unroll
-        for (int d = 1; d < LPP; d <<= 1)
-#pragma unroll
-            for (int c = 0; c < COM; ++c) acc[c] += __shfl_xor(acc[c], d, 64);
-        if (l < co) {
-            float r = acc[0];
-#pragma unroll
-            for (int c = 1; c < COM; ++c) r = l == c ? acc[c] : r;
-            y[px * co + l] = r + (bias ? bias[l] : 0.f);
-        }
+    const int per_img = tiles_y * tiles_x, img = t / per_img, r = t - img * per_img;
+    return HcTile{img, (r / tiles_x) * HC_TR, (r % tiles_x) * HC_TC};
+}
+
+template <int CI>
+__device__ __forceinline__ void hc_stage(const void *__restrict__ x, int x_bf16, const HcTile &t, int h, int wd, float *patch)
+{
+    constexpr int LPP = CI / 4;
+    for (int e = threadIdx.x; e < HC_PH * HC_PW * LPP; e += HC_THREADS) {
+        const int pp = e / LPP, l4 = e - pp * LPP;
+        const int py = pp / HC_PW, pxx = pp - py * HC_PW;
+        const int y = t.y0 - 1 + py, xx = t.x0 - 1 + pxx;
+        const bool ok = (unsigned)y < (unsigned)h && (unsigned)xx < (unsigned)wd;
+        const int yc = min(max(y, 0), h - 1), xc = min(max(xx, 0), wd - 1);                     // always load, then select (see the data gradient)
+        float4 v = hc_ld4(x, x_bf16, (((int64_t)t.img * h + yc) * wd + xc) * LPP + l4);
+        if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4 *>(patch + pp * CI + l4 * 4) = v;
     }
 }
 
 template <int CI, int COM>
+__global__ __launch_bounds__(HC_THREADS) void head_conv_fwd_kernel(const void *__restrict__ x, int x_bf16, const float *__restrict__ w,
+                                                                   const float *__restrict__ bias, float *__restrict__ y, int n_img, int h,
+                                                                   int wd, int co, int64_t ws_o, int64_t ws_i, int64_t ws_y, int64_t ws_x,
+                                                                   int tiles_y, int tiles_x)
+{
+    constexpr int LPP = CI / 4, PPB = HC_THREADS / LPP;        // lanes per pixel, pixels per pass
+    extern __shared__ __attribute__((aligned(16))) float hc_lds[];
+    float *patch = hc_lds;                                     // [HC_PH][HC_PW][CI]
+    const int l = threadIdx.x % LPP, slot = threadIdx.x / LPP;
+    float4 wr[9][COM];                                         // w[c][4 l .. 4 l + 3][tap]: the lane's weights stay in registers
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int c = 0; c < COM; ++c) {
+            const float *wp = w + c * ws_o + (4 * l) * ws_i + (tap / 3) * ws_y + (tap % 3) * ws_x;
+            wr[tap][c] = c < co ? make_float4(wp[0], wp[ws_i], wp[2 * ws_i], wp[3 * ws_i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    const int n_tiles = n_img * tiles_y * tiles_x;
+    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const HcTile tl = hc_tile(t, tiles_y, tiles_x);
+        __syncthreads();                                       // the previous tile's readers are done
+        hc_stage<CI>(x, x_bf16, tl, h, wd, patch);
+        __syncthreads();
+        for (int q = slot; q < HC_TR * HC_TC; q += PPB) {
+            const int row = q / HC_TC, col = q % HC_TC;
+            float acc[COM];
+#pragma unroll
+            for (int c = 0; c < COM; ++c) acc[c] = 0.f;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const float4 v = *reinterpret_cast<const float4 *>(patch + ((row + tap / 3) * HC_PW + col + tap % 3) * CI + 4 * l);
+#pragma unroll
+                for (int c = 0; c < COM; ++c) acc[c] += v.x * wr[tap][c].x + v.y * wr[tap][c].y + v.z * wr[tap][c].z + v.w * wr[tap][c].w;
+            }
+#pragma unroll
+            for (int d = 1; d < LPP; d <<= 1)
+#pragma unroll
+                for (int c = 0; c < COM; ++c) acc[c] += __shfl_xor(acc[c], d, 64);
+            const int yy = tl.y0 + row, xx = tl.x0 + col;
+            if (l < co && yy < h && xx < wd) {
+                float r = acc[0];
+#pragma unroll
+                for (int c = 1; c < COM; ++c) r = l == c ? acc[c] : r;
+                y[(((int64_t)tl.img * h + yy) * wd + xx) * co + l] = r + (bias ? bias[l] : 0.f);
+            }
+        }
+    }
+}
+
+// data gradient: 8 bytes in, 128 bytes out per pixel.  The lane's 9 x c_out x 4 weights live in registers; a tile's dy patch (10 x 34 pixels x c_out)
+// is staged in LDS, so the nine reads per pixel are LDS broadcasts instead of dependent global loads
+template <int CI, int COM>
 __global__ __launch_bounds__(HC_THREADS) void head_conv_dgrad_kernel(const float *__restrict__ dy, const float *__restrict__ w, void *__restrict__ dx,
                                                                      int dx_bf16, int n_img, int h, int wd, int co, int64_t ws_o, int64_t ws_i,
-                                                                     int64_t ws_y, int64_t ws_x)
+                                                                     int64_t ws_y, int64_t ws_x, int tiles_y, int tiles_x)
 {
     constexpr int LPP = CI / 4, PPB = HC_THREADS / LPP;
-    __shared__ float wl[9][COM][CI];                      // [tap][co][ci]
-    for (int e = threadIdx.x; e < 9 * COM * CI; e += HC_THREADS) {
-        const int ci = e % CI, c = (e / CI) % COM, tap = e / (CI * COM);
-        wl[tap][c][ci] = c < co ? w[c * ws_o + ci * ws_i + (tap / 3) * ws_y + (tap % 3) * ws_x] : 0.f;
-    }
-    __syncthreads();
+    __shared__ float gp[HC_PH * HC_PW * COM];
     const int l = threadIdx.x % LPP, slot = threadIdx.x / LPP;
-    const int64_t n_px = (int64_t)n_img * h * wd;
-    for (int64_t px = (int64_t)blockIdx.x * PPB + slot; px < n_px; px += (int64_t)gridDim.x * PPB) {
-        const unsigned pq = (unsigned)px / (unsigned)wd;                 // 32-bit: n_img * h * w < 2^31 (checked by the host)
-        const int xx = (int)((unsigned)px - pq * (unsigned)wd), yy = (int)(pq % (unsigned)h);
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        float gv[9][COM];
+    float4 wr[9][COM];                                         // w[c][4 l .. 4 l + 3][tap]
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {                    // output pixel px - tap offset saw this pixel through tap `tap`
-            const int y2 = yy - (tap / 3 - 1), x2 = xx - (tap % 3 - 1);
-            const bool ok = (unsigned)y2 < (unsigned)h && (unsigned)x2 < (unsigned)wd;
-            const float *g = dy + (ok ? px - (int64_t)(tap / 3 - 1) * wd - (tap % 3 - 1) : px) * co;      // unconditional loads, see the forward kernel
+    for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-            for (int c = 0; c < COM; ++c) gv[tap][c] = (c < co && ok) ? g[c < co ? c : 0] : 0.f;
+        for (int c = 0; c < COM; ++c) {
+            const float *wp = w + c * ws_o + (4 * l) * ws_i + (tap / 3) * ws_y + (tap % 3) * ws_x;
+            wr[tap][c] = c < co ? make_float4(wp[0], wp[ws_i], wp[2 * ws_i], wp[3 * ws_i]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+    const int n_tiles = n_img * tiles_y * tiles_x;
+    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const HcTile tl = hc_tile(t, tiles_y, tiles_x);
+        __syncthreads();
+        for (int e = threadIdx.x; e < HC_PH * HC_PW * COM; e += HC_THREADS) {
+            const int pp = e / COM, c = e - pp * COM;
+            const int py = pp / HC_PW, pxx = pp - py * HC_PW;
+            const int y = tl.y0 - 1 + py, xx = tl.x0 - 1 + pxx;
+            const bool ok = (unsigned)y < (unsigned)h && (unsigned)xx < (unsigned)wd && c < co;
+            const int yc = min(max(y, 0), h - 1), xc = min(max(xx, 0), wd - 1);
+            const float v = dy[(((int64_t)tl.img * h + yc) * wd + xc) * co + (c < co ? c : 0)];       // always load, then select
+            gp[e] = ok ? v : 0.f;
+        }
+        __syncthreads();
+        for (int q = slot; q < HC_TR * HC_TC; q += PPB) {
+            const int row = q / HC_TC, col = q % HC_TC;
+            const int yy = tl.y0 + row, xx = tl.x0 + col;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
+            for (int tap = 0; tap < 9; ++tap) {                // output pixel (this - tap offset) saw this pixel through tap `tap`
+                const float *g = gp + ((row + 2 - tap / 3) * HC_PW + col + 2 - tap % 3) * COM;
 #pragma unroll
-            for (int c = 0; c < COM; ++c) {
-                const float4 wv = *reinterpret_cast<const float4 *>(&wl[tap][c][4 * l]);
-                acc.x += gv[tap][c] * wv.x; acc.y += gv[tap][c] * wv.y; acc.z += gv[tap][c] * wv.z; acc.w += gv[tap][c] * wv.w;
+                for (int c = 0; c < COM; ++c) {
+                    const float gv = g[c];
+                    acc.x += gv * wr[tap][c].x; acc.y += gv * wr[tap][c].y; acc.z += gv * wr[tap][c].z; acc.w += gv * wr[tap][c].w;
+                }
             }
-        pcacc_st4(dx, dx_bf16 != 0, px * LPP + l, acc);
+            if (yy < h && xx < wd) pcacc_st4(dx, dx_bf16 != 0, (((int64_t)tl.img * h + yy) * wd + xx) * LPP + l, acc);
+        }
     }
 }
 
@@ -107,12 +150,15 @@ __global__ __launch_bounds__(HC_THREADS) void head_conv_dgrad_kernel(const float
 // and workgroup from ~10^3 workgroups onto 578 words serialised in L2: 707 us for this launch)
 template <int CI, int COM>
 __global__ __launch_bounds__(HC_THREADS) void head_conv_wgrad_kernel(const float *__restrict__ dy, const void *__restrict__ x, int x_bf16,
-                                                                     float *__restrict__ partial, int n_img, int h, int wd, int co)
+                                                                     float *__restrict__ partial, int n_img, int h, int wd, int co, int tiles_y,
+                                                                     int tiles_x)
 {
-    constexpr int LPP = CI / 4, PPB = HC_THREADS / LPP, SPW = 64 / LPP;      // pixel slots per wave
-    __shared__ float red[HC_THREADS / 64][LPP][9 * COM * 4 + COM];
+    constexpr int LPP = CI / 4, PPB = HC_THREADS / LPP;
+    extern __shared__ __attribute__((aligned(16))) float hc_lds[];
+    float *patch = hc_lds;                                     // [HC_PH][HC_PW][CI]; afterwards the cross-wave reduction [4][LPP][9 COM 4 + COM]
+    constexpr int RED = 9 * COM * 4 + COM;
+    static_assert(4 * LPP * RED <= HC_PH * HC_PW * CI, "reduction scratch fits the patch");
     const int l = threadIdx.x % LPP, slot = threadIdx.x / LPP, wave = threadIdx.x >> 6;
-    const int64_t n_px = (int64_t)n_img * h * wd;
     float acc[9][COM][4], bs[COM];
 #pragma unroll
     for (int c = 0; c < COM; ++c) bs[c] = 0.f;
@@ -122,28 +168,37 @@ __global__ __launch_bounds__(HC_THREADS) void head_conv_wgrad_kernel(const float
         for (int c = 0; c < COM; ++c)
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[t][c][q] = 0.f;
-    for (int64_t px = (int64_t)blockIdx.x * PPB + slot; px < n_px; px += (int64_t)gridDim.x * PPB) {
-        const unsigned pq = (unsigned)px / (unsigned)wd;                 // 32-bit: n_img * h * w < 2^31 (checked by the host)
-        const int xx = (int)((unsigned)px - pq * (unsigned)wd), yy = (int)(pq % (unsigned)h);
-        float g[COM];
-        float4 v[9];
+    const int n_tiles = n_img * tiles_y * tiles_x;
+    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const HcTile tl = hc_tile(t, tiles_y, tiles_x);
+        __syncthreads();
+        hc_stage<CI>(x, x_bf16, tl, h, wd, patch);
+        __syncthreads();
+        for (int q = slot; q < HC_TR * HC_TC; q += PPB) {
+            const int row = q / HC_TC, col = q % HC_TC;
+            const int yy = tl.y0 + row, xx = tl.x0 + col;
+            const bool ok = yy < h && xx < wd;
+            const float *gp = dy + (((int64_t)tl.img * h + min(yy, h - 1)) * wd + min(xx, wd - 1)) * co;
+            float g[COM];
+            if (COM == 2 && co == 2) {
+                const float2 g2 = *reinterpret_cast<const float2 *>(gp);
+                g[0] = ok ? g2.x : 0.f;
+                g[1] = ok ? g2.y : 0.f;
+            } else {
 #pragma unroll
-        for (int c = 0; c < COM; ++c) g[c] = c < co ? dy[px * co + c] : 0.f;
-#pragma unroll
-        for (int c = 0; c < COM; ++c) bs[c] += g[c];
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int y2 = yy + tap / 3 - 1, x2 = xx + tap % 3 - 1;
-            const bool ok = (unsigned)y2 < (unsigned)h && (unsigned)x2 < (unsigned)wd;
-            v[tap] = hc_ld4(x, x_bf16, (ok ? px + (int64_t)(tap / 3 - 1) * wd + (tap % 3 - 1) : px) * LPP + l);      // unconditional, see the forward kernel
-            if (!ok) v[tap] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-            for (int c = 0; c < COM; ++c) {
-                acc[tap][c][0] += g[c] * v[tap].x; acc[tap][c][1] += g[c] * v[tap].y; acc[tap][c][2] += g[c] * v[tap].z; acc[tap][c][3] += g[c] * v[tap].w;
+                for (int c = 0; c < COM; ++c) g[c] = (c < co && ok) ? gp[c < co ? c : 0] : 0.f;
             }
+#pragma unroll
+            for (int c = 0; c < COM; ++c) bs[c] += g[c];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const float4 v = *reinterpret_cast<const float4 *>(patch + ((row + tap / 3) * HC_PW + col + tap % 3) * CI + 4 * l);
+#pragma unroll
+                for (int c = 0; c < COM; ++c) {
+                    acc[tap][c][0] += g[c] * v.x; acc[tap][c][1] += g[c] * v.y; acc[tap][c][2] += g[c] * v.z; acc[tap][c][3] += g[c] * v.w;
+                }
+            }
+        }
     }
     // the pixel slots of a wave (lanes l, l + LPP, ...) hold partial sums of the same outputs
 #pragma unroll
@@ -157,9 +212,10 @@ __global__ __launch_bounds__(HC_THREADS) void head_conv_wgrad_kernel(const float
 #pragma unroll
         for (int c = 0; c < COM; ++c) bs[c] += __shfl_xor(bs[c], d, 64);
     }
-    (void)SPW;
+    __syncthreads();                                           // the last tile's readers are done with the patch
+    float *red = patch;
     if ((threadIdx.x & 63) < LPP) {
-        float *r = red[wave][l];
+        float *r = red + (wave * LPP + l) * RED;
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -176,13 +232,13 @@ __global__ __launch_bounds__(HC_THREADS) void head_conv_wgrad_kernel(const float
         const int tap = e % 9, ci = (e / 9) % CI, c = e / (9 * CI);
         float s = 0.f;
 #pragma unroll
-        for (int wv = 0; wv < HC_THREADS / 64; ++wv) s += red[wv][ci / 4][(tap * COM + c) * 4 + (ci & 3)];
+        for (int wv = 0; wv < HC_THREADS / 64; ++wv) s += red[(wv * LPP + ci / 4) * RED + (tap * COM + c) * 4 + (ci & 3)];
         mine[e] = s;
     }
     if (threadIdx.x < co) {
         float s = 0.f;
 #pragma unroll
-        for (int wv = 0; wv < HC_THREADS / 64; ++wv) s += red[wv][0][9 * COM * 4 + threadIdx.x];      // every lane group saw every pixel's dy: take group 0
+        for (int wv = 0; wv < HC_THREADS / 64; ++wv) s += red[(wv * LPP) * RED + 9 * COM * 4 + threadIdx.x];      // every lane group saw every pixel's dy: take group 0
         mine[co * CI * 9 + threadIdx.x] = s;
     }
 }
@@ -222,11 +278,18 @@ extern "C" int pcacc_head_conv3x3_forward(const void *x, int32_t x_dtype, const 
                                           int32_t n_img, int32_t h, int32_t wd, int32_t c_in, int32_t c_out, void *stream)
 {
     if (!x || !w || !w_strides || !y || !hc_ok(n_img, h, wd, c_in, c_out)) return PCACC_E_ARG;
-    const int64_t n_px = (int64_t)n_img * h * wd;
-    const int ppb = HC_THREADS / (c_in / 4);
-    const int grid = pcacc_grid(n_px, ppb, PCACC_CUS * 8);
-#define HC_FWD(CIV, COV) hipLaunchKernelGGL((head_conv_fwd_kernel<CIV, COV>), dim3(grid), dim3(HC_THREADS), 0, pcacc_stream(stream), x, x_dtype, w, bias, y, n_img, \
-                                            h, wd, c_out, w_strides[0], w_strides[1], w_strides[2], w_strides[3])
+    const int tiles_y = (h + HC_TR - 1) / HC_TR, tiles_x = (wd + HC_TC - 1) / HC_TC;
+    const int64_t n_tiles = (int64_t)n_img * tiles_y * tiles_x;
+    const int grid = (int)(n_tiles < PCACC_CUS * 6 ? n_tiles : PCACC_CUS * 6);
+#define HC_FWD(CIV, COV)                                                                                                                        \
+    do {                                                                                                                                        \
+        const size_t lds = (size_t)(HC_PH * HC_PW * CIV) * sizeof(float);                                                       \
+        auto kern = head_conv_fwd_kernel<CIV, COV>;                                                                                             \
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)     \
+            return PCACC_E_LAUNCH;                                                                                                              \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(HC_THREADS), lds, pcacc_stream(stream), x, x_dtype, w, bias, y, n_img, h, wd, c_out, w_strides[0], \
+                           w_strides[1], w_strides[2], w_strides[3], tiles_y, tiles_x);                                                         \
+    } while (0)
     if (c_in == 32 && c_out <= 2) HC_FWD(32, 2); else if (c_in == 32) HC_FWD(32, 4); else if (c_out <= 2) HC_FWD(64, 2); else HC_FWD(64, 4);
 #undef HC_FWD
     PCACC_CHECK_LAUNCH();
@@ -238,23 +301,27 @@ extern "C" int pcacc_head_conv3x3_dgrad(const float *dy, const float *w, const i
                                         int32_t wd, int32_t c_in, int32_t c_out, void *stream)
 {
     if (!dy || !w || !w_strides || !dx || !hc_ok(n_img, h, wd, c_in, c_out)) return PCACC_E_ARG;
-    const int64_t n_px = (int64_t)n_img * h * wd;
-    const int ppb = HC_THREADS / (c_in / 4);
-    const int grid = pcacc_grid(n_px, ppb, PCACC_CUS * 8);
+    const int tiles_y = (h + HC_TR - 1) / HC_TR, tiles_x = (wd + HC_TC - 1) / HC_TC;
+    const int64_t n_tiles = (int64_t)n_img * tiles_y * tiles_x;
+    const int grid = (int)(n_tiles < PCACC_CUS * 8 ? n_tiles : PCACC_CUS * 8);
 #define HC_DG(CIV, COV) hipLaunchKernelGGL((head_conv_dgrad_kernel<CIV, COV>), dim3(grid), dim3(HC_THREADS), 0, pcacc_stream(stream), dy, w, dx, dx_dtype, n_img, \
-                                           h, wd, c_out, w_strides[0], w_strides[1], w_strides[2], w_strides[3])
+                                           h, wd, c_out, w_strides[0], w_strides[1], w_strides[2], w_strides[3], tiles_y, tiles_x)
     if (c_in == 32 && c_out <= 2) HC_DG(32, 2); else if (c_in == 32) HC_DG(32, 4); else if (c_out <= 2) HC_DG(64, 2); else HC_DG(64, 4);
 #undef HC_DG
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
 }
 
-static int hc_wgrad_grid(int64_t n_px, int c_in) { return pcacc_grid(n_px, HC_THREADS / (c_in / 4), PCACC_CUS * 3); }
+static int hc_wgrad_grid(int n_img, int h, int wd)
+{
+    const int64_t n_tiles = (int64_t)n_img * ((h + HC_TR - 1) / HC_TR) * ((wd + HC_TC - 1) / HC_TC);
+    return (int)(n_tiles < PCACC_CUS * 3 ? n_tiles : PCACC_CUS * 3);
+}
 
 extern "C" int pcacc_head_conv3x3_wgrad_workspace_bytes(int32_t n_img, int32_t h, int32_t wd, int32_t c_in, int32_t c_out, size_t *bytes)
 {
     if (!bytes || !hc_ok(n_img, h, wd, c_in, c_out)) return PCACC_E_ARG;
-    *bytes = (size_t)hc_wgrad_grid((int64_t)n_img * h * wd, c_in) * (c_out * c_in * 9 + c_out) * sizeof(float);
+    *bytes = (size_t)hc_wgrad_grid(n_img, h, wd) * (c_out * c_in * 9 + c_out) * sizeof(float);
     return PCACC_OK;
 }
 
@@ -266,9 +333,17 @@ extern "C" int pcacc_head_conv3x3_wgrad(const float *dy, const void *x, int32_t 
     if (!dy || !x || !dw || !workspace || pcacc_head_conv3x3_wgrad_workspace_bytes(n_img, h, wd, c_in, c_out, &need) != PCACC_OK) return PCACC_E_ARG;
     if (workspace_bytes < need) return PCACC_E_WORKSPACE;
     hipStream_t st = pcacc_stream(stream);
-    const int grid = hc_wgrad_grid((int64_t)n_img * h * wd, c_in);
+    const int grid = hc_wgrad_grid(n_img, h, wd);
+    const int tiles_y = (h + HC_TR - 1) / HC_TR, tiles_x = (wd + HC_TC - 1) / HC_TC;
     float *partial = static_cast<float *>(workspace);
-#define HC_WG(CIV, COV) hipLaunchKernelGGL((head_conv_wgrad_kernel<CIV, COV>), dim3(grid), dim3(HC_THREADS), 0, st, dy, x, x_dtype, partial, n_img, h, wd, c_out)
+#define HC_WG(CIV, COV)                                                                                                                         \
+    do {                                                                                                                                        \
+        const size_t lds = (size_t)(HC_PH * HC_PW * CIV) * sizeof(float);                                                                       \
+        auto kern = head_conv_wgrad_kernel<CIV, COV>;                                                                                           \
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)     \
+            return PCACC_E_LAUNCH;                                                                                                              \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(HC_THREADS), lds, st, dy, x, x_dtype, partial, n_img, h, wd, c_out, tiles_y, tiles_x);        \
+    } while (0)
     if (c_in == 32 && c_out <= 2) HC_WG(32, 2); else if (c_in == 32) HC_WG(32, 4); else if (c_out <= 2) HC_WG(64, 2); else HC_WG(64, 4);
 #undef HC_WG
     const int n_w = c_out * c_in * 9;
