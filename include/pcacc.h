@@ -545,6 +545,15 @@ int pcacc_bn_rows_backward(const void *grad_y, const void *x, int dtype, int64_t
                            const float *save_mean, const float *save_invstd, void *grad_x, float *grad_gamma, float *grad_beta,
                            void *workspace, size_t workspace_bytes, void *stream);
 
+/* BatchNorm + ReLU in the same passes (SegHead2D, models/unet.py:264-268: conv, BatchNorm2d, ReLU, conv): y = max(bn(x), 0); the backward
+ * takes grad_y only where that output was > 0 -- recomputed from x, the saved statistics, gamma and beta (NULL = 1 / 0), no mask tensor. */
+int pcacc_bn_relu_rows_forward(const void *x, int dtype, int64_t rows, int32_t c, const float *gamma, const float *beta, float eps,
+                               float momentum, float *running_mean, float *running_var, void *y, float *save_mean, float *save_invstd,
+                               void *workspace, size_t workspace_bytes, void *stream);
+int pcacc_bn_relu_rows_backward(const void *grad_y, const void *x, int dtype, int64_t rows, int32_t c, const float *gamma, const float *beta,
+                                const float *save_mean, const float *save_invstd, void *grad_x, float *grad_gamma, float *grad_beta,
+                                void *workspace, size_t workspace_bytes, void *stream);
+
 /* A ResnetBlockFC of the pillar encoder -- models/pillar_encoder.py:13-55 with size_in 64, size_h 32, size_out 32 and the linear
  * shortcut (the blocks of PillarFeatureNet, :76-78) -- fused over bf16 point rows:
  *     h = relu(x) w0^T + b0,   out = relu(h) w1^T + b1 + x ws^T          w0, ws [32,64], w1 [32,32], b0, b1 [32] f32

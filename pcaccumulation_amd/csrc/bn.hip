@@ -39,27 +39,37 @@ __device__ __forceinline__ void bn_store(void *p, int64_t vec_index, const float
 // partial[block][2][c]: sums of a and a*b' per channel over the rows this workgroup visits.
 //   forward  (B == NULL): a = x,  second sum = x^2
 //   backward            : a = dy, second sum = dy * (x - mean) * invstd
+// relu_gamma / relu_beta (backward of BatchNorm + ReLU): dy counts only where the forward output x * scale + shift was > 0
 template <bool BF>
 __global__ __launch_bounds__(256) void bn_sums_kernel(const void *__restrict__ A, const void *__restrict__ B, const float *__restrict__ mean,
-                                                      const float *__restrict__ invstd, int64_t rows, int c, float *__restrict__ partial)
+                                                      const float *__restrict__ invstd, int64_t rows, int c, float *__restrict__ partial,
+                                                      bool relu = false, const float *__restrict__ relu_gamma = nullptr,
+                                                      const float *__restrict__ relu_beta = nullptr)
 {
     constexpr int V = BF ? 8 : 4;
     __shared__ float red[2 * 256 * 8];
     const int lanes = c / V;                                        // lanes per row
     const int rows_per_pass = 256 / lanes;
     const int sub = threadIdx.x % lanes, rsub = threadIdx.x / lanes;
-    float s0[V], s1[V], mu[V], is[V];
+    float s0[V], s1[V], mu[V], is[V], rsc[V], rsh[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) {
         s0[k] = s1[k] = 0.f;
         mu[k] = B ? mean[sub * V + k] : 0.f;
         is[k] = B ? invstd[sub * V + k] : 0.f;
+        const float g = (relu && relu_gamma) ? relu_gamma[sub * V + k] : 1.f;
+        rsc[k] = is[k] * g;                                         // the forward's scale and shift, formed the same way (bn_apply_kernel)
+        rsh[k] = ((relu && relu_beta) ? relu_beta[sub * V + k] : 0.f) - mu[k] * is[k] * g;
     }
     if (rsub < rows_per_pass)
         for (int64_t row = (int64_t)blockIdx.x * rows_per_pass + rsub; row < rows; row += (int64_t)gridDim.x * rows_per_pass) {
             float a[V], b[V];
             bn_load<BF>(A, row * lanes + sub, a);
             if (B) bn_load<BF>(B, row * lanes + sub, b);
+            if (relu) {
+#pragma unroll
+                for (int k = 0; k < V; ++k) a[k] = (b[k] * rsc[k] + rsh[k] > 0.f) ? a[k] : 0.f;
+            }
 #pragma unroll
             for (int k = 0; k < V; ++k) {
                 s0[k] += a[k];
@@ -142,7 +152,7 @@ template <bool BF>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const void *__restrict__ X, const void *__restrict__ DY, const float *__restrict__ mean,
                                                        const float *__restrict__ invstd, const float *__restrict__ gamma,
                                                        const float *__restrict__ beta_or_dbeta, const float *__restrict__ dgamma, int64_t rows,
-                                                       int c, void *__restrict__ out)
+                                                       int c, void *__restrict__ out, bool relu = false, const float *__restrict__ relu_beta = nullptr)
 {
     constexpr int V = BF ? 8 : 4;
     const int lanes = c / V;
@@ -165,11 +175,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const void *__restrict__ 
             kx[k] = -g * is * dgamma[ch] * inv_n;
         }
     }
-    float is_[V], mis[V];
+    float is_[V], mis[V], rsc[V], rsh[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) {
         is_[k] = invstd[sub * V + k];
         mis[k] = mean[sub * V + k] * is_[k];
+        const float g = gamma ? gamma[sub * V + k] : 1.f;
+        rsc[k] = is_[k] * g;                                        // forward scale / shift (the ReLU mask of the backward)
+        rsh[k] = ((relu && relu_beta) ? relu_beta[sub * V + k] : 0.f) - mean[sub * V + k] * is_[k] * g;
     }
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         float x[V], o[V];
@@ -177,9 +190,17 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const void *__restrict__ 
         if (!DY) {
 #pragma unroll
             for (int k = 0; k < V; ++k) o[k] = x[k] * scale[k] + shift[k];
+            if (relu) {
+#pragma unroll
+                for (int k = 0; k < V; ++k) o[k] = fmaxf(o[k], 0.f);
+            }
         } else {
             float g[V];
             bn_load<BF>(DY, e, g);
+            if (relu) {
+#pragma unroll
+                for (int k = 0; k < V; ++k) g[k] = (x[k] * rsc[k] + rsh[k] > 0.f) ? g[k] : 0.f;
+            }
 #pragma unroll
             for (int k = 0; k < V; ++k) o[k] = g[k] * scale[k] + (x[k] * is_[k] - mis[k]) * kx[k] + shift[k];
         }
@@ -210,9 +231,9 @@ extern "C" int pcacc_bn_rows_workspace_bytes(int64_t rows, int32_t c, size_t *by
     return PCACC_OK;
 }
 
-extern "C" int pcacc_bn_rows_forward(const void *x, int dtype, int64_t rows, int32_t c, const float *gamma, const float *beta, float eps,
-                                     float momentum, float *running_mean, float *running_var, void *y, float *save_mean,
-                                     float *save_invstd, void *workspace, size_t workspace_bytes, void *stream)
+static int bn_forward_any(const void *x, int dtype, int64_t rows, int32_t c, const float *gamma, const float *beta, float eps,
+                          float momentum, float *running_mean, float *running_var, void *y, float *save_mean,
+                          float *save_invstd, void *workspace, size_t workspace_bytes, void *stream, bool relu)
 {
     if (bn_args(dtype, rows, c) != PCACC_OK || !x || !y || !save_mean || !save_invstd || !workspace) return PCACC_E_ARG;
     const bool bf = dtype == PCACC_BF16;
@@ -224,15 +245,32 @@ extern "C" int pcacc_bn_rows_forward(const void *x, int dtype, int64_t rows, int
     else bn_sums_kernel<false><<<nb, 256, 0, s>>>(x, nullptr, nullptr, nullptr, rows, c, partial);
     bn_finalize_fwd_kernel<<<c, 256, 0, s>>>(partial, nb, c, rows, eps, momentum, running_mean, running_var, save_mean, save_invstd);
     const int grid = pcacc_grid(rows * (c / (bf ? 8 : 4)), 256, PCACC_CUS * 16);
-    if (bf) bn_apply_kernel<true><<<grid, 256, 0, s>>>(x, nullptr, save_mean, save_invstd, gamma, beta, nullptr, rows, c, y);
-    else bn_apply_kernel<false><<<grid, 256, 0, s>>>(x, nullptr, save_mean, save_invstd, gamma, beta, nullptr, rows, c, y);
+    if (bf) bn_apply_kernel<true><<<grid, 256, 0, s>>>(x, nullptr, save_mean, save_invstd, gamma, beta, nullptr, rows, c, y, relu);
+    else bn_apply_kernel<false><<<grid, 256, 0, s>>>(x, nullptr, save_mean, save_invstd, gamma, beta, nullptr, rows, c, y, relu);
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
 }
 
-extern "C" int pcacc_bn_rows_backward(const void *grad_y, const void *x, int dtype, int64_t rows, int32_t c, const float *gamma,
-                                      const float *save_mean, const float *save_invstd, void *grad_x, float *grad_gamma, float *grad_beta,
-                                      void *workspace, size_t workspace_bytes, void *stream)
+extern "C" int pcacc_bn_rows_forward(const void *x, int dtype, int64_t rows, int32_t c, const float *gamma, const float *beta, float eps,
+                                     float momentum, float *running_mean, float *running_var, void *y, float *save_mean,
+                                     float *save_invstd, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return bn_forward_any(x, dtype, rows, c, gamma, beta, eps, momentum, running_mean, running_var, y, save_mean, save_invstd, workspace,
+                          workspace_bytes, stream, false);
+}
+
+// y = max(BatchNorm(x), 0): the ReLU that follows the normalisation in SegHead2D (models/unet.py:264-268) in the same pass
+extern "C" int pcacc_bn_relu_rows_forward(const void *x, int dtype, int64_t rows, int32_t c, const float *gamma, const float *beta, float eps,
+                                          float momentum, float *running_mean, float *running_var, void *y, float *save_mean,
+                                          float *save_invstd, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return bn_forward_any(x, dtype, rows, c, gamma, beta, eps, momentum, running_mean, running_var, y, save_mean, save_invstd, workspace,
+                          workspace_bytes, stream, true);
+}
+
+static int bn_backward_any(const void *grad_y, const void *x, int dtype, int64_t rows, int32_t c, const float *gamma,
+                           const float *save_mean, const float *save_invstd, void *grad_x, float *grad_gamma, float *grad_beta,
+                           void *workspace, size_t workspace_bytes, void *stream, bool relu, const float *beta)
 {
     if (bn_args(dtype, rows, c) != PCACC_OK || !grad_y || !x || !save_mean || !save_invstd || !grad_x || !grad_gamma || !grad_beta || !workspace)
         return PCACC_E_ARG;
@@ -241,12 +279,29 @@ extern "C" int pcacc_bn_rows_backward(const void *grad_y, const void *x, int dty
     if (workspace_bytes < (size_t)nb * 2 * c * sizeof(float)) return PCACC_E_WORKSPACE;
     hipStream_t s = pcacc_stream(stream);
     float *partial = reinterpret_cast<float *>(workspace);
-    if (bf) bn_sums_kernel<true><<<nb, 256, 0, s>>>(grad_y, x, save_mean, save_invstd, rows, c, partial);
-    else bn_sums_kernel<false><<<nb, 256, 0, s>>>(grad_y, x, save_mean, save_invstd, rows, c, partial);
+    if (bf) bn_sums_kernel<true><<<nb, 256, 0, s>>>(grad_y, x, save_mean, save_invstd, rows, c, partial, relu, gamma, beta);
+    else bn_sums_kernel<false><<<nb, 256, 0, s>>>(grad_y, x, save_mean, save_invstd, rows, c, partial, relu, gamma, beta);
     bn_finalize_bwd_kernel<<<c, 256, 0, s>>>(partial, nb, c, grad_beta, grad_gamma);
     const int grid = pcacc_grid(rows * (c / (bf ? 8 : 4)), 256, PCACC_CUS * 16);
-    if (bf) bn_apply_kernel<true><<<grid, 256, 0, s>>>(x, grad_y, save_mean, save_invstd, gamma, grad_beta, grad_gamma, rows, c, grad_x);
-    else bn_apply_kernel<false><<<grid, 256, 0, s>>>(x, grad_y, save_mean, save_invstd, gamma, grad_beta, grad_gamma, rows, c, grad_x);
+    if (bf) bn_apply_kernel<true><<<grid, 256, 0, s>>>(x, grad_y, save_mean, save_invstd, gamma, grad_beta, grad_gamma, rows, c, grad_x, relu, beta);
+    else bn_apply_kernel<false><<<grid, 256, 0, s>>>(x, grad_y, save_mean, save_invstd, gamma, grad_beta, grad_gamma, rows, c, grad_x, relu, beta);
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
+}
+
+extern "C" int pcacc_bn_rows_backward(const void *grad_y, const void *x, int dtype, int64_t rows, int32_t c, const float *gamma,
+                                      const float *save_mean, const float *save_invstd, void *grad_x, float *grad_gamma, float *grad_beta,
+                                      void *workspace, size_t workspace_bytes, void *stream)
+{
+    return bn_backward_any(grad_y, x, dtype, rows, c, gamma, save_mean, save_invstd, grad_x, grad_gamma, grad_beta, workspace, workspace_bytes, stream,
+                           false, nullptr);
+}
+
+// backward of pcacc_bn_relu_rows_forward: grad_y counts where the forward output was > 0 (recomputed from x, the saved statistics, gamma, beta)
+extern "C" int pcacc_bn_relu_rows_backward(const void *grad_y, const void *x, int dtype, int64_t rows, int32_t c, const float *gamma,
+                                           const float *beta, const float *save_mean, const float *save_invstd, void *grad_x, float *grad_gamma,
+                                           float *grad_beta, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return bn_backward_any(grad_y, x, dtype, rows, c, gamma, save_mean, save_invstd, grad_x, grad_gamma, grad_beta, workspace, workspace_bytes, stream,
+                           true, beta);
 }

@@ -60,7 +60,7 @@ EXPORTS = [
     'pcacc_tube_rows', 'pcacc_tube_code', 'pcacc_tube_code_backward', 'pcacc_tube_pose_forward', 'pcacc_tube_gap_forward', 'pcacc_tube_finish',
     'pcacc_tube_gap_backward', 'pcacc_tube_pose_backward', 'pcacc_rows_wgrad_few_supported', 'pcacc_rows_wgrad_few_workspace_bytes', 'pcacc_rows_wgrad_few',
     'pcacc_maxpool2x2_bf16', 'pcacc_pool_skip_relu_backward_bf16',
-    'pcacc_pfn_block_forward', 'pcacc_pfn_block_backward_workspace_bytes', 'pcacc_pfn_block_backward', 'pcacc_pfn_block_split_forward', 'pcacc_pfn_block_split_dgrad', 'pcacc_inv4x4',
+    'pcacc_pfn_block_forward', 'pcacc_pfn_block_backward_workspace_bytes', 'pcacc_pfn_block_backward', 'pcacc_bn_relu_rows_forward', 'pcacc_bn_relu_rows_backward', 'pcacc_pfn_block_split_forward', 'pcacc_pfn_block_split_dgrad', 'pcacc_inv4x4',
     'pcacc_conv3x3_split_prepare_weights', 'pcacc_conv3x3_split_supported', 'pcacc_conv3x3_split', 'pcacc_conv3x3_wgrad_split_workspace_bytes',
     'pcacc_conv3x3_wgrad_split', 'pcacc_absmax256',
     'pcacc_rows_linear_split', 'pcacc_rows_linear_cat_split', 'pcacc_rows_wgrad_split_workspace_bytes', 'pcacc_rows_wgrad_split',
@@ -1122,23 +1122,24 @@ def _bn_ws(rows, c, dev):
     return _ws(need.value, dev)
 
 
-def bn_rows_forward(x, gamma, beta, eps, momentum, running_mean, running_var):
+def bn_rows_forward(x, gamma, beta, eps, momentum, running_mean, running_var, relu=False):
     """Training-mode BatchNorm1d over the rows of x [rows,c] (include/pcacc.h): -> (y like x, save_mean [c], save_invstd [c]);
-    running_mean / running_var (f32, or None) are updated in place."""
+    running_mean / running_var (f32, or None) are updated in place.  relu: y = max(bn(x), 0) in the same pass."""
     rows, c = x.shape
     y = torch.empty_like(x)
     mean = torch.empty((c,), dtype=torch.float32, device=x.device)
     invstd = torch.empty((c,), dtype=torch.float32, device=x.device)
     ws = _bn_ws(rows, c, x.device)
-    _check(lib().pcacc_bn_rows_forward(_dev(x, None, 'x'), _dtype_code(x), _i64(rows), int(c), _opt(gamma, torch.float32, 'gamma'),
+    fn = lib().pcacc_bn_relu_rows_forward if relu else lib().pcacc_bn_rows_forward
+    _check(fn(_dev(x, None, 'x'), _dtype_code(x), _i64(rows), int(c), _opt(gamma, torch.float32, 'gamma'),
                                        _opt(beta, torch.float32, 'beta'), ctypes.c_float(eps), ctypes.c_float(momentum),
                                        _opt(running_mean, torch.float32, 'running_mean'), _opt(running_var, torch.float32, 'running_var'),
                                        _dev(y), _dev(mean), _dev(invstd), _dev(ws), ctypes.c_size_t(ws.numel()), _stream()), 'bn_rows_forward')
     return y, mean, invstd
 
 
-def bn_rows_backward(grad_y, x, gamma, save_mean, save_invstd):
-    """-> (grad_x like x, grad_gamma [c] f32, grad_beta [c] f32)."""
+def bn_rows_backward(grad_y, x, gamma, save_mean, save_invstd, relu_beta=None, relu=False):
+    """-> (grad_x like x, grad_gamma [c] f32, grad_beta [c] f32).  relu: the backward of bn_rows_forward(relu=True) (relu_beta = its beta)."""
     rows, c = x.shape
     gx = torch.empty_like(x)
     gg = torch.empty((c,), dtype=torch.float32, device=x.device)
@@ -1146,6 +1147,12 @@ def bn_rows_backward(grad_y, x, gamma, save_mean, save_invstd):
     ws = _bn_ws(rows, c, x.device)
     if grad_y.dtype != x.dtype:
         raise NativeError('bn_rows_backward: grad_y must have the type of x')
+    if relu:
+        _check(lib().pcacc_bn_relu_rows_backward(_dev(grad_y, None, 'grad_y'), _dev(x, None, 'x'), _dtype_code(x), _i64(rows), int(c),
+                                                 _opt(gamma, torch.float32, 'gamma'), _opt(relu_beta, torch.float32, 'beta'),
+                                                 _dev(save_mean, torch.float32), _dev(save_invstd, torch.float32), _dev(gx), _dev(gg), _dev(gb),
+                                                 _dev(ws), ctypes.c_size_t(ws.numel()), _stream()), 'bn_relu_rows_backward')
+        return gx, gg, gb
     _check(lib().pcacc_bn_rows_backward(_dev(grad_y, None, 'grad_y'), _dev(x, None, 'x'), _dtype_code(x), _i64(rows), int(c),
                                         _opt(gamma, torch.float32, 'gamma'), _dev(save_mean, torch.float32), _dev(save_invstd, torch.float32),
                                         _dev(gx), _dev(gg), _dev(gb), _dev(ws), ctypes.c_size_t(ws.numel()), _stream()), 'bn_rows_backward')

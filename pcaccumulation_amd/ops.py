@@ -1234,17 +1234,18 @@ class _BatchNormRows(torch.autograd.Function):
     """Training-mode nn.BatchNorm1d on [rows, c] rows (models/unet.py:240-245) in four streaming passes (csrc/bn.hip)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, momentum, running_mean, running_var):
+    def forward(ctx, x, gamma, beta, eps, momentum, running_mean, running_var, relu=False):
         x = x.contiguous()
-        y, mean, invstd = native.bn_rows_forward(x, gamma, beta, eps, momentum, running_mean, running_var)
-        ctx.save_for_backward(x, gamma, mean, invstd)
+        y, mean, invstd = native.bn_rows_forward(x, gamma, beta, eps, momentum, running_mean, running_var, relu=relu)
+        ctx.save_for_backward(x, gamma, mean, invstd, beta if relu else None)
+        ctx.relu = relu
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, gamma, mean, invstd = ctx.saved_tensors
-        gx, gg, gb = native.bn_rows_backward(gy.contiguous().to(x.dtype), x, gamma, mean, invstd)
-        return gx, (gg if gamma is not None else None), (gb if gamma is not None else None), None, None, None, None
+        x, gamma, mean, invstd, beta = ctx.saved_tensors
+        gx, gg, gb = native.bn_rows_backward(gy.contiguous().to(x.dtype), x, gamma, mean, invstd, relu_beta=beta, relu=ctx.relu)
+        return gx, (gg if gamma is not None else None), (gb if gamma is not None else None), None, None, None, None, None
 
 
 def batch_norm_rows(x, bn):
@@ -1260,22 +1261,22 @@ def batch_norm_rows(x, bn):
     return _BatchNormRows.apply(x, bn.weight, bn.bias, float(bn.eps), float(bn.momentum), rm, rv)
 
 
-def batch_norm_nchw(x, bn):
-    """`bn(x)` for an nn.BatchNorm2d on a channels-last NCHW tensor (models/unet.py:259-277, the two SegHead2D): training mode on the GPU
+def batch_norm_nchw(x, bn, relu=False):
+    """`bn(x)` (relu: `relu(bn(x))`, one pass each way) for an nn.BatchNorm2d on a channels-last NCHW tensor (models/unet.py:259-277, the two SegHead2D): training mode on the GPU
     runs the streaming passes of csrc/bn.hip on the [N*H*W, C] rows the memory already is (f32 or bf16 rows, statistics in fp32 /
     float64 as the module's); everything else is the module (library)."""
     if not (bn.training and x.is_cuda and x.dim() == 4 and bn.momentum is not None and x.dtype in (torch.float32, torch.bfloat16)
             and (bn.weight is None or bn.weight.dtype == torch.float32)):
-        return bn(x)
+        return torch.relu(bn(x)) if relu else bn(x)
     rows = x.permute(0, 2, 3, 1)
     if not rows.is_contiguous():
-        return bn(x)
+        return torch.relu(bn(x)) if relu else bn(x)
     n, h, w, c = rows.shape
     rows = rows.reshape(n * h * w, c)
     if not native.bn_rows_supported(rows) or rows.shape[0] < MIN_ROWS_FUSED_LINEAR:
-        return bn(x)
+        return torch.relu(bn(x)) if relu else bn(x)
     if bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
-    y = _BatchNormRows.apply(rows, bn.weight, bn.bias, float(bn.eps), float(bn.momentum), rm, rv)
+    y = _BatchNormRows.apply(rows, bn.weight, bn.bias, float(bn.eps), float(bn.momentum), rm, rv, relu)
     return y.view(n, h, w, c).permute(0, 3, 1, 2)

@@ -123,4 +123,6 @@ class SegHead2D(nn.Module):
 
     def forward(self, feats):
         conv0, bn, act, conv1 = self.seg_head
-        return ops.conv3x3(act(ops.batch_norm_nchw(ops.conv3x3(feats, conv0), bn)), conv1)          # library for c_out = 2, MFMA kernel for 64 -> 64
+        fused = isinstance(act, nn.ReLU)                       # normalisation and ReLU in one pass each way (csrc/bn.hip)
+        h = ops.batch_norm_nchw(ops.conv3x3(feats, conv0), bn, relu=fused)
+        return ops.conv3x3(h if fused else act(h), conv1)      # c_out = 2: the streamed head kernels (csrc/head_conv.hip)

@@ -942,7 +942,8 @@ def test_batch_norm_rows_is_batchnorm1d(native, dev, dtype, c):
 
 
 @pytest.mark.parametrize('dtype,c', [(torch.float32, 32), (torch.float32, 64), (torch.bfloat16, 32), (torch.bfloat16, 64)])
-def test_batch_norm_nchw_is_batchnorm2d(native, dev, dtype, c):
+@pytest.mark.parametrize('relu', [False, True])
+def test_batch_norm_nchw_is_batchnorm2d(native, dev, dtype, c, relu):
     """models/unet.py:259-277 (SegHead2D): training-mode BatchNorm2d on a channels-last map through the row passes of csrc/bn.hip --
     output, input / affine gradients and running statistics against nn.BatchNorm2d on float32 values of the same map."""
     from pcaccumulation_amd import ops
@@ -959,15 +960,17 @@ def test_batch_norm_nchw_is_batchnorm2d(native, dev, dtype, c):
     native.bn_rows_forward = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
     try:
         xm = x.clone().requires_grad_(True)
-        ym = ops.batch_norm_nchw(xm, mine)
+        ym = ops.batch_norm_nchw(xm, mine, relu=relu)              # relu: BatchNorm + ReLU in one pass each way (pcacc_bn_relu_rows_*)
         ym.backward(g)
     finally:
         native.bn_rows_forward = orig
     assert calls and ym.shape == x.shape and ym.dtype == dtype
     xr = x.float().clone().requires_grad_(True)
-    yr = ref(xr)
+    yr = torch.relu(ref(xr)) if relu else ref(xr)
     yr.backward(g.float())
     tol = 1e-4 if dtype == torch.float32 else 2e-2
+    if relu:
+        assert float(ym.min()) >= 0.0 and 0.2 < float((ym > 0).float().mean()) < 0.8
     assert (ym.float() - yr).abs().max() <= tol * yr.abs().max()
     assert (xm.grad.float() - xr.grad).abs().max() <= tol * xr.grad.abs().max()
     assert (mine.weight.grad - ref.weight.grad).abs().max() <= 2e-3 * ref.weight.grad.abs().max()
