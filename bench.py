@@ -205,10 +205,12 @@ def step_model(stepper, batcher, feed):
                 dy = a[0]
                 kk = (a[2].shape[1] + a[4].shape[1]) if name.endswith('split') else (a[1].shape[1] + a[2].shape[1])
                 return 2.0 * dy.shape[0] * dy.shape[1] * kk
-            if name == 'pfn_block_forward':
+            if name in ('pfn_block_forward', 'pfn_block_split_forward'):
                 return 2.0 * a[0].shape[0] * (64 * 32 * 2 + 32 * 32)
             if name == 'pfn_block_backward':
                 return 2.0 * a[0].shape[0] * (64 * 32 * 2 + 32 * 32) * 2
+            if name == 'pfn_block_split_dgrad':                      # the data gradients; its three weight gradients are rows_wgrad*_split calls
+                return 2.0 * a[0].shape[0] * (64 * 32 * 2 + 32 * 32)
             if name in ('chamfer_forward',):
                 return 8.0 * a[0].shape[0] * a[1].shape[0] * 2
         except Exception:
@@ -371,7 +373,7 @@ def main():
         torch.cuda.synchronize()
         dt32 = time.perf_counter() - t1
         fp32_leg = {'dtype': 'fp32x3', 'value': args.batch * T_FRAMES * k32 / dt32, 'unit': 'LiDAR-frames/s', 'ms_per_step': dt32 / k32 * 1e3,
-                    'steps': k32, 'warmup': args.warmup, 'note': 'same step in the fp32x3 mode (fp32 tensors, split-bf16 products on the matrix cores, hand-written '
+                    'steps': k32, 'warmup': args.warmup, 'note': 'same step in the fp32x3 mode (fp32 tensors, products from scaled fp16 hi/lo halves on the matrix cores, hand-written '
                                           'kernels): mos_iou / ego errors / EPE match the reference within 1e-3 on c2-c5 + nus11 '
                                           '(tests/test_config_parity.py::test_gpu_config_fp32[fp32x3-*]); bf16 bound: DESIGN.md section 4'}
         del st32, m32, o32
