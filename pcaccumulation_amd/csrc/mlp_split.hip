@@ -237,6 +237,183 @@ __global__ __launch_bounds__(MS_THREADS) void rows_linear_split_kernel(const flo
     }
 }
 
+// The wide layers (K x N = 128 x 128, 128 x 64, 64 x 128): in the kernel above their weight planes alone take 35 - 70 KB of LDS next to the
+// 70 KB of staged rows -- one workgroup per CU, whose load / split / MFMA / store phases then run in series (2.0 TB/s on the 128 x 128
+// layers of the STPN heads).  Here a WAVE owns a 32-feature tile (and, for N = 64, half of the rows): its weight fragments -- K/16 x (hi, lo)
+// -- are split once from global memory into registers and stay there, the LDS holds only the rows, and two workgroups share a CU out of phase.
+template <int K, int CT>
+__global__ __launch_bounds__(MS_THREADS, 2) void rows_linear_split_fm_kernel(const float *__restrict__ X, const float *__restrict__ x_amax,
+                                                                             const float *__restrict__ x_amax2, const float *__restrict__ in_mask,
+                                                                             const float *__restrict__ W, const float *__restrict__ bias,
+                                                                             const float *__restrict__ residual, const float *__restrict__ out_mask,
+                                                                             float *__restrict__ Y, int64_t rows, int flags, MsPieces xs2, MsPieces ms2,
+                                                                             float *__restrict__ Y2, int na, float *__restrict__ y_amax)
+{
+    constexpr int N = CT * 32, KC = K / 16;
+    constexpr int RG = 4 / CT, RT = 4 / RG;                    // row groups among the 4 waves, 32-row tiles per wave
+    constexpr int XS = K + 8, YS = N + 4;
+    constexpr int XPLANE = MS_TILE * XS;
+    constexpr int REGION_B = (2 * XPLANE * 2 > MS_TILE * YS * 4) ? 2 * XPLANE * 2 : MS_TILE * YS * 4;
+    constexpr int X_PER_THREAD = MS_TILE * K / 8 / MS_THREADS, Y_PER_THREAD = MS_TILE * N / 4 / MS_THREADS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    uint16_t *xs = reinterpret_cast<uint16_t *>(lds_raw);                    // [2][MS_TILE][XS]
+    float *ys = reinterpret_cast<float *>(lds_raw);                          // [MS_TILE][YS]  (after the MFMAs)
+    float *bias_l = reinterpret_cast<float *>(lds_raw + REGION_B);           // [N]
+    float *invt = bias_l + N;                                                // [N]  1 / (row scale of W)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lp = lane & 31, lh = lane >> 5;
+    const int ct = wave % CT, rg = wave / CT;
+
+    // this wave's weight rows n = ct * 32 + lp: row maximum -> power-of-two scale -> hi / lo fragments in registers
+    ms_f16x8 wh[KC], wl[KC];
+    {
+        const float *wrow = W + (int64_t)(ct * 32 + lp) * K + lh * 8;
+        float m = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {                      // two passes over the (cached) row instead of 2 KC live float4s
+            const float4 a = *reinterpret_cast<const float4 *>(wrow + kc * 16), b = *reinterpret_cast<const float4 *>(wrow + kc * 16 + 4);
+            m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))),
+                               fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w)))));
+            if (!(a.x == a.x && a.y == a.y && a.z == a.z && a.w == a.w && b.x == b.x && b.y == b.y && b.z == b.z && b.w == b.w)) m = __builtin_inff();
+        }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));                   // the row's other k-half
+        const float t = ms_scale_of(m);
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            uint4 hi, lo;
+            ms_split8(*reinterpret_cast<const float4 *>(wrow + kc * 16), *reinterpret_cast<const float4 *>(wrow + kc * 16 + 4), t, hi, lo);
+            wh[kc] = *reinterpret_cast<const ms_f16x8 *>(&hi);
+            wl[kc] = *reinterpret_cast<const ms_f16x8 *>(&lo);
+        }
+        if (rg == 0 && lh == 0) {
+            invt[ct * 32 + lp] = 1.f / t;
+            bias_l[ct * 32 + lp] = bias ? bias[ct * 32 + lp] : 0.f;
+        }
+    }
+    const float sx = ms_scale_of(ms_amax(x_amax, x_amax2));
+    const float inv_sx = 1.f / sx;
+
+    const int64_t n_tiles = (rows + MS_TILE - 1) / MS_TILE;
+    float4 xreg[X_PER_THREAD][2];
+    auto fetch = [&](int64_t tile) {
+        const int64_t base = tile * MS_TILE * K;
+        const int64_t limit = rows * K;
+#pragma unroll
+        for (int q = 0; q < X_PER_THREAD; ++q) {
+            const int64_t e = base + (int64_t)(threadIdx.x + q * MS_THREADS) * 8;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+            if (e < limit) {
+                const float *src = ms_piece(X, xs2, K, e / K, (int)(e % K));
+                a = *reinterpret_cast<const float4 *>(src);
+                b = *reinterpret_cast<const float4 *>(src + 4);
+                if (flags & MS_PRE_RELU) { a = ms_relu4(a); b = ms_relu4(b); }
+                if (in_mask) {
+                    a = ms_mask4(a, *reinterpret_cast<const float4 *>(in_mask + e));
+                    b = ms_mask4(b, *reinterpret_cast<const float4 *>(in_mask + e + 4));
+                }
+            }
+            xreg[q][0] = a;
+            xreg[q][1] = b;
+        }
+    };
+
+    float omax = 0.f;
+    int64_t tile = blockIdx.x;
+    if (tile < n_tiles) fetch(tile);
+    for (; tile < n_tiles; tile += gridDim.x) {
+        __syncthreads();                                                      // the previous tile's output left the region (first pass: invt / bias written)
+#pragma unroll
+        for (int q = 0; q < X_PER_THREAD; ++q) {
+            const int c = threadIdx.x + q * MS_THREADS;
+            uint4 hi, lo;
+            ms_split8(xreg[q][0], xreg[q][1], sx, hi, lo);
+            uint16_t *dst = xs + (c / (K / 8)) * XS + (c % (K / 8)) * 8;
+            *reinterpret_cast<uint4 *>(dst) = hi;
+            *reinterpret_cast<uint4 *>(dst + XPLANE) = lo;
+        }
+        __syncthreads();
+        if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);              // in flight during the MFMAs and the store phase
+
+        ms_f32x16 acc[RT];
+#pragma unroll
+        for (int j = 0; j < RT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        const uint16_t *xrow = xs + (rg * RT * 32 + lp) * XS + lh * 8;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+            for (int j = 0; j < RT; ++j) {
+                const ms_f16x8 bh = *reinterpret_cast<const ms_f16x8 *>(xrow + j * 32 * XS + kc * 16);
+                const ms_f16x8 bl = *reinterpret_cast<const ms_f16x8 *>(xrow + XPLANE + j * 32 * XS + kc * 16);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[kc], bl, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[kc], bh, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[kc], bh, acc[j], 0, 0, 0);
+            }
+        __syncthreads();                                                      // every wave is done reading the input planes
+#pragma unroll
+        for (int j = 0; j < RT; ++j) {
+            float *yrow = ys + ((rg * RT + j) * 32 + lp) * YS + ct * 32;      // lane = row; quads of 4 consecutive features
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = 8 * g + 4 * lh;
+                const float4 bv = *reinterpret_cast<const float4 *>(bias_l + ct * 32 + c);
+                const float4 sc = *reinterpret_cast<const float4 *>(invt + ct * 32 + c);
+                *reinterpret_cast<float4 *>(yrow + c) = make_float4(acc[j][4 * g] * (sc.x * inv_sx) + bv.x, acc[j][4 * g + 1] * (sc.y * inv_sx) + bv.y,
+                                                                    acc[j][4 * g + 2] * (sc.z * inv_sx) + bv.z, acc[j][4 * g + 3] * (sc.w * inv_sx) + bv.w);
+            }
+        }
+        __syncthreads();
+        const int64_t ybase = tile * MS_TILE * N, ylimit = rows * N;
+#pragma unroll
+        for (int q = 0; q < Y_PER_THREAD; ++q) {
+            const int c = threadIdx.x + q * MS_THREADS;
+            const int64_t e = ybase + (int64_t)c * 4;
+            if (e >= ylimit) continue;
+            float4 v = *reinterpret_cast<const float4 *>(ys + (c / (N / 4)) * YS + (c % (N / 4)) * 4);
+            if (residual) {
+                const float4 r = *reinterpret_cast<const float4 *>(residual + e);
+                v = make_float4(v.x + r.x, v.y + r.y, v.z + r.z, v.w + r.w);
+            }
+            if (flags & MS_POST_RELU) v = ms_relu4(v);
+            const int64_t row = e / N;
+            const int col = (int)(e % N);
+            if (out_mask) v = ms_mask4(v, *reinterpret_cast<const float4 *>(ms_piece(out_mask, ms2, N, row, col)));
+            omax = fmaxf(fmaxf(omax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+            if (!(v.x == v.x && v.y == v.y && v.z == v.z && v.w == v.w)) omax = __builtin_inff();
+            if (!Y2) *reinterpret_cast<float4 *>(Y + e) = v;
+            else if (col < na) *reinterpret_cast<float4 *>(Y + row * na + col) = v;
+            else *reinterpret_cast<float4 *>(Y2 + row * (N - na) + (col - na)) = v;
+        }
+    }
+    if (y_amax) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) omax = fmaxf(omax, __shfl_xor(omax, d, 64));
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned *>(y_amax) + (blockIdx.x & 255), __float_as_uint(omax));
+    }
+}
+
+template <int K, int CT>
+static int ms_launch_fm(const float *x, const float *x_amax, const float *x_amax2, const float *in_mask, const float *w, const float *bias,
+                        const float *residual, const float *out_mask, float *y, int64_t rows, int flags, hipStream_t st, MsPieces xs2, MsPieces ms2,
+                        float *y2, int na, float *y_amax)
+{
+    constexpr int N = CT * 32, XS = K + 8, YS = N + 4;
+    constexpr size_t region = (size_t)(2 * MS_TILE * XS * 2 > MS_TILE * YS * 4 ? 2 * MS_TILE * XS * 2 : MS_TILE * YS * 4);
+    const size_t lds = region + (size_t)2 * N * 4;
+    auto kern = rows_linear_split_fm_kernel<K, CT>;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return PCACC_E_LAUNCH;
+    const int64_t n_tiles = (rows + MS_TILE - 1) / MS_TILE;
+    int64_t grid = (int64_t)PCACC_CUS * 2;
+    if (grid > n_tiles) grid = n_tiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(MS_THREADS), lds, st, x, x_amax, x_amax2, in_mask, w, bias, residual, out_mask, y, rows, flags,
+                       xs2, ms2, y2, na, y_amax);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}
+
 template <int K, int CT>
 static size_t ms_linear_lds()
 {
@@ -272,6 +449,10 @@ static int ms_dispatch(const float *x, const float *x_amax, const float *x_amax2
 {
 #define MS_CASE(KK, CTV) \
     if (k == KK && n == CTV * 32) return ms_launch<KK, CTV>(x, x_amax, x_amax2, in_mask, w, bias, residual, out_mask, y, rows, flags, st, xs2, ms2, y2, na, y_amax)
+#define MS_CASE_FM(KK, CTV) \
+    if (k == KK && n == CTV * 32 && !getenv("PCACC_ROWS_FM_OFF")) return ms_launch_fm<KK, CTV>(x, x_amax, x_amax2, in_mask, w, bias, residual, out_mask, y, rows, flags, st, xs2, ms2, y2, na, y_amax)
+    MS_CASE_FM(128, 4); MS_CASE_FM(128, 2); MS_CASE_FM(64, 4);              // weights in registers, two workgroups per CU
+#undef MS_CASE_FM
     MS_CASE(32, 1); MS_CASE(32, 2); MS_CASE(32, 4);
     MS_CASE(64, 1); MS_CASE(64, 2); MS_CASE(64, 4);
     MS_CASE(128, 1); MS_CASE(128, 2); MS_CASE(128, 4);
