@@ -170,17 +170,23 @@ def _check_bf16(name, golden):
             del model, inp, out, stats
     mean = lambda dt, k: float(np.mean([d[k] for d in draws[dt]]))
     res = {k: (mean('bf16', k), mean('fp32x3', k)) for k in draws['bf16'][0]}
-    _dump(name, 'bf16-vs-fp32x3 seed means', {k: v[0] for k, v in res.items()}, {k: v[1] for k, v in res.items()}, dict(fb_flips=first[0]))
-    # the two means must agree within 4 standard errors of their difference (the spread over key-point draws is measured in the same
-    # runs: rotation error 3.1 +- 0.9 deg on c3) or within a small absolute floor, and never differ by more than BF16_TOL (no blow-up)
+    ses = {k: float(np.sqrt(sum(np.var([d[k] for d in draws[dt]], ddof=1) / N_DRAWS for dt in draws))) for k in res}
+    _dump(name, 'bf16-vs-fp32x3 seed means', {k: v[0] for k, v in res.items()}, {k: v[1] for k, v in res.items()}, dict(fb_flips=first[0], se=ses))
+    # the two means must agree within Z standard errors of their difference (the spread over key-point draws is measured in the same
+    # runs: rotation error 3.1 +- 0.9 deg on c3) or within a small absolute floor, and never differ by more than 2 x BF16_TOL (no
+    # blow-up).  Z = 6: the standard error is itself estimated from 2 x 6 draws (about 10 degrees of freedom), so the ratio follows a
+    # Student t, not a normal -- at Z = 4 a suite run (6 configs x 4-5 statistics, two of the configs not run-to-run deterministic:
+    # atomics on crowded pillars) failed about once in five (observed ratios up to 3.1 in 18 config runs; a fixed 5 % bound on the loss
+    # failed once at 5.3 % with a standard error of 2.7 %); P(|t_10| > 6) = 1.3e-4 per statistic.
+    Z = 6.0
     floors = dict(ego_rot_error=0.1, ego_trans_error=0.1, mos_iou=1e-2, epe_mean=0.1)
     caps = dict(ego_rot_error=BF16_TOL['ego'], ego_trans_error=BF16_TOL['ego'], mos_iou=BF16_TOL['iou'], epe_mean=BF16_TOL['epe'])
     for k in floors:
-        se = float(np.sqrt(sum(np.var([d[k] for d in draws[dt]], ddof=1) / N_DRAWS for dt in draws)))
         diff = abs(res[k][0] - res[k][1])
-        assert diff < max(floors[k], 4.0 * se) and diff < 2 * caps[k], (k, res[k], se, draws)
+        assert diff < max(floors[k], Z * ses[k]) and diff < 2 * caps[k], (k, res[k], ses[k], draws)
     if train:
-        assert abs(res['loss'][0] - res['loss'][1]) < 5e-2 * abs(res['loss'][1]), (res['loss'], draws)
+        assert abs(res['loss'][0] - res['loss'][1]) < max(5e-2 * abs(res['loss'][1]), Z * ses['loss']), (res['loss'], ses['loss'], draws)
+        assert abs(res['loss'][0] - res['loss'][1]) < 0.25 * abs(res['loss'][1]), (res['loss'], draws)             # no blow-up
     return first
 
 
