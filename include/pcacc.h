@@ -593,6 +593,11 @@ int pcacc_pfn_block_split_dgrad(const float *grad_out, const float *grad_out_ama
 int pcacc_maxpool2x2_bf16(const uint16_t *x, int64_t n_img, int32_t h, int32_t w, int32_t c, uint16_t *out, void *stream);
 int pcacc_pool_skip_relu_backward_bf16(const uint16_t *y, const uint16_t *grad_pooled, const uint16_t *grad_skip, int64_t n_img, int32_t h,
                                        int32_t w, int32_t c, uint16_t *grad_y, void *stream);
+/* The same two passes on fp32 rows (c % 4 == 0; compute mode fp32x3).  out_amax: 256 zeroed f32 slots receiving the largest magnitude of
+ * grad_y (pcacc_absmax256 layout) for the split kernels that read it, or NULL. */
+int pcacc_maxpool2x2_f32(const float *x, int64_t n_img, int32_t h, int32_t w, int32_t c, float *out, void *stream);
+int pcacc_pool_skip_relu_backward_f32(const float *y, const float *grad_pooled, const float *grad_skip, int64_t n_img, int32_t h, int32_t w,
+                                      int32_t c, float *grad_y, float *out_amax, void *stream);
 
 /* Batched inverse of n 4x4 f32 matrices (the pose tables: torch.linalg.inv at models/motionnet.py:100 and models/alignnet.py:33),
  * Gauss-Jordan with partial pivoting, one launch; a singular matrix yields inf / nan entries (no status word). */

@@ -141,3 +141,121 @@ extern "C" int pcacc_pool_skip_relu_backward_bf16(const uint16_t *y, const uint1
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
 }
+
+// ---- the same two passes on fp32 rows (compute modes fp32x3 / fp32): 4 channels per lane -------------------------------------------------
+__device__ __forceinline__ float pool_fmax(float a, float b) { return (b > a || b != b) ? b : a; }
+
+__global__ __launch_bounds__(256) void maxpool2x2_f32_kernel(const float4 *__restrict__ x, int64_t n_img, int h, int w, int c4, float4 *__restrict__ out)
+{
+    const int h2 = h / 2, w2 = w / 2;
+    const int64_t total = n_img * h2 * w2 * c4;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e % c4);
+        int64_t q = e / c4;
+        const int xo = (int)(q % w2); q /= w2;
+        const int yo = (int)(q % h2);
+        const int64_t img = q / h2;
+        const int64_t base = ((img * h + 2 * yo) * w + 2 * xo) * c4 + c;
+        const float4 a = x[base], b = x[base + c4], d = x[base + (int64_t)w * c4], f = x[base + (int64_t)w * c4 + c4];
+        out[e] = make_float4(pool_fmax(pool_fmax(pool_fmax(a.x, b.x), d.x), f.x), pool_fmax(pool_fmax(pool_fmax(a.y, b.y), d.y), f.y),
+                             pool_fmax(pool_fmax(pool_fmax(a.z, b.z), d.z), f.z), pool_fmax(pool_fmax(pool_fmax(a.w, b.w), d.w), f.w));
+    }
+}
+
+__device__ __forceinline__ void pool_bwd1(const float (&y)[4], const float (&gs)[4], float gp, float (&o)[4])
+{
+    float best = y[0];
+    int arg = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (y[i] > best || y[i] != y[i]) { best = y[i]; arg = i; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = (y[i] > 0.f) ? gs[i] + (arg == i ? gp : 0.f) : 0.f;
+}
+
+// out_amax (256 zeroed slots, pcacc_absmax256 layout, or NULL): the largest magnitude written -- the scale of the split kernels that read grad_y
+template <bool HAS_POOL, bool HAS_SKIP>
+__global__ __launch_bounds__(256) void pool_skip_relu_bwd_f32_kernel(const float4 *__restrict__ y, const float4 *__restrict__ g_pool,
+                                                                     const float4 *__restrict__ g_skip, int64_t n_img, int h, int w, int c4,
+                                                                     float4 *__restrict__ out, float *__restrict__ out_amax)
+{
+    const int h2 = (h + 1) / 2, w2 = (w + 1) / 2, hp = h / 2, wp = w / 2;
+    const int64_t total = n_img * h2 * w2 * c4;
+    float mx = 0.f;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e % c4);
+        int64_t q = e / c4;
+        const int xo = (int)(q % w2); q /= w2;
+        const int yo = (int)(q % h2);
+        const int64_t img = q / h2;
+        const bool in_x = 2 * xo + 1 < w, in_y = 2 * yo + 1 < h;
+        const int64_t base = ((img * h + 2 * yo) * w + 2 * xo) * c4 + c;
+        const int64_t off[4] = {0, c4, (int64_t)w * c4, (int64_t)w * c4 + c4};
+        const bool ok[4] = {true, in_x, in_y, in_x && in_y};
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 yv[4], gs[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            yv[i] = ok[i] ? y[base + off[i]] : zero;
+            gs[i] = (HAS_SKIP && ok[i]) ? g_skip[base + off[i]] : zero;
+        }
+        float4 gp = zero;
+        if (HAS_POOL && in_x && in_y && yo < hp && xo < wp) gp = g_pool[((img * hp + yo) * wp + xo) * c4 + c];
+        float4 o[4];
+        {
+            float a[4], b[4], r[4];
+#define POOL_LANE(F)                                                                                                   \
+            a[0] = yv[0].F; a[1] = yv[1].F; a[2] = yv[2].F; a[3] = yv[3].F;                                            \
+            b[0] = gs[0].F; b[1] = gs[1].F; b[2] = gs[2].F; b[3] = gs[3].F;                                            \
+            pool_bwd1(a, b, gp.F, r);                                                                                  \
+            o[0].F = r[0]; o[1].F = r[1]; o[2].F = r[2]; o[3].F = r[3];
+            POOL_LANE(x) POOL_LANE(y) POOL_LANE(z) POOL_LANE(w)
+#undef POOL_LANE
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (ok[i]) {
+                out[base + off[i]] = o[i];
+                mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o[i].x), fabsf(o[i].y))), fmaxf(fabsf(o[i].z), fabsf(o[i].w)));
+                if (!(o[i].x == o[i].x && o[i].y == o[i].y && o[i].z == o[i].z && o[i].w == o[i].w)) mx = __builtin_inff();
+            }
+    }
+    if (out_amax) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+        if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned *>(out_amax) + (blockIdx.x & 255), __float_as_uint(mx));
+    }
+}
+
+extern "C" int pcacc_maxpool2x2_f32(const float *x, int64_t n_img, int32_t h, int32_t w, int32_t c, float *out, void *stream)
+{
+    if (n_img < 0 || h < 2 || w < 2 || c <= 0 || (c % 4)) return PCACC_E_ARG;
+    if (n_img == 0) return PCACC_OK;
+    if (!x || !out) return PCACC_E_ARG;
+    const int64_t total = n_img * (h / 2) * (w / 2) * (c / 4);
+    maxpool2x2_f32_kernel<<<pcacc_grid(total, 256, PCACC_CUS * 16), 256, 0, pcacc_stream(stream)>>>(
+        reinterpret_cast<const float4 *>(x), n_img, h, w, c / 4, reinterpret_cast<float4 *>(out));
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}
+
+extern "C" int pcacc_pool_skip_relu_backward_f32(const float *y, const float *grad_pooled, const float *grad_skip, int64_t n_img, int32_t h,
+                                                 int32_t w, int32_t c, float *grad_y, float *out_amax, void *stream)
+{
+    if (n_img < 0 || h < 2 || w < 2 || c <= 0 || (c % 4)) return PCACC_E_ARG;
+    if (n_img == 0) return PCACC_OK;
+    if (!y || !grad_y) return PCACC_E_ARG;
+    const int64_t total = n_img * ((h + 1) / 2) * ((w + 1) / 2) * (c / 4);
+    const int grid = pcacc_grid(total, 256, PCACC_CUS * 16);
+    hipStream_t s = pcacc_stream(stream);
+    const float4 *yy = reinterpret_cast<const float4 *>(y), *gp = reinterpret_cast<const float4 *>(grad_pooled),
+                 *gs = reinterpret_cast<const float4 *>(grad_skip);
+    float4 *o = reinterpret_cast<float4 *>(grad_y);
+    if (gp && gs) pool_skip_relu_bwd_f32_kernel<true, true><<<grid, 256, 0, s>>>(yy, gp, gs, n_img, h, w, c / 4, o, out_amax);
+    else if (gp) pool_skip_relu_bwd_f32_kernel<true, false><<<grid, 256, 0, s>>>(yy, gp, gs, n_img, h, w, c / 4, o, out_amax);
+    else if (gs) pool_skip_relu_bwd_f32_kernel<false, true><<<grid, 256, 0, s>>>(yy, gp, gs, n_img, h, w, c / 4, o, out_amax);
+    else pool_skip_relu_bwd_f32_kernel<false, false><<<grid, 256, 0, s>>>(yy, gp, gs, n_img, h, w, c / 4, o, out_amax);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}
+

@@ -60,7 +60,7 @@ EXPORTS = [
     'pcacc_tube_rows', 'pcacc_tube_code', 'pcacc_tube_code_backward', 'pcacc_tube_pose_forward', 'pcacc_tube_gap_forward', 'pcacc_tube_finish',
     'pcacc_tube_gap_backward', 'pcacc_tube_pose_backward', 'pcacc_rows_wgrad_few_supported', 'pcacc_rows_wgrad_few_workspace_bytes', 'pcacc_rows_wgrad_few',
     'pcacc_maxpool2x2_bf16', 'pcacc_pool_skip_relu_backward_bf16',
-    'pcacc_pfn_block_forward', 'pcacc_pfn_block_backward_workspace_bytes', 'pcacc_pfn_block_backward', 'pcacc_bn_relu_rows_forward', 'pcacc_bn_relu_rows_backward', 'pcacc_pfn_block_split_forward', 'pcacc_pfn_block_split_dgrad', 'pcacc_inv4x4',
+    'pcacc_pfn_block_forward', 'pcacc_pfn_block_backward_workspace_bytes', 'pcacc_pfn_block_backward', 'pcacc_maxpool2x2_f32', 'pcacc_pool_skip_relu_backward_f32', 'pcacc_bn_relu_rows_forward', 'pcacc_bn_relu_rows_backward', 'pcacc_pfn_block_split_forward', 'pcacc_pfn_block_split_dgrad', 'pcacc_inv4x4',
     'pcacc_conv3x3_split_prepare_weights', 'pcacc_conv3x3_split_supported', 'pcacc_conv3x3_split', 'pcacc_conv3x3_wgrad_split_workspace_bytes',
     'pcacc_conv3x3_wgrad_split', 'pcacc_absmax256',
     'pcacc_rows_linear_split', 'pcacc_rows_linear_cat_split', 'pcacc_rows_wgrad_split_workspace_bytes', 'pcacc_rows_wgrad_split',
@@ -1241,17 +1241,27 @@ def tube_pose_backward(pose_vec, remaining, slot_centre, weights, wsum, grad_pos
 
 # ---- tail of a U-Net encoder stage (include/pcacc.h: pcacc_maxpool2x2_bf16, pcacc_pool_skip_relu_backward_bf16) -----------------------
 def maxpool2x2(x_rows):
-    """[n_img, h, w, c] bf16 channels-last -> [n_img, h/2, w/2, c]."""
+    """[n_img, h, w, c] bf16 / f32 channels-last -> [n_img, h/2, w/2, c]."""
     n, h, w, c = x_rows.shape
-    out = torch.empty((n, h // 2, w // 2, c), dtype=torch.bfloat16, device=x_rows.device)
-    _check(lib().pcacc_maxpool2x2_bf16(_dev(x_rows, torch.bfloat16, 'x'), _i64(n), int(h), int(w), int(c), _dev(out), _stream()), 'maxpool2x2')
+    out = torch.empty((n, h // 2, w // 2, c), dtype=x_rows.dtype, device=x_rows.device)
+    if x_rows.dtype == torch.float32:
+        _check(lib().pcacc_maxpool2x2_f32(_dev(x_rows, torch.float32, 'x'), _i64(n), int(h), int(w), int(c), _dev(out), _stream()), 'maxpool2x2')
+    else:
+        _check(lib().pcacc_maxpool2x2_bf16(_dev(x_rows, torch.bfloat16, 'x'), _i64(n), int(h), int(w), int(c), _dev(out), _stream()), 'maxpool2x2')
     return out
 
 
-def pool_skip_relu_backward(y_rows, grad_pooled, grad_skip):
-    """(un-pool(grad_pooled) + grad_skip) * (y > 0) in one pass; either gradient may be None."""
+def pool_skip_relu_backward(y_rows, grad_pooled, grad_skip, want_amax=False):
+    """(un-pool(grad_pooled) + grad_skip) * (y > 0) in one pass; either gradient may be None.  bf16 or f32 rows (all of y's type);
+    want_amax (f32): -> (grad, absmax256 array of it)."""
     n, h, w, c = y_rows.shape
     out = torch.empty_like(y_rows)
+    if y_rows.dtype == torch.float32:
+        amax = _zero256(y_rows.device) if want_amax else None
+        _check(lib().pcacc_pool_skip_relu_backward_f32(_dev(y_rows, torch.float32, 'y'), _opt(grad_pooled, torch.float32, 'grad_pooled'),
+                                                       _opt(grad_skip, torch.float32, 'grad_skip'), _i64(n), int(h), int(w), int(c), _dev(out),
+                                                       _dev(amax) if want_amax else None, _stream()), 'pool_skip_relu_backward')
+        return (out, amax) if want_amax else out
     _check(lib().pcacc_pool_skip_relu_backward_bf16(_dev(y_rows, torch.bfloat16, 'y'), _opt(grad_pooled, torch.bfloat16, 'grad_pooled'),
                                                     _opt(grad_skip, torch.bfloat16, 'grad_skip'), _i64(n), int(h), int(w), int(c), _dev(out),
                                                     _stream()), 'pool_skip_relu_backward')

@@ -881,12 +881,13 @@ class _Conv3x3Split(torch.autograd.Function):
     the incoming gradient once for both backward kernels)."""
 
     @staticmethod
-    def forward(ctx, x_rows, weight, bias, frames, relu):
+    def forward(ctx, x_rows, weight, bias, frames, relu, premasked=False):
         x_amax = amax_of(x_rows)
         y, y_amax = native.conv3x3_split(x_rows, prepared_conv_weights_split(weight)[0], bias.detach().float() if bias is not None else None, frames,
                                          relu, amax=x_amax, want_amax=True)
         set_amax_tag(y, y_amax)
-        ctx.save_for_backward(x_rows, weight, y if relu else None, x_amax)
+        # premasked: every consumer of y hands back a gradient that is already zero where y <= 0 (_PoolSkip): no mask reads in the backward
+        ctx.save_for_backward(x_rows, weight, y if relu and not premasked else None, x_amax)
         ctx.meta = (frames, bias is not None)
         return y
 
@@ -914,7 +915,7 @@ class _Conv3x3Split(torch.autograd.Function):
                 gw = gw.view(o, 3, 3, i).permute(0, 3, 1, 2)
             gw = gw.to(weight.dtype)
             gb = gb if has_bias and ctx.needs_input_grad[2] else None
-        return gx, gw, gb, None, None
+        return gx, gw, gb, None, None, None
 
 
 _PREPARED_UP = {}
@@ -1045,7 +1046,7 @@ def conv3x3_rows(x_rows, weight, bias, frames=1, relu=False, premasked=False):
         xc = x_rows.contiguous()
         if xc is not x_rows:
             carry_amax(x_rows, xc)
-        return _Conv3x3Split.apply(xc, weight, bias, int(frames), bool(relu))
+        return _Conv3x3Split.apply(xc, weight, bias, int(frames), bool(relu), bool(premasked))
     if x_rows.dtype != torch.bfloat16:
         x_rows = x_rows.to(torch.bfloat16)
     return _Conv3x3.apply(x_rows.contiguous(), weight, bias, int(frames), bool(relu), bool(premasked))
@@ -1075,18 +1076,27 @@ def conv3x3(x, conv, relu=False):
 
 
 class _PoolSkip(torch.autograd.Function):
-    """y [n, H, W, C] bf16 rows = a ReLU output -> (2x2 max-pool of y, y).  Backward: ONE pass that un-pools the first gradient, adds
-    the second and zeroes the sum where y <= 0 (csrc/pool.hip) -- in place of max_pool2d_backward + add + threshold_backward."""
+    """y [n, H, W, C] bf16 (f32 in the fp32x3 mode) rows = a ReLU output -> (2x2 max-pool of y, y).  Backward: ONE pass that un-pools the
+    first gradient, adds the second and zeroes the sum where y <= 0 (csrc/pool.hip) -- in place of max_pool2d_backward + add +
+    threshold_backward; on f32 rows the pass also leaves the gradient's maximum for the split kernels that read it."""
 
     @staticmethod
     def forward(ctx, y_rows):
         ctx.save_for_backward(y_rows)
-        return native.maxpool2x2(y_rows), y_rows.view_as(y_rows)
+        pooled = native.maxpool2x2(y_rows)
+        skip = y_rows.view_as(y_rows)
+        if y_rows.dtype == torch.float32:
+            carry_amax(y_rows, pooled)                          # window maxima of y: its bound holds
+            carry_amax(y_rows, skip)
+        return pooled, skip
 
     @staticmethod
     def backward(ctx, g_pool, g_skip):
         y_rows, = ctx.saved_tensors
-        c = lambda g: g.contiguous().to(torch.bfloat16) if g is not None else None
+        c = lambda g: g.contiguous().to(y_rows.dtype) if g is not None else None
+        if y_rows.dtype == torch.float32:
+            g, g_amax = native.pool_skip_relu_backward(y_rows, c(g_pool), c(g_skip), want_amax=True)
+            return set_amax_tag(g, g_amax)
         return native.pool_skip_relu_backward(y_rows, c(g_pool), c(g_skip))
 
 

@@ -30,7 +30,7 @@ class DownConv(nn.Module):
 
     def forward(self, x):
         x = ops.conv3x3(x, self.conv1, relu=True)
-        if self.pooling and ops.conv3x3_native(x, self.conv2) == 'bf16' and self.out_channels % 8 == 0:
+        if self.pooling and ops.conv3x3_native(x, self.conv2) in ('bf16', 'split') and self.out_channels % 8 == 0:
             return ops.conv3x3_relu_pool(x, self.conv2)            # second conv + ReLU + pool, their backward in one pass (csrc/pool.hip)
         x = ops.conv3x3(x, self.conv2, relu=True)
         return (ops.carry_amax(x, self.pool(x)) if self.pooling else x), x          # window maxima of x: x's bound holds (fp32x3 scales)

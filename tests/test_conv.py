@@ -190,18 +190,20 @@ def test_conv3x3_prepare_weights_pair_and_cache(shape):
     assert b[0] is not a[0] and torch.equal(b[0], native.conv3x3_prepare_weights(p.detach().contiguous()))
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize('n,h,w,c', [(2, 16, 24, 32), (1, 9, 7, 64), (3, 2, 2, 8), (1, 37, 40, 128)])
-def test_pool_skip_kernels_bit_exact(n, h, w, c):
-    """csrc/pool.hip against the three library passes it replaces (max_pool2d backward, add, threshold_backward) on the same bf16
-    maps: bit-identical, including ties inside a window (first maximum in scan order), zeros from the ReLU and odd sizes."""
+def test_pool_skip_kernels_bit_exact(n, h, w, c, dtype):
+    """csrc/pool.hip against the three library passes it replaces (max_pool2d backward, add, threshold_backward) on the same bf16 / f32
+    maps: bit-identical, including ties inside a window (first maximum in scan order), zeros from the ReLU and odd sizes; the f32 pass
+    reports the largest magnitude it wrote."""
     g = torch.Generator(device='cpu').manual_seed(h * 100 + w)
-    y = torch.relu(torch.randn(n, h, w, c, generator=g)).to(DEV).to(torch.bfloat16)
+    y = torch.relu(torch.randn(n, h, w, c, generator=g)).to(DEV).to(dtype)
     y[:, : h // 2 * 2 : 2, : w // 2 * 2 : 2][..., ::3] = y[:, 1::2, 1::2][:, : h // 2, : w // 2][..., ::3]      # ties between window corners
     pooled = native.maxpool2x2(y)
     ref_pooled, idx = F.max_pool2d(y.permute(0, 3, 1, 2), 2, return_indices=True)
     assert torch.equal(pooled, ref_pooled.permute(0, 2, 3, 1))
-    gp = torch.randn(n, h // 2, w // 2, c, generator=g).to(DEV).to(torch.bfloat16)
-    gs = torch.randn(n, h, w, c, generator=g).to(DEV).to(torch.bfloat16)
+    gp = torch.randn(n, h // 2, w // 2, c, generator=g).to(DEV).to(dtype)
+    gs = torch.randn(n, h, w, c, generator=g).to(DEV).to(dtype)
     unpooled = torch.ops.aten.max_pool2d_with_indices_backward(gp.permute(0, 3, 1, 2), y.permute(0, 3, 1, 2), [2, 2], [2, 2], [0, 0], [1, 1],
                                                                False, idx).permute(0, 2, 3, 1)
     for a, b, want in ((gp, gs, torch.ops.aten.threshold_backward(unpooled + gs, y, 0)),
@@ -209,30 +211,47 @@ def test_pool_skip_kernels_bit_exact(n, h, w, c):
                        (None, gs, torch.ops.aten.threshold_backward(gs, y, 0))):
         got = native.pool_skip_relu_backward(y, a, b)
         assert torch.equal(got, want.contiguous())
+        if dtype == torch.float32:
+            got2, amax = native.pool_skip_relu_backward(y, a, b, want_amax=True)
+            assert torch.equal(got2, got) and float(amax.max()) == float(got.abs().max())
 
 
-def test_down_conv_fused_tail_matches_separate_ops():
+@pytest.mark.parametrize('mode', ['bf16', 'fp32x3'])
+def test_down_conv_fused_tail_matches_separate_ops(mode):
     """unet.DownConv with the fused conv + ReLU + pool tail against the same stage written with separate ops: same outputs, same
-    gradients of the input and of both convolutions."""
+    gradients of the input and of both convolutions (bf16 rows, and fp32 rows in the fp32x3 mode)."""
     from pcaccumulation_amd.unet import DownConv
     torch.manual_seed(3)
-    stage = DownConv(32, 64).to(DEV)
-    x = torch.randn(2, 32, 24, 40, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
-    gp = torch.randn(2, 64, 12, 20, device=DEV).to(torch.bfloat16)
-    gs = torch.randn(2, 64, 24, 40, device=DEV).to(torch.bfloat16)
-    assert ops.conv3x3_native(x, stage.conv2)
-    pooled, skip = stage(x)
-    ((pooled * gp).sum() + (skip * gs).sum()).backward()
-    got = [pooled.detach(), skip.detach(), x.grad.clone()] + [p.grad.clone() for p in stage.parameters()]
-    x.grad = None
-    stage.zero_grad()
-    y = ops.conv3x3(ops.conv3x3(x, stage.conv1, relu=True), stage.conv2, relu=True)
-    p2 = F.max_pool2d(y, 2)
-    ((p2 * gp).sum() + (y * gs).sum()).backward()
-    want = [p2.detach(), y.detach(), x.grad.clone()] + [p.grad.clone() for p in stage.parameters()]
+    dt = torch.bfloat16 if mode == 'bf16' else torch.float32
+    ops.set_split(mode == 'fp32x3')
+    try:
+        stage = DownConv(32, 64).to(DEV)
+        x = torch.randn(2, 32, 24, 40, device=DEV).to(dt).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        gp = torch.randn(2, 64, 12, 20, device=DEV).to(dt)
+        gs = torch.randn(2, 64, 24, 40, device=DEV).to(dt)
+        assert ops.conv3x3_native(x, stage.conv2) == ('bf16' if mode == 'bf16' else 'split')
+        calls = []
+        orig = native.pool_skip_relu_backward
+        native.pool_skip_relu_backward = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        try:
+            pooled, skip = stage(x)
+            ((pooled * gp).sum() + (skip * gs).sum()).backward()
+        finally:
+            native.pool_skip_relu_backward = orig
+        assert calls, 'the stage runs the fused tail'
+        got = [pooled.detach(), skip.detach(), x.grad.clone()] + [p.grad.clone() for p in stage.parameters()]
+        x.grad = None
+        stage.zero_grad()
+        y = ops.conv3x3(ops.conv3x3(x, stage.conv1, relu=True), stage.conv2, relu=True)
+        p2 = F.max_pool2d(y, 2)
+        ((p2 * gp).sum() + (y * gs).sum()).backward()
+        want = [p2.detach(), y.detach(), x.grad.clone()] + [p.grad.clone() for p in stage.parameters()]
+    finally:
+        ops.set_split(False)
+    tol = 1e-3 if mode == 'bf16' else 1e-5
     for a, b in zip(got, want):
         assert a.shape == b.shape
-        assert torch.allclose(a.float(), b.float(), rtol=1e-3, atol=1e-3 * float(b.float().abs().max())), float((a.float() - b.float()).abs().max())
+        assert torch.allclose(a.float(), b.float(), rtol=tol, atol=tol * float(b.float().abs().max())), float((a.float() - b.float()).abs().max())
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
