@@ -63,8 +63,10 @@ class PreparedInputs(object):
         return [t for t in out if torch.is_tensor(t)]
 
     def matches(self, input_dict):
-        return (self.pidx.m == input_dict['coordinates'].shape[0] and self.pidx.n == input_dict['input_points'].shape[0]
-                and self.features.device == input_dict['input_points'].device)
+        src = getattr(self, 'source', None)                   # (storage address, version) of the batch's points when prepare_inputs built this
+        pts = input_dict['input_points']
+        return (self.pidx.m == input_dict['coordinates'].shape[0] and self.pidx.n == pts.shape[0] and self.features.device == pts.device
+                and (src is None or src == (pts.data_ptr(), pts._version)))
 
 
 def grid_shape(cfg):
@@ -153,8 +155,10 @@ class MotionNet(nn.Module):
         occ = ops.pillar_scatter(torch.ones((pidx.m, 1), device=device), pidx)
         fb_map = ops.pillar_scatter(fb_labels_sub.float().unsqueeze(1), pidx)
         features = self.pillar_encoder.point_features(input_points, pidx, pidx.coordinates, pillar_mean, time_indice)
-        return PreparedInputs(pidx=pidx, batch_idx=batch_idx, frame_idx=frame_idx, pillar_mean=pillar_mean, fb_labels_sub=fb_labels_sub,
+        prep = PreparedInputs(pidx=pidx, batch_idx=batch_idx, frame_idx=frame_idx, pillar_mean=pillar_mean, fb_labels_sub=fb_labels_sub,
                               occ_map=occ.view(B, nt, 1, ny, nx), fb_seg_gt=fb_map.view(B, nt, 1, ny, nx).to(fb_labels.dtype), features=features)
+        prep.source = (input_dict['input_points'].data_ptr(), input_dict['input_points']._version)      # a `_prepared` of another batch is refused
+        return prep
 
     def forward(self, input_dict):
         input_points = input_dict['input_points'].float()                    # [N,3]
