@@ -272,8 +272,8 @@ def scatter_flushed(dtype, batch, pillars):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--pts-per-frame', type=int, default=160000)
     ap.add_argument('--batch', type=int, default=4, help='sequences per GPU per step (reference default: train.batch_size = 4, configs/default.yaml:33)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32', 'fp32x3'])
