@@ -74,5 +74,30 @@ for _ in range(3):
     native.rows_wgrad_split(dyr, ad, xr, ar)
 for _ in range(3):
     native.absmax256(xr)
+# fused pillar-encoder block (two-piece rows), wide row layer with weights in registers, fg/bg head kernels
+m = 1_169_433
+xa, pooled = f32(rows, 32), f32(m, 32)
+p2v = torch.randint(0, m, (rows,), device=dev, dtype=torch.int32)
+w0, ws, w1 = torch.randn(32, 64, device=dev) / 8, torch.randn(32, 64, device=dev) / 8, torch.randn(32, 32, device=dev) / 6
+b0, b1 = torch.randn(32, device=dev), torch.randn(32, device=dev)
+aa, ap = native.absmax256(xa), native.absmax256(pooled)
+for _ in range(3):
+    out, hr, xm, hm, oa, ha = native.pfn_block_split_forward(xa, aa, pooled, ap, p2v, w0, b0, ws, w1, b1)
+g = f32(rows, 32)
+ag = native.absmax256(g)
+for _ in range(3):
+    native.pfn_block_split_dgrad(g, ag, xm, hm, w0, ws, w1, True)
+x128 = f32(429_567, 128)
+a128 = native.absmax256(x128)
+w128 = torch.randn(128, 128, device=dev) / 11
+for _ in range(3):
+    native.rows_linear_split(x128, a128, w128, None, None, False, True)      # rows_linear_split_fm_kernel<128, 4>
+xh = bf(20, 288, 288, 32)
+wh = torch.randn(2, 32, 3, 3, device=dev) / 17
+dyh = f32(20, 288, 288, 2)
+for _ in range(3):
+    native.head_conv3x3_forward(xh, wh, torch.zeros(2, device=dev))
+    native.head_conv3x3_dgrad(dyh, wh, 32, torch.bfloat16)
+    native.head_conv3x3_wgrad(dyh, xh)
 torch.cuda.synchronize()
 print('done')

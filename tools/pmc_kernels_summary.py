@@ -27,6 +27,12 @@ KERNELS = {  # name fragment -> (label, algorithmic FLOPs per launch, algorithmi
     'rows_linear_split_kernel': ('fp32x3 rows linear 32->32, 3.2 M rows', 2.0 * 3.2e6 * 32 * 32, 3.2e6 * 64 * 4),
     'rows_wgrad_split_kernel': ('fp32x3 rows wgrad 32x32, 3.2 M rows', 2.0 * 3.2e6 * 32 * 33, 3.2e6 * 64 * 4),
     'absmax256_kernel': ('absmax of 3.2 M x 32 f32', 3.2e6 * 32, 3.2e6 * 32 * 4),
+    'pfn_block_split_fwd_kernel': ('fp32x3 pillar-encoder block forward, 3.2 M two-piece rows', 2.0 * 3.2e6 * (2 * 32 * 64 + 32 * 32), 3.2e6 * (128 + 128 + 128 + 128 + 12 + 4)),
+    'pfn_block_split_dgrad_kernel': ('fp32x3 pillar-encoder block data gradient, 3.2 M rows', 2.0 * 3.2e6 * (2 * 32 * 64 + 32 * 32), 3.2e6 * (128 + 12 + 256 + 128)),
+    'rows_linear_split_fm_kernel': ('fp32x3 rows linear 128->128, 430 k rows (weights in registers)', 2.0 * 429567 * 128 * 128, 429567 * 256 * 4),
+    'head_conv_fwd_kernel': ('fg/bg head conv 32->2 forward @288^2 x20 (bf16 in)', 2.0 * 20 * 288 * 288 * 32 * 2 * 9, 20 * 288 * 288 * (32 * 2 + 2 * 4)),
+    'head_conv_dgrad_kernel': ('fg/bg head conv data gradient (bf16 out)', 2.0 * 20 * 288 * 288 * 32 * 2 * 9, 20 * 288 * 288 * (32 * 2 + 2 * 4)),
+    'head_conv_wgrad_kernel': ('fg/bg head conv weight gradient (bf16 in)', 2.0 * 20 * 288 * 288 * 32 * 2 * 9, 20 * 288 * 288 * (32 * 2 + 2 * 4)),
 }
 
 
