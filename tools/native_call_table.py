@@ -1,7 +1,10 @@
 #!/usr/bin/env python
 """Every call into libpcacc_hip.so during one training step: shapes, event-timed duration, bytes of its tensor arguments and
 results (an upper bound of the algorithmic traffic: every operand once) and the resulting GB/s.  Shows which calls sit far from
-the 8 TB/s HBM roofline at their real shapes.  Development aid.  Usage: [PCACC_DTYPE=bf16|fp32|fp32x3] python tools/native_call_table.py [min_us]"""
+the 8 TB/s HBM roofline at their real shapes.  Each call is timed alone between two events; a spin kernel queued in front of the first
+event lets the host finish issuing the call (allocations, ctypes, several launches) before the GPU reaches it, so the interval is the
+call's kernels back to back and not the host's issue latency (about 25 us per call before round 3's end, which put a 48 us kernel at
+77 us).  Development aid.  Usage: [PCACC_DTYPE=bf16|fp32|fp32x3] [PCACC_POINTS=lidar] python tools/native_call_table.py [min_us]"""
 import os, sys, collections, types
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -17,7 +20,7 @@ cfg = default_config('waymo', 'train', n_sweeps=5)
 cfg['misc']['compute_dtype'] = os.environ.get('PCACC_DTYPE', 'bf16'); cfg['pose_estimation']['kpt_sampler'] = 'device'
 model, opt, loss_fn = bench.build(cfg, dev)
 batcher = DeviceBatcher(cfg)
-scenes = [sample_to_device(make_sequence(i, 5, 160000, cfg), dev) for i in range(4)]
+scenes = [sample_to_device(make_sequence(i, 5, 160000, cfg, mode='lidar_scan' if os.environ.get('PCACC_POINTS') == 'lidar' else 'uniform'), dev) for i in range(4)]
 stepper = pdist.DataParallelStep(model, opt, loss_fn, iter_size=1, grad_clip=1.0)
 for _ in range(3):
     bench.train_step(stepper, batcher, scenes)
@@ -33,10 +36,26 @@ def tensors(obj):
             yield from tensors(o)
 
 
+depth = [0]
+
+
 def wrap(name, fn):
     def w(*a, **k):
+        if depth[0]:                                            # a call made by another native wrapper (bilinear backward -> csr_build): part of the outer call
+            return fn(*a, **k)
+        depth[0] += 1
+        try:
+            return timed(name, fn, a, k)
+        finally:
+            depth[0] -= 1
+    return w
+
+
+def timed(name, fn, a, k):
+    if True:
         torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(600_000)                              # ~0.3 ms of spinning: the host issues the whole call behind it
         s.record()
         r = fn(*a, **k)
         e.record()
@@ -47,7 +66,6 @@ def wrap(name, fn):
         desc = ' '.join('%s%s' % (str(t.dtype).replace('torch.', '')[:4], tuple(t.shape)) for t in ins[:4])
         calls.append((name, desc, s.elapsed_time(e) * 1e3, nbytes))
         return r
-    return w
 
 
 skip = {'lib', 'upload_small'}
@@ -63,7 +81,7 @@ for name, desc, us, nb in calls:
     a = agg.setdefault(key, [0, 0.0, nb])
     a[0] += 1
     a[1] += us
-print('%d native calls, %.2f ms in total (each timed alone, queue drained)' % (len(calls), sum(c[2] for c in calls) / 1e3))
+print('%d native calls, %.2f ms in total (each timed alone behind a spin kernel: kernel time, no host issue latency)' % (len(calls), sum(c[2] for c in calls) / 1e3))
 print('%8s %4s %8s %8s %7s  %s' % ('tot us', 'n', 'avg us', 'MB', 'GB/s', 'call'))
 for (name, desc), (n, us, nb) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     if us / n < min_us:
