@@ -598,6 +598,12 @@ int pcacc_pool_skip_relu_backward_bf16(const uint16_t *y, const uint16_t *grad_p
 int pcacc_maxpool2x2_f32(const float *x, int64_t n_img, int32_t h, int32_t w, int32_t c, float *out, void *stream);
 int pcacc_pool_skip_relu_backward_f32(const float *y, const float *grad_pooled, const float *grad_skip, int64_t n_img, int32_t h, int32_t w,
                                       int32_t c, float *grad_y, float *out_amax, void *stream);
+/* grad_skip read in place from a wider map (skip_pitch = elements between consecutive pixels, >= c, a multiple of 8 (bf16) / 4 (f32), the
+ * pointer 16-byte aligned): the skip half of the decoder's concatenation gradient (models/unet.py:101-113) without a contiguous copy. */
+int pcacc_pool_skip_relu_backward_strided_bf16(const uint16_t *y, const uint16_t *grad_pooled, const uint16_t *grad_skip, int64_t skip_pitch,
+                                               int64_t n_img, int32_t h, int32_t w, int32_t c, uint16_t *grad_y, void *stream);
+int pcacc_pool_skip_relu_backward_strided_f32(const float *y, const float *grad_pooled, const float *grad_skip, int64_t skip_pitch,
+                                              int64_t n_img, int32_t h, int32_t w, int32_t c, float *grad_y, float *out_amax, void *stream);
 
 /* Batched inverse of n 4x4 f32 matrices (the pose tables: torch.linalg.inv at models/motionnet.py:100 and models/alignnet.py:33),
  * Gauss-Jordan with partial pivoting, one launch; a singular matrix yields inf / nan entries (no status word). */

@@ -70,8 +70,10 @@ __device__ __forceinline__ void pool_bwd2(const uint32_t (&y)[4], const uint32_t
 template <bool HAS_POOL, bool HAS_SKIP>
 __global__ __launch_bounds__(256) void pool_skip_relu_bwd_kernel(const uint4 *__restrict__ y, const uint4 *__restrict__ g_pool,
                                                                  const uint4 *__restrict__ g_skip, int64_t n_img, int h, int w, int c8,
-                                                                 uint4 *__restrict__ out)
+                                                                 uint4 *__restrict__ out, int gs_pitch)
 {
+    // gs_pitch: 16-byte units between consecutive pixels of g_skip (c8 for a dense map; 2 c8 for a channel slice of the decoder's
+    // concatenation gradient, read in place instead of through a contiguous copy)
     const int h2 = (h + 1) / 2, w2 = (w + 1) / 2, hp = h / 2, wp = w / 2;
     const int64_t total = n_img * h2 * w2 * c8;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
@@ -83,13 +85,15 @@ __global__ __launch_bounds__(256) void pool_skip_relu_bwd_kernel(const uint4 *__
         const bool in_x = 2 * xo + 1 < w, in_y = 2 * yo + 1 < h;
         const int64_t base = ((img * h + 2 * yo) * w + 2 * xo) * c8 + c;
         const int64_t off[4] = {0, c8, (int64_t)w * c8, (int64_t)w * c8 + c8};
+        const int64_t gbase = ((img * h + 2 * yo) * w + 2 * xo) * gs_pitch + c;
+        const int64_t goff[4] = {0, gs_pitch, (int64_t)w * gs_pitch, (int64_t)w * gs_pitch + gs_pitch};
         const bool ok[4] = {true, in_x, in_y, in_x && in_y};
         const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
         uint4 yv[4], gs[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             yv[i] = ok[i] ? y[base + off[i]] : zero;
-            gs[i] = (HAS_SKIP && ok[i]) ? g_skip[base + off[i]] : zero;
+            gs[i] = (HAS_SKIP && ok[i]) ? g_skip[gbase + goff[i]] : zero;
         }
         uint4 gp = zero;
         if (HAS_POOL && in_x && in_y && yo < hp && xo < wp) gp = g_pool[((img * hp + yo) * wp + xo) * c8 + c];
@@ -122,10 +126,12 @@ extern "C" int pcacc_maxpool2x2_bf16(const uint16_t *x, int64_t n_img, int32_t h
     return PCACC_OK;
 }
 
-extern "C" int pcacc_pool_skip_relu_backward_bf16(const uint16_t *y, const uint16_t *grad_pooled, const uint16_t *grad_skip, int64_t n_img,
-                                                  int32_t h, int32_t w, int32_t c, uint16_t *grad_y, void *stream)
+static int pool_skip_bwd_bf16(const uint16_t *y, const uint16_t *grad_pooled, const uint16_t *grad_skip, int64_t skip_pitch, int64_t n_img,
+                              int32_t h, int32_t w, int32_t c, uint16_t *grad_y, void *stream)
 {
-    if (n_img < 0 || h < 2 || w < 2 || c <= 0 || (c % 8)) return PCACC_E_ARG;
+    if (n_img < 0 || h < 2 || w < 2 || c <= 0 || (c % 8) || skip_pitch < c || (skip_pitch % 8) || skip_pitch / 8 > 0x7fffffff) return PCACC_E_ARG;
+    if (grad_skip && (reinterpret_cast<uintptr_t>(grad_skip) & 15)) return PCACC_E_ARG;
+    const int gs_pitch = (int)(skip_pitch / 8);
     if (n_img == 0) return PCACC_OK;
     if (!y || !grad_y) return PCACC_E_ARG;
     const int64_t total = n_img * ((h + 1) / 2) * ((w + 1) / 2) * (c / 8);
@@ -134,12 +140,27 @@ extern "C" int pcacc_pool_skip_relu_backward_bf16(const uint16_t *y, const uint1
     const uint4 *yy = reinterpret_cast<const uint4 *>(y), *gp = reinterpret_cast<const uint4 *>(grad_pooled),
                 *gs = reinterpret_cast<const uint4 *>(grad_skip);
     uint4 *o = reinterpret_cast<uint4 *>(grad_y);
-    if (gp && gs) pool_skip_relu_bwd_kernel<true, true><<<grid, 256, 0, s>>>(yy, gp, gs, n_img, h, w, c / 8, o);
-    else if (gp) pool_skip_relu_bwd_kernel<true, false><<<grid, 256, 0, s>>>(yy, gp, gs, n_img, h, w, c / 8, o);
-    else if (gs) pool_skip_relu_bwd_kernel<false, true><<<grid, 256, 0, s>>>(yy, gp, gs, n_img, h, w, c / 8, o);
-    else pool_skip_relu_bwd_kernel<false, false><<<grid, 256, 0, s>>>(yy, gp, gs, n_img, h, w, c / 8, o);
+    if (gp && gs) pool_skip_relu_bwd_kernel<true, true><<<grid, 256, 0, s>>>(yy, gp, gs, n_img, h, w, c / 8, o, gs_pitch);
+    else if (gp) pool_skip_relu_bwd_kernel<true, false><<<grid, 256, 0, s>>>(yy, gp, gs, n_img, h, w, c / 8, o, gs_pitch);
+    else if (gs) pool_skip_relu_bwd_kernel<false, true><<<grid, 256, 0, s>>>(yy, gp, gs, n_img, h, w, c / 8, o, gs_pitch);
+    else pool_skip_relu_bwd_kernel<false, false><<<grid, 256, 0, s>>>(yy, gp, gs, n_img, h, w, c / 8, o, gs_pitch);
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
+}
+
+extern "C" int pcacc_pool_skip_relu_backward_bf16(const uint16_t *y, const uint16_t *grad_pooled, const uint16_t *grad_skip, int64_t n_img,
+                                                  int32_t h, int32_t w, int32_t c, uint16_t *grad_y, void *stream)
+{
+    return pool_skip_bwd_bf16(y, grad_pooled, grad_skip, c, n_img, h, w, c, grad_y, stream);
+}
+
+// grad_skip read in place from a wider map: skip_pitch = elements between consecutive pixels (>= c, a multiple of 8 / 4 for bf16 / f32; the
+// pointer 16-byte aligned) -- the skip half of the decoder's concatenation gradient (models/unet.py:101-113) without a contiguous copy
+extern "C" int pcacc_pool_skip_relu_backward_strided_bf16(const uint16_t *y, const uint16_t *grad_pooled, const uint16_t *grad_skip,
+                                                          int64_t skip_pitch, int64_t n_img, int32_t h, int32_t w, int32_t c, uint16_t *grad_y,
+                                                          void *stream)
+{
+    return pool_skip_bwd_bf16(y, grad_pooled, grad_skip, skip_pitch, n_img, h, w, c, grad_y, stream);
 }
 
 // ---- the same two passes on fp32 rows (compute modes fp32x3 / fp32): 4 channels per lane -------------------------------------------------
@@ -177,7 +198,7 @@ __device__ __forceinline__ void pool_bwd1(const float (&y)[4], const float (&gs)
 template <bool HAS_POOL, bool HAS_SKIP>
 __global__ __launch_bounds__(256) void pool_skip_relu_bwd_f32_kernel(const float4 *__restrict__ y, const float4 *__restrict__ g_pool,
                                                                      const float4 *__restrict__ g_skip, int64_t n_img, int h, int w, int c4,
-                                                                     float4 *__restrict__ out, float *__restrict__ out_amax)
+                                                                     float4 *__restrict__ out, float *__restrict__ out_amax, int gs_pitch)
 {
     const int h2 = (h + 1) / 2, w2 = (w + 1) / 2, hp = h / 2, wp = w / 2;
     const int64_t total = n_img * h2 * w2 * c4;
@@ -191,13 +212,15 @@ __global__ __launch_bounds__(256) void pool_skip_relu_bwd_f32_kernel(const float
         const bool in_x = 2 * xo + 1 < w, in_y = 2 * yo + 1 < h;
         const int64_t base = ((img * h + 2 * yo) * w + 2 * xo) * c4 + c;
         const int64_t off[4] = {0, c4, (int64_t)w * c4, (int64_t)w * c4 + c4};
+        const int64_t gbase = ((img * h + 2 * yo) * w + 2 * xo) * gs_pitch + c;
+        const int64_t goff[4] = {0, gs_pitch, (int64_t)w * gs_pitch, (int64_t)w * gs_pitch + gs_pitch};
         const bool ok[4] = {true, in_x, in_y, in_x && in_y};
         const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
         float4 yv[4], gs[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             yv[i] = ok[i] ? y[base + off[i]] : zero;
-            gs[i] = (HAS_SKIP && ok[i]) ? g_skip[base + off[i]] : zero;
+            gs[i] = (HAS_SKIP && ok[i]) ? g_skip[gbase + goff[i]] : zero;
         }
         float4 gp = zero;
         if (HAS_POOL && in_x && in_y && yo < hp && xo < wp) gp = g_pool[((img * hp + yo) * wp + xo) * c4 + c];
@@ -239,10 +262,12 @@ extern "C" int pcacc_maxpool2x2_f32(const float *x, int64_t n_img, int32_t h, in
     return PCACC_OK;
 }
 
-extern "C" int pcacc_pool_skip_relu_backward_f32(const float *y, const float *grad_pooled, const float *grad_skip, int64_t n_img, int32_t h,
-                                                 int32_t w, int32_t c, float *grad_y, float *out_amax, void *stream)
+static int pool_skip_bwd_f32(const float *y, const float *grad_pooled, const float *grad_skip, int64_t skip_pitch, int64_t n_img, int32_t h,
+                             int32_t w, int32_t c, float *grad_y, float *out_amax, void *stream)
 {
-    if (n_img < 0 || h < 2 || w < 2 || c <= 0 || (c % 4)) return PCACC_E_ARG;
+    if (n_img < 0 || h < 2 || w < 2 || c <= 0 || (c % 4) || skip_pitch < c || (skip_pitch % 4) || skip_pitch / 4 > 0x7fffffff) return PCACC_E_ARG;
+    if (grad_skip && (reinterpret_cast<uintptr_t>(grad_skip) & 15)) return PCACC_E_ARG;
+    const int gs_pitch = (int)(skip_pitch / 4);
     if (n_img == 0) return PCACC_OK;
     if (!y || !grad_y) return PCACC_E_ARG;
     const int64_t total = n_img * ((h + 1) / 2) * ((w + 1) / 2) * (c / 4);
@@ -251,11 +276,24 @@ extern "C" int pcacc_pool_skip_relu_backward_f32(const float *y, const float *gr
     const float4 *yy = reinterpret_cast<const float4 *>(y), *gp = reinterpret_cast<const float4 *>(grad_pooled),
                  *gs = reinterpret_cast<const float4 *>(grad_skip);
     float4 *o = reinterpret_cast<float4 *>(grad_y);
-    if (gp && gs) pool_skip_relu_bwd_f32_kernel<true, true><<<grid, 256, 0, s>>>(yy, gp, gs, n_img, h, w, c / 4, o, out_amax);
-    else if (gp) pool_skip_relu_bwd_f32_kernel<true, false><<<grid, 256, 0, s>>>(yy, gp, gs, n_img, h, w, c / 4, o, out_amax);
-    else if (gs) pool_skip_relu_bwd_f32_kernel<false, true><<<grid, 256, 0, s>>>(yy, gp, gs, n_img, h, w, c / 4, o, out_amax);
-    else pool_skip_relu_bwd_f32_kernel<false, false><<<grid, 256, 0, s>>>(yy, gp, gs, n_img, h, w, c / 4, o, out_amax);
+    if (gp && gs) pool_skip_relu_bwd_f32_kernel<true, true><<<grid, 256, 0, s>>>(yy, gp, gs, n_img, h, w, c / 4, o, out_amax, gs_pitch);
+    else if (gp) pool_skip_relu_bwd_f32_kernel<true, false><<<grid, 256, 0, s>>>(yy, gp, gs, n_img, h, w, c / 4, o, out_amax, gs_pitch);
+    else if (gs) pool_skip_relu_bwd_f32_kernel<false, true><<<grid, 256, 0, s>>>(yy, gp, gs, n_img, h, w, c / 4, o, out_amax, gs_pitch);
+    else pool_skip_relu_bwd_f32_kernel<false, false><<<grid, 256, 0, s>>>(yy, gp, gs, n_img, h, w, c / 4, o, out_amax, gs_pitch);
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
+}
+
+extern "C" int pcacc_pool_skip_relu_backward_f32(const float *y, const float *grad_pooled, const float *grad_skip, int64_t n_img, int32_t h,
+                                                 int32_t w, int32_t c, float *grad_y, float *out_amax, void *stream)
+{
+    return pool_skip_bwd_f32(y, grad_pooled, grad_skip, c, n_img, h, w, c, grad_y, out_amax, stream);
+}
+
+extern "C" int pcacc_pool_skip_relu_backward_strided_f32(const float *y, const float *grad_pooled, const float *grad_skip, int64_t skip_pitch,
+                                                         int64_t n_img, int32_t h, int32_t w, int32_t c, float *grad_y, float *out_amax,
+                                                         void *stream)
+{
+    return pool_skip_bwd_f32(y, grad_pooled, grad_skip, skip_pitch, n_img, h, w, c, grad_y, out_amax, stream);
 }
 

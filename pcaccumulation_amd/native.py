@@ -60,7 +60,7 @@ EXPORTS = [
     'pcacc_tube_rows', 'pcacc_tube_code', 'pcacc_tube_code_backward', 'pcacc_tube_pose_forward', 'pcacc_tube_gap_forward', 'pcacc_tube_finish',
     'pcacc_tube_gap_backward', 'pcacc_tube_pose_backward', 'pcacc_rows_wgrad_few_supported', 'pcacc_rows_wgrad_few_workspace_bytes', 'pcacc_rows_wgrad_few',
     'pcacc_maxpool2x2_bf16', 'pcacc_pool_skip_relu_backward_bf16',
-    'pcacc_pfn_block_forward', 'pcacc_pfn_block_backward_workspace_bytes', 'pcacc_pfn_block_backward', 'pcacc_maxpool2x2_f32', 'pcacc_pool_skip_relu_backward_f32', 'pcacc_bn_relu_rows_forward', 'pcacc_bn_relu_rows_backward', 'pcacc_pfn_block_split_forward', 'pcacc_pfn_block_split_dgrad', 'pcacc_inv4x4',
+    'pcacc_pfn_block_forward', 'pcacc_pfn_block_backward_workspace_bytes', 'pcacc_pfn_block_backward', 'pcacc_maxpool2x2_f32', 'pcacc_pool_skip_relu_backward_f32', 'pcacc_pool_skip_relu_backward_strided_bf16', 'pcacc_pool_skip_relu_backward_strided_f32', 'pcacc_bn_relu_rows_forward', 'pcacc_bn_relu_rows_backward', 'pcacc_pfn_block_split_forward', 'pcacc_pfn_block_split_dgrad', 'pcacc_inv4x4',
     'pcacc_conv3x3_split_prepare_weights', 'pcacc_conv3x3_split_supported', 'pcacc_conv3x3_split', 'pcacc_conv3x3_wgrad_split_workspace_bytes',
     'pcacc_conv3x3_wgrad_split', 'pcacc_absmax256',
     'pcacc_rows_linear_split', 'pcacc_rows_linear_cat_split', 'pcacc_rows_wgrad_split_workspace_bytes', 'pcacc_rows_wgrad_split',
@@ -1251,20 +1251,42 @@ def maxpool2x2(x_rows):
     return out
 
 
+def _pixel_pitch(g, shape):
+    """Elements between consecutive pixels of a [n,h,w,c] map whose channels are contiguous and whose pixels are evenly spaced (a dense map,
+    or a channel slice of a wider dense map); None when the layout is anything else."""
+    n, h, w, c = shape
+    if tuple(g.shape) != tuple(shape) or g.stride(3) != 1:
+        return None
+    p = g.stride(2)
+    if p < c or g.stride(1) != w * p or g.stride(0) != h * w * p or g.data_ptr() % 16:
+        return None
+    return p
+
+
 def pool_skip_relu_backward(y_rows, grad_pooled, grad_skip, want_amax=False):
     """(un-pool(grad_pooled) + grad_skip) * (y > 0) in one pass; either gradient may be None.  bf16 or f32 rows (all of y's type);
-    want_amax (f32): -> (grad, absmax256 array of it)."""
+    grad_skip may be a channel slice of a wider map (read in place); want_amax (f32): -> (grad, absmax256 array of it)."""
     n, h, w, c = y_rows.shape
     out = torch.empty_like(y_rows)
-    if y_rows.dtype == torch.float32:
+    f32 = y_rows.dtype == torch.float32
+    dt = torch.float32 if f32 else torch.bfloat16
+    pitch, gs_ptr = c, None
+    if grad_skip is not None:
+        if grad_skip.dtype != dt or not grad_skip.is_cuda:
+            raise NativeError('pool_skip_relu_backward: grad_skip must be a %s GPU tensor' % dt)
+        pitch = _pixel_pitch(grad_skip, y_rows.shape)
+        if pitch is None or pitch % (4 if f32 else 8):
+            grad_skip, pitch = grad_skip.contiguous(), c
+        gs_ptr = ctypes.c_void_p(grad_skip.data_ptr())
+    if f32:
         amax = _zero256(y_rows.device) if want_amax else None
-        _check(lib().pcacc_pool_skip_relu_backward_f32(_dev(y_rows, torch.float32, 'y'), _opt(grad_pooled, torch.float32, 'grad_pooled'),
-                                                       _opt(grad_skip, torch.float32, 'grad_skip'), _i64(n), int(h), int(w), int(c), _dev(out),
-                                                       _dev(amax) if want_amax else None, _stream()), 'pool_skip_relu_backward')
+        _check(lib().pcacc_pool_skip_relu_backward_strided_f32(_dev(y_rows, torch.float32, 'y'), _opt(grad_pooled, torch.float32, 'grad_pooled'), gs_ptr,
+                                                               _i64(pitch), _i64(n), int(h), int(w), int(c), _dev(out),
+                                                               _dev(amax) if want_amax else None, _stream()), 'pool_skip_relu_backward')
         return (out, amax) if want_amax else out
-    _check(lib().pcacc_pool_skip_relu_backward_bf16(_dev(y_rows, torch.bfloat16, 'y'), _opt(grad_pooled, torch.bfloat16, 'grad_pooled'),
-                                                    _opt(grad_skip, torch.bfloat16, 'grad_skip'), _i64(n), int(h), int(w), int(c), _dev(out),
-                                                    _stream()), 'pool_skip_relu_backward')
+    _check(lib().pcacc_pool_skip_relu_backward_strided_bf16(_dev(y_rows, torch.bfloat16, 'y'), _opt(grad_pooled, torch.bfloat16, 'grad_pooled'), gs_ptr,
+                                                            _i64(pitch), _i64(n), int(h), int(w), int(c), _dev(out), _stream()),
+           'pool_skip_relu_backward')
     return out
 
 

@@ -1094,10 +1094,12 @@ class _PoolSkip(torch.autograd.Function):
     def backward(ctx, g_pool, g_skip):
         y_rows, = ctx.saved_tensors
         c = lambda g: g.contiguous().to(y_rows.dtype) if g is not None else None
+        # the skip gradient usually arrives as a channel slice of the decoder's concatenation gradient: the kernel reads it in place
+        gs = g_skip.to(y_rows.dtype) if g_skip is not None else None
         if y_rows.dtype == torch.float32:
-            g, g_amax = native.pool_skip_relu_backward(y_rows, c(g_pool), c(g_skip), want_amax=True)
+            g, g_amax = native.pool_skip_relu_backward(y_rows, c(g_pool), gs, want_amax=True)
             return set_amax_tag(g, g_amax)
-        return native.pool_skip_relu_backward(y_rows, c(g_pool), c(g_skip))
+        return native.pool_skip_relu_backward(y_rows, c(g_pool), gs)
 
 
 def conv3x3_relu_pool(x, conv):

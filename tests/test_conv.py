@@ -214,6 +214,9 @@ def test_pool_skip_kernels_bit_exact(n, h, w, c, dtype):
         if dtype == torch.float32:
             got2, amax = native.pool_skip_relu_backward(y, a, b, want_amax=True)
             assert torch.equal(got2, got) and float(amax.max()) == float(got.abs().max())
+        if b is not None:                                      # the skip gradient as a channel slice of a wider map (the decoder's concatenation), read in place
+            wide = torch.cat([torch.randn_like(b), b], dim=3)
+            assert not wide[..., c:].is_contiguous() and torch.equal(native.pool_skip_relu_backward(y, a, wide[..., c:]), got)
 
 
 @pytest.mark.parametrize('mode', ['bf16', 'fp32x3'])
