@@ -14,7 +14,7 @@
 
 // ---- 1. affinity = -(max(2 - 2 <fs_i, ft_j>, 1e-12) - softplus(alpha)) * inv_temp, written into the padded matrix ----------
 __global__ __launch_bounds__(256) void ego_affinity_kernel(const float *__restrict__ fs, const float *__restrict__ ft, int k, int c,
-                                                           const float *__restrict__ params, float *__restrict__ la)
+                                                           const float *__restrict__ params, float *__restrict__ la, int kp)
 {
     const float softplus_alpha = params[0], denom = params[1];      // device scalars: no host sync to read alpha / beta
     __shared__ float As[EGO_TILE][17], Bs[EGO_TILE][17];
@@ -23,8 +23,7 @@ __global__ __launch_bounds__(256) void ego_affinity_kernel(const float *__restri
     const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;
     fs += (int64_t)p * k * c;
     ft += (int64_t)p * k * c;
-    const int kp = k + 1;
-    la += (int64_t)p * kp * kp;
+    la += (int64_t)p * kp * kp;                                 // kp = k + 1: the padded matrix of the eval pipeline; k: a dense [k, k] result
     float acc[4][4] = {};
     for (int c0 = 0; c0 < c; c0 += 16) {
         for (int e = threadIdx.x; e < EGO_TILE * 16; e += 256) {
@@ -145,9 +144,8 @@ __global__ __launch_bounds__(64 * EGO_CG) void ego_sinkhorn_cols_kernel(int k, f
 __global__ __launch_bounds__(256) void ego_rows_finish_kernel(const float *__restrict__ la, const float *__restrict__ cs,
                                                               const float *__restrict__ ct, const float *__restrict__ thr2, int k,
                                                               int n_pairs, float *__restrict__ perm, float *__restrict__ rowsum,
-                                                              float *__restrict__ wt)
+                                                              float *__restrict__ wt, int kp)
 {
-    const int kp = k + 1;
     const int lane = threadIdx.x & 63;
     const int64_t n_rows = (int64_t)n_pairs * k;
     for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < n_rows; row += (int64_t)gridDim.x * 4) {
@@ -314,14 +312,14 @@ extern "C" int pcacc_sinkhorn_kabsch(const float *feats_s, const float *feats_t,
     float *rowsum = reinterpret_cast<float *>(ws); ws += pcacc_align((size_t)n_pairs * k * 4);
     float *wt = reinterpret_cast<float *>(ws);
     const int tiles = (k + EGO_TILE - 1) / EGO_TILE;
-    ego_affinity_kernel<<<dim3(tiles, tiles, n_pairs), 256, 0, s>>>(feats_s, feats_t, k, c, params, la);
+    ego_affinity_kernel<<<dim3(tiles, tiles, n_pairs), 256, 0, s>>>(feats_s, feats_t, k, c, params, la, k + 1);
     ego_pad_kernel<<<pcacc_grid((int64_t)n_pairs * (2 * k + 1), 256), 256, 0, s>>>(k, n_pairs, la);
     const int row_grid = pcacc_grid((int64_t)n_pairs * k * 64, 256);
     for (int it = 0; it < n_iters; ++it) {
         ego_sinkhorn_rows_kernel<<<row_grid, 256, 0, s>>>(k, n_pairs, la);
         ego_sinkhorn_cols_kernel<<<dim3((k + 63) / 64, n_pairs), 64 * EGO_CG, 0, s>>>(k, la);
     }
-    ego_rows_finish_kernel<<<row_grid, 256, 0, s>>>(la, coor_s, coor_t, thr2, k, n_pairs, perm, rowsum, wt);
+    ego_rows_finish_kernel<<<row_grid, 256, 0, s>>>(la, coor_s, coor_t, thr2, k, n_pairs, perm, rowsum, wt, k + 1);
     ego_kabsch_kernel<<<n_pairs, 256, 0, s>>>(coor_s, wt, rowsum, k, pose);
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
@@ -872,3 +870,144 @@ extern "C" int pcacc_svd3_backward(const float *u, const float *s, const float *
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
 }
+
+// ---- the same two stages for the TRAINING path (models/egomotion.py:169-184 under autograd) -------------------------------------------
+// The batched torch formulation spent ~17 element-wise passes over the [P, k, k] matrices (64 MB each at 16 x 1024^2) forward and as many
+// backward: square_distance's matmul / scale / shift / clamp, the affinity's sub / neg / div, exp, the support mask and its product, the
+// row sums and the soft targets -- about 1 ms of a 29 ms step.  Here: the affinity comes from the eval pipeline's tiled kernel (one write),
+// its backward is one pass producing d(dot) (the two feature gradients are then library GEMMs on it) plus the two scalar gradients; perm,
+// row sums and soft targets are one pass over the Sinkhorn result, their backward one pass as well.
+
+// d(dot) = 2 g / b where the clamp passed, partial sums of g and g * aff per workgroup (d softplus(alpha) = sum g / b, d denom = -sum g aff / b)
+__global__ __launch_bounds__(256) void ego_affinity_bwd_kernel(const float4 *__restrict__ g_aff, const float4 *__restrict__ aff, int64_t n4,
+                                                               const float *__restrict__ params, float4 *__restrict__ g_dot,
+                                                               double *__restrict__ partial, int tail)
+{
+    const float a = params[0], b = params[1];
+    const float two_over_b = 2.0f / b;
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (int64_t)gridDim.x * 256) {
+        const float4 g = g_aff[e], v = aff[e];
+        // aff = -(dist - a) / b  =>  dist = a - aff * b; the clamp at 1e-12 passes the gradient where the un-clamped distance was >= 1e-12
+        float4 o;
+        o.x = (a - v.x * b > 1e-12f) ? g.x * two_over_b : 0.f;
+        o.y = (a - v.y * b > 1e-12f) ? g.y * two_over_b : 0.f;
+        o.z = (a - v.z * b > 1e-12f) ? g.z * two_over_b : 0.f;
+        o.w = (a - v.w * b > 1e-12f) ? g.w * two_over_b : 0.f;
+        g_dot[e] = o;
+        s1 += (double)g.x + (double)g.y + (double)g.z + (double)g.w;
+        s2 += (double)g.x * v.x + (double)g.y * v.y + (double)g.z * v.z + (double)g.w * v.w;
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < tail) {            // the last n % 4 elements
+        const int64_t e = n4 * 4 + threadIdx.x;
+        const float g = reinterpret_cast<const float *>(g_aff)[e], v = reinterpret_cast<const float *>(aff)[e];
+        reinterpret_cast<float *>(g_dot)[e] = (a - v * b > 1e-12f) ? g * two_over_b : 0.f;
+        s1 += (double)g;
+        s2 += (double)g * v;
+    }
+    __shared__ double red[8];
+    s1 = block_sum256(s1, red);
+    s2 = block_sum256(s2, red);
+    if (threadIdx.x == 0) { partial[2 * blockIdx.x] = s1; partial[2 * blockIdx.x + 1] = s2; }
+}
+
+__global__ __launch_bounds__(256) void ego_affinity_bwd_final_kernel(const double *__restrict__ partial, int nb, const float *__restrict__ params,
+                                                                     float *__restrict__ g_params)
+{
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 256) { s1 += partial[2 * i]; s2 += partial[2 * i + 1]; }
+    __shared__ double red[8];
+    s1 = block_sum256(s1, red);
+    s2 = block_sum256(s2, red);
+    if (threadIdx.x == 0) {
+        const double b = params[1];
+        g_params[0] = (float)(s1 / b);
+        g_params[1] = (float)(-s2 / b);
+    }
+}
+
+// d(log_perm)[i, j] = perm[i, j] * (g_perm[i, j] + A_i + <B_i, ct_j>),  A_i = g_rowsum_i - <g_wt_i, wt_i> / (r_i + eps),  B_i = g_wt_i / (r_i + eps)
+// (perm = exp(log_perm) * support: the support mask carries no gradient and zero entries of perm give zero)
+__global__ __launch_bounds__(256) void ego_perm_bwd_kernel(const float *__restrict__ g_perm, const float *__restrict__ g_rowsum,
+                                                           const float *__restrict__ g_wt, const float *__restrict__ perm,
+                                                           const float *__restrict__ ct, const float *__restrict__ rowsum,
+                                                           const float *__restrict__ wt, int k, int n_pairs, float *__restrict__ g_lp)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t n_rows = (int64_t)n_pairs * k;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < n_rows; row += (int64_t)gridDim.x * 4) {
+        const int p = (int)(row / k);
+        const float *t = ct + (int64_t)p * k * 3;
+        const float den = rowsum[row] + 1e-20f;
+        float bx = 0.f, by = 0.f, bz = 0.f, a = g_rowsum ? g_rowsum[row] : 0.f;
+        if (g_wt) {
+            bx = g_wt[row * 3 + 0] / den; by = g_wt[row * 3 + 1] / den; bz = g_wt[row * 3 + 2] / den;
+            a -= bx * wt[row * 3 + 0] + by * wt[row * 3 + 1] + bz * wt[row * 3 + 2];
+        }
+        for (int j = lane; j < k; j += 64) {
+            const float g = (g_perm ? g_perm[row * k + j] : 0.f) + a + (bx * t[j * 3 + 0] + by * t[j * 3 + 1] + bz * t[j * 3 + 2]);
+            g_lp[row * k + j] = g * perm[row * k + j];
+        }
+    }
+}
+
+// affinity [P, k, k] = -(max(2 - 2 <fs_i, ft_j>, 1e-12) - params[0]) / params[1]   (params = softplus(alpha), exp(beta) + 0.02 on the device)
+extern "C" int pcacc_ego_affinity_forward(const float *feats_s, const float *feats_t, const float *params, int n_pairs, int k, int c,
+                                          float *affinity, void *stream)
+{
+    if (n_pairs < 1 || k < 1 || c < 1 || !feats_s || !feats_t || !params || !affinity) return PCACC_E_ARG;
+    const int tiles = (k + EGO_TILE - 1) / EGO_TILE;
+    ego_affinity_kernel<<<dim3(tiles, tiles, n_pairs), 256, 0, pcacc_stream(stream)>>>(feats_s, feats_t, k, c, params, affinity, k);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}
+
+extern "C" int pcacc_ego_affinity_backward_workspace_bytes(size_t *bytes)
+{
+    if (!bytes) return PCACC_E_ARG;
+    *bytes = (size_t)PCACC_CUS * 4 * 2 * sizeof(double);
+    return PCACC_OK;
+}
+
+// grad_dot [P, k, k] = d loss / d <fs_i, ft_j> (the feature gradients are grad_dot @ ft and grad_dot^T @ fs); grad_params [2]
+extern "C" int pcacc_ego_affinity_backward(const float *grad_affinity, const float *affinity, const float *params, int64_t n, float *grad_dot,
+                                           float *grad_params, void *workspace, size_t workspace_bytes, void *stream)
+{
+    size_t need;
+    pcacc_ego_affinity_backward_workspace_bytes(&need);
+    if (n < 1 || !grad_affinity || !affinity || !params || !grad_dot || !grad_params || !workspace) return PCACC_E_ARG;
+    if (workspace_bytes < need) return PCACC_E_WORKSPACE;
+    hipStream_t s = pcacc_stream(stream);
+    const int nb = pcacc_grid(n / 4 > 0 ? n / 4 : 1, 256, PCACC_CUS * 4);
+    double *partial = static_cast<double *>(workspace);
+    ego_affinity_bwd_kernel<<<nb, 256, 0, s>>>(reinterpret_cast<const float4 *>(grad_affinity), reinterpret_cast<const float4 *>(affinity), n / 4, params,
+                                               reinterpret_cast<float4 *>(grad_dot), partial, (int)(n % 4));
+    ego_affinity_bwd_final_kernel<<<1, 256, 0, s>>>(partial, nb, params, grad_params);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}
+
+// perm = exp(log_perm) * [ |cs_i - ct_j|^2 < thr2 ], rowsum [P, k], weighted_t [P, k, 3] = perm @ ct / (rowsum + 1e-20)   (egomotion.py:173-184)
+extern "C" int pcacc_ego_perm_forward(const float *log_perm, const float *coor_s, const float *coor_t, const float *thr2, int n_pairs, int k,
+                                      float *perm, float *rowsum, float *weighted_t, void *stream)
+{
+    if (n_pairs < 1 || k < 1 || !log_perm || !coor_s || !coor_t || !thr2 || !perm || !rowsum || !weighted_t) return PCACC_E_ARG;
+    const int row_grid = pcacc_grid((int64_t)n_pairs * k, 4, PCACC_CUS * 16);
+    ego_rows_finish_kernel<<<row_grid, 256, 0, pcacc_stream(stream)>>>(log_perm, coor_s, coor_t, thr2, k, n_pairs, perm, rowsum, weighted_t, k);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}
+
+// grad_log_perm from the gradients of the three results (any of them NULL = 0)
+extern "C" int pcacc_ego_perm_backward(const float *grad_perm, const float *grad_rowsum, const float *grad_weighted_t, const float *perm,
+                                       const float *coor_t, const float *rowsum, const float *weighted_t, int n_pairs, int k,
+                                       float *grad_log_perm, void *stream)
+{
+    if (n_pairs < 1 || k < 1 || !perm || !coor_t || !rowsum || !weighted_t || !grad_log_perm) return PCACC_E_ARG;
+    const int row_grid = pcacc_grid((int64_t)n_pairs * k, 4, PCACC_CUS * 16);
+    ego_perm_bwd_kernel<<<row_grid, 256, 0, pcacc_stream(stream)>>>(grad_perm, grad_rowsum, grad_weighted_t, perm, coor_t, rowsum, weighted_t, k,
+                                                                    n_pairs, grad_log_perm);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}
+

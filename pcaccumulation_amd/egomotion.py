@@ -9,6 +9,8 @@ torch.manual_seed gives the same key points.
 """
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -125,6 +127,10 @@ class EgoMotionHead(nn.Module):
         # 'device'   : the same uniform subset drawn with torch.randperm on the GPU generator (no 50 k-element host shuffle,
         #              1.8 ms each on the host, 32 of them per 4-sequence step).
         self.kpt_sampler = pe.get('kpt_sampler', 'reference')
+        # the matching stage around the Sinkhorn iterations as four kernels (csrc/ego.hip) instead of the batched torch formulation; default: with
+        # the device key-point sampler (the production configuration); the reference-sampler configuration keeps the formulation the
+        # parity fixtures were validated with (both are fp32; gradient norms downstream are chaotic at the per-cent level)
+        self.fused_matching = bool(pe.get('fused_matching', self.kpt_sampler == 'device'))
         self.seq_pose = pe['seq_pose']
         if self.seq_pose not in ('skip', 'chain', 'full'):
             raise NotImplementedError("pose_estimation.seq_pose='%s' (models/egomotion.py:53-61 knows skip / chain / full)" % self.seq_pose)
@@ -277,12 +283,19 @@ class EgoMotionHead(nn.Module):
                                                     self.sinkhorn_iter)
             return self._collect_pairs(sequences, T, perm, pose_est, perm_matrix_list, relative_pose_est_list,
                                        relative_pose_gt_list, chained_pose_est_list, chained_pose_gt_list)
-        support = (square_distance(coor_s, coor_t, normalised=False) < thr2[:, None, None]).float()     # :173-174
-        feat_dist = square_distance(feats_s, feats_t, normalised=True)                                   # :177
-        affinity = -(feat_dist - self.softplus(self.alpha)) / (torch.exp(self.beta) + 0.02)              # :180
-        perm = torch.exp(self.sinkhorn(affinity, n_iters=self.sinkhorn_iter, slack=self.slack)) * support
-        rowsum = torch.sum(perm, dim=2, keepdim=True)
-        weighted_t = perm @ coor_t / (rowsum + _EPS)
+        fused = self.fused_matching if os.environ.get('PCACC_EGO_FUSED') is None else os.environ['PCACC_EGO_FUSED'] != '0'
+        if fused and feats_s.is_cuda and self.slack and feats_s.dim() == 3:
+            # the matching stage around the Sinkhorn iterations as four kernels (csrc/ego.hip): the batched torch formulation below costs
+            # ~17 element-wise passes over the [P, k, k] matrices each way
+            affinity = ops.ego_affinity(feats_s, feats_t, self.softplus(self.alpha), torch.exp(self.beta) + 0.02)         # :177-180
+            perm, rowsum, weighted_t = ops.ego_perm(self.sinkhorn(affinity, n_iters=self.sinkhorn_iter, slack=True), coor_s, coor_t, thr2)
+        else:
+            support = (square_distance(coor_s, coor_t, normalised=False) < thr2[:, None, None]).float()     # :173-174
+            feat_dist = square_distance(feats_s, feats_t, normalised=True)                                   # :177
+            affinity = -(feat_dist - self.softplus(self.alpha)) / (torch.exp(self.beta) + 0.02)              # :180
+            perm = torch.exp(self.sinkhorn(affinity, n_iters=self.sinkhorn_iter, slack=self.slack)) * support
+            rowsum = torch.sum(perm, dim=2, keepdim=True)
+            weighted_t = perm @ coor_t / (rowsum + _EPS)
         R_est, t_est, _, _ = kabsch_transformation_estimation(coor_s, weighted_t, weights=rowsum[:, :, 0])
         P = R_est.shape[0]
         pose_est = torch.eye(4, device=dev, dtype=t_est.dtype).repeat(P, 1, 1)

@@ -49,6 +49,7 @@ EXPORTS = [
     'pcacc_cluster_workspace_bytes', 'pcacc_cluster', 'pcacc_conv3x3_prepare_weights', 'pcacc_conv3x3_bf16',
     'pcacc_rows_linear_bf16', 'pcacc_rows_linear_mixed', 'pcacc_rows_wgrad_mixed',
     'pcacc_segment_max_t', 'pcacc_segment_max_backward_t', 'pcacc_segment_max_backward_acc', 'pcacc_segment_sum_t', 'pcacc_rows_wgrad_bf16_workspace_bytes', 'pcacc_rows_wgrad_bf16', 'pcacc_sample_subsets', 'pcacc_conv3x3_wgrad_workspace_bytes', 'pcacc_conv3x3_wgrad_bf16', 'pcacc_upload_words', 'pcacc_bilinear_base_cells', 'pcacc_bilinear_sorted_workspace_bytes', 'pcacc_bilinear_gather_backward_sorted', 'pcacc_prep_points',
+    'pcacc_ego_affinity_forward', 'pcacc_ego_affinity_backward_workspace_bytes', 'pcacc_ego_affinity_backward', 'pcacc_ego_perm_forward', 'pcacc_ego_perm_backward',
     'pcacc_sinkhorn_train_workspace_bytes', 'pcacc_sinkhorn_forward', 'pcacc_sinkhorn_backward',
     'pcacc_seg_loss_workspace_bytes', 'pcacc_seg_loss_forward', 'pcacc_seg_loss_backward',
     'pcacc_offset_loss_workspace_bytes', 'pcacc_offset_loss_forward', 'pcacc_offset_loss_backward',
@@ -1357,6 +1358,52 @@ def pfn_block_split_dgrad(grad_out, grad_out_amax, xmask, hmask, w0, ws, w1, two
                                              _opt(gxb, torch.float32, 'grad_xb'), _dev(dh), _dev(gx_amax), _dev(dh_amax), _i64(rows), _stream()),
            'pfn_block_split_dgrad')
     return gxa, gxb, dh, gx_amax, dh_amax
+
+
+# ---- matching stage of the ego head under autograd (include/pcacc.h: pcacc_ego_affinity_* / pcacc_ego_perm_*) -------------------------
+def ego_affinity_forward(feats_s, feats_t, params):
+    """feats [P,k,c] f32 (L2-normalised rows), params [2] f32 = (softplus(alpha), exp(beta) + 0.02) -> affinity [P,k,k]."""
+    p, k, c = feats_s.shape
+    out = torch.empty((p, k, k), dtype=torch.float32, device=feats_s.device)
+    _check(lib().pcacc_ego_affinity_forward(_dev(feats_s, torch.float32, 'feats_s'), _dev(feats_t, torch.float32, 'feats_t'),
+                                            _dev(params, torch.float32, 'params'), int(p), int(k), int(c), _dev(out), _stream()), 'ego_affinity_forward')
+    return out
+
+
+def ego_affinity_backward(grad_aff, aff, params):
+    """-> (grad_dot [P,k,k], grad_params [2])."""
+    gd = torch.empty_like(aff)
+    gp = torch.empty((2,), dtype=torch.float32, device=aff.device)
+    need = ctypes.c_size_t(0)
+    _check(lib().pcacc_ego_affinity_backward_workspace_bytes(ctypes.byref(need)), 'ego_affinity_backward_workspace')
+    ws = _ws(need.value, aff.device)
+    _check(lib().pcacc_ego_affinity_backward(_dev(grad_aff, torch.float32, 'grad_affinity'), _dev(aff, torch.float32, 'affinity'),
+                                             _dev(params, torch.float32, 'params'), _i64(aff.numel()), _dev(gd), _dev(gp), _dev(ws),
+                                             ctypes.c_size_t(ws.numel()), _stream()), 'ego_affinity_backward')
+    return gd, gp
+
+
+def ego_perm_forward(log_perm, coor_s, coor_t, thr2):
+    """-> (perm [P,k,k], rowsum [P,k], weighted_t [P,k,3])."""
+    p, k, _ = log_perm.shape
+    dev = log_perm.device
+    perm = torch.empty_like(log_perm)
+    rowsum = torch.empty((p, k), dtype=torch.float32, device=dev)
+    wt = torch.empty((p, k, 3), dtype=torch.float32, device=dev)
+    _check(lib().pcacc_ego_perm_forward(_dev(log_perm, torch.float32, 'log_perm'), _dev(coor_s, torch.float32, 'coor_s'),
+                                        _dev(coor_t, torch.float32, 'coor_t'), _dev(thr2, torch.float32, 'thr2'), int(p), int(k), _dev(perm),
+                                        _dev(rowsum), _dev(wt), _stream()), 'ego_perm_forward')
+    return perm, rowsum, wt
+
+
+def ego_perm_backward(g_perm, g_rowsum, g_wt, perm, coor_t, rowsum, wt):
+    p, k, _ = perm.shape
+    out = torch.empty_like(perm)
+    _check(lib().pcacc_ego_perm_backward(_opt(g_perm, torch.float32, 'grad_perm'), _opt(g_rowsum, torch.float32, 'grad_rowsum'),
+                                         _opt(g_wt, torch.float32, 'grad_weighted_t'), _dev(perm, torch.float32, 'perm'),
+                                         _dev(coor_t, torch.float32, 'coor_t'), _dev(rowsum, torch.float32, 'rowsum'),
+                                         _dev(wt, torch.float32, 'weighted_t'), int(p), int(k), _dev(out), _stream()), 'ego_perm_backward')
+    return out
 
 
 def inv4x4(m):

@@ -1127,6 +1127,53 @@ class _Sinkhorn(torch.autograd.Function):
         return native.sinkhorn_backward(grad.contiguous().float(), log_alpha, lr, lc), None
 
 
+class _EgoAffinity(torch.autograd.Function):
+    """affinity = -(square_distance(fs, ft, normalised) - softplus(alpha)) / (exp(beta) + 0.02)  (models/egomotion.py:177-180) for P pairs:
+    one tiled kernel forward; backward = one pass giving d(dot) and the two scalar gradients + two library GEMMs for the features."""
+
+    @staticmethod
+    def forward(ctx, feats_s, feats_t, params):
+        fs, ft = feats_s.contiguous().float(), feats_t.contiguous().float()
+        aff = native.ego_affinity_forward(fs, ft, params)
+        ctx.save_for_backward(fs, ft, aff, params)
+        return aff
+
+    @staticmethod
+    def backward(ctx, g):
+        fs, ft, aff, params = ctx.saved_tensors
+        gd, gp = native.ego_affinity_backward(g.contiguous().float(), aff, params)
+        return torch.bmm(gd, ft), torch.bmm(gd.transpose(1, 2), fs), gp
+
+
+def ego_affinity(feats_s, feats_t, softplus_alpha, denom):
+    """feats [P,k,c] (rows L2-normalised by the caller), the two scalars as tensors -> [P,k,k]."""
+    params = torch.stack([softplus_alpha.reshape(()), denom.reshape(())]).float()
+    return _EgoAffinity.apply(feats_s, feats_t, params)
+
+
+class _EgoPerm(torch.autograd.Function):
+    """(perm, rowsum, weighted_t) of models/egomotion.py:173-184 from the Sinkhorn result in one pass each way (the support mask is
+    rebuilt from the coordinates inside the kernel; coordinates and thresholds carry no gradient)."""
+
+    @staticmethod
+    def forward(ctx, log_perm, coor_s, coor_t, thr2):
+        ct = coor_t.contiguous().float()
+        perm, rowsum, wt = native.ego_perm_forward(log_perm.contiguous().float(), coor_s.contiguous().float(), ct, thr2.contiguous().float())
+        ctx.save_for_backward(perm, ct, rowsum, wt)
+        return perm, rowsum.unsqueeze(2), wt
+
+    @staticmethod
+    def backward(ctx, g_perm, g_rowsum, g_wt):
+        perm, ct, rowsum, wt = ctx.saved_tensors
+        c = lambda t: t.contiguous().float() if t is not None else None
+        g = native.ego_perm_backward(c(g_perm), c(g_rowsum.squeeze(2)) if g_rowsum is not None else None, c(g_wt), perm, ct, rowsum, wt)
+        return g, None, None, None
+
+
+def ego_perm(log_perm, coor_s, coor_t, thr2):
+    return _EgoPerm.apply(log_perm, coor_s, coor_t, thr2)
+
+
 def sinkhorn(log_alpha, n_iters):
     return _Sinkhorn.apply(log_alpha, int(n_iters))
 

@@ -456,6 +456,49 @@ def test_pfn_features_vs_oracle_and_pfn_golden(native, dev, golden):
     np.testing.assert_allclose(out.cpu().numpy(), g['pfn_out'], rtol=1e-4, atol=5e-5)
 
 
+def test_ego_matching_stage_kernels(native, dev):
+    """models/egomotion.py:169-184 under autograd: ops.ego_affinity + ops.sinkhorn + ops.ego_perm (csrc/ego.hip) against the batched torch
+    formulation of the same lines in float64 -- values and the gradients of the features, of alpha / beta and through all three results."""
+    from pcaccumulation_amd import ops
+    from pcaccumulation_amd.egomotion import square_distance
+    torch.manual_seed(4)
+    P, k, c = 3, 257, 64
+    fs = torch.nn.functional.normalize(torch.randn(P, k, c, device=dev), dim=2).requires_grad_(True)
+    ft = torch.nn.functional.normalize(torch.randn(P, k, c, device=dev), dim=2).requires_grad_(True)
+    cs, ct = torch.randn(P, k, 3, device=dev) * 3, torch.randn(P, k, 3, device=dev) * 3
+    thr2 = torch.tensor([4.0, 9.0, 25.0], device=dev)
+    alpha, beta = torch.tensor(-1.0, device=dev, requires_grad=True), torch.tensor(-2.0, device=dev, requires_grad=True)
+    g_perm, g_rs, g_wt = torch.randn(P, k, k, device=dev), torch.randn(P, k, 1, device=dev), torch.randn(P, k, 3, device=dev)
+
+    def run(fused, dt):
+        a, b = torch.nn.functional.softplus(alpha.to(dt)), torch.exp(beta.to(dt)) + 0.02
+        if fused:
+            aff = ops.ego_affinity(fs, ft, a, b)
+            perm, rs, wt = ops.ego_perm(ops.sinkhorn(aff, 3), cs, ct, thr2)
+        else:
+            f1, f2 = fs.to(dt), ft.to(dt)
+            support = (square_distance(cs.to(dt), ct.to(dt)) < thr2.to(dt)[:, None, None]).to(dt)
+            aff = -(square_distance(f1, f2, normalised=True) - a) / b
+            la = torch.nn.functional.pad(aff, (0, 1, 0, 1))
+            for _ in range(3):
+                la = torch.cat((la[:, :-1, :] - torch.logsumexp(la[:, :-1, :], dim=2, keepdim=True), la[:, -1, None, :]), dim=1)
+                la = torch.cat((la[:, :, :-1] - torch.logsumexp(la[:, :, :-1], dim=1, keepdim=True), la[:, :, -1, None]), dim=2)
+            perm = torch.exp(la[:, :-1, :-1]) * support
+            rs = perm.sum(2, keepdim=True)
+            wt = perm @ ct.to(dt) / (rs + 1e-20)
+        loss = (perm * g_perm.to(dt)).sum() + (rs * g_rs.to(dt)).sum() + (wt * g_wt.to(dt)).sum()
+        grads = torch.autograd.grad(loss, [fs, ft, alpha, beta])
+        return [aff.detach(), perm.detach(), rs.detach(), wt.detach()] + [g.detach() for g in grads]
+    got, ref = run(True, torch.float32), run(False, torch.float64)
+    names = ['affinity', 'perm', 'rowsum', 'weighted_t', 'd feats_s', 'd feats_t', 'd alpha', 'd beta']
+    for n, a, b in zip(names, got, ref):
+        tol = 2e-5 if n in names[:4] else (2e-4 if n.startswith('d feats') else 2e-3)      # the scalar gradients are sums with cancellation over P k^2 fp32 terms
+        err = float((a.double() - b).abs().max() / b.abs().max().clamp_min(1e-30))
+        assert err <= tol, (n, err)
+    support_frac = float((ref[1] > 0).double().mean())
+    assert 0.02 < support_frac < 0.9                             # the masks are neither empty nor full: the support path is exercised
+
+
 # ---------------------------------------------------------------- A8 fused Sinkhorn + Kabsch (forward)
 def test_sinkhorn_kabsch_golden_pair(native, dev, golden):
     """The reference's pairwise_ego_motion_estimation output (tests/golden/ego.npz) for one pair, k = 64 key points."""

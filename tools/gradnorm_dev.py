@@ -1,0 +1,17 @@
+import os, sys, numpy as np, torch
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import test_config_parity as T
+from conftest import *  # noqa
+def golden(name):
+    return np.load('/root/repo/tests/golden/%s.npz' % name, allow_pickle=True)
+for cfgname in ('c3', 'c5'):
+    g = golden('model_' + cfgname)
+    for mode in ('fp32', 'fp32x3'):
+        model, inp, out, stats, Tn = T._run(g, mode)
+        grads = dict(model.named_parameters())
+        devs = []
+        for n, ref in zip([str(x) for x in g['grad_names']], g['grad_norms']):
+            got = float(grads[n].grad.norm()) if grads[n].grad is not None else 0.0
+            devs.append((abs(got - ref) / max(abs(ref), 1e-2), n))
+        devs.sort(reverse=True)
+        print(cfgname, mode, 'EGO_FUSED=%s' % os.environ.get('PCACC_EGO_FUSED', '1'), ' '.join('%s %.3f' % (n[-28:], d) for d, n in devs[:4]))
