@@ -292,18 +292,19 @@ int pcacc_sinkhorn_backward(const float *grad_log_perm, const float *log_alpha, 
  *  ego_affinity_forward   affinity [P,k,k] = -(max(2 - 2 <fs_i, ft_j>, 1e-12) - params[0]) / params[1]; feats [P,k,c] f32 (L2-normalised rows),
  *                         params [2] f32 on the device = (softplus(alpha), exp(beta) + 0.02)
  *  ego_affinity_backward  grad_dot [P,k,k] = d loss / d <fs_i, ft_j> (feature gradients: grad_dot @ ft, grad_dot^T @ fs), grad_params [2]
- *  ego_perm_forward       perm = exp(log_perm) * [ |cs_i - ct_j|^2 < thr2[p] ], rowsum [P,k], weighted_t [P,k,3] = perm @ ct / (rowsum + 1e-20)
- *  ego_perm_backward      grad_log_perm from the gradients of perm / rowsum / weighted_t (any of them NULL = 0) */
+ *  ego_perm_forward       perm = exp(log_perm) * [ |cs_i - ct_j|^2 < thr2[p] ], rowsum [P,k], weighted_t [P,k,3] = perm @ ct / (rowsum + 1e-20),
+ *                         colsum [P,k] (NULL = not wanted): with rowsum all the outlier loss (libs/outlier_loss.py) reads of perm
+ *  ego_perm_backward      grad_log_perm from the gradients of perm / rowsum / weighted_t / colsum (any of them NULL = 0) */
 int pcacc_ego_affinity_forward(const float *feats_s, const float *feats_t, const float *params, int n_pairs, int k, int c, float *affinity,
                                void *stream);
 int pcacc_ego_affinity_backward_workspace_bytes(size_t *bytes /*host*/);
 int pcacc_ego_affinity_backward(const float *grad_affinity, const float *affinity, const float *params, int64_t n, float *grad_dot,
                                 float *grad_params, void *workspace, size_t workspace_bytes, void *stream);
 int pcacc_ego_perm_forward(const float *log_perm, const float *coor_s, const float *coor_t, const float *thr2, int n_pairs, int k, float *perm,
-                           float *rowsum, float *weighted_t, void *stream);
-int pcacc_ego_perm_backward(const float *grad_perm, const float *grad_rowsum, const float *grad_weighted_t, const float *perm,
-                            const float *coor_t, const float *rowsum, const float *weighted_t, int n_pairs, int k, float *grad_log_perm,
-                            void *stream);
+                           float *rowsum, float *weighted_t, float *colsum, void *stream);
+int pcacc_ego_perm_backward(const float *grad_perm, const float *grad_rowsum, const float *grad_weighted_t, const float *grad_colsum,
+                            const float *perm, const float *coor_t, const float *rowsum, const float *weighted_t, int n_pairs, int k,
+                            float *grad_log_perm, void *stream);
 /* Batched 3x3 SVD of the Kabsch solve in the training path -- toolbox/register_utils.py:293 (`torch.svd(cov_mat)`):
  * a [n,3,3] f32 = u diag(s) v^T, s descending, no status word read back on the host.  backward: grad_a from the gradients of
  * u, s, v (any of them NULL = 0), closed form for distinct singular values. */

@@ -931,7 +931,8 @@ __global__ __launch_bounds__(256) void ego_affinity_bwd_final_kernel(const doubl
 __global__ __launch_bounds__(256) void ego_perm_bwd_kernel(const float *__restrict__ g_perm, const float *__restrict__ g_rowsum,
                                                            const float *__restrict__ g_wt, const float *__restrict__ perm,
                                                            const float *__restrict__ ct, const float *__restrict__ rowsum,
-                                                           const float *__restrict__ wt, int k, int n_pairs, float *__restrict__ g_lp)
+                                                           const float *__restrict__ wt, int k, int n_pairs, float *__restrict__ g_lp,
+                                                           const float *__restrict__ g_colsum)
 {
     const int lane = threadIdx.x & 63;
     const int64_t n_rows = (int64_t)n_pairs * k;
@@ -944,11 +945,29 @@ __global__ __launch_bounds__(256) void ego_perm_bwd_kernel(const float *__restri
             bx = g_wt[row * 3 + 0] / den; by = g_wt[row * 3 + 1] / den; bz = g_wt[row * 3 + 2] / den;
             a -= bx * wt[row * 3 + 0] + by * wt[row * 3 + 1] + bz * wt[row * 3 + 2];
         }
+        const float *gc = g_colsum ? g_colsum + (int64_t)p * k : nullptr;
         for (int j = lane; j < k; j += 64) {
-            const float g = (g_perm ? g_perm[row * k + j] : 0.f) + a + (bx * t[j * 3 + 0] + by * t[j * 3 + 1] + bz * t[j * 3 + 2]);
+            const float g = (g_perm ? g_perm[row * k + j] : 0.f) + (gc ? gc[j] : 0.f) + a + (bx * t[j * 3 + 0] + by * t[j * 3 + 1] + bz * t[j * 3 + 2]);
             g_lp[row * k + j] = g * perm[row * k + j];
         }
     }
+}
+
+// column sums of perm (the other half of the outlier loss, libs/outlier_loss.py): 64 columns x 4 row lanes per workgroup, fixed order
+__global__ __launch_bounds__(256) void ego_colsum_kernel(const float *__restrict__ perm, int k, float *__restrict__ colsum)
+{
+    __shared__ float red[4][64];
+    const int p = blockIdx.y, j = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const float *m = perm + (int64_t)p * k * k;
+    float s0 = 0.f, s1 = 0.f;
+    if (j < k) {
+        int i = rl;
+        for (; i + 4 < k; i += 8) { s0 += m[(int64_t)i * k + j]; s1 += m[(int64_t)(i + 4) * k + j]; }
+        if (i < k) s0 += m[(int64_t)i * k + j];
+    }
+    red[rl][threadIdx.x & 63] = s0 + s1;
+    __syncthreads();
+    if (rl == 0 && j < k) colsum[(int64_t)p * k + j] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // affinity [P, k, k] = -(max(2 - 2 <fs_i, ft_j>, 1e-12) - params[0]) / params[1]   (params = softplus(alpha), exp(beta) + 0.02 on the device)
@@ -987,26 +1006,28 @@ extern "C" int pcacc_ego_affinity_backward(const float *grad_affinity, const flo
     return PCACC_OK;
 }
 
-// perm = exp(log_perm) * [ |cs_i - ct_j|^2 < thr2 ], rowsum [P, k], weighted_t [P, k, 3] = perm @ ct / (rowsum + 1e-20)   (egomotion.py:173-184)
+// perm = exp(log_perm) * [ |cs_i - ct_j|^2 < thr2 ], rowsum [P, k], weighted_t [P, k, 3] = perm @ ct / (rowsum + 1e-20)   (egomotion.py:173-184);
+// colsum [P, k] (may be NULL): the column sums the outlier loss takes beside the row sums
 extern "C" int pcacc_ego_perm_forward(const float *log_perm, const float *coor_s, const float *coor_t, const float *thr2, int n_pairs, int k,
-                                      float *perm, float *rowsum, float *weighted_t, void *stream)
+                                      float *perm, float *rowsum, float *weighted_t, float *colsum, void *stream)
 {
     if (n_pairs < 1 || k < 1 || !log_perm || !coor_s || !coor_t || !thr2 || !perm || !rowsum || !weighted_t) return PCACC_E_ARG;
     const int row_grid = pcacc_grid((int64_t)n_pairs * k, 4, PCACC_CUS * 16);
     ego_rows_finish_kernel<<<row_grid, 256, 0, pcacc_stream(stream)>>>(log_perm, coor_s, coor_t, thr2, k, n_pairs, perm, rowsum, weighted_t, k);
+    if (colsum) ego_colsum_kernel<<<dim3((k + 63) / 64, n_pairs), 256, 0, pcacc_stream(stream)>>>(perm, k, colsum);
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
 }
 
 // grad_log_perm from the gradients of the three results (any of them NULL = 0)
-extern "C" int pcacc_ego_perm_backward(const float *grad_perm, const float *grad_rowsum, const float *grad_weighted_t, const float *perm,
-                                       const float *coor_t, const float *rowsum, const float *weighted_t, int n_pairs, int k,
+extern "C" int pcacc_ego_perm_backward(const float *grad_perm, const float *grad_rowsum, const float *grad_weighted_t, const float *grad_colsum,
+                                       const float *perm, const float *coor_t, const float *rowsum, const float *weighted_t, int n_pairs, int k,
                                        float *grad_log_perm, void *stream)
 {
     if (n_pairs < 1 || k < 1 || !perm || !coor_t || !rowsum || !weighted_t || !grad_log_perm) return PCACC_E_ARG;
     const int row_grid = pcacc_grid((int64_t)n_pairs * k, 4, PCACC_CUS * 16);
     ego_perm_bwd_kernel<<<row_grid, 256, 0, pcacc_stream(stream)>>>(grad_perm, grad_rowsum, grad_weighted_t, perm, coor_t, rowsum, weighted_t, k,
-                                                                    n_pairs, grad_log_perm);
+                                                                    n_pairs, grad_log_perm, grad_colsum);
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
 }

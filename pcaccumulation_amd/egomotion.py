@@ -83,8 +83,10 @@ def kabsch_transformation_estimation(x1, x2, weights=None, normalize_w=True, eps
 
 class PermList(list):
     """results['perm_matrix']: the per-pair [1,k,k] matrices of the reference (models/egomotion.py:352), plus the [P,k,k] tensor
-    they are slices of when one batched solve produced them all (`stacked`), so that the outlier loss is two reductions."""
+    they are slices of when one batched solve produced them all (`stacked`), so that the outlier loss is two reductions -- and, from the
+    fused matching kernels, the row / column sums of that tensor (`sums`), which are all the loss reads of it."""
     stacked = None
+    sums = None
 
 
 class _RowRef(object):
@@ -288,7 +290,9 @@ class EgoMotionHead(nn.Module):
             # the matching stage around the Sinkhorn iterations as four kernels (csrc/ego.hip): the batched torch formulation below costs
             # ~17 element-wise passes over the [P, k, k] matrices each way
             affinity = ops.ego_affinity(feats_s, feats_t, self.softplus(self.alpha), torch.exp(self.beta) + 0.02)         # :177-180
-            perm, rowsum, weighted_t = ops.ego_perm(self.sinkhorn(affinity, n_iters=self.sinkhorn_iter, slack=True), coor_s, coor_t, thr2)
+            perm, rowsum, weighted_t, colsum = ops.ego_perm(self.sinkhorn(affinity, n_iters=self.sinkhorn_iter, slack=True), coor_s, coor_t, thr2)
+            if isinstance(perm_matrix_list, PermList):
+                perm_matrix_list.sums = (rowsum[:, :, 0], colsum) if len(perm_matrix_list) == 0 else None     # all the outlier loss reads
         else:
             support = (square_distance(coor_s, coor_t, normalised=False) < thr2[:, None, None]).float()     # :173-174
             feat_dist = square_distance(feats_s, feats_t, normalised=True)                                   # :177

@@ -85,6 +85,9 @@ class OutlierLoss(object):
     """libs/outlier_loss.py: mean mass missing from the rows and columns of each permutation matrix."""
 
     def __call__(self, perm_matrix):
+        sums = getattr(perm_matrix, 'sums', None)
+        if sums is not None and getattr(perm_matrix, 'stacked', None) is not None:     # row sums [P,k] (dim 2) and column sums [P,k] (dim 1) from the kernel
+            return torch.mean(1.0 - sums[1]) + torch.mean(1.0 - sums[0])
         stacked = getattr(perm_matrix, 'stacked', None)
         if stacked is not None:                                            # equal-sized pairs: the means of the concatenations
             return torch.mean(1.0 - torch.sum(stacked, dim=1)) + torch.mean(1.0 - torch.sum(stacked, dim=2))

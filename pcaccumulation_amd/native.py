@@ -1384,25 +1384,27 @@ def ego_affinity_backward(grad_aff, aff, params):
 
 
 def ego_perm_forward(log_perm, coor_s, coor_t, thr2):
-    """-> (perm [P,k,k], rowsum [P,k], weighted_t [P,k,3])."""
+    """-> (perm [P,k,k], rowsum [P,k], weighted_t [P,k,3], colsum [P,k])."""
     p, k, _ = log_perm.shape
     dev = log_perm.device
     perm = torch.empty_like(log_perm)
     rowsum = torch.empty((p, k), dtype=torch.float32, device=dev)
+    colsum = torch.empty((p, k), dtype=torch.float32, device=dev)
     wt = torch.empty((p, k, 3), dtype=torch.float32, device=dev)
     _check(lib().pcacc_ego_perm_forward(_dev(log_perm, torch.float32, 'log_perm'), _dev(coor_s, torch.float32, 'coor_s'),
                                         _dev(coor_t, torch.float32, 'coor_t'), _dev(thr2, torch.float32, 'thr2'), int(p), int(k), _dev(perm),
-                                        _dev(rowsum), _dev(wt), _stream()), 'ego_perm_forward')
-    return perm, rowsum, wt
+                                        _dev(rowsum), _dev(wt), _dev(colsum), _stream()), 'ego_perm_forward')
+    return perm, rowsum, wt, colsum
 
 
-def ego_perm_backward(g_perm, g_rowsum, g_wt, perm, coor_t, rowsum, wt):
+def ego_perm_backward(g_perm, g_rowsum, g_wt, g_colsum, perm, coor_t, rowsum, wt):
     p, k, _ = perm.shape
     out = torch.empty_like(perm)
     _check(lib().pcacc_ego_perm_backward(_opt(g_perm, torch.float32, 'grad_perm'), _opt(g_rowsum, torch.float32, 'grad_rowsum'),
-                                         _opt(g_wt, torch.float32, 'grad_weighted_t'), _dev(perm, torch.float32, 'perm'),
-                                         _dev(coor_t, torch.float32, 'coor_t'), _dev(rowsum, torch.float32, 'rowsum'),
-                                         _dev(wt, torch.float32, 'weighted_t'), int(p), int(k), _dev(out), _stream()), 'ego_perm_backward')
+                                         _opt(g_wt, torch.float32, 'grad_weighted_t'), _opt(g_colsum, torch.float32, 'grad_colsum'),
+                                         _dev(perm, torch.float32, 'perm'), _dev(coor_t, torch.float32, 'coor_t'),
+                                         _dev(rowsum, torch.float32, 'rowsum'), _dev(wt, torch.float32, 'weighted_t'), int(p), int(k), _dev(out),
+                                         _stream()), 'ego_perm_backward')
     return out
 
 

@@ -1152,25 +1152,29 @@ def ego_affinity(feats_s, feats_t, softplus_alpha, denom):
 
 
 class _EgoPerm(torch.autograd.Function):
-    """(perm, rowsum, weighted_t) of models/egomotion.py:173-184 from the Sinkhorn result in one pass each way (the support mask is
-    rebuilt from the coordinates inside the kernel; coordinates and thresholds carry no gradient)."""
+    """(perm, rowsum, weighted_t, colsum) of models/egomotion.py:173-184 + libs/outlier_loss.py from the Sinkhorn result: one pass each way
+    plus a column-sum pass (the support mask is rebuilt from the coordinates inside the kernel; coordinates and thresholds carry no
+    gradient).  With the two sum vectors the outlier loss no longer touches the [P,k,k] matrix: its gradient -- a constant per row and
+    column -- reaches the backward kernel as two [P,k] vectors instead of a dense matrix built by expand + add."""
 
     @staticmethod
     def forward(ctx, log_perm, coor_s, coor_t, thr2):
         ct = coor_t.contiguous().float()
-        perm, rowsum, wt = native.ego_perm_forward(log_perm.contiguous().float(), coor_s.contiguous().float(), ct, thr2.contiguous().float())
+        perm, rowsum, wt, colsum = native.ego_perm_forward(log_perm.contiguous().float(), coor_s.contiguous().float(), ct, thr2.contiguous().float())
         ctx.save_for_backward(perm, ct, rowsum, wt)
-        return perm, rowsum.unsqueeze(2), wt
+        ctx.set_materialize_grads(False)
+        return perm, rowsum.unsqueeze(2), wt, colsum
 
     @staticmethod
-    def backward(ctx, g_perm, g_rowsum, g_wt):
+    def backward(ctx, g_perm, g_rowsum, g_wt, g_colsum):
         perm, ct, rowsum, wt = ctx.saved_tensors
         c = lambda t: t.contiguous().float() if t is not None else None
-        g = native.ego_perm_backward(c(g_perm), c(g_rowsum.squeeze(2)) if g_rowsum is not None else None, c(g_wt), perm, ct, rowsum, wt)
+        g = native.ego_perm_backward(c(g_perm), c(g_rowsum.squeeze(2)) if g_rowsum is not None else None, c(g_wt), c(g_colsum), perm, ct, rowsum, wt)
         return g, None, None, None
 
 
 def ego_perm(log_perm, coor_s, coor_t, thr2):
+    """-> (perm [P,k,k], rowsum [P,k,1], weighted_t [P,k,3], colsum [P,k])."""
     return _EgoPerm.apply(log_perm, coor_s, coor_t, thr2)
 
 

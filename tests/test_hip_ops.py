@@ -474,7 +474,7 @@ def test_ego_matching_stage_kernels(native, dev):
         a, b = torch.nn.functional.softplus(alpha.to(dt)), torch.exp(beta.to(dt)) + 0.02
         if fused:
             aff = ops.ego_affinity(fs, ft, a, b)
-            perm, rs, wt = ops.ego_perm(ops.sinkhorn(aff, 3), cs, ct, thr2)
+            perm, rs, wt, colsum = ops.ego_perm(ops.sinkhorn(aff, 3), cs, ct, thr2)
         else:
             f1, f2 = fs.to(dt), ft.to(dt)
             support = (square_distance(cs.to(dt), ct.to(dt)) < thr2.to(dt)[:, None, None]).to(dt)
@@ -486,13 +486,14 @@ def test_ego_matching_stage_kernels(native, dev):
             perm = torch.exp(la[:, :-1, :-1]) * support
             rs = perm.sum(2, keepdim=True)
             wt = perm @ ct.to(dt) / (rs + 1e-20)
-        loss = (perm * g_perm.to(dt)).sum() + (rs * g_rs.to(dt)).sum() + (wt * g_wt.to(dt)).sum()
+            colsum = perm.sum(1)
+        loss = (perm * g_perm.to(dt)).sum() + (rs * g_rs.to(dt)).sum() + (wt * g_wt.to(dt)).sum() + (colsum * g_rs[:, :, 0].to(dt).flip(1)).sum()
         grads = torch.autograd.grad(loss, [fs, ft, alpha, beta])
-        return [aff.detach(), perm.detach(), rs.detach(), wt.detach()] + [g.detach() for g in grads]
+        return [aff.detach(), perm.detach(), rs.detach(), wt.detach(), colsum.detach()] + [g.detach() for g in grads]
     got, ref = run(True, torch.float32), run(False, torch.float64)
-    names = ['affinity', 'perm', 'rowsum', 'weighted_t', 'd feats_s', 'd feats_t', 'd alpha', 'd beta']
+    names = ['affinity', 'perm', 'rowsum', 'weighted_t', 'colsum', 'd feats_s', 'd feats_t', 'd alpha', 'd beta']
     for n, a, b in zip(names, got, ref):
-        tol = 2e-5 if n in names[:4] else (2e-4 if n.startswith('d feats') else 2e-3)      # the scalar gradients are sums with cancellation over P k^2 fp32 terms
+        tol = 2e-5 if n in names[:5] else (2e-4 if n.startswith('d feats') else 2e-3)      # the scalar gradients are sums with cancellation over P k^2 fp32 terms
         err = float((a.double() - b).abs().max() / b.abs().max().clamp_min(1e-30))
         assert err <= tol, (n, err)
     support_frac = float((ref[1] > 0).double().mean())
