@@ -41,3 +41,28 @@ def test_lazy_results_behave_like_the_reference_dict():
     p = LazyDict(x=LazyValue(copy, 3, 4, lambda v: float(v[0])))
     assert p.pop('x') == 3.0 and 'x' not in p and p.pop('x', None) is None
     assert raw({'k': 1}, 'k') == 1                                            # plain dicts pass through
+
+
+def test_amax_tags_follow_views_and_versions():
+    """ops.amax_tag (the fp32x3 scale bookkeeping): a tag rides on the tensor object, a view inherits its base's tag (autograd hands data
+    gradients on as permuted views), an in-place write to either invalidates it, and dense() keeps it across a contiguous copy."""
+    from pcaccumulation_amd import ops
+    x = torch.randn(4, 6, 8)
+    parts = torch.zeros(256)
+    parts[3] = float(x.abs().max())
+    assert ops.amax_tag(x) is None
+    ops.set_amax_tag(x, parts)
+    assert ops.amax_tag(x) is parts
+    v = x.permute(0, 2, 1)
+    assert v._base is x and ops.amax_tag(v) is parts                      # a re-arrangement of the same elements
+    assert ops.amax_tag(x[:, :3]) is parts                                # a slice: the bound still holds
+    d = ops.dense(v)
+    assert d.is_contiguous() and d is not v and ops.amax_tag(d) is parts  # the tag survives the copy
+    assert ops.dense(x) is x
+    y = torch.randn(4, 6, 8)
+    assert ops.amax_tag(ops.carry_amax(x, y)) is parts
+    x.mul_(2.0)                                                           # a new version: neither the tensor nor its views may use the old bound
+    assert ops.amax_tag(x) is None and ops.amax_tag(v) is None and ops.amax_tag(x[:, :3]) is None
+    assert ops.amax_tag(d) is parts                                       # the copy made before the write keeps its own
+    m = ops.merge_amax(torch.randn(2), x, y)
+    assert ops.amax_tag(m) is None                                        # a source without a tag: nothing to merge
