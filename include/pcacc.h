@@ -396,6 +396,12 @@ int pcacc_conv3x3_deep_bf16(const uint16_t *in, const uint16_t *in_mask, const u
 int pcacc_conv3x3_masked_bf16(const uint16_t *in, const uint16_t *in_mask, const uint16_t *wp, const float *bias, uint16_t *out,
                               int32_t n_img, int32_t frames, int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t kt,
                               int32_t relu, void *stream);
+/* ReLU backward on the OUTPUT side of a data gradient: the convolution's result is stored as zero where out_mask [n_img,h,w,c_out] (the
+ * forward input of the layer, itself a ReLU output: models/unet.py:45-71 conv -> ReLU -> conv) is <= 0, so the producing layer needs no
+ * threshold pass.  No bias, no ReLU.  The layers the strip kernels would take are not supported (pcacc_conv3x3_outmask_supported = 0). */
+int pcacc_conv3x3_outmask_supported(int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t kt);
+int pcacc_conv3x3_outmask_bf16(const uint16_t *in, const uint16_t *wp, const uint16_t *out_mask, uint16_t *out, int32_t n_img, int32_t frames,
+                               int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t kt, void *stream);
 /* Weight gradient of the same deep layers (c_in, c_out multiples of 64, at least one of them > 64; kt = 1): dw [c_out][9][c_in] f32 and
  * db [c_out] f32 = bias gradient, from dy [n_img,h,w,c_out] and x [n_img,h,w,c_in] (bf16, channels-last).  64 x 64 blocks of the weight
  * tensor per workgroup, strips of consecutive pixels, per-workgroup partial slots in the workspace + a reduce launch. */

@@ -116,16 +116,42 @@ __device__ __forceinline__ void conv_pack_tile(const f32x16_t (&acc)[R][CT], con
 }
 
 // `row0` = first of the wave's R rows inside the tile, `co` = its first output channel
+// aten::threshold_backward(v, m, 0) on packed bf16 pairs: a half of v is dropped where the same half of m is <= 0 (zeros of either sign,
+// negative numbers, -inf); NaN compares false and keeps it, as the library does
+__device__ __forceinline__ uint32_t conv_mask2(uint32_t v, uint32_t m)
+{
+    auto drop = [](uint32_t h) { const uint32_t mag = h & 0x7fffu; return mag == 0u || ((h & 0x8000u) && mag <= 0x7f80u); };
+    const uint32_t lo = drop(m & 0xffffu) ? 0u : 0xffffu;
+    const uint32_t hi = drop(m >> 16) ? 0u : 0xffff0000u;
+    return v & (lo | hi);
+}
+
+// omask (may be NULL): a map of the output's shape; results are stored as zero where it is <= 0 -- the data gradient of a layer whose input
+// was a ReLU output leaves already masked for that ReLU (the producer then needs no threshold pass of its own)
 template <int R, int CT>
 __device__ __forceinline__ void conv_store_packed(const uint2 (&pk)[R][CT][4], uint16_t *__restrict__ out, int img, int y0, int x0, int h,
-                                                  int w, int c_out, int co, int row0, int lp, int lh)
+                                                  int w, int c_out, int co, int row0, int lp, int lh, const uint16_t *__restrict__ omask = nullptr)
 {
     const int x = x0 + lp;
 #pragma unroll
     for (int m = 0; m < R; ++m) {
         const int y = y0 + row0 + m;
         if (y >= h || x >= w) continue;
-        uint16_t *dst = out + (((int64_t)img * h + y) * w + x) * c_out + co;
+        const int64_t off = (((int64_t)img * h + y) * w + x) * c_out + co;
+        uint16_t *dst = out + off;
+        if (omask) {
+            uint2 mk[CT][4];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) mk[ct][g] = *reinterpret_cast<const uint2 *>(omask + off + ct * 32 + 8 * g + 4 * lh);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<uint2 *>(dst + ct * 32 + 8 * g + 4 * lh) = make_uint2(conv_mask2(pk[m][ct][g].x, mk[ct][g].x), conv_mask2(pk[m][ct][g].y, mk[ct][g].y));
+            continue;
+        }
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -136,11 +162,11 @@ __device__ __forceinline__ void conv_store_packed(const uint2 (&pk)[R][CT][4], u
 template <int CT>
 __device__ __forceinline__ void conv_store_tile(const f32x16_t (&acc)[2][CT], const float *__restrict__ bias, uint16_t *__restrict__ out,
                                                 int img, int y0, int x0, int h, int w, int c_out, int co0, int relu, int wave, int lp,
-                                                int lh)
+                                                int lh, const uint16_t *__restrict__ omask = nullptr)
 {
     uint2 pk[2][CT][4];
     conv_pack_tile<2, CT>(acc, bias ? bias + co0 : nullptr, relu, lh, pk);
-    conv_store_packed<2, CT>(pk, out, img, y0, x0, h, w, c_out, co0, 2 * wave, lp, lh);
+    conv_store_packed<2, CT>(pk, out, img, y0, x0, h, w, c_out, co0, 2 * wave, lp, lh, omask);
 }
 
 // ---- the convolution ------------------------------------------------------------------------------------------------------------
@@ -149,7 +175,8 @@ template <int CT, int CS>
 __global__ __launch_bounds__(CV_THREADS) void conv3x3_mfma_kernel(const uint16_t *__restrict__ in, const uint16_t *__restrict__ wp,
                                                                   const float *__restrict__ bias, uint16_t *__restrict__ out,
                                                                   int n_img, int frames, int h, int w, int c_in, int c_out, int kt,
-                                                                  int relu, int tiles_x, int tiles_y, int co_groups)
+                                                                  int relu, int tiles_x, int tiles_y, int co_groups,
+                                                                  const uint16_t *__restrict__ omask)
 {
     constexpr int PS = CS + 8;                                 // padded row length (elements) of both LDS images
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
@@ -239,7 +266,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_mfma_kernel(const uint16_t
         }
     }
 
-    conv_store_tile<CT>(acc, bias, out, img, y0, x0, h, w, c_out, co0, relu, wave, lp, lh);
+    conv_store_tile<CT>(acc, bias, out, img, y0, x0, h, w, c_out, co0, relu, wave, lp, lh, omask);
 }
 
 // All (tap, 16-channel) steps of one pass over a patch, as one straight line of code with the LDS fragment reads issued
@@ -286,7 +313,7 @@ template <int CT, int CS, int R, int CTW>
 __global__ __launch_bounds__(64 * (8 / R) * (CT / CTW)) __attribute__((amdgpu_waves_per_eu((CT == 1 && CS == 32 && R == 2) ? 3 : 1, (CT == 1 && CS == 32 && R == 2) ? 3 : 8)))
 void conv3x3_resident_kernel(
     const uint16_t *__restrict__ in, const uint16_t *__restrict__ wp, const float *__restrict__ bias, uint16_t *__restrict__ out,
-    int n_img, int frames, int h, int w, int c_out, int kt, int relu, int tiles_x, int tiles_y, int co_groups)
+    int n_img, int frames, int h, int w, int c_out, int kt, int relu, int tiles_x, int tiles_y, int co_groups, const uint16_t *__restrict__ omask)
 {
     constexpr int THREADS = 64 * (8 / R) * (CT / CTW);
     constexpr int PS = CS + 8;
@@ -350,7 +377,7 @@ void conv3x3_resident_kernel(
     };
     auto store_pending = [&](const uint2 (&pk)[R][CTW][4], int t) {
         const int img = t / (tiles_y * tiles_x), rem = t % (tiles_y * tiles_x);
-        conv_store_packed<R, CTW>(pk, out, img, (rem / tiles_x) * CV_TH, (rem % tiles_x) * CV_TW, h, w, c_out, co0 + cw0, row0, lp, lh);
+        conv_store_packed<R, CTW>(pk, out, img, (rem / tiles_x) * CV_TH, (rem % tiles_x) * CV_TW, h, w, c_out, co0 + cw0, row0, lp, lh, omask);
     };
 
     int tile = lo + slot, f = 0;
@@ -405,7 +432,7 @@ void conv3x3_resident_kernel(
 
 template <int CT, int CS, int R, int CTW>
 static int conv_launch_resident(const uint16_t *in, const uint16_t *wp, const float *bias, uint16_t *out, int n_img, int frames, int h,
-                                int w, int c_out, int kt, int relu, hipStream_t st)
+                                int w, int c_out, int kt, int relu, hipStream_t st, const uint16_t *omask = nullptr)
 {
     constexpr int THREADS = 64 * (8 / R) * (CT / CTW);
     const int tiles_x = (w + CV_TW - 1) / CV_TW, tiles_y = (h + CV_TH - 1) / CV_TH;
@@ -426,14 +453,14 @@ static int conv_launch_resident(const uint16_t *in, const uint16_t *wp, const fl
     if (slots < 1) slots = 1;
     const unsigned grid = (unsigned)(8 * co_groups * slots);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, st, in, wp, bias, out, n_img, frames, h, w, c_out, kt, relu, tiles_x,
-                       tiles_y, co_groups);
+                       tiles_y, co_groups, omask);
     PCACC_CHECK_LAUNCH();
     return 0;
 }
 
 template <int CT, int CS>
 static int conv_launch(const uint16_t *in, const uint16_t *wp, const float *bias, uint16_t *out, int n_img, int frames, int h, int w,
-                       int c_in, int c_out, int kt, int relu, hipStream_t st)
+                       int c_in, int c_out, int kt, int relu, hipStream_t st, const uint16_t *omask = nullptr)
 {
     const int tiles_x = (w + CV_TW - 1) / CV_TW, tiles_y = (h + CV_TH - 1) / CV_TH;
     const int co_groups = c_out / (CT * 32);
@@ -446,14 +473,14 @@ static int conv_launch(const uint16_t *in, const uint16_t *wp, const float *bias
     const int64_t blocks = (int64_t)n_img * tiles_y * tiles_x * co_groups;
     if (blocks > 0x7fffffff) return PCACC_E_ARG;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(CV_THREADS), lds, st, in, wp, bias, out, n_img, frames, h, w, c_in, c_out, kt,
-                       relu, tiles_x, tiles_y, co_groups);
+                       relu, tiles_x, tiles_y, co_groups, omask);
     PCACC_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int pcacc_conv3x3_bf16(const uint16_t *in, const uint16_t *wp, const float *bias, uint16_t *out, int32_t n_img,
-                                  int32_t frames, int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t kt, int32_t relu,
-                                  void *stream)
+static int conv3x3_bf16_any(const uint16_t *in, const uint16_t *wp, const float *bias, uint16_t *out, int32_t n_img,
+                            int32_t frames, int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t kt, int32_t relu,
+                            void *stream, const uint16_t *omask)
 {
     if (!in || !wp || !out || n_img < 1 || h < 1 || w < 1 || (kt != 1 && kt != 3) || frames < 1 || n_img % frames) return PCACC_E_ARG;
     if (c_in % 32 || c_out % 32 || c_in < 32 || c_out < 32) return PCACC_E_ARG;
@@ -466,7 +493,7 @@ extern "C" int pcacc_conv3x3_bf16(const uint16_t *in, const uint16_t *wp, const 
             if (lds > 150 * 1024) continue;
             const bool alone = lds > 80 * 1024;                    // one workgroup per CU: run it with 8 waves
 #define CV_RES(CTV, CSV, RV, CTWV) \
-    return conv_launch_resident<CTV, CSV, RV, CTWV>(in, wp, bias, out, n_img, frames, h, w, c_out, kt, relu, st)
+    return conv_launch_resident<CTV, CSV, RV, CTWV>(in, wp, bias, out, n_img, frames, h, w, c_out, kt, relu, st, omask)
             if (c_in == 32 && ctr == 1) { if (alone) CV_RES(1, 32, 1, 1); CV_RES(1, 32, 2, 1); }
             if (c_in == 32 && ctr == 2) { if (alone) CV_RES(2, 32, 2, 1); CV_RES(2, 32, 2, 2); }
             if (c_in == 32 && ctr == 4) { CV_RES(4, 32, 2, 2); }
@@ -476,17 +503,43 @@ extern "C" int pcacc_conv3x3_bf16(const uint16_t *in, const uint16_t *wp, const 
         }
     }
     // deep layers on small images: strips of consecutive pixels, K-deep tiling (conv_deep.hip)
-    if (kt == 1 && pcacc_conv3x3_deep_supported(h, w, c_in, c_out))
+    if (kt == 1 && pcacc_conv3x3_deep_supported(h, w, c_in, c_out)) {
+        if (omask) return PCACC_E_ARG;                             // the strip kernels take an input mask only (pcacc_conv3x3_outmask_supported)
         return pcacc_conv3x3_deep_bf16(in, nullptr, wp, bias, out, n_img, h, w, c_in, c_out, relu, stream);
+    }
     const int cs_sel = c_in % 128 == 0 ? 128 : (c_in % 64 == 0 ? 64 : 32);   // input channels per LDS pass
     const int ct = c_out % 128 == 0 ? 4 : (c_out % 64 == 0 ? 2 : 1);
 #define CV_CASE(CTV, CSV) \
-    if (ct == CTV && cs_sel == CSV) return conv_launch<CTV, CSV>(in, wp, bias, out, n_img, frames, h, w, c_in, c_out, kt, relu, st)
+    if (ct == CTV && cs_sel == CSV) return conv_launch<CTV, CSV>(in, wp, bias, out, n_img, frames, h, w, c_in, c_out, kt, relu, st, omask)
     CV_CASE(1, 32); CV_CASE(2, 32); CV_CASE(4, 32);
     CV_CASE(1, 64); CV_CASE(2, 64); CV_CASE(4, 64);
     CV_CASE(1, 128); CV_CASE(2, 128); CV_CASE(4, 128);
 #undef CV_CASE
     return PCACC_E_ARG;
+}
+
+extern "C" int pcacc_conv3x3_bf16(const uint16_t *in, const uint16_t *wp, const float *bias, uint16_t *out, int32_t n_img,
+                                  int32_t frames, int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t kt, int32_t relu,
+                                  void *stream)
+{
+    return conv3x3_bf16_any(in, wp, bias, out, n_img, frames, h, w, c_in, c_out, kt, relu, stream, nullptr);
+}
+
+// The same convolution with its result zeroed where out_mask [n_img, h, w, c_out] is <= 0: the data gradient of a layer whose forward input
+// was a ReLU output (models/unet.py:45-71 conv -> ReLU -> conv), masked for that ReLU in the epilogue instead of by a threshold pass
+// (three sweeps of the map).  Layers the strip kernels of conv_deep.hip would take are not supported (they mask on the input side).
+extern "C" int pcacc_conv3x3_outmask_supported(int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t kt)
+{
+    if (c_in % 32 || c_out % 32 || c_in < 32 || c_out < 32 || (kt != 1 && kt != 3)) return 0;
+    if (c_in == 32 || c_in == 64) return 1;                        // the resident kernels
+    return !(kt == 1 && pcacc_conv3x3_deep_supported(h, w, c_in, c_out));
+}
+
+extern "C" int pcacc_conv3x3_outmask_bf16(const uint16_t *in, const uint16_t *wp, const uint16_t *out_mask, uint16_t *out, int32_t n_img,
+                                          int32_t frames, int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t kt, void *stream)
+{
+    if (!out_mask || !pcacc_conv3x3_outmask_supported(h, w, c_in, c_out, kt)) return PCACC_E_ARG;
+    return conv3x3_bf16_any(in, wp, nullptr, out, n_img, frames, h, w, c_in, c_out, kt, 0, stream, out_mask);
 }
 
 // ReLU backward fused into the consumer of the gradient: only the deep (MFMA-bound) layers take it, where the second read is free.

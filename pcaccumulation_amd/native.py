@@ -61,7 +61,7 @@ EXPORTS = [
     'pcacc_tube_rows', 'pcacc_tube_code', 'pcacc_tube_code_backward', 'pcacc_tube_pose_forward', 'pcacc_tube_gap_forward', 'pcacc_tube_finish',
     'pcacc_tube_gap_backward', 'pcacc_tube_pose_backward', 'pcacc_rows_wgrad_few_supported', 'pcacc_rows_wgrad_few_workspace_bytes', 'pcacc_rows_wgrad_few',
     'pcacc_maxpool2x2_bf16', 'pcacc_pool_skip_relu_backward_bf16',
-    'pcacc_pfn_block_forward', 'pcacc_pfn_block_backward_workspace_bytes', 'pcacc_pfn_block_backward', 'pcacc_maxpool2x2_f32', 'pcacc_pool_skip_relu_backward_f32', 'pcacc_pool_skip_relu_backward_strided_bf16', 'pcacc_pool_skip_relu_backward_strided_f32', 'pcacc_bn_relu_rows_forward', 'pcacc_bn_relu_rows_backward', 'pcacc_pfn_block_split_forward', 'pcacc_pfn_block_split_dgrad', 'pcacc_inv4x4',
+    'pcacc_pfn_block_forward', 'pcacc_pfn_block_backward_workspace_bytes', 'pcacc_pfn_block_backward', 'pcacc_conv3x3_outmask_supported', 'pcacc_conv3x3_outmask_bf16', 'pcacc_maxpool2x2_f32', 'pcacc_pool_skip_relu_backward_f32', 'pcacc_pool_skip_relu_backward_strided_bf16', 'pcacc_pool_skip_relu_backward_strided_f32', 'pcacc_bn_relu_rows_forward', 'pcacc_bn_relu_rows_backward', 'pcacc_pfn_block_split_forward', 'pcacc_pfn_block_split_dgrad', 'pcacc_inv4x4',
     'pcacc_conv3x3_split_prepare_weights', 'pcacc_conv3x3_split_supported', 'pcacc_conv3x3_split', 'pcacc_conv3x3_wgrad_split_workspace_bytes',
     'pcacc_conv3x3_wgrad_split', 'pcacc_absmax256',
     'pcacc_rows_linear_split', 'pcacc_rows_linear_cat_split', 'pcacc_rows_wgrad_split_workspace_bytes', 'pcacc_rows_wgrad_split',
@@ -543,15 +543,27 @@ def conv3x3_prepare_weights_pair(weight):
     return fwd, bwd
 
 
-def conv3x3(x_rows, wp, bias, frames, relu, mask=None):
+def conv3x3_outmask_supported(h, w, c_in, c_out, kt=1):
+    return bool(lib().pcacc_conv3x3_outmask_supported(int(h), int(w), int(c_in), int(c_out), int(kt)))
+
+
+def conv3x3(x_rows, wp, bias, frames, relu, mask=None, out_mask=None):
     """x_rows bf16 [n_img,h,w,c_in] contiguous, wp from conv3x3_prepare_weights -> bf16 [n_img,h,w,c_out].
     mask (same shape as x_rows): x_rows is the gradient of a ReLU layer whose forward output is `mask`; elements where mask <= 0 are
-    read as zero (ReLU backward fused into the staging)."""
+    read as zero (ReLU backward fused into the staging).  out_mask (shape of the result; no bias / relu / mask with it): the result is
+    stored as zero where out_mask <= 0 (conv3x3_outmask_supported)."""
     n_img, h, w, c_in = x_rows.shape
     taps, c_out, wc_in = wp.shape
     if wc_in != c_in:
         raise NativeError('conv3x3: weights prepared for %d input channels, input has %d' % (wc_in, c_in))
     out = torch.empty((n_img, h, w, c_out), dtype=torch.bfloat16, device=x_rows.device)
+    if out_mask is not None:
+        if bias is not None or relu or mask is not None or tuple(out_mask.shape) != tuple(out.shape):
+            raise NativeError('conv3x3: out_mask goes with no bias / relu / input mask and has the shape of the result')
+        _check(lib().pcacc_conv3x3_outmask_bf16(_dev(x_rows, torch.bfloat16, 'x'), _dev(wp, torch.bfloat16, 'wp'),
+                                                _dev(out_mask, torch.bfloat16, 'out_mask'), _dev(out), int(n_img), int(frames), int(h), int(w),
+                                                int(c_in), int(c_out), taps // 9, _stream()), 'conv3x3_outmask')
+        return out
     if mask is not None and mask.shape != x_rows.shape:
         raise NativeError('conv3x3: mask shape %s != input shape %s' % (tuple(mask.shape), tuple(x_rows.shape)))
     _check(lib().pcacc_conv3x3_masked_bf16(_dev(x_rows, torch.bfloat16, 'x'), _dev(mask, torch.bfloat16, 'mask') if mask is not None else None,

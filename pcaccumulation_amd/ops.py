@@ -793,17 +793,19 @@ class _Conv3x3(torch.autograd.Function):
     transposed weights, weight and bias gradients with the library's backward-weights kernel (fp32 results)."""
 
     @staticmethod
-    def forward(ctx, x_rows, weight, bias, frames, relu, premasked=False):
+    def forward(ctx, x_rows, weight, bias, frames, relu, premasked=False, input_relu=False):
         y = native.conv3x3(x_rows, prepared_conv_weights(weight)[0], bias.detach().float() if bias is not None else None, frames, relu)
-        # premasked: every consumer of y hands back a gradient that is already zero where y <= 0 (pool_skip below): no ReLU pass here
+        # premasked: every consumer of y hands back a gradient that is already zero where y <= 0 (pool_skip below; a following layer
+        # called with input_relu): no ReLU pass here.  input_relu: x_rows is a ReLU output whose producer was called with premasked --
+        # the data gradient leaves masked where x_rows <= 0 (in the kernel's epilogue where it can, by a threshold pass otherwise)
         ctx.save_for_backward(x_rows, weight, y if relu and not premasked else None)
-        ctx.meta = (frames, relu and not premasked, bias is not None)
+        ctx.meta = (frames, relu and not premasked, bias is not None, bool(input_relu))
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x_rows, weight, y = ctx.saved_tensors
-        frames, relu, has_bias = ctx.meta
+        frames, relu, has_bias, input_relu = ctx.meta
         gy = gy.contiguous()
         gx = gw = gb = None
         kt = 3 if weight.dim() == 5 else 1
@@ -818,8 +820,13 @@ class _Conv3x3(torch.autograd.Function):
         mask = y if relu and (deep_w or not need_w) and (deep_d or not ctx.needs_input_grad[0]) else None
         if relu and mask is None:
             gy = torch.ops.aten.threshold_backward(gy, y, 0)
+        gx_masked = False
         if ctx.needs_input_grad[0] and not lib_dgrad:
-            gx = native.conv3x3(gy, prepared_conv_weights(weight)[1], None, frames, False, mask=mask)
+            if input_relu and mask is None and native.conv3x3_outmask_supported(h, w, o, i, kt):
+                gx = native.conv3x3(gy, prepared_conv_weights(weight)[1], None, frames, False, out_mask=x_rows)
+                gx_masked = True
+            else:
+                gx = native.conv3x3(gy, prepared_conv_weights(weight)[1], None, frames, False, mask=mask)
         if need_w and native.conv3x3_wgrad_supported(i, o):
             # weight gradient on the matrix cores too (one launch per frame tap); bias gradient = a column sum of dY
             if kt == 3:
@@ -844,14 +851,16 @@ class _Conv3x3(torch.autograd.Function):
                 gy.permute(0, 3, 1, 2), xin.permute(0, 3, 1, 2), w2.to(torch.bfloat16).contiguous(memory_format=torch.channels_last),
                 [o] if has_bias else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [lib_dgrad, need_w, has_bias and need_w])
             if lib_dgrad:
-                gx = gx2.permute(0, 2, 3, 1)
+                gx = gx2.permute(0, 2, 3, 1).contiguous()
             if need_w:
                 gw = gw2.float()
                 if kt == 3:
                     gw = gw.reshape(o, 3, i, 3, 3).permute(0, 2, 1, 3, 4)
                 gw = gw.reshape(weight.shape)
                 gb = gb2.float() if has_bias else None
-        return gx, gw, gb, None, None, None
+        if input_relu and gx is not None and not gx_masked:                               # the producer relies on it: mask here if the kernel did not
+            gx = torch.ops.aten.threshold_backward(gx, x_rows, 0)
+        return gx, gw, gb, None, None, None, None
 
 
 _PREPARED_SPLIT = {}
@@ -881,7 +890,8 @@ class _Conv3x3Split(torch.autograd.Function):
     the incoming gradient once for both backward kernels)."""
 
     @staticmethod
-    def forward(ctx, x_rows, weight, bias, frames, relu, premasked=False):
+    def forward(ctx, x_rows, weight, bias, frames, relu, premasked=False, input_relu=False):
+        assert not input_relu, 'the epilogue mask is a bf16-kernel feature (conv_pair_fusable)'
         x_amax = amax_of(x_rows)
         y, y_amax = native.conv3x3_split(x_rows, prepared_conv_weights_split(weight)[0], bias.detach().float() if bias is not None else None, frames,
                                          relu, amax=x_amax, want_amax=True)
@@ -915,7 +925,7 @@ class _Conv3x3Split(torch.autograd.Function):
                 gw = gw.view(o, 3, 3, i).permute(0, 3, 1, 2)
             gw = gw.to(weight.dtype)
             gb = gb if has_bias and ctx.needs_input_grad[2] else None
-        return gx, gw, gb, None, None, None
+        return gx, gw, gb, None, None, None, None
 
 
 _PREPARED_UP = {}
@@ -1040,16 +1050,16 @@ def conv3x3_available(x, weight):
     return None
 
 
-def conv3x3_rows(x_rows, weight, bias, frames=1, relu=False, premasked=False):
+def conv3x3_rows(x_rows, weight, bias, frames=1, relu=False, premasked=False, input_relu=False):
     """x_rows [n_img, H, W, C_in] -> [n_img, H, W, C_out] (bf16; f32 in the fp32x3 mode).  weight [O,I,3,3] (frames ignored) or [O,I,3,3,3]."""
     if _SPLIT and x_rows.dtype == torch.float32 and not torch.is_autocast_enabled():
         xc = x_rows.contiguous()
         if xc is not x_rows:
             carry_amax(x_rows, xc)
-        return _Conv3x3Split.apply(xc, weight, bias, int(frames), bool(relu), bool(premasked))
+        return _Conv3x3Split.apply(xc, weight, bias, int(frames), bool(relu), bool(premasked), bool(input_relu))
     if x_rows.dtype != torch.bfloat16:
         x_rows = x_rows.to(torch.bfloat16)
-    return _Conv3x3.apply(x_rows.contiguous(), weight, bias, int(frames), bool(relu), bool(premasked))
+    return _Conv3x3.apply(x_rows.contiguous(), weight, bias, int(frames), bool(relu), bool(premasked), bool(input_relu))
 
 
 def conv3x3_native(x, conv):
@@ -1059,9 +1069,20 @@ def conv3x3_native(x, conv):
     return None
 
 
-def conv3x3(x, conv, relu=False):
+def conv_pair_fusable(x, conv1, conv2):
+    """conv1 -> ReLU -> conv2 (models/unet.py:45-71) where the first ReLU's backward can ride in conv2's data-gradient epilogue: both layers on
+    the bf16 MFMA kernels.  The caller then passes premasked=True to conv1 and input_relu=True to conv2 -- conv1's output must have no
+    other consumer."""
+    if conv3x3_native(x, conv1) != 'bf16' or conv2.in_channels != conv1.out_channels:
+        return False
+    probe = torch.empty((0, conv1.out_channels, x.shape[-2], x.shape[-1]), dtype=torch.bfloat16, device=x.device)
+    return conv3x3_native(probe, conv2) == 'bf16'
+
+
+def conv3x3(x, conv, relu=False, premasked=False, input_relu=False):
     """`relu?(conv(x))` for an nn.Conv2d(3x3, stride 1, padding 1) on an NCHW tensor; channels-last bf16 inputs on the GPU go
-    through the MFMA kernel, everything else through the library with the same semantics."""
+    through the MFMA kernel, everything else through the library with the same semantics.  premasked / input_relu: see
+    conv_pair_fusable (only with it)."""
     if not relu and head_conv3x3_available(x, conv):            # c_out <= 4: the streamed fp32 kernels, f32 logits out
         return _HeadConv3x3.apply(x.permute(0, 2, 3, 1), conv.weight, conv.bias).permute(0, 3, 1, 2)
     mode = conv3x3_native(x, conv)
@@ -1069,8 +1090,9 @@ def conv3x3(x, conv, relu=False):
         xr = x.permute(0, 2, 3, 1)
         if mode == 'split' and xr.is_contiguous():
             set_amax_tag(xr, amax_of(x))                       # measured (or inherited) on the caller's tensor: its next reader finds it there
-        y = conv3x3_rows(xr, conv.weight, conv.bias, 1, relu)
+        y = conv3x3_rows(xr, conv.weight, conv.bias, 1, relu, premasked=premasked and mode == 'bf16', input_relu=input_relu and mode == 'bf16')
         return carry_amax(y, y.permute(0, 3, 1, 2))
+    assert not premasked and not input_relu
     y = conv(x)
     return torch.relu(y) if relu else y
 
@@ -1102,10 +1124,10 @@ class _PoolSkip(torch.autograd.Function):
         return native.pool_skip_relu_backward(y_rows, c(g_pool), gs)
 
 
-def conv3x3_relu_pool(x, conv):
+def conv3x3_relu_pool(x, conv, input_relu=False):
     """(max_pool2d(y, 2), y) with y = relu(conv(x)) -- the tail of models/unet.py:60-71 -- when conv3x3_native(x, conv) and the
     channel count suits the pooling kernel; the ReLU's backward is folded into the pooling's (one pass, see _PoolSkip)."""
-    y = conv3x3_rows(x.permute(0, 2, 3, 1), conv.weight, conv.bias, 1, True, premasked=True)
+    y = conv3x3_rows(x.permute(0, 2, 3, 1), conv.weight, conv.bias, 1, True, premasked=True, input_relu=input_relu)
     pooled, skip = _PoolSkip.apply(y)
     return pooled.permute(0, 3, 1, 2), skip.permute(0, 3, 1, 2)
 

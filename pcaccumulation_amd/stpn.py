@@ -52,14 +52,17 @@ class STPN(nn.Module):
         backward-weights path, which took 48 ms per layer on MI355X (profiles/r01_*)."""
         B, C, T, H, W = x.shape
         rows = ops.carry_amax(x, x.permute(0, 2, 3, 4, 1).contiguous())            # [B,T,H,W,C]; free for warp output
-        for layer in self.init_conv:
-            if not isinstance(layer, nn.Conv3d):
-                continue
+        convs = [l for l in self.init_conv if isinstance(l, nn.Conv3d)]
+        native = [ops.conv3x3_available(torch.empty((0, l.in_channels, H, W), dtype=rows.dtype, device=rows.device), l.weight)
+                  if l.kernel_size == (3, 3, 3) and l.padding == (1, 1, 1) else None for l in convs]
+        # bf16 chain: a layer's ReLU backward rides in the NEXT layer's data-gradient epilogue (ops.conv_pair_fusable's scheme along the chain)
+        chain = rows.dtype == torch.bfloat16 and all(n == 'bf16' for n in native)
+        for k, layer in enumerate(convs):
             cin = layer.in_channels
-            if ops.conv3x3_available(rows.view(B * T, H, W, cin).permute(0, 3, 1, 2), layer.weight) and layer.kernel_size == (3, 3, 3) \
-                    and layer.padding == (1, 1, 1):
+            if native[k]:
                 # bf16 / fp32x3 on the GPU: the MFMA kernels read frames t-1, t, t+1 in place (no channel-stacked copy)
-                y = ops.conv3x3_rows(ops.carry_amax(rows, rows.view(B * T, H, W, cin)), layer.weight, layer.bias, frames=T, relu=True)
+                y = ops.conv3x3_rows(ops.carry_amax(rows, rows.view(B * T, H, W, cin)), layer.weight, layer.bias, frames=T, relu=True,
+                                     premasked=chain and k + 1 < len(convs), input_relu=chain and k > 0)
                 rows = ops.carry_amax(y, y.view(B, T, H, W, layer.out_channels))
                 continue
             stacked = ops._stack_frames(rows.view(B * T, H, W, cin), T)                # [B*T,H,W,3C]

@@ -29,10 +29,11 @@ class DownConv(nn.Module):
             self.pool = nn.MaxPool2d(kernel_size=2, stride=2)
 
     def forward(self, x):
-        x = ops.conv3x3(x, self.conv1, relu=True)
+        pair = ops.conv_pair_fusable(x, self.conv1, self.conv2)   # bf16: conv1's ReLU backward in conv2's data-gradient epilogue
+        x = ops.conv3x3(x, self.conv1, relu=True, premasked=pair)
         if self.pooling and ops.conv3x3_native(x, self.conv2) in ('bf16', 'split') and self.out_channels % 8 == 0:
-            return ops.conv3x3_relu_pool(x, self.conv2)            # second conv + ReLU + pool, their backward in one pass (csrc/pool.hip)
-        x = ops.conv3x3(x, self.conv2, relu=True)
+            return ops.conv3x3_relu_pool(x, self.conv2, input_relu=pair)   # second conv + ReLU + pool, their backward in one pass (csrc/pool.hip)
+        x = ops.conv3x3(x, self.conv2, relu=True, input_relu=pair)
         return (ops.carry_amax(x, self.pool(x)) if self.pooling else x), x          # window maxima of x: x's bound holds (fp32x3 scales)
 
 
@@ -50,7 +51,8 @@ class UpConv(nn.Module):
     def forward(self, from_down, from_up):
         from_up = ops.upconv2x2(from_up, self.upconv)                   # fp32x3 mode: the 1-tap split kernels; else the library
         x = ops.merge_amax(torch.cat((from_up, from_down), 1), from_up, from_down) if self.merge_mode == 'concat' else from_up + from_down
-        return ops.conv3x3(ops.conv3x3(x, self.conv1, relu=True), self.conv2, relu=True)
+        pair = ops.conv_pair_fusable(x, self.conv1, self.conv2)
+        return ops.conv3x3(ops.conv3x3(x, self.conv1, relu=True, premasked=pair), self.conv2, relu=True, input_relu=pair)
 
 
 class UNet(nn.Module):

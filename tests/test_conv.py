@@ -109,6 +109,31 @@ def test_conv3x3_module_dispatch():
         native.conv3x3(torch.zeros(1, 8, 8, 32, dtype=torch.bfloat16), torch.zeros(9, 32, 32, dtype=torch.bfloat16), None, 1, False)
 
 
+@pytest.mark.parametrize('ci,co,kt,h,w', [(32, 32, 1, 19, 45), (64, 32, 1, 16, 40), (32, 64, 1, 33, 17), (64, 64, 1, 19, 45), (32, 32, 3, 16, 40),
+                                          (128, 64, 1, 20, 70)])
+def test_conv3x3_out_mask(ci, co, kt, h, w):
+    """pcacc_conv3x3_outmask_bf16 (the data gradient of conv -> ReLU -> conv masked for the first ReLU in the epilogue) == the plain kernel
+    followed by aten::threshold_backward, bit for bit -- zeros, negatives, NaN and inf in the mask included."""
+    b, t = 2, 3
+    g = torch.Generator(device='cpu').manual_seed(ci + 3 * co + kt)
+    gy = torch.randn(b * t, h, w, ci, generator=g).to(DEV).to(torch.bfloat16)
+    wt = torch.randn(*((co, ci, 3, 3, 3) if kt == 3 else (co, ci, 3, 3)), generator=g).to(DEV) / (3 * (ci * kt) ** 0.5)
+    wp = native.conv3x3_prepare_weights(wt)
+    x = torch.relu(torch.randn(b * t, h, w, co, generator=g)).to(DEV).to(torch.bfloat16)      # about half zeros, as a ReLU output is
+    x[0, 0, 0, :4] = torch.tensor([float('nan'), float('inf'), -1.0, -0.0], dtype=torch.bfloat16)
+    frames = t if kt == 3 else 1
+    if not native.conv3x3_outmask_supported(h, w, ci, co, kt):          # a layer of the strip kernels (they mask on the input side): refused, not ignored
+        assert ci >= 128
+        with pytest.raises(native.NativeError):
+            native.conv3x3(gy, wp, None, frames, False, out_mask=x)
+        return
+    plain = native.conv3x3(gy, wp, None, frames, False)
+    got = native.conv3x3(gy, wp, None, frames, False, out_mask=x)
+    want = torch.ops.aten.threshold_backward(plain, x, 0)
+    assert torch.equal(got, want)
+    assert float(got[0, 0, 0, 2]) == 0.0 and float(got[0, 0, 0, 3]) == 0.0 and torch.equal(got[0, 0, 0, :2], plain[0, 0, 0, :2])      # NaN <= 0 is false: kept
+
+
 @pytest.mark.parametrize('ci,co,kt', [(32, 32, 1), (64, 32, 1), (32, 64, 1), (64, 64, 1), (32, 32, 3)])
 def test_conv3x3_wgrad_kernel(ci, co, kt):
     """pcacc_conv3x3_wgrad_bf16 against the library's weight gradient on the same bf16 tensors (fp32 sums, different order)."""
