@@ -1,9 +1,10 @@
+"""Per-parameter deviation of the gradient norms of the c3 / c5 train fixtures from the reference golden values (fp32 and fp32x3); PCACC_EGO_FUSED=0/1\nselects the formulation of the ego matching stage.  Development aid."""
 import os, sys, numpy as np, torch
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import test_config_parity as T
 from conftest import *  # noqa
 def golden(name):
-    return np.load('/root/repo/tests/golden/%s.npz' % name, allow_pickle=True)
+    return np.load(os.path.join(ROOT, 'tests', 'golden', '%s.npz' % name), allow_pickle=True)
 for cfgname in ('c3', 'c5'):
     g = golden('model_' + cfgname)
     for mode in ('fp32', 'fp32x3'):
