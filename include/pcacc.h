@@ -434,6 +434,11 @@ int pcacc_conv3x3_split_supported(int32_t h, int32_t w, int32_t c_in, int32_t c_
 int pcacc_conv3x3_split(const float *in, const float *in_amax, const float *in_mask, const uint16_t *wp, const float *wscale,
                         const float *bias, float *out, float *out_amax, int32_t n_img, int32_t frames, int32_t h, int32_t w, int32_t c_in,
                         int32_t c_out, int32_t kt, int32_t relu, void *stream);
+/* The same convolution (no bias, no ReLU; in_mask as above) with its result stored as zero where out_mask [n_img,h,w,c_out] f32 is <= 0: the
+ * data gradient of conv -> ReLU -> conv masked for the first ReLU in the epilogue (the fp32x3 twin of pcacc_conv3x3_outmask_bf16). */
+int pcacc_conv3x3_split_outmask(const float *in, const float *in_amax, const float *in_mask, const uint16_t *wp, const float *wscale,
+                                const float *out_mask, float *out, float *out_amax, int32_t n_img, int32_t frames, int32_t h, int32_t w,
+                                int32_t c_in, int32_t c_out, int32_t kt, void *stream);
 int pcacc_conv3x3_wgrad_split_workspace_bytes(int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_out, size_t *bytes /*host*/);
 int pcacc_conv3x3_wgrad_split(const float *dy, const float *dy_amax, const float *dy_mask, const float *x, const float *x_amax, float *dw,
                               float *db, int32_t n_img, int32_t frames, int32_t dt, int32_t h, int32_t w, int32_t c_in, int32_t c_out,

@@ -210,6 +210,14 @@ extern "C" int pcacc_conv3x3_split_prepare_weights(const float *w, int32_t c_out
 #define CSP_UP 1
 #define CSP_S2D 2
 
+// relu == CSP_OUTMASK: no bias, no ReLU -- `bias` carries an fp32 map of the output's shape and the result is stored as zero where that map is
+// <= 0 (aten::threshold_backward semantics: NaN keeps): the data gradient of conv -> ReLU -> conv masked for the first ReLU where it is stored
+#define CSP_OUTMASK 2
+__device__ __forceinline__ float4 csp_outmask4(float4 v, float4 m)
+{
+    return make_float4(m.x <= 0.f ? 0.f : v.x, m.y <= 0.f ? 0.f : v.y, m.z <= 0.f ? 0.f : v.z, m.w <= 0.f ? 0.f : v.w);
+}
+
 template <int CS, int NW, int NGW, int MT, int TAPS>
 __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float *__restrict__ in, const float *__restrict__ in_amax,
                                                                     const float *__restrict__ in_mask, const uint16_t *__restrict__ wp,
@@ -429,12 +437,13 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float 
                     cb -= ab2 * c_up;
                     dst = out + (((int64_t)img * 2 * h + 2 * (pyx[j] >> 16) + (ab2 >> 1)) * 2 * w + 2 * (pyx[j] & 0xffff) + (ab2 & 1)) * c_up + cb - c;
                 }
-                if (bias) bv = *reinterpret_cast<const float4 *>(bias + cb);
+                if (bias && relu != CSP_OUTMASK) bv = *reinterpret_cast<const float4 *>(bias + cb);
                 float4 sc = *reinterpret_cast<const float4 *>(wscale + cw0 + c);          // 1 / t per output channel
                 sc = make_float4(sc.x * inv_sx, sc.y * inv_sx, sc.z * inv_sx, sc.w * inv_sx);
                 float4 v = make_float4(acc[j][n][4 * g] * sc.x + bv.x, acc[j][n][4 * g + 1] * sc.y + bv.y, acc[j][n][4 * g + 2] * sc.z + bv.z,
                                        acc[j][n][4 * g + 3] * sc.w + bv.w);
-                if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                if (relu == CSP_OUTMASK) v = csp_outmask4(v, *reinterpret_cast<const float4 *>(bias + ((dst + c) - out)));
+                else if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
                 *reinterpret_cast<float4 *>(dst + c) = v;
                 omax = fmaxf(fmaxf(omax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
                 if (!(v.x == v.x && v.y == v.y && v.z == v.z && v.w == v.w)) omax = __builtin_inff();
@@ -673,12 +682,15 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_res_kernel(const fl
                     for (int g = 0; g < 4; ++g) {
                         const int c = n * 32 + 8 * g + 4 * lh;
                         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (bias) bv = *reinterpret_cast<const float4 *>(bias + co0 + c);
+                        if (bias && relu != CSP_OUTMASK) bv = *reinterpret_cast<const float4 *>(bias + co0 + c);
                         float4 sc = *reinterpret_cast<const float4 *>(wscale + co0 + c);
                         sc = make_float4(sc.x * inv_sx, sc.y * inv_sx, sc.z * inv_sx, sc.w * inv_sx);
                         float4 v = make_float4(acc[j][n][4 * g] * sc.x + bv.x, acc[j][n][4 * g + 1] * sc.y + bv.y, acc[j][n][4 * g + 2] * sc.z + bv.z,
                                                acc[j][n][4 * g + 3] * sc.w + bv.w);
-                        if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                        if (relu == CSP_OUTMASK) {
+                            if (pyx[j] >= 0)
+                                v = csp_outmask4(v, *reinterpret_cast<const float4 *>(bias + (((int64_t)img * h + (pyx[j] >> 16)) * w + (pyx[j] & 0xffff)) * c_out + co0 + c));
+                        } else if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
                         pend[j][n][g] = v;
                         if (pyx[j] >= 0) {
                             omax = fmaxf(fmaxf(omax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
@@ -903,6 +915,15 @@ extern "C" int pcacc_conv3x3_split(const float *in, const float *in_amax, const 
     CSP_CASE(32, 1, 1, 1); CSP_CASE(32, 1, 1, 2); CSP_CASE(32, 1, 1, 3);
 #undef CSP_CASE
     return PCACC_E_ARG;
+}
+
+// the same convolution (no bias, no ReLU) with its result stored as zero where out_mask [n_img, h, w, c_out] f32 is <= 0 (see CSP_OUTMASK)
+extern "C" int pcacc_conv3x3_split_outmask(const float *in, const float *in_amax, const float *in_mask, const uint16_t *wp, const float *wscale,
+                                           const float *out_mask, float *out, float *out_amax, int32_t n_img, int32_t frames, int32_t h, int32_t w,
+                                           int32_t c_in, int32_t c_out, int32_t kt, void *stream)
+{
+    if (!out_mask) return PCACC_E_ARG;
+    return pcacc_conv3x3_split(in, in_amax, in_mask, wp, wscale, out_mask, out, out_amax, n_img, frames, h, w, c_in, c_out, kt, CSP_OUTMASK, stream);
 }
 
 // ---- weight gradient ------------------------------------------------------------------------------------------------------------------

@@ -61,7 +61,7 @@ EXPORTS = [
     'pcacc_tube_rows', 'pcacc_tube_code', 'pcacc_tube_code_backward', 'pcacc_tube_pose_forward', 'pcacc_tube_gap_forward', 'pcacc_tube_finish',
     'pcacc_tube_gap_backward', 'pcacc_tube_pose_backward', 'pcacc_rows_wgrad_few_supported', 'pcacc_rows_wgrad_few_workspace_bytes', 'pcacc_rows_wgrad_few',
     'pcacc_maxpool2x2_bf16', 'pcacc_pool_skip_relu_backward_bf16',
-    'pcacc_pfn_block_forward', 'pcacc_pfn_block_backward_workspace_bytes', 'pcacc_pfn_block_backward', 'pcacc_conv3x3_outmask_supported', 'pcacc_conv3x3_outmask_bf16', 'pcacc_maxpool2x2_f32', 'pcacc_pool_skip_relu_backward_f32', 'pcacc_pool_skip_relu_backward_strided_bf16', 'pcacc_pool_skip_relu_backward_strided_f32', 'pcacc_bn_relu_rows_forward', 'pcacc_bn_relu_rows_backward', 'pcacc_pfn_block_split_forward', 'pcacc_pfn_block_split_dgrad', 'pcacc_inv4x4',
+    'pcacc_pfn_block_forward', 'pcacc_pfn_block_backward_workspace_bytes', 'pcacc_pfn_block_backward', 'pcacc_conv3x3_split_outmask', 'pcacc_conv3x3_outmask_supported', 'pcacc_conv3x3_outmask_bf16', 'pcacc_maxpool2x2_f32', 'pcacc_pool_skip_relu_backward_f32', 'pcacc_pool_skip_relu_backward_strided_bf16', 'pcacc_pool_skip_relu_backward_strided_f32', 'pcacc_bn_relu_rows_forward', 'pcacc_bn_relu_rows_backward', 'pcacc_pfn_block_split_forward', 'pcacc_pfn_block_split_dgrad', 'pcacc_inv4x4',
     'pcacc_conv3x3_split_prepare_weights', 'pcacc_conv3x3_split_supported', 'pcacc_conv3x3_split', 'pcacc_conv3x3_wgrad_split_workspace_bytes',
     'pcacc_conv3x3_wgrad_split', 'pcacc_absmax256',
     'pcacc_rows_linear_split', 'pcacc_rows_linear_cat_split', 'pcacc_rows_wgrad_split_workspace_bytes', 'pcacc_rows_wgrad_split',
@@ -672,7 +672,7 @@ def conv3x3_split_prepare_weights(weight):
     return (fwd, sf), (bwd, sb)
 
 
-def conv3x3_split(x_rows, wps, bias, frames, relu, mask=None, amax=None, want_amax=False):
+def conv3x3_split(x_rows, wps, bias, frames, relu, mask=None, amax=None, want_amax=False, out_mask=None):
     """x_rows f32 [n_img,h,w,c_in] contiguous, wps = (planes, scale) from conv3x3_split_prepare_weights -> f32 [n_img,h,w,c_out]; mask as in
     conv3x3 (f32); amax = absmax256(x_rows) when the caller has it already.  want_amax: -> (out, absmax256 array of out), the maxima
     collected by the kernel's epilogue."""
@@ -688,6 +688,14 @@ def conv3x3_split(x_rows, wps, bias, frames, relu, mask=None, amax=None, want_am
         amax = absmax256(x_rows)
     out = torch.empty((n_img, h, w, c_out), dtype=torch.float32, device=x_rows.device)
     out_amax = _zero256(x_rows.device) if want_amax else None
+    if out_mask is not None:                                   # result zeroed where out_mask <= 0 (no bias / relu with it)
+        if bias is not None or relu or tuple(out_mask.shape) != tuple(out.shape):
+            raise NativeError('conv3x3_split: out_mask goes with no bias / relu and has the shape of the result')
+        _check(lib().pcacc_conv3x3_split_outmask(xp, _dev(amax, torch.float32, 'amax'), _dev(mask, torch.float32, 'mask') if mask is not None else None,
+                                                 _dev(wp, torch.float16, 'wp'), _dev(wscale, torch.float32, 'wscale'),
+                                                 _dev(out_mask, torch.float32, 'out_mask'), _dev(out), _dev(out_amax) if want_amax else None, int(n_img),
+                                                 int(frames), int(h), int(w), int(c_in), int(c_out), taps // 9, _stream()), 'conv3x3_split_outmask')
+        return (out, out_amax) if want_amax else out
     _check(lib().pcacc_conv3x3_split(xp, _dev(amax, torch.float32, 'amax'), _dev(mask, torch.float32, 'mask') if mask is not None else None,
                                      _dev(wp, torch.float16, 'wp'), _dev(wscale, torch.float32, 'wscale'),
                                      _dev(bias, torch.float32, 'bias') if bias is not None else None,

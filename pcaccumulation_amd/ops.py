@@ -891,20 +891,21 @@ class _Conv3x3Split(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x_rows, weight, bias, frames, relu, premasked=False, input_relu=False):
-        assert not input_relu, 'the epilogue mask is a bf16-kernel feature (conv_pair_fusable)'
         x_amax = amax_of(x_rows)
         y, y_amax = native.conv3x3_split(x_rows, prepared_conv_weights_split(weight)[0], bias.detach().float() if bias is not None else None, frames,
                                          relu, amax=x_amax, want_amax=True)
         set_amax_tag(y, y_amax)
-        # premasked: every consumer of y hands back a gradient that is already zero where y <= 0 (_PoolSkip): no mask reads in the backward
+        # premasked: every consumer of y hands back a gradient that is already zero where y <= 0 (_PoolSkip, a following layer called with
+        # input_relu): no mask reads in the backward.  input_relu: x_rows is a ReLU output whose producer was called with premasked -- the
+        # data gradient is stored masked where x_rows <= 0 (one read of x in the epilogue instead of two mask reads in the producer's backward)
         ctx.save_for_backward(x_rows, weight, y if relu and not premasked else None, x_amax)
-        ctx.meta = (frames, bias is not None)
+        ctx.meta = (frames, bias is not None, bool(input_relu))
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x_rows, weight, y, x_amax = ctx.saved_tensors
-        frames, has_bias = ctx.meta
+        frames, has_bias, input_relu = ctx.meta
         gy = dense(gy)
         if gy.dtype != torch.float32:
             gy = gy.float()
@@ -913,7 +914,8 @@ class _Conv3x3Split(torch.autograd.Function):
         o, i = weight.shape[0], weight.shape[1]
         g_amax = amax_of(gy)                                   # of the unmasked gradient: an upper bound is all the scale needs
         if ctx.needs_input_grad[0]:
-            gx, gx_amax = native.conv3x3_split(gy, prepared_conv_weights_split(weight)[1], None, frames, False, mask=y, amax=g_amax, want_amax=True)
+            gx, gx_amax = native.conv3x3_split(gy, prepared_conv_weights_split(weight)[1], None, frames, False, mask=y, amax=g_amax, want_amax=True,
+                                               out_mask=x_rows if input_relu else None)
             set_amax_tag(gx, gx_amax)
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             if kt == 3:
@@ -1071,12 +1073,13 @@ def conv3x3_native(x, conv):
 
 def conv_pair_fusable(x, conv1, conv2):
     """conv1 -> ReLU -> conv2 (models/unet.py:45-71) where the first ReLU's backward can ride in conv2's data-gradient epilogue: both layers on
-    the bf16 MFMA kernels.  The caller then passes premasked=True to conv1 and input_relu=True to conv2 -- conv1's output must have no
+    the bf16 MFMA kernels, or both on the fp32x3 kernels.  The caller then passes premasked=True to conv1 and input_relu=True to conv2 -- conv1's output must have no
     other consumer."""
-    if conv3x3_native(x, conv1) != 'bf16' or conv2.in_channels != conv1.out_channels:
+    mode = conv3x3_native(x, conv1)
+    if mode not in ('bf16', 'split') or conv2.in_channels != conv1.out_channels or os.environ.get('PCACC_CONV_PAIR', '1') == '0':      # A/B switch
         return False
-    probe = torch.empty((0, conv1.out_channels, x.shape[-2], x.shape[-1]), dtype=torch.bfloat16, device=x.device)
-    return conv3x3_native(probe, conv2) == 'bf16'
+    probe = torch.empty((0, conv1.out_channels, x.shape[-2], x.shape[-1]), dtype=torch.bfloat16 if mode == 'bf16' else torch.float32, device=x.device)
+    return conv3x3_native(probe, conv2) == mode
 
 
 def conv3x3(x, conv, relu=False, premasked=False, input_relu=False):
@@ -1090,7 +1093,7 @@ def conv3x3(x, conv, relu=False, premasked=False, input_relu=False):
         xr = x.permute(0, 2, 3, 1)
         if mode == 'split' and xr.is_contiguous():
             set_amax_tag(xr, amax_of(x))                       # measured (or inherited) on the caller's tensor: its next reader finds it there
-        y = conv3x3_rows(xr, conv.weight, conv.bias, 1, relu, premasked=premasked and mode == 'bf16', input_relu=input_relu and mode == 'bf16')
+        y = conv3x3_rows(xr, conv.weight, conv.bias, 1, relu, premasked=premasked, input_relu=input_relu)
         return carry_amax(y, y.permute(0, 3, 1, 2))
     assert not premasked and not input_relu
     y = conv(x)

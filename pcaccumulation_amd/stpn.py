@@ -1,5 +1,7 @@
 """Spatio-temporal motion head: host mirror of models/stpn.py (state_dict keys `init_conv.{0,2,4,6}`,
 `down_convs`, `up_convs`, `positional_encoding.{0,2}`, `final_proj.0`, `mos_seg`, `offset_head`)."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -55,8 +57,8 @@ class STPN(nn.Module):
         convs = [l for l in self.init_conv if isinstance(l, nn.Conv3d)]
         native = [ops.conv3x3_available(torch.empty((0, l.in_channels, H, W), dtype=rows.dtype, device=rows.device), l.weight)
                   if l.kernel_size == (3, 3, 3) and l.padding == (1, 1, 1) else None for l in convs]
-        # bf16 chain: a layer's ReLU backward rides in the NEXT layer's data-gradient epilogue (ops.conv_pair_fusable's scheme along the chain)
-        chain = rows.dtype == torch.bfloat16 and all(n == 'bf16' for n in native)
+        # bf16 / fp32x3 chain: a layer's ReLU backward rides in the NEXT layer's data-gradient epilogue (ops.conv_pair_fusable's scheme along the chain)
+        chain = (all(n == 'bf16' for n in native) or all(n == 'split' for n in native)) and os.environ.get('PCACC_CONV_PAIR', '1') != '0'
         for k, layer in enumerate(convs):
             cin = layer.in_channels
             if native[k]:

@@ -269,3 +269,28 @@ def test_upconv2x2_split(n, h, w, ci, cu):
     assert _rel(y, yr.detach()) <= TOL and _rel(x.grad, xr.grad) <= TOL
     assert _rel(conv.weight.grad, c64.weight.grad) <= TOL and _rel(conv.bias.grad, c64.bias.grad) <= TOL
     assert float(ops.amax_tag(y).max()) == float(y.abs().max())
+
+
+@pytest.mark.parametrize('ci,co,kt,h,w,res', [(32, 32, 1, 24, 40, '2'), (32, 32, 1, 24, 40, '0'), (64, 32, 1, 17, 33, '2'), (32, 64, 1, 20, 36, '0'),
+                                              (32, 32, 3, 16, 40, '2'), (128, 64, 1, 18, 18, '0')])
+def test_conv_split_out_mask(ci, co, kt, h, w, res, monkeypatch):
+    """pcacc_conv3x3_split_outmask: the data gradient stored as zero where the mask map is <= 0 == the plain kernel followed by
+    aten::threshold_backward, bit for bit (streaming and resident kernels, with and without the input-side mask); the reported maximum
+    is that of the masked result."""
+    monkeypatch.setenv('PCACC_CONV_RES', res)
+    b, t = 2, 3
+    g = torch.Generator(device='cpu').manual_seed(ci + 5 * co + kt)
+    gy = torch.randn(b * t, h, w, ci, generator=g).to(DEV)
+    y = torch.relu(torch.randn(b * t, h, w, ci, generator=g)).to(DEV)
+    wt = torch.randn(*((co, ci, 3, 3, 3) if kt == 3 else (co, ci, 3, 3)), generator=g).to(DEV) / (3 * (ci * kt) ** 0.5)
+    wf, _ = native.conv3x3_split_prepare_weights(wt)
+    x = torch.relu(torch.randn(b * t, h, w, co, generator=g)).to(DEV)
+    x[0, 0, 0, :3] = torch.tensor([float('nan'), -1.0, -0.0])
+    frames = t if kt == 3 else 1
+    am = native.absmax256(gy)
+    for mask in (None, y):
+        plain = native.conv3x3_split(gy, wf, None, frames, False, mask=mask, amax=am)
+        got, got_amax = native.conv3x3_split(gy, wf, None, frames, False, mask=mask, amax=am, want_amax=True, out_mask=x)
+        want = torch.ops.aten.threshold_backward(plain, x, 0)
+        assert torch.equal(got, want)
+        assert float(got_amax.max()) == float(want[torch.isfinite(want)].abs().max()) or not torch.isfinite(want).all()
