@@ -654,7 +654,6 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_res_kernel(const fl
 #pragma unroll
             for (int st = 0; st < STEPS; ++st) {
                 if (st + AHEAD < STEPS) load((st + AHEAD) % (AHEAD + 1), st + AHEAD);
-                constexpr int DUMMY = 0; (void)DUMMY;
                 const int c = st % (AHEAD + 1);
 #pragma unroll
                 for (int j = 0; j < MT; ++j)

@@ -52,20 +52,19 @@ def wrap(name, fn):
 
 
 def timed(name, fn, a, k):
-    if True:
-        torch.cuda.synchronize()
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda._sleep(600_000)                              # ~0.3 ms of spinning: the host issues the whole call behind it
-        s.record()
-        r = fn(*a, **k)
-        e.record()
-        torch.cuda.synchronize()
-        ins = list(tensors(a)) + list(tensors(list(k.values())))
-        outs = list(tensors(r))
-        nbytes = sum(t.numel() * t.element_size() for t in ins + outs)
-        desc = ' '.join('%s%s' % (str(t.dtype).replace('torch.', '')[:4], tuple(t.shape)) for t in ins[:4])
-        calls.append((name, desc, s.elapsed_time(e) * 1e3, nbytes))
-        return r
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda._sleep(600_000)                              # ~0.3 ms of spinning: the host issues the whole call behind it
+    s.record()
+    r = fn(*a, **k)
+    e.record()
+    torch.cuda.synchronize()
+    ins = list(tensors(a)) + list(tensors(list(k.values())))
+    outs = list(tensors(r))
+    nbytes = sum(t.numel() * t.element_size() for t in ins + outs)
+    desc = ' '.join('%s%s' % (str(t.dtype).replace('torch.', '')[:4], tuple(t.shape)) for t in ins[:4])
+    calls.append((name, desc, s.elapsed_time(e) * 1e3, nbytes))
+    return r
 
 
 skip = {'lib', 'upload_small'}
