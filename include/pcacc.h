@@ -305,6 +305,14 @@ int pcacc_ego_perm_forward(const float *log_perm, const float *coor_s, const flo
 int pcacc_ego_perm_backward(const float *grad_perm, const float *grad_rowsum, const float *grad_weighted_t, const float *grad_colsum,
                             const float *perm, const float *coor_t, const float *rowsum, const float *weighted_t, int n_pairs, int k,
                             float *grad_log_perm, void *stream);
+/* Weighted Kabsch in front of its 3x3 SVD, under autograd (toolbox/register_utils.py:263-291), P pairs at once: weights w [P,k] normalised by
+ * (sum w + 1e-7), weighted means m1, m2 [P,3] of x1, x2 [P,k,3] (divided by sum wn + 1e-7), covariance cov [P,3,3] of the centred clouds;
+ * norm [P,2] = the two normalisers, kept for the backward.  backward: grad_x2, grad_w (x1 -- pillar means -- carries no gradient). */
+int pcacc_kabsch_cov_forward(const float *x1, const float *x2, const float *w, int n_pairs, int k, float *cov, float *m1, float *m2, float *norm,
+                             void *stream);
+int pcacc_kabsch_cov_backward(const float *x1, const float *x2, const float *w, const float *m1, const float *m2, const float *norm,
+                              const float *grad_cov, const float *grad_m1, const float *grad_m2, int n_pairs, int k, float *grad_x2,
+                              float *grad_w, void *stream);
 /* Batched 3x3 SVD of the Kabsch solve in the training path -- toolbox/register_utils.py:293 (`torch.svd(cov_mat)`):
  * a [n,3,3] f32 = u diag(s) v^T, s descending, no status word read back on the host.  backward: grad_a from the gradients of
  * u, s, v (any of them NULL = 0), closed form for distinct singular values. */

@@ -1032,3 +1032,143 @@ extern "C" int pcacc_ego_perm_backward(const float *grad_perm, const float *grad
     return PCACC_OK;
 }
 
+// ---- weighted Kabsch, the part in front of the 3x3 SVD, under autograd (toolbox/register_utils.py:263-291) -----------------------------------
+// weights w [P,k] -> normalised wn = w / (sum w + 1e-7), wsum = sum wn + 1e-7, weighted means m1, m2 of x1, x2 [P,k,3], covariance
+// cov[a][b] = sum_i (x1_i - m1)[a] wn_i (x2_i - m2)[b].  One workgroup per pair, sums in float64.  The batched torch formulation is ~15 small
+// launches forward and ~35 backward on [16, 1024, 3] tensors.
+template <int N>
+__device__ __forceinline__ void kb_block_sums(double (&v)[N], double *red /*[4 * N]*/)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) v[i] += __shfl_xor(v[i], d, 64);
+    __syncthreads();
+    if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < N; ++i) red[w * N + i] = v[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = red[i] + red[N + i] + red[2 * N + i] + red[3 * N + i];
+}
+
+__global__ __launch_bounds__(256) void kabsch_cov_fwd_kernel(const float *__restrict__ x1, const float *__restrict__ x2, const float *__restrict__ w,
+                                                             int k, float *__restrict__ cov, float *__restrict__ m1o, float *__restrict__ m2o,
+                                                             float *__restrict__ norm /*[P][2] = W, wsum*/)
+{
+    __shared__ double red[4 * 9];
+    const int p = blockIdx.x;
+    x1 += (int64_t)p * k * 3; x2 += (int64_t)p * k * 3; w += (int64_t)p * k;
+    double a1[1] = {0.0};
+    for (int i = threadIdx.x; i < k; i += 256) a1[0] += w[i];
+    kb_block_sums<1>(a1, red);
+    const double W = a1[0] + 1e-7;
+    double a7[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int i = threadIdx.x; i < k; i += 256) {
+        const double wn = w[i] / W;
+        a7[0] += wn;
+        a7[1] += wn * x1[i * 3 + 0]; a7[2] += wn * x1[i * 3 + 1]; a7[3] += wn * x1[i * 3 + 2];
+        a7[4] += wn * x2[i * 3 + 0]; a7[5] += wn * x2[i * 3 + 1]; a7[6] += wn * x2[i * 3 + 2];
+    }
+    kb_block_sums<7>(a7, red);
+    const double wsum = a7[0] + 1e-7;
+    const double m1[3] = {a7[1] / wsum, a7[2] / wsum, a7[3] / wsum}, m2[3] = {a7[4] / wsum, a7[5] / wsum, a7[6] / wsum};
+    double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = threadIdx.x; i < k; i += 256) {
+        const double wn = w[i] / W;
+        const double c1[3] = {x1[i * 3 + 0] - m1[0], x1[i * 3 + 1] - m1[1], x1[i * 3 + 2] - m1[2]};
+        const double c2[3] = {wn * (x2[i * 3 + 0] - m2[0]), wn * (x2[i * 3 + 1] - m2[1]), wn * (x2[i * 3 + 2] - m2[2])};
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) c[a * 3 + b] += c1[a] * c2[b];
+    }
+    kb_block_sums<9>(c, red);
+    if (threadIdx.x < 9) cov[p * 9 + threadIdx.x] = (float)c[threadIdx.x];
+    if (threadIdx.x < 3) { m1o[p * 3 + threadIdx.x] = (float)m1[threadIdx.x]; m2o[p * 3 + threadIdx.x] = (float)m2[threadIdx.x]; }
+    if (threadIdx.x == 0) { norm[p * 2] = (float)W; norm[p * 2 + 1] = (float)wsum; }
+}
+
+// gradients of x2 and w from those of cov, m1, m2 (x1 carries none: pillar means)
+__global__ __launch_bounds__(256) void kabsch_cov_bwd_kernel(const float *__restrict__ x1, const float *__restrict__ x2, const float *__restrict__ w,
+                                                             const float *__restrict__ m1i, const float *__restrict__ m2i,
+                                                             const float *__restrict__ norm, const float *__restrict__ g_cov,
+                                                             const float *__restrict__ g_m1, const float *__restrict__ g_m2, int k,
+                                                             float *__restrict__ g_x2, float *__restrict__ g_w)
+{
+    __shared__ double red[4 * 6];
+    const int p = blockIdx.x;
+    x1 += (int64_t)p * k * 3; x2 += (int64_t)p * k * 3; w += (int64_t)p * k;
+    g_x2 += (int64_t)p * k * 3; g_w += (int64_t)p * k;
+    const double W = norm[p * 2], wsum = norm[p * 2 + 1];
+    double m1[3], m2[3], gc[9], gm1[3], gm2[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        m1[d] = m1i[p * 3 + d]; m2[d] = m2i[p * 3 + d];
+        gm1[d] = g_m1 ? g_m1[p * 3 + d] : 0.f; gm2[d] = g_m2 ? g_m2[p * 3 + d] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 9; ++e) gc[e] = g_cov ? g_cov[p * 9 + e] : 0.f;
+    // phase 1: sum_i g_c1_i, sum_i g_c2_i -> totals on the means
+    double s[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = threadIdx.x; i < k; i += 256) {
+        const double wn = w[i] / W;
+        const double c1[3] = {x1[i * 3 + 0] - m1[0], x1[i * 3 + 1] - m1[1], x1[i * 3 + 2] - m1[2]};
+        const double c2[3] = {x2[i * 3 + 0] - m2[0], x2[i * 3 + 1] - m2[1], x2[i * 3 + 2] - m2[2]};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) s[a] += wn * (gc[a * 3 + 0] * c2[0] + gc[a * 3 + 1] * c2[1] + gc[a * 3 + 2] * c2[2]);      // g_c1_i[a]
+#pragma unroll
+        for (int b = 0; b < 3; ++b) s[3 + b] += wn * (gc[0 * 3 + b] * c1[0] + gc[1 * 3 + b] * c1[1] + gc[2 * 3 + b] * c1[2]);  // g_c2_i[b]
+    }
+    kb_block_sums<6>(s, red);
+    const double G1[3] = {gm1[0] - s[0], gm1[1] - s[1], gm1[2] - s[2]}, G2[3] = {gm2[0] - s[3], gm2[1] - s[4], gm2[2] - s[5]};
+    const double g_wsum = -((m1[0] * G1[0] + m1[1] * G1[1] + m1[2] * G1[2]) + (m2[0] * G2[0] + m2[1] * G2[1] + m2[2] * G2[2])) / wsum;
+    auto g_wn = [&](int i) {
+        const double c1[3] = {x1[i * 3 + 0] - m1[0], x1[i * 3 + 1] - m1[1], x1[i * 3 + 2] - m1[2]};
+        const double c2[3] = {x2[i * 3 + 0] - m2[0], x2[i * 3 + 1] - m2[1], x2[i * 3 + 2] - m2[2]};
+        double g = 0.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) g += gc[a * 3 + b] * c1[a] * c2[b];
+        g += ((double)x2[i * 3 + 0] * G2[0] + (double)x2[i * 3 + 1] * G2[1] + (double)x2[i * 3 + 2] * G2[2]) / wsum;
+        g += ((double)x1[i * 3 + 0] * G1[0] + (double)x1[i * 3 + 1] * G1[1] + (double)x1[i * 3 + 2] * G1[2]) / wsum;
+        return g + g_wsum;
+    };
+    // phase 2: sum_j g_wn_j w_j (the normalisation w / (sum w + eps))
+    double t[1] = {0.0};
+    for (int i = threadIdx.x; i < k; i += 256) t[0] += g_wn(i) * w[i];
+    kb_block_sums<1>(t, red);
+    // phase 3: the results
+    for (int i = threadIdx.x; i < k; i += 256) {
+        const double wn = w[i] / W;
+        const double c1[3] = {x1[i * 3 + 0] - m1[0], x1[i * 3 + 1] - m1[1], x1[i * 3 + 2] - m1[2]};
+        g_w[i] = (float)(g_wn(i) / W - t[0] / (W * W));
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+            g_x2[i * 3 + b] = (float)(wn * (gc[0 * 3 + b] * c1[0] + gc[1 * 3 + b] * c1[1] + gc[2 * 3 + b] * c1[2]) + wn * G2[b] / wsum);
+    }
+}
+
+// cov [P,3,3], m1 / m2 [P,3] (the weighted means), norm [P,2] (kept for the backward) from x1, x2 [P,k,3] and the weights w [P,k]
+extern "C" int pcacc_kabsch_cov_forward(const float *x1, const float *x2, const float *w, int n_pairs, int k, float *cov, float *m1, float *m2,
+                                        float *norm, void *stream)
+{
+    if (n_pairs < 1 || k < 1 || !x1 || !x2 || !w || !cov || !m1 || !m2 || !norm) return PCACC_E_ARG;
+    kabsch_cov_fwd_kernel<<<n_pairs, 256, 0, pcacc_stream(stream)>>>(x1, x2, w, k, cov, m1, m2, norm);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}
+
+// grad_x2 [P,k,3], grad_w [P,k] from the gradients of cov / m1 / m2 (any of them NULL = 0)
+extern "C" int pcacc_kabsch_cov_backward(const float *x1, const float *x2, const float *w, const float *m1, const float *m2, const float *norm,
+                                         const float *grad_cov, const float *grad_m1, const float *grad_m2, int n_pairs, int k, float *grad_x2,
+                                         float *grad_w, void *stream)
+{
+    if (n_pairs < 1 || k < 1 || !x1 || !x2 || !w || !m1 || !m2 || !norm || !grad_x2 || !grad_w) return PCACC_E_ARG;
+    kabsch_cov_bwd_kernel<<<n_pairs, 256, 0, pcacc_stream(stream)>>>(x1, x2, w, m1, m2, norm, grad_cov, grad_m1, grad_m2, k, grad_x2, grad_w);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}
+

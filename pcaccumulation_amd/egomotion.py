@@ -50,8 +50,17 @@ def get_relative_pose_torch(tsfm_src, tsfm_tgt, dataset):
     return torch.linalg.solve_ex(tsfm_tgt, tsfm_src)[0]          # solve() without the singularity check (a host sync per call)
 
 
-def kabsch_transformation_estimation(x1, x2, weights=None, normalize_w=True, eps=1e-7, best_k=0, w_threshold=0):
-    """toolbox/register_utils.py:247-317 (best_k = 0, w_threshold = 0 path).  Returns (R [b,3,3], t [b,3,1], res, flag)."""
+def kabsch_transformation_estimation(x1, x2, weights=None, normalize_w=True, eps=1e-7, best_k=0, w_threshold=0, fused=False):
+    """toolbox/register_utils.py:247-317 (best_k = 0, w_threshold = 0 path).  Returns (R [b,3,3], t [b,3,1], res, flag).
+    fused (GPU, weights given, x1 without gradient): means and covariance from ops.kabsch_cov -- one kernel each way; res is not computed."""
+    if fused and weights is not None and normalize_w and eps == 1e-7 and x1.is_cuda and not x1.requires_grad:
+        cov_mat, x1_mean, x2_mean = ops.kabsch_cov(x1, x2, weights)
+        u, s, v = ops.svd3(cov_mat)
+        det = torch.det(torch.matmul(v.transpose(1, 2), u.transpose(1, 2)))
+        dmat = torch.diag_embed(torch.cat((torch.ones((det.shape[0], 2), device=x1.device), det.unsqueeze(1)), 1))
+        rotation = torch.matmul(v, torch.matmul(dmat, u.transpose(1, 2)))
+        translation = x2_mean.transpose(1, 2) - torch.matmul(rotation, x1_mean.transpose(1, 2))
+        return rotation, translation, None, False
     if weights is None:
         weights = torch.ones(x1.shape[0], x1.shape[1]).type_as(x1).to(x1.device)
     if normalize_w:
@@ -300,7 +309,7 @@ class EgoMotionHead(nn.Module):
             perm = torch.exp(self.sinkhorn(affinity, n_iters=self.sinkhorn_iter, slack=self.slack)) * support
             rowsum = torch.sum(perm, dim=2, keepdim=True)
             weighted_t = perm @ coor_t / (rowsum + _EPS)
-        R_est, t_est, _, _ = kabsch_transformation_estimation(coor_s, weighted_t, weights=rowsum[:, :, 0])
+        R_est, t_est, _, _ = kabsch_transformation_estimation(coor_s, weighted_t, weights=rowsum[:, :, 0], fused=fused)
         P = R_est.shape[0]
         pose_est = torch.eye(4, device=dev, dtype=t_est.dtype).repeat(P, 1, 1)
         pose_est[:, :3, :3] = R_est

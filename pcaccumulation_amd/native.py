@@ -49,7 +49,7 @@ EXPORTS = [
     'pcacc_cluster_workspace_bytes', 'pcacc_cluster', 'pcacc_conv3x3_prepare_weights', 'pcacc_conv3x3_bf16',
     'pcacc_rows_linear_bf16', 'pcacc_rows_linear_mixed', 'pcacc_rows_wgrad_mixed',
     'pcacc_segment_max_t', 'pcacc_segment_max_backward_t', 'pcacc_segment_max_backward_acc', 'pcacc_segment_sum_t', 'pcacc_rows_wgrad_bf16_workspace_bytes', 'pcacc_rows_wgrad_bf16', 'pcacc_sample_subsets', 'pcacc_conv3x3_wgrad_workspace_bytes', 'pcacc_conv3x3_wgrad_bf16', 'pcacc_upload_words', 'pcacc_bilinear_base_cells', 'pcacc_bilinear_sorted_workspace_bytes', 'pcacc_bilinear_gather_backward_sorted', 'pcacc_prep_points',
-    'pcacc_ego_affinity_forward', 'pcacc_ego_affinity_backward_workspace_bytes', 'pcacc_ego_affinity_backward', 'pcacc_ego_perm_forward', 'pcacc_ego_perm_backward',
+    'pcacc_kabsch_cov_forward', 'pcacc_kabsch_cov_backward', 'pcacc_ego_affinity_forward', 'pcacc_ego_affinity_backward_workspace_bytes', 'pcacc_ego_affinity_backward', 'pcacc_ego_perm_forward', 'pcacc_ego_perm_backward',
     'pcacc_sinkhorn_train_workspace_bytes', 'pcacc_sinkhorn_forward', 'pcacc_sinkhorn_backward',
     'pcacc_seg_loss_workspace_bytes', 'pcacc_seg_loss_forward', 'pcacc_seg_loss_backward',
     'pcacc_offset_loss_workspace_bytes', 'pcacc_offset_loss_forward', 'pcacc_offset_loss_backward',
@@ -1426,6 +1426,28 @@ def ego_perm_backward(g_perm, g_rowsum, g_wt, g_colsum, perm, coor_t, rowsum, wt
                                          _dev(rowsum, torch.float32, 'rowsum'), _dev(wt, torch.float32, 'weighted_t'), int(p), int(k), _dev(out),
                                          _stream()), 'ego_perm_backward')
     return out
+
+
+def kabsch_cov_forward(x1, x2, w):
+    """x1, x2 [P,k,3], w [P,k] f32 -> (cov [P,3,3], m1 [P,3], m2 [P,3], norm [P,2])."""
+    p, k, _ = x1.shape
+    dev = x1.device
+    f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    cov, m1, m2, norm = f(p, 3, 3), f(p, 3), f(p, 3), f(p, 2)
+    _check(lib().pcacc_kabsch_cov_forward(_dev(x1, torch.float32, 'x1'), _dev(x2, torch.float32, 'x2'), _dev(w, torch.float32, 'w'), int(p), int(k),
+                                          _dev(cov), _dev(m1), _dev(m2), _dev(norm), _stream()), 'kabsch_cov_forward')
+    return cov, m1, m2, norm
+
+
+def kabsch_cov_backward(x1, x2, w, m1, m2, norm, g_cov, g_m1, g_m2):
+    p, k, _ = x1.shape
+    gx2 = torch.empty_like(x2)
+    gw = torch.empty_like(w)
+    _check(lib().pcacc_kabsch_cov_backward(_dev(x1, torch.float32, 'x1'), _dev(x2, torch.float32, 'x2'), _dev(w, torch.float32, 'w'),
+                                           _dev(m1, torch.float32, 'm1'), _dev(m2, torch.float32, 'm2'), _dev(norm, torch.float32, 'norm'),
+                                           _opt(g_cov, torch.float32, 'grad_cov'), _opt(g_m1, torch.float32, 'grad_m1'),
+                                           _opt(g_m2, torch.float32, 'grad_m2'), int(p), int(k), _dev(gx2), _dev(gw), _stream()), 'kabsch_cov_backward')
+    return gx2, gw
 
 
 def inv4x4(m):

@@ -1203,6 +1203,32 @@ def ego_perm(log_perm, coor_s, coor_t, thr2):
     return _EgoPerm.apply(log_perm, coor_s, coor_t, thr2)
 
 
+class _KabschCov(torch.autograd.Function):
+    """(cov, x1_mean, x2_mean) of the weighted Kabsch solve (toolbox/register_utils.py:263-291) for P pairs: one kernel each way instead of
+    ~15 + ~35 small launches on [P,k,3] tensors.  x1 (pillar means) carries no gradient."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, w):
+        x1, x2, w = x1.contiguous().float(), x2.contiguous().float(), w.contiguous().float()
+        cov, m1, m2, norm = native.kabsch_cov_forward(x1, x2, w)
+        ctx.save_for_backward(x1, x2, w, m1, m2, norm)
+        ctx.set_materialize_grads(False)
+        return cov, m1.unsqueeze(1), m2.unsqueeze(1)
+
+    @staticmethod
+    def backward(ctx, g_cov, g_m1, g_m2):
+        x1, x2, w, m1, m2, norm = ctx.saved_tensors
+        c = lambda t: t.contiguous().float() if t is not None else None
+        gx2, gw = native.kabsch_cov_backward(x1, x2, w, m1, m2, norm, c(g_cov), c(g_m1.squeeze(1)) if g_m1 is not None else None,
+                                             c(g_m2.squeeze(1)) if g_m2 is not None else None)
+        return None, gx2, gw
+
+
+def kabsch_cov(x1, x2, w):
+    """-> (cov [P,3,3], x1_mean [P,1,3], x2_mean [P,1,3])."""
+    return _KabschCov.apply(x1, x2, w)
+
+
 def sinkhorn(log_alpha, n_iters):
     return _Sinkhorn.apply(log_alpha, int(n_iters))
 

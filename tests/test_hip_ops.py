@@ -500,6 +500,44 @@ def test_ego_matching_stage_kernels(native, dev):
     assert 0.02 < support_frac < 0.9                             # the masks are neither empty nor full: the support path is exercised
 
 
+def test_kabsch_cov_kernels(native, dev):
+    """ops.kabsch_cov (weighted means and covariance of toolbox/register_utils.py:263-291, one kernel each way) and the fused branch of
+    kabsch_transformation_estimation against the batched torch formulation in float64: values, gradients of x2 and of the weights."""
+    from pcaccumulation_amd import ops
+    from pcaccumulation_amd.egomotion import kabsch_transformation_estimation
+    torch.manual_seed(6)
+    P, k = 5, 300
+    x1 = torch.randn(P, k, 3, device=dev) * 5
+    rot = torch.linalg.qr(torch.randn(P, 3, 3, device=dev))[0]
+    x2 = (x1 @ rot.transpose(1, 2) + torch.randn(P, 1, 3, device=dev) + 0.05 * torch.randn(P, k, 3, device=dev)).requires_grad_(True)
+    w = torch.rand(P, k, device=dev).requires_grad_(True)
+    g_cov, g_m1, g_m2 = torch.randn(P, 3, 3, device=dev), torch.randn(P, 1, 3, device=dev), torch.randn(P, 1, 3, device=dev)
+
+    def ref(dt):
+        a, b, ww = x1.to(dt), x2.to(dt), w.to(dt)
+        wn = (ww / (ww.sum(1, keepdim=True) + 1e-7)).unsqueeze(2)
+        wsum = wn.sum(1).unsqueeze(1) + 1e-7
+        m1, m2 = wn.transpose(1, 2) @ a / wsum, wn.transpose(1, 2) @ b / wsum
+        cov = (a - m1).transpose(1, 2) @ (wn * (b - m2))
+        return cov, m1, m2
+    cov, m1, m2 = ops.kabsch_cov(x1, x2, w)
+    got = torch.autograd.grad((cov * g_cov).sum() + (m1 * g_m1).sum() + (m2 * g_m2).sum(), [x2, w])
+    rc, rm1, rm2 = ref(torch.float64)
+    want = torch.autograd.grad((rc * g_cov.double()).sum() + (rm1 * g_m1.double()).sum() + (rm2 * g_m2.double()).sum(), [x2, w])
+    rel = lambda a, b: float((a.double() - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    assert rel(cov, rc) < 1e-5 and rel(m1, rm1) < 1e-6 and rel(m2, rm2) < 1e-6
+    assert rel(got[0], want[0]) < 1e-5 and rel(got[1], want[1]) < 1e-4
+    # the whole solve: rotation / translation and their gradients, fused branch against the torch branch (both fp32)
+    gR, gt = torch.randn(P, 3, 3, device=dev), torch.randn(P, 3, 1, device=dev)
+    out = []
+    for fused in (True, False):
+        R, t, _, _ = kabsch_transformation_estimation(x1, x2, weights=w, fused=fused)
+        out.append([R.detach(), t.detach()] + list(torch.autograd.grad((R * gR).sum() + (t * gt).sum(), [x2, w])))
+    assert rel(out[0][0], out[1][0].double()) < 1e-5 and rel(out[0][1], out[1][1].double()) < 1e-5
+    assert rel(out[0][2], out[1][2].double()) < 2e-3 and rel(out[0][3], out[1][3].double()) < 2e-3
+    assert float((out[0][0] - rot).abs().max()) < 0.05                          # and it is the rotation that was applied
+
+
 # ---------------------------------------------------------------- A8 fused Sinkhorn + Kabsch (forward)
 def test_sinkhorn_kabsch_golden_pair(native, dev, golden):
     """The reference's pairwise_ego_motion_estimation output (tests/golden/ego.npz) for one pair, k = 64 key points."""
