@@ -313,6 +313,12 @@ int pcacc_kabsch_cov_forward(const float *x1, const float *x2, const float *w, i
 int pcacc_kabsch_cov_backward(const float *x1, const float *x2, const float *w, const float *m1, const float *m2, const float *norm,
                               const float *grad_cov, const float *grad_m1, const float *grad_m2, int n_pairs, int k, float *grad_x2,
                               float *grad_w, void *stream);
+/* ... and behind the SVD (toolbox/register_utils.py:305-313): rot [n,3,3] = V diag(1, 1, det(V U^T)) U^T, trans [n,3] = m2 - rot m1, from the
+ * singular vectors u, v [n,3,3] and the weighted means m1, m2 [n,3]; backward from grad_rot / grad_trans (NULL = 0) incl. the path through
+ * the determinant (its derivative is the cofactor matrix: no LU factorisation of a 3x3 matrix). */
+int pcacc_kabsch_rt_forward(const float *u, const float *v, const float *m1, const float *m2, int n, float *rot, float *trans, void *stream);
+int pcacc_kabsch_rt_backward(const float *u, const float *v, const float *m1, const float *grad_rot, const float *grad_trans, int n,
+                             float *grad_u, float *grad_v, float *grad_m1, float *grad_m2, void *stream);
 /* Batched 3x3 SVD of the Kabsch solve in the training path -- toolbox/register_utils.py:293 (`torch.svd(cov_mat)`):
  * a [n,3,3] f32 = u diag(s) v^T, s descending, no status word read back on the host.  backward: grad_a from the gradients of
  * u, s, v (any of them NULL = 0), closed form for distinct singular values. */

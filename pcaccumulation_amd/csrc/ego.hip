@@ -1172,3 +1172,95 @@ extern "C" int pcacc_kabsch_cov_backward(const float *x1, const float *x2, const
     return PCACC_OK;
 }
 
+// ---- ... and the part behind the SVD: R = V diag(1, 1, det(V U^T)) U^T, t = m2 - R m1 (toolbox/register_utils.py:305-313), one thread per pair.
+// The torch formulation runs det() through an LU factorisation (rocsolver launches, forward and backward) for a 3x3 matrix.
+__device__ __forceinline__ void kb_cofactor(const double (&m)[3][3], double (&c)[3][3])
+{
+    c[0][0] = m[1][1] * m[2][2] - m[1][2] * m[2][1]; c[0][1] = m[1][2] * m[2][0] - m[1][0] * m[2][2]; c[0][2] = m[1][0] * m[2][1] - m[1][1] * m[2][0];
+    c[1][0] = m[0][2] * m[2][1] - m[0][1] * m[2][2]; c[1][1] = m[0][0] * m[2][2] - m[0][2] * m[2][0]; c[1][2] = m[0][1] * m[2][0] - m[0][0] * m[2][1];
+    c[2][0] = m[0][1] * m[1][2] - m[0][2] * m[1][1]; c[2][1] = m[0][2] * m[1][0] - m[0][0] * m[1][2]; c[2][2] = m[0][0] * m[1][1] - m[0][1] * m[1][0];
+}
+
+__global__ __launch_bounds__(64) void kabsch_rt_fwd_kernel(const float *__restrict__ u, const float *__restrict__ v, const float *__restrict__ m1,
+                                                           const float *__restrict__ m2, int n, float *__restrict__ rot, float *__restrict__ trans)
+{
+    const int p = blockIdx.x * 64 + threadIdx.x;
+    if (p >= n) return;
+    double U[3][3], V[3][3], M[3][3], C[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) { U[i][j] = u[p * 9 + i * 3 + j]; V[i][j] = v[p * 9 + i * 3 + j]; }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) M[i][j] = V[i][0] * U[j][0] + V[i][1] * U[j][1] + V[i][2] * U[j][2];
+    kb_cofactor(M, C);
+    const double d = M[0][0] * C[0][0] + M[0][1] * C[0][1] + M[0][2] * C[0][2];
+    for (int i = 0; i < 3; ++i) {
+        double R[3];
+        for (int j = 0; j < 3; ++j) {
+            R[j] = V[i][0] * U[j][0] + V[i][1] * U[j][1] + d * V[i][2] * U[j][2];
+            rot[p * 9 + i * 3 + j] = (float)R[j];
+        }
+        trans[p * 3 + i] = (float)((double)m2[p * 3 + i] - (R[0] * m1[p * 3 + 0] + R[1] * m1[p * 3 + 1] + R[2] * m1[p * 3 + 2]));
+    }
+}
+
+__global__ __launch_bounds__(64) void kabsch_rt_bwd_kernel(const float *__restrict__ u, const float *__restrict__ v, const float *__restrict__ m1,
+                                                           const float *__restrict__ g_rot, const float *__restrict__ g_trans, int n,
+                                                           float *__restrict__ g_u, float *__restrict__ g_v, float *__restrict__ g_m1,
+                                                           float *__restrict__ g_m2)
+{
+    const int p = blockIdx.x * 64 + threadIdx.x;
+    if (p >= n) return;
+    double U[3][3], V[3][3], M[3][3], C[3][3], R[3][3], G[3][3], gt[3], a[3];
+    for (int i = 0; i < 3; ++i) {
+        a[i] = m1[p * 3 + i];
+        gt[i] = g_trans ? g_trans[p * 3 + i] : 0.f;
+        for (int j = 0; j < 3; ++j) { U[i][j] = u[p * 9 + i * 3 + j]; V[i][j] = v[p * 9 + i * 3 + j]; }
+    }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) M[i][j] = V[i][0] * U[j][0] + V[i][1] * U[j][1] + V[i][2] * U[j][2];
+    kb_cofactor(M, C);
+    const double d = M[0][0] * C[0][0] + M[0][1] * C[0][1] + M[0][2] * C[0][2];
+    const double D[3] = {1.0, 1.0, d};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            R[i][j] = V[i][0] * U[j][0] + V[i][1] * U[j][1] + d * V[i][2] * U[j][2];
+            G[i][j] = (g_rot ? (double)g_rot[p * 9 + i * 3 + j] : 0.0) - gt[i] * a[j];      // t = m2 - R m1
+        }
+    for (int j = 0; j < 3; ++j) {
+        g_m2[p * 3 + j] = (float)gt[j];
+        g_m1[p * 3 + j] = (float)(-(R[0][j] * gt[0] + R[1][j] * gt[1] + R[2][j] * gt[2]));
+    }
+    double gd = 0.0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) gd += G[i][j] * V[i][2] * U[j][2];
+    // d = det(M), M = V U^T: d(det) / dM = cofactor matrix
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < 3; ++k) {
+            double gv = 0.0, gu = 0.0;
+            for (int j = 0; j < 3; ++j) {
+                gv += (G[i][j] * D[k] + gd * C[i][j]) * U[j][k];      // g_V[i][k]
+                gu += (G[j][i] * D[k] + gd * C[j][i]) * V[j][k];      // g_U[i][k] (row i of U pairs with column i of G / C)
+            }
+            g_v[p * 9 + i * 3 + k] = (float)gv;
+            g_u[p * 9 + i * 3 + k] = (float)gu;
+        }
+}
+
+extern "C" int pcacc_kabsch_rt_forward(const float *u, const float *v, const float *m1, const float *m2, int n, float *rot, float *trans,
+                                       void *stream)
+{
+    if (n < 1 || !u || !v || !m1 || !m2 || !rot || !trans) return PCACC_E_ARG;
+    kabsch_rt_fwd_kernel<<<(n + 63) / 64, 64, 0, pcacc_stream(stream)>>>(u, v, m1, m2, n, rot, trans);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}
+
+extern "C" int pcacc_kabsch_rt_backward(const float *u, const float *v, const float *m1, const float *grad_rot, const float *grad_trans, int n,
+                                        float *grad_u, float *grad_v, float *grad_m1, float *grad_m2, void *stream)
+{
+    if (n < 1 || !u || !v || !m1 || !grad_u || !grad_v || !grad_m1 || !grad_m2) return PCACC_E_ARG;
+    kabsch_rt_bwd_kernel<<<(n + 63) / 64, 64, 0, pcacc_stream(stream)>>>(u, v, m1, grad_rot, grad_trans, n, grad_u, grad_v, grad_m1, grad_m2);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}
+

@@ -52,14 +52,12 @@ def get_relative_pose_torch(tsfm_src, tsfm_tgt, dataset):
 
 def kabsch_transformation_estimation(x1, x2, weights=None, normalize_w=True, eps=1e-7, best_k=0, w_threshold=0, fused=False):
     """toolbox/register_utils.py:247-317 (best_k = 0, w_threshold = 0 path).  Returns (R [b,3,3], t [b,3,1], res, flag).
-    fused (GPU, weights given, x1 without gradient): means and covariance from ops.kabsch_cov -- one kernel each way; res is not computed."""
+    fused (GPU, weights given, x1 without gradient): means and covariance from ops.kabsch_cov, rotation / translation behind the SVD from
+    ops.kabsch_rt -- one kernel each way each; res is not computed."""
     if fused and weights is not None and normalize_w and eps == 1e-7 and x1.is_cuda and not x1.requires_grad:
         cov_mat, x1_mean, x2_mean = ops.kabsch_cov(x1, x2, weights)
         u, s, v = ops.svd3(cov_mat)
-        det = torch.det(torch.matmul(v.transpose(1, 2), u.transpose(1, 2)))
-        dmat = torch.diag_embed(torch.cat((torch.ones((det.shape[0], 2), device=x1.device), det.unsqueeze(1)), 1))
-        rotation = torch.matmul(v, torch.matmul(dmat, u.transpose(1, 2)))
-        translation = x2_mean.transpose(1, 2) - torch.matmul(rotation, x1_mean.transpose(1, 2))
+        rotation, translation = ops.kabsch_rt(u, v, x1_mean, x2_mean)       # V diag(1, 1, det) U^T and x2_mean - R x1_mean, one thread per pair
         return rotation, translation, None, False
     if weights is None:
         weights = torch.ones(x1.shape[0], x1.shape[1]).type_as(x1).to(x1.device)

@@ -49,7 +49,7 @@ EXPORTS = [
     'pcacc_cluster_workspace_bytes', 'pcacc_cluster', 'pcacc_conv3x3_prepare_weights', 'pcacc_conv3x3_bf16',
     'pcacc_rows_linear_bf16', 'pcacc_rows_linear_mixed', 'pcacc_rows_wgrad_mixed',
     'pcacc_segment_max_t', 'pcacc_segment_max_backward_t', 'pcacc_segment_max_backward_acc', 'pcacc_segment_sum_t', 'pcacc_rows_wgrad_bf16_workspace_bytes', 'pcacc_rows_wgrad_bf16', 'pcacc_sample_subsets', 'pcacc_conv3x3_wgrad_workspace_bytes', 'pcacc_conv3x3_wgrad_bf16', 'pcacc_upload_words', 'pcacc_bilinear_base_cells', 'pcacc_bilinear_sorted_workspace_bytes', 'pcacc_bilinear_gather_backward_sorted', 'pcacc_prep_points',
-    'pcacc_kabsch_cov_forward', 'pcacc_kabsch_cov_backward', 'pcacc_ego_affinity_forward', 'pcacc_ego_affinity_backward_workspace_bytes', 'pcacc_ego_affinity_backward', 'pcacc_ego_perm_forward', 'pcacc_ego_perm_backward',
+    'pcacc_kabsch_cov_forward', 'pcacc_kabsch_cov_backward', 'pcacc_kabsch_rt_forward', 'pcacc_kabsch_rt_backward', 'pcacc_ego_affinity_forward', 'pcacc_ego_affinity_backward_workspace_bytes', 'pcacc_ego_affinity_backward', 'pcacc_ego_perm_forward', 'pcacc_ego_perm_backward',
     'pcacc_sinkhorn_train_workspace_bytes', 'pcacc_sinkhorn_forward', 'pcacc_sinkhorn_backward',
     'pcacc_seg_loss_workspace_bytes', 'pcacc_seg_loss_forward', 'pcacc_seg_loss_backward',
     'pcacc_offset_loss_workspace_bytes', 'pcacc_offset_loss_forward', 'pcacc_offset_loss_backward',
@@ -1448,6 +1448,26 @@ def kabsch_cov_backward(x1, x2, w, m1, m2, norm, g_cov, g_m1, g_m2):
                                            _opt(g_cov, torch.float32, 'grad_cov'), _opt(g_m1, torch.float32, 'grad_m1'),
                                            _opt(g_m2, torch.float32, 'grad_m2'), int(p), int(k), _dev(gx2), _dev(gw), _stream()), 'kabsch_cov_backward')
     return gx2, gw
+
+
+def kabsch_rt_forward(u, v, m1, m2):
+    """u, v [n,3,3], m1, m2 [n,3] f32 -> (rot [n,3,3], trans [n,3])."""
+    n = u.shape[0]
+    rot = torch.empty((n, 3, 3), dtype=torch.float32, device=u.device)
+    trans = torch.empty((n, 3), dtype=torch.float32, device=u.device)
+    _check(lib().pcacc_kabsch_rt_forward(_dev(u, torch.float32, 'u'), _dev(v, torch.float32, 'v'), _dev(m1, torch.float32, 'm1'),
+                                         _dev(m2, torch.float32, 'm2'), int(n), _dev(rot), _dev(trans), _stream()), 'kabsch_rt_forward')
+    return rot, trans
+
+
+def kabsch_rt_backward(u, v, m1, g_rot, g_trans):
+    n = u.shape[0]
+    f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=u.device)
+    gu, gv, gm1, gm2 = f(n, 3, 3), f(n, 3, 3), f(n, 3), f(n, 3)
+    _check(lib().pcacc_kabsch_rt_backward(_dev(u, torch.float32, 'u'), _dev(v, torch.float32, 'v'), _dev(m1, torch.float32, 'm1'),
+                                          _opt(g_rot, torch.float32, 'grad_rot'), _opt(g_trans, torch.float32, 'grad_trans'), int(n), _dev(gu),
+                                          _dev(gv), _dev(gm1), _dev(gm2), _stream()), 'kabsch_rt_backward')
+    return gu, gv, gm1, gm2
 
 
 def inv4x4(m):

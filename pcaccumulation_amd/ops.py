@@ -1229,6 +1229,33 @@ def kabsch_cov(x1, x2, w):
     return _KabschCov.apply(x1, x2, w)
 
 
+class _KabschRT(torch.autograd.Function):
+    """rotation = V diag(1, 1, det(V U^T)) U^T and translation = x2_mean - R x1_mean (toolbox/register_utils.py:305-313) from the SVD factors
+    and the weighted means: one thread per pair each way (the torch formulation's det() is an LU factorisation, forward and backward)."""
+
+    @staticmethod
+    def forward(ctx, u, v, m1, m2):
+        u, v = u.contiguous().float(), v.contiguous().float()
+        m1c, m2c = m1.reshape(-1, 3).contiguous().float(), m2.reshape(-1, 3).contiguous().float()
+        rot, trans = native.kabsch_rt_forward(u, v, m1c, m2c)
+        ctx.save_for_backward(u, v, m1c)
+        ctx.shapes = (m1.shape, m2.shape)
+        ctx.set_materialize_grads(False)
+        return rot, trans.unsqueeze(2)
+
+    @staticmethod
+    def backward(ctx, g_rot, g_trans):
+        u, v, m1c = ctx.saved_tensors
+        c = lambda t: t.contiguous().float() if t is not None else None
+        gu, gv, gm1, gm2 = native.kabsch_rt_backward(u, v, m1c, c(g_rot), c(g_trans.squeeze(2)) if g_trans is not None else None)
+        return gu, gv, gm1.view(ctx.shapes[0]), gm2.view(ctx.shapes[1])
+
+
+def kabsch_rt(u, v, x1_mean, x2_mean):
+    """-> (rotation [n,3,3], translation [n,3,1])."""
+    return _KabschRT.apply(u, v, x1_mean, x2_mean)
+
+
 def sinkhorn(log_alpha, n_iters):
     return _Sinkhorn.apply(log_alpha, int(n_iters))
 
