@@ -94,6 +94,7 @@ class PermList(list):
     fused matching kernels, the row / column sums of that tensor (`sums`), which are all the loss reads of it."""
     stacked = None
     sums = None
+    chains = None       # (estimated, ground-truth) chained poses [B*T,4,4] when one batched solve produced the whole forward's
 
 
 class _RowRef(object):
@@ -335,7 +336,11 @@ class EgoMotionHead(nn.Module):
         p = 0
         ref_pts, lens = [], []
         if isinstance(perm_matrix_list, PermList):
-            perm_matrix_list.stacked = perm if len(perm_matrix_list) == 0 else None     # all pairs of this forward as one tensor
+            whole = len(perm_matrix_list) == 0
+            perm_matrix_list.stacked = perm if whole else None     # all pairs of this forward as one tensor
+            # the two stacks _finish would build from the 2*B*T list entries below, as the tensors they are slices of
+            perm_matrix_list.chains = (chain.reshape(B * T, 4, 4), torch.cat((identity.expand(B, 1, 4, 4).to(pose_gt_all.dtype), pose_gt_all), dim=1)
+                                       .reshape(B * T, 4, 4)) if whole else None
         for b, (points_list, feats_list, bg_list, gt) in enumerate(sequences):
             for lst in (relative_pose_est_list, relative_pose_gt_list, chained_pose_est_list, chained_pose_gt_list):
                 lst.append(identity)
@@ -406,8 +411,12 @@ class EgoMotionHead(nn.Module):
 
     def _finish(self, B, T, total_l1, total_l2, count, perm_matrix_list, chained_pose_est_list, chained_pose_gt_list, results):
         """models/egomotion.py:448-469."""
-        chained_pose_est = torch.stack(chained_pose_est_list)
-        chained_pose_gt = torch.stack(chained_pose_gt_list)
+        chains = getattr(perm_matrix_list, 'chains', None)
+        if chains is not None and chains[0].shape[0] == len(chained_pose_est_list):
+            chained_pose_est, chained_pose_gt = chains
+        else:
+            chained_pose_est = torch.stack(chained_pose_est_list)
+            chained_pose_gt = torch.stack(chained_pose_gt_list)
         rot_est, rot_gt = chained_pose_est[:, :3, :3], chained_pose_gt[:, :3, :3]
         trans_est, trans_gt = chained_pose_est[:, :3, 3].unsqueeze(-1), chained_pose_gt[:, :3, 3].unsqueeze(-1)
         # 0-d tensors here; MotionNet.forward turns them into Python floats (the reference's .item(), egomotion.py:456)
