@@ -302,6 +302,76 @@ __device__ __forceinline__ void conv_pass_mfma(f32x16_t (&acc)[R][CT], const uin
     }
 }
 
+// The tiles of a persistent workgroup -- numbers first, first + stride, ... -- decoded 64 at a time on the vector unit: lane i holds the
+// image, frame and tile coordinates of the workgroup's tile number base + i, and a pass picks its tile up with v_readlane.  Decoding
+// tile -> (image, row, column) with scalar divisions in every pass came to ~400 scalar instructions per pass and wave next to 18 MFMAs:
+// the waves of a workgroup did that arithmetic in step between two barriers with the matrix pipe idle (27-tap 32 -> 32 layer: MFMA
+// 31 %, LDS 38 %, address unit 30 % busy, none of them the bound).
+struct ConvTile { int img, fr, y0, x0; };
+struct ConvTileWalk {
+    int first, stride, count;                                  // `count` tiles
+    int tyx, tiles_x, frames, frame_fastest, th;
+    int v_img, v_fr, v_ty, v_tx;                               // per lane
+    __device__ __forceinline__ void init(int lo, int hi, int slot, int slots, int tiles_y, int tiles_x_, int frames_, int ff, int th_)
+    {
+        first = lo + slot; stride = slots; count = first < hi ? (hi - first + slots - 1) / slots : 0;
+        tyx = tiles_y * tiles_x_; tiles_x = tiles_x_; frames = frames_; frame_fastest = ff; th = th_;
+        v_img = v_fr = v_ty = v_tx = 0;
+    }
+    __device__ __forceinline__ void refill(int k0)
+    {
+        const int t = first + (k0 + (int)(threadIdx.x & 63)) * stride;       // lanes past `count` decode numbers nobody reads
+        int img, pos;
+        if (frame_fastest) {                                   // frame fastest inside a sample, then the position
+            const int q = t / frames, smp = q / tyx;
+            v_fr = t - q * frames; pos = q - smp * tyx; img = smp * frames + v_fr;
+        } else {
+            img = t / tyx; pos = t - img * tyx; v_fr = frames > 1 ? img % frames : 0;
+        }
+        v_img = img; v_ty = pos / tiles_x; v_tx = pos - v_ty * tiles_x;
+    }
+    __device__ __forceinline__ ConvTile get(int k)             // k ascending, each k once
+    {
+        if ((k & 63) == 0) refill(k);
+        ConvTile t;
+        t.img = __builtin_amdgcn_readlane(v_img, k & 63); t.fr = __builtin_amdgcn_readlane(v_fr, k & 63);
+        t.y0 = __builtin_amdgcn_readlane(v_ty, k & 63) * th; t.x0 = __builtin_amdgcn_readlane(v_tx, k & 63) * CV_TW;
+        return t;
+    }
+};
+
+// The same pass for 32-channel rows stored UNPADDED (64 B per pixel / weight row) with the 16-byte chunk index XOR-ed by (row >> 2) & 3:
+// a ds_read_b128 lane group holds rows {o..o+3, o+12..o+15, o+20..o+27}; the four of them that share row % 4 (hence the 16-byte slot
+// group row * 4 % 16) differ in (row >> 2) & 3 for every offset o, so the reads stay conflict-free like the 80-byte rows', and the 27-tap
+// layer's weights + patch take 77 KB instead of 96: two workgroups per CU.  `lrow` = the lane's patch row for tap (0,0) of the wave's
+// first pixel row; `wtap0` = the lane's weight row of tap 0; `wsw` = its swizzled element offset of channel chunk lh.
+template <int R>
+__device__ __forceinline__ void conv_pass_mfma_swz(f32x16_t (&acc)[R][1], const uint16_t *patch, int lrow, int lh, const uint16_t *wtap0, int wsw)
+{
+    constexpr int STEPS = 18;
+    constexpr int AHEAD = 2;
+    bf16x8_t fb[AHEAD + 1][R], fa[AHEAD + 1];
+    auto load = [&](int slot, int s) {
+        const int tap = s / 2, kc = s % 2;
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+            const int v = lrow + (tap / 3 + m) * CV_PW + tap % 3;
+            fb[slot][m] = *reinterpret_cast<const bf16x8_t *>(patch + v * 32 + (((kc * 2 + lh) ^ ((v >> 2) & 3)) << 3));
+        }
+        fa[slot] = *reinterpret_cast<const bf16x8_t *>(wtap0 + tap * 32 * 32 + (wsw ^ (kc * 16)));
+    };
+#pragma unroll
+    for (int s = 0; s < AHEAD; ++s) load(s, s);
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        if (s + AHEAD < STEPS) load((s + AHEAD) % (AHEAD + 1), s + AHEAD);
+#pragma unroll
+        for (int m = 0; m < R; ++m)
+            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s % (AHEAD + 1)], fb[s % (AHEAD + 1)][m], acc[m][0], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // ---- small layers (c_in <= 64): all taps' weights resident in LDS, persistent workgroups, patch prefetch -------------------
 // One pass = one (tile, frame tap): the patch of the NEXT pass is fetched into registers while the matrix cores work on
 // the current one, so global latency is paid once per workgroup instead of once per tap.  Workgroups are dealt to XCDs
@@ -309,16 +379,20 @@ __device__ __forceinline__ void conv_pass_mfma(f32x16_t (&acc)[R][CT], const uin
 // CT = channel tiles of 32 per workgroup; a wave owns R rows of the 8 x 32 tile and CTW of the CT channel tiles, so the
 // workgroup has (8/R) * (CT/CTW) waves: when LDS leaves room for one workgroup per CU only, 8 waves instead of 4 let one
 // wave's epilogue / staging run under another's MFMAs.
-template <int CT, int CS, int R, int CTW>
-__global__ __launch_bounds__(64 * (8 / R) * (CT / CTW)) __attribute__((amdgpu_waves_per_eu((CT == 1 && CS == 32 && R == 2) ? 3 : 1, (CT == 1 && CS == 32 && R == 2) ? 3 : 8)))
+// SWZ (CT = 1, CS = 32 only): unpadded swizzled rows, see conv_pass_mfma_swz.
+template <int CT, int CS, int R, int CTW, bool SWZ = false>
+__global__ __launch_bounds__(64 * (8 / R) * (CT / CTW)) __attribute__((amdgpu_waves_per_eu((CT == 1 && CS == 32 && R == 2) ? (SWZ ? 2 : 3) : 1, (CT == 1 && CS == 32 && R == 2) ? (SWZ ? 2 : 3) : 8)))
 void conv3x3_resident_kernel(
     const uint16_t *__restrict__ in, const uint16_t *__restrict__ wp, const float *__restrict__ bias, uint16_t *__restrict__ out,
-    int n_img, int frames, int h, int w, int c_out, int kt, int relu, int tiles_x, int tiles_y, int co_groups, const uint16_t *__restrict__ omask)
+    int n_img, int frames, int h, int w, int c_out, int kt, int relu, int tiles_x, int tiles_y, int co_groups, const uint16_t *__restrict__ omask,
+    int frame_order)
 {
+    static_assert(!SWZ || (CT == 1 && CS == 32 && CTW == 1), "swizzled rows: 32 channels, one channel tile");
     constexpr int THREADS = 64 * (8 / R) * (CT / CTW);
-    constexpr int PS = CS + 8;
+    constexpr int PS = SWZ ? CS : CS + 8;
     constexpr int P_CHUNKS = CV_PH * CV_PW * CS / 8;
     constexpr int P_PER_THREAD = (P_CHUNKS + THREADS - 1) / THREADS;
+    auto chunk_at = [](int row, int c8) { return row * PS + ((SWZ ? c8 ^ ((row >> 2) & 3) : c8) << 3); };   // element offset of a 16-byte chunk
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     uint16_t *patch = lds;                                     // [CV_PH * CV_PW][PS]
     uint16_t *wl = lds + CV_PH * CV_PW * PS;                   // [kt * 9][CT * 32][PS]
@@ -341,7 +415,7 @@ void conv3x3_resident_kernel(
     for (int c = threadIdx.x; c < w_rows * (CS / 8); c += THREADS) {
         const int row = c / (CS / 8), c8 = c % (CS / 8);
         const int tap = row / (CT * 32), r = row % (CT * 32);
-        *reinterpret_cast<uint4 *>(wl + row * PS + c8 * 8) =
+        *reinterpret_cast<uint4 *>(wl + chunk_at(row, c8)) =
             *reinterpret_cast<const uint4 *>(wp + ((int64_t)tap * c_out + co0 + r) * CS + c8 * 8);
     }
     if (threadIdx.x < CT * 32) bias_l[threadIdx.x] = bias ? bias[co0 + threadIdx.x] : 0.f;
@@ -357,56 +431,67 @@ void conv3x3_resident_kernel(
         p_yx[q] = c < P_CHUNKS ? (py << 8 | pxx) : (0x7f << 8);                  // row 127 never passes the bounds test
         p_off[q] = ((py - 1) * w + pxx - 1) * CS + c8 * 8;
     }
-    auto pass_valid = [&](int tile, int f) {
+    // with frame taps the FRAME runs fastest in the tile order, so that the tiles an XCD works on at one time are the same positions of
+    // consecutive frames and the three reads of a frame's patch (as tap -1, 0, +1) meet in its L2 (FETCH_SIZE of the 27-tap layer at
+    // 20 x 288^2: 148 -> 63 MB); frame-major order puts a whole frame (5.3 MB) between them
+    ConvTileWalk walk;
+    walk.init(lo, hi, slot, slots, tiles_y, tiles_x, frames, kt == 3 && frame_order, CV_TH);
+    auto pass_valid = [&](const ConvTile &t, int f) {
         if (kt == 1) return true;
-        const int t_frame = (tile / (tiles_y * tiles_x)) % frames + f - 1;
+        const int t_frame = t.fr + f - 1;
         return t_frame >= 0 && t_frame < frames;
     };
-    auto fetch = [&](int tile, int f) {
-        const int img = tile / (tiles_y * tiles_x) + (kt == 3 ? f - 1 : 0);
-        const int rem = tile % (tiles_y * tiles_x);
-        const int y0 = (rem / tiles_x) * CV_TH, x0 = (rem % tiles_x) * CV_TW;
-        const uint16_t *src = in + ((int64_t)img * h * w + (int64_t)y0 * w + x0) * CS;
+    auto fetch = [&](const ConvTile &t, int f) {
+        const int img = t.img + (kt == 3 ? f - 1 : 0);
+        const uint16_t *src = in + ((int64_t)img * h * w + (int64_t)t.y0 * w + t.x0) * CS;
 #pragma unroll
         for (int q = 0; q < P_PER_THREAD; ++q) {
-            const int y = y0 - 1 + (p_yx[q] >> 8), x = x0 - 1 + (p_yx[q] & 0xff);
+            const int y = t.y0 - 1 + (p_yx[q] >> 8), x = t.x0 - 1 + (p_yx[q] & 0xff);
             uint4 v = make_uint4(0, 0, 0, 0);
             if ((unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w) v = *reinterpret_cast<const uint4 *>(src + p_off[q]);
             preg[q] = v;
         }
     };
-    auto store_pending = [&](const uint2 (&pk)[R][CTW][4], int t) {
-        const int img = t / (tiles_y * tiles_x), rem = t % (tiles_y * tiles_x);
-        conv_store_packed<R, CTW>(pk, out, img, (rem / tiles_x) * CV_TH, (rem % tiles_x) * CV_TW, h, w, c_out, co0 + cw0, row0, lp, lh, omask);
+    auto store_pending = [&](const uint2 (&pk)[R][CTW][4], const ConvTile &t) {
+        conv_store_packed<R, CTW>(pk, out, t.img, t.y0, t.x0, h, w, c_out, co0 + cw0, row0, lp, lh, omask);
     };
 
-    int tile = lo + slot, f = 0;
-    while (tile < hi && !pass_valid(tile, f)) ++f;             // frame tap 1 (the frame itself) is always valid
-    if (tile < hi) fetch(tile, f);
+    const int n_mine = walk.count;
+    int k = 0, f = 0;
+    ConvTile cur = {0, 0, 0, 0}, nxt = cur, pnd = cur;
+    if (n_mine > 0) {
+        cur = walk.get(0);
+        while (!pass_valid(cur, f)) ++f;                       // frame tap 1 (the frame itself) is always valid
+        fetch(cur, f);
+    }
 
     f32x16_t acc[R][CTW];
     uint2 pend[R][CTW][4];                                     // finished tile waiting for its stores
-    int pend_tile = -1;
-    bool fresh = true;
-    while (tile < hi) {
+    bool have_pend = false, fresh = true;
+    while (k < n_mine) {
         __syncthreads();                                       // the previous pass is done with the patch
 #pragma unroll
         for (int q = 0; q < P_PER_THREAD; ++q) {
             const int c = threadIdx.x + q * THREADS;
-            if (c < P_CHUNKS) *reinterpret_cast<uint4 *>(patch + (c / (CS / 8)) * PS + (c % (CS / 8)) * 8) = preg[q];
+            if (c < P_CHUNKS) *reinterpret_cast<uint4 *>(patch + chunk_at(c / (CS / 8), c % (CS / 8))) = preg[q];
         }
         __syncthreads();
-        if (pend_tile >= 0) {
-            store_pending(pend, pend_tile);
-            pend_tile = -1;
+        if (have_pend) {
+            store_pending(pend, pnd);
+            have_pend = false;
         }
-        int nt = tile, nf = f + 1;
-        while (nt < hi) {
-            if (nf >= kt) { nf = 0; nt += slots; continue; }
-            if (pass_valid(nt, nf)) break;
+        int nk = k, nf = f + 1;
+        nxt = cur;
+        while (true) {
+            if (nf >= kt) {
+                nf = 0;
+                if (++nk >= n_mine) break;
+                nxt = walk.get(nk);
+            }
+            if (pass_valid(nxt, nf)) break;
             ++nf;
         }
-        if (nt < hi) fetch(nt, nf);                            // in flight during the MFMAs below
+        if (nk < n_mine) fetch(nxt, nf);                       // in flight during the MFMAs below
 
         if (fresh) {
 #pragma unroll
@@ -417,28 +502,33 @@ void conv3x3_resident_kernel(
                     for (int r = 0; r < 16; ++r) acc[m][ct][r] = 0.f;
             fresh = false;
         }
-        conv_pass_mfma<R, CTW, CS, CT * 32>(acc, patch + (row0 * CV_PW + lp) * PS + lh * 8,
-                                            wl + ((f * 9) * CT * 32 + cw0 + lp) * PS + lh * 8);
-        if (nt != tile) {                                      // last pass of this tile
+        if constexpr (SWZ)
+            conv_pass_mfma_swz<R>(acc, patch, row0 * CV_PW + lp, lh, wl + (f * 9 * 32 + lp) * 32, (lh ^ ((lp >> 2) & 3)) << 3);
+        else
+            conv_pass_mfma<R, CTW, CS, CT * 32>(acc, patch + (row0 * CV_PW + lp) * PS + lh * 8,
+                                                wl + ((f * 9) * CT * 32 + cw0 + lp) * PS + lh * 8);
+        if (nk != k) {                                         // last pass of this tile
             conv_pack_tile<R, CTW>(acc, bias_l + cw0, relu, lh, pend);
-            pend_tile = tile;
+            pnd = cur;
+            have_pend = true;
             fresh = true;
         }
-        tile = nt;
+        k = nk;
         f = nf;
+        cur = nxt;
     }
-    if (pend_tile >= 0) store_pending(pend, pend_tile);
+    if (have_pend) store_pending(pend, pnd);
 }
 
-template <int CT, int CS, int R, int CTW>
+template <int CT, int CS, int R, int CTW, bool SWZ = false>
 static int conv_launch_resident(const uint16_t *in, const uint16_t *wp, const float *bias, uint16_t *out, int n_img, int frames, int h,
                                 int w, int c_out, int kt, int relu, hipStream_t st, const uint16_t *omask = nullptr)
 {
     constexpr int THREADS = 64 * (8 / R) * (CT / CTW);
     const int tiles_x = (w + CV_TW - 1) / CV_TW, tiles_y = (h + CV_TH - 1) / CV_TH;
     const int co_groups = c_out / (CT * 32);
-    const size_t lds = (size_t)(CV_PH * CV_PW + kt * 9 * CT * 32) * (CS + 8) * sizeof(uint16_t) + CT * 32 * sizeof(float);
-    auto kern = conv3x3_resident_kernel<CT, CS, R, CTW>;
+    const size_t lds = (size_t)(CV_PH * CV_PW + kt * 9 * CT * 32) * (SWZ ? CS : CS + 8) * sizeof(uint16_t) + CT * 32 * sizeof(float);
+    auto kern = conv3x3_resident_kernel<CT, CS, R, CTW, SWZ>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return PCACC_E_LAUNCH;
     int per_cu = (int)((160 * 1024) / lds);
@@ -453,7 +543,7 @@ static int conv_launch_resident(const uint16_t *in, const uint16_t *wp, const fl
     if (slots < 1) slots = 1;
     const unsigned grid = (unsigned)(8 * co_groups * slots);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, st, in, wp, bias, out, n_img, frames, h, w, c_out, kt, relu, tiles_x,
-                       tiles_y, co_groups, omask);
+                       tiles_y, co_groups, omask, getenv("PCACC_CONV_FRAME_MAJOR") ? 0 : 1);
     PCACC_CHECK_LAUNCH();
     return 0;
 }
@@ -494,7 +584,13 @@ static int conv3x3_bf16_any(const uint16_t *in, const uint16_t *wp, const float 
             const bool alone = lds > 80 * 1024;                    // one workgroup per CU: run it with 8 waves
 #define CV_RES(CTV, CSV, RV, CTWV) \
     return conv_launch_resident<CTV, CSV, RV, CTWV>(in, wp, bias, out, n_img, frames, h, w, c_out, kt, relu, st, omask)
-            if (c_in == 32 && ctr == 1) { if (alone) CV_RES(1, 32, 1, 1); CV_RES(1, 32, 2, 1); }
+            if (c_in == 32 && ctr == 1) {
+                // 27 taps: 96 KB with padded rows = one 8-wave workgroup per CU, 77 KB with swizzled rows = two of 4 waves, 2 rows each
+                if (alone && !getenv("PCACC_CONV_SWZ_OFF"))                 // the switch is for A/B measurements and the equality test
+                    return conv_launch_resident<1, 32, 1, 1, true>(in, wp, bias, out, n_img, frames, h, w, c_out, kt, relu, st, omask);
+                if (alone) CV_RES(1, 32, 1, 1);
+                CV_RES(1, 32, 2, 1);
+            }
             if (c_in == 32 && ctr == 2) { if (alone) CV_RES(2, 32, 2, 1); CV_RES(2, 32, 2, 2); }
             if (c_in == 32 && ctr == 4) { CV_RES(4, 32, 2, 2); }
             if (c_in == 64 && ctr == 1) { if (alone) CV_RES(1, 64, 1, 1); CV_RES(1, 64, 2, 1); }
