@@ -114,3 +114,44 @@ __device__ __forceinline__ int block256_exclusive_scan(int v, int *lds, int *tot
     __syncthreads();
     return base + incl - v;
 }
+
+// The tiles of a persistent workgroup -- numbers first, first + stride, ... -- decoded 64 at a time on the vector unit: lane i holds the
+// image, frame and tile coordinates of the workgroup's tile number base + i, and a pass picks its tile up with v_readlane.  Decoding
+// tile -> (image, row, column) with scalar divisions in every pass came to ~400 scalar instructions per pass and wave next to 18 MFMAs:
+// the waves of a workgroup did that arithmetic in step between two barriers with the matrix pipe idle (27-tap 32 -> 32 layer: MFMA
+// 31 %, LDS 38 %, address unit 30 % busy, none of them the bound).
+struct ConvTile { int img, fr, y0, x0; };
+#define PCACC_WALK_OK(n_img, frames, tiles_y, tiles_x) ((n_img) < (1 << 24) && (frames) < 128 && (tiles_y) < 32768 && (tiles_x) < 65536)
+struct ConvTileWalk {
+    int first, stride, count;                                  // `count` tiles
+    int tyx, tiles_x, frames, frame_fastest, th, tw;                // th x tw pixels per tile
+    int v_if, v_yx;                                            // per lane: image | frame << 24 (PCACC_WALK_OK), tile row << 16 | tile column
+    __device__ __forceinline__ void init(int lo, int hi, int slot, int slots, int tiles_y, int tiles_x_, int frames_, int ff, int th_, int tw_)
+    {
+        first = lo + slot; stride = slots; count = first < hi ? (hi - first + slots - 1) / slots : 0;
+        tyx = tiles_y * tiles_x_; tiles_x = tiles_x_; frames = frames_; frame_fastest = ff; th = th_; tw = tw_;
+        v_if = v_yx = 0;
+    }
+    __device__ __forceinline__ void refill(int k0)
+    {
+        const int t = first + (k0 + (int)(threadIdx.x & 63)) * stride;       // lanes past `count` decode numbers nobody reads
+        int img, pos, fr;
+        if (frame_fastest) {                                   // frame fastest inside a sample, then the position
+            const int q = t / frames, smp = q / tyx;
+            fr = t - q * frames; pos = q - smp * tyx; img = smp * frames + fr;
+        } else {
+            img = t / tyx; pos = t - img * tyx; fr = frames > 1 ? img % frames : 0;
+        }
+        const int ty = pos / tiles_x;
+        v_if = img | fr << 24; v_yx = ty << 16 | (pos - ty * tiles_x);
+    }
+    __device__ __forceinline__ ConvTile get(int k)             // k ascending, each k once
+    {
+        if ((k & 63) == 0) refill(k);
+        ConvTile t;
+        const int a = __builtin_amdgcn_readlane(v_if, k & 63), b = __builtin_amdgcn_readlane(v_yx, k & 63);
+        t.img = a & 0xffffff; t.fr = (unsigned)a >> 24;
+        t.y0 = (b >> 16) * th; t.x0 = (b & 0xffff) * tw;
+        return t;
+    }
+};

@@ -302,44 +302,6 @@ __device__ __forceinline__ void conv_pass_mfma(f32x16_t (&acc)[R][CT], const uin
     }
 }
 
-// The tiles of a persistent workgroup -- numbers first, first + stride, ... -- decoded 64 at a time on the vector unit: lane i holds the
-// image, frame and tile coordinates of the workgroup's tile number base + i, and a pass picks its tile up with v_readlane.  Decoding
-// tile -> (image, row, column) with scalar divisions in every pass came to ~400 scalar instructions per pass and wave next to 18 MFMAs:
-// the waves of a workgroup did that arithmetic in step between two barriers with the matrix pipe idle (27-tap 32 -> 32 layer: MFMA
-// 31 %, LDS 38 %, address unit 30 % busy, none of them the bound).
-struct ConvTile { int img, fr, y0, x0; };
-struct ConvTileWalk {
-    int first, stride, count;                                  // `count` tiles
-    int tyx, tiles_x, frames, frame_fastest, th;
-    int v_img, v_fr, v_ty, v_tx;                               // per lane
-    __device__ __forceinline__ void init(int lo, int hi, int slot, int slots, int tiles_y, int tiles_x_, int frames_, int ff, int th_)
-    {
-        first = lo + slot; stride = slots; count = first < hi ? (hi - first + slots - 1) / slots : 0;
-        tyx = tiles_y * tiles_x_; tiles_x = tiles_x_; frames = frames_; frame_fastest = ff; th = th_;
-        v_img = v_fr = v_ty = v_tx = 0;
-    }
-    __device__ __forceinline__ void refill(int k0)
-    {
-        const int t = first + (k0 + (int)(threadIdx.x & 63)) * stride;       // lanes past `count` decode numbers nobody reads
-        int img, pos;
-        if (frame_fastest) {                                   // frame fastest inside a sample, then the position
-            const int q = t / frames, smp = q / tyx;
-            v_fr = t - q * frames; pos = q - smp * tyx; img = smp * frames + v_fr;
-        } else {
-            img = t / tyx; pos = t - img * tyx; v_fr = frames > 1 ? img % frames : 0;
-        }
-        v_img = img; v_ty = pos / tiles_x; v_tx = pos - v_ty * tiles_x;
-    }
-    __device__ __forceinline__ ConvTile get(int k)             // k ascending, each k once
-    {
-        if ((k & 63) == 0) refill(k);
-        ConvTile t;
-        t.img = __builtin_amdgcn_readlane(v_img, k & 63); t.fr = __builtin_amdgcn_readlane(v_fr, k & 63);
-        t.y0 = __builtin_amdgcn_readlane(v_ty, k & 63) * th; t.x0 = __builtin_amdgcn_readlane(v_tx, k & 63) * CV_TW;
-        return t;
-    }
-};
-
 // The same pass for 32-channel rows stored UNPADDED (64 B per pixel / weight row) with the 16-byte chunk index XOR-ed by (row >> 2) & 3:
 // a ds_read_b128 lane group holds rows {o..o+3, o+12..o+15, o+20..o+27}; the four of them that share row % 4 (hence the 16-byte slot
 // group row * 4 % 16) differ in (row >> 2) & 3 for every offset o, so the reads stay conflict-free like the 80-byte rows', and the 27-tap
@@ -435,7 +397,7 @@ void conv3x3_resident_kernel(
     // consecutive frames and the three reads of a frame's patch (as tap -1, 0, +1) meet in its L2 (FETCH_SIZE of the 27-tap layer at
     // 20 x 288^2: 148 -> 63 MB); frame-major order puts a whole frame (5.3 MB) between them
     ConvTileWalk walk;
-    walk.init(lo, hi, slot, slots, tiles_y, tiles_x, frames, kt == 3 && frame_order, CV_TH);
+    walk.init(lo, hi, slot, slots, tiles_y, tiles_x, frames, kt == 3 && frame_order, CV_TH, CV_TW);
     auto pass_valid = [&](const ConvTile &t, int f) {
         if (kt == 1) return true;
         const int t_frame = t.fr + f - 1;
@@ -536,7 +498,7 @@ static int conv_launch_resident(const uint16_t *in, const uint16_t *wp, const fl
     per_cu = per_cu > by_waves ? by_waves : per_cu;
     per_cu = per_cu < 1 ? 1 : per_cu;
     const int64_t n_tiles = (int64_t)n_img * tiles_y * tiles_x;
-    if (n_tiles > 0x7fffffff) return PCACC_E_ARG;
+    if (n_tiles > 0x7fffffff || !PCACC_WALK_OK(n_img, frames, tiles_y, tiles_x)) return PCACC_E_ARG;
     int64_t slots = (int64_t)PCACC_CUS * per_cu / 8 / co_groups;            // per XCD and channel group
     const int64_t need = (n_tiles + 7) / 8;
     if (slots > need) slots = need;
@@ -696,13 +658,22 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_wgrad_kernel(const uint16_
     constexpr int Y_CHUNKS = CV_TH * CV_TW * CO / 8, Y_PER_THREAD = Y_CHUNKS / CV_THREADS;
     constexpr int X_CHUNKS = CV_PH * CV_PW * CI / 8, X_PER_THREAD = (X_CHUNKS + CV_THREADS - 1) / CV_THREADS;
     uint4 yreg[Y_PER_THREAD], xreg[X_PER_THREAD];
-    auto tile_valid = [&](int tile) {
-        const int t_frame = (tile / (tiles_y * tiles_x)) % frames + dt;
-        return t_frame >= 0 && t_frame < frames;
+    ConvTileWalk walk;                                         // tile coordinates without scalar divisions per tile
+    walk.init(lo, hi, slot, slots, tiles_y, tiles_x, frames, 0, CV_TH, CV_TW);
+    ConvTile cur = {0, 0, 0, 0};
+    const int n_mine = walk.count;
+    auto advance = [&](int from) {                             // the first of the workgroup's tiles >= from whose frame + dt exists
+        int kk = from;
+        while (kk < n_mine) {
+            cur = walk.get(kk);
+            const int t_frame = cur.fr + dt;
+            if (t_frame >= 0 && t_frame < frames) break;       // a missing frame contributes nothing
+            ++kk;
+        }
+        return kk;
     };
-    auto fetch = [&](int tile) {
-        const int img = tile / (tiles_y * tiles_x), rem = tile % (tiles_y * tiles_x);
-        const int y0 = (rem / tiles_x) * CV_TH, x0 = (rem % tiles_x) * CV_TW;
+    auto fetch = [&]() {
+        const int img = cur.img, y0 = cur.y0, x0 = cur.x0;
         const uint16_t *gsrc = dy + (int64_t)img * h * w * CO;
 #pragma unroll
         for (int q = 0; q < Y_PER_THREAD; ++q) {
@@ -725,10 +696,9 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_wgrad_kernel(const uint16_
             xreg[q] = v;
         }
     };
-    int tile = lo + slot;
-    while (tile < hi && !tile_valid(tile)) tile += slots;      // a missing frame contributes nothing
-    if (tile < hi) fetch(tile);
-    while (tile < hi) {
+    int k = advance(0);
+    if (k < n_mine) fetch();
+    while (k < n_mine) {
         __syncthreads();                                       // the previous tile's gathers are done
 #pragma unroll
         for (int q = 0; q < Y_PER_THREAD; ++q) {
@@ -747,10 +717,8 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_wgrad_kernel(const uint16_
             }
         }
         __syncthreads();
-        int next = tile + slots;
-        while (next < hi && !tile_valid(next)) next += slots;
-        if (next < hi) fetch(next);
-        tile = next;
+        k = advance(k + 1);
+        if (k < n_mine) fetch();
         // 16-pixel steps of the tile: step s = row s/2, columns (s%2)*16 ..; this wave's share is every GROUPS-th step
         // fragments through the LDS transpose read (see rows_wgrad_bf16_kernel in mlp_mfma.hip): two ds_read_b64_tr_b16 give a
         // lane its 8 consecutive pixels of one channel
@@ -844,7 +812,7 @@ extern "C" int pcacc_conv3x3_wgrad_bf16(const uint16_t *dy, const uint16_t *x, f
     hipStream_t st = pcacc_stream(stream);
     const int tiles_x = (w + CV_TW - 1) / CV_TW, tiles_y = (h + CV_TH - 1) / CV_TH;
     const int64_t n_tiles = (int64_t)n_img * tiles_y * tiles_x;
-    if (n_tiles > 0x7fffffff) return PCACC_E_ARG;
+    if (n_tiles > 0x7fffffff || !PCACC_WALK_OK(n_img, frames, tiles_y, tiles_x)) return PCACC_E_ARG;
     const int grid = conv_wgrad_grid(c_in, c_out, n_tiles);
     const int elems = c_out * 9 * c_in + c_out;                 // weight gradient, then the bias gradient
     if (workspace_bytes < (size_t)grid * elems * sizeof(float)) return PCACC_E_WORKSPACE;

@@ -498,8 +498,11 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_res_kernel(const fl
     const float inv_sx = 1.f / sx;
 
     // slices of a tile that exist: frame taps f_lo .. f_hi (a missing frame contributes zeros), all channel slices of each
-    auto first_slice = [&](int tile) { return (kt == 3 && (tile / tiles_img) % frames == 0) ? nc : 0; };
-    auto end_slice = [&](int tile) { return kt == 3 ? ((tile / tiles_img) % frames == frames - 1 ? 2 * nc : 3 * nc) : nc; };
+    // (tile coordinates come from the walker, frame tap f and channel slice cs of a slice s = f * nc + cs are carried along: no divisions per pass)
+    auto first_slice = [&](const ConvTile &t) { return (kt == 3 && t.fr == 0) ? nc : 0; };
+    auto end_slice = [&](const ConvTile &t) { return kt == 3 ? (t.fr == frames - 1 ? 2 * nc : 3 * nc) : nc; };
+    ConvTileWalk walk;                                         // with frame taps the frame runs fastest: a frame's three reads meet in the L2
+    walk.init(0, n_tiles, slot, slots, tiles_y, tiles_x, frames, kt == 3, rows, bw);
 
     // patch chunks (8 channels) of this thread: position packed as py << 20 | px << 8 | c8
     const int n_chunks = pp * C8;
@@ -512,10 +515,8 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_res_kernel(const fl
         const int py = px / pw, pxx = px - py * pw;
         pinfo[q] = c < n_chunks ? (py << 20 | pxx << 8 | c8) : (0x7ff << 20);
     }
-    auto fetch_patch = [&](int tile, int s) __attribute__((always_inline)) {
-        const int img = tile / tiles_img, rem = tile - img * tiles_img;
-        const int y0 = (rem / tiles_x) * rows, x0 = (rem % tiles_x) * bw;
-        const int f = s / nc, cs = s - f * nc;
+    auto fetch_patch = [&](const ConvTile &t, int f, int cs) __attribute__((always_inline)) {
+        const int img = t.img, y0 = t.y0, x0 = t.x0;
         const int64_t img_off = (int64_t)(img + (kt == 3 ? f - 1 : 0)) * h * w * c_in;
 #pragma unroll
         for (int q = 0; q < PCH; ++q) {
@@ -553,8 +554,7 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_res_kernel(const fl
     const int64_t w_plane = (int64_t)kt * 9 * c_out * c_in;
     typedef uint32_t wvec_t __attribute__((ext_vector_type(4 * W_PER)));      // one SSA value, not an array: as `uint4 wreg[W_PER]` it stayed in scratch memory
     wvec_t wreg;
-    auto fetch_w = [&](int s) __attribute__((always_inline)) {
-        const int f = s / nc, cs = s - f * nc;
+    auto fetch_w = [&](int f, int cs) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < W_PER; ++q) {
             const int c = min((int)threadIdx.x + q * CSP_THREADS, W_CHUNKS - 1);
@@ -574,11 +574,13 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_res_kernel(const fl
     };
 
     float omax = 0.f;
-    int tile = slot;
-    if (tile >= n_tiles) return;
-    int s = first_slice(tile);
-    fetch_patch(tile, s);
-    fetch_w(s);
+    const int n_mine = walk.count;
+    if (n_mine == 0) return;
+    int k = 0;
+    ConvTile cur = walk.get(0), nxt = cur;
+    int s = first_slice(cur), f = s ? 1 : 0, cs = 0;
+    fetch_patch(cur, f, cs);
+    fetch_w(f, cs);
     if (!RESTAGE) write_w();                                   // a one-slice layer (RESTAGE false): its nine tap tiles are staged once; the first pass's barriers publish them
     f32x16_t acc[MT][NW];
     // a finished tile's values wait in registers and leave one pass later, right after the next patch loads are issued: the wait for those
@@ -599,8 +601,8 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_res_kernel(const fl
                 for (int g = 0; g < 4; ++g) *reinterpret_cast<float4 *>(dst + n * 32 + 8 * g + 4 * lh) = pend[j][n][g];
         }
     };
-    while (tile < n_tiles) {
-        if (s == first_slice(tile)) {
+    while (k < n_mine) {
+        if (s == first_slice(cur)) {
 #pragma unroll
             for (int j = 0; j < MT; ++j)
 #pragma unroll
@@ -613,16 +615,21 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_res_kernel(const fl
         if (RESTAGE && !(CSR_EXP & 16)) write_w();             // unconditionally (46 - 92 KB of LDS writes against ~1 MB of fragment reads per pass):
         __syncthreads();                                       // under a condition the compiler keeps the pieces in scratch memory
         // the next pass: its patch and its weight tiles in flight during this pass's MFMAs
-        int nt = tile, ns = s + 1;
-        if (ns >= end_slice(tile)) { nt = tile + slots; ns = nt < n_tiles ? first_slice(nt) : s; }
-        if (nt < n_tiles && !(CSR_EXP & 8)) fetch_patch(nt, ns);
-        if (RESTAGE && !(CSR_EXP & 16)) fetch_w(ns);
+        int nk = k, ns = s + 1, nf = f, ncs = cs + 1;
+        nxt = cur;
+        if (ncs == nc) { ncs = 0; ++nf; }
+        if (ns >= end_slice(cur)) {
+            nk = k + 1;
+            if (nk < n_mine) { nxt = walk.get(nk); ns = first_slice(nxt); nf = ns ? 1 : 0; ncs = 0; }
+            else { ns = s; nf = f; ncs = cs; }
+        }
+        if (nk < n_mine && !(CSR_EXP & 8)) fetch_patch(nxt, nf, ncs);
+        if (RESTAGE && !(CSR_EXP & 16)) fetch_w(nf, ncs);
         if (have_pend && !(CSR_EXP & 4)) flush();
         have_pend = false;
 
         // the lane's pixels of this tile
-        const int img = tile / tiles_img, rem = tile - img * tiles_img;
-        const int y0 = (rem / tiles_x) * rows, x0 = (rem % tiles_x) * bw;
+        const int img = cur.img, y0 = cur.y0, x0 = cur.x0;
         int poff[MT], pyx[MT];
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
@@ -670,7 +677,7 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_res_kernel(const fl
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (nt != tile) {                                      // last slice of this tile: scales off, bias, ReLU -> the pending registers
+        if (nk != k) {                                         // last slice of this tile: scales off, bias, ReLU -> the pending registers
             pend_img = img;
 #pragma unroll
             for (int j = 0; j < MT; ++j) {
@@ -703,8 +710,11 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_res_kernel(const fl
                 have_pend = false;
             }
         }
-        tile = nt;
+        k = nk;
         s = ns;
+        f = nf;
+        cs = ncs;
+        cur = nxt;
     }
     if (have_pend && !(CSR_EXP & 4)) flush();
     if (out_amax) {
@@ -890,7 +900,7 @@ extern "C" int pcacc_conv3x3_split(const float *in, const float *in_amax, const 
         return PCACC_E_ARG;
     hipStream_t st = pcacc_stream(stream);
     ConvResPlan rp;
-    if (conv_res_plan(n_img, h, w, c_in, c_out, &rp)) {
+    if (conv_res_plan(n_img, h, w, c_in, c_out, &rp) && PCACC_WALK_OK(n_img, frames, rp.tiles_y, rp.tiles_x)) {
         if (getenv("PCACC_CONV_PLAN"))
             fprintf(stderr, "split conv plan (resident) %dx%d %d->%d kt=%d n=%d: cs=%d nw=%d mt=%d rows=%d bw=%d slots=%d lds=%zu\n", h, w, c_in, c_out,
                     kt, n_img, rp.cs, rp.nw, rp.mt, rp.rows, rp.bw, rp.slots, rp.lds);
