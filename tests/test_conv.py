@@ -69,23 +69,25 @@ def test_conv3x3x3_forward(b, t, h, w, ci, co):
     _close(y, ref, ref.abs().max().item())
 
 
-@pytest.mark.parametrize('b,t,h,w,co', [(2, 5, 16, 40, 32), (1, 3, 9, 33, 64), (1, 5, 41, 70, 32)])
-def test_conv3x3x3_swizzled_rows_equal_padded_rows(b, t, h, w, co, monkeypatch):
-    """The 27-tap 32-channel layers run on unpadded XOR-swizzled LDS rows (two workgroups per CU); PCACC_CONV_SWZ_OFF selects the
-    padded-row kernel they replaced.  Same products in the same order: bit-identical, with and without an epilogue mask."""
+@pytest.mark.parametrize('b,t,h,w,co', [(2, 5, 16, 40, 32), (1, 3, 9, 33, 64), (1, 5, 41, 70, 32), (3, 1, 8, 32, 32), (2, 2, 17, 64, 64)])
+def test_conv3x3x3_kernels_agree(b, t, h, w, co, monkeypatch):
+    """The 27-tap 32-channel layers run on unpadded XOR-swizzled LDS rows (two workgroups per CU) with their tiles in frame-fastest order;
+    PCACC_CONV_FRAME_MAJOR selects the frame-by-frame order, PCACC_CONV_SWZ_OFF the padded-row kernel of round 2.  Same products in the
+    same order per output: bit-identical, with and without an epilogue mask."""
     g = torch.Generator(device='cpu').manual_seed(11 + co)
     x = torch.randn(b * t, h, w, 32, generator=g).to(DEV).to(torch.bfloat16)
     wt = (torch.randn(co, 32, 3, 3, 3, generator=g) / (5 * 32 ** 0.5)).to(DEV)
     bias = torch.randn(co, generator=g).to(DEV)
     mask = torch.randn(b * t, h, w, co, generator=g).to(DEV).to(torch.bfloat16)
     wp = native.conv3x3_prepare_weights(wt)
-    got = native.conv3x3(x, wp, bias, t, True), native.conv3x3(x, wp, None, t, False, out_mask=mask)
-    monkeypatch.setenv('PCACC_CONV_SWZ_OFF', '1')
-    ref = native.conv3x3(x, wp, bias, t, True), native.conv3x3(x, wp, None, t, False, out_mask=mask)
-    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
-    monkeypatch.setenv('PCACC_CONV_FRAME_MAJOR', '1')          # tiles frame by frame instead of frame-fastest: the same tiles in another order
-    ref = native.conv3x3(x, wp, bias, t, True), native.conv3x3(x, wp, None, t, False, out_mask=mask)
-    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+    run = lambda: (native.conv3x3(x, wp, bias, t, True), native.conv3x3(x, wp, None, t, False, out_mask=mask))
+    got = run()
+    for env in ({'PCACC_CONV_FRAME_MAJOR': '1'}, {'PCACC_CONV_SWZ_OFF': '1'}, {'PCACC_CONV_SWZ_OFF': '1', 'PCACC_CONV_FRAME_MAJOR': '1'}):
+        with monkeypatch.context() as m:
+            for k, v in env.items():
+                m.setenv(k, v)
+            ref = run()
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), env
 
 
 @pytest.mark.parametrize('kt', [1, 3])
