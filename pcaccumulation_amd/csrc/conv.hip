@@ -128,6 +128,18 @@ __device__ __forceinline__ uint32_t conv_mask2(uint32_t v, uint32_t m)
 
 // omask (may be NULL): a map of the output's shape; results are stored as zero where it is <= 0 -- the data gradient of a layer whose input
 // was a ReLU output leaves already masked for that ReLU (the producer then needs no threshold pass of its own)
+// A lane holds 4 channels (8 bytes) of each of the four 8-channel groups of its pixel, lane + 32 the other 4: stored as they are, every
+// global_store_dwordx2 of a wave writes 16 bytes into each of 32 different 64-byte lines, four instructions per row.  Lanes l and l + 32
+// exchange halves first (v_permlane32_swap: the upper half-wave's group 2j against the lower half-wave's group 2j + 1), after which lane l
+// holds channels 16j .. 16j + 7 and lane l + 32 channels 16j + 8 .. + 15: two dwordx4 stores per row, 32 contiguous bytes per pixel each.
+__device__ __forceinline__ uint4 conv_pair16(uint2 g_even, uint2 g_odd)
+{
+    typedef unsigned cv_u2 __attribute__((ext_vector_type(2)));
+    const cv_u2 x = __builtin_amdgcn_permlane32_swap(g_even.x, g_odd.x, false, false);
+    const cv_u2 y = __builtin_amdgcn_permlane32_swap(g_even.y, g_odd.y, false, false);
+    return make_uint4(x[0], y[0], x[1], y[1]);
+}
+
 template <int R, int CT>
 __device__ __forceinline__ void conv_store_packed(const uint2 (&pk)[R][CT][4], uint16_t *__restrict__ out, int img, int y0, int x0, int h,
                                                   int w, int c_out, int co, int row0, int lp, int lh, const uint16_t *__restrict__ omask = nullptr)
@@ -136,26 +148,33 @@ __device__ __forceinline__ void conv_store_packed(const uint2 (&pk)[R][CT][4], u
 #pragma unroll
     for (int m = 0; m < R; ++m) {
         const int y = y0 + row0 + m;
+        uint4 v[CT][2];                                        // the exchange involves both half-waves: before any lane drops out
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) v[ct][j] = conv_pair16(pk[m][ct][2 * j], pk[m][ct][2 * j + 1]);
         if (y >= h || x >= w) continue;
-        const int64_t off = (((int64_t)img * h + y) * w + x) * c_out + co;
+        const int64_t off = (((int64_t)img * h + y) * w + x) * c_out + co + 8 * lh;
         uint16_t *dst = out + off;
         if (omask) {
-            uint2 mk[CT][4];
+            uint4 mk[CT][2];
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) mk[ct][g] = *reinterpret_cast<const uint2 *>(omask + off + ct * 32 + 8 * g + 4 * lh);
+                for (int j = 0; j < 2; ++j) mk[ct][j] = *reinterpret_cast<const uint4 *>(omask + off + ct * 32 + 16 * j);
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<uint2 *>(dst + ct * 32 + 8 * g + 4 * lh) = make_uint2(conv_mask2(pk[m][ct][g].x, mk[ct][g].x), conv_mask2(pk[m][ct][g].y, mk[ct][g].y));
+                for (int j = 0; j < 2; ++j)
+                    *reinterpret_cast<uint4 *>(dst + ct * 32 + 16 * j) =
+                        make_uint4(conv_mask2(v[ct][j].x, mk[ct][j].x), conv_mask2(v[ct][j].y, mk[ct][j].y), conv_mask2(v[ct][j].z, mk[ct][j].z),
+                                   conv_mask2(v[ct][j].w, mk[ct][j].w));
             continue;
         }
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) *reinterpret_cast<uint2 *>(dst + ct * 32 + 8 * g + 4 * lh) = pk[m][ct][g];
+            for (int j = 0; j < 2; ++j) *reinterpret_cast<uint4 *>(dst + ct * 32 + 16 * j) = v[ct][j];
     }
 }
 
