@@ -395,29 +395,46 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_wgrad_strip_kernel(const u
         const int next = job + slots;
         if (next < n_jobs) fetch(next);
         job = next;
-        for (int s = 0; s < n_steps; ++s) {
+        // software pipeline: a step's dY fragment and patch-row indices are read during the previous step's MFMAs, a tap's X fragment
+        // during the previous tap's MFMA (as first written every MFMA waited for the LDS reads issued right before it: 16 % matrix-pipe
+        // utilisation at 256 x 256 channels on 36^2 images)
+        int toff[TG];                                          // wave-uniform tap offsets inside the patch
+#pragma unroll
+        for (int t = 0; t < TG; ++t) {
+            const int tap = min(tap0 + t, 8);
+            toff[t] = ((tap / 3) * pw + tap % 3) * XS;
+        }
+        auto load_a = [&](int s, cd_frag &af, int &p0, int &p1) {
             const int r0 = s * 16 + tr_row;
             const uint16_t *pa = sdy + r0 * YS + ct * 32 + tr_col;
-            cd_frag af;
             af.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cd_s16x4 __attribute__((address_space(3))) *)pa);
             af.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cd_s16x4 __attribute__((address_space(3))) *)(pa + 4 * YS));
+            p0 = ptab[r0]; p1 = ptab[r0 + 4];
+        };
+        auto load_b = [&](cd_frag &bf, const uint16_t *pb0, const uint16_t *pb1, int t) {
+            bf.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cd_s16x4 __attribute__((address_space(3))) *)(pb0 + toff[t]));
+            bf.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cd_s16x4 __attribute__((address_space(3))) *)(pb1 + toff[t]));
+        };
+        cd_frag af_n;
+        int p0_n, p1_n;
+        load_a(0, af_n, p0_n, p1_n);
+        for (int s = 0; s < n_steps; ++s) {
+            const cd_frag af = af_n;
+            const uint16_t *pb0 = sx + p0_n * XS + it * 32 + tr_col, *pb1 = sx + p1_n * XS + it * 32 + tr_col;
+            cd_frag bf[2];
+            load_b(bf[0], pb0, pb1, 0);
+            load_b(bf[1], pb0, pb1, 1);
+            if (s + 1 < n_steps) load_a(s + 1, af_n, p0_n, p1_n);
             if (it == 0 && grp == 0) {                         // bias gradient = column sums of dY: the fragment is at hand
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) bsum += bf16_to_f32((uint16_t)af.h[j][q]);
             }
-            const int p0 = ptab[r0], p1 = ptab[r0 + 4];
-            const uint16_t *pb0 = sx + p0 * XS + it * 32 + tr_col, *pb1 = sx + p1 * XS + it * 32 + tr_col;
 #pragma unroll
-            for (int t = 0; t < TG; ++t) {
-                if (t >= n_tap) continue;
-                const int tap = tap0 + t;
-                const int toff = ((tap / 3) * pw + tap % 3) * XS;
-                cd_frag bf;
-                bf.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cd_s16x4 __attribute__((address_space(3))) *)(pb0 + toff));
-                bf.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cd_s16x4 __attribute__((address_space(3))) *)(pb1 + toff));
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.v, bf.v, acc[t], 0, 0, 0);
+            for (int t = 0; t < TG; ++t) {                     // n_tap is 4 or 5
+                if (t < TG - 1 || n_tap == TG) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.v, bf[t & 1].v, acc[t], 0, 0, 0);
+                if (t + 2 < TG - 1 || (t + 2 == TG - 1 && n_tap == TG)) load_b(bf[t & 1], pb0, pb1, t + 2);
             }
         }
     }
