@@ -30,6 +30,8 @@ import contextlib
 import torch
 import torch.distributed as dist
 
+from . import ops
+
 
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torch.distributed.run sets them).
@@ -419,8 +421,10 @@ class DataParallelStep(object):
                 elif self._device_skip:
                     self.optimizer.grad_scale, self.optimizer.found_inf = None, bad
                     self.optimizer.step()
+                    ops.weights_may_have_changed()
                 elif not bool(bad.item()):
                     self.optimizer.step()
+                    ops.weights_may_have_changed()
         return stats
 
 

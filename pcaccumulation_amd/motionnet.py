@@ -108,6 +108,12 @@ class MotionNet(nn.Module):
         mods = (self.pillar_encoder, self.unet, self.semseg_head, self.ego_feats_head, self.ego_motion_head)
         return [p for m in mods for p in m.parameters()]
 
+    def train(self, mode=True):
+        """nn.Module.train / eval; a mode switch also drops the prepared copies of the convolution weights (ops.weights_may_have_changed:
+        a fused optimizer step between the last training forward and this switch leaves no trace in the parameters' version counters)."""
+        ops.weights_may_have_changed()
+        return super().train(mode)
+
     def channels_last_(self):
         """Store conv weights in the layout the channels-last activations want (no state_dict change)."""
         for m in self.modules():
@@ -174,6 +180,8 @@ class MotionNet(nn.Module):
         device = coordinates.device
         ops.set_point_dtype(self.compute_dtype if device.type == 'cuda' else torch.float32)
         ops.set_split(self.compute_mode == 'fp32x3' and device.type == 'cuda')
+        if self.training:
+            ops.weights_may_have_changed()                                     # an optimizer step lies between two training forwards
         results = LazyDict()
 
         # 0. index structures shared by every irregular op of this forward, and everything else that follows from the batch alone

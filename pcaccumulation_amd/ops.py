@@ -767,15 +767,30 @@ def tube_pose(pose_vec, rows, plan, remaining, total, slot_centre, weights, n_fr
 
 
 _PREPARED = {}
+_WEIGHT_EPOCH = 0
+
+
+def weights_may_have_changed():
+    """Forget every prepared (packed / split) copy of a weight.  A parameter's version counter does not see every writer: the fused
+    optimizers (torch.optim.Adam(fused=True): `_fused_adam_`) update parameters WITHOUT incrementing it, so a copy keyed on
+    (object, version, address) alone outlives an optimizer step.  MotionNet calls this at the start of every training-mode forward and on
+    every train() / eval() switch, DataParallelStep after its optimizer step; call it yourself after writing weights through anything
+    else that bypasses the counter (raw pointers, another fused optimizer outside these paths)."""
+    global _WEIGHT_EPOCH
+    _WEIGHT_EPOCH += 1
+
+
+def _weight_key(weight):
+    return (weight._version, weight.data_ptr(), _WEIGHT_EPOCH)
 
 
 def prepared_conv_weights(weight):
-    """(forward form, data-gradient form) of a 3x3 / 3x3x3 weight for the MFMA kernels, prepared once per weight VERSION: the
-    forward of a training step and its backward share one launch, evaluation passes reuse the forms until the optimizer (or a
-    load_state_dict) writes the parameter again."""
+    """(forward form, data-gradient form) of a 3x3 / 3x3x3 weight for the MFMA kernels, prepared once per weight VERSION and weight
+    epoch (weights_may_have_changed): the forward of a training step and its backward share one launch, evaluation passes reuse the forms
+    until the optimizer (or a load_state_dict) writes the parameter again."""
     key = id(weight)
     hit = _PREPARED.get(key)
-    if hit is not None and hit[0]() is weight and hit[1] == (weight._version, weight.data_ptr()):
+    if hit is not None and hit[0]() is weight and hit[1] == _weight_key(weight):
         return hit[2], hit[3]
     w = weight.detach()
     if w.dtype != torch.float32:
@@ -783,7 +798,7 @@ def prepared_conv_weights(weight):
     fwd, bwd = native.conv3x3_prepare_weights_pair(w)
     if len(_PREPARED) > 4096:
         _PREPARED.clear()
-    _PREPARED[key] = (weakref.ref(weight), (weight._version, weight.data_ptr()), fwd, bwd)
+    _PREPARED[key] = (weakref.ref(weight), _weight_key(weight), fwd, bwd)
     return fwd, bwd
 
 
@@ -870,7 +885,7 @@ def prepared_conv_weights_split(weight):
     """(forward form, data-gradient form) of a 3x3 / 3x3x3 weight as fp16 hi / lo planes + row scales (fp32x3 mode), once per weight version."""
     key = id(weight)
     hit = _PREPARED_SPLIT.get(key)
-    if hit is not None and hit[0]() is weight and hit[1] == (weight._version, weight.data_ptr()):
+    if hit is not None and hit[0]() is weight and hit[1] == _weight_key(weight):
         return hit[2], hit[3]
     w = weight.detach()
     if w.dtype != torch.float32:
@@ -878,7 +893,7 @@ def prepared_conv_weights_split(weight):
     fwd, bwd = native.conv3x3_split_prepare_weights(w)
     if len(_PREPARED_SPLIT) > 4096:
         _PREPARED_SPLIT.clear()
-    _PREPARED_SPLIT[key] = (weakref.ref(weight), (weight._version, weight.data_ptr()), fwd, bwd)
+    _PREPARED_SPLIT[key] = (weakref.ref(weight), _weight_key(weight), fwd, bwd)
     return fwd, bwd
 
 
@@ -936,12 +951,12 @@ _PREPARED_UP = {}
 def prepared_upconv_weights_split(weight):
     key = id(weight)
     hit = _PREPARED_UP.get(key)
-    if hit is not None and hit[0]() is weight and hit[1] == (weight._version, weight.data_ptr()):
+    if hit is not None and hit[0]() is weight and hit[1] == _weight_key(weight):
         return hit[2], hit[3]
     fwd, bwd = native.upconv2x2_split_prepare_weights(weight.detach())
     if len(_PREPARED_UP) > 4096:
         _PREPARED_UP.clear()
-    _PREPARED_UP[key] = (weakref.ref(weight), (weight._version, weight.data_ptr()), fwd, bwd)
+    _PREPARED_UP[key] = (weakref.ref(weight), _weight_key(weight), fwd, bwd)
     return fwd, bwd
 
 

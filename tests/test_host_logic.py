@@ -66,3 +66,27 @@ def test_amax_tags_follow_views_and_versions():
     assert ops.amax_tag(d) is parts                                       # the copy made before the write keeps its own
     m = ops.merge_amax(torch.randn(2), x, y)
     assert ops.amax_tag(m) is None                                        # a source without a tag: nothing to merge
+
+
+def test_prepared_weight_copies_are_keyed_on_the_weight_epoch_too():
+    """ops.prepared_conv_weights* key their copies on (object, version, address, weight epoch): torch's fused optimizers do not increment
+    the version counter, so MotionNet bumps the epoch on every training forward / mode switch and DataParallelStep after its optimizer step."""
+    import torch
+    from pcaccumulation_amd import ops
+    from pcaccumulation_amd.config import default_config
+    from pcaccumulation_amd.motionnet import MotionNet
+    w = torch.nn.Parameter(torch.randn(4, 4, 3, 3))
+    k0 = ops._weight_key(w)
+    ops.weights_may_have_changed()
+    k1 = ops._weight_key(w)
+    assert k0 != k1 and k0[:2] == k1[:2]
+    with torch.no_grad():
+        w.add_(1.0)
+    assert ops._weight_key(w)[0] != k1[0]                       # ordinary in-place writes still show in the version
+    model = MotionNet(default_config('waymo', 'train', n_sweeps=3, xy_range=8))
+    e = ops._WEIGHT_EPOCH
+    model.eval()
+    assert ops._WEIGHT_EPOCH > e
+    e = ops._WEIGHT_EPOCH
+    model.train()
+    assert ops._WEIGHT_EPOCH > e
