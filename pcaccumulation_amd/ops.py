@@ -784,6 +784,11 @@ def _weight_key(weight):
     return (weight._version, weight.data_ptr(), _WEIGHT_EPOCH)
 
 
+def _weight_ref(cache, key, weight):
+    """A weak reference that removes the weight's entry (and frees its device copies) when the weight dies."""
+    return weakref.ref(weight, lambda _r, c=cache, k=key: c.pop(k, None))
+
+
 def prepared_conv_weights(weight):
     """(forward form, data-gradient form) of a 3x3 / 3x3x3 weight for the MFMA kernels, prepared once per weight VERSION and weight
     epoch (weights_may_have_changed): the forward of a training step and its backward share one launch, evaluation passes reuse the forms
@@ -798,7 +803,7 @@ def prepared_conv_weights(weight):
     fwd, bwd = native.conv3x3_prepare_weights_pair(w)
     if len(_PREPARED) > 4096:
         _PREPARED.clear()
-    _PREPARED[key] = (weakref.ref(weight), _weight_key(weight), fwd, bwd)
+    _PREPARED[key] = (_weight_ref(_PREPARED, key, weight), _weight_key(weight), fwd, bwd)
     return fwd, bwd
 
 
@@ -893,7 +898,7 @@ def prepared_conv_weights_split(weight):
     fwd, bwd = native.conv3x3_split_prepare_weights(w)
     if len(_PREPARED_SPLIT) > 4096:
         _PREPARED_SPLIT.clear()
-    _PREPARED_SPLIT[key] = (weakref.ref(weight), _weight_key(weight), fwd, bwd)
+    _PREPARED_SPLIT[key] = (_weight_ref(_PREPARED_SPLIT, key, weight), _weight_key(weight), fwd, bwd)
     return fwd, bwd
 
 
@@ -956,7 +961,7 @@ def prepared_upconv_weights_split(weight):
     fwd, bwd = native.upconv2x2_split_prepare_weights(weight.detach())
     if len(_PREPARED_UP) > 4096:
         _PREPARED_UP.clear()
-    _PREPARED_UP[key] = (weakref.ref(weight), _weight_key(weight), fwd, bwd)
+    _PREPARED_UP[key] = (_weight_ref(_PREPARED_UP, key, weight), _weight_key(weight), fwd, bwd)
     return fwd, bwd
 
 

@@ -90,3 +90,13 @@ def test_prepared_weight_copies_are_keyed_on_the_weight_epoch_too():
     e = ops._WEIGHT_EPOCH
     model.train()
     assert ops._WEIGHT_EPOCH > e
+    # an entry goes with its weight (no device copies of dead parameters until the 4096-entry sweep)
+    import gc
+    cache = {}
+    w2 = torch.nn.Parameter(torch.randn(2, 2, 3, 3))
+    cache[id(w2)] = (ops._weight_ref(cache, id(w2), w2), ops._weight_key(w2), None, None)
+    assert len(cache) == 1
+    del w2
+    gc.collect()
+    assert len(cache) == 0
+
