@@ -51,7 +51,10 @@ class PillarIndex(object):
             self.coordinates = coordinates[spl]
             self._frames = (torch.arange(self.m, dtype=torch.int32, device=sp.device), offs)
             if p2v is not None:
-                p2v = rank[p2v.long()]
+                # points of a pillar without a rank (malformed `coordinates`: MotionNet.forward raises at its host sync, but the kernels
+                # queued before that would index with -1) are parked on pillar 0: wrong values for a batch that is rejected anyway, no
+                # out-of-bounds access
+                p2v = rank.clamp(min=0)[p2v.long()]
         if p2v is not None:
             self.p2v = p2v.contiguous()
             self.n = int(self.p2v.shape[0])
