@@ -276,7 +276,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--pts-per-frame', type=int, default=160000)
     ap.add_argument('--batch', type=int, default=4, help='sequences per GPU per step (reference default: train.batch_size = 4, configs/default.yaml:33)')
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32', 'fp32x3'])
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32', 'fp32x3', 'mixed'])
     ap.add_argument('--iter-size', type=int, default=1, help='micro-steps per optimizer step (gradient accumulation; the all-reduce fires on the last one; reference yaml: 2)')
     ap.add_argument('--points', default='uniform', choices=['uniform', 'lidar'], help="synthetic point distribution: 'uniform' (BASELINE.json: synthetic; the headline) or 'lidar' = 1/r range density, 64 beams, scan-ordered within a frame (SURVEY 8d; synthetic.make_sequence(mode='lidar_scan'))")
     ap.add_argument('--no-cpu-baseline', action='store_true')

@@ -38,6 +38,10 @@ extern "C" {
 /* Library / build identification: returns the gfx target string the kernels were compiled for. */
 const char *pcacc_target(void);
 
+/* The launchers' A/B switches (PCACC_CONV_FRAME_MAJOR, PCACC_CONV_SWZ_OFF, PCACC_CONV_RES, PCACC_ROWS_FM_OFF, PCACC_CONV_PLAN: experiments and
+ * the equality tests only) are read from the environment once per process; this reads them again.  Returns 0. */
+int pcacc_reload_switches(void);
+
 /* ------------------------------------------------------------------------------------------------
  * A1. 4-D pillar voxelisation, first-touch numbering, bit-exact.
  * Replaces libs/voxel_generator.py:4-61 (_points_to_voxel_reverse_kernel), :64-114 (points_to_voxel)
@@ -448,6 +452,13 @@ int pcacc_conv3x3_split_supported(int32_t h, int32_t w, int32_t c_in, int32_t c_
 int pcacc_conv3x3_split(const float *in, const float *in_amax, const float *in_mask, const uint16_t *wp, const float *wscale,
                         const float *bias, float *out, float *out_amax, int32_t n_img, int32_t frames, int32_t h, int32_t w, int32_t c_in,
                         int32_t c_out, int32_t kt, int32_t relu, void *stream);
+/* pcacc_conv3x3_split with a second result, out16 [n_img,h,w,c_out] bf16 = the fp32 result rounded to nearest even, written by the same epilogue
+ * ('mixed' compute mode: fp32x3 forward values, bf16 gradient graph -- the shadow the bf16 data / weight gradient kernels read; 2 extra bytes per
+ * element stored instead of a 6-byte cast pass).  models/unet.py:11-20,45-113, models/stpn.py:13-43. */
+int pcacc_conv3x3_split_dual(const float *in, const float *in_amax, const float *in_mask, const uint16_t *wp, const float *wscale,
+                             const float *bias, float *out, float *out_amax, uint16_t *out16, int32_t n_img, int32_t frames, int32_t h,
+                             int32_t w, int32_t c_in, int32_t c_out, int32_t kt, int32_t relu, void *stream);
+
 /* The same convolution (no bias, no ReLU; in_mask as above) with its result stored as zero where out_mask [n_img,h,w,c_out] f32 is <= 0: the
  * data gradient of conv -> ReLU -> conv masked for the first ReLU in the epilogue (the fp32x3 twin of pcacc_conv3x3_outmask_bf16). */
 int pcacc_conv3x3_split_outmask(const float *in, const float *in_amax, const float *in_mask, const uint16_t *wp, const float *wscale,
@@ -471,6 +482,9 @@ int pcacc_upconv2x2_split_prepare_weights(const float *w, int32_t c_in, int32_t 
 int pcacc_upconv2x2_split_supported(int32_t h, int32_t w, int32_t c_in, int32_t c_up);
 int pcacc_upconv2x2_split(const float *in, const float *in_amax, const uint16_t *wp, const float *wscale, const float *bias, float *out,
                           float *out_amax, int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_up, int32_t direction, void *stream);
+/* pcacc_upconv2x2_split (direction 0) with the bf16 shadow of its result as a second output ('mixed' mode, see pcacc_conv3x3_split_dual). */
+int pcacc_upconv2x2_split_dual(const float *in, const float *in_amax, const uint16_t *wp, const float *wscale, const float *bias, float *out,
+                               float *out_amax, uint16_t *out16, int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_up, void *stream);
 int pcacc_upconv2x2_wgrad_split_workspace_bytes(int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_up, size_t *bytes /*host*/);
 int pcacc_upconv2x2_wgrad_split(const float *dy, const float *dy_amax, const float *x, const float *x_amax, float *dw, float *db4, int32_t n_img,
                                 int32_t h, int32_t w, int32_t c_in, int32_t c_up, void *workspace, size_t workspace_bytes, void *stream);
@@ -646,6 +660,10 @@ int pcacc_pool_skip_relu_backward_strided_bf16(const uint16_t *y, const uint16_t
                                                int64_t n_img, int32_t h, int32_t w, int32_t c, uint16_t *grad_y, void *stream);
 int pcacc_pool_skip_relu_backward_strided_f32(const float *y, const float *grad_pooled, const float *grad_skip, int64_t skip_pitch,
                                               int64_t n_img, int32_t h, int32_t w, int32_t c, float *grad_y, float *out_amax, void *stream);
+/* 'mixed' compute mode: y f32 (the forward's own values decide the window's winner -- a bf16 copy of y ties values closer than 2^-8 and sends
+ * ~1 % of the windows' gradient to the wrong pixel), gradients and result bf16; c a multiple of 8. */
+int pcacc_pool_skip_relu_backward_strided_y32(const float *y, const uint16_t *grad_pooled, const uint16_t *grad_skip, int64_t skip_pitch,
+                                              int64_t n_img, int32_t h, int32_t w, int32_t c, uint16_t *grad_y, void *stream);
 
 /* Batched inverse of n 4x4 f32 matrices (the pose tables: torch.linalg.inv at models/motionnet.py:100 and models/alignnet.py:33),
  * Gauss-Jordan with partial pivoting, one launch; a singular matrix yields inf / nan entries (no status word). */

@@ -318,6 +318,32 @@ extern "C" int pcacc_gather_rows(const void *src, int row_bytes, const int32_t *
 
 extern "C" const char *pcacc_target(void) { return "gfx950"; }
 
+static PcaccSwitches g_switches;
+static bool g_switches_read = false;
+
+static void switches_read()
+{
+    const char *e = getenv("PCACC_CONV_RES");
+    g_switches.conv_frame_major = getenv("PCACC_CONV_FRAME_MAJOR") != nullptr;
+    g_switches.conv_swz_off = getenv("PCACC_CONV_SWZ_OFF") != nullptr;
+    g_switches.rows_fm_off = getenv("PCACC_ROWS_FM_OFF") != nullptr;
+    g_switches.conv_plan = getenv("PCACC_CONV_PLAN") != nullptr;
+    g_switches.conv_res = e ? e[0] : 0;
+    g_switches_read = true;
+}
+
+const PcaccSwitches &pcacc_switches()
+{
+    if (!g_switches_read) switches_read();        // benign race: every thread writes the same values
+    return g_switches;
+}
+
+extern "C" int pcacc_reload_switches(void)
+{
+    switches_read();
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Small host arrays (per-sample counts, label offsets, thresholds: a few dozen words) to device memory as KERNEL ARGUMENTS.
 // A hipMemcpy from pageable host memory on the compute stream waits for everything queued before it -- each

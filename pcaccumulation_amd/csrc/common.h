@@ -13,6 +13,17 @@
         if (hipGetLastError() != hipSuccess) return PCACC_E_LAUNCH; \
     } while (0)
 
+// A/B switches of the launchers (experiments and the equality tests; never set in production): environment variables read ONCE per process
+// (a libc environment scan per convolution launch otherwise) -- pcacc_reload_switches() reads them again (tests change them at run time).
+struct PcaccSwitches {
+    bool conv_frame_major;   // PCACC_CONV_FRAME_MAJOR: bf16 resident convolution tiles frame by frame instead of frame-fastest
+    bool conv_swz_off;       // PCACC_CONV_SWZ_OFF: 27-tap layers on the padded-row kernel of round 2
+    bool rows_fm_off;        // PCACC_ROWS_FM_OFF: wide fp32x3 row layers on the weights-in-LDS kernel
+    bool conv_plan;          // PCACC_CONV_PLAN: print the launch plans of the strip kernels
+    char conv_res;           // PCACC_CONV_RES: '0' never the resident fp32x3 kernel, '2' whatever the size, 0 unset
+};
+const PcaccSwitches &pcacc_switches();           // canvas.hip
+
 static inline hipStream_t pcacc_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 // Grid for a grid-stride, HBM-bound kernel: enough workgroups to fill 256 CUs x 8 waves, never more

@@ -524,7 +524,7 @@ static int conv_launch_resident(const uint16_t *in, const uint16_t *wp, const fl
     if (slots < 1) slots = 1;
     const unsigned grid = (unsigned)(8 * co_groups * slots);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, st, in, wp, bias, out, n_img, frames, h, w, c_out, kt, relu, tiles_x,
-                       tiles_y, co_groups, omask, getenv("PCACC_CONV_FRAME_MAJOR") ? 0 : 1);
+                       tiles_y, co_groups, omask, pcacc_switches().conv_frame_major ? 0 : 1);
     PCACC_CHECK_LAUNCH();
     return 0;
 }
@@ -567,7 +567,7 @@ static int conv3x3_bf16_any(const uint16_t *in, const uint16_t *wp, const float 
     return conv_launch_resident<CTV, CSV, RV, CTWV>(in, wp, bias, out, n_img, frames, h, w, c_out, kt, relu, st, omask)
             if (c_in == 32 && ctr == 1) {
                 // 27 taps: 96 KB with padded rows = one 8-wave workgroup per CU, 77 KB with swizzled rows = two of 4 waves, 2 rows each
-                if (alone && !getenv("PCACC_CONV_SWZ_OFF"))                 // the switch is for A/B measurements and the equality test
+                if (alone && !pcacc_switches().conv_swz_off)                 // the switch is for A/B measurements and the equality test
                     return conv_launch_resident<1, 32, 1, 1, true>(in, wp, bias, out, n_img, frames, h, w, c_out, kt, relu, st, omask);
                 if (alone) CV_RES(1, 32, 1, 1);
                 CV_RES(1, 32, 2, 1);

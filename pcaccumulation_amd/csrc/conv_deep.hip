@@ -289,7 +289,7 @@ extern "C" int pcacc_conv3x3_deep_bf16(const uint16_t *in, const uint16_t *in_ma
 {
     ConvStripPlan p;
     if (!in || !wp || !out || n_img < 1 || !conv_strip_plan(n_img, h, w, c_in, c_out, &p)) return PCACC_E_ARG;
-    if (getenv("PCACC_CONV_PLAN")) fprintf(stderr, "conv plan %dx%d %d->%d n=%d: cs=%d ng=%d mt=%d rows=%d blocks=%lld\n", h, w, c_in, c_out, n_img, p.cs, p.ng, p.mt, p.rows, (long long)p.blocks);
+    if (pcacc_switches().conv_plan) fprintf(stderr, "conv plan %dx%d %d->%d n=%d: cs=%d ng=%d mt=%d rows=%d blocks=%lld\n", h, w, c_in, c_out, n_img, p.cs, p.ng, p.mt, p.rows, (long long)p.blocks);
     hipStream_t st = pcacc_stream(stream);
 #define CD_CASE(CSV, NGV, MTV) \
     if (p.cs == CSV && p.ng == NGV && p.mt == MTV) \

@@ -222,7 +222,8 @@ template <int CS, int NW, int NGW, int MT, int TAPS>
 __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float *__restrict__ in, const float *__restrict__ in_amax,
                                                                     const float *__restrict__ in_mask, const uint16_t *__restrict__ wp,
                                                                     const float *__restrict__ wscale, const float *__restrict__ bias,
-                                                                    float *__restrict__ out, float *__restrict__ out_amax, int n_img, int frames,
+                                                                    float *__restrict__ out, float *__restrict__ out_amax, uint16_t *__restrict__ out16,
+                                                                    int n_img, int frames,
                                                                     int h, int w, int c_in, int c_out, int kt, int relu, int rows, int bw,
                                                                     int tiles_y, int tiles_x, int co_groups, int mode, int c_up)
 {
@@ -445,6 +446,8 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float 
                 if (relu == CSP_OUTMASK) v = csp_outmask4(v, *reinterpret_cast<const float4 *>(bias + ((dst + c) - out)));
                 else if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
                 *reinterpret_cast<float4 *>(dst + c) = v;
+                if (out16)                                     // 'mixed' mode: the bf16 shadow of the result (same element offsets), for the bf16 backward
+                    *reinterpret_cast<uint2 *>(out16 + ((dst + c) - out)) = make_uint2(pcacc_pack_bf16x2(v.x, v.y), pcacc_pack_bf16x2(v.z, v.w));
                 omax = fmaxf(fmaxf(omax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
                 if (!(v.x == v.x && v.y == v.y && v.z == v.z && v.w == v.w)) omax = __builtin_inff();
             }
@@ -472,7 +475,7 @@ template <int CS, int NW, int MT, int PCH, bool RESTAGE>
 __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_res_kernel(const float *__restrict__ in, const float *__restrict__ in_amax,
                                                                         const float *__restrict__ in_mask, const uint16_t *__restrict__ wp,
                                                                         const float *__restrict__ wscale, const float *__restrict__ bias,
-                                                                        float *__restrict__ out, float *__restrict__ out_amax, int n_img, int frames,
+                                                                        float *__restrict__ out, float *__restrict__ out_amax, uint16_t *__restrict__ out16, int n_img, int frames,
                                                                         int h, int w, int c_in, int c_out, int kt, int relu, int rows, int bw,
                                                                         int tiles_y, int tiles_x, int co_groups, int slots)
 {
@@ -598,7 +601,13 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_res_kernel(const fl
 #pragma unroll
             for (int n = 0; n < NW; ++n)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) *reinterpret_cast<float4 *>(dst + n * 32 + 8 * g + 4 * lh) = pend[j][n][g];
+                for (int g = 0; g < 4; ++g) {
+                    const float4 v = pend[j][n][g];
+                    *reinterpret_cast<float4 *>(dst + n * 32 + 8 * g + 4 * lh) = v;
+                    if (out16)                                 // 'mixed' mode: the bf16 shadow of the result, same element offsets
+                        *reinterpret_cast<uint2 *>(out16 + ((dst + n * 32 + 8 * g + 4 * lh) - out)) =
+                            make_uint2(pcacc_pack_bf16x2(v.x, v.y), pcacc_pack_bf16x2(v.z, v.w));
+                }
         }
     };
     while (k < n_mine) {
@@ -747,9 +756,9 @@ static bool conv_res_fits(int cs, int nw, int mt, int rows, int bw, size_t *lds)
 // c_in, c_out in {32, 64} on maps of at least a few thousand pixels (below that the launch is latency, not throughput)
 static bool conv_res_plan(int n_img, int h, int w, int c_in, int c_out, ConvResPlan *best)
 {
-    const char *e = getenv("PCACC_CONV_RES");                 // "0": never, "2": whatever the size (tests)
-    if ((c_in != 32 && c_in != 64) || (c_out != 32 && c_out != 64) || (e && e[0] == '0')) return false;
-    if ((int64_t)n_img * h * w < 200000 && !(e && e[0] == '2')) return false;
+    const char e = pcacc_switches().conv_res;                 // '0': never, '2': whatever the size (tests)
+    if ((c_in != 32 && c_in != 64) || (c_out != 32 && c_out != 64) || e == '0') return false;
+    if ((int64_t)n_img * h * w < 200000 && e != '2') return false;
     const int nw = c_out / 32;
     bool found = false;
     int64_t best_cost = 0;
@@ -793,14 +802,14 @@ static bool conv_res_plan(int n_img, int h, int w, int c_in, int c_out, ConvResP
 
 template <int CS, int NW, int MT, int PCH, bool RESTAGE>
 static int conv_res_launch(const ConvResPlan &p, const float *in, const float *in_amax, const float *in_mask, const uint16_t *wp,
-                           const float *wscale, const float *bias, float *out, float *out_amax, int n_img, int frames, int h, int w, int c_in,
-                           int c_out, int kt, int relu, hipStream_t st)
+                           const float *wscale, const float *bias, float *out, float *out_amax, uint16_t *out16, int n_img, int frames, int h, int w,
+                           int c_in, int c_out, int kt, int relu, hipStream_t st)
 {
     auto kern = conv3x3_split_res_kernel<CS, NW, MT, PCH, RESTAGE>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds) != hipSuccess)
         return PCACC_E_LAUNCH;
     hipLaunchKernelGGL(kern, dim3((unsigned)(p.co_groups * p.slots)), dim3(CSP_THREADS), p.lds, st, in, in_amax, in_mask, wp, wscale, bias, out, out_amax,
-                       n_img, frames, h, w, c_in, c_out, kt, relu, p.rows, p.bw, p.tiles_y, p.tiles_x, p.co_groups, p.slots);
+                       out16, n_img, frames, h, w, c_in, c_out, kt, relu, p.rows, p.bw, p.tiles_y, p.tiles_x, p.co_groups, p.slots);
     PCACC_CHECK_LAUNCH();
     return 0;
 }
@@ -871,14 +880,14 @@ static bool conv_split_plan(int n_img, int h, int w, int c_in, int c_out, int kt
 
 template <int CS, int NW, int NGW, int MT, int TAPS = 9>
 static int conv_split_launch(const ConvSplitPlan &p, const float *in, const float *in_amax, const float *in_mask, const uint16_t *wp,
-                             const float *wscale, const float *bias, float *out, float *out_amax, int n_img, int frames, int h, int w, int c_in,
-                             int c_out, int kt, int relu, hipStream_t st, int mode = CSP_PLAIN, int c_up = 0)
+                             const float *wscale, const float *bias, float *out, float *out_amax, uint16_t *out16, int n_img, int frames, int h, int w,
+                             int c_in, int c_out, int kt, int relu, hipStream_t st, int mode = CSP_PLAIN, int c_up = 0)
 {
     auto kern = conv3x3_split_kernel<CS, NW, NGW, MT, TAPS>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds) != hipSuccess)
         return PCACC_E_LAUNCH;
     if (p.blocks > 0x7fffffff) return PCACC_E_ARG;
-    hipLaunchKernelGGL(kern, dim3((unsigned)p.blocks), dim3(CSP_THREADS), p.lds, st, in, in_amax, in_mask, wp, wscale, bias, out, out_amax, n_img,
+    hipLaunchKernelGGL(kern, dim3((unsigned)p.blocks), dim3(CSP_THREADS), p.lds, st, in, in_amax, in_mask, wp, wscale, bias, out, out_amax, out16, n_img,
                        frames, h, w, c_in, c_out, kt, relu, p.rows, p.bw, p.tiles_y, p.tiles_x, p.co_groups, mode, c_up);
     PCACC_CHECK_LAUNCH();
     return 0;
@@ -890,9 +899,9 @@ extern "C" int pcacc_conv3x3_split_supported(int32_t h, int32_t w, int32_t c_in,
     return conv_split_plan(1, h, w, c_in, c_out, 1, &p) ? 1 : 0;
 }
 
-extern "C" int pcacc_conv3x3_split(const float *in, const float *in_amax, const float *in_mask, const uint16_t *wp, const float *wscale,
-                                   const float *bias, float *out, float *out_amax, int32_t n_img, int32_t frames, int32_t h, int32_t w,
-                                   int32_t c_in, int32_t c_out, int32_t kt, int32_t relu, void *stream)
+static int conv3x3_split_impl(const float *in, const float *in_amax, const float *in_mask, const uint16_t *wp, const float *wscale,
+                              const float *bias, float *out, float *out_amax, uint16_t *out16, int32_t n_img, int32_t frames, int32_t h, int32_t w,
+                              int32_t c_in, int32_t c_out, int32_t kt, int32_t relu, void *stream)
 {
     ConvSplitPlan p;
     if (!in || !in_amax || !wp || !wscale || !out || n_img < 1 || (kt != 1 && kt != 3) || frames < 1 || n_img % frames ||
@@ -901,23 +910,23 @@ extern "C" int pcacc_conv3x3_split(const float *in, const float *in_amax, const 
     hipStream_t st = pcacc_stream(stream);
     ConvResPlan rp;
     if (conv_res_plan(n_img, h, w, c_in, c_out, &rp) && PCACC_WALK_OK(n_img, frames, rp.tiles_y, rp.tiles_x)) {
-        if (getenv("PCACC_CONV_PLAN"))
+        if (pcacc_switches().conv_plan)
             fprintf(stderr, "split conv plan (resident) %dx%d %d->%d kt=%d n=%d: cs=%d nw=%d mt=%d rows=%d bw=%d slots=%d lds=%zu\n", h, w, c_in, c_out,
                     kt, n_img, rp.cs, rp.nw, rp.mt, rp.rows, rp.bw, rp.slots, rp.lds);
         const bool restage = kt == 3 || c_in != rp.cs;         // more than one (frame tap, channel slice) per tile
 #define CSR_CASE(CSV, NWV, MTV, PCHV)                                          \
     if (rp.cs == CSV && rp.nw == NWV && rp.mt == MTV)                          \
-        return restage ? conv_res_launch<CSV, NWV, MTV, PCHV, true>(rp, in, in_amax, in_mask, wp, wscale, bias, out, out_amax, n_img, frames, h, w, c_in, c_out, kt, relu, st) \
-                       : conv_res_launch<CSV, NWV, MTV, PCHV, false>(rp, in, in_amax, in_mask, wp, wscale, bias, out, out_amax, n_img, frames, h, w, c_in, c_out, kt, relu, st)
+        return restage ? conv_res_launch<CSV, NWV, MTV, PCHV, true>(rp, in, in_amax, in_mask, wp, wscale, bias, out, out_amax, out16, n_img, frames, h, w, c_in, c_out, kt, relu, st) \
+                       : conv_res_launch<CSV, NWV, MTV, PCHV, false>(rp, in, in_amax, in_mask, wp, wscale, bias, out, out_amax, out16, n_img, frames, h, w, c_in, c_out, kt, relu, st)
         CSR_CASE(32, 1, 1, 3); CSR_CASE(32, 2, 1, 3); CSR_CASE(32, 1, 2, 5); CSR_CASE(64, 1, 1, 6);
 #undef CSR_CASE
     }
-    if (getenv("PCACC_CONV_PLAN"))
+    if (pcacc_switches().conv_plan)
         fprintf(stderr, "split conv plan %dx%d %d->%d kt=%d n=%d: cs=%d nw=%d ngw=%d mt=%d rows=%d bw=%d blocks=%lld lds=%zu\n", h, w, c_in, c_out,
                 kt, n_img, p.cs, p.nw, p.ngw, p.mt, p.rows, p.bw, (long long)p.blocks, p.lds);
 #define CSP_CASE(CSV, NWV, NGWV, MTV)                                          \
     if (p.cs == CSV && p.nw == NWV && p.ngw == NGWV && p.mt == MTV)            \
-        return conv_split_launch<CSV, NWV, NGWV, MTV>(p, in, in_amax, in_mask, wp, wscale, bias, out, out_amax, n_img, frames, h, w, c_in, c_out, kt, relu, st)
+        return conv_split_launch<CSV, NWV, NGWV, MTV>(p, in, in_amax, in_mask, wp, wscale, bias, out, out_amax, out16, n_img, frames, h, w, c_in, c_out, kt, relu, st)
     CSP_CASE(64, 2, 2, 1); CSP_CASE(64, 2, 2, 2); CSP_CASE(64, 2, 1, 1); CSP_CASE(64, 2, 1, 2);
     CSP_CASE(64, 1, 1, 1); CSP_CASE(64, 1, 1, 2); CSP_CASE(64, 1, 1, 3);
     CSP_CASE(32, 2, 2, 1); CSP_CASE(32, 2, 2, 2); CSP_CASE(32, 2, 1, 1); CSP_CASE(32, 2, 1, 2);
@@ -926,13 +935,30 @@ extern "C" int pcacc_conv3x3_split(const float *in, const float *in_amax, const 
     return PCACC_E_ARG;
 }
 
+extern "C" int pcacc_conv3x3_split(const float *in, const float *in_amax, const float *in_mask, const uint16_t *wp, const float *wscale,
+                                   const float *bias, float *out, float *out_amax, int32_t n_img, int32_t frames, int32_t h, int32_t w,
+                                   int32_t c_in, int32_t c_out, int32_t kt, int32_t relu, void *stream)
+{
+    return conv3x3_split_impl(in, in_amax, in_mask, wp, wscale, bias, out, out_amax, nullptr, n_img, frames, h, w, c_in, c_out, kt, relu, stream);
+}
+
+// the same convolution with a second result: out16 [n_img, h, w, c_out] bf16 = the fp32 result rounded to nearest even ('mixed' compute mode:
+// the shadow the bf16 backward reads; one extra 2-byte store per element instead of a separate cast pass of 6 bytes per element)
+extern "C" int pcacc_conv3x3_split_dual(const float *in, const float *in_amax, const float *in_mask, const uint16_t *wp, const float *wscale,
+                                        const float *bias, float *out, float *out_amax, uint16_t *out16, int32_t n_img, int32_t frames, int32_t h,
+                                        int32_t w, int32_t c_in, int32_t c_out, int32_t kt, int32_t relu, void *stream)
+{
+    if (!out16 || relu == CSP_OUTMASK) return PCACC_E_ARG;
+    return conv3x3_split_impl(in, in_amax, in_mask, wp, wscale, bias, out, out_amax, out16, n_img, frames, h, w, c_in, c_out, kt, relu, stream);
+}
+
 // the same convolution (no bias, no ReLU) with its result stored as zero where out_mask [n_img, h, w, c_out] f32 is <= 0 (see CSP_OUTMASK)
 extern "C" int pcacc_conv3x3_split_outmask(const float *in, const float *in_amax, const float *in_mask, const uint16_t *wp, const float *wscale,
                                            const float *out_mask, float *out, float *out_amax, int32_t n_img, int32_t frames, int32_t h, int32_t w,
                                            int32_t c_in, int32_t c_out, int32_t kt, void *stream)
 {
     if (!out_mask) return PCACC_E_ARG;
-    return pcacc_conv3x3_split(in, in_amax, in_mask, wp, wscale, out_mask, out, out_amax, n_img, frames, h, w, c_in, c_out, kt, CSP_OUTMASK, stream);
+    return conv3x3_split_impl(in, in_amax, in_mask, wp, wscale, out_mask, out, out_amax, nullptr, n_img, frames, h, w, c_in, c_out, kt, CSP_OUTMASK, stream);
 }
 
 // ---- weight gradient ------------------------------------------------------------------------------------------------------------------
@@ -1237,7 +1263,7 @@ extern "C" int pcacc_conv3x3_wgrad_split(const float *dy, const float *dy_amax, 
     if (workspace_bytes < need) return PCACC_E_WORKSPACE;
     hipStream_t st = pcacc_stream(stream);
     float *partial = static_cast<float *>(workspace);
-    if (getenv("PCACC_CONV_PLAN"))
+    if (pcacc_switches().conv_plan)
         fprintf(stderr, "split wgrad plan %dx%d %d->%d n=%d: block %dx%d rows=%d bw=%d blocks=%d slots=%d lds=%zu\n", h, w, c_in, c_out, n_img,
                 p.cob, p.cib, p.rows, p.bw, p.blocks, p.slots, p.lds);
 #define CSW_CASE(COT, CIT)                                                                                                              \
@@ -1318,28 +1344,43 @@ extern "C" int pcacc_upconv2x2_split_supported(int32_t h, int32_t w, int32_t c_i
 
 // direction 0: out [n, 2h, 2w, c_up] = upconv(in [n, h, w, c_in]) + bias;  direction 1: out [n, h, w, c_in] = data gradient of in = dy [n, 2h, 2w, c_up]
 // (h, w = the SMALL map's size in both directions; wp / wscale: the matching form of prepare_weights; bias NULL for direction 1)
-extern "C" int pcacc_upconv2x2_split(const float *in, const float *in_amax, const uint16_t *wp, const float *wscale, const float *bias, float *out,
-                                     float *out_amax, int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_up, int32_t direction,
-                                     void *stream)
+static int upconv2x2_split_impl(const float *in, const float *in_amax, const uint16_t *wp, const float *wscale, const float *bias, float *out,
+                                float *out_amax, uint16_t *out16, int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_up, int32_t direction,
+                                void *stream)
 {
     if (!in || !in_amax || !wp || !wscale || !out || n_img < 1 || c_up < 32 || c_up % 32 || (direction != 0 && direction != 1)) return PCACC_E_ARG;
     const int k_in = direction ? 4 * c_up : c_in, k_out = direction ? c_in : 4 * c_up;
     ConvSplitPlan p;
     if (!conv_split_plan(n_img, h, w, k_in, k_out, 1, &p, 1, direction ? c_up : 0)) return PCACC_E_ARG;
-    if (getenv("PCACC_CONV_PLAN"))
+    if (pcacc_switches().conv_plan)
         fprintf(stderr, "upconv plan dir %d %dx%d %d->%d n=%d: cs=%d nw=%d ngw=%d mt=%d rows=%d bw=%d blocks=%lld lds=%zu\n", direction, h, w, k_in, k_out,
                 n_img, p.cs, p.nw, p.ngw, p.mt, p.rows, p.bw, (long long)p.blocks, p.lds);
     hipStream_t st = pcacc_stream(stream);
     const int mode = direction ? CSP_S2D : CSP_UP;
 #define CSU_CASE(CSV, NWV, NGWV, MTV)                                          \
     if (p.cs == CSV && p.nw == NWV && p.ngw == NGWV && p.mt == MTV)            \
-        return conv_split_launch<CSV, NWV, NGWV, MTV, 1>(p, in, in_amax, nullptr, wp, wscale, bias, out, out_amax, n_img, 1, h, w, k_in, k_out, 1, 0, st, mode, c_up)
+        return conv_split_launch<CSV, NWV, NGWV, MTV, 1>(p, in, in_amax, nullptr, wp, wscale, bias, out, out_amax, out16, n_img, 1, h, w, k_in, k_out, 1, 0, st, mode, c_up)
     CSU_CASE(64, 2, 2, 1); CSU_CASE(64, 2, 2, 2); CSU_CASE(64, 2, 1, 1); CSU_CASE(64, 2, 1, 2);
     CSU_CASE(64, 1, 1, 1); CSU_CASE(64, 1, 1, 2); CSU_CASE(64, 1, 1, 3);
     CSU_CASE(32, 2, 2, 1); CSU_CASE(32, 2, 2, 2); CSU_CASE(32, 2, 1, 1); CSU_CASE(32, 2, 1, 2);
     CSU_CASE(32, 1, 1, 1); CSU_CASE(32, 1, 1, 2); CSU_CASE(32, 1, 1, 3);
 #undef CSU_CASE
     return PCACC_E_ARG;
+}
+
+extern "C" int pcacc_upconv2x2_split(const float *in, const float *in_amax, const uint16_t *wp, const float *wscale, const float *bias, float *out,
+                                     float *out_amax, int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_up, int32_t direction,
+                                     void *stream)
+{
+    return upconv2x2_split_impl(in, in_amax, wp, wscale, bias, out, out_amax, nullptr, n_img, h, w, c_in, c_up, direction, stream);
+}
+
+// direction 0 with a second result: out16 [n, 2h, 2w, c_up] bf16 = the fp32 result rounded to nearest even ('mixed' compute mode, see pcacc_conv3x3_split_dual)
+extern "C" int pcacc_upconv2x2_split_dual(const float *in, const float *in_amax, const uint16_t *wp, const float *wscale, const float *bias, float *out,
+                                          float *out_amax, uint16_t *out16, int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_up, void *stream)
+{
+    if (!out16) return PCACC_E_ARG;
+    return upconv2x2_split_impl(in, in_amax, wp, wscale, bias, out, out_amax, out16, n_img, h, w, c_in, c_up, 0, stream);
 }
 
 extern "C" int pcacc_upconv2x2_wgrad_split_workspace_bytes(int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_up, size_t *bytes)

@@ -450,7 +450,7 @@ static int ms_dispatch(const float *x, const float *x_amax, const float *x_amax2
 #define MS_CASE(KK, CTV) \
     if (k == KK && n == CTV * 32) return ms_launch<KK, CTV>(x, x_amax, x_amax2, in_mask, w, bias, residual, out_mask, y, rows, flags, st, xs2, ms2, y2, na, y_amax)
 #define MS_CASE_FM(KK, CTV) \
-    if (k == KK && n == CTV * 32 && !getenv("PCACC_ROWS_FM_OFF")) return ms_launch_fm<KK, CTV>(x, x_amax, x_amax2, in_mask, w, bias, residual, out_mask, y, rows, flags, st, xs2, ms2, y2, na, y_amax)
+    if (k == KK && n == CTV * 32 && !pcacc_switches().rows_fm_off) return ms_launch_fm<KK, CTV>(x, x_amax, x_amax2, in_mask, w, bias, residual, out_mask, y, rows, flags, st, xs2, ms2, y2, na, y_amax)
     MS_CASE_FM(128, 4); MS_CASE_FM(128, 2); MS_CASE_FM(64, 4);              // weights in registers, two workgroups per CU
 #undef MS_CASE_FM
     MS_CASE(32, 1); MS_CASE(32, 2); MS_CASE(32, 4);

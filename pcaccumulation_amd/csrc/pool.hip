@@ -297,3 +297,100 @@ extern "C" int pcacc_pool_skip_relu_backward_strided_f32(const float *y, const f
     return pool_skip_bwd_f32(y, grad_pooled, grad_skip, skip_pitch, n_img, h, w, c, grad_y, out_amax, stream);
 }
 
+
+// ---- 'mixed' compute mode: y f32 (the forward's own values), gradients bf16 -----------------------------------------------------------------
+// The window's winner must be the one the fp32 forward picked.  Recomputed from a bf16 copy of y, two window values that differ by less than
+// 2^-8 relative tie and the gradient goes to the first of them: about 1 % of the windows route their whole gradient element to a neighbouring
+// pixel -- an error of 100 % on 1 % of the elements is a noise of sqrt(0.01) = 10 % of the gradient's norm per pooling stage (measured: +3.3 % on
+// the pillar encoder's gradient norms behind four stages, i.e. ~25 % noise).  One lane per (2x2 window, 8 channels): two float4 of y, one uint4
+// of each gradient per position.
+template <bool HAS_POOL, bool HAS_SKIP>
+__global__ __launch_bounds__(256) void pool_skip_relu_bwd_y32_kernel(const float4 *__restrict__ y, const uint4 *__restrict__ g_pool,
+                                                                     const uint4 *__restrict__ g_skip, int64_t n_img, int h, int w, int c8,
+                                                                     uint4 *__restrict__ out, int gs_pitch)
+{
+    const int h2 = (h + 1) / 2, w2 = (w + 1) / 2, hp = h / 2, wp = w / 2;
+    const int64_t total = n_img * h2 * w2 * c8;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e % c8);
+        int64_t q = e / c8;
+        const int xo = (int)(q % w2); q /= w2;
+        const int yo = (int)(q % h2);
+        const int64_t img = q / h2;
+        const bool in_x = 2 * xo + 1 < w, in_y = 2 * yo + 1 < h;
+        const int64_t base = ((img * h + 2 * yo) * w + 2 * xo) * c8 + c;
+        const int64_t off[4] = {0, c8, (int64_t)w * c8, (int64_t)w * c8 + c8};
+        const int64_t gbase = ((img * h + 2 * yo) * w + 2 * xo) * gs_pitch + c;
+        const int64_t goff[4] = {0, gs_pitch, (int64_t)w * gs_pitch, (int64_t)w * gs_pitch + gs_pitch};
+        const bool ok[4] = {true, in_x, in_y, in_x && in_y};
+        const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+        const float4 fzero = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 ya[4], yb[4];
+        uint4 gs[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ya[i] = ok[i] ? y[2 * (base + off[i])] : fzero;
+            yb[i] = ok[i] ? y[2 * (base + off[i]) + 1] : fzero;
+            gs[i] = (HAS_SKIP && ok[i]) ? g_skip[gbase + goff[i]] : zero;
+        }
+        uint4 gp = zero;
+        if (HAS_POOL && in_x && in_y && yo < hp && xo < wp) gp = g_pool[((img * hp + yo) * wp + xo) * c8 + c];
+        uint4 o[4];
+        {
+            float a[4], b[4], r0[4], r1[4];
+#define POOL_PAIR(F, YA, YB)                                                                                           \
+            a[0] = YA(0); a[1] = YA(1); a[2] = YA(2); a[3] = YA(3);                                                    \
+            b[0] = pool_lo(gs[0].F); b[1] = pool_lo(gs[1].F); b[2] = pool_lo(gs[2].F); b[3] = pool_lo(gs[3].F);        \
+            pool_bwd1(a, b, pool_lo(gp.F), r0);                                                                        \
+            a[0] = YB(0); a[1] = YB(1); a[2] = YB(2); a[3] = YB(3);                                                    \
+            b[0] = pool_hi(gs[0].F); b[1] = pool_hi(gs[1].F); b[2] = pool_hi(gs[2].F); b[3] = pool_hi(gs[3].F);        \
+            pool_bwd1(a, b, pool_hi(gp.F), r1);                                                                        \
+            o[0].F = pcacc_pack_bf16x2(r0[0], r1[0]); o[1].F = pcacc_pack_bf16x2(r0[1], r1[1]);                        \
+            o[2].F = pcacc_pack_bf16x2(r0[2], r1[2]); o[3].F = pcacc_pack_bf16x2(r0[3], r1[3]);
+#define YAX(i) ya[i].x
+#define YAY(i) ya[i].y
+#define YAZ(i) ya[i].z
+#define YAW(i) ya[i].w
+#define YBX(i) yb[i].x
+#define YBY(i) yb[i].y
+#define YBZ(i) yb[i].z
+#define YBW(i) yb[i].w
+            POOL_PAIR(x, YAX, YAY) POOL_PAIR(y, YAZ, YAW) POOL_PAIR(z, YBX, YBY) POOL_PAIR(w, YBZ, YBW)
+#undef POOL_PAIR
+#undef YAX
+#undef YAY
+#undef YAZ
+#undef YAW
+#undef YBX
+#undef YBY
+#undef YBZ
+#undef YBW
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (ok[i]) out[base + off[i]] = o[i];
+    }
+}
+
+// y [n,h,w,c] f32; grad_pooled [n,h/2,w/2,c] / grad_skip (pixel pitch skip_pitch elements) / grad_y bf16; c % 8 == 0
+extern "C" int pcacc_pool_skip_relu_backward_strided_y32(const float *y, const uint16_t *grad_pooled, const uint16_t *grad_skip, int64_t skip_pitch,
+                                                         int64_t n_img, int32_t h, int32_t w, int32_t c, uint16_t *grad_y, void *stream)
+{
+    if (n_img < 0 || h < 2 || w < 2 || c <= 0 || (c % 8) || skip_pitch < c || (skip_pitch % 8) || skip_pitch / 8 > 0x7fffffff) return PCACC_E_ARG;
+    if (grad_skip && (reinterpret_cast<uintptr_t>(grad_skip) & 15)) return PCACC_E_ARG;
+    const int gs_pitch = (int)(skip_pitch / 8);
+    if (n_img == 0) return PCACC_OK;
+    if (!y || !grad_y) return PCACC_E_ARG;
+    const int64_t total = n_img * ((h + 1) / 2) * ((w + 1) / 2) * (c / 8);
+    const int grid = pcacc_grid(total, 256, PCACC_CUS * 16);
+    hipStream_t s = pcacc_stream(stream);
+    const float4 *yy = reinterpret_cast<const float4 *>(y);
+    const uint4 *gp = reinterpret_cast<const uint4 *>(grad_pooled), *gs = reinterpret_cast<const uint4 *>(grad_skip);
+    uint4 *o = reinterpret_cast<uint4 *>(grad_y);
+    if (gp && gs) pool_skip_relu_bwd_y32_kernel<true, true><<<grid, 256, 0, s>>>(yy, gp, gs, n_img, h, w, c / 8, o, gs_pitch);
+    else if (gp) pool_skip_relu_bwd_y32_kernel<true, false><<<grid, 256, 0, s>>>(yy, gp, gs, n_img, h, w, c / 8, o, gs_pitch);
+    else if (gs) pool_skip_relu_bwd_y32_kernel<false, true><<<grid, 256, 0, s>>>(yy, gp, gs, n_img, h, w, c / 8, o, gs_pitch);
+    else pool_skip_relu_bwd_y32_kernel<false, false><<<grid, 256, 0, s>>>(yy, gp, gs, n_img, h, w, c / 8, o, gs_pitch);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}

@@ -333,6 +333,11 @@ class DataParallelStep(object):
         allow = world_size() == 1 or os.environ.get('PCACC_TWO_STREAMS_DIST') == '1'      # opt-in with a process group (see above)
         self.side = torch.cuda.Stream(device=dev) if (self.pipelined and self._two_streams and dev.type == 'cuda' and allow
                                                       and hasattr(model, 'side_stream')) else None
+        # the optimizer's step invalidates the prepared (packed / split) convolution weights (fused optimizers do not bump version counters)
+        if hasattr(model, 'watch_optimizer'):
+            model.watch_optimizer(optimizer)
+        else:
+            optimizer.register_step_post_hook(lambda *a, **k: ops.weights_may_have_changed())
         self.micro = 0
         self.ok = True
         self.last_error = None
@@ -420,11 +425,9 @@ class DataParallelStep(object):
                     pass
                 elif self._device_skip:
                     self.optimizer.grad_scale, self.optimizer.found_inf = None, bad
-                    self.optimizer.step()
-                    ops.weights_may_have_changed()
+                    self.optimizer.step()                     # its post-step hook drops the prepared weight copies (watch_optimizer below)
                 elif not bool(bad.item()):
                     self.optimizer.step()
-                    ops.weights_may_have_changed()
         return stats
 
 

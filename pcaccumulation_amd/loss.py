@@ -47,15 +47,16 @@ def mean_iou(stats_list):
 
 
 def lovasz_grad(gt_sorted):
-    """libs/lovasz_softmax.py:56-68."""
-    p = len(gt_sorted)
-    gts = gt_sorted.sum()
-    intersection = gts - gt_sorted.float().cumsum(0)
-    union = gts + (1 - gt_sorted).float().cumsum(0)
-    jaccard = 1. - intersection / union
-    if p > 1:
-        jaccard[1:p] = jaccard[1:p] - jaccard[0:-1]
-    return jaccard
+    """Gradient of the Lovasz extension of the Jaccard loss w.r.t. the sorted errors (Berman et al. 2018, alg. 1; libs/lovasz_softmax.py:56-68
+    is the same formula).  With G = #foreground and, after rank r (inclusive), f_r foreground and b_r background members, the Jaccard value of
+    the first r + 1 errors is J_r = 1 - (G - f_r) / (G + b_r); the result is J_0, J_1 - J_0, J_2 - J_1, ...  (fallback path only: the
+    product's loss runs in csrc/loss.hip, seg_lovasz_kernel, which forms the same differences per rank)."""
+    fg = gt_sorted.to(torch.float32)
+    ranks = torch.arange(1, fg.numel() + 1, device=fg.device, dtype=torch.float32)
+    f = torch.cumsum(fg, 0)
+    total = f[-1] if fg.numel() else fg.sum()
+    j = 1.0 - (total - f) / (total + (ranks - f))
+    return torch.diff(j, prepend=j.new_zeros(1))
 
 
 def lovasz_softmax_flat(probas, labels):

@@ -13,6 +13,7 @@ cfg['misc']['compute_dtype'] ('fp32' default | 'bf16' | 'fp32x3'): element type 
 (autocast for bf16; 'fp32x3' = fp32 tensors with split-bf16 MFMA products, the fast mode that matches the reference to 1e-3).  Sinkhorn / Kabsch / normalisation / grid arithmetic always stay fp32.
 """
 import contextlib
+import weakref
 
 import torch
 import torch.nn as nn
@@ -63,10 +64,13 @@ class PreparedInputs(object):
         return [t for t in out if torch.is_tensor(t)]
 
     def matches(self, input_dict):
-        src = getattr(self, 'source', None)                   # (storage address, version) of the batch's points when prepare_inputs built this
+        """True when this object was built from THIS batch: the batch's `input_points` is the very tensor object prepare_inputs saw (a weak
+        reference; an address + version pair can recur -- the caching allocator recycles addresses and a fresh tensor starts at version 0) and has
+        not been written since.  A batch whose points were copied or moved after the preparation is prepared again inside the forward."""
+        src = getattr(self, 'source', None)
         pts = input_dict['input_points']
         return (self.pidx.m == input_dict['coordinates'].shape[0] and self.pidx.n == pts.shape[0] and self.features.device == pts.device
-                and (src is None or src == (pts.data_ptr(), pts._version)))
+                and (src is None or (src[0]() is pts and src[1] == pts._version)))
 
 
 def grid_shape(cfg):
@@ -96,9 +100,10 @@ class MotionNet(nn.Module):
         self.grid = grid_shape(cfg)
         # 'fp32x3': fp32 tensors, products of the dense stacks / wide row layers on the bf16 matrix cores from hi / lo halves (ops.set_split)
         self.compute_mode = cfg['misc'].get('compute_dtype', 'fp32')
-        self.compute_dtype = {'fp32': torch.float32, 'fp32x3': torch.float32, 'bf16': torch.bfloat16}[self.compute_mode]
+        self.compute_dtype = {'fp32': torch.float32, 'fp32x3': torch.float32, 'mixed': torch.float32, 'bf16': torch.bfloat16}[self.compute_mode]
         # pillars renumbered in canvas-cell order inside forward() (ops.PillarIndex); False keeps the voxeliser's numbering
         self.cell_ordered_pillars = bool(cfg['misc'].get('cell_ordered_pillars', True))
+        self._optimizer_watched = False          # watch_optimizer()
         self.after_ego = None                    # optional callable(results), see forward()
         self.side_stream = None                  # optional torch.cuda.Stream for stages 5-6 while after_ego's backward runs
 
@@ -113,6 +118,15 @@ class MotionNet(nn.Module):
         a fused optimizer step between the last training forward and this switch leaves no trace in the parameters' version counters)."""
         ops.weights_may_have_changed()
         return super().train(mode)
+
+    def watch_optimizer(self, optimizer):
+        """Invalidate the prepared convolution weights at the writer: every `optimizer.step()` calls ops.weights_may_have_changed()
+        (register_step_post_hook).  forward() then stops invalidating on its own, so the micro-steps of an accumulation window (iter_size > 1)
+        reuse one set of copies.  DataParallelStep calls this for its optimizer; call it yourself in a custom loop -- parameters that some
+        OTHER writer changes behind the version counter still need ops.weights_may_have_changed()."""
+        optimizer.register_step_post_hook(lambda *a, **k: ops.weights_may_have_changed())
+        self._optimizer_watched = True
+        return optimizer
 
     def channels_last_(self):
         """Store conv weights in the layout the channels-last activations want (no state_dict change)."""
@@ -163,7 +177,7 @@ class MotionNet(nn.Module):
         features = self.pillar_encoder.point_features(input_points, pidx, pidx.coordinates, pillar_mean, time_indice)
         prep = PreparedInputs(pidx=pidx, batch_idx=batch_idx, frame_idx=frame_idx, pillar_mean=pillar_mean, fb_labels_sub=fb_labels_sub,
                               occ_map=occ.view(B, nt, 1, ny, nx), fb_seg_gt=fb_map.view(B, nt, 1, ny, nx).to(fb_labels.dtype), features=features)
-        prep.source = (input_dict['input_points'].data_ptr(), input_dict['input_points']._version)      # a `_prepared` of another batch is refused
+        prep.source = (weakref.ref(input_dict['input_points']), input_dict['input_points']._version)      # a `_prepared` of another batch is refused
         return prep
 
     def forward(self, input_dict):
@@ -179,9 +193,16 @@ class MotionNet(nn.Module):
         B, T, Ny, Nx = batch_size, nt, ny, nx
         device = coordinates.device
         ops.set_point_dtype(self.compute_dtype if device.type == 'cuda' else torch.float32)
-        ops.set_split(self.compute_mode == 'fp32x3' and device.type == 'cuda')
-        if self.training:
-            ops.weights_may_have_changed()                                     # an optimizer step lies between two training forwards
+        ops.set_split(self.compute_mode in ('fp32x3', 'mixed') and device.type == 'cuda')
+        # 'mixed': fp32x3 forward values, bf16 gradient graph inside the two convolution segments (ops.set_mixed)
+        ops.set_mixed(self.compute_mode == 'mixed' and device.type == 'cuda')
+        ops.twins_clear()
+        # Prepared (packed / split) copies of the convolution weights outlive writers that bypass the parameters' version counters (fused
+        # optimizers).  With the optimizer watched (watch_optimizer: its step invalidates the copies) nothing is needed here and the micro-steps of a
+        # gradient-accumulation window share one preparation; otherwise every forward that can be followed by an optimizer step -- gradients
+        # enabled and a trainable parameter, in train() OR eval() mode (fine-tuning with frozen BatchNorm statistics) -- starts from fresh copies.
+        if not self._optimizer_watched and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            ops.weights_may_have_changed()
         results = LazyDict()
 
         # 0. index structures shared by every irregular op of this forward, and everything else that follows from the batch alone
@@ -198,6 +219,7 @@ class MotionNet(nn.Module):
                                              features=prep.features)
         canvas = ops.carry_amax(input_features, ops.pillar_scatter(input_features, pidx, self.compute_dtype))     # rows or zeros
         bev = ops.carry_amax(canvas, ops.canvas_as_nchw(canvas, pidx))         # [B*T, C, Ny, Nx]
+        bev = ops.enter_mixed(bev)                                             # mixed mode: segment 1 = U-Net + the two heads on bf16 shadows
 
         # 2. backbone + 3. fg/bg head
         with self._dense():
@@ -236,7 +258,7 @@ class MotionNet(nn.Module):
         # The ego feature head (two full-resolution convolutions, needed by the ego head only) is queued between the request for the
         # sizes and the wait for them: the GPU still has work when the host wakes up and starts issuing the ego head's small launches.
         with self._dense():
-            geometric_feats = self.ego_feats_head(bev_feats)
+            geometric_feats = ops.exit_mixed(self.ego_feats_head(bev_feats))      # the ego head reads fp32 (mixed mode: the twin)
         sizes = sizes.numpy().tolist()
         nf = B * T + 1
         frame_offsets, bg_at = sizes[:nf], sizes[nf:2 * nf]
@@ -281,9 +303,10 @@ class MotionNet(nn.Module):
             bev_feats = bev_feats.detach()
             C = bev_feats.size(1)
             bev_cl = bev_feats.permute(0, 2, 3, 1).contiguous().view(B, T, Ny, Nx, C)
-            warped = ops.bev_warp(bev_cl, native.inv4x4(pose_est), self.resolution[0], self.resolution[1],
+            warped = ops.bev_warp(ops.twin_or_self(bev_cl), native.inv4x4(pose_est), self.resolution[0], self.resolution[1],
                                   self.pc_range[0], self.pc_range[1])
-            ops.carry_amax(bev_feats, warped)                                      # convex combinations of bev_feats' cells (or zero)
+            ops.carry_amax(ops.twin_or_self(bev_feats), warped)                    # convex combinations of bev_feats' cells (or zero)
+            warped = ops.enter_mixed(warped)                                       # mixed mode: segment 2 = STPN temporal stack + U-Net
             warped_feats = ops.carry_amax(warped, warped.permute(0, 4, 1, 2, 3))   # [B,C,T,H,W], channels_last_3d memory
             transformed_points = ops.rigid_transform(input_points, frame_idx, pose_est)
             results['transformed_points'] = transformed_points

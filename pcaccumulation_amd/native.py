@@ -39,7 +39,7 @@ def lib():
 
 # every symbol include/pcacc.h declares (tests check the .so exports exactly these)
 EXPORTS = [
-    'pcacc_voxelize_workspace_bytes', 'pcacc_voxelize', 'pcacc_cell_index',
+    'pcacc_reload_switches', 'pcacc_pool_skip_relu_backward_strided_y32', 'pcacc_conv3x3_split_dual', 'pcacc_upconv2x2_split_dual', 'pcacc_voxelize_workspace_bytes', 'pcacc_voxelize', 'pcacc_cell_index',
     'pcacc_frame_pillars_workspace_bytes', 'pcacc_frame_pillars',
     'pcacc_csr_workspace_bytes', 'pcacc_csr_build', 'pcacc_segment_mean3_maxlabel',
     'pcacc_segment_workspace_bytes', 'pcacc_segment_max', 'pcacc_segment_max_backward', 'pcacc_segment_sum', 'pcacc_scatter_sum_small',
@@ -70,6 +70,11 @@ EXPORTS = [
     'pcacc_head_conv3x3_supported', 'pcacc_head_conv3x3_forward', 'pcacc_head_conv3x3_dgrad', 'pcacc_head_conv3x3_wgrad',
     'pcacc_head_conv3x3_wgrad_workspace_bytes',
 ]
+
+
+def reload_switches():
+    """The launchers read their A/B environment switches once per process (include/pcacc.h: pcacc_reload_switches); call this after changing one."""
+    lib().pcacc_reload_switches()
 
 
 def _check(rc, what):
@@ -672,7 +677,7 @@ def conv3x3_split_prepare_weights(weight):
     return (fwd, sf), (bwd, sb)
 
 
-def conv3x3_split(x_rows, wps, bias, frames, relu, mask=None, amax=None, want_amax=False, out_mask=None):
+def conv3x3_split(x_rows, wps, bias, frames, relu, mask=None, amax=None, want_amax=False, out_mask=None, want_bf16=False):
     """x_rows f32 [n_img,h,w,c_in] contiguous, wps = (planes, scale) from conv3x3_split_prepare_weights -> f32 [n_img,h,w,c_out]; mask as in
     conv3x3 (f32); amax = absmax256(x_rows) when the caller has it already.  want_amax: -> (out, absmax256 array of out), the maxima
     collected by the kernel's epilogue."""
@@ -696,6 +701,14 @@ def conv3x3_split(x_rows, wps, bias, frames, relu, mask=None, amax=None, want_am
                                                  _dev(out_mask, torch.float32, 'out_mask'), _dev(out), _dev(out_amax) if want_amax else None, int(n_img),
                                                  int(frames), int(h), int(w), int(c_in), int(c_out), taps // 9, _stream()), 'conv3x3_split_outmask')
         return (out, out_amax) if want_amax else out
+    if want_bf16:                                              # 'mixed' mode: -> (out, out_amax, bf16 copy of out written by the same epilogue)
+        out16 = torch.empty((n_img, h, w, c_out), dtype=torch.bfloat16, device=x_rows.device)
+        _check(lib().pcacc_conv3x3_split_dual(xp, _dev(amax, torch.float32, 'amax'), _dev(mask, torch.float32, 'mask') if mask is not None else None,
+                                              _dev(wp, torch.float16, 'wp'), _dev(wscale, torch.float32, 'wscale'),
+                                              _dev(bias, torch.float32, 'bias') if bias is not None else None,
+                                              _dev(out), _dev(out_amax) if want_amax else None, _dev(out16), int(n_img), int(frames), int(h), int(w),
+                                              int(c_in), int(c_out), taps // 9, 1 if relu else 0, _stream()), 'conv3x3_split_dual')
+        return out, out_amax, out16
     _check(lib().pcacc_conv3x3_split(xp, _dev(amax, torch.float32, 'amax'), _dev(mask, torch.float32, 'mask') if mask is not None else None,
                                      _dev(wp, torch.float16, 'wp'), _dev(wscale, torch.float32, 'wscale'),
                                      _dev(bias, torch.float32, 'bias') if bias is not None else None,
@@ -745,8 +758,9 @@ def upconv2x2_split_prepare_weights(weight):
     return (fwd, sf), (bwd, sb)
 
 
-def upconv2x2_split(x_rows, amax, wps, bias, direction):
-    """direction 0: x_rows f32 [n,h,w,c_in] -> ([n,2h,2w,c_up], its absmax256 array); direction 1: x_rows = dy [n,2h,2w,c_up] -> ([n,h,w,c_in], amax)."""
+def upconv2x2_split(x_rows, amax, wps, bias, direction, want_bf16=False):
+    """direction 0: x_rows f32 [n,h,w,c_in] -> ([n,2h,2w,c_up], its absmax256 array); direction 1: x_rows = dy [n,2h,2w,c_up] -> ([n,h,w,c_in], amax).
+    want_bf16 (direction 0): -> (out, amax, bf16 copy of out written by the same epilogue)."""
     wp, wscale = wps
     n = x_rows.shape[0]
     if direction == 0:
@@ -758,6 +772,14 @@ def upconv2x2_split(x_rows, amax, wps, bias, direction):
         c_in = wp.shape[1]
         out = torch.empty((n, h, w, c_in), dtype=torch.float32, device=x_rows.device)
     out_amax = _zero256(x_rows.device)
+    if want_bf16:
+        if direction != 0:
+            raise NativeError('upconv2x2_split: the bf16 second output goes with direction 0')
+        out16 = torch.empty(out.shape, dtype=torch.bfloat16, device=x_rows.device)
+        _check(lib().pcacc_upconv2x2_split_dual(_dev(x_rows, torch.float32, 'x'), _dev(amax, torch.float32, 'amax'), _dev(wp, torch.float16, 'wp'),
+                                                _dev(wscale, torch.float32, 'wscale'), _opt(bias, torch.float32, 'bias'), _dev(out), _dev(out_amax),
+                                                _dev(out16), int(n), int(h), int(w), int(c_in), int(c_up), _stream()), 'upconv2x2_split_dual')
+        return out, out_amax, out16
     _check(lib().pcacc_upconv2x2_split(_dev(x_rows, torch.float32, 'x'), _dev(amax, torch.float32, 'amax'), _dev(wp, torch.float16, 'wp'),
                                        _dev(wscale, torch.float32, 'wscale'), _opt(bias, torch.float32, 'bias'), _dev(out), _dev(out_amax), int(n),
                                        int(h), int(w), int(c_in), int(c_up), int(direction), _stream()), 'upconv2x2_split')
@@ -1288,6 +1310,19 @@ def pool_skip_relu_backward(y_rows, grad_pooled, grad_skip, want_amax=False):
     """(un-pool(grad_pooled) + grad_skip) * (y > 0) in one pass; either gradient may be None.  bf16 or f32 rows (all of y's type);
     grad_skip may be a channel slice of a wider map (read in place); want_amax (f32): -> (grad, absmax256 array of it)."""
     n, h, w, c = y_rows.shape
+    if y_rows.dtype == torch.float32 and any(g is not None and g.dtype == torch.bfloat16 for g in (grad_pooled, grad_skip)):
+        # 'mixed' mode: the forward's own fp32 y decides the windows' winners, the gradients are bf16
+        out = torch.empty(y_rows.shape, dtype=torch.bfloat16, device=y_rows.device)
+        pitch, gs_ptr = c, None
+        if grad_skip is not None:
+            pitch = _pixel_pitch(grad_skip, y_rows.shape)
+            if pitch is None or pitch % 8:
+                grad_skip, pitch = grad_skip.contiguous(), c
+            gs_ptr = ctypes.c_void_p(grad_skip.data_ptr())
+        _check(lib().pcacc_pool_skip_relu_backward_strided_y32(_dev(y_rows, torch.float32, 'y'), _opt(grad_pooled, torch.bfloat16, 'grad_pooled'), gs_ptr,
+                                                               _i64(pitch), _i64(n), int(h), int(w), int(c), _dev(out), _stream()),
+               'pool_skip_relu_backward')
+        return out
     out = torch.empty_like(y_rows)
     f32 = y_rows.dtype == torch.float32
     dt = torch.float32 if f32 else torch.bfloat16

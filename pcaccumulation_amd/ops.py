@@ -189,7 +189,7 @@ class _BilinearGather(torch.autograd.Function):
         ctx.in_dtype = fmap.dtype
         ctx.scales = (float(x_scale), float(y_scale))
         ctx.save_for_backward(points, map_idx)
-        return native.bilinear_gather(fm, points, map_idx, float(x_scale), float(y_scale))
+        return native.bilinear_gather(twin_or_self(fm), points, map_idx, float(x_scale), float(y_scale))
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -593,6 +593,155 @@ def split_mode():
     return _SPLIT
 
 
+# ---- 'mixed' compute mode: fp32x3 forward values, bf16 gradient graph --------------------------------------------------------------------
+# north_star's 1e-3 is a statement about FORWARD outputs (mos_iou, ego errors, EPE): they need the fp32-accurate products of the fp32x3
+# kernels.  The backward does not: a data / weight gradient formed from bf16 operands with fp32 accumulation carries a relative rounding of
+# 2^-9 per element and layer, random in sign -- nothing a gradient norm or an Adam step resolves -- and moves half the bytes.  Autograd ties a
+# gradient's type to the type of the forward tensor it belongs to, so inside a mixed SEGMENT (U-Net + heads; STPN temporal stack + U-Net) the
+# tensors autograd sees are bf16 SHADOWS of the fp32 activations; every operator of a segment computes its forward from the fp32 TWIN of its
+# input shadow (fp32x3 kernels), registers the twin of its output and saves shadows for a bf16 backward (the bf16 mode's kernels).  Forward
+# values never come from a shadow: PCACC_MIXED_POISON=1 fills every shadow with NaN in the forward (tests/test_mixed.py).
+_MIXED = False
+_TWINS = {}            # storage address of a shadow -> (shadow, fp32 twin); same sizes and strides, both at storage offset 0; strong references
+_POISON = os.environ.get('PCACC_MIXED_POISON') == '1'
+
+
+def set_mixed(flag):
+    global _MIXED
+    _MIXED = bool(flag)
+    if not _MIXED:
+        _TWINS.clear()
+
+
+def mixed_mode():
+    return _MIXED
+
+
+def set_poison(flag):
+    """Test switch: every shadow made from now on holds NaN instead of the rounded twin (forward values must not change; the backward is garbage)."""
+    global _POISON
+    _POISON = bool(flag)
+
+
+def twins_clear():
+    """Start of a forward: the pairs of the previous one are no longer needed (its backward is done)."""
+    _TWINS.clear()
+
+
+def shadow(y32, y16=None):
+    """The bf16 shadow of a dense fp32 tensor (same sizes, same strides), registered as its twin's key.  y16: a shadow somebody else produced
+    (torch.cat of shadows, a kernel's second output)."""
+    if y32.storage_offset() != 0 or y32.dtype != torch.float32:
+        raise native.NativeError('shadow: the twin must be a float32 tensor at storage offset 0')
+    if y16 is None:
+        y16 = torch.empty_strided(y32.size(), y32.stride(), dtype=torch.bfloat16, device=y32.device)
+        if _POISON:
+            y16.fill_(float('nan'))
+        else:
+            y16.copy_(y32)
+    elif tuple(y16.stride()) != tuple(y32.stride()) or tuple(y16.size()) != tuple(y32.size()) or y16.storage_offset() != 0:
+        raise native.NativeError('shadow: layouts differ')
+    elif _POISON and not y16.requires_grad:
+        y16.fill_(float('nan'))
+    _TWINS[y16.untyped_storage().data_ptr()] = (y16, y32)
+    return y16
+
+
+def twin(t16, required=True):
+    """The fp32 twin of a shadow or of any view of one (same view of the twin's storage)."""
+    e = _TWINS.get(t16.untyped_storage().data_ptr()) if t16.dtype == torch.bfloat16 else None
+    if e is None:
+        if required:
+            raise native.NativeError('mixed mode: a bf16 tensor without an fp32 twin reached a segment operator (shape %s): its forward values '
+                                     'would come from bf16 data' % (tuple(t16.shape),))
+        return None
+    base = e[1]
+    if tuple(t16.size()) == tuple(base.size()) and tuple(t16.stride()) == tuple(base.stride()) and t16.storage_offset() == 0:
+        return base
+    return torch.as_strided(base, t16.size(), t16.stride(), t16.storage_offset())
+
+
+def twin_or_self(t):
+    """fp32 view of `t` for a forward-only consumer (BEV warp, bilinear gathers, the ego head): the twin of a shadow, `t` itself otherwise."""
+    if _MIXED and t.dtype == torch.bfloat16:
+        return twin(t)
+    return t
+
+
+class _EnterMixed(torch.autograd.Function):
+    """fp32 tensor -> its bf16 shadow: the head of a mixed segment.  The gradient arrives in bf16 and is handed on in fp32."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return shadow(carry_amax(x, x.detach()))
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.float()
+
+
+class _ExitMixed(torch.autograd.Function):
+    """shadow -> its fp32 twin as an autograd-visible tensor: the tail of a mixed segment (the fp32 consumer's gradient enters in bf16)."""
+
+    @staticmethod
+    def forward(ctx, x16):
+        return twin(x16).view_as(x16)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16)
+
+
+class _OnTwin(torch.autograd.Function):
+    """Any differentiable fp32 function of one map, inside a mixed segment, without a kernel pair of its own (BatchNorm2d in eval mode, maps too
+    small for the streaming kernels): forward = fn(twin) in fp32; backward = `replay` (default: fn) re-evaluated on the twin under autograd in
+    fp32 (the gradient arrives and leaves in bf16).  Correct and slow -- the segment's hot operators do not come through here."""
+
+    @staticmethod
+    def forward(ctx, x16, fn, replay, *params):
+        ctx.replay, ctx.x32, ctx.params = (replay or fn), twin(x16), params
+        y = fn(ctx.x32)
+        return shadow(y.contiguous() if y.storage_offset() else y)
+
+    @staticmethod
+    def backward(ctx, gy):
+        with torch.enable_grad():
+            x = ctx.x32.detach().requires_grad_(True)
+            y = ctx.replay(x)
+            leaves = [x] + [p for p in ctx.params if p.requires_grad]
+            grads = torch.autograd.grad(y, leaves, gy.float(), allow_unused=True)
+        it = iter(grads[1:])
+        return (grads[0].to(torch.bfloat16), None, None) + tuple(next(it) if p.requires_grad else None for p in ctx.params)
+
+
+def on_twin(x16, fn, params=(), replay=None):
+    """fn(twin of x16) as a shadow; `params`: the tensors fn closes over that may need gradients; `replay`: what the backward differentiates
+    when fn has side effects (a training-mode BatchNorm's running statistics)."""
+    return _OnTwin.apply(x16, fn, replay, *params)
+
+
+def enter_mixed(x):
+    return _EnterMixed.apply(x) if _MIXED and x.is_cuda and x.dtype == torch.float32 else x
+
+
+def exit_mixed(x):
+    return _ExitMixed.apply(x) if _MIXED and x.dtype == torch.bfloat16 else x
+
+
+def cat_maps(tensors, dim=1):
+    """torch.cat for maps inside a mixed segment (shadows: the twins are concatenated too and registered); plain torch.cat otherwise."""
+    y = torch.cat(tensors, dim)
+    if _MIXED and y.dtype == torch.bfloat16:
+        tw = [twin(t) for t in tensors]
+        y32 = merge_amax(torch.cat(tw, dim), *tw)
+        if _POISON:
+            with torch.no_grad():
+                y.fill_(float('nan'))
+        shadow(y32, y)
+        return y
+    return merge_amax(y, *tensors)
+
+
 # ---- absolute maxima of the fp32 tensors the fp32x3 kernels split (their power-of-two scales) ----------------------------------------
 # The kernels that produce a tensor collect its maximum in their store phase; the array rides on the tensor OBJECT as `_pcacc_amax` together
 # with the tensor's version counter (an in-place write invalidates it) and is picked up by the next split kernel that reads the tensor --
@@ -953,6 +1102,24 @@ class _Conv3x3Split(torch.autograd.Function):
         return gx, gw, gb, None, None, None, None
 
 
+class _Conv3x3Mixed(_Conv3x3):
+    """_Conv3x3Split's forward on the fp32 twin of a bf16 shadow, _Conv3x3's backward on the shadows ('mixed' compute mode): fp32-accurate
+    forward values, bf16 data / weight gradients (fp32 accumulation, fp32 weight gradients)."""
+
+    @staticmethod
+    def forward(ctx, x_rows, weight, bias, frames, relu, premasked=False, input_relu=False):
+        x32 = twin(x_rows)
+        if not x32.is_contiguous():
+            raise native.NativeError('mixed conv3x3: the twin of the input rows must be contiguous')
+        y32, y_amax, y16 = native.conv3x3_split(x32, prepared_conv_weights_split(weight)[0], bias.detach().float() if bias is not None else None, frames,
+                                                relu, amax=amax_of(x32), want_amax=True, want_bf16=True)      # the shadow from the same epilogue
+        set_amax_tag(y32, y_amax)
+        y = shadow(y32, y16)
+        ctx.save_for_backward(x_rows, weight, y if relu and not premasked else None)
+        ctx.meta = (frames, relu and not premasked, bias is not None, bool(input_relu))
+        return y
+
+
 _PREPARED_UP = {}
 
 
@@ -999,12 +1166,45 @@ class _UpConv2x2Split(torch.autograd.Function):
         return gx, gw, gb
 
 
+class _UpConv2x2Mixed(torch.autograd.Function):
+    """_UpConv2x2Split's forward on the twin, bf16 backward ('mixed' mode).  The bf16 data / weight gradients of the transposed convolution
+    go through the library for now (as in the bf16 mode)."""
+
+    @staticmethod
+    def forward(ctx, x_rows, weight, bias):
+        x32 = twin(x_rows)
+        y32, y_amax, y16 = native.upconv2x2_split(x32, amax_of(x32), prepared_upconv_weights_split(weight)[0], bias.detach() if bias is not None else None, 0,
+                                                  want_bf16=True)
+        set_amax_tag(y32, y_amax)
+        ctx.save_for_backward(x_rows, weight)
+        ctx.has_bias = bias is not None
+        return shadow(y32, y16)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x_rows, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        w16 = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        gx, gw, gb = torch.ops.aten.convolution_backward(
+            gy.permute(0, 3, 1, 2), x_rows.permute(0, 3, 1, 2), w16, [weight.shape[1]] if ctx.has_bias else None, [2, 2], [0, 0], [1, 1], True, [0, 0], 1,
+            [ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]])
+        if gx is not None:
+            gx = gx.permute(0, 2, 3, 1).contiguous()
+        return gx, (gw.float().contiguous(memory_format=torch.channels_last) if gw is not None else None), (gb.float() if gb is not None else None)
+
+
 def upconv2x2(x, conv):
     """`conv(x)` for the decoders' nn.ConvTranspose2d(kernel 2, stride 2) (models/unet.py:22-30): fp32 channels-last maps in the fp32x3 mode
     run the split kernels, everything else the module (library)."""
-    if (_SPLIT and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled() and conv.kernel_size == (2, 2) and conv.stride == (2, 2)
-            and conv.padding == (0, 0) and conv.output_padding == (0, 0) and conv.groups == 1 and conv.dilation == (1, 1)
-            and conv.weight.dtype == torch.float32 and native.upconv2x2_split_supported(x.shape[-2], x.shape[-1], conv.in_channels, conv.out_channels)):
+    plain = (conv.kernel_size == (2, 2) and conv.stride == (2, 2) and conv.padding == (0, 0) and conv.output_padding == (0, 0) and conv.groups == 1
+             and conv.dilation == (1, 1) and conv.weight.dtype == torch.float32)
+    if _MIXED and x.is_cuda and x.dtype == torch.bfloat16:
+        xr = x.permute(0, 2, 3, 1)
+        if not (plain and xr.is_contiguous() and native.upconv2x2_split_supported(x.shape[-2], x.shape[-1], conv.in_channels, conv.out_channels)):
+            raise native.NativeError('mixed mode: transposed convolution outside the split kernels (%s)' % (tuple(x.shape),))
+        return _UpConv2x2Mixed.apply(xr, conv.weight, conv.bias).permute(0, 3, 1, 2)
+    if (_SPLIT and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled() and plain
+            and native.upconv2x2_split_supported(x.shape[-2], x.shape[-1], conv.in_channels, conv.out_channels)):
         xr = x.permute(0, 2, 3, 1)
         if xr.is_contiguous():
             set_amax_tag(xr, amax_of(x))
@@ -1021,7 +1221,7 @@ class _HeadConv3x3(torch.autograd.Function):
     def forward(ctx, x_rows, weight, bias):
         ctx.save_for_backward(x_rows, weight)
         ctx.has_bias = bias is not None
-        return native.head_conv3x3_forward(x_rows, weight.detach(), bias.detach() if bias is not None else None)
+        return native.head_conv3x3_forward(twin_or_self(x_rows), weight.detach(), bias.detach() if bias is not None else None)
 
     @staticmethod
     def backward(ctx, gy):
@@ -1067,6 +1267,11 @@ def conv3x3_available(x, weight):
     bf16 compute (bf16 kernels) or fp32 rows in the fp32x3 mode (split-bf16 kernels, csrc/conv_split.hip)."""
     if not x.is_cuda:
         return None
+    if _MIXED and x.dtype == torch.bfloat16:
+        # a shadow inside a mixed segment: forward on the split kernels, backward on the bf16 kernels -- both must take the layer
+        if not (weight.dtype == torch.float32 and native.conv3x3_split_supported(x.shape[-2], x.shape[-1], weight.shape[1], weight.shape[0])):
+            raise native.NativeError('mixed mode: 3x3 convolution outside the split kernels (%s, weight %s)' % (tuple(x.shape), tuple(weight.shape)))
+        return 'mixed'
     if x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16):
         return 'bf16' if conv3x3_preferred(weight.shape[1], weight.shape[0], x.shape[-2], x.shape[-1]) else None
     if _SPLIT and x.dtype == torch.float32 and weight.dtype == torch.float32 \
@@ -1077,6 +1282,8 @@ def conv3x3_available(x, weight):
 
 def conv3x3_rows(x_rows, weight, bias, frames=1, relu=False, premasked=False, input_relu=False):
     """x_rows [n_img, H, W, C_in] -> [n_img, H, W, C_out] (bf16; f32 in the fp32x3 mode).  weight [O,I,3,3] (frames ignored) or [O,I,3,3,3]."""
+    if _MIXED and x_rows.dtype == torch.bfloat16:
+        return _Conv3x3Mixed.apply(x_rows.contiguous(), weight, bias, int(frames), bool(relu), bool(premasked), bool(input_relu))
     if _SPLIT and x_rows.dtype == torch.float32 and not torch.is_autocast_enabled():
         xc = x_rows.contiguous()
         if xc is not x_rows:
@@ -1099,9 +1306,9 @@ def conv_pair_fusable(x, conv1, conv2):
     the bf16 MFMA kernels, or both on the fp32x3 kernels.  The caller then passes premasked=True to conv1 and input_relu=True to conv2 -- conv1's output must have no
     other consumer."""
     mode = conv3x3_native(x, conv1)
-    if mode not in ('bf16', 'split') or conv2.in_channels != conv1.out_channels or os.environ.get('PCACC_CONV_PAIR', '1') == '0':      # A/B switch
+    if mode not in ('bf16', 'split', 'mixed') or conv2.in_channels != conv1.out_channels or os.environ.get('PCACC_CONV_PAIR', '1') == '0':      # A/B switch
         return False
-    probe = torch.empty((0, conv1.out_channels, x.shape[-2], x.shape[-1]), dtype=torch.bfloat16 if mode == 'bf16' else torch.float32, device=x.device)
+    probe = torch.empty((0, conv1.out_channels, x.shape[-2], x.shape[-1]), dtype=torch.float32 if mode == 'split' else torch.bfloat16, device=x.device)
     return conv3x3_native(probe, conv2) == mode
 
 
@@ -1130,7 +1337,13 @@ class _PoolSkip(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y_rows):
+        if _MIXED and y_rows.dtype == torch.bfloat16:              # shadow: pooled twin from the fp32 twin, its shadow registered; the skip is a view
+            y32 = twin(y_rows)
+            ctx.save_for_backward(y32)                             # the forward's own values pick the windows' winners in the backward too
+            ctx.mixed = True
+            return shadow(carry_amax(y32, native.maxpool2x2(y32))), y_rows.view_as(y_rows)
         ctx.save_for_backward(y_rows)
+        ctx.mixed = False
         pooled = native.maxpool2x2(y_rows)
         skip = y_rows.view_as(y_rows)
         if y_rows.dtype == torch.float32:
@@ -1141,6 +1354,9 @@ class _PoolSkip(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_pool, g_skip):
         y_rows, = ctx.saved_tensors
+        if ctx.mixed:                                              # y f32, gradients bf16 (pcacc_pool_skip_relu_backward_strided_y32)
+            b16 = lambda g: g.to(torch.bfloat16) if g is not None else None
+            return native.pool_skip_relu_backward(y_rows, b16(g_pool.contiguous() if g_pool is not None else None), b16(g_skip))
         c = lambda g: g.contiguous().to(y_rows.dtype) if g is not None else None
         # the skip gradient usually arrives as a channel slice of the decoder's concatenation gradient: the kernel reads it in place
         gs = g_skip.to(y_rows.dtype) if g_skip is not None else None
@@ -1357,10 +1573,12 @@ class _FramesMax(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x):
-        out, arg = native.frames_max(x)
+        mixed = _MIXED and x.dtype == torch.bfloat16
+        x32 = twin(x) if mixed else x
+        out, arg = native.frames_max(x32)
         ctx.save_for_backward(arg)
         ctx.frames = x.shape[1]
-        return out
+        return shadow(carry_amax(x32, out)) if mixed else out
 
     @staticmethod
     def backward(ctx, grad):
@@ -1400,10 +1618,11 @@ class _BatchNormRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, momentum, running_mean, running_var, relu=False):
         x = x.contiguous()
-        y, mean, invstd = native.bn_rows_forward(x, gamma, beta, eps, momentum, running_mean, running_var, relu=relu)
+        mixed = _MIXED and x.dtype == torch.bfloat16               # shadow rows: statistics and output from the fp32 twin, bf16 backward on the shadow
+        y, mean, invstd = native.bn_rows_forward(twin(x) if mixed else x, gamma, beta, eps, momentum, running_mean, running_var, relu=relu)
         ctx.save_for_backward(x, gamma, mean, invstd, beta if relu else None)
         ctx.relu = relu
-        return y
+        return shadow(y) if mixed else y
 
     @staticmethod
     def backward(ctx, gy):
@@ -1429,16 +1648,28 @@ def batch_norm_nchw(x, bn, relu=False):
     """`bn(x)` (relu: `relu(bn(x))`, one pass each way) for an nn.BatchNorm2d on a channels-last NCHW tensor (models/unet.py:259-277, the two SegHead2D): training mode on the GPU
     runs the streaming passes of csrc/bn.hip on the [N*H*W, C] rows the memory already is (f32 or bf16 rows, statistics in fp32 /
     float64 as the module's); everything else is the module (library)."""
+    def module(t):
+        return torch.relu(bn(t)) if relu else bn(t)
+
+    def replay(t):                                                              # the same function without the running-statistics update
+        y = torch.nn.functional.batch_norm(t, None if bn.training else bn.running_mean, None if bn.training else bn.running_var, bn.weight, bn.bias,
+                                           bn.training, 0.0, bn.eps)
+        return torch.relu(y) if relu else y
+
+    def fallback():
+        if _MIXED and x.dtype == torch.bfloat16:                                # a shadow: the module on its fp32 twin
+            return on_twin(x, module, [p for p in (bn.weight, bn.bias) if p is not None], replay)
+        return module(x)
     if not (bn.training and x.is_cuda and x.dim() == 4 and bn.momentum is not None and x.dtype in (torch.float32, torch.bfloat16)
             and (bn.weight is None or bn.weight.dtype == torch.float32)):
-        return torch.relu(bn(x)) if relu else bn(x)
+        return fallback()
     rows = x.permute(0, 2, 3, 1)
     if not rows.is_contiguous():
-        return torch.relu(bn(x)) if relu else bn(x)
+        return fallback()
     n, h, w, c = rows.shape
     rows = rows.reshape(n * h * w, c)
     if not native.bn_rows_supported(rows) or rows.shape[0] < MIN_ROWS_FUSED_LINEAR:
-        return torch.relu(bn(x)) if relu else bn(x)
+        return fallback()
     if bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)

@@ -58,7 +58,7 @@ class STPN(nn.Module):
         native = [ops.conv3x3_available(torch.empty((0, l.in_channels, H, W), dtype=rows.dtype, device=rows.device), l.weight)
                   if l.kernel_size == (3, 3, 3) and l.padding == (1, 1, 1) else None for l in convs]
         # bf16 / fp32x3 chain: a layer's ReLU backward rides in the NEXT layer's data-gradient epilogue (ops.conv_pair_fusable's scheme along the chain)
-        chain = (all(n == 'bf16' for n in native) or all(n == 'split' for n in native)) and os.environ.get('PCACC_CONV_PAIR', '1') != '0'
+        chain = (all(n == 'bf16' for n in native) or all(n == 'split' for n in native) or all(n == 'mixed' for n in native)) and os.environ.get('PCACC_CONV_PAIR', '1') != '0'
         for k, layer in enumerate(convs):
             cin = layer.in_channels
             if native[k]:

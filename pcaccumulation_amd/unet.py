@@ -31,7 +31,7 @@ class DownConv(nn.Module):
     def forward(self, x):
         pair = ops.conv_pair_fusable(x, self.conv1, self.conv2)   # bf16: conv1's ReLU backward in conv2's data-gradient epilogue
         x = ops.conv3x3(x, self.conv1, relu=True, premasked=pair)
-        if self.pooling and ops.conv3x3_native(x, self.conv2) in ('bf16', 'split') and self.out_channels % 8 == 0:
+        if self.pooling and ops.conv3x3_native(x, self.conv2) in ('bf16', 'split', 'mixed') and self.out_channels % 8 == 0:
             return ops.conv3x3_relu_pool(x, self.conv2, input_relu=pair)   # second conv + ReLU + pool, their backward in one pass (csrc/pool.hip)
         x = ops.conv3x3(x, self.conv2, relu=True, input_relu=pair)
         return (ops.carry_amax(x, self.pool(x)) if self.pooling else x), x          # window maxima of x: x's bound holds (fp32x3 scales)
@@ -50,7 +50,7 @@ class UpConv(nn.Module):
 
     def forward(self, from_down, from_up):
         from_up = ops.upconv2x2(from_up, self.upconv)                   # fp32x3 mode: the 1-tap split kernels; else the library
-        x = ops.merge_amax(torch.cat((from_up, from_down), 1), from_up, from_down) if self.merge_mode == 'concat' else from_up + from_down
+        x = ops.cat_maps((from_up, from_down), 1) if self.merge_mode == 'concat' else from_up + from_down      # mixed mode: twins concatenated too
         pair = ops.conv_pair_fusable(x, self.conv1, self.conv2)
         return ops.conv3x3(ops.conv3x3(x, self.conv1, relu=True, premasked=pair), self.conv2, relu=True, input_relu=pair)
 
@@ -126,5 +126,9 @@ class SegHead2D(nn.Module):
     def forward(self, feats):
         conv0, bn, act, conv1 = self.seg_head
         fused = isinstance(act, nn.ReLU)                       # normalisation and ReLU in one pass each way (csrc/bn.hip)
-        h = ops.batch_norm_nchw(ops.conv3x3(feats, conv0), bn, relu=fused)
+        # 'mixed' mode: the bf16 gradient graph ends behind conv0.  A BatchNorm's backward subtracts most of the gradient it receives (its mean and
+        # its projection on the normalised activations); a gradient rounded to bf16 BEFORE that subtraction keeps 2^-9 of the large incoming values
+        # as noise on the small difference -- measured: +3 % on the pillar encoder's gradient norms, i.e. ~25 % noise.  So everything between a loss
+        # and the first normalisation on its way back (this BatchNorm2d, the second convolution) keeps fp32 gradients and fp32x3 products.
+        h = ops.batch_norm_nchw(ops.exit_mixed(ops.conv3x3(feats, conv0)), bn, relu=fused)
         return ops.conv3x3(h if fused else act(h), conv1)      # c_out = 2: the streamed head kernels (csrc/head_conv.hip)

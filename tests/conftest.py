@@ -30,6 +30,13 @@ def _fp32_point_rows():
     from pcaccumulation_amd import ops
     ops.set_point_dtype(torch.float32)
     ops.set_split(False)
+    ops.set_mixed(False)
+    ops.set_poison(False)
     yield
     ops.set_point_dtype(torch.float32)
     ops.set_split(False)
+    ops.set_mixed(False)
+    ops.set_poison(False)
+    from pcaccumulation_amd import native
+    if native._lib is not None:                   # a test may have changed a launcher switch through the environment (monkeypatch is undone by now)
+        native.reload_switches()

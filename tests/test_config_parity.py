@@ -58,7 +58,7 @@ BF16_TOL = dict(ego=1.5, iou=5e-2, epe=1.5)
 # terms), gradient norms up to 6 % off; fp32 itself with 1e-5 relative noise on the U-Net output moves the STPN gradient norms by 4.2 %
 # (tools/exp_gradnorm_sensitivity.py, profiles/r03_gradnorm_sensitivity.txt).  That is why the kernels split into scaled fp16 halves
 # (22 bits, 3e-7 per product): the fp32 bounds then hold in both modes.
-GRAD_TOL = {'fp32': (3e-2, 2.5e-2), 'fp32x3': (3e-2, 2.5e-2)}
+GRAD_TOL = {'fp32': (3e-2, 2.5e-2), 'fp32x3': (3e-2, 2.5e-2), 'mixed': (3e-2, 2.5e-2)}
 # c3_lidar (LiDAR-distributed points: two thirds of the BEV cells are empty, so far more of the STPN's max-over-frames / max-pool winners
 # are near-ties decided by summation order): the routed gradients differ more between implementations -- measured over three runs
 # each, fp32 (library convolutions) and fp32x3 alike: STPN temporal-conv biases 3.6 - 3.9 %, TubeNet embedding biases 2.9 % off the
@@ -140,7 +140,7 @@ def _check(name, compute_dtype, golden):
     return g, model, out, stats, (flips, False)
 
 
-N_DRAWS = 6
+N_DRAWS = 12
 
 
 def _check_bf16(name, golden):
@@ -172,21 +172,24 @@ def _check_bf16(name, golden):
     res = {k: (mean('bf16', k), mean('fp32x3', k)) for k in draws['bf16'][0]}
     ses = {k: float(np.sqrt(sum(np.var([d[k] for d in draws[dt]], ddof=1) / N_DRAWS for dt in draws))) for k in res}
     _dump(name, 'bf16-vs-fp32x3 seed means', {k: v[0] for k, v in res.items()}, {k: v[1] for k, v in res.items()}, dict(fb_flips=first[0], se=ses))
-    # the two means must agree within Z standard errors of their difference (the spread over key-point draws is measured in the same
-    # runs: rotation error 3.1 +- 0.9 deg on c3) or within a small absolute floor, and never differ by more than 2 x BF16_TOL (no
-    # blow-up).  Z = 6: the standard error is itself estimated from 2 x 6 draws (about 10 degrees of freedom), so the ratio follows a
-    # Student t, not a normal -- at Z = 4 a suite run (6 configs x 4-5 statistics, two of the configs not run-to-run deterministic:
-    # atomics on crowded pillars) failed about once in five (observed ratios up to 3.1 in 18 config runs; a fixed 5 % bound on the loss
-    # failed once at 5.3 % with a standard error of 2.7 %); P(|t_10| > 6) = 1.3e-4 per statistic.
-    Z = 6.0
+    # The two means must agree within Z standard errors of their difference (the spread over key-point draws is measured in the same runs:
+    # rotation error 3.1 +- 0.9 deg on c3) or within a small absolute floor, and NEVER differ by more than BF16_TOL (round-3 advice: the cap was
+    # 2 x BF16_TOL, i.e. the effective bound wherever 6 SE exceeded it; N_DRAWS went 6 -> 12 instead of widening Z: SE shrinks by sqrt 2, the
+    # ratio is Student-t with ~22 degrees of freedom, P(|t| > 5) = 5e-5 per statistic).  A noisier bf16 arm must not buy slack through a larger
+    # SE: its spread is held to 3 x the fp32x3 arm's (+ half the floor).  One direct check against the reference's golden value stays: mos_iou.
+    Z = 5.0
     floors = dict(ego_rot_error=0.1, ego_trans_error=0.1, mos_iou=1e-2, epe_mean=0.1)
     caps = dict(ego_rot_error=BF16_TOL['ego'], ego_trans_error=BF16_TOL['ego'], mos_iou=BF16_TOL['iou'], epe_mean=BF16_TOL['epe'])
+    sd = lambda dt, k: float(np.std([d[k] for d in draws[dt]], ddof=1))
     for k in floors:
         diff = abs(res[k][0] - res[k][1])
-        assert diff < max(floors[k], Z * ses[k]) and diff < 2 * caps[k], (k, res[k], ses[k], draws)
+        assert diff < max(floors[k], Z * ses[k]) and diff < caps[k], (k, res[k], ses[k], draws)
+        assert sd('bf16', k) <= 3.0 * sd('fp32x3', k) + 0.5 * floors[k], (k, sd('bf16', k), sd('fp32x3', k))
+    assert abs(draws['bf16'][0]['mos_iou'] - float(g['mos_iou'])) < BF16_TOL['iou'], (draws['bf16'][0]['mos_iou'], float(g['mos_iou']))
     if train:
+        # 5 % or Z standard errors (a fixed 5 % failed once at 5.3 % with SE 2.7 %: the two means differ by noise of that size), never more than 10 %
         assert abs(res['loss'][0] - res['loss'][1]) < max(5e-2 * abs(res['loss'][1]), Z * ses['loss']), (res['loss'], ses['loss'], draws)
-        assert abs(res['loss'][0] - res['loss'][1]) < 0.25 * abs(res['loss'][1]), (res['loss'], draws)             # no blow-up
+        assert abs(res['loss'][0] - res['loss'][1]) < 0.10 * abs(res['loss'][1]), (res['loss'], draws)
     return first
 
 
@@ -209,7 +212,7 @@ def test_gpu_config_fused_matching(name, golden, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('name', CONFIGS)
-@pytest.mark.parametrize('mode', ['fp32', 'fp32x3'])
+@pytest.mark.parametrize('mode', ['fp32', 'fp32x3', 'mixed'])
 def test_gpu_config_fp32(name, mode, golden):
     """north_star's 1e-3 in both fp32-accurate modes: 'fp32' (library fp32 convolutions, fp32 vector row kernels) and 'fp32x3' (the
     hand-written split-bf16 MFMA kernels of csrc/conv_split.hip: the matched-accuracy figure of bench.py)."""

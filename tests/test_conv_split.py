@@ -221,6 +221,7 @@ def test_conv3x3_split_resident_kernel(n, t, h, w, ci, co, kt, monkeypatch):
     """The persistent kernel of the narrow layers (weights of a slice resident in LDS, patches prefetched across tiles), forced on at
     test sizes: forward and masked data gradient against float64, and bit-equal maxima reporting."""
     monkeypatch.setenv('PCACC_CONV_RES', '2')
+    native.reload_switches()                                   # the launchers read their switches once per process
     g = torch.Generator(device='cpu').manual_seed(n + h + w + ci + co)
     x = torch.randn(n, h, w, ci, generator=g).to(DEV).requires_grad_(True)
     shape = (co, ci, 3, 3, 3) if kt == 3 else (co, ci, 3, 3)
@@ -238,6 +239,7 @@ def test_conv3x3_split_resident_kernel(n, t, h, w, ci, co, kt, monkeypatch):
     assert _rel(y, torch.relu(yr.detach())) <= TOL and _rel(x.grad, xr.grad) <= TOL and _rel(wt.grad, wr.grad) <= TOL
     assert float(ops.amax_tag(y).max()) == float(y.abs().max())
     monkeypatch.setenv('PCACC_CONV_RES', '0')
+    native.reload_switches()
     y0 = ops.conv3x3_rows(x.detach(), wt.detach(), bias.detach(), t if kt == 3 else 1, True)
     assert _rel(y0, y.detach()) <= 1e-6                        # the two kernels sum in different orders
 
@@ -278,6 +280,7 @@ def test_conv_split_out_mask(ci, co, kt, h, w, res, monkeypatch):
     aten::threshold_backward, bit for bit (streaming and resident kernels, with and without the input-side mask); the reported maximum
     is that of the masked result."""
     monkeypatch.setenv('PCACC_CONV_RES', res)
+    native.reload_switches()
     b, t = 2, 3
     g = torch.Generator(device='cpu').manual_seed(ci + 5 * co + kt)
     gy = torch.randn(b * t, h, w, ci, generator=g).to(DEV)

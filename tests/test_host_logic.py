@@ -70,7 +70,8 @@ def test_amax_tags_follow_views_and_versions():
 
 def test_prepared_weight_copies_are_keyed_on_the_weight_epoch_too():
     """ops.prepared_conv_weights* key their copies on (object, version, address, weight epoch): torch's fused optimizers do not increment
-    the version counter, so MotionNet bumps the epoch on every training forward / mode switch and DataParallelStep after its optimizer step."""
+    the version counter, so the epoch advances on every train() / eval() switch, after every step of a watched optimizer (MotionNet.watch_optimizer;
+    DataParallelStep watches its own), and -- without a watched optimizer -- at every forward that runs with gradients enabled."""
     import torch
     from pcaccumulation_amd import ops
     from pcaccumulation_amd.config import default_config
@@ -90,6 +91,16 @@ def test_prepared_weight_copies_are_keyed_on_the_weight_epoch_too():
     e = ops._WEIGHT_EPOCH
     model.train()
     assert ops._WEIGHT_EPOCH > e
+    # invalidation at the writer: a watched optimizer's step advances the epoch -- also for a fused optimizer, which leaves the
+    # version counters alone -- and MotionNet.forward then no longer invalidates by itself (accumulation micro-steps share one preparation)
+    assert not model._optimizer_watched
+    opt = model.watch_optimizer(torch.optim.SGD(model.parameters(), lr=0.0))
+    assert model._optimizer_watched
+    for p_ in model.parameters():
+        p_.grad = torch.zeros_like(p_)
+    e = ops._WEIGHT_EPOCH
+    opt.step()
+    assert ops._WEIGHT_EPOCH == e + 1
     # an entry goes with its weight (no device copies of dead parameters until the 4096-entry sweep)
     import gc
     cache = {}

@@ -1,0 +1,164 @@
+"""The 'mixed' compute mode (ops.set_mixed): forward values of the fp32x3 mode, bf16 gradient graph inside the two convolution segments.
+
+1. Forward: the SAME numbers as the fp32x3 mode, bit for bit, on the same weights / scene / seed -- also with every bf16 shadow filled with NaN
+   (ops.set_poison): no forward value may come from a shadow.
+2. Backward: per-parameter gradients against the fp32x3 mode's -- norms within 1 %, directions (cosine) within 1e-3 for every parameter whose
+   gradient is not rounding noise.
+3. The registry: shadows, views of shadows, concatenations (host logic, CPU).
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_batch
+from pcaccumulation_amd import ops
+from pcaccumulation_amd.config import default_config
+from pcaccumulation_amd.loss import FuseLoss
+from pcaccumulation_amd.motionnet import MotionNet
+from pcaccumulation_amd.synthetic import fill_state_dict_
+
+
+def test_twin_registry_views_and_cat():
+    ops.set_split(True)
+    ops.set_mixed(True)
+    x = torch.randn(2, 4, 6, 8)
+    x16 = ops.shadow(x)
+    assert ops.twin(x16) is x
+    v = x16.permute(0, 3, 1, 2)[:, 2:6]                                    # a channel slice of the NCHW view
+    assert torch.equal(ops.twin(v), x.permute(0, 3, 1, 2)[:, 2:6])
+    assert torch.equal(ops.twin(x16.detach().view(8, 6, 8)), x.view(8, 6, 8))
+    a = torch.randn(2, 3, 4, 4).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(2, 5, 4, 4).contiguous(memory_format=torch.channels_last)
+    c = ops.cat_maps((ops.shadow(a), ops.shadow(b)), 1)
+    assert c.dtype == torch.bfloat16 and torch.equal(ops.twin(c), torch.cat((a, b), 1))
+    with pytest.raises(RuntimeError):
+        ops.twin(torch.zeros(4, 4, dtype=torch.bfloat16))                   # a bf16 tensor nobody registered: refused, not up-cast
+    ops.twins_clear()
+    with pytest.raises(RuntimeError):
+        ops.twin(x16)
+
+
+def _model(cfg, dev):
+    model = MotionNet(cfg)
+    fill_state_dict_(model)
+    with torch.no_grad():
+        model.semseg_head.seg_head[3].bias += torch.tensor([2.0, 0.0])     # some pillars foreground, some background
+    return model.to(dev).train().channels_last_()
+
+
+def _step(mode, inp, poison=False, backward=True):
+    dev = torch.device('cuda:0')
+    cfg = default_config('waymo', 'train', n_sweeps=3, xy_range=16)
+    cfg['misc']['compute_dtype'] = mode
+    model = _model(cfg, dev)
+    ops.set_poison(poison)
+    torch.manual_seed(7)
+    out = model(inp)
+    stats = FuseLoss(cfg['loss'])(out, inp)
+    if backward:
+        stats['loss'].backward()
+    ops.set_poison(False)
+    keep = {k: out[k].detach().float().clone() for k in ('fb_seg_est', 'mos_est', 'offset_est', 'rec_est', 'ego_motion_est', 'transformed_points')}
+    return keep, float(stats['loss'].detach()), ({k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None} if backward else None)
+
+
+@pytest.mark.gpu
+def test_mixed_forward_is_the_fp32x3_forward_and_never_reads_a_shadow():
+    dev = torch.device('cuda:0')
+    cfg = default_config('waymo', 'train', n_sweeps=3, xy_range=16)
+    inp = make_batch(cfg, [51, 52], 3, 6000)
+    inp = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}
+    ref, ref_loss, _ = _step('fp32x3', inp, backward=False)
+    again, _, _ = _step('fp32x3', inp, backward=False)                     # the fp32x3 forward against itself (the TubeNet's LDS-atomic row sums)
+    for poison in (False, True):
+        got, loss, _ = _step('mixed', inp, poison=poison, backward=False)
+        bad = []
+        for k in ref:
+            if not bool(torch.isfinite(got[k]).all()):
+                bad.append((k, 'non-finite'))
+                continue
+            # same kernels on the same fp32 inputs; the scales come from maxima collected with atomics (order-independent)
+            d, scale = float((got[k] - ref[k]).abs().max()), float(ref[k].abs().max())
+            if d > max(1e-6 * scale, 4 * float((again[k] - ref[k]).abs().max())):
+                bad.append((k, d, scale))
+        assert not bad, (poison, bad)
+        assert abs(loss - ref_loss) <= 1e-6 * abs(ref_loss), (poison, loss, ref_loss)
+
+
+@pytest.mark.gpu
+def test_mixed_gradients_against_fp32x3():
+    dev = torch.device('cuda:0')
+    cfg = default_config('waymo', 'train', n_sweeps=3, xy_range=16)
+    inp = make_batch(cfg, [51, 52], 3, 6000)
+    inp = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}
+    _, _, ref = _step('fp32x3', inp)
+    _, _, again = _step('fp32x3', inp)
+    _, _, got = _step('mixed', inp)
+    assert got.keys() == ref.keys()
+    total = float(torch.sqrt(sum((g.double() ** 2).sum() for g in ref.values())))
+    bad = []
+    for k, g in ref.items():
+        n = float(g.norm())
+        if n < 1e-5 * total:                                               # rounding noise on both sides (a conv bias in front of a BatchNorm)
+            continue
+        own = float((again[k] - g).norm()) / n                              # the fp32x3 step against itself (atomics in the row sums)
+        dn = abs(float(got[k].norm()) - n) / n
+        cos = float((got[k].double() * g.double()).sum() / (got[k].double().norm() * g.double().norm()))
+        if dn > max(1e-2, 4 * own) or 1 - cos > max(1e-3, 4 * own):
+            bad.append((k, dn, 1 - cos, own))
+    assert not bad, bad[:10]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,h,w,c,pitch', [(3, 16, 24, 32, 32), (2, 17, 9, 64, 128), (1, 288, 288, 32, 64)])
+def test_pool_backward_with_fp32_winners(n, h, w, c, pitch):
+    """pcacc_pool_skip_relu_backward_strided_y32 (y f32, gradients bf16) == the f32 kernel on the up-cast gradients, rounded once -- and NOT what a
+    bf16 copy of y gives (values closer than 2^-8 tie there)."""
+    from pcaccumulation_amd import native
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device='cpu').manual_seed(n + h + c)
+    y = torch.relu(torch.randn(n, h, w, c, generator=g) + 0.5).to(dev)
+    y[0, :2, :2, :4] = torch.tensor([1.0, 1.0 + 2.0 ** -12, 1.0 + 2.0 ** -11, 1.0 - 2.0 ** -12], device=dev).view(2, 2, 1)   # one bf16 value, four fp32 values
+    gp = torch.randn(n, h // 2, w // 2, c, generator=g).to(dev).to(torch.bfloat16)
+    wide = torch.randn(n, h, w, pitch, generator=g).to(dev).to(torch.bfloat16)
+    gs = wide[..., pitch - c:]                                              # a channel slice of a wider map, read in place
+    got = native.pool_skip_relu_backward(y, gp, gs)
+    ref = native.pool_skip_relu_backward(y, gp.float(), gs.float().contiguous()).to(torch.bfloat16)
+    assert got.dtype == torch.bfloat16 and torch.equal(got, ref)
+    for a, b in ((gp, None), (None, gs)):
+        assert torch.equal(native.pool_skip_relu_backward(y, a, b),
+                           native.pool_skip_relu_backward(y, a.float() if a is not None else None, b.float().contiguous() if b is not None else None).to(torch.bfloat16))
+    low = native.pool_skip_relu_backward(y.to(torch.bfloat16), gp, gs)      # winners from the rounded copy
+    assert not torch.equal(low[0, :2, :2, :4], got[0, :2, :2, :4])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,t,h,w,ci,co,kt', [(2, 1, 16, 32, 32, 32, 1), (4, 2, 33, 70, 32, 64, 3), (2, 1, 18, 18, 128, 64, 1), (1, 1, 100, 300, 64, 64, 1)])
+def test_split_kernels_second_output_is_the_rounded_first(n, t, h, w, ci, co, kt):
+    """pcacc_conv3x3_split_dual / pcacc_upconv2x2_split_dual: the bf16 shadow written by the epilogue == the fp32 result rounded to nearest even,
+    and the fp32 result == the plain entry's."""
+    from pcaccumulation_amd import native
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device='cpu').manual_seed(n + h + ci + co)
+    x = torch.randn(n, h, w, ci, generator=g).to(dev)
+    wt = (torch.randn(*((co, ci, 3, 3, 3) if kt == 3 else (co, ci, 3, 3)), generator=g) / (4 * ci ** 0.5)).to(dev)
+    bias = torch.randn(co, generator=g).to(dev)
+    wf, _ = native.conv3x3_split_prepare_weights(wt)
+    am = native.absmax256(x)
+    for force in ('0', '2'):                                                # streaming and resident kernels
+        import os
+        os.environ['PCACC_CONV_RES'] = force
+        native.reload_switches()
+        try:
+            y, ya = native.conv3x3_split(x, wf, bias, t, True, amax=am, want_amax=True)
+            y2, ya2, y16 = native.conv3x3_split(x, wf, bias, t, True, amax=am, want_amax=True, want_bf16=True)
+        finally:
+            del os.environ['PCACC_CONV_RES']
+            native.reload_switches()
+        assert torch.equal(y, y2) and torch.equal(ya, ya2) and torch.equal(y16, y.to(torch.bfloat16))
+    if kt == 1 and native.upconv2x2_split_supported(h, w, ci, co):
+        wu = (torch.randn(ci, co, 2, 2, generator=g) / (2 * ci ** 0.5)).to(dev)
+        uf, _ = native.upconv2x2_split_prepare_weights(wu)
+        u, ua = native.upconv2x2_split(x, am, uf, bias, 0)
+        u2, ua2, u16 = native.upconv2x2_split(x, am, uf, bias, 0, want_bf16=True)
+        assert torch.equal(u, u2) and torch.equal(u16, u.to(torch.bfloat16))

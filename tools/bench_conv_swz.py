@@ -24,6 +24,7 @@ for kt, co in ((3, 32), (3, 64)):
         for k in KNOBS:
             os.environ.pop(k, None)
         os.environ.update(env)
+        native.reload_switches()
         y = native.conv3x3(x, wp, bias, fr, True)
         ts = [round(timeit(lambda: native.conv3x3(x, wp, bias, fr, True), iters=50), 1) for _ in range(3)]
         ref = y if ref is None else ref
