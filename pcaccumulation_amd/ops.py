@@ -86,8 +86,14 @@ class _SegmentMax(torch.autograd.Function):
     @staticmethod
     def forward(ctx, src, pidx):
         src = src.contiguous()
-        out, arg = native.segment_max(src if src.dtype in (torch.float32, torch.bfloat16) else src.float(), pidx.seg_offsets,
-                                      pidx.order, pidx.m)
+        mixed = _MIXED and src.dtype == torch.bfloat16 and twin(src, required=False) is not None
+        if mixed:                                                  # shadow rows: maxima AND winners from the fp32 twin (a bf16 copy ties close values)
+            s32 = twin(src)
+            out, arg = native.segment_max(s32, pidx.seg_offsets, pidx.order, pidx.m)
+            out = shadow(carry_amax(s32, out))
+        else:
+            out, arg = native.segment_max(src if src.dtype in (torch.float32, torch.bfloat16) else src.float(), pidx.seg_offsets,
+                                          pidx.order, pidx.m)
         ctx.pidx = pidx
         ctx.src_dtype = src.dtype
         ctx.save_for_backward(arg)
@@ -145,6 +151,13 @@ class _PillarScatter(torch.autograd.Function):
     def forward(ctx, feats, pidx, out_dtype):
         ctx.pidx, ctx.in_dtype = pidx, feats.dtype
         feats = feats.contiguous()
+        if _MIXED and feats.dtype == torch.bfloat16 and feats.shape[1] % 8 == 0 and twin(feats, required=False) is not None:
+            # shadow rows -> shadow canvas: the fp32 canvas from the twin rows, the bf16 canvas from the shadow rows (two streaming fills instead
+            # of a fill and a cast pass); the gradient comes back as a bf16 canvas and leaves as bf16 rows
+            f32 = twin(feats)
+            canvas32 = carry_amax(f32, native.pillar_scatter(f32, pidx.cell2pillar, torch.float32))
+            canvas16 = native.pillar_scatter(feats, pidx.cell2pillar, torch.bfloat16)
+            return shadow(canvas32, canvas16)
         if not (feats.dtype == torch.bfloat16 and out_dtype == torch.bfloat16 and feats.shape[1] % 8 == 0):
             feats = feats.float()
         return native.pillar_scatter(feats, pidx.cell2pillar, out_dtype)
@@ -384,6 +397,29 @@ class _RowsLinear(torch.autograd.Function):
         return gx, gw, gb, gres, None, None, None
 
 
+class _RowsLinearMixed(_RowsLinear):
+    """'mixed' mode: _RowsLinear's forward in fp32 (on the twin of a shadow input, or on an fp32 input that carries no gradient: the
+    9-feature rows), the result registered as the twin of the bf16 shadow autograd sees; the backward is _RowsLinear's on bf16 rows."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, pre_relu, post_relu, out_dtype):
+        x = x.contiguous()
+        w = weight.contiguous()
+        x32 = twin(x) if x.dtype == torch.bfloat16 else x
+        res = residual.contiguous() if residual is not None else None
+        res32 = (twin(res) if res.dtype == torch.bfloat16 else res) if res is not None else None
+        k, n = w.shape[1], w.shape[0]
+        if native.rows_split_supported(k, n) and w.dtype == torch.float32:
+            y32, y_amax = native.rows_linear_split(x32, amax_of(x32), w, bias, res32, pre_relu, post_relu, want_amax=True)
+            set_amax_tag(y32, y_amax)
+        else:
+            y32 = native.rows_linear(x32, w, bias, res32, pre_relu, post_relu, out_dtype=torch.float32)
+        y = shadow(y32)
+        ctx.flags = (pre_relu, post_relu, bias is not None, residual is not None, res.dtype if res is not None else None, False)
+        ctx.save_for_backward(x, w, y if post_relu else None, None)
+        return y
+
+
 class _RowsLinearCat(torch.autograd.Function):
     """_RowsLinear on x = cat(xa, pooled[p2v]) without materialising the gather or the concatenation (bf16 rows, or fp32 rows in the
     fp32x3 mode, on the GPU; pcacc_rows_linear_cat_bf16 / _cat_split): the PFN blocks' input (models/pillar_encoder.py:116-118).
@@ -539,6 +575,37 @@ class _PfnBlockSplit(torch.autograd.Function):
         return gxa, gpool, None, gw0, gb0 if ctx.has_bias[0] else None, gws, gw1, gb1 if ctx.has_bias[1] else None, None
 
 
+class _PfnBlockMixed(_PfnBlock):
+    """'mixed' mode: _PfnBlockSplit's forward on the twins of shadow rows, _PfnBlock's bf16 backward (one kernel for the data gradients and the
+    three weight gradients).  The pooling's winners come from the fp32 rows."""
+
+    @staticmethod
+    def forward(ctx, xa, pooled, pidx, w0, b0, ws, w1, b1, pool=False):
+        xa = xa.contiguous()
+        xa32 = twin(xa)
+        a_amax = amax_of(xa32)
+        arg = None
+        if pool:
+            pooled32, arg = native.segment_max(xa32, pidx.seg_offsets, pidx.order, pidx.m)
+            p_amax = a_amax
+            pooled = pooled32.to(torch.bfloat16) if not _POISON else torch.full_like(pooled32, float('nan'), dtype=torch.bfloat16)
+        elif pooled is not None:
+            pooled = pooled.contiguous()
+            pooled32 = twin(pooled)
+            p_amax = amax_of(pooled32)
+        else:
+            pooled32 = p_amax = None
+        w0, ws, w1 = w0.contiguous(), ws.contiguous(), w1.contiguous()
+        out32, hr32, _xm, _hm, out_amax, _hr_amax = native.pfn_block_split_forward(xa32, a_amax, pooled32, p_amax, pidx.p2v if pooled32 is not None else None,
+                                                                                   w0, b0, ws, w1, b1)
+        set_amax_tag(out32, out_amax)
+        hr = hr32.to(torch.bfloat16) if not _POISON else torch.full_like(hr32, float('nan'), dtype=torch.bfloat16)
+        ctx.pidx = pidx
+        ctx.save_for_backward(xa, pooled, hr, w0, ws, w1, arg)
+        ctx.has_bias = (b0 is not None, b1 is not None)
+        return shadow(out32)
+
+
 def pfn_block_available(block, x, pooled=None):
     """The fused block takes bf16 rows (or fp32 rows in the fp32x3 mode) on the GPU, the encoder's widths (64 -> 32 -> 32 with a shortcut)
     and fp32 parameters."""
@@ -552,7 +619,7 @@ def pfn_block_available(block, x, pooled=None):
 def pfn_block(block, x, pooled=None, pidx=None, pool=False):
     """block(x) or block(cat(x, pooled[pidx.p2v])) for a pillar_encoder.ResnetBlockFC -- see _PfnBlock / _PfnBlockSplit.
     pool=True: pooled = segment_max(x, pidx), taken inside the same autograd node."""
-    fn = _PfnBlockSplit if x.dtype == torch.float32 else _PfnBlock
+    fn = _PfnBlockSplit if x.dtype == torch.float32 else (_PfnBlockMixed if _MIXED else _PfnBlock)
     return fn.apply(x, pooled, pidx, block.fc_0.weight, block.fc_0.bias, block.shortcut.weight, block.fc_1.weight, block.fc_1.bias, pool)
 
 
@@ -797,14 +864,20 @@ def amax_of(t):
     return a
 
 
-def linear_rows(x, layer, pre_relu=False, post_relu=False, residual=None, out_dtype=None):
+def linear_rows(x, layer, pre_relu=False, post_relu=False, residual=None, out_dtype=None, mixed=False):
     """`layer(relu?(x))` (+ residual, relu?) for an nn.Linear `layer` on a 2-D `x`.  Large row counts with a supported
     feature width go through the fused HIP kernels; anything else is the library GEMM with the same semantics.
     out_dtype: element type of the result (default: that of x); bf16 rows are only taken on the GPU."""
     k, n = layer.in_features, layer.out_features
     out_dtype = out_dtype or x.dtype
-    if x.dim() == 2 and x.dtype in (torch.float32, torch.bfloat16) and x.shape[0] >= MIN_ROWS_FUSED_LINEAR \
-            and native.rows_linear_supported(k, n) and not torch.is_autocast_enabled():
+    fused = (x.dim() == 2 and x.dtype in (torch.float32, torch.bfloat16) and x.shape[0] >= MIN_ROWS_FUSED_LINEAR
+             and native.rows_linear_supported(k, n) and not torch.is_autocast_enabled())
+    if _MIXED and x.is_cuda and (x.dtype == torch.bfloat16 or mixed):
+        # a shadow (or, with mixed=True, the fp32 head of a chain that is to continue as shadows): fp32 forward, bf16 backward
+        if not fused:
+            raise native.NativeError('mixed mode: a row layer outside the fused kernels (%s, %d -> %d)' % (tuple(x.shape), k, n))
+        return _RowsLinearMixed.apply(x, layer.weight, layer.bias, residual, pre_relu, post_relu, torch.bfloat16)
+    if fused:
         return _RowsLinear.apply(x, layer.weight, layer.bias, residual, pre_relu, post_relu, out_dtype)
     h = torch.relu(x) if pre_relu else x
     y = torch.nn.functional.linear(h.to(layer.weight.dtype), layer.weight, layer.bias)

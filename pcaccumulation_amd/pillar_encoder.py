@@ -91,7 +91,7 @@ class PillarFeatureNet(nn.Module):
         if features is None:
             features = self.point_features(raw_points, pidx, coordinates, pillar_mean, time_indice)
         pd = ops.point_dtype() if features.is_cuda else features.dtype     # bf16 rows in the bf16 compute mode (GPU only)
-        net = ops.linear_rows(features, self.fc_pos, out_dtype=pd)
+        net = ops.linear_rows(features, self.fc_pos, out_dtype=pd, mixed=ops.mixed_mode())     # 'mixed' mode: the chain continues as bf16 shadows of fp32 rows
         net = self.blocks[0](net)
         for block in self.blocks[1:]:
             if ops.pfn_pool_block_available(block, net, pidx):

@@ -96,7 +96,12 @@ class UNet(nn.Module):
             skips.append(before_pool)
         for i, module in enumerate(self.up_convs):
             x = module(skips[-(i + 2)], x)
-        return ops.conv3x3(x, self.conv_final)
+        # 'mixed' mode: the bf16 gradient graph covers the encoder / decoder body and ends here.  The last convolution and the two heads behind it
+        # keep fp32 gradients and fp32x3 products: each head starts conv -> BatchNorm, whose backward returns a zero-mean gradient -- the bias
+        # gradients of those first convolutions and of conv_final are sums that cancel (to rounding / to a boundary term), and formed from
+        # bf16-rounded gradient maps they were 50 % - 100 x off (0.0020 against 0.0013, 5e-4 against 4e-6 on c3); a BatchNorm fed a
+        # bf16-rounded gradient keeps 2^-9 of what it subtracts as noise.  Everything from here to the losses stays fp32.
+        return ops.conv3x3(ops.exit_mixed(x), self.conv_final)
 
 
 class SegHead1D(nn.Module):
@@ -126,9 +131,5 @@ class SegHead2D(nn.Module):
     def forward(self, feats):
         conv0, bn, act, conv1 = self.seg_head
         fused = isinstance(act, nn.ReLU)                       # normalisation and ReLU in one pass each way (csrc/bn.hip)
-        # 'mixed' mode: the bf16 gradient graph ends behind conv0.  A BatchNorm's backward subtracts most of the gradient it receives (its mean and
-        # its projection on the normalised activations); a gradient rounded to bf16 BEFORE that subtraction keeps 2^-9 of the large incoming values
-        # as noise on the small difference -- measured: +3 % on the pillar encoder's gradient norms, i.e. ~25 % noise.  So everything between a loss
-        # and the first normalisation on its way back (this BatchNorm2d, the second convolution) keeps fp32 gradients and fp32x3 products.
-        h = ops.batch_norm_nchw(ops.exit_mixed(ops.conv3x3(feats, conv0)), bn, relu=fused)
+        h = ops.batch_norm_nchw(ops.exit_mixed(ops.conv3x3(feats, conv0)), bn, relu=fused)     # (mixed mode: fp32 here already, see UNet.forward)
         return ops.conv3x3(h if fused else act(h), conv1)      # c_out = 2: the streamed head kernels (csrc/head_conv.hip)

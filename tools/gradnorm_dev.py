@@ -5,9 +5,9 @@ import test_config_parity as T
 from conftest import *  # noqa
 def golden(name):
     return np.load(os.path.join(ROOT, 'tests', 'golden', '%s.npz' % name), allow_pickle=True)
-for cfgname in ('c3', 'c5'):
+for cfgname in (sys.argv[1:] or ('c3', 'c5')):
     g = golden('model_' + cfgname)
-    for mode in ('fp32', 'fp32x3'):
+    for mode in os.environ.get('PCACC_MODES', 'fp32,fp32x3,mixed').split(','):
         model, inp, out, stats, Tn = T._run(g, mode)
         grads = dict(model.named_parameters())
         devs = []
@@ -15,4 +15,4 @@ for cfgname in ('c3', 'c5'):
             got = float(grads[n].grad.norm()) if grads[n].grad is not None else 0.0
             devs.append((abs(got - ref) / max(abs(ref), 1e-2), n))
         devs.sort(reverse=True)
-        print(cfgname, mode, 'EGO_FUSED=%s' % os.environ.get('PCACC_EGO_FUSED', '1'), ' '.join('%s %.3f' % (n[-28:], d) for d, n in devs[:4]))
+        print(cfgname, mode, 'EGO_FUSED=%s' % os.environ.get('PCACC_EGO_FUSED', '1'), ' '.join('%s %.3f' % (n[-28:], d) for d, n in devs[:8]))
