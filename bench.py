@@ -240,6 +240,45 @@ def step_model(stepper, batcher, feed):
     return tot
 
 
+def config_throughput(kind, name, dataset, T, ppf, batch, mode, steps, warmup, device):
+    """Throughput of one BASELINE.json configuration: kind 'train' = this file's training step (voxelise + collate, forward, FuseLoss, backward,
+    clip, fused Adam through DataParallelStep, next batch prefetched), kind 'eval' = voxelise + collate + MotionNet forward under no_grad."""
+    cfg = default_config(dataset, 'train' if kind == 'train' else 'val', n_sweeps=T)
+    cfg['misc']['compute_dtype'] = mode
+    cfg['pose_estimation']['kpt_sampler'] = 'device'
+    batcher = DeviceBatcher(cfg)
+    if kind == 'train':
+        model, opt, loss_fn = build(cfg, device)
+        scenes = [sample_to_device(make_sequence(100 + i, T, ppf, cfg), device) for i in range(2 * batch)]
+        batch_of = lambda i: [scenes[(i * batch + j) % len(scenes)] for j in range(batch)]
+        stepper = pdist.DataParallelStep(model, opt, loss_fn, iter_size=1, grad_clip=cfg['train']['grad_clip'])
+        feed = BatchFeed(batcher, batch_of, True)
+        run = lambda: train_step(stepper, batcher, feed)
+    else:
+        torch.manual_seed(0)
+        model = MotionNet(cfg).to(device).channels_last_().eval()
+        scenes = [sample_to_device(make_sequence(100 + i, T, ppf, cfg), device) for i in range(batch)]
+
+        def run():
+            with torch.no_grad():
+                model(batcher(scenes))
+    for _ in range(warmup):
+        run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return dict(config=name, kind='train step' if kind == 'train' else 'eval forward (voxelise + MotionNet)', dataset=dataset, frames=T, pts_per_frame=ppf,
+                sequences_per_step=batch, dtype=mode, ms_per_step=round(dt * 1e3, 3), lidar_frames_per_s=round(batch * T / dt, 1), steps=steps, warmup=warmup)
+
+
+# the other BASELINE.json configurations beside the headline (c3, 4 sequences per step): (kind, name, dataset, frames, points per frame, sequences per step)
+OTHER_CONFIGS = [('eval', 'c2', 'nuscene', 5, 80000, 4), ('train', 'c3', 'waymo', 5, 160000, 1), ('eval', 'c4', 'waymo', 10, 200000, 2),
+                 ('train', 'c5', 'nuscene', 5, 80000, 4)]
+
+
 def scatter_flushed(dtype, batch, pillars):
     """The pillar-scatter launch of the roofline object with cold caches: 1 GiB read and written between launches (the in-step launch
     follows the pillar encoder's last layers and finds part of its feature table in the 256 MB Infinity Cache)."""
@@ -283,6 +322,7 @@ def main():
     ap.add_argument('--iter-size', type=int, default=1, help='micro-steps per optimizer step (gradient accumulation; the all-reduce fires on the last one; reference yaml: 2)')
     ap.add_argument('--points', default='uniform', choices=['uniform', 'lidar'], help="synthetic point distribution: 'uniform' (BASELINE.json: synthetic; the headline) or 'lidar' = 1/r range density, 64 beams, scan-ordered within a frame (SURVEY 8d; synthetic.make_sequence(mode='lidar_scan'))")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-configs', action='store_true', help='skip the short runs of the other BASELINE.json configurations (c2 / c4 eval forward, c3 at one sequence per step, c5 train step) reported as `configs` at N = 1')
     ap.add_argument('--no-step-model', action='store_true', help='skip the instrumented extra step behind roofline_step and the cold-cache scatter launches')
     ap.add_argument('--no-fp32-leg', '--no-second-leg', dest='no_fp32_leg', action='store_true', help='skip the second timing of the same step in the other mode (bf16 beside the mixed headline; fp32x3 beside a bf16 run) that follows at N = 1')
     ap.add_argument('--no-miopen-find', action='store_true', help='library convolutions through the immediate-mode heuristic instead of the find-db')
@@ -460,6 +500,17 @@ def main():
         switches = sorted(k for k in os.environ if k.startswith('PCACC_') and k not in ('PCACC_DIST_BACKEND', 'PCACC_BENCH_DEBUG'))
         if switches:
             line['config']['kernel_switches'] = {k: os.environ[k] for k in switches}      # A/B switches in effect (none in a default run)
+        if world == 1 and not args.no_configs:
+            # the other BASELINE configurations on the same tree, a few steps each: the certified mode ('mixed' for train steps, its forward alone =
+            # 'fp32x3' for the eval-only configurations); profiles/r04_bench_configs.jsonl holds the longer runs incl. bf16
+            rows = []
+            for kind, name, ds, T, ppf, b in OTHER_CONFIGS:
+                try:
+                    rows.append(config_throughput(kind, name, ds, T, ppf, b, 'mixed' if kind == 'train' else 'fp32x3', 4, 2, device))
+                except Exception as e:                                 # diagnostics must never take the bench line down
+                    rows.append({'config': name, 'error': repr(e)})
+                torch.cuda.empty_cache()
+            line['configs'] = rows
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line['cpu_baseline'] = cpu_baseline(cfg, args.pts_per_frame)

@@ -636,6 +636,11 @@ int pcacc_pfn_block_split_forward(const float *xa, const float *xa_amax, const f
                                   const float *w0, const float *b0, const float *ws, const float *w1, const float *b1, float *out,
                                   float *relu_h, uint64_t *xmask, uint32_t *hmask, float *out_amax, float *hr_amax, int64_t rows,
                                   void *stream);
+/* 'mixed' compute mode: pcacc_pfn_block_split_forward's fp32 result plus the two operands of the bf16 backward kernel pcacc_pfn_block_backward,
+ * written by the same epilogue: out16 = bf16(out), hr16 = bf16(relu(h)) [rows,32]; no fp32 relu(h), no sign masks.  models/pillar_encoder.py:13-55. */
+int pcacc_pfn_block_split_forward_dual(const float *xa, const float *xa_amax, const float *pooled, const float *pooled_amax, const int32_t *p2v,
+                                       const float *w0, const float *b0, const float *ws, const float *w1, const float *b1, float *out,
+                                       uint16_t *out16, uint16_t *hr16, float *out_amax, int64_t rows, void *stream);
 int pcacc_pfn_block_split_dgrad(const float *grad_out, const float *grad_out_amax, const uint64_t *xmask, const uint32_t *hmask,
                                 const float *w0, const float *ws, const float *w1, float *grad_xa, float *grad_xb, float *grad_h,
                                 float *gx_amax, float *dh_amax, int64_t rows, void *stream);

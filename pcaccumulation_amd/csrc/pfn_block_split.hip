@@ -125,7 +125,8 @@ __global__ __launch_bounds__(PBS_THREADS, 2) void pfn_block_split_fwd_kernel(con
                                                                           const float *__restrict__ W1, const float *__restrict__ b1,
                                                                           float *__restrict__ out, float *__restrict__ hr, uint64_t *__restrict__ xmask,
                                                                           uint32_t *__restrict__ hmask, float *__restrict__ out_amax,
-                                                                          float *__restrict__ hr_amax, int64_t rows)
+                                                                          float *__restrict__ hr_amax, int64_t rows, uint16_t *__restrict__ out16,
+                                                                          uint16_t *__restrict__ hr16)
 {
     constexpr int XS = 72, HS = 40, OS = 36;
     constexpr int XPL = PBS_TILE * XS, HPL = PBS_TILE * HS, W64 = 32 * XS, W32 = 32 * HS;
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(PBS_THREADS, 2) void pfn_block_split_fwd_kernel(con
         }
         {
             const int64_t row = tile * PBS_TILE + myrow;
-            if (lh == 0 && row < rows) { xmask[row] = xbits; hmask[row] = hbits; }
+            if (lh == 0 && row < rows && xmask) { xmask[row] = xbits; hmask[row] = hbits; }
         }
         __syncthreads();                                                      // the two output tiles are staged
 #pragma unroll
@@ -296,8 +297,13 @@ __global__ __launch_bounds__(PBS_THREADS, 2) void pfn_block_split_fwd_kernel(con
             *reinterpret_cast<float4 *>(out + row * 32 + (c & 7) * 4) = o;
             omax = fmaxf(fmaxf(omax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
             if (!(o.x == o.x && o.y == o.y && o.z == o.z && o.w == o.w)) omax = __builtin_inff();
-            if (hr) *reinterpret_cast<float4 *>(hr + row * 32 + (c & 7) * 4) =
-                        *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(hs) + (c >> 3) * OS + (c & 7) * 4);
+            if (out16)                                                        // 'mixed' mode: the bf16 shadows the bf16 backward kernel reads
+                *reinterpret_cast<uint2 *>(out16 + row * 32 + (c & 7) * 4) = make_uint2(pcacc_pack_bf16x2(o.x, o.y), pcacc_pack_bf16x2(o.z, o.w));
+            if (hr || hr16) {
+                const float4 hq = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(hs) + (c >> 3) * OS + (c & 7) * 4);
+                if (hr) *reinterpret_cast<float4 *>(hr + row * 32 + (c & 7) * 4) = hq;
+                if (hr16) *reinterpret_cast<uint2 *>(hr16 + row * 32 + (c & 7) * 4) = make_uint2(pcacc_pack_bf16x2(hq.x, hq.y), pcacc_pack_bf16x2(hq.z, hq.w));
+            }
         }
     }
     omax = pbs_wave_max(omax);
@@ -495,14 +501,14 @@ static constexpr size_t PBS_FWD_LDS = (size_t)(2 * PBS_TILE * 72 + 2 * PBS_TILE 
 static constexpr size_t PBS_DG_LDS = (size_t)(4 * PBS_TILE * 40 + 2 * 32 * 40 + 4 * 64 * 40) * 2 + 16;
 
 // out [rows,32], relu_h [rows,32] f32; xmask [rows] u64 / hmask [rows] u32: x > 0 / h > 0 per channel; out_amax / hr_amax: 256 zeroed slots each
-extern "C" int pcacc_pfn_block_split_forward(const float *xa, const float *xa_amax, const float *pooled, const float *pooled_amax, const int32_t *p2v,
-                                             const float *w0, const float *b0, const float *ws, const float *w1, const float *b1, float *out,
-                                             float *relu_h, uint64_t *xmask, uint32_t *hmask, float *out_amax, float *hr_amax, int64_t rows,
-                                             void *stream)
+static int pfn_block_split_forward_impl(const float *xa, const float *xa_amax, const float *pooled, const float *pooled_amax, const int32_t *p2v,
+                                        const float *w0, const float *b0, const float *ws, const float *w1, const float *b1, float *out,
+                                        float *relu_h, uint64_t *xmask, uint32_t *hmask, float *out_amax, float *hr_amax, int64_t rows,
+                                        uint16_t *out16, uint16_t *hr16, void *stream)
 {
     if (rows < 0 || (pooled && (!p2v || !pooled_amax))) return PCACC_E_ARG;
     if (rows == 0) return PCACC_OK;
-    if (!xa || !xa_amax || !w0 || !ws || !w1 || !out || !relu_h || !xmask || !hmask) return PCACC_E_ARG;
+    if (!xa || !xa_amax || !w0 || !ws || !w1 || !out || (!out16 && (!relu_h || !xmask || !hmask)) || (xmask && !hmask)) return PCACC_E_ARG;
     hipStream_t st = pcacc_stream(stream);
     const int grid = pbs_grid(rows, 2);
     const PbsPieces xp{pooled, p2v};
@@ -510,15 +516,35 @@ extern "C" int pcacc_pfn_block_split_forward(const float *xa, const float *xa_am
         auto kern = pfn_block_split_fwd_kernel<true>;
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PBS_FWD_LDS) != hipSuccess) return PCACC_E_LAUNCH;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(PBS_THREADS), PBS_FWD_LDS, st, xa, xp, xa_amax, pooled_amax, w0, b0, ws, w1, b1, out, relu_h, xmask, hmask,
-                           out_amax, hr_amax, rows);
+                           out_amax, hr_amax, rows, out16, hr16);
     } else {
         auto kern = pfn_block_split_fwd_kernel<false>;
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PBS_FWD_LDS) != hipSuccess) return PCACC_E_LAUNCH;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(PBS_THREADS), PBS_FWD_LDS, st, xa, xp, xa_amax, nullptr, w0, b0, ws, w1, b1, out, relu_h, xmask, hmask,
-                           out_amax, hr_amax, rows);
+                           out_amax, hr_amax, rows, out16, hr16);
     }
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
+}
+
+extern "C" int pcacc_pfn_block_split_forward(const float *xa, const float *xa_amax, const float *pooled, const float *pooled_amax, const int32_t *p2v,
+                                             const float *w0, const float *b0, const float *ws, const float *w1, const float *b1, float *out,
+                                             float *relu_h, uint64_t *xmask, uint32_t *hmask, float *out_amax, float *hr_amax, int64_t rows,
+                                             void *stream)
+{
+    return pfn_block_split_forward_impl(xa, xa_amax, pooled, pooled_amax, p2v, w0, b0, ws, w1, b1, out, relu_h, xmask, hmask, out_amax, hr_amax, rows,
+                                        nullptr, nullptr, stream);
+}
+
+// 'mixed' compute mode: the fp32 result plus what the bf16 backward kernel (pcacc_pfn_block_backward) reads -- out16 = bf16(out), hr16 = bf16(relu(h)) --
+// from the same epilogue; no fp32 relu(h), no sign masks (the fp32x3 data-gradient kernel's inputs)
+extern "C" int pcacc_pfn_block_split_forward_dual(const float *xa, const float *xa_amax, const float *pooled, const float *pooled_amax, const int32_t *p2v,
+                                                  const float *w0, const float *b0, const float *ws, const float *w1, const float *b1, float *out,
+                                                  uint16_t *out16, uint16_t *hr16, float *out_amax, int64_t rows, void *stream)
+{
+    if (!out16 || !hr16) return PCACC_E_ARG;
+    return pfn_block_split_forward_impl(xa, xa_amax, pooled, pooled_amax, p2v, w0, b0, ws, w1, b1, out, nullptr, nullptr, nullptr, out_amax, nullptr, rows,
+                                        out16, hr16, stream);
 }
 
 // grad_xa [rows,64] (grad_xb NULL) or grad_xa [rows,32] + grad_xb [rows,32]; grad_h [rows,32]: d(h), the operand of fc_0's weight gradient

@@ -385,7 +385,7 @@ class MotionNet(nn.Module):
         mh = self.motionhead
         ungridded = ops.bilinear_gather(stpn_map, points, batch_idx, abs(self.pc_range[0]), abs(self.pc_range[1]))
         pos = mh.point_mlp(mh.positional_encoding, points / abs(self.pc_range[0]))          # rows in ops.point_dtype()
-        enc = mh.point_mlp(mh.final_proj, torch.cat([pos, ungridded.to(pos.dtype)], dim=-1))
+        enc = mh.point_mlp(mh.final_proj, ops.cat_rows(pos, ungridded))
         classes = mh.point_head(mh.mos_seg, enc)
         offset = mh.safe_guard_offset(mh.point_head(mh.offset_head, enc))
         return classes, offset, stpn_map

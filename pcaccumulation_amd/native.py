@@ -39,7 +39,7 @@ def lib():
 
 # every symbol include/pcacc.h declares (tests check the .so exports exactly these)
 EXPORTS = [
-    'pcacc_reload_switches', 'pcacc_pool_skip_relu_backward_strided_y32', 'pcacc_conv3x3_split_dual', 'pcacc_upconv2x2_split_dual', 'pcacc_voxelize_workspace_bytes', 'pcacc_voxelize', 'pcacc_cell_index',
+    'pcacc_reload_switches', 'pcacc_pfn_block_split_forward_dual', 'pcacc_pool_skip_relu_backward_strided_y32', 'pcacc_conv3x3_split_dual', 'pcacc_upconv2x2_split_dual', 'pcacc_voxelize_workspace_bytes', 'pcacc_voxelize', 'pcacc_cell_index',
     'pcacc_frame_pillars_workspace_bytes', 'pcacc_frame_pillars',
     'pcacc_csr_workspace_bytes', 'pcacc_csr_build', 'pcacc_segment_mean3_maxlabel',
     'pcacc_segment_workspace_bytes', 'pcacc_segment_max', 'pcacc_segment_max_backward', 'pcacc_segment_sum', 'pcacc_scatter_sum_small',
@@ -1397,6 +1397,21 @@ def pfn_block_split_forward(xa, xa_amax, pooled, pooled_amax, p2v, w0, b0, ws, w
                                                _dev(w1, torch.float32, 'w1'), _opt(b1, torch.float32, 'b1'), _dev(out), _dev(hr), _dev(xmask),
                                                _dev(hmask), _dev(out_amax), _dev(hr_amax), _i64(rows), _stream()), 'pfn_block_split_forward')
     return out, hr, xmask, hmask, out_amax, hr_amax
+
+
+def pfn_block_split_forward_dual(xa, xa_amax, pooled, pooled_amax, p2v, w0, b0, ws, w1, b1):
+    """'mixed' mode: -> (out [rows,32] f32, its absmax256 array, out as bf16, relu(h) [rows,32] bf16) from one kernel."""
+    rows, dev = xa.shape[0], xa.device
+    out = torch.empty((rows, 32), dtype=torch.float32, device=dev)
+    out16 = torch.empty((rows, 32), dtype=torch.bfloat16, device=dev)
+    hr16 = torch.empty((rows, 32), dtype=torch.bfloat16, device=dev)
+    out_amax = _zero256(dev)
+    _check(lib().pcacc_pfn_block_split_forward_dual(_dev(xa, torch.float32, 'xa'), _dev(xa_amax, torch.float32, 'xa_amax'), _opt(pooled, torch.float32, 'pooled'),
+                                                    _opt(pooled_amax, torch.float32, 'pooled_amax'), _opt(p2v, torch.int32, 'p2v'),
+                                                    _dev(w0, torch.float32, 'w0'), _opt(b0, torch.float32, 'b0'), _dev(ws, torch.float32, 'ws'),
+                                                    _dev(w1, torch.float32, 'w1'), _opt(b1, torch.float32, 'b1'), _dev(out), _dev(out16), _dev(hr16),
+                                                    _dev(out_amax), _i64(rows), _stream()), 'pfn_block_split_forward_dual')
+    return out, out_amax, out16, hr16
 
 
 def pfn_block_split_dgrad(grad_out, grad_out_amax, xmask, hmask, w0, ws, w1, two_pieces):

@@ -327,6 +327,8 @@ def scatter(src, index, dim=0, dim_size=None, reduce='sum', plan=None):
     elif reduce == 'max' and x.dtype == torch.bfloat16:
         xp, c = _pad4(x)                                                              # bf16 rows go in as they are (max is exact)
         out = _SegmentMax.apply(xp, plan)[0]
+        if _MIXED and twin(out, required=False) is not None:                          # shadow rows: the pooled rows leave the bf16 graph as their fp32 twin
+            out = exit_mixed(out)
     else:
         x32, c = _pad4(x.to(torch.float32))
         out = _SegmentMax.apply(x32, plan)[0] if reduce == 'max' else _SegmentSum.apply(x32, plan)
@@ -596,14 +598,15 @@ class _PfnBlockMixed(_PfnBlock):
         else:
             pooled32 = p_amax = None
         w0, ws, w1 = w0.contiguous(), ws.contiguous(), w1.contiguous()
-        out32, hr32, _xm, _hm, out_amax, _hr_amax = native.pfn_block_split_forward(xa32, a_amax, pooled32, p_amax, pidx.p2v if pooled32 is not None else None,
-                                                                                   w0, b0, ws, w1, b1)
+        out32, out_amax, out16, hr = native.pfn_block_split_forward_dual(xa32, a_amax, pooled32, p_amax, pidx.p2v if pooled32 is not None else None,
+                                                                         w0, b0, ws, w1, b1)     # shadows of out and relu(h) from the same epilogue
         set_amax_tag(out32, out_amax)
-        hr = hr32.to(torch.bfloat16) if not _POISON else torch.full_like(hr32, float('nan'), dtype=torch.bfloat16)
+        if _POISON:
+            hr.fill_(float('nan'))
         ctx.pidx = pidx
         ctx.save_for_backward(xa, pooled, hr, w0, ws, w1, arg)
         ctx.has_bias = (b0 is not None, b1 is not None)
-        return shadow(out32)
+        return shadow(out32, out16)
 
 
 def pfn_block_available(block, x, pooled=None):
@@ -757,6 +760,14 @@ class _ExitMixed(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return g.to(torch.bfloat16)
+
+
+def cat_rows(a, b):
+    """cat([a, b in a's element type], dim=-1) for point rows; in the 'mixed' mode (a = bf16 shadow, b = fp32 rows) b enters the shadow graph
+    and the twins are concatenated too (models/stpn.py:96-97: positional code | gathered map features)."""
+    if _MIXED and a.dtype == torch.bfloat16 and twin(a, required=False) is not None:
+        return cat_maps((a, enter_mixed(b.contiguous()) if b.dtype == torch.float32 else b), dim=-1)
+    return torch.cat([a, b.to(a.dtype)], dim=-1)
 
 
 class _OnTwin(torch.autograd.Function):

@@ -5,6 +5,9 @@ Produces exactly the input_dict layout the reference's collate_fn produces (same
 see SURVEY.md 8b) so the model boundary does not change; only the voxeliser runs in the HIP kernel instead
 of numba on a DataLoader worker.
 """
+import os
+import time
+
 import torch
 
 from . import native
@@ -16,6 +19,16 @@ def sample_to_device(sample, device):
     # everything, including the per-instance motion table (the reference's collate keeps that one as a host list and every
     # consumer moves it with .to(device), models/alignnet.py:22, libs/loss.py:222: a blocking copy per sample per step)
     return {k: torch.from_numpy(v).to(device) for k, v in sample.items()}
+
+
+def _host_wait(event):
+    """Wait on the host for `event` (the voxel counts have reached pinned memory).  PCACC_PREFETCH_WAIT=poll: query the event in a sleep loop
+    instead of blocking inside the runtime's event wait (experiment for the two-ranks-on-one-GPU collapse of DESIGN.md section 6)."""
+    if os.environ.get('PCACC_PREFETCH_WAIT') == 'poll':
+        while not event.query():
+            time.sleep(20e-6)
+        return
+    event.synchronize()
 
 
 class _Pending(object):
@@ -98,7 +111,7 @@ class DeviceBatcher(object):
         arrived by then); finish() then only joins the streams."""
         if p.event is None or p.result is not None:
             return
-        p.event.synchronize()
+        _host_wait(p.event)
         with torch.cuda.stream(p.stream):
             out = self._collate(p, p.counts.tolist())
             if prepare is not None:
@@ -116,7 +129,7 @@ class DeviceBatcher(object):
             share_with_stream(main, p.result, [x for l in p.launched for x in l[:2]])     # allocated there, consumed here
             return p.result
         if p.event is not None:
-            p.event.synchronize()                                        # long past when the batch was started a step ago
+            _host_wait(p.event)                                          # long past when the batch was started a step ago
             main = torch.cuda.current_stream(dev)
             main.wait_event(p.event)
             for t in [x for l in p.launched for x in l[:2]] + list(p.static.values()):

@@ -91,9 +91,11 @@ class STPN(nn.Module):
         mods = list(seq)
         i = 0
         pd = ops.point_dtype() if x.is_cuda else x.dtype          # bf16 rows in the bf16 compute mode (GPU only)
+        # 'mixed' mode: an fp32 input without a shadow (the 3-feature positions) starts a chain of bf16 shadows of fp32 rows
+        head = ops.mixed_mode() and x.is_cuda and x.dtype == torch.float32 and x.shape[0] >= ops.MIN_ROWS_FUSED_LINEAR
         while i < len(mods):
             relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
-            x = ops.linear_rows(x, mods[i], post_relu=relu, out_dtype=pd)
+            x = ops.linear_rows(x, mods[i], post_relu=relu, out_dtype=pd, mixed=head and i == 0)
             i += 2 if relu else 1
         return x
 
@@ -102,6 +104,7 @@ class STPN(nn.Module):
         """SegHead1D = Linear, BatchNorm1d, ReLU, Linear (models/unet.py:240-245): the two Linear layers are fused row
         kernels, BatchNorm1d (batch statistics over the K points in train mode, trap 16) four streaming passes (ops.batch_norm_rows)."""
         lin0, bn, _, lin1 = head.seg_head
+        x = ops.exit_mixed(x)             # 'mixed' mode: from the losses back to (and including) the layer in front of a BatchNorm everything is fp32 (unet.UNet.forward)
         return ops.linear_rows(ops.batch_norm_rows(ops.linear_rows(x, lin0), bn), lin1, pre_relu=True, out_dtype=torch.float32)
 
     def forward(self, x, points, time_indice, pc_range):
@@ -110,7 +113,7 @@ class STPN(nn.Module):
         batch_idx = time_indice[:, 0].to(torch.int32).contiguous()
         ungridded = ops.bilinear_gather(x, points, batch_idx, abs(pc_range[0]), abs(pc_range[1]))
         pos = self.point_mlp(self.positional_encoding, points / abs(pc_range[0]))
-        enc = self.point_mlp(self.final_proj, torch.cat([pos, ungridded.to(pos.dtype)], dim=-1))
+        enc = self.point_mlp(self.final_proj, ops.cat_rows(pos, ungridded))
         classes = self.point_head(self.mos_seg, enc)
         offset = self.safe_guard_offset(self.point_head(self.offset_head, enc))
         return classes, offset, x

@@ -9,6 +9,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .chamfer_distance import ChamferDistance
+from . import ops
 from .ops import scatter, ScatterPlan, linear_rows, transform_by_index, point_dtype, tube_rows, tube_code, tube_pose
 
 _EPS = 1e-20
@@ -188,9 +189,17 @@ def _embed(seq, x):
     pd = point_dtype() if x.is_cuda else x.dtype                  # bf16 rows in the bf16 compute mode (GPU only)
     if pd != x.dtype and mods[0].in_features >= 32:
         x = x.to(pd)                                               # wide first layer: take the matrix-core path from the start
+    # 'mixed' mode: the chain runs as bf16 shadows of fp32 rows (fp32x3 forward, bf16 backward): a wide fp32 input enters the shadow graph,
+    # a narrow one (the 4-feature positional rows, no gradient) is taken as it is by the first layer
+    head = False
+    if ops.mixed_mode() and x.is_cuda and x.dtype == torch.float32 and x.shape[0] >= ops.MIN_ROWS_FUSED_LINEAR:
+        if mods[0].in_features >= 32:
+            x = ops.enter_mixed(x.contiguous())
+        else:
+            head = True
     while i < len(mods):
         relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
-        x = linear_rows(x, mods[i], post_relu=relu, out_dtype=pd)
+        x = linear_rows(x, mods[i], post_relu=relu, out_dtype=pd, mixed=head and i == 0)
         i += 2 if relu else 1
     return x
 

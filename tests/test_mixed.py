@@ -162,3 +162,23 @@ def test_split_kernels_second_output_is_the_rounded_first(n, t, h, w, ci, co, kt
         u, ua = native.upconv2x2_split(x, am, uf, bias, 0)
         u2, ua2, u16 = native.upconv2x2_split(x, am, uf, bias, 0, want_bf16=True)
         assert torch.equal(u, u2) and torch.equal(u16, u.to(torch.bfloat16))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('pooled', [False, True])
+def test_pfn_block_second_outputs_are_the_rounded_first(pooled):
+    """pcacc_pfn_block_split_forward_dual: out16 / hr16 == bf16 of the plain entry's out / relu(h); out itself unchanged."""
+    from pcaccumulation_amd import native
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device='cpu').manual_seed(5)
+    rows, m = 70000, 9000
+    xa = torch.randn(rows, 32 if pooled else 64, generator=g).to(dev)
+    pl = torch.randn(m, 32, generator=g).to(dev) if pooled else None
+    p2v = torch.randint(0, m, (rows,), generator=g).to(dev).to(torch.int32) if pooled else None
+    w0, ws, w1 = (torch.randn(32, 64, generator=g) / 8).to(dev), (torch.randn(32, 64, generator=g) / 8).to(dev), (torch.randn(32, 32, generator=g) / 6).to(dev)
+    b0, b1 = torch.randn(32, generator=g).to(dev), torch.randn(32, generator=g).to(dev)
+    am, pm = native.absmax256(xa), (native.absmax256(pl) if pooled else None)
+    out, hr, _, _, oa, _ = native.pfn_block_split_forward(xa, am, pl, pm, p2v, w0, b0, ws, w1, b1)
+    out2, oa2, out16, hr16 = native.pfn_block_split_forward_dual(xa, am, pl, pm, p2v, w0, b0, ws, w1, b1)
+    assert torch.equal(out, out2) and torch.equal(oa, oa2)
+    assert torch.equal(out16, out.to(torch.bfloat16)) and torch.equal(hr16, hr.to(torch.bfloat16))

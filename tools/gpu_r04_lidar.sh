@@ -4,7 +4,7 @@
 mkdir -p gpurun_out
 for i in 1 2; do
 for p in uniform lidar; do
-  ms=$(timeout 900 python bench.py --dtype fp32x3 --points $p --no-cpu-baseline --no-fp32-leg --no-step-model 2>gpurun_out/err_$p.txt | tail -1 | python3 -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])" 2>/dev/null)
+  ms=$(timeout 900 python bench.py --dtype fp32x3 --points $p --no-cpu-baseline --no-configs --no-fp32-leg --no-step-model 2>gpurun_out/err_$p.txt | tail -1 | python3 -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])" 2>/dev/null)
   echo "fp32x3 $p $ms"
 done
 done
@@ -13,6 +13,6 @@ for p in uniform lidar; do
   head -30 gpurun_out/r04_native_call_table_fp32x3_$p.txt | cut -c1-200
 done
 cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_x3_lidar -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --dtype fp32x3 --points lidar --steps 5 --warmup 3 --no-cpu-baseline --no-fp32-leg --no-step-model --one-stream > $GRAFT_REPO_ROOT/gpurun_out/rocprof_x3_lidar.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_x3_lidar -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --dtype fp32x3 --points lidar --steps 5 --warmup 3 --no-cpu-baseline --no-configs --no-fp32-leg --no-step-model --one-stream > $GRAFT_REPO_ROOT/gpurun_out/rocprof_x3_lidar.log 2>&1
 cd $GRAFT_REPO_ROOT
 python3 tools/kstats_steady.py gpurun_out/prof_x3_lidar/bench_kernel_trace.csv 4 200 > gpurun_out/r04_fp32x3_lidar_steady.txt; head -40 gpurun_out/r04_fp32x3_lidar_steady.txt | cut -c1-200

@@ -3,7 +3,7 @@
 # and the per-stage GPU times of the bf16 and fp32x3 steps (forward stages / loss / backward)
 mkdir -p gpurun_out
 for i in 1 2; do
-  timeout 900 python bench.py --points lidar --no-cpu-baseline > gpurun_out/r04_bench_lidar_$i.json 2> gpurun_out/err_lidar_$i.txt
+  timeout 900 python bench.py --points lidar --no-cpu-baseline --no-configs > gpurun_out/r04_bench_lidar_$i.json 2> gpurun_out/err_lidar_$i.txt
   python3 -c "
 import json,sys
 d=json.loads(open('gpurun_out/r04_bench_lidar_$i.json').read().strip().splitlines()[-1])

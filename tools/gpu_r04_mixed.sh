@@ -7,7 +7,7 @@ PCACC_TRAJ_VERBOSE=1 timeout 1500 python -m pytest tests/test_train_trajectory.p
 if [ "$1" != "nobench" ]; then
 for i in 1 2; do
 for d in mixed fp32x3; do
-  ms=$(timeout 900 python bench.py --dtype $d --no-cpu-baseline --no-fp32-leg --no-step-model 2>gpurun_out/err_$d.txt | tail -1 | python3 -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])" 2>/dev/null)
+  ms=$(timeout 900 python bench.py --dtype $d --no-cpu-baseline --no-configs --no-fp32-leg --no-step-model 2>gpurun_out/err_$d.txt | tail -1 | python3 -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])" 2>/dev/null)
   echo "$d $ms"
 done
 done

@@ -6,8 +6,8 @@
 set -e
 mkdir -p gpurun_out
 rm -rf .miopen_cache
-timeout 1500 python bench.py --steps 3 --warmup 4 --no-cpu-baseline --no-fp32-leg --no-step-model > /dev/null
-timeout 1500 python bench.py --steps 3 --warmup 4 --no-cpu-baseline --no-fp32-leg --no-step-model --points lidar > /dev/null
+timeout 1500 python bench.py --steps 3 --warmup 4 --no-cpu-baseline --no-configs --no-fp32-leg --no-step-model > /dev/null
+timeout 1500 python bench.py --steps 3 --warmup 4 --no-cpu-baseline --no-configs --no-fp32-leg --no-step-model --points lidar > /dev/null
 timeout 1500 python -m pytest tests/test_config_parity.py -q -m gpu -k "fp32-" > /dev/null || true     # the fp32 parity mode's library convolutions
 tar czf gpurun_out/miopen_cache.tgz .miopen_cache
 ls -la .miopen_cache
