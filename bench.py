@@ -337,6 +337,11 @@ def main():
     # cuda:0); the driver's multi-GPU runs use the default: nccl = RCCL over xGMI, one rank per GPU.
     backend = os.environ.get('PCACC_DIST_BACKEND') or None
     n_dev = max(torch.cuda.device_count(), 1)
+    if int(os.environ.get('LOCAL_WORLD_SIZE', '1') or 1) > n_dev and 'GPU_MAX_HW_QUEUES' not in os.environ:
+        # ranks SHARING a device (the gloo test configuration of a one-GPU box): two hardware queues per process keep every queue of every rank
+        # resident on the device -- with the default four the staged two-stream step collapses (388 ms instead of 62.5 ms per step for two ranks,
+        # DESIGN.md section 6).  Read by the HIP runtime when it initialises, i.e. after this line.
+        os.environ['GPU_MAX_HW_QUEUES'] = '2'
     if backend is None and int(os.environ.get('WORLD_SIZE', '1')) > n_dev:
         raise SystemExit('WORLD_SIZE exceeds the %d visible GPU(s); set PCACC_DIST_BACKEND=gloo to share devices' % n_dev)
     torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % n_dev)

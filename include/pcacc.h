@@ -510,6 +510,10 @@ int pcacc_head_conv3x3_wgrad(const float *dy, const void *x, int32_t x_dtype, fl
 int pcacc_rows_linear_split(const float *x, const float *x_amax, const float *in_mask, const float *w, const float *bias,
                             const float *residual, const float *out_mask, float *y, float *y_amax, int64_t rows, int32_t k, int32_t n,
                             int32_t flags, void *stream);
+/* 'mixed' compute mode: pcacc_rows_linear_split with y16 [rows,n] = bf16(y) as a second output of the same epilogue (see pcacc_conv3x3_split_dual). */
+int pcacc_rows_linear_split_dual(const float *x, const float *x_amax, const float *in_mask, const float *w, const float *bias,
+                                 const float *residual, const float *out_mask, float *y, uint16_t *y16, float *y_amax, int64_t rows, int32_t k,
+                                 int32_t n, int32_t flags, void *stream);
 int pcacc_rows_linear_cat_split(const float *xa, const float *xa_amax, const float *xb, const float *xb_amax, const int32_t *b_index,
                                 int32_t ka, const float *in_mask, const float *w, const float *bias, const float *residual,
                                 const float *out_mask_a, const float *out_mask_b, float *y, float *y2, int32_t na, float *y_amax, int64_t rows,

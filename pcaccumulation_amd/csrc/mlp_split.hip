@@ -225,8 +225,10 @@ __global__ __launch_bounds__(MS_THREADS) void rows_linear_split_kernel(const flo
             if (out_mask) v = ms_mask4(v, *reinterpret_cast<const float4 *>(ms_piece(out_mask, ms2, N, row, col)));
             omax = fmaxf(fmaxf(omax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
             if (!(v.x == v.x && v.y == v.y && v.z == v.z && v.w == v.w)) omax = __builtin_inff();
-            if (!Y2) *reinterpret_cast<float4 *>(Y + e) = v;
-            else if (col < na) *reinterpret_cast<float4 *>(Y + row * na + col) = v;
+            if (!Y2 || na < 0) {                                              // na < 0: Y2 is the bf16 SHADOW of Y ('mixed' mode), same offsets
+                *reinterpret_cast<float4 *>(Y + e) = v;
+                if (Y2) *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(Y2) + e) = make_uint2(pcacc_pack_bf16x2(v.x, v.y), pcacc_pack_bf16x2(v.z, v.w));
+            } else if (col < na) *reinterpret_cast<float4 *>(Y + row * na + col) = v;
             else *reinterpret_cast<float4 *>(Y2 + row * (N - na) + (col - na)) = v;
         }
     }
@@ -381,8 +383,10 @@ __global__ __launch_bounds__(MS_THREADS, 2) void rows_linear_split_fm_kernel(con
             if (out_mask) v = ms_mask4(v, *reinterpret_cast<const float4 *>(ms_piece(out_mask, ms2, N, row, col)));
             omax = fmaxf(fmaxf(omax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
             if (!(v.x == v.x && v.y == v.y && v.z == v.z && v.w == v.w)) omax = __builtin_inff();
-            if (!Y2) *reinterpret_cast<float4 *>(Y + e) = v;
-            else if (col < na) *reinterpret_cast<float4 *>(Y + row * na + col) = v;
+            if (!Y2 || na < 0) {                                              // na < 0: Y2 is the bf16 SHADOW of Y ('mixed' mode), same offsets
+                *reinterpret_cast<float4 *>(Y + e) = v;
+                if (Y2) *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(Y2) + e) = make_uint2(pcacc_pack_bf16x2(v.x, v.y), pcacc_pack_bf16x2(v.z, v.w));
+            } else if (col < na) *reinterpret_cast<float4 *>(Y + row * na + col) = v;
             else *reinterpret_cast<float4 *>(Y2 + row * (N - na) + (col - na)) = v;
         }
     }
@@ -469,6 +473,19 @@ extern "C" int pcacc_rows_linear_split(const float *x, const float *x_amax, cons
     if (!x || !x_amax || !w || !y) return PCACC_E_ARG;
     const MsPieces none{nullptr, nullptr, 0};
     return ms_dispatch(x, x_amax, nullptr, in_mask, w, bias, residual, out_mask, y, rows, k, n, flags, pcacc_stream(stream), none, none, nullptr, 0, y_amax);
+}
+
+// 'mixed' compute mode: the same layer with y16 = bf16(y) [rows,n] as a second output of the same epilogue (the shadow the bf16 backward reads)
+extern "C" int pcacc_rows_linear_split_dual(const float *x, const float *x_amax, const float *in_mask, const float *w, const float *bias,
+                                            const float *residual, const float *out_mask, float *y, uint16_t *y16, float *y_amax, int64_t rows,
+                                            int32_t k, int32_t n, int32_t flags, void *stream)
+{
+    if (rows < 0 || (k != 32 && k != 64 && k != 128) || (n != 32 && n != 64 && n != 128)) return PCACC_E_ARG;
+    if (rows == 0) return PCACC_OK;
+    if (!x || !x_amax || !w || !y || !y16) return PCACC_E_ARG;
+    const MsPieces none{nullptr, nullptr, 0};
+    return ms_dispatch(x, x_amax, nullptr, in_mask, w, bias, residual, out_mask, y, rows, k, n, flags, pcacc_stream(stream), none, none,
+                       reinterpret_cast<float *>(y16), -1, y_amax);
 }
 
 // The same layer on rows made of two pieces (see MsPieces; the fp32 twin of pcacc_rows_linear_cat_bf16).  Forward: x = cat(xa [rows,ka],

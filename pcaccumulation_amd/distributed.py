@@ -54,6 +54,16 @@ def world_size():
     return dist.get_world_size() if dist.is_initialized() else 1
 
 
+def ranks_share_a_device():
+    """True when this node runs more ranks than it has GPUs (torch.distributed.run exports LOCAL_WORLD_SIZE): the test configuration of a
+    one-GPU box, never the production layout."""
+    try:
+        local = int(os.environ.get('LOCAL_WORLD_SIZE', '1'))
+    except ValueError:
+        local = 1
+    return torch.cuda.is_available() and local > max(torch.cuda.device_count(), 1)
+
+
 def _reachable_parameters(loss):
     """ids of the leaf tensors whose AccumulateGrad node is reachable from `loss` (what this backward can write)."""
     seen, found, stack = set(), set(), [loss.grad_fn]
@@ -311,28 +321,34 @@ class DataParallelStep(object):
         self.model, self.optimizer, self.loss_fn = model, optimizer, loss_fn
         # pipelined: back-propagate the loss terms of the lower half of the model (pillar encoder, U-Net, heads, ego head) as soon as
         # the ego head has run, before the motion heads and the TubeNet are even issued (MotionNet.after_ego, FuseLoss.early_terms);
-        # default: whenever model and loss offer the two hooks
-        can = hasattr(model, 'after_ego') and hasattr(loss_fn, 'early_terms')
-        # default: staged only where it can use the second stream (one process, see below).  On ONE stream the staged step no longer
-        # pays: 30.4 ms against 30.0 ms unstaged at N = 1 (4 interleaved runs each, sd 0.3), 92 ms against 76 ms with two gloo ranks on
-        # one GPU -- it won 1.9 ms only while ~800 tiny launches behind the forward's host sync left the GPU idle.
-        self.pipelined = (can and world_size() == 1) if pipelined is None else (bool(pipelined) and can)
         # two_streams: the rest of the forward, its loss terms and their backward run on a side stream while the early backward
-        # occupies the main one (MotionNet.side_stream); joined before the clip / optimizer block
+        # occupies the main one (MotionNet.side_stream); joined before the clip / optimizer block.  The staged step pays only WITH the
+        # second stream (N = 1: 30.4 ms staged on one stream against 30.0 ms unstaged, 28.9 ms with the second stream).
+        can = hasattr(model, 'after_ego') and hasattr(loss_fn, 'early_terms')
         self._two_streams = bool(two_streams)
         self.iter_size, self.grad_clip, self.check_finite, self.catch = int(iter_size), grad_clip, check_finite, catch
         self.reducer = reducer if reducer is not None else BucketedGradReducer(model.parameters())
+        dev = self.reducer.params[0].device
+        # With a process group the second stream is used whenever every rank owns its GPU -- the production layout, one process per device.
+        # Ranks SHARING a device (the gloo test configuration of a one-GPU box) oversubscribe the device's hardware queues: each process maps
+        # its streams (main, side, batch prefetch, the backend's copy streams) onto GPU_MAX_HW_QUEUES hardware queues (default 4), two processes
+        # then hold more queues than the device runs at once, the scheduler rotates them, and a stream waiting on an event of a queue that is
+        # currently rotated out stalls for whole time slices.  Measured with two gloo ranks on one MI355X (tools/gpu_r04_2rank.sh, bf16, 2 x 4
+        # sequences): 65.8 ms plain one-stream step; staged + second stream + prefetch stream 388 ms at the default 4 queues per process,
+        # 2 555 ms at 8, 62.5 ms at 2 (all queues of both processes resident: the best of all); 66.0 ms without the prefetch stream;
+        # polling the prefetch event instead of blocking in the runtime changed nothing (304 ms) -- it is not the host wait.  So: ranks that
+        # share a device get the second stream only with GPU_MAX_HW_QUEUES <= 2 (bench.py sets it for such launches), else the plain step.
+        shared = ranks_share_a_device()
+        queues_ok = int(os.environ.get('GPU_MAX_HW_QUEUES', '4') or 4) <= 2
+        allow = world_size() == 1 or not shared or queues_ok or os.environ.get('PCACC_TWO_STREAMS_DIST') == '1'
+        if os.environ.get('PCACC_TWO_STREAMS_DIST') == '0':
+            allow = world_size() == 1
+        want_side = self._two_streams and dev.type == 'cuda' and allow and hasattr(model, 'side_stream')
+        # default: staged exactly where the second stream is available -- N > 1 then runs the step N = 1 runs
+        self.pipelined = (can and (want_side or world_size() == 1)) if pipelined is None else (bool(pipelined) and can)
         if self.pipelined and hasattr(model, 'early_parameters'):
             self.reducer.set_early(model.early_parameters())
-        dev = self.reducer.params[0].device
-        # Second stream only without a process group.  With N > 1 the collectives draw further streams from the pool, HIP folds all of
-        # them onto a few hardware queues, and together with a data pipeline that host-waits on its own prefetch stream the step
-        # collapsed: two gloo ranks sharing one MI355X took 1.4-2.9 s per step (75 ms with the prefetch off, 94 ms with one stream;
-        # 70 ms / 418 ms with GPU_MAX_HW_QUEUES = 2 / 16 -- the dependence on the queue count is measured, the exact mechanism is not,
-        # and RCCL could not be tried with two ranks on one GPU).  One stream is the safe choice there.
-        allow = world_size() == 1 or os.environ.get('PCACC_TWO_STREAMS_DIST') == '1'      # opt-in with a process group (see above)
-        self.side = torch.cuda.Stream(device=dev) if (self.pipelined and self._two_streams and dev.type == 'cuda' and allow
-                                                      and hasattr(model, 'side_stream')) else None
+        self.side = torch.cuda.Stream(device=dev) if (self.pipelined and want_side) else None
         # the optimizer's step invalidates the prepared (packed / split) convolution weights (fused optimizers do not bump version counters)
         if hasattr(model, 'watch_optimizer'):
             model.watch_optimizer(optimizer)

@@ -300,7 +300,7 @@ class MotionNet(nn.Module):
             nonlocal bev_feats, rec_mask, n_rec
             # 5. motion segmentation on ego-motion-compensated features
             pose_est = results['ego_motion_est'].float().detach()
-            bev_feats = bev_feats.detach()
+            bev_feats = ops.carry_amax(bev_feats, bev_feats.detach())            # (the scale bound travels with the detached alias)
             C = bev_feats.size(1)
             bev_cl = bev_feats.permute(0, 2, 3, 1).contiguous().view(B, T, Ny, Nx, C)
             warped = ops.bev_warp(ops.twin_or_self(bev_cl), native.inv4x4(pose_est), self.resolution[0], self.resolution[1],

@@ -39,7 +39,7 @@ def lib():
 
 # every symbol include/pcacc.h declares (tests check the .so exports exactly these)
 EXPORTS = [
-    'pcacc_reload_switches', 'pcacc_pfn_block_split_forward_dual', 'pcacc_pool_skip_relu_backward_strided_y32', 'pcacc_conv3x3_split_dual', 'pcacc_upconv2x2_split_dual', 'pcacc_voxelize_workspace_bytes', 'pcacc_voxelize', 'pcacc_cell_index',
+    'pcacc_reload_switches', 'pcacc_rows_linear_split_dual', 'pcacc_pfn_block_split_forward_dual', 'pcacc_pool_skip_relu_backward_strided_y32', 'pcacc_conv3x3_split_dual', 'pcacc_upconv2x2_split_dual', 'pcacc_voxelize_workspace_bytes', 'pcacc_voxelize', 'pcacc_cell_index',
     'pcacc_frame_pillars_workspace_bytes', 'pcacc_frame_pillars',
     'pcacc_csr_workspace_bytes', 'pcacc_csr_build', 'pcacc_segment_mean3_maxlabel',
     'pcacc_segment_workspace_bytes', 'pcacc_segment_max', 'pcacc_segment_max_backward', 'pcacc_segment_sum', 'pcacc_scatter_sum_small',
@@ -845,14 +845,23 @@ def rows_split_supported(k, n):
     return k in (32, 64, 128) and n in (32, 64, 128)
 
 
-def rows_linear_split(x, x_amax, w, bias=None, residual=None, pre_relu=False, post_relu=False, in_mask=None, out_mask=None, want_amax=False):
+def rows_linear_split(x, x_amax, w, bias=None, residual=None, pre_relu=False, post_relu=False, in_mask=None, out_mask=None, want_amax=False,
+                      want_bf16=False):
     """rows_linear on f32 rows at fp32 accuracy on the matrix cores; x_amax = absmax256(x) (of the tensor before ReLU / mask: an upper bound
-    is what the scale needs).  want_amax: -> (y, absmax256 array of y) from the kernel's store phase."""
+    is what the scale needs).  want_amax: -> (y, absmax256 array of y) from the kernel's store phase.  want_bf16 ('mixed' mode):
+    -> (y, y_amax, y as bf16 from the same epilogue)."""
     rows, k = x.shape
     n = w.shape[0]
     y = torch.empty((rows, n), dtype=torch.float32, device=x.device)
-    y_amax = _zero256(x.device) if want_amax else None
+    y_amax = _zero256(x.device) if want_amax or want_bf16 else None
     flags = (1 if pre_relu else 0) | (2 if post_relu else 0)
+    if want_bf16:
+        y16 = torch.empty((rows, n), dtype=torch.bfloat16, device=x.device)
+        _check(lib().pcacc_rows_linear_split_dual(_dev(x, torch.float32, 'x'), _dev(x_amax, torch.float32, 'x_amax'), _opt(in_mask, torch.float32, 'in_mask'),
+                                                  _dev(w, torch.float32, 'w'), _opt(bias, torch.float32, 'bias'), _opt(residual, torch.float32, 'residual'),
+                                                  _opt(out_mask, torch.float32, 'out_mask'), _dev(y), _dev(y16), _dev(y_amax), _i64(rows), int(k),
+                                                  int(n), flags, _stream()), 'rows_linear_split_dual')
+        return y, y_amax, y16
     _check(lib().pcacc_rows_linear_split(_dev(x, torch.float32, 'x'), _dev(x_amax, torch.float32, 'x_amax'), _opt(in_mask, torch.float32, 'in_mask'),
                                          _dev(w, torch.float32, 'w'), _opt(bias, torch.float32, 'bias'), _opt(residual, torch.float32, 'residual'),
                                          _opt(out_mask, torch.float32, 'out_mask'), _dev(y), _opt(y_amax, torch.float32, 'y_amax'), _i64(rows), int(k),

@@ -328,7 +328,7 @@ def scatter(src, index, dim=0, dim_size=None, reduce='sum', plan=None):
         xp, c = _pad4(x)                                                              # bf16 rows go in as they are (max is exact)
         out = _SegmentMax.apply(xp, plan)[0]
         if _MIXED and twin(out, required=False) is not None:                          # shadow rows: the pooled rows leave the bf16 graph as their fp32 twin
-            out = exit_mixed(out)
+            return exit_mixed(out)[:, :c].reshape((plan.m,) + shape_tail)             # (fp32: NOT rounded back to the shadow's element type)
     else:
         x32, c = _pad4(x.to(torch.float32))
         out = _SegmentMax.apply(x32, plan)[0] if reduce == 'max' else _SegmentSum.apply(x32, plan)
@@ -412,11 +412,12 @@ class _RowsLinearMixed(_RowsLinear):
         res32 = (twin(res) if res.dtype == torch.bfloat16 else res) if res is not None else None
         k, n = w.shape[1], w.shape[0]
         if native.rows_split_supported(k, n) and w.dtype == torch.float32:
-            y32, y_amax = native.rows_linear_split(x32, amax_of(x32), w, bias, res32, pre_relu, post_relu, want_amax=True)
+            y32, y_amax, y16 = native.rows_linear_split(x32, amax_of(x32), w, bias, res32, pre_relu, post_relu, want_bf16=True)   # shadow from the same epilogue
             set_amax_tag(y32, y_amax)
+            y = shadow(y32, y16)
         else:
             y32 = native.rows_linear(x32, w, bias, res32, pre_relu, post_relu, out_dtype=torch.float32)
-        y = shadow(y32)
+            y = shadow(y32)
         ctx.flags = (pre_relu, post_relu, bias is not None, residual is not None, res.dtype if res is not None else None, False)
         ctx.save_for_backward(x, w, y if post_relu else None, None)
         return y

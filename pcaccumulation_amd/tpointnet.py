@@ -192,13 +192,20 @@ def _embed(seq, x):
     # 'mixed' mode: the chain runs as bf16 shadows of fp32 rows (fp32x3 forward, bf16 backward): a wide fp32 input enters the shadow graph,
     # a narrow one (the 4-feature positional rows, no gradient) is taken as it is by the first layer
     head = False
-    if ops.mixed_mode() and x.is_cuda and x.dtype == torch.float32 and x.shape[0] >= ops.MIN_ROWS_FUSED_LINEAR:
+    n_lin = sum(isinstance(m, nn.Linear) for m in mods)
+    if ops.mixed_mode() and x.is_cuda and x.dtype == torch.float32 and x.shape[0] >= ops.MIN_ROWS_FUSED_LINEAR and n_lin > 1:
         if mods[0].in_features >= 32:
             x = ops.enter_mixed(x.contiguous())
         else:
             head = True
+    k = 0
     while i < len(mods):
         relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+        k += 1
+        if k == n_lin:
+            # the LAST layer leaves the bf16 graph: the pooled codes feed Linear -> BatchNorm1d (the regressor), whose backward hands back a gradient
+            # that sums to zero over the instances -- this layer's bias gradient is that sum, exact in fp32 (1e-7) and 1e-3 from bf16-rounded rows
+            x = ops.exit_mixed(x)
         x = linear_rows(x, mods[i], post_relu=relu, out_dtype=pd, mixed=head and i == 0)
         i += 2 if relu else 1
     return x

@@ -34,5 +34,9 @@ def test_two_gloo_ranks_share_the_gpu():
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['steps'] == 3 and d['scaling'] == 'weak' and d['config']['parallelism'] == 'dp2'
     assert d['value'] > 0 and 'roofline' in d
-    # two sequences per rank, two ranks time-slicing one device: ~45 ms measured; the collapse was 1 400 ms at this size
-    assert d['ms_per_step'] < 300, d['ms_per_step']
+    # N > 1 runs the step N = 1 runs (round-3 verdict item 5): staged, motion heads + TubeNet on the second stream, next batch on the prefetch
+    # stream -- on a shared device with two hardware queues per process (bench.py sets GPU_MAX_HW_QUEUES = 2 for such launches)
+    assert 'second stream' in d['config']['step_variant'], d['config']['step_variant']
+    # two sequences per rank, two ranks time-slicing one device + a gloo all-reduce of 44.5 MB through host memory: ~45-60 ms measured
+    # (2.3-2.4 x the N = 1 step of the same batch); the collapse was 388 - 2 555 ms
+    assert d['ms_per_step'] < 150, d['ms_per_step']

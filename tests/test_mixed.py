@@ -182,3 +182,18 @@ def test_pfn_block_second_outputs_are_the_rounded_first(pooled):
     out2, oa2, out16, hr16 = native.pfn_block_split_forward_dual(xa, am, pl, pm, p2v, w0, b0, ws, w1, b1)
     assert torch.equal(out, out2) and torch.equal(oa, oa2)
     assert torch.equal(out16, out.to(torch.bfloat16)) and torch.equal(hr16, hr.to(torch.bfloat16))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('k,n', [(32, 32), (64, 128), (128, 128), (128, 64)])
+def test_rows_linear_second_output_is_the_rounded_first(k, n):
+    from pcaccumulation_amd import native
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device='cpu').manual_seed(k + n)
+    x = torch.randn(50000, k, generator=g).to(dev)
+    w, b = (torch.randn(n, k, generator=g) / k ** 0.5).to(dev), torch.randn(n, generator=g).to(dev)
+    res = torch.randn(50000, n, generator=g).to(dev)
+    am = native.absmax256(x)
+    y, ya = native.rows_linear_split(x, am, w, b, res, True, True, want_amax=True)
+    y2, ya2, y16 = native.rows_linear_split(x, am, w, b, res, True, True, want_bf16=True)
+    assert torch.equal(y, y2) and torch.equal(ya, ya2) and torch.equal(y16, y.to(torch.bfloat16))

@@ -126,7 +126,9 @@ def test_fused_optimizer_steps_reach_the_prepared_convolution_weights(compute_dt
     p.grad = torch.zeros_like(p)
     probe.step()
     fused_is_silent = p._version == v0                         # true on torch 2.10 + ROCm; the test holds either way
-    opt = torch.optim.Adam(model.parameters(), lr=1e-2, fused=True)
+    # lr 3e-3 (was 1e-2: three such steps on default-initialised weights occasionally drove a whole frame to 'foreground' -- no background pillar
+    # left for the ego head to register, an IndexError in the reference's algorithm as well)
+    opt = torch.optim.Adam(model.parameters(), lr=3e-3, fused=True)
     loss_fn = FuseLoss(cfg['loss'])
     batcher = DeviceBatcher(cfg)
     scene = lambda s: sample_to_device(make_sequence(s, 3, 6000, cfg), dev)
@@ -153,4 +155,4 @@ def test_fused_optimizer_steps_reach_the_prepared_convolution_weights(compute_dt
         scale = float(ref.abs().max())
         assert float((got - ref).abs().max()) <= 2e-2 * scale + 1e-3, (train, fused_is_silent, float((got - ref).abs().max()), scale)
     after = forward(model, 900, True)
-    assert float((after - before).abs().max()) > 1e-3 * float(before.abs().max()), 'three optimizer steps at lr 1e-2 left the training forward unchanged'
+    assert float((after - before).abs().max()) > 1e-3 * float(before.abs().max()), 'three optimizer steps at lr 3e-3 left the training forward unchanged'

@@ -11,7 +11,7 @@ from pcaccumulation_amd.synthetic import make_sequence
 
 dev = torch.device('cuda:0')
 cfg = default_config('waymo', 'train', n_sweeps=5)
-cfg['misc']['compute_dtype'] = 'fp32x3'
+cfg['misc']['compute_dtype'] = os.environ.get('PCACC_DTYPE', 'fp32x3')
 cfg['pose_estimation']['kpt_sampler'] = 'device'
 model, opt, loss_fn = bench.build(cfg, dev)
 stepper = pdist.DataParallelStep(model, opt, loss_fn, iter_size=1, grad_clip=cfg['train']['grad_clip'], catch=False)
