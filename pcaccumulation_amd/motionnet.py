@@ -318,7 +318,7 @@ class MotionNet(nn.Module):
             if n_fb > MIN_POINTS:
                 with self._dense():
                     stpn_map = self.motionhead.backbone(warped_feats)
-                mos, offset, mos_feats = self._stpn_heads(stpn_map, transformed_points[fb_idx], batch_idx[fb_idx])
+                mos, offset, mos_feats = self._stpn_heads(stpn_map, self._take_rows(transformed_points, fb_idx), batch_idx.index_select(0, fb_idx))
                 full_mos = full_mos.index_copy(0, fb_idx, mos)
                 full_offset = full_offset.index_copy(0, fb_idx, offset)
             results['mos_est'] = full_mos
@@ -340,14 +340,15 @@ class MotionNet(nn.Module):
                 if self.mode in ['train', 'val']:
                     results['_gtfg_idx'] = rec_idx            # = nonzero(fb_labels == 1), what FuseLoss.get_offset_loss supervises (libs/loss.py:199)
                 # mos_feats exists whenever rec_mask passes in train/val (fb_mask is a superset of rec_mask)
-                backbone_feats = ops.bilinear_gather(bev_feats, input_points[rec_idx], frame_idx[rec_idx],
+                backbone_feats = ops.bilinear_gather(bev_feats, self._take_rows(input_points, rec_idx), frame_idx.index_select(0, rec_idx),
                                                      abs(self.pc_range[0]), abs(self.pc_range[1]))       # temporal_ungrid
-                motion_feats = ops.bilinear_gather(mos_feats, transformed_points[rec_idx], batch_idx[rec_idx],
+                tp_rec = self._take_rows(transformed_points, rec_idx)
+                motion_feats = ops.bilinear_gather(mos_feats, tp_rec, batch_idx.index_select(0, rec_idx),
                                                    abs(self.pc_range[0]), abs(self.pc_range[1]))          # ungrid
                 reconstructor_input = {
                     'inst_labels': inst_labels[rec_idx],
                     'time_indice': time_indice[rec_idx],
-                    'transformed_points': transformed_points[rec_idx],
+                    'transformed_points': tp_rec,
                     'backbone_feats': backbone_feats,
                     'motion_feats': motion_feats,
                     'inst_motion_gt': input_dict['inst_motion_gt'],
@@ -369,6 +370,14 @@ class MotionNet(nn.Module):
         self.side_stream.wait_event(fork)
         with torch.cuda.stream(self.side_stream):
             return upper()
+
+    @staticmethod
+    def _take_rows(points, idx):
+        """points[idx] for the [N,3] f32 point tables (no gradient): one row-gather launch of the library instead of the generic advanced-indexing
+        kernel (73 us per call at 3.2 M points)."""
+        if points.is_cuda and points.dim() == 2 and points.dtype == torch.float32 and not points.requires_grad:
+            return native.gather_rows(points.contiguous(), idx.to(torch.int32))
+        return points[idx]
 
     @staticmethod
     def _resolve_scalars(results):

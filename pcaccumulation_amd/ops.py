@@ -1270,12 +1270,15 @@ class _UpConv2x2Mixed(torch.autograd.Function):
         x_rows, weight = ctx.saved_tensors
         gy = gy.contiguous()
         w16 = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        gx, gw, gb = torch.ops.aten.convolution_backward(
-            gy.permute(0, 3, 1, 2), x_rows.permute(0, 3, 1, 2), w16, [weight.shape[1]] if ctx.has_bias else None, [2, 2], [0, 0], [1, 1], True, [0, 0], 1,
-            [ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]])
+        gx, gw, _ = torch.ops.aten.convolution_backward(
+            gy.permute(0, 3, 1, 2), x_rows.permute(0, 3, 1, 2), w16, None, [2, 2], [0, 0], [1, 1], True, [0, 0], 1,
+            [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
+        # bias gradient = column sums of the gradient rows, fp32 accumulation (the library's own bias path reduces the channels-last map over
+        # three dimensions: 0.32 ms for the [20, 256, 36, 36] map alone)
+        gb = gy.reshape(-1, gy.shape[-1]).sum(0, dtype=torch.float32) if ctx.has_bias and ctx.needs_input_grad[2] else None
         if gx is not None:
             gx = gx.permute(0, 2, 3, 1).contiguous()
-        return gx, (gw.float().contiguous(memory_format=torch.channels_last) if gw is not None else None), (gb.float() if gb is not None else None)
+        return gx, (gw.float().contiguous(memory_format=torch.channels_last) if gw is not None else None), gb
 
 
 def upconv2x2(x, conv):
