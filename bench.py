@@ -448,8 +448,9 @@ def main():
         # HBM traffic of the same kernel from the committed PMC passes (profiles/r02_pmc_scatter_summary.json, taken at this
         # launch's size: 4 sequences): measured bytes / algorithmic bytes, applied to this run's per-launch algorithmic bytes
         traffic = None
+        pmc_file = next((f for f in ('r04_pmc_scatter_summary.json', 'r02_pmc_scatter_summary.json') if os.path.exists(os.path.join(ROOT, 'profiles', f))), None)
         try:
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_scatter_summary.json')))
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', pmc_file)))
             key = 'pillar_scatter_rows16' if main_bf16 else 'pillar_scatter_vec4<0>'
             traffic = pmc[key]['traffic_over_algorithmic'] * (sum(alg) / len(alg)) if alg else None
         except Exception:
@@ -472,7 +473,7 @@ def main():
                             'device': str(device), 'ranks_per_device': max(1, world // n_dev) if world > n_dev else 1},
             'roofline': {'kernel': 'pillar_scatter_rows16 (BEV canvas fill, bf16 rows -> bf16 canvas)' if main_bf16 else 'pillar_scatter_vec4<0> (BEV canvas fill)', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
-                         'traffic_source': 'PMC FETCH_SIZE x2 + WRITE_SIZE (calibrated on a 128 MiB copy), profiles/r02_pmc_scatter_summary.json',
+                         'traffic_source': 'PMC FETCH_SIZE x2 + WRITE_SIZE (calibrated on a 128 MiB copy), profiles/%s' % pmc_file,
                          'launches_timed': len(durs), 'avg_launch_us': (sum(durs) / len(durs) * 1e6) if durs else None,
                          'timing': 'HIP events attached to each dispatch (hipExtLaunchKernel start/stop)',
                          'algorithmic_bytes_per_launch': (sum(alg) / len(alg)) if alg else None,

@@ -38,6 +38,10 @@ extern "C" {
 /* Library / build identification: returns the gfx target string the kernels were compiled for. */
 const char *pcacc_target(void);
 
+/* torch.cat((a, b), 1) of two channels-last maps as rows: out [rows, a_row_bytes + b_row_bytes] = a [rows, a_row_bytes] | b [rows, b_row_bytes]; row sizes
+ * and pointers multiples of 16 bytes.  The decoder concatenations of models/unet.py:101-113. */
+int pcacc_cat2_rows(const void *a, int32_t a_row_bytes, const void *b, int32_t b_row_bytes, int64_t rows, void *out, void *stream);
+
 /* The launchers' A/B switches (PCACC_CONV_FRAME_MAJOR, PCACC_CONV_SWZ_OFF, PCACC_CONV_RES, PCACC_ROWS_FM_OFF, PCACC_CONV_PLAN: experiments and
  * the equality tests only) are read from the environment once per process; this reads them again.  Returns 0. */
 int pcacc_reload_switches(void);
@@ -59,6 +63,20 @@ int pcacc_voxelize(const float *points, int64_t n, const float *voxel_size, cons
                    int nx, int ny, int nz, int nt, int max_voxels,
                    int32_t *coords, int32_t *p2v, int32_t *num_voxels,
                    void *workspace, size_t workspace_bytes, void *stream);
+
+/* A1 + A2 for a whole batch of samples that already live in HBM: libs/dataset.py:183-199 (the voxelisation at the end of prep_input, per sample) and
+ * libs/dataloader.py:7-40 (collate_fn: concatenation, the batch column, pillar ids offset by the pillars of the samples before) in ONE set of launches.
+ *   points[b] [n_b,3] f64, time[b] [n_b] i64 (frame index), sd / inst / fb [b] [n_b] i64 (each of the three arrays may be NULL): DEVICE pointers in HOST
+ *   arrays of n_samples <= 16 entries; counts host int64 [n_samples], every n_b >= 1.
+ *   points_out [N,3] f64, time_out [N,2] f64 (sample, frame), sd_out / inst_out / fb_out [N] i64, coords_out [capacity >= N, 5] f64 rows
+ *   (sample, z, y, x, t) in first-touch order (rows >= the total pillar count untouched), p2v_out [N] i32 (row of coords_out; a point outside the grid or with t outside [0, nt) gets
+ *   (pillars of the samples before its own) - 1, what collate_fn's blind offset makes of its -1), num_voxels [n_samples] i32 -- all device.  Bit-identical to pcacc_voxelize per sample + the reference's collate_fn. */
+int pcacc_collate_voxelize_workspace_bytes(int64_t n_total, int32_t n_samples, int nx, int ny, int nz, int nt, size_t *bytes /*host*/);
+int pcacc_collate_voxelize(const double *const *points /*host*/, const int64_t *const *time /*host*/, const int64_t *const *sd /*host*/,
+                           const int64_t *const *inst /*host*/, const int64_t *const *fb /*host*/, const int64_t *counts /*host*/, int32_t n_samples,
+                           const float *voxel_size, const float *range, int nx, int ny, int nz, int nt, double *points_out, double *time_out,
+                           int64_t *sd_out, int64_t *inst_out, int64_t *fb_out, double *coords_out, int32_t *p2v_out, int32_t *num_voxels,
+                           void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * A2'. Decode the collated `coordinates` tensor once per forward.
@@ -482,9 +500,12 @@ int pcacc_upconv2x2_split_prepare_weights(const float *w, int32_t c_in, int32_t 
 int pcacc_upconv2x2_split_supported(int32_t h, int32_t w, int32_t c_in, int32_t c_up);
 int pcacc_upconv2x2_split(const float *in, const float *in_amax, const uint16_t *wp, const float *wscale, const float *bias, float *out,
                           float *out_amax, int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_up, int32_t direction, void *stream);
-/* pcacc_upconv2x2_split (direction 0) with the bf16 shadow of its result as a second output ('mixed' mode, see pcacc_conv3x3_split_dual). */
+/* pcacc_upconv2x2_split (direction 0) with the bf16 shadow of its result as a second output ('mixed' mode, see pcacc_conv3x3_split_dual).
+ * out_pitch: elements between consecutive pixels of out and out16 (0 = c_up, dense; 2 c_up: both results are the first half of the decoder's
+ * concatenation buffers [n,2h,2w,2 c_up], models/unet.py:101-113 -- the up-sampled half is never copied). */
 int pcacc_upconv2x2_split_dual(const float *in, const float *in_amax, const uint16_t *wp, const float *wscale, const float *bias, float *out,
-                               float *out_amax, uint16_t *out16, int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_up, void *stream);
+                               float *out_amax, uint16_t *out16, int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_up,
+                               int32_t out_pitch, void *stream);
 int pcacc_upconv2x2_wgrad_split_workspace_bytes(int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_up, size_t *bytes /*host*/);
 int pcacc_upconv2x2_wgrad_split(const float *dy, const float *dy_amax, const float *x, const float *x_amax, float *dw, float *db4, int32_t n_img,
                                 int32_t h, int32_t w, int32_t c_in, int32_t c_up, void *workspace, size_t workspace_bytes, void *stream);

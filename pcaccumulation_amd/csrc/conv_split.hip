@@ -225,7 +225,7 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float 
                                                                     float *__restrict__ out, float *__restrict__ out_amax, uint16_t *__restrict__ out16,
                                                                     int n_img, int frames,
                                                                     int h, int w, int c_in, int c_out, int kt, int relu, int rows, int bw,
-                                                                    int tiles_y, int tiles_x, int co_groups, int mode, int c_up)
+                                                                    int tiles_y, int tiles_x, int co_groups, int mode, int c_up, int up_pitch)
 {
     constexpr int PS = CS + 8;                                 // padded LDS row (elements)
     constexpr int MG = 8 / NGW;                                // waves along the pixel dimension
@@ -436,7 +436,9 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float 
                 if (mode == CSP_UP) {
                     const int ab2 = cb / c_up;
                     cb -= ab2 * c_up;
-                    dst = out + (((int64_t)img * 2 * h + 2 * (pyx[j] >> 16) + (ab2 >> 1)) * 2 * w + 2 * (pyx[j] & 0xffff) + (ab2 & 1)) * c_up + cb - c;
+                    // up_pitch: elements between consecutive pixels of the [2h, 2w] result (c_up, or the width of the decoder's concatenation
+                    // buffer the result is written into, models/unet.py:101-113)
+                    dst = out + (((int64_t)img * 2 * h + 2 * (pyx[j] >> 16) + (ab2 >> 1)) * 2 * w + 2 * (pyx[j] & 0xffff) + (ab2 & 1)) * up_pitch + cb - c;
                 }
                 if (bias && relu != CSP_OUTMASK) bv = *reinterpret_cast<const float4 *>(bias + cb);
                 float4 sc = *reinterpret_cast<const float4 *>(wscale + cw0 + c);          // 1 / t per output channel
@@ -881,14 +883,14 @@ static bool conv_split_plan(int n_img, int h, int w, int c_in, int c_out, int kt
 template <int CS, int NW, int NGW, int MT, int TAPS = 9>
 static int conv_split_launch(const ConvSplitPlan &p, const float *in, const float *in_amax, const float *in_mask, const uint16_t *wp,
                              const float *wscale, const float *bias, float *out, float *out_amax, uint16_t *out16, int n_img, int frames, int h, int w,
-                             int c_in, int c_out, int kt, int relu, hipStream_t st, int mode = CSP_PLAIN, int c_up = 0)
+                             int c_in, int c_out, int kt, int relu, hipStream_t st, int mode = CSP_PLAIN, int c_up = 0, int up_pitch = 0)
 {
     auto kern = conv3x3_split_kernel<CS, NW, NGW, MT, TAPS>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds) != hipSuccess)
         return PCACC_E_LAUNCH;
     if (p.blocks > 0x7fffffff) return PCACC_E_ARG;
     hipLaunchKernelGGL(kern, dim3((unsigned)p.blocks), dim3(CSP_THREADS), p.lds, st, in, in_amax, in_mask, wp, wscale, bias, out, out_amax, out16, n_img,
-                       frames, h, w, c_in, c_out, kt, relu, p.rows, p.bw, p.tiles_y, p.tiles_x, p.co_groups, mode, c_up);
+                       frames, h, w, c_in, c_out, kt, relu, p.rows, p.bw, p.tiles_y, p.tiles_x, p.co_groups, mode, c_up, up_pitch ? up_pitch : c_up);
     PCACC_CHECK_LAUNCH();
     return 0;
 }
@@ -1346,8 +1348,9 @@ extern "C" int pcacc_upconv2x2_split_supported(int32_t h, int32_t w, int32_t c_i
 // (h, w = the SMALL map's size in both directions; wp / wscale: the matching form of prepare_weights; bias NULL for direction 1)
 static int upconv2x2_split_impl(const float *in, const float *in_amax, const uint16_t *wp, const float *wscale, const float *bias, float *out,
                                 float *out_amax, uint16_t *out16, int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_up, int32_t direction,
-                                void *stream)
+                                void *stream, int32_t out_pitch = 0)
 {
+    if (out_pitch && (direction != 0 || out_pitch < c_up || out_pitch % 8)) return PCACC_E_ARG;
     if (!in || !in_amax || !wp || !wscale || !out || n_img < 1 || c_up < 32 || c_up % 32 || (direction != 0 && direction != 1)) return PCACC_E_ARG;
     const int k_in = direction ? 4 * c_up : c_in, k_out = direction ? c_in : 4 * c_up;
     ConvSplitPlan p;
@@ -1359,7 +1362,7 @@ static int upconv2x2_split_impl(const float *in, const float *in_amax, const uin
     const int mode = direction ? CSP_S2D : CSP_UP;
 #define CSU_CASE(CSV, NWV, NGWV, MTV)                                          \
     if (p.cs == CSV && p.nw == NWV && p.ngw == NGWV && p.mt == MTV)            \
-        return conv_split_launch<CSV, NWV, NGWV, MTV, 1>(p, in, in_amax, nullptr, wp, wscale, bias, out, out_amax, out16, n_img, 1, h, w, k_in, k_out, 1, 0, st, mode, c_up)
+        return conv_split_launch<CSV, NWV, NGWV, MTV, 1>(p, in, in_amax, nullptr, wp, wscale, bias, out, out_amax, out16, n_img, 1, h, w, k_in, k_out, 1, 0, st, mode, c_up, out_pitch)
     CSU_CASE(64, 2, 2, 1); CSU_CASE(64, 2, 2, 2); CSU_CASE(64, 2, 1, 1); CSU_CASE(64, 2, 1, 2);
     CSU_CASE(64, 1, 1, 1); CSU_CASE(64, 1, 1, 2); CSU_CASE(64, 1, 1, 3);
     CSU_CASE(32, 2, 2, 1); CSU_CASE(32, 2, 2, 2); CSU_CASE(32, 2, 1, 1); CSU_CASE(32, 2, 1, 2);
@@ -1376,11 +1379,14 @@ extern "C" int pcacc_upconv2x2_split(const float *in, const float *in_amax, cons
 }
 
 // direction 0 with a second result: out16 [n, 2h, 2w, c_up] bf16 = the fp32 result rounded to nearest even ('mixed' compute mode, see pcacc_conv3x3_split_dual)
+// out_pitch: elements between consecutive pixels of out AND out16 (0 = c_up: dense results; 2 c_up: the result is the first half of the decoder's
+// concatenation buffer [n, 2h, 2w, 2 c_up], models/unet.py:101-113 -- no copy of the up-sampled half into it)
 extern "C" int pcacc_upconv2x2_split_dual(const float *in, const float *in_amax, const uint16_t *wp, const float *wscale, const float *bias, float *out,
-                                          float *out_amax, uint16_t *out16, int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_up, void *stream)
+                                          float *out_amax, uint16_t *out16, int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_up,
+                                          int32_t out_pitch, void *stream)
 {
     if (!out16) return PCACC_E_ARG;
-    return upconv2x2_split_impl(in, in_amax, wp, wscale, bias, out, out_amax, out16, n_img, h, w, c_in, c_up, 0, stream);
+    return upconv2x2_split_impl(in, in_amax, wp, wscale, bias, out, out_amax, out16, n_img, h, w, c_in, c_up, 0, stream, out_pitch);
 }
 
 extern "C" int pcacc_upconv2x2_wgrad_split_workspace_bytes(int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_up, size_t *bytes)

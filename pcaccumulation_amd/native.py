@@ -39,7 +39,7 @@ def lib():
 
 # every symbol include/pcacc.h declares (tests check the .so exports exactly these)
 EXPORTS = [
-    'pcacc_reload_switches', 'pcacc_rows_linear_split_dual', 'pcacc_pfn_block_split_forward_dual', 'pcacc_pool_skip_relu_backward_strided_y32', 'pcacc_conv3x3_split_dual', 'pcacc_upconv2x2_split_dual', 'pcacc_voxelize_workspace_bytes', 'pcacc_voxelize', 'pcacc_cell_index',
+    'pcacc_reload_switches', 'pcacc_cat2_rows', 'pcacc_collate_voxelize_workspace_bytes', 'pcacc_collate_voxelize', 'pcacc_rows_linear_split_dual', 'pcacc_pfn_block_split_forward_dual', 'pcacc_pool_skip_relu_backward_strided_y32', 'pcacc_conv3x3_split_dual', 'pcacc_upconv2x2_split_dual', 'pcacc_voxelize_workspace_bytes', 'pcacc_voxelize', 'pcacc_cell_index',
     'pcacc_frame_pillars_workspace_bytes', 'pcacc_frame_pillars',
     'pcacc_csr_workspace_bytes', 'pcacc_csr_build', 'pcacc_segment_mean3_maxlabel',
     'pcacc_segment_workspace_bytes', 'pcacc_segment_max', 'pcacc_segment_max_backward', 'pcacc_segment_sum', 'pcacc_scatter_sum_small',
@@ -130,6 +130,53 @@ def voxelize(points, voxel_size, pc_range, grid, nt, max_voxels):
                                 int(max_voxels), _dev(coords), _dev(p2v), _dev(num), _dev(ws),
                                 ctypes.c_size_t(ws.numel()), _stream()), 'voxelize')
     return coords, p2v, num
+
+
+def collate_voxelize(samples, voxel_size, pc_range, grid, nt):
+    """Voxelise and collate a list of device samples (dicts with input_points [n,3] f64, time_indice [n,1] i64 and optionally sd_labels /
+    inst_labels / fb_labels [n,1] i64) in one set of launches (include/pcacc.h: pcacc_collate_voxelize).  -> dict with the collated
+    input_points [N,3] f64, time_indice [N,2] f64, the label tensors [N,1] i64, coords [N,5] f64 (rows beyond the pillar count unused),
+    point_to_voxel_map [N,1] i32, num_voxels [B] i32 (device)."""
+    B = len(samples)
+    dev = samples[0]['input_points'].device
+    nx, ny, nz = (int(g) for g in grid)
+    keep = []                                                                  # contiguous views must outlive the launch
+
+    def ptrs(key, dtype):
+        arr = (ctypes.c_void_p * B)()
+        for i, s in enumerate(samples):
+            t = s[key]
+            t = t.reshape(t.shape[0], -1) if t.dim() > 1 else t
+            if t.dtype != dtype or not t.is_contiguous():
+                t = t.to(dtype).contiguous()
+            if not t.is_cuda:
+                raise NativeError('collate_voxelize: %s must be a GPU tensor' % key)
+            keep.append(t)
+            arr[i] = t.data_ptr()
+        return arr
+    counts = (ctypes.c_int64 * B)(*[int(s['input_points'].shape[0]) for s in samples])
+    n = sum(counts)
+    pts = ptrs('input_points', torch.float64)
+    tim = ptrs('time_indice', torch.int64)
+    labels = {k: (ptrs(k, torch.int64) if all(k in s for s in samples) else None) for k in ('sd_labels', 'inst_labels', 'fb_labels')}
+    out = {'input_points': torch.empty((n, 3), dtype=torch.float64, device=dev), 'time_indice': torch.empty((n, 2), dtype=torch.float64, device=dev)}
+    for k, v in labels.items():
+        if v is not None:
+            out[k] = torch.empty((n, 1), dtype=torch.int64, device=dev)
+    coords = torch.empty((n, 5), dtype=torch.float64, device=dev)
+    p2v = torch.empty((n, 1), dtype=torch.int32, device=dev)
+    num = torch.empty((B,), dtype=torch.int32, device=dev)
+    need = ctypes.c_size_t(0)
+    _check(lib().pcacc_collate_voxelize_workspace_bytes(_i64(n), B, nx, ny, nz, int(nt), ctypes.byref(need)), 'collate_voxelize_workspace')
+    ws = _ws(need.value, dev)
+    vs = (ctypes.c_float * 3)(*[float(v) for v in voxel_size])
+    rg = (ctypes.c_float * 6)(*[float(v) for v in pc_range])
+    opt = lambda k: _dev(out[k]) if labels[k] is not None else None
+    _check(lib().pcacc_collate_voxelize(pts, tim, labels['sd_labels'], labels['inst_labels'], labels['fb_labels'], counts, B, vs, rg, nx, ny, nz, int(nt),
+                                        _dev(out['input_points']), _dev(out['time_indice']), opt('sd_labels'), opt('inst_labels'), opt('fb_labels'),
+                                        _dev(coords), _dev(p2v), _dev(num), _dev(ws), ctypes.c_size_t(ws.numel()), _stream()), 'collate_voxelize')
+    out.update(coords=coords, point_to_voxel_map=p2v, num_voxels=num, _keep=keep)
+    return out
 
 
 def cell_index(coords, nx, ny, nt, n_batch):
@@ -288,6 +335,18 @@ def pillar_scatter(feats, cell2pillar, out_dtype=torch.float32):
                                         int(c), _dev(canvas), _dtype_code(canvas), t.start if t else None, t.stop if t else None,
                                         _stream()), 'pillar_scatter')
     return canvas
+
+
+def cat2_rows(a, b):
+    """cat((a, b), -1) for two contiguous [..., ca] / [..., cb] tensors of one dtype whose rows are multiples of 16 bytes (channels-last maps)."""
+    ca, cb = a.shape[-1], b.shape[-1]
+    rows = a.numel() // ca
+    if a.dtype != b.dtype or tuple(a.shape[:-1]) != tuple(b.shape[:-1]) or not a.is_contiguous() or not b.is_contiguous():
+        raise NativeError('cat2_rows: two contiguous tensors of one dtype and equal leading dimensions expected')
+    out = torch.empty(tuple(a.shape[:-1]) + (ca + cb,), dtype=a.dtype, device=a.device)
+    _check(lib().pcacc_cat2_rows(_dev(a, None, 'a'), int(ca * a.element_size()), _dev(b, None, 'b'), int(cb * b.element_size()), _i64(rows), _dev(out),
+                                 _stream()), 'cat2_rows')
+    return out
 
 
 def gather_rows(src, idx):
@@ -758,7 +817,7 @@ def upconv2x2_split_prepare_weights(weight):
     return (fwd, sf), (bwd, sb)
 
 
-def upconv2x2_split(x_rows, amax, wps, bias, direction, want_bf16=False):
+def upconv2x2_split(x_rows, amax, wps, bias, direction, want_bf16=False, into=None):
     """direction 0: x_rows f32 [n,h,w,c_in] -> ([n,2h,2w,c_up], its absmax256 array); direction 1: x_rows = dy [n,2h,2w,c_up] -> ([n,h,w,c_in], amax).
     want_bf16 (direction 0): -> (out, amax, bf16 copy of out written by the same epilogue)."""
     wp, wscale = wps
@@ -766,7 +825,7 @@ def upconv2x2_split(x_rows, amax, wps, bias, direction, want_bf16=False):
     if direction == 0:
         h, w, c_in = x_rows.shape[1:]
         c_up = wp.shape[1] // 4
-        out = torch.empty((n, 2 * h, 2 * w, c_up), dtype=torch.float32, device=x_rows.device)
+        out = torch.empty((n, 2 * h, 2 * w, c_up), dtype=torch.float32, device=x_rows.device) if into is None else None
     else:
         h, w, c_up = x_rows.shape[1] // 2, x_rows.shape[2] // 2, x_rows.shape[3]
         c_in = wp.shape[1]
@@ -775,10 +834,17 @@ def upconv2x2_split(x_rows, amax, wps, bias, direction, want_bf16=False):
     if want_bf16:
         if direction != 0:
             raise NativeError('upconv2x2_split: the bf16 second output goes with direction 0')
-        out16 = torch.empty(out.shape, dtype=torch.bfloat16, device=x_rows.device)
+        pitch = 0
+        if into is not None:                                   # (f32 buffer, bf16 buffer) [n,2h,2w,wide]: the results are their first c_up channels
+            out, out16 = into
+            pitch = out.shape[3]
+            if tuple(out.shape) != (n, 2 * h, 2 * w, pitch) or tuple(out16.shape) != tuple(out.shape) or not out.is_contiguous() or not out16.is_contiguous():
+                raise NativeError('upconv2x2_split: concatenation buffers must be contiguous [n,2h,2w,wide] tensors of one shape')
+        else:
+            out16 = torch.empty(out.shape, dtype=torch.bfloat16, device=x_rows.device)
         _check(lib().pcacc_upconv2x2_split_dual(_dev(x_rows, torch.float32, 'x'), _dev(amax, torch.float32, 'amax'), _dev(wp, torch.float16, 'wp'),
                                                 _dev(wscale, torch.float32, 'wscale'), _opt(bias, torch.float32, 'bias'), _dev(out), _dev(out_amax),
-                                                _dev(out16), int(n), int(h), int(w), int(c_in), int(c_up), _stream()), 'upconv2x2_split_dual')
+                                                _dev(out16), int(n), int(h), int(w), int(c_in), int(c_up), int(pitch), _stream()), 'upconv2x2_split_dual')
         return out, out_amax, out16
     _check(lib().pcacc_upconv2x2_split(_dev(x_rows, torch.float32, 'x'), _dev(amax, torch.float32, 'amax'), _dev(wp, torch.float16, 'wp'),
                                        _dev(wscale, torch.float32, 'wscale'), _opt(bias, torch.float32, 'bias'), _dev(out), _dev(out_amax), int(n),

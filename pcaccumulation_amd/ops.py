@@ -807,12 +807,45 @@ def exit_mixed(x):
     return _ExitMixed.apply(x) if _MIXED and x.dtype == torch.bfloat16 else x
 
 
+class _Cat2(torch.autograd.Function):
+    """cat((a, b), -1) of two contiguous row tensors on the library's own copy kernel (pcacc_cat2_rows); the gradient goes back as the two channel
+    slices of the incoming gradient (views: the encoder's pool tail reads its slice in place)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.ca = a.shape[-1]
+        return native.cat2_rows(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[..., :ctx.ca], g[..., ctx.ca:]
+
+
+def _cat2(a, b, dim):
+    """torch.cat((a, b), dim) -- through pcacc_cat2_rows when both are channels-last maps concatenated along the channels (dim 1 of NCHW) or plain
+    rows concatenated along their last dimension, on the GPU, with 16-byte row pieces."""
+    if a.is_cuda and a.dtype == b.dtype and a.dtype in (torch.float32, torch.bfloat16) and a.dim() == b.dim() \
+            and os.environ.get('PCACC_OWN_CAT', '1') != '0':
+        ar = None
+        if a.dim() == 4 and dim == 1:
+            ar, br = a.permute(0, 2, 3, 1), b.permute(0, 2, 3, 1)
+            back = lambda y: y.permute(0, 3, 1, 2)
+        elif dim in (-1, a.dim() - 1):
+            ar, br, back = a, b, (lambda y: y)
+        if ar is not None and ar.is_contiguous() and br.is_contiguous() and tuple(ar.shape[:-1]) == tuple(br.shape[:-1]) \
+                and (ar.shape[-1] * a.element_size()) % 16 == 0 and (br.shape[-1] * a.element_size()) % 16 == 0 and ar.numel() > 0 \
+                and ar.data_ptr() % 16 == 0 and br.data_ptr() % 16 == 0:
+            return back(_Cat2.apply(ar, br))
+    return torch.cat((a, b), dim)
+
+
 def cat_maps(tensors, dim=1):
-    """torch.cat for maps inside a mixed segment (shadows: the twins are concatenated too and registered); plain torch.cat otherwise."""
-    y = torch.cat(tensors, dim)
+    """torch.cat for maps inside a mixed segment (shadows: the twins are concatenated too and registered); the plain concatenation otherwise."""
+    a, b = tensors
+    y = _cat2(a, b, dim)
     if _MIXED and y.dtype == torch.bfloat16:
         tw = [twin(t) for t in tensors]
-        y32 = merge_amax(torch.cat(tw, dim), *tw)
+        y32 = merge_amax(_cat2(tw[0], tw[1], dim), *tw)
         if _POISON:
             with torch.no_grad():
                 y.fill_(float('nan'))
@@ -1279,6 +1312,63 @@ class _UpConv2x2Mixed(torch.autograd.Function):
         if gx is not None:
             gx = gx.permute(0, 2, 3, 1).contiguous()
         return gx, (gw.float().contiguous(memory_format=torch.channels_last) if gw is not None else None), gb
+
+
+class _UpConvCatMixed(torch.autograd.Function):
+    """cat(upconv(x), skip) of a decoder stage (models/unet.py:101-113) in the 'mixed' mode: the transposed convolution writes its fp32 result and
+    the bf16 shadow straight into the first halves of the two concatenation buffers (pcacc_upconv2x2_split_dual with a pixel pitch); only the
+    skip halves are copied.  Backward: the up-sampled half of the buffer's gradient goes through the transposed convolution's bf16 backward, the
+    skip half is handed on as the channel slice it is (the encoder's pool tail reads it in place).  Opt-in (PCACC_UPCONV_CAT=1): measured neutral."""
+
+    @staticmethod
+    def forward(ctx, x_rows, skip_rows, weight, bias):
+        x32, s32 = twin(x_rows), twin(skip_rows)
+        n, h, w, _ = x_rows.shape
+        c_up, c_skip = weight.shape[1], skip_rows.shape[3]
+        if c_skip != c_up or tuple(skip_rows.shape[:3]) != (n, 2 * h, 2 * w):
+            raise native.NativeError('upconv + concatenation: the skip map must have the up-sampled map\'s shape')
+        buf32 = torch.empty((n, 2 * h, 2 * w, 2 * c_up), dtype=torch.float32, device=x_rows.device)
+        buf16 = torch.empty((n, 2 * h, 2 * w, 2 * c_up), dtype=torch.bfloat16, device=x_rows.device)
+        _, up_amax, _ = native.upconv2x2_split(x32, amax_of(x32), prepared_upconv_weights_split(weight)[0], bias.detach() if bias is not None else None, 0,
+                                               want_bf16=True, into=(buf32, buf16))
+        buf32[..., c_up:].copy_(s32)
+        if _POISON:
+            buf16.fill_(float('nan'))
+        else:
+            buf16[..., c_up:].copy_(skip_rows)
+        set_amax_tag(buf32, torch.maximum(up_amax, amax_of(s32)))
+        ctx.save_for_backward(x_rows, weight)
+        ctx.has_bias, ctx.c_up = bias is not None, c_up
+        return shadow(buf32, buf16)
+
+    @staticmethod
+    def backward(ctx, g):
+        x_rows, weight = ctx.saved_tensors
+        c_up = ctx.c_up
+        gy = g[..., :c_up].contiguous()
+        w16 = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        gx, gw, _ = torch.ops.aten.convolution_backward(
+            gy.permute(0, 3, 1, 2), x_rows.permute(0, 3, 1, 2), w16, None, [2, 2], [0, 0], [1, 1], True, [0, 0], 1,
+            [ctx.needs_input_grad[0], ctx.needs_input_grad[2], False])
+        gb = gy.reshape(-1, c_up).sum(0, dtype=torch.float32) if ctx.has_bias and ctx.needs_input_grad[3] else None
+        if gx is not None:
+            gx = gx.permute(0, 2, 3, 1).contiguous()
+        return (gx, g[..., c_up:] if ctx.needs_input_grad[1] else None,
+                gw.float().contiguous(memory_format=torch.channels_last) if gw is not None else None, gb)
+
+
+def upconv_cat(from_up, from_down, conv):
+    """cat((conv(from_up), from_down), 1) for a decoder stage.  PCACC_UPCONV_CAT=1 ('mixed' mode): without the copy of the up-sampled half
+    (_UpConvCatMixed) -- opt-in: measured neutral (36.2 / 36.2 / 39.1 ms without, 37.6 / 37.0 / 38.5 with: the strided copies of the skip halves cost
+    what the saved half of the concatenation cost)."""
+    if (_MIXED and from_up.is_cuda and from_up.dtype == torch.bfloat16 and from_down.dtype == torch.bfloat16
+            and conv.kernel_size == (2, 2) and conv.stride == (2, 2) and conv.padding == (0, 0) and conv.output_padding == (0, 0) and conv.groups == 1
+            and conv.dilation == (1, 1) and conv.weight.dtype == torch.float32 and conv.out_channels == from_down.shape[1]
+            and os.environ.get('PCACC_UPCONV_CAT', '0') == '1'):
+        xr, sr = from_up.permute(0, 2, 3, 1), from_down.permute(0, 2, 3, 1)
+        if xr.is_contiguous() and sr.is_contiguous() and native.upconv2x2_split_supported(from_up.shape[-2], from_up.shape[-1], conv.in_channels, conv.out_channels):
+            return _UpConvCatMixed.apply(xr, sr, conv.weight, conv.bias).permute(0, 3, 1, 2)
+    return cat_maps((upconv2x2(from_up, conv), from_down), 1)
 
 
 def upconv2x2(x, conv):

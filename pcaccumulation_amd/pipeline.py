@@ -33,7 +33,7 @@ def _host_wait(event):
 
 class _Pending(object):
     """A batch whose voxelisation has been launched: everything that does not depend on the voxel counts is already queued."""
-    __slots__ = ('samples', 'launched', 'static', 'tis', 'counts', 'event', 'stream', 'device', 'ready', 'result')
+    __slots__ = ('samples', 'launched', 'static', 'tis', 'counts', 'event', 'stream', 'device', 'ready', 'result', 'batched')
 
 
 class DeviceBatcher(object):
@@ -48,6 +48,20 @@ class DeviceBatcher(object):
 
     def _launch(self, p):
         vox, samples, dev = self.voxeliser, p.samples, p.device
+        p.batched = None
+        if dev.type == 'cuda' and len(samples) <= 16 and os.environ.get('PCACC_BATCHED_COLLATE', '1') != '0' \
+                and all(s['input_points'].shape[0] > 0 for s in samples):
+            # one set of launches for the whole batch: copy into the collated layout + first-touch tables (one per sample) + ranks that ARE the
+            # collated pillar ids (pcacc_collate_voxelize); ~7 launches instead of ~70
+            b = native.collate_voxelize(samples, vox.voxel_size.tolist(), vox.point_cloud_range.tolist(), vox.grid_size.tolist(), vox.n_sweeps)
+            p.batched = b
+            p.launched = [(b['coords'], b['point_to_voxel_map'], b['num_voxels'])]
+            p.static = {k: b[k] for k in ('input_points', 'time_indice', 'sd_labels', 'inst_labels', 'fb_labels') if k in b}
+            p.static['num_points'] = torch.cat([s['num_points'] for s in samples], dim=0)
+            p.static['ego_motion_gt'] = torch.stack([s['ego_motion_gt'] for s in samples], 0)
+            p.static = {k: p.static[k] for k in ('input_points', 'num_points', 'time_indice', 'sd_labels', 'inst_labels', 'fb_labels', 'ego_motion_gt')
+                        if k in p.static}
+            return b['num_voxels']
         p.launched = []
         for s in samples:                                                # launch every voxelisation, then ONE read-back
             pts4 = torch.cat((s['input_points'].float(), s['time_indice'].float()), dim=1)
@@ -85,6 +99,17 @@ class DeviceBatcher(object):
     def _collate(self, p, counts):
         """The batch dict of the reference's collate_fn from the launched voxelisations and their pillar counts."""
         vox, samples, dev = self.voxeliser, p.samples, p.device
+        if getattr(p, 'batched', None) is not None:
+            n_vox = [int(c) for c in counts]
+            grid = torch.tensor(list(vox.grid_size) + [vox.n_sweeps], dtype=torch.int64)
+            out = dict(p.static)
+            out.update({
+                'inst_motion_gt': [s['inst_motion_gt'] for s in samples],
+                'coordinates': p.batched['coords'][:sum(n_vox)], 'num_voxels': native.upload_small(n_vox, torch.int64, dev),
+                'shape': native.upload_small(grid[None].repeat(len(samples), 1), torch.int64, dev),
+                'point_to_voxel_map': p.batched['point_to_voxel_map'],
+            })
+            return out
         coords, p2vs, n_vox = [], [], []
         offset = 0
         for b, s in enumerate(samples):

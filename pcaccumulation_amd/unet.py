@@ -49,8 +49,10 @@ class UpConv(nn.Module):
         self.conv2 = conv3x3(out_channels, out_channels)
 
     def forward(self, from_down, from_up):
-        from_up = ops.upconv2x2(from_up, self.upconv)                   # fp32x3 mode: the 1-tap split kernels; else the library
-        x = ops.cat_maps((from_up, from_down), 1) if self.merge_mode == 'concat' else from_up + from_down      # mixed mode: twins concatenated too
+        if self.merge_mode == 'concat':
+            x = ops.upconv_cat(from_up, from_down, self.upconv)        # fp32x3: the 1-tap split kernels (mixed: written straight into the concatenation buffers); else the library
+        else:
+            x = ops.upconv2x2(from_up, self.upconv) + from_down
         pair = ops.conv_pair_fusable(x, self.conv1, self.conv2)
         return ops.conv3x3(ops.conv3x3(x, self.conv1, relu=True, premasked=pair), self.conv2, relu=True, input_relu=pair)
 

@@ -990,6 +990,35 @@ def test_batcher_side_stream_start_finish_equals_call(native, dev):
                 assert len(v) == len(got[k]) and all(torch.equal(a, b) for a, b in zip(v, got[k])), k
 
 
+@pytest.mark.parametrize('sizes', [(1500,), (1200, 1500, 900), (4000, 1, 2500, 3100)])
+def test_batched_collate_voxelize_is_the_reference_collate(native, dev, sizes, monkeypatch):
+    """pcacc_collate_voxelize (one set of launches for the whole batch: collated copies + one first-touch table per sample + ranks that are the
+    collated pillar ids) against (a) the reference's layout -- collate_fn over samples voxelised by the oracle, libs/dataloader.py:7-40 -- key by
+    key, dtype by dtype, bit by bit, and (b) the per-sample launches + torch.cat path it replaces."""
+    from helpers import oracle_voxeliser
+    from pcaccumulation_amd.dataloader import collate_fn
+    from pcaccumulation_amd.pipeline import DeviceBatcher, sample_to_device
+    from pcaccumulation_amd.synthetic import make_sequence, attach_voxels
+    cfg = default_config('waymo', 'train', n_sweeps=3, xy_range=8)
+    raw = [make_sequence(90 + i, 3, max(n // 3, 1), cfg) for i, n in enumerate(sizes)]
+    for r in raw[1:2]:                                                       # some points outside the grid and in a frame that does not exist
+        r['input_points'][::7, 0] += 100.0
+        r['time_indice'][::11, 0] = 5
+    want = collate_fn([attach_voxels(dict(r), oracle_voxeliser(cfg)) for r in raw])
+    samples = [sample_to_device(r, dev) for r in raw]
+    got = DeviceBatcher(cfg)(samples)
+    monkeypatch.setenv('PCACC_BATCHED_COLLATE', '0')
+    old = DeviceBatcher(cfg)(samples)
+    for name, other in (('reference layout', want), ('per-sample path', old)):
+        for k, v in other.items():
+            if k == 'inst_motion_gt':
+                assert all(torch.equal(a.cpu(), torch.as_tensor(b).cpu()) for a, b in zip(got[k], v)), (name, k)
+                continue
+            v = torch.as_tensor(v)
+            assert got[k].dtype == v.dtype and tuple(got[k].shape) == tuple(v.shape), (name, k, got[k].dtype, v.dtype, got[k].shape, v.shape)
+            assert torch.equal(got[k].cpu(), v.cpu()), (name, k)
+
+
 @pytest.mark.parametrize('dtype,c', [(torch.float32, 128), (torch.bfloat16, 128), (torch.bfloat16, 64), (torch.float32, 32)])
 def test_batch_norm_rows_is_batchnorm1d(native, dev, dtype, c):
     """models/unet.py:240-245: training-mode BatchNorm1d over K rows (trap 16) -- output, input / affine gradients, running

@@ -162,6 +162,12 @@ def test_split_kernels_second_output_is_the_rounded_first(n, t, h, w, ci, co, kt
         u, ua = native.upconv2x2_split(x, am, uf, bias, 0)
         u2, ua2, u16 = native.upconv2x2_split(x, am, uf, bias, 0, want_bf16=True)
         assert torch.equal(u, u2) and torch.equal(u16, u.to(torch.bfloat16))
+        # written straight into the first halves of two concatenation buffers (pixel pitch 2 c_up): same values, the other halves untouched
+        b32 = torch.full((n, 2 * h, 2 * w, 2 * co), 7.0, device=dev)
+        b16 = torch.full((n, 2 * h, 2 * w, 2 * co), 7.0, device=dev, dtype=torch.bfloat16)
+        native.upconv2x2_split(x, am, uf, bias, 0, want_bf16=True, into=(b32, b16))
+        assert torch.equal(b32[..., :co], u) and torch.equal(b16[..., :co], u16)
+        assert bool((b32[..., co:] == 7.0).all()) and bool((b16[..., co:] == 7.0).all())
 
 
 @pytest.mark.gpu
@@ -197,3 +203,22 @@ def test_rows_linear_second_output_is_the_rounded_first(k, n):
     y, ya = native.rows_linear_split(x, am, w, b, res, True, True, want_amax=True)
     y2, ya2, y16 = native.rows_linear_split(x, am, w, b, res, True, True, want_bf16=True)
     assert torch.equal(y, y2) and torch.equal(ya, ya2) and torch.equal(y16, y.to(torch.bfloat16))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('shape,ca,cb', [((3, 17, 9), 32, 32), ((2, 36, 36), 256, 256), ((5000,), 64, 64), ((4, 8, 8), 8, 24)])
+def test_own_concatenation_kernel(dtype, shape, ca, cb):
+    """pcacc_cat2_rows == torch.cat along the channels, forward and (through ops.cat_maps) backward."""
+    from pcaccumulation_amd import native
+    dev = torch.device('cuda:0')
+    a = torch.randn(*shape, ca, device=dev).to(dtype)
+    b = torch.randn(*shape, cb, device=dev).to(dtype)
+    assert torch.equal(native.cat2_rows(a, b), torch.cat((a, b), -1))
+    if len(shape) == 3:
+        an, bn = a.permute(0, 3, 1, 2).requires_grad_(True), b.permute(0, 3, 1, 2).requires_grad_(True)
+        y = ops.cat_maps((an, bn), 1)
+        assert torch.equal(y, torch.cat((an, bn), 1)) and y.permute(0, 2, 3, 1).is_contiguous()
+        g = torch.randn_like(y)
+        ga, gb = torch.autograd.grad(y, (an, bn), g)
+        assert torch.equal(ga, g[:, :ca]) and torch.equal(gb, g[:, ca:])

@@ -99,5 +99,22 @@ for _ in range(3):
     native.head_conv3x3_forward(xh, wh, torch.zeros(2, device=dev))
     native.head_conv3x3_dgrad(dyh, wh, 32, torch.bfloat16)
     native.head_conv3x3_wgrad(dyh, xh)
+# ---- round 4: the 'mixed' mode's kernels -- fp32x3 forward with a bf16 second output, pool backward with fp32 winners, batched collate + voxelise
+# (the bf16 second outputs of the split kernels share their kernels' names with the plain launches above: one extra 2-byte store per element;
+#  they are timed in tools/native_call_table.py, not here)
+yp = torch.relu(f32(20, 288, 288, 32))
+gp, gs = bf(20, 144, 144, 32), bf(20, 288, 288, 64)[..., 32:]
+for _ in range(3):
+    native.pool_skip_relu_backward(yp, gp, gs)                                                                          # pool_skip_relu_bwd_y32_kernel
+from pcaccumulation_amd.config import default_config  # noqa: E402
+from pcaccumulation_amd.pipeline import sample_to_device  # noqa: E402
+from pcaccumulation_amd.synthetic import make_sequence  # noqa: E402
+cfgv = default_config('waymo', 'train', n_sweeps=5)
+smp = [sample_to_device(make_sequence(i, 5, 160000, cfgv), dev) for i in range(4)]
+vg = cfgv['voxel_generator']
+import numpy as np  # noqa: E402
+grid = np.round((np.array(vg['range'][3:], np.float32) - np.array(vg['range'][:3], np.float32)) / np.array(vg['voxel_size'], np.float32)).astype(int).tolist()
+for _ in range(3):
+    native.collate_voxelize(smp, vg['voxel_size'], vg['range'], grid, 5)                                               # vox_batch_keys / vox_batch_assign / vox_p2v
 torch.cuda.synchronize()
 print('done')

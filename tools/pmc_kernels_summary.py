@@ -32,6 +32,12 @@ KERNELS = {  # name fragment -> (label, algorithmic FLOPs per launch, algorithmi
     'rows_linear_split_fm_kernel': ('fp32x3 rows linear 128->128, 430 k rows (weights in registers)', 2.0 * 429567 * 128 * 128, 429567 * 256 * 4),
     'head_conv_fwd_kernel': ('fg/bg head conv 32->2 forward @288^2 x20 (bf16 in)', 2.0 * 20 * 288 * 288 * 32 * 2 * 9, 20 * 288 * 288 * (32 * 2 + 2 * 4)),
     'head_conv_dgrad_kernel': ('fg/bg head conv data gradient (bf16 out)', 2.0 * 20 * 288 * 288 * 32 * 2 * 9, 20 * 288 * 288 * (32 * 2 + 2 * 4)),
+    # round 4
+    'pool_skip_relu_bwd_y32_kernel': ('pool tail backward, fp32 winners + bf16 gradients, 32 ch @288^2 x20', 0.0, 20 * 288 * 288 * 32 * (4 + 2 + 2) + 20 * 144 * 144 * 32 * 2),
+    'vox_batch_keys': ('batched collate + first-touch keys, 4 x 800 k points', 0.0, 3.2e6 * (56 + 24 + 16 + 24 + 4)),
+    'vox_batch_assign': ('batched voxeliser: ranks + float64 coordinates rows, 3.2 M points', 0.0, 3.2e6 * 8 + 1.17e6 * (40 + 4)),
+    'vox_batch_p2v': ('point -> collated pillar id, 3.2 M points', 0.0, 3.2e6 * 12),
+    'vox_count': ('first-touch flags per chunk, 3.2 M points', 0.0, 3.2e6 * 8),
     'head_conv_wgrad_kernel': ('fg/bg head conv weight gradient (bf16 in)', 2.0 * 20 * 288 * 288 * 32 * 2 * 9, 20 * 288 * 288 * (32 * 2 + 2 * 4)),
 }
 
