@@ -332,16 +332,14 @@ def main():
     ap.add_argument('--prepare-ahead', action='store_true', help='build the pillar index / CSR / point features of the next batch on the prefetch stream during the current step (MotionNet.prepare_inputs) instead of inside its own forward; measured neutral: 29.16 vs 29.22 ms over 8 interleaved runs each, sd 0.5')
     ap.add_argument('--no-prefetch', action='store_true', help='voxelise each batch at the start of its own step instead of one step ahead on a side stream')
     args = ap.parse_args()
+    if os.environ.get('PCACC_HANG_DUMP'):                      # debugging aid: every thread's Python stack after N seconds, then exit
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ['PCACC_HANG_DUMP']), exit=True)
 
     # PCACC_DIST_BACKEND=gloo lets the N > 1 path be exercised on a box with fewer GPUs than ranks (ranks then share
     # cuda:0); the driver's multi-GPU runs use the default: nccl = RCCL over xGMI, one rank per GPU.
     backend = os.environ.get('PCACC_DIST_BACKEND') or None
     n_dev = max(torch.cuda.device_count(), 1)
-    if int(os.environ.get('LOCAL_WORLD_SIZE', '1') or 1) > n_dev and 'GPU_MAX_HW_QUEUES' not in os.environ:
-        # ranks SHARING a device (the gloo test configuration of a one-GPU box): two hardware queues per process keep every queue of every rank
-        # resident on the device -- with the default four the staged two-stream step collapses (388 ms instead of 62.5 ms per step for two ranks,
-        # DESIGN.md section 6).  Read by the HIP runtime when it initialises, i.e. after this line.
-        os.environ['GPU_MAX_HW_QUEUES'] = '2'
     if backend is None and int(os.environ.get('WORLD_SIZE', '1')) > n_dev:
         raise SystemExit('WORLD_SIZE exceeds the %d visible GPU(s); set PCACC_DIST_BACKEND=gloo to share devices' % n_dev)
     torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % n_dev)

@@ -337,10 +337,12 @@ class DataParallelStep(object):
         # sequences): 65.8 ms plain one-stream step; staged + second stream + prefetch stream 388 ms at the default 4 queues per process,
         # 2 555 ms at 8, 62.5 ms at 2 (all queues of both processes resident: the best of all); 66.0 ms without the prefetch stream;
         # polling the prefetch event instead of blocking in the runtime changed nothing (304 ms) -- it is not the host wait.  So: ranks that
-        # share a device get the second stream only with GPU_MAX_HW_QUEUES <= 2 (bench.py sets it for such launches), else the plain step.
+        # share a device do not get the second stream by default.
+        # (With GPU_MAX_HW_QUEUES = 2 as the default for shared devices the driver-style two-rank bench hung once in ~10 runs -- as the first GPU test of a
+        # fresh box, ranks connected, no step finished in 600 s; not reproduced in five further runs.  Ranks that share a device therefore keep the plain
+        # one-stream step of rounds 2-3; PCACC_TWO_STREAMS_DIST=1 (+ GPU_MAX_HW_QUEUES=2 in the environment) opts in, =0 forces the plain step everywhere.)
         shared = ranks_share_a_device()
-        queues_ok = int(os.environ.get('GPU_MAX_HW_QUEUES', '4') or 4) <= 2
-        allow = world_size() == 1 or not shared or queues_ok or os.environ.get('PCACC_TWO_STREAMS_DIST') == '1'
+        allow = world_size() == 1 or not shared or os.environ.get('PCACC_TWO_STREAMS_DIST') == '1'
         if os.environ.get('PCACC_TWO_STREAMS_DIST') == '0':
             allow = world_size() == 1
         want_side = self._two_streams and dev.type == 'cuda' and allow and hasattr(model, 'side_stream')

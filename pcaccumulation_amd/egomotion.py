@@ -255,7 +255,11 @@ class EgoMotionHead(nn.Module):
             offs = native.upload_small([flat['bg_at'][f] for f in frames], torch.int64, dev)
             pillar = flat['sp'][flat['bg_sorted_idx'][offs[:, None] + drawn.long()]]              # [2P,k] pillar ids
             coor = flat['pillar_mean'][pillar]                                                    # [2P,k,3]
-            feats = flat['geo_rows'][flat['cells'][pillar]].float()                               # [2P,k,C], one index op
+            geo = flat['geo_rows']
+            if hasattr(geo, 'at'):                                                                # ops.SparseConvRows: the head's last convolution at these cells only
+                feats = geo.at(flat['cells'][pillar]).float()                                     # [2P,k,C]
+            else:
+                feats = geo[flat['cells'][pillar]].float()                                        # [2P,k,C], one index op
             feats_s, feats_t, coor_s, coor_t = feats[0::2], feats[1::2], coor[0::2], coor[1::2]
             durations = [dur for _ in sequences for _, _, dur in plan]
             sequences_loop = []
@@ -446,6 +450,8 @@ class EgoMotionHead(nn.Module):
         sequences, bg_start, bg_at = [], 0, []
         # all key points in five gathers (_estimate_pairs); flat_keypoints = False keeps the per-pair loop (tests compare the two)
         fast = self.kpt_sampler == 'device' and geo_rows.is_cuda and getattr(self, 'flat_keypoints', True)
+        if not fast and hasattr(geo_rows, 'dense'):
+            geo_rows = geo_rows.dense()                                      # whole frames are indexed below: the dense map as rows
         mean_sorted = pillar_mean[sp]                                        # xyz of every pillar in frame / cell order: one gather
         for b in range(B):
             points_list, getters, bg_list = [], [], []

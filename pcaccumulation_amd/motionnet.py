@@ -258,7 +258,12 @@ class MotionNet(nn.Module):
         # The ego feature head (two full-resolution convolutions, needed by the ego head only) is queued between the request for the
         # sizes and the wait for them: the GPU still has work when the host wakes up and starts issuing the ego head's small launches.
         with self._dense():
-            geometric_feats = ops.exit_mixed(self.ego_feats_head(bev_feats))      # the ego head reads fp32 (mixed mode: the twin)
+            # With the device key-point sampler the ego head reads <= 1024 rows per frame of this head's output: its last convolution is then
+            # evaluated at those cells only (ops.SparseConvRows); the dense map otherwise (reference sampler: whole frames are indexed)
+            if self.ego_motion_head.kpt_sampler == 'device' and bev_feats.is_cuda and getattr(self.ego_motion_head, 'flat_keypoints', True):
+                geo_rows = self.ego_feats_head.sparse_rows(bev_feats)
+            else:
+                geo_rows = ops.nchw_as_rows(ops.exit_mixed(self.ego_feats_head(bev_feats)))      # the ego head reads fp32 (mixed mode: the twin)
         sizes = sizes.numpy().tolist()
         nf = B * T + 1
         frame_offsets, bg_at = sizes[:nf], sizes[nf:2 * nf]
@@ -280,7 +285,7 @@ class MotionNet(nn.Module):
 
         # 4. ego motion (fp32).  The per-cell L2 normalisation of motionnet.py:199 (no epsilon, trap 7) is applied to the
         #    gathered key-point rows inside the head instead of to the whole map.
-        self.ego_motion_head.forward_pillars(ops.nchw_as_rows(geometric_feats), pillar_mean, pidx, ego_motion_gt, results,
+        self.ego_motion_head.forward_pillars(geo_rows, pillar_mean, pidx, ego_motion_gt, results,
                                              frame_offsets, bg_sorted_idx, bg_counts)
         # Everything below works on detached features and poses (motionnet.py:205-209): the graph of the pillar encoder, the
         # U-Net, the two heads and the ego head is complete here.  A training step may hook in (`after_ego`) to evaluate the loss terms

@@ -1552,6 +1552,71 @@ def conv3x3_relu_pool(x, conv, input_relu=False):
     return pooled.permute(0, 3, 1, 2), skip.permute(0, 3, 1, 2)
 
 
+class _SparseConv3x3(torch.autograd.Function):
+    """A 3x3 convolution (padding 1) evaluated ONLY at selected cells of a channels-last map: out[j] = bias + sum over the 3x3 neighbourhood of cell
+    cells[j] of W[:, :, dy, dx] . h[neighbour] -- the rows a dense convolution followed by a row gather would give.  The ego head reads the last layer of
+    its feature head at <= 1024 key points per frame (models/motionnet.py:196-201 computes the whole [B*T, 64, Ny, Nx] map, models/egomotion.py:156-166
+    samples it): 32 768 of 1 658 880 cells of a 4-sequence step, i.e. 2.4 of 122 GFLOP, and the backward is two small GEMMs plus a scatter-add
+    instead of a dense data / weight gradient.  fp32 throughout (plain library GEMMs: [K, 9 C] x [9 C, O])."""
+
+    @staticmethod
+    def forward(ctx, h_rows, weight, bias, cells):
+        n, H, W, C = h_rows.shape
+        cells = cells.reshape(-1).long()
+        x, y, img = cells % W, (cells // W) % H, cells // (W * H)
+        d = torch.arange(-1, 2, device=cells.device)
+        yy, xx = (y[:, None, None] + d[None, :, None]).expand(-1, 3, 3), (x[:, None, None] + d[None, None, :]).expand(-1, 3, 3)
+        ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W)
+        idx = torch.where(ok, (img[:, None, None] * H + yy) * W + xx, torch.full_like(yy, -1)).reshape(-1).to(torch.int32)     # [K * 9], -1 = zero padding
+        patches = native.gather_rows(h_rows.reshape(-1, C), idx).view(-1, 9 * C)                                              # [K, 9 C] (tap-major)
+        w2 = weight.detach().float().permute(2, 3, 1, 0).reshape(9 * C, -1)                                                     # [(dy, dx, ci), co]
+        out = torch.addmm(bias.detach().float(), patches, w2) if bias is not None else patches @ w2
+        ctx.save_for_backward(patches, w2, idx)
+        ctx.meta = (tuple(h_rows.shape), tuple(weight.shape), bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        patches, w2, idx = ctx.saved_tensors
+        (n, H, W, C), wshape, has_bias = ctx.meta
+        g = g.contiguous().float()
+        gh = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gp = (g @ w2.t()).view(-1, C)                                                      # [K * 9, C] rows of the neighbourhoods' gradients
+            gh = torch.zeros((n * H * W, C), dtype=torch.float32, device=g.device)
+            valid = idx >= 0
+            gh.index_add_(0, idx.clamp(min=0).long(), gp * valid[:, None])                     # overlapping neighbourhoods add up
+            gh = gh.view(n, H, W, C)
+        if ctx.needs_input_grad[1]:
+            gw = (patches.t() @ g).view(3, 3, wshape[1], wshape[0]).permute(3, 2, 0, 1).contiguous()
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = g.sum(0)
+        return gh, gw, gb, None
+
+
+class SparseConvRows(object):
+    """The rows of `conv(h)` as a lazily evaluated table: `.at(cells)` computes the convolution at those cells only (_SparseConv3x3), `.dense()`
+    the whole map as rows.  h: NCHW view of a channels-last fp32 map."""
+
+    def __init__(self, h, conv):
+        self.h, self.conv = h, conv
+        self.is_cuda, self.device = h.is_cuda, h.device
+
+    def at(self, cells):
+        rows = self.h.permute(0, 2, 3, 1)
+        out = _SparseConv3x3.apply(rows if rows.is_contiguous() else rows.contiguous(), self.conv.weight, self.conv.bias, cells)
+        return out.view(tuple(cells.shape) + (out.shape[-1],))
+
+    def dense(self):
+        return nchw_as_rows(exit_mixed(conv3x3(self.h, self.conv)))
+
+
+def sparse_conv_available(h, conv):
+    return (h.is_cuda and h.dtype == torch.float32 and h.dim() == 4 and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.weight.dtype == torch.float32 and h.shape[1] % 4 == 0
+            and os.environ.get('PCACC_SPARSE_EGO', '1') != '0')
+
+
 class _Sinkhorn(torch.autograd.Function):
     """Log-domain Sinkhorn with slack (models/egomotion.py:100-137) on [P,k,k] log-affinities: two launches per iteration forward,
     two backward (csrc/ego.hip); the backward replays the half-steps from the input and the recorded log-sum-exp vectors."""

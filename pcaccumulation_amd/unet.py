@@ -133,5 +133,19 @@ class SegHead2D(nn.Module):
     def forward(self, feats):
         conv0, bn, act, conv1 = self.seg_head
         fused = isinstance(act, nn.ReLU)                       # normalisation and ReLU in one pass each way (csrc/bn.hip)
+        h = self.hidden(feats)
+        return ops.conv3x3(h, conv1)                           # c_out = 2: the streamed head kernels (csrc/head_conv.hip)
+
+    def hidden(self, feats):
+        """relu(bn(conv0(feats))): everything in front of the head's last convolution."""
+        conv0, bn, act, conv1 = self.seg_head
+        fused = isinstance(act, nn.ReLU)
         h = ops.batch_norm_nchw(ops.exit_mixed(ops.conv3x3(feats, conv0)), bn, relu=fused)     # (mixed mode: fp32 here already, see UNet.forward)
-        return ops.conv3x3(h if fused else act(h), conv1)      # c_out = 2: the streamed head kernels (csrc/head_conv.hip)
+        return h if fused else act(h)
+
+    def sparse_rows(self, feats):
+        """The head's output as a table of rows evaluated on demand (ops.SparseConvRows): for a consumer that reads a few thousand cells of the map
+        (the ego head's key points), when the last convolution qualifies; None otherwise."""
+        h = self.hidden(feats)
+        conv1 = self.seg_head[3]
+        return ops.SparseConvRows(h, conv1) if ops.sparse_conv_available(h, conv1) else ops.nchw_as_rows(ops.exit_mixed(ops.conv3x3(h, conv1)))

@@ -222,3 +222,55 @@ def test_own_concatenation_kernel(dtype, shape, ca, cb):
         g = torch.randn_like(y)
         ga, gb = torch.autograd.grad(y, (an, bn), g)
         assert torch.equal(ga, g[:, :ca]) and torch.equal(gb, g[:, ca:])
+
+
+@pytest.mark.gpu
+def test_sparse_conv_rows_is_the_dense_convolution_at_the_selected_cells():
+    """ops.SparseConvRows.at(cells) == rows `cells` of conv(h), values and gradients (h, weight, bias), incl. cells on the border and repeated cells."""
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device='cpu').manual_seed(3)
+    n, C, O, H, W = 3, 64, 64, 20, 24
+    h = torch.randn(n, C, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    conv = torch.nn.Conv2d(C, O, 3, padding=1).to(dev)
+    cells = torch.randint(0, n * H * W, (5, 700), generator=g).to(dev)
+    cells[0, :6] = torch.tensor([0, W - 1, (H - 1) * W, H * W - 1, 5, 5], device=dev)          # corners of image 0, one cell twice
+    assert ops.sparse_conv_available(h, conv)
+    got = ops.SparseConvRows(h, conv).at(cells)
+    gy = torch.randn(5, 700, O, generator=g).to(dev)
+    gh, gw, gb = torch.autograd.grad(got, (h, conv.weight, conv.bias), gy)
+    hd = h.detach().double().requires_grad_(True)
+    wd, bd = conv.weight.detach().double().requires_grad_(True), conv.bias.detach().double().requires_grad_(True)
+    dense = torch.nn.functional.conv2d(hd, wd, bd, padding=1).permute(0, 2, 3, 1).reshape(-1, O)[cells]
+    rh, rw, rb = torch.autograd.grad(dense, (hd, wd, bd), gy.double())
+    rel = lambda a, b: float((a.double() - b).abs().max() / b.abs().max())
+    assert rel(got, dense.detach()) < 1e-5 and rel(gh, rh) < 1e-5 and rel(gw, rw) < 1e-5 and rel(gb, rb) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['fp32x3', 'mixed'])
+def test_sparse_ego_feature_head_matches_the_dense_head(mode, monkeypatch):
+    """With the device key-point sampler the ego feature head's last convolution is evaluated at the key-point cells only: same poses, loss and
+    gradients as the dense head (PCACC_SPARSE_EGO=0) on the same seed."""
+    dev = torch.device('cuda:0')
+    cfg = default_config('waymo', 'train', n_sweeps=3, xy_range=16)
+    cfg['misc']['compute_dtype'] = mode
+    cfg['pose_estimation']['kpt_sampler'] = 'device'
+    inp = make_batch(cfg, [61, 62], 3, 6000)
+    inp = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}
+    res = {}
+    for flag in ('0', '1'):
+        monkeypatch.setenv('PCACC_SPARSE_EGO', flag)
+        model = _model(cfg, dev)
+        torch.manual_seed(11)
+        out = model(inp)
+        stats = FuseLoss(cfg['loss'])(out, inp)
+        stats['loss'].backward()
+        res[flag] = (out['ego_motion_est'].detach().clone(), float(stats['loss'].detach()),
+                     {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None})
+    (pose0, loss0, g0), (pose1, loss1, g1) = res['0'], res['1']
+    assert float((pose0 - pose1).abs().max()) < 1e-4 and abs(loss0 - loss1) < 1e-4 * abs(loss0)
+    assert g0.keys() == g1.keys()
+    total = float(torch.sqrt(sum((g.double() ** 2).sum() for g in g0.values())))
+    bad = [(k, float((g1[k] - g0[k]).norm()) / float(g0[k].norm())) for k in g0
+           if float(g0[k].norm()) > 1e-5 * total and float((g1[k] - g0[k]).norm()) > 5e-2 * float(g0[k].norm())]      # (the STPN's temporal-conv biases move by 2 % for poses that differ by 1e-5: the known sensitive group)
+    assert not bad, bad[:8]

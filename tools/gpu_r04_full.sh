@@ -1,7 +1,7 @@
 #!/bin/bash
-# the whole GPU suite (no -x: every failure listed), outputs to gpurun_out/
+# the whole GPU suite (no -x: every failure listed), then the default bench command
 mkdir -p gpurun_out
 t0=$(date +%s)
 timeout 4000 python -m pytest tests -q -m gpu > gpurun_out/t_full.txt 2>&1; tail -15 gpurun_out/t_full.txt
 echo "suite wall $(( $(date +%s) - t0 )) s"
-if [ "$1" = "2rank" ]; then bash tools/gpu_r04_2rank.sh; fi
+bash tools/gpu_default_bench.sh

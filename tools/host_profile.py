@@ -11,7 +11,7 @@ from pcaccumulation_amd.synthetic import make_sequence
 B = int(os.environ.get('BATCH', '4'))
 dev = torch.device('cuda:0')
 cfg = default_config('waymo', 'train', n_sweeps=5)
-cfg['misc']['compute_dtype'] = 'bf16'; cfg['pose_estimation']['kpt_sampler'] = 'device'
+cfg['misc']['compute_dtype'] = os.environ.get('PCACC_DTYPE', 'bf16'); cfg['pose_estimation']['kpt_sampler'] = 'device'
 model, opt, loss_fn = bench.build(cfg, dev)
 batcher = DeviceBatcher(cfg)
 scenes = [sample_to_device(make_sequence(i, 5, 160000, cfg), dev) for i in range(B)]
