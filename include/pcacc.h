@@ -498,6 +498,17 @@ int pcacc_conv3x3_wgrad_split(const float *dy, const float *dy_amax, const float
 int pcacc_upconv2x2_split_prepare_weights(const float *w, int32_t c_in, int32_t c_up, const int64_t *strides /*host*/, uint16_t *out_fwd,
                                           float *scale_fwd, uint16_t *out_bwd, float *scale_bwd, void *stream);
 int pcacc_upconv2x2_split_supported(int32_t h, int32_t w, int32_t c_in, int32_t c_up);
+
+/* Every prepared form of every weight of a model in ONE launch (a training step re-prepares ~90 forms right after the optimizer wrote the
+ * parameters -- the per-layer weight handling of the reference's nn.Conv2d / nn.Conv3d / nn.ConvTranspose2d, models/unet.py:22-113,
+ * models/stpn.py:39-70).  `jobs` = DEVICE table, 16 int64 per job:
+ *   [0] w (f32, device)  [1] out_fwd  [2] scale_fwd  [3] out_bwd  [4] scale_bwd  [5..9] strides of w in elements
+ *   [10] a  [11] b  [12] kt  [13] kind  [14] first workgroup of the job (ascending, job 0 starts at 0)  [15] workgroups of the job
+ * kind 0 = pcacc_conv3x3_split_prepare_weights   (a = c_out, b = c_in; strides o, i, t, y, x; a + b workgroups)
+ * kind 1 = pcacc_upconv2x2_split_prepare_weights (a = c_in, b = c_up; strides i, o, -, y, x; 4 b + a workgroups)
+ * kind 2 = pcacc_conv3x3_prepare_weights_pair    (a = c_out, b = c_in; strides o, i, t, y, x; any number of workgroups >= 1; no scales)
+ * with the outputs of those entry points; total_blocks = [14] + [15] of the last job. */
+int pcacc_prepare_weights_batch(const int64_t *jobs, int32_t n_jobs, int32_t total_blocks, void *stream);
 int pcacc_upconv2x2_split(const float *in, const float *in_amax, const uint16_t *wp, const float *wscale, const float *bias, float *out,
                           float *out_amax, int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_up, int32_t direction, void *stream);
 /* pcacc_upconv2x2_split (direction 0) with the bf16 shadow of its result as a second output ('mixed' mode, see pcacc_conv3x3_split_dual).

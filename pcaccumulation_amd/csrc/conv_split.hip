@@ -148,13 +148,13 @@ __device__ __forceinline__ float4 csp_relu_mask4(float4 g, float4 y)
 // the scale vector the convolution's epilogue multiplies with.
 struct CspWStrides { int64_t o, i, t, y, x; };
 
-__global__ __launch_bounds__(256) void conv_split_prepare_kernel(const float *__restrict__ w, int o, int i, int kt, CspWStrides st,
-                                                                 uint16_t *__restrict__ out_fwd, float *__restrict__ inv_fwd,
-                                                                 uint16_t *__restrict__ out_bwd, float *__restrict__ inv_bwd)
+// `blk` = the row of the two forms (o forward rows, then i data-gradient rows) this workgroup prepares
+__device__ __forceinline__ void csp_prepare_row(const float *__restrict__ w, int o, int i, int kt, CspWStrides st, uint16_t *__restrict__ out_fwd,
+                                                float *__restrict__ inv_fwd, uint16_t *__restrict__ out_bwd, float *__restrict__ inv_bwd, int blk)
 {
     const int taps = kt * 9;
-    const bool transpose = (int)blockIdx.x >= o;
-    const int row = transpose ? blockIdx.x - o : blockIdx.x;     // output channel of this form
+    const bool transpose = blk >= o;
+    const int row = transpose ? blk - o : blk;                   // output channel of this form
     const int op = transpose ? i : o, ip = transpose ? o : i;
     const int64_t total = (int64_t)taps * o * i;
     const int n = taps * ip;                                      // elements of the row: (tap, input channel of this form)
@@ -188,6 +188,13 @@ __global__ __launch_bounds__(256) void conv_split_prepare_kernel(const float *__
         dst[r] = *reinterpret_cast<const uint16_t *>(&hi);
         dst[total + r] = *reinterpret_cast<const uint16_t *>(&lo);
     }
+}
+
+__global__ __launch_bounds__(256) void conv_split_prepare_kernel(const float *__restrict__ w, int o, int i, int kt, CspWStrides st,
+                                                                 uint16_t *__restrict__ out_fwd, float *__restrict__ inv_fwd,
+                                                                 uint16_t *__restrict__ out_bwd, float *__restrict__ inv_bwd)
+{
+    csp_prepare_row(w, o, i, kt, st, out_fwd, inv_fwd, out_bwd, inv_bwd, (int)blockIdx.x);
 }
 
 extern "C" int pcacc_conv3x3_split_prepare_weights(const float *w, int32_t c_out, int32_t c_in, int32_t kt, const int64_t *strides,
@@ -1289,13 +1296,13 @@ extern "C" int pcacc_conv3x3_wgrad_split(const float *dy, const float *dy_amax, 
 // weights: w f32 [c_in][c_up][2][2] (torch layout, read through `strides`: elements i, o, y, x) ->
 //   forward form      fp16 [2][1][4 c_up][c_in]  rows co' = (a, b, co)      + 1 / row scale [4 c_up]
 //   data-gradient form fp16 [2][1][c_in][4 c_up]  columns k' = (a, b, co)    + 1 / row scale [c_in]
-__global__ __launch_bounds__(256) void upconv_split_prepare_kernel(const float *__restrict__ w, int c_in, int c_up, int64_t si, int64_t so, int64_t sy,
-                                                                   int64_t sx, uint16_t *__restrict__ out_fwd, float *__restrict__ inv_fwd,
-                                                                   uint16_t *__restrict__ out_bwd, float *__restrict__ inv_bwd)
+__device__ __forceinline__ void upconv_prepare_row(const float *__restrict__ w, int c_in, int c_up, int64_t si, int64_t so, int64_t sy, int64_t sx,
+                                                   uint16_t *__restrict__ out_fwd, float *__restrict__ inv_fwd, uint16_t *__restrict__ out_bwd,
+                                                   float *__restrict__ inv_bwd, int blk)
 {
     const int n4 = 4 * c_up;
-    const bool bwd = (int)blockIdx.x >= n4;
-    const int row = bwd ? blockIdx.x - n4 : blockIdx.x;
+    const bool bwd = blk >= n4;
+    const int row = bwd ? blk - n4 : blk;
     const int n = bwd ? n4 : c_in;                             // elements of the row
     const int64_t total = (int64_t)n4 * c_in;
     auto src = [&](int e) {
@@ -1324,6 +1331,66 @@ __global__ __launch_bounds__(256) void upconv_split_prepare_kernel(const float *
         dst[e] = *reinterpret_cast<const uint16_t *>(&hi);
         dst[total + e] = *reinterpret_cast<const uint16_t *>(&lo);
     }
+}
+
+__global__ __launch_bounds__(256) void upconv_split_prepare_kernel(const float *__restrict__ w, int c_in, int c_up, int64_t si, int64_t so, int64_t sy,
+                                                                   int64_t sx, uint16_t *__restrict__ out_fwd, float *__restrict__ inv_fwd,
+                                                                   uint16_t *__restrict__ out_bwd, float *__restrict__ inv_bwd)
+{
+    upconv_prepare_row(w, c_in, c_up, si, so, sy, sx, out_fwd, inv_fwd, out_bwd, inv_bwd, (int)blockIdx.x);
+}
+
+// ---- every prepared form of every weight of a model in ONE launch ---------------------------------------------------------------------
+// A training step prepares ~90 weight forms right after the optimizer wrote the parameters (43 split pairs + 8 transposed-convolution pairs
+// + 39 bf16 pairs in the 'mixed' mode): 90 launches of 10-20 us kernels and 90 host calls.  `jobs` is a DEVICE table of 16 int64 per
+// job (include/pcacc.h): the workgroup finds its job by bisection over the jobs' first-workgroup numbers and runs the body of the
+// single-weight kernel on it.  kind 0: csp_prepare_row; 1: upconv_prepare_row; 2: the bf16 forms of conv.hip's conv_prepare_weights_pair_kernel.
+#define PWB_FIELDS 16
+__global__ __launch_bounds__(256) void prepare_weights_batch_kernel(const int64_t *__restrict__ jobs, int n_jobs)
+{
+    int lo = 0, hi = n_jobs - 1;                               // last job whose first workgroup <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[(int64_t)mid * PWB_FIELDS + 14] <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const int64_t *j = jobs + (int64_t)lo * PWB_FIELDS;
+    const float *w = reinterpret_cast<const float *>(j[0]);
+    uint16_t *out_fwd = reinterpret_cast<uint16_t *>(j[1]);
+    float *inv_fwd = reinterpret_cast<float *>(j[2]);
+    uint16_t *out_bwd = reinterpret_cast<uint16_t *>(j[3]);
+    float *inv_bwd = reinterpret_cast<float *>(j[4]);
+    const int o = (int)j[10], i = (int)j[11], kt = (int)j[12], kind = (int)j[13];
+    const int blk = (int)blockIdx.x - (int)j[14], n_blk = (int)j[15];
+    if (blk >= n_blk) return;
+    if (kind == 0) {
+        const CspWStrides st = {j[5], j[6], j[7], j[8], j[9]};
+        csp_prepare_row(w, o, i, kt, st, out_fwd, inv_fwd, out_bwd, inv_bwd, blk);
+    } else if (kind == 1) {
+        upconv_prepare_row(w, /*c_in*/ o, /*c_up*/ i, /*si*/ j[5], /*so*/ j[6], j[8], j[9], out_fwd, inv_fwd, out_bwd, inv_bwd, blk);
+    } else {
+        const int taps = kt * 9;
+        const int64_t total = (int64_t)taps * o * i;
+        for (int64_t e = (int64_t)blk * 256 + threadIdx.x; e < 2 * total; e += (int64_t)n_blk * 256) {
+            const bool transpose = e >= total;
+            const int64_t r = transpose ? e - total : e;
+            const int op = transpose ? i : o, ip = transpose ? o : i;
+            const int ci = (int)(r % ip);
+            const int co = (int)((r / ip) % op);
+            const int tap = (int)(r / ((int64_t)ip * op));
+            const int src_tap = transpose ? (taps - 1 - tap) : tap;
+            const int so = transpose ? ci : co, si = transpose ? co : ci;
+            const int ft = src_tap / 9, fy = (src_tap % 9) / 3, fx = src_tap % 3;
+            (transpose ? out_bwd : out_fwd)[r] = f32_to_bf16(w[so * j[5] + si * j[6] + ft * j[7] + fy * j[8] + fx * j[9]]);
+        }
+    }
+}
+
+extern "C" int pcacc_prepare_weights_batch(const int64_t *jobs, int32_t n_jobs, int32_t total_blocks, void *stream)
+{
+    if (!jobs || n_jobs < 1 || total_blocks < 1) return PCACC_E_ARG;
+    hipLaunchKernelGGL(prepare_weights_batch_kernel, dim3(total_blocks), dim3(256), 0, pcacc_stream(stream), jobs, n_jobs);
+    PCACC_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int pcacc_upconv2x2_split_prepare_weights(const float *w, int32_t c_in, int32_t c_up, const int64_t *strides, uint16_t *out_fwd,

@@ -65,7 +65,7 @@ EXPORTS = [
     'pcacc_conv3x3_split_prepare_weights', 'pcacc_conv3x3_split_supported', 'pcacc_conv3x3_split', 'pcacc_conv3x3_wgrad_split_workspace_bytes',
     'pcacc_conv3x3_wgrad_split', 'pcacc_absmax256',
     'pcacc_rows_linear_split', 'pcacc_rows_linear_cat_split', 'pcacc_rows_wgrad_split_workspace_bytes', 'pcacc_rows_wgrad_split',
-    'pcacc_rows_wgrad_cat_split', 'pcacc_upconv2x2_split_prepare_weights', 'pcacc_upconv2x2_split_supported', 'pcacc_upconv2x2_split',
+    'pcacc_rows_wgrad_cat_split', 'pcacc_upconv2x2_split_prepare_weights', 'pcacc_prepare_weights_batch', 'pcacc_upconv2x2_split_supported', 'pcacc_upconv2x2_split',
     'pcacc_upconv2x2_wgrad_split_workspace_bytes', 'pcacc_upconv2x2_wgrad_split',
     'pcacc_head_conv3x3_supported', 'pcacc_head_conv3x3_forward', 'pcacc_head_conv3x3_dgrad', 'pcacc_head_conv3x3_wgrad',
     'pcacc_head_conv3x3_wgrad_workspace_bytes',
@@ -823,6 +823,13 @@ def upconv2x2_split_prepare_weights(weight):
     _check(lib().pcacc_upconv2x2_split_prepare_weights(ctypes.c_void_p(weight.data_ptr()), int(ci), int(cu), strides, _dev(fwd), _dev(sf), _dev(bwd),
                                                        _dev(sb), _stream()), 'upconv2x2_split_prepare_weights')
     return (fwd, sf), (bwd, sb)
+
+
+def prepare_weights_batch(jobs, n_jobs, total_blocks):
+    """jobs: int64 GPU tensor [n_jobs, 16] (include/pcacc.h: pcacc_prepare_weights_batch) -- every prepared form of every listed weight, one launch."""
+    if not jobs.is_cuda or jobs.dtype != torch.int64 or not jobs.is_contiguous() or jobs.numel() != 16 * n_jobs:
+        raise NativeError('prepare_weights_batch: jobs must be a contiguous int64 GPU tensor [n_jobs, 16]')
+    _check(lib().pcacc_prepare_weights_batch(ctypes.c_void_p(jobs.data_ptr()), int(n_jobs), int(total_blocks), _stream()), 'prepare_weights_batch')
 
 
 def upconv2x2_split(x_rows, amax, wps, bias, direction, want_bf16=False, into=None):

@@ -1059,6 +1059,89 @@ def _weight_ref(cache, key, weight):
     return weakref.ref(weight, lambda _r, c=cache, k=key: c.pop(k, None))
 
 
+# ---- every prepared form a step needs, in one launch --------------------------------------------------------------------------------
+# The per-weight caches below miss once per weight and optimizer step: ~90 host calls and launches of 10-20 us kernels at the start of a
+# 'mixed' training step.  The first miss after the weights changed (a new weight epoch) instead re-prepares EVERY form the process has
+# asked for so far (weights still alive, fp32, on that device) with one launch into buffers that stay allocated
+# (native.prepare_weights_batch), and fills all three caches; a miss for any other reason (a version change inside an epoch, a weight
+# seen for the first time) takes the per-weight path as before.  PCACC_BATCH_PREPARE=0 switches it off.
+_BATCH_ON = os.environ.get('PCACC_BATCH_PREPARE', '1') != '0'
+_BATCH_SEEN = {}            # (id(weight), kind) -> weak reference; kind 0 = split 3x3, 1 = split transposed 2x2, 2 = bf16 3x3
+_BATCH_STATE = {}           # device index -> {'sig', 'jobs', 'n', 'blocks', 'forms': [(ref, kind, fwd, bwd)], 'epoch'}
+
+
+def _batch_note(weight, kind):
+    k = (id(weight), kind)
+    if _BATCH_ON and k not in _BATCH_SEEN and weight.is_cuda and weight.dtype == torch.float32:
+        _BATCH_SEEN[k] = weakref.ref(weight, lambda _r, k=k: _BATCH_SEEN.pop(k, None))
+
+
+def _batch_build(dev, live):
+    import numpy as np
+    jobs = np.zeros((len(live), 16), dtype=np.int64)
+    forms, b0 = [], 0
+    for row, (ref, w, kind) in zip(jobs, live):
+        st = w.stride()
+        if kind == 1:
+            a, b, kt = w.shape[0], w.shape[1], 1                                # c_in, c_up
+            fwd = (torch.empty((2, 4 * b, a), dtype=torch.float16, device=dev), torch.empty((4 * b,), dtype=torch.float32, device=dev))
+            bwd = (torch.empty((2, a, 4 * b), dtype=torch.float16, device=dev), torch.empty((a,), dtype=torch.float32, device=dev))
+            strides, blocks = (st[0], st[1], 0, st[2], st[3]), 4 * b + a
+        else:
+            a, b, kt = w.shape[0], w.shape[1], (3 if w.dim() == 5 else 1)       # c_out, c_in
+            strides = tuple(st) if kt == 3 else (st[0], st[1], 0, st[2], st[3])
+            if kind == 0:
+                fwd = (torch.empty((2, kt * 9, a, b), dtype=torch.float16, device=dev), torch.empty((a,), dtype=torch.float32, device=dev))
+                bwd = (torch.empty((2, kt * 9, b, a), dtype=torch.float16, device=dev), torch.empty((b,), dtype=torch.float32, device=dev))
+                blocks = a + b
+            else:
+                fwd = torch.empty((kt * 9, a, b), dtype=torch.bfloat16, device=dev)
+                bwd = torch.empty((kt * 9, b, a), dtype=torch.bfloat16, device=dev)
+                blocks = min(512, max(1, (2 * kt * 9 * a * b + 2047) // 2048))
+        ptrs = (fwd[0].data_ptr(), fwd[1].data_ptr(), bwd[0].data_ptr(), bwd[1].data_ptr()) if kind != 2 else (fwd.data_ptr(), 0, bwd.data_ptr(), 0)
+        row[:] = (w.data_ptr(),) + ptrs + strides + (a, b, kt, kind, b0, blocks)
+        b0 += blocks
+        forms.append((ref, kind, fwd, bwd))
+    return {'jobs': torch.from_numpy(jobs).to(dev), 'n': len(live), 'blocks': b0, 'forms': forms}
+
+
+def _batch_refresh(dev):
+    """-> True if every known form on `dev` was (re)prepared for the current weight epoch by this call."""
+    state = _BATCH_STATE.get(dev.index)
+    if state is not None and state['epoch'] == _WEIGHT_EPOCH:
+        return False
+    live = []
+    for (_, kind), ref in list(_BATCH_SEEN.items()):
+        w = ref()
+        if w is not None and w.is_cuda and w.device == dev and w.dtype == torch.float32:
+            live.append((ref, w, kind))
+    if len(live) < 2:
+        return False
+    sig = tuple((id(w), kind, w.data_ptr(), w.stride()) for _, w, kind in live)
+    if state is None or state['sig'] != sig:
+        state = _batch_build(dev, live)
+        state['sig'] = sig
+        _BATCH_STATE[dev.index] = state
+    native.prepare_weights_batch(state['jobs'], state['n'], state['blocks'])
+    state['epoch'] = _WEIGHT_EPOCH
+    caches = (_PREPARED_SPLIT, _PREPARED_UP, _PREPARED)
+    for ref, kind, fwd, bwd in state['forms']:
+        w = ref()
+        if w is not None:
+            caches[kind][id(w)] = (_weight_ref(caches[kind], id(w), w), _weight_key(w), fwd, bwd)
+    return True
+
+
+def _batch_hit(cache, weight, kind):
+    """The prepared forms of `weight` out of a batch refresh, or None (the caller then prepares this weight alone)."""
+    if not (_BATCH_ON and (id(weight), kind) in _BATCH_SEEN and _batch_refresh(weight.device)):
+        return None
+    hit = cache.get(id(weight))
+    if hit is not None and hit[0]() is weight and hit[1] == _weight_key(weight):
+        return hit[2], hit[3]
+    return None
+
+
 def prepared_conv_weights(weight):
     """(forward form, data-gradient form) of a 3x3 / 3x3x3 weight for the MFMA kernels, prepared once per weight VERSION and weight
     epoch (weights_may_have_changed): the forward of a training step and its backward share one launch, evaluation passes reuse the forms
@@ -1067,6 +1150,10 @@ def prepared_conv_weights(weight):
     hit = _PREPARED.get(key)
     if hit is not None and hit[0]() is weight and hit[1] == _weight_key(weight):
         return hit[2], hit[3]
+    got = _batch_hit(_PREPARED, weight, 2)
+    if got is not None:
+        return got
+    _batch_note(weight, 2)
     w = weight.detach()
     if w.dtype != torch.float32:
         w = w.float()
@@ -1162,6 +1249,10 @@ def prepared_conv_weights_split(weight):
     hit = _PREPARED_SPLIT.get(key)
     if hit is not None and hit[0]() is weight and hit[1] == _weight_key(weight):
         return hit[2], hit[3]
+    got = _batch_hit(_PREPARED_SPLIT, weight, 0)
+    if got is not None:
+        return got
+    _batch_note(weight, 0)
     w = weight.detach()
     if w.dtype != torch.float32:
         w = w.float()
@@ -1246,6 +1337,10 @@ def prepared_upconv_weights_split(weight):
     hit = _PREPARED_UP.get(key)
     if hit is not None and hit[0]() is weight and hit[1] == _weight_key(weight):
         return hit[2], hit[3]
+    got = _batch_hit(_PREPARED_UP, weight, 1)
+    if got is not None:
+        return got
+    _batch_note(weight, 1)
     fwd, bwd = native.upconv2x2_split_prepare_weights(weight.detach())
     if len(_PREPARED_UP) > 4096:
         _PREPARED_UP.clear()
