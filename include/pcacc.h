@@ -174,6 +174,12 @@ int pcacc_rows_linear(const float *x, const float *in_mask, const float *w, cons
 int pcacc_rows_wgrad(const float *dy, const float *dy_mask, const float *x, int x_relu, int64_t rows, int k, int n,
                      float *dw_aug, void *stream);
 
+/* 'mixed' mode, k <= 9 inputs (the position layer of the pillar encoder, models/pillar_encoder.py:100-108): pcacc_rows_linear on f32 rows in plain
+ * fp32 arithmetic with two more outputs from the same store phase: y16 = y as bf16 [rows][n], y_amax = 256 partial absolute maxima of y
+ * (zero-filled by the caller; layout of pcacc_absmax256).  n in {8,16,32,64,128}; flags as pcacc_rows_linear. */
+int pcacc_rows_linear_few_dual(const float *x, const float *w, const float *bias, const float *residual, float *y, uint16_t *y16,
+                               float *y_amax, int64_t rows, int k, int n, int flags, void *stream);
+
 /* bf16 compute mode of the same layers (cfg misc.compute_dtype = bf16): rows stored as bf16, fp32 accumulation.
  *   pcacc_rows_linear_bf16: x, in_mask, residual, out_mask, y all bf16; k, n in {32, 64, 128}; w, bias f32 (rounded to
  *     bf16 once per launch); the product runs on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16).

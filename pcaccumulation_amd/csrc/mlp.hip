@@ -178,11 +178,13 @@ template <int K, int G>
 __global__ __launch_bounds__(256) void rows_linear_fewk_kernel(const void *__restrict__ X, const void *__restrict__ in_mask,
                                                                const float *__restrict__ W, const float *__restrict__ bias,
                                                                const void *__restrict__ residual, const void *__restrict__ out_mask,
-                                                               void *__restrict__ Y, int64_t rows, int flags, int dt)
+                                                               void *__restrict__ Y, int64_t rows, int flags, int dt,
+                                                               uint16_t *__restrict__ Y16 = nullptr, float *__restrict__ out_amax = nullptr)
 {
     const bool x_bf = dt & MLP_X_BF16, im_bf = dt & MLP_INMASK_BF16, r_bf = dt & MLP_RES_BF16, om_bf = dt & MLP_OUTMASK_BF16,
                y_bf = dt & MLP_Y_BF16;
     constexpr int N = 8 * G, RB = 256 / G, NL = (K + G - 1) / G;      // rows per workgroup pass, loads per lane and row
+    float omax = 0.f;                                                 // Y16 / out_amax ('mixed' mode, fp32 Y): bf16 copy of Y and its 256 partial maxima
     const int g = threadIdx.x % G, rsub = threadIdx.x / G;
     const int lane = threadIdx.x & 63, rowbase = lane - g;
     const int n0 = g * 8;
@@ -248,8 +250,18 @@ __global__ __launch_bounds__(256) void rows_linear_fewk_kernel(const void *__res
                     if (!(mk.w > 0.f)) v.w = 0.f;
                 }
                 pcacc_st4(Y, y_bf, g4 + h, v);
+                if (Y16) reinterpret_cast<uint2 *>(Y16)[g4 + h] = make_uint2(pcacc_pack_bf16x2(v.x, v.y), pcacc_pack_bf16x2(v.z, v.w));
+                if (out_amax) {
+                    omax = fmaxf(fmaxf(omax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                    if (!(v.x == v.x && v.y == v.y && v.z == v.z && v.w == v.w)) omax = __builtin_inff();
+                }
             }
         }
+    }
+    if (out_amax) {                                                   // uniform: one atomic per wave into one of the 256 slots (zeroed by the caller)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) omax = fmaxf(omax, __shfl_xor(omax, d, 64));
+        if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned *>(out_amax) + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 255), __float_as_uint(omax));
     }
 }
 
@@ -317,7 +329,8 @@ __global__ __launch_bounds__(256) void rows_linear_fewn_kernel(const void *__res
 static bool mlp_k_supported(int k) { return k == 2 || k == 3 || k == 4 || k == 9 || k == 32 || k == 64 || k == 128; }
 
 static int rows_linear_any(const void *x, const void *in_mask, const float *w, const float *bias, const void *residual,
-                           const void *out_mask, void *y, int64_t rows, int k, int n, int flags, int dt, void *stream)
+                           const void *out_mask, void *y, int64_t rows, int k, int n, int flags, int dt, void *stream, uint16_t *y16 = nullptr,
+                           float *y_amax = nullptr)
 {
     if (rows < 0 || n <= 0 || n > 128 || !mlp_k_supported(k)) return PCACC_E_ARG;
     if (rows == 0) return PCACC_OK;
@@ -325,7 +338,7 @@ static int rows_linear_any(const void *x, const void *in_mask, const float *w, c
     hipStream_t s = pcacc_stream(stream);
     if (k <= 9 && (n == 8 || n == 16 || n == 32 || n == 64 || n == 128)) {   // few inputs: lane per (row, 8 outputs)
         const int grid = pcacc_grid(rows * (n / 8), 256 * FEW_U, PCACC_CUS * 8);
-#define FEWK(KK, GG) rows_linear_fewk_kernel<KK, GG><<<grid, 256, 0, s>>>(x, in_mask, w, bias, residual, out_mask, y, rows, flags, dt)
+#define FEWK(KK, GG) rows_linear_fewk_kernel<KK, GG><<<grid, 256, 0, s>>>(x, in_mask, w, bias, residual, out_mask, y, rows, flags, dt, y16, y_amax)
 #define FEWK_G(KK) do { switch (n) { case 8: FEWK(KK, 1); break; case 16: FEWK(KK, 2); break; case 32: FEWK(KK, 4); break; \
                                      case 64: FEWK(KK, 8); break; default: FEWK(KK, 16); break; } } while (0)
         if (k == 2) FEWK_G(2);
@@ -337,6 +350,7 @@ static int rows_linear_any(const void *x, const void *in_mask, const float *w, c
         PCACC_CHECK_LAUNCH();
         return PCACC_OK;
     }
+    if (y16 || y_amax) return PCACC_E_ARG;                         // the second output exists in the few-input kernel only
     if (n <= 2 && k >= 32) {                                       // few outputs: k/8 lanes per row
         const int grid = pcacc_grid(rows * (k / 8), 256, PCACC_CUS * 16);
 #define FEWN(KK, NN) rows_linear_fewn_kernel<KK, NN><<<grid, 256, 0, s>>>(x, in_mask, w, bias, residual, out_mask, y, rows, flags, dt)
@@ -377,6 +391,16 @@ extern "C" int pcacc_rows_linear(const float *x, const float *in_mask, const flo
                                  const float *out_mask, float *y, int64_t rows, int k, int n, int flags, void *stream)
 {
     return rows_linear_any(x, in_mask, w, bias, residual, out_mask, y, rows, k, n, flags, 0, stream);
+}
+
+// 'mixed' mode, few inputs (k <= 9: the 9 -> 64 position layer of the pillar encoder, models/pillar_encoder.py:100-108): fp32 rows in exact fp32
+// arithmetic (no matrix cores: 9 FMAs per output), the bf16 shadow of the result and its 256 partial maxima from the same store phase
+// (y_amax zero-filled by the caller) -- a copy pass and a maximum pass over 3.2 M x 64 values less.
+extern "C" int pcacc_rows_linear_few_dual(const float *x, const float *w, const float *bias, const float *residual, float *y, uint16_t *y16,
+                                          float *y_amax, int64_t rows, int k, int n, int flags, void *stream)
+{
+    if (k > 9 || !(n == 8 || n == 16 || n == 32 || n == 64 || n == 128) || !y16 || !y_amax) return PCACC_E_ARG;
+    return rows_linear_any(x, nullptr, w, bias, residual, nullptr, y, rows, k, n, flags, 0, stream, y16, y_amax);
 }
 
 extern "C" int pcacc_rows_linear_mixed(const void *x, const void *in_mask, const float *w, const float *bias, const void *residual,

@@ -39,7 +39,7 @@ def lib():
 
 # every symbol include/pcacc.h declares (tests check the .so exports exactly these)
 EXPORTS = [
-    'pcacc_reload_switches', 'pcacc_cat2_rows', 'pcacc_collate_voxelize_workspace_bytes', 'pcacc_collate_voxelize', 'pcacc_rows_linear_split_dual', 'pcacc_pfn_block_split_forward_dual', 'pcacc_pool_skip_relu_backward_strided_y32', 'pcacc_conv3x3_split_dual', 'pcacc_upconv2x2_split_dual', 'pcacc_voxelize_workspace_bytes', 'pcacc_voxelize', 'pcacc_cell_index',
+    'pcacc_reload_switches', 'pcacc_cat2_rows', 'pcacc_collate_voxelize_workspace_bytes', 'pcacc_collate_voxelize', 'pcacc_rows_linear_split_dual', 'pcacc_rows_linear_few_dual', 'pcacc_pfn_block_split_forward_dual', 'pcacc_pool_skip_relu_backward_strided_y32', 'pcacc_conv3x3_split_dual', 'pcacc_upconv2x2_split_dual', 'pcacc_voxelize_workspace_bytes', 'pcacc_voxelize', 'pcacc_cell_index',
     'pcacc_frame_pillars_workspace_bytes', 'pcacc_frame_pillars',
     'pcacc_csr_workspace_bytes', 'pcacc_csr_build', 'pcacc_segment_mean3_maxlabel',
     'pcacc_segment_workspace_bytes', 'pcacc_segment_max', 'pcacc_segment_max_backward', 'pcacc_segment_sum', 'pcacc_scatter_sum_small',
@@ -948,6 +948,21 @@ def rows_linear_split(x, x_amax, w, bias=None, residual=None, pre_relu=False, po
                                          _opt(out_mask, torch.float32, 'out_mask'), _dev(y), _opt(y_amax, torch.float32, 'y_amax'), _i64(rows), int(k),
                                          int(n), flags, _stream()), 'rows_linear_split')
     return (y, y_amax) if want_amax else y
+
+
+def rows_linear_few_dual(x, w, bias=None, residual=None, pre_relu=False, post_relu=False):
+    """rows_linear on f32 rows with k <= 9 inputs in plain fp32 arithmetic -> (y f32, absmax256 array of y, y as bf16), one store phase
+    ('mixed' mode: the pillar encoder's position layer)."""
+    rows, k = x.shape
+    n = w.shape[0]
+    y = torch.empty((rows, n), dtype=torch.float32, device=x.device)
+    y16 = torch.empty((rows, n), dtype=torch.bfloat16, device=x.device)
+    y_amax = _zero256(x.device)
+    flags = (1 if pre_relu else 0) | (2 if post_relu else 0)
+    _check(lib().pcacc_rows_linear_few_dual(_dev(x, torch.float32, 'x'), _dev(w, torch.float32, 'w'), _opt(bias, torch.float32, 'bias'),
+                                            _opt(residual, torch.float32, 'residual'), _dev(y), _dev(y16), _dev(y_amax), _i64(rows), int(k), int(n),
+                                            flags, _stream()), 'rows_linear_few_dual')
+    return y, y_amax, y16
 
 
 def rows_wgrad_split(dy, dy_amax, x, x_amax, dy_mask=None, x_relu=False, split=False):

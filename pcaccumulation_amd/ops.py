@@ -415,6 +415,10 @@ class _RowsLinearMixed(_RowsLinear):
             y32, y_amax, y16 = native.rows_linear_split(x32, amax_of(x32), w, bias, res32, pre_relu, post_relu, want_bf16=True)   # shadow from the same epilogue
             set_amax_tag(y32, y_amax)
             y = shadow(y32, y16)
+        elif k <= 9 and n in (8, 16, 32, 64, 128) and w.dtype == torch.float32 and x32.dtype == torch.float32:
+            y32, y_amax, y16 = native.rows_linear_few_dual(x32, w, bias, res32, pre_relu, post_relu)      # plain fp32 FMAs; shadow + maxima from the store phase
+            set_amax_tag(y32, y_amax)
+            y = shadow(y32, y16)
         else:
             y32 = native.rows_linear(x32, w, bias, res32, pre_relu, post_relu, out_dtype=torch.float32)
             y = shadow(y32)
@@ -846,6 +850,8 @@ def cat_maps(tensors, dim=1):
     if _MIXED and y.dtype == torch.bfloat16:
         tw = [twin(t) for t in tensors]
         y32 = merge_amax(_cat2(tw[0], tw[1], dim), *tw)
+        if y32._base is not None and y32._base.numel() == y32.numel():        # a permuted view of the whole concatenation: the consumer's view of the
+            carry_amax(y32, y32._base)                                        # twin is rebuilt from the storage and finds the tag on the base only
         if _POISON:
             with torch.no_grad():
                 y.fill_(float('nan'))

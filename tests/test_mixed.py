@@ -206,6 +206,56 @@ def test_rows_linear_second_output_is_the_rounded_first(k, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('k,n', [(9, 64), (3, 32), (4, 128), (2, 8)])
+@pytest.mark.parametrize('relu', [False, True])
+def test_few_input_rows_second_output_and_maxima(k, n, relu):
+    """pcacc_rows_linear_few_dual: the fp32 result is pcacc_rows_linear's bit for bit, the bf16 output its rounding, the 256 partial maxima bound
+    it exactly (the maximum of the array == the maximum of |y|)."""
+    from pcaccumulation_amd import native
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device='cpu').manual_seed(7 * k + n)
+    rows = 70001
+    x = torch.randn(rows, k, generator=g).to(dev)
+    w, b = torch.randn(n, k, generator=g).to(dev), torch.randn(n, generator=g).to(dev)
+    res = torch.randn(rows, n, generator=g).to(dev) if relu else None
+    ref = native.rows_linear(x, w, b, res, relu, relu, out_dtype=torch.float32)
+    y, ya, y16 = native.rows_linear_few_dual(x, w, b, res, relu, relu)
+    assert torch.equal(y, ref) and torch.equal(y16, ref.to(torch.bfloat16))
+    assert ya.shape == (256,) and float(ya.max()) == float(ref.abs().max())
+    x[5, 0] = float('nan')
+    _, ya, _ = native.rows_linear_few_dual(x, w, b, None, False, False)
+    assert float(ya.max()) == float('inf')                      # a NaN anywhere poisons the scale the way pcacc_absmax256 does
+
+
+@pytest.mark.gpu
+def test_concatenated_twin_keeps_its_maxima():
+    """ops.cat_maps in the mixed mode: the consumer's view of the concatenated twin (rebuilt from the storage) finds the merged maxima -- no pass over it."""
+    dev = torch.device('cuda:0')
+    ops.set_split(True)
+    ops.set_mixed(True)
+    try:
+        tw = [torch.randn(2, 8, 8, 32, device=dev) for _ in range(2)]
+        sh = []
+        for t in tw:
+            ops.set_amax_tag(t, native_absmax(t))
+            sh.append(ops.shadow(t).permute(0, 3, 1, 2))
+        y = ops.cat_maps(sh, 1)
+        rows = y.permute(0, 2, 3, 1)
+        t32 = ops.twin(rows)
+        tag = ops.amax_tag(t32)
+        assert tag is not None and float(tag.max()) == float(torch.cat(tw, -1).abs().max())
+    finally:
+        ops.set_mixed(False)
+        ops.set_split(False)
+        ops.twins_clear()
+
+
+def native_absmax(t):
+    from pcaccumulation_amd import native
+    return native.absmax256(t)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('shape,ca,cb', [((3, 17, 9), 32, 32), ((2, 36, 36), 256, 256), ((5000,), 64, 64), ((4, 8, 8), 8, 24)])
 def test_own_concatenation_kernel(dtype, shape, ca, cb):
