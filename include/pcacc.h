@@ -485,6 +485,12 @@ int pcacc_conv3x3_split_dual(const float *in, const float *in_amax, const float 
 
 /* The same convolution (no bias, no ReLU; in_mask as above) with its result stored as zero where out_mask [n_img,h,w,c_out] f32 is <= 0: the
  * data gradient of conv -> ReLU -> conv masked for the first ReLU in the epilogue (the fp32x3 twin of pcacc_conv3x3_outmask_bf16). */
+/* pcacc_conv3x3_split_dual (kt = 1, no input mask) on the channel concatenation of TWO inputs read in place: in_a [n_img][h][w][c_a], in_b
+ * [n_img][h][w][c_in - c_a] -- conv1(cat(upconv(x), skip)) of a decoder stage (models/unet.py:101-113) without writing the fp32 concatenation.
+ * in_amax bounds both inputs (element-wise maximum of their pcacc_absmax256 arrays); out16 may be NULL; c_a and c_in - c_a multiples of 32. */
+int pcacc_conv3x3_split_cat(const float *in_a, const float *in_b, int32_t c_a, const float *in_amax, const uint16_t *wp, const float *wscale,
+                            const float *bias, float *out, float *out_amax, uint16_t *out16, int32_t n_img, int32_t h, int32_t w, int32_t c_in,
+                            int32_t c_out, int32_t relu, void *stream);
 int pcacc_conv3x3_split_outmask(const float *in, const float *in_amax, const float *in_mask, const uint16_t *wp, const float *wscale,
                                 const float *out_mask, float *out, float *out_amax, int32_t n_img, int32_t frames, int32_t h, int32_t w,
                                 int32_t c_in, int32_t c_out, int32_t kt, void *stream);
@@ -505,6 +511,26 @@ int pcacc_upconv2x2_split_prepare_weights(const float *w, int32_t c_in, int32_t 
                                           float *scale_fwd, uint16_t *out_bwd, float *scale_bwd, void *stream);
 int pcacc_upconv2x2_split_supported(int32_t h, int32_t w, int32_t c_in, int32_t c_up);
 
+/* The same layer (nn.ConvTranspose2d(kernel 2, stride 2), models/unet.py:22-30,101-113) on bf16 channels-last rows -- the bf16 compute mode's forward
+ * and backward, the 'mixed' mode's backward -- on the bf16 matrix cores, fp32 accumulation.  c_in a multiple of 64, c_up a multiple of 32.
+ *   prepare_weights: w f32 [c_in][c_up][2][2] through `strides` (host, elements: i, o, y, x) -> out_fwd bf16 [4 c_up][c_in] (rows (a, b, co)),
+ *       out_bwd bf16 [c_in][4 c_up]
+ *   upconv2x2_bf16: direction 0: in [n,h,w,c_in] (pixel pitch in_pitch >= c_in elements), wp = out_fwd -> out [n,2h,2w,c_up] (pixel pitch out_pitch),
+ *       + bias[c_up] (f32, may be NULL); direction 1: in = dy [n,2h,2w,c_up] (pixel pitch in_pitch: dy may be a channel slice of a wider map),
+ *       wp = out_bwd -> out [n,h,w,c_in] (pixel pitch out_pitch).  Pitches are multiples of 8 elements, pointers 16-byte aligned.
+ *   wgrad: dy as above, x [n,h,w,c_in] (pitch x_pitch) -> dw f32 [c_in][c_up][2][2] written through `dw_strides` (host, elements: i, o, y, x -- the
+ *       layout of the weight the gradient belongs to; NULL = contiguous), db f32 [c_up] (may be NULL); workspace from
+ *       pcacc_upconv2x2_bf16_wgrad_workspace_bytes. */
+int pcacc_upconv2x2_bf16_supported(int32_t c_in, int32_t c_up);
+int pcacc_upconv2x2_bf16_prepare_weights(const float *w, int32_t c_in, int32_t c_up, const int64_t *strides /*host*/, uint16_t *out_fwd,
+                                         uint16_t *out_bwd, void *stream);
+int pcacc_upconv2x2_bf16(const uint16_t *in, const uint16_t *wp, const float *bias, uint16_t *out, int32_t n_img, int32_t h, int32_t w,
+                         int32_t c_in, int32_t c_up, int32_t direction, int32_t in_pitch, int32_t out_pitch, void *stream);
+int pcacc_upconv2x2_bf16_wgrad_workspace_bytes(int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_up, size_t *bytes);
+int pcacc_upconv2x2_bf16_wgrad(const uint16_t *dy, int32_t dy_pitch, const uint16_t *x, int32_t x_pitch, float *dw, const int64_t *dw_strides /*host*/,
+                               float *db, int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_up, void *workspace, size_t workspace_bytes,
+                               void *stream);
+
 /* Every prepared form of every weight of a model in ONE launch (a training step re-prepares ~90 forms right after the optimizer wrote the
  * parameters -- the per-layer weight handling of the reference's nn.Conv2d / nn.Conv3d / nn.ConvTranspose2d, models/unet.py:22-113,
  * models/stpn.py:39-70).  `jobs` = DEVICE table, 16 int64 per job:
@@ -513,6 +539,7 @@ int pcacc_upconv2x2_split_supported(int32_t h, int32_t w, int32_t c_in, int32_t 
  * kind 0 = pcacc_conv3x3_split_prepare_weights   (a = c_out, b = c_in; strides o, i, t, y, x; a + b workgroups)
  * kind 1 = pcacc_upconv2x2_split_prepare_weights (a = c_in, b = c_up; strides i, o, -, y, x; 4 b + a workgroups)
  * kind 2 = pcacc_conv3x3_prepare_weights_pair    (a = c_out, b = c_in; strides o, i, t, y, x; any number of workgroups >= 1; no scales)
+ * kind 3 = pcacc_upconv2x2_bf16_prepare_weights  (a = c_in, b = c_up; strides i, o, -, y, x; any number of workgroups >= 1; no scales)
  * with the outputs of those entry points; total_blocks = [14] + [15] of the last job. */
 int pcacc_prepare_weights_batch(const int64_t *jobs, int32_t n_jobs, int32_t total_blocks, void *stream);
 int pcacc_upconv2x2_split(const float *in, const float *in_amax, const uint16_t *wp, const float *wscale, const float *bias, float *out,

@@ -232,7 +232,8 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float 
                                                                     float *__restrict__ out, float *__restrict__ out_amax, uint16_t *__restrict__ out16,
                                                                     int n_img, int frames,
                                                                     int h, int w, int c_in, int c_out, int kt, int relu, int rows, int bw,
-                                                                    int tiles_y, int tiles_x, int co_groups, int mode, int c_up, int up_pitch)
+                                                                    int tiles_y, int tiles_x, int co_groups, int mode, int c_up, int up_pitch,
+                                                                    const float *__restrict__ in2, int c_a)
 {
     constexpr int PS = CS + 8;                                 // padded LDS row (elements)
     constexpr int MG = 8 / NGW;                                // waves along the pixel dimension
@@ -297,7 +298,14 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float 
     }
     auto fetch_patch = [&](int sl) {                           // sl = index into the valid slices
         const int s = s0 + sl, f = s / nc, cs = s - f * nc;
-        const int64_t img_off = (int64_t)(img + (kt == 3 ? f - 1 : 0)) * h * w * c_in;
+        // two inputs (in2 != NULL: the decoder's cat(up, skip), models/unet.py:101-113, read in place): channels [0, c_a) of a pixel live in `in`,
+        // [c_a, c_in) in `in2`; a slice never straddles the boundary (the planner keeps CS a divisor of c_a)
+        const float *src = in;
+        int pitch = c_in, ch0p = cs * CS;
+        if (in2) {
+            if (ch0p >= c_a) { src = in2; pitch = c_in - c_a; ch0p -= c_a; } else pitch = c_a;
+        }
+        const int64_t img_off = (int64_t)(img + (kt == 3 ? f - 1 : 0)) * h * w * pitch;
         // space-to-depth source (CSP_S2D): the slice's channels (a, b, ch ..) live in pixel (2y + a, 2x + b) of the [2h, 2w, c_up] map
         const int ab = mode == CSP_S2D ? (cs * CS) / c_up : 0, ch0 = mode == CSP_S2D ? (cs * CS) % c_up : 0;
 #pragma unroll
@@ -309,8 +317,8 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float 
             const int yc = min(max(y, 0), h - 1), xc = min(max(x, 0), w - 1);
             const int64_t off = mode == CSP_S2D
                                     ? (((int64_t)img * 2 * h + 2 * yc + (ab >> 1)) * 2 * w + 2 * xc + (ab & 1)) * c_up + ch0 + c8 * 8
-                                    : img_off + ((int64_t)yc * w + xc) * c_in + cs * CS + c8 * 8;
-            float4 a = *reinterpret_cast<const float4 *>(in + off), b = *reinterpret_cast<const float4 *>(in + off + 4);
+                                    : img_off + ((int64_t)yc * w + xc) * pitch + ch0p + c8 * 8;
+            float4 a = *reinterpret_cast<const float4 *>(src + off), b = *reinterpret_cast<const float4 *>(src + off + 4);
             if (in_mask) {                                     // uniform
                 a = csp_relu_mask4(a, *reinterpret_cast<const float4 *>(in_mask + off));
                 b = csp_relu_mask4(b, *reinterpret_cast<const float4 *>(in_mask + off + 4));
@@ -486,7 +494,8 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_res_kernel(const fl
                                                                         const float *__restrict__ wscale, const float *__restrict__ bias,
                                                                         float *__restrict__ out, float *__restrict__ out_amax, uint16_t *__restrict__ out16, int n_img, int frames,
                                                                         int h, int w, int c_in, int c_out, int kt, int relu, int rows, int bw,
-                                                                        int tiles_y, int tiles_x, int co_groups, int slots)
+                                                                        int tiles_y, int tiles_x, int co_groups, int slots,
+                                                                        const float *__restrict__ in2, int c_a)
 {
     constexpr int PS = CS + 8;
     constexpr int WROWS = 32 * NW;
@@ -529,15 +538,20 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_res_kernel(const fl
     }
     auto fetch_patch = [&](const ConvTile &t, int f, int cs) __attribute__((always_inline)) {
         const int img = t.img, y0 = t.y0, x0 = t.x0;
-        const int64_t img_off = (int64_t)(img + (kt == 3 ? f - 1 : 0)) * h * w * c_in;
+        const float *src = in;                                 // two inputs: see conv3x3_split_kernel
+        int pitch = c_in, ch0p = cs * CS;
+        if (in2) {
+            if (ch0p >= c_a) { src = in2; pitch = c_in - c_a; ch0p -= c_a; } else pitch = c_a;
+        }
+        const int64_t img_off = (int64_t)(img + (kt == 3 ? f - 1 : 0)) * h * w * pitch;
 #pragma unroll
         for (int q = 0; q < PCH; ++q) {
             const int py = pinfo[q] >> 20, pxx = (pinfo[q] >> 8) & 0xfff, c8 = pinfo[q] & 0xff;
             const int y = y0 - 1 + py, x = x0 - 1 + pxx;
             const bool ok = (unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w;
             const int yc = min(max(y, 0), h - 1), xc = min(max(x, 0), w - 1);
-            const int64_t off = img_off + ((int64_t)yc * w + xc) * c_in + cs * CS + c8 * 8;
-            float4 a = *reinterpret_cast<const float4 *>(in + off), b = *reinterpret_cast<const float4 *>(in + off + 4);
+            const int64_t off = img_off + ((int64_t)yc * w + xc) * pitch + ch0p + c8 * 8;
+            float4 a = *reinterpret_cast<const float4 *>(src + off), b = *reinterpret_cast<const float4 *>(src + off + 4);
             if (in_mask) {                                     // uniform
                 a = csp_relu_mask4(a, *reinterpret_cast<const float4 *>(in_mask + off));
                 b = csp_relu_mask4(b, *reinterpret_cast<const float4 *>(in_mask + off + 4));
@@ -763,7 +777,7 @@ static bool conv_res_fits(int cs, int nw, int mt, int rows, int bw, size_t *lds)
 }
 
 // c_in, c_out in {32, 64} on maps of at least a few thousand pixels (below that the launch is latency, not throughput)
-static bool conv_res_plan(int n_img, int h, int w, int c_in, int c_out, ConvResPlan *best)
+static bool conv_res_plan(int n_img, int h, int w, int c_in, int c_out, ConvResPlan *best, int cs_must_divide = 0)
 {
     const char e = pcacc_switches().conv_res;                 // '0': never, '2': whatever the size (tests)
     if ((c_in != 32 && c_in != 64) || (c_out != 32 && c_out != 64) || e == '0') return false;
@@ -774,7 +788,7 @@ static bool conv_res_plan(int n_img, int h, int w, int c_in, int c_out, ConvResP
     for (int mt = 2; mt >= 1; --mt) {
         const int cap = 8 * mt * 32;
         for (int cs = 64; cs >= 32; cs -= 32) {
-            if (c_in % cs || !conv_res_pch(cs, nw, mt)) continue;
+            if (c_in % cs || !conv_res_pch(cs, nw, mt) || (cs_must_divide && cs_must_divide % cs)) continue;
             for (int bi = 0; bi < 4; ++bi) {
                 int bw = bi == 0 ? w : 32 * bi;
                 if (bi > 0 && bw >= w) continue;
@@ -812,13 +826,13 @@ static bool conv_res_plan(int n_img, int h, int w, int c_in, int c_out, ConvResP
 template <int CS, int NW, int MT, int PCH, bool RESTAGE>
 static int conv_res_launch(const ConvResPlan &p, const float *in, const float *in_amax, const float *in_mask, const uint16_t *wp,
                            const float *wscale, const float *bias, float *out, float *out_amax, uint16_t *out16, int n_img, int frames, int h, int w,
-                           int c_in, int c_out, int kt, int relu, hipStream_t st)
+                           int c_in, int c_out, int kt, int relu, hipStream_t st, const float *in2 = nullptr, int c_a = 0)
 {
     auto kern = conv3x3_split_res_kernel<CS, NW, MT, PCH, RESTAGE>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds) != hipSuccess)
         return PCACC_E_LAUNCH;
     hipLaunchKernelGGL(kern, dim3((unsigned)(p.co_groups * p.slots)), dim3(CSP_THREADS), p.lds, st, in, in_amax, in_mask, wp, wscale, bias, out, out_amax,
-                       out16, n_img, frames, h, w, c_in, c_out, kt, relu, p.rows, p.bw, p.tiles_y, p.tiles_x, p.co_groups, p.slots);
+                       out16, n_img, frames, h, w, c_in, c_out, kt, relu, p.rows, p.bw, p.tiles_y, p.tiles_x, p.co_groups, p.slots, in2, c_a);
     PCACC_CHECK_LAUNCH();
     return 0;
 }
@@ -890,14 +904,15 @@ static bool conv_split_plan(int n_img, int h, int w, int c_in, int c_out, int kt
 template <int CS, int NW, int NGW, int MT, int TAPS = 9>
 static int conv_split_launch(const ConvSplitPlan &p, const float *in, const float *in_amax, const float *in_mask, const uint16_t *wp,
                              const float *wscale, const float *bias, float *out, float *out_amax, uint16_t *out16, int n_img, int frames, int h, int w,
-                             int c_in, int c_out, int kt, int relu, hipStream_t st, int mode = CSP_PLAIN, int c_up = 0, int up_pitch = 0)
+                             int c_in, int c_out, int kt, int relu, hipStream_t st, int mode = CSP_PLAIN, int c_up = 0, int up_pitch = 0,
+                             const float *in2 = nullptr, int c_a = 0)
 {
     auto kern = conv3x3_split_kernel<CS, NW, NGW, MT, TAPS>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds) != hipSuccess)
         return PCACC_E_LAUNCH;
     if (p.blocks > 0x7fffffff) return PCACC_E_ARG;
     hipLaunchKernelGGL(kern, dim3((unsigned)p.blocks), dim3(CSP_THREADS), p.lds, st, in, in_amax, in_mask, wp, wscale, bias, out, out_amax, out16, n_img,
-                       frames, h, w, c_in, c_out, kt, relu, p.rows, p.bw, p.tiles_y, p.tiles_x, p.co_groups, mode, c_up, up_pitch ? up_pitch : c_up);
+                       frames, h, w, c_in, c_out, kt, relu, p.rows, p.bw, p.tiles_y, p.tiles_x, p.co_groups, mode, c_up, up_pitch ? up_pitch : c_up, in2, c_a);
     PCACC_CHECK_LAUNCH();
     return 0;
 }
@@ -910,23 +925,25 @@ extern "C" int pcacc_conv3x3_split_supported(int32_t h, int32_t w, int32_t c_in,
 
 static int conv3x3_split_impl(const float *in, const float *in_amax, const float *in_mask, const uint16_t *wp, const float *wscale,
                               const float *bias, float *out, float *out_amax, uint16_t *out16, int32_t n_img, int32_t frames, int32_t h, int32_t w,
-                              int32_t c_in, int32_t c_out, int32_t kt, int32_t relu, void *stream)
+                              int32_t c_in, int32_t c_out, int32_t kt, int32_t relu, void *stream, const float *in2 = nullptr, int32_t c_a = 0)
 {
     ConvSplitPlan p;
+    if (in2 && (c_a < 32 || c_a % 32 || c_a >= c_in || (c_in - c_a) % 32 || in_mask || kt != 1)) return PCACC_E_ARG;
+    const int divides = in2 ? ((c_a % 64 == 0 && (c_in - c_a) % 64 == 0) ? 64 : 32) : 0;       // slice width the channel boundary allows
     if (!in || !in_amax || !wp || !wscale || !out || n_img < 1 || (kt != 1 && kt != 3) || frames < 1 || n_img % frames ||
-        !conv_split_plan(n_img, h, w, c_in, c_out, kt, &p))
+        !conv_split_plan(n_img, h, w, c_in, c_out, kt, &p, 9, divides))
         return PCACC_E_ARG;
     hipStream_t st = pcacc_stream(stream);
     ConvResPlan rp;
-    if (conv_res_plan(n_img, h, w, c_in, c_out, &rp) && PCACC_WALK_OK(n_img, frames, rp.tiles_y, rp.tiles_x)) {
+    if (conv_res_plan(n_img, h, w, c_in, c_out, &rp, divides) && PCACC_WALK_OK(n_img, frames, rp.tiles_y, rp.tiles_x)) {
         if (pcacc_switches().conv_plan)
             fprintf(stderr, "split conv plan (resident) %dx%d %d->%d kt=%d n=%d: cs=%d nw=%d mt=%d rows=%d bw=%d slots=%d lds=%zu\n", h, w, c_in, c_out,
                     kt, n_img, rp.cs, rp.nw, rp.mt, rp.rows, rp.bw, rp.slots, rp.lds);
         const bool restage = kt == 3 || c_in != rp.cs;         // more than one (frame tap, channel slice) per tile
 #define CSR_CASE(CSV, NWV, MTV, PCHV)                                          \
     if (rp.cs == CSV && rp.nw == NWV && rp.mt == MTV)                          \
-        return restage ? conv_res_launch<CSV, NWV, MTV, PCHV, true>(rp, in, in_amax, in_mask, wp, wscale, bias, out, out_amax, out16, n_img, frames, h, w, c_in, c_out, kt, relu, st) \
-                       : conv_res_launch<CSV, NWV, MTV, PCHV, false>(rp, in, in_amax, in_mask, wp, wscale, bias, out, out_amax, out16, n_img, frames, h, w, c_in, c_out, kt, relu, st)
+        return restage ? conv_res_launch<CSV, NWV, MTV, PCHV, true>(rp, in, in_amax, in_mask, wp, wscale, bias, out, out_amax, out16, n_img, frames, h, w, c_in, c_out, kt, relu, st, in2, c_a) \
+                       : conv_res_launch<CSV, NWV, MTV, PCHV, false>(rp, in, in_amax, in_mask, wp, wscale, bias, out, out_amax, out16, n_img, frames, h, w, c_in, c_out, kt, relu, st, in2, c_a)
         CSR_CASE(32, 1, 1, 3); CSR_CASE(32, 2, 1, 3); CSR_CASE(32, 1, 2, 5); CSR_CASE(64, 1, 1, 6);
 #undef CSR_CASE
     }
@@ -935,7 +952,7 @@ static int conv3x3_split_impl(const float *in, const float *in_amax, const float
                 kt, n_img, p.cs, p.nw, p.ngw, p.mt, p.rows, p.bw, (long long)p.blocks, p.lds);
 #define CSP_CASE(CSV, NWV, NGWV, MTV)                                          \
     if (p.cs == CSV && p.nw == NWV && p.ngw == NGWV && p.mt == MTV)            \
-        return conv_split_launch<CSV, NWV, NGWV, MTV>(p, in, in_amax, in_mask, wp, wscale, bias, out, out_amax, out16, n_img, frames, h, w, c_in, c_out, kt, relu, st)
+        return conv_split_launch<CSV, NWV, NGWV, MTV>(p, in, in_amax, in_mask, wp, wscale, bias, out, out_amax, out16, n_img, frames, h, w, c_in, c_out, kt, relu, st, CSP_PLAIN, 0, 0, in2, c_a)
     CSP_CASE(64, 2, 2, 1); CSP_CASE(64, 2, 2, 2); CSP_CASE(64, 2, 1, 1); CSP_CASE(64, 2, 1, 2);
     CSP_CASE(64, 1, 1, 1); CSP_CASE(64, 1, 1, 2); CSP_CASE(64, 1, 1, 3);
     CSP_CASE(32, 2, 2, 1); CSP_CASE(32, 2, 2, 2); CSP_CASE(32, 2, 1, 1); CSP_CASE(32, 2, 1, 2);
@@ -959,6 +976,17 @@ extern "C" int pcacc_conv3x3_split_dual(const float *in, const float *in_amax, c
 {
     if (!out16 || relu == CSP_OUTMASK) return PCACC_E_ARG;
     return conv3x3_split_impl(in, in_amax, in_mask, wp, wscale, bias, out, out_amax, out16, n_img, frames, h, w, c_in, c_out, kt, relu, stream);
+}
+
+// the same convolution (3x3, forward) on the channel concatenation of TWO inputs read in place: in_a [n_img, h, w, c_a], in_b [n_img, h, w, c_in - c_a]
+// (the decoder's cat(upconv(x), skip), models/unet.py:101-113 -- the fp32 concatenation is never written); in_amax bounds both (the element-wise
+// maximum of their arrays); out16 may be NULL.  c_a and c_in - c_a multiples of 32.
+extern "C" int pcacc_conv3x3_split_cat(const float *in_a, const float *in_b, int32_t c_a, const float *in_amax, const uint16_t *wp, const float *wscale,
+                                       const float *bias, float *out, float *out_amax, uint16_t *out16, int32_t n_img, int32_t h, int32_t w,
+                                       int32_t c_in, int32_t c_out, int32_t relu, void *stream)
+{
+    if (!in_b || relu == CSP_OUTMASK) return PCACC_E_ARG;
+    return conv3x3_split_impl(in_a, in_amax, nullptr, wp, wscale, bias, out, out_amax, out16, n_img, 1, h, w, c_in, c_out, 1, relu, stream, in_b, c_a);
 }
 
 // the same convolution (no bias, no ReLU) with its result stored as zero where out_mask [n_img, h, w, c_out] f32 is <= 0 (see CSP_OUTMASK)
@@ -1344,7 +1372,8 @@ __global__ __launch_bounds__(256) void upconv_split_prepare_kernel(const float *
 // A training step prepares ~90 weight forms right after the optimizer wrote the parameters (43 split pairs + 8 transposed-convolution pairs
 // + 39 bf16 pairs in the 'mixed' mode): 90 launches of 10-20 us kernels and 90 host calls.  `jobs` is a DEVICE table of 16 int64 per
 // job (include/pcacc.h): the workgroup finds its job by bisection over the jobs' first-workgroup numbers and runs the body of the
-// single-weight kernel on it.  kind 0: csp_prepare_row; 1: upconv_prepare_row; 2: the bf16 forms of conv.hip's conv_prepare_weights_pair_kernel.
+// single-weight kernel on it.  kind 0: csp_prepare_row; 1: upconv_prepare_row; 2: the bf16 forms of conv.hip's conv_prepare_weights_pair_kernel;
+// 3: those of upconv_bf16.hip's upconv_bf16_prepare_kernel.
 #define PWB_FIELDS 16
 __global__ __launch_bounds__(256) void prepare_weights_batch_kernel(const int64_t *__restrict__ jobs, int n_jobs)
 {
@@ -1367,6 +1396,17 @@ __global__ __launch_bounds__(256) void prepare_weights_batch_kernel(const int64_
         csp_prepare_row(w, o, i, kt, st, out_fwd, inv_fwd, out_bwd, inv_bwd, blk);
     } else if (kind == 1) {
         upconv_prepare_row(w, /*c_in*/ o, /*c_up*/ i, /*si*/ j[5], /*so*/ j[6], j[8], j[9], out_fwd, inv_fwd, out_bwd, inv_bwd, blk);
+    } else if (kind == 3) {                                    // bf16 forms of a transposed 2 x 2 convolution (upconv_bf16.hip): o = c_in, i = c_up
+        const int n4 = 4 * i;
+        const int64_t total = (int64_t)n4 * o;
+        for (int64_t e = (int64_t)blk * 256 + threadIdx.x; e < 2 * total; e += (int64_t)n_blk * 256) {
+            const bool bwd = e >= total;
+            const int64_t r = bwd ? e - total : e;
+            const int ci = bwd ? (int)(r / n4) : (int)(r % o);
+            const int cop = bwd ? (int)(r % n4) : (int)(r / o);
+            const int ab = cop / i, co = cop - ab * i;
+            (bwd ? out_bwd : out_fwd)[r] = f32_to_bf16(w[ci * j[5] + co * j[6] + (ab >> 1) * j[8] + (ab & 1) * j[9]]);
+        }
     } else {
         const int taps = kt * 9;
         const int64_t total = (int64_t)taps * o * i;

@@ -39,7 +39,7 @@ def lib():
 
 # every symbol include/pcacc.h declares (tests check the .so exports exactly these)
 EXPORTS = [
-    'pcacc_reload_switches', 'pcacc_cat2_rows', 'pcacc_collate_voxelize_workspace_bytes', 'pcacc_collate_voxelize', 'pcacc_rows_linear_split_dual', 'pcacc_rows_linear_few_dual', 'pcacc_pfn_block_split_forward_dual', 'pcacc_pool_skip_relu_backward_strided_y32', 'pcacc_conv3x3_split_dual', 'pcacc_upconv2x2_split_dual', 'pcacc_voxelize_workspace_bytes', 'pcacc_voxelize', 'pcacc_cell_index',
+    'pcacc_reload_switches', 'pcacc_cat2_rows', 'pcacc_collate_voxelize_workspace_bytes', 'pcacc_collate_voxelize', 'pcacc_rows_linear_split_dual', 'pcacc_rows_linear_few_dual', 'pcacc_pfn_block_split_forward_dual', 'pcacc_pool_skip_relu_backward_strided_y32', 'pcacc_conv3x3_split_dual', 'pcacc_conv3x3_split_cat', 'pcacc_upconv2x2_split_dual', 'pcacc_voxelize_workspace_bytes', 'pcacc_voxelize', 'pcacc_cell_index',
     'pcacc_frame_pillars_workspace_bytes', 'pcacc_frame_pillars',
     'pcacc_csr_workspace_bytes', 'pcacc_csr_build', 'pcacc_segment_mean3_maxlabel',
     'pcacc_segment_workspace_bytes', 'pcacc_segment_max', 'pcacc_segment_max_backward', 'pcacc_segment_sum', 'pcacc_scatter_sum_small',
@@ -65,7 +65,8 @@ EXPORTS = [
     'pcacc_conv3x3_split_prepare_weights', 'pcacc_conv3x3_split_supported', 'pcacc_conv3x3_split', 'pcacc_conv3x3_wgrad_split_workspace_bytes',
     'pcacc_conv3x3_wgrad_split', 'pcacc_absmax256',
     'pcacc_rows_linear_split', 'pcacc_rows_linear_cat_split', 'pcacc_rows_wgrad_split_workspace_bytes', 'pcacc_rows_wgrad_split',
-    'pcacc_rows_wgrad_cat_split', 'pcacc_upconv2x2_split_prepare_weights', 'pcacc_prepare_weights_batch', 'pcacc_upconv2x2_split_supported', 'pcacc_upconv2x2_split',
+    'pcacc_rows_wgrad_cat_split', 'pcacc_upconv2x2_split_prepare_weights', 'pcacc_prepare_weights_batch', 'pcacc_upconv2x2_bf16_supported', 'pcacc_upconv2x2_bf16_prepare_weights', 'pcacc_upconv2x2_bf16',
+    'pcacc_upconv2x2_bf16_wgrad_workspace_bytes', 'pcacc_upconv2x2_bf16_wgrad', 'pcacc_upconv2x2_split_supported', 'pcacc_upconv2x2_split',
     'pcacc_upconv2x2_wgrad_split_workspace_bytes', 'pcacc_upconv2x2_wgrad_split',
     'pcacc_head_conv3x3_supported', 'pcacc_head_conv3x3_forward', 'pcacc_head_conv3x3_dgrad', 'pcacc_head_conv3x3_wgrad',
     'pcacc_head_conv3x3_wgrad_workspace_bytes',
@@ -809,6 +810,25 @@ def upconv2x2_split_supported(h, w, c_in, c_up):
     return bool(lib().pcacc_upconv2x2_split_supported(int(h), int(w), int(c_in), int(c_up)))
 
 
+def conv3x3_split_cat(a_rows, b_rows, amax, wps, bias, relu, want_bf16=False):
+    """conv3x3_split on cat(a_rows, b_rows) along the channels without the concatenation: a_rows f32 [n,h,w,c_a], b_rows f32 [n,h,w,c_b], both
+    contiguous; amax bounds both.  -> (out f32 [n,h,w,c_out], its absmax256 array[, out as bf16])."""
+    wp, wscale = wps
+    n_img, h, w, c_a = a_rows.shape
+    c_in = c_a + b_rows.shape[3]
+    _, taps, c_out, wc_in = wp.shape
+    if wc_in != c_in or taps != 9 or tuple(b_rows.shape[:3]) != (n_img, h, w):
+        raise NativeError('conv3x3_split_cat: weights prepared for %d input channels (%d taps), inputs have %d + %d' % (wc_in, taps, c_a, c_in - c_a))
+    out = torch.empty((n_img, h, w, c_out), dtype=torch.float32, device=a_rows.device)
+    out16 = torch.empty((n_img, h, w, c_out), dtype=torch.bfloat16, device=a_rows.device) if want_bf16 else None
+    out_amax = _zero256(a_rows.device)
+    _check(lib().pcacc_conv3x3_split_cat(_dev(a_rows, torch.float32, 'a'), _dev(b_rows, torch.float32, 'b'), int(c_a), _dev(amax, torch.float32, 'amax'),
+                                         _dev(wp), _dev(wscale), _opt(bias, torch.float32, 'bias'), _dev(out), _dev(out_amax),
+                                         _dev(out16) if out16 is not None else None, int(n_img), int(h), int(w), int(c_in), int(c_out), 1 if relu else 0,
+                                         _stream()), 'conv3x3_split_cat')
+    return (out, out_amax, out16) if want_bf16 else (out, out_amax)
+
+
 def upconv2x2_split_prepare_weights(weight):
     """nn.ConvTranspose2d(k=2, s=2).weight f32 [c_in, c_up, 2, 2] (any dense layout) -> ((planes fp16 [2, 4 c_up, c_in], scale [4 c_up]),
     (planes fp16 [2, c_in, 4 c_up], scale [c_in])): forward and data-gradient form."""
@@ -823,6 +843,87 @@ def upconv2x2_split_prepare_weights(weight):
     _check(lib().pcacc_upconv2x2_split_prepare_weights(ctypes.c_void_p(weight.data_ptr()), int(ci), int(cu), strides, _dev(fwd), _dev(sf), _dev(bwd),
                                                        _dev(sb), _stream()), 'upconv2x2_split_prepare_weights')
     return (fwd, sf), (bwd, sb)
+
+
+def upconv2x2_bf16_supported(c_in, c_up):
+    return bool(lib().pcacc_upconv2x2_bf16_supported(int(c_in), int(c_up)))
+
+
+def upconv2x2_bf16_prepare_weights(weight):
+    """nn.ConvTranspose2d(k=2, s=2).weight f32 [c_in, c_up, 2, 2] (any dense layout) -> (bf16 [4 c_up, c_in], bf16 [c_in, 4 c_up])."""
+    ci, cu = weight.shape[0], weight.shape[1]
+    if not weight.is_cuda or weight.dtype != torch.float32 or tuple(weight.shape[2:]) != (2, 2):
+        raise NativeError('upconv2x2_bf16_prepare_weights: float32 GPU weight [c_in, c_up, 2, 2] expected')
+    fwd = torch.empty((4 * cu, ci), dtype=torch.bfloat16, device=weight.device)
+    bwd = torch.empty((ci, 4 * cu), dtype=torch.bfloat16, device=weight.device)
+    strides = (ctypes.c_int64 * 4)(*weight.stride())
+    _check(lib().pcacc_upconv2x2_bf16_prepare_weights(ctypes.c_void_p(weight.data_ptr()), int(ci), int(cu), strides, _dev(fwd), _dev(bwd), _stream()),
+           'upconv2x2_bf16_prepare_weights')
+    return fwd, bwd
+
+
+def _rows_pitch(rows, what):
+    """rows: a [n, h, w, c] bf16 view whose pixels are `pitch` elements apart (a channel slice of a wider channels-last map, or a dense map) ->
+    pitch, or None when the view is anything else."""
+    n, h, w, c = rows.shape
+    st = rows.stride()
+    pitch = st[2]
+    if st[3] != 1 or pitch < c or st[1] != w * pitch or st[0] != h * w * pitch or pitch % 8 or rows.data_ptr() % 16:
+        return None
+    return pitch
+
+
+def upconv2x2_bf16(x_rows, wp, bias, direction):
+    """direction 0: x_rows bf16 [n,h,w,c_in], wp = forward form -> bf16 [n,2h,2w,c_up] (+ bias f32 [c_up]); direction 1: x_rows = dy [n,2h,2w,c_up]
+    (a dense map or a channel slice of a wider one), wp = data-gradient form -> bf16 [n,h,w,c_in]."""
+    if x_rows.dtype != torch.bfloat16 or not x_rows.is_cuda:
+        raise NativeError('upconv2x2_bf16: bf16 GPU rows expected')
+    pitch = _rows_pitch(x_rows, 'x')
+    if pitch is None:
+        x_rows = x_rows.contiguous()
+        pitch = x_rows.shape[3]
+    n = x_rows.shape[0]
+    if direction == 0:
+        h, w, c_in = x_rows.shape[1:]
+        c_up = wp.shape[0] // 4
+        out = torch.empty((n, 2 * h, 2 * w, c_up), dtype=torch.bfloat16, device=x_rows.device)
+        out_pitch = c_up
+    else:
+        h, w, c_up = x_rows.shape[1] // 2, x_rows.shape[2] // 2, x_rows.shape[3]
+        c_in = wp.shape[0]
+        out = torch.empty((n, h, w, c_in), dtype=torch.bfloat16, device=x_rows.device)
+        out_pitch = c_in
+    _check(lib().pcacc_upconv2x2_bf16(ctypes.c_void_p(x_rows.data_ptr()), _dev(wp, torch.bfloat16, 'wp'), _opt(bias, torch.float32, 'bias') if direction == 0 else None,
+                                      _dev(out), int(n), int(h), int(w), int(c_in), int(c_up), int(direction), int(pitch), int(out_pitch), _stream()),
+           'upconv2x2_bf16')
+    return out
+
+
+def upconv2x2_bf16_wgrad(dy_rows, x_rows, want_bias=True, like=None):
+    """dy_rows bf16 [n,2h,2w,c_up] (dense or a channel slice), x_rows bf16 [n,h,w,c_in] -> (dw f32 [c_in,c_up,2,2] in the memory layout of `like`
+    (the weight; default contiguous), db f32 [c_up] or None)."""
+    n, h, w, c_in = x_rows.shape
+    c_up = dy_rows.shape[3]
+    dp, xp = _rows_pitch(dy_rows, 'dy'), _rows_pitch(x_rows, 'x')
+    if dp is None:
+        dy_rows, dp = dy_rows.contiguous(), c_up
+    if xp is None:
+        x_rows, xp = x_rows.contiguous(), c_in
+    if dy_rows.dtype != torch.bfloat16 or x_rows.dtype != torch.bfloat16 or tuple(dy_rows.shape[:3]) != (n, 2 * h, 2 * w):
+        raise NativeError('upconv2x2_bf16_wgrad: bf16 rows [n,2h,2w,c_up] and [n,h,w,c_in] expected')
+    if like is not None and tuple(like.shape) == (c_in, c_up, 2, 2):
+        dw = torch.empty_strided(like.shape, like.stride(), dtype=torch.float32, device=x_rows.device)
+    else:
+        dw = torch.empty((c_in, c_up, 2, 2), dtype=torch.float32, device=x_rows.device)
+    dws = (ctypes.c_int64 * 4)(*dw.stride())
+    db = torch.empty((c_up,), dtype=torch.float32, device=x_rows.device) if want_bias else None
+    need = ctypes.c_size_t(0)
+    _check(lib().pcacc_upconv2x2_bf16_wgrad_workspace_bytes(int(n), int(h), int(w), int(c_in), int(c_up), ctypes.byref(need)), 'upconv2x2_bf16_wgrad_workspace')
+    ws = _ws(need.value, x_rows.device)
+    _check(lib().pcacc_upconv2x2_bf16_wgrad(ctypes.c_void_p(dy_rows.data_ptr()), int(dp), ctypes.c_void_p(x_rows.data_ptr()), int(xp), ctypes.c_void_p(dw.data_ptr()),
+                                            dws, _dev(db) if db is not None else None, int(n), int(h), int(w), int(c_in), int(c_up), _dev(ws),
+                                            ctypes.c_size_t(ws.numel()), _stream()), 'upconv2x2_bf16_wgrad')
+    return dw, db
 
 
 def prepare_weights_batch(jobs, n_jobs, total_blocks):

@@ -1072,7 +1072,7 @@ def _weight_ref(cache, key, weight):
 # (native.prepare_weights_batch), and fills all three caches; a miss for any other reason (a version change inside an epoch, a weight
 # seen for the first time) takes the per-weight path as before.  PCACC_BATCH_PREPARE=0 switches it off.
 _BATCH_ON = os.environ.get('PCACC_BATCH_PREPARE', '1') != '0'
-_BATCH_SEEN = {}            # (id(weight), kind) -> weak reference; kind 0 = split 3x3, 1 = split transposed 2x2, 2 = bf16 3x3
+_BATCH_SEEN = {}            # (id(weight), kind) -> weak reference; kind 0 = split 3x3, 1 = split transposed 2x2, 2 = bf16 3x3, 3 = bf16 transposed 2x2
 _BATCH_STATE = {}           # device index -> {'sig', 'jobs', 'n', 'blocks', 'forms': [(ref, kind, fwd, bwd)], 'epoch'}
 
 
@@ -1093,6 +1093,11 @@ def _batch_build(dev, live):
             fwd = (torch.empty((2, 4 * b, a), dtype=torch.float16, device=dev), torch.empty((4 * b,), dtype=torch.float32, device=dev))
             bwd = (torch.empty((2, a, 4 * b), dtype=torch.float16, device=dev), torch.empty((a,), dtype=torch.float32, device=dev))
             strides, blocks = (st[0], st[1], 0, st[2], st[3]), 4 * b + a
+        elif kind == 3:
+            a, b, kt = w.shape[0], w.shape[1], 1                                # c_in, c_up
+            fwd = torch.empty((4 * b, a), dtype=torch.bfloat16, device=dev)
+            bwd = torch.empty((a, 4 * b), dtype=torch.bfloat16, device=dev)
+            strides, blocks = (st[0], st[1], 0, st[2], st[3]), min(512, max(1, (8 * a * b + 2047) // 2048))
         else:
             a, b, kt = w.shape[0], w.shape[1], (3 if w.dim() == 5 else 1)       # c_out, c_in
             strides = tuple(st) if kt == 3 else (st[0], st[1], 0, st[2], st[3])
@@ -1104,7 +1109,7 @@ def _batch_build(dev, live):
                 fwd = torch.empty((kt * 9, a, b), dtype=torch.bfloat16, device=dev)
                 bwd = torch.empty((kt * 9, b, a), dtype=torch.bfloat16, device=dev)
                 blocks = min(512, max(1, (2 * kt * 9 * a * b + 2047) // 2048))
-        ptrs = (fwd[0].data_ptr(), fwd[1].data_ptr(), bwd[0].data_ptr(), bwd[1].data_ptr()) if kind != 2 else (fwd.data_ptr(), 0, bwd.data_ptr(), 0)
+        ptrs = (fwd[0].data_ptr(), fwd[1].data_ptr(), bwd[0].data_ptr(), bwd[1].data_ptr()) if kind < 2 else (fwd.data_ptr(), 0, bwd.data_ptr(), 0)
         row[:] = (w.data_ptr(),) + ptrs + strides + (a, b, kt, kind, b0, blocks)
         b0 += blocks
         forms.append((ref, kind, fwd, bwd))
@@ -1130,7 +1135,7 @@ def _batch_refresh(dev):
         _BATCH_STATE[dev.index] = state
     native.prepare_weights_batch(state['jobs'], state['n'], state['blocks'])
     state['epoch'] = _WEIGHT_EPOCH
-    caches = (_PREPARED_SPLIT, _PREPARED_UP, _PREPARED)
+    caches = (_PREPARED_SPLIT, _PREPARED_UP, _PREPARED, _PREPARED_UPB)
     for ref, kind, fwd, bwd in state['forms']:
         w = ref()
         if w is not None:
@@ -1335,6 +1340,43 @@ class _Conv3x3Mixed(_Conv3x3):
         return y
 
 
+class _Conv3x3CatMixed(_Conv3x3):
+    """conv1(cat(up, skip)) of a decoder stage (models/unet.py:101-113) in the 'mixed' mode: the forward reads the two fp32 twins in place
+    (pcacc_conv3x3_split_cat -- the fp32 concatenation is never written), autograd sees the convolution of the bf16 concatenation `x_rows` (the
+    shadow the bf16 backward reads; it has no twin of its own)."""
+
+    @staticmethod
+    def forward(ctx, x_rows, weight, bias, relu, premasked, a32, b32):
+        amax = torch.maximum(amax_of(a32), amax_of(b32))
+        y32, y_amax, y16 = native.conv3x3_split_cat(a32, b32, amax, prepared_conv_weights_split(weight)[0], bias.detach().float() if bias is not None else None,
+                                                    relu, want_bf16=True)
+        set_amax_tag(y32, y_amax)
+        y = shadow(y32, y16)
+        ctx.save_for_backward(x_rows, weight, y if relu and not premasked else None)
+        ctx.meta = (1, relu and not premasked, bias is not None, False)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        return _Conv3x3.backward(ctx, gy)[:3] + (None, None, None, None)
+
+
+def conv3x3_cat(a, b, conv, relu=False, premasked=False):
+    """`relu?(conv(cat((a, b), 1)))` for a decoder stage.  'mixed' mode on the GPU: the fp32 forward reads the two twins in place, only the bf16
+    shadows are concatenated (for the bf16 backward); everything else: cat_maps + conv3x3."""
+    if (_MIXED and a.is_cuda and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.dim() == 4 and a.shape[1] % 32 == 0
+            and b.shape[1] % 32 == 0 and os.environ.get('PCACC_CONV_CAT', '1') != '0' and conv3x3_native(a.new_empty((0, a.shape[1] + b.shape[1]) + tuple(a.shape[2:])), conv) == 'mixed'):
+        ar, br = a.permute(0, 2, 3, 1), b.permute(0, 2, 3, 1)
+        a32, b32 = twin(ar), twin(br)
+        if ar.is_contiguous() and br.is_contiguous() and a32.is_contiguous() and b32.is_contiguous():
+            x16 = _cat2(ar, br, -1)                             # the shadow: what the weight gradient reads, whose gradient is split between a and b
+            if _POISON:
+                with torch.no_grad():
+                    x16.fill_(float('nan'))
+            return _Conv3x3CatMixed.apply(x16, conv.weight, conv.bias, bool(relu), bool(premasked), a32, b32).permute(0, 3, 1, 2)
+    return conv3x3(cat_maps((a, b), 1), conv, relu=relu, premasked=premasked)
+
+
 _PREPARED_UP = {}
 
 
@@ -1385,9 +1427,69 @@ class _UpConv2x2Split(torch.autograd.Function):
         return gx, gw, gb
 
 
+_PREPARED_UPB = {}
+
+
+def prepared_upconv_weights_bf16(weight):
+    """(forward form bf16 [4 c_up, c_in], data-gradient form bf16 [c_in, 4 c_up]) of a transposed 2 x 2 weight (csrc/upconv_bf16.hip)."""
+    key = id(weight)
+    hit = _PREPARED_UPB.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == _weight_key(weight):
+        return hit[2], hit[3]
+    got = _batch_hit(_PREPARED_UPB, weight, 3)
+    if got is not None:
+        return got
+    _batch_note(weight, 3)
+    fwd, bwd = native.upconv2x2_bf16_prepare_weights(weight.detach())
+    if len(_PREPARED_UPB) > 4096:
+        _PREPARED_UPB.clear()
+    _PREPARED_UPB[key] = (_weight_ref(_PREPARED_UPB, key, weight), _weight_key(weight), fwd, bwd)
+    return fwd, bwd
+
+
+def _upconv_bf16_backward(ctx, gy, x_rows, weight):
+    """Data, weight and bias gradient of the transposed 2 x 2 convolution from bf16 rows.  gy may be a channel slice of the decoder's concatenation
+    gradient (read in place through its pixel pitch).  Own kernels (csrc/upconv_bf16.hip) where the channel counts allow, else the library."""
+    c_in, c_up = weight.shape[0], weight.shape[1]
+    if gy.dtype != torch.bfloat16:
+        gy = gy.to(torch.bfloat16)
+    if native.upconv2x2_bf16_supported(c_in, c_up) and weight.dtype == torch.float32 and os.environ.get('PCACC_UPCONV_BF16', '1') != '0':
+        gx = native.upconv2x2_bf16(gy, prepared_upconv_weights_bf16(weight)[1], None, 1) if ctx.needs_input_grad[0] else None
+        gw = gb = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw, gb = native.upconv2x2_bf16_wgrad(gy, x_rows, want_bias=ctx.has_bias and ctx.needs_input_grad[2], like=weight)    # in the weight's layout
+        return gx, gw, gb
+    gy = gy.contiguous()
+    w16 = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gx, gw, _ = torch.ops.aten.convolution_backward(
+        gy.permute(0, 3, 1, 2), x_rows.permute(0, 3, 1, 2), w16, None, [2, 2], [0, 0], [1, 1], True, [0, 0], 1,
+        [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
+    # bias gradient = column sums of the gradient rows, fp32 accumulation (the library's own bias path reduces the channels-last map over
+    # three dimensions: 0.32 ms for the [20, 256, 36, 36] map alone)
+    gb = gy.reshape(-1, gy.shape[-1]).sum(0, dtype=torch.float32) if ctx.has_bias and ctx.needs_input_grad[2] else None
+    if gx is not None:
+        gx = gx.permute(0, 2, 3, 1).contiguous()
+    return gx, (gw.float().contiguous(memory_format=torch.channels_last) if gw is not None else None), gb
+
+
+class _UpConv2x2Bf16(torch.autograd.Function):
+    """nn.ConvTranspose2d(kernel 2, stride 2) on bf16 channels-last rows [n,h,w,c_in] -> [n,2h,2w,c_up] (bf16 compute mode): forward, data and
+    weight gradient on the bf16 matrix cores (csrc/upconv_bf16.hip), fp32 accumulation, fp32 weight / bias gradients."""
+
+    @staticmethod
+    def forward(ctx, x_rows, weight, bias):
+        ctx.save_for_backward(x_rows, weight)
+        ctx.has_bias = bias is not None
+        return native.upconv2x2_bf16(x_rows, prepared_upconv_weights_bf16(weight)[0], bias.detach().float() if bias is not None else None, 0)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x_rows, weight = ctx.saved_tensors
+        return _upconv_bf16_backward(ctx, gy, x_rows, weight)
+
+
 class _UpConv2x2Mixed(torch.autograd.Function):
-    """_UpConv2x2Split's forward on the twin, bf16 backward ('mixed' mode).  The bf16 data / weight gradients of the transposed convolution
-    go through the library for now (as in the bf16 mode)."""
+    """_UpConv2x2Split's forward on the twin, bf16 backward ('mixed' mode: csrc/upconv_bf16.hip)."""
 
     @staticmethod
     def forward(ctx, x_rows, weight, bias):
@@ -1402,17 +1504,7 @@ class _UpConv2x2Mixed(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x_rows, weight = ctx.saved_tensors
-        gy = gy.contiguous()
-        w16 = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        gx, gw, _ = torch.ops.aten.convolution_backward(
-            gy.permute(0, 3, 1, 2), x_rows.permute(0, 3, 1, 2), w16, None, [2, 2], [0, 0], [1, 1], True, [0, 0], 1,
-            [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
-        # bias gradient = column sums of the gradient rows, fp32 accumulation (the library's own bias path reduces the channels-last map over
-        # three dimensions: 0.32 ms for the [20, 256, 36, 36] map alone)
-        gb = gy.reshape(-1, gy.shape[-1]).sum(0, dtype=torch.float32) if ctx.has_bias and ctx.needs_input_grad[2] else None
-        if gx is not None:
-            gx = gx.permute(0, 2, 3, 1).contiguous()
-        return gx, (gw.float().contiguous(memory_format=torch.channels_last) if gw is not None else None), gb
+        return _upconv_bf16_backward(ctx, gy, x_rows, weight)
 
 
 class _UpConvCatMixed(torch.autograd.Function):
@@ -1489,6 +1581,11 @@ def upconv2x2(x, conv):
             set_amax_tag(xr, amax_of(x))
             y = _UpConv2x2Split.apply(xr, conv.weight, conv.bias)
             return carry_amax(y, y.permute(0, 3, 1, 2))
+    if (x.is_cuda and plain and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16))
+            and native.upconv2x2_bf16_supported(conv.in_channels, conv.out_channels) and os.environ.get('PCACC_UPCONV_BF16', '1') != '0'):
+        xr = x.permute(0, 2, 3, 1)                              # bf16 compute mode: own kernels, no library call, no layout copies
+        if xr.is_contiguous():
+            return _UpConv2x2Bf16.apply(xr if xr.dtype == torch.bfloat16 else xr.to(torch.bfloat16), conv.weight, conv.bias).permute(0, 3, 1, 2)
     return conv(x)
 
 

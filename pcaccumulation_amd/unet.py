@@ -5,6 +5,8 @@ Attribute names fix the state_dict contract: `down_convs.
 library GEMMs (MIOpen through PyTorch-ROCm) fed channels-last tensors; see DESIGN.md for why the C<=64
 full-resolution layers are HBM-bound and what is fused around them.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -49,8 +51,14 @@ class UpConv(nn.Module):
         self.conv2 = conv3x3(out_channels, out_channels)
 
     def forward(self, from_down, from_up):
+        if self.merge_mode == 'concat' and os.environ.get('PCACC_UPCONV_CAT', '0') != '1':
+            up = ops.upconv2x2(from_up, self.upconv)                  # fp32x3 / mixed: the 1-tap split kernels; bf16: csrc/upconv_bf16.hip; else the library
+            probe = up.new_empty((0, self.conv1.in_channels) + tuple(up.shape[2:]))
+            pair = ops.conv_pair_fusable(probe, self.conv1, self.conv2)
+            x = ops.conv3x3_cat(up, from_down, self.conv1, relu=True, premasked=pair)      # mixed: conv1 reads the two fp32 maps in place, no fp32 concatenation
+            return ops.conv3x3(x, self.conv2, relu=True, input_relu=pair)
         if self.merge_mode == 'concat':
-            x = ops.upconv_cat(from_up, from_down, self.upconv)        # fp32x3: the 1-tap split kernels (mixed: written straight into the concatenation buffers); else the library
+            x = ops.upconv_cat(from_up, from_down, self.upconv)        # opt-in experiment: the transposed convolution writes into the concatenation buffers
         else:
             x = ops.upconv2x2(from_up, self.upconv) + from_down
         pair = ops.conv_pair_fusable(x, self.conv1, self.conv2)

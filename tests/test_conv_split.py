@@ -297,3 +297,36 @@ def test_conv_split_out_mask(ci, co, kt, h, w, res, monkeypatch):
         want = torch.ops.aten.threshold_backward(plain, x, 0)
         assert torch.equal(got, want)
         assert float(got_amax.max()) == float(want[torch.isfinite(want)].abs().max()) or not torch.isfinite(want).all()
+
+
+@pytest.mark.parametrize('n,h,w,ca,cb,co,res', [(2, 40, 36, 32, 32, 32, '2'), (2, 40, 36, 32, 32, 32, '0'), (1, 72, 72, 128, 128, 128, '1'),
+                                                (2, 36, 36, 256, 256, 256, '1'), (2, 64, 64, 64, 64, 64, '2'), (1, 33, 45, 32, 64, 64, '1'),
+                                                (1, 20, 28, 64, 32, 32, '2'), (3, 18, 18, 96, 32, 64, '1')])
+@pytest.mark.parametrize('relu', [False, True])
+def test_conv3x3_split_on_two_inputs(n, h, w, ca, cb, co, res, relu, monkeypatch):
+    """pcacc_conv3x3_split_cat: the convolution of cat(a, b) read in place == the float64 convolution of the concatenation at the layer tolerance,
+    == the one-input kernel on the materialised concatenation up to the summation order (the channel boundary may force narrower slices), bf16
+    second output = rounding of the first, maxima = those of the result.  res: PCACC_CONV_RES ('0' never / '2' always the resident kernel)."""
+    monkeypatch.setenv('PCACC_CONV_RES', res)
+    native.reload_switches()
+    try:
+        g = torch.Generator().manual_seed(ca + cb + h)
+        a = torch.randn(n, h, w, ca, generator=g).to(DEV)
+        b = (3.0 * torch.randn(n, h, w, cb, generator=g)).to(DEV)
+        wt = (torch.randn(co, ca + cb, 3, 3, generator=g) / (3 * (ca + cb) ** 0.5)).to(DEV)
+        bias = torch.randn(co, generator=g).to(DEV)
+        wps = native.conv3x3_split_prepare_weights(wt)[0]
+        cat = torch.cat((a, b), -1)
+        amax = torch.maximum(native.absmax256(a), native.absmax256(b))
+        y, ya, y16 = native.conv3x3_split_cat(a, b, amax, wps, bias, relu, want_bf16=True)
+        ref = _ref64(cat, wt, bias, relu)
+        assert _rel(y, ref) < TOL
+        one = native.conv3x3_split(cat, wps, bias, 1, relu, amax=amax)
+        assert _rel(y, one.double()) < 1e-6
+        assert torch.equal(y16, y.to(torch.bfloat16))
+        assert float(ya.max()) == float(y.abs().max())
+        y2, _ = native.conv3x3_split_cat(a, b, amax, wps, bias, relu)
+        assert torch.equal(y2, y)
+    finally:
+        monkeypatch.delenv('PCACC_CONV_RES')
+        native.reload_switches()

@@ -111,3 +111,19 @@ def test_prepared_weight_copies_are_keyed_on_the_weight_epoch_too():
     gc.collect()
     assert len(cache) == 0
 
+
+
+def test_no_module_level_name_is_defined_twice():
+    """A second `def` of the same name silently replaces the first for every earlier caller (round 4: a new helper in native.py shadowed the pool
+    tail's `_pixel_pitch`)."""
+    import ast
+    import collections
+    import os
+    import pcaccumulation_amd
+    root = os.path.dirname(pcaccumulation_amd.__file__)
+    for name in sorted(os.listdir(root)):
+        if not name.endswith('.py'):
+            continue
+        tree = ast.parse(open(os.path.join(root, name)).read())
+        counts = collections.Counter(n.name for n in tree.body if isinstance(n, (ast.FunctionDef, ast.ClassDef)))
+        assert not [k for k, v in counts.items() if v > 1], name

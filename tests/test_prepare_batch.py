@@ -33,12 +33,15 @@ def test_batch_equals_single_and_follows_the_weights():
     dev = torch.device('cuda:0')
     w2, w2cl, w3, wu, big = _weights(dev)
     asks = [(ops.prepared_conv_weights_split, w2), (ops.prepared_conv_weights_split, w2cl), (ops.prepared_conv_weights_split, w3),
-            (ops.prepared_conv_weights_split, big), (ops.prepared_upconv_weights_split, wu), (ops.prepared_conv_weights, w2),
+            (ops.prepared_conv_weights_split, big), (ops.prepared_upconv_weights_split, wu), (ops.prepared_upconv_weights_bf16, wu),
+            (ops.prepared_conv_weights, w2),
             (ops.prepared_conv_weights, w2cl), (ops.prepared_conv_weights, w3), (ops.prepared_conv_weights, big)]
     for fn, w in asks:                                          # first sight: the per-weight path, and the batch learns the weight
         fn(w)
-    singles = {0: native.conv3x3_split_prepare_weights, 1: native.upconv2x2_split_prepare_weights, 2: native.conv3x3_prepare_weights_pair}
-    kind_of = {ops.prepared_conv_weights_split: 0, ops.prepared_upconv_weights_split: 1, ops.prepared_conv_weights: 2}
+    singles = {0: native.conv3x3_split_prepare_weights, 1: native.upconv2x2_split_prepare_weights, 2: native.conv3x3_prepare_weights_pair,
+               3: native.upconv2x2_bf16_prepare_weights}
+    kind_of = {ops.prepared_conv_weights_split: 0, ops.prepared_upconv_weights_split: 1, ops.prepared_conv_weights: 2,
+               ops.prepared_upconv_weights_bf16: 3}
     for step in range(3):
         with torch.no_grad():
             for w in (w2, w2cl, w3, wu, big):                   # what a fused optimizer does: new values, same version counter
