@@ -1,9 +1,10 @@
 """Dense 2-D encoder-decoder and the small conv / linear heads: host mirror of models/unet.py.
 
 Attribute names fix the state_dict contract: `down_convs.{i}.{conv1,conv2}`,
-`up_convs.{i}.{upconv,conv1,conv2}`, `conv_final`, `seg_head.{0,1,3}`.  The convolutions themselves are
-library GEMMs (MIOpen through PyTorch-ROCm) fed channels-last tensors; see DESIGN.md for why the C<=64
-full-resolution layers are HBM-bound and what is fused around them.
+`up_convs.{i}.{upconv,conv1,conv2}`, `conv_final`, `seg_head.{0,1,3}`.  On the GPU the convolutions run on the
+package's own MFMA kernels (pcaccumulation_amd.ops: 3x3 / 3x3x3, the 2x2 transposed convolutions, the 32 -> 2 head) fed
+channels-last tensors; the library (MIOpen through PyTorch-ROCm) is the fallback for shapes they do not take and the CPU
+path.  DESIGN.md sections 3, 15, 16 and 18: why the C <= 64 full-resolution layers are HBM-bound and what is fused around them.
 """
 import os
 

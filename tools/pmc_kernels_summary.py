@@ -38,6 +38,23 @@ KERNELS = {  # name fragment -> (label, algorithmic FLOPs per launch, algorithmi
     'vox_batch_assign': ('batched voxeliser: ranks + float64 coordinates rows, 3.2 M points', 0.0, 3.2e6 * 8 + 1.17e6 * (40 + 4)),
     'vox_batch_p2v': ('point -> collated pillar id, 3.2 M points', 0.0, 3.2e6 * 12),
     'vox_count': ('first-touch flags per chunk, 3.2 M points', 0.0, 3.2e6 * 8),
+    # round 4, second half (verdict item 7 kernels; late round-4 kernels)
+    'bilinear_gather_bwd_sorted_kernel': ('bilinear gather backward (sorted), 320 k points x 64 ch into 4 x 288^2 (bf16 out)', 0.0, 320000 * (64 * 4 + 16) + 4 * 288 * 288 * (64 * 2 + 4)),
+    'bilinear_sorted_prep_kernel': ('its preparation pass: gradient rows into CSR order + tap weights', 0.0, 320000 * (64 * 8 + 12 + 4 + 16)),
+    'ego_sinkhorn_rows_ro_kernel': ('Sinkhorn forward row half-step, 16 x 1024^2 (matrix read once, one vector written)', 0.0, 16 * 1024 * 1024 * 4),
+    'ego_sinkhorn_cols_ro_kernel': ('Sinkhorn forward column half-step, 16 x 1024^2', 0.0, 16 * 1024 * 1024 * 4),
+    'ego_sinkhorn_finish_ro_kernel': ('Sinkhorn forward: the normalised matrix written', 0.0, 16 * 1024 * 1024 * 8),
+    'sk_cols_kernel': ('Sinkhorn backward column pass, 16 x 1024^2', 0.0, 16 * 1024 * 1024 * 8),
+    'sk_rows_kernel': ('Sinkhorn backward row pass, 16 x 1024^2', 0.0, 16 * 1024 * 1024 * 8),
+    'sk_final_kernel': ('Sinkhorn backward: gradient matrix written', 0.0, 16 * 1024 * 1024 * 12),
+    'seg_rows_kernel': ('fg/bg loss: cross entropy + error keys, 600 k rows', 0.0, 600000 * (8 + 8 + 8)),
+    'seg_lovasz_kernel': ('fg/bg loss: Lovasz sums over the sorted errors, 600 k x 2 classes', 0.0, 600000 * 2 * (8 + 4)),
+    'upconv_bf16_kernel<4, 0>': ('bf16 transposed conv forward 64->32 @144^2 x20', 2.0 * 20 * 144 * 144 * 64 * 128, 20 * 144 * 144 * (64 + 128) * 2),
+    'upconv_bf16_kernel<2, 1>': ('bf16 transposed conv data gradient 64->32 (dy = channel slice)', 2.0 * 20 * 144 * 144 * 64 * 128, 20 * 144 * 144 * (64 + 128) * 2),
+    'upconv_bf16_wgrad_kernel': ('bf16 transposed conv weight gradient 64->32', 2.0 * 20 * 144 * 144 * 64 * 128, 20 * 144 * 144 * (64 + 128) * 2 + 1024 * 8192 * 4),
+    'upconv_bf16_wgrad_reduce_kernel': ('its partial-slot reduce (1024 slots x 8192)', 0.0, 1024 * 8192 * 4),
+    'rows_linear_fewk_kernel<9, 8>': ('position layer 9->64, 3.2 M rows: fp32 + bf16 outputs + maxima', 2.0 * 3.2e6 * 9 * 64, 3.2e6 * (36 + 256 + 128)),
+    'conv3x3_split_res_kernel<32, 1, 2, 5, true': ('fp32x3 conv on two inputs cat(32, 32)->32 @288^2 x20 (+ bf16 second output)', 2.0 * 20 * 288 * 288 * 64 * 32 * 9, 20 * 288 * 288 * (64 * 4 + 32 * 4 + 32 * 2)),
     'head_conv_wgrad_kernel': ('fg/bg head conv weight gradient (bf16 in)', 2.0 * 20 * 288 * 288 * 32 * 2 * 9, 20 * 288 * 288 * (32 * 2 + 2 * 4)),
 }
 
@@ -60,7 +77,8 @@ def main():
             continue
         c = {k: sum(v) / len(v) for k, v in vals[frag].items()}
         us = sum(durs[frag]) / len(durs[frag])
-        row = {'what': label, 'avg_us_under_pmc': round(us, 1), 'TFLOPs': round(flops / us / 1e6, 1), 'counters': {k: round(v, 1) for k, v in sorted(c.items())}}
+        row = {'what': label, 'avg_us_under_pmc': round(us, 1), 'TFLOPs': round(flops / us / 1e6, 1), 'algorithmic_GBps': round(hbm / us / 1e3, 1),
+               'counters': {k: round(v, 1) for k, v in sorted(c.items())}}
         if 'SQ_VALU_MFMA_BUSY_CYCLES' in c and 'GRBM_GUI_ACTIVE' in c:
             row["mfma_busy_frac"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8 * 1024), 4)   # GRBM_GUI_ACTIVE is summed over the 8 XCDs
         if 'SQ_LDS_BANK_CONFLICT' in c and c.get('SQ_LDS_IDX_ACTIVE'):
