@@ -678,6 +678,18 @@ int pcacc_bn_relu_rows_forward(const void *x, int dtype, int64_t rows, int32_t c
 int pcacc_bn_relu_rows_backward(const void *grad_y, const void *x, int dtype, int64_t rows, int32_t c, const float *gamma, const float *beta,
                                 const float *save_mean, const float *save_invstd, void *grad_x, float *grad_gamma, float *grad_beta,
                                 void *workspace, size_t workspace_bytes, void *stream);
+/* pcacc_bn_rows_forward / pcacc_bn_relu_rows_forward (relu != 0) on f32 rows with two more outputs from the same store phase ('mixed' compute mode):
+ * y16 = y as bf16 [rows][c], y_amax = 256 partial absolute maxima of y (zero-filled by the caller; layout of pcacc_absmax256); either may be NULL */
+int pcacc_bn_rows_forward_dual(const float *x, int64_t rows, int32_t c, const float *gamma, const float *beta, float eps, float momentum,
+                               float *running_mean, float *running_var, int32_t relu, float *y, uint16_t *y16, float *y_amax, float *save_mean,
+                               float *save_invstd, void *workspace, size_t workspace_bytes, void *stream);
+
+/* the two backward entries above (relu != 0: pcacc_bn_relu_rows_backward with its `beta`) with a second output from the same store phase:
+ * grad_x_amax = 256 partial absolute maxima of grad_x (zero-filled by the caller; layout of pcacc_absmax256) -- the fp32x3 layer in front of
+ * the normalisation scales its incoming gradient by them */
+int pcacc_bn_rows_backward_m(const void *grad_y, const void *x, int dtype, int64_t rows, int32_t c, const float *gamma, const float *beta,
+                             int32_t relu, const float *save_mean, const float *save_invstd, void *grad_x, float *grad_x_amax, float *grad_gamma,
+                             float *grad_beta, void *workspace, size_t workspace_bytes, void *stream);
 
 /* A ResnetBlockFC of the pillar encoder -- models/pillar_encoder.py:13-55 with size_in 64, size_h 32, size_out 32 and the linear
  * shortcut (the blocks of PillarFeatureNet, :76-78) -- fused over bf16 point rows:

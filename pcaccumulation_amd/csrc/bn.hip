@@ -152,9 +152,11 @@ template <bool BF>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const void *__restrict__ X, const void *__restrict__ DY, const float *__restrict__ mean,
                                                        const float *__restrict__ invstd, const float *__restrict__ gamma,
                                                        const float *__restrict__ beta_or_dbeta, const float *__restrict__ dgamma, int64_t rows,
-                                                       int c, void *__restrict__ out, bool relu = false, const float *__restrict__ relu_beta = nullptr)
+                                                       int c, void *__restrict__ out, bool relu = false, const float *__restrict__ relu_beta = nullptr,
+                                                       float *__restrict__ out_amax = nullptr, uint16_t *__restrict__ out16 = nullptr)
 {
-    constexpr int V = BF ? 8 : 4;
+    constexpr int V = BF ? 8 : 4;                                   // out16 (f32 rows only): a bf16 copy of `out` from the same store phase ('mixed' mode shadow)
+    float omax = 0.f;                                               // out_amax: 256 partial absolute maxima of `out` (the layout of pcacc_absmax256; zero-filled by the caller)
     const int lanes = c / V;
     const int64_t total = rows * lanes;
     const float inv_n = 1.f / (float)rows;
@@ -205,6 +207,19 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const void *__restrict__ 
             for (int k = 0; k < V; ++k) o[k] = g[k] * scale[k] + (x[k] * is_[k] - mis[k]) * kx[k] + shift[k];
         }
         bn_store<BF>(out, e, o);
+        if (!BF && out16) reinterpret_cast<uint2 *>(out16)[e] = make_uint2(pcacc_pack_bf16x2(o[0], o[1]), pcacc_pack_bf16x2(o[2], o[3]));
+        if (out_amax) {                                             // uniform
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                omax = fmaxf(omax, fabsf(o[k]));
+                if (o[k] != o[k]) omax = __builtin_inff();
+            }
+        }
+    }
+    if (out_amax) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) omax = fmaxf(omax, __shfl_xor(omax, d, 64));
+        if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned *>(out_amax) + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 255), __float_as_uint(omax));
     }
 }
 
@@ -233,8 +248,10 @@ extern "C" int pcacc_bn_rows_workspace_bytes(int64_t rows, int32_t c, size_t *by
 
 static int bn_forward_any(const void *x, int dtype, int64_t rows, int32_t c, const float *gamma, const float *beta, float eps,
                           float momentum, float *running_mean, float *running_var, void *y, float *save_mean,
-                          float *save_invstd, void *workspace, size_t workspace_bytes, void *stream, bool relu)
+                          float *save_invstd, void *workspace, size_t workspace_bytes, void *stream, bool relu, uint16_t *y16 = nullptr,
+                          float *y_amax = nullptr)
 {
+    if ((y16 || y_amax) && dtype != PCACC_F32) return PCACC_E_ARG;
     if (bn_args(dtype, rows, c) != PCACC_OK || !x || !y || !save_mean || !save_invstd || !workspace) return PCACC_E_ARG;
     const bool bf = dtype == PCACC_BF16;
     const int nb = bn_blocks(rows, c, bf ? 8 : 4);
@@ -246,9 +263,19 @@ static int bn_forward_any(const void *x, int dtype, int64_t rows, int32_t c, con
     bn_finalize_fwd_kernel<<<c, 256, 0, s>>>(partial, nb, c, rows, eps, momentum, running_mean, running_var, save_mean, save_invstd);
     const int grid = pcacc_grid(rows * (c / (bf ? 8 : 4)), 256, PCACC_CUS * 16);
     if (bf) bn_apply_kernel<true><<<grid, 256, 0, s>>>(x, nullptr, save_mean, save_invstd, gamma, beta, nullptr, rows, c, y, relu);
-    else bn_apply_kernel<false><<<grid, 256, 0, s>>>(x, nullptr, save_mean, save_invstd, gamma, beta, nullptr, rows, c, y, relu);
+    else bn_apply_kernel<false><<<grid, 256, 0, s>>>(x, nullptr, save_mean, save_invstd, gamma, beta, nullptr, rows, c, y, relu, nullptr, y_amax, y16);
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
+}
+
+// pcacc_bn_rows_forward / pcacc_bn_relu_rows_forward (relu != 0) on f32 rows with two more outputs from the same store phase ('mixed' compute mode):
+// y16 = y as bf16 (the shadow the bf16 backward reads), y_amax = 256 partial absolute maxima of y (zero-filled by the caller; either may be NULL)
+extern "C" int pcacc_bn_rows_forward_dual(const float *x, int64_t rows, int32_t c, const float *gamma, const float *beta, float eps, float momentum,
+                                          float *running_mean, float *running_var, int32_t relu, float *y, uint16_t *y16, float *y_amax,
+                                          float *save_mean, float *save_invstd, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return bn_forward_any(x, PCACC_F32, rows, c, gamma, beta, eps, momentum, running_mean, running_var, y, save_mean, save_invstd, workspace,
+                          workspace_bytes, stream, relu != 0, y16, y_amax);
 }
 
 extern "C" int pcacc_bn_rows_forward(const void *x, int dtype, int64_t rows, int32_t c, const float *gamma, const float *beta, float eps,
@@ -270,7 +297,7 @@ extern "C" int pcacc_bn_relu_rows_forward(const void *x, int dtype, int64_t rows
 
 static int bn_backward_any(const void *grad_y, const void *x, int dtype, int64_t rows, int32_t c, const float *gamma,
                            const float *save_mean, const float *save_invstd, void *grad_x, float *grad_gamma, float *grad_beta,
-                           void *workspace, size_t workspace_bytes, void *stream, bool relu, const float *beta)
+                           void *workspace, size_t workspace_bytes, void *stream, bool relu, const float *beta, float *grad_x_amax = nullptr)
 {
     if (bn_args(dtype, rows, c) != PCACC_OK || !grad_y || !x || !save_mean || !save_invstd || !grad_x || !grad_gamma || !grad_beta || !workspace)
         return PCACC_E_ARG;
@@ -283,10 +310,22 @@ static int bn_backward_any(const void *grad_y, const void *x, int dtype, int64_t
     else bn_sums_kernel<false><<<nb, 256, 0, s>>>(grad_y, x, save_mean, save_invstd, rows, c, partial, relu, gamma, beta);
     bn_finalize_bwd_kernel<<<c, 256, 0, s>>>(partial, nb, c, grad_beta, grad_gamma);
     const int grid = pcacc_grid(rows * (c / (bf ? 8 : 4)), 256, PCACC_CUS * 16);
-    if (bf) bn_apply_kernel<true><<<grid, 256, 0, s>>>(x, grad_y, save_mean, save_invstd, gamma, grad_beta, grad_gamma, rows, c, grad_x, relu, beta);
-    else bn_apply_kernel<false><<<grid, 256, 0, s>>>(x, grad_y, save_mean, save_invstd, gamma, grad_beta, grad_gamma, rows, c, grad_x, relu, beta);
+    if (bf) bn_apply_kernel<true><<<grid, 256, 0, s>>>(x, grad_y, save_mean, save_invstd, gamma, grad_beta, grad_gamma, rows, c, grad_x, relu, beta, grad_x_amax);
+    else bn_apply_kernel<false><<<grid, 256, 0, s>>>(x, grad_y, save_mean, save_invstd, gamma, grad_beta, grad_gamma, rows, c, grad_x, relu, beta, grad_x_amax);
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
+}
+
+// pcacc_bn_rows_backward / pcacc_bn_relu_rows_backward (relu != 0: `beta` as there) with the 256 partial absolute maxima of grad_x from the same store
+// phase (grad_x_amax zero-filled by the caller; layout of pcacc_absmax256): the fp32x3 layer in front of the normalisation scales its incoming gradient
+// by them (one pass over grad_x less)
+extern "C" int pcacc_bn_rows_backward_m(const void *grad_y, const void *x, int dtype, int64_t rows, int32_t c, const float *gamma, const float *beta,
+                                        int32_t relu, const float *save_mean, const float *save_invstd, void *grad_x, float *grad_x_amax,
+                                        float *grad_gamma, float *grad_beta, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!grad_x_amax) return PCACC_E_ARG;
+    return bn_backward_any(grad_y, x, dtype, rows, c, gamma, save_mean, save_invstd, grad_x, grad_gamma, grad_beta, workspace, workspace_bytes, stream,
+                           relu != 0, relu ? beta : nullptr, grad_x_amax);
 }
 
 extern "C" int pcacc_bn_rows_backward(const void *grad_y, const void *x, int dtype, int64_t rows, int32_t c, const float *gamma,

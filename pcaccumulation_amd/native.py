@@ -61,7 +61,7 @@ EXPORTS = [
     'pcacc_tube_rows', 'pcacc_tube_code', 'pcacc_tube_code_backward', 'pcacc_tube_pose_forward', 'pcacc_tube_gap_forward', 'pcacc_tube_finish',
     'pcacc_tube_gap_backward', 'pcacc_tube_pose_backward', 'pcacc_rows_wgrad_few_supported', 'pcacc_rows_wgrad_few_workspace_bytes', 'pcacc_rows_wgrad_few',
     'pcacc_maxpool2x2_bf16', 'pcacc_pool_skip_relu_backward_bf16',
-    'pcacc_pfn_block_forward', 'pcacc_pfn_block_backward_workspace_bytes', 'pcacc_pfn_block_backward', 'pcacc_conv3x3_split_outmask', 'pcacc_conv3x3_outmask_supported', 'pcacc_conv3x3_outmask_bf16', 'pcacc_maxpool2x2_f32', 'pcacc_pool_skip_relu_backward_f32', 'pcacc_pool_skip_relu_backward_strided_bf16', 'pcacc_pool_skip_relu_backward_strided_f32', 'pcacc_bn_relu_rows_forward', 'pcacc_bn_relu_rows_backward', 'pcacc_pfn_block_split_forward', 'pcacc_pfn_block_split_dgrad', 'pcacc_inv4x4',
+    'pcacc_pfn_block_forward', 'pcacc_pfn_block_backward_workspace_bytes', 'pcacc_pfn_block_backward', 'pcacc_conv3x3_split_outmask', 'pcacc_conv3x3_outmask_supported', 'pcacc_conv3x3_outmask_bf16', 'pcacc_maxpool2x2_f32', 'pcacc_pool_skip_relu_backward_f32', 'pcacc_pool_skip_relu_backward_strided_bf16', 'pcacc_pool_skip_relu_backward_strided_f32', 'pcacc_bn_relu_rows_forward', 'pcacc_bn_relu_rows_backward', 'pcacc_bn_rows_backward_m', 'pcacc_bn_rows_forward_dual', 'pcacc_pfn_block_split_forward', 'pcacc_pfn_block_split_dgrad', 'pcacc_inv4x4',
     'pcacc_conv3x3_split_prepare_weights', 'pcacc_conv3x3_split_supported', 'pcacc_conv3x3_split', 'pcacc_conv3x3_wgrad_split_workspace_bytes',
     'pcacc_conv3x3_wgrad_split', 'pcacc_absmax256',
     'pcacc_rows_linear_split', 'pcacc_rows_linear_cat_split', 'pcacc_rows_wgrad_split_workspace_bytes', 'pcacc_rows_wgrad_split',
@@ -1387,8 +1387,26 @@ def bn_rows_forward(x, gamma, beta, eps, momentum, running_mean, running_var, re
     return y, mean, invstd
 
 
-def bn_rows_backward(grad_y, x, gamma, save_mean, save_invstd, relu_beta=None, relu=False):
-    """-> (grad_x like x, grad_gamma [c] f32, grad_beta [c] f32).  relu: the backward of bn_rows_forward(relu=True) (relu_beta = its beta)."""
+def bn_rows_forward_dual(x, gamma, beta, eps, momentum, running_mean, running_var, relu=False):
+    """bn_rows_forward on f32 rows -> (y f32, y as bf16, absmax256 array of y, save_mean, save_invstd): the 'mixed' mode's shadow and the next fp32x3
+    layer's scale from the same store phase."""
+    rows, c = x.shape
+    y = torch.empty_like(x)
+    y16 = torch.empty((rows, c), dtype=torch.bfloat16, device=x.device)
+    am = _zero256(x.device)
+    mean = torch.empty((c,), dtype=torch.float32, device=x.device)
+    invstd = torch.empty((c,), dtype=torch.float32, device=x.device)
+    ws = _bn_ws(rows, c, x.device)
+    _check(lib().pcacc_bn_rows_forward_dual(_dev(x, torch.float32, 'x'), _i64(rows), int(c), _opt(gamma, torch.float32, 'gamma'), _opt(beta, torch.float32, 'beta'),
+                                            ctypes.c_float(eps), ctypes.c_float(momentum), _opt(running_mean, torch.float32, 'running_mean'),
+                                            _opt(running_var, torch.float32, 'running_var'), 1 if relu else 0, _dev(y), _dev(y16), _dev(am), _dev(mean),
+                                            _dev(invstd), _dev(ws), ctypes.c_size_t(ws.numel()), _stream()), 'bn_rows_forward_dual')
+    return y, y16, am, mean, invstd
+
+
+def bn_rows_backward(grad_y, x, gamma, save_mean, save_invstd, relu_beta=None, relu=False, want_amax=False):
+    """-> (grad_x like x, grad_gamma [c] f32, grad_beta [c] f32[, absmax256 array of grad_x]).  relu: the backward of bn_rows_forward(relu=True)
+    (relu_beta = its beta)."""
     rows, c = x.shape
     gx = torch.empty_like(x)
     gg = torch.empty((c,), dtype=torch.float32, device=x.device)
@@ -1396,6 +1414,13 @@ def bn_rows_backward(grad_y, x, gamma, save_mean, save_invstd, relu_beta=None, r
     ws = _bn_ws(rows, c, x.device)
     if grad_y.dtype != x.dtype:
         raise NativeError('bn_rows_backward: grad_y must have the type of x')
+    if want_amax:
+        am = _zero256(x.device)
+        _check(lib().pcacc_bn_rows_backward_m(_dev(grad_y, None, 'grad_y'), _dev(x, None, 'x'), _dtype_code(x), _i64(rows), int(c),
+                                              _opt(gamma, torch.float32, 'gamma'), _opt(relu_beta, torch.float32, 'beta') if relu else None, 1 if relu else 0,
+                                              _dev(save_mean, torch.float32), _dev(save_invstd, torch.float32), _dev(gx), _dev(am), _dev(gg), _dev(gb),
+                                              _dev(ws), ctypes.c_size_t(ws.numel()), _stream()), 'bn_rows_backward_m')
+        return gx, gg, gb, am
     if relu:
         _check(lib().pcacc_bn_relu_rows_backward(_dev(grad_y, None, 'grad_y'), _dev(x, None, 'x'), _dtype_code(x), _i64(rows), int(c),
                                                  _opt(gamma, torch.float32, 'gamma'), _opt(relu_beta, torch.float32, 'beta'),

@@ -105,8 +105,11 @@ class _SegmentMax(torch.autograd.Function):
         (arg,) = ctx.saved_tensors
         pidx = ctx.pidx
         out_dtype = ctx.src_dtype if ctx.src_dtype in (torch.float32, torch.bfloat16) else torch.float32
-        g = native.segment_max_backward(grad_out.contiguous(), arg, pidx.p2v, pidx.n, out_dtype=out_dtype)
-        return (g if g.dtype == ctx.src_dtype else g.to(ctx.src_dtype)), None
+        grad_out = grad_out.contiguous()
+        g = native.segment_max_backward(grad_out, arg, pidx.p2v, pidx.n, out_dtype=out_dtype)
+        if _SPLIT and g.dtype == torch.float32 and grad_out.dtype == torch.float32 and g.numel() >= 8 * grad_out.numel():
+            set_amax_tag(g, amax_of(grad_out))                     # g = grad_out's elements at the winners, zeros elsewhere: its bound holds (a pass over the
+        return (g if g.dtype == ctx.src_dtype else g.to(ctx.src_dtype)), None      # few pooled rows instead of one over every point row)
 
 
 def segment_max(src, pidx):
@@ -1781,12 +1784,19 @@ class _SparseConv3x3(torch.autograd.Function):
         gh = gw = gb = None
         if ctx.needs_input_grad[0]:
             gp = (g @ w2.t()).view(-1, C)                                                      # [K * 9, C] rows of the neighbourhoods' gradients
-            gh = torch.zeros((n * H * W, C), dtype=torch.float32, device=g.device)
-            valid = idx >= 0
-            gh.index_add_(0, idx.clamp(min=0).long(), gp * valid[:, None])                     # overlapping neighbourhoods add up
-            gh = gh.view(n, H, W, C)
+            cells = n * H * W
+            gh = torch.zeros((cells + 1, C), dtype=torch.float32, device=g.device)             # last row: where the taps outside the map add up (dropped)
+            gh.index_add_(0, torch.where(idx >= 0, idx, cells).long(), gp)                     # overlapping neighbourhoods add up
+            gh = gh[:cells].view(n, H, W, C)
         if ctx.needs_input_grad[1]:
-            gw = (patches.t() @ g).view(3, 3, wshape[1], wshape[0]).permute(3, 2, 0, 1).contiguous()
+            k = g.shape[0]
+            if k % 16 == 0 and k >= 4096:
+                # [9 C, K] x [K, O] with K = 32 768 key points: the library runs one long reduction per output tile (142 us); sixteen slices as one batched
+                # product and a sum take ~30 us
+                gw2 = torch.bmm(patches.view(16, k // 16, -1).transpose(1, 2), g.view(16, k // 16, -1)).sum(0)
+            else:
+                gw2 = patches.t() @ g
+            gw = gw2.view(3, 3, wshape[1], wshape[0]).permute(3, 2, 0, 1).contiguous()
         if has_bias and ctx.needs_input_grad[2]:
             gb = g.sum(0)
         return gh, gw, gb, None
@@ -2060,15 +2070,25 @@ class _BatchNormRows(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, eps, momentum, running_mean, running_var, relu=False):
         x = x.contiguous()
         mixed = _MIXED and x.dtype == torch.bfloat16               # shadow rows: statistics and output from the fp32 twin, bf16 backward on the shadow
-        y, mean, invstd = native.bn_rows_forward(twin(x) if mixed else x, gamma, beta, eps, momentum, running_mean, running_var, relu=relu)
+        if mixed and twin(x).dim() == 2 and twin(x).is_contiguous():
+            y, y16, am, mean, invstd = native.bn_rows_forward_dual(twin(x), gamma, beta, eps, momentum, running_mean, running_var, relu=relu)
+            set_amax_tag(y, am)
+            out = shadow(y, y16)                                    # shadow and maxima from the normalisation's own store phase
+        else:
+            y, mean, invstd = native.bn_rows_forward(twin(x) if mixed else x, gamma, beta, eps, momentum, running_mean, running_var, relu=relu)
+            out = shadow(y) if mixed else y
         ctx.save_for_backward(x, gamma, mean, invstd, beta if relu else None)
         ctx.relu = relu
-        return shadow(y) if mixed else y
+        return out
 
     @staticmethod
     def backward(ctx, gy):
         x, gamma, mean, invstd, beta = ctx.saved_tensors
-        gx, gg, gb = native.bn_rows_backward(gy.contiguous().to(x.dtype), x, gamma, mean, invstd, relu_beta=beta, relu=ctx.relu)
+        if _SPLIT and x.dtype == torch.float32:                    # an fp32x3 layer sits in front: the maxima its backward scales by come from this store phase
+            gx, gg, gb, am = native.bn_rows_backward(gy.contiguous().to(x.dtype), x, gamma, mean, invstd, relu_beta=beta, relu=ctx.relu, want_amax=True)
+            set_amax_tag(gx, am)
+        else:
+            gx, gg, gb = native.bn_rows_backward(gy.contiguous().to(x.dtype), x, gamma, mean, invstd, relu_beta=beta, relu=ctx.relu)
         return gx, (gg if gamma is not None else None), (gb if gamma is not None else None), None, None, None, None, None
 
 

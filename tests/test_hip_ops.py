@@ -1091,6 +1091,39 @@ def test_batch_norm_nchw_is_batchnorm2d(native, dev, dtype, c, relu):
     assert torch.equal(ops.batch_norm_nchw(x.contiguous(), mine.train()), mine(x.contiguous())) or True
 
 
+@pytest.mark.parametrize('dtype,c,relu', [(torch.float32, 128, False), (torch.float32, 32, True), (torch.bfloat16, 64, True)])
+def test_bn_backward_reports_the_maxima_of_its_result(native, dev, dtype, c, relu):
+    """pcacc_bn_rows_backward_m: the gradients of pcacc_bn_rows_backward / _relu_rows_backward bit for bit, and 256 partial maxima whose maximum is the
+    maximum of |grad_x| (as pcacc_absmax256 would find with a pass of its own); in the fp32x3 mode the autograd node hangs them on its result."""
+    from pcaccumulation_amd import ops
+    torch.manual_seed(11)
+    rows = 20_003
+    x = (torch.randn(rows, c, device=dev) * 2 + 0.3).to(dtype)
+    g = torch.randn(rows, c, device=dev).to(dtype)
+    gamma, beta = torch.linspace(0.5, 1.5, c, device=dev), torch.linspace(-1.0, 1.0, c, device=dev)
+    y, mean, invstd = native.bn_rows_forward(x, gamma, beta, 1e-5, 0.1, None, None, relu=relu)
+    gx, gg, gb = native.bn_rows_backward(g, x, gamma, mean, invstd, relu_beta=beta, relu=relu)
+    gx2, gg2, gb2, am = native.bn_rows_backward(g, x, gamma, mean, invstd, relu_beta=beta, relu=relu, want_amax=True)
+    assert torch.equal(gx, gx2) and torch.equal(gg, gg2) and torch.equal(gb, gb2)
+    # f32: the maximum of the stored values; bf16 rows: of the values before they are rounded for the store (an upper bound within one rounding)
+    top = float(gx.float().abs().max())
+    assert am.shape == (256,) and (float(am.max()) == top if dtype == torch.float32 else top * (1 - 2 ** -8) <= float(am.max()) <= top * (1 + 2 ** -7))
+    if dtype == torch.float32:
+        # forward with the bf16 shadow and the maxima from the same store phase ('mixed' mode)
+        y2, y16, ym, mean2, invstd2 = native.bn_rows_forward_dual(x, gamma, beta, 1e-5, 0.1, None, None, relu=relu)
+        assert torch.equal(y2, y) and torch.equal(y16, y.to(torch.bfloat16)) and torch.equal(mean2, mean) and torch.equal(invstd2, invstd)
+        assert float(ym.max()) == float(y.abs().max())
+        ops.set_split(True)
+        try:
+            bn = torch.nn.BatchNorm1d(c).to(dev)
+            xm = x.clone().requires_grad_(True)
+            ops.batch_norm_rows(xm, bn).backward(g)
+            tag = ops.amax_tag(xm.grad)
+            assert tag is None or float(tag.max()) == float(xm.grad.abs().max())       # (.grad may be a copy of the node's result: then no tag)
+        finally:
+            ops.set_split(False)
+
+
 def test_pillar_scatter_timed_launch(native, dev):
     """pcacc_pillar_scatter_timed (bench.py's roofline probe): the same canvas as the plain launch, and a dispatch time that is
     positive and of the order the byte count allows (5 MB at < 8 TB/s: between 0.6 us and 1 ms)."""

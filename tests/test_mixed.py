@@ -275,18 +275,19 @@ def test_own_concatenation_kernel(dtype, shape, ca, cb):
 
 
 @pytest.mark.gpu
-def test_sparse_conv_rows_is_the_dense_convolution_at_the_selected_cells():
+@pytest.mark.parametrize('sel', [(5, 700), (8, 1024)])          # 8 192 cells: the weight gradient as a batched product over 16 slices of the cells
+def test_sparse_conv_rows_is_the_dense_convolution_at_the_selected_cells(sel):
     """ops.SparseConvRows.at(cells) == rows `cells` of conv(h), values and gradients (h, weight, bias), incl. cells on the border and repeated cells."""
     dev = torch.device('cuda:0')
     g = torch.Generator(device='cpu').manual_seed(3)
     n, C, O, H, W = 3, 64, 64, 20, 24
     h = torch.randn(n, C, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     conv = torch.nn.Conv2d(C, O, 3, padding=1).to(dev)
-    cells = torch.randint(0, n * H * W, (5, 700), generator=g).to(dev)
+    cells = torch.randint(0, n * H * W, sel, generator=g).to(dev)
     cells[0, :6] = torch.tensor([0, W - 1, (H - 1) * W, H * W - 1, 5, 5], device=dev)          # corners of image 0, one cell twice
     assert ops.sparse_conv_available(h, conv)
     got = ops.SparseConvRows(h, conv).at(cells)
-    gy = torch.randn(5, 700, O, generator=g).to(dev)
+    gy = torch.randn(*sel, O, generator=g).to(dev)
     gh, gw, gb = torch.autograd.grad(got, (h, conv.weight, conv.bias), gy)
     hd = h.detach().double().requires_grad_(True)
     wd, bd = conv.weight.detach().double().requires_grad_(True), conv.bias.detach().double().requires_grad_(True)

@@ -47,10 +47,11 @@ def test_two_stream_pipelined_step_matches_plain_step(compute_dtype):
 
     plain = pdist.DataParallelStep(model, opt, loss_fn, iter_size=1, grad_clip=None, catch=False, pipelined=False)
     assert plain.side is None
-    ref, again = run(plain), run(plain)
-    # the step is not bit-reproducible (atomic row sums, library convolutions; in bf16 a rounding can flip a foreground decision and
-    # with it a key-point draw): the plain step against itself sets the scale for "the same"
-    noise_g, noise_l = rel(again, ref)
+    ref, again, again2 = run(plain), run(plain), run(plain)
+    # the step is not bit-reproducible (atomic row sums; in bf16 a rounding can flip a foreground decision and with it a key-point
+    # draw): the plain step against itself sets the scale for "the same" -- the larger of two repeats (one repeat is one draw of a
+    # maximum over ~200 tensors: 0.017 one run, 0.03 the next, and the bound failed about one run in ten)
+    noise_g, noise_l = (max(v) for v in zip(rel(again, ref), rel(again2, ref)))
     tol_g = max(4 * noise_g, 2e-2 if compute_dtype == 'bf16' else 5e-3)
     tol_l = max(4 * noise_l, 1e-4)
     for kw in (dict(two_streams=True), dict(two_streams=False)):
