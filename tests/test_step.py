@@ -41,8 +41,13 @@ def test_two_stream_pipelined_step_matches_plain_step(compute_dtype):
                 {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None})
 
     def rel(a, b):
-        """largest |difference| of two gradient sets relative to the largest entry of the tensor it occurs in; loss difference"""
-        worst = max(float((a[2][k] - b[2][k]).abs().max()) / (float(b[2][k].abs().max()) + 1e-12) for k in b[2])
+        """largest |difference| of two gradient sets relative to the largest entry of the tensor it occurs in; loss difference.  A tensor whose
+        gradient is analytically zero (the bias of the layer in front of a BatchNorm: motionhead.offset_head.seg_head.0.bias, 2e-6 of pure
+        rounding against 1.2 elsewhere) has no scale of its own: the denominator is floored at 1e-4 of the largest entry of the whole set --
+        once the bf16 step had become reproducible enough for its noise scale to drop below that tensor's summation-order scatter (round 4,
+        own transposed-convolution kernels), it alone failed the comparison."""
+        top = max(float(v.abs().max()) for v in b[2].values())
+        worst = max(float((a[2][k] - b[2][k]).abs().max()) / max(float(b[2][k].abs().max()), 1e-4 * top) for k in b[2])
         return worst, abs(a[0] - b[0]) / abs(b[0])
 
     plain = pdist.DataParallelStep(model, opt, loss_fn, iter_size=1, grad_clip=None, catch=False, pipelined=False)
