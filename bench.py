@@ -262,7 +262,7 @@ def config_throughput(kind, name, dataset, T, ppf, batch, mode, steps, warmup, d
         def run():
             with torch.no_grad():
                 model(batcher(scenes))
-    for _ in range(warmup):
+    for _ in range(max(warmup, 7) if kind == 'train' else warmup):     # a train stepper settles how it issues its early backward over its first seven steps
         run()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -370,7 +370,8 @@ def main():
     stepper = pdist.DataParallelStep(model, opt, loss_fn, iter_size=args.iter_size, grad_clip=cfg['train']['grad_clip'],
                                      pipelined=False if args.no_pipeline else (True if args.pipeline else None), two_streams=not args.one_stream)
 
-    step_variant = ('staged (early backward of the ego / fb / perm terms)' + (' + second stream' if stepper.side is not None else '')) if stepper.pipelined else 'one backward'
+    step_variant = ('staged (early backward of the ego / fb / perm terms)' + (' + second stream' if stepper.side is not None else '')
+                    ) if stepper.pipelined else 'one backward'
     torch.manual_seed(1234 + rank)
     feed = BatchFeed(batcher, batch_of, not args.no_prefetch, prepare=model.prepare_inputs if args.prepare_ahead else None)
     for i in range(args.warmup):
@@ -466,7 +467,7 @@ def main():
                        'kpt_sampler': "device: the ego head's 1024 key points per frame are drawn by pcacc_sample_subsets (keyed Feistel permutation, one "
                                       "launch) instead of the reference's host torch.randperm stream (models/egomotion.py:157) -- same uniform "
                                       "distribution over subsets, different draw; the parity tests use the host stream",
-                       'step_variant': step_variant},
+                       'step_variant': step_variant, 'early_backward_thread': getattr(stepper, 'early_thread_choice', None)},
             'distributed': {'world_size': world, 'backend': (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
                             'device': str(device), 'ranks_per_device': max(1, world // n_dev) if world > n_dev else 1},
             'roofline': {'kernel': 'pillar_scatter_rows16 (BEV canvas fill, bf16 rows -> bf16 canvas)' if main_bf16 else 'pillar_scatter_vec4<0> (BEV canvas fill)', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,

@@ -24,6 +24,8 @@ Design for MotionNet on an 8 x MI355X node:
     which is what single-process Adam sees (it skips them instead of applying stale momentum).
 """
 import os
+import sys
+import threading
 
 import contextlib
 
@@ -317,8 +319,17 @@ class DataParallelStep(object):
     GradScaler uses; `skipped` counts on the device (read it with skipped_steps()).  Optimizers without that input (CPU tests)
     read the flag on the host."""
 
-    def __init__(self, model, optimizer, loss_fn, iter_size=1, grad_clip=1.0, check_finite=True, catch=True, reducer=None, pipelined=None, two_streams=True):
+    def __init__(self, model, optimizer, loss_fn, iter_size=1, grad_clip=1.0, check_finite=True, catch=True, reducer=None, pipelined=None, two_streams=True,
+                 early_thread=None):
         self.model, self.optimizer, self.loss_fn = model, optimizer, loss_fn
+        # early_thread: issue the early backward from a helper thread (see early_backward).  True / False, or None = decide by measurement: it takes
+        # 2 ms off a GPU-heavy step (mixed mode, four sequences: 33.2-34.5 -> 31.2-32.0 ms on two boxes) and ADDS up to 6 ms to a host-bound one on
+        # some boxes (one sequence per step; bf16 at four: two threads contending for the interpreter lock and the runtime's launch path), so the
+        # stepper times two steps each way after a warm-up step (device events at the step boundaries, no extra synchronisation until the
+        # decision) and keeps the faster -- the way a convolution library picks its algorithm.  PCACC_EARLY_THREAD=0 / 1 fixes the choice.
+        env = os.environ.get('PCACC_EARLY_THREAD')
+        self._early_thread_want = (env == '1') if env in ('0', '1') else early_thread
+        self._tune_events = []
         # pipelined: back-propagate the loss terms of the lower half of the model (pillar encoder, U-Net, heads, ego head) as soon as
         # the ego head has run, before the motion heads and the TubeNet are even issued (MotionNet.after_ego, FuseLoss.early_terms);
         # two_streams: the rest of the forward, its loss terms and their backward run on a side stream while the early backward
@@ -351,6 +362,10 @@ class DataParallelStep(object):
         if self.pipelined and hasattr(model, 'early_parameters'):
             self.reducer.set_early(model.early_parameters())
         self.side = torch.cuda.Stream(device=dev) if (self.pipelined and want_side) else None
+        can_thread = bool(self.pipelined and dev.type == 'cuda')
+        self._early_thread = bool(self._early_thread_want) and can_thread
+        self._tuning = can_thread and self._early_thread_want is None
+        self.early_thread_choice = None if self._tuning else ('fixed on' if self._early_thread else 'fixed off')
         # the optimizer's step invalidates the prepared (packed / split) convolution weights (fused optimizers do not bump version counters)
         if hasattr(model, 'watch_optimizer'):
             model.watch_optimizer(optimizer)
@@ -361,6 +376,27 @@ class DataParallelStep(object):
         self.last_error = None
         self._skipped = torch.zeros(1, dtype=torch.float32, device=self.reducer.params[0].device)
         self._device_skip = bool(getattr(optimizer, '_step_supports_amp_scaling', False))
+
+    def _tune_step(self):
+        """Step 0: warm-up; steps 1-4 alternate (early backward from this thread, from the helper thread, this, helper); step 5: this thread; at the
+        start of step 6 the two pairs are compared by the device time between the steps' first launches (events recorded at the step boundaries
+        on the main stream)."""
+        k = len(self._tune_events)
+        if k <= 6:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._tune_events.append(ev)
+        if k < 6:
+            self._early_thread = k in (2, 4)
+            return
+        ev = self._tune_events
+        ev[5].synchronize()                                   # reached by the GPU when step 4 was done: normally long past
+        plain, threaded = ev[1].elapsed_time(ev[2]) + ev[3].elapsed_time(ev[4]), ev[2].elapsed_time(ev[3]) + ev[4].elapsed_time(ev[5])
+        self._early_thread = threaded < 0.98 * plain          # 2 %: below the run-to-run scatter of two steps
+        self.early_thread_choice = 'measured: %.1f ms from this thread, %.1f ms from a helper thread per step -> %s' % (
+            plain / 2, threaded / 2, 'helper thread' if self._early_thread else 'this thread')
+        self._tuning = False
+        self._tune_events = []
 
     def skipped_steps(self):
         return int(self._skipped.item())
@@ -375,9 +411,21 @@ class DataParallelStep(object):
         if self.micro == 0:
             r.zero()
             self.ok = True
+            if self._tuning:
+                self._tune_step()
         last = self.micro == self.iter_size - 1
         stats = None
         early = []
+
+        pending = []                                          # [(thread, [exception])] of an early backward issued from a helper thread
+
+        def join_early():
+            while pending:
+                t, err = pending.pop()
+                t.join()
+                sys.setswitchinterval(self._switch_interval)
+                if err:
+                    raise err[0]
 
         def early_backward(results):
             e = self.loss_fn.early_terms(results)
@@ -386,8 +434,30 @@ class DataParallelStep(object):
                 self._early_ready.record()
             loss_e = e['loss_early'] / self.iter_size if self.iter_size > 1 else e['loss_early']
             r.prepare(loss_e, part='early')                   # the lower half's buckets go out now, under the rest of the forward
-            loss_e.backward()
             early.append(e)
+            if not self._early_thread:
+                loss_e.backward()
+                return
+            # The lower half's backward is ~300 launches the autograd thread issues while the caller of backward() sleeps; the upper half of the
+            # forward (motion heads, TubeNet: ~800 small launches) is bound by the rate the host issues them.  Calling backward() from a helper
+            # thread lets this thread go on issuing the upper half meanwhile (the kernels go to the streams they went to before: the backward to
+            # the main stream its forward ran on, the upper half to the side stream); joined before the second backward of the step.
+            err, dev_ = [], loss_e.device
+
+            def work():
+                try:
+                    if dev_.type == 'cuda':
+                        torch.cuda.set_device(dev_)           # the current device is a per-thread setting
+                    loss_e.backward()
+                except BaseException as ex:                   # noqa: BLE001 -- re-raised in the step's thread by join_early
+                    err.append(ex)
+            t = threading.Thread(target=work, name='pcacc-early-backward', daemon=True)
+            pending.append((t, err))
+            # two threads now want the interpreter lock (this one for the upper half's Python, the autograd thread for the backward's custom
+            # functions): at the default 5 ms switch interval they starve each other in 5 ms turns
+            self._switch_interval = sys.getswitchinterval()
+            sys.setswitchinterval(float(os.environ.get('PCACC_SWITCH_INTERVAL', '2e-4')))
+            t.start()
         r.begin(sync=last)
         try:
             if self.pipelined:
@@ -395,6 +465,12 @@ class DataParallelStep(object):
                 self.model.side_stream = self.side
             try:
                 out = self.model(inp)
+            except BaseException:
+                try:
+                    join_early()                              # never leave the helper thread running behind a failed forward
+                except BaseException:                         # noqa: BLE001 -- the forward's own error is the one to report
+                    pass
+                raise
             finally:
                 if self.pipelined:
                     self.model.after_ego = None
@@ -407,7 +483,10 @@ class DataParallelStep(object):
                 share_with_stream(self.side, early[0], inp)
                 self.side.wait_event(self._early_ready)
             with (torch.cuda.stream(self.side) if two else contextlib.nullcontext()):
-                stats = self.loss_fn(out, inp, early=early[0]) if early else self.loss_fn(out, inp)
+                try:
+                    stats = self.loss_fn(out, inp, early=early[0]) if early else self.loss_fn(out, inp)
+                finally:
+                    join_early()                              # the early backward is issued (and its errors are ours) before the second one starts
                 loss = stats['loss'] / self.iter_size if self.iter_size > 1 else stats['loss']
                 r.prepare(loss, part='rest')
                 # after an early backward the rest of the loss may be constants only (motion heads and TubeNet both skipped on a batch

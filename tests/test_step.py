@@ -59,9 +59,9 @@ def test_two_stream_pipelined_step_matches_plain_step(compute_dtype):
     noise_g, noise_l = (max(v) for v in zip(rel(again, ref), rel(again2, ref)))
     tol_g = max(4 * noise_g, 2e-2 if compute_dtype == 'bf16' else 5e-3)
     tol_l = max(4 * noise_l, 1e-4)
-    for kw in (dict(two_streams=True), dict(two_streams=False)):
-        step = pdist.DataParallelStep(model, opt, loss_fn, iter_size=1, grad_clip=None, catch=False, pipelined=True, **kw)
-        assert (step.side is not None) == kw['two_streams']
+    for kw in (dict(two_streams=True, early_thread=False), dict(two_streams=False, early_thread=False), dict(two_streams=True, early_thread=True)):
+        step = pdist.DataParallelStep(model, opt, loss_fn, iter_size=1, grad_clip=None, catch=False, pipelined=True, **kw)   # early_thread: the early backward issued from a helper thread
+        assert (step.side is not None) == kw['two_streams'] and step._early_thread == kw['early_thread'] and not step._tuning
         run(step)                                                             # twice: the second call reuses cached blocks of both streams
         got = run(step)
         assert got[1].keys() == ref[1].keys() and got[2].keys() == ref[2].keys()
@@ -162,3 +162,38 @@ def test_fused_optimizer_steps_reach_the_prepared_convolution_weights(compute_dt
         assert float((got - ref).abs().max()) <= 2e-2 * scale + 1e-3, (train, fused_is_silent, float((got - ref).abs().max()), scale)
     after = forward(model, 900, True)
     assert float((after - before).abs().max()) > 1e-3 * float(before.abs().max()), 'three optimizer steps at lr 3e-3 left the training forward unchanged'
+
+
+def test_stepper_settles_how_it_issues_the_early_backward():
+    """early_thread=None: one warm-up step, four alternating steps timed by device events, the choice reported; every step of the measurement
+    phase is a full training step (gradients finite, optimizer stepped); an environment override fixes the choice."""
+    import os
+    dev = torch.device('cuda:0')
+    cfg = default_config('waymo', 'train', n_sweeps=3, xy_range=16)
+    cfg['misc']['compute_dtype'] = 'mixed'
+    torch.manual_seed(0)
+    model = MotionNet(cfg)
+    fill_state_dict_(model)
+    model = model.to(dev).train().channels_last_()
+    inp = make_batch(cfg, [11, 12], 3, 6000)
+    inp = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
+    assert os.environ.get('PCACC_EARLY_THREAD') not in ('0', '1')
+    step = pdist.DataParallelStep(model, opt, FuseLoss(cfg['loss']), iter_size=1, grad_clip=1.0, catch=False)
+    assert step.pipelined and step._tuning and step.early_thread_choice is None
+    modes = []
+    for k in range(8):
+        stats = step(inp)
+        modes.append(step._early_thread)
+        assert torch.isfinite(torch.as_tensor(float(stats['loss'])))
+    torch.cuda.synchronize()
+    assert modes[:6] == [False, False, True, False, True, False] and modes[6] == modes[7]
+    assert not step._tuning and step.early_thread_choice.startswith('measured:') and step.skipped == 0
+    os.environ['PCACC_EARLY_THREAD'] = '1'
+    try:
+        fixed = pdist.DataParallelStep(model, opt, FuseLoss(cfg['loss']), iter_size=1, grad_clip=1.0, catch=False)
+        assert fixed._early_thread and not fixed._tuning and fixed.early_thread_choice == 'fixed on'
+        fixed(inp)
+        torch.cuda.synchronize()
+    finally:
+        del os.environ['PCACC_EARLY_THREAD']

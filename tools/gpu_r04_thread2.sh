@@ -1,0 +1,5 @@
+#!/bin/bash
+for i in 1 2; do for e in "PCACC_EARLY_THREAD=0" "PCACC_EARLY_THREAD=1 PCACC_SWITCH_INTERVAL=2e-4" "PCACC_EARLY_THREAD=1 PCACC_SWITCH_INTERVAL=2e-5" "PCACC_EARLY_THREAD=1 PCACC_SWITCH_INTERVAL=5e-3"; do for b in 1 4; do for d in mixed bf16; do
+  ms=$(env $e timeout 900 python bench.py --dtype $d --batch $b --no-cpu-baseline --no-configs --no-fp32-leg --no-step-model 2>gpurun_out/err_t.txt | tail -1 | python3 -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])" 2>/dev/null)
+  echo "$e $d B=$b $ms"
+done; done; done; done
