@@ -330,6 +330,7 @@ def main():
     ap.add_argument('--no-pipeline', action='store_true', help='one backward at the end of the forward instead of the early backward of the ego / fb / perm terms (DataParallelStep.pipelined)')
     ap.add_argument('--one-stream', action='store_true', help='motion heads and TubeNet on the main stream behind the early backward instead of beside it on a second stream')
     ap.add_argument('--prepare-ahead', action='store_true', help='build the pillar index / CSR / point features of the next batch on the prefetch stream during the current step (MotionNet.prepare_inputs) instead of inside its own forward; measured neutral: 29.16 vs 29.22 ms over 8 interleaved runs each, sd 0.5')
+    ap.add_argument('--cpu-affinity', default='l3', choices=['l3', 'none'], help="'l3' (default): bind the process to the CPUs of one last-level-cache domain (a different one per local rank) for the GPU part of the run -- the step's two host threads then share a cache instead of landing on two sockets in some runs (distributed.bind_to_l3_domain); restored for the CPU baseline")
     ap.add_argument('--no-prefetch', action='store_true', help='voxelise each batch at the start of its own step instead of one step ahead on a side stream')
     args = ap.parse_args()
     if os.environ.get('PCACC_HANG_DUMP'):                      # debugging aid: every thread's Python stack after N seconds, then exit
@@ -343,6 +344,9 @@ def main():
     if backend is None and int(os.environ.get('WORLD_SIZE', '1')) > n_dev:
         raise SystemExit('WORLD_SIZE exceeds the %d visible GPU(s); set PCACC_DIST_BACKEND=gloo to share devices' % n_dev)
     torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % n_dev)
+    affinity_before = None
+    if args.cpu_affinity == 'l3':
+        affinity_before = pdist.bind_to_l3_domain(int(os.environ.get('LOCAL_RANK', '0')), int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('WORLD_SIZE', '1'))))
     rank, world, local_rank = pdist.init_from_env(backend)
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit('--gpus %d needs torch.distributed.run with --nproc-per-node %d' % (args.gpus, args.gpus))
@@ -389,6 +393,7 @@ def main():
     timer, native.scatter_timer = native.scatter_timer, None
     if stepper.skipped:
         raise SystemExit('bench: %d optimizer step(s) were skipped (rank %d: %r)' % (stepper.skipped, rank, stepper.last_error))
+    thread_choice = getattr(stepper, 'early_thread_choice', None)     # how the stepper settled on issuing its early backward (distributed.DataParallelStep)
     model_tot = flushed = None
     if rank == 0 and not args.no_step_model:
         try:
@@ -423,7 +428,7 @@ def main():
                          '(validation-set level on trained weights: EPE 6e-3 m, mos_iou 3e-3; DESIGN.md section 4) -- bounded, not matched',
                  'fp32x3': 'same step with fp32 tensors and fp32-accurate matrix-core products (scaled fp16 hi / lo halves) in the forward AND the backward'}
         second_leg = {'dtype': second_mode, 'value': args.batch * T_FRAMES * k2 / dt2, 'unit': 'LiDAR-frames/s', 'ms_per_step': dt2 / k2 * 1e3,
-                      'steps': k2, 'warmup': args.warmup, 'note': notes[second_mode]}
+                      'steps': k2, 'warmup': args.warmup, 'early_backward_thread': getattr(st2, 'early_thread_choice', None), 'note': notes[second_mode]}
         del st2, m2, o2
 
     if rank == 0:
@@ -467,7 +472,8 @@ def main():
                        'kpt_sampler': "device: the ego head's 1024 key points per frame are drawn by pcacc_sample_subsets (keyed Feistel permutation, one "
                                       "launch) instead of the reference's host torch.randperm stream (models/egomotion.py:157) -- same uniform "
                                       "distribution over subsets, different draw; the parity tests use the host stream",
-                       'step_variant': step_variant, 'early_backward_thread': getattr(stepper, 'early_thread_choice', None)},
+                       'step_variant': step_variant, 'early_backward_thread': thread_choice,
+                       'cpu_affinity': ('one L3 domain: %d CPUs' % len(os.sched_getaffinity(0))) if affinity_before is not None else 'unbound'},
             'distributed': {'world_size': world, 'backend': (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
                             'device': str(device), 'ranks_per_device': max(1, world // n_dev) if world > n_dev else 1},
             'roofline': {'kernel': 'pillar_scatter_rows16 (BEV canvas fill, bf16 rows -> bf16 canvas)' if main_bf16 else 'pillar_scatter_vec4<0> (BEV canvas fill)', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
@@ -518,6 +524,8 @@ def main():
             line['configs'] = rows
         if world == 1 and not args.no_cpu_baseline:
             try:
+                if affinity_before is not None:
+                    os.sched_setaffinity(0, affinity_before)       # the CPU leg probes 8 / 16 / 32 threads: give it the whole host back
                 line['cpu_baseline'] = cpu_baseline(cfg, args.pts_per_frame)
             except Exception as e:                                     # the baseline must never take the bench line down
                 line['cpu_baseline'] = {'value': None, 'unit': 'LiDAR-frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',

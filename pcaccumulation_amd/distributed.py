@@ -56,6 +56,49 @@ def world_size():
     return dist.get_world_size() if dist.is_initialized() else 1
 
 
+def l3_domains():
+    """The CPU sets that share a last-level cache, out of the CPUs this process may run on (Linux sysfs; [] when that is not readable)."""
+    try:
+        allowed = os.sched_getaffinity(0)
+    except (AttributeError, OSError):
+        return []
+    seen, out = set(), []
+    for cpu in sorted(allowed):
+        try:
+            with open('/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list' % cpu) as f:
+                text = f.read().strip()
+        except OSError:
+            return []
+        if text in seen:
+            continue
+        seen.add(text)
+        cpus = set()
+        for part in text.split(','):
+            lo, _, hi = part.partition('-')
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= allowed
+        if cpus:
+            out.append(sorted(cpus))
+    return out
+
+
+def bind_to_l3_domain(local_rank=0, local_world=1):
+    """Bind this process (every thread it has and will start) to the CPUs of ONE last-level-cache domain, a different one per local rank.
+    A training step keeps two host threads busy that hand the interpreter lock back and forth thousands of times (the thread issuing the
+    forward, the autograd thread issuing a backward: DataParallelStep's early_thread): left to the scheduler they land on different
+    sockets of a two-socket host in some runs and the step time is bimodal (mixed mode, four sequences, one MI355X box: 31.4 / 31.8 / 33.9 /
+    34.4 ms unbound, 31.1 - 31.6 ms bound; tools/gpu_r04_affinity.sh).  Returns the previous affinity (for os.sched_setaffinity(0, ...) to
+    restore, e.g. around CPU-heavy work that wants every core), or None when nothing was changed."""
+    doms = l3_domains()
+    if len(doms) < 2:
+        return None
+    before = os.sched_getaffinity(0)
+    n = len(doms)
+    idx = (int(local_rank) * max(n // max(int(local_world), 1), 1)) % n
+    os.sched_setaffinity(0, doms[idx])
+    return before
+
+
 def ranks_share_a_device():
     """True when this node runs more ranks than it has GPUs (torch.distributed.run exports LOCAL_WORLD_SIZE): the test configuration of a
     one-GPU box, never the production layout."""

@@ -127,3 +127,23 @@ def test_no_module_level_name_is_defined_twice():
         tree = ast.parse(open(os.path.join(root, name)).read())
         counts = collections.Counter(n.name for n in tree.body if isinstance(n, (ast.FunctionDef, ast.ClassDef)))
         assert not [k for k, v in counts.items() if v > 1], name
+
+
+def test_l3_domain_binding_is_a_subset_and_restorable():
+    """distributed.bind_to_l3_domain: one cache domain per local rank out of the CPUs the process may use; the returned set restores the rest."""
+    import os
+    from pcaccumulation_amd import distributed as pdist
+    before = os.sched_getaffinity(0)
+    doms = pdist.l3_domains()
+    assert all(set(d) <= before for d in doms) and len({c for d in doms for c in d}) == sum(len(d) for d in doms)
+    try:
+        prev = pdist.bind_to_l3_domain(1, 2)
+        if len(doms) < 2:
+            assert prev is None and os.sched_getaffinity(0) == before
+        else:
+            assert prev == before and os.sched_getaffinity(0) == set(doms[len(doms) // 2])
+            os.sched_setaffinity(0, before)
+            pdist.bind_to_l3_domain(0, 2)
+            assert os.sched_getaffinity(0) == set(doms[0])
+    finally:
+        os.sched_setaffinity(0, before)
