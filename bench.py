@@ -54,8 +54,9 @@ def build(cfg, device, seed=0):
 class BatchFeed(object):
     """One batch ahead: next() hands out the batch whose voxelisation was queued (on a side stream) during the previous step,
     prefetch() queues the following one -- every step still voxelises and collates exactly one batch.  train_step calls
-    prefetch() after the forward pass, so the side stream's copies run under the backward pass and not under the
-    pillar-scatter launch the roofline object times."""
+    prefetch() while the forward waits for its host sync (after the pillar-scatter launch the roofline object times has been issued; the
+    side stream's kernels then run into the host-bound stretch behind the sync), and again after the forward for a forward without that hook
+    (a no-op when the batch is already queued)."""
 
     def __init__(self, batcher, batch_of, ahead, prepare=None):
         self.batcher, self.batch_of, self.ahead, self.i, self.prepare = batcher, batch_of, ahead, 0, prepare
@@ -88,7 +89,9 @@ def train_step(stepper, batcher, scenes):
     `iter_size` micro-steps -- agreement across ranks, non-finite check, clip, Adam, zero."""
     feed = isinstance(scenes, BatchFeed)
     inp = scenes.next() if feed else batcher(scenes)
-    stats = stepper(inp, after_forward=scenes.prefetch if feed else None, after_backward=scenes.prepare_next if feed else None)
+    early = feed and os.environ.get('PCACC_PREFETCH_AT', 'sync') == 'sync'       # 'forward': after the forward's launches, as rounds 2-4 did (A/B)
+    stats = stepper(inp, before_sync=scenes.prefetch if early else None, after_forward=scenes.prefetch if feed else None,
+                    after_backward=scenes.prepare_next if feed else None)
     if stats is not None and hasattr(stats, 'resolve'):
         stats.resolve()                 # the metrics the reference reads with .item(): on the host before the step counts as done
     return stats

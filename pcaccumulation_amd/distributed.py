@@ -448,8 +448,9 @@ class DataParallelStep(object):
     def skipped(self):
         return self.skipped_steps()
 
-    def __call__(self, inp, after_forward=None, after_backward=None):
-        """One micro-step on `inp`.  Returns the loss stats (None when this rank's forward failed)."""
+    def __call__(self, inp, after_forward=None, after_backward=None, before_sync=None):
+        """One micro-step on `inp`.  Returns the loss stats (None when this rank's forward failed).  before_sync: called inside the forward right
+        before its host sync (MotionNet.before_sync); after_forward / after_backward: after the forward's / the backward's launches are issued."""
         r = self.reducer
         if self.micro == 0:
             r.zero()
@@ -506,6 +507,8 @@ class DataParallelStep(object):
             if self.pipelined:
                 self.model.after_ego = early_backward
                 self.model.side_stream = self.side
+            if before_sync is not None and hasattr(self.model, 'before_sync'):
+                self.model.before_sync = before_sync
             try:
                 out = self.model(inp)
             except BaseException:
@@ -518,6 +521,8 @@ class DataParallelStep(object):
                 if self.pipelined:
                     self.model.after_ego = None
                     self.model.side_stream = None
+                if before_sync is not None and hasattr(self.model, 'before_sync'):
+                    self.model.before_sync = None
             if after_forward is not None:
                 after_forward()
             two = self.side is not None and bool(early)

@@ -105,6 +105,7 @@ class MotionNet(nn.Module):
         self.cell_ordered_pillars = bool(cfg['misc'].get('cell_ordered_pillars', True))
         self._optimizer_watched = False          # watch_optimizer()
         self.after_ego = None                    # optional callable(results), see forward()
+        self.before_sync = None                  # optional callable(): host work to do while the forward waits for its one host sync, see forward()
         self.side_stream = None                  # optional torch.cuda.Stream for stages 5-6 while after_ego's backward runs
 
     # ------------------------------------------------------------------------------------------------
@@ -264,6 +265,11 @@ class MotionNet(nn.Module):
                 geo_rows = self.ego_feats_head.sparse_rows(bev_feats)
             else:
                 geo_rows = ops.nchw_as_rows(ops.exit_mixed(self.ego_feats_head(bev_feats)))      # the ego head reads fp32 (mixed mode: the twin)
+        if self.before_sync is not None:
+            # the host is about to wait for the GPU to reach the sizes (the whole lower half of the forward is still queued): anything the caller wants
+            # issued that does not depend on this forward -- the next batch's voxelisation on its own stream -- costs no host time here, and its
+            # kernels run into the host-bound stretch that follows the wait (the ego head's ~100 small launches) instead of into the backward
+            self.before_sync()
         sizes = sizes.numpy().tolist()
         nf = B * T + 1
         frame_offsets, bg_at = sizes[:nf], sizes[nf:2 * nf]
