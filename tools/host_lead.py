@@ -62,6 +62,15 @@ def lower_marked(*a, **k):
 
 
 model.pillar_encoder.forward = lower_marked
+ego_fp = model.ego_motion_head.forward_pillars
+
+
+def ego_marked(*a, **k):
+    mark('host sync returned, ego head starts')
+    return ego_fp(*a, **k)
+
+
+model.ego_motion_head.forward_pillars = ego_marked
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 for _ in range(4):
     bench.train_step(stepper, batcher, feed)
@@ -74,7 +83,8 @@ for it in range(n):
     t0 = time.perf_counter()                                # host and GPU clocks aligned here (to the sync's return latency)
     del marks[:]
     mark('step starts')
-    bench.train_step(stepper, batcher, feed)
+    inp = feed.next()
+    stepper(inp, before_sync=lambda: (mark('lower half issued, host starts waiting'), feed.prefetch()), after_forward=feed.prefetch).resolve()
     mark('backward + clip + Adam issued')
     torch.cuda.synchronize()
     t_end = time.perf_counter()
