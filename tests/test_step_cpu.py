@@ -37,3 +37,28 @@ def test_pipelined_step_with_few_foreground_points_still_steps(monkeypatch):
         assert abs(got[True][0] - got[False][0]) <= 1e-5 * abs(got[False][0])
         for k, g in got[False][1].items():
             assert torch.allclose(got[True][1][k], g, rtol=1e-4, atol=1e-6 * float(g.abs().max()) + 1e-12), k
+
+
+def test_step_hooks_are_called_once_each_and_cleared(monkeypatch):
+    """before_sync (inside the forward, in front of its one host sync), after_forward, after_backward: each exactly once per micro-step, in that
+    order, and the model keeps no hook of the step afterwards -- also when the forward raises."""
+    cpu_backend.install(monkeypatch)
+    cfg = default_config('waymo', 'train', n_sweeps=3, xy_range=8)
+    inp = dist_worker.motionnet_batch(cfg, 0)
+    model = dist_worker.motionnet_model(cfg)
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)
+    step = pdist.DataParallelStep(model, opt, FuseLoss(cfg['loss']), iter_size=1, grad_clip=None, catch=False, pipelined=True)
+    assert not step._early_thread and not step._tuning                  # the helper thread is a GPU matter
+    calls = []
+    stats = step(inp, before_sync=lambda: calls.append('sync'), after_forward=lambda: calls.append('fwd'), after_backward=lambda: calls.append('bwd'))
+    assert calls == ['sync', 'fwd', 'bwd'] and stats is not None
+    assert model.before_sync is None and model.after_ego is None and model.side_stream is None
+
+    def boom():
+        raise RuntimeError('data pipeline')
+    try:
+        step(inp, before_sync=boom)
+        raise AssertionError('the hook error must surface')
+    except RuntimeError as e:
+        assert 'data pipeline' in str(e)
+    assert model.before_sync is None and model.after_ego is None
