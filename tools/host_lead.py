@@ -38,9 +38,9 @@ def mark(name):
 early_terms, call = loss_fn.early_terms, type(loss_fn).__call__
 
 
-def early_terms_marked(results):
+def early_terms_marked(results, **k):
     mark('sync + ego head issued (early backward starts)')
-    return early_terms(results)
+    return early_terms(results, **k)
 
 
 class Marked(type(loss_fn)):
