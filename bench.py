@@ -4,17 +4,20 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A step = one pass of the hot path over one synthetic 5-frame x 160k-point sequence per GPU (BASELINE config
-c3 shape): GPU voxelisation + collate layout -> MotionNet forward (bf16 canvas / conv stacks, fp32 ego head)
--> FuseLoss -> backward into a flat gradient buffer (N > 1: bucketed all-reduce overlapped with backward) -> non-finite check
--> grad clip -> Adam step (pdist.DataParallelStep, the cadence of libs/trainer.py:165-237).  Inputs (raw points,
-labels, poses) are resident in HBM before the timed region.  Scenes are independent, so ranks run different
-scenes and the only collective is the gradient all-reduce: weak scaling.
+A step = one pass of the hot path over `--batch` (default 4: the reference's train.batch_size) synthetic 5-frame x 160k-point sequences per
+GPU (BASELINE config c3 shape): GPU voxelisation + collate layout -> MotionNet forward -> FuseLoss -> backward into a flat gradient buffer
+(N > 1: bucketed all-reduce overlapped with backward) -> non-finite check -> grad clip -> Adam step (pdist.DataParallelStep, the cadence of
+libs/trainer.py:165-237).  Default compute mode `mixed`: the fp32-accurate forward (outputs within 1e-3 of the reference) with a bf16 gradient
+graph; the all-bf16 step is timed beside it (`bf16` object).  Inputs (raw points, labels, poses) are resident in HBM before the timed region.
+Scenes are independent, so ranks run different scenes and the only collective is the gradient all-reduce: weak scaling.
 
-Extra objects on the JSON line: `roofline` for the pillar-scatter kernel (the kernel BASELINE.json's north_star
-names), timed live with HIP events on the launch stream inside the timed region; `cpu_baseline`: the same step
-on the host cores with the oracle-backed CPU backend (rank 0, N = 1 only); `matched_accuracy`: the same step with fp32 compute,
-the precision at which the path matches the reference within 1e-3 (N = 1 only).
+Host side: the process is bound to the CPUs of one last-level-cache domain (`--cpu-affinity l3`, a different domain per local rank; restored
+for the CPU baseline), and the stepper decides over its first seven steps -- inside the warm-up at the default `--warmup 5` plus two timed
+steps -- whether it issues its early backward from a helper thread (`config.early_backward_thread` reports the measurement).
+
+Extra objects on the JSON line: `roofline` for the pillar-scatter kernel (the kernel BASELINE.json's north_star names), timed live with HIP
+events on the launch stream inside the timed region; `cpu_baseline`: the same step on the host cores with the oracle-backed CPU backend (rank 0,
+N = 1 only); `bf16` / `matched_accuracy`: the same step in the other compute mode (N = 1 only); `configs`: the other BASELINE configurations.
 """
 import argparse
 import json
