@@ -40,3 +40,25 @@ def test_two_gloo_ranks_share_the_gpu():
     assert d['config']['step_variant'] == 'one backward', d['config']['step_variant']
     # two sequences per rank, two ranks time-slicing one device + a gloo all-reduce of 44.5 MB through host memory: ~45-55 ms measured; the collapse was 388 - 2 555 ms
     assert d['ms_per_step'] < 150, d['ms_per_step']
+
+
+def test_single_rank_line_keeps_the_contract():
+    """`python bench.py --steps K --warmup W` (one rank, short): ONE JSON line with the contract's keys, the roofline object of the pillar-scatter
+    kernel (HBM-bound, fraction = achieved / peak, positive measured duration), the configured step variant, the host-side settings, and EXACTLY
+    K timed steps."""
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '4', '--warmup', '3', '--batch', '2', '--no-cpu-baseline', '--no-fp32-leg', '--no-configs',
+           '--no-step-model']
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config',
+              'roofline'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['steps'] == 4 and d['warmup'] == 3 and d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None
+    assert d['dtype'] == 'mixed' and d['data'] == 'synthetic' and 'workload' in d['config'] and 'model' not in d['config']
+    assert abs(d['value'] - 2 * 5 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']          # frames per second of 2 sequences x 5 frames per step
+    r = d['roofline']
+    assert r['bound'] == 'hbm' and r['peak'] == 8000.0 and r['unit'] == 'GB/s' and 0.05 < r['frac'] < 1.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
+    assert d['config']['step_variant'].startswith('staged') and 'cpu_affinity' in d['config'] and 'early_backward_thread' in d['config']
