@@ -12,8 +12,9 @@ graph; the all-bf16 step is timed beside it (`bf16` object).  Inputs (raw points
 Scenes are independent, so ranks run different scenes and the only collective is the gradient all-reduce: weak scaling.
 
 Host side: the process is bound to the CPUs of one last-level-cache domain (`--cpu-affinity l3`, a different domain per local rank; restored
-for the CPU baseline), and the stepper decides over its first seven steps -- inside the warm-up at the default `--warmup 5` plus two timed
-steps -- whether it issues its early backward from a helper thread (`config.early_backward_thread` reports the measurement).
+for the CPU baseline), and the stepper decides over its first five steps -- inside the warm-up at the default `--warmup 5` -- whether it
+issues its early backward from a helper thread (`config.early_backward_thread` reports the measurement).  The line carries the spread of
+the timed steps beside their mean (`ms_per_step_p10 / _p50 / _p90`: device time between the steps' first launches).
 
 Extra objects on the JSON line: `roofline` for the pillar-scatter kernel (the kernel BASELINE.json's north_star names), timed live with HIP
 events on the launch stream inside the timed region; `cpu_baseline`: the same step on the host cores with the oracle-backed CPU backend (rank 0,
@@ -89,6 +90,56 @@ class BatchFeed(object):
         (pillar index, CSR, per-pillar means, point features) on the prefetch stream, under the rest of the current step."""
         if self.ahead and self.pending is not None and self.prepare is not None:
             self.batcher.finish_early(self.pending, self.prepare)
+
+
+class Watchdog(object):
+    """No progress for S seconds -> every thread's Python stack on stderr and the process exits with status 1 (a fresh exit of THIS process; the
+    launcher then ends the other ranks).  The timer is faulthandler's C thread: it fires although the main thread sits in a runtime call that holds the
+    interpreter lock.  arm() restarts it -- called at every phase boundary and after every step -- so S bounds one step, not the run.
+    PCACC_HANG_DUMP = S (seconds; 0 = off).  Default: 120 s with a process group (a rank that waits for a peer that died or never arrives must not sit
+    there until somebody's 10-minute limit), off for a single process; the first interval (imports of the other ranks, rendezvous, library load, the
+    first step's code-object load and library find) gets 3 S."""
+
+    def __init__(self):
+        v = os.environ.get('PCACC_HANG_DUMP')
+        if v is None:
+            v = '120' if int(os.environ.get('WORLD_SIZE', '1')) > 1 else '0'
+        try:
+            self.seconds = float(v)
+        except ValueError:
+            self.seconds = 0.0
+        self.trace = bool(os.environ.get('PCACC_BENCH_TRACE'))
+        self.t0 = time.time()
+
+    def arm(self, what=None, first=False):
+        if self.trace and what:
+            print('[bench rank %s +%.1fs] %s' % (os.environ.get('RANK', '0'), time.time() - self.t0, what), file=sys.stderr, flush=True)
+        if self.seconds > 0:
+            import faulthandler
+            faulthandler.dump_traceback_later(self.seconds * (3 if first else 1), exit=True)
+
+    def off(self):
+        if self.seconds > 0:
+            import faulthandler
+            faulthandler.cancel_dump_traceback_later()
+
+
+watchdog = Watchdog()
+
+
+def die_with_launcher():
+    """A rank started by torch.distributed.run lives in its own session (elastic's subprocess handler): killing the launcher -- a test's or a driver's
+    timeout -- would leave the ranks behind, holding the GPU.  Ask the kernel to SIGKILL this process when its parent goes (prctl PR_SET_PDEATHSIG)."""
+    if 'TORCHELASTIC_RUN_ID' not in os.environ and int(os.environ.get('WORLD_SIZE', '1')) <= 1:
+        return
+    try:
+        import ctypes
+        import signal
+        ctypes.CDLL('libc.so.6', use_errno=True).prctl(1, int(signal.SIGKILL), 0, 0, 0)
+        if os.getppid() == 1:                                   # the launcher went between fork and prctl
+            os._exit(1)
+    except (OSError, AttributeError):
+        pass
 
 
 def train_step(stepper, batcher, scenes):
@@ -273,7 +324,7 @@ def config_throughput(kind, name, dataset, T, ppf, batch, mode, steps, warmup, d
         def run():
             with torch.no_grad():
                 model(batcher(scenes))
-    for _ in range(max(warmup, 7) if kind == 'train' else warmup):     # a train stepper settles how it issues its early backward over its first seven steps
+    for _ in range(max(warmup, 5) if kind == 'train' else warmup):     # a train stepper settles how it issues its early backward over its first five steps
         run()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -336,7 +387,9 @@ def main():
     ap.add_argument('--no-configs', action='store_true', help='skip the short runs of the other BASELINE.json configurations (c2 / c4 eval forward, c3 at one sequence per step, c5 train step) reported as `configs` at N = 1')
     ap.add_argument('--no-step-model', action='store_true', help='skip the instrumented extra step behind roofline_step and the cold-cache scatter launches')
     ap.add_argument('--no-fp32-leg', '--no-second-leg', dest='no_fp32_leg', action='store_true', help='skip the second timing of the same step in the other mode (bf16 beside the mixed headline; fp32x3 beside a bf16 run) that follows at N = 1')
-    ap.add_argument('--no-miopen-find', action='store_true', help='library convolutions through the immediate-mode heuristic instead of the find-db')
+    ap.add_argument('--miopen-find', action='store_true', help='library find mode (torch.backends.cudnn.benchmark) for whatever still goes to the convolution library; off by default: '
+                    'no convolution of the default step does, and the headline must not depend on an untracked find-db directory')
+    ap.add_argument('--no-miopen-find', action='store_true', help='(default since round 5; kept for the command lines of earlier rounds)')
     ap.add_argument('--pipeline', action='store_true', help='force the staged step (default: staged with a second stream at N = 1, one backward at N > 1)')
     ap.add_argument('--no-pipeline', action='store_true', help='one backward at the end of the forward instead of the early backward of the ego / fb / perm terms (DataParallelStep.pipelined)')
     ap.add_argument('--one-stream', action='store_true', help='motion heads and TubeNet on the main stream behind the early backward instead of beside it on a second stream')
@@ -344,9 +397,8 @@ def main():
     ap.add_argument('--cpu-affinity', default='l3', choices=['l3', 'none'], help="'l3' (default): bind the process to the CPUs of one last-level-cache domain (a different one per local rank) for the GPU part of the run -- the step's two host threads then share a cache instead of landing on two sockets in some runs (distributed.bind_to_l3_domain); restored for the CPU baseline")
     ap.add_argument('--no-prefetch', action='store_true', help='voxelise each batch at the start of its own step instead of one step ahead on a side stream')
     args = ap.parse_args()
-    if os.environ.get('PCACC_HANG_DUMP'):                      # debugging aid: every thread's Python stack after N seconds, then exit
-        import faulthandler
-        faulthandler.dump_traceback_later(float(os.environ['PCACC_HANG_DUMP']), exit=True)
+    die_with_launcher()
+    watchdog.arm(first=True)
 
     # PCACC_DIST_BACKEND=gloo lets the N > 1 path be exercised on a box with fewer GPUs than ranks (ranks then share
     # cuda:0); the driver's multi-GPU runs use the default: nccl = RCCL over xGMI, one rank per GPU.
@@ -359,16 +411,15 @@ def main():
     if args.cpu_affinity == 'l3':
         affinity_before = pdist.bind_to_l3_domain(int(os.environ.get('LOCAL_RANK', '0')), int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('WORLD_SIZE', '1'))))
     rank, world, local_rank = pdist.init_from_env(backend)
+    watchdog.arm('process group up (world %d)' % world, first=True)
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit('--gpus %d needs torch.distributed.run with --nproc-per-node %d' % (args.gpus, args.gpus))
     device = torch.device('cuda', local_rank % n_dev)
     torch.cuda.set_device(device)
     pdist.per_rank_library_cache(rank, world)
     native.lib()
-    if not args.no_miopen_find:
-        # MIOpen find mode for the layers that stay with the library (c_in >= 128): the applicable solvers are benchmarked once
-        # per layer shape and the choice is kept in the user find-db (.miopen_cache/, travels with the repo); the immediate-mode
-        # heuristic picks kernels that are ~1.5 ms per step slower in total
+    watchdog.arm('libpcacc_hip.so loaded', first=True)
+    if args.miopen_find and not args.no_miopen_find:
         torch.backends.cudnn.benchmark = True
 
     cfg = default_config('waymo', 'train', n_sweeps=T_FRAMES)
@@ -389,23 +440,46 @@ def main():
                     ) if stepper.pipelined else 'one backward'
     torch.manual_seed(1234 + rank)
     feed = BatchFeed(batcher, batch_of, not args.no_prefetch, prepare=model.prepare_inputs if args.prepare_ahead else None)
+    watchdog.arm('model, scenes and first prefetch queued', first=True)
     for i in range(args.warmup):
         train_step(stepper, batcher, feed)
+        if watchdog.trace:
+            torch.cuda.synchronize()
+        watchdog.arm('warm-up step %d done' % i)
 
     native.scatter_timer = []
     pdist.barrier()
     torch.cuda.synchronize()
+    watchdog.arm('warm-up done, barrier passed')
+    collectives_before = stepper.reducer.collectives
     t0 = time.perf_counter()
+    marks = []                                                          # one event per step boundary on the main stream: the spread of the K steps
     for i in range(args.steps):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        marks.append(ev)
         train_step(stepper, batcher, feed)
+        watchdog.arm()
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record()
+    marks.append(ev)
     torch.cuda.synchronize()
     pdist.barrier()
+    watchdog.arm('timed steps done')
+    collectives_per_step = (stepper.reducer.collectives - collectives_before) / max(args.steps, 1)
+    stepper_buckets = list(stepper.reducer.buckets)
     dt = pdist.max_over_ranks(time.perf_counter() - t0, device)
     timer, native.scatter_timer = native.scatter_timer, None
+    per_step = sorted(a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:]))
+
+    def pct(q):
+        return per_step[min(len(per_step) - 1, int(round(q * (len(per_step) - 1))))] if per_step else None
     if stepper.skipped:
         raise SystemExit('bench: %d optimizer step(s) were skipped (rank %d: %r)' % (stepper.skipped, rank, stepper.last_error))
     thread_choice = getattr(stepper, 'early_thread_choice', None)     # how the stepper settled on issuing its early backward (distributed.DataParallelStep)
     model_tot = flushed = None
+    if world == 1:
+        watchdog.off()                                                  # the single-process legs below (other modes, other configs, CPU baseline) run minutes by design
     if rank == 0 and not args.no_step_model:
         try:
             model_tot = step_model(stepper, batcher, feed)
@@ -473,6 +547,7 @@ def main():
         line = {
             'metric': 'LiDAR-frames/sec (5-frame seq, 160k pts) fwd+bwd', 'value': frames / dt, 'unit': 'LiDAR-frames/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'ms_per_step_p10': pct(0.1), 'ms_per_step_p50': pct(0.5), 'ms_per_step_p90': pct(0.9),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': 'c3 shape: Waymo geometry 288x288x%d, %d pts/frame %s synthetic, %d sequences per GPU per step, '
                                    'train step = GPU voxelise + MotionNet fwd + FuseLoss + bwd + bucketed grad all-reduce (overlapped) + clip + Adam'
@@ -487,7 +562,8 @@ def main():
                        'cpu_affinity': ('one L3 domain: %d CPUs' % len(os.sched_getaffinity(0))) if affinity_before is not None else 'unbound',
                        'HIP_FORCE_DEV_KERNARG': os.environ.get('HIP_FORCE_DEV_KERNARG')},
             'distributed': {'world_size': world, 'backend': (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
-                            'device': str(device), 'ranks_per_device': max(1, world // n_dev) if world > n_dev else 1},
+                            'device': str(device), 'ranks_per_device': max(1, world // n_dev) if world > n_dev else 1,
+                            'collectives_per_step': collectives_per_step, 'gradient_buckets': len(stepper_buckets), 'bucket_mb': [round(4e-6 * (e - b), 2) for b, e in stepper_buckets]},
             'roofline': {'kernel': 'pillar_scatter_rows16 (BEV canvas fill, bf16 rows -> bf16 canvas)' if main_bf16 else 'pillar_scatter_vec4<0> (BEV canvas fill)', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
                          'traffic_source': 'PMC FETCH_SIZE x2 + WRITE_SIZE (calibrated on a 128 MiB copy), profiles/%s' % pmc_file,
@@ -537,7 +613,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             try:
                 if affinity_before is not None:
-                    os.sched_setaffinity(0, affinity_before)       # the CPU leg probes 8 / 16 / 32 threads: give it the whole host back
+                    pdist.set_affinity_all_threads(affinity_before)  # the CPU leg probes 8 / 16 / 32 threads: give it -- every existing thread, pools included -- the whole host back
                 line['cpu_baseline'] = cpu_baseline(cfg, args.pts_per_frame)
             except Exception as e:                                     # the baseline must never take the bench line down
                 line['cpu_baseline'] = {'value': None, 'unit': 'LiDAR-frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',

@@ -174,6 +174,42 @@ __global__ __launch_bounds__(256) void pillar_scatter_rows16(const uint4 *__rest
     }
 }
 
+// The same fill with K 16-byte pieces per lane and iteration -- K table words, then K row pieces, then K stores in flight per lane -- and, with NT,
+// the streaming cache policy on both sides (`nt` loads of the row table, `nt` stores of the canvas: every byte is touched once by this kernel).
+typedef uint32_t pcacc_u32x4 __attribute__((ext_vector_type(4)));
+template <int K, bool NT>
+__global__ __launch_bounds__(256) void pillar_scatter_rows16_k(const pcacc_u32x4 *__restrict__ feats, const int32_t *__restrict__ c2p,
+                                                               int64_t n_pieces, int ppc /*16-byte pieces per cell*/, pcacc_u32x4 *__restrict__ canvas)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t e0 = (int64_t)blockIdx.x * 256 + threadIdx.x; e0 < n_pieces; e0 += K * stride) {
+        int p[K];
+        int64_t src[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int64_t e = e0 + k * stride;
+            const bool in = e < n_pieces;
+            const int64_t cell = in ? e / ppc : 0;
+            p[k] = in ? (NT ? __builtin_nontemporal_load(c2p + cell) : c2p[cell]) : -1;
+            src[k] = e - cell * ppc;
+        }
+        pcacc_u32x4 o[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            o[k] = (pcacc_u32x4){0u, 0u, 0u, 0u};
+            if (p[k] >= 0) o[k] = NT ? __builtin_nontemporal_load(feats + (int64_t)p[k] * ppc + src[k]) : feats[(int64_t)p[k] * ppc + src[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int64_t e = e0 + k * stride;
+            if (e < n_pieces) {
+                if (NT) __builtin_nontemporal_store(o[k], canvas + e);
+                else canvas[e] = o[k];
+            }
+        }
+    }
+}
+
 // narrow canvases (C = 1, 2, 3: occupancy, labels, pillar means) -- one element per lane
 template <int OUT_BF16>
 __global__ __launch_bounds__(256) void pillar_scatter_scalar(const float *__restrict__ feats, const int32_t *__restrict__ c2p,
@@ -199,12 +235,20 @@ static int pillar_scatter_launch(const void *feats, int feats_dtype, const int32
     if (feats_dtype != PCACC_F32 && !(feats_dtype == PCACC_BF16 && dtype == PCACC_BF16 && c % 8 == 0)) return PCACC_E_ARG;
     if (n_cells == 0) return PCACC_OK;
     int64_t n;
-    int width;
+    int width, per_lane = 1;
     const void *fn;
     if (feats_dtype == PCACC_BF16) {
         width = c / 8;
         n = n_cells * width;
         fn = reinterpret_cast<const void *>(pillar_scatter_rows16);
+        switch (pcacc_switches().scatter_variant) {               // A/B: PCACC_SCATTER_VARIANT
+        case '1': fn = reinterpret_cast<const void *>(pillar_scatter_rows16_k<4, true>); per_lane = 4; break;
+        case '2': fn = reinterpret_cast<const void *>(pillar_scatter_rows16_k<2, true>); per_lane = 2; break;
+        case '3': fn = reinterpret_cast<const void *>(pillar_scatter_rows16_k<4, false>); per_lane = 4; break;
+        case '4': fn = reinterpret_cast<const void *>(pillar_scatter_rows16_k<8, true>); per_lane = 8; break;
+        case '5': fn = reinterpret_cast<const void *>(pillar_scatter_rows16_k<1, true>); per_lane = 1; break;
+        default: per_lane = 2; break;
+        }
     } else if (dtype == PCACC_F32 ? (c % 4 == 0) : (c % 8 == 0)) {
         width = c / 4;
         n = dtype == PCACC_F32 ? n_cells * width : n_cells * (width / 2);
@@ -216,8 +260,9 @@ static int pillar_scatter_launch(const void *feats, int feats_dtype, const int32
     }
     // all kernel families take (features, cell2pillar, n, width, canvas)
     void *args[] = {(void *)&feats, (void *)&cell2pillar, (void *)&n, (void *)&width, (void *)&canvas};
-    const int64_t items = feats_dtype == PCACC_BF16 ? (n + 1) / 2 : n;
-    if (hipExtLaunchKernel(fn, dim3(pcacc_grid(items, 256)), dim3(256), args, 0, s, start, stop, 0) != hipSuccess) return PCACC_E_LAUNCH;
+    const int64_t items = (n + per_lane - 1) / per_lane;
+    const int blocks_per_cu = pcacc_switches().scatter_blocks > 0 ? pcacc_switches().scatter_blocks : 8;
+    if (hipExtLaunchKernel(fn, dim3(pcacc_grid(items, 256, PCACC_CUS * blocks_per_cu)), dim3(256), args, 0, s, start, stop, 0) != hipSuccess) return PCACC_E_LAUNCH;
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
 }
@@ -361,6 +406,10 @@ static void switches_read()
     g_switches.rows_fm_off = getenv("PCACC_ROWS_FM_OFF") != nullptr;
     g_switches.conv_plan = getenv("PCACC_CONV_PLAN") != nullptr;
     g_switches.conv_res = e ? e[0] : 0;
+    const char *v = getenv("PCACC_SCATTER_VARIANT");
+    g_switches.scatter_variant = v ? v[0] : 0;
+    const char *b = getenv("PCACC_SCATTER_BLOCKS");
+    g_switches.scatter_blocks = b ? atoi(b) : 0;
     g_switches_read = true;
 }
 

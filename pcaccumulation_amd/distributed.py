@@ -41,7 +41,8 @@ def init_from_env(backend=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    forced = world == 1 and os.environ.get('PCACC_FORCE_PROCESS_GROUP') == '1' and 'MASTER_ADDR' in os.environ
+    if (world > 1 or forced) and not dist.is_initialized():
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -82,12 +83,29 @@ def l3_domains():
     return out
 
 
+def set_affinity_all_threads(cpus):
+    """sched_setaffinity for EVERY thread this process has now (Linux binds one thread per call and only threads created afterwards inherit: the
+    OpenMP / intra-op pool threads that already exist would otherwise keep their old mask -- ADVICE round 4); -> number of threads changed."""
+    n = 0
+    try:
+        tids = [int(t) for t in os.listdir('/proc/self/task')]
+    except OSError:
+        tids = [0]
+    for tid in tids:
+        try:
+            os.sched_setaffinity(tid, cpus)
+            n += 1
+        except OSError:                                       # a thread that ended meanwhile
+            pass
+    return n
+
+
 def bind_to_l3_domain(local_rank=0, local_world=1):
-    """Bind this process (every thread it has and will start) to the CPUs of ONE last-level-cache domain, a different one per local rank.
+    """Bind this process (every thread it has -- set_affinity_all_threads -- and will start) to the CPUs of ONE last-level-cache domain, a different one per local rank.
     A training step keeps two host threads busy that hand the interpreter lock back and forth thousands of times (the thread issuing the
     forward, the autograd thread issuing a backward: DataParallelStep's early_thread): left to the scheduler they land on different
     sockets of a two-socket host in some runs and the step time is bimodal (mixed mode, four sequences, one MI355X box: 31.4 / 31.8 / 33.9 /
-    34.4 ms unbound, 31.1 - 31.6 ms bound; tools/gpu_r04_affinity.sh).  Returns the previous affinity (for os.sched_setaffinity(0, ...) to
+    34.4 ms unbound, 31.1 - 31.6 ms bound; tools/gpu_r04_affinity.sh).  Returns the previous affinity (for set_affinity_all_threads(...) to
     restore, e.g. around CPU-heavy work that wants every core), or None when nothing was changed."""
     doms = l3_domains()
     if len(doms) < 2:
@@ -95,18 +113,49 @@ def bind_to_l3_domain(local_rank=0, local_world=1):
     before = os.sched_getaffinity(0)
     n = len(doms)
     idx = (int(local_rank) * max(n // max(int(local_world), 1), 1)) % n
-    os.sched_setaffinity(0, doms[idx])
+    set_affinity_all_threads(doms[idx])
     return before
 
 
+_SHARED = {}
+
+
 def ranks_share_a_device():
-    """True when this node runs more ranks than it has GPUs (torch.distributed.run exports LOCAL_WORLD_SIZE): the test configuration of a
-    one-GPU box, never the production layout."""
+    """True when two ranks of this job run on the same physical GPU: the test configuration of a one-GPU box, never the production layout.
+    Decided from device identity -- every rank's (host, PCI bus id of its current device) gathered once per process group -- not from counting
+    visible devices: a launcher that gives each rank its own HIP_VISIBLE_DEVICES mask shows every rank ONE device, and LOCAL_WORLD_SIZE >
+    device_count() would call the one-rank-per-GPU layout 'shared' (ADVICE round 4).  Without a process group: LOCAL_WORLD_SIZE against the
+    device count, as before."""
+    if not torch.cuda.is_available():
+        return False
+    if dist.is_initialized():
+        key = id(dist.group.WORLD)
+        if key not in _SHARED:
+            import socket
+            try:
+                prop = torch.cuda.get_device_properties(torch.cuda.current_device())
+                ident = '%s/%s' % (socket.gethostname(), getattr(prop, 'uuid', None) or '%s:%s:%s' % (
+                    getattr(prop, 'pci_domain_id', '?'), getattr(prop, 'pci_bus_id', '?'), getattr(prop, 'pci_device_id', torch.cuda.current_device())))
+            except Exception:                                 # noqa: BLE001 -- identity unknown: fall back to the count below
+                ident = None
+            idents = [None] * dist.get_world_size()
+            dist.all_gather_object(idents, ident)
+            if any(i is None for i in idents):
+                _SHARED[key] = _count_says_shared()
+            else:
+                _SHARED[key] = len(set(idents)) < len(idents)
+            if dist.get_rank() == 0 and os.environ.get('PCACC_BENCH_TRACE'):
+                print('[distributed] devices of the ranks: %s -> %s' % (idents, 'shared' if _SHARED[key] else 'one rank per device'), file=sys.stderr)
+        return _SHARED[key]
+    return _count_says_shared()
+
+
+def _count_says_shared():
     try:
         local = int(os.environ.get('LOCAL_WORLD_SIZE', '1'))
     except ValueError:
         local = 1
-    return torch.cuda.is_available() and local > max(torch.cuda.device_count(), 1)
+    return local > max(torch.cuda.device_count(), 1)
 
 
 def _reachable_parameters(loss):
@@ -152,10 +201,14 @@ class BucketedGradReducer(object):
     def __init__(self, params, bucket_bytes=8 << 20):
         self.params = [p for p in params if p.requires_grad]
         self.world = world_size()
+        # `active`: gradients go through the flat buffer and the collectives.  One rank has nothing to reduce -- unless a process group exists and
+        # PCACC_FORCE_PROCESS_GROUP=1 asks for the production code path anyway (tests/test_bench_multirank.py: backend nccl at world size 1)
+        self.active = self.world > 1 or (dist.is_initialized() and os.environ.get('PCACC_FORCE_PROCESS_GROUP') == '1')
+        self.collectives = 0                                 # all-reduce calls issued so far (gradient buckets + agreement reduces)
         dev, dtype = self.params[0].device, self.params[0].dtype
         order = list(reversed(range(len(self.params))))
         self.numel = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(self.numel if self.world > 1 else 0, dtype=dtype, device=dev)
+        self.flat = torch.zeros(self.numel if self.active else 0, dtype=dtype, device=dev)
         self.views = [None] * len(self.params)
         self.bucket_of = [0] * len(self.params)
         self.members = [[]]                                  # parameter indices per bucket
@@ -167,7 +220,7 @@ class BucketedGradReducer(object):
                 self.buckets.append((start, off))
                 self.members.append([])
                 start = off
-            if self.world > 1:
+            if self.active:
                 self.views[i] = self._view_like(p, off)
             self.bucket_of[i] = len(self.buckets)
             self.members[-1].append(i)
@@ -202,7 +255,7 @@ class BucketedGradReducer(object):
     def _make_hook(self, i):
         def hook(param):
             self.touched[i] = True
-            if self._sync and self.world > 1:
+            if self._sync and self.active:
                 if not self._callback_queued:                # the rest of the buckets go out when this backward ends
                     torch.autograd.Variable._execution_engine.queue_callback(self._launch_all)
                     self._callback_queued = True
@@ -231,6 +284,7 @@ class BucketedGradReducer(object):
             torch._foreach_zero_(zero)
         avg = dist.get_backend() == 'nccl'
         work = dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=True)
+        self.collectives += 1
         self._works.append((work, b, avg))
 
     def _launch_ready(self):
@@ -265,7 +319,7 @@ class BucketedGradReducer(object):
         self._sync = bool(sync)
         self._works = []
         self._launched = [False] * len(self.buckets)
-        self._next = 0 if (self._sync and self.world > 1) else len(self._seq)
+        self._next = 0 if (self._sync and self.active) else len(self._seq)
         self._limit = self._next
 
     def prepare(self, loss, sync=None, part=None):
@@ -274,7 +328,7 @@ class BucketedGradReducer(object):
         if sync is not None:
             self.begin(sync)
         self._callback_queued = False
-        if not self._sync or self.world == 1:
+        if not self._sync or not self.active:
             return
         self._limit = self._n_early if part == 'early' else len(self._seq)
         reach = _reachable_parameters(loss) if loss is not None else None
@@ -290,14 +344,14 @@ class BucketedGradReducer(object):
 
     def flush(self):
         """A rank whose forward / backward raised still issues every collective of the step (in order), so the others do not hang."""
-        if self._sync and self.world > 1:
+        if self._sync and self.active:
             self._limit = len(self._seq)
             self._launch_all()
 
     def finish(self):
         """After backward: every bucket is out; the current stream waits for them (no host block with RCCL); `.grad` of every
         parameter becomes its averaged view."""
-        if not self._sync or self.world == 1:
+        if not self._sync or not self.active:
             self._sync = False
             return
         self._limit = len(self._seq)
@@ -317,12 +371,13 @@ class BucketedGradReducer(object):
         gradient"; it is read back on the host only by ranks that lack a gradient themselves (a skipped branch -- otherwise the
         answer is known to be "somebody did"), so the common step has no host synchronisation at all."""
         dev = self.params[0].device
-        if self.world == 1:
+        if not self.active:
             self._mask = None
             return torch.full((1,), 1 if ok else 0, dtype=torch.int32, device=dev)
         flags = torch.tensor([1 if ok else 0] + [0 if t else 1 for t in self.touched], dtype=torch.int32)
         t = flags.to(dev, non_blocking=True)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        self.collectives += 1
         self._mask = t[1:] if not all(self.touched) else None
         return t[:1]
 
@@ -332,7 +387,7 @@ class BucketedGradReducer(object):
 
         def __enter__(self):
             r = self.r
-            if r.world == 1:
+            if not r.active:
                 return                                        # untouched parameters already have .grad = None
             if r._mask is not None:                           # this rank skipped a branch: did every other rank skip it too?
                 absent = r._mask.cpu().tolist()
@@ -342,7 +397,7 @@ class BucketedGradReducer(object):
 
         def __exit__(self, *exc):
             r = self.r
-            if r.world > 1 and r._mask is not None:
+            if r.active and r._mask is not None:
                 for i, p in enumerate(r.params):
                     p.grad = r.views[i]
             return False
@@ -372,6 +427,11 @@ class DataParallelStep(object):
         # decision) and keeps the faster -- the way a convolution library picks its algorithm.  PCACC_EARLY_THREAD=0 / 1 fixes the choice.
         env = os.environ.get('PCACC_EARLY_THREAD')
         self._early_thread_want = (env == '1') if env in ('0', '1') else early_thread
+        try:                                                  # parsed here: a malformed value must not raise between "thread queued" and "thread started"
+            self._helper_switch_interval = float(os.environ.get('PCACC_SWITCH_INTERVAL', '2e-4'))
+        except ValueError:
+            self._helper_switch_interval = 2e-4
+        self._switch_interval = sys.getswitchinterval()
         self._tune_events = []
         # pipelined: back-propagate the loss terms of the lower half of the model (pillar encoder, U-Net, heads, ego head) as soon as
         # the ego head has run, before the motion heads and the TubeNet are even issued (MotionNet.after_ego, FuseLoss.early_terms);
@@ -405,15 +465,16 @@ class DataParallelStep(object):
         if self.pipelined and hasattr(model, 'early_parameters'):
             self.reducer.set_early(model.early_parameters())
         self.side = torch.cuda.Stream(device=dev) if (self.pipelined and want_side) else None
-        can_thread = bool(self.pipelined and dev.type == 'cuda')
+        # the helper thread only WITH the second stream: on one stream both threads would launch into the same queue and share native._ZERO_POOL's
+        # rotating rows under one key -- and there is nothing to gain, the two halves serialise on the device anyway
+        can_thread = bool(self.pipelined and dev.type == 'cuda' and self.side is not None)
         self._early_thread = bool(self._early_thread_want) and can_thread
         self._tuning = can_thread and self._early_thread_want is None
         self.early_thread_choice = None if self._tuning else ('fixed on' if self._early_thread else 'fixed off')
         # the optimizer's step invalidates the prepared (packed / split) convolution weights (fused optimizers do not bump version counters)
+        ops.watch_all_optimizers()                            # process-wide and registered once: also an optimizer created later (resume, LR phase change)
         if hasattr(model, 'watch_optimizer'):
             model.watch_optimizer(optimizer)
-        else:
-            optimizer.register_step_post_hook(lambda *a, **k: ops.weights_may_have_changed())
         self.micro = 0
         self.ok = True
         self.last_error = None
@@ -421,19 +482,18 @@ class DataParallelStep(object):
         self._device_skip = bool(getattr(optimizer, '_step_supports_amp_scaling', False))
 
     def _tune_step(self):
-        """Step 0: warm-up; steps 1-4 alternate (early backward from this thread, from the helper thread, this, helper); step 5: this thread; at the
-        start of step 6 the two pairs are compared by the device time between the steps' first launches (events recorded at the step boundaries
-        on the main stream)."""
+        """Step 0: warm-up; steps 1-4 alternate (early backward from this thread, from the helper thread, this, helper); at the start of step 5 the two
+        pairs are compared by the device time between the steps' first launches (events recorded at the step boundaries on the main stream) and step 5
+        already runs the way that won: with five warm-up steps (bench.py's default) no trial step falls into a timed region."""
         k = len(self._tune_events)
-        if k <= 6:
-            ev = torch.cuda.Event(enable_timing=True)
-            ev.record()
-            self._tune_events.append(ev)
-        if k < 6:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self._tune_events.append(ev)
+        if k < 5:
             self._early_thread = k in (2, 4)
             return
         ev = self._tune_events
-        ev[5].synchronize()                                   # reached by the GPU when step 4 was done: normally long past
+        ev[5].synchronize()                                   # reached by the GPU when step 4 was done (a bench has just synchronised anyway)
         plain, threaded = ev[1].elapsed_time(ev[2]) + ev[3].elapsed_time(ev[4]), ev[2].elapsed_time(ev[3]) + ev[4].elapsed_time(ev[5])
         self._early_thread = threaded < 0.98 * plain          # 2 %: below the run-to-run scatter of two steps
         self.early_thread_choice = 'measured: %.1f ms from this thread, %.1f ms from a helper thread per step -> %s' % (
@@ -464,12 +524,17 @@ class DataParallelStep(object):
         pending = []                                          # [(thread, [exception])] of an early backward issued from a helper thread
 
         def join_early():
+            """Join the helper thread (if one was started) and restore the interpreter's switch interval; re-raises what the thread raised."""
+            first = None
             while pending:
                 t, err = pending.pop()
-                t.join()
+                if t.ident is not None:                       # started
+                    t.join()
                 sys.setswitchinterval(self._switch_interval)
-                if err:
-                    raise err[0]
+                if err and first is None:
+                    first = err[0]
+            if first is not None:
+                raise first
 
         def early_backward(results):
             e = self.loss_fn.early_terms(results)
@@ -496,11 +561,11 @@ class DataParallelStep(object):
                 except BaseException as ex:                   # noqa: BLE001 -- re-raised in the step's thread by join_early
                     err.append(ex)
             t = threading.Thread(target=work, name='pcacc-early-backward', daemon=True)
-            pending.append((t, err))
             # two threads now want the interpreter lock (this one for the upper half's Python, the autograd thread for the backward's custom
             # functions): at the default 5 ms switch interval they starve each other in 5 ms turns
             self._switch_interval = sys.getswitchinterval()
-            sys.setswitchinterval(float(os.environ.get('PCACC_SWITCH_INTERVAL', '2e-4')))
+            pending.append((t, err))
+            sys.setswitchinterval(self._helper_switch_interval)
             t.start()
         r.begin(sync=last)
         try:
@@ -509,40 +574,42 @@ class DataParallelStep(object):
                 self.model.side_stream = self.side
             if before_sync is not None and hasattr(self.model, 'before_sync'):
                 self.model.before_sync = before_sync
+            # From the forward to the second backward, ONE try / finally joins the helper thread: whatever raises in between (the forward, a caller's
+            # after_forward hook, the hand-over to the side stream, the loss), no 'pcacc-early-backward' thread is left writing .grad and firing reducer
+            # hooks behind a step that has moved on to flush / clip / optimizer, and the interpreter's switch interval is restored.
             try:
-                out = self.model(inp)
+                try:
+                    out = self.model(inp)
+                finally:
+                    if self.pipelined:
+                        self.model.after_ego = None
+                        self.model.side_stream = None
+                    if before_sync is not None and hasattr(self.model, 'before_sync'):
+                        self.model.before_sync = None
+                if after_forward is not None:
+                    after_forward()
+                two = self.side is not None and bool(early)
+                if two:
+                    from .motionnet import share_with_stream
+                    share_with_stream(self.side, early[0], inp)
+                    self.side.wait_event(self._early_ready)
+                with (torch.cuda.stream(self.side) if two else contextlib.nullcontext()):
+                    stats = self.loss_fn(out, inp, early=early[0]) if early else self.loss_fn(out, inp)
+                    join_early()                              # the early backward is issued (and its errors are ours) before the second one starts
+                    loss = stats['loss'] / self.iter_size if self.iter_size > 1 else stats['loss']
+                    r.prepare(loss, part='rest')
+                    # after an early backward the rest of the loss may be constants only (motion heads and TubeNet both skipped on a batch
+                    # with 0 < n_fb <= MIN_POINTS): the early gradients are the step's gradients then, as in the unstaged path
+                    if loss.requires_grad or not early:
+                        loss.backward()
+                if two:
+                    torch.cuda.current_stream().wait_stream(self.side)     # join: clip / optimizer read the gradients of both halves
             except BaseException:
                 try:
-                    join_early()                              # never leave the helper thread running behind a failed forward
-                except BaseException:                         # noqa: BLE001 -- the forward's own error is the one to report
+                    join_early()                              # the first error is the one to report; the helper thread's own comes second
+                except BaseException:                         # noqa: BLE001
                     pass
                 raise
-            finally:
-                if self.pipelined:
-                    self.model.after_ego = None
-                    self.model.side_stream = None
-                if before_sync is not None and hasattr(self.model, 'before_sync'):
-                    self.model.before_sync = None
-            if after_forward is not None:
-                after_forward()
-            two = self.side is not None and bool(early)
-            if two:
-                from .motionnet import share_with_stream
-                share_with_stream(self.side, early[0], inp)
-                self.side.wait_event(self._early_ready)
-            with (torch.cuda.stream(self.side) if two else contextlib.nullcontext()):
-                try:
-                    stats = self.loss_fn(out, inp, early=early[0]) if early else self.loss_fn(out, inp)
-                finally:
-                    join_early()                              # the early backward is issued (and its errors are ours) before the second one starts
-                loss = stats['loss'] / self.iter_size if self.iter_size > 1 else stats['loss']
-                r.prepare(loss, part='rest')
-                # after an early backward the rest of the loss may be constants only (motion heads and TubeNet both skipped on a batch
-                # with 0 < n_fb <= MIN_POINTS): the early gradients are the step's gradients then, as in the unstaged path
-                if loss.requires_grad or not early:
-                    loss.backward()
-            if two:
-                torch.cuda.current_stream().wait_stream(self.side)     # join: clip / optimizer read the gradients of both halves
         except Exception as e:                                # noqa: BLE001 -- libs/trainer.py:234-235
             if not self.catch:
                 raise

@@ -120,12 +120,14 @@ class MotionNet(nn.Module):
         ops.weights_may_have_changed()
         return super().train(mode)
 
-    def watch_optimizer(self, optimizer):
-        """Invalidate the prepared convolution weights at the writer: every `optimizer.step()` calls ops.weights_may_have_changed()
-        (register_step_post_hook).  forward() then stops invalidating on its own, so the micro-steps of an accumulation window (iter_size > 1)
-        reuse one set of copies.  DataParallelStep calls this for its optimizer; call it yourself in a custom loop -- parameters that some
-        OTHER writer changes behind the version counter still need ops.weights_may_have_changed()."""
-        optimizer.register_step_post_hook(lambda *a, **k: ops.weights_may_have_changed())
+    def watch_optimizer(self, optimizer=None):
+        """Invalidate the prepared convolution weights at the writer: EVERY optimizer's step() in this process calls ops.weights_may_have_changed()
+        (ops.watch_all_optimizers: torch's process-wide post-step hook, registered once) -- the optimizer DataParallelStep was built with, one
+        re-created on resume or at a learning-rate phase change, a second one for another parameter group alike.  forward() then stops
+        invalidating on its own, so the micro-steps of an accumulation window (iter_size > 1) reuse one set of copies.  `optimizer` is accepted for
+        the call sites of earlier rounds and returned unchanged.  A writer that is neither an optimizer step nor visible to the parameters'
+        version counters (raw pointers) still needs ops.weights_may_have_changed()."""
+        ops.watch_all_optimizers()
         self._optimizer_watched = True
         return optimizer
 

@@ -1059,6 +1059,19 @@ def weights_may_have_changed():
     _WEIGHT_EPOCH += 1
 
 
+_ALL_OPTIMIZERS_WATCHED = False
+
+
+def watch_all_optimizers():
+    """Register -- once per process -- a post-step hook on EVERY torch optimizer (torch.optim.optimizer.register_optimizer_step_post_hook) that
+    calls weights_may_have_changed(): whichever optimizer object writes the parameters, now or later, the prepared copies are dropped."""
+    global _ALL_OPTIMIZERS_WATCHED
+    if not _ALL_OPTIMIZERS_WATCHED:
+        from torch.optim.optimizer import register_optimizer_step_post_hook
+        register_optimizer_step_post_hook(lambda *a, **k: weights_may_have_changed())
+        _ALL_OPTIMIZERS_WATCHED = True
+
+
 def _weight_key(weight):
     return (weight._version, weight.data_ptr(), _WEIGHT_EPOCH)
 

@@ -40,3 +40,11 @@ def _fp32_point_rows():
     from pcaccumulation_amd import native
     if native._lib is not None:                   # a test may have changed a launcher switch through the environment (monkeypatch is undone by now)
         native.reload_switches()
+
+
+def pytest_collection_modifyitems(config, items):
+    """Tests that start process trees (bench.py under the launcher, subprocess benches) run LAST: `pytest -x` then reaches every parity test before
+    the first process tree is started, and a launch that misbehaves cannot take the parity evidence with it (round 4: one hanging launch collected
+    first zeroed the GPU suite).  Stable for everything else."""
+    last = ('test_bench_multirank.py',)
+    items.sort(key=lambda it: 1 if os.path.basename(str(it.fspath)) in last else 0)

@@ -1,12 +1,20 @@
-"""bench.py with two ranks on the one GPU of the test box (gloo, both on cuda:0 -- the only N > 1 configuration such a box can run):
-the launch contract of the driver (`python -m torch.distributed.run ... bench.py --gpus N`), one JSON line from rank 0, no skipped
-steps, and a step time in the range two processes sharing a device can reach.  Guards against the collapse found in round 2 (second
-stream x process group x batch-prefetch stream: 1.4-2.9 s per step instead of ~75 ms) and against hangs."""
+"""bench.py through the launch contract of the driver (`python -m torch.distributed.run ... bench.py --gpus N`) on the one GPU of the test box:
+two gloo ranks sharing cuda:0 (the only N > 1 configuration such a box can run), one RCCL rank (backend nccl at world size 1: communicator
+set-up, the bucketed all-reduces, the agreement reduce and the staged two-stream step WITH a process group), and the single-process line.
+Guards against the collapse found in round 2 (second stream x process group x batch-prefetch stream: 1.4-2.9 s per step instead of ~75 ms,
+DESIGN.md section 6) and against hangs.
+
+These tests start process trees.  Every launch runs in its own session with bench.py's watchdog on (PCACC_HANG_DUMP: no step for that long ->
+every thread's stack on stderr, exit 1), is given a limit well under the suite's, and on timeout the WHOLE tree is killed (the launcher's
+ranks live in sessions of their own: they are found through /proc and killed by pid; bench.py additionally asks the kernel to kill a rank whose
+launcher died).  conftest.py collects this file last, so `pytest -x` reaches every parity test before the first process tree is started."""
 import json
 import os
+import signal
 import socket
 import subprocess
 import sys
+import time
 
 import pytest
 
@@ -22,24 +30,92 @@ def _free_port():
     return port
 
 
+def _descendants(pid):
+    """pids of every live descendant of `pid` (children sit in other sessions / process groups: walk /proc by parent pid)."""
+    parent = {}
+    for d in os.listdir('/proc'):
+        if d.isdigit():
+            try:
+                with open('/proc/%s/stat' % d) as f:
+                    parent[int(d)] = int(f.read().rsplit(')', 1)[1].split()[1])
+            except (OSError, ValueError, IndexError):
+                pass
+    out, todo = [], [pid]
+    while todo:
+        p = todo.pop()
+        kids = [c for c, pp in parent.items() if pp == p]
+        out += kids
+        todo += kids
+    return out
+
+
+def run_tree(cmd, env, limit):
+    """Run `cmd` in its own session; -> (returncode or None on timeout, stdout, stderr).  Whatever happens, nothing of its tree survives."""
+    proc = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    timed_out = False
+    try:
+        try:
+            out, err = proc.communicate(timeout=limit)
+        except subprocess.TimeoutExpired:
+            timed_out = True
+            tree = _descendants(proc.pid)
+            proc.send_signal(signal.SIGTERM)                    # the launcher's handler ends its ranks
+            try:
+                out, err = proc.communicate(timeout=10)
+            except subprocess.TimeoutExpired:
+                for p in tree + [proc.pid]:
+                    try:
+                        os.kill(p, signal.SIGKILL)
+                    except OSError:
+                        pass
+                out, err = proc.communicate()
+    finally:
+        for p in _descendants(proc.pid):                        # stragglers (none in a clean exit)
+            try:
+                os.kill(p, signal.SIGKILL)
+            except OSError:
+                pass
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except OSError:
+            pass
+    return (None if timed_out else proc.returncode), out, err
+
+
+def _launch(nproc, extra, env_extra, limit=170, hang_dump='45'):
+    env = dict(os.environ, PCACC_HANG_DUMP=hang_dump, PCACC_BENCH_TRACE='1', **env_extra)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc), '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', str(nproc)] + extra
+    t0 = time.time()
+    rc, out, err = run_tree(cmd, env, limit)
+    assert rc == 0, 'rc %r after %.0f s\n--- stderr tail ---\n%s' % (rc, time.time() - t0, err[-6000:])
+    lines = [l for l in out.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out[-2000:]                          # rank 0 prints, the others do not
+    return json.loads(lines[0])
+
+
 def test_two_gloo_ranks_share_the_gpu():
-    env = dict(os.environ, PCACC_DIST_BACKEND='gloo')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '2',
-           '--batch', '2', '--no-cpu-baseline', '--no-fp32-leg']
-    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
-    assert len(lines) == 1, out.stdout[-2000:]                  # rank 0 prints, rank 1 does not
-    d = json.loads(lines[0])
+    d = _launch(2, ['--steps', '3', '--warmup', '2', '--batch', '2', '--no-cpu-baseline', '--no-fp32-leg'], {'PCACC_DIST_BACKEND': 'gloo'})
     assert d['n_gpus'] == 2 and d['steps'] == 3 and d['scaling'] == 'weak' and d['config']['parallelism'] == 'dp2'
     assert d['value'] > 0 and 'roofline' in d
     # Ranks SHARING a device keep the plain one-stream step (DESIGN.md section 18: two processes x (main, side, prefetch) streams oversubscribe the device's
-    # hardware queues -- 388 ms per step at 4 queues per process, 2 555 at 8, 62.5 at 2 -- and the 2-queue setting hung once); one rank per device, the
+    # hardware queues -- 388 ms per step at 4 queues per process, 2 555 at 8, 62.5 at 2); one rank per device, the
     # production layout, runs the staged two-stream step of N = 1 (distributed.DataParallelStep).
     assert d['config']['step_variant'] == 'one backward', d['config']['step_variant']
     # two sequences per rank, two ranks time-slicing one device + a gloo all-reduce of 44.5 MB through host memory: ~45-55 ms measured; the collapse was 388 - 2 555 ms
     assert d['ms_per_step'] < 150, d['ms_per_step']
+
+
+def test_one_rccl_rank_runs_the_production_step():
+    """backend nccl (= RCCL) at world size 1 under the driver's launcher: the communicator is created, every gradient bucket goes through
+    ncclAllReduce (AVG) on the process group's stream, the agreement MIN-reduce runs, and -- one rank per device -- the step is the staged
+    two-stream step of N = 1.  The collectives of one rank move no data over xGMI; what this pins is that the production code path executes."""
+    d = _launch(1, ['--steps', '4', '--warmup', '7', '--batch', '2', '--no-cpu-baseline', '--no-fp32-leg', '--no-configs', '--no-step-model'],
+                {'PCACC_FORCE_PROCESS_GROUP': '1'})
+    assert d['distributed']['backend'] == 'nccl' and d['distributed']['world_size'] == 1 and d['n_gpus'] == 1
+    assert d['distributed']['collectives_per_step'] >= 2, d['distributed']                      # gradient buckets + the agreement reduce
+    assert d['config']['step_variant'].startswith('staged') and d['config']['step_variant'].endswith('second stream'), d['config']['step_variant']
+    assert d['value'] > 0 and d['steps'] == 4
 
 
 def test_single_rank_line_keeps_the_contract():
@@ -48,10 +124,10 @@ def test_single_rank_line_keeps_the_contract():
     K timed steps."""
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '4', '--warmup', '3', '--batch', '2', '--no-cpu-baseline', '--no-fp32-leg', '--no-configs',
            '--no-step-model']
-    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
-    assert len(lines) == 1, out.stdout[-2000:]
+    rc, out, err = run_tree(cmd, dict(os.environ, PCACC_HANG_DUMP='60'), 240)
+    assert rc == 0, 'rc %r\n%s' % (rc, err[-4000:])
+    lines = [l for l in out.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out[-2000:]
     d = json.loads(lines[0])
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config',
               'roofline'):

@@ -101,6 +101,14 @@ def test_prepared_weight_copies_are_keyed_on_the_weight_epoch_too():
     e = ops._WEIGHT_EPOCH
     opt.step()
     assert ops._WEIGHT_EPOCH == e + 1
+    # ... and so does ANY other optimizer of the process, created later (resume, a second parameter group) and never shown to the model:
+    # the hook is torch's process-wide one, registered once -- a second watch does not stack a second increment
+    model.watch_optimizer(opt)
+    ops.watch_all_optimizers()
+    opt2 = torch.optim.Adam(model.parameters(), lr=0.0)
+    e = ops._WEIGHT_EPOCH
+    opt2.step()
+    assert ops._WEIGHT_EPOCH == e + 1
     # an entry goes with its weight (no device copies of dead parameters until the 4096-entry sweep)
     import gc
     cache = {}

@@ -62,3 +62,39 @@ def test_step_hooks_are_called_once_each_and_cleared(monkeypatch):
     except RuntimeError as e:
         assert 'data pipeline' in str(e)
     assert model.before_sync is None and model.after_ego is None
+
+
+def test_helper_thread_is_joined_whatever_fails_after_the_forward(monkeypatch):
+    """the early backward issued from a helper thread must be joined -- and the interpreter's switch interval restored -- when
+    something between the forward and the second backward raises (a caller's after_forward hook here), with catch=True (the reference's
+    swallow-and-continue loop, libs/trainer.py:234-235) as well as catch=False; a malformed PCACC_SWITCH_INTERVAL must not raise mid-step."""
+    import threading
+    cpu_backend.install(monkeypatch)
+    monkeypatch.setenv('PCACC_SWITCH_INTERVAL', 'not-a-number')
+    cfg = default_config('waymo', 'train', n_sweeps=3, xy_range=8)
+    inp = dist_worker.motionnet_batch(cfg, 0)
+    model = dist_worker.motionnet_model(cfg)
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)
+    before = sys.getswitchinterval()
+
+    def boom():
+        raise RuntimeError('prefetch failed')
+    for catch in (True, False):
+        step = pdist.DataParallelStep(model, opt, FuseLoss(cfg['loss']), iter_size=1, grad_clip=None, catch=catch, pipelined=True)
+        step._early_thread = True                                          # the GPU-only choice, forced: the mechanism is host code
+        assert step._helper_switch_interval == 2e-4
+        if catch:
+            assert step(inp, after_forward=boom) is None and not step.ok and 'prefetch failed' in str(step.last_error)
+        else:
+            try:
+                step(inp, after_forward=boom)
+                raise AssertionError('the hook error must surface')
+            except RuntimeError as e:
+                assert 'prefetch failed' in str(e)
+        assert not [t for t in threading.enumerate() if t.name == 'pcacc-early-backward']
+        assert sys.getswitchinterval() == before
+    # and the threaded step itself completes on this backend
+    step = pdist.DataParallelStep(model, opt, FuseLoss(cfg['loss']), iter_size=1, grad_clip=None, catch=False, pipelined=True)
+    step._early_thread = True
+    assert step(inp) is not None and step.ok
+    assert sys.getswitchinterval() == before
