@@ -142,6 +142,34 @@ def die_with_launcher():
         pass
 
 
+def bring_up_in_turn(device, local_rank, n_dev):
+    """Ranks that SHARE a device (more local ranks than GPUs: the gloo test configuration of a one-GPU box) create their GPU context, load
+    libpcacc_hip.so's code object and run their first kernels ONE AFTER THE OTHER (an exclusive file lock per job and device).  A precaution, not a
+    diagnosis: both round-4 hangs of the two-rank launch were the first GPU work of a fresh box with two processes initialising at once, and a later
+    process could not initialise the device either while they sat there -- which points below this code; 40 fresh-box launches with stack dumps armed
+    did not reproduce it (profiles/r05_2rank_hang.txt).  One rank per device (production) takes no lock."""
+    try:
+        local_world = int(os.environ.get('LOCAL_WORLD_SIZE', '1'))
+    except ValueError:
+        local_world = 1
+    if local_world <= n_dev:
+        return False
+    import fcntl
+    import tempfile
+    path = os.path.join(tempfile.gettempdir(), 'pcacc_bringup_%s_%d.lock' % (os.environ.get('MASTER_PORT', '0'), device.index or 0))
+    with open(path, 'w') as f:
+        fcntl.flock(f, fcntl.LOCK_EX)
+        try:
+            torch.cuda.init()
+            x = torch.zeros(1 << 16, device=device)
+            native.lib()
+            float(native.absmax256(x).max())                      # a kernel of the library: its code object is loaded and has run
+            torch.cuda.synchronize()
+        finally:
+            fcntl.flock(f, fcntl.LOCK_UN)
+    return True
+
+
 def train_step(stepper, batcher, scenes):
     """One micro-step of the reference's loop (libs/trainer.py:165-237) through pdist.DataParallelStep: voxelise + collate, forward,
     FuseLoss, backward into the flat gradient buffer (bucketed all-reduce overlapped with backward when N > 1), and -- every
@@ -417,6 +445,7 @@ def main():
     device = torch.device('cuda', local_rank % n_dev)
     torch.cuda.set_device(device)
     pdist.per_rank_library_cache(rank, world)
+    took_turns = bring_up_in_turn(device, local_rank, n_dev)
     native.lib()
     watchdog.arm('libpcacc_hip.so loaded', first=True)
     if args.miopen_find and not args.no_miopen_find:
@@ -537,7 +566,7 @@ def main():
         # HBM traffic of the same kernel from the committed PMC passes (profiles/r02_pmc_scatter_summary.json, taken at this
         # launch's size: 4 sequences): measured bytes / algorithmic bytes, applied to this run's per-launch algorithmic bytes
         traffic = None
-        pmc_file = next((f for f in ('r04_pmc_scatter_summary.json', 'r02_pmc_scatter_summary.json') if os.path.exists(os.path.join(ROOT, 'profiles', f))), None)
+        pmc_file = next((f for f in ('r05_pmc_scatter_summary.json', 'r04_pmc_scatter_summary.json', 'r02_pmc_scatter_summary.json') if os.path.exists(os.path.join(ROOT, 'profiles', f))), None)
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', pmc_file)))
             key = 'pillar_scatter_rows16' if main_bf16 else 'pillar_scatter_vec4<0>'
@@ -562,9 +591,9 @@ def main():
                        'cpu_affinity': ('one L3 domain: %d CPUs' % len(os.sched_getaffinity(0))) if affinity_before is not None else 'unbound',
                        'HIP_FORCE_DEV_KERNARG': os.environ.get('HIP_FORCE_DEV_KERNARG')},
             'distributed': {'world_size': world, 'backend': (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
-                            'device': str(device), 'ranks_per_device': max(1, world // n_dev) if world > n_dev else 1,
+                            'device': str(device), 'ranks_per_device': max(1, world // n_dev) if world > n_dev else 1, 'gpu_bring_up_in_turn': took_turns,
                             'collectives_per_step': collectives_per_step, 'gradient_buckets': len(stepper_buckets), 'bucket_mb': [round(4e-6 * (e - b), 2) for b, e in stepper_buckets]},
-            'roofline': {'kernel': 'pillar_scatter_rows16 (BEV canvas fill, bf16 rows -> bf16 canvas)' if main_bf16 else 'pillar_scatter_vec4<0> (BEV canvas fill)', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
+            'roofline': {'kernel': 'pillar_scatter_rows16_k<1, true, true> (BEV canvas fill, bf16 rows -> bf16 canvas, streaming loads / stores)' if main_bf16 else 'pillar_scatter_vec4<0> (BEV canvas fill)', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
                          'traffic_source': 'PMC FETCH_SIZE x2 + WRITE_SIZE (calibrated on a 128 MiB copy), profiles/%s' % pmc_file,
                          'launches_timed': len(durs), 'avg_launch_us': (sum(durs) / len(durs) * 1e6) if durs else None,
@@ -587,7 +616,7 @@ def main():
             d32 = [t[0].elapsed_us() * 1e-6 for t in fills32]
             a32 = [t[1] * t[2] * 4 + t[3] * t[2] * 4 + 4 * t[3] for t in fills32]
             ach = (sum(a32) / len(a32)) / (sum(d32) / len(d32)) / 1e9
-            line['roofline']['f32_fill'] = {'kernel': 'pillar_scatter_vec4<0> (the fp32 twin canvas of the mixed mode)', 'achieved': ach, 'frac': ach / HBM_PEAK_GBPS,
+            line['roofline']['f32_fill'] = {'kernel': 'pillar_scatter_vec4<0> (the fp32 twin canvas of the mixed mode; cached stores: the first convolution reads it next)', 'achieved': ach, 'frac': ach / HBM_PEAK_GBPS,
                                             'avg_launch_us': sum(d32) / len(d32) * 1e6, 'algorithmic_bytes_per_launch': sum(a32) / len(a32), 'launches_timed': len(d32)}
         if second_leg is not None:
             line[second_leg['dtype'] if args.dtype == 'mixed' else 'matched_accuracy'] = second_leg

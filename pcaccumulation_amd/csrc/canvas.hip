@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void pillar_scatter_rows16(const uint4 *__rest
 // The same fill with K 16-byte pieces per lane and iteration -- K table words, then K row pieces, then K stores in flight per lane -- and, with NT,
 // the streaming cache policy on both sides (`nt` loads of the row table, `nt` stores of the canvas: every byte is touched once by this kernel).
 typedef uint32_t pcacc_u32x4 __attribute__((ext_vector_type(4)));
-template <int K, bool NT>
+template <int K, bool NT, bool NTL = NT>
 __global__ __launch_bounds__(256) void pillar_scatter_rows16_k(const pcacc_u32x4 *__restrict__ feats, const int32_t *__restrict__ c2p,
                                                                int64_t n_pieces, int ppc /*16-byte pieces per cell*/, pcacc_u32x4 *__restrict__ canvas)
 {
@@ -190,14 +190,14 @@ __global__ __launch_bounds__(256) void pillar_scatter_rows16_k(const pcacc_u32x4
             const int64_t e = e0 + k * stride;
             const bool in = e < n_pieces;
             const int64_t cell = in ? e / ppc : 0;
-            p[k] = in ? (NT ? __builtin_nontemporal_load(c2p + cell) : c2p[cell]) : -1;
+            p[k] = in ? (NTL ? __builtin_nontemporal_load(c2p + cell) : c2p[cell]) : -1;
             src[k] = e - cell * ppc;
         }
         pcacc_u32x4 o[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             o[k] = (pcacc_u32x4){0u, 0u, 0u, 0u};
-            if (p[k] >= 0) o[k] = NT ? __builtin_nontemporal_load(feats + (int64_t)p[k] * ppc + src[k]) : feats[(int64_t)p[k] * ppc + src[k]];
+            if (p[k] >= 0) o[k] = NTL ? __builtin_nontemporal_load(feats + (int64_t)p[k] * ppc + src[k]) : feats[(int64_t)p[k] * ppc + src[k]];
         }
 #pragma unroll
         for (int k = 0; k < K; ++k) {
@@ -207,6 +207,20 @@ __global__ __launch_bounds__(256) void pillar_scatter_rows16_k(const pcacc_u32x4
                 else canvas[e] = o[k];
             }
         }
+    }
+}
+
+// fp32 rows -> fp32 canvas with the streaming policy on both sides (the fp32 twin canvas of the 'mixed' / fp32x3 modes)
+typedef float pcacc_f32x4v __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void pillar_scatter_f32_nt(const pcacc_f32x4v *__restrict__ feats, const int32_t *__restrict__ c2p, int64_t n_pieces,
+                                                             int ppc, pcacc_f32x4v *__restrict__ canvas)
+{
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n_pieces; e += (int64_t)gridDim.x * 256) {
+        const int64_t cell = e / ppc;
+        const int p = __builtin_nontemporal_load(c2p + cell);
+        pcacc_f32x4v o = {0.f, 0.f, 0.f, 0.f};
+        if (p >= 0) o = __builtin_nontemporal_load(feats + (int64_t)p * ppc + (e - cell * ppc));
+        __builtin_nontemporal_store(o, canvas + e);
     }
 }
 
@@ -240,19 +254,30 @@ static int pillar_scatter_launch(const void *feats, int feats_dtype, const int32
     if (feats_dtype == PCACC_BF16) {
         width = c / 8;
         n = n_cells * width;
-        fn = reinterpret_cast<const void *>(pillar_scatter_rows16);
+        // [r5] default: one piece per lane, streaming (`nt`) loads and stores -- the canvas is written once and read much later, the row table is read
+        // once: in the step 35.4 -> 32.7 us (0.66 -> 0.71 of 8 TB/s), behind 1 GiB of dirty lines 51 -> 34 us (0.46 -> 0.69), and the kernels that follow
+        // find their operands still cached (step 31.15 -> 30.65 ms, two runs each; profiles/r05_scatter_variants.txt).  '0' = round 4's kernel.
+        fn = reinterpret_cast<const void *>(pillar_scatter_rows16_k<1, true>);
+        per_lane = 1;
         switch (pcacc_switches().scatter_variant) {               // A/B: PCACC_SCATTER_VARIANT
+        case '0': fn = reinterpret_cast<const void *>(pillar_scatter_rows16); per_lane = 2; break;
         case '1': fn = reinterpret_cast<const void *>(pillar_scatter_rows16_k<4, true>); per_lane = 4; break;
         case '2': fn = reinterpret_cast<const void *>(pillar_scatter_rows16_k<2, true>); per_lane = 2; break;
         case '3': fn = reinterpret_cast<const void *>(pillar_scatter_rows16_k<4, false>); per_lane = 4; break;
         case '4': fn = reinterpret_cast<const void *>(pillar_scatter_rows16_k<8, true>); per_lane = 8; break;
         case '5': fn = reinterpret_cast<const void *>(pillar_scatter_rows16_k<1, true>); per_lane = 1; break;
-        default: per_lane = 2; break;
+        case '6': fn = reinterpret_cast<const void *>(pillar_scatter_rows16_k<1, true, false>); per_lane = 1; break;     // streaming stores, cached loads
+        case '7': fn = reinterpret_cast<const void *>(pillar_scatter_rows16_k<2, true, false>); per_lane = 2; break;
+        default: break;
         }
     } else if (dtype == PCACC_F32 ? (c % 4 == 0) : (c % 8 == 0)) {
         width = c / 4;
         n = dtype == PCACC_F32 ? n_cells * width : n_cells * (width / 2);
         fn = dtype == PCACC_F32 ? reinterpret_cast<const void *>(pillar_scatter_vec4<0>) : reinterpret_cast<const void *>(pillar_scatter_vec4<1>);
+        // the fp32 canvas is read by the first convolution right behind this fill: cached stores.  The streaming variant (PCACC_SCATTER_VARIANT=f) left the
+        // step where it was and slowed the bf16 fill that follows it in the 'mixed' mode from 32.7 to 41 us (profiles/r05_cache_policy_ab.txt)
+        if (dtype == PCACC_F32 && pcacc_switches().scatter_variant == 'f')
+            fn = reinterpret_cast<const void *>(pillar_scatter_f32_nt);
     } else {
         width = c;
         n = n_cells * c;
@@ -406,6 +431,8 @@ static void switches_read()
     g_switches.rows_fm_off = getenv("PCACC_ROWS_FM_OFF") != nullptr;
     g_switches.conv_plan = getenv("PCACC_CONV_PLAN") != nullptr;
     g_switches.conv_res = e ? e[0] : 0;
+    const char *cr = getenv("PCACC_CONV_REG");
+    g_switches.conv_reg = cr ? cr[0] : 0;
     const char *v = getenv("PCACC_SCATTER_VARIANT");
     g_switches.scatter_variant = v ? v[0] : 0;
     const char *b = getenv("PCACC_SCATTER_BLOCKS");

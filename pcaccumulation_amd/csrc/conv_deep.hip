@@ -317,13 +317,15 @@ union cd_frag { bf16x8_t v; cd_s16x4 h[2]; };
 __global__ __launch_bounds__(CD_THREADS) void conv3x3_wgrad_strip_kernel(const uint16_t *__restrict__ dy, const uint16_t *__restrict__ dy_mask,
                                                                          const uint16_t *__restrict__ x,
                                                                          float *__restrict__ partial, int n_img, int h, int w, int c_in,
-                                                                         int c_out, int rows, int strips, int ci_blocks, int slots)
+                                                                         int c_out, int rows, int strips, int ci_blocks, int slots, int sw, int segs)
 {
+    // sw / segs: a strip is `rows` image rows x `sw` columns, `segs` of them side by side cover a row (sw = w, segs = 1 whenever a full-width row
+    // fits the staging; wider maps -- the 288-wide ego feature head -- are cut into column segments, each with its own one-pixel halo)
     constexpr int CO = 64, CI = 64, PAIRS = 4, TG = 5;        // TG = taps of the first tap group
     constexpr int YS = pcacc_tr_stride(CO), XS = pcacc_tr_stride(CI);
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
-    const int pw = w + 2, pp = (rows + 2) * pw;
-    const int n_px = rows * w, n_steps = (n_px + 15) >> 4, py_rows = n_steps * 16;
+    const int pw = sw + 2, pp = (rows + 2) * pw;
+    const int n_px = rows * sw, n_steps = (n_px + 15) >> 4, py_rows = n_steps * 16;
     uint16_t *sdy = lds;                                       // [py_rows][YS]   (rows >= n_px are zero)
     uint16_t *sx = sdy + (size_t)py_rows * YS;                 // [pp][XS]
     uint16_t *ptab = sx + (size_t)pp * XS;                     // [py_rows] patch row of the pixel's top-left tap
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_wgrad_strip_kernel(const u
     const int block = blockIdx.x / slots, slot = blockIdx.x % slots;
     const int co0 = (block / ci_blocks) * CO, ci0 = (block % ci_blocks) * CI;
 
-    for (int q = threadIdx.x; q < py_rows; q += CD_THREADS) ptab[q] = q < n_px ? (uint16_t)((q / w) * pw + q % w) : 0;
+    for (int q = threadIdx.x; q < py_rows; q += CD_THREADS) ptab[q] = q < n_px ? (uint16_t)((q / sw) * pw + q % sw) : 0;
 
     const int tap0 = grp * TG, n_tap = grp ? 9 - TG : TG;      // this wave's taps (wave-uniform)
     f32x16_t acc[TG];
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_wgrad_strip_kernel(const u
     const int y_chunks = py_rows * (CO / 8), n_chunks = y_chunks + pp * (CI / 8);
     uint4 sreg[CDW_PCH];
     auto fetch = [&](int job) {
-        const int img = job / strips, y0 = (job % strips) * rows;
+        const int img = job / (strips * segs), sj = job % (strips * segs), y0 = (sj / segs) * rows, x0 = (sj % segs) * sw;
         const uint16_t *ysrc = dy + (int64_t)img * h * w * c_out + co0;
         const uint16_t *xsrc = x + (int64_t)img * h * w * c_in + ci0;
 #pragma unroll
@@ -360,8 +362,8 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_wgrad_strip_kernel(const u
             const bool is_y = c < y_chunks;
             const int e = is_y ? c : min(c, n_chunks - 1) - y_chunks;
             const int px = e >> 3, c8 = e & 7;
-            const int yy = is_y ? y0 + px / w : y0 - 1 + px / pw;
-            const int xx = is_y ? px % w : px % pw - 1;
+            const int yy = is_y ? y0 + px / sw : y0 - 1 + px / pw;
+            const int xx = x0 + (is_y ? px % sw : px % pw - 1);
             const bool ok = c < n_chunks && (unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w && (!is_y || px < n_px);
             const int64_t pos = (int64_t)min(max(yy, 0), h - 1) * w + min(max(xx, 0), w - 1);
             const uint16_t *src = is_y ? ysrc + pos * c_out + c8 * 8 : xsrc + pos * c_in + c8 * 8;
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_wgrad_strip_kernel(const u
         }
     };
 
-    const int n_jobs = n_img * strips;
+    const int n_jobs = n_img * strips * segs;
     const int tg = lane >> 4, tl = lane & 15;
     const int tr_row = (tg >> 1) * 8 + (tl >> 2), tr_col = (tg & 1) * 16 + (tl & 3) * 4;
     int job = slot;
@@ -481,18 +483,35 @@ __global__ __launch_bounds__(256) void conv_wgrad_strip_reduce_kernel(const floa
     }
 }
 
-// strip height for the weight gradient: least padded work (strips x 16-pixel steps) among the heights whose staging fits
-static int conv_wgrad_strip_rows(int h, int w, size_t *lds_bytes)
+// strip shape for the weight gradient: full-width rows (segs = 1), the height with the least padded work (strips x 16-pixel steps) among those
+// whose staging fits; maps wider than a strip's pixel budget are cut into the fewest equal column segments (width a multiple of 16, so no
+// padded step), as many rows of them as fit
+static int conv_wgrad_strip_rows(int h, int w, size_t *lds_bytes, int *sw_out = nullptr, int *segs_out = nullptr)
 {
-    int best = 0;
+    auto fits = [&](int rows, int sw, size_t *lds) {
+        const int pp = (rows + 2) * (sw + 2), py_rows = (rows * sw + 15) / 16 * 16;
+        *lds = ((size_t)py_rows * pcacc_tr_stride(64) + (size_t)pp * pcacc_tr_stride(64) + py_rows) * sizeof(uint16_t);
+        return (py_rows + pp) * 8 <= CD_THREADS * CDW_PCH && *lds <= 150 * 1024;
+    };
+    int best = 0, sw = w, segs = 1;
     int64_t best_cost = 0;
     for (int rows = 1; rows <= h && rows * w <= CDW_MAXP; ++rows) {
-        const int pp = (rows + 2) * (w + 2), py_rows = (rows * w + 15) / 16 * 16;
-        const size_t lds = ((size_t)py_rows * pcacc_tr_stride(64) + (size_t)pp * pcacc_tr_stride(64) + py_rows) * sizeof(uint16_t);
-        if ((py_rows + pp) * 8 > CD_THREADS * CDW_PCH || lds > 150 * 1024) continue;
-        const int64_t cost = (int64_t)((h + rows - 1) / rows) * py_rows;
+        size_t lds;
+        if (!fits(rows, w, &lds)) continue;
+        const int64_t cost = (int64_t)((h + rows - 1) / rows) * ((rows * w + 15) / 16 * 16);
         if (!best || cost <= best_cost) { best = rows; best_cost = cost; *lds_bytes = lds; }
     }
+    if (!best && w > CDW_MAXP) {
+        for (int sg = (w + CDW_MAXP - 1) / CDW_MAXP; sg <= 8 && !best; ++sg) {
+            const int width = ((w + sg - 1) / sg + 15) / 16 * 16;
+            for (int rows = 1; rows <= h && rows * width <= CDW_MAXP; ++rows) {
+                size_t lds;
+                if (fits(rows, width, &lds)) { best = rows; *lds_bytes = lds; sw = width; segs = sg; }
+            }
+        }
+    }
+    if (sw_out) *sw_out = sw;
+    if (segs_out) *segs_out = segs;
     return best;
 }
 
@@ -515,9 +534,10 @@ extern "C" int pcacc_conv3x3_wgrad_deep_workspace_bytes(int32_t n_img, int32_t h
 {
     size_t lds;
     if (!bytes || n_img < 1 || !pcacc_conv3x3_wgrad_deep_supported(h, w, c_in, c_out)) return PCACC_E_ARG;
-    const int rows = conv_wgrad_strip_rows(h, w, &lds);
+    int sw, segs;
+    const int rows = conv_wgrad_strip_rows(h, w, &lds, &sw, &segs);
     const int blocks = (c_out / 64) * (c_in / 64);
-    *bytes = (size_t)blocks * conv_wgrad_strip_slots(n_img, (h + rows - 1) / rows, blocks) * (64 * 9 * 64 + 64) * sizeof(float);
+    *bytes = (size_t)blocks * conv_wgrad_strip_slots(n_img, (h + rows - 1) / rows * segs, blocks) * (64 * 9 * 64 + 64) * sizeof(float);
     return 0;
 }
 
@@ -530,15 +550,16 @@ extern "C" int pcacc_conv3x3_wgrad_deep_bf16(const uint16_t *dy, const uint16_t 
         return PCACC_E_ARG;
     if (workspace_bytes < need) return PCACC_E_WORKSPACE;
     hipStream_t st = pcacc_stream(stream);
-    const int rows = conv_wgrad_strip_rows(h, w, &lds);
+    int sw, segs;
+    const int rows = conv_wgrad_strip_rows(h, w, &lds, &sw, &segs);
     const int strips = (h + rows - 1) / rows, ci_blocks = c_in / 64, blocks = (c_out / 64) * ci_blocks;
-    const int slots = conv_wgrad_strip_slots(n_img, strips, blocks);
+    const int slots = conv_wgrad_strip_slots(n_img, strips * segs, blocks);
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_wgrad_strip_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
         return PCACC_E_LAUNCH;
     float *partial = static_cast<float *>(workspace);
     hipLaunchKernelGGL(conv3x3_wgrad_strip_kernel, dim3(blocks * slots), dim3(CD_THREADS), lds, st, dy, dy_mask, x, partial, n_img, h, w, c_in, c_out,
-                       rows, strips, ci_blocks, slots);
+                       rows, strips, ci_blocks, slots, sw, segs);
     const int64_t elems = (int64_t)c_out * 9 * c_in + c_out;
     hipLaunchKernelGGL(conv_wgrad_strip_reduce_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, partial, slots, c_in, c_out,
                        ci_blocks, dw, db);

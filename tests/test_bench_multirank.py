@@ -98,6 +98,7 @@ def test_two_gloo_ranks_share_the_gpu():
     d = _launch(2, ['--steps', '3', '--warmup', '2', '--batch', '2', '--no-cpu-baseline', '--no-fp32-leg'], {'PCACC_DIST_BACKEND': 'gloo'})
     assert d['n_gpus'] == 2 and d['steps'] == 3 and d['scaling'] == 'weak' and d['config']['parallelism'] == 'dp2'
     assert d['value'] > 0 and 'roofline' in d
+    assert d['distributed']['backend'] == 'gloo' and d['distributed']['ranks_per_device'] == 2 and d['distributed']['gpu_bring_up_in_turn'] is True
     # Ranks SHARING a device keep the plain one-stream step (two processes x (main, side, prefetch) streams oversubscribe the device's
     # hardware queues -- 388 ms per step at 4 queues per process, 2 555 at 8, 62.5 at 2); one rank per device, the
     # production layout, runs the staged two-stream step of N = 1 (distributed.DataParallelStep).

@@ -205,9 +205,12 @@ def test_conv3x3_backward_deep(n, h, w, ci, co):
 
 
 @pytest.mark.parametrize('n,h,w,ci,co', [(3, 18, 18, 256, 128), (2, 36, 36, 128, 256), (1, 72, 72, 128, 128), (5, 18, 18, 512, 512),
-                                         (2, 20, 144, 128, 64), (1, 19, 37, 64, 192), (2, 7, 5, 128, 128)])
+                                         (2, 20, 144, 128, 64), (1, 19, 37, 64, 192), (2, 7, 5, 128, 128),
+                                         (2, 24, 288, 128, 64), (1, 5, 301, 64, 128), (1, 3, 600, 128, 64)])
 def test_conv3x3_wgrad_deep_kernel(n, h, w, ci, co):
-    """pcacc_conv3x3_wgrad_deep_bf16 against the library's weight gradient on the same bf16 tensors (fp32 sums, different order)."""
+    """pcacc_conv3x3_wgrad_deep_bf16 against the library's weight gradient on the same bf16 tensors (fp32 sums, different order).  The last three
+    shapes are wider than one strip's pixel budget: rows cut into 2 / 2 / 3 column segments with their own halos (the ego feature head's 128 -> 64
+    layer on 288-wide maps, the last 3x3 weight gradient that went to the convolution library until round 5)."""
     g = torch.Generator(device='cpu').manual_seed(ci + 2 * co + n)
     x = torch.randn(n, h, w, ci, generator=g).to(DEV).to(torch.bfloat16)
     gy = torch.randn(n, h, w, co, generator=g).to(DEV).to(torch.bfloat16)

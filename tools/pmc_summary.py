@@ -11,6 +11,7 @@ csv.field_size_limit(1 << 30)
 N_CELLS, M, C = 20 * 288 * 288, 1_169_433, 32
 KERNELS = {                                  # kernel-name fragment -> (label, algorithmic bytes: SURVEY 8d  C*s*cells + C*s_in*M + 4*M)
     'pillar_scatter_vec4<0>': ('f32 rows -> f32 canvas', N_CELLS * C * 4 + M * C * 4 + 4 * M),
+    'pillar_scatter_f32_nt': ('f32 rows -> f32 canvas, streaming loads / stores (round 5 default for large canvases)', N_CELLS * C * 4 + M * C * 4 + 4 * M),
     'pillar_scatter_vec4<1>': ('f32 rows -> bf16 canvas', N_CELLS * C * 2 + M * C * 4 + 4 * M),
     'pillar_scatter_rows16': ('bf16 rows -> bf16 canvas (bf16 compute mode)', N_CELLS * C * 2 + M * C * 2 + 4 * M),
 }
