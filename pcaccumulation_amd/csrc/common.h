@@ -22,6 +22,7 @@ struct PcaccSwitches {
     bool conv_plan;          // PCACC_CONV_PLAN: print the launch plans of the strip kernels
     char conv_res;           // PCACC_CONV_RES: '0' never the resident fp32x3 kernel, '2' whatever the size, 0 unset
     char conv_reg;           // PCACC_CONV_REG: '0' never the register-operand fp32x3 kernel (round 5), '2' whatever the size, 0 unset
+    bool xcd_off;            // PCACC_XCD_REMAP=0: workgroups in launch order (round 4) instead of the XCD-contiguous walk of the multi-group convolution kernels
     char scatter_variant;    // PCACC_SCATTER_VARIANT: pillar_scatter_rows16 variants (pieces per lane / cache policy), 0 unset = the default kernel
     int scatter_blocks;      // PCACC_SCATTER_BLOCKS: workgroups per CU of the pillar-scatter launch (0 = default)
 };
@@ -40,6 +41,16 @@ static inline int pcacc_grid(int64_t work_items, int block, int max_blocks = PCA
 }
 
 static inline size_t pcacc_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// Hardware hands workgroup b of a launch to XCD b % 8 (each XCD has its own 4 MB L2).  pcacc_xcd_block maps b to a LOGICAL block id such that every XCD
+// walks a CONTIGUOUS range of logical ids in increasing order: workgroups with neighbouring logical ids -- the output-channel groups of one pixel tile, the
+// (co, ci) blocks of one strip -- run on the same XCD at about the same time and share their operand reads in its L2 instead of fetching them once per
+// XCD (PMC, round 4: 1.9 - 2.7 x the algorithmic HBM bytes on these kernels).  A bijection on [0, n).
+__device__ __forceinline__ int pcacc_xcd_block(int b, int n)
+{
+    const int per = (n + 7) >> 3, rem = n & 7, x = b & 7, i = b >> 3;
+    return (rem == 0 || x < rem) ? x * per + i : rem * per + (x - rem) * (per - 1) + i;
+}
 
 // ---- bf16 <-> f32 (round to nearest even, the conversion torch uses) --------------------------------
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }

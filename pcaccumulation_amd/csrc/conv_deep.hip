@@ -29,7 +29,7 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_strip_kernel(const uint16_
                                                                    const uint16_t *__restrict__ wp,
                                                                    const float *__restrict__ bias, uint16_t *__restrict__ out, int n_img,
                                                                    int h, int w, int c_in, int c_out, int relu, int rows, int strips,
-                                                                   int co_groups)
+                                                                   int co_groups, int xcd)
 {
     constexpr int PS = CS + 8;                                 // padded LDS row (elements): conflict-free 16-byte fragment reads
     constexpr int MG = NG == 2 ? 4 : 8;                        // waves along the pixel dimension; MT = 32-pixel tiles per wave
@@ -40,7 +40,9 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_strip_kernel(const uint16_
     uint16_t *patch = lds;                                     // [pp][PS]
     uint16_t *wbuf = lds + (size_t)pp * PS;                    // [2][WROWS][PS]
 
-    int bid = blockIdx.x;
+    // xcd: the XCD-contiguous walk (common.h) -- the channel groups of a strip on one XCD share its input patch in that L2; an XCD then sees every group's
+    // weight slice instead of the few that block % 8 gave it (the block order of round 2), which the strips of a launch re-read from the L2 all the same
+    int bid = xcd ? pcacc_xcd_block(blockIdx.x, gridDim.x) : blockIdx.x;
     const int cog = bid % co_groups; bid /= co_groups;
     const int strip = bid % strips;
     const int img = bid / strips;
@@ -271,7 +273,7 @@ static int conv_strip_launch(const ConvStripPlan &p, const uint16_t *in, const u
         return PCACC_E_LAUNCH;
     if (p.blocks > 0x7fffffff) return PCACC_E_ARG;
     hipLaunchKernelGGL(kern, dim3((unsigned)p.blocks), dim3(CD_THREADS), p.lds, st, in, in_mask, wp, bias, out, n_img, h, w, c_in, c_out, relu,
-                       p.rows, p.strips, p.co_groups);
+                       p.rows, p.strips, p.co_groups, (p.co_groups > 1 && !pcacc_switches().xcd_off) ? 1 : 0);
     PCACC_CHECK_LAUNCH();
     return 0;
 }
@@ -317,7 +319,7 @@ union cd_frag { bf16x8_t v; cd_s16x4 h[2]; };
 __global__ __launch_bounds__(CD_THREADS) void conv3x3_wgrad_strip_kernel(const uint16_t *__restrict__ dy, const uint16_t *__restrict__ dy_mask,
                                                                          const uint16_t *__restrict__ x,
                                                                          float *__restrict__ partial, int n_img, int h, int w, int c_in,
-                                                                         int c_out, int rows, int strips, int ci_blocks, int slots, int sw, int segs)
+                                                                         int c_out, int rows, int strips, int ci_blocks, int slots, int sw, int segs, int xcd)
 {
     // sw / segs: a strip is `rows` image rows x `sw` columns, `segs` of them side by side cover a row (sw = w, segs = 1 whenever a full-width row
     // fits the staging; wider maps -- the 288-wide ego feature head -- are cut into column segments, each with its own one-pixel halo)
@@ -334,7 +336,10 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_wgrad_strip_kernel(const u
     const int lp = lane & 31, lh = lane >> 5;
     const int pair = wave % PAIRS, grp = wave / PAIRS;
     const int ct = pair >> 1, it = pair & 1;
-    const int block = blockIdx.x / slots, slot = blockIdx.x % slots;
+    // xcd: the (co, ci) blocks of a strip next to each other on one XCD (block fastest in the logical order of common.h's walk): the dY and X rows that two
+    // blocks share are fetched into that XCD's L2 once (PMC round 4: 2.66 x the algorithmic bytes with block-major order -- every block on every XCD)
+    const int n_blocks = gridDim.x / slots, lb = xcd ? pcacc_xcd_block(blockIdx.x, gridDim.x) : 0;
+    const int block = xcd ? lb % n_blocks : blockIdx.x / slots, slot = xcd ? lb / n_blocks : blockIdx.x % slots;
     const int co0 = (block / ci_blocks) * CO, ci0 = (block % ci_blocks) * CI;
 
     for (int q = threadIdx.x; q < py_rows; q += CD_THREADS) ptab[q] = q < n_px ? (uint16_t)((q / sw) * pw + q % sw) : 0;
@@ -441,7 +446,7 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_wgrad_strip_kernel(const u
         }
     }
     // slot of this workgroup: [CO][9][CI] then [CO] bias sums; D has lane = ci, register quads = co
-    float *mine = partial + (int64_t)blockIdx.x * (CO * 9 * CI + CO);
+    float *mine = partial + ((int64_t)block * slots + slot) * (CO * 9 * CI + CO);
 #pragma unroll
     for (int t = 0; t < TG; ++t)
         if (t < n_tap)
@@ -559,7 +564,7 @@ extern "C" int pcacc_conv3x3_wgrad_deep_bf16(const uint16_t *dy, const uint16_t 
         return PCACC_E_LAUNCH;
     float *partial = static_cast<float *>(workspace);
     hipLaunchKernelGGL(conv3x3_wgrad_strip_kernel, dim3(blocks * slots), dim3(CD_THREADS), lds, st, dy, dy_mask, x, partial, n_img, h, w, c_in, c_out,
-                       rows, strips, ci_blocks, slots, sw, segs);
+                       rows, strips, ci_blocks, slots, sw, segs, (blocks > 1 && !pcacc_switches().xcd_off) ? 1 : 0);
     const int64_t elems = (int64_t)c_out * 9 * c_in + c_out;
     hipLaunchKernelGGL(conv_wgrad_strip_reduce_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, partial, slots, c_in, c_out,
                        ci_blocks, dw, db);

@@ -261,7 +261,7 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float 
                                                                     int n_img, int frames,
                                                                     int h, int w, int c_in, int c_out, int kt, int relu, int rows, int bw,
                                                                     int tiles_y, int tiles_x, int co_groups, int mode, int c_up, int up_pitch,
-                                                                    const float *__restrict__ in2, int c_a)
+                                                                    const float *__restrict__ in2, int c_a, int xcd)
 {
     constexpr int PS = CS + 8;                                 // padded LDS row (elements)
     constexpr int MG = 8 / NGW;                                // waves along the pixel dimension
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float 
     uint16_t *patch = lds;                                     // [2 = hi, lo][pp][PS]
     uint16_t *wbuf = lds + 2 * (size_t)plane;                  // [2 buffers][2 = hi, lo][WROWS][PS]
 
-    int bid = blockIdx.x;
+    int bid = xcd ? pcacc_xcd_block(blockIdx.x, gridDim.x) : blockIdx.x;   // the channel groups of a tile on one XCD: its input patch is fetched into one L2 once
     const int cog = bid % co_groups; bid /= co_groups;
     const int tx = bid % tiles_x; bid /= tiles_x;
     const int ty = bid % tiles_y;
@@ -1051,7 +1051,8 @@ static int conv_split_launch(const ConvSplitPlan &p, const float *in, const floa
         return PCACC_E_LAUNCH;
     if (p.blocks > 0x7fffffff) return PCACC_E_ARG;
     hipLaunchKernelGGL(kern, dim3((unsigned)p.blocks), dim3(CSP_THREADS), p.lds, st, in, in_amax, in_mask, wp, wscale, bias, out, out_amax, out16, n_img,
-                       frames, h, w, c_in, c_out, kt, relu, p.rows, p.bw, p.tiles_y, p.tiles_x, p.co_groups, mode, c_up, up_pitch ? up_pitch : c_up, in2, c_a);
+                       frames, h, w, c_in, c_out, kt, relu, p.rows, p.bw, p.tiles_y, p.tiles_x, p.co_groups, mode, c_up, up_pitch ? up_pitch : c_up, in2, c_a,
+                       (p.co_groups > 1 && !pcacc_switches().xcd_off) ? 1 : 0);
     PCACC_CHECK_LAUNCH();
     return 0;
 }
@@ -1170,7 +1171,7 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_wgrad_split_kernel(const 
                                                                           const float *__restrict__ dy_mask, const float *__restrict__ x,
                                                                           const float *__restrict__ x_amax, float *__restrict__ partial,
                                                                           int n_img, int frames, int dt, int h, int w, int c_in, int c_out,
-                                                                          int rows, int bw, int tiles_y, int tiles_x, int ci_blocks, int slots, int c_up)
+                                                                          int rows, int bw, int tiles_y, int tiles_x, int ci_blocks, int slots, int c_up, int xcd)
 {
     // 32 x 32 blocks: one (co, ci) pair -- the 8 waves are 2 halves of the 16-pixel steps x 4 tap groups (3 | 2 | 2 | 2 taps) and each half
     // keeps its own partial slot; with 8 tap groups (2 | 1 x 7 taps) wave 0 did twice the work of the others.
@@ -1192,7 +1193,9 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_wgrad_split_kernel(const 
     const int lp = lane & 31, lh = lane >> 5;
     const int pair = wave % PAIRS, grp = (wave / PAIRS) % G, half = wave / (PAIRS * G);
     const int ct = pair / CI_T, it = pair % CI_T;
-    const int block = blockIdx.x / slots, slot = blockIdx.x % slots;
+    // xcd: the (co, ci) blocks of a strip next to each other on one XCD (block fastest in the logical order): the dY / X rows they share are fetched once
+    const int n_blocks = gridDim.x / slots, lb = xcd ? pcacc_xcd_block(blockIdx.x, gridDim.x) : 0;
+    const int block = xcd ? lb % n_blocks : blockIdx.x / slots, slot = xcd ? lb / n_blocks : blockIdx.x % slots;
     const int co0 = (block / ci_blocks) * CO, ci0 = (block % ci_blocks) * CI;
     const float sy = csp_scale_from_parts(dy_amax), sxs = csp_scale_from_parts(x_amax);   // the reduce launch divides by sy * sxs
 
@@ -1313,7 +1316,7 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_wgrad_split_kernel(const 
         }
     }
     // slot of this workgroup: [CO][9][CI] then [CO] bias sums; D has lane = ci, register quads = co
-    float *mine = partial + ((int64_t)blockIdx.x * HALVES + half) * SLOT;
+    float *mine = partial + (((int64_t)block * slots + slot) * HALVES + half) * SLOT;       // the reduce launch's order: a block's slots are consecutive
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int tap = grp + j * G;
@@ -1457,7 +1460,7 @@ extern "C" int pcacc_conv3x3_wgrad_split(const float *dy, const float *dy_amax, 
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds) != hipSuccess) \
             return PCACC_E_LAUNCH;                                                                                                      \
         hipLaunchKernelGGL(kern, dim3(p.blocks * p.slots), dim3(CSP_THREADS), p.lds, st, dy, dy_amax, dy_mask, x, x_amax, partial, n_img, frames, dt, h, w, \
-                           c_in, c_out, p.rows, p.bw, p.tiles_y, p.tiles_x, c_in / p.cib, p.slots, 0);                                  \
+                           c_in, c_out, p.rows, p.bw, p.tiles_y, p.tiles_x, c_in / p.cib, p.slots, 0, (p.blocks > 1 && !pcacc_switches().xcd_off) ? 1 : 0); \
     }
     CSW_CASE(1, 1) else CSW_CASE(1, 2) else CSW_CASE(2, 1) else CSW_CASE(2, 2) else return PCACC_E_ARG;
 #undef CSW_CASE
@@ -1673,7 +1676,7 @@ extern "C" int pcacc_upconv2x2_wgrad_split(const float *dy, const float *dy_amax
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds) != hipSuccess) \
             return PCACC_E_LAUNCH;                                                                                                      \
         hipLaunchKernelGGL(kern, dim3(p.blocks * p.slots), dim3(CSP_THREADS), p.lds, st, dy, dy_amax, nullptr, x, x_amax, partial, n_img, 1, 0, h, w, \
-                           c_in, c_out, p.rows, p.bw, p.tiles_y, p.tiles_x, c_in / p.cib, p.slots, c_up);                               \
+                           c_in, c_out, p.rows, p.bw, p.tiles_y, p.tiles_x, c_in / p.cib, p.slots, c_up, (p.blocks > 1 && !pcacc_switches().xcd_off) ? 1 : 0); \
     }
     CSUW_CASE(1, 1) else CSUW_CASE(1, 2) else CSUW_CASE(2, 1) else CSUW_CASE(2, 2) else return PCACC_E_ARG;
 #undef CSUW_CASE

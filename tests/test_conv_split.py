@@ -367,3 +367,38 @@ def test_register_operand_kernel_is_bit_identical_to_the_resident_kernel(n, t, h
     for u, v in zip(got['2'], got['0']):
         assert torch.equal(u, v)
     assert float(got['2'][1]) == float(got['2'][0].abs().max())
+
+
+def test_xcd_contiguous_block_walk_changes_no_result(monkeypatch):
+    """Round 5: the multi-group convolution kernels map blockIdx to a logical block id such that the output-channel groups of a tile / the (co, ci)
+    blocks of a strip run on ONE XCD and share their operand reads in its L2 (common.h: pcacc_xcd_block).  A pure re-ordering of workgroups: forward
+    results, weight gradients (same partial slots, same reduce order) and maxima are bit-identical to launch order (PCACC_XCD_REMAP=0), fp32x3 and bf16."""
+    g = torch.Generator(device='cpu').manual_seed(5)
+    got = {}
+    try:
+        for remap in ('1', '0'):
+            monkeypatch.setenv('PCACC_XCD_REMAP', remap)
+            native.reload_switches()
+            out = []
+            for n, h, w, ci, co in ((3, 36, 36, 128, 256), (2, 18, 18, 256, 512), (5, 19, 23, 64, 128)):
+                gg = torch.Generator(device='cpu').manual_seed(n + h + ci)
+                x = torch.randn(n, h, w, ci, generator=gg).to(DEV)
+                gy = torch.randn(n, h, w, co, generator=gg).to(DEV)
+                wt = (torch.randn(co, ci, 3, 3, generator=gg) / (3 * ci ** 0.5)).to(DEV)
+                bias = torch.randn(co, generator=gg).to(DEV)
+                wf, wb = native.conv3x3_split_prepare_weights(wt)
+                y, ya = native.conv3x3_split(x, wf, bias, 1, True, want_amax=True)
+                out += [y, ya.max(), native.conv3x3_split(gy, wb, None, 1, False, mask=y)]
+                out += list(native.conv3x3_wgrad_split(gy, x, mask=y))
+                xb, gb = x.to(torch.bfloat16), gy.to(torch.bfloat16)
+                if native.conv3x3_deep_supported(h, w, ci, co):
+                    out.append(native.conv3x3(xb, native.conv3x3_prepare_weights(wt), bias, 1, True))     # the strip kernel of conv_deep.hip (c_in >= 128)
+                if native.conv3x3_wgrad_deep_supported(h, w, ci, co):
+                    out += list(native.conv3x3_wgrad_deep(gb, xb))
+            got[remap] = out
+    finally:
+        monkeypatch.delenv('PCACC_XCD_REMAP')
+        native.reload_switches()
+    assert len(got['1']) == len(got['0']) and len(got['1']) >= 20
+    for a, b in zip(got['1'], got['0']):
+        assert torch.equal(a, b)
