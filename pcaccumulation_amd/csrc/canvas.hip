@@ -433,8 +433,6 @@ static void switches_read()
     g_switches.conv_res = e ? e[0] : 0;
     const char *xr = getenv("PCACC_XCD_REMAP");
     g_switches.xcd_off = xr && xr[0] == '0';
-    const char *cr = getenv("PCACC_CONV_REG");
-    g_switches.conv_reg = cr ? cr[0] : 0;
     const char *v = getenv("PCACC_SCATTER_VARIANT");
     g_switches.scatter_variant = v ? v[0] : 0;
     const char *b = getenv("PCACC_SCATTER_BLOCKS");

@@ -516,33 +516,7 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float 
 #endif
 #define CSR_WPT 9                               // 16-byte weight pieces a thread carries for the next slice (9 taps x 64 rows x 32 ch x 2 planes / 512)
 
-// [r5] NCT > 0: the pixel operand comes from REGISTERS.  The kernel above is bound by its LDS fragment reads (per step and wave 2 NW weight + 2 MT
-// pixel fragments of 1 KiB for 3 MT NW MFMAs: with MT = 2, NW = 1 the LDS pipe and the matrix pipe are both busy 100 % of a perfectly overlapped
-// schedule; measured MFMA-busy 0.30, profiles/r04_pmc_kernels_summary.json), and two thirds of those reads fetch the SAME pixels again: the nine
-// taps of a tile read nine shifted copies of one patch.  Here a wave owns MT consecutive image rows of a 32-column window: it reads the MT + 2 patch
-// rows of the window ONCE per pass (both planes, every k step: (MT + 2) KC 2 fragments), keeps them in registers, and makes the fragments of the
-// dx = -1 / +1 taps by shifting the wave by one lane (v_mov_b32 DPP wave_shr:1 / wave_shl:1 -- the B operand of the 32x32x16 MFMA holds pixel
-// n in lanes n and n + 32, so one lane = one pixel), the dy taps by taking the next row's registers.  The window's first and last column have no
-// left / right neighbour in the wave: they are halo, 30 of the 32 columns produce output, a workgroup tile is (8 / NCT) MT rows x 30 NCT columns
-// (288 columns = 5 tiles of 60: 90 % of the MFMA lanes useful, against half the LDS reads).  Order of accumulation per pixel: tap-major,
-// k-minor, (hi lo, lo hi, hi hi) -- the order of the kernel above, so the results are bit-identical (tests/test_conv_split.py).
-__device__ __forceinline__ f16x8_t csr_shift_px(f16x8_t v, int dx)     // dx is a constant after unrolling: one branch survives
-{
-    if (dx == 1) return v;
-    union { f16x8_t v; int i[4]; } u;
-    u.v = v;
-    // bound_ctrl: the lane without a source (lane 0 / lane 63: halo columns, their results are discarded) reads 0 -- no `old` operand to initialise
-    if (dx == 0) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) u.i[q] = __builtin_amdgcn_mov_dpp(u.i[q], 0x138 /* wave_shr:1: lane n takes lane n - 1 */, 0xf, 0xf, true);
-    } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) u.i[q] = __builtin_amdgcn_mov_dpp(u.i[q], 0x130 /* wave_shl:1: lane n takes lane n + 1 */, 0xf, 0xf, true);
-    }
-    return u.v;
-}
-
-template <int CS, int NW, int MT, int PCH, bool RESTAGE, int NCT = 0>
+template <int CS, int NW, int MT, int PCH, bool RESTAGE>
 __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_res_kernel(const float *__restrict__ in, const float *__restrict__ in_amax,
                                                                         const float *__restrict__ in_mask, const uint16_t *__restrict__ wp,
                                                                         const float *__restrict__ wscale, const float *__restrict__ bias,
@@ -666,7 +640,7 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_res_kernel(const fl
     // a finished tile's values wait in registers and leave one pass later, right after the next patch loads are issued: the wait for those
     // loads at the top of a pass (vmcnt counts stores too) then finds the stores a whole MFMA phase old instead of just issued -- as
     // written before, load burst, MFMA phase and store burst took turns (57 + 53 + 71 us of a 181 us layer, measured by knocking each out)
-    constexpr bool DEFER = !RESTAGE && NCT == 0;               // the register-operand variant has no registers to spare either
+    constexpr bool DEFER = !RESTAGE;
     float4 pend[MT][NW][4];
     int pend_pyx[MT], pend_img = 0;
     bool have_pend = false;
@@ -716,80 +690,14 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_res_kernel(const fl
         // the lane's pixels of this tile
         const int img = cur.img, y0 = cur.y0, x0 = cur.x0;
         int poff[MT], pyx[MT];
-        if constexpr (NCT > 0) {
-            // wave = (column window tc, row group rg): rows rg MT .. rg MT + MT - 1, patch columns tc 30 .. tc 30 + 31 (lane = column; lanes 0 and 31 are halo)
-            const int tc = wave % NCT, rg = wave / NCT;
 #pragma unroll
-            for (int j = 0; j < MT; ++j) {
-                const int y = rg * MT + j, x = tc * 30 + lp - 1;
-                const bool ok = lp >= 1 && lp <= 30 && x < bw && y < rows && y0 + y < h && x0 + x < w;
-                poff[j] = 0;
-                pyx[j] = ok ? ((y0 + y) << 16 | (x0 + x)) : -1;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < MT; ++j) {
-                const int q = (wave + 8 * j) * 32 + lp;
-                const int y = q / bw, x = q - y * bw;
-                const bool ok = q < n_px && y0 + y < h && x0 + x < w;
-                poff[j] = ok ? (y * pw + x) * PS : 0;
-                pyx[j] = ok ? ((y0 + y) << 16 | (x0 + x)) : -1;
-            }
+        for (int j = 0; j < MT; ++j) {
+            const int q = (wave + 8 * j) * 32 + lp;
+            const int y = q / bw, x = q - y * bw;
+            const bool ok = q < n_px && y0 + y < h && x0 + x < w;
+            poff[j] = ok ? (y * pw + x) * PS : 0;
+            pyx[j] = ok ? ((y0 + y) << 16 | (x0 + x)) : -1;
         }
-        if constexpr (NCT > 0) {
-            if (!(CSR_EXP & 1)) {
-                const int tc = wave % NCT, rg = wave / NCT;
-                const uint16_t *cb = patch + ((rg * MT) * pw + tc * 30 + lp) * PS + lh * 8;
-                // the window's MT + 2 patch rows, every k step, hi / lo plane.  Rows 0 .. MT - 1 now; row MT + dy at the start of the taps of row
-                // offset dy (needed from dy + 1 on), so that at most MT + 1 rows are live at a time
-                f16x8_t ch[MT + 2][KC], cl[MT + 2][KC];
-                auto load_row = [&](int r) __attribute__((always_inline)) {
-#pragma unroll
-                    for (int kc = 0; kc < KC; ++kc) {
-                        ch[r][kc] = *reinterpret_cast<const f16x8_t *>(cb + r * pw * PS + kc * 16);
-                        cl[r][kc] = *reinterpret_cast<const f16x8_t *>(cb + plane + r * pw * PS + kc * 16);
-                    }
-                };
-#pragma unroll
-                for (int r = 0; r < MT; ++r) load_row(r);
-                f16x8_t ah[2][NW], al[2][NW];
-                const uint16_t *wa = wl + lp * PS + lh * 8;
-                auto load_a = [&](int slt, int st) __attribute__((always_inline)) {
-                    const int tap = st / KC, kc = st - tap * KC;
-#pragma unroll
-                    for (int n = 0; n < NW; ++n) {
-                        ah[slt][n] = *reinterpret_cast<const f16x8_t *>(wa + (tap * WROWS + n * 32) * PS + kc * 16);
-                        al[slt][n] = *reinterpret_cast<const f16x8_t *>(wa + WPL + (tap * WROWS + n * 32) * PS + kc * 16);
-                    }
-                };
-                load_a(0, 0);
-#pragma unroll
-                for (int st = 0; st < STEPS; ++st) {
-                    if (st + 1 < STEPS) load_a((st + 1) & 1, st + 1);
-                    const int c = st & 1, tap = st / KC, kc = st - tap * KC, dy = tap / 3, dx = tap - dy * 3;
-                    if (kc == 0 && dx == 0 && dy < 2) load_row(MT + dy);
-                    f16x8_t bh[MT], bl[MT];
-#pragma unroll
-                    for (int j = 0; j < MT; ++j) {
-                        bh[j] = csr_shift_px(ch[j + dy][kc], dx);
-                        bl[j] = csr_shift_px(cl[j + dy][kc], dx);
-                    }
-#pragma unroll
-                    for (int j = 0; j < MT; ++j)
-#pragma unroll
-                        for (int n = 0; n < NW; ++n) acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[c][n], bl[j], acc[j][n], 0, 0, 0);
-#pragma unroll
-                    for (int j = 0; j < MT; ++j)
-#pragma unroll
-                        for (int n = 0; n < NW; ++n) acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[c][n], bh[j], acc[j][n], 0, 0, 0);
-#pragma unroll
-                    for (int j = 0; j < MT; ++j)
-#pragma unroll
-                        for (int n = 0; n < NW; ++n) acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[c][n], bh[j], acc[j][n], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        } else
         if (!(CSR_EXP & 1)) {
             f16x8_t ah[AHEAD + 1][NW], al[AHEAD + 1][NW], bh[AHEAD + 1][MT], bl[AHEAD + 1][MT];
             const uint16_t *wa = wl + lp * PS + lh * 8;
@@ -942,32 +850,12 @@ static bool conv_res_plan(int n_img, int h, int w, int c_in, int c_out, ConvResP
     return found;
 }
 
-// [r5] the register-operand configuration: CS = 32, NW = 1, MT = 2, NCT = 2 -> 8 rows x 60 columns per workgroup tile
-static bool conv_reg_plan(int n_img, int h, int w, int c_in, int c_out, ConvResPlan *p)
-{
-    const char e = pcacc_switches().conv_res, r = pcacc_switches().conv_reg;
-    // OFF unless PCACC_CONV_REG=1 (or 2: whatever the size): bit-identical to the resident kernel and half its LDS reads, but SLOWER where it was tried
-    // (20 x 288^2: 32 -> 32 194 vs 172 us, 64 -> 32 456 vs 289, 27 taps 498 vs 330; profiles/r05_conv_reg_ab.txt) -- the resident kernel's time is its
-    // staging / MFMA / store phases in series on a CU that holds one workgroup, not its fragment reads, and the re-staging variants spill here
-    if ((c_in != 32 && c_in != 64) || c_out != 32 || e == '0' || (r != '1' && r != '2') || w < 31) return false;
-    if ((int64_t)n_img * h * w < 200000 && e != '2' && r != '2') return false;
-    const int rows = 8, bw = 60;
-    size_t lds;
-    if (!conv_res_fits(32, 1, 2, rows, bw, &lds)) return false;
-    const int tiles_y = (h + rows - 1) / rows, tiles_x = (w + bw - 1) / bw;
-    int64_t slots = PCACC_CUS;
-    const int64_t n_tiles = (int64_t)n_img * tiles_y * tiles_x;
-    if (slots > n_tiles) slots = n_tiles;
-    *p = ConvResPlan{32, 1, 2, rows, bw, tiles_y, tiles_x, 1, (int)slots, lds};
-    return true;
-}
-
-template <int CS, int NW, int MT, int PCH, bool RESTAGE, int NCT = 0>
+template <int CS, int NW, int MT, int PCH, bool RESTAGE>
 static int conv_res_launch(const ConvResPlan &p, const float *in, const float *in_amax, const float *in_mask, const uint16_t *wp,
                            const float *wscale, const float *bias, float *out, float *out_amax, uint16_t *out16, int n_img, int frames, int h, int w,
                            int c_in, int c_out, int kt, int relu, hipStream_t st, const float *in2 = nullptr, int c_a = 0)
 {
-    auto kern = conv3x3_split_res_kernel<CS, NW, MT, PCH, RESTAGE, NCT>;
+    auto kern = conv3x3_split_res_kernel<CS, NW, MT, PCH, RESTAGE>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds) != hipSuccess)
         return PCACC_E_LAUNCH;
     hipLaunchKernelGGL(kern, dim3((unsigned)(p.co_groups * p.slots)), dim3(CSP_THREADS), p.lds, st, in, in_amax, in_mask, wp, wscale, bias, out, out_amax,
@@ -1075,15 +963,6 @@ static int conv3x3_split_impl(const float *in, const float *in_amax, const float
         return PCACC_E_ARG;
     hipStream_t st = pcacc_stream(stream);
     ConvResPlan rp;
-    // [r5] c_out = 32 on full-resolution maps: the pixel operand from registers (NCT = 2: tiles of 8 rows x 60 columns); PCACC_CONV_REG=0 switches it off (A/B, equality test)
-    if (conv_reg_plan(n_img, h, w, c_in, c_out, &rp) && PCACC_WALK_OK(n_img, frames, rp.tiles_y, rp.tiles_x)) {
-        if (pcacc_switches().conv_plan)
-            fprintf(stderr, "split conv plan (resident, pixel operand in registers) %dx%d %d->%d kt=%d n=%d: rows=%d bw=%d slots=%d lds=%zu\n", h, w, c_in, c_out,
-                    kt, n_img, rp.rows, rp.bw, rp.slots, rp.lds);
-        const bool restage = kt == 3 || c_in != rp.cs;
-        return restage ? conv_res_launch<32, 1, 2, 5, true, 2>(rp, in, in_amax, in_mask, wp, wscale, bias, out, out_amax, out16, n_img, frames, h, w, c_in, c_out, kt, relu, st, in2, c_a)
-                       : conv_res_launch<32, 1, 2, 5, false, 2>(rp, in, in_amax, in_mask, wp, wscale, bias, out, out_amax, out16, n_img, frames, h, w, c_in, c_out, kt, relu, st, in2, c_a);
-    }
     if (conv_res_plan(n_img, h, w, c_in, c_out, &rp, divides) && PCACC_WALK_OK(n_img, frames, rp.tiles_y, rp.tiles_x)) {
         if (pcacc_switches().conv_plan)
             fprintf(stderr, "split conv plan (resident) %dx%d %d->%d kt=%d n=%d: cs=%d nw=%d mt=%d rows=%d bw=%d slots=%d lds=%zu\n", h, w, c_in, c_out,

@@ -332,43 +332,6 @@ def test_conv3x3_split_on_two_inputs(n, h, w, ca, cb, co, res, relu, monkeypatch
         native.reload_switches()
 
 
-@pytest.mark.parametrize('n,t,h,w,ci,kt', [(2, 1, 40, 70, 32, 1), (1, 1, 19, 45, 64, 1), (6, 3, 12, 36, 32, 3), (2, 1, 100, 61, 32, 1), (2, 2, 3, 300, 64, 3),
-                                           (1, 1, 9, 31, 32, 1), (2, 1, 8, 60, 64, 1), (1, 1, 17, 121, 32, 1)])
-def test_register_operand_kernel_is_bit_identical_to_the_resident_kernel(n, t, h, w, ci, kt, monkeypatch):
-    """Round 5 (experimental, off by default: PCACC_CONV_REG=1 / 2): c_out = 32 layers take the pixel operand of the MFMAs from registers (a wave keeps its
-    window's patch rows and makes the dx = -1 / +1 taps by one-lane DPP shifts; csrc/conv_split.hip, NCT > 0) instead of reading nine shifted copies from LDS.  Same staging, same order of
-    accumulation per pixel: forward, bf16 shadow, reported maximum and the masked data gradient are BIT-identical to the resident kernel it replaces
-    (PCACC_CONV_REG=0), on widths that are / are not multiples of the 30-column windows and of the 60-column tiles, one- and two-slice inputs, frame taps."""
-    g = torch.Generator(device='cpu').manual_seed(n + h + w + ci)
-    x = torch.randn(n, h, w, ci, generator=g).to(DEV)
-    shape = (32, ci, 3, 3, 3) if kt == 3 else (32, ci, 3, 3)
-    wt = (torch.randn(*shape, generator=g) / (4 * ci ** 0.5)).to(DEV)
-    bias = torch.randn(32, generator=g).to(DEV)
-    wps = native.conv3x3_split_prepare_weights(wt)[0]
-    frames = t if kt == 3 else 1
-    mask = torch.randn(n, h, w, 32, generator=g).to(DEV)
-    got = {}
-    try:
-        for reg in ('2', '0'):                                  # '2': the register-operand kernel whatever the size; '0': never
-            monkeypatch.setenv('PCACC_CONV_RES', '2')
-            monkeypatch.setenv('PCACC_CONV_REG', reg)
-            native.reload_switches()
-            y, ya, y16 = native.conv3x3_split(x, wps, bias, frames, True, want_amax=True, want_bf16=True)
-            ym = native.conv3x3_split(x, wps, None, frames, False, out_mask=mask)
-            got[reg] = (y, ya.max(), y16, ym)
-            if ci == 64 and kt == 1:
-                a, b = x[..., :32].contiguous(), x[..., 32:].contiguous()
-                amax = torch.maximum(native.absmax256(a), native.absmax256(b))
-                got[reg] += (native.conv3x3_split_cat(a, b, amax, wps, bias, True)[0],)
-    finally:
-        monkeypatch.delenv('PCACC_CONV_RES')
-        monkeypatch.delenv('PCACC_CONV_REG')
-        native.reload_switches()
-    for u, v in zip(got['2'], got['0']):
-        assert torch.equal(u, v)
-    assert float(got['2'][1]) == float(got['2'][0].abs().max())
-
-
 def test_xcd_contiguous_block_walk_changes_no_result(monkeypatch):
     """Round 5: the multi-group convolution kernels map blockIdx to a logical block id such that the output-channel groups of a tile / the (co, ci)
     blocks of a strip run on ONE XCD and share their operand reads in its L2 (common.h: pcacc_xcd_block).  A pure re-ordering of workgroups: forward
