@@ -431,8 +431,6 @@ static void switches_read()
     g_switches.rows_fm_off = getenv("PCACC_ROWS_FM_OFF") != nullptr;
     g_switches.conv_plan = getenv("PCACC_CONV_PLAN") != nullptr;
     g_switches.conv_res = e ? e[0] : 0;
-    const char *r2 = getenv("PCACC_CONV_RES2");
-    g_switches.conv_res2 = r2 ? r2[0] : 0;
     const char *xr = getenv("PCACC_XCD_REMAP");
     g_switches.xcd_off = xr && xr[0] == '0';
     const char *v = getenv("PCACC_SCATTER_VARIANT");

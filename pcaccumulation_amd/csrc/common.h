@@ -21,7 +21,6 @@ struct PcaccSwitches {
     bool rows_fm_off;        // PCACC_ROWS_FM_OFF: wide fp32x3 row layers on the weights-in-LDS kernel
     bool conv_plan;          // PCACC_CONV_PLAN: print the launch plans of the strip kernels
     char conv_res;           // PCACC_CONV_RES: '0' never the resident fp32x3 kernel, '2' whatever the size, 0 unset
-    char conv_res2;          // PCACC_CONV_RES2: '0' never the two-workgroups-per-CU form of the resident fp32x3 kernel (round 5), '2' whatever the size, 0 unset
     bool xcd_off;            // PCACC_XCD_REMAP=0: workgroups in launch order (round 4) instead of the XCD-contiguous walk of the multi-group convolution kernels
     char scatter_variant;    // PCACC_SCATTER_VARIANT: pillar_scatter_rows16 variants (pieces per lane / cache policy), 0 unset = the default kernel
     int scatter_blocks;      // PCACC_SCATTER_BLOCKS: workgroups per CU of the pillar-scatter launch (0 = default)

@@ -516,15 +516,8 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float 
 #endif
 #define CSR_WPT 9                               // 16-byte weight pieces a thread carries for the next slice (9 taps x 64 rows x 32 ch x 2 planes / 512)
 
-// [r5] TH = 256, SWZ: the same kernel as 4-wave workgroups of <= 80 KB of LDS, TWO of which share a CU.  One 144 KB workgroup per CU runs its phases in
-// series (patch loads + fp32 -> hi / lo staging, MFMA loop, epilogue + stores: 57 + 53 + 71 us of the 181 us of a 32 -> 32 layer, measured by knocking each
-// out) and all CUs run them in step: read burst, idle memory, write burst.  Two independent workgroups per CU drift out of phase
-// and one's MFMA loop covers the other's memory phases.  What makes them fit: tiles of 8 x 32 pixels (patch 10 x 34) and UNPADDED 64-byte rows for the
-// patch and the weight tiles (2 x 340 x 64 + 2 x 288 x 64 B = 80 384 B), the 16-byte chunk index of a row XOR-ed with (row >> 2) & 3 -- conflict-free for
-// the 16-lane groups of a ds_read_b128 whose lanes address consecutive rows (rows r, r + 4, r + 8, r + 12 share their banks at equal chunk index and get
-// four different ones), the scheme of conv.hip's 27-tap kernel.  Same arithmetic in the same order: results are bit-identical to the 512-thread kernel.
-template <int CS, int NW, int MT, int PCH, bool RESTAGE, int TH = CSP_THREADS, bool SWZ = false>
-__global__ __launch_bounds__(TH, 2) void conv3x3_split_res_kernel(const float *__restrict__ in, const float *__restrict__ in_amax,
+template <int CS, int NW, int MT, int PCH, bool RESTAGE>
+__global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_res_kernel(const float *__restrict__ in, const float *__restrict__ in_amax,
                                                                         const float *__restrict__ in_mask, const uint16_t *__restrict__ wp,
                                                                         const float *__restrict__ wscale, const float *__restrict__ bias,
                                                                         float *__restrict__ out, float *__restrict__ out_amax, uint16_t *__restrict__ out16, int n_img, int frames,
@@ -532,9 +525,7 @@ __global__ __launch_bounds__(TH, 2) void conv3x3_split_res_kernel(const float *_
                                                                         int tiles_y, int tiles_x, int co_groups, int slots,
                                                                         const float *__restrict__ in2, int c_a)
 {
-    static_assert(!SWZ || CS == 32, "swizzled rows are 64 bytes");
-    constexpr int PS = SWZ ? CS : CS + 8;
-    constexpr int NWV = TH / 64;                               // waves per workgroup
+    constexpr int PS = CS + 8;
     constexpr int WROWS = 32 * NW;
     constexpr int C8 = CS / 8;
     constexpr int WPL = 9 * WROWS * PS;                        // one weight plane (nine taps)
@@ -544,8 +535,6 @@ __global__ __launch_bounds__(TH, 2) void conv3x3_split_res_kernel(const float *_
     const int plane = pp * PS;
     uint16_t *patch = lds;                                     // [2 = hi, lo][pp][PS]
     uint16_t *wl = lds + 2 * (size_t)plane;                    // [2 = hi, lo][9][WROWS][PS]
-    // element offset of 16-byte chunk `chunk` of row `row` (rows counted inside a plane / the weight array)
-    auto lofs = [&](int row, int chunk) __attribute__((always_inline)) { return SWZ ? row * PS + ((chunk ^ ((row >> 2) & 3)) << 3) : row * PS + chunk * 8; };
 
     const int cog = blockIdx.x % co_groups, slot = blockIdx.x / co_groups;
     const int co0 = cog * WROWS;
@@ -570,7 +559,7 @@ __global__ __launch_bounds__(TH, 2) void conv3x3_split_res_kernel(const float *_
     float4 preg[PCH][2];
 #pragma unroll
     for (int q = 0; q < PCH; ++q) {
-        const int c = threadIdx.x + q * TH;
+        const int c = threadIdx.x + q * CSP_THREADS;
         const int px = c / C8, c8 = c - px * C8;
         const int py = px / pw, pxx = px - py * pw;
         pinfo[q] = c < n_chunks ? (py << 20 | pxx << 8 | c8) : (0x7ff << 20);
@@ -603,18 +592,18 @@ __global__ __launch_bounds__(TH, 2) void conv3x3_split_res_kernel(const float *_
     auto write_patch = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < PCH; ++q) {
-            const int c = threadIdx.x + q * TH;
+            const int c = threadIdx.x + q * CSP_THREADS;
             if (c < n_chunks) {
                 uint4 hi, lo;
                 csp_split8(preg[q][0], preg[q][1], sx, hi, lo);
-                uint16_t *dst = patch + lofs(c / C8, c % C8);
+                uint16_t *dst = patch + (c / C8) * PS + (c % C8) * 8;
                 *reinterpret_cast<uint4 *>(dst) = hi;
                 *reinterpret_cast<uint4 *>(dst + plane) = lo;
             }
         }
     };
     // the nine tap tiles of slice s, both planes: 2 x 9 x WROWS rows of CS elements
-    constexpr int W_ROWS_ALL = 2 * 9 * WROWS, W_CHUNKS = W_ROWS_ALL * C8, W_PER = (W_CHUNKS + TH - 1) / TH;
+    constexpr int W_ROWS_ALL = 2 * 9 * WROWS, W_CHUNKS = W_ROWS_ALL * C8, W_PER = (W_CHUNKS + CSP_THREADS - 1) / CSP_THREADS;
     static_assert(W_PER <= CSR_WPT, "weight pieces per thread");
     const int64_t w_plane = (int64_t)kt * 9 * c_out * c_in;
     typedef uint32_t wvec_t __attribute__((ext_vector_type(4 * W_PER)));      // one SSA value, not an array: as `uint4 wreg[W_PER]` it stayed in scratch memory
@@ -622,7 +611,7 @@ __global__ __launch_bounds__(TH, 2) void conv3x3_split_res_kernel(const float *_
     auto fetch_w = [&](int f, int cs) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < W_PER; ++q) {
-            const int c = min((int)threadIdx.x + q * TH, W_CHUNKS - 1);
+            const int c = min((int)threadIdx.x + q * CSP_THREADS, W_CHUNKS - 1);
             const int row = c / C8, c8 = c - row * C8;         // row = (plane, tap, r)
             const int pl = row / (9 * WROWS), tr = row - pl * 9 * WROWS;
             const int tap = tr / WROWS, r = tr - tap * WROWS;
@@ -633,8 +622,8 @@ __global__ __launch_bounds__(TH, 2) void conv3x3_split_res_kernel(const float *_
     auto write_w = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < W_PER; ++q) {
-            const int c = threadIdx.x + q * TH;
-            if (c < W_CHUNKS) *reinterpret_cast<uint4 *>(wl + lofs(c / C8, c % C8)) = make_uint4(wreg[4 * q], wreg[4 * q + 1], wreg[4 * q + 2], wreg[4 * q + 3]);
+            const int c = threadIdx.x + q * CSP_THREADS;
+            if (c < W_CHUNKS) *reinterpret_cast<uint4 *>(wl + (c / C8) * PS + (c % C8) * 8) = make_uint4(wreg[4 * q], wreg[4 * q + 1], wreg[4 * q + 2], wreg[4 * q + 3]);
         }
     };
 
@@ -651,7 +640,7 @@ __global__ __launch_bounds__(TH, 2) void conv3x3_split_res_kernel(const float *_
     // a finished tile's values wait in registers and leave one pass later, right after the next patch loads are issued: the wait for those
     // loads at the top of a pass (vmcnt counts stores too) then finds the stores a whole MFMA phase old instead of just issued -- as
     // written before, load burst, MFMA phase and store burst took turns (57 + 53 + 71 us of a 181 us layer, measured by knocking each out)
-    constexpr bool DEFER = !RESTAGE && TH == CSP_THREADS;       // two workgroups per CU: the other one covers the store burst, and the registers are needed
+    constexpr bool DEFER = !RESTAGE;
     float4 pend[MT][NW][4];
     int pend_pyx[MT], pend_img = 0;
     bool have_pend = false;
@@ -703,44 +692,27 @@ __global__ __launch_bounds__(TH, 2) void conv3x3_split_res_kernel(const float *_
         int poff[MT], pyx[MT];
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
-            const int q = (wave + NWV * j) * 32 + lp;
+            const int q = (wave + 8 * j) * 32 + lp;
             const int y = q / bw, x = q - y * bw;
             const bool ok = q < n_px && y0 + y < h && x0 + x < w;
-            poff[j] = ok ? (y * pw + x) * (SWZ ? 1 : PS) : 0;          // SWZ: the patch ROW of the pixel's top-left tap (the chunk swizzle depends on the row)
+            poff[j] = ok ? (y * pw + x) * PS : 0;
             pyx[j] = ok ? ((y0 + y) << 16 | (x0 + x)) : -1;
         }
         if (!(CSR_EXP & 1)) {
             f16x8_t ah[AHEAD + 1][NW], al[AHEAD + 1][NW], bh[AHEAD + 1][MT], bl[AHEAD + 1][MT];
             const uint16_t *wa = wl + lp * PS + lh * 8;
-            const int sa = (lp >> 2) & 3;                      // SWZ: chunk swizzle of this lane's weight rows (tap * WROWS + n * 32 + lp: the multiples of 32 drop out)
             auto load = [&](int slt, int st) __attribute__((always_inline)) {
                 const int tap = st / KC, kc = st - tap * KC;
-                if constexpr (SWZ) {
-                    const uint16_t *wr = wl + (tap * WROWS + lp) * PS + (((kc * 2 + lh) ^ sa) << 3);
+                const int toff = ((tap / 3) * pw + tap % 3) * PS + lh * 8 + kc * 16;
 #pragma unroll
-                    for (int n = 0; n < NW; ++n) {
-                        ah[slt][n] = *reinterpret_cast<const f16x8_t *>(wr + n * 32 * PS);
-                        al[slt][n] = *reinterpret_cast<const f16x8_t *>(wr + WPL + n * 32 * PS);
-                    }
+                for (int n = 0; n < NW; ++n) {
+                    ah[slt][n] = *reinterpret_cast<const f16x8_t *>(wa + (tap * WROWS + n * 32) * PS + kc * 16);
+                    al[slt][n] = *reinterpret_cast<const f16x8_t *>(wa + WPL + (tap * WROWS + n * 32) * PS + kc * 16);
+                }
 #pragma unroll
-                    for (int j = 0; j < MT; ++j) {
-                        const int row = poff[j] + (tap / 3) * pw + tap % 3;
-                        const int o = row * PS + (((kc * 2 + lh) ^ ((row >> 2) & 3)) << 3);
-                        bh[slt][j] = *reinterpret_cast<const f16x8_t *>(patch + o);
-                        bl[slt][j] = *reinterpret_cast<const f16x8_t *>(patch + plane + o);
-                    }
-                } else {
-                    const int toff = ((tap / 3) * pw + tap % 3) * PS + lh * 8 + kc * 16;
-#pragma unroll
-                    for (int n = 0; n < NW; ++n) {
-                        ah[slt][n] = *reinterpret_cast<const f16x8_t *>(wa + (tap * WROWS + n * 32) * PS + kc * 16);
-                        al[slt][n] = *reinterpret_cast<const f16x8_t *>(wa + WPL + (tap * WROWS + n * 32) * PS + kc * 16);
-                    }
-#pragma unroll
-                    for (int j = 0; j < MT; ++j) {
-                        bh[slt][j] = *reinterpret_cast<const f16x8_t *>(patch + poff[j] + toff);
-                        bl[slt][j] = *reinterpret_cast<const f16x8_t *>(patch + plane + poff[j] + toff);
-                    }
+                for (int j = 0; j < MT; ++j) {
+                    bh[slt][j] = *reinterpret_cast<const f16x8_t *>(patch + poff[j] + toff);
+                    bl[slt][j] = *reinterpret_cast<const f16x8_t *>(patch + plane + poff[j] + toff);
                 }
             };
 #pragma unroll
@@ -878,34 +850,15 @@ static bool conv_res_plan(int n_img, int h, int w, int c_in, int c_out, ConvResP
     return found;
 }
 
-// [r5] the two-workgroups-per-CU configuration of the resident kernel: c_out = 32 (NW = 1), 32-channel slices, 4 waves x 2 pixel tiles = 8 x 32 pixels,
-// swizzled 64-byte rows: 80 384 B of LDS.  PCACC_CONV_RES2=0 switches it off (A/B, bit-identity test), =2 takes it whatever the map size.
-static bool conv_res2_plan(int n_img, int h, int w, int c_in, int c_out, ConvResPlan *p)
-{
-    const char e = pcacc_switches().conv_res, t = pcacc_switches().conv_res2;
-    if ((c_in != 32 && c_in != 64) || c_out != 32 || e == '0' || t == '0') return false;
-    if ((int64_t)n_img * h * w < 200000 && e != '2' && t != '2') return false;
-    const int rows = 8, bw = 32;
-    const int64_t pp = (int64_t)(rows + 2) * (bw + 2);
-    const size_t lds = (size_t)(2 * pp + 2 * 9 * 32) * 32 * sizeof(uint16_t);
-    if (pp * 4 > 256 * 6 || 2 * lds > CSP_LDS_MAX) return false;
-    const int tiles_y = (h + rows - 1) / rows, tiles_x = (w + bw - 1) / bw;
-    int64_t slots = 2 * PCACC_CUS;
-    const int64_t n_tiles = (int64_t)n_img * tiles_y * tiles_x;
-    if (slots > n_tiles) slots = n_tiles;
-    *p = ConvResPlan{32, 1, 2, rows, bw, tiles_y, tiles_x, 1, (int)slots, lds};
-    return true;
-}
-
-template <int CS, int NW, int MT, int PCH, bool RESTAGE, int TH = CSP_THREADS, bool SWZ = false>
+template <int CS, int NW, int MT, int PCH, bool RESTAGE>
 static int conv_res_launch(const ConvResPlan &p, const float *in, const float *in_amax, const float *in_mask, const uint16_t *wp,
                            const float *wscale, const float *bias, float *out, float *out_amax, uint16_t *out16, int n_img, int frames, int h, int w,
                            int c_in, int c_out, int kt, int relu, hipStream_t st, const float *in2 = nullptr, int c_a = 0)
 {
-    auto kern = conv3x3_split_res_kernel<CS, NW, MT, PCH, RESTAGE, TH, SWZ>;
+    auto kern = conv3x3_split_res_kernel<CS, NW, MT, PCH, RESTAGE>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds) != hipSuccess)
         return PCACC_E_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(p.co_groups * p.slots)), dim3(TH), p.lds, st, in, in_amax, in_mask, wp, wscale, bias, out, out_amax,
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.co_groups * p.slots)), dim3(CSP_THREADS), p.lds, st, in, in_amax, in_mask, wp, wscale, bias, out, out_amax,
                        out16, n_img, frames, h, w, c_in, c_out, kt, relu, p.rows, p.bw, p.tiles_y, p.tiles_x, p.co_groups, p.slots, in2, c_a);
     PCACC_CHECK_LAUNCH();
     return 0;
@@ -1010,14 +963,6 @@ static int conv3x3_split_impl(const float *in, const float *in_amax, const float
         return PCACC_E_ARG;
     hipStream_t st = pcacc_stream(stream);
     ConvResPlan rp;
-    if (conv_res2_plan(n_img, h, w, c_in, c_out, &rp) && PCACC_WALK_OK(n_img, frames, rp.tiles_y, rp.tiles_x)) {
-        if (pcacc_switches().conv_plan)
-            fprintf(stderr, "split conv plan (resident, two workgroups per CU) %dx%d %d->%d kt=%d n=%d: rows=%d bw=%d slots=%d lds=%zu\n", h, w, c_in, c_out, kt,
-                    n_img, rp.rows, rp.bw, rp.slots, rp.lds);
-        const bool restage = kt == 3 || c_in != rp.cs;
-        return restage ? conv_res_launch<32, 1, 2, 6, true, 256, true>(rp, in, in_amax, in_mask, wp, wscale, bias, out, out_amax, out16, n_img, frames, h, w, c_in, c_out, kt, relu, st, in2, c_a)
-                       : conv_res_launch<32, 1, 2, 6, false, 256, true>(rp, in, in_amax, in_mask, wp, wscale, bias, out, out_amax, out16, n_img, frames, h, w, c_in, c_out, kt, relu, st, in2, c_a);
-    }
     if (conv_res_plan(n_img, h, w, c_in, c_out, &rp, divides) && PCACC_WALK_OK(n_img, frames, rp.tiles_y, rp.tiles_x)) {
         if (pcacc_switches().conv_plan)
             fprintf(stderr, "split conv plan (resident) %dx%d %d->%d kt=%d n=%d: cs=%d nw=%d mt=%d rows=%d bw=%d slots=%d lds=%zu\n", h, w, c_in, c_out,

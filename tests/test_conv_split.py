@@ -365,40 +365,3 @@ def test_xcd_contiguous_block_walk_changes_no_result(monkeypatch):
     assert len(got['1']) == len(got['0']) and len(got['1']) >= 20
     for a, b in zip(got['1'], got['0']):
         assert torch.equal(a, b)
-
-
-@pytest.mark.parametrize('n,t,h,w,ci,kt', [(2, 1, 40, 70, 32, 1), (1, 1, 19, 45, 64, 1), (6, 3, 12, 36, 32, 3), (2, 1, 100, 61, 32, 1), (2, 2, 3, 300, 64, 3),
-                                           (1, 1, 9, 31, 32, 1), (2, 1, 8, 32, 64, 1), (1, 1, 17, 121, 32, 1)])
-def test_two_workgroups_per_cu_form_is_bit_identical_to_the_resident_kernel(n, t, h, w, ci, kt, monkeypatch):
-    """Round 5: the c_out = 32 layers run the resident fp32x3 kernel as 256-thread workgroups of 80 KB of LDS (8 x 32 pixel tiles, unpadded 64-byte rows
-    with the chunk index XOR-ed by (row >> 2) & 3), two per CU, so that one's MFMA loop covers the other's load / store phases.  Same staging arithmetic,
-    same order of accumulation: forward, bf16 shadow, reported maximum, the masked data gradient and the two-input form are BIT-identical to the
-    512-thread kernel (PCACC_CONV_RES2=0), on widths / heights that are and are not multiples of the tile, one- and two-slice inputs, frame taps."""
-    g = torch.Generator(device='cpu').manual_seed(n + h + w + ci)
-    x = torch.randn(n, h, w, ci, generator=g).to(DEV)
-    shape = (32, ci, 3, 3, 3) if kt == 3 else (32, ci, 3, 3)
-    wt = (torch.randn(*shape, generator=g) / (4 * ci ** 0.5)).to(DEV)
-    bias = torch.randn(32, generator=g).to(DEV)
-    wps = native.conv3x3_split_prepare_weights(wt)[0]
-    frames = t if kt == 3 else 1
-    mask = torch.randn(n, h, w, 32, generator=g).to(DEV)
-    got = {}
-    try:
-        for two in ('2', '0'):                                  # '2': the two-per-CU form whatever the size; '0': never
-            monkeypatch.setenv('PCACC_CONV_RES', '2')
-            monkeypatch.setenv('PCACC_CONV_RES2', two)
-            native.reload_switches()
-            y, ya, y16 = native.conv3x3_split(x, wps, bias, frames, True, want_amax=True, want_bf16=True)
-            ym = native.conv3x3_split(x, wps, None, frames, False, out_mask=mask)
-            got[two] = (y, ya.max(), y16, ym)
-            if ci == 64 and kt == 1:
-                a, b = x[..., :32].contiguous(), x[..., 32:].contiguous()
-                amax = torch.maximum(native.absmax256(a), native.absmax256(b))
-                got[two] += (native.conv3x3_split_cat(a, b, amax, wps, bias, True)[0],)
-    finally:
-        monkeypatch.delenv('PCACC_CONV_RES')
-        monkeypatch.delenv('PCACC_CONV_RES2')
-        native.reload_switches()
-    for u, v in zip(got['2'], got['0']):
-        assert torch.equal(u, v)
-    assert float(got['2'][1]) == float(got['2'][0].abs().max())
