@@ -499,7 +499,10 @@ def main():
     stepper_buckets = list(stepper.reducer.buckets)
     dt = pdist.max_over_ranks(time.perf_counter() - t0, device)
     timer, native.scatter_timer = native.scatter_timer, None
-    per_step = sorted(a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:]))
+    per_step_in_order = [a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:])]
+    per_step = sorted(per_step_in_order)
+    if os.environ.get('PCACC_BENCH_DEBUG'):
+        print('per-step ms, in order:', ['%.2f' % t for t in per_step_in_order], file=sys.stderr)
 
     def pct(q):
         return per_step[min(len(per_step) - 1, int(round(q * (len(per_step) - 1))))] if per_step else None
@@ -576,7 +579,7 @@ def main():
         line = {
             'metric': 'LiDAR-frames/sec (5-frame seq, 160k pts) fwd+bwd', 'value': frames / dt, 'unit': 'LiDAR-frames/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
-            'ms_per_step_p10': pct(0.1), 'ms_per_step_p50': pct(0.5), 'ms_per_step_p90': pct(0.9),
+            'ms_per_step_p10': pct(0.1), 'ms_per_step_p50': pct(0.5), 'ms_per_step_p90': pct(0.9), 'ms_per_step_max': per_step[-1] if per_step else None,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': 'c3 shape: Waymo geometry 288x288x%d, %d pts/frame %s synthetic, %d sequences per GPU per step, '
                                    'train step = GPU voxelise + MotionNet fwd + FuseLoss + bwd + bucketed grad all-reduce (overlapped) + clip + Adam'

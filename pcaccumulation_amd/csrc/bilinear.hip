@@ -213,6 +213,11 @@ __global__ __launch_bounds__(256) void bilinear_sorted_prep_kernel(const void *_
     }
 }
 
+// [r5] cells are walked in 4 x 4 tiles (one tile = the 16 cells x c / 4 lanes a 64-channel workgroup pass covers): a point's gradient row is read by the
+// four cells around it, and with row-major cells the two in the next map row were 288 cells = another workgroup, usually another XCD, away -- every row
+// came out of HBM / the Infinity Cache twice (PMC round 4: 1.83 x the algorithmic bytes); inside a tile the second reader finds it in the CU's cache.
+// The six segment offsets a cell needs are loaded up front (independent loads) instead of two behind each tap's bounds test.  Same taps in the same
+// order per cell: results bit-identical to the row-major walk.
 template <int G_BF16, int OUT_BF16>
 __global__ __launch_bounds__(256) void bilinear_gather_bwd_sorted_kernel(const void *__restrict__ g_sorted, const float4 *__restrict__ wts,
                                                                          int n_maps, int h, int w, int c,
@@ -220,19 +225,37 @@ __global__ __launch_bounds__(256) void bilinear_gather_bwd_sorted_kernel(const v
                                                                          void *__restrict__ grad_fmap)
 {
     const int lpp = c / 4;
-    const int64_t total = (int64_t)n_maps * h * w * lpp;
+    const int tw = (w + 3) >> 2, th = (h + 3) >> 2;
+    const int64_t total = (int64_t)n_maps * th * tw * 16 * lpp;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int64_t cell = e / lpp;
-        const int ch = (int)(e - cell * lpp) * 4;
-        const int x = (int)(cell % w), y = (int)((cell / w) % h);
+        const int64_t k = e / lpp;                                               // tile-major cell number
+        const int ch = (int)(e - k * lpp) * 4;
+        const int64_t tile = k >> 4;
+        const int ci = (int)(k & 15);
+        const int tx0 = (int)(tile % tw), ty0 = (int)((tile / tw) % th), mi = (int)(tile / ((int64_t)tw * th));
+        const int x = tx0 * 4 + (ci & 3), y = ty0 * 4 + (ci >> 2);
+        if (x >= w || y >= h) continue;
+        const int64_t cell = ((int64_t)mi * h + y) * w + x;
+        // segment bounds of the four base cells (x - tx, y - ty); a base outside the map gets the empty range
+        int b[4], en[4];
+        {
+            const int o_c = seg_offsets[cell], o_c1 = seg_offsets[cell + 1];
+            const int o_l = x > 0 ? seg_offsets[cell - 1] : o_c;
+            b[0] = o_c; en[0] = o_c1;
+            b[1] = o_l; en[1] = o_c;
+            if (y > 0) {
+                const int o_u = seg_offsets[cell - w], o_u1 = seg_offsets[cell - w + 1];
+                const int o_ul = x > 0 ? seg_offsets[cell - w - 1] : o_u;
+                b[2] = o_u; en[2] = o_u1;
+                b[3] = o_ul; en[3] = o_u;
+            } else {
+                b[2] = en[2] = b[3] = en[3] = 0;
+            }
+        }
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int tap = 0; tap < 4; ++tap) {                                      // this cell as tap (ty, tx) of base cell (y-ty, x-tx)
-            const int tx = tap & 1, ty = tap >> 1;
-            if (x - tx < 0 || y - ty < 0) continue;
-            const int64_t base = cell - (int64_t)ty * w - tx;
-            const int b = seg_offsets[base], en = seg_offsets[base + 1];
-            for (int q = b; q < en; ++q) {
+            for (int q = b[tap]; q < en[tap]; ++q) {
                 const float4 w4 = wts[q];
                 const float wt = tap == 0 ? w4.x : tap == 1 ? w4.y : tap == 2 ? w4.z : w4.w;
                 if (wt == 0.f) continue;                                         // outside the map (or an exact zero weight)
@@ -282,7 +305,7 @@ extern "C" int pcacc_bilinear_gather_backward_sorted(const void *grad_out, int g
         else bilinear_sorted_prep_kernel<0><<<pgrid, 256, 0, s>>>(grad_out, c, h, w, points, order, k, x_scale, y_scale, wts, g_sorted);
     }
     // many short workgroups: the per-cell loops are as long as the cell is crowded, a fine grid evens that out
-    const int grid = pcacc_grid((int64_t)n_maps * h * w * (c / 4), 256, PCACC_CUS * 64);
+    const int grid = pcacc_grid((int64_t)n_maps * ((h + 3) / 4) * ((w + 3) / 4) * 16 * (c / 4), 256, PCACC_CUS * 64);
 #define BGS(GB, OB) bilinear_gather_bwd_sorted_kernel<GB, OB><<<grid, 256, 0, s>>>(g_sorted, wts, n_maps, h, w, c, seg_offsets, grad_fmap)
     if (grad_dtype == PCACC_BF16) { if (out_dtype == PCACC_BF16) BGS(1, 1); else BGS(1, 0); }
     else { if (out_dtype == PCACC_BF16) BGS(0, 1); else BGS(0, 0); }

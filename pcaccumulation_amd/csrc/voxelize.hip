@@ -52,8 +52,10 @@ __device__ __forceinline__ int vox_is_first(const uint32_t *keys, const uint32_t
 }
 
 // pass 2: number of first-touch points per 2048-point chunk (wave ballot + popcount)
+// first_bits (may be NULL): one 64-bit word per 64 points, bit = "this point is the first of its cell" -- the ranking pass of the batched voxeliser reads
+// it back instead of gathering the table word of every point a second time ([r5]: 3.2 M random 4-byte reads = most of that pass's 4.7 x algorithmic bytes)
 __global__ __launch_bounds__(256) void vox_count(const uint32_t *__restrict__ keys, const uint32_t *table,
-                                                 int64_t n, int *chunk_sums)
+                                                 int64_t n, int *chunk_sums, unsigned long long *__restrict__ first_bits = nullptr)
 {
     __shared__ int lds[4];
     const int64_t base = (int64_t)blockIdx.x * PCACC_CHUNK;
@@ -61,8 +63,11 @@ __global__ __launch_bounds__(256) void vox_count(const uint32_t *__restrict__ ke
 #pragma unroll
     for (int r = 0; r < PCACC_CHUNK_ROWS; ++r) {
         uint32_t key;
-        const int f = vox_is_first(keys, table, base + r * 256 + threadIdx.x, n, &key);
-        acc += __popcll(__ballot(f));                       // same value in all 64 lanes
+        const int64_t i = base + r * 256 + threadIdx.x;
+        const int f = vox_is_first(keys, table, i, n, &key);
+        const unsigned long long m = __ballot(f);
+        if (first_bits && lane_id() == 0 && i < n) first_bits[i >> 6] = m;      // lane 0 holds the lowest index of the wave's 64 (aligned: 256-thread rows of 2048-point chunks)
+        acc += __popcll(m);                                 // same value in all 64 lanes
     }
     if (lane_id() == 0) lds[threadIdx.x >> 6] = acc;
     __syncthreads();
@@ -212,15 +217,16 @@ __global__ __launch_bounds__(256) void vox_batch_keys(VoxBatch b, int64_t n, Vox
 
 // ranks the firsts like vox_assign; a row of `coordinates` is (sample, z, y, x, t) in float64; rank_at_start[s] = number of pillars before sample s
 __global__ __launch_bounds__(256) void vox_batch_assign(const uint32_t *__restrict__ keys, uint32_t *table, int64_t n, const int *chunk_offsets, VoxGeom g,
-                                                        uint32_t cells, VoxBatch b, double *__restrict__ coords, int *__restrict__ rank_at_start)
+                                                        uint32_t cells, VoxBatch b, double *__restrict__ coords, int *__restrict__ rank_at_start,
+                                                        const unsigned long long *__restrict__ first_bits)
 {
     __shared__ int lds[4];
     const int64_t base = (int64_t)blockIdx.x * PCACC_CHUNK;
     int carry = chunk_offsets[blockIdx.x];
     for (int r = 0; r < PCACC_CHUNK_ROWS; ++r) {
         const int64_t i = base + r * 256 + threadIdx.x;
-        uint32_t key;
-        const int f = vox_is_first(keys, table, i, n, &key);
+        // the first-touch flags of this wave's 64 points: one word written by vox_count (same value in every lane: a scalar load)
+        const int f = i < n ? (int)((first_bits[i >> 6] >> (i & 63)) & 1ull) : 0;
         int tot;
         const int rank = carry + block256_exclusive_scan(f, lds, &tot);
         carry += tot;
@@ -230,6 +236,7 @@ __global__ __launch_bounds__(256) void vox_batch_assign(const uint32_t *__restri
                 if (k < b.n_samples && i == b.start[k]) rank_at_start[k] = rank;      // pillars of the samples before this one
         }
         if (f) {
+            const uint32_t key = keys[i];
             const uint32_t s = key / cells;
             uint32_t q = key - s * cells;
             const int t = q % g.nt; q /= g.nt;
@@ -267,7 +274,8 @@ extern "C" int pcacc_collate_voxelize_workspace_bytes(int64_t n, int32_t n_sampl
 {
     if (!bytes || n < 0 || n_samples < 1 || n_samples > VOX_MAX_SAMPLES || nx <= 0 || ny <= 0 || nz <= 0 || nt <= 0) return PCACC_E_ARG;
     const size_t cells = (size_t)nx * ny * nz * nt * n_samples;
-    *bytes = pcacc_align(cells * 4) + pcacc_align((size_t)n * 4) + pcacc_align((size_t)(pcacc_chunks(n) + 1) * 4) + pcacc_align((VOX_MAX_SAMPLES + 1) * 4);
+    *bytes = pcacc_align(cells * 4) + pcacc_align((size_t)n * 4) + pcacc_align((size_t)(pcacc_chunks(n) + 1) * 4) + pcacc_align((VOX_MAX_SAMPLES + 1) * 4) +
+             pcacc_align(((size_t)n / 64 + 1) * 8);
     return PCACC_OK;
 }
 
@@ -312,14 +320,16 @@ extern "C" int pcacc_collate_voxelize(const double *const *points, const int64_t
     int *sums = reinterpret_cast<int *>(ws + pcacc_align(cells * 4) + pcacc_align((size_t)n * 4));
     int *rank_at_start = reinterpret_cast<int *>(ws + pcacc_align(cells * 4) + pcacc_align((size_t)n * 4) + pcacc_align((size_t)(pcacc_chunks(n) + 1) * 4));
     int *total = rank_at_start + VOX_MAX_SAMPLES;
+    unsigned long long *first_bits = reinterpret_cast<unsigned long long *>(ws + pcacc_align(cells * 4) + pcacc_align((size_t)n * 4) +
+                                                                           pcacc_align((size_t)(pcacc_chunks(n) + 1) * 4) + pcacc_align((VOX_MAX_SAMPLES + 1) * 4));
     VoxGeom g{range[0], range[1], range[2], voxel_size[0], voxel_size[1], voxel_size[2], nx, ny, nz, nt};
     if (hipMemsetAsync(table, 0xFF, cells * 4, st) != hipSuccess) return PCACC_E_LAUNCH;
     const int chunks = pcacc_chunks(n);
     vox_batch_keys<<<pcacc_grid(n, 256), 256, 0, st>>>(b, n, g, (uint32_t)cells1, points_out, time_out, sd ? sd_out : nullptr, inst ? inst_out : nullptr,
                                                         fb ? fb_out : nullptr, keys, table);
-    vox_count<<<chunks, 256, 0, st>>>(keys, table, n, sums);
+    vox_count<<<chunks, 256, 0, st>>>(keys, table, n, sums, first_bits);
     scan_chunk_sums<<<1, 1024, 0, st>>>(sums, chunks, total, -1);
-    vox_batch_assign<<<chunks, 256, 0, st>>>(keys, table, n, sums, g, (uint32_t)cells1, b, coords_out, rank_at_start);
+    vox_batch_assign<<<chunks, 256, 0, st>>>(keys, table, n, sums, g, (uint32_t)cells1, b, coords_out, rank_at_start, first_bits);
     vox_batch_p2v<<<pcacc_grid(n, 256), 256, 0, st>>>(keys, table, n, b, rank_at_start, p2v_out);
     vox_batch_counts<<<1, 64, 0, st>>>(rank_at_start, total, n_samples, num_voxels);
     PCACC_CHECK_LAUNCH();
