@@ -99,6 +99,15 @@ int pcacc_frame_pillars(const int32_t *cell2pillar, int64_t n_cells, int64_t cel
                         int32_t *sorted_pillars, int32_t *frame_offsets,
                         void *workspace, size_t workspace_bytes, void *stream);
 
+/* Indices of the non-zero entries of a byte mask, ascending: the boolean-mask indexing of models/motionnet.py:222-243 (`points[fb_mask]`,
+ * `inst_labels[rec_mask]`) and models/egomotion.py:419-424 (background pillars), as ONE index list the caller gathers with -- the reference
+ * re-evaluates the mask at every indexed tensor.  Wave ballot + popcount per 2048-entry chunk, a one-workgroup scan of the chunk sums, ranks by
+ * ballot prefix inside a wave ([r5]: replaces three torch.nonzero_static calls = 0.3 ms of library select kernels behind the forward's host sync).
+ *   mask [n] u8 (torch.bool); indices [capacity] i64: the first min(count, capacity) entries are written; count_out [1] i32 may be NULL */
+int pcacc_compact_mask_workspace_bytes(int64_t n, size_t *bytes /*host*/);
+int pcacc_compact_mask(const uint8_t *mask, int64_t n, int64_t *indices, int64_t capacity, int32_t *count_out,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Point -> pillar CSR (points grouped by pillar, ascending point index inside a pillar for
  * pillars of <= 64 points).  Internal layout shared by every per-pillar reduction below; it is what

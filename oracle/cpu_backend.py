@@ -284,7 +284,12 @@ NAMES = ['voxelize', 'cell_index', 'frame_pillars', 'csr_build', 'segment_mean3_
          'bilinear_gather_backward', 'bev_warp', 'rigid_transform', 'chamfer_forward', 'chamfer_backward',
          'rows_linear', 'rows_wgrad', 'rows_linear_supported', 'pfn_features', 'scatter_sum_small', 'sinkhorn_kabsch', 'cluster', 'sample_subsets', 'upload_small', 'bilinear_gather_backward_sorted', 'prep_points', 'sinkhorn_forward', 'sinkhorn_backward',
          'seg_loss_forward', 'seg_loss_backward', 'offset_loss_forward', 'offset_loss_backward', 'frames_max', 'frames_max_backward', 'svd3', 'svd3_backward',
-         'tube_rows', 'tube_code', 'tube_code_backward', 'tube_pose_forward', 'tube_gap_forward', 'tube_finish', 'tube_gap_backward', 'tube_pose_backward', 'inv4x4']
+         'tube_rows', 'tube_code', 'tube_code_backward', 'tube_pose_forward', 'tube_gap_forward', 'tube_finish', 'tube_gap_backward', 'tube_pose_backward', 'inv4x4', 'compact_mask']
+
+
+def compact_mask(mask, size):
+    """Indices of the non-zero entries, ascending (include/pcacc.h: pcacc_compact_mask)."""
+    return torch.nonzero_static(mask, size=int(size))[:, 0]
 
 
 def install(monkeypatch=None):

@@ -84,6 +84,80 @@ __global__ __launch_bounds__(256) void fp_assign(const int32_t *__restrict__ c2p
     }
 }
 
+// ---- indices of the non-zero entries of a byte mask (include/pcacc.h: pcacc_compact_mask) ---------------------------------------------------
+// 16 mask bytes per lane and load (one uint4): a 2048-entry chunk is half a wave-load; workgroups of 256 threads take 4096 entries = 2 chunks
+// of the scan helpers' size -- here a chunk is 4096 entries (own constants: the helpers of scan.h walk 4-byte items).
+#define CM_CHUNK 4096
+__device__ __forceinline__ uint32_t cm_nonzero_bits(const uint8_t *mask, int64_t i0, int64_t n)      // bit b = mask[i0 + b] != 0, 16 entries
+{
+    uint32_t bits = 0;
+    if (i0 + 16 <= n) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(mask + i0);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bits |= ((w[k] >> (8 * b)) & 0xffu) ? (1u << (4 * k + b)) : 0u;
+    } else {
+        for (int b = 0; b < 16 && i0 + b < n; ++b) bits |= mask[i0 + b] ? (1u << b) : 0u;
+    }
+    return bits;
+}
+
+__global__ __launch_bounds__(256) void cm_count(const uint8_t *__restrict__ mask, int64_t n, int *chunk_sums)
+{
+    __shared__ int lds[4];
+    const int64_t i0 = (int64_t)blockIdx.x * CM_CHUNK + threadIdx.x * 16;
+    int acc = i0 < n ? __popc(cm_nonzero_bits(mask, i0, n)) : 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if (lane_id() == 0) lds[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_sums[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+}
+
+__global__ __launch_bounds__(256) void cm_assign(const uint8_t *__restrict__ mask, int64_t n, const int *__restrict__ chunk_offsets,
+                                                 int64_t *__restrict__ indices, int64_t capacity)
+{
+    __shared__ int lds[4];
+    const int64_t i0 = (int64_t)blockIdx.x * CM_CHUNK + threadIdx.x * 16;
+    const uint32_t bits = i0 < n ? cm_nonzero_bits(mask, i0, n) : 0u;
+    int tot;
+    int64_t rank = chunk_offsets[blockIdx.x] + block256_exclusive_scan(__popc(bits), lds, &tot);
+    uint32_t b = bits;
+    while (b) {
+        const int k = __ffs(b) - 1;
+        b &= b - 1;
+        if (rank < capacity) indices[rank] = i0 + k;
+        ++rank;
+    }
+}
+
+extern "C" int pcacc_compact_mask_workspace_bytes(int64_t n, size_t *bytes)
+{
+    if (!bytes || n < 0) return PCACC_E_ARG;
+    *bytes = pcacc_align((size_t)((n + CM_CHUNK - 1) / CM_CHUNK + 1) * 4);
+    return PCACC_OK;
+}
+
+extern "C" int pcacc_compact_mask(const uint8_t *mask, int64_t n, int64_t *indices, int64_t capacity, int32_t *count_out, void *workspace,
+                                  size_t workspace_bytes, void *stream)
+{
+    size_t need;
+    if (pcacc_compact_mask_workspace_bytes(n, &need) != PCACC_OK || capacity < 0 || n >= 0x7fffffffLL * 16) return PCACC_E_ARG;
+    if (n == 0) return PCACC_OK;
+    if (!mask || (capacity > 0 && !indices) || (reinterpret_cast<uintptr_t>(mask) % 16)) return PCACC_E_ARG;
+    if (!workspace || workspace_bytes < need) return PCACC_E_WORKSPACE;
+    hipStream_t s = pcacc_stream(stream);
+    int *sums = static_cast<int *>(workspace);
+    const int chunks = (int)((n + CM_CHUNK - 1) / CM_CHUNK);
+    cm_count<<<chunks, 256, 0, s>>>(mask, n, sums);
+    scan_chunk_sums<<<1, 1024, 0, s>>>(sums, chunks, count_out, -1);
+    cm_assign<<<chunks, 256, 0, s>>>(mask, n, sums, indices, capacity);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}
+
 extern "C" int pcacc_frame_pillars_workspace_bytes(int64_t n_cells, size_t *bytes)
 {
     if (!bytes || n_cells < 0) return PCACC_E_ARG;

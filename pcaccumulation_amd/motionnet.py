@@ -283,8 +283,9 @@ class MotionNet(nn.Module):
         n_fb, n_rec = int(sizes[2 * nf]), int(sizes[2 * nf + 1])
         if pad_flags is not None:
             pad_flags = torch.tensor(sizes[2 * nf + 2:], dtype=torch.bool).view(2, -1)
-        bg_sorted_idx = torch.nonzero_static(bg_flag_sorted, size=bg_at[-1])[:, 0]
-        fb_idx = torch.nonzero_static(fb_mask, size=n_fb)[:, 0]
+        # boolean-mask indexing as one index list per mask (wave ballot / prefix-sum compaction: native.compact_mask; the counts came with the host sync)
+        bg_sorted_idx = native.compact_mask(bg_flag_sorted, bg_at[-1])
+        fb_idx = native.compact_mask(fb_mask, n_fb)
         results['_fb_idx'], results['_cell'] = fb_idx, pidx.cell
         if self.mode in ['train', 'val']:
             # FuseLoss.get_mos_loss supervises GT-or-estimated foreground in EVERY mode (libs/loss.py:145-147): only in train / val is
@@ -348,7 +349,7 @@ class MotionNet(nn.Module):
                 rec_mask = inst_labels != 0
                 n_rec = int(rec_mask.sum())                   # the one extra host sync of test mode
             if n_rec > MIN_POINTS:
-                rec_idx = torch.nonzero_static(rec_mask, size=n_rec)[:, 0]
+                rec_idx = native.compact_mask(rec_mask, n_rec)
                 results['_rec_idx'] = rec_idx
                 if self.mode in ['train', 'val']:
                     results['_gtfg_idx'] = rec_idx            # = nonzero(fb_labels == 1), what FuseLoss.get_offset_loss supervises (libs/loss.py:199)

@@ -40,7 +40,7 @@ def lib():
 # every symbol include/pcacc.h declares (tests check the .so exports exactly these)
 EXPORTS = [
     'pcacc_reload_switches', 'pcacc_cat2_rows', 'pcacc_collate_voxelize_workspace_bytes', 'pcacc_collate_voxelize', 'pcacc_rows_linear_split_dual', 'pcacc_rows_linear_few_dual', 'pcacc_pfn_block_split_forward_dual', 'pcacc_pool_skip_relu_backward_strided_y32', 'pcacc_conv3x3_split_dual', 'pcacc_conv3x3_split_cat', 'pcacc_upconv2x2_split_dual', 'pcacc_voxelize_workspace_bytes', 'pcacc_voxelize', 'pcacc_cell_index',
-    'pcacc_frame_pillars_workspace_bytes', 'pcacc_frame_pillars',
+    'pcacc_frame_pillars_workspace_bytes', 'pcacc_frame_pillars', 'pcacc_compact_mask_workspace_bytes', 'pcacc_compact_mask',
     'pcacc_csr_workspace_bytes', 'pcacc_csr_build', 'pcacc_segment_mean3_maxlabel',
     'pcacc_segment_workspace_bytes', 'pcacc_segment_max', 'pcacc_segment_max_backward', 'pcacc_segment_sum', 'pcacc_scatter_sum_small',
     'pcacc_pfn_features', 'pcacc_rows_linear', 'pcacc_rows_wgrad', 'pcacc_pillar_scatter', 'pcacc_gather_rows',
@@ -217,6 +217,23 @@ def frame_pillars(cell2pillar, cells_per_frame, m):
                                      _dev(sorted_p), _dev(offs), _dev(ws), ctypes.c_size_t(ws.numel()), _stream()),
            'frame_pillars')
     return sorted_p, offs
+
+
+def compact_mask(mask, size):
+    """mask [n] bool / uint8 (contiguous) -> [size] int64: the indices of its non-zero entries, ascending (torch.nonzero_static(mask, size=size)[:, 0] for a
+    `size` that equals the number of non-zeros -- the forward knows it from its host sync; entries beyond the count are left unwritten)."""
+    if mask.dtype not in (torch.bool, torch.uint8) or mask.dim() != 1:
+        raise NativeError('compact_mask: a 1-D bool / uint8 mask expected, got %s %s' % (mask.dtype, tuple(mask.shape)))
+    n, dev = mask.shape[0], mask.device
+    out = torch.empty((int(size),), dtype=torch.int64, device=dev)
+    if n == 0 or size == 0:
+        return out
+    need = ctypes.c_size_t(0)
+    _check(lib().pcacc_compact_mask_workspace_bytes(_i64(n), ctypes.byref(need)), 'compact_mask_workspace')
+    ws = _ws(need.value, dev)
+    _check(lib().pcacc_compact_mask(_dev(mask, None, 'mask'), _i64(n), _dev(out), _i64(size), None, _dev(ws), ctypes.c_size_t(ws.numel()), _stream()),
+           'compact_mask')
+    return out
 
 
 def csr_build(p2v, m):

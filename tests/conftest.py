@@ -43,8 +43,30 @@ def _fp32_point_rows():
 
 
 def pytest_collection_modifyitems(config, items):
-    """Tests that start process trees (bench.py under the launcher, subprocess benches) run LAST: `pytest -x` then reaches every parity test before
-    the first process tree is started, and a launch that misbehaves cannot take the parity evidence with it (round 4: one hanging launch collected
-    first zeroed the GPU suite).  Stable for everything else."""
+    """Collection order = blast radius under `pytest -x`.  Kernel-level parity tests first (deterministic or tightly bounded); then the whole-model
+    tests, whose bounds sit a small factor above run-to-run effects of atomic summation order (one observed failure of
+    test_gpu_config_fp32[fp32-c3_lidar] in ~20 runs of it during round 5, not reproduced in 15 repeats: DESIGN.md section 19) -- a rare miss there must not
+    hide four hundred kernel tests behind it; LAST the tests that start process trees (bench.py under the launcher): a launch that misbehaves cannot
+    take the parity evidence with it (round 4: one hanging launch collected first zeroed the GPU suite).  Stable inside each group."""
+    whole_model = ('test_config_parity.py', 'test_model_parity.py', 'test_train_trajectory.py')
     last = ('test_bench_multirank.py',)
-    items.sort(key=lambda it: 1 if os.path.basename(str(it.fspath)) in last else 0)
+
+    def group(it):
+        name = os.path.basename(str(it.fspath))
+        return 2 if name in last else (1 if name in whole_model else 0)
+    items.sort(key=group)
+
+
+@pytest.hookimpl(hookwrapper=True)
+def pytest_runtest_makereport(item, call):
+    """Every failing test's full report is also appended to gpurun_out/test_failures.txt (merged back from the GPU box): a failure that shows up once in
+    a few hundred tests and not again leaves its assertion message behind instead of one line of `-q` output."""
+    outcome = yield
+    rep = outcome.get_result()
+    if rep.when == 'call' and rep.failed:
+        try:
+            os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+            with open(os.path.join(ROOT, 'gpurun_out', 'test_failures.txt'), 'a') as f:
+                f.write('==== %s\n%s\n' % (item.nodeid, rep.longreprtext))
+        except OSError:
+            pass

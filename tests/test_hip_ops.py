@@ -1259,3 +1259,26 @@ def test_pfn_block_fused_matches_row_layers(rows, pooled):
         assert a.shape == b.shape
         tol = 3e-2 * float(b.abs().max()) + 1e-6
         assert float((a - b).abs().max()) <= tol, (tuple(a.shape), float((a - b).abs().max()), float(b.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,p', [(1, 1.0), (15, 0.5), (16, 0.0), (4096, 0.3), (4097, 0.9), (3_200_003, 0.1), (1_169_433, 0.7), (70_000, 1.0)])
+def test_compact_mask_is_nonzero_static(n, p):
+    """pcacc_compact_mask (ballot / popcount per chunk, one-workgroup scan, ranks inside a wave) == torch.nonzero_static on bool masks: lengths that are / are
+    not multiples of the 16-byte loads and of the 4096-entry chunks, empty, full and sparse masks, a capacity below the count (truncation, nothing written
+    beyond it), and the reported count."""
+    import torch
+    from pcaccumulation_amd import native
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(n)
+    mask = (torch.rand(n, generator=g) < p).to(dev)
+    want = torch.nonzero(mask)[:, 0]
+    got = native.compact_mask(mask, want.numel())
+    assert got.dtype == torch.int64 and torch.equal(got, want)
+    assert torch.equal(native.compact_mask(mask.to(torch.uint8), want.numel()), want)
+    if want.numel() > 3:
+        k = want.numel() // 2
+        buf = native.compact_mask(mask, k)
+        assert torch.equal(buf, want[:k])
+    with pytest.raises(native.NativeError):
+        native.compact_mask(mask.float(), 1)
