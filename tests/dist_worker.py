@@ -190,6 +190,31 @@ def motionnet(rank, world, out):
                 'n_buckets': len(step.reducer.buckets), 'n_early': step.reducer._n_early, 'seq': list(step.reducer._seq)}, out)
 
 
+def forced(rank, world, out):
+    """World size 1 with PCACC_FORCE_PROCESS_GROUP=1 (set by the test): a process group exists, the reducer is ACTIVE -- gradients travel through the flat
+    buffer and every bucket through all_reduce -- and the result is the plain single-process gradient; without the switch one rank reduces nothing."""
+    from pcaccumulation_amd import distributed as pdist
+    assert world == 1 and torch.distributed.is_initialized()
+    torch.manual_seed(0)
+    net = Net()
+    red = pdist.BucketedGradReducer(net.parameters(), bucket_bytes=64 * 1024)
+    assert red.active and red.world == 1 and red.flat.numel() == red.numel
+    red.zero()
+    loss = net(toy_input(0, 0), use_b=True)
+    red.prepare(loss, sync=True)
+    loss.backward()
+    red.finish()
+    flag = red.agree(True)
+    res = {'grads': {k: (p.grad.clone() if p.grad is not None else None) for k, p in net.named_parameters()}, 'collectives': red.collectives,
+           'n_buckets': len(red.buckets), 'flag': int(flag.item()), 'views': all(p.grad is None or p.grad.data_ptr() == v.data_ptr() for p, v in zip(red.params, red.views))}
+    with red.sparse_grads():
+        res['none_inside'] = [k for k, p in net.named_parameters() if p.grad is None]
+    os.environ.pop('PCACC_FORCE_PROCESS_GROUP')
+    plain = pdist.BucketedGradReducer(Net().parameters())
+    res['plain_active'] = plain.active
+    torch.save(res, out)
+
+
 def main():
     mode, rank, world, port, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=port)
@@ -197,7 +222,7 @@ def main():
     from pcaccumulation_amd import distributed as pdist
     r, w, _ = pdist.init_from_env(backend='gloo')
     assert (r, w) == (rank, world)
-    {'toy': toy, 'motionnet': motionnet, 'branchy': branchy}[mode](rank, world, out)
+    {'toy': toy, 'motionnet': motionnet, 'branchy': branchy, 'forced': forced}[mode](rank, world, out)
     pdist.barrier()
     torch.distributed.destroy_process_group()
 

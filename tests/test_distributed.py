@@ -155,3 +155,23 @@ def test_four_gloo_ranks_with_rank_dependent_branches(tmp_path):
         assert got[rank]['skipped'] == 0 and got[rank]['n_buckets'] >= 4
         for k, p in net.named_parameters():
             assert torch.allclose(got[rank]['params'][k], p.detach(), atol=1e-6), (rank, k)
+
+
+def test_forced_process_group_at_world_size_one(tmp_path, monkeypatch):
+    """The code path of tests/test_bench_multirank.py::test_one_rccl_rank_runs_the_production_step on CPU: one gloo rank with
+    PCACC_FORCE_PROCESS_GROUP=1 initialises a process group (distributed.init_from_env), the reducer goes through its flat buffer and issues one
+    all_reduce per bucket plus the agreement reduce, `.grad` become views of the flat buffer, and the gradient is the single-process gradient."""
+    sys.path.insert(0, HERE)
+    from dist_worker import Net, toy_input
+    monkeypatch.setenv('PCACC_FORCE_PROCESS_GROUP', '1')
+    got = _launch('forced', tmp_path, 120, world=1)[0]
+    torch.manual_seed(0)
+    net = Net()
+    net(toy_input(0, 0), use_b=True).backward()
+    assert got['n_buckets'] >= 3 and got['collectives'] == got['n_buckets'] + 1 and got['flag'] == 1 and got['views']
+    assert got['none_inside'] == ['c.weight', 'c.bias'] and got['plain_active'] is False
+    for k, p in net.named_parameters():
+        if p.grad is None:
+            assert float(got['grads'][k].abs().sum()) == 0.0          # outside sparse_grads() an untouched parameter shows its zeroed view
+        else:
+            assert torch.allclose(got['grads'][k], p.grad, atol=1e-6), k

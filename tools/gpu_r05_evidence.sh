@@ -2,14 +2,14 @@
 # round 5 evidence on the current tree: probe; default bench as the driver runs it; the same command under rocprofv3 --kernel-trace --stats; steady-state
 # kernel summaries (mixed, bf16); counter passes for the pillar-scatter kernels and the kernel set; per-config table
 mkdir -p gpurun_out
-bash tools/gpu_r05_probe.sh
+# (probe: run by the caller)
 bash tools/gpu_default_bench.sh; cp gpurun_out/bench_default_full.json gpurun_out/r05_bench_default_full.json
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_default -o bench -- python3 $R/bench.py --no-cpu-baseline --no-configs > $R/gpurun_out/rocprof_default.log 2>&1
 cp $R/gpurun_out/prof_default/bench_kernel_stats.csv $R/gpurun_out/r05_default_kernel_stats.csv
 grep -n "pillar_scatter" $R/gpurun_out/prof_default/bench_kernel_stats.csv | cut -c1-220
-tail -1 $R/gpurun_out/rocprof_default.log | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('under rocprofv3:', round(d['ms_per_step'],2), 'scatter avg us', d['roofline']['avg_launch_us'], 'frac', d['roofline']['frac'])"
+grep "^{" $R/gpurun_out/rocprof_default.log | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('under rocprofv3:', round(d['ms_per_step'],2), 'scatter avg us', d['roofline']['avg_launch_us'], 'frac', d['roofline']['frac'])"
 for d in mixed bf16; do
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$d -o bench -- python3 $R/bench.py --dtype $d --steps 5 --warmup 5 --no-cpu-baseline --no-configs --no-fp32-leg --no-step-model --one-stream > $R/gpurun_out/rocprof_$d.log 2>&1
 python3 $R/tools/kstats_steady.py $R/gpurun_out/prof_$d/bench_kernel_trace.csv 6 200 > $R/gpurun_out/r05_${d}_steady.txt; head -9 $R/gpurun_out/r05_${d}_steady.txt | cut -c1-190
