@@ -516,7 +516,7 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float 
 #endif
 #define CSR_WPT 9                               // 16-byte weight pieces a thread carries for the next slice (9 taps x 64 rows x 32 ch x 2 planes / 512)
 
-template <int CS, int NW, int MT, int PCH, bool RESTAGE>
+template <int CS, int NW, int MT, int PCH, bool RESTAGE, bool MASKED>          // MASKED: in_mask != NULL (a compile-time fact: a run-time branch behind the loads made the compiler copy -- and so wait for -- every loaded register at once)
 __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_res_kernel(const float *__restrict__ in, const float *__restrict__ in_amax,
                                                                         const float *__restrict__ in_mask, const uint16_t *__restrict__ wp,
                                                                         const float *__restrict__ wscale, const float *__restrict__ bias,
@@ -535,6 +535,10 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_res_kernel(const fl
     const int plane = pp * PS;
     uint16_t *patch = lds;                                     // [2 = hi, lo][pp][PS]
     uint16_t *wl = lds + 2 * (size_t)plane;                    // [2 = hi, lo][9][WROWS][PS]
+    // [r5] per-channel scale (weight scale / input scale) and bias of this workgroup's WROWS output channels, staged ONCE: the epilogue read them from global
+    // memory for every (tile, channel group) and each of those loads was followed by s_waitcnt vmcnt(0) -- which also waits for every store issued before
+    // it (loads and stores retire in order on one counter): 16 memory round trips per pass in series, and the stores never overlapped anything
+    float *sb = reinterpret_cast<float *>(wl + 2 * WPL);       // [2][WROWS]: scale, bias
 
     const int cog = blockIdx.x % co_groups, slot = blockIdx.x / co_groups;
     const int co0 = cog * WROWS;
@@ -545,6 +549,10 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_res_kernel(const fl
     const int tiles_img = tiles_y * tiles_x, n_tiles = n_img * tiles_img;
     const float sx = csp_scale_from_parts(in_amax);
     const float inv_sx = 1.f / sx;
+    if ((int)threadIdx.x < WROWS) {                            // published by the first pass's barriers
+        sb[threadIdx.x] = wscale[blockIdx.x % co_groups * WROWS + threadIdx.x] * inv_sx;
+        sb[WROWS + threadIdx.x] = (bias && relu != CSP_OUTMASK) ? bias[blockIdx.x % co_groups * WROWS + threadIdx.x] : 0.f;
+    }
 
     // slices of a tile that exist: frame taps f_lo .. f_hi (a missing frame contributes zeros), all channel slices of each
     // (tile coordinates come from the walker, frame tap f and channel slice cs of a slice s = f * nc + cs are carried along: no divisions per pass)
@@ -557,6 +565,7 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_res_kernel(const fl
     const int n_chunks = pp * C8;
     int pinfo[PCH];                                            // PCH: patch chunks a thread carries (3 .. 6 by configuration: registers)
     float4 preg[PCH][2];
+    int pok = 0;                                               // bit q: chunk q of preg lies inside the image
 #pragma unroll
     for (int q = 0; q < PCH; ++q) {
         const int c = threadIdx.x + q * CSP_THREADS;
@@ -572,22 +581,34 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_res_kernel(const fl
             if (ch0p >= c_a) { src = in2; pitch = c_in - c_a; ch0p -= c_a; } else pitch = c_a;
         }
         const int64_t img_off = (int64_t)(img + (kt == 3 ? f - 1 : 0)) * h * w * pitch;
+        // [r5] ALL loads of the pass are issued before anything reads a loaded value: the "inside the image" select moved to write_patch (one pass later, pok
+        // carries the flags).  As first written every chunk's two loads were followed by their selects -- and the uniform branches between the chunks kept the
+        // compiler from hoisting the loads over them: issue 2 loads, s_waitcnt vmcnt(0), five times per pass, each a full memory round trip in series
+        // (the ISA of the round-4 kernel; it is what the "loads + staging" phase of the knock-out measurements was made of).
+        int64_t offs[PCH];
+        int okb = 0;
 #pragma unroll
         for (int q = 0; q < PCH; ++q) {
             const int py = pinfo[q] >> 20, pxx = (pinfo[q] >> 8) & 0xfff, c8 = pinfo[q] & 0xff;
             const int y = y0 - 1 + py, x = x0 - 1 + pxx;
             const bool ok = (unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w;
             const int yc = min(max(y, 0), h - 1), xc = min(max(x, 0), w - 1);
-            const int64_t off = img_off + ((int64_t)yc * w + xc) * pitch + ch0p + c8 * 8;
-            float4 a = csp_load_in4(src + off), b = csp_load_in4(src + off + 4);
-            if (in_mask) {                                     // uniform
-                a = csp_relu_mask4(a, *reinterpret_cast<const float4 *>(in_mask + off));
-                b = csp_relu_mask4(b, *reinterpret_cast<const float4 *>(in_mask + off + 4));
-            }
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            preg[q][0] = ok ? a : z;
-            preg[q][1] = ok ? b : z;
+            offs[q] = img_off + ((int64_t)yc * w + xc) * pitch + ch0p + c8 * 8;
+            okb |= ok ? (1 << q) : 0;
         }
+#pragma unroll
+        for (int q = 0; q < PCH; ++q) {
+            preg[q][0] = csp_load_in4(src + offs[q]);
+            preg[q][1] = csp_load_in4(src + offs[q] + 4);
+        }
+        if constexpr (MASKED) {                                // the masked data gradient of the fp32x3 backward (not on the mixed mode's path)
+#pragma unroll
+            for (int q = 0; q < PCH; ++q) {
+                preg[q][0] = csp_relu_mask4(preg[q][0], *reinterpret_cast<const float4 *>(in_mask + offs[q]));
+                preg[q][1] = csp_relu_mask4(preg[q][1], *reinterpret_cast<const float4 *>(in_mask + offs[q] + 4));
+            }
+        }
+        pok = okb;
     };
     auto write_patch = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -595,7 +616,9 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_res_kernel(const fl
             const int c = threadIdx.x + q * CSP_THREADS;
             if (c < n_chunks) {
                 uint4 hi, lo;
-                csp_split8(preg[q][0], preg[q][1], sx, hi, lo);
+                const bool ok = (pok >> q) & 1;                  // outside the image: zeros (the load came from a clamped position)
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                csp_split8(ok ? preg[q][0] : z, ok ? preg[q][1] : z, sx, hi, lo);
                 uint16_t *dst = patch + (c / C8) * PS + (c % C8) * 8;
                 *reinterpret_cast<uint4 *>(dst) = hi;
                 *reinterpret_cast<uint4 *>(dst + plane) = lo;
@@ -746,10 +769,8 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_res_kernel(const fl
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int c = n * 32 + 8 * g + 4 * lh;
-                        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (bias && relu != CSP_OUTMASK) bv = *reinterpret_cast<const float4 *>(bias + co0 + c);
-                        float4 sc = *reinterpret_cast<const float4 *>(wscale + co0 + c);
-                        sc = make_float4(sc.x * inv_sx, sc.y * inv_sx, sc.z * inv_sx, sc.w * inv_sx);
+                        const float4 bv = *reinterpret_cast<const float4 *>(sb + WROWS + c);
+                        const float4 sc = *reinterpret_cast<const float4 *>(sb + c);
                         float4 v = make_float4(acc[j][n][4 * g] * sc.x + bv.x, acc[j][n][4 * g + 1] * sc.y + bv.y, acc[j][n][4 * g + 2] * sc.z + bv.z,
                                                acc[j][n][4 * g + 3] * sc.w + bv.w);
                         if (relu == CSP_OUTMASK) {
@@ -798,7 +819,7 @@ static bool conv_res_fits(int cs, int nw, int mt, int rows, int bw, size_t *lds)
 {
     const int64_t pp = (int64_t)(rows + 2) * (bw + 2);
     const int wrows = 32 * nw, pch = conv_res_pch(cs, nw, mt);
-    *lds = (size_t)(2 * pp + 2 * 9 * wrows) * (cs + 8) * sizeof(uint16_t);
+    *lds = (size_t)(2 * pp + 2 * 9 * wrows) * (cs + 8) * sizeof(uint16_t) + 2 * wrows * sizeof(float);     // + scale / bias of the workgroup's channels
     return pch > 0 && pp * (cs / 8) <= CSP_THREADS * pch && *lds <= CSP_LDS_MAX && 2 * 9 * wrows * (cs / 8) <= CSP_THREADS * CSR_WPT &&
            rows + 2 < 0x7ff && bw + 2 < 0xfff;
 }
@@ -855,7 +876,7 @@ static int conv_res_launch(const ConvResPlan &p, const float *in, const float *i
                            const float *wscale, const float *bias, float *out, float *out_amax, uint16_t *out16, int n_img, int frames, int h, int w,
                            int c_in, int c_out, int kt, int relu, hipStream_t st, const float *in2 = nullptr, int c_a = 0)
 {
-    auto kern = conv3x3_split_res_kernel<CS, NW, MT, PCH, RESTAGE>;
+    auto kern = in_mask ? conv3x3_split_res_kernel<CS, NW, MT, PCH, RESTAGE, true> : conv3x3_split_res_kernel<CS, NW, MT, PCH, RESTAGE, false>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds) != hipSuccess)
         return PCACC_E_LAUNCH;
     hipLaunchKernelGGL(kern, dim3((unsigned)(p.co_groups * p.slots)), dim3(CSP_THREADS), p.lds, st, in, in_amax, in_mask, wp, wscale, bias, out, out_amax,
