@@ -24,7 +24,7 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 #define CD_THREADS 512
 #define CD_PCH 10                              // patch pieces (16 B) a thread carries per channel slice
 
-template <int CS, int NG, int MT>
+template <int CS, int NG, int MT, bool MASKED>          // MASKED: in_mask != NULL as a compile-time fact (a run-time branch behind the loads makes the compiler copy -- and wait for -- every loaded register)
 __global__ __launch_bounds__(CD_THREADS) void conv3x3_strip_kernel(const uint16_t *__restrict__ in, const uint16_t *__restrict__ in_mask,
                                                                    const uint16_t *__restrict__ wp,
                                                                    const float *__restrict__ bias, uint16_t *__restrict__ out, int n_img,
@@ -84,25 +84,43 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_strip_kernel(const uint16_
         pinfo[q] = c < n_chunks ? (py << 20 | pxx << 8 | c8) : (0x7ff << 20);
     }
     const uint16_t *img_in = in + (int64_t)img * h * w * c_in;
+    int pok = 0;                                               // bit q: piece q of preg lies inside the image (else it is written to LDS as zeros)
+    // [r5] addresses first, then every load of the slice back to back, masking behind them, the zero select in write_patch (a slice later).  A select (and,
+    // with a mask, a branch) behind each load had made the fetch a chain of `global_load, s_waitcnt vmcnt(0)`: ten memory round trips in series per slice.
+    auto piece_off = [&](int q, int cs, bool *ok) __attribute__((always_inline)) {   // element offset of piece q inside the image (clamped: always valid)
+        const int py = pinfo[q] >> 20, pxx = (pinfo[q] >> 8) & 0xfff, c8 = pinfo[q] & 0xff;
+        const int y = y0 - 1 + py, x = pxx - 1;
+        *ok = (unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w;
+        return (min(max(y, 0), h - 1) * w + min(max(x, 0), w - 1)) * c_in + cs * CS + c8 * 8;      // h * w * c_in < 2^31: checked by the planner
+    };
     auto fetch_patch = [&](int cs) {
+        int okb = 0;
 #pragma unroll
-        for (int q = 0; q < CD_PCH; ++q) {
-            const int py = pinfo[q] >> 20, pxx = (pinfo[q] >> 8) & 0xfff, c8 = pinfo[q] & 0xff;
-            const int y = y0 - 1 + py, x = pxx - 1;
-            // always load (from a clamped position), then select: a load under a lane mask would cost a branch and an early wait
-            const bool ok = (unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w;
-            const int yc = min(max(y, 0), h - 1), xc = min(max(x, 0), w - 1);
-            const int64_t off = ((int64_t)yc * w + xc) * c_in + cs * CS + c8 * 8;
-            uint4 v = *reinterpret_cast<const uint4 *>(img_in + off);
-            if (in_mask) v = pcacc_relu_mask8(v, *reinterpret_cast<const uint4 *>(in_mask + (int64_t)img * h * w * c_in + off));   // uniform
-            preg[q] = ok ? v : make_uint4(0, 0, 0, 0);
+        for (int q = 0; q < CD_PCH; ++q) {                     // straight-line: no select, no branch between the loads
+            bool ok;
+            preg[q] = *reinterpret_cast<const uint4 *>(img_in + piece_off(q, cs, &ok));
+            okb |= ok ? (1 << q) : 0;
         }
+        if constexpr (MASKED) {                                // the ReLU backward of the layer whose gradient `in` is
+            const uint16_t *mk = in_mask + (int64_t)img * h * w * c_in;
+            constexpr int ROUNDS = MT >= 3 ? 5 : 2, HALF = CD_PCH / ROUNDS;   // rounds of mask loads: the registers for all ten at once are not there (three-tile waves: two at a time)
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r) {
+                uint4 m[HALF];
+                bool ok;
+#pragma unroll
+                for (int q = 0; q < HALF; ++q) m[q] = *reinterpret_cast<const uint4 *>(mk + piece_off(r * HALF + q, cs, &ok));
+#pragma unroll
+                for (int q = 0; q < HALF; ++q) preg[r * HALF + q] = pcacc_relu_mask8(preg[r * HALF + q], m[q]);
+            }
+        }
+        pok = okb;
     };
     auto write_patch = [&]() {
 #pragma unroll
         for (int q = 0; q < CD_PCH; ++q) {
             const int c = threadIdx.x + q * CD_THREADS;
-            if (c < n_chunks) *reinterpret_cast<uint4 *>(patch + (c / C8) * PS + (c % C8) * 8) = preg[q];
+            if (c < n_chunks) *reinterpret_cast<uint4 *>(patch + (c / C8) * PS + (c % C8) * 8) = (pok >> q) & 1 ? preg[q] : make_uint4(0, 0, 0, 0);
         }
     };
     // weight tile of (tap, slice): WROWS rows of CS elements = WROWS * C8 pieces, <= 2 per thread.  Tiles are requested TWO taps
@@ -189,8 +207,19 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_strip_kernel(const uint16_
 
     // epilogue: lane = pixel, register quad g of tile n = channels n*32 + 8g + 4*lh .. +3 of this wave's 64
     const float *bptr = bias ? bias + co0 + ng * 64 : nullptr;
+    // [r5] the wave's eight bias quads as ONE batch of loads (they were loaded, and waited for, one in front of every store): once for all tiles where the
+    // registers are there, once per tile in the three-tile waves
+    float4 bvs[2][4];
+    auto load_bias = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bvs[n][g] = bptr ? *reinterpret_cast<const float4 *>(bptr + n * 32 + 8 * g + 4 * lh) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    if (MT < 3) load_bias();
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
+        if (MT >= 3) load_bias();
         if (pyx[j] < 0) continue;
         uint16_t *dst = out + (((int64_t)img * h + (pyx[j] >> 16)) * w + (pyx[j] & 0xffff)) * c_out + co0 + ng * 64;
 #pragma unroll
@@ -198,8 +227,7 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_strip_kernel(const uint16_
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int c = n * 32 + 8 * g + 4 * lh;
-                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (bptr) bv = *reinterpret_cast<const float4 *>(bptr + c);
+                const float4 bv = bvs[n][g];
                 float v[4] = {acc[j][n][4 * g] + bv.x, acc[j][n][4 * g + 1] + bv.y, acc[j][n][4 * g + 2] + bv.z, acc[j][n][4 * g + 3] + bv.w};
                 if (relu) {
 #pragma unroll
@@ -225,7 +253,7 @@ static bool conv_strip_fits(int cs, int ng, int rows, int w, size_t *lds)
 
 static bool conv_strip_plan(int n_img, int h, int w, int c_in, int c_out, ConvStripPlan *best)
 {
-    if (c_in < 128 || c_in % 64 || c_out < 64 || c_out % 64 || h < 1 || w < 1) return false;
+    if (c_in < 128 || c_in % 64 || c_out < 64 || c_out % 64 || h < 1 || w < 1 || (int64_t)h * w * c_in >= 0x7fffffffLL) return false;   // the kernel's in-image offsets are 32-bit
     bool found = false;
     int64_t best_cost = 0, best_waste = 0;
     for (int ng = 2; ng >= 1; --ng) {
@@ -268,7 +296,7 @@ template <int CS, int NG, int MT>
 static int conv_strip_launch(const ConvStripPlan &p, const uint16_t *in, const uint16_t *in_mask, const uint16_t *wp, const float *bias,
                              uint16_t *out, int n_img, int h, int w, int c_in, int c_out, int relu, hipStream_t st)
 {
-    auto kern = conv3x3_strip_kernel<CS, NG, MT>;
+    auto kern = in_mask ? conv3x3_strip_kernel<CS, NG, MT, true> : conv3x3_strip_kernel<CS, NG, MT, false>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds) != hipSuccess)
         return PCACC_E_LAUNCH;
     if (p.blocks > 0x7fffffff) return PCACC_E_ARG;

@@ -253,7 +253,7 @@ __device__ __forceinline__ float4 csp_outmask4(float4 v, float4 m)
     return make_float4(m.x <= 0.f ? 0.f : v.x, m.y <= 0.f ? 0.f : v.y, m.z <= 0.f ? 0.f : v.z, m.w <= 0.f ? 0.f : v.w);
 }
 
-template <int CS, int NW, int NGW, int MT, int TAPS>
+template <int CS, int NW, int NGW, int MT, int TAPS, bool MASKED>        // MASKED: in_mask != NULL, a compile-time fact (see conv3x3_split_res_kernel)
 __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float *__restrict__ in, const float *__restrict__ in_amax,
                                                                     const float *__restrict__ in_mask, const uint16_t *__restrict__ wp,
                                                                     const float *__restrict__ wscale, const float *__restrict__ bias,
@@ -317,6 +317,7 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float 
     const int n_chunks = pp * C8;
     int pinfo[CSP_PCH];
     float4 preg[CSP_PCH][2];
+    int pok = 0;                                               // bit q: chunk q of preg lies inside the image
 #pragma unroll
     for (int q = 0; q < CSP_PCH; ++q) {
         const int c = threadIdx.x + q * CSP_THREADS;
@@ -336,25 +337,34 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float 
         const int64_t img_off = (int64_t)(img + (kt == 3 ? f - 1 : 0)) * h * w * pitch;
         // space-to-depth source (CSP_S2D): the slice's channels (a, b, ch ..) live in pixel (2y + a, 2x + b) of the [2h, 2w, c_up] map
         const int ab = mode == CSP_S2D ? (cs * CS) / c_up : 0, ch0 = mode == CSP_S2D ? (cs * CS) % c_up : 0;
+        // [r5] every load of the slice is issued before anything reads a loaded value; the "inside the image" select happens in write_patch, a slice later
+        // (pok carries the flags) -- see conv3x3_split_res_kernel: a select behind each pair of loads made the fetch a chain of memory round trips
+        int64_t offs[CSP_PCH];
+        int okb = 0;
 #pragma unroll
         for (int q = 0; q < CSP_PCH; ++q) {
             const int py = pinfo[q] >> 20, pxx = (pinfo[q] >> 8) & 0xfff, c8 = pinfo[q] & 0xff;
             const int y = y0 - 1 + py, x = x0 - 1 + pxx;
-            // always load (from a clamped position), then select: a load under a lane mask costs a branch and an early wait
             const bool ok = (unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w;
             const int yc = min(max(y, 0), h - 1), xc = min(max(x, 0), w - 1);
-            const int64_t off = mode == CSP_S2D
-                                    ? (((int64_t)img * 2 * h + 2 * yc + (ab >> 1)) * 2 * w + 2 * xc + (ab & 1)) * c_up + ch0 + c8 * 8
-                                    : img_off + ((int64_t)yc * w + xc) * pitch + ch0p + c8 * 8;
-            float4 a = csp_load_in4(src + off), b = csp_load_in4(src + off + 4);
-            if (in_mask) {                                     // uniform
-                a = csp_relu_mask4(a, *reinterpret_cast<const float4 *>(in_mask + off));
-                b = csp_relu_mask4(b, *reinterpret_cast<const float4 *>(in_mask + off + 4));
-            }
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            preg[q][0] = ok ? a : z;
-            preg[q][1] = ok ? b : z;
+            offs[q] = mode == CSP_S2D
+                          ? (((int64_t)img * 2 * h + 2 * yc + (ab >> 1)) * 2 * w + 2 * xc + (ab & 1)) * c_up + ch0 + c8 * 8
+                          : img_off + ((int64_t)yc * w + xc) * pitch + ch0p + c8 * 8;
+            okb |= ok ? (1 << q) : 0;
         }
+#pragma unroll
+        for (int q = 0; q < CSP_PCH; ++q) {
+            preg[q][0] = csp_load_in4(src + offs[q]);
+            preg[q][1] = csp_load_in4(src + offs[q] + 4);
+        }
+        if constexpr (MASKED) {
+#pragma unroll
+            for (int q = 0; q < CSP_PCH; ++q) {
+                preg[q][0] = csp_relu_mask4(preg[q][0], *reinterpret_cast<const float4 *>(in_mask + offs[q]));
+                preg[q][1] = csp_relu_mask4(preg[q][1], *reinterpret_cast<const float4 *>(in_mask + offs[q] + 4));
+            }
+        }
+        pok = okb;
     };
     auto write_patch = [&]() {
 #pragma unroll
@@ -362,7 +372,9 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float 
             const int c = threadIdx.x + q * CSP_THREADS;
             if (c < n_chunks) {
                 uint4 hi, lo;
-                csp_split8(preg[q][0], preg[q][1], sx, hi, lo);
+                const bool ok = (pok >> q) & 1;                  // outside the image: zeros (the load came from a clamped position)
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                csp_split8(ok ? preg[q][0] : z, ok ? preg[q][1] : z, sx, hi, lo);
                 uint16_t *dst = patch + (c / C8) * PS + (c % C8) * 8;
                 *reinterpret_cast<uint4 *>(dst) = hi;
                 *reinterpret_cast<uint4 *>(dst + plane) = lo;
@@ -955,7 +967,7 @@ static int conv_split_launch(const ConvSplitPlan &p, const float *in, const floa
                              int c_in, int c_out, int kt, int relu, hipStream_t st, int mode = CSP_PLAIN, int c_up = 0, int up_pitch = 0,
                              const float *in2 = nullptr, int c_a = 0)
 {
-    auto kern = conv3x3_split_kernel<CS, NW, NGW, MT, TAPS>;
+    auto kern = in_mask ? conv3x3_split_kernel<CS, NW, NGW, MT, TAPS, true> : conv3x3_split_kernel<CS, NW, NGW, MT, TAPS, false>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds) != hipSuccess)
         return PCACC_E_LAUNCH;
     if (p.blocks > 0x7fffffff) return PCACC_E_ARG;
