@@ -136,25 +136,53 @@ __global__ __launch_bounds__(MS_THREADS) void rows_linear_split_kernel(const flo
 
     const int64_t n_tiles = (rows + MS_TILE - 1) / MS_TILE;
     float4 xreg[X_PER_THREAD][2];
+    int xok = 0;                                                              // bit q: piece q of xreg is a real row of X
+    int64_t xbase = 0;                                                        // element offset of the fetched tile
     auto fetch = [&](int64_t tile) {
         const int64_t base = tile * MS_TILE * K;                              // element offset of the tile
         const int64_t limit = rows * K;
+        // [r5] every load of the tile is issued before anything reads a loaded value: rows past the end are read from row 0 and zeroed when the tile is staged
+        // (xok carries the flags), the optional ReLU / mask are applied there too -- a per-piece `if (e < limit) { load; relu; mask }` had made the fetch a chain
+        // of `global_load, s_waitcnt vmcnt(0)` (see conv3x3_split_res_kernel)
+        int okb = 0;
+        if (!xs2.b) {                                                         // one-piece rows (uniform): straight-line code, the loads go out back to back
 #pragma unroll
-        for (int q = 0; q < X_PER_THREAD; ++q) {
-            const int64_t e = base + (int64_t)(threadIdx.x + q * MS_THREADS) * 8;
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-            if (e < limit) {
-                const float *src = ms_piece(X, xs2, K, e / K, (int)(e % K));
-                a = *reinterpret_cast<const float4 *>(src);
-                b = *reinterpret_cast<const float4 *>(src + 4);
-                if (flags & MS_PRE_RELU) { a = ms_relu4(a); b = ms_relu4(b); }
-                if (in_mask) {
-                    a = ms_mask4(a, *reinterpret_cast<const float4 *>(in_mask + e));
-                    b = ms_mask4(b, *reinterpret_cast<const float4 *>(in_mask + e + 4));
-                }
+            for (int q = 0; q < X_PER_THREAD; ++q) {
+                const int64_t e = base + (int64_t)(threadIdx.x + q * MS_THREADS) * 8;
+                const bool ok = e < limit;
+                const float *src = X + (ok ? e : 0);
+                xreg[q][0] = *reinterpret_cast<const float4 *>(src);
+                xreg[q][1] = *reinterpret_cast<const float4 *>(src + 4);
+                okb |= ok ? (1 << q) : 0;
             }
-            xreg[q][0] = a;
-            xreg[q][1] = b;
+        } else {                                                              // two-piece rows (a row index may sit between the pieces: a dependent load anyway)
+#pragma unroll
+            for (int q = 0; q < X_PER_THREAD; ++q) {
+                const int64_t e = base + (int64_t)(threadIdx.x + q * MS_THREADS) * 8;
+                const bool ok = e < limit;
+                const int64_t ec = ok ? e : 0;
+                const float *src = ms_piece(X, xs2, K, ec / K, (int)(ec % K));
+                xreg[q][0] = *reinterpret_cast<const float4 *>(src);
+                xreg[q][1] = *reinterpret_cast<const float4 *>(src + 4);
+                okb |= ok ? (1 << q) : 0;
+            }
+        }
+        xok = okb;
+        xbase = base;
+    };
+    // the staged form of piece q of the fetched tile: out-of-range rows zero, optional ReLU, optional mask (the order the fetch applied them in)
+    auto staged = [&](int q, float4 &a, float4 &b) __attribute__((always_inline)) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool ok = (xok >> q) & 1;
+        a = ok ? xreg[q][0] : z;
+        b = ok ? xreg[q][1] : z;
+        if (flags & MS_PRE_RELU) { a = ms_relu4(a); b = ms_relu4(b); }
+        if (in_mask) {                                                        // uniform; the masked layers of the fp32x3 backward
+            const int64_t e = xbase + (int64_t)(threadIdx.x + q * MS_THREADS) * 8;
+            if (ok) {
+                a = ms_mask4(a, *reinterpret_cast<const float4 *>(in_mask + e));
+                b = ms_mask4(b, *reinterpret_cast<const float4 *>(in_mask + e + 4));
+            }
         }
     };
 
@@ -167,7 +195,9 @@ __global__ __launch_bounds__(MS_THREADS) void rows_linear_split_kernel(const flo
         for (int q = 0; q < X_PER_THREAD; ++q) {
             const int c = threadIdx.x + q * MS_THREADS;
             uint4 hi, lo;
-            ms_split8(xreg[q][0], xreg[q][1], sx, hi, lo);
+            float4 xa, xb;
+            staged(q, xa, xb);
+            ms_split8(xa, xb, sx, hi, lo);
             uint16_t *dst = xs + (c / (K / 8)) * XS + (c % (K / 8)) * 8;
             *reinterpret_cast<uint4 *>(dst) = hi;
             *reinterpret_cast<uint4 *>(dst + XPLANE) = lo;
@@ -297,25 +327,53 @@ __global__ __launch_bounds__(MS_THREADS, 2) void rows_linear_split_fm_kernel(con
 
     const int64_t n_tiles = (rows + MS_TILE - 1) / MS_TILE;
     float4 xreg[X_PER_THREAD][2];
+    int xok = 0;                                                              // bit q: piece q of xreg is a real row of X
+    int64_t xbase = 0;                                                        // element offset of the fetched tile
     auto fetch = [&](int64_t tile) {
         const int64_t base = tile * MS_TILE * K;
         const int64_t limit = rows * K;
+        // [r5] every load of the tile is issued before anything reads a loaded value: rows past the end are read from row 0 and zeroed when the tile is staged
+        // (xok carries the flags), the optional ReLU / mask are applied there too -- a per-piece `if (e < limit) { load; relu; mask }` had made the fetch a chain
+        // of `global_load, s_waitcnt vmcnt(0)` (see conv3x3_split_res_kernel)
+        int okb = 0;
+        if (!xs2.b) {                                                         // one-piece rows (uniform): straight-line code, the loads go out back to back
 #pragma unroll
-        for (int q = 0; q < X_PER_THREAD; ++q) {
-            const int64_t e = base + (int64_t)(threadIdx.x + q * MS_THREADS) * 8;
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-            if (e < limit) {
-                const float *src = ms_piece(X, xs2, K, e / K, (int)(e % K));
-                a = *reinterpret_cast<const float4 *>(src);
-                b = *reinterpret_cast<const float4 *>(src + 4);
-                if (flags & MS_PRE_RELU) { a = ms_relu4(a); b = ms_relu4(b); }
-                if (in_mask) {
-                    a = ms_mask4(a, *reinterpret_cast<const float4 *>(in_mask + e));
-                    b = ms_mask4(b, *reinterpret_cast<const float4 *>(in_mask + e + 4));
-                }
+            for (int q = 0; q < X_PER_THREAD; ++q) {
+                const int64_t e = base + (int64_t)(threadIdx.x + q * MS_THREADS) * 8;
+                const bool ok = e < limit;
+                const float *src = X + (ok ? e : 0);
+                xreg[q][0] = *reinterpret_cast<const float4 *>(src);
+                xreg[q][1] = *reinterpret_cast<const float4 *>(src + 4);
+                okb |= ok ? (1 << q) : 0;
             }
-            xreg[q][0] = a;
-            xreg[q][1] = b;
+        } else {                                                              // two-piece rows (a row index may sit between the pieces: a dependent load anyway)
+#pragma unroll
+            for (int q = 0; q < X_PER_THREAD; ++q) {
+                const int64_t e = base + (int64_t)(threadIdx.x + q * MS_THREADS) * 8;
+                const bool ok = e < limit;
+                const int64_t ec = ok ? e : 0;
+                const float *src = ms_piece(X, xs2, K, ec / K, (int)(ec % K));
+                xreg[q][0] = *reinterpret_cast<const float4 *>(src);
+                xreg[q][1] = *reinterpret_cast<const float4 *>(src + 4);
+                okb |= ok ? (1 << q) : 0;
+            }
+        }
+        xok = okb;
+        xbase = base;
+    };
+    // the staged form of piece q of the fetched tile: out-of-range rows zero, optional ReLU, optional mask (the order the fetch applied them in)
+    auto staged = [&](int q, float4 &a, float4 &b) __attribute__((always_inline)) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool ok = (xok >> q) & 1;
+        a = ok ? xreg[q][0] : z;
+        b = ok ? xreg[q][1] : z;
+        if (flags & MS_PRE_RELU) { a = ms_relu4(a); b = ms_relu4(b); }
+        if (in_mask) {                                                        // uniform; the masked layers of the fp32x3 backward
+            const int64_t e = xbase + (int64_t)(threadIdx.x + q * MS_THREADS) * 8;
+            if (ok) {
+                a = ms_mask4(a, *reinterpret_cast<const float4 *>(in_mask + e));
+                b = ms_mask4(b, *reinterpret_cast<const float4 *>(in_mask + e + 4));
+            }
         }
     };
 
@@ -328,7 +386,9 @@ __global__ __launch_bounds__(MS_THREADS, 2) void rows_linear_split_fm_kernel(con
         for (int q = 0; q < X_PER_THREAD; ++q) {
             const int c = threadIdx.x + q * MS_THREADS;
             uint4 hi, lo;
-            ms_split8(xreg[q][0], xreg[q][1], sx, hi, lo);
+            float4 xa, xb;
+            staged(q, xa, xb);
+            ms_split8(xa, xb, sx, hi, lo);
             uint16_t *dst = xs + (c / (K / 8)) * XS + (c % (K / 8)) * 8;
             *reinterpret_cast<uint4 *>(dst) = hi;
             *reinterpret_cast<uint4 *>(dst + XPLANE) = lo;
