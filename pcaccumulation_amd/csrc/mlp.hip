@@ -198,19 +198,38 @@ __global__ __launch_bounds__(256) void rows_linear_fewk_kernel(const void *__res
     const int64_t stride = (int64_t)gridDim.x * RB;
     for (int64_t r0 = (int64_t)blockIdx.x * RB + rsub; r0 < rows; r0 += FEW_U * stride) {      // the lanes of a row share r0: the shuffles below stay inside the row
         float part[FEW_U][NL];
+        if (!x_bf && !in_mask) {
+            // [r5] the common case (fp32 rows, no mask) as straight-line code: FEW_U x NL unconditional loads from clamped indices go out back to back, the
+            // range test is a select behind them.  The general loop below guards each load with a branch (and picks the element type at run time): the ISA was
+            // `global_load, s_waitcnt vmcnt(0)` once per element, eight round trips in series per pass of a lane.
+            const float *x32 = static_cast<const float *>(X);
 #pragma unroll
-        for (int u = 0; u < FEW_U; ++u) {
-            const int64_t row = r0 + u * stride;
+            for (int u = 0; u < FEW_U; ++u) {
+                const int64_t row = r0 + u * stride;
 #pragma unroll
-            for (int l = 0; l < NL; ++l) {
-                const int k = g + l * G;
-                float v = 0.f;
-                if (row < rows && k < K) {
-                    v = mlp_ld1(X, x_bf, row * K + k);
+                for (int l = 0; l < NL; ++l) {
+                    const int k = g + l * G;
+                    const bool ok = row < rows && k < K;
+                    float v = x32[ok ? row * K + k : 0];
                     if (flags & MLP_PRE_RELU) v = fmaxf(v, 0.f);
-                    if (in_mask && !(mlp_ld1(in_mask, im_bf, row * K + k) > 0.f)) v = 0.f;
+                    part[u][l] = ok ? v : 0.f;
                 }
-                part[u][l] = v;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < FEW_U; ++u) {
+                const int64_t row = r0 + u * stride;
+#pragma unroll
+                for (int l = 0; l < NL; ++l) {
+                    const int k = g + l * G;
+                    float v = 0.f;
+                    if (row < rows && k < K) {
+                        v = mlp_ld1(X, x_bf, row * K + k);
+                        if (flags & MLP_PRE_RELU) v = fmaxf(v, 0.f);
+                        if (in_mask && !(mlp_ld1(in_mask, im_bf, row * K + k) > 0.f)) v = 0.f;
+                    }
+                    part[u][l] = v;
+                }
             }
         }
 #pragma unroll
