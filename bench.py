@@ -512,12 +512,27 @@ def main():
     model_tot = flushed = None
     if world == 1:
         watchdog.off()                                                  # the single-process legs below (other modes, other configs, CPU baseline) run minutes by design
-    if rank == 0 and not args.no_step_model:
+    if not args.no_step_model:
+        # The instrumented extra step is a whole training step: with a process group it issues the step's collectives (bucketed all-reduce, the
+        # agreement flag), so EVERY rank takes it -- rank 0 alone would wait for peers that have already left (an unmatched RCCL all-reduce never
+        # returns: the N > 1 launch would end in the watchdog, not in a bench line).  Only rank 0 counts calls; the barrier keeps the ranks together
+        # until rank 0's cold-cache launches are done too.
         try:
-            model_tot = step_model(stepper, batcher, feed)
-            flushed = scatter_flushed('bf16' if args.dtype in ('bf16', 'mixed') else args.dtype, args.batch, sum(t[3] for t in timer) / max(len(timer), 1)) if timer else None
+            if rank == 0:
+                model_tot = step_model(stepper, batcher, feed)
+            else:
+                train_step(stepper, batcher, feed)
+                torch.cuda.synchronize()
+            watchdog.arm('instrumented step done')
+            if rank == 0:
+                flushed = scatter_flushed('bf16' if args.dtype in ('bf16', 'mixed') else args.dtype, args.batch, sum(t[3] for t in timer) / max(len(timer), 1)) if timer else None
         except Exception as e:                                         # diagnostics must never take the bench line down
             model_tot, flushed = {'error': repr(e)}, None
+        if stepper.skipped and rank == 0:
+            model_tot = {'error': 'the instrumented step was skipped: %r' % (stepper.last_error,)}
+        if world > 1:
+            pdist.barrier()
+            watchdog.arm('diagnostics done, barrier passed')
 
     # The same step in the other mode, N = 1 only: beside the default 'mixed' headline (forward at the accuracy that matches the reference within
     # north_star's 1e-3, tests/test_config_parity.py::test_gpu_config_fp32[mixed-*]) the all-bf16 step; beside a bf16 run the fp32x3 step.

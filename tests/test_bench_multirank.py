@@ -98,6 +98,9 @@ def test_two_gloo_ranks_share_the_gpu():
     d = _launch(2, ['--steps', '3', '--warmup', '2', '--batch', '2', '--no-cpu-baseline', '--no-fp32-leg'], {'PCACC_DIST_BACKEND': 'gloo'})
     assert d['n_gpus'] == 2 and d['steps'] == 3 and d['scaling'] == 'weak' and d['config']['parallelism'] == 'dp2'
     assert d['value'] > 0 and 'roofline' in d
+    # the instrumented extra step behind `roofline_step` is a training step with collectives: both ranks take it (rank 0 alone would sit in an all-reduce
+    # no peer answers -- with RCCL for good), and it is a step that ran, not one the stepper skipped
+    assert 'error' not in d['roofline_step'] and d['roofline_step']['native_calls_per_step'] > 100, d['roofline_step']
     assert d['distributed']['backend'] == 'gloo' and d['distributed']['ranks_per_device'] == 2 and d['distributed']['gpu_bring_up_in_turn'] is True
     # Ranks SHARING a device keep the plain one-stream step (two processes x (main, side, prefetch) streams oversubscribe the device's
     # hardware queues -- 388 ms per step at 4 queues per process, 2 555 at 8, 62.5 at 2); one rank per device, the
@@ -111,12 +114,13 @@ def test_one_rccl_rank_runs_the_production_step():
     """backend nccl (= RCCL) at world size 1 under the driver's launcher: the communicator is created, every gradient bucket goes through
     ncclAllReduce (AVG) on the process group's stream, the agreement MIN-reduce runs, and -- one rank per device -- the step is the staged
     two-stream step of N = 1.  The collectives of one rank move no data over xGMI; what this pins is that the production code path executes."""
-    d = _launch(1, ['--steps', '4', '--warmup', '7', '--batch', '2', '--no-cpu-baseline', '--no-fp32-leg', '--no-configs', '--no-step-model'],
+    d = _launch(1, ['--steps', '4', '--warmup', '7', '--batch', '2', '--no-cpu-baseline', '--no-fp32-leg', '--no-configs'],
                 {'PCACC_FORCE_PROCESS_GROUP': '1'})
     assert d['distributed']['backend'] == 'nccl' and d['distributed']['world_size'] == 1 and d['n_gpus'] == 1
     assert d['distributed']['collectives_per_step'] >= 2, d['distributed']                      # gradient buckets + the agreement reduce
     assert d['config']['step_variant'].startswith('staged') and d['config']['step_variant'].endswith('second stream'), d['config']['step_variant']
     assert d['value'] > 0 and d['steps'] == 4
+    assert 'error' not in d['roofline_step'] and d['roofline_step']['native_calls_per_step'] > 100, d['roofline_step']      # the instrumented step under RCCL too
 
 
 def test_single_rank_line_keeps_the_contract():
