@@ -13,6 +13,7 @@
 // wave-uniform, so weights come through the scalar cache as SGPR operands of v_fma (no LDS traffic for them).
 // rows_wgrad: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain): A = dY^T (n x 2 rows), B = X (2 rows x k), each half-wave loads
 // one contiguous 128-byte row piece; per-wave 32x32 tiles are reduced with fp32 atomics into the zero-filled output.
+#include <type_traits>
 #include "common.h"
 
 // rows per tile = threads per workgroup: 128 when max(K,N) <= 64 (33 KB of LDS), 64 otherwise (33 KB at 128 features)
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(MLP_ROWS) void rows_linear_kernel(const void *__res
 // barrier, two rows in flight per lane.  (r02: the former version -- K global loads of 4 bytes per lane and 8 x K weight reads from LDS --
 // ran the 3.2 M x 9 -> 64 layer of the pillar encoder in 297 us, address-unit- and LDS-bound; the HBM floor is 65 us.)
 #define FEW_U 4                     // rows in flight per lane in the few-feature streaming kernels
-template <int K, int G>
+template <int K, int G, bool HALVES>
 __global__ __launch_bounds__(256) void rows_linear_fewk_kernel(const void *__restrict__ X, const void *__restrict__ in_mask,
                                                                const float *__restrict__ W, const float *__restrict__ bias,
                                                                const void *__restrict__ residual, const void *__restrict__ out_mask,
@@ -187,13 +188,18 @@ __global__ __launch_bounds__(256) void rows_linear_fewk_kernel(const void *__res
     float omax = 0.f;                                                 // Y16 / out_amax ('mixed' mode, fp32 Y): bf16 copy of Y and its 256 partial maxima
     const int g = threadIdx.x % G, rsub = threadIdx.x / G;
     const int lane = threadIdx.x & 63, rowbase = lane - g;
-    const int n0 = g * 8;
+    // [r5] fp32 rows: the lane's eight outputs are channels 4g .. 4g+3 of each HALF of the row (was 8g .. 8g+7): one store instruction of the row's G lanes
+    // then covers a contiguous half row (128 B at N = 64: whole cache lines) instead of every other 16 bytes of the whole row -- 398 -> 357 us for the
+    // 3.2 M x 9 -> 64 layer with its bf16 copy, 284 -> 234 us without (profiles/r05_fewk_stores_ab.txt).  bf16-only rows keep 8g .. 8g+7: one 16-byte
+    // store per lane beats two 8-byte ones there (160 against 171 us).
+    constexpr bool halves = HALVES;                                  // the launcher passes HALVES = fp32 rows
     float w[8][K], b[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        b[j] = bias ? bias[n0 + j] : 0.f;
+        const int ch = halves ? (j >> 2) * (4 * G) + 4 * g + (j & 3) : 8 * g + j;
+        b[j] = bias ? bias[ch] : 0.f;
 #pragma unroll
-        for (int k = 0; k < K; ++k) w[j][k] = W[(n0 + j) * K + k];
+        for (int k = 0; k < K; ++k) w[j][k] = W[ch * K + k];
     }
     const int64_t stride = (int64_t)gridDim.x * RB;
     for (int64_t r0 = (int64_t)blockIdx.x * RB + rsub; r0 < rows; r0 += FEW_U * stride) {      // the lanes of a row share r0: the shuffles below stay inside the row
@@ -246,30 +252,33 @@ __global__ __launch_bounds__(256) void rows_linear_fewk_kernel(const void *__res
 #pragma unroll
                 for (int k = 0; k < K; ++k) acc[j] = fmaf(x[k], w[j][k], acc[j]);
             }
-            const int64_t g4 = (row * N + n0) / 4;
+            // groups of four channels: fp32 rows q4 (first half of the row) and q4 + G (second half); bf16 rows the lane's two adjacent groups
+            const int64_t q4 = row * (N / 4) + (halves ? g : 2 * g);
+            constexpr int hstep = halves ? G : 1;
             if (y_bf && !residual && !out_mask) {                     // the common case: one 16-byte store of 8 bf16
                 if (flags & MLP_POST_RELU) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) acc[j] = fmaxf(acc[j], 0.f);
                 }
-                reinterpret_cast<uint4 *>(Y)[g4 / 2] = make_uint4(pcacc_pack_bf16x2(acc[0], acc[1]), pcacc_pack_bf16x2(acc[2], acc[3]),
+                reinterpret_cast<uint4 *>(Y)[q4 / 2] = make_uint4(pcacc_pack_bf16x2(acc[0], acc[1]), pcacc_pack_bf16x2(acc[2], acc[3]),
                                                                  pcacc_pack_bf16x2(acc[4], acc[5]), pcacc_pack_bf16x2(acc[6], acc[7]));
                 continue;
             }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
+                const int64_t i4 = q4 + h * hstep;
                 float4 v = make_float4(acc[4 * h], acc[4 * h + 1], acc[4 * h + 2], acc[4 * h + 3]);
-                if (residual) { const float4 r = pcacc_ld4(residual, r_bf, g4 + h); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+                if (residual) { const float4 r = pcacc_ld4(residual, r_bf, i4); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
                 if (flags & MLP_POST_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 if (out_mask) {
-                    const float4 mk = pcacc_ld4(out_mask, om_bf, g4 + h);
+                    const float4 mk = pcacc_ld4(out_mask, om_bf, i4);
                     if (!(mk.x > 0.f)) v.x = 0.f;
                     if (!(mk.y > 0.f)) v.y = 0.f;
                     if (!(mk.z > 0.f)) v.z = 0.f;
                     if (!(mk.w > 0.f)) v.w = 0.f;
                 }
-                pcacc_st4(Y, y_bf, g4 + h, v);
-                if (Y16) reinterpret_cast<uint2 *>(Y16)[g4 + h] = make_uint2(pcacc_pack_bf16x2(v.x, v.y), pcacc_pack_bf16x2(v.z, v.w));
+                pcacc_st4(Y, y_bf, i4, v);
+                if (Y16) reinterpret_cast<uint2 *>(Y16)[i4] = make_uint2(pcacc_pack_bf16x2(v.x, v.y), pcacc_pack_bf16x2(v.z, v.w));
                 if (out_amax) {
                     omax = fmaxf(fmaxf(omax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
                     if (!(v.x == v.x && v.y == v.y && v.z == v.z && v.w == v.w)) omax = __builtin_inff();
@@ -357,7 +366,8 @@ static int rows_linear_any(const void *x, const void *in_mask, const float *w, c
     hipStream_t s = pcacc_stream(stream);
     if (k <= 9 && (n == 8 || n == 16 || n == 32 || n == 64 || n == 128)) {   // few inputs: lane per (row, 8 outputs)
         const int grid = pcacc_grid(rows * (n / 8), 256 * FEW_U, PCACC_CUS * 8);
-#define FEWK(KK, GG) rows_linear_fewk_kernel<KK, GG><<<grid, 256, 0, s>>>(x, in_mask, w, bias, residual, out_mask, y, rows, flags, dt, y16, y_amax)
+#define FEWK(KK, GG) do { if (dt & MLP_Y_BF16) rows_linear_fewk_kernel<KK, GG, false><<<grid, 256, 0, s>>>(x, in_mask, w, bias, residual, out_mask, y, rows, flags, dt, y16, y_amax); \
+                          else rows_linear_fewk_kernel<KK, GG, true><<<grid, 256, 0, s>>>(x, in_mask, w, bias, residual, out_mask, y, rows, flags, dt, y16, y_amax); } while (0)
 #define FEWK_G(KK) do { switch (n) { case 8: FEWK(KK, 1); break; case 16: FEWK(KK, 2); break; case 32: FEWK(KK, 4); break; \
                                      case 64: FEWK(KK, 8); break; default: FEWK(KK, 16); break; } } while (0)
         if (k == 2) FEWK_G(2);
@@ -548,7 +558,7 @@ __global__ __launch_bounds__(256) void rows_wgrad_kernel(const void *__restrict_
 //   wide = dY, narrow = X (few inputs) : dW[n][k] = P[n][k], bias column = wide sums
 //   wide = X, narrow = dY (few outputs): dW[n][k] = P[k][n], bias column = narrow sums
 #define FEW_WU 2                    // (4 rows in flight cost the weight-gradient kernel half its occupancy: 500 us instead of 308)
-template <int F, int C4N>
+template <int F, int C4N, int FAST = 0>                                  // FAST: 0 the general loop, 1 / 2 the straight-line bf16 form without / with a mask
 __global__ __launch_bounds__(256) void rows_wgrad_few_kernel(const void *__restrict__ wide, const void *__restrict__ wide_mask, int wide_relu,
                                                              const void *__restrict__ narrow, const void *__restrict__ narrow_mask,
                                                              int narrow_relu, int64_t rows, int wide_is_dy, int flags_bf,
@@ -564,6 +574,75 @@ __global__ __launch_bounds__(256) void rows_wgrad_few_kernel(const void *__restr
 #pragma unroll
     for (int f = 0; f < F; ++f) { ssum[f] = 0.f; acc[f][0] = acc[f][1] = acc[f][2] = acc[f][3] = 0.f; }
     const int64_t stride = (int64_t)gridDim.x * RB;
+    auto consume = [&](const float4 &wv, const float (&pt)[NL]) {
+        wsum[0] += wv.x; wsum[1] += wv.y; wsum[2] += wv.z; wsum[3] += wv.w;
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const float v = __shfl(pt[f / C4N], rowbase + (f % C4N), 64);
+            ssum[f] += v;
+            acc[f][0] = fmaf(v, wv.x, acc[f][0]);
+            acc[f][1] = fmaf(v, wv.y, acc[f][1]);
+            acc[f][2] = fmaf(v, wv.z, acc[f][2]);
+            acc[f][3] = fmaf(v, wv.w, acc[f][3]);
+        }
+    };
+    // [r5] the common calls (narrow operand fp32 and unmasked; wide operand and its mask of one element type) as straight-line code: the loads of
+    // FEW_WF rows -- wide row piece, its mask piece, the narrow element -- go out back to back from clamped row numbers, conversion / ReLU / mask / range
+    // test follow as selects.  The general loop below guards every load with a branch and picks element types at run time: `global_load, s_waitcnt
+    // vmcnt(0)` per element and two rows in flight (the 3.2 M x 64 x 9 weight gradient of the pillar encoder's position layer ran at 2.1 TB/s).
+    constexpr int FEW_WF = 4;
+    // (fp32 wide rows already carry 16 bytes per lane and load: there the four-row form costs occupancy and measured 7 - 20 % slower -- they keep the loop below)
+    // Own instantiations (FAST, chosen by the launcher): inside one kernel the two forms shared a register budget and the general loop lost a third of its speed.
+    auto fast_pass = [&](auto bf_tag, auto mask_tag) {
+        constexpr bool BF = decltype(bf_tag)::value, MASKED = decltype(mask_tag)::value;
+        using R = typename std::conditional<BF, uint2, float4>::type;
+        auto to_f4 = [](const R &r) {
+            if constexpr (BF) return make_float4(pcacc_bf16_lo(r.x), pcacc_bf16_hi(r.x), pcacc_bf16_lo(r.y), pcacc_bf16_hi(r.y));
+            else return r;
+        };
+        const R *wp = static_cast<const R *>(wide), *mp = static_cast<const R *>(wide_mask);
+        const float *np = static_cast<const float *>(narrow);
+        for (int64_t r0 = (int64_t)blockIdx.x * RB + rsub; r0 < rows; r0 += FEW_WF * stride) {
+            R wr[FEW_WF], mr[FEW_WF];
+            float nr[FEW_WF][NL];
+#pragma unroll
+            for (int u = 0; u < FEW_WF; ++u) {
+                const int64_t row = r0 + u * stride, rc = row < rows ? row : rows - 1;
+                wr[u] = wp[rc * C4N + c4];
+                if constexpr (MASKED) mr[u] = mp[rc * C4N + c4];
+#pragma unroll
+                for (int l = 0; l < NL; ++l) {
+                    const int f = c4 + l * C4N;
+                    nr[u][l] = np[f < F ? rc * F + f : 0];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < FEW_WF; ++u) {
+                const bool in = r0 + u * stride < rows;
+                float4 wv = to_f4(wr[u]);
+                if (wide_relu) { wv.x = fmaxf(wv.x, 0.f); wv.y = fmaxf(wv.y, 0.f); wv.z = fmaxf(wv.z, 0.f); wv.w = fmaxf(wv.w, 0.f); }
+                if constexpr (MASKED) {
+                    const float4 mk = to_f4(mr[u]);
+                    if (!(mk.x > 0.f)) wv.x = 0.f;
+                    if (!(mk.y > 0.f)) wv.y = 0.f;
+                    if (!(mk.z > 0.f)) wv.z = 0.f;
+                    if (!(mk.w > 0.f)) wv.w = 0.f;
+                }
+                if (!in) wv = make_float4(0.f, 0.f, 0.f, 0.f);
+                float pt[NL];
+#pragma unroll
+                for (int l = 0; l < NL; ++l) {
+                    float v = nr[u][l];
+                    if (narrow_relu) v = fmaxf(v, 0.f);
+                    pt[l] = (in && c4 + l * C4N < F) ? v : 0.f;
+                }
+                consume(wv, pt);
+            }
+        }
+    };
+    if constexpr (FAST == 2) fast_pass(std::true_type(), std::true_type());
+    else if constexpr (FAST == 1) fast_pass(std::true_type(), std::false_type());
+    else
     for (int64_t r0 = (int64_t)blockIdx.x * RB + rsub; r0 < rows; r0 += FEW_WU * stride) {       // the lanes of a row share r0
         float4 w[FEW_WU];
         float part[FEW_WU][NL];
@@ -595,18 +674,7 @@ __global__ __launch_bounds__(256) void rows_wgrad_few_kernel(const void *__restr
             }
         }
 #pragma unroll
-        for (int u = 0; u < FEW_WU; ++u) {
-            wsum[0] += w[u].x; wsum[1] += w[u].y; wsum[2] += w[u].z; wsum[3] += w[u].w;
-#pragma unroll
-            for (int f = 0; f < F; ++f) {
-                const float v = __shfl(part[u][f / C4N], rowbase + (f % C4N), 64);
-                ssum[f] += v;
-                acc[f][0] = fmaf(v, w[u].x, acc[f][0]);
-                acc[f][1] = fmaf(v, w[u].y, acc[f][1]);
-                acc[f][2] = fmaf(v, w[u].z, acc[f][2]);
-                acc[f][3] = fmaf(v, w[u].w, acc[f][3]);
-            }
-        }
+        for (int u = 0; u < FEW_WU; ++u) consume(w[u], part[u]);
     }
     // lanes c4, c4 + C4N, ... of a wave own the same columns
     float vals[V];
@@ -723,9 +791,13 @@ extern "C" int pcacc_rows_wgrad_few(const void *dy, const void *dy_mask, const v
     float *partial = reinterpret_cast<float *>(workspace);
     // bf16 flags: wide, wide mask, narrow, narrow mask (dt: bit 0 dY, bit 1 dy_mask, bit 2 X)
     const int fb = few_in ? (dt & 7) : (((dt & 4) ? 1 : 0) | ((dt & 1) ? 4 : 0) | ((dt & 2) ? 8 : 0));
+    // few inputs, bf16 dY (and mask), fp32 X: the straight-line form (rows_wgrad_few_kernel, FAST)
+    const bool fast = few_in && (fb & 1) && !(fb & 4) && (!dy_mask || (fb & 2));
 #define WG_FEW(FF, CC)                                                                                                                     \
     do {                                                                                                                                   \
-        if (few_in) rows_wgrad_few_kernel<FF, CC><<<grid, 256, 0, s>>>(dy, dy_mask, 0, x, nullptr, x_relu, rows, 1, fb, partial);          \
+        if (few_in && fast && dy_mask) rows_wgrad_few_kernel<FF, CC, 2><<<grid, 256, 0, s>>>(dy, dy_mask, 0, x, nullptr, x_relu, rows, 1, fb, partial); \
+        else if (few_in && fast) rows_wgrad_few_kernel<FF, CC, 1><<<grid, 256, 0, s>>>(dy, dy_mask, 0, x, nullptr, x_relu, rows, 1, fb, partial); \
+        else if (few_in) rows_wgrad_few_kernel<FF, CC><<<grid, 256, 0, s>>>(dy, dy_mask, 0, x, nullptr, x_relu, rows, 1, fb, partial);     \
         else rows_wgrad_few_kernel<FF, CC><<<grid, 256, 0, s>>>(x, nullptr, x_relu, dy, dy_mask, 0, rows, 0, fb, partial);                 \
     } while (0)
 #define WG_FEW_C(FF) do { if (c == 32) WG_FEW(FF, 8); else if (c == 64) WG_FEW(FF, 16); else WG_FEW(FF, 32); } while (0)

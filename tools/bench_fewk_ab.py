@@ -31,6 +31,27 @@ def main():
             row[name + '_us'] = round(min(timeit(f) for _ in range(3)), 1)
             row[name + '_sha'] = sha(y)
         print(json.dumps(row), flush=True)
+    # the weight gradients of the same layers (mlp.hip: rows_wgrad_few_kernel): dY bf16 + ReLU mask (the 'mixed' / bf16 backward), dY fp32 unmasked
+    for rows, k, n in ((3200000, 9, 64), (320000, 3, 32), (335444, 128, 2), (3200000, 4, 32)):
+        x = torch.randn(rows, k, device=dev)
+        dy = torch.randn(rows, n, device=dev)
+        mk = torch.randn(rows, n, device=dev)
+        row = {'wgrad': '%d x (%d <- %d)' % (rows, k, n)}
+        cases = (('bf16_masked', lambda: native.rows_wgrad(dy.bfloat16(), x, dy_mask=mk.bfloat16())),
+                 ('f32', lambda: native.rows_wgrad(dy, x)),
+                 ('f32_masked', lambda: native.rows_wgrad(dy, x, dy_mask=mk)))
+        for name, f in cases:
+            if name == 'bf16_masked':
+                d16, m16 = dy.bfloat16(), mk.bfloat16()
+                f = lambda: native.rows_wgrad(d16, x, dy_mask=m16)
+            try:
+                y = f()
+            except Exception as e:
+                row[name] = repr(e)[:60]
+                continue
+            row[name + '_us'] = round(min(timeit(f) for _ in range(3)), 1)
+            row[name + '_sha'] = sha(y)
+        print(json.dumps(row), flush=True)
 
 
 if __name__ == '__main__':
