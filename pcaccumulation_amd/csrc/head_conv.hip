@@ -8,6 +8,7 @@
 //   wgrad   : dw[co][ci][tap] = sum_px dy[px][co] x[px + tap][ci],  db[co] = sum_px dy[px][co]
 // Lane layout: c_in / 4 lanes per pixel, each owning 4 consecutive input channels (one 16-byte / 8-byte load per tap: the lanes of a
 // pixel read one contiguous row); a 256-thread workgroup covers 256 / (c_in / 4) consecutive pixels.
+#include <type_traits>
 #include "common.h"
 
 #define HC_THREADS 256
@@ -46,7 +47,48 @@ __device__ __forceinline__ void hc_stage(const void *__restrict__ x, int x_bf16,
     }
 }
 
-template <int CI, int COM>
+// [r5] the same staging in two halves, so that the NEXT tile's rows travel in registers while the current tile is computed (forward and weight gradient
+// were load -> barrier -> compute -> barrier per tile, the load latency covered only by the two other workgroups of the CU): hc_fetch issues a thread's
+// loads back to back from clamped positions (raw element type: 8 bytes per piece for bf16 rows), hc_put converts, zeroes what lies outside and stores.
+template <int CI, bool BF> struct HcRaw { typedef typename std::conditional<BF, uint2, float4>::type T; };
+template <int CI> struct HcPieces { static constexpr int N = (HC_PH * HC_PW * (CI / 4) + HC_THREADS - 1) / HC_THREADS; };
+
+template <int CI, bool BF>
+__device__ __forceinline__ void hc_fetch(const void *__restrict__ x, const HcTile &t, int h, int wd, typename HcRaw<CI, BF>::T (&r)[HcPieces<CI>::N])
+{
+    constexpr int LPP = CI / 4;
+    const typename HcRaw<CI, BF>::T *src = static_cast<const typename HcRaw<CI, BF>::T *>(x);
+#pragma unroll
+    for (int q = 0; q < HcPieces<CI>::N; ++q) {
+        const int e = min((int)threadIdx.x + q * HC_THREADS, HC_PH * HC_PW * LPP - 1);
+        const int pp = e / LPP, l4 = e - pp * LPP;
+        const int py = pp / HC_PW, pxx = pp - py * HC_PW;
+        const int yc = min(max(t.y0 - 1 + py, 0), h - 1), xc = min(max(t.x0 - 1 + pxx, 0), wd - 1);
+        r[q] = src[(((int64_t)t.img * h + yc) * wd + xc) * LPP + l4];
+    }
+}
+
+template <int CI, bool BF>
+__device__ __forceinline__ void hc_put(const typename HcRaw<CI, BF>::T (&r)[HcPieces<CI>::N], const HcTile &t, int h, int wd, float *patch)
+{
+    constexpr int LPP = CI / 4;
+#pragma unroll
+    for (int q = 0; q < HcPieces<CI>::N; ++q) {
+        const int e = threadIdx.x + q * HC_THREADS;
+        if (e >= HC_PH * HC_PW * LPP) break;
+        const int pp = e / LPP, l4 = e - pp * LPP;
+        const int py = pp / HC_PW, pxx = pp - py * HC_PW;
+        const int y = t.y0 - 1 + py, xx = t.x0 - 1 + pxx;
+        const bool ok = (unsigned)y < (unsigned)h && (unsigned)xx < (unsigned)wd;
+        float4 v;
+        if constexpr (BF) v = make_float4(pcacc_bf16_lo(r[q].x), pcacc_bf16_hi(r[q].x), pcacc_bf16_lo(r[q].y), pcacc_bf16_hi(r[q].y));
+        else v = r[q];
+        if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4 *>(patch + pp * CI + l4 * 4) = v;
+    }
+}
+
+template <int CI, int COM, bool BF>
 __global__ __launch_bounds__(HC_THREADS) void head_conv_fwd_kernel(const void *__restrict__ x, int x_bf16, const float *__restrict__ w,
                                                                    const float *__restrict__ bias, float *__restrict__ y, int n_img, int h,
                                                                    int wd, int co, int64_t ws_o, int64_t ws_i, int64_t ws_y, int64_t ws_x,
@@ -65,11 +107,15 @@ __global__ __launch_bounds__(HC_THREADS) void head_conv_fwd_kernel(const void *_
             wr[tap][c] = c < co ? make_float4(wp[0], wp[ws_i], wp[2 * ws_i], wp[3 * ws_i]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     const int n_tiles = n_img * tiles_y * tiles_x;
+    constexpr bool PIPE = CI == 32;                            // 64 channels: 22 pieces per thread in flight would cost the kernel its occupancy -- staged in place
+    typename HcRaw<CI, BF>::T raw[HcPieces<CI>::N];
+    if (PIPE && (int)blockIdx.x < n_tiles) hc_fetch<CI, BF>(x, hc_tile(blockIdx.x, tiles_y, tiles_x), h, wd, raw);
     for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const HcTile tl = hc_tile(t, tiles_y, tiles_x);
         __syncthreads();                                       // the previous tile's readers are done
-        hc_stage<CI>(x, x_bf16, tl, h, wd, patch);
+        if constexpr (PIPE) hc_put<CI, BF>(raw, tl, h, wd, patch); else hc_stage<CI>(x, x_bf16, tl, h, wd, patch);
         __syncthreads();
+        if (PIPE && t + (int)gridDim.x < n_tiles) hc_fetch<CI, BF>(x, hc_tile(t + gridDim.x, tiles_y, tiles_x), h, wd, raw);
         for (int q = slot; q < HC_TR * HC_TC; q += PPB) {
             const int row = q / HC_TC, col = q % HC_TC;
             float acc[COM];
@@ -148,7 +194,7 @@ __global__ __launch_bounds__(HC_THREADS) void head_conv_dgrad_kernel(const float
 
 // per-workgroup partial sums of dw (+ db) go to a workspace slot; a second launch sums the slots in a fixed order (one atomic per element
 // and workgroup from ~10^3 workgroups onto 578 words serialised in L2: 707 us for this launch)
-template <int CI, int COM>
+template <int CI, int COM, bool BF>
 __global__ __launch_bounds__(HC_THREADS) void head_conv_wgrad_kernel(const float *__restrict__ dy, const void *__restrict__ x, int x_bf16,
                                                                      float *__restrict__ partial, int n_img, int h, int wd, int co, int tiles_y,
                                                                      int tiles_x)
@@ -169,19 +215,32 @@ __global__ __launch_bounds__(HC_THREADS) void head_conv_wgrad_kernel(const float
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[t][c][q] = 0.f;
     const int n_tiles = n_img * tiles_y * tiles_x;
+    constexpr bool PIPE = CI == 32 && COM == 4;                // measured: 32 -> 4 272 -> 196 us; 32 -> 2 loses a workgroup per CU to the extra registers (121 -> 135 us): staged in place
+    typename HcRaw<CI, BF>::T raw[HcPieces<CI>::N];
+    if (PIPE && (int)blockIdx.x < n_tiles) hc_fetch<CI, BF>(x, hc_tile(blockIdx.x, tiles_y, tiles_x), h, wd, raw);
     for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const HcTile tl = hc_tile(t, tiles_y, tiles_x);
         __syncthreads();
-        hc_stage<CI>(x, x_bf16, tl, h, wd, patch);
+        if constexpr (PIPE) hc_put<CI, BF>(raw, tl, h, wd, patch); else hc_stage<CI>(x, x_bf16, tl, h, wd, patch);
         __syncthreads();
+        if (PIPE && t + (int)gridDim.x < n_tiles) hc_fetch<CI, BF>(x, hc_tile(t + gridDim.x, tiles_y, tiles_x), h, wd, raw);
+        // [r5] two-output head: the pixel's gradient pair for the NEXT pass is loaded while this pass multiplies (it was a global load at the head of every
+        // pass, used at once)
+        auto dy_at = [&](int q) {
+            const int yy = tl.y0 + q / HC_TC, xx = tl.x0 + q % HC_TC;
+            return dy + (((int64_t)tl.img * h + min(yy, h - 1)) * wd + min(xx, wd - 1)) * co;
+        };
+        float2 g_next = make_float2(0.f, 0.f);
+        if (COM == 2 && co == 2) g_next = *reinterpret_cast<const float2 *>(dy_at(slot));
         for (int q = slot; q < HC_TR * HC_TC; q += PPB) {
             const int row = q / HC_TC, col = q % HC_TC;
             const int yy = tl.y0 + row, xx = tl.x0 + col;
             const bool ok = yy < h && xx < wd;
-            const float *gp = dy + (((int64_t)tl.img * h + min(yy, h - 1)) * wd + min(xx, wd - 1)) * co;
+            const float *gp = dy_at(q);
             float g[COM];
             if (COM == 2 && co == 2) {
-                const float2 g2 = *reinterpret_cast<const float2 *>(gp);
+                const float2 g2 = g_next;
+                if (q + PPB < HC_TR * HC_TC) g_next = *reinterpret_cast<const float2 *>(dy_at(q + PPB));
                 g[0] = ok ? g2.x : 0.f;
                 g[1] = ok ? g2.y : 0.f;
             } else {
@@ -284,7 +343,7 @@ extern "C" int pcacc_head_conv3x3_forward(const void *x, int32_t x_dtype, const 
 #define HC_FWD(CIV, COV)                                                                                                                        \
     do {                                                                                                                                        \
         const size_t lds = (size_t)(HC_PH * HC_PW * CIV) * sizeof(float);                                                       \
-        auto kern = head_conv_fwd_kernel<CIV, COV>;                                                                                             \
+        auto kern = x_dtype ? head_conv_fwd_kernel<CIV, COV, true> : head_conv_fwd_kernel<CIV, COV, false>;                                     \
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)     \
             return PCACC_E_LAUNCH;                                                                                                              \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(HC_THREADS), lds, pcacc_stream(stream), x, x_dtype, w, bias, y, n_img, h, wd, c_out, w_strides[0], \
@@ -339,7 +398,7 @@ extern "C" int pcacc_head_conv3x3_wgrad(const float *dy, const void *x, int32_t 
 #define HC_WG(CIV, COV)                                                                                                                         \
     do {                                                                                                                                        \
         const size_t lds = (size_t)(HC_PH * HC_PW * CIV) * sizeof(float);                                                                       \
-        auto kern = head_conv_wgrad_kernel<CIV, COV>;                                                                                           \
+        auto kern = x_dtype ? head_conv_wgrad_kernel<CIV, COV, true> : head_conv_wgrad_kernel<CIV, COV, false>;                                 \
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)     \
             return PCACC_E_LAUNCH;                                                                                                              \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(HC_THREADS), lds, st, dy, x, x_dtype, partial, n_img, h, wd, c_out, tiles_y, tiles_x);        \
