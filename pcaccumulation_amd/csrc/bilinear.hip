@@ -252,13 +252,32 @@ __global__ __launch_bounds__(256) void bilinear_gather_bwd_sorted_kernel(const v
                 b[2] = en[2] = b[3] = en[3] = 0;
             }
         }
+        // [r5] the FIRST point of each of the four segments is fetched up front -- tap weights and gradient row, eight independent loads from clamped
+        // positions -- before anything is added: with ~1 point per cell that is the whole cell in two memory round trips (offsets, then rows) instead of a
+        // weights -> row chain per tap, one after the other (in the step, on cold data, the kernel ran at 0.55 TB/s: 235 us against 79 us on a warm
+        // benchmark loop).  Sums run in the same order as before -- tap by tap, points in segment order, zero weights skipped: bit-identical.
+        float4 w0[4], g0[4];
+#pragma unroll
+        for (int tap = 0; tap < 4; ++tap) {
+            const int q = b[tap] < en[tap] ? b[tap] : 0;                         // row 0 exists (the launcher handles k = 0)
+            w0[tap] = wts[q];
+            g0[tap] = load4<G_BF16>(g_sorted, (int64_t)q * c + ch);
+        }
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int tap = 0; tap < 4; ++tap) {                                      // this cell as tap (ty, tx) of base cell (y-ty, x-tx)
-            for (int q = b[tap]; q < en[tap]; ++q) {
+            if (b[tap] >= en[tap]) continue;
+            {
+                const float wt = tap == 0 ? w0[tap].x : tap == 1 ? w0[tap].y : tap == 2 ? w0[tap].z : w0[tap].w;
+                if (wt != 0.f) {                                                 // 0: outside the map (or an exact zero weight)
+                    const float4 g = g0[tap];
+                    acc.x += wt * g.x; acc.y += wt * g.y; acc.z += wt * g.z; acc.w += wt * g.w;
+                }
+            }
+            for (int q = b[tap] + 1; q < en[tap]; ++q) {
                 const float4 w4 = wts[q];
                 const float wt = tap == 0 ? w4.x : tap == 1 ? w4.y : tap == 2 ? w4.z : w4.w;
-                if (wt == 0.f) continue;                                         // outside the map (or an exact zero weight)
+                if (wt == 0.f) continue;
                 const float4 g = load4<G_BF16>(g_sorted, (int64_t)q * c + ch);
                 acc.x += wt * g.x; acc.y += wt * g.y; acc.z += wt * g.z; acc.w += wt * g.w;
             }
@@ -303,6 +322,11 @@ extern "C" int pcacc_bilinear_gather_backward_sorted(const void *grad_out, int g
         const int pgrid = pcacc_grid(k * (c / 4), 256);
         if (grad_dtype == PCACC_BF16) bilinear_sorted_prep_kernel<1><<<pgrid, 256, 0, s>>>(grad_out, c, h, w, points, order, k, x_scale, y_scale, wts, g_sorted);
         else bilinear_sorted_prep_kernel<0><<<pgrid, 256, 0, s>>>(grad_out, c, h, w, points, order, k, x_scale, y_scale, wts, g_sorted);
+    }
+    if (k == 0) {                                                               // no point: every cell's sum is empty (the kernel reads row 0 unconditionally)
+        const size_t esz = out_dtype == PCACC_BF16 ? 2 : 4;
+        if (hipMemsetAsync(grad_fmap, 0, (size_t)n_maps * h * w * c * esz, s) != hipSuccess) return PCACC_E_LAUNCH;
+        return PCACC_OK;
     }
     // many short workgroups: the per-cell loops are as long as the cell is crowded, a fine grid evens that out
     const int grid = pcacc_grid((int64_t)n_maps * ((h + 3) / 4) * ((w + 3) / 4) * 16 * (c / 4), 256, PCACC_CUS * 64);
