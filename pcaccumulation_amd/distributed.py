@@ -134,20 +134,38 @@ def ranks_share_a_device():
             import socket
             try:
                 prop = torch.cuda.get_device_properties(torch.cuda.current_device())
-                ident = '%s/%s' % (socket.gethostname(), getattr(prop, 'uuid', None) or '%s:%s:%s' % (
-                    getattr(prop, 'pci_domain_id', '?'), getattr(prop, 'pci_bus_id', '?'), getattr(prop, 'pci_device_id', torch.cuda.current_device())))
+                hw = str(getattr(prop, 'uuid', None) or '%s:%s:%s' % (getattr(prop, 'pci_domain_id', '?'), getattr(prop, 'pci_bus_id', '?'),
+                                                                         getattr(prop, 'pci_device_id', torch.cuda.current_device())))
+                mask = os.environ.get('HIP_VISIBLE_DEVICES') or os.environ.get('ROCR_VISIBLE_DEVICES') or os.environ.get('CUDA_VISIBLE_DEVICES') or ''
+                ident = (socket.gethostname(), hw, mask, int(torch.cuda.current_device()))
             except Exception:                                 # noqa: BLE001 -- identity unknown: fall back to the count below
                 ident = None
             idents = [None] * dist.get_world_size()
             dist.all_gather_object(idents, ident)
-            if any(i is None for i in idents):
-                _SHARED[key] = _count_says_shared()
-            else:
-                _SHARED[key] = len(set(idents)) < len(idents)
+            _SHARED[key] = _count_says_shared() if any(i is None for i in idents) else _idents_say_shared(idents)
             if dist.get_rank() == 0 and os.environ.get('PCACC_BENCH_TRACE'):
                 print('[distributed] devices of the ranks: %s -> %s' % (idents, 'shared' if _SHARED[key] else 'one rank per device'), file=sys.stderr)
         return _SHARED[key]
     return _count_says_shared()
+
+
+def _idents_say_shared(idents):
+    """idents: per rank (host, hardware id, visibility mask, device index).  Two ranks share a device when they sit on one host with the same hardware id --
+    unless that id is uninformative there (a runtime that reports one id for every GPU of the host would turn the one-rank-per-GPU layout into 'shared' and
+    silently cost it the two-stream step): an id every rank of a host reports counts only if those ranks also use the same (mask, index)."""
+    by_host = {}
+    for host, hw, mask, index in idents:
+        by_host.setdefault(host, []).append((hw, mask, index))
+    for ranks in by_host.values():
+        if len(ranks) < 2:
+            continue
+        hws = [r[0] for r in ranks]
+        informative = len(set(hws)) > 1
+        if informative and len(set(hws)) < len(hws):
+            return True
+        if len(set((r[1], r[2]) for r in ranks)) < len(ranks):
+            return True
+    return False
 
 
 def _count_says_shared():

@@ -178,3 +178,17 @@ def test_tolerances_are_the_frozen_ones():
     assert tt.TOL['mixed'] == dict(loss_tol=1e-3, grad_cos=0.999, grad_rel=3e-2, upd_cos=0.98)
     assert tt.TOL['bf16'] == dict(loss_tol=0.15, grad_cos=0.9, grad_rel=3.0, upd_cos=0.5, term_tol=0.5, norm_tol=0.1, require_fb=False)
     assert cs.TOL == 3e-6 and ms.TOL == 3e-6
+
+
+def test_device_sharing_is_decided_from_identity_and_survives_an_uninformative_id():
+    """distributed.ranks_share_a_device gathers (host, hardware id, visibility mask, device index) per rank: two ranks on one GPU are 'shared' (the
+    one-GPU test box), one rank per GPU is not -- also when the runtime reports ONE id for every GPU of the host (the ranks then differ by index or by
+    mask), and never across hosts."""
+    from pcaccumulation_amd.distributed import _idents_say_shared as shared
+    assert shared([('h', 'a', '', 0), ('h', 'a', '', 0)])
+    assert shared([('h', 'a', '0', 0), ('h', 'a', '0', 0)])
+    assert shared([('h', 'a', '', 0), ('h', 'b', '', 1), ('h', 'a', '', 0)])
+    assert not shared([('h', 'a', '', 0), ('h', 'b', '', 1)])
+    assert not shared([('h', 'z', '', i) for i in range(8)])
+    assert not shared([('h', 'z', str(i), 0) for i in range(8)])
+    assert not shared([('h1', 'a', '', 0), ('h2', 'a', '', 0)])
