@@ -196,8 +196,9 @@ template <int G_BF16>
 __global__ __launch_bounds__(256) void bilinear_sorted_prep_kernel(const void *__restrict__ grad_out, int c, int h, int w,
                                                                    const float *__restrict__ pts, const int32_t *__restrict__ order,
                                                                    int64_t k, float xs, float ys, float4 *__restrict__ wts,
-                                                                   void *__restrict__ g_sorted)
+                                                                   void *__restrict__ g_sorted, int *__restrict__ crowded)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) crowded[0] = 0;                     // the work list of the per-cell pass that follows starts empty
     const int lpp = c / 4;
     const int64_t total = k * lpp;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
@@ -218,11 +219,30 @@ __global__ __launch_bounds__(256) void bilinear_sorted_prep_kernel(const void *_
 // came out of HBM / the Infinity Cache twice (PMC round 4: 1.83 x the algorithmic bytes); inside a tile the second reader finds it in the CU's cache.
 // The six segment offsets a cell needs are loaded up front (independent loads) instead of two behind each tap's bounds test.  Same taps in the same
 // order per cell: results bit-identical to the row-major walk.
+#define BG_CROWD 8                    // a cell with a longer segment is summed by the crowded-cell kernel
+#define BG_U 16                       // its batch: points whose weights and rows are in flight together
+// segment bounds of the four base cells (x - tx, y - ty) of a cell; a base outside the map gets the empty range
+__device__ __forceinline__ void bg_bounds(const int32_t *__restrict__ seg_offsets, int64_t cell, int x, int y, int w, int (&b)[4], int (&en)[4])
+{
+    const int o_c = seg_offsets[cell], o_c1 = seg_offsets[cell + 1];
+    const int o_l = x > 0 ? seg_offsets[cell - 1] : o_c;
+    b[0] = o_c; en[0] = o_c1;
+    b[1] = o_l; en[1] = o_c;
+    if (y > 0) {
+        const int o_u = seg_offsets[cell - w], o_u1 = seg_offsets[cell - w + 1];
+        const int o_ul = x > 0 ? seg_offsets[cell - w - 1] : o_u;
+        b[2] = o_u; en[2] = o_u1;
+        b[3] = o_ul; en[3] = o_u;
+    } else {
+        b[2] = en[2] = b[3] = en[3] = 0;
+    }
+}
+
 template <int G_BF16, int OUT_BF16>
 __global__ __launch_bounds__(256) void bilinear_gather_bwd_sorted_kernel(const void *__restrict__ g_sorted, const float4 *__restrict__ wts,
                                                                          int n_maps, int h, int w, int c,
                                                                          const int32_t *__restrict__ seg_offsets,
-                                                                         void *__restrict__ grad_fmap)
+                                                                         void *__restrict__ grad_fmap, int *__restrict__ crowded)
 {
     const int lpp = c / 4;
     const int tw = (w + 3) >> 2, th = (h + 3) >> 2;
@@ -236,21 +256,14 @@ __global__ __launch_bounds__(256) void bilinear_gather_bwd_sorted_kernel(const v
         const int x = tx0 * 4 + (ci & 3), y = ty0 * 4 + (ci >> 2);
         if (x >= w || y >= h) continue;
         const int64_t cell = ((int64_t)mi * h + y) * w + x;
-        // segment bounds of the four base cells (x - tx, y - ty); a base outside the map gets the empty range
         int b[4], en[4];
-        {
-            const int o_c = seg_offsets[cell], o_c1 = seg_offsets[cell + 1];
-            const int o_l = x > 0 ? seg_offsets[cell - 1] : o_c;
-            b[0] = o_c; en[0] = o_c1;
-            b[1] = o_l; en[1] = o_c;
-            if (y > 0) {
-                const int o_u = seg_offsets[cell - w], o_u1 = seg_offsets[cell - w + 1];
-                const int o_ul = x > 0 ? seg_offsets[cell - w - 1] : o_u;
-                b[2] = o_u; en[2] = o_u1;
-                b[3] = o_ul; en[3] = o_u;
-            } else {
-                b[2] = en[2] = b[3] = en[3] = 0;
-            }
+        bg_bounds(seg_offsets, cell, x, y, w, b, en);
+        // [r5] crowded cells -- a segment of more than BG_CROWD points: the step's points sit in a few boxes, tens to hundreds per cell -- go to a work list
+        // and are summed by bilinear_gather_bwd_crowded_kernel (same order, loads in batches); here they would hold a lane group for hundreds of dependent
+        // round trips, and giving THIS kernel the registers for batches cost the sparse cells 20 % (occupancy 8 -> 5)
+        if (max(max(en[0] - b[0], en[1] - b[1]), max(en[2] - b[2], en[3] - b[3])) > BG_CROWD) {
+            if (ch == 0) crowded[1 + atomicAdd(crowded, 1)] = (int)cell;
+            continue;
         }
         // [r5] the FIRST point of each of the four segments is fetched up front -- tap weights and gradient row, eight independent loads from clamped
         // positions -- before anything is added: with ~1 point per cell that is the whole cell in two memory round trips (offsets, then rows) instead of a
@@ -286,6 +299,45 @@ __global__ __launch_bounds__(256) void bilinear_gather_bwd_sorted_kernel(const v
     }
 }
 
+// The crowded cells of the work list (crowded[0] = their number): c / 4 lanes per cell as above, the same sums in the same order -- tap by tap, points in
+// segment order, zero weights skipped -- with the loads of BG_U points in flight at a time.  Cells are independent, so the order of the list does not matter.
+template <int G_BF16, int OUT_BF16>
+__global__ __launch_bounds__(256) void bilinear_gather_bwd_crowded_kernel(const void *__restrict__ g_sorted, const float4 *__restrict__ wts, int h, int w, int c,
+                                                                          const int32_t *__restrict__ seg_offsets, void *__restrict__ grad_fmap,
+                                                                          const int *__restrict__ crowded)
+{
+    const int lpp = c / 4;
+    const int64_t total = (int64_t)crowded[0] * lpp;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t k = e / lpp;
+        const int ch = (int)(e - k * lpp) * 4;
+        const int64_t cell = crowded[1 + k];
+        const int x = (int)(cell % w), y = (int)((cell / w) % h);
+        int b[4], en[4];
+        bg_bounds(seg_offsets, cell, x, y, w, b, en);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int tap = 0; tap < 4; ++tap) {
+            for (int q = b[tap]; q < en[tap]; q += BG_U) {                       // the last batch loads its tail from the segment's last row and skips it
+                float4 wq[BG_U], gq[BG_U];
+#pragma unroll
+                for (int u = 0; u < BG_U; ++u) {
+                    const int qq = min(q + u, en[tap] - 1);
+                    wq[u] = wts[qq];
+                    gq[u] = load4<G_BF16>(g_sorted, (int64_t)qq * c + ch);
+                }
+#pragma unroll
+                for (int u = 0; u < BG_U; ++u) {
+                    const float wt = tap == 0 ? wq[u].x : tap == 1 ? wq[u].y : tap == 2 ? wq[u].z : wq[u].w;
+                    if (q + u >= en[tap] || wt == 0.f) continue;
+                    acc.x += wt * gq[u].x; acc.y += wt * gq[u].y; acc.z += wt * gq[u].z; acc.w += wt * gq[u].w;
+                }
+            }
+        }
+        store4<OUT_BF16>(grad_fmap, cell * c + ch, acc);
+    }
+}
+
 extern "C" int pcacc_bilinear_base_cells(const float *points, const int32_t *map_idx, int64_t k, int n_maps, int h, int w,
                                          float x_scale, float y_scale, int32_t *cell, void *stream)
 {
@@ -300,7 +352,9 @@ extern "C" int pcacc_bilinear_base_cells(const float *points, const int32_t *map
 extern "C" int pcacc_bilinear_sorted_workspace_bytes(int64_t k, int c, int grad_dtype, size_t *bytes)
 {
     if (!bytes || k < 0 || c <= 0 || (c % 4) || (grad_dtype != PCACC_F32 && grad_dtype != PCACC_BF16)) return PCACC_E_ARG;
-    *bytes = pcacc_align((size_t)k * 16) + pcacc_align((size_t)k * c * (grad_dtype == PCACC_BF16 ? 2 : 4));
+    // tap weights, gradient rows in CSR order, and the work list of crowded cells: its count + at most 4 k / (BG_CROWD + 1) cells (a crowded cell reads a segment
+    // of more than BG_CROWD points, and a segment is read by four cells)
+    *bytes = pcacc_align((size_t)k * 16) + pcacc_align((size_t)k * c * (grad_dtype == PCACC_BF16 ? 2 : 4)) + pcacc_align(((size_t)k / 2 + 8) * 4);
     return PCACC_OK;
 }
 
@@ -318,10 +372,11 @@ extern "C" int pcacc_bilinear_gather_backward_sorted(const void *grad_out, int g
     hipStream_t s = pcacc_stream(stream);
     float4 *wts = reinterpret_cast<float4 *>(workspace);
     void *g_sorted = static_cast<char *>(workspace) + pcacc_align((size_t)k * 16);
+    int *crowded = reinterpret_cast<int *>(static_cast<char *>(g_sorted) + pcacc_align((size_t)k * c * (grad_dtype == PCACC_BF16 ? 2 : 4)));
     if (k > 0) {
         const int pgrid = pcacc_grid(k * (c / 4), 256);
-        if (grad_dtype == PCACC_BF16) bilinear_sorted_prep_kernel<1><<<pgrid, 256, 0, s>>>(grad_out, c, h, w, points, order, k, x_scale, y_scale, wts, g_sorted);
-        else bilinear_sorted_prep_kernel<0><<<pgrid, 256, 0, s>>>(grad_out, c, h, w, points, order, k, x_scale, y_scale, wts, g_sorted);
+        if (grad_dtype == PCACC_BF16) bilinear_sorted_prep_kernel<1><<<pgrid, 256, 0, s>>>(grad_out, c, h, w, points, order, k, x_scale, y_scale, wts, g_sorted, crowded);
+        else bilinear_sorted_prep_kernel<0><<<pgrid, 256, 0, s>>>(grad_out, c, h, w, points, order, k, x_scale, y_scale, wts, g_sorted, crowded);
     }
     if (k == 0) {                                                               // no point: every cell's sum is empty (the kernel reads row 0 unconditionally)
         const size_t esz = out_dtype == PCACC_BF16 ? 2 : 4;
@@ -330,7 +385,9 @@ extern "C" int pcacc_bilinear_gather_backward_sorted(const void *grad_out, int g
     }
     // many short workgroups: the per-cell loops are as long as the cell is crowded, a fine grid evens that out
     const int grid = pcacc_grid((int64_t)n_maps * ((h + 3) / 4) * ((w + 3) / 4) * 16 * (c / 4), 256, PCACC_CUS * 64);
-#define BGS(GB, OB) bilinear_gather_bwd_sorted_kernel<GB, OB><<<grid, 256, 0, s>>>(g_sorted, wts, n_maps, h, w, c, seg_offsets, grad_fmap)
+    const int cgrid = pcacc_grid(((int64_t)k / 2 + 8) * (c / 4), 256, PCACC_CUS * 8);
+#define BGS(GB, OB) do { bilinear_gather_bwd_sorted_kernel<GB, OB><<<grid, 256, 0, s>>>(g_sorted, wts, n_maps, h, w, c, seg_offsets, grad_fmap, crowded); \
+                         bilinear_gather_bwd_crowded_kernel<GB, OB><<<cgrid, 256, 0, s>>>(g_sorted, wts, h, w, c, seg_offsets, grad_fmap, crowded); } while (0)
     if (grad_dtype == PCACC_BF16) { if (out_dtype == PCACC_BF16) BGS(1, 1); else BGS(1, 0); }
     else { if (out_dtype == PCACC_BF16) BGS(0, 1); else BGS(0, 0); }
 #undef BGS
