@@ -30,6 +30,9 @@ import time
 # with long chains of small dependent kernels (mixed, four sequences: median 30.9 -> 30.5 ms over six interleaved pairs, tools/gpu_r04_kernarg.sh).
 # Read by the HIP runtime when it initialises: set before the first GPU call; an explicit setting in the environment wins.
 os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')
+# This pool's host driver only supports dmabuf IPC: with the legacy mode RCCL (and any sharing of device memory between processes) fails with
+# `hipIpcGetMemHandle: invalid argument`.  The image exports it; a launcher that builds its own environment may not.  An explicit setting wins.
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
