@@ -837,6 +837,43 @@ def test_bilinear_gather_backward_sorted_matches_atomic():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('per_cell', [9, 16, 17, 33, 150])
+def test_bilinear_backward_crowded_cells_take_the_work_list(per_cell):
+    """Cells that read a segment of more than 8 points are summed by the crowded-cell kernel from a device work list (csrc/bilinear.hip).  The densest
+    list the workspace must hold: isolated base cells of exactly 9 points each -- every such segment makes FOUR cells crowded (4 k / 9 entries against
+    a capacity of k / 2 + 8); longer segments exercise the 16-point batches and their clamped tails.  Against the atomic kernel (same products,
+    another summation order) and against itself (index-ordered sums: identical while no segment exceeds 64 points)."""
+    import torch
+    from pcaccumulation_amd import native
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(per_cell)
+    n_maps, h, w, c = 2, 48, 60, 32
+    cells = [(m, y, x) for m in range(n_maps) for y in range(1, h - 2, 3) for x in range(1, w - 2, 3)]      # base cells three apart: their 2 x 2 taps never meet
+    base = torch.tensor(cells, dtype=torch.float32).repeat_interleave(per_cell, dim=0)
+    k = base.shape[0]
+    frac = torch.rand(k, 2, generator=g) * 0.8 + 0.1                       # strictly inside the base cell: four non-zero taps
+    px = (base[:, 2] + frac[:, 0] + 0.5) * 2.0 / w - 1.0                   # pixel centre convention of grid_sample(align_corners=False)
+    py = (base[:, 1] + frac[:, 1] + 0.5) * 2.0 / h - 1.0
+    pts = torch.stack((px, py, torch.zeros(k)), dim=1)
+    perm = torch.randperm(k, generator=g)                                   # points of a cell are not neighbours in memory
+    pts, idx = pts[perm].contiguous().to(dev), base[perm, 0].to(torch.int32).to(dev)
+    go = torch.randn(k, c, generator=g).to(dev)
+    ref = native.bilinear_gather_backward(go, (n_maps, h, w, c), pts, idx, 1.0, 1.0)
+    got = native.bilinear_gather_backward_sorted(go, (n_maps, h, w, c), pts, idx, 1.0, 1.0)
+    touched = (ref != 0).any(dim=3).float().mean().item()
+    assert touched > 0.35, touched                                           # 4 of every 9 cells receive a gradient: the taps really spread
+    assert (got - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
+    again = native.bilinear_gather_backward_sorted(go, (n_maps, h, w, c), pts, idx, 1.0, 1.0)
+    if per_cell <= 64:
+        assert torch.equal(got, again)
+    else:
+        assert (got - again).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
+    g16 = native.bilinear_gather_backward_sorted(go.to(torch.bfloat16), (n_maps, h, w, c), pts, idx, 1.0, 1.0, out_dtype=torch.bfloat16)
+    r16 = native.bilinear_gather_backward_sorted(go.to(torch.bfloat16).float(), (n_maps, h, w, c), pts, idx, 1.0, 1.0)
+    assert (g16.float() - r16).abs().max().item() <= 2 ** -7 * max(1.0, r16.abs().max().item())
+
+
+@pytest.mark.gpu
 def test_two_level_segment_max_bf16_rows():
     """Long segments (per-instance poolings): bf16 rows reduced to f32 results, identical to the f32-row reduction; backward writes
     bf16 rows from an f32 gradient."""
