@@ -193,11 +193,28 @@ __device__ __forceinline__ void csp_prepare_row(const float *__restrict__ w, int
         const int ft = src_tap / 9, fy = (src_tap % 9) / 3, fx = src_tap % 3;
         return w[so * st.o + si * st.i + ft * st.t + fy * st.y + fx * st.x];
     };
+    // [r5] a row of up to CSP_PREP_KEEP * 256 elements (every layer of the model: 9 x 512 = 4 608) is read ONCE and kept in registers between the maximum
+    // pass and the split pass -- the rows of the data-gradient form are gathers of single floats at a stride of 9 c_in, and reading them twice was most of
+    // the 250 us the batched preparation takes at the head of every step
+    constexpr int CSP_PREP_KEEP = 18;
+    const bool keep = n <= CSP_PREP_KEEP * 256;
+    float kept[CSP_PREP_KEEP];
     float m = 0.f;
-    for (int e = threadIdx.x; e < n; e += 256) {
-        const float v = src(e);
-        m = fmaxf(m, fabsf(v));
-        if (v != v) m = __builtin_inff();
+    if (keep) {
+#pragma unroll
+        for (int j = 0; j < CSP_PREP_KEEP; ++j) {
+            const int e = threadIdx.x + j * 256;
+            const float v = e < n ? src(e) : 0.f;
+            kept[j] = v;
+            m = fmaxf(m, fabsf(v));
+            if (v != v) m = __builtin_inff();
+        }
+    } else {
+        for (int e = threadIdx.x; e < n; e += 256) {
+            const float v = src(e);
+            m = fmaxf(m, fabsf(v));
+            if (v != v) m = __builtin_inff();
+        }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
@@ -207,14 +224,23 @@ __device__ __forceinline__ void csp_prepare_row(const float *__restrict__ w, int
     const float t = csp_scale_of(fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3])));
     if (threadIdx.x == 0) (transpose ? inv_bwd : inv_fwd)[row] = 1.f / t;
     uint16_t *dst = transpose ? out_bwd : out_fwd;
-    for (int e = threadIdx.x; e < n; e += 256) {
+    auto put = [&](int e, float raw) {
         const int tap = e / ip, ci = e - tap * ip;
-        const float v = src(e) * t;
+        const float v = raw * t;
         const _Float16 hi = (_Float16)v;
         const _Float16 lo = (_Float16)(v - (float)hi);
         const int64_t r = ((int64_t)tap * op + row) * ip + ci;
         dst[r] = *reinterpret_cast<const uint16_t *>(&hi);
         dst[total + r] = *reinterpret_cast<const uint16_t *>(&lo);
+    };
+    if (keep) {
+#pragma unroll
+        for (int j = 0; j < CSP_PREP_KEEP; ++j) {
+            const int e = threadIdx.x + j * 256;
+            if (e < n) put(e, kept[j]);
+        }
+    } else {
+        for (int e = threadIdx.x; e < n; e += 256) put(e, src(e));
     }
 }
 
