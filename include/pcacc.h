@@ -145,6 +145,11 @@ int pcacc_segment_sum(const float *src, int c, const int32_t *seg_offsets, const
  * either type, results always f32.  max_backward: grad_out and grad_src types are independent. */
 int pcacc_segment_max_t(const void *src, int dtype, int c, const int32_t *seg_offsets, const int32_t *order, int64_t n,
                         int64_t m, void *out, int32_t *arg, void *workspace, size_t workspace_bytes, void *stream);
+/* segment_max on f32 rows of SHORT segments with a second output: out16 [m,c] = `out` rounded to bf16, from the same store (the 'mixed' mode's
+ * shadow of the pooled rows: models/pillar_encoder.py:116,120 -- it was a conversion pass over [m,c] after each of the three poolings).
+ * PCACC_E_ARG when the segments are long (n / m > 16: the two-level reduction has no second output). */
+int pcacc_segment_max_dual(const float *src, int c, const int32_t *seg_offsets, const int32_t *order, int64_t n, int64_t m, float *out,
+                           uint16_t *out16, int32_t *arg, void *workspace, size_t workspace_bytes, void *stream);
 int pcacc_segment_max_backward_t(const void *grad_out, int dtype, const int32_t *arg, const int32_t *p2v, int64_t n, int c,
                                  void *grad_src, int out_dtype, void *stream);
 int pcacc_segment_sum_t(const void *src, int dtype, int c, const int32_t *seg_offsets, const int32_t *order, int64_t n,

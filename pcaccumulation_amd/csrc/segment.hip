@@ -224,7 +224,8 @@ extern "C" int pcacc_segment_mean3_maxlabel(const float *points, const int64_t *
 template <int LPP>   // lanes per pillar = c / 4
 __global__ __launch_bounds__(256) void seg_max_kernel(const void *__restrict__ src, const int32_t *__restrict__ seg_offsets,
                                                       const int32_t *__restrict__ order, int64_t m,
-                                                      void *__restrict__ out, int4 *__restrict__ arg, bool bf)
+                                                      void *__restrict__ out, int4 *__restrict__ arg, bool bf,
+                                                      uint16_t *__restrict__ out16 = nullptr)      // out16 (f32 rows): a bf16 copy of `out` from the same store ('mixed' mode shadow)
 {
     const int sub = threadIdx.x % LPP;
     const int64_t per_block = 256 / LPP;
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(256) void seg_max_kernel(const void *__restrict__ s
             }
         }
         pcacc_st4(out, bf, s * LPP + sub, best);
+        if (out16) reinterpret_cast<uint2 *>(out16)[s * LPP + sub] = make_uint2(pcacc_pack_bf16x2(best.x, best.y), pcacc_pack_bf16x2(best.z, best.w));
         arg[s * LPP + sub] = bi;
     }
 }
@@ -421,13 +423,14 @@ static int seg_two_level(const void *src, bool src_bf, int c, const int32_t *seg
 }
 
 static int segment_max_any(const void *src, int dtype, int c, const int32_t *seg_offsets, const int32_t *order, int64_t n, int64_t m,
-                           void *out, int32_t *arg, void *workspace, size_t workspace_bytes, void *stream)
+                           void *out, int32_t *arg, void *workspace, size_t workspace_bytes, void *stream, uint16_t *out16 = nullptr)
 {
     if (m < 0 || n < 0 || c <= 0 || (c % 4) || c > 256 || (dtype != PCACC_F32 && dtype != PCACC_BF16)) return PCACC_E_ARG;
     const bool bf = dtype == PCACC_BF16;
     if (m > 0 && (!seg_offsets || !out || !arg || (n > 0 && (!src || !order)))) return PCACC_E_ARG;
     if (m == 0) return PCACC_OK;
     hipStream_t s = pcacc_stream(stream);
+    if (out16 && (dtype != PCACC_F32 || seg_use_two_level(n, m))) return PCACC_E_ARG;      // the second output exists on the short-segment f32 path only
     if (seg_use_two_level(n, m)) {
         // long segments: rows in either type, result always f32 (m is small)
         const int rc = seg_two_level<true>(src, bf, c, seg_offsets, order, n, m, reinterpret_cast<float *>(out), arg, workspace,
@@ -437,7 +440,7 @@ static int segment_max_any(const void *src, int dtype, int c, const int32_t *seg
         return PCACC_OK;
     }
     int4 *arg4 = reinterpret_cast<int4 *>(arg);
-#define LAUNCH(L) seg_max_kernel<L><<<pcacc_grid(m * L, 256), 256, 0, s>>>(src, seg_offsets, order, m, out, arg4, bf)
+#define LAUNCH(L) seg_max_kernel<L><<<pcacc_grid(m * L, 256), 256, 0, s>>>(src, seg_offsets, order, m, out, arg4, bf, out16)
     switch (c / 4) {
         case 1: LAUNCH(1); break;
         case 2: LAUNCH(2); break;
@@ -463,6 +466,13 @@ extern "C" int pcacc_segment_max_t(const void *src, int dtype, int c, const int3
                                    int64_t m, void *out, int32_t *arg, void *workspace, size_t workspace_bytes, void *stream)
 {
     return segment_max_any(src, dtype, c, seg_offsets, order, n, m, out, arg, workspace, workspace_bytes, stream);
+}
+
+extern "C" int pcacc_segment_max_dual(const float *src, int c, const int32_t *seg_offsets, const int32_t *order, int64_t n, int64_t m, float *out,
+                                      uint16_t *out16, int32_t *arg, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!out16) return PCACC_E_ARG;
+    return segment_max_any(src, PCACC_F32, c, seg_offsets, order, n, m, out, arg, workspace, workspace_bytes, stream, out16);
 }
 
 // grad_src[i,k] = (arg[p2v[i],k] == i) ? grad_out[p2v[i],k] : 0        (fully coalesced, no atomics)

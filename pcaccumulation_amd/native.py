@@ -48,7 +48,7 @@ EXPORTS = [
     'pcacc_sinkhorn_kabsch_workspace_bytes', 'pcacc_sinkhorn_kabsch', 'pcacc_chamfer_workspace_bytes', 'pcacc_chamfer_forward', 'pcacc_chamfer_backward',
     'pcacc_cluster_workspace_bytes', 'pcacc_cluster', 'pcacc_conv3x3_prepare_weights', 'pcacc_conv3x3_bf16',
     'pcacc_rows_linear_bf16', 'pcacc_rows_linear_mixed', 'pcacc_rows_wgrad_mixed',
-    'pcacc_segment_max_t', 'pcacc_segment_max_backward_t', 'pcacc_segment_max_backward_acc', 'pcacc_segment_sum_t', 'pcacc_rows_wgrad_bf16_workspace_bytes', 'pcacc_rows_wgrad_bf16', 'pcacc_sample_subsets', 'pcacc_conv3x3_wgrad_workspace_bytes', 'pcacc_conv3x3_wgrad_bf16', 'pcacc_upload_words', 'pcacc_bilinear_base_cells', 'pcacc_bilinear_sorted_workspace_bytes', 'pcacc_bilinear_gather_backward_sorted', 'pcacc_prep_points',
+    'pcacc_segment_max_t', 'pcacc_segment_max_dual', 'pcacc_segment_max_backward_t', 'pcacc_segment_max_backward_acc', 'pcacc_segment_sum_t', 'pcacc_rows_wgrad_bf16_workspace_bytes', 'pcacc_rows_wgrad_bf16', 'pcacc_sample_subsets', 'pcacc_conv3x3_wgrad_workspace_bytes', 'pcacc_conv3x3_wgrad_bf16', 'pcacc_upload_words', 'pcacc_bilinear_base_cells', 'pcacc_bilinear_sorted_workspace_bytes', 'pcacc_bilinear_gather_backward_sorted', 'pcacc_prep_points',
     'pcacc_kabsch_cov_forward', 'pcacc_kabsch_cov_backward', 'pcacc_kabsch_rt_forward', 'pcacc_kabsch_rt_backward', 'pcacc_ego_affinity_forward', 'pcacc_ego_affinity_backward_workspace_bytes', 'pcacc_ego_affinity_backward', 'pcacc_ego_perm_forward', 'pcacc_ego_perm_backward',
     'pcacc_sinkhorn_train_workspace_bytes', 'pcacc_sinkhorn_forward', 'pcacc_sinkhorn_backward',
     'pcacc_seg_loss_workspace_bytes', 'pcacc_seg_loss_forward', 'pcacc_seg_loss_backward',
@@ -284,6 +284,20 @@ def segment_max(src, offs, order, m):
                                      _i64(n), _i64(m), _dev(out), _dev(arg), _dev(ws), ctypes.c_size_t(ws.numel()), _stream()),
            'segment_max')
     return out, arg
+
+
+def segment_max_dual(src, offs, order, m):
+    """segment_max on f32 rows of short segments -> (out [m,c] f32, out as bf16, arg [m,c] i32): the 'mixed' mode's shadow from the same store."""
+    n, c = src.shape
+    if _seg_two_level(n, m):
+        raise NativeError('segment_max_dual: long segments (n / m > 16) have no second output')
+    out = torch.empty((m, c), dtype=torch.float32, device=src.device)
+    out16 = torch.empty((m, c), dtype=torch.bfloat16, device=src.device)
+    arg = torch.empty((m, c), dtype=torch.int32, device=src.device)
+    ws = _segment_ws(n, m, c, src.device)
+    _check(lib().pcacc_segment_max_dual(_dev(src, torch.float32, 'src'), int(c), _dev(offs, torch.int32), _dev(order, torch.int32), _i64(n), _i64(m),
+                                        _dev(out), _dev(out16), _dev(arg), _dev(ws), ctypes.c_size_t(ws.numel()), _stream()), 'segment_max_dual')
+    return out, out16, arg
 
 
 def segment_max_backward(grad_out, arg, p2v, n, out_dtype=None):

@@ -80,6 +80,9 @@ class PillarIndex(object):
 
 
 # ---------------------------------------------------------------------------------------------------
+_SEGMAX_DUAL = os.environ.get('PCACC_SEGMAX_DUAL', '1') != '0'      # A/B switch: '0' = the pooled rows' bf16 shadow by a conversion pass of its own (before round 5)
+
+
 class _SegmentMax(torch.autograd.Function):
     """scatter(net, p2v, dim=0, reduce='max') -- models/pillar_encoder.py:116,120."""
 
@@ -89,8 +92,12 @@ class _SegmentMax(torch.autograd.Function):
         mixed = _MIXED and src.dtype == torch.bfloat16 and twin(src, required=False) is not None
         if mixed:                                                  # shadow rows: maxima AND winners from the fp32 twin (a bf16 copy ties close values)
             s32 = twin(src)
-            out, arg = native.segment_max(s32, pidx.seg_offsets, pidx.order, pidx.m)
-            out = shadow(carry_amax(s32, out))
+            if _SEGMAX_DUAL and s32.dtype == torch.float32 and s32.is_contiguous() and not native._seg_two_level(s32.shape[0], pidx.m):
+                out, out16, arg = native.segment_max_dual(s32, pidx.seg_offsets, pidx.order, pidx.m)   # the shadow from the same store, not a pass of its own
+                out = shadow(carry_amax(s32, out), out16)
+            else:
+                out, arg = native.segment_max(s32, pidx.seg_offsets, pidx.order, pidx.m)
+                out = shadow(carry_amax(s32, out))
         else:
             out, arg = native.segment_max(src if src.dtype in (torch.float32, torch.bfloat16) else src.float(), pidx.seg_offsets,
                                           pidx.order, pidx.m)
