@@ -34,6 +34,97 @@ os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')
 # `hipIpcGetMemHandle: invalid argument`.  The image exports it; a launcher that builds its own environment may not.  An explicit setting wins.
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
+
+
+def _descendants(pid):
+    """pids of every live descendant of `pid` (torch.distributed.run gives each rank a session of its own: walk /proc by parent pid)."""
+    parent = {}
+    for d in os.listdir('/proc'):
+        if d.isdigit():
+            try:
+                with open('/proc/%s/stat' % d) as f:
+                    parent[int(d)] = int(f.read().rsplit(')', 1)[1].split()[1])
+            except (OSError, ValueError, IndexError):
+                pass
+    out, todo = [], [pid]
+    while todo:
+        p = todo.pop()
+        kids = [c for c, pp in parent.items() if pp == p]
+        out += kids
+        todo += kids
+    return out
+
+
+def self_launch(argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (no WORLD_SIZE / TORCHELASTIC_RUN_ID in the environment): this process -- which has
+    imported nothing that touches a GPU -- starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py <same arguments>`
+    as a CHILD (never an exec), relays its output (rank 0's JSON line on stdout) and its exit status, and kills the whole tree (the ranks live in sessions of their
+    own) when PCACC_BENCH_LAUNCH_TIMEOUT seconds (default 1800) pass or this process is told to stop.  Returns the exit status, or None when this process
+    is to run the bench itself (N = 1, or already one rank of a launch)."""
+    n = 1
+    for i, a in enumerate(argv):
+        if a == '--gpus' and i + 1 < len(argv):
+            n = argv[i + 1]
+        elif a.startswith('--gpus='):
+            n = a.split('=', 1)[1]
+    try:
+        n = int(n)
+    except ValueError:
+        return None                                             # argparse reports it
+    if n <= 1 or 'WORLD_SIZE' in os.environ or 'TORCHELASTIC_RUN_ID' in os.environ or 'RANK' in os.environ:
+        return None
+    import signal
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    try:
+        limit = float(os.environ.get('PCACC_BENCH_LAUNCH_TIMEOUT', '1800'))
+    except ValueError:
+        limit = 1800.0
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.abspath(__file__)] + list(argv)
+    print('[bench] --gpus %d without a launcher: starting %s' % (n, ' '.join(cmd[1:9])), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, start_new_session=True)      # stdout / stderr inherited: rank 0's line is this process's line
+
+    def kill_tree(*_):
+        tree = _descendants(proc.pid)
+        try:
+            proc.send_signal(signal.SIGTERM)                    # the launcher's handler ends its ranks
+            proc.wait(timeout=10)
+        except (OSError, subprocess.TimeoutExpired):
+            pass
+        for p in tree + _descendants(proc.pid) + [proc.pid]:
+            try:
+                os.kill(p, signal.SIGKILL)
+            except OSError:
+                pass
+    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sig, lambda *a: (kill_tree(), os._exit(128 + a[0])))
+    try:
+        rc = proc.wait(timeout=limit)
+    except subprocess.TimeoutExpired:
+        print('[bench] the %d-rank launch did not finish within %.0f s: killing its process tree' % (n, limit), file=sys.stderr, flush=True)
+        kill_tree()
+        return 124
+    finally:
+        for p in _descendants(proc.pid):                        # stragglers (none after a clean exit)
+            try:
+                os.kill(p, signal.SIGKILL)
+            except OSError:
+                pass
+    return rc if rc >= 0 else 128 - rc
+
+
+if __name__ == '__main__':
+    _rc = self_launch(sys.argv[1:])                             # before torch is imported: the parent of a launch makes no GPU call at all
+    if _rc is not None:
+        sys.exit(_rc)
+
+_PARENT_AT_IMPORT = os.getppid()
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -139,7 +230,9 @@ def die_with_launcher():
         import ctypes
         import signal
         ctypes.CDLL('libc.so.6', use_errno=True).prctl(1, int(signal.SIGKILL), 0, 0, 0)
-        if os.getppid() == 1:                                   # the launcher went between fork and prctl
+        # the launcher went between fork and prctl: the parent CHANGED since this module was imported.  (A parent that was pid 1 all along is a launcher that
+        # is the container's entry point -- `python -m torch.distributed.run` as PID 1 under docker / k8s -- and very much alive: ADVICE round 5.)
+        if os.getppid() != _PARENT_AT_IMPORT:
             os._exit(1)
     except (OSError, AttributeError):
         pass
@@ -333,7 +426,7 @@ def step_model(stepper, batcher, feed):
     return tot
 
 
-def config_throughput(kind, name, dataset, T, ppf, batch, mode, steps, warmup, device):
+def config_throughput(kind, name, dataset, T, ppf, batch, mode, steps, warmup, device, points='uniform'):
     """Throughput of one BASELINE.json configuration: kind 'train' = this file's training step (voxelise + collate, forward, FuseLoss, backward,
     clip, fused Adam through DataParallelStep, next batch prefetched), kind 'eval' = voxelise + collate + MotionNet forward under no_grad."""
     cfg = default_config(dataset, 'train' if kind == 'train' else 'val', n_sweeps=T)
@@ -342,7 +435,7 @@ def config_throughput(kind, name, dataset, T, ppf, batch, mode, steps, warmup, d
     batcher = DeviceBatcher(cfg)
     if kind == 'train':
         model, opt, loss_fn = build(cfg, device)
-        scenes = [sample_to_device(make_sequence(100 + i, T, ppf, cfg), device) for i in range(2 * batch)]
+        scenes = [sample_to_device(make_sequence(100 + i, T, ppf, cfg, mode='lidar_scan' if points == 'lidar' else 'uniform'), device) for i in range(2 * batch)]
         batch_of = lambda i: [scenes[(i * batch + j) % len(scenes)] for j in range(batch)]
         stepper = pdist.DataParallelStep(model, opt, loss_fn, iter_size=1, grad_clip=cfg['train']['grad_clip'])
         feed = BatchFeed(batcher, batch_of, True)
@@ -350,7 +443,7 @@ def config_throughput(kind, name, dataset, T, ppf, batch, mode, steps, warmup, d
     else:
         torch.manual_seed(0)
         model = MotionNet(cfg).to(device).channels_last_().eval()
-        scenes = [sample_to_device(make_sequence(100 + i, T, ppf, cfg), device) for i in range(batch)]
+        scenes = [sample_to_device(make_sequence(100 + i, T, ppf, cfg, mode='lidar_scan' if points == 'lidar' else 'uniform'), device) for i in range(batch)]
 
         def run():
             with torch.no_grad():
@@ -364,12 +457,15 @@ def config_throughput(kind, name, dataset, T, ppf, batch, mode, steps, warmup, d
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     return dict(config=name, kind='train step' if kind == 'train' else 'eval forward (voxelise + MotionNet)', dataset=dataset, frames=T, pts_per_frame=ppf,
-                sequences_per_step=batch, dtype=mode, ms_per_step=round(dt * 1e3, 3), lidar_frames_per_s=round(batch * T / dt, 1), steps=steps, warmup=warmup)
+                sequences_per_step=batch, dtype=mode, points=points, ms_per_step=round(dt * 1e3, 3), lidar_frames_per_s=round(batch * T / dt, 1), steps=steps, warmup=warmup)
 
 
 # the other BASELINE.json configurations beside the headline (c3, 4 sequences per step): (kind, name, dataset, frames, points per frame, sequences per step)
-OTHER_CONFIGS = [('eval', 'c2', 'nuscene', 5, 80000, 4), ('train', 'c3', 'waymo', 5, 160000, 1), ('eval', 'c4', 'waymo', 10, 200000, 2),
-                 ('train', 'c5', 'nuscene', 5, 80000, 4)]
+OTHER_CONFIGS = [('eval', 'c2', 'nuscene', 5, 80000, 4, 'uniform'), ('train', 'c3', 'waymo', 5, 160000, 1, 'uniform'), ('eval', 'c4', 'waymo', 10, 200000, 2, 'uniform'),
+                 ('train', 'c5', 'nuscene', 5, 80000, 4, 'uniform'),
+                 # the headline's step on LiDAR-distributed points (1/r range density, 64 beams, scan order; 10 % foreground in 20 boxes): real sweeps are not
+                 # uniform, and a kernel that is fast on uniform points can hide a factor behind them (the bilinear backward did for two rounds)
+                 ('train', 'c3_lidar', 'waymo', 5, 160000, 4, 'lidar')]
 
 
 def scatter_flushed(dtype, batch, pillars):
@@ -444,7 +540,8 @@ def main():
     rank, world, local_rank = pdist.init_from_env(backend)
     watchdog.arm('process group up (world %d)' % world, first=True)
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit('--gpus %d needs torch.distributed.run with --nproc-per-node %d' % (args.gpus, args.gpus))
+        raise SystemExit('--gpus %d inside a launch of %d rank(s): start `python bench.py --gpus %d` without a launcher (it starts its own ranks) or give '
+                         'torch.distributed.run --nproc-per-node %d' % (args.gpus, world, args.gpus, args.gpus))
     device = torch.device('cuda', local_rank % n_dev)
     torch.cuda.set_device(device)
     pdist.per_rank_library_cache(rank, world)
@@ -484,6 +581,7 @@ def main():
     torch.cuda.synchronize()
     watchdog.arm('warm-up done, barrier passed')
     collectives_before = stepper.reducer.collectives
+    stepper.reducer.time_exposed = world > 1 or stepper.reducer.active
     t0 = time.perf_counter()
     marks = []                                                          # one event per step boundary on the main stream: the spread of the K steps
     for i in range(args.steps):
@@ -500,7 +598,18 @@ def main():
     watchdog.arm('timed steps done')
     collectives_per_step = (stepper.reducer.collectives - collectives_before) / max(args.steps, 1)
     stepper_buckets = list(stepper.reducer.buckets)
-    dt = pdist.max_over_ranks(time.perf_counter() - t0, device)
+    dt_own = time.perf_counter() - t0
+    dt = pdist.max_over_ranks(dt_own, device)
+    stepper.reducer.time_exposed = False
+    exposed = [a.elapsed_time(b) for a, b in stepper.reducer.exposed_events]
+    # what makes the first real N > 1 run diagnosable: every rank's own wall clock per step, the part of the gradient all-reduce that the backward did not
+    # cover (device time the main stream spent waiting in reducer.finish), and who reported -- gathered from all ranks, printed by rank 0
+    mine = {'rank': rank, 'ms_per_step': dt_own / max(args.steps, 1) * 1e3, 'exposed_allreduce_ms': (sum(exposed) / len(exposed)) if exposed else 0.0,
+            'device': '%s:%d' % (os.uname().nodename, device.index or 0)}
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        torch.distributed.all_gather_object(per_rank, mine)
     timer, native.scatter_timer = native.scatter_timer, None
     per_step_in_order = [a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:])]
     per_step = sorted(per_step_in_order)
@@ -613,7 +722,9 @@ def main():
                        'HIP_FORCE_DEV_KERNARG': os.environ.get('HIP_FORCE_DEV_KERNARG')},
             'distributed': {'world_size': world, 'backend': (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
                             'device': str(device), 'ranks_per_device': max(1, world // n_dev) if world > n_dev else 1, 'gpu_bring_up_in_turn': took_turns,
-                            'collectives_per_step': collectives_per_step, 'gradient_buckets': len(stepper_buckets), 'bucket_mb': [round(4e-6 * (e - b), 2) for b, e in stepper_buckets]},
+                            'collectives_per_step': collectives_per_step, 'gradient_buckets': len(stepper_buckets), 'bucket_mb': [round(4e-6 * (e - b), 2) for b, e in stepper_buckets],
+                            'ranks_seen': sorted(r['rank'] for r in per_rank if r), 'per_rank_ms_per_step': [round(r['ms_per_step'], 3) for r in per_rank if r],
+                            'exposed_allreduce_ms': [round(r['exposed_allreduce_ms'], 3) for r in per_rank if r], 'rank_devices': [r['device'] for r in per_rank if r]},
             'roofline': {'kernel': 'pillar_scatter_rows16_k<1, true, true> (BEV canvas fill, bf16 rows -> bf16 canvas, streaming loads / stores)' if main_bf16 else 'pillar_scatter_vec4<0> (BEV canvas fill)', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
                          'traffic_source': 'PMC FETCH_SIZE x2 + WRITE_SIZE (calibrated on a 128 MiB copy), profiles/%s' % pmc_file,
@@ -653,9 +764,9 @@ def main():
             # the other BASELINE configurations on the same tree, a few steps each: the certified mode ('mixed' for train steps, its forward alone =
             # 'fp32x3' for the eval-only configurations); profiles/r04_bench_configs.jsonl holds the longer runs incl. bf16
             rows = []
-            for kind, name, ds, T, ppf, b in OTHER_CONFIGS:
+            for kind, name, ds, T, ppf, b, pts in OTHER_CONFIGS:
                 try:
-                    rows.append(config_throughput(kind, name, ds, T, ppf, b, 'mixed' if kind == 'train' else 'fp32x3', 4, 2, device))
+                    rows.append(config_throughput(kind, name, ds, T, ppf, b, 'mixed' if kind == 'train' else 'fp32x3', 4, 2, device, points=pts))
                 except Exception as e:                                 # diagnostics must never take the bench line down
                     rows.append({'config': name, 'error': repr(e)})
                 torch.cuda.empty_cache()

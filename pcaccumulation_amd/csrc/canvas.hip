@@ -117,9 +117,12 @@ __global__ __launch_bounds__(256) void cm_count(const uint8_t *__restrict__ mask
 }
 
 __global__ __launch_bounds__(256) void cm_assign(const uint8_t *__restrict__ mask, int64_t n, const int *__restrict__ chunk_offsets,
-                                                 int64_t *__restrict__ indices, int64_t capacity)
+                                                 int64_t *__restrict__ indices, int64_t capacity, const int *__restrict__ total)
 {
     __shared__ int lds[4];
+    // [r6] entries behind the count hold -1, as torch.nonzero_static's tail does: a `capacity` above the true count (a stale host count) then gives a
+    // deterministic failure downstream instead of gathers through uninitialised int64 values.  No iteration when capacity == count.
+    for (int64_t j = (int64_t)*total + (int64_t)blockIdx.x * 256 + threadIdx.x; j < capacity; j += (int64_t)gridDim.x * 256) indices[j] = -1;
     const int64_t i0 = (int64_t)blockIdx.x * CM_CHUNK + threadIdx.x * 16;
     const uint32_t bits = i0 < n ? cm_nonzero_bits(mask, i0, n) : 0u;
     int tot;
@@ -152,8 +155,9 @@ extern "C" int pcacc_compact_mask(const uint8_t *mask, int64_t n, int64_t *indic
     int *sums = static_cast<int *>(workspace);
     const int chunks = (int)((n + CM_CHUNK - 1) / CM_CHUNK);
     cm_count<<<chunks, 256, 0, s>>>(mask, n, sums);
-    scan_chunk_sums<<<1, 1024, 0, s>>>(sums, chunks, count_out, -1);
-    cm_assign<<<chunks, 256, 0, s>>>(mask, n, sums, indices, capacity);
+    int *total = count_out ? count_out : sums + chunks;         // the workspace holds chunks + 1 words
+    scan_chunk_sums<<<1, 1024, 0, s>>>(sums, chunks, total, -1);
+    cm_assign<<<chunks, 256, 0, s>>>(mask, n, sums, indices, capacity, total);
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
 }

@@ -150,9 +150,11 @@ def ranks_share_a_device():
 
 
 def _idents_say_shared(idents):
-    """idents: per rank (host, hardware id, visibility mask, device index).  Two ranks share a device when they sit on one host with the same hardware id --
-    unless that id is uninformative there (a runtime that reports one id for every GPU of the host would turn the one-rank-per-GPU layout into 'shared' and
-    silently cost it the two-stream step): an id every rank of a host reports counts only if those ranks also use the same (mask, index)."""
+    """idents: per rank (host, hardware id, visibility mask, device index).  Two ranks share a device when they sit on one host with the same hardware id.
+    The hardware ids of a host's ranks are INFORMATIVE when they are not all equal: then they alone decide -- duplicated ids = shared, all distinct = one rank
+    per device, whatever (mask, index) say (cgroup / device-plugin isolation -- Slurm ConstrainDevices, ROCR masks behind one HIP_VISIBLE_DEVICES -- shows every
+    rank device index 0 under the same or an empty mask: ADVICE round 5).  Only an id every rank of the host reports (a runtime that names all GPUs alike, or
+    ranks that really share the device) falls back to the (mask, index) pairs: equal pairs = shared."""
     by_host = {}
     for host, hw, mask, index in idents:
         by_host.setdefault(host, []).append((hw, mask, index))
@@ -160,9 +162,10 @@ def _idents_say_shared(idents):
         if len(ranks) < 2:
             continue
         hws = [r[0] for r in ranks]
-        informative = len(set(hws)) > 1
-        if informative and len(set(hws)) < len(hws):
-            return True
+        if len(set(hws)) > 1:                                 # informative
+            if len(set(hws)) < len(hws):
+                return True
+            continue
         if len(set((r[1], r[2]) for r in ranks)) < len(ranks):
             return True
     return False
@@ -223,6 +226,8 @@ class BucketedGradReducer(object):
         # PCACC_FORCE_PROCESS_GROUP=1 asks for the production code path anyway (tests/test_bench_multirank.py: backend nccl at world size 1)
         self.active = self.world > 1 or (dist.is_initialized() and os.environ.get('PCACC_FORCE_PROCESS_GROUP') == '1')
         self.collectives = 0                                 # all-reduce calls issued so far (gradient buckets + agreement reduces)
+        self.time_exposed = False                            # True: finish() brackets its waits with events (exposed_events)
+        self.exposed_events = []
         dev, dtype = self.params[0].device, self.params[0].dtype
         order = list(reversed(range(len(self.params))))
         self.numel = sum(p.numel() for p in self.params)
@@ -374,11 +379,19 @@ class BucketedGradReducer(object):
             return
         self._limit = len(self._seq)
         self._launch_all()
+        timed = self.time_exposed and self.flat.is_cuda
+        if timed:                                             # the stretch of the current stream that waits for collectives still in flight after the
+            e0 = torch.cuda.Event(enable_timing=True)         # backward: the EXPOSED part of the all-reduce (bench.py reports its mean at N > 1)
+            e0.record()
         for work, b, averaged in self._works:
             work.wait()
             if not averaged:
                 s, e = self.buckets[b]
                 self.flat[s:e].div_(self.world)
+        if timed:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.exposed_events.append((e0, e1))
         self._works = []
         self._sync = False
         for i, p in enumerate(self.params):

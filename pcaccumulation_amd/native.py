@@ -221,13 +221,20 @@ def frame_pillars(cell2pillar, cells_per_frame, m):
 
 def compact_mask(mask, size):
     """mask [n] bool / uint8 (contiguous) -> [size] int64: the indices of its non-zero entries, ascending (torch.nonzero_static(mask, size=size)[:, 0] for a
-    `size` that equals the number of non-zeros -- the forward knows it from its host sync; entries beyond the count are left unwritten)."""
+    `size` that equals the number of non-zeros -- the forward knows it from its host sync; entries beyond the count hold -1, as nonzero_static's do).
+    A mask view that does not start on a 16-byte boundary is copied first (the kernel reads 16 mask bytes per lane)."""
     if mask.dtype not in (torch.bool, torch.uint8) or mask.dim() != 1:
         raise NativeError('compact_mask: a 1-D bool / uint8 mask expected, got %s %s' % (mask.dtype, tuple(mask.shape)))
     n, dev = mask.shape[0], mask.device
     out = torch.empty((int(size),), dtype=torch.int64, device=dev)
-    if n == 0 or size == 0:
+    if size == 0:
         return out
+    if n == 0:
+        return out.fill_(-1)
+    if mask.data_ptr() % 16 or not mask.is_contiguous():
+        mask = mask.clone(memory_format=torch.contiguous_format)
+        if mask.data_ptr() % 16:
+            raise NativeError('compact_mask: the allocator returned an unaligned block')
     need = ctypes.c_size_t(0)
     _check(lib().pcacc_compact_mask_workspace_bytes(_i64(n), ctypes.byref(need)), 'compact_mask_workspace')
     ws = _ws(need.value, dev)

@@ -143,3 +143,27 @@ def test_single_rank_line_keeps_the_contract():
     r = d['roofline']
     assert r['bound'] == 'hbm' and r['peak'] == 8000.0 and r['unit'] == 'GB/s' and 0.05 < r['frac'] < 1.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
     assert d['config']['step_variant'].startswith('staged') and 'cpu_affinity' in d['config'] and 'early_backward_thread' in d['config']
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2 ...` WITHOUT a launcher around it: the parent -- which imports nothing that touches the GPU before
+    it decides -- starts `python -m torch.distributed.run --nproc-per-node 2 bench.py ...` as a child process, relays rank 0's ONE JSON line and the exit
+    status.  Two gloo ranks on the one GPU of the test box; the line carries what makes a first real scaling run diagnosable (every rank's own step time,
+    the exposed part of the all-reduce, which ranks reported)."""
+    env = dict(os.environ, PCACC_DIST_BACKEND='gloo', PCACC_HANG_DUMP='45', PCACC_BENCH_TRACE='1', PCACC_BENCH_LAUNCH_TIMEOUT='160')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'TORCHELASTIC_RUN_ID', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '2', '--batch', '2', '--no-cpu-baseline', '--no-fp32-leg',
+           '--no-step-model']
+    t0 = time.time()
+    rc, out, err = run_tree(cmd, env, 200)
+    assert rc == 0, 'rc %r after %.0f s\n--- stderr tail ---\n%s' % (rc, time.time() - t0, err[-6000:])
+    lines = [l for l in out.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 3 and d['config']['parallelism'] == 'dp2' and d['value'] > 0
+    dist = d['distributed']
+    assert dist['backend'] == 'gloo' and dist['ranks_seen'] == [0, 1]
+    assert len(dist['per_rank_ms_per_step']) == 2 and all(t > 0 for t in dist['per_rank_ms_per_step'])
+    assert len(dist['exposed_allreduce_ms']) == 2 and all(t >= 0 for t in dist['exposed_allreduce_ms'])
+    assert d['ms_per_step'] >= max(dist['per_rank_ms_per_step']) - 1e-6          # the line's time is the maximum over the ranks

@@ -1317,5 +1317,13 @@ def test_compact_mask_is_nonzero_static(n, p):
         k = want.numel() // 2
         buf = native.compact_mask(mask, k)
         assert torch.equal(buf, want[:k])
+    # a capacity above the count: the tail holds -1 (torch.nonzero_static's fill), never uninitialised values
+    over = native.compact_mask(mask, want.numel() + 37)
+    assert torch.equal(over, torch.nonzero_static(mask, size=want.numel() + 37, fill_value=-1)[:, 0])
+    if n > 40:                                                        # a view that does not start on a 16-byte boundary is copied, not refused
+        view = mask[3:]
+        assert view.data_ptr() % 16 != 0
+        ref = torch.nonzero(view)[:, 0]
+        assert torch.equal(native.compact_mask(view, ref.numel()), ref)
     with pytest.raises(native.NativeError):
         native.compact_mask(mask.float(), 1)

@@ -192,3 +192,33 @@ def test_device_sharing_is_decided_from_identity_and_survives_an_uninformative_i
     assert not shared([('h', 'z', '', i) for i in range(8)])
     assert not shared([('h', 'z', str(i), 0) for i in range(8)])
     assert not shared([('h1', 'a', '', 0), ('h2', 'a', '', 0)])
+    # cgroup / device-plugin isolation: every rank sees device index 0 under the same (or an empty) mask, but the hardware ids differ -- informative ids
+    # alone decide (the fall-through to (mask, index) called this production layout 'shared' and cost it the two-stream step)
+    assert not shared([('h', 'uuid-%d' % i, '', 0) for i in range(8)])
+    assert not shared([('h', 'uuid-%d' % i, '0', 0) for i in range(8)])
+    assert shared([('h', 'uuid-0', '', 0), ('h', 'uuid-1', '', 0), ('h', 'uuid-1', '', 0)])
+    assert shared([('h1', 'a', '', 0), ('h2', 'b', '', 0), ('h2', 'b', '', 0)])
+
+
+def test_bench_self_launch_decides_without_touching_a_gpu(monkeypatch):
+    """bench.self_launch: None (= run the bench in this process) for one GPU, for a malformed --gpus, and inside a launch (WORLD_SIZE / RANK /
+    TORCHELASTIC_RUN_ID set: this process IS a rank); only `--gpus N > 1` without a launcher starts a process tree (exercised on the GPU box,
+    tests/test_bench_multirank.py::test_bench_starts_its_own_ranks)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_under_test', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)                                   # not __main__: nothing is launched by the import
+    for k in ('WORLD_SIZE', 'RANK', 'TORCHELASTIC_RUN_ID'):
+        monkeypatch.delenv(k, raising=False)
+    assert bench.self_launch([]) is None
+    assert bench.self_launch(['--gpus', '1', '--steps', '3']) is None
+    assert bench.self_launch(['--gpus=1']) is None
+    assert bench.self_launch(['--gpus', 'many']) is None
+    monkeypatch.setenv('WORLD_SIZE', '2')
+    assert bench.self_launch(['--gpus', '2']) is None
+    monkeypatch.delenv('WORLD_SIZE')
+    monkeypatch.setenv('TORCHELASTIC_RUN_ID', 'x')
+    assert bench.self_launch(['--gpus=8']) is None
+    assert bench._descendants(os.getpid()) == [] or all(isinstance(p, int) for p in bench._descendants(os.getpid()))
