@@ -112,6 +112,42 @@ __host__ __device__ constexpr int pcacc_tr_stride(int c)
 // ---- wave64 / block scans ------------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// [r6] Fixed-order reduction of per-workgroup partial slots (weight / bias gradients): partial[p][e], p < n_parts, e < elems -> store(e, sum over p).
+// The reduce kernels of rounds 2-5 cut the slots into 16-64 slices that met in `out` through fp32 atomicAdd: the order of those additions changed from run to
+// run, and with it the last bit of every weight gradient -- a training step was not reproducible.  Here a workgroup of 1024 threads owns EL consecutive
+// elements and SL = 1024 / EL interleaved slices of the slots (slice s takes slots s, s + SL, ...; the EL threads of a slice read consecutive elements of one
+// slot); a thread keeps four running sums over its slots in a fixed order, and the SL slice sums of an element are added in slice order by one thread
+// through LDS.  Same bits every run, no zero-filled output needed, no atomics.  Launch: (elems + EL - 1) / EL workgroups of 1024 threads.
+template <int EL, class Store>
+__device__ __forceinline__ void pcacc_reduce_partials(const float *__restrict__ partial, int n_parts, int elems, Store store)
+{
+    constexpr int SL = 1024 / EL;
+    __shared__ float red[SL][EL + 1];
+    const int el = threadIdx.x % EL, slice = threadIdx.x / EL;
+    const int e = blockIdx.x * EL + el;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (e < elems) {
+        int p = slice;
+        for (; p + 3 * SL < n_parts; p += 4 * SL) {
+            s0 += partial[(int64_t)p * elems + e];
+            s1 += partial[(int64_t)(p + SL) * elems + e];
+            s2 += partial[(int64_t)(p + 2 * SL) * elems + e];
+            s3 += partial[(int64_t)(p + 3 * SL) * elems + e];
+        }
+        for (; p < n_parts; p += SL) s0 += partial[(int64_t)p * elems + e];
+    }
+    red[slice][el] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (slice == 0 && e < elems) {
+        float v = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < SL; ++k) v += red[k][el];
+        store(e, v);
+    }
+}
+// elements per workgroup: long element ranges read whole 256-byte pieces of a slot per slice, short ones spread their slots over 64 slices
+static inline int pcacc_reduce_el(int elems) { return elems >= 8192 ? 64 : 16; }
+
 // inclusive prefix sum across the 64 lanes of a wave
 __device__ __forceinline__ int wave_inclusive_scan(int v)
 {

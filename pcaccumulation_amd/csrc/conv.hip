@@ -785,20 +785,11 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_wgrad_kernel(const uint16_
     if (it == 0 && lh == 0) mine[CO * 9 * CI + ct * 32 + lp] = bsum;
 }
 
-__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__restrict__ partial, int n_parts, int elems, float *out)
+// out[e] = sum over the workgroup partials in a fixed order (common.h: pcacc_reduce_partials) -- run-to-run identical
+template <int EL>
+__global__ __launch_bounds__(1024) void conv_wgrad_reduce_kernel(const float *__restrict__ partial, int n_parts, int elems, float *__restrict__ out)
 {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= elems) return;
-    const int per = (n_parts + gridDim.y - 1) / gridDim.y;
-    const int p0 = blockIdx.y * per, p1 = min(n_parts, p0 + per);
-    float s0 = 0.f, s1 = 0.f;
-    int p = p0;
-    for (; p + 2 <= p1; p += 2) {
-        s0 += partial[(int64_t)p * elems + e];
-        s1 += partial[(int64_t)(p + 1) * elems + e];
-    }
-    if (p < p1) s0 += partial[(int64_t)p * elems + e];
-    if (p1 > p0) atomicAdd(&out[e], s0 + s1);
+    pcacc_reduce_partials<EL>(partial, n_parts, elems, [&](int e, float v) { out[e] = v; });
 }
 
 static int conv_wgrad_grid(int c_in, int c_out, int64_t n_tiles)
@@ -850,7 +841,8 @@ extern "C" int pcacc_conv3x3_wgrad_bf16(const uint16_t *dy, const uint16_t *x, f
     else if (c_out == 64 && c_in == 32) CV_WG(2, 1);
     else CV_WG(2, 2);
 #undef CV_WG
-    conv_wgrad_reduce_kernel<<<dim3((elems + 255) / 256, 16), 256, 0, st>>>(partial, grid, elems, dw);
+    if (pcacc_reduce_el(elems) == 64) conv_wgrad_reduce_kernel<64><<<(elems + 63) / 64, 1024, 0, st>>>(partial, grid, elems, dw);
+    else conv_wgrad_reduce_kernel<16><<<(elems + 15) / 16, 1024, 0, st>>>(partial, grid, elems, dw);
     PCACC_CHECK_LAUNCH();
     return 0;
 }

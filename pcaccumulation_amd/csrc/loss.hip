@@ -336,14 +336,18 @@ __device__ __forceinline__ void apply_pose(const float *__restrict__ m, float &x
 
 // sums[k] = (sum x, sum y, count) of the reconstructed points of instance k (libs/loss.py:213-216).  LDS copy of the whole table
 // per workgroup when it fits (few instances, many points each), global atomics otherwise.
+// [r6] The sums are kept in 64-bit FIXED POINT (2^-24 m: finer than an fp32 ulp anywhere beyond 0.5 m; |x| < 2^15 m x 3.2 M points stays far inside 63 bits):
+// integer additions commute, so the centres -- and with them the offset loss and its gradient -- are the same bits every run.  Rounds 1-5 added fp32 values
+// with atomics in arrival order (as torch_scatter does); the fixed-point sum is exact, i.e. what those sums approximated.
+#define OFF_FIX 16777216.0f
 __global__ __launch_bounds__(256) void offset_centres_kernel(const float *__restrict__ points, const int64_t *__restrict__ time_indice,
                                                              const int64_t *__restrict__ inst, const int64_t *__restrict__ label_base,
                                                              const float *__restrict__ ego, const float *__restrict__ inst_tsfm, int n_frames,
-                                                             int64_t n, int k3, bool use_lds, float *__restrict__ sums)
+                                                             int64_t n, int k3, bool use_lds, unsigned long long *__restrict__ sums)
 {
-    extern __shared__ float tab[];
+    extern __shared__ unsigned long long tab[];
     if (use_lds) {
-        for (int j = threadIdx.x; j < k3; j += 256) tab[j] = 0.f;
+        for (int j = threadIdx.x; j < k3; j += 256) tab[j] = 0ull;
         __syncthreads();
     }
     const int64_t per_block = (n + gridDim.x - 1) / gridDim.x;
@@ -354,23 +358,25 @@ __global__ __launch_bounds__(256) void offset_centres_kernel(const float *__rest
         float x = points[3 * i], y = points[3 * i + 1], z = points[3 * i + 2];
         apply_pose(ego + (b * n_frames + t) * 16, x, y, z);
         apply_pose(inst_tsfm + (lab * n_frames + t) * 16, x, y, z);
-        float *dst = (use_lds ? tab : sums) + lab * 3;
-        atomicAdd(dst, x);
-        atomicAdd(dst + 1, y);
-        atomicAdd(dst + 2, 1.f);
+        unsigned long long *dst = (use_lds ? tab : sums) + lab * 3;
+        // non-finite coordinates (never produced by finite poses) would poison a float sum; here they are clamped into the representable range
+        const float cx = fminf(fmaxf(x, -1.0e9f), 1.0e9f), cy = fminf(fmaxf(y, -1.0e9f), 1.0e9f);
+        atomicAdd(dst, (unsigned long long)(long long)llrintf(cx * OFF_FIX));        // two's complement: signed sums through the unsigned add
+        atomicAdd(dst + 1, (unsigned long long)(long long)llrintf(cy * OFF_FIX));
+        atomicAdd(dst + 2, 1ull);
     }
     if (use_lds) {
         __syncthreads();
         for (int j = threadIdx.x; j < k3; j += 256) {
-            const float v = tab[j];
-            if (v != 0.f) atomicAdd(&sums[j], v);
+            const unsigned long long v = tab[j];
+            if (v != 0ull) atomicAdd(&sums[j], v);
         }
     }
 }
 
 // per selected row: offset to the instance centre, and the partial sums |dx|, |dy|, ||d||, 1 - cos
 __global__ __launch_bounds__(256) void offset_terms_kernel(const int64_t *__restrict__ time_indice, const int64_t *__restrict__ inst,
-                                                           const int64_t *__restrict__ label_base, const float *__restrict__ sums,
+                                                           const int64_t *__restrict__ label_base, const unsigned long long *__restrict__ sums,
                                                            const float *__restrict__ tp, const float *__restrict__ est, const int64_t *__restrict__ rows,
                                                            int64_t m, float *__restrict__ offset_gt, double *__restrict__ part)
 {
@@ -379,8 +385,10 @@ __global__ __launch_bounds__(256) void offset_terms_kernel(const int64_t *__rest
     for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < m; j += (int64_t)gridDim.x * 256) {
         const int64_t i = rows ? rows[j] : j;
         const int64_t lab = inst[i] + label_base[time_indice[2 * i]];
-        const float cnt = fmaxf(sums[lab * 3 + 2], 1.f);
-        const float gx = sums[lab * 3] / cnt - tp[3 * i], gy = sums[lab * 3 + 1] / cnt - tp[3 * i + 1];
+        const float cnt = fmaxf((float)sums[lab * 3 + 2], 1.f);
+        // the fixed-point sums back as fp32 (the correctly rounded sum), then the reference's fp32 division by the count (torch_scatter 'mean')
+        const float sx = (float)((double)(long long)sums[lab * 3] * (1.0 / (double)OFF_FIX)), sy = (float)((double)(long long)sums[lab * 3 + 1] * (1.0 / (double)OFF_FIX));
+        const float gx = sx / cnt - tp[3 * i], gy = sy / cnt - tp[3 * i + 1];
         const float ex = est[2 * i], ey = est[2 * i + 1];
         offset_gt[2 * j] = gx;
         offset_gt[2 * j + 1] = gy;
@@ -431,11 +439,11 @@ __global__ __launch_bounds__(256) void offset_backward_kernel(const float *__res
     }
 }
 
-#define OFF_LDS_FLOATS 8192
+#define OFF_LDS_FLOATS 6144      // table entries (8 bytes each since [r6]: 48 KB of LDS)
 
 static size_t offset_ws_bytes(int64_t m, int64_t k)
 {
-    return pcacc_align((size_t)k * 3 * 4) + pcacc_align((size_t)pcacc_grid(m, 256, PCACC_CUS * 4) * 4 * 8);
+    return pcacc_align((size_t)k * 3 * 8) + pcacc_align((size_t)pcacc_grid(m, 256, PCACC_CUS * 4) * 4 * 8);
 }
 
 extern "C" int pcacc_offset_loss_workspace_bytes(int64_t m, int64_t k, size_t *bytes)
@@ -455,13 +463,13 @@ extern "C" int pcacc_offset_loss_forward(const float *points, const int64_t *tim
         return PCACC_E_ARG;
     if (ws_bytes < offset_ws_bytes(m, k)) return PCACC_E_WORKSPACE;
     hipStream_t s = pcacc_stream(stream);
-    float *sums = (float *)ws;
-    double *part = (double *)((char *)ws + pcacc_align((size_t)k * 3 * 4));
-    if (hipMemsetAsync(sums, 0, (size_t)k * 3 * 4, s) != hipSuccess) return PCACC_E_LAUNCH;
+    unsigned long long *sums = (unsigned long long *)ws;
+    double *part = (double *)((char *)ws + pcacc_align((size_t)k * 3 * 8));
+    if (hipMemsetAsync(sums, 0, (size_t)k * 3 * 8, s) != hipSuccess) return PCACC_E_LAUNCH;
     const bool use_lds = k * 3 <= OFF_LDS_FLOATS;
     int grid = (int)((n + 256 * 16 - 1) / (256 * 16));
     if (grid > PCACC_CUS * 4) grid = PCACC_CUS * 4;
-    offset_centres_kernel<<<grid, 256, use_lds ? (size_t)k * 3 * 4 : 0, s>>>(points, time_indice, inst_labels, label_base, ego_motion, inst_motion, n_frames, n,
+    offset_centres_kernel<<<grid, 256, use_lds ? (size_t)k * 3 * 8 : 0, s>>>(points, time_indice, inst_labels, label_base, ego_motion, inst_motion, n_frames, n,
                                                                              (int)(k * 3), use_lds, sums);
     PCACC_CHECK_LAUNCH();
     const int nb = pcacc_grid(m, 256, PCACC_CUS * 4);

@@ -396,29 +396,19 @@ __global__ __launch_bounds__(NW * 64) void rows_wgrad_bf16_kernel(const uint16_t
     }
 }
 
-// out[e] += sum over a slice of the workgroup partials (blockIdx.y = slice); out is zero-filled before the launch
+// out[e] = sum over the workgroup partials in a fixed order (common.h: pcacc_reduce_partials) -- run-to-run identical
 // split_k > 0: the [n][split_k + 1] result is written as dW [n][split_k] followed by the bias gradients [n], both contiguous
-__global__ __launch_bounds__(256) void rows_wgrad_reduce_kernel(const float *__restrict__ partial, int n_parts, int elems, float *out, int split_k)
+template <int EL>
+__global__ __launch_bounds__(1024) void rows_wgrad_reduce_kernel(const float *__restrict__ partial, int n_parts, int elems, float *__restrict__ out, int split_k)
 {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= elems) return;
-    const int per = (n_parts + gridDim.y - 1) / gridDim.y;
-    const int p0 = blockIdx.y * per, p1 = min(n_parts, p0 + per);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int p = p0;
-    for (; p + 4 <= p1; p += 4) {
-        s0 += partial[(int64_t)p * elems + e];
-        s1 += partial[(int64_t)(p + 1) * elems + e];
-        s2 += partial[(int64_t)(p + 2) * elems + e];
-        s3 += partial[(int64_t)(p + 3) * elems + e];
-    }
-    for (; p < p1; ++p) s0 += partial[(int64_t)p * elems + e];
-    int o = e;
-    if (split_k > 0) {
-        const int row = e / (split_k + 1), col = e % (split_k + 1);
-        o = col < split_k ? row * split_k + col : (elems / (split_k + 1)) * split_k + row;
-    }
-    if (p1 > p0) atomicAdd(&out[o], (s0 + s1) + (s2 + s3));
+    pcacc_reduce_partials<EL>(partial, n_parts, elems, [&](int e, float v) {
+        int o = e;
+        if (split_k > 0) {
+            const int row = e / (split_k + 1), col = e % (split_k + 1);
+            o = col < split_k ? row * split_k + col : (elems / (split_k + 1)) * split_k + row;
+        }
+        out[o] = v;
+    });
 }
 
 static int wgrad_bf16_tile_rows(int k, int n) { return k + n <= 64 ? 256 : (k + n <= 128 ? 128 : 64); }
@@ -467,8 +457,8 @@ static int rows_wgrad_bf16_any(const uint16_t *dy, const uint16_t *dy_mask, cons
     else if (total <= 12) WGB(3, 64);
     else rows_wgrad_bf16_kernel<3, 64, 8><<<grid, 512, lds, st>>>(dy, dy_mask, x, x_relu, rows, k, n, k_tiles, total, tiles_par, partial, xs2, dw_aug);
 #undef WGB
-    const int slices = elems >= 8192 ? 16 : 64;                               // ~1000 workgroups in flight either way
-    rows_wgrad_reduce_kernel<<<dim3((elems + 255) / 256, slices), 256, 0, st>>>(partial, grid * parts_per_wg, elems, dw_aug, split_k);
+    if (pcacc_reduce_el(elems) == 64) rows_wgrad_reduce_kernel<64><<<(elems + 63) / 64, 1024, 0, st>>>(partial, grid * parts_per_wg, elems, dw_aug, split_k);
+    else rows_wgrad_reduce_kernel<16><<<(elems + 15) / 16, 1024, 0, st>>>(partial, grid * parts_per_wg, elems, dw_aug, split_k);
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
 }

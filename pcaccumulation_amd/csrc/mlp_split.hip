@@ -734,30 +734,20 @@ __global__ __launch_bounds__(NW * 64) void rows_wgrad_split_kernel(const float *
     }
 }
 
-// out[e] += scale-free sum over a slice of the workgroup partials (blockIdx.y = slice); out was cleared by block 0 of the kernel above.
+// out[e] = (sum over the workgroup partials in a fixed order: common.h pcacc_reduce_partials -- run-to-run identical) / the operand scales.
 // split_k > 0: the [n][split_k + 1] result is written as dW [n][split_k] followed by the bias gradients [n], both contiguous.
-__global__ __launch_bounds__(256) void rows_wgrad_split_reduce_kernel(const float *__restrict__ partial, int n_parts, int elems, int ka,
-                                                                      const float *__restrict__ dy_amax, const float *__restrict__ x_amax,
-                                                                      const float *__restrict__ x_amax2, float *out, int split_k)
+template <int EL>
+__global__ __launch_bounds__(1024) void rows_wgrad_split_reduce_kernel(const float *__restrict__ partial, int n_parts, int elems, int ka,
+                                                                       const float *__restrict__ dy_amax, const float *__restrict__ x_amax,
+                                                                       const float *__restrict__ x_amax2, float *__restrict__ out, int split_k)
 {
     const float inv_y = 1.f / ms_scale_of(ms_amax(dy_amax, nullptr)), inv_yx = inv_y / ms_scale_of(ms_amax(x_amax, x_amax2));
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= elems) return;
-    const int per = (n_parts + gridDim.y - 1) / gridDim.y;
-    const int p0 = blockIdx.y * per, p1 = min(n_parts, p0 + per);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int p = p0;
-    for (; p + 4 <= p1; p += 4) {
-        s0 += partial[(int64_t)p * elems + e];
-        s1 += partial[(int64_t)(p + 1) * elems + e];
-        s2 += partial[(int64_t)(p + 2) * elems + e];
-        s3 += partial[(int64_t)(p + 3) * elems + e];
-    }
-    for (; p < p1; ++p) s0 += partial[(int64_t)p * elems + e];
-    const int row = e / ka, col = e % ka;
-    int o = e;
-    if (split_k > 0) o = col < split_k ? row * split_k + col : (elems / ka) * split_k + row;
-    if (p1 > p0) atomicAdd(&out[o], ((s0 + s1) + (s2 + s3)) * (col == ka - 1 ? inv_y : inv_yx));
+    pcacc_reduce_partials<EL>(partial, n_parts, elems, [&](int e, float v) {
+        const int row = e / ka, col = e % ka;
+        int o = e;
+        if (split_k > 0) o = col < split_k ? row * split_k + col : (elems / ka) * split_k + row;
+        out[o] = v * (col == ka - 1 ? inv_y : inv_yx);
+    });
 }
 
 static int wsplit_tile_rows(int k, int n) { return (k <= 64 && n <= 64) ? 128 : 64; }
@@ -818,9 +808,12 @@ static int rows_wgrad_split_any(const float *dy, const float *dy_amax, const flo
     else if (total <= 12) WSP(3, 64, 4);
     else WSP(3, 64, 8);
 #undef WSP
-    const int slices = elems >= 8192 ? 16 : 64;                               // ~1000 workgroups in flight either way
-    hipLaunchKernelGGL(rows_wgrad_split_reduce_kernel, dim3((elems + 255) / 256, slices), dim3(256), 0, st, partial, grid * parts_per_wg, elems, k + 1,
-                       dy_amax, x_amax, x_amax2, dw_aug, split_k);
+    if (pcacc_reduce_el(elems) == 64)
+        hipLaunchKernelGGL(rows_wgrad_split_reduce_kernel<64>, dim3((elems + 63) / 64), dim3(1024), 0, st, partial, grid * parts_per_wg, elems, k + 1,
+                           dy_amax, x_amax, x_amax2, dw_aug, split_k);
+    else
+        hipLaunchKernelGGL(rows_wgrad_split_reduce_kernel<16>, dim3((elems + 15) / 16), dim3(1024), 0, st, partial, grid * parts_per_wg, elems, k + 1,
+                           dy_amax, x_amax, x_amax2, dw_aug, split_k);
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
 }

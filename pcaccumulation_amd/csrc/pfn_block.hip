@@ -363,23 +363,10 @@ __global__ __launch_bounds__(PB_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     mine[(lh ? PB_OFF_B0 : PB_OFF_B1) + lp] = bias_sum;
 }
 
-// out[e] += sum over a slice of the partial slots (blockIdx.y = slice); out is zero-filled before the launch
-__global__ __launch_bounds__(256) void pfn_block_reduce_kernel(const float *__restrict__ partial, int n_parts, float *out)
+// out[e] = sum over the partial slots in a fixed order (common.h: pcacc_reduce_partials) -- run-to-run identical
+__global__ __launch_bounds__(1024) void pfn_block_reduce_kernel(const float *__restrict__ partial, int n_parts, float *__restrict__ out)
 {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= PB_PARTIAL) return;
-    const int per = (n_parts + gridDim.y - 1) / gridDim.y;
-    const int p0 = blockIdx.y * per, p1 = min(n_parts, p0 + per);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int p = p0;
-    for (; p + 4 <= p1; p += 4) {
-        s0 += partial[(int64_t)p * PB_PARTIAL + e];
-        s1 += partial[(int64_t)(p + 1) * PB_PARTIAL + e];
-        s2 += partial[(int64_t)(p + 2) * PB_PARTIAL + e];
-        s3 += partial[(int64_t)(p + 3) * PB_PARTIAL + e];
-    }
-    for (; p < p1; ++p) s0 += partial[(int64_t)p * PB_PARTIAL + e];
-    if (p1 > p0) atomicAdd(&out[e], (s0 + s1) + (s2 + s3));
+    pcacc_reduce_partials<16>(partial, n_parts, PB_PARTIAL, [&](int e, float v) { out[e] = v; });
 }
 
 static int pb_grid(int64_t rows, int per_cu)
@@ -426,7 +413,7 @@ extern "C" int pcacc_pfn_block_backward(const uint16_t *xa, const uint16_t *pool
     float *partial = reinterpret_cast<float *>(workspace);
     if (pooled) pfn_block_bwd_kernel<true><<<grid, PB_THREADS, 0, s>>>(xa, PbPieces{pooled, p2v}, relu_h, grad_out, w0, ws, w1, grad_xa, grad_xb, partial, rows, grad_params);
     else pfn_block_bwd_kernel<false><<<grid, PB_THREADS, 0, s>>>(xa, PbPieces{pooled, p2v}, relu_h, grad_out, w0, ws, w1, grad_xa, grad_xb, partial, rows, grad_params);
-    pfn_block_reduce_kernel<<<dim3((PB_PARTIAL + 255) / 256, 32), 256, 0, s>>>(partial, grid * 4, grad_params);
+    pfn_block_reduce_kernel<<<(PB_PARTIAL + 15) / 16, 1024, 0, s>>>(partial, grid * 4, grad_params);
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
 }

@@ -8,7 +8,7 @@
 #include "scan.h"
 
 
-#define CSR_SORT_MAX 64      // pillars with more points keep the (arbitrary) cursor order
+#define CSR_SORT_MAX 64      // segments with more points: csr_list_long / csr_sort_long below ([r6]: ascending for ANY length)
 
 // [r5] the counting pass keeps what its atomic returns -- the point's arrival number inside its segment -- and the fill pass places the point at
 // seg_offsets[s] + that number: one atomic per point instead of two (the second pass re-counted every segment through a cursor: 124 + 164 us for the
@@ -27,11 +27,16 @@ __global__ __launch_bounds__(256) void csr_fill(const int32_t *__restrict__ p2v,
         order[seg_offsets[p2v[i]] + rank[i]] = (int32_t)i;
 }
 
-// Few segments (TubeNet instances, K*T ~ 100 rows): one global atomic per point would serialise on a handful of
-// addresses.  Privatise the histogram in LDS per 2048-point chunk and touch global memory once per (chunk, bin).
+// Few segments (TubeNet instances, K*T ~ 100 rows; m <= CSR_SMALL_M): one global atomic per point would serialise on a handful of addresses, and a
+// segment holds tens of thousands of points -- far beyond any sorting network.  [r6] A stable counting sort instead, so that the order inside a segment is
+// ascending point index BY CONSTRUCTION (rounds 1-5 placed the chunks' slices in arrival order: sums over such a segment changed in the last bit from run to
+// run): (1) every 2048-point chunk counts its points per segment in LDS and writes its row of a [chunks][m] table; (2) a scan down the table's columns
+// turns the counts into each chunk's start inside each segment; (3) ONE WAVE per chunk walks its points in index order, 64 at a time: lanes holding the same
+// segment find each other by ballot (one round per distinct segment in the wave), a lane's place is the segment's running cursor in LDS plus the number
+// of lower lanes with the same segment, and the leader advances the cursor.  Integer atomics only (order-independent); no sort pass afterwards.
 #define CSR_SMALL_M 2048
 
-__global__ __launch_bounds__(256) void csr_histogram_small(const int32_t *__restrict__ p2v, int64_t n, int m, int *counts)
+__global__ __launch_bounds__(256) void csr_histogram_small(const int32_t *__restrict__ p2v, int64_t n, int m, int *counts, int *__restrict__ table)
 {
     __shared__ int hist[CSR_SMALL_M];
     for (int k = threadIdx.x; k < m; k += 256) hist[k] = 0;
@@ -43,34 +48,53 @@ __global__ __launch_bounds__(256) void csr_histogram_small(const int32_t *__rest
         if (i < n) atomicAdd(&hist[p2v[i]], 1);
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < m; k += 256)
-        if (hist[k]) atomicAdd(&counts[k], hist[k]);
-}
-
-__global__ __launch_bounds__(256) void csr_fill_small(const int32_t *__restrict__ p2v, int64_t n, int m,
-                                                      const int32_t *__restrict__ seg_offsets, int *cursor, int32_t *order)
-{
-    __shared__ int hist[CSR_SMALL_M];
-    for (int k = threadIdx.x; k < m; k += 256) hist[k] = 0;
-    __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * PCACC_CHUNK;
-    int seg[PCACC_CHUNK_ROWS], rank[PCACC_CHUNK_ROWS];
-#pragma unroll
-    for (int r = 0; r < PCACC_CHUNK_ROWS; ++r) {
-        const int64_t i = base + r * 256 + threadIdx.x;
-        seg[r] = (i < n) ? p2v[i] : -1;
-        rank[r] = (seg[r] >= 0) ? atomicAdd(&hist[seg[r]], 1) : 0;
-    }
-    __syncthreads();
     for (int k = threadIdx.x; k < m; k += 256) {
         const int c = hist[k];
-        hist[k] = c ? seg_offsets[k] + atomicAdd(&cursor[k], c) : 0;     // start of this chunk's slice of segment k
+        table[(int64_t)blockIdx.x * m + k] = c;
+        if (c) atomicAdd(&counts[k], c);
     }
+}
+
+// table[chunk][k]: count of chunk `chunk` in segment k -> seg_offsets[k] + the counts of the chunks in front of it.  One wave per segment, 64 chunks per round.
+__global__ __launch_bounds__(256) void csr_table_scan(int *__restrict__ table, int n_chunks, int m, const int32_t *__restrict__ seg_offsets)
+{
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = lane_id();
+    if (k >= m) return;
+    int carry = seg_offsets[k];
+    for (int c0 = 0; c0 < n_chunks; c0 += 64) {
+        const int c = c0 + lane;
+        const int v = c < n_chunks ? table[(int64_t)c * m + k] : 0;
+        const int incl = wave_inclusive_scan(v);
+        if (c < n_chunks) table[(int64_t)c * m + k] = carry + incl - v;
+        carry += __shfl(incl, 63, 64);
+    }
+}
+
+__global__ __launch_bounds__(64) void csr_fill_small(const int32_t *__restrict__ p2v, int64_t n, int m, const int *__restrict__ table, int32_t *__restrict__ order)
+{
+    __shared__ int cursor[CSR_SMALL_M];
+    const int lane = threadIdx.x;
+    for (int k = lane; k < m; k += 64) cursor[k] = table[(int64_t)blockIdx.x * m + k];
     __syncthreads();
-#pragma unroll
-    for (int r = 0; r < PCACC_CHUNK_ROWS; ++r) {
-        const int64_t i = base + r * 256 + threadIdx.x;
-        if (seg[r] >= 0) order[hist[seg[r]] + rank[r]] = (int32_t)i;
+    const int64_t base = (int64_t)blockIdx.x * PCACC_CHUNK;
+    for (int r = 0; r < PCACC_CHUNK / 64; ++r) {
+        const int64_t i = base + r * 64 + lane;
+        const bool live = i < n;
+        const int key = live ? p2v[i] : -1;
+        unsigned long long todo = __ballot(live);
+        int place = 0;
+        while (todo) {                                                  // one round per distinct segment among the wave's 64 points
+            const int leader = __ffsll((long long)todo) - 1;
+            const int lk = __shfl(key, leader, 64);
+            const unsigned long long same = __ballot(live && key == lk);
+            const int start = cursor[lk];                                 // every lane reads the cursor before the leader moves it
+            if (live && key == lk) place = start + __popcll(same & ((1ull << lane) - 1ull));
+            __syncthreads();
+            if (lane == leader) cursor[lk] = start + __popcll(same);
+            __syncthreads();
+            todo &= ~same;
+        }
+        if (live) order[place] = (int32_t)i;
     }
 }
 
@@ -121,10 +145,71 @@ __global__ __launch_bounds__(256) void csr_sort_segments(const int32_t *__restri
 }
 #undef CSR_CE
 
+// [r6] Segments of more than CSR_SORT_MAX points on the many-segment path (crowded pillars of a LiDAR sweep, the cells of a foreground box in the bilinear
+// backward's cell keys): rounds 1-5 left them in arrival order -- the one place where two runs of the same step summed the same numbers in a different
+// order without an atomic add being involved.  The counting pass lists them (one append per such segment; the ORDER of the list does not matter, every
+// entry is sorted on its own), and one workgroup per entry sorts the segment ascending: up to CSR_LONG_LDS entries in LDS, longer ones in place in global
+// memory.  Both run the bitonic network in its all-ascending form (first step of every merge mirrors the partner index), which tolerates a length that
+// is not a power of two: positions at and beyond the length are +infinity that never has to move.
+#define CSR_LONG_LDS 4096
+
+__global__ __launch_bounds__(256) void csr_list_long(const int32_t *__restrict__ seg_offsets, int64_t m, int *count, int32_t *__restrict__ list)
+{
+    for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < m; s += (int64_t)gridDim.x * 256)
+        if (seg_offsets[s + 1] - seg_offsets[s] > CSR_SORT_MAX) list[atomicAdd(count, 1)] = (int32_t)s;
+}
+
+__global__ __launch_bounds__(256) void csr_sort_long(const int32_t *__restrict__ seg_offsets, const int *__restrict__ count, const int32_t *__restrict__ list,
+                                                     int32_t *order)
+{
+    __shared__ int32_t v[CSR_LONG_LDS];
+    const int n_long = *count;
+    for (int q = blockIdx.x; q < n_long; q += gridDim.x) {
+        const int s = list[q];
+        const int b = seg_offsets[s], cnt = seg_offsets[s + 1] - b;
+        int pow2 = 128;
+        while (pow2 < cnt) pow2 <<= 1;
+        if (cnt <= CSR_LONG_LDS) {
+            for (int i = threadIdx.x; i < pow2; i += 256) v[i] = i < cnt ? order[b + i] : 0x7fffffff;
+            __syncthreads();
+            for (int k = 2; k <= pow2; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int t = threadIdx.x; t < (pow2 >> 1); t += 256) {
+                        const int lo = ((t / j) * 2 * j) + (t % j);                       // lower index of compare-exchange pair t at distance j
+                        const int hi = (j == (k >> 1)) ? (lo ^ (k - 1)) : (lo + j);       // first step of a merge: mirrored partner (all-ascending network)
+                        const int32_t a = v[lo], c = v[hi];
+                        if (a > c) { v[lo] = c; v[hi] = a; }
+                    }
+                    __syncthreads();
+                }
+            for (int i = threadIdx.x; i < cnt; i += 256) order[b + i] = v[i];
+            __syncthreads();
+        } else {
+            int32_t *g = order + b;
+            for (int k = 2; k <= pow2; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int t = threadIdx.x; t < (pow2 >> 1); t += 256) {
+                        const int lo = ((t / j) * 2 * j) + (t % j);
+                        const int hi = (j == (k >> 1)) ? (lo ^ (k - 1)) : (lo + j);
+                        if (hi < cnt) {                                                     // beyond the length: +infinity, already in place
+                            const int32_t a = g[lo], c = g[hi];
+                            if (a > c) { g[lo] = c; g[hi] = a; }
+                        }
+                    }
+                    __threadfence_block();
+                    __syncthreads();
+                }
+        }
+    }
+}
+
+static inline size_t csr_table_bytes(int64_t n, int64_t m) { return m <= CSR_SMALL_M ? pcacc_align((size_t)pcacc_chunks(n) * (size_t)m * 4) : 0; }
+
 extern "C" int pcacc_csr_workspace_bytes(int64_t n, int64_t m, size_t *bytes)
 {
     if (!bytes || n < 0 || m < 0) return PCACC_E_ARG;
-    *bytes = pcacc_align((size_t)(m + 1) * 4) + pcacc_align((size_t)(pcacc_chunks(m) + 1) * 4) + pcacc_align((size_t)n * 4);      // counts, chunk sums, arrival numbers
+    // counts (+ the long-segment counter), chunk sums, arrival numbers (many segments; afterwards the list of long segments) / the [chunks][m] table (few)
+    *bytes = pcacc_align((size_t)(m + 2) * 4) + pcacc_align((size_t)(pcacc_chunks(m) + 1) * 4) + pcacc_align((size_t)n * 4) + csr_table_bytes(n, m);
     return PCACC_OK;
 }
 
@@ -139,23 +224,31 @@ extern "C" int pcacc_csr_build(const int32_t *p2v, int64_t n, int64_t m, int32_t
     hipStream_t s = pcacc_stream(stream);
     char *ws = static_cast<char *>(workspace);
     int *counts = reinterpret_cast<int *>(ws);
-    int *sums = reinterpret_cast<int *>(ws + pcacc_align((size_t)(m + 1) * 4));
-    int32_t *rank = reinterpret_cast<int32_t *>(ws + pcacc_align((size_t)(m + 1) * 4) + pcacc_align((size_t)(pcacc_chunks(m) + 1) * 4));
+    int *sums = reinterpret_cast<int *>(ws + pcacc_align((size_t)(m + 2) * 4));
+    int32_t *rank = reinterpret_cast<int32_t *>(ws + pcacc_align((size_t)(m + 2) * 4) + pcacc_align((size_t)(pcacc_chunks(m) + 1) * 4));
+    int *table = reinterpret_cast<int *>(reinterpret_cast<char *>(rank) + pcacc_align((size_t)n * 4));
     if (m == 0 || n == 0) {                                   // no points: every segment is empty
         if (hipMemsetAsync(seg_offsets, 0, (size_t)(m + 1) * 4, s) != hipSuccess) return PCACC_E_LAUNCH;
         return PCACC_OK;
     }
-    if (hipMemsetAsync(counts, 0, (size_t)(m + 1) * 4, s) != hipSuccess) return PCACC_E_LAUNCH;
-    const int chunks = pcacc_chunks(m);
+    if (hipMemsetAsync(counts, 0, (size_t)(m + 2) * 4, s) != hipSuccess) return PCACC_E_LAUNCH;
+    const int chunks = pcacc_chunks(m), n_chunks = pcacc_chunks(n);
     const bool small = m <= CSR_SMALL_M;
-    if (small) csr_histogram_small<<<pcacc_chunks(n), 256, 0, s>>>(p2v, n, (int)m, counts);
+    if (small) csr_histogram_small<<<n_chunks, 256, 0, s>>>(p2v, n, (int)m, counts, table);
     else csr_histogram<<<pcacc_grid(n, 256), 256, 0, s>>>(p2v, n, counts, rank);
     chunk_sums_i32<<<chunks, 256, 0, s>>>(counts, m, sums);
     scan_chunk_sums<<<1, 1024, 0, s>>>(sums, chunks, nullptr, -1);
-    chunk_scan_i32<<<chunks, 256, 0, s>>>(counts, m, sums, seg_offsets, 1, counts);      // counts -> cursors (zeroed behind the scan)
-    if (small) csr_fill_small<<<pcacc_chunks(n), 256, 0, s>>>(p2v, n, (int)m, seg_offsets, counts, order);
-    else csr_fill<<<pcacc_grid(n, 256), 256, 0, s>>>(p2v, n, seg_offsets, rank, order);
-    csr_sort_segments<<<pcacc_grid(m, 256), 256, 0, s>>>(seg_offsets, m, order);
+    chunk_scan_i32<<<chunks, 256, 0, s>>>(counts, m, sums, seg_offsets, 1);
+    if (small) {
+        csr_table_scan<<<(int)((m + 3) / 4), 256, 0, s>>>(table, n_chunks, (int)m, seg_offsets);
+        csr_fill_small<<<n_chunks, 64, 0, s>>>(p2v, n, (int)m, table, order);           // ascending inside every segment by construction
+    } else {
+        csr_fill<<<pcacc_grid(n, 256), 256, 0, s>>>(p2v, n, seg_offsets, rank, order);
+        csr_sort_segments<<<pcacc_grid(m, 256), 256, 0, s>>>(seg_offsets, m, order);
+        int *n_long = counts + m + 1;                          // zero since the memset above; `rank` is free again: the list of long segments (<= n / 65 entries)
+        csr_list_long<<<pcacc_grid(m, 256), 256, 0, s>>>(seg_offsets, m, n_long, rank);
+        csr_sort_long<<<PCACC_CUS, 256, 0, s>>>(seg_offsets, n_long, rank, order);
+    }
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
 }
@@ -326,14 +419,10 @@ __global__ __launch_bounds__(256) void seg_level1(const void *__restrict__ src, 
                 }
             }
         }
-        if (IS_MAX) {
-            pval[(int64_t)p * LPP + sub] = acc;
-            parg[(int64_t)p * LPP + sub] = bi;
-        } else if (e > b) {
-            // sums need no second level: one fp32 atomic per (piece, channel) into the zero-filled output
-            float *o = reinterpret_cast<float *>(pval) + ((int64_t)s * LPP + sub) * 4;
-            atomicAdd(o + 0, acc.x); atomicAdd(o + 1, acc.y); atomicAdd(o + 2, acc.z); atomicAdd(o + 3, acc.w);
-        }
+        // [r6] sums take the second level too (rounds 1-5: one fp32 atomic per piece and channel into the zero-filled output -- the pieces of a segment then
+        // met in arrival order): piece sums, added in piece order by seg_level2
+        pval[(int64_t)p * LPP + sub] = acc;
+        if (IS_MAX) parg[(int64_t)p * LPP + sub] = bi;
     }
 }
 
@@ -401,13 +490,9 @@ static int seg_two_level(const void *src, bool src_bf, int c, const int32_t *seg
     chunk_sums_i32<<<chunks, 256, 0, s>>>(pieces, m, sums);
     scan_chunk_sums<<<1, 1024, 0, s>>>(sums, chunks, nullptr, -1);
     chunk_scan_i32<<<chunks, 256, 0, s>>>(pieces, m, sums, piece_off, 1);
-    if (!IS_MAX) {       // sum: level 1 adds into `out` directly
-        if (hipMemsetAsync(out, 0, (size_t)m * c * sizeof(float), s) != hipSuccess) return PCACC_E_LAUNCH;
-        pval = out4;
-    }
 #define LAUNCH2(L)                                                                                                   \
     seg_level1<L, IS_MAX><<<pcacc_grid((int64_t)P * L, 256), 256, 0, s>>>(src, src_bf, seg_offsets, order, piece_off, (int)m, pval, parg); \
-    if (IS_MAX) seg_level2<L, IS_MAX><<<pcacc_grid(m * L, 256), 256, 0, s>>>(pval, parg, piece_off, m, out4, arg4)
+    seg_level2<L, IS_MAX><<<pcacc_grid(m * L, 256), 256, 0, s>>>(pval, parg, piece_off, m, out4, arg4)
     switch (c / 4) {
         case 1: LAUNCH2(1); break;
         case 2: LAUNCH2(2); break;

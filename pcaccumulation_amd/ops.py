@@ -248,6 +248,13 @@ def gather_rows(src2d, idx):
     return native.gather_rows(src2d.contiguous(), idx.to(torch.int32).contiguous())
 
 
+# [r6] A training step is bit-reproducible: every sum over rows runs in a fixed order (CSR ascending inside segments of any length, piece sums added in piece
+# order, partial-slot reductions in slot order, the offset centres in fixed point).  The few-row sums of the TubeNet and the neighbourhood sums of the sparse ego
+# head convolution used to go through LDS / global fp32 atomics (pcacc_scatter_sum_small, Tensor.index_add_): with this switch on (default) they take the CSR
+# path instead.  PCACC_DETERMINISTIC=0 restores the atomic kernels (A/B: tools/gpu_r06_determinism.sh).
+DETERMINISTIC = os.environ.get('PCACC_DETERMINISTIC', '1') != '0'
+
+
 class ScatterPlan(object):
     """An index vector prepared for several scatter() calls: int32 copy now, CSR (for 'max') and counts (for 'mean') on demand."""
 
@@ -273,7 +280,7 @@ class ScatterPlan(object):
         return self._build()[1]
 
     def small(self, c):
-        return 0 < self.m * c <= 8192
+        return 0 < self.m * c <= 8192 and not DETERMINISTIC
 
     def count(self):
         if self._count is None:
@@ -1805,9 +1812,16 @@ class _SparseConv3x3(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gp = (g @ w2.t()).view(-1, C)                                                      # [K * 9, C] rows of the neighbourhoods' gradients
             cells = n * H * W
-            gh = torch.zeros((cells + 1, C), dtype=torch.float32, device=g.device)             # last row: where the taps outside the map add up (dropped)
-            gh.index_add_(0, torch.where(idx >= 0, idx, cells).long(), gp)                     # overlapping neighbourhoods add up
-            gh = gh[:cells].view(n, H, W, C)
+            if DETERMINISTIC and C % 4 == 0:
+                # overlapping neighbourhoods add up in ascending tap-row order: a CSR over the cells (taps outside the map go to an extra last cell that is
+                # dropped) + the atomic-free segment sum -- index_add_ adds with atomics, in arrival order
+                key = torch.where(idx >= 0, idx, cells).to(torch.int32)
+                offs, order = native.csr_build(key, cells + 1)
+                gh = native.segment_sum(gp.contiguous(), offs, order, cells + 1)[:cells].view(n, H, W, C)
+            else:
+                gh = torch.zeros((cells + 1, C), dtype=torch.float32, device=g.device)         # last row: where the taps outside the map add up (dropped)
+                gh.index_add_(0, torch.where(idx >= 0, idx, cells).long(), gp)                 # overlapping neighbourhoods add up
+                gh = gh[:cells].view(n, H, W, C)
         if ctx.needs_input_grad[1]:
             k = g.shape[0]
             if k % 16 == 0 and k >= 4096:

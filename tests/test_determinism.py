@@ -1,0 +1,74 @@
+"""A training step is bit-reproducible ([r6]): the same weights, batch and seeds give the same bits -- every forward result, every
+loss term, every parameter gradient -- on every run.  What made two runs differ in rounds 1-5 (reference: models/stpn.py:83, models/pillar_encoder.py:116-120
+route gradients by arg-max, so last-bit noise could flip a winner): fp32 atomicAdd in the partial-slot reductions of the weight gradients, in the few-row
+sums of the TubeNet, in the two-level segment sums and in the offset centres; segments of more than 64 points summed in the arrival order of an atomic
+counter; Tensor.index_add_ in the sparse ego-head convolution.  All of them now run in a fixed order."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+
+pytestmark = pytest.mark.gpu
+
+
+def _differences(a, b):
+    import r06_determinism as det
+    return det.compare(a, b)
+
+
+@pytest.mark.parametrize('compute_dtype', ['mixed', 'bf16', 'fp32x3'])
+def test_c3_lidar_train_step_is_bit_reproducible(golden, compute_dtype):
+    """Forward + FuseLoss + backward of the c3_lidar fixture (LiDAR-distributed points: crowded pillars, near-tied max-over-frames winners -- the fixture whose
+    gradient-norm check was bimodal in round 5), twice from identical state: bit-identical results, loss terms and gradients."""
+    import r06_determinism as det
+    import test_config_parity as cp
+    g = golden('model_c3_lidar')
+    snaps = []
+    for _ in range(2):
+        model, inp, out, stats, T = cp._run(g, compute_dtype)
+        torch.cuda.synchronize()
+        snaps.append(det.snapshot(model, out, stats))
+        del model, inp, out, stats
+    assert any(k.startswith('grad.') for k in snaps[0]) and len(snaps[0]) > 150
+    rows = _differences(snaps[0], snaps[1])
+    assert not rows, '%d of %d tensors differ between two runs of the same step; first: %s' % (len(rows), len(snaps[0]), rows[:8])
+
+
+def test_staged_two_stream_step_is_bit_reproducible():
+    """The step as bench.py runs it -- distributed.DataParallelStep: early backward of the ego / fb / perm terms from a helper thread, motion heads and TubeNet
+    on a second stream -- three times on the same batch: identical loss statistics and gradients.  (Two host threads and two streams change WHEN kernels
+    run, not what they add up in which order.)"""
+    import r06_determinism as det
+    from helpers import make_batch
+    from pcaccumulation_amd import distributed as pdist
+    from pcaccumulation_amd.config import default_config
+    from pcaccumulation_amd.loss import FuseLoss
+    from pcaccumulation_amd.motionnet import MotionNet
+    from pcaccumulation_amd.synthetic import fill_state_dict_
+    dev = torch.device('cuda:0')
+    cfg = default_config('waymo', 'train', n_sweeps=5)
+    cfg['misc']['compute_dtype'] = 'mixed'
+    torch.manual_seed(0)
+    model = MotionNet(cfg)
+    fill_state_dict_(model)
+    model = model.to(dev).train().channels_last_()
+    inp = make_batch(cfg, [21, 22], 5, 30000, mode='lidar')
+    inp = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)
+    step = pdist.DataParallelStep(model, opt, FuseLoss(cfg['loss']), iter_size=1, grad_clip=None, catch=False, pipelined=True, two_streams=True, early_thread=True)
+    assert step.side is not None and step._early_thread
+    snaps = []
+    for r in range(4):
+        torch.manual_seed(5)
+        stats = step(dict(inp))
+        torch.cuda.synchronize()
+        assert step.skipped == 0
+        if r:                                                     # the first call sizes the allocator pools of both streams
+            snaps.append(det.snapshot(model, {}, {k: v for k, v in stats.items() if torch.is_tensor(v)}))
+    for other in snaps[1:]:
+        rows = _differences(snaps[0], other)
+        assert not rows, '%d tensors differ between two staged steps; first: %s' % (len(rows), rows[:8])

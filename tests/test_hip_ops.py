@@ -161,6 +161,53 @@ def test_csr_large_pillar_unsorted_is_still_correct(native, dev):
     assert np.array_equal(out.cpu().numpy(), ro) and np.array_equal(arg.cpu().numpy(), ra)
 
 
+@pytest.mark.parametrize('case', ['few_long', 'boundary_2048', 'many_crowded', 'global_sort', 'ragged_small'])
+def test_csr_order_is_ascending_for_any_segment_length(native, dev, case):
+    """[r6] pcacc_csr_build is a STABLE sort of the points by segment for ANY segment length: `order` == argsort(p2v, kind='stable').  Rounds 1-5 sorted only
+    segments of <= 64 points; longer ones (crowded pillars of a LiDAR sweep, the cells of a foreground box, the TubeNet's per-instance segments of tens
+    of thousands of points) kept the arrival order of an atomic counter -- sums over them changed in the last bit from run to run.  Few segments
+    (m <= 2048): counting sort with per-chunk tables; many: sorting network up to 64, workgroup bitonic sort in LDS up to 4096, in global memory beyond.
+    Also: the two-level segment sum (piece sums added in piece order, no atomics) gives the same bits on every call."""
+    rng = np.random.RandomState(7)
+    if case == 'few_long':                          # TubeNet shape: ~100 segments x thousands of points, some empty
+        n, m = 300_001, 105
+        p2v = rng.randint(0, m - 5, n)
+    elif case == 'boundary_2048':                   # the largest m of the counting-sort path, n not a multiple of the 2048-point chunks
+        n, m = 70_001, 2048
+        p2v = rng.randint(0, m, n)
+    elif case == 'many_crowded':                    # pillars: ~3 points each, a few hundred crowded ones of 65 .. 4096 points
+        m = 40_000
+        sizes = np.concatenate([rng.randint(0, 7, m - 300), rng.randint(65, 600, 290), [64, 65, 128, 129, 1024, 4095, 4096, 2049, 3000, 100]])
+        rng.shuffle(sizes)
+        p2v = np.repeat(np.arange(m), sizes)
+        rng.shuffle(p2v)
+        n = p2v.shape[0]
+    elif case == 'global_sort':                     # segments beyond the LDS sort: 4097 and 20 000 points among small ones
+        m = 3000
+        sizes = np.concatenate([rng.randint(0, 5, m - 3), [4097, 20_000, 9001]])
+        rng.shuffle(sizes)
+        p2v = np.repeat(np.arange(m), sizes)
+        rng.shuffle(p2v)
+        n = p2v.shape[0]
+    else:                                           # a handful of points, one segment, an empty tail
+        n, m = 130, 1
+        p2v = np.zeros(n, np.int64)
+    p2v = p2v.astype(np.int32)
+    t = torch.from_numpy(p2v).to(dev)
+    offs, order = native.csr_build(t, m)
+    cnt = np.bincount(p2v, minlength=m)
+    assert np.array_equal(offs.cpu().numpy(), np.concatenate([[0], np.cumsum(cnt)]))
+    assert np.array_equal(order.cpu().numpy(), np.argsort(p2v, kind='stable'))
+    offs2, order2 = native.csr_build(t, m)
+    assert torch.equal(order, order2) and torch.equal(offs, offs2)
+    src = torch.from_numpy(rng.randn(n, 16).astype(np.float32)).to(dev)
+    a, b = native.segment_sum(src, offs, order, m), native.segment_sum(src, offs, order, m)
+    assert torch.equal(a, b)
+    ref = np.zeros((m, 16), np.float64)
+    np.add.at(ref, p2v, src.cpu().numpy().astype(np.float64))
+    np.testing.assert_allclose(a.float().cpu().numpy(), ref, rtol=2e-5, atol=2e-4)
+
+
 # ---------------------------------------------------------------- A5, A6
 def test_pillar_scatter_and_gather_golden(native, dev, golden):
     g = golden('scatter')

@@ -1,0 +1,122 @@
+#!/usr/bin/env python
+"""Is a training step bit-reproducible?  Runs one whole-model fixture (default: c3_lidar, 'mixed') N times from identical state -- same weights,
+same batch, same seeds -- and compares EVERYTHING bit for bit against the first run: every tensor of the forward's result dict, every loss term,
+every parameter gradient.  Prints what differs (largest absolute difference, how many elements) in the order the step produces it, so the first
+line names the earliest source of run-to-run differences.
+
+    python tools/r06_determinism.py [--config c3_lidar] [--dtype mixed] [--runs 3] [--step]      (on the GPU box)
+
+--step: the same through distributed.DataParallelStep (staged two-stream step with the helper thread, as bench.py runs it) instead of the plain
+forward / loss / backward of the parity tests.  Exit status 1 when anything differs."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def flatten(prefix, obj, out):
+    if torch.is_tensor(obj):
+        out[prefix] = obj.detach().clone()
+    elif isinstance(obj, dict):
+        for k in obj:
+            v = dict.__getitem__(obj, k)
+            flatten('%s.%s' % (prefix, k), v, out)
+    elif isinstance(obj, (list, tuple)):
+        for i, v in enumerate(obj):
+            flatten('%s[%d]' % (prefix, i), v, out)
+    elif isinstance(obj, (int, float)):
+        out[prefix] = torch.tensor(float(obj), dtype=torch.float64)
+
+
+def snapshot(model, out, stats):
+    snap = {}
+    flatten('out', out, snap)
+    flatten('stats', stats, snap)
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            snap['grad.' + k] = p.grad.detach().clone()
+    return snap
+
+
+def compare(a, b):
+    rows = []
+    for k in a:
+        if k not in b:
+            rows.append((k, 'missing in the second run', 0, 0))
+            continue
+        x, y = a[k], b[k]
+        if x.shape != y.shape:
+            rows.append((k, 'shape %s vs %s' % (tuple(x.shape), tuple(y.shape)), 0, 0))
+            continue
+        if x.dtype.is_floating_point:
+            same = (x == y) | (torch.isnan(x) & torch.isnan(y))
+        else:
+            same = x == y
+        if not bool(same.all()):
+            d = (x.double() - y.double()).abs()
+            d = torch.where(torch.isfinite(d), d, torch.zeros_like(d))
+            scale = float(x.double().abs().max()) or 1.0
+            rows.append((k, 'max |diff| %.3e (rel. to max %.3e)' % (float(d.max()), float(d.max()) / scale), int((~same).sum()), x.numel()))
+    return rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--config', default='c3_lidar')
+    ap.add_argument('--dtype', default='mixed')
+    ap.add_argument('--runs', type=int, default=3)
+    ap.add_argument('--step', action='store_true')
+    args = ap.parse_args()
+    import test_config_parity as cp
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'model_%s.npz' % args.config), allow_pickle=False)
+    snaps = []
+    if not args.step:
+        for r in range(args.runs):
+            model, inp, out, stats, T = cp._run(g, args.dtype)
+            torch.cuda.synchronize()
+            snaps.append(snapshot(model, out, stats))
+            del model, inp, out, stats
+            torch.cuda.empty_cache()
+    else:
+        from pcaccumulation_amd import distributed as pdist
+        from pcaccumulation_amd.config import default_config
+        from pcaccumulation_amd.loss import FuseLoss
+        from pcaccumulation_amd.motionnet import MotionNet
+        from pcaccumulation_amd.synthetic import fill_state_dict_
+        from helpers import make_batch
+        dev = torch.device('cuda:0')
+        T, ppf, mode = int(g['n_frames']), int(g['pts_per_frame']), str(g['mode'])
+        cfg = default_config(str(g['dataset']), mode, n_sweeps=T)
+        cfg['misc']['compute_dtype'] = args.dtype
+        inp = make_batch(cfg, [int(s) for s in g['seeds']], T, ppf, mode=str(g['points']) if 'points' in g.files else 'uniform')
+        inp = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}
+        model = MotionNet(cfg)
+        fill_state_dict_(model)
+        model = model.to(dev).train().channels_last_()
+        opt = torch.optim.SGD(model.parameters(), lr=0.0)
+        step = pdist.DataParallelStep(model, opt, FuseLoss(cfg['loss']), iter_size=1, grad_clip=None, catch=False, pipelined=True, two_streams=True, early_thread=True)
+        for r in range(args.runs + 1):
+            torch.manual_seed(5)
+            stats = step(dict(inp))
+            torch.cuda.synchronize()
+            if r:                                                 # the first call warms allocator pools of both streams
+                snaps.append(snapshot(model, {}, {k: v for k, v in stats.items() if torch.is_tensor(v)}))
+    bad = 0
+    for r in range(1, len(snaps)):
+        rows = compare(snaps[0], snaps[r])
+        print('run %d vs run 0: %d of %d tensors differ' % (r, len(rows), len(snaps[0])))
+        for k, what, n, tot in rows[:60]:
+            print('   %-70s %s  [%d / %d elements]' % (k, what, n, tot))
+        bad += len(rows)
+    print('BIT-IDENTICAL' if not bad else 'NOT reproducible')
+    return 1 if bad else 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())
