@@ -228,9 +228,13 @@ int pcacc_rows_wgrad_cat_bf16(const uint16_t *dy, const uint16_t *dy_mask, const
                               float *dw_aug, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Sum of rows per index for FEW output rows (m*c <= 8192), no CSR needed: LDS-privatised accumulation.
- * The per-instance 'sum' / 'mean' poolings of models/tpointnet.py:227,251,283-284 and libs/loss.py:216.
- *   src [n,c] f32; idx [n] i32 in [0,m) (negative = skip); out [m,c] f32 (zero-filled by the call). */
-int pcacc_scatter_sum_small(const float *src, const int32_t *idx, int64_t n, int c, int m, float *out, void *stream);
+ * The per-instance 'sum' / 'mean' poolings of models/tpointnet.py:227,251,283-284 and libs/loss.py:216 (torch_scatter: fp32 atomics in arrival order).
+ * [r6] run-to-run identical: every workgroup sums its slice in 64-bit fixed point (scaled by the slice's own maximum; integer additions commute) and the
+ * workgroups' fp32 partials meet in a fixed order.  A non-finite input element makes the affected partial -- and so every output element -- NaN.
+ *   src [n,c] f32; idx [n] i32 in [0,m) (negative = skip); out [m,c] f32 (every element written); workspace: the per-workgroup partials */
+int pcacc_scatter_sum_small_workspace_bytes(int64_t n, int c, int m, size_t *bytes /*host*/);
+int pcacc_scatter_sum_small(const float *src, const int32_t *idx, int64_t n, int c, int m, float *out, void *workspace, size_t workspace_bytes,
+                            void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * A5. Pillar scatter into the BEV canvas -- models/pillar_encoder.py:125-174 (scatter_point_pillar).

@@ -109,6 +109,23 @@ __host__ __device__ constexpr int pcacc_tr_stride(int c)
     return c == 32 ? 32 : (c == 64 ? 96 : (c == 96 ? 96 : (c == 128 ? 160 : c + 4)));
 }
 
+// ---- [r6] precision-map experiment build (-DPCACC_X3_EXPERIMENT, tools/r06_precision_map.py; NEVER defined for the shipped library) ----------------------
+// Which stages of the forward need all three terms of the fp32x3 product?  In this build the split kernels read a per-translation-unit device word that
+// pcacc_x3_experiment() sets between stages: bit 0 -- activations without their lo half (two terms: (w_hi + w_lo) x_hi), bit 1 -- weights without theirs,
+// bits 0 + 1 -- one fp16 term, bit 2 / 3 -- the hi half of activations / weights rounded to bf16's 8 significant bits (with the lo half dropped: what
+// a one-term bf16 product of that stage computes, tensors still travelling as fp32).  The arithmetic is emulated at full cost: this build measures accuracy, not time.
+#ifdef PCACC_X3_EXPERIMENT
+__device__ __forceinline__ float pcacc_x_round_bf16(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+// (a, b) as the experiment sees them: rounded to bf16 precision when `f` has bit 2; -> true when the lo half is to be dropped (bit 0 or bit 2)
+__device__ __forceinline__ bool pcacc_x_apply(int f, float &a, float &b)
+{
+    if (f & 4) { a = pcacc_x_round_bf16(a); b = pcacc_x_round_bf16(b); }
+    return (f & 5) != 0;
+}
+#define PCACC_X_ACT(word) ((word) & 5)
+#define PCACC_X_W(word) (((word) >> 1) & 5)
+#endif
+
 // ---- wave64 / block scans ------------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 

@@ -150,11 +150,43 @@ __device__ __forceinline__ pcacc_f32x2 csp_unpack_f16x2(uint32_t v)
 {
     return __builtin_convertvector(*reinterpret_cast<const f16x2_t *>(&v), pcacc_f32x2);
 }
+#ifdef PCACC_X3_EXPERIMENT
+__device__ int csp_xword;                                    // common.h: precision-map experiment build
+extern "C" int pcacc_x3_experiment_conv(int word, void *stream)
+{
+    if (hipStreamSynchronize(pcacc_stream(stream)) != hipSuccess) return PCACC_E_LAUNCH;     // kernels already queued keep the word they were launched under
+    return hipMemcpyToSymbol(HIP_SYMBOL(csp_xword), &word, sizeof(int)) == hipSuccess ? PCACC_OK : PCACC_E_LAUNCH;
+}
+// a 16-byte piece of a prepared WEIGHT plane (plane 0 = hi, 1 = lo) as the experiment sees it
+__device__ __forceinline__ uint4 csp_x_weight(uint4 v, int plane)
+{
+    const int f = PCACC_X_W(csp_xword);
+    if (plane == 1) return (f & 5) ? make_uint4(0u, 0u, 0u, 0u) : v;
+    if (f & 4) {
+        uint32_t *u = reinterpret_cast<uint32_t *>(&v);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            h2 h = *reinterpret_cast<const h2 *>(&u[i]);
+            h[0] = (_Float16)pcacc_x_round_bf16((float)h[0]);
+            h[1] = (_Float16)pcacc_x_round_bf16((float)h[1]);
+            u[i] = *reinterpret_cast<const uint32_t *>(&h);
+        }
+    }
+    return v;
+}
+#endif
 __device__ __forceinline__ void csp_split2(float a, float b, uint32_t &hi, uint32_t &lo)
 {
+#ifdef PCACC_X3_EXPERIMENT
+    const bool drop = pcacc_x_apply(PCACC_X_ACT(csp_xword), a, b);
+#endif
     hi = csp_pack_f16x2(a, b);
     const pcacc_f32x2 back = csp_unpack_f16x2(hi);
     lo = csp_pack_f16x2(a - back[0], b - back[1]);           // exact differences (Sterbenz); an inf hi gives NaN here, as it should
+#ifdef PCACC_X3_EXPERIMENT
+    if (drop) lo = 0u;
+#endif
 }
 // eight fp32, scaled by s -> eight fp16 hi + eight fp16 lo (round to nearest even both times)
 __device__ __forceinline__ void csp_split8(const float4 &a, const float4 &b, float s, uint4 &hi, uint4 &lo)
@@ -421,6 +453,9 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float 
             const int c = (W_CHUNKS % CSP_THREADS) ? min((int)threadIdx.x + q * CSP_THREADS, W_CHUNKS - 1) : threadIdx.x + q * CSP_THREADS;
             const int p = c / W_CH_PLANE, r = c - p * W_CH_PLANE;
             wreg[set][q] = *reinterpret_cast<const uint4 *>(src + p * w_plane + (int64_t)(r / C8) * c_in + (r % C8) * 8);   // clamped, never masked
+#ifdef PCACC_X3_EXPERIMENT
+            wreg[set][q] = csp_x_weight(wreg[set][q], p);
+#endif
         }
     };
     auto write_w = [&](uint16_t *dst, int set) {
@@ -676,7 +711,10 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_res_kernel(const fl
             const int row = c / C8, c8 = c - row * C8;         // row = (plane, tap, r)
             const int pl = row / (9 * WROWS), tr = row - pl * 9 * WROWS;
             const int tap = tr / WROWS, r = tr - tap * WROWS;
-            const uint4 v = *reinterpret_cast<const uint4 *>(wp + pl * w_plane + ((int64_t)(f * 9 + tap) * c_out + co0 + r) * c_in + cs * CS + c8 * 8);
+            uint4 v = *reinterpret_cast<const uint4 *>(wp + pl * w_plane + ((int64_t)(f * 9 + tap) * c_out + co0 + r) * c_in + cs * CS + c8 * 8);
+#ifdef PCACC_X3_EXPERIMENT
+            v = csp_x_weight(v, pl);
+#endif
             wreg[4 * q] = v.x; wreg[4 * q + 1] = v.y; wreg[4 * q + 2] = v.z; wreg[4 * q + 3] = v.w;
         }
     };

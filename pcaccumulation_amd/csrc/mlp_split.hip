@@ -45,18 +45,35 @@ __device__ __forceinline__ uint32_t ms_pack(float a, float b)
     const ms_f16x2 r = __builtin_convertvector(f, ms_f16x2);
     return *reinterpret_cast<const uint32_t *>(&r);
 }
+#ifdef PCACC_X3_EXPERIMENT
+__device__ int ms_xword;                                     // common.h: precision-map experiment build
+extern "C" int pcacc_x3_experiment_rows(int word, void *stream)
+{
+    if (hipStreamSynchronize(pcacc_stream(stream)) != hipSuccess) return PCACC_E_LAUNCH;     // kernels already queued keep the word they were launched under
+    return hipMemcpyToSymbol(HIP_SYMBOL(ms_xword), &word, sizeof(int)) == hipSuccess ? PCACC_OK : PCACC_E_LAUNCH;
+}
+#endif
+// WEIGHT: the operand is a weight (the experiment build treats activations and weights separately; no difference in the shipped library)
+template <bool WEIGHT = false>
 __device__ __forceinline__ void ms_split2(float a, float b, uint32_t &hi, uint32_t &lo)
 {
+#ifdef PCACC_X3_EXPERIMENT
+    const bool drop = pcacc_x_apply(WEIGHT ? PCACC_X_W(ms_xword) : PCACC_X_ACT(ms_xword), a, b);
+#endif
     hi = ms_pack(a, b);
     const pcacc_f32x2 back = __builtin_convertvector(*reinterpret_cast<const ms_f16x2 *>(&hi), pcacc_f32x2);
     lo = ms_pack(a - back[0], b - back[1]);
+#ifdef PCACC_X3_EXPERIMENT
+    if (drop) lo = 0u;
+#endif
 }
+template <bool WEIGHT = false>
 __device__ __forceinline__ void ms_split8(const float4 &a, const float4 &b, float s, uint4 &hi, uint4 &lo)
 {
-    ms_split2(a.x * s, a.y * s, hi.x, lo.x);
-    ms_split2(a.z * s, a.w * s, hi.y, lo.y);
-    ms_split2(b.x * s, b.y * s, hi.z, lo.z);
-    ms_split2(b.z * s, b.w * s, hi.w, lo.w);
+    ms_split2<WEIGHT>(a.x * s, a.y * s, hi.x, lo.x);
+    ms_split2<WEIGHT>(a.z * s, a.w * s, hi.y, lo.y);
+    ms_split2<WEIGHT>(b.x * s, b.y * s, hi.z, lo.z);
+    ms_split2<WEIGHT>(b.z * s, b.w * s, hi.w, lo.w);
 }
 __device__ __forceinline__ float4 ms_relu4(float4 v) { return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)); }
 __device__ __forceinline__ float4 ms_mask4(float4 v, float4 m)
@@ -123,7 +140,7 @@ __global__ __launch_bounds__(MS_THREADS) void rows_linear_split_kernel(const flo
         const float t = ms_scale_of(__uint_as_float(wmax[n]));
         const float2 w2 = *reinterpret_cast<const float2 *>(W + (int64_t)n * K + k);
         uint32_t hi, lo;
-        ms_split2(w2.x * t, w2.y * t, hi, lo);
+        ms_split2<true>(w2.x * t, w2.y * t, hi, lo);
         *reinterpret_cast<uint32_t *>(ws + n * XS + k) = hi;
         *reinterpret_cast<uint32_t *>(ws + WPLANE + n * XS + k) = lo;
     }
@@ -313,7 +330,7 @@ __global__ __launch_bounds__(MS_THREADS, 2) void rows_linear_split_fm_kernel(con
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
             uint4 hi, lo;
-            ms_split8(*reinterpret_cast<const float4 *>(wrow + kc * 16), *reinterpret_cast<const float4 *>(wrow + kc * 16 + 4), t, hi, lo);
+            ms_split8<true>(*reinterpret_cast<const float4 *>(wrow + kc * 16), *reinterpret_cast<const float4 *>(wrow + kc * 16 + 4), t, hi, lo);
             wh[kc] = *reinterpret_cast<const ms_f16x8 *>(&hi);
             wl[kc] = *reinterpret_cast<const ms_f16x8 *>(&lo);
         }

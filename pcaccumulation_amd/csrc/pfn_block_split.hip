@@ -56,11 +56,25 @@ __device__ __forceinline__ uint32_t pbs_pack(float a, float b)
     const pbs_f16x2 r = __builtin_convertvector(f, pbs_f16x2);
     return *reinterpret_cast<const uint32_t *>(&r);
 }
+#ifdef PCACC_X3_EXPERIMENT
+__device__ int pbs_xword;                                    // common.h: precision-map experiment build
+extern "C" int pcacc_x3_experiment_pfn(int word, void *stream)
+{
+    if (hipStreamSynchronize(pcacc_stream(stream)) != hipSuccess) return PCACC_E_LAUNCH;     // kernels already queued keep the word they were launched under
+    return hipMemcpyToSymbol(HIP_SYMBOL(pbs_xword), &word, sizeof(int)) == hipSuccess ? PCACC_OK : PCACC_E_LAUNCH;
+}
+#endif
 __device__ __forceinline__ void pbs_split2(float a, float b, uint32_t &hi, uint32_t &lo)
 {
+#ifdef PCACC_X3_EXPERIMENT
+    const bool drop = pcacc_x_apply(PCACC_X_ACT(pbs_xword), a, b);
+#endif
     hi = pbs_pack(a, b);
     const pcacc_f32x2 back = __builtin_convertvector(*reinterpret_cast<const pbs_f16x2 *>(&hi), pcacc_f32x2);
     lo = pbs_pack(a - back[0], b - back[1]);
+#ifdef PCACC_X3_EXPERIMENT
+    if (drop) lo = 0u;
+#endif
 }
 __device__ __forceinline__ void pbs_split8(const float4 &a, const float4 &b, float s, uint4 &hi, uint4 &lo)
 {
@@ -100,8 +114,16 @@ __device__ __forceinline__ float pbs_stage_weights(const float *__restrict__ src
     for (int e = threadIdx.x; e < n * k; e += PBS_THREADS) {
         const int sr = e / k, sc = e % k;
         const int r = transposed ? sc : sr, c = transposed ? sr : sc;
-        const float v = src[e] * t;
-        const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+        float v = src[e] * t;
+#ifdef PCACC_X3_EXPERIMENT
+        float v2 = v;
+        const bool xdrop = pcacc_x_apply(PCACC_X_W(pbs_xword), v, v2);
+#endif
+        const _Float16 hi = (_Float16)v;
+        _Float16 lo = (_Float16)(v - (float)hi);
+#ifdef PCACC_X3_EXPERIMENT
+        if (xdrop) lo = (_Float16)0.f;
+#endif
         dst[r * ld + c] = *reinterpret_cast<const uint16_t *>(&hi);
         dst[plane + r * ld + c] = *reinterpret_cast<const uint16_t *>(&lo);
     }

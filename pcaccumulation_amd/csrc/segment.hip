@@ -31,9 +31,9 @@ __global__ __launch_bounds__(256) void csr_fill(const int32_t *__restrict__ p2v,
 // segment holds tens of thousands of points -- far beyond any sorting network.  [r6] A stable counting sort instead, so that the order inside a segment is
 // ascending point index BY CONSTRUCTION (rounds 1-5 placed the chunks' slices in arrival order: sums over such a segment changed in the last bit from run to
 // run): (1) every 2048-point chunk counts its points per segment in LDS and writes its row of a [chunks][m] table; (2) a scan down the table's columns
-// turns the counts into each chunk's start inside each segment; (3) ONE WAVE per chunk walks its points in index order, 64 at a time: lanes holding the same
-// segment find each other by ballot (one round per distinct segment in the wave), a lane's place is the segment's running cursor in LDS plus the number
-// of lower lanes with the same segment, and the leader advances the cursor.  Integer atomics only (order-independent); no sort pass afterwards.
+// turns the counts into each chunk's start inside each segment; (3) the waves of a chunk walk their points in index order, 64 at a time: lanes holding the
+// same segment find each other by ballot (one round per distinct segment in the wave), a lane's place is the segment's running cursor in LDS plus the
+// number of lower lanes with the same segment, and the leader advances the cursor.  Integer atomics only (order-independent); no sort pass afterwards.
 #define CSR_SMALL_M 2048
 
 __global__ __launch_bounds__(256) void csr_histogram_small(const int32_t *__restrict__ p2v, int64_t n, int m, int *counts, int *__restrict__ table)
@@ -70,17 +70,39 @@ __global__ __launch_bounds__(256) void csr_table_scan(int *__restrict__ table, i
     }
 }
 
-__global__ __launch_bounds__(64) void csr_fill_small(const int32_t *__restrict__ p2v, int64_t n, int m, const int *__restrict__ table, int32_t *__restrict__ order)
+// Four waves per 2048-point chunk, each owning 512 CONSECUTIVE points: a counting pass per wave (integer LDS atomics into the wave's own table), the four
+// tables turned into the waves' starts inside every segment (wave 0 first), then every wave places its points in index order, 64 at a time.  Inside a wave the
+// LDS instructions execute in program order, so the cursor read (all lanes) / cursor write (leader) pairs need no barrier; no wave touches another's table.
+__global__ __launch_bounds__(256) void csr_fill_small(const int32_t *__restrict__ p2v, int64_t n, int m, const int *__restrict__ table, int32_t *__restrict__ order)
 {
-    __shared__ int cursor[CSR_SMALL_M];
-    const int lane = threadIdx.x;
-    for (int k = lane; k < m; k += 64) cursor[k] = table[(int64_t)blockIdx.x * m + k];
+    extern __shared__ int cursors[];                                      // [4][m]
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    int *cursor = cursors + wave * m;
+    for (int k = threadIdx.x; k < 4 * m; k += 256) cursors[k] = 0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * PCACC_CHUNK;
-    for (int r = 0; r < PCACC_CHUNK / 64; ++r) {
+    const int64_t base = (int64_t)blockIdx.x * PCACC_CHUNK + wave * (PCACC_CHUNK / 4);
+    int keys[PCACC_CHUNK / 256];
+#pragma unroll
+    for (int r = 0; r < PCACC_CHUNK / 256; ++r) {
         const int64_t i = base + r * 64 + lane;
-        const bool live = i < n;
-        const int key = live ? p2v[i] : -1;
+        keys[r] = i < n ? p2v[i] : -1;
+        if (keys[r] >= 0) atomicAdd(&cursor[keys[r]], 1);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < m; k += 256) {
+        int start = table[(int64_t)blockIdx.x * m + k];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int c = cursors[w * m + k];
+            cursors[w * m + k] = start;
+            start += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < PCACC_CHUNK / 256; ++r) {
+        const int key = keys[r];
+        const bool live = key >= 0;
         unsigned long long todo = __ballot(live);
         int place = 0;
         while (todo) {                                                  // one round per distinct segment among the wave's 64 points
@@ -89,12 +111,12 @@ __global__ __launch_bounds__(64) void csr_fill_small(const int32_t *__restrict__
             const unsigned long long same = __ballot(live && key == lk);
             const int start = cursor[lk];                                 // every lane reads the cursor before the leader moves it
             if (live && key == lk) place = start + __popcll(same & ((1ull << lane) - 1ull));
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();
             if (lane == leader) cursor[lk] = start + __popcll(same);
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();
             todo &= ~same;
         }
-        if (live) order[place] = (int32_t)i;
+        if (live) order[place] = (int32_t)(base + r * 64 + lane);
     }
 }
 
@@ -241,7 +263,7 @@ extern "C" int pcacc_csr_build(const int32_t *p2v, int64_t n, int64_t m, int32_t
     chunk_scan_i32<<<chunks, 256, 0, s>>>(counts, m, sums, seg_offsets, 1);
     if (small) {
         csr_table_scan<<<(int)((m + 3) / 4), 256, 0, s>>>(table, n_chunks, (int)m, seg_offsets);
-        csr_fill_small<<<n_chunks, 64, 0, s>>>(p2v, n, (int)m, table, order);           // ascending inside every segment by construction
+        csr_fill_small<<<n_chunks, 256, (size_t)4 * m * sizeof(int), s>>>(p2v, n, (int)m, table, order);      // ascending inside every segment by construction
     } else {
         csr_fill<<<pcacc_grid(n, 256), 256, 0, s>>>(p2v, n, seg_offsets, rank, order);
         csr_sort_segments<<<pcacc_grid(m, 256), 256, 0, s>>>(seg_offsets, m, order);
@@ -701,43 +723,97 @@ extern "C" int pcacc_segment_sum_t(const void *src, int dtype, int c, const int3
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Few output rows (instances x frames ~ 100, m*c <= 8192 floats): sums need no CSR at all.  Every workgroup accumulates its
-// slice of the input into an LDS copy of the whole [m,c] output with ds_add_f32 and flushes it with one global atomic per
-// touched element.  (models/tpointnet.py:227,251,283-284 `scatter(..., 'sum' | 'mean')`, libs/loss.py:216.)
+// Few output rows (instances x frames ~ 100, m*c <= 8192 floats): sums need no CSR at all.  Every workgroup accumulates its slice of the input into an
+// LDS copy of the whole [m,c] output.  (models/tpointnet.py:227,251,283-284 `scatter(..., 'sum' | 'mean')`, libs/loss.py:216.)
+// [r6] The LDS copy is 64-bit FIXED POINT: a workgroup first takes the largest magnitude of its slice (the slice is read twice; the second read hits the
+// caches), scales by the power of two that puts it at 2^40, and adds integers (ds_add_u64) -- integer sums do not depend on the order of the additions,
+// where the fp32 LDS / global atomics of rounds 2-5 made every few-row sum of the TubeNet differ in the last bits from run to run.  A slice is at most
+// 2^22 elements, so a segment's sum stays below 2^62; an element loses what lies 2^-40 below the slice's maximum (an fp32 sum loses 2^-24 below its running
+// value).  The workgroups' tables leave as fp32 partials and meet in a fixed order (pcacc_reduce_partials).  A non-finite input makes its workgroup's whole
+// partial NaN -- the sum is non-finite either way, the step's finite check sees it.
 // ---------------------------------------------------------------------------------------------------
+#define SSS_SLICE_MAX (1 << 22)
 __global__ __launch_bounds__(256) void scatter_sum_small_kernel(const float *__restrict__ src, const int32_t *__restrict__ idx,
-                                                                int64_t n_elem, int c, int mc, float *out)
+                                                                int64_t n_elem, int c, int mc, float *__restrict__ partial)
 {
-    extern __shared__ float acc[];
-    for (int j = threadIdx.x; j < mc; j += 256) acc[j] = 0.f;
-    __syncthreads();
+    extern __shared__ unsigned long long acc64[];
+    __shared__ float wmax[4];
+    for (int j = threadIdx.x; j < mc; j += 256) acc64[j] = 0ull;
     const int64_t per_block = (n_elem + gridDim.x - 1) / gridDim.x;
     const int64_t lo = (int64_t)blockIdx.x * per_block, hi = min(n_elem, lo + per_block);
+    float mx = 0.f;
+    bool bad = false;
+    for (int64_t e = lo + threadIdx.x; e < hi; e += 256) {
+        const float v = src[e];
+        mx = fmaxf(mx, fabsf(v));
+        bad |= !(fabsf(v) < __builtin_inff());
+    }
+    if (bad) mx = __builtin_inff();
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+    if (lane_id() == 0) wmax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    float *mine = partial + (int64_t)blockIdx.x * mc;
+    if (!(mx < __builtin_inff())) {                                     // uniform
+        for (int j = threadIdx.x; j < mc; j += 256) mine[j] = __builtin_nanf("");
+        return;
+    }
+    int k = 0;
+    if (mx > 0.f) frexpf(mx, &k);                                       // mx = f 2^k, f in [0.5, 1): scaled values below 2^40
+    const float up = ldexpf(1.f, 40 - k > 126 ? 126 : 40 - k);          // (a slice of denormals only: scaled as far as a float factor reaches)
+    const double down = 1.0 / (double)up;
     for (int64_t e = lo + threadIdx.x; e < hi; e += 256) {
         const int64_t r = e / c;
-        const int k = (int)(e - r * c);
+        const int kk = (int)(e - r * c);
         const int s = idx[r];
-        if (s >= 0) atomicAdd(&acc[s * c + k], src[e]);
+        if (s >= 0) atomicAdd(&acc64[s * c + kk], (unsigned long long)(long long)llrintf(src[e] * up));
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < mc; j += 256) {
-        const float v = acc[j];
-        if (v != 0.f) atomicAdd(&out[j], v);
-    }
+    for (int j = threadIdx.x; j < mc; j += 256) mine[j] = (float)((double)(long long)acc64[j] * down);
 }
 
-extern "C" int pcacc_scatter_sum_small(const float *src, const int32_t *idx, int64_t n, int c, int m, float *out, void *stream)
+__global__ __launch_bounds__(1024) void scatter_sum_small_reduce_kernel(const float *__restrict__ partial, int n_parts, int elems, float *__restrict__ out)
 {
-    if (n < 0 || c <= 0 || m <= 0 || (int64_t)m * c > 8192 || !out) return PCACC_E_ARG;
-    hipStream_t s = pcacc_stream(stream);
-    if (hipMemsetAsync(out, 0, (size_t)m * c * sizeof(float), s) != hipSuccess) return PCACC_E_LAUNCH;
-    if (n == 0) return PCACC_OK;
-    if (!src || !idx) return PCACC_E_ARG;
-    const int64_t n_elem = n * c;
+    pcacc_reduce_partials<16>(partial, n_parts, elems, [&](int e, float v) { out[e] = v; });
+}
+
+static int sss_grid(int64_t n_elem)
+{
     int grid = (int)((n_elem + 256 * 32 - 1) / (256 * 32));
-    if (grid > PCACC_CUS * 4) grid = PCACC_CUS * 4;
-    if (grid < 1) grid = 1;
-    scatter_sum_small_kernel<<<grid, 256, (size_t)m * c * sizeof(float), s>>>(src, idx, n_elem, c, m * c, out);
+    if (grid > PCACC_CUS) grid = PCACC_CUS;                              // one table per CU: the fixed-order reduce behind reads grid x m x c partials
+    const int64_t need = (n_elem + SSS_SLICE_MAX - 1) / SSS_SLICE_MAX;   // a slice never exceeds 2^22 elements (the fixed-point head room)
+    if (grid < need) grid = (int)need;
+    return grid < 1 ? 1 : grid;
+}
+
+extern "C" int pcacc_scatter_sum_small_workspace_bytes(int64_t n, int c, int m, size_t *bytes)
+{
+    if (!bytes || n < 0 || c <= 0 || m <= 0 || (int64_t)m * c > 8192) return PCACC_E_ARG;
+    *bytes = pcacc_align((size_t)sss_grid(n * c) * (size_t)m * c * sizeof(float));
+    return PCACC_OK;
+}
+
+extern "C" int pcacc_scatter_sum_small(const float *src, const int32_t *idx, int64_t n, int c, int m, float *out, void *workspace, size_t workspace_bytes,
+                                       void *stream)
+{
+    size_t need;
+    if (n < 0 || c <= 0 || m <= 0 || (int64_t)m * c > 8192 || !out || pcacc_scatter_sum_small_workspace_bytes(n, c, m, &need) != PCACC_OK) return PCACC_E_ARG;
+    hipStream_t s = pcacc_stream(stream);
+    if (n == 0) {
+        if (hipMemsetAsync(out, 0, (size_t)m * c * sizeof(float), s) != hipSuccess) return PCACC_E_LAUNCH;
+        return PCACC_OK;
+    }
+    if (!src || !idx) return PCACC_E_ARG;
+    if (!workspace || workspace_bytes < need) return PCACC_E_WORKSPACE;
+    const int64_t n_elem = n * c;
+    const int grid = sss_grid(n_elem), mc = m * c;
+    const size_t lds = (size_t)mc * sizeof(unsigned long long);
+    if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(scatter_sum_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return PCACC_E_LAUNCH;
+    float *partial = static_cast<float *>(workspace);
+    scatter_sum_small_kernel<<<grid, 256, lds, s>>>(src, idx, n_elem, c, mc, partial);
+    scatter_sum_small_reduce_kernel<<<(mc + 15) / 16, 1024, 0, s>>>(partial, grid, mc, out);
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;
 }

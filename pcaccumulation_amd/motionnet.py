@@ -218,8 +218,9 @@ class MotionNet(nn.Module):
         results['fb_seg_gt'], results['occ_map'] = prep.fb_seg_gt, prep.occ_map
 
         # 1. pillar encoder -> BEV canvas (channels-last, one streaming pass)
-        input_features = self.pillar_encoder(input_points, None, coordinates, pillar_mean, time_indice, pidx=pidx, keep_dtype=True,
-                                             features=prep.features)
+        with ops.stage('pillar_encoder'):
+            input_features = self.pillar_encoder(input_points, None, coordinates, pillar_mean, time_indice, pidx=pidx, keep_dtype=True,
+                                                 features=prep.features)
         canvas = ops.carry_amax(input_features, ops.pillar_scatter(input_features, pidx, self.compute_dtype))     # rows or zeros
         bev = ops.carry_amax(canvas, ops.canvas_as_nchw(canvas, pidx))         # [B*T, C, Ny, Nx]
         bev = ops.enter_mixed(bev)                                             # mixed mode: segment 1 = U-Net + the two heads on bf16 shadows
@@ -227,7 +228,8 @@ class MotionNet(nn.Module):
         # 2. backbone + 3. fg/bg head
         with self._dense():
             bev_feats = self.unet(bev)
-            fb_seg = self.semseg_head(bev_feats)
+            with ops.stage('fb_head'):
+                fb_seg = self.semseg_head(bev_feats)
         fb_seg = fb_seg.float()
         results['fb_seg_est'] = fb_seg.view(B, T, 2, Ny, Nx)
         fb_est = (fb_seg[:, 1] > fb_seg[:, 0]).long()                          # argmax, ties -> 0 (motionnet.py:190)
@@ -260,7 +262,7 @@ class MotionNet(nn.Module):
                                    + ([pad_flags.reshape(-1).long()] if pad_flags is not None else [])))
         # The ego feature head (two full-resolution convolutions, needed by the ego head only) is queued between the request for the
         # sizes and the wait for them: the GPU still has work when the host wakes up and starts issuing the ego head's small launches.
-        with self._dense():
+        with self._dense(), ops.stage('ego_head'):
             # With the device key-point sampler the ego head reads <= 1024 rows per frame of this head's output: its last convolution is then
             # evaluated at those cells only (ops.SparseConvRows); the dense map otherwise (reference sampler: whole frames are indexed)
             if self.ego_motion_head.kpt_sampler == 'device' and bev_feats.is_cuda and getattr(self.ego_motion_head, 'flat_keypoints', True):
@@ -371,7 +373,8 @@ class MotionNet(nn.Module):
                     'ego_motion_gt': results['ego_motion_gt'],
                     '_pad_flags': pad_flags if self.mode in ['train', 'val'] else None,
                 }
-                self.reconstructor(reconstructor_input, results)
+                with ops.stage('tubenet'):
+                    self.reconstructor(reconstructor_input, results)
                 results['rec_est'] = results['rec_est'].index_copy(0, rec_idx, results['sub_rec_est'])
             self._resolve_scalars(results)
             return results
@@ -406,9 +409,10 @@ class MotionNet(nn.Module):
     def _stpn_heads(self, stpn_map, points, batch_idx):
         """Per-point part of STPN.forward (models/stpn.py:91-104) on the already computed map."""
         mh = self.motionhead
-        ungridded = ops.bilinear_gather(stpn_map, points, batch_idx, abs(self.pc_range[0]), abs(self.pc_range[1]))
-        pos = mh.point_mlp(mh.positional_encoding, points / abs(self.pc_range[0]))          # rows in ops.point_dtype()
-        enc = mh.point_mlp(mh.final_proj, ops.cat_rows(pos, ungridded))
-        classes = mh.point_head(mh.mos_seg, enc)
-        offset = mh.safe_guard_offset(mh.point_head(mh.offset_head, enc))
+        with ops.stage('point_heads'):
+            ungridded = ops.bilinear_gather(stpn_map, points, batch_idx, abs(self.pc_range[0]), abs(self.pc_range[1]))
+            pos = mh.point_mlp(mh.positional_encoding, points / abs(self.pc_range[0]))          # rows in ops.point_dtype()
+            enc = mh.point_mlp(mh.final_proj, ops.cat_rows(pos, ungridded))
+            classes = mh.point_head(mh.mos_seg, enc)
+            offset = mh.safe_guard_offset(mh.point_head(mh.offset_head, enc))
         return classes, offset, stpn_map

@@ -32,7 +32,11 @@ def lib():
                               'g.build()"` or `make -C pcaccumulation_amd/csrc`. There is no CPU fallback.' % LIB_PATH)
         _lib = ctypes.CDLL(LIB_PATH)
         for name in EXPORTS:
-            getattr(_lib, name).restype = ctypes.c_int
+            try:
+                getattr(_lib, name).restype = ctypes.c_int
+            except AttributeError:
+                if not os.environ.get('PCACC_LIB'):               # an experiment build of an earlier round (A/B runs) may lack entry points added since
+                    raise
         _lib.pcacc_target.restype = ctypes.c_char_p
     return _lib
 
@@ -42,7 +46,7 @@ EXPORTS = [
     'pcacc_reload_switches', 'pcacc_cat2_rows', 'pcacc_collate_voxelize_workspace_bytes', 'pcacc_collate_voxelize', 'pcacc_rows_linear_split_dual', 'pcacc_rows_linear_few_dual', 'pcacc_pfn_block_split_forward_dual', 'pcacc_pool_skip_relu_backward_strided_y32', 'pcacc_conv3x3_split_dual', 'pcacc_conv3x3_split_cat', 'pcacc_upconv2x2_split_dual', 'pcacc_voxelize_workspace_bytes', 'pcacc_voxelize', 'pcacc_cell_index',
     'pcacc_frame_pillars_workspace_bytes', 'pcacc_frame_pillars', 'pcacc_compact_mask_workspace_bytes', 'pcacc_compact_mask',
     'pcacc_csr_workspace_bytes', 'pcacc_csr_build', 'pcacc_segment_mean3_maxlabel',
-    'pcacc_segment_workspace_bytes', 'pcacc_segment_max', 'pcacc_segment_max_backward', 'pcacc_segment_sum', 'pcacc_scatter_sum_small',
+    'pcacc_segment_workspace_bytes', 'pcacc_segment_max', 'pcacc_segment_max_backward', 'pcacc_segment_sum', 'pcacc_scatter_sum_small_workspace_bytes', 'pcacc_scatter_sum_small',
     'pcacc_pfn_features', 'pcacc_rows_linear', 'pcacc_rows_wgrad', 'pcacc_pillar_scatter', 'pcacc_gather_rows',
     'pcacc_bilinear_gather', 'pcacc_bilinear_gather_backward', 'pcacc_bev_warp', 'pcacc_rigid_transform',
     'pcacc_sinkhorn_kabsch_workspace_bytes', 'pcacc_sinkhorn_kabsch', 'pcacc_chamfer_workspace_bytes', 'pcacc_chamfer_forward', 'pcacc_chamfer_backward',
@@ -71,6 +75,18 @@ EXPORTS = [
     'pcacc_head_conv3x3_supported', 'pcacc_head_conv3x3_forward', 'pcacc_head_conv3x3_dgrad', 'pcacc_head_conv3x3_wgrad',
     'pcacc_head_conv3x3_wgrad_workspace_bytes',
 ]
+
+
+def x3_experiment(word):
+    """Precision-map experiment (csrc/common.h, -DPCACC_X3_EXPERIMENT build only): the fp32x3 kernels launched on the current stream after this call drop /
+    round the operand halves `word` names.  Raises on the shipped library, which has no such entry points."""
+    l = lib()
+    if not hasattr(l, 'pcacc_x3_experiment_conv'):
+        raise NativeError('x3_experiment: this is not the experiment build of libpcacc_hip.so (tools/r06_precision_map.py builds and loads it)')
+    for name in ('pcacc_x3_experiment_conv', 'pcacc_x3_experiment_rows', 'pcacc_x3_experiment_pfn'):
+        fn = getattr(l, name)
+        fn.restype = ctypes.c_int
+        _check(fn(int(word), _stream()), name)
 
 
 def reload_switches():
@@ -580,8 +596,15 @@ def scatter_sum_small(src, idx, m):
     """out[m,c] = sum of src rows per idx, for m*c <= 8192 (LDS-privatised, no CSR)."""
     n, c = src.shape
     out = torch.empty((m, c), dtype=torch.float32, device=src.device)
+    if os.environ.get('PCACC_R05_ABI'):                           # A/B against a round-5 library (PCACC_LIB): its entry point took no workspace
+        _check(lib().pcacc_scatter_sum_small(_dev(src, torch.float32, 'src'), _dev(idx, torch.int32, 'idx'), _i64(n), int(c), int(m), _dev(out), _stream()),
+               'scatter_sum_small')
+        return out
+    need = ctypes.c_size_t(0)
+    _check(lib().pcacc_scatter_sum_small_workspace_bytes(_i64(n), int(c), int(m), ctypes.byref(need)), 'scatter_sum_small_workspace')
+    ws = _ws(need.value, src.device)
     _check(lib().pcacc_scatter_sum_small(_dev(src, torch.float32, 'src'), _dev(idx, torch.int32, 'idx'), _i64(n), int(c), int(m),
-                                         _dev(out), _stream()), 'scatter_sum_small')
+                                         _dev(out), _dev(ws), ctypes.c_size_t(ws.numel()), _stream()), 'scatter_sum_small')
     return out
 
 

@@ -248,10 +248,10 @@ def gather_rows(src2d, idx):
     return native.gather_rows(src2d.contiguous(), idx.to(torch.int32).contiguous())
 
 
-# [r6] A training step is bit-reproducible: every sum over rows runs in a fixed order (CSR ascending inside segments of any length, piece sums added in piece
-# order, partial-slot reductions in slot order, the offset centres in fixed point).  The few-row sums of the TubeNet and the neighbourhood sums of the sparse ego
-# head convolution used to go through LDS / global fp32 atomics (pcacc_scatter_sum_small, Tensor.index_add_): with this switch on (default) they take the CSR
-# path instead.  PCACC_DETERMINISTIC=0 restores the atomic kernels (A/B: tools/gpu_r06_determinism.sh).
+# [r6] A training step is bit-reproducible: every sum over rows runs in a fixed order or in integers (CSR ascending inside segments of any length, piece sums
+# added in piece order, partial-slot reductions in slot order, the offset centres and the few-row sums of the TubeNet in 64-bit fixed point).  The
+# neighbourhood sums of the sparse ego-head convolution's backward used Tensor.index_add_ (fp32 atomics in arrival order): with this switch on (default) they
+# take a CSR + the atomic-free segment sum instead.  PCACC_DETERMINISTIC=0 restores index_add_ (A/B only).
 DETERMINISTIC = os.environ.get('PCACC_DETERMINISTIC', '1') != '0'
 
 
@@ -280,7 +280,7 @@ class ScatterPlan(object):
         return self._build()[1]
 
     def small(self, c):
-        return 0 < self.m * c <= 8192 and not DETERMINISTIC
+        return 0 < self.m * c <= 8192
 
     def count(self):
         if self._count is None:
@@ -653,6 +653,39 @@ def pfn_pool_block_available(block, x, pidx):
     (short segments: native.segment_max keeps the type)."""
     return (x.shape[1] == 32 and x.is_cuda and not native._seg_two_level(x.shape[0], pidx.m) and os.environ.get('PCACC_PFN_POOL_NODE', '1') != '0'
             and pfn_block_available(block, x, torch.empty((0, 32), dtype=x.dtype, device=x.device)))
+
+
+# ---- stages of the forward, for the precision-map experiment (tools/r06_precision_map.py + the -DPCACC_X3_EXPERIMENT build of the library) -------------
+# MotionNet.forward brackets its stages with `with ops.stage(name):`; without an experiment configured (always, in production) that is a shared null context.
+import contextlib as _contextlib
+_NO_STAGE = _contextlib.nullcontext()
+_STAGE_WORDS = None                     # {stage name: experiment word (csrc/common.h)}; set by the experiment driver only
+
+
+class _Stage(object):
+    def __init__(self, word):
+        self.word = int(word)
+
+    def __enter__(self):
+        native.x3_experiment(self.word)
+
+    def __exit__(self, *exc):
+        native.x3_experiment(0)
+        return False
+
+
+def stage(name):
+    if _STAGE_WORDS is None:
+        return _NO_STAGE
+    return _Stage(_STAGE_WORDS.get(name, 0))
+
+
+def set_stage_words(words):
+    """Experiment driver: {stage: word} or None.  Needs the experiment build of the library (PCACC_LIB=build/x3exp/libpcacc_hip.so)."""
+    global _STAGE_WORDS
+    _STAGE_WORDS = dict(words) if words is not None else None
+    if words is not None:
+        native.x3_experiment(0)
 
 
 _POINT_DTYPE = torch.float32

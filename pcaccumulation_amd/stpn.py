@@ -76,13 +76,15 @@ class STPN(nn.Module):
 
     def backbone(self, x):
         """[B, C, T, H, W] -> [B, 64, H, W]: temporal conv stack, max over T, U-Net (models/stpn.py:82-92)."""
-        x = self.temporal_convs(x)
+        with ops.stage('stpn_temporal'):
+            x = self.temporal_convs(x)
         skips = []
-        for module in self.down_convs:
-            x, before_pool = module(x)
-            skips.append(before_pool)
-        for i, module in enumerate(self.up_convs):
-            x = module(skips[-(i + 2)], x)
+        with ops.stage('stpn_unet'):
+            for module in self.down_convs:
+                x, before_pool = module(x)
+                skips.append(before_pool)
+            for i, module in enumerate(self.up_convs):
+                x = module(skips[-(i + 2)], x)
         return x
 
     @staticmethod

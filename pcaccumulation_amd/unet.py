@@ -102,17 +102,20 @@ class UNet(nn.Module):
 
     def forward(self, x):
         skips = []
-        for module in self.down_convs:
-            x, before_pool = module(x)
-            skips.append(before_pool)
-        for i, module in enumerate(self.up_convs):
-            x = module(skips[-(i + 2)], x)
+        with ops.stage('unet_enc'):
+            for module in self.down_convs:
+                x, before_pool = module(x)
+                skips.append(before_pool)
+        with ops.stage('unet_dec'):
+            for i, module in enumerate(self.up_convs):
+                x = module(skips[-(i + 2)], x)
         # 'mixed' mode: the bf16 gradient graph covers the encoder / decoder body and ends here.  The last convolution and the two heads behind it
         # keep fp32 gradients and fp32x3 products: each head starts conv -> BatchNorm, whose backward returns a zero-mean gradient -- the bias
         # gradients of those first convolutions and of conv_final are sums that cancel (to rounding / to a boundary term), and formed from
         # bf16-rounded gradient maps they were 50 % - 100 x off (0.0020 against 0.0013, 5e-4 against 4e-6 on c3); a BatchNorm fed a
         # bf16-rounded gradient keeps 2^-9 of what it subtracts as noise.  Everything from here to the losses stays fp32.
-        return ops.conv3x3(ops.exit_mixed(x), self.conv_final)
+        with ops.stage('unet_dec'):
+            return ops.conv3x3(ops.exit_mixed(x), self.conv_final)
 
 
 class SegHead1D(nn.Module):

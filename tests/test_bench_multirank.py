@@ -166,4 +166,4 @@ def test_bench_starts_its_own_ranks():
     assert dist['backend'] == 'gloo' and dist['ranks_seen'] == [0, 1]
     assert len(dist['per_rank_ms_per_step']) == 2 and all(t > 0 for t in dist['per_rank_ms_per_step'])
     assert len(dist['exposed_allreduce_ms']) == 2 and all(t >= 0 for t in dist['exposed_allreduce_ms'])
-    assert d['ms_per_step'] >= max(dist['per_rank_ms_per_step']) - 1e-6          # the line's time is the maximum over the ranks
+    assert d["ms_per_step"] >= max(dist["per_rank_ms_per_step"]) - 1e-3          # the line's time is the maximum over the ranks

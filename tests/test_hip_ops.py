@@ -208,6 +208,31 @@ def test_csr_order_is_ascending_for_any_segment_length(native, dev, case):
     np.testing.assert_allclose(a.float().cpu().numpy(), ref, rtol=2e-5, atol=2e-4)
 
 
+@pytest.mark.parametrize('n,c,m', [(300_001, 16, 400), (320_000, 4, 105), (77, 4, 3), (2_000_003, 4, 2048), (5000, 64, 128)])
+def test_scatter_sum_small_is_exact_and_reproducible(native, dev, n, c, m):
+    """[r6] pcacc_scatter_sum_small (few output rows: the TubeNet's per-instance sums, models/tpointnet.py:227-284) in 64-bit fixed point per workgroup:
+    the same bits on every call (rounds 2-5: fp32 LDS / global atomics), within fp32 rounding of the exact sums, negative indices skipped, values spanning
+    many orders of magnitude, a non-finite input seen as NaN."""
+    rng = np.random.RandomState(n % 1000 + c)
+    src = (rng.randn(n, c) * np.exp(rng.uniform(-12, 6, (n, 1)))).astype(np.float32)
+    idx = rng.randint(-1, m, n).astype(np.int32)
+    a = native.scatter_sum_small(torch.from_numpy(src).to(dev), torch.from_numpy(idx).to(dev), m)
+    b = native.scatter_sum_small(torch.from_numpy(src).to(dev), torch.from_numpy(idx).to(dev), m)
+    assert torch.equal(a, b)
+    ref = np.zeros((m, c), np.float64)
+    keep = idx >= 0
+    np.add.at(ref, idx[keep], src[keep].astype(np.float64))
+    scale = np.zeros((m, c), np.float64)
+    np.add.at(scale, idx[keep], np.abs(src[keep]).astype(np.float64))
+    err = np.abs(a.cpu().numpy().astype(np.float64) - ref)
+    assert (err <= 1e-6 * scale + 1e-30).all(), float((err / (scale + 1e-30)).max())      # fp32 partials of exact integer sums: far inside an fp32 sum's own error
+    src[n // 2, c - 1] = np.inf
+    bad = native.scatter_sum_small(torch.from_numpy(src).to(dev), torch.from_numpy(idx).to(dev), m)
+    assert not bool(torch.isfinite(bad).all())
+    empty = native.scatter_sum_small(torch.zeros((0, c), device=dev), torch.zeros((0,), dtype=torch.int32, device=dev), m)
+    assert empty.shape == (m, c) and float(empty.abs().max()) == 0.0
+
+
 # ---------------------------------------------------------------- A5, A6
 def test_pillar_scatter_and_gather_golden(native, dev, golden):
     g = golden('scatter')

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import make_batch, second_draw
+from helpers import make_batch
 from pcaccumulation_amd import ops
 from pcaccumulation_amd.config import default_config
 from pcaccumulation_amd.loss import FuseLoss
@@ -86,7 +86,6 @@ def test_mixed_forward_is_the_fp32x3_forward_and_never_reads_a_shadow():
 
 
 @pytest.mark.gpu
-@second_draw
 def test_mixed_gradients_against_fp32x3():
     dev = torch.device('cuda:0')
     cfg = default_config('waymo', 'train', n_sweeps=3, xy_range=16)

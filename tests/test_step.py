@@ -4,7 +4,7 @@ stream) on the same weights, scene and seed: same loss statistics, same gradient
 import pytest
 import torch
 
-from helpers import make_batch, second_draw
+from helpers import make_batch
 from pcaccumulation_amd import distributed as pdist
 from pcaccumulation_amd.config import default_config
 from pcaccumulation_amd.loss import FuseLoss
@@ -15,7 +15,6 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize('compute_dtype', ['fp32', 'bf16'])
-@second_draw
 def test_two_stream_pipelined_step_matches_plain_step(compute_dtype):
     dev = torch.device('cuda:0')
     cfg = default_config('waymo', 'train', n_sweeps=3, xy_range=16)

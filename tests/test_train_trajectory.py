@@ -25,7 +25,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
-from helpers import make_batch, second_draw  # noqa: E402
+from helpers import make_batch  # noqa: E402
 from pcaccumulation_amd import distributed as pdist  # noqa: E402
 from pcaccumulation_amd.config import default_config  # noqa: E402
 from pcaccumulation_amd.loss import FuseLoss  # noqa: E402
@@ -227,7 +227,6 @@ def test_cpu_trajectory_tiny(name, golden, monkeypatch):
 @pytest.mark.gpu
 @pytest.mark.parametrize('name', TRAJ)
 @pytest.mark.parametrize('mode', ['fp32', 'fp32x3', 'mixed', 'bf16'])
-@second_draw
 def test_gpu_trajectory(name, mode, golden):
     if mode == 'bf16' and name.startswith('c1'):
         pytest.skip('bf16 is bounded on the tiny fixtures only (see TOL)')
