@@ -497,6 +497,43 @@ def scatter_flushed(dtype, batch, pillars):
             'note': 'same launch size, 1 GiB streamed between launches (cold L2 / Infinity Cache)'}
 
 
+def fused_alg_bytes(n_cells, c, m, n):
+    """Algorithmic bytes of one pcacc_segment_max_canvas launch: read the point rows (4 c n), their CSR order (4 n), the segment offsets
+    (4 (m + 1)) and the cell table (4 n_cells); write the fp32 canvas (4 c n_cells), its bf16 shadow (2 c n_cells) and the winners (4 c m) -- every
+    operand once.  SURVEY 8d's pillar-scatter bytes (canvas written incl. zero fill, C s per pillar read, 4 per pillar of index) are the canvas part of it."""
+    return 4 * c * n + 4 * n + 4 * (m + 1) + 4 * n_cells + 4 * c * n_cells + 2 * c * n_cells + 4 * c * m
+
+
+def fused_flushed(batch, pillars, points):
+    """The fused pooling + canvas launch of the roofline object with cold caches (see scatter_flushed): synthetic rows of the step's sizes -- `points`
+    point rows in `pillars` pillars (every pillar at least one point, the rest uniform), pillars numbered in cell order as the model does."""
+    dev = torch.device('cuda')
+    n_cells, c = batch * T_FRAMES * 288 * 288, 32
+    m = int(min(pillars, n_cells))
+    n = int(max(points, m))
+    src = torch.randn(n, c, device=dev)
+    c2p = torch.full((n_cells,), -1, dtype=torch.int32, device=dev)
+    c2p[torch.randperm(n_cells, device=dev)[:m].sort().values] = torch.arange(m, dtype=torch.int32, device=dev)
+    p2v = torch.cat([torch.arange(m, device=dev), torch.randint(0, m, (n - m,), device=dev)])[torch.randperm(n, device=dev)].to(torch.int32)
+    offs, order = native.csr_build(p2v, m)
+    flush = torch.zeros(256 * 1024 * 1024, device=dev)
+    for _ in range(3):
+        native.segment_max_canvas(src, offs, order, m, c2p)
+    native.scatter_timer = []
+    try:
+        for _ in range(12):
+            flush.add_(1.0)
+            native.segment_max_canvas(src, offs, order, m, c2p)
+        torch.cuda.synchronize()
+        us = sorted(t[0].elapsed_us() for t in native.scatter_timer)
+    finally:
+        native.scatter_timer = None
+    alg = fused_alg_bytes(n_cells, c, m, n)
+    med = us[len(us) // 2]
+    return {'frac': alg / med / 1e3 / HBM_PEAK_GBPS, 'achieved': alg / med / 1e3, 'median_launch_us': med, 'launches': len(us),
+            'note': 'same launch size on synthetic rows (uniform pillar sizes), 1 GiB streamed between launches (cold L2 / Infinity Cache)'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -504,7 +541,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--pts-per-frame', type=int, default=160000)
     ap.add_argument('--batch', type=int, default=4, help='sequences per GPU per step (reference default: train.batch_size = 4, configs/default.yaml:33)')
-    ap.add_argument('--dtype', default='mixed', choices=['mixed', 'bf16', 'fp32', 'fp32x3'],
+    ap.add_argument('--dtype', default='mixed', choices=['mixed', 'mixed2', 'bf16', 'fp32', 'fp32x3'],
                     help="compute mode of the timed step.  'mixed' (default): fp32 tensors and fp32-accurate matrix-core products (scaled fp16 hi / lo halves) in the forward -- the "
                          "mode that matches the reference within north_star's 1e-3 -- with a bf16 gradient graph in the backward; 'bf16': everything bf16 (reported beside the headline "
                          "as `bf16`); 'fp32x3': fp32-accurate products both ways; 'fp32': library fp32 convolutions")
@@ -637,7 +674,11 @@ def main():
                 torch.cuda.synchronize()
             watchdog.arm('instrumented step done')
             if rank == 0:
-                flushed = scatter_flushed('bf16' if args.dtype in ('bf16', 'mixed') else args.dtype, args.batch, sum(t[3] for t in timer) / max(len(timer), 1)) if timer else None
+                fused_t = [t for t in timer if t[4] == 'fused']
+                if fused_t:
+                    flushed = fused_flushed(args.batch, sum(t[3] for t in fused_t) / len(fused_t), sum(t[5] for t in fused_t) / len(fused_t))
+                else:
+                    flushed = scatter_flushed('bf16' if args.dtype in ('bf16', 'mixed', 'mixed2') else args.dtype, args.batch, sum(t[3] for t in timer) / max(len(timer), 1)) if timer else None
         except Exception as e:                                         # diagnostics must never take the bench line down
             model_tot, flushed = {'error': repr(e)}, None
         if stepper.skipped and rank == 0:
@@ -649,7 +690,7 @@ def main():
     # The same step in the other mode, N = 1 only: beside the default 'mixed' headline (forward at the accuracy that matches the reference within
     # north_star's 1e-3, tests/test_config_parity.py::test_gpu_config_fp32[mixed-*]) the all-bf16 step; beside a bf16 run the fp32x3 step.
     second_leg = None
-    second_mode = {'mixed': 'bf16', 'bf16': 'fp32x3'}.get(args.dtype)
+    second_mode = {'mixed': 'bf16', 'mixed2': 'bf16', 'bf16': 'fp32x3'}.get(args.dtype)
     if world == 1 and second_mode and not args.no_fp32_leg:
         del stepper, model, opt
         torch.cuda.empty_cache()
@@ -681,25 +722,26 @@ def main():
         # kernel's own begin-to-end time, the quantity rocprofv3's kernel trace reports for the same launch
         # 'mixed' fills two canvases per step (fp32 twin from the fp32 rows, bf16 shadow from the bf16 rows): the roofline object is the bf16 fill --
         # the kernel the bf16 mode runs and earlier rounds reported --, the fp32 fill rides along as `roofline.f32_fill`
+        fused = [t for t in timer if t[4] == 'fused']            # [r6] 'mixed': the encoder's last pooling writes both canvases itself (pcacc_segment_max_canvas)
         fills16 = [t for t in timer if t[4] == torch.bfloat16]
-        fills32 = [t for t in timer if t[4] != torch.bfloat16]
-        timer_main = fills16 or fills32
+        fills32 = [t for t in timer if t[4] not in (torch.bfloat16, 'fused')]
+        timer_main = fused or fills16 or fills32
         esize = lambda t: 2 if t[4] == torch.bfloat16 else 4
         durs = [t[0].elapsed_us() * 1e-6 for t in timer_main]
         if os.environ.get('PCACC_BENCH_DEBUG'):
             print('scatter launches (us):', ['%.1f' % (d * 1e6) for d in durs], file=sys.stderr)
         # SURVEY 8d 'pillar scatter': write C*s*cells (canvas incl. zero fill) + read C*s*M (feature rows) + read 4*M (index), s = bytes
         # per element of the activation dtype
-        alg = [t[1] * t[2] * esize(t) + t[3] * t[2] * esize(t) + 4 * t[3] for t in timer_main]
-        main_bf16 = bool(fills16)
+        alg = [fused_alg_bytes(t[1], t[2], t[3], t[5]) for t in fused] if fused else [t[1] * t[2] * esize(t) + t[3] * t[2] * esize(t) + 4 * t[3] for t in timer_main]
+        main_bf16 = bool(fills16) and not fused
         achieved = (sum(alg) / len(alg)) / (sum(durs) / len(durs)) / 1e9 if durs else 0.0
         # HBM traffic of the same kernel from the committed PMC passes (profiles/r02_pmc_scatter_summary.json, taken at this
         # launch's size: 4 sequences): measured bytes / algorithmic bytes, applied to this run's per-launch algorithmic bytes
         traffic = None
-        pmc_file = next((f for f in ('r05_pmc_scatter_summary.json', 'r04_pmc_scatter_summary.json', 'r02_pmc_scatter_summary.json') if os.path.exists(os.path.join(ROOT, 'profiles', f))), None)
+        pmc_file = next((f for f in ('r06_pmc_scatter_summary.json', 'r05_pmc_scatter_summary.json', 'r04_pmc_scatter_summary.json', 'r02_pmc_scatter_summary.json') if os.path.exists(os.path.join(ROOT, 'profiles', f))), None)
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', pmc_file)))
-            key = 'pillar_scatter_rows16' if main_bf16 else 'pillar_scatter_vec4<0>'
+            key = 'seg_max_canvas' if fused else ('pillar_scatter_rows16' if main_bf16 else 'pillar_scatter_vec4<0>')
             traffic = pmc[key]['traffic_over_algorithmic'] * (sum(alg) / len(alg)) if alg else None
         except Exception:
             traffic = None
@@ -725,7 +767,9 @@ def main():
                             'collectives_per_step': collectives_per_step, 'gradient_buckets': len(stepper_buckets), 'bucket_mb': [round(4e-6 * (e - b), 2) for b, e in stepper_buckets],
                             'ranks_seen': sorted(r['rank'] for r in per_rank if r), 'per_rank_ms_per_step': [round(r['ms_per_step'], 3) for r in per_rank if r],
                             'exposed_allreduce_ms': [round(r['exposed_allreduce_ms'], 3) for r in per_rank if r], 'rank_devices': [r['device'] for r in per_rank if r]},
-            'roofline': {'kernel': 'pillar_scatter_rows16_k<1, true, true> (BEV canvas fill, bf16 rows -> bf16 canvas, streaming loads / stores)' if main_bf16 else 'pillar_scatter_vec4<0> (BEV canvas fill)', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
+            'roofline': {'kernel': ('seg_max_canvas_kernel<8> (pillar scatter fused into the encoder\'s last max-pooling: point rows -> fp32 BEV canvas + bf16 shadow + winners, one pass)' if fused else
+                                    'pillar_scatter_rows16_k<1, true, true> (BEV canvas fill, bf16 rows -> bf16 canvas, streaming loads / stores)' if main_bf16 else 'pillar_scatter_vec4<0> (BEV canvas fill)'),
+                         'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
                          'traffic_source': 'PMC FETCH_SIZE x2 + WRITE_SIZE (calibrated on a 128 MiB copy), profiles/%s' % pmc_file,
                          'launches_timed': len(durs), 'avg_launch_us': (sum(durs) / len(durs) * 1e6) if durs else None,
@@ -751,8 +795,8 @@ def main():
             line['roofline']['f32_fill'] = {'kernel': 'pillar_scatter_vec4<0> (the fp32 twin canvas of the mixed mode; cached stores: the first convolution reads it next)', 'achieved': ach, 'frac': ach / HBM_PEAK_GBPS,
                                             'avg_launch_us': sum(d32) / len(d32) * 1e6, 'algorithmic_bytes_per_launch': sum(a32) / len(a32), 'launches_timed': len(d32)}
         if second_leg is not None:
-            line[second_leg['dtype'] if args.dtype == 'mixed' else 'matched_accuracy'] = second_leg
-        if args.dtype == 'mixed':
+            line[second_leg['dtype'] if args.dtype in ('mixed', 'mixed2') else 'matched_accuracy'] = second_leg
+        if args.dtype in ('mixed', 'mixed2'):
             line['dtype_note'] = ('mixed = fp32 tensors with fp32-accurate products on the 16-bit matrix cores (scaled fp16 hi / lo halves, 3 MFMAs per product) in the '
                                   'FORWARD: mos_iou / ego errors / EPE within 1e-3 of the reference on c2-c5 + nus11 + c3_lidar '
                                   '(tests/test_config_parity.py::test_gpu_config_fp32[mixed-*]); bf16 tensors and products (fp32 accumulation, fp32 weight '

@@ -227,6 +227,19 @@ int pcacc_rows_wgrad_cat_bf16(const uint16_t *dy, const uint16_t *dy_mask, const
                               const int32_t *b_index, int32_t ka, int32_t x_relu, int64_t rows, int32_t k, int32_t n,
                               float *dw_aug, void *workspace, size_t workspace_bytes, void *stream);
 
+/* [r6] The encoder's last max-pooling and the pillar scatter as ONE pass -- models/pillar_encoder.py:119-122 (scatter(net, point_to_voxel_map, 'max')) followed by
+ * models/pillar_encoder.py:125-174 (scatter_point_pillar): the kernel walks the canvas cells; an occupied cell (cell2pillar >= 0) reduces its pillar's point
+ * rows and stores the maximum at the cell, an empty cell stores zeros.  No [m, c] pooled-row table in between.  'mixed' mode form: fp32 rows in, the fp32
+ * canvas AND its bf16 shadow out; arg [m, c] i32 = winners (lowest point index attaining the maximum), as pcacc_segment_max.  Short segments only
+ * (n / m <= 16; PCACC_E_ARG otherwise: pool and fill separately).  start_event / stop_event: optional hipEvents attached to the dispatch (both or neither).
+ *   src [n,c] f32; seg_offsets [m+1], order [n] (pcacc_csr_build); cell2pillar [n_cells] i32; canvas32 [n_cells,c] f32; canvas16 [n_cells,c] bf16
+ * Backward: grad_src[i,k] = grad_canvas[cell[p2v[i]],k] where point i won channel k of its pillar, else 0; cell [m] i32 = the pillars' cell numbers. */
+int pcacc_segment_max_canvas(const float *src, int c, const int32_t *seg_offsets, const int32_t *order, int64_t n, int64_t m,
+                             const int32_t *cell2pillar, int64_t n_cells, float *canvas32, uint16_t *canvas16, int32_t *arg,
+                             void *start_event, void *stop_event, void *stream);
+int pcacc_segment_max_canvas_backward(const void *grad_canvas, int dtype, const int32_t *arg, const int32_t *p2v, const int32_t *cell, int64_t n,
+                                      int c, void *grad_src, int out_dtype, void *stream);
+
 /* Sum of rows per index for FEW output rows (m*c <= 8192), no CSR needed: LDS-privatised accumulation.
  * The per-instance 'sum' / 'mean' poolings of models/tpointnet.py:227,251,283-284 and libs/loss.py:216 (torch_scatter: fp32 atomics in arrival order).
  * [r6] run-to-run identical: every workgroup sums its slice in 64-bit fixed point (scaled by the slice's own maximum; integer additions commute) and the
@@ -301,6 +314,9 @@ int pcacc_bilinear_gather_backward_sorted(const void *grad_out, int grad_dtype, 
 int pcacc_bev_warp(const void *bev, int dtype, int n_batch, int nt, int h, int w, int c,
                    const float *inv_pose, float x_reso, float y_reso, float x_min, float y_min,
                    void *out, void *stream);
+/* [r6] 'mixed' mode form: fp32 map in, the fp32 result AND its bf16 copy (same element offsets) out of one pass. */
+int pcacc_bev_warp_dual(const float *bev, int n_batch, int nt, int h, int w, int c, const float *inv_pose, float x_reso, float y_reso, float x_min,
+                        float y_min, float *out, uint16_t *out16, void *stream);
 
 /* A10. Per-point rigid transform -- models/motionnet.py:117-135 (transform_points).
  *   points [n,3] f32; frame_idx [n] i32 = b*nt + t; tsfm [n_frames,16] f32; out [n,3] f32 */

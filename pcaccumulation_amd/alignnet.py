@@ -18,7 +18,7 @@ def update_gt_inst_motion(inst_motion_gt, ego_motion_gt, ego_motion_est):
     T = ego_motion_gt.size(1)
     if sum(sizes) == 0:
         return [m.to(device).float().view(0, T, 4, 4) for m in inst_motion_gt]
-    motion = torch.cat([m.to(device).float() for m in inst_motion_gt], dim=0) if len(sizes) > 1 else inst_motion_gt[0].to(device).float()
+    motion = (torch.cat([m.to(device) for m in inst_motion_gt], dim=0) if len(sizes) > 1 else inst_motion_gt[0].to(device)).float()     # one conversion, not one per sample
     est_inv = native.inv4x4(ego_motion_est.detach().float())                   # inv() minus its host sync and its dozen launches
     if len(sizes) > 1:
         sample = native.upload_small([b for b, k in enumerate(sizes) for _ in range(k)], torch.int64, device)
@@ -73,7 +73,11 @@ class AlignNet(BaseModel):
         alive_idx = torch.where(flags[1])[0]
         relabel = -1 * torch.ones(K).long()
         relabel[alive_idx] = torch.arange(alive_idx.numel())
-        compact = native.upload_small(relabel, torch.int64, device)[inst_indice]   # every point's instance is alive by construction
+        table = native.upload_small(relabel, torch.int64, device)
+        if inst_indice.is_cuda and inst_indice.numel():                             # a row gather of the small table (the generic index kernel: 150 us at 320 k points)
+            compact = native.gather_rows(table.view(-1, 1), inst_indice.to(torch.int32)).view(-1)
+        else:
+            compact = table[inst_indice]                                            # every point's instance is alive by construction
         return extra, inst_motion[native.upload_small(alive_idx, torch.int64, device)], compact
 
     def _merge_batch_instances(self, labels, batch_col, motions):
@@ -82,6 +86,8 @@ class AlignNet(BaseModel):
         # every sample of a collated batch non-empty this is the running sum of the instance counts, known on the host.
         sizes = [m.size(0) for m in motions]
         base = native.upload_small([sum(sizes[:b]) for b in range(len(sizes))], labels.dtype, labels.device)
+        if labels.is_cuda and labels.numel():
+            return labels + native.gather_rows(base.view(-1, 1), batch_col.to(torch.int32)).view(-1), torch.cat(motions)
         return labels + base[batch_col.long()], torch.cat(motions)
 
     def forward(self, input_dict, results):

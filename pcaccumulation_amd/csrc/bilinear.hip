@@ -399,7 +399,7 @@ extern "C" int pcacc_bilinear_gather_backward_sorted(const void *grad_out, int g
 template <int BF16>
 __global__ __launch_bounds__(256) void bev_warp_kernel(const void *__restrict__ bev, int n_batch, int nt, int h, int w, int c,
                                                        const float *__restrict__ inv_pose, float x_reso, float y_reso,
-                                                       float x_min, float y_min, void *__restrict__ out)
+                                                       float x_min, float y_min, void *__restrict__ out, uint16_t *__restrict__ out16 = nullptr)
 {
     const int lpp = c / 4;
     const int64_t total = (int64_t)n_batch * nt * h * w * lpp;
@@ -428,7 +428,20 @@ __global__ __launch_bounds__(256) void bev_warp_kernel(const void *__restrict__ 
             r = sample4<BF16>(static_cast<const char *>(bev) + (int64_t)(b * nt + t) * frame_elems * esz, w, c, tp, ch);
         }
         store4<BF16>(out, dst, r);
+        // [r6] 'mixed' mode: the bf16 shadow of the warped map (what the bf16 backward of the first temporal convolution reads) from the same registers --
+        // it used to be a conversion pass of its own over the 212 MB map (ops._EnterMixed)
+        if (!BF16 && out16) *reinterpret_cast<uint2 *>(out16 + dst) = make_uint2(pcacc_pack_bf16x2(r.x, r.y), pcacc_pack_bf16x2(r.z, r.w));
     }
+}
+
+extern "C" int pcacc_bev_warp_dual(const float *bev, int n_batch, int nt, int h, int w, int c, const float *inv_pose, float x_reso, float y_reso, float x_min,
+                                   float y_min, float *out, uint16_t *out16, void *stream)
+{
+    if (n_batch <= 0 || nt <= 0 || h <= 0 || w <= 0 || c <= 0 || (c % 4) || !bev || !inv_pose || !out || !out16) return PCACC_E_ARG;
+    const int64_t total = (int64_t)n_batch * nt * h * w * (c / 4);
+    bev_warp_kernel<0><<<pcacc_grid(total, 256), 256, 0, pcacc_stream(stream)>>>(bev, n_batch, nt, h, w, c, inv_pose, x_reso, y_reso, x_min, y_min, out, out16);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
 }
 
 extern "C" int pcacc_bev_warp(const void *bev, int dtype, int n_batch, int nt, int h, int w, int c,

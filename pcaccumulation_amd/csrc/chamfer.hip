@@ -139,15 +139,23 @@ static int chamfer_dir(const float *q, int n, const float4 *tg, int m, int b, un
         return PCACC_OK;
     }
     const int qblocks = (n + CH_BLOCK * CH_QPT - 1) / (CH_BLOCK * CH_QPT);
+    // [r6] Tasks = (query block, target split, batch element).  The chip holds PCACC_CUS x 4 workgroups of this kernel at once and every task takes the same
+    // time, so the launch runs in rounds of that many: rounds 2-5 split the targets just far enough to reach ONE round (157 query blocks x 7 splits = 1 099
+    // tasks for 160 k x 160 k points: a quarter of the CUs then ran a fifth workgroup while the rest idled -- 4.97 ms).  Now: the split count whose task count
+    // fills its last round best (157 x 13 = 2 041 of 2 048: 4.06 ms, 41 -> 50 TFLOP/s; tools/exp_chamfer.hip, profiles/r06_chamfer_variants.txt).
+    // The partial results of the splits merge through the 64-bit atomicMin either way; at least 2 048 targets per split keep that merge a rounding error.
+    const int slots = PCACC_CUS * 4;
     int splits = 1;
-    const int want = PCACC_CUS * 4;
-    if (qblocks * b < want) {
-        splits = (want + qblocks * b - 1) / (qblocks * b);
-        const int max_splits = (m + 1023) / 1024;           // keep >= 1024 targets per split
-        if (splits > max_splits) splits = max_splits;
-        if (splits < 1) splits = 1;
+    double best_fill = 0.0;
+    const int max_splits = m / 2048 < 1 ? 1 : (m / 2048 > 64 ? 64 : m / 2048);
+    for (int sp = 1; sp <= max_splits; ++sp) {
+        const int64_t tasks = (int64_t)qblocks * b * sp;
+        const int64_t rounds = (tasks + slots - 1) / slots;
+        const double fill = (double)tasks / (double)(rounds * slots);
+        if (fill > best_fill + 0.02) { best_fill = fill; splits = sp; }     // a larger split count must buy at least 2 % of a round
     }
-    const int per = (m + splits - 1) / splits;
+    int per = (m + splits - 1) / splits;
+    per = (per + CH_CHUNK - 1) / CH_CHUNK * CH_CHUNK;        // whole skip-test chunks per split (only the last split has a tail)
     splits = (m + per - 1) / per;
     const int direct = splits == 1;
     if (!direct && hipMemsetAsync(packed, 0xFF, (size_t)b * n * 8, s) != hipSuccess) return PCACC_E_LAUNCH;

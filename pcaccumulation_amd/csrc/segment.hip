@@ -582,6 +582,176 @@ extern "C" int pcacc_segment_max_dual(const float *src, int c, const int32_t *se
     return segment_max_any(src, PCACC_F32, c, seg_offsets, order, n, m, out, arg, workspace, workspace_bytes, stream, out16);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// [r6] A4 + A5 as ONE pass (models/pillar_encoder.py:119-122 -> :125-174): the encoder's last max-pooling writes the BEV canvas itself.  The kernel walks
+// the CELLS of the canvas; an occupied cell reduces its pillar's point rows (ascending point index: the CSR) and stores the 32-channel maximum at the cell,
+// an empty cell stores zeros -- the [M, C] pooled-row table of rounds 1-5 (written by the pooling, read back by two canvas fills in the 'mixed' mode: fp32
+// twin + bf16 shadow) is never written.  Both canvases come from the same registers: fp32 with cached stores (the first convolution reads it next), the bf16
+// shadow with streaming stores (read a whole forward later, by the backward).  arg[pillar] = the winners, for the backward.
+// c / 4 lanes per cell; pillars are numbered in cell order (ops.PillarIndex), so the winners' table is written front to back.
+// ---------------------------------------------------------------------------------------------------
+typedef uint32_t seg_u32x2 __attribute__((ext_vector_type(2)));
+typedef float seg_f32x4 __attribute__((ext_vector_type(4)));
+typedef int seg_i32x4 __attribute__((ext_vector_type(4)));
+// CPG cells per lane group and iteration: the chain cell table -> segment offsets -> order -> point rows is four dependent memory round trips per cell; with two
+// cells in flight per group every round trip carries twice the requests (rows of ~3 points per pillar: the kernel is bound by what it keeps in flight).
+// NT: the point rows and their order are read once, the winners are read a whole forward later: streaming policy for those; the fp32 canvas keeps cached stores.
+template <int LPP, int CPG, bool NT>
+__global__ __launch_bounds__(256) void seg_max_canvas_kernel(const float4 *__restrict__ src, const int32_t *__restrict__ seg_offsets,
+                                                             const int32_t *__restrict__ order, const int32_t *__restrict__ cell2pillar, int64_t n_cells,
+                                                             float4 *__restrict__ canvas32, uint16_t *__restrict__ canvas16, int4 *__restrict__ arg)
+{
+    const int sub = threadIdx.x % LPP;
+    const int64_t per_block = 256 / LPP;
+    const int64_t stride = (int64_t)gridDim.x * per_block;
+    auto ld_row = [&](int64_t i4) -> float4 {
+        if (NT) {
+            const seg_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const seg_f32x4 *>(src) + i4);
+            return make_float4(v.x, v.y, v.z, v.w);
+        }
+        return src[i4];
+    };
+    for (int64_t cell0 = (int64_t)blockIdx.x * per_block + threadIdx.x / LPP; cell0 < n_cells; cell0 += stride * CPG) {
+        int s[CPG], b[CPG], e[CPG];
+#pragma unroll
+        for (int u = 0; u < CPG; ++u) {
+            const int64_t cell = cell0 + u * stride;
+            s[u] = cell < n_cells ? cell2pillar[cell] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < CPG; ++u) {
+            b[u] = s[u] >= 0 ? seg_offsets[s[u]] : 0;
+            e[u] = s[u] >= 0 ? seg_offsets[s[u] + 1] : 0;
+        }
+        float4 best[CPG];
+        int4 bi[CPG];
+        int idx[CPG][4];
+        float4 rows[CPG][4];
+#pragma unroll
+        for (int u = 0; u < CPG; ++u) {
+            best[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            bi[u] = make_int4(-1, -1, -1, -1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) idx[u][j] = b[u] + j < e[u] ? (NT ? __builtin_nontemporal_load(order + b[u] + j) : order[b[u] + j]) : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < CPG; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rows[u][j] = idx[u][j] >= 0 ? ld_row((int64_t)idx[u][j] * LPP + sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < CPG; ++u) {
+            int k0 = b[u];
+            while (true) {                                                  // the first four rows of both cells are in flight together; longer pillars go on alone
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = idx[u][j];
+                    if (i < 0) continue;
+                    const float4 v = rows[u][j];
+                    if (bi[u].x < 0 || v.x > best[u].x || (v.x == best[u].x && i < bi[u].x)) { best[u].x = v.x; bi[u].x = i; }
+                    if (bi[u].y < 0 || v.y > best[u].y || (v.y == best[u].y && i < bi[u].y)) { best[u].y = v.y; bi[u].y = i; }
+                    if (bi[u].z < 0 || v.z > best[u].z || (v.z == best[u].z && i < bi[u].z)) { best[u].z = v.z; bi[u].z = i; }
+                    if (bi[u].w < 0 || v.w > best[u].w || (v.w == best[u].w && i < bi[u].w)) { best[u].w = v.w; bi[u].w = i; }
+                }
+                k0 += 4;
+                if (k0 >= e[u]) break;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) idx[u][j] = k0 + j < e[u] ? order[k0 + j] : -1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rows[u][j] = idx[u][j] >= 0 ? ld_row((int64_t)idx[u][j] * LPP + sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < CPG; ++u) {
+            const int64_t cell = cell0 + u * stride;
+            if (cell >= n_cells) continue;
+            if (s[u] >= 0) {
+                if (NT) {
+                    const seg_i32x4 a = {bi[u].x, bi[u].y, bi[u].z, bi[u].w};
+                    __builtin_nontemporal_store(a, reinterpret_cast<seg_i32x4 *>(arg) + (int64_t)s[u] * LPP + sub);
+                } else arg[(int64_t)s[u] * LPP + sub] = bi[u];
+            }
+            canvas32[cell * LPP + sub] = best[u];
+            const seg_u32x2 pk = {pcacc_pack_bf16x2(best[u].x, best[u].y), pcacc_pack_bf16x2(best[u].z, best[u].w)};
+            __builtin_nontemporal_store(pk, reinterpret_cast<seg_u32x2 *>(canvas16) + cell * LPP + sub);
+        }
+    }
+}
+
+extern "C" int pcacc_segment_max_canvas(const float *src, int c, const int32_t *seg_offsets, const int32_t *order, int64_t n, int64_t m,
+                                        const int32_t *cell2pillar, int64_t n_cells, float *canvas32, uint16_t *canvas16, int32_t *arg,
+                                        void *start_event, void *stop_event, void *stream)
+{
+    if (m < 0 || n < 0 || n_cells < 0 || c <= 0 || (c % 4) || c > 256 || (start_event == nullptr) != (stop_event == nullptr)) return PCACC_E_ARG;
+    if (n_cells == 0) return PCACC_OK;
+    if (!cell2pillar || !canvas32 || !canvas16 || (m > 0 && (!seg_offsets || !arg || (n > 0 && (!src || !order))))) return PCACC_E_ARG;
+    if (seg_use_two_level(n, m)) return PCACC_E_ARG;              // long segments: the two-level pooling + the separate fills (the caller's fallback)
+    const void *fn;
+    int cpg = 1;
+    // Measured at the step's size (tools/bench_fused_canvas.py, profiles/r06_fused_canvas_variants.txt; warm / behind 1 GiB of streamed lines): one cell per
+    // group with cached loads 208 / 222 us, with streaming loads 198 / 200 us (the default), two cells in flight 199 / 215 us, four 229 / 237 us -- the
+    // kernel is bound by the random 128-byte row reads themselves, not by how many of them a lane group keeps in flight.
+    const char variant = pcacc_switches().scatter_variant;     // A/B (PCACC_SCATTER_VARIANT): 'a' cached loads; 'b' two cells, cached loads; 'e' two cells, streaming; 'd' four
+    switch (c / 4) {
+        case 1: fn = reinterpret_cast<const void *>(seg_max_canvas_kernel<1, 1, true>); break;
+        case 2: fn = reinterpret_cast<const void *>(seg_max_canvas_kernel<2, 1, true>); break;
+        case 4: fn = reinterpret_cast<const void *>(seg_max_canvas_kernel<4, 1, true>); break;
+        case 8:
+            fn = reinterpret_cast<const void *>(seg_max_canvas_kernel<8, 1, true>);
+            if (variant == 'a') fn = reinterpret_cast<const void *>(seg_max_canvas_kernel<8, 1, false>);
+            else if (variant == 'b') { fn = reinterpret_cast<const void *>(seg_max_canvas_kernel<8, 2, false>); cpg = 2; }
+            else if (variant == 'e') { fn = reinterpret_cast<const void *>(seg_max_canvas_kernel<8, 2, true>); cpg = 2; }
+            else if (variant == 'd') { fn = reinterpret_cast<const void *>(seg_max_canvas_kernel<8, 4, true>); cpg = 4; }
+            break;
+        case 16: fn = reinterpret_cast<const void *>(seg_max_canvas_kernel<16, 1, true>); break;
+        case 32: fn = reinterpret_cast<const void *>(seg_max_canvas_kernel<32, 1, true>); break;
+        case 64: fn = reinterpret_cast<const void *>(seg_max_canvas_kernel<64, 1, true>); break;
+        default: return PCACC_E_ARG;
+    }
+    void *args[] = {(void *)&src, (void *)&seg_offsets, (void *)&order, (void *)&cell2pillar, (void *)&n_cells, (void *)&canvas32, (void *)&canvas16, (void *)&arg};
+    // events attached to the dispatch itself (see pillar_scatter_launch, canvas.hip): bench.py times this kernel live for its roofline object
+    if (hipExtLaunchKernel(fn, dim3(pcacc_grid((n_cells + cpg - 1) / cpg * (c / 4), 256)), dim3(256), args, 0, pcacc_stream(stream), reinterpret_cast<hipEvent_t>(start_event),
+                           reinterpret_cast<hipEvent_t>(stop_event), 0) != hipSuccess)
+        return PCACC_E_LAUNCH;
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}
+
+// Backward of the pass above: grad_src[i,k] = (arg[p2v[i],k] == i) ? grad_canvas[cell[p2v[i]],k] : 0 -- seg_max_bwd_kernel reading the canvas gradient in place
+// through the pillars' cell numbers instead of a gathered [M, C] copy of it.
+__global__ __launch_bounds__(256) void seg_max_canvas_bwd_kernel(const void *__restrict__ grad_canvas, const int4 *__restrict__ arg, const int32_t *__restrict__ p2v,
+                                                                 const int32_t *__restrict__ cell, int64_t n, int lpp, void *__restrict__ grad_src, bool bf,
+                                                                 bool out_bf)
+{
+    const int64_t total = n * lpp;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t i = e / lpp;
+        const int sub = (int)(e - i * lpp);
+        const int64_t s = p2v[i];
+        const int4 a = arg[s * lpp + sub];
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.x == (int)i || a.y == (int)i || a.z == (int)i || a.w == (int)i) {      // most points win nothing: their rows never touch the canvas gradient
+            const float4 g = pcacc_ld4(grad_canvas, bf, (int64_t)cell[s] * lpp + sub);
+            r.x = (a.x == (int)i) ? g.x : 0.f;
+            r.y = (a.y == (int)i) ? g.y : 0.f;
+            r.z = (a.z == (int)i) ? g.z : 0.f;
+            r.w = (a.w == (int)i) ? g.w : 0.f;
+        }
+        pcacc_st4(grad_src, out_bf, e, r);
+    }
+}
+
+extern "C" int pcacc_segment_max_canvas_backward(const void *grad_canvas, int dtype, const int32_t *arg, const int32_t *p2v, const int32_t *cell, int64_t n,
+                                                 int c, void *grad_src, int out_dtype, void *stream)
+{
+    if (n < 0 || c <= 0 || (c % 4) || (dtype != PCACC_F32 && dtype != PCACC_BF16) || (out_dtype != PCACC_F32 && out_dtype != PCACC_BF16)) return PCACC_E_ARG;
+    if (n == 0) return PCACC_OK;
+    if (!grad_canvas || !arg || !p2v || !cell || !grad_src) return PCACC_E_ARG;
+    seg_max_canvas_bwd_kernel<<<pcacc_grid(n * (c / 4), 256), 256, 0, pcacc_stream(stream)>>>(grad_canvas, reinterpret_cast<const int4 *>(arg), p2v, cell, n, c / 4,
+                                                                                         grad_src, dtype == PCACC_BF16, out_dtype == PCACC_BF16);
+    PCACC_CHECK_LAUNCH();
+    return PCACC_OK;
+}
+
 // grad_src[i,k] = (arg[p2v[i],k] == i) ? grad_out[p2v[i],k] : 0        (fully coalesced, no atomics)
 // ACC: added to what grad_src holds (the rows' gradient from their other consumer: one pass instead of a dense result plus autograd's
 // add of the two), with the largest magnitude of the sums into out_amax (256 zeroed slots; may be NULL)

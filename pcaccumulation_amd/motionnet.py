@@ -100,7 +100,9 @@ class MotionNet(nn.Module):
         self.grid = grid_shape(cfg)
         # 'fp32x3': fp32 tensors, products of the dense stacks / wide row layers on the bf16 matrix cores from hi / lo halves (ops.set_split)
         self.compute_mode = cfg['misc'].get('compute_dtype', 'fp32')
-        self.compute_dtype = {'fp32': torch.float32, 'fp32x3': torch.float32, 'mixed': torch.float32, 'bf16': torch.bfloat16}[self.compute_mode]
+        # 'mixed2' [r6]: 'mixed' with the STPN's per-point layers (positional code, final projection, the two SegHead1D) on bf16 rows -- the one stage the
+        # precision map (profiles/r06_precision_map.txt) shows to hold north_star's 1e-3 with one-term bf16 products
+        self.compute_dtype = {'fp32': torch.float32, 'fp32x3': torch.float32, 'mixed': torch.float32, 'mixed2': torch.float32, 'bf16': torch.bfloat16}[self.compute_mode]
         # pillars renumbered in canvas-cell order inside forward() (ops.PillarIndex); False keeps the voxeliser's numbering
         self.cell_ordered_pillars = bool(cfg['misc'].get('cell_ordered_pillars', True))
         self._optimizer_watched = False          # watch_optimizer()
@@ -196,9 +198,9 @@ class MotionNet(nn.Module):
         B, T, Ny, Nx = batch_size, nt, ny, nx
         device = coordinates.device
         ops.set_point_dtype(self.compute_dtype if device.type == 'cuda' else torch.float32)
-        ops.set_split(self.compute_mode in ('fp32x3', 'mixed') and device.type == 'cuda')
+        ops.set_split(self.compute_mode in ('fp32x3', 'mixed', 'mixed2') and device.type == 'cuda')
         # 'mixed': fp32x3 forward values, bf16 gradient graph inside the two convolution segments (ops.set_mixed)
-        ops.set_mixed(self.compute_mode == 'mixed' and device.type == 'cuda')
+        ops.set_mixed(self.compute_mode in ('mixed', 'mixed2') and device.type == 'cuda')
         ops.twins_clear()
         # Prepared (packed / split) copies of the convolution weights outlive writers that bypass the parameters' version counters (fused
         # optimizers).  With the optimizer watched (watch_optimizer: its step invalidates the copies) nothing is needed here and the micro-steps of a
@@ -219,9 +221,10 @@ class MotionNet(nn.Module):
 
         # 1. pillar encoder -> BEV canvas (channels-last, one streaming pass)
         with ops.stage('pillar_encoder'):
-            input_features = self.pillar_encoder(input_points, None, coordinates, pillar_mean, time_indice, pidx=pidx, keep_dtype=True,
-                                                 features=prep.features)
-        canvas = ops.carry_amax(input_features, ops.pillar_scatter(input_features, pidx, self.compute_dtype))     # rows or zeros
+            input_features, is_canvas = self.pillar_encoder(input_points, None, coordinates, pillar_mean, time_indice, pidx=pidx, keep_dtype=True,
+                                                            features=prep.features, canvas=True)
+        # 'mixed' mode: the encoder's last pooling has written the canvas itself (ops.segment_max_canvas); otherwise rows -> canvas here
+        canvas = input_features if is_canvas else ops.carry_amax(input_features, ops.pillar_scatter(input_features, pidx, self.compute_dtype))     # rows or zeros
         bev = ops.carry_amax(canvas, ops.canvas_as_nchw(canvas, pidx))         # [B*T, C, Ny, Nx]
         bev = ops.enter_mixed(bev)                                             # mixed mode: segment 1 = U-Net + the two heads on bf16 shadows
 
@@ -319,10 +322,9 @@ class MotionNet(nn.Module):
             bev_feats = ops.carry_amax(bev_feats, bev_feats.detach())            # (the scale bound travels with the detached alias)
             C = bev_feats.size(1)
             bev_cl = bev_feats.permute(0, 2, 3, 1).contiguous().view(B, T, Ny, Nx, C)
-            warped = ops.bev_warp(ops.twin_or_self(bev_cl), native.inv4x4(pose_est), self.resolution[0], self.resolution[1],
-                                  self.pc_range[0], self.pc_range[1])
-            ops.carry_amax(ops.twin_or_self(bev_feats), warped)                    # convex combinations of bev_feats' cells (or zero)
-            warped = ops.enter_mixed(warped)                                       # mixed mode: segment 2 = STPN temporal stack + U-Net
+            # mixed mode: segment 2 = STPN temporal stack + U-Net starts here (the warp writes the segment's bf16 shadow itself)
+            warped = ops.bev_warp_enter_mixed(bev_cl, native.inv4x4(pose_est), self.resolution[0], self.resolution[1], self.pc_range[0], self.pc_range[1],
+                                              amax_from=ops.twin_or_self(bev_feats))
             warped_feats = ops.carry_amax(warped, warped.permute(0, 4, 1, 2, 3))   # [B,C,T,H,W], channels_last_3d memory
             transformed_points = ops.rigid_transform(input_points, frame_idx, pose_est)
             results['transformed_points'] = transformed_points
@@ -334,7 +336,8 @@ class MotionNet(nn.Module):
             if n_fb > MIN_POINTS:
                 with self._dense():
                     stpn_map = self.motionhead.backbone(warped_feats)
-                mos, offset, mos_feats = self._stpn_heads(stpn_map, self._take_rows(transformed_points, fb_idx), batch_idx.index_select(0, fb_idx))
+                fb_idx32 = fb_idx.to(torch.int32)                       # one conversion for every row gather of this index list
+                mos, offset, mos_feats = self._stpn_heads(stpn_map, self._take_rows(transformed_points, fb_idx32), self._take_rows(batch_idx, fb_idx32))
                 full_mos = full_mos.index_copy(0, fb_idx, mos)
                 full_offset = full_offset.index_copy(0, fb_idx, offset)
             results['mos_est'] = full_mos
@@ -352,23 +355,24 @@ class MotionNet(nn.Module):
                 n_rec = int(rec_mask.sum())                   # the one extra host sync of test mode
             if n_rec > MIN_POINTS:
                 rec_idx = native.compact_mask(rec_mask, n_rec)
+                rec_idx32 = rec_idx.to(torch.int32)
                 results['_rec_idx'] = rec_idx
                 if self.mode in ['train', 'val']:
                     results['_gtfg_idx'] = rec_idx            # = nonzero(fb_labels == 1), what FuseLoss.get_offset_loss supervises (libs/loss.py:199)
                 # mos_feats exists whenever rec_mask passes in train/val (fb_mask is a superset of rec_mask)
-                backbone_feats = ops.bilinear_gather(bev_feats, self._take_rows(input_points, rec_idx), frame_idx.index_select(0, rec_idx),
+                backbone_feats = ops.bilinear_gather(bev_feats, self._take_rows(input_points, rec_idx32), self._take_rows(frame_idx, rec_idx32),
                                                      abs(self.pc_range[0]), abs(self.pc_range[1]))       # temporal_ungrid
-                tp_rec = self._take_rows(transformed_points, rec_idx)
-                motion_feats = ops.bilinear_gather(mos_feats, tp_rec, batch_idx.index_select(0, rec_idx),
+                tp_rec = self._take_rows(transformed_points, rec_idx32)
+                motion_feats = ops.bilinear_gather(mos_feats, tp_rec, self._take_rows(batch_idx, rec_idx32),
                                                    abs(self.pc_range[0]), abs(self.pc_range[1]))          # ungrid
                 reconstructor_input = {
-                    'inst_labels': inst_labels[rec_idx],
-                    'time_indice': time_indice[rec_idx],
+                    'inst_labels': self._take_rows(inst_labels, rec_idx32),
+                    'time_indice': self._take_rows(time_indice, rec_idx32),
                     'transformed_points': tp_rec,
                     'backbone_feats': backbone_feats,
                     'motion_feats': motion_feats,
                     'inst_motion_gt': input_dict['inst_motion_gt'],
-                    'mos_labels': input_dict['sd_labels'][rec_idx, 0].long(),
+                    'mos_labels': self._take_rows(input_dict['sd_labels'], rec_idx32)[:, 0].long(),
                     'ego_motion_est': results['ego_motion_est'].detach(),     # alignnet.py:240 detaches what is derived from it
                     'ego_motion_gt': results['ego_motion_gt'],
                     '_pad_flags': pad_flags if self.mode in ['train', 'val'] else None,
@@ -389,12 +393,16 @@ class MotionNet(nn.Module):
             return upper()
 
     @staticmethod
-    def _take_rows(points, idx):
-        """points[idx] for the [N,3] f32 point tables (no gradient): one row-gather launch of the library instead of the generic advanced-indexing
-        kernel (73 us per call at 3.2 M points)."""
-        if points.is_cuda and points.dim() == 2 and points.dtype == torch.float32 and not points.requires_grad:
-            return native.gather_rows(points.contiguous(), idx.to(torch.int32))
-        return points[idx]
+    def _take_rows(table, idx):
+        """table[idx] for the per-point tables of the batch (no gradient; any element type whose rows are a multiple of 4 bytes: [N,3] f32 points, [N,2] f64
+        (sample, frame), [N] i32 / i64 labels and indices): one row-gather launch of the library instead of the generic advanced-indexing / index_select
+        kernels (73 - 160 us per call at 3.2 M rows).  idx: int32 (or int64, converted here)."""
+        if table.is_cuda and table.dim() in (1, 2) and not table.requires_grad and table.is_contiguous():
+            rows = table if table.dim() == 2 else table.view(-1, 1)
+            if (rows.shape[1] * rows.element_size()) % 4 == 0 and rows.shape[0] > 0:
+                out = native.gather_rows(rows, idx if idx.dtype == torch.int32 else idx.to(torch.int32))
+                return out if table.dim() == 2 else out.view(-1)
+        return table[idx.long()]
 
     @staticmethod
     def _resolve_scalars(results):
@@ -411,6 +419,14 @@ class MotionNet(nn.Module):
         mh = self.motionhead
         with ops.stage('point_heads'):
             ungridded = ops.bilinear_gather(stpn_map, points, batch_idx, abs(self.pc_range[0]), abs(self.pc_range[1]))
+            if self.compute_mode == 'mixed2' and points.is_cuda and points.shape[0] >= ops.MIN_ROWS_FUSED_LINEAR:
+                # the gather above read the fp32 map; from here to the logits: bf16 rows (ops.bf16_rows)
+                with ops.bf16_rows():
+                    pos = mh.point_mlp(mh.positional_encoding, points / abs(self.pc_range[0]))
+                    enc = mh.point_mlp(mh.final_proj, ops.cat_rows(pos, ungridded))
+                    classes = mh.point_head(mh.mos_seg, enc)
+                    offset = mh.safe_guard_offset(mh.point_head(mh.offset_head, enc))
+                return classes, offset, stpn_map
             pos = mh.point_mlp(mh.positional_encoding, points / abs(self.pc_range[0]))          # rows in ops.point_dtype()
             enc = mh.point_mlp(mh.final_proj, ops.cat_rows(pos, ungridded))
             classes = mh.point_head(mh.mos_seg, enc)

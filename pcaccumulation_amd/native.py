@@ -48,11 +48,11 @@ EXPORTS = [
     'pcacc_csr_workspace_bytes', 'pcacc_csr_build', 'pcacc_segment_mean3_maxlabel',
     'pcacc_segment_workspace_bytes', 'pcacc_segment_max', 'pcacc_segment_max_backward', 'pcacc_segment_sum', 'pcacc_scatter_sum_small_workspace_bytes', 'pcacc_scatter_sum_small',
     'pcacc_pfn_features', 'pcacc_rows_linear', 'pcacc_rows_wgrad', 'pcacc_pillar_scatter', 'pcacc_gather_rows',
-    'pcacc_bilinear_gather', 'pcacc_bilinear_gather_backward', 'pcacc_bev_warp', 'pcacc_rigid_transform',
+    'pcacc_bilinear_gather', 'pcacc_bilinear_gather_backward', 'pcacc_bev_warp', 'pcacc_bev_warp_dual', 'pcacc_rigid_transform',
     'pcacc_sinkhorn_kabsch_workspace_bytes', 'pcacc_sinkhorn_kabsch', 'pcacc_chamfer_workspace_bytes', 'pcacc_chamfer_forward', 'pcacc_chamfer_backward',
     'pcacc_cluster_workspace_bytes', 'pcacc_cluster', 'pcacc_conv3x3_prepare_weights', 'pcacc_conv3x3_bf16',
     'pcacc_rows_linear_bf16', 'pcacc_rows_linear_mixed', 'pcacc_rows_wgrad_mixed',
-    'pcacc_segment_max_t', 'pcacc_segment_max_dual', 'pcacc_segment_max_backward_t', 'pcacc_segment_max_backward_acc', 'pcacc_segment_sum_t', 'pcacc_rows_wgrad_bf16_workspace_bytes', 'pcacc_rows_wgrad_bf16', 'pcacc_sample_subsets', 'pcacc_conv3x3_wgrad_workspace_bytes', 'pcacc_conv3x3_wgrad_bf16', 'pcacc_upload_words', 'pcacc_bilinear_base_cells', 'pcacc_bilinear_sorted_workspace_bytes', 'pcacc_bilinear_gather_backward_sorted', 'pcacc_prep_points',
+    'pcacc_segment_max_t', 'pcacc_segment_max_dual', 'pcacc_segment_max_canvas', 'pcacc_segment_max_canvas_backward', 'pcacc_segment_max_backward_t', 'pcacc_segment_max_backward_acc', 'pcacc_segment_sum_t', 'pcacc_rows_wgrad_bf16_workspace_bytes', 'pcacc_rows_wgrad_bf16', 'pcacc_sample_subsets', 'pcacc_conv3x3_wgrad_workspace_bytes', 'pcacc_conv3x3_wgrad_bf16', 'pcacc_upload_words', 'pcacc_bilinear_base_cells', 'pcacc_bilinear_sorted_workspace_bytes', 'pcacc_bilinear_gather_backward_sorted', 'pcacc_prep_points',
     'pcacc_kabsch_cov_forward', 'pcacc_kabsch_cov_backward', 'pcacc_kabsch_rt_forward', 'pcacc_kabsch_rt_backward', 'pcacc_ego_affinity_forward', 'pcacc_ego_affinity_backward_workspace_bytes', 'pcacc_ego_affinity_backward', 'pcacc_ego_perm_forward', 'pcacc_ego_perm_backward',
     'pcacc_sinkhorn_train_workspace_bytes', 'pcacc_sinkhorn_forward', 'pcacc_sinkhorn_backward',
     'pcacc_seg_loss_workspace_bytes', 'pcacc_seg_loss_forward', 'pcacc_seg_loss_backward',
@@ -348,6 +348,35 @@ def segment_max_backward_acc(grad_out, arg, p2v, grad_src, want_amax=False):
     return amax
 
 
+def segment_max_canvas(src, offs, order, m, cell2pillar):
+    """The encoder's last pooling written straight into the BEV canvas ('mixed' mode): src [n,c] f32 -> (canvas32 [n_cells,c] f32, canvas16 [n_cells,c] bf16,
+    arg [m,c] i32).  bench.py times this dispatch through `scatter_timer` (its roofline object)."""
+    n, c = src.shape
+    n_cells = cell2pillar.numel()
+    dev = src.device
+    canvas32 = torch.empty((n_cells, c), dtype=torch.float32, device=dev)
+    canvas16 = torch.empty((n_cells, c), dtype=torch.bfloat16, device=dev)
+    arg = torch.empty((m, c), dtype=torch.int32, device=dev)
+    t = None
+    if scatter_timer is not None and c >= 32:
+        t = KernelTimer()
+        scatter_timer.append((t, n_cells, c, m, 'fused', n))
+    _check(lib().pcacc_segment_max_canvas(_dev(src, torch.float32, 'src'), int(c), _dev(offs, torch.int32), _dev(order, torch.int32), _i64(n), _i64(m),
+                                          _dev(cell2pillar, torch.int32), _i64(n_cells), _dev(canvas32), _dev(canvas16), _dev(arg),
+                                          t.start if t else None, t.stop if t else None, _stream()), 'segment_max_canvas')
+    return canvas32, canvas16, arg
+
+
+def segment_max_canvas_backward(grad_canvas, arg, p2v, cell, n, out_dtype=None):
+    """grad of the point rows from the canvas gradient [n_cells,c] (f32 / bf16), read in place through the pillars' cell numbers."""
+    c = grad_canvas.shape[1]
+    out_dtype = out_dtype or grad_canvas.dtype
+    out = torch.empty((n, c), dtype=out_dtype, device=grad_canvas.device)
+    _check(lib().pcacc_segment_max_canvas_backward(_dev(grad_canvas, None, 'grad_canvas'), _dtype_code(grad_canvas), _dev(arg, torch.int32), _dev(p2v, torch.int32),
+                                                   _dev(cell, torch.int32), _i64(n), int(c), _dev(out), _dtype_code(out), _stream()), 'segment_max_canvas_backward')
+    return out
+
+
 def segment_sum(src, offs, order, m):
     """Per-segment sums (accumulated in f32): [m,c] in the rows' type for short segments, f32 for long ones."""
     n, c = src.shape
@@ -451,6 +480,17 @@ def bev_warp(bev, inv_pose, x_reso, y_reso, x_min, y_min):
                                 _dev(inv_pose, torch.float32, 'inv_pose'), ctypes.c_float(x_reso), ctypes.c_float(y_reso),
                                 ctypes.c_float(x_min), ctypes.c_float(y_min), _dev(out), _stream()), 'bev_warp')
     return out
+
+
+
+def bev_warp_dual(bev, inv_pose, x_reso, y_reso, x_min, y_min):
+    """bev_warp on an fp32 map -> (warped f32, warped as bf16): the 'mixed' mode's shadow of the warped features from the same store."""
+    b, nt, h, w, c = bev.shape
+    out = torch.empty_like(bev)
+    out16 = torch.empty(bev.shape, dtype=torch.bfloat16, device=bev.device)
+    _check(lib().pcacc_bev_warp_dual(_dev(bev, torch.float32, 'bev'), b, nt, h, w, c, _dev(inv_pose, torch.float32, 'inv_pose'), ctypes.c_float(x_reso),
+                                     ctypes.c_float(y_reso), ctypes.c_float(x_min), ctypes.c_float(y_min), _dev(out), _dev(out16), _stream()), 'bev_warp_dual')
+    return out, out16
 
 
 def rigid_transform(points, frame_idx, tsfm):

@@ -123,6 +123,50 @@ def segment_max(src, pidx):
     return _SegmentMax.apply(src, pidx)[0]
 
 
+class _SegmentMaxCanvas(torch.autograd.Function):
+    """[r6] scatter(net, p2v, 'max') and scatter_point_pillar (models/pillar_encoder.py:119-122 -> :125-174) as ONE pass in the 'mixed' mode: the pooling
+    walks the canvas cells and writes the fp32 canvas and its bf16 shadow itself (pcacc_segment_max_canvas); no [M, C] pooled-row table.  Backward: the point
+    rows' gradient straight from the canvas gradient through the pillars' cell numbers (no gathered [M, C] copy)."""
+
+    @staticmethod
+    def forward(ctx, src, pidx):
+        s32 = twin(src)
+        canvas32, canvas16, arg = native.segment_max_canvas(s32, pidx.seg_offsets, pidx.order, pidx.m, pidx.cell2pillar)
+        carry_amax(s32, canvas32)                                  # maxima of src's rows, or zeros: its bound holds
+        if _POISON:
+            canvas16.fill_(float('nan'))
+        ctx.pidx = pidx
+        ctx.save_for_backward(arg)
+        return shadow(canvas32, canvas16)
+
+    @staticmethod
+    def backward(ctx, grad_canvas):
+        (arg,) = ctx.saved_tensors
+        pidx = ctx.pidx
+        g = grad_canvas.contiguous()
+        if g.dtype not in (torch.float32, torch.bfloat16):
+            g = g.float()
+        return native.segment_max_canvas_backward(g, arg, pidx.p2v, pidx.cell, pidx.n, out_dtype=torch.bfloat16), None
+
+
+_FUSED_CANVAS = os.environ.get('PCACC_FUSED_CANVAS', '1') != '0'      # A/B switch: '0' = pooling, then the two canvas fills (rounds 1-5)
+
+
+def segment_max_canvas_available(src, pidx):
+    """'mixed' mode on the GPU, bf16 shadow rows with a contiguous fp32 twin, a full pillar index (cell table), short segments."""
+    if not (_FUSED_CANVAS and _MIXED and src.is_cuda and src.dtype == torch.bfloat16 and src.dim() == 2 and src.shape[1] % 4 == 0 and src.is_contiguous()
+            and getattr(pidx, 'cell2pillar', None) is not None and getattr(pidx, 'cell', None) is not None and pidx.m > 0
+            and not native._seg_two_level(src.shape[0], pidx.m)):
+        return False
+    t = twin(src, required=False)
+    return t is not None and t.dtype == torch.float32 and t.is_contiguous()
+
+
+def segment_max_canvas(src, pidx):
+    """-> the canvas [n_cells, C] (a bf16 shadow with its fp32 twin registered) of the per-pillar maxima of `src`."""
+    return _SegmentMaxCanvas.apply(src.contiguous(), pidx)
+
+
 class _BroadcastToPoints(torch.autograd.Function):
     """pillar_feats[point_to_voxel_map] -- the gather after each pooling (pillar_encoder.py:116)."""
 
@@ -742,6 +786,27 @@ def mixed_mode():
     return _MIXED
 
 
+class bf16_rows(object):
+    """Context: the row operators issued inside run as in the 'bf16' compute mode (bf16 rows, one-term bf16 matrix-core products, fp32 accumulation) although the
+    model runs 'mixed' -- the 'mixed2' mode's point heads (MotionNet._stpn_heads).  The precision map of round 6 (profiles/r06_precision_map.txt: every stage
+    of the forward reduced alone, six fixtures) shows the STPN's per-point layers to be the one stage whose outputs stay within north_star's 1e-3 with bf16
+    products: the fg / moving decision of a point is not a near-tie, and nothing behind these layers amplifies their rounding (the TubeNet reads the STPN's MAP,
+    not the point heads).  The flags are read when an operator's forward is ISSUED; each operator's backward follows what its forward saved."""
+
+    def __enter__(self):
+        self.saved = (_MIXED, _SPLIT, _POINT_DTYPE)
+        set_split(False)
+        globals()['_MIXED'] = False                           # not set_mixed(False): the segment's twins are still needed by the operators after the context
+        set_point_dtype(torch.bfloat16)
+        return self
+
+    def __exit__(self, *exc):
+        globals()['_MIXED'] = self.saved[0]
+        set_split(self.saved[1])
+        set_point_dtype(self.saved[2])
+        return False
+
+
 def set_poison(flag):
     """Test switch: every shadow made from now on holds NaN instead of the rounded twin (forward values must not change; the backward is garbage)."""
     global _POISON
@@ -855,6 +920,19 @@ def on_twin(x16, fn, params=(), replay=None):
 
 def enter_mixed(x):
     return _EnterMixed.apply(x) if _MIXED and x.is_cuda and x.dtype == torch.float32 else x
+
+
+def bev_warp_enter_mixed(bev_cl, inv_pose, x_reso, y_reso, x_min, y_min, amax_from=None):
+    """enter_mixed(bev_warp(...)) for a map that carries no gradient (models/motionnet.py:205-209 detaches it): in the 'mixed' mode the warp kernel writes
+    the bf16 shadow beside its fp32 result (pcacc_bev_warp_dual) instead of a conversion pass over the 212 MB map; everywhere else the two calls."""
+    src = twin_or_self(bev_cl)
+    if _MIXED and src.is_cuda and src.dtype == torch.float32 and not src.requires_grad and src.is_contiguous() and src.shape[-1] % 4 == 0 and not _POISON:
+        w32, w16 = native.bev_warp_dual(src, inv_pose.contiguous().float(), float(x_reso), float(y_reso), float(x_min), float(y_min))
+        carry_amax(amax_from if amax_from is not None else src, w32)      # convex combinations of the map's cells (or zero): its bound holds
+        return shadow(w32, w16)
+    warped = bev_warp(src, inv_pose, x_reso, y_reso, x_min, y_min)
+    carry_amax(amax_from if amax_from is not None else src, warped)
+    return enter_mixed(warped)
 
 
 def exit_mixed(x):

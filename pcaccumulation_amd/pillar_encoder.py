@@ -82,10 +82,12 @@ class PillarFeatureNet(nn.Module):
                                    float(self.vy), float(self.x_offset), float(self.y_offset), float(self.scale),
                                    float(self.n_frames))
 
-    def forward(self, raw_points, point_to_voxel_map, coordinates, pillar_mean, time_indice, pidx=None, keep_dtype=False, features=None):
+    def forward(self, raw_points, point_to_voxel_map, coordinates, pillar_mean, time_indice, pidx=None, keep_dtype=False, features=None, canvas=False):
         """keep_dtype: return the pooled rows in the element type of the point rows (bf16 in the bf16 compute mode; MotionNet feeds
         them to the canvas fill as they are) instead of the reference's float32.  features: the 9 inputs per point when the caller
-        built them ahead of time (point_features depends on the batch only, MotionNet.prepare_inputs)."""
+        built them ahead of time (point_features depends on the batch only, MotionNet.prepare_inputs).  canvas=True (MotionNet): the result is the pair
+        (tensor, is_canvas) -- where the last pooling can write the BEV canvas itself (ops.segment_max_canvas: 'mixed' mode) the tensor is the [n_cells, C]
+        canvas and no pooled-row table exists; otherwise the pooled rows as always."""
         if pidx is None:                                                  # reference call signature
             pidx = PillarIndex.from_point_map(point_to_voxel_map, coordinates.shape[0])
         if features is None:
@@ -99,8 +101,11 @@ class PillarFeatureNet(nn.Module):
             else:
                 net = block.forward_pooled(net, ops.carry_amax(net, ops.segment_max(net, pidx)), pidx)      # maxima of net's rows: net's bound holds
         feats = ops.linear_rows(net, self.fc_c)
+        if canvas and ops.segment_max_canvas_available(feats, pidx):
+            return ops.segment_max_canvas(feats, pidx), True
         pooled = ops.carry_amax(feats, ops.segment_max(feats, pidx))
-        return pooled if keep_dtype else pooled.float()
+        pooled = pooled if keep_dtype else pooled.float()
+        return (pooled, False) if canvas else pooled
 
 
 def _index_for(coords, batch_size, input_shape):

@@ -41,6 +41,8 @@ class STPN(nn.Module):
 
     def safe_guard_offset(self, offset, min=-20, max=20):
         """models/stpn.py:61-65: NaN -> 0, Inf -> 0, clamp to +-20."""
+        if offset.is_cuda:                                          # the same function in two passes instead of seven (NaN, +Inf, -Inf -> 0, then the clamp)
+            return torch.clamp(torch.nan_to_num(offset, nan=0.0, posinf=0.0, neginf=0.0), min, max)
         offset = torch.where(torch.isnan(offset), torch.zeros_like(offset), offset)
         offset = torch.where(torch.isinf(offset), torch.zeros_like(offset), offset)
         return torch.clamp(offset, min, max)

@@ -62,7 +62,9 @@ GRAD_TOL = {'fp32': (3e-2, 2.5e-2), 'fp32x3': (3e-2, 2.5e-2),
             # 'mixed' (fp32x3 forward, bf16 backward inside the pillar encoder and the convolution stacks): the same metrics bit for bit as fp32x3; its
             # bf16 gradient products add 0.1 - 0.3 % to the deviations of the STPN group, which sits at the fp32 modes' own limit (c3:
             # motionhead.init_conv.2.bias 3.0 % in fp32x3, 3.3 % in mixed; tools/gradnorm_dev.py) -- pre-declared 3.5 % for that group
-            'mixed': (3.5e-2, 2.5e-2)}
+            'mixed': (3.5e-2, 2.5e-2),
+            # 'mixed2' [r6] = 'mixed' with the STPN's per-point layers on bf16 rows (profiles/r06_precision_map.txt): a new mode held to mixed's bounds
+            'mixed2': (3.5e-2, 2.5e-2)}
 # c3_lidar (LiDAR-distributed points: two thirds of the BEV cells are empty, so far more of the STPN's max-over-frames / max-pool winners
 # are near-ties decided by summation order): the routed gradients differ more between implementations -- measured over three runs
 # each, fp32 (library convolutions) and fp32x3 alike: STPN temporal-conv biases 3.6 - 3.9 %, TubeNet embedding biases 2.9 % off the
@@ -265,7 +267,7 @@ def test_device_key_point_sampler_gives_the_host_sampler_error_distribution(gold
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('name', CONFIGS)
-@pytest.mark.parametrize('mode', ['fp32', 'fp32x3', 'mixed'])
+@pytest.mark.parametrize('mode', ['fp32', 'fp32x3', 'mixed', 'mixed2'])
 def test_gpu_config_fp32(name, mode, golden):
     """north_star's 1e-3 in both fp32-accurate modes: 'fp32' (library fp32 convolutions, fp32 vector row kernels) and 'fp32x3' (the
     hand-written split-bf16 MFMA kernels of csrc/conv_split.hip: the matched-accuracy figure of bench.py)."""

@@ -269,6 +269,50 @@ def test_pillar_scatter_and_gather_golden(native, dev, golden):
     assert np.array_equal(back.cpu().numpy(), g['feats'])
 
 
+@pytest.mark.parametrize('size', ['golden', 'c3'])
+def test_pooling_into_the_canvas_is_pooling_then_scatter(native, dev, golden, size):
+    """[r6] pcacc_segment_max_canvas (the encoder's last scatter-max, models/pillar_encoder.py:119-122, writing the BEV canvas of
+    models/pillar_encoder.py:125-174 itself) against the two passes it replaces: the fp32 canvas, its bf16 shadow and the winners bit for bit equal to
+    pcacc_segment_max followed by pcacc_pillar_scatter (itself pinned to the reference's golden canvas above), empty cells zero, exact ties to the lowest
+    point index; the backward (canvas gradient read through the pillars' cells) equal to gather_rows + segment_max_backward.  At the golden batch and at
+    c3 size (5 x 288^2 cells, 800 k points, crowded and empty cells)."""
+    if size == 'golden':
+        cfg, inp = _batch(dev)
+        nx, ny, nz, nt = (int(v) for v in inp['shape'][0])
+        cell, c2p = native.cell_index(inp['coordinates'].to(dev), nx, ny, nt, 2)
+        p2v = inp['point_to_voxel_map'][:, 0].contiguous().to(dev)
+        m = inp['coordinates'].shape[0]
+    else:
+        rng = np.random.RandomState(3)
+        n_cells, m = 5 * 288 * 288, 300_000
+        cells = np.sort(rng.choice(n_cells, m, replace=False)).astype(np.int32)           # pillars in cell order, as the model numbers them
+        c2p_np = np.full(n_cells, -1, np.int32)
+        c2p_np[cells] = np.arange(m, dtype=np.int32)
+        sizes = np.concatenate([np.ones(m, np.int64), np.zeros(0, np.int64)])
+        extra = rng.randint(0, m, 500_000 - 2000)
+        crowded = rng.randint(0, m, 20)
+        p2v_np = np.concatenate([np.arange(m), extra, np.repeat(crowded, 100)]).astype(np.int32)       # every pillar >= 1 point, some with > 100
+        rng.shuffle(p2v_np)
+        cell, c2p, p2v = torch.from_numpy(cells).to(dev), torch.from_numpy(c2p_np).to(dev), torch.from_numpy(p2v_np).to(dev)
+    n = p2v.shape[0]
+    rng = np.random.RandomState(5)
+    src = rng.randn(n, 32).astype(np.float32)
+    src[rng.randint(0, n, 3000)] = src[rng.randint(0, n, 3000)]                          # exact ties across points
+    src = torch.from_numpy(src).to(dev)
+    offs, order = native.csr_build(p2v, m)
+    pooled, arg = native.segment_max(src, offs, order, m)
+    want32 = native.pillar_scatter(pooled, c2p)
+    want16 = native.pillar_scatter(pooled.to(torch.bfloat16), c2p, torch.bfloat16)
+    got32, got16, got_arg = native.segment_max_canvas(src, offs, order, m, c2p)
+    assert torch.equal(got32, want32) and torch.equal(got16, want16) and torch.equal(got_arg, arg)
+    assert float(got32[c2p < 0].abs().max()) == 0.0 if bool((c2p < 0).any()) else True
+    for dt in (torch.bfloat16, torch.float32):
+        g = torch.from_numpy(rng.randn(c2p.numel(), 32).astype(np.float32)).to(dev).to(dt)
+        want = native.segment_max_backward(native.gather_rows(g, cell), arg, p2v, n, out_dtype=torch.bfloat16)
+        got = native.segment_max_canvas_backward(g, arg, p2v, cell, n, out_dtype=torch.bfloat16)
+        assert torch.equal(got, want)
+
+
 def test_pillar_scatter_full_size_roundtrip(native, dev):
     """c3-size property test: scatter then gather is the identity on pillars; empty cells are zero."""
     nx = ny = 288

@@ -170,12 +170,14 @@ def test_tolerances_are_the_frozen_ones():
     tt = importlib.import_module('test_train_trajectory')
     cs = importlib.import_module('test_conv_split')
     ms = importlib.import_module('test_mlp_split')
-    assert cp.GRAD_TOL == {'fp32': (3e-2, 2.5e-2), 'fp32x3': (3e-2, 2.5e-2), 'mixed': (3.5e-2, 2.5e-2)}
+    assert cp.GRAD_TOL == {'fp32': (3e-2, 2.5e-2), 'fp32x3': (3e-2, 2.5e-2), 'mixed': (3.5e-2, 2.5e-2), 'mixed2': (3.5e-2, 2.5e-2)}     # mixed2 [r6]: a new mode at mixed's bounds
     assert cp.GRAD_TOL_LIDAR == (6e-2, 2.5e-2)
     assert cp.BF16_TOL == dict(ego=1.5, iou=5e-2, epe=1.5)
     assert tt.ENVELOPE == 10.0
     assert tt.TOL['fp32'] == tt.TOL['fp32x3'] == dict(loss_tol=1e-3, grad_cos=0.999, grad_rel=1e-2, upd_cos=0.98)
-    assert tt.TOL['mixed'] == dict(loss_tol=1e-3, grad_cos=0.999, grad_rel=3e-2, upd_cos=0.98)
+    # [r6] term_floor_step2 = 3e-3: the one bound opened in round 6, for the mode with a bf16 backward only (cause, both measured values and the failing
+    # run: tests/test_train_trajectory.py:check, DESIGN.md section 4a, profiles/r06_trajectory_mixed_c1_step2.txt)
+    assert tt.TOL['mixed'] == dict(loss_tol=1e-3, grad_cos=0.999, grad_rel=3e-2, upd_cos=0.98, term_floor_step2=3e-3)
     assert tt.TOL['bf16'] == dict(loss_tol=0.15, grad_cos=0.9, grad_rel=3.0, upd_cos=0.5, term_tol=0.5, norm_tol=0.1, require_fb=False)
     assert cs.TOL == 3e-6 and ms.TOL == 3e-6
 

@@ -131,7 +131,7 @@ def _cos(a, b):
 ENVELOPE = 10.0
 
 
-def check(g, got, loss_tol, grad_cos, grad_rel, upd_cos, term_tol=1e-2, norm_tol=1e-2, require_fb=True):
+def check(g, got, loss_tol, grad_cos, grad_rel, upd_cos, term_tol=1e-2, norm_tol=1e-2, require_fb=True, term_floor_step2=1e-3):
     """Every bound is max(the mode's own tolerance, ENVELOPE x what the REFERENCE's trajectory moves by when it is re-run with another thread
     count or with its weights perturbed by a few ulps (fixture keys *_runs; row 0 is the fixture)): the reference against itself agrees to
     1e-7 on the first loss and drifts apart by a factor of ~5 per optimizer step on the tiny scene (1.3e-3 - 2.4e-3 at step 5), by per cent
@@ -155,10 +155,20 @@ def check(g, got, loss_tol, grad_cos, grad_rel, upd_cos, term_tol=1e-2, norm_tol
     trel = np.abs(ta - tb) / np.maximum(np.abs(tb), 1e-1)
     if os.environ.get('PCACC_TRAJ_VERBOSE'):
         print('term rel max per term', dict(zip([str(x) for x in g['term_keys']], trel.max(0))), 'envelope', tenv.max(0))
+        with np.printoptions(threshold=10000, linewidth=240, precision=3):
+            print('term rel per step (rows) and term (columns):')
+            print(trel)
+            print('its bound:')
+            print(np.maximum(np.array([[min(term_tol, 1e-4 * 10 ** j if j != 1 else term_floor_step2)] for j in range(k)]) if term_tol <= 1e-2 else term_tol, ENVELOPE * tenv))
     # the ego term goes through Sinkhorn + SVD on soft correspondences: two fp32 implementations of that chain differ more than one
     # implementation re-run with another thread count (step 2: 2e-4 here against an envelope of 1e-6), hence a floor of term_tol (1e-2 from
     # the second optimizer step on); the first optimizer step's terms are pure forward parity and held to 1e-4 x 10^micro-step
-    floor = np.array([[min(term_tol, 1e-4 * 10 ** j)] for j in range(k)]) if term_tol <= 1e-2 else term_tol
+    # [r6] term_floor_step2: the floor of the SECOND micro-step (the first forward on updated weights).  1e-3 where the gradients are fp32-accurate; the 'mixed'
+    # mode's bf16 backward puts 3e-3 there (TOL): Adam's first step moves every weight by lr * sign(g) whatever |g|, so gradient entries below the bf16 noise
+    # floor (3e-2 of a tensor's largest entry, grad_rel) take a random sign, and the ego term -- Sinkhorn + SVD on soft correspondences -- of the next forward
+    # moves by ~1e-3: 6.8e-4 with round 5's summation order, 1.33e-3 with round 6's fixed-order sums (two draws of the same noise; the step is bit-reproducible
+    # since round 6, so a draw is now a property of the build: profiles/r06_trajectory_mixed_c1_step2.txt).
+    floor = np.array([[min(term_tol, 1e-4 * 10 ** j if j != 1 else term_floor_step2)] for j in range(k)]) if term_tol <= 1e-2 else term_tol
     assert (trel < np.maximum(floor, ENVELOPE * tenv)).all(), ('loss terms', [str(x) for x in g['term_keys']], ta.tolist(), tb.tolist(), trel)
     # sampled gradient entries of the first optimizer step (before the clip)
     a, b = got['grads'].astype(np.float64), g['grad_samples_step1'].astype(np.float64)
@@ -206,7 +216,7 @@ TOL = {'fp32': dict(loss_tol=1e-3, grad_cos=0.999, grad_rel=1e-2, upd_cos=0.98),
        # mixed: the forward is the fp32x3 forward; the backward's bf16 products leave ~1 % of a parameter's largest entry on single entries behind a
        # dozen layers (measured 1.1 - 1.5e-2 on U-Net bias gradients; cosine over all samples 1 - 7.5e-5 / 3.7e-5 / 3.3e-4 / 2.4e-4 on the four fixtures,
        # fp32x3: 1.4e-5 / 1.6e-5 / 2.9e-4 / 2.1e-4, the reference against itself with weights perturbed by 1e-6: 3.4e-5 / 1.4e-5 / 2.0e-4 / 4.5e-4)
-       'mixed': dict(loss_tol=1e-3, grad_cos=0.999, grad_rel=3e-2, upd_cos=0.98),
+       'mixed': dict(loss_tol=1e-3, grad_cos=0.999, grad_rel=3e-2, upd_cos=0.98, term_floor_step2=3e-3),
        # bf16: bounded, not matched: decisions may flip, the draw then changes
        # bf16: bounded, not matched -- on the tiny fixtures only.  At c1 size with closed-form weights (|g| ~ 1100, the
        # reference's own trajectories part by per cent from step 3) the bf16 step's gradient direction decorrelates from the reference's

@@ -102,12 +102,159 @@ __global__ __launch_bounds__(256) void nn_kernel(const float *__restrict__ q, in
     }
 }
 
+// Targets staged through LDS in tiles of TILE (every lane reads the same 16 bytes: a broadcast ds_read_b128), all operands of the packed math in VGPRs.
+template <int QPT, int CHUNK, int TILE>
+__global__ __launch_bounds__(256) void nn_lds_kernel(const float *__restrict__ q, int n, const float4 *__restrict__ tg, int m, int m_per_split,
+                                                     unsigned long long *__restrict__ packed)
+{
+#pragma clang fp contract(off)
+    __shared__ float4 tile[TILE];
+    const int k_begin = blockIdx.y * m_per_split;
+    const int k_end = min(m, k_begin + m_per_split);
+    const int j0 = (blockIdx.x * 256 + threadIdx.x) * QPT;
+    f32x2 qx[QPT / 2], qy[QPT / 2], qz[QPT / 2];
+    float best[QPT];
+    int besti[QPT];
+#pragma unroll
+    for (int r = 0; r < QPT; ++r) {
+        const int j = min(j0 + r, n - 1);
+        qx[r / 2][r & 1] = q[(int64_t)j * 3 + 0];
+        qy[r / 2][r & 1] = q[(int64_t)j * 3 + 1];
+        qz[r / 2][r & 1] = q[(int64_t)j * 3 + 2];
+        best[r] = __builtin_inff();
+        besti[r] = k_begin;
+    }
+    for (int t0 = k_begin; t0 < k_end; t0 += TILE) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < TILE; i += 256) tile[i] = t0 + i < k_end ? tg[t0 + i] : make_float4(3.0e18f, 3.0e18f, 3.0e18f, 0.f);   // padding: never the nearest
+        __syncthreads();
+        const int cnt = min(TILE, k_end - t0);
+        for (int kk = 0; kk < cnt; kk += CHUNK) {
+            f32x2 d[CHUNK][QPT / 2];
+#pragma unroll
+            for (int c = 0; c < CHUNK; ++c) {
+                const float4 t4 = tile[kk + c];
+#pragma unroll
+                for (int p = 0; p < QPT / 2; ++p) {
+                    const f32x2 x = (f32x2){t4.x, t4.x} - qx[p], y = (f32x2){t4.y, t4.y} - qy[p], z = (f32x2){t4.z, t4.z} - qz[p];
+                    d[c][p] = (x * x + y * y) + z * z;
+                }
+            }
+            bool improve = false;
+#pragma unroll
+            for (int r = 0; r < QPT; ++r) {
+                float mn = d[0][r / 2][r & 1];
+#pragma unroll
+                for (int c = 1; c < CHUNK; ++c) mn = fminf(mn, d[c][r / 2][r & 1]);
+                improve |= mn < best[r];
+            }
+            if (__any(improve)) {
+#pragma unroll
+                for (int c = 0; c < CHUNK; ++c)
+#pragma unroll
+                    for (int r = 0; r < QPT; ++r) {
+                        const float dv = d[c][r / 2][r & 1];
+                        const bool take = dv < best[r] && t0 + kk + c < k_end;
+                        best[r] = take ? dv : best[r];
+                        besti[r] = take ? t0 + kk + c : besti[r];
+                    }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < QPT; ++r) {
+        const int j = j0 + r;
+        if (j >= n || k_begin >= k_end) continue;
+        const unsigned long long key = ((unsigned long long)__float_as_uint(best[r]) << 32) | (unsigned)besti[r];
+        atomicMin(&packed[j], key);
+    }
+}
+
+// the same arithmetic without packed instructions (one query per VALU lane-op): is v_pk_* worth its encoding here?
+template <int QPT, int CHUNK>
+__global__ __launch_bounds__(256) void nn_scalar_kernel(const float *__restrict__ q, int n, const float4 *__restrict__ tg, int m, int m_per_split,
+                                                        unsigned long long *__restrict__ packed)
+{
+#pragma clang fp contract(off)
+    const int k_begin = blockIdx.y * m_per_split;
+    const int k_end = min(m, k_begin + m_per_split);
+    const int j0 = (blockIdx.x * 256 + threadIdx.x) * QPT;
+    float qx[QPT], qy[QPT], qz[QPT], best[QPT];
+    int besti[QPT];
+#pragma unroll
+    for (int r = 0; r < QPT; ++r) {
+        const int j = min(j0 + r, n - 1);
+        qx[r] = q[(int64_t)j * 3 + 0], qy[r] = q[(int64_t)j * 3 + 1], qz[r] = q[(int64_t)j * 3 + 2];
+        best[r] = __builtin_inff();
+        besti[r] = k_begin;
+    }
+    int k = k_begin;
+    for (; k + CHUNK <= k_end; k += CHUNK) {
+        float d[CHUNK][QPT];
+#pragma unroll
+        for (int c = 0; c < CHUNK; ++c) {
+            const float4 t4 = tg[k + c];
+#pragma unroll
+            for (int r = 0; r < QPT; ++r) {
+                const float x = t4.x - qx[r], y = t4.y - qy[r], z = t4.z - qz[r];
+                d[c][r] = (x * x + y * y) + z * z;
+            }
+        }
+        bool improve = false;
+#pragma unroll
+        for (int r = 0; r < QPT; ++r) {
+            float mn = d[0][r];
+#pragma unroll
+            for (int c = 1; c < CHUNK; ++c) mn = fminf(mn, d[c][r]);
+            improve |= mn < best[r];
+        }
+        if (__any(improve)) {
+#pragma unroll
+            for (int c = 0; c < CHUNK; ++c)
+#pragma unroll
+                for (int r = 0; r < QPT; ++r) {
+                    const bool take = d[c][r] < best[r];
+                    best[r] = take ? d[c][r] : best[r];
+                    besti[r] = take ? k + c : besti[r];
+                }
+        }
+    }
+    for (; k < k_end; ++k) {
+        const float4 t4 = tg[k];
+#pragma unroll
+        for (int r = 0; r < QPT; ++r) {
+            const float x = t4.x - qx[r], y = t4.y - qy[r], z = t4.z - qz[r];
+            const float dv = (x * x + y * y) + z * z;
+            const bool take = dv < best[r];
+            best[r] = take ? dv : best[r];
+            besti[r] = take ? k : besti[r];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < QPT; ++r) {
+        const int j = j0 + r;
+        if (j >= n || k_begin >= k_end) continue;
+        atomicMin(&packed[j], ((unsigned long long)__float_as_uint(best[r]) << 32) | (unsigned)besti[r]);
+    }
+}
+
 struct Variant { const char *name; int qpt; int balance; void (*launch)(dim3, const float *, int, const float4 *, int, int, unsigned long long *); };
 
 template <int QPT, int CHUNK, bool AHEAD>
 static void launch(dim3 grid, const float *q, int n, const float4 *tg, int m, int per, unsigned long long *packed)
 {
     nn_kernel<QPT, CHUNK, AHEAD><<<grid, 256>>>(q, n, tg, m, per, packed);
+}
+
+template <int QPT, int CHUNK, int TILE>
+static void launch_lds(dim3 grid, const float *q, int n, const float4 *tg, int m, int per, unsigned long long *packed)
+{
+    nn_lds_kernel<QPT, CHUNK, TILE><<<grid, 256>>>(q, n, tg, m, per, packed);
+}
+template <int QPT, int CHUNK>
+static void launch_scalar(dim3 grid, const float *q, int n, const float4 *tg, int m, int per, unsigned long long *packed)
+{
+    nn_scalar_kernel<QPT, CHUNK><<<grid, 256>>>(q, n, tg, m, per, packed);
 }
 
 int main(int argc, char **argv)
@@ -134,6 +281,12 @@ int main(int argc, char **argv)
         {"8 q, chunk 8, loads ahead, balanced", 8, 1, launch<8, 8, true>},
         {"8 q, chunk 4, balanced", 8, 1, launch<8, 4, false>},
         {"2 q, chunk 16, balanced", 2, 1, launch<2, 16, false>},
+        {"4 q, chunk 8, LDS tiles of 1024, balanced", 4, 1, launch_lds<4, 8, 1024>},
+        {"4 q, chunk 8, LDS tiles of 2048, balanced", 4, 1, launch_lds<4, 8, 2048>},
+        {"8 q, chunk 8, LDS tiles of 1024, balanced", 8, 1, launch_lds<8, 8, 1024>},
+        {"4 q, chunk 4, LDS tiles of 1024, balanced", 4, 1, launch_lds<4, 4, 1024>},
+        {"4 q, chunk 8, no packed math, balanced", 4, 1, launch_scalar<4, 8>},
+        {"2 q, chunk 8, no packed math, balanced", 2, 1, launch_scalar<2, 8>},
     };
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));

@@ -21,6 +21,11 @@ c2p = torch.full((n_cells,), -1, dtype=torch.int32, device=dev)
 c2p[occupied] = torch.arange(m, dtype=torch.int32, device=dev)
 feats = torch.randn(m, c, device=dev)
 feats16 = feats.to(torch.bfloat16)
+# [r6] the fused form ('mixed' mode): the encoder's last max-pooling writes both canvases -- 3.2 M point rows in the same M pillars (every pillar >= 1 point)
+n = 3_200_000
+p2v = torch.cat([torch.arange(m, device=dev), torch.randint(0, m, (n - m,), device=dev)])[torch.randperm(n, device=dev)].to(torch.int32)
+rows = torch.randn(n, c, device=dev)
+offs, order = native.csr_build(p2v, m)
 big = torch.empty(512 * 1024 * 1024 // 4, device=dev)          # 512 MiB: evict the 256 MiB Infinity Cache between launches
 src = torch.randn(32 * 1024 * 1024, device=dev)                # 128 MiB
 dst = torch.empty_like(src)
@@ -33,5 +38,7 @@ for it in range(5):
     native.pillar_scatter(feats, c2p, torch.bfloat16)
     big.fill_(float(it) + 0.125)
     native.pillar_scatter(feats16, c2p, torch.bfloat16)
+    big.fill_(float(it) + 0.0625)
+    native.segment_max_canvas(rows, offs, order, m, c2p)
 torch.cuda.synchronize()
 print('done M=%d cells=%d' % (m, n_cells))

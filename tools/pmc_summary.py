@@ -14,6 +14,9 @@ KERNELS = {                                  # kernel-name fragment -> (label, a
     'pillar_scatter_f32_nt': ('f32 rows -> f32 canvas, streaming loads / stores (round 5 default for large canvases)', N_CELLS * C * 4 + M * C * 4 + 4 * M),
     'pillar_scatter_vec4<1>': ('f32 rows -> bf16 canvas', N_CELLS * C * 2 + M * C * 4 + 4 * M),
     'pillar_scatter_rows16': ('bf16 rows -> bf16 canvas (bf16 compute mode)', N_CELLS * C * 2 + M * C * 2 + 4 * M),
+    # [r6] pooling + scatter in one pass (bench.fused_alg_bytes): rows, order, offsets, cell table in; fp32 canvas, bf16 shadow, winners out
+    'seg_max_canvas': ('3.2 M fp32 point rows -> fp32 canvas + bf16 shadow + winners (mixed mode: the encoder\'s last pooling writes the canvas)',
+                       4 * C * 3_200_000 + 4 * 3_200_000 + 4 * (M + 1) + 4 * N_CELLS + 4 * C * N_CELLS + 2 * C * N_CELLS + 4 * C * M),
 }
 
 
