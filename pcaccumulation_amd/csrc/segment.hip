@@ -687,24 +687,25 @@ extern "C" int pcacc_segment_max_canvas(const float *src, int c, const int32_t *
     if (seg_use_two_level(n, m)) return PCACC_E_ARG;              // long segments: the two-level pooling + the separate fills (the caller's fallback)
     const void *fn;
     int cpg = 1;
-    // Measured at the step's size (tools/bench_fused_canvas.py, profiles/r06_fused_canvas_variants.txt; warm / behind 1 GiB of streamed lines): one cell per
-    // group with cached loads 208 / 222 us, with streaming loads 198 / 200 us (the default), two cells in flight 199 / 215 us, four 229 / 237 us -- the
-    // kernel is bound by the random 128-byte row reads themselves, not by how many of them a lane group keeps in flight.
-    const char variant = pcacc_switches().scatter_variant;     // A/B (PCACC_SCATTER_VARIANT): 'a' cached loads; 'b' two cells, cached loads; 'e' two cells, streaming; 'd' four
+    // Measured (tools/bench_fused_canvas.py, profiles/r06_fused_canvas_variants.txt; alone, warm / behind 1 GiB of streamed lines): one cell per group with
+    // cached loads 208 / 222 us, with streaming loads 198 / 200 us, two cells in flight 199 / 215 us, four 229 / 237 us -- bound by the random 128-byte row
+    // reads themselves, not by how many of them a lane group keeps in flight.  INSIDE the step the rows were written by the layer in front and partly still
+    // sit in the Infinity Cache: cached loads 191 us, streaming loads 199 - 209 us (three bench runs each) -- cached loads are the default.
+    const char variant = pcacc_switches().scatter_variant;     // A/B (PCACC_SCATTER_VARIANT): 'c' streaming loads; 'b' two cells, cached loads; 'e' two cells, streaming; 'd' four
     switch (c / 4) {
-        case 1: fn = reinterpret_cast<const void *>(seg_max_canvas_kernel<1, 1, true>); break;
-        case 2: fn = reinterpret_cast<const void *>(seg_max_canvas_kernel<2, 1, true>); break;
-        case 4: fn = reinterpret_cast<const void *>(seg_max_canvas_kernel<4, 1, true>); break;
+        case 1: fn = reinterpret_cast<const void *>(seg_max_canvas_kernel<1, 1, false>); break;
+        case 2: fn = reinterpret_cast<const void *>(seg_max_canvas_kernel<2, 1, false>); break;
+        case 4: fn = reinterpret_cast<const void *>(seg_max_canvas_kernel<4, 1, false>); break;
         case 8:
-            fn = reinterpret_cast<const void *>(seg_max_canvas_kernel<8, 1, true>);
-            if (variant == 'a') fn = reinterpret_cast<const void *>(seg_max_canvas_kernel<8, 1, false>);
+            fn = reinterpret_cast<const void *>(seg_max_canvas_kernel<8, 1, false>);
+            if (variant == 'c') fn = reinterpret_cast<const void *>(seg_max_canvas_kernel<8, 1, true>);
             else if (variant == 'b') { fn = reinterpret_cast<const void *>(seg_max_canvas_kernel<8, 2, false>); cpg = 2; }
             else if (variant == 'e') { fn = reinterpret_cast<const void *>(seg_max_canvas_kernel<8, 2, true>); cpg = 2; }
             else if (variant == 'd') { fn = reinterpret_cast<const void *>(seg_max_canvas_kernel<8, 4, true>); cpg = 4; }
             break;
-        case 16: fn = reinterpret_cast<const void *>(seg_max_canvas_kernel<16, 1, true>); break;
-        case 32: fn = reinterpret_cast<const void *>(seg_max_canvas_kernel<32, 1, true>); break;
-        case 64: fn = reinterpret_cast<const void *>(seg_max_canvas_kernel<64, 1, true>); break;
+        case 16: fn = reinterpret_cast<const void *>(seg_max_canvas_kernel<16, 1, false>); break;
+        case 32: fn = reinterpret_cast<const void *>(seg_max_canvas_kernel<32, 1, false>); break;
+        case 64: fn = reinterpret_cast<const void *>(seg_max_canvas_kernel<64, 1, false>); break;
         default: return PCACC_E_ARG;
     }
     void *args[] = {(void *)&src, (void *)&seg_offsets, (void *)&order, (void *)&cell2pillar, (void *)&n_cells, (void *)&canvas32, (void *)&canvas16, (void *)&arg};

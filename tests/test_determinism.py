@@ -40,7 +40,7 @@ def test_c3_lidar_train_step_is_bit_reproducible(golden, compute_dtype):
 
 def test_staged_two_stream_step_is_bit_reproducible():
     """The step as bench.py runs it -- distributed.DataParallelStep: early backward of the ego / fb / perm terms from a helper thread, motion heads and TubeNet
-    on a second stream -- three times on the same batch: identical loss statistics and gradients.  (Two host threads and two streams change WHEN kernels
+    on a second stream -- twelve times on the same batch: identical loss statistics and gradients.  (Two host threads and two streams change WHEN kernels
     run, not what they add up in which order.)"""
     import r06_determinism as det
     from helpers import make_batch
@@ -59,10 +59,12 @@ def test_staged_two_stream_step_is_bit_reproducible():
     inp = make_batch(cfg, [21, 22], 5, 30000, mode='lidar')
     inp = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}
     opt = torch.optim.SGD(model.parameters(), lr=0.0)
-    step = pdist.DataParallelStep(model, opt, FuseLoss(cfg['loss']), iter_size=1, grad_clip=None, catch=False, pipelined=True, two_streams=True, early_thread=True)
-    assert step.side is not None and step._early_thread
+    variant = os.environ.get('PCACC_DET_VARIANT', 'tt')             # diagnosis: 'tf' = second stream without the helper thread, 'ff' = one stream
+    step = pdist.DataParallelStep(model, opt, FuseLoss(cfg['loss']), iter_size=1, grad_clip=None, catch=False, pipelined=True, two_streams=variant[0] == 't',
+                                  early_thread=variant[1] == 't')
+    assert (step.side is not None) == (variant[0] == 't') and step._early_thread == (variant == 'tt')
     snaps = []
-    for r in range(4):
+    for r in range(13):
         torch.manual_seed(5)
         stats = step(dict(inp))
         torch.cuda.synchronize()

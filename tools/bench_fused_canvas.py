@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """pcacc_segment_max_canvas (pooling + pillar scatter in one pass) at the step's size: variants (PCACC_SCATTER_VARIANT: cells in flight per lane group, cache
 policy of the row loads) on uniform and on LiDAR-shaped pillar sizes (a few crowded pillars, two thirds of the cells empty), warm and behind 1 GiB of
-streamed lines; results compared bit for bit with variant 'a'.  Usage: python tools/bench_fused_canvas.py"""
+streamed lines; results compared bit for bit with the default.  Usage: python tools/bench_fused_canvas.py"""
 import os
 import sys
 
@@ -38,7 +38,7 @@ def main():
         src, offs, order, m, c2p, n_cells, c, n = case(kind, dev)
         alg = bench.fused_alg_bytes(n_cells, c, m, n)
         ref = None
-        for variant in ('a', 'b', '', 'e', 'd'):
+        for variant in ('', 'c', 'b', 'e', 'd'):
             if variant:
                 os.environ['PCACC_SCATTER_VARIANT'] = variant
             else:
