@@ -230,15 +230,26 @@ __global__ __launch_bounds__(HC_THREADS) void head_conv_wgrad_kernel(const float
             const int yy = tl.y0 + q / HC_TC, xx = tl.x0 + q % HC_TC;
             return dy + (((int64_t)tl.img * h + min(yy, h - 1)) * wd + min(xx, wd - 1)) * co;
         };
+        // [r6] HC_DY_AHEAD (default OFF).  Round 5 loaded the two-output head's gradient pair one pixel row ahead (`g_next`, one 8-byte load kept in a register pair
+        // across the loop's back edge).  tests/test_determinism.py found the ONE gradient of the model that still differed between two staged steps -- this
+        // kernel's dW, and only its second output channel (the odd register of the pair): with the pair carried across the back edge the kernel's result, on
+        // the same operands (also on private copies of them), differed from its result on a quiet device in 8 of 256 calls made while the other stream kept
+        // the device busy, and in 0 of 256 with plain per-pass loads (tools/r06_diag_headconv3.py, profiles/r06_headconv_race.txt).  The compiled loop waits
+        // for the early load right after issuing it (s_waitcnt vmcnt(0) in front of the first use), so the early load never overlapped anything: nothing is
+        // lost with it.  The mechanism below the ISA is not known; the construct is gone.
+#ifndef HC_DY_AHEAD
+#define HC_DY_AHEAD 0
+#endif
+        constexpr bool AHEAD = COM == 2 && HC_DY_AHEAD;
         float2 g_next = make_float2(0.f, 0.f);
-        if (COM == 2 && co == 2) g_next = *reinterpret_cast<const float2 *>(dy_at(slot));
+        if (AHEAD && co == 2) g_next = *reinterpret_cast<const float2 *>(dy_at(slot));
         for (int q = slot; q < HC_TR * HC_TC; q += PPB) {
             const int row = q / HC_TC, col = q % HC_TC;
             const int yy = tl.y0 + row, xx = tl.x0 + col;
             const bool ok = yy < h && xx < wd;
             const float *gp = dy_at(q);
             float g[COM];
-            if (COM == 2 && co == 2) {
+            if (AHEAD && co == 2) {
                 const float2 g2 = g_next;
                 if (q + PPB < HC_TR * HC_TC) g_next = *reinterpret_cast<const float2 *>(dy_at(q + PPB));
                 g[0] = ok ? g2.x : 0.f;

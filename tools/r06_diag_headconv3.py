@@ -58,7 +58,38 @@ def spy(gy, x, want_bias=True):
     elems = gy.shape[3] * x.shape[3] * 9 + gy.shape[3]
     d = (p1 != ws2).nonzero()[:, 0]
     slots = torch.unique(d // elems).tolist()
-    events.append(dict(on_copies_vs_quiet=copies, gy_inflight_copy_col0=int((g1[..., 0] != gy[..., 0]).sum()), gy_inflight_copy_col1=int((g1[..., 1] != gy[..., 1]).sum()), gy_changed=int((g0 != gy).sum()), x_changed=int((x0 != x).sum()), dw_inflight_vs_quiet=int((dw1 != dw2).sum()), api_vs_quiet=int((out[0] != dw2).sum()),
+    explain = []
+    if d.numel():
+        # which pixel's dy explains the difference?  delta[c][ci][tap] = k_c * x[pixel + tap][ci] for the pixel whose gradient the kernel saw differently
+        n_img, H, W, co = gy.shape
+        ci_n = x.shape[3]
+        tiles_y, tiles_x = (H + 7) // 8, (W + 31) // 32
+        n_tiles = n_img * tiles_y * tiles_x
+        grid = p1.numel() // elems
+        xp = torch.nn.functional.pad(x, (0, 0, 1, 1, 1, 1))                       # [n, H+2, W+2, ci]
+        for slot in slots[:3]:
+            delta = (p1.view(grid, elems)[slot] - ws2.view(grid, elems)[slot])[:co * ci_n * 9].view(co, ci_n, 9).double()
+            best = None
+            for t in range(slot, n_tiles, grid):
+                img, r = divmod(t, tiles_y * tiles_x)
+                y0, x0_ = (r // tiles_x) * 8, (r % tiles_x) * 32
+                patch = xp[img, y0:y0 + 10, x0_:x0_ + 34]                          # [10, 34, ci]
+                win = torch.stack([patch[dy_:dy_ + 8, dx_:dx_ + 32] for dy_ in range(3) for dx_ in range(3)], dim=-1).double()   # [8, 32, ci, 9]
+                for c in range(co):
+                    num = (win * delta[c]).sum(dim=(2, 3))
+                    den = (win * win).sum(dim=(2, 3)).clamp(min=1e-30)
+                    k = num / den
+                    res = ((delta[c] - k[..., None, None] * win) ** 2).sum(dim=(2, 3)) / (delta[c] ** 2).sum().clamp(min=1e-30)
+                    j = int(res.argmin())
+                    yy, xx = divmod(j, 32)
+                    cand = (float(res.view(-1)[j]), c, t, img, y0 + yy, x0_ + xx, float(k.view(-1)[j]))
+                    if float((delta[c] ** 2).sum()) > 0 and (best is None or cand[0] < best[0]):
+                        best = cand
+            if best:
+                _, c, t, img, yy, xx, k = best
+                explain.append(dict(slot=slot, channel=c, tile=t, pixel=(img, yy, xx), k=k, residual=best[0], dy_at_pixel=gy[img, min(yy, H - 1), min(xx, W - 1)].tolist(),
+                                    dy_next_in_thread=gy[img, min(yy + 1, H - 1), min(xx, W - 1)].tolist() if yy + 1 < H else None))
+    events.append(dict(explain=explain, on_copies_vs_quiet=copies, gy_inflight_copy_col0=int((g1[..., 0] != gy[..., 0]).sum()), gy_inflight_copy_col1=int((g1[..., 1] != gy[..., 1]).sum()), gy_changed=int((g0 != gy).sum()), x_changed=int((x0 != x).sum()), dw_inflight_vs_quiet=int((dw1 != dw2).sum()), api_vs_quiet=int((out[0] != dw2).sum()),
                        partial_elems_differ=int(d.numel()), slots=slots[:8], n_elems_in_slot=len(set((d % elems).tolist())),
                        max_rel=float(((p1 - ws2).abs().max() / ws2.abs().max()).item()) if d.numel() else 0.0))
     return out
