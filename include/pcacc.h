@@ -169,6 +169,12 @@ int pcacc_pfn_features(const float *points, const int32_t *p2v, const float *pil
                        int coords_is_f64, const double *time_col, int64_t time_stride, int64_t n,
                        double vx, double vy, double x_offset, double y_offset, float scale, float n_frames,
                        float *out, void *stream);
+/* The same rows in the order of `order` [n] i32 (row r = point order[r]; NULL = point order): with the point -> pillar CSR's point list the rows come out
+ * pillar-major like the reference's own [M, max_points, C] tensor (libs/voxel_generator.py:41-58) and every per-pillar pass behind this call streams. */
+int pcacc_pfn_features_ordered(const float *points, const int32_t *p2v, const float *pillar_mean, const void *coords,
+                               int coords_is_f64, const double *time_col, int64_t time_stride, int64_t n,
+                               double vx, double vy, double x_offset, double y_offset, float scale, float n_frames,
+                               const int32_t *order, float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * A4 (MLP part). Per-point linear layers: nn.Linear applied to 10^5..10^6 rows with <= 128 features, as the pillar

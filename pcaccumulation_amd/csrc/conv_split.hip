@@ -588,6 +588,31 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_kernel(const float 
 #define CSR_EXP 0                               // phase knock-outs for tools/exp_conv_res_phases.sh (1 MFMA loop, 2 patch staging, 4 stores, 8 patch loads, 16 weight staging)
 #endif
 #define CSR_WPT 9                               // 16-byte weight pieces a thread carries for the next slice (9 taps x 64 rows x 32 ch x 2 planes / 512)
+// [r6] experiment CSR_LINES = 1: whole-line stores (VERDICT round 5, item 1's second half).  As first written the weights were the MFMA's A operand and the pixels its B operand: a lane ended up with ONE pixel's
+// channels 8 g + 4 lh + 0..3 -- a store instruction wrote 32-byte pieces (two lanes) of 32 different lines, the shadow 16-byte pieces, four instructions to
+// complete a line (4 096 write requests per 512-pixel tile).  With the operands exchanged (the accumulator holds the transposed tile: same products, same
+// order of additions, bit-identical) a lane has one CHANNEL of pixels 8 g + 4 lh + 0..3; a 4 x 4 transpose inside each lane quad (two quad_perm exchanges)
+// gives quad lane k the pixel 8 g + 4 lh + k with channels 4 Q .. 4 Q + 3: eight quads write one pixel's 128-byte row, a store instruction eight whole lines
+// (the shadow: whole 64-byte rows, neighbours in memory) -- 1 024 requests per tile.
+// MEASURED (profiles/r06_conv_line_stores_ab.txt, two interleaved rounds alone + three interleaved pairs of the whole step, one box): bit-identical results;
+// alone 32 -> 32 182 vs 184 us, 64 -> 32 277 vs 284, 27 taps 316 vs 318, 32 -> 64 294 vs 320 us; in the step 30.12 / 30.05 / 30.00 ms against 29.87 / 29.87 /
+// 29.94 ms with the partial-line stores.  The write-request count is NOT what holds these layers at 3.5 TB/s (the L2 merges the pieces before they reach HBM:
+// counter traffic was 1.0 x before as well); the partial-line form stays the default, this one is kept behind the macro for the next reader of that idea.
+#ifndef CSR_LINES
+#define CSR_LINES 0
+#endif
+__device__ __forceinline__ float csr_quad_xchg1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)); }   // lane ^ 1
+__device__ __forceinline__ float csr_quad_xchg2(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)); }   // lane ^ 2
+// quad lane k holds column k of a 4 x 4 block (a0 .. a3 = its rows 0 .. 3) -> row k of the block
+__device__ __forceinline__ float4 csr_quad_transpose(float a0, float a1, float a2, float a3, int k)
+{
+    const bool odd = k & 1, hi = k & 2;
+    const float r01 = csr_quad_xchg1(odd ? a0 : a1), r23 = csr_quad_xchg1(odd ? a2 : a3);
+    const float b0 = odd ? r01 : a0, b1 = odd ? a1 : r01;      // rows (k & 1) and 2 + (k & 1), columns (k & ~1), (k & ~1) + 1
+    const float b2 = odd ? r23 : a2, b3 = odd ? a3 : r23;
+    const float s0 = csr_quad_xchg2(hi ? b0 : b2), s1 = csr_quad_xchg2(hi ? b1 : b3);
+    return hi ? make_float4(s0, s1, b2, b3) : make_float4(b0, b1, s0, s1);
+}
 
 template <int CS, int NW, int MT, int PCH, bool RESTAGE, bool MASKED>          // MASKED: in_mask != NULL (a compile-time fact: a run-time branch behind the loads made the compiler copy -- and so wait for -- every loaded register at once)
 __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_res_kernel(const float *__restrict__ in, const float *__restrict__ in_amax,
@@ -612,6 +637,7 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_res_kernel(const fl
     // memory for every (tile, channel group) and each of those loads was followed by s_waitcnt vmcnt(0) -- which also waits for every store issued before
     // it (loads and stores retire in order on one counter): 16 memory round trips per pass in series, and the stores never overlapped anything
     float *sb = reinterpret_cast<float *>(wl + 2 * WPL);       // [2][WROWS]: scale, bias
+    int *ptab = reinterpret_cast<int *>(sb + 2 * WROWS);       // [8 MT 32] (CSR_LINES): y << 16 | x of the tile's q-th pixel, -1 behind its last
 
     const int cog = blockIdx.x % co_groups, slot = blockIdx.x / co_groups;
     const int co0 = cog * WROWS;
@@ -626,6 +652,8 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_res_kernel(const fl
         sb[threadIdx.x] = wscale[blockIdx.x % co_groups * WROWS + threadIdx.x] * inv_sx;
         sb[WROWS + threadIdx.x] = (bias && relu != CSP_OUTMASK) ? bias[blockIdx.x % co_groups * WROWS + threadIdx.x] : 0.f;
     }
+    if (CSR_LINES)
+        for (int q = threadIdx.x; q < 8 * MT * 32; q += CSP_THREADS) ptab[q] = q < n_px ? ((q / bw) << 16 | (q % bw)) : -1;
 
     // slices of a tile that exist: frame taps f_lo .. f_hi (a missing frame contributes zeros), all channel slices of each
     // (tile coordinates come from the walker, frame tap f and channel slice cs of a slice s = f * nc + cs are carried along: no divisions per pass)
@@ -741,9 +769,32 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_res_kernel(const fl
     // written before, load burst, MFMA phase and store burst took turns (57 + 53 + 71 us of a 181 us layer, measured by knocking each out)
     constexpr bool DEFER = !RESTAGE;
     float4 pend[MT][NW][4];
-    int pend_pyx[MT], pend_img = 0;
+    int pend_pyx[MT], pend_img = 0, pend_y0 = 0, pend_x0 = 0;
     bool have_pend = false;
+    // the image position of the pixel this lane stores for pixel tile j, group g (CSR_LINES): -1 outside the tile or the image
+    auto line_pyx = [&](int j, int g, int y0, int x0) __attribute__((always_inline)) {
+        const int t = ptab[(wave + 8 * j) * 32 + 8 * g + 4 * lh + (lp & 3)];
+        const int y = y0 + (t >> 16), x = x0 + (t & 0xffff);
+        return (t >= 0 && y < h && x < w) ? (y << 16 | x) : -1;
+    };
     auto flush = [&]() __attribute__((always_inline)) {
+        if (CSR_LINES) {
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int yx = line_pyx(j, g, pend_y0, pend_x0);
+                    if (yx < 0) continue;
+                    const int64_t o = (((int64_t)pend_img * h + (yx >> 16)) * w + (yx & 0xffff)) * c_out + co0 + 4 * (lp >> 2);
+#pragma unroll
+                    for (int n = 0; n < NW; ++n) {
+                        const float4 v = pend[j][n][g];
+                        *reinterpret_cast<float4 *>(out + o + n * 32) = v;
+                        if (out16) csp_store_shadow(out16 + o + n * 32, pcacc_pack_bf16x2(v.x, v.y), pcacc_pack_bf16x2(v.z, v.w));
+                    }
+                }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
             if (pend_pyx[j] < 0) continue;
@@ -823,19 +874,62 @@ __global__ __launch_bounds__(CSP_THREADS) void conv3x3_split_res_kernel(const fl
 #pragma unroll
                 for (int j = 0; j < MT; ++j)
 #pragma unroll
-                    for (int n = 0; n < NW; ++n) acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[c][n], bl[c][j], acc[j][n], 0, 0, 0);
+                    for (int n = 0; n < NW; ++n)
+                        acc[j][n] = CSR_LINES ? __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[c][j], ah[c][n], acc[j][n], 0, 0, 0)
+                                              : __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[c][n], bl[c][j], acc[j][n], 0, 0, 0);
 #pragma unroll
                 for (int j = 0; j < MT; ++j)
 #pragma unroll
-                    for (int n = 0; n < NW; ++n) acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[c][n], bh[c][j], acc[j][n], 0, 0, 0);
+                    for (int n = 0; n < NW; ++n)
+                        acc[j][n] = CSR_LINES ? __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[c][j], al[c][n], acc[j][n], 0, 0, 0)
+                                              : __builtin_amdgcn_mfma_f32_32x32x16_f16(al[c][n], bh[c][j], acc[j][n], 0, 0, 0);
 #pragma unroll
                 for (int j = 0; j < MT; ++j)
 #pragma unroll
-                    for (int n = 0; n < NW; ++n) acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[c][n], bh[c][j], acc[j][n], 0, 0, 0);
+                    for (int n = 0; n < NW; ++n)
+                        acc[j][n] = CSR_LINES ? __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[c][j], ah[c][n], acc[j][n], 0, 0, 0)
+                                              : __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[c][n], bh[c][j], acc[j][n], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (nk != k) {                                         // last slice of this tile: scales off, bias, ReLU -> the pending registers
+        if (nk != k && CSR_LINES) {                            // last slice of this tile: a lane holds channel lp of pixels 8 g + 4 lh + 0..3 -- scales off, bias, ReLU, then the quad transpose
+            pend_img = img;
+            pend_y0 = y0;
+            pend_x0 = x0;
+#pragma unroll
+            for (int n = 0; n < NW; ++n) {
+                const float sc = sb[n * 32 + lp], bv = sb[WROWS + n * 32 + lp];
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float a[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            a[i] = acc[j][n][4 * g + i] * sc + bv;
+                            if (relu && relu != CSP_OUTMASK) a[i] = fmaxf(a[i], 0.f);
+                        }
+                        float4 v = csr_quad_transpose(a[0], a[1], a[2], a[3], lp & 3);
+                        bool ok = true;                        // a pixel outside the tile or the image repeats the tile's first pixel: it cannot raise the maximum ...
+                        if (relu == CSP_OUTMASK) {             // ... unless that pixel's own result is masked away
+                            const int yx = line_pyx(j, g, y0, x0);
+                            ok = yx >= 0;
+                            if (ok) v = csp_outmask4(v, *reinterpret_cast<const float4 *>(bias + (((int64_t)img * h + (yx >> 16)) * w + (yx & 0xffff)) * c_out + co0 + n * 32 + 4 * (lp >> 2)));
+                        }
+                        pend[j][n][g] = v;
+                        if (ok) {
+                            omax = fmaxf(fmaxf(omax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                            if (!(v.x == v.x && v.y == v.y && v.z == v.z && v.w == v.w)) omax = __builtin_inff();
+                        }
+                    }
+            }
+            have_pend = true;
+            if (!DEFER) {
+                if (!(CSR_EXP & 4)) flush();
+                have_pend = false;
+            }
+        }
+        if (nk != k && !CSR_LINES) {                           // last slice of this tile: scales off, bias, ReLU -> the pending registers
             pend_img = img;
 #pragma unroll
             for (int j = 0; j < MT; ++j) {
@@ -895,7 +989,8 @@ static bool conv_res_fits(int cs, int nw, int mt, int rows, int bw, size_t *lds)
 {
     const int64_t pp = (int64_t)(rows + 2) * (bw + 2);
     const int wrows = 32 * nw, pch = conv_res_pch(cs, nw, mt);
-    *lds = (size_t)(2 * pp + 2 * 9 * wrows) * (cs + 8) * sizeof(uint16_t) + 2 * wrows * sizeof(float);     // + scale / bias of the workgroup's channels
+    *lds = (size_t)(2 * pp + 2 * 9 * wrows) * (cs + 8) * sizeof(uint16_t) + 2 * wrows * sizeof(float) +    // + scale / bias of the workgroup's channels
+           (CSR_LINES ? 8 * mt * 32 * sizeof(int) : 0);                                                      // + the tile's pixel positions
     return pch > 0 && pp * (cs / 8) <= CSP_THREADS * pch && *lds <= CSP_LDS_MAX && 2 * 9 * wrows * (cs / 8) <= CSP_THREADS * CSR_WPT &&
            rows + 2 < 0x7ff && bw + 2 < 0xfff;
 }

@@ -13,6 +13,7 @@ cfg['misc']['compute_dtype'] ('fp32' default | 'bf16' | 'fp32x3'): element type 
 (autocast for bf16; 'fp32x3' = fp32 tensors with split-bf16 MFMA products, the fast mode that matches the reference to 1e-3).  Sinkhorn / Kabsch / normalisation / grid arithmetic always stay fp32.
 """
 import contextlib
+import os
 import weakref
 
 import torch
@@ -105,6 +106,11 @@ class MotionNet(nn.Module):
         self.compute_dtype = {'fp32': torch.float32, 'fp32x3': torch.float32, 'mixed': torch.float32, 'mixed2': torch.float32, 'bf16': torch.bfloat16}[self.compute_mode]
         # pillars renumbered in canvas-cell order inside forward() (ops.PillarIndex); False keeps the voxeliser's numbering
         self.cell_ordered_pillars = bool(cfg['misc'].get('cell_ordered_pillars', True))
+        # [r6] the pillar encoder on rows stored pillar by pillar (PillarIndex.pillar_major).  Bit-identical forward (tests/test_mixed.py); measured in the step on
+        # uniform synthetic points (profiles/r06_pillar_major_ab.txt): 29.68 / 29.51 / 29.85 ms against 29.59 / 29.70 / 29.69 ms -- the poolings do not get faster
+        # (223 vs 223 us, 165 vs 165 us: a frame's 20 MB of rows already sit in the Infinity Cache when they are gathered), the blocks gain 11 - 14 us each and
+        # the feature build pays 51 us for its random point reads.  Off by default; PCACC_PILLAR_MAJOR=1 or misc.pillar_major_rows turn it on.
+        self.pillar_major_rows = bool(cfg['misc'].get('pillar_major_rows', os.environ.get('PCACC_PILLAR_MAJOR', '0') != '0'))
         self._optimizer_watched = False          # watch_optimizer()
         self.after_ego = None                    # optional callable(results), see forward()
         self.before_sync = None                  # optional callable(): host work to do while the forward waits for its one host sync, see forward()
@@ -179,7 +185,9 @@ class MotionNet(nn.Module):
         pillar_mean, fb_labels_sub = ops.segment_mean3_maxlabel(input_points, fb_labels, pidx)   # motionnet.py:159-160
         occ = ops.pillar_scatter(torch.ones((pidx.m, 1), device=device), pidx)
         fb_map = ops.pillar_scatter(fb_labels_sub.float().unsqueeze(1), pidx)
-        features = self.pillar_encoder.point_features(input_points, pidx, pidx.coordinates, pillar_mean, time_indice)
+        # [r6] the encoder's rows in pillar order on the GPU (PillarIndex.pillar_major): nothing per point leaves the encoder, so the order is its own business
+        features = self.pillar_encoder.point_features(input_points, pidx, pidx.coordinates, pillar_mean, time_indice,
+                                                      pillar_major=self.pillar_major_rows and device.type == 'cuda')
         prep = PreparedInputs(pidx=pidx, batch_idx=batch_idx, frame_idx=frame_idx, pillar_mean=pillar_mean, fb_labels_sub=fb_labels_sub,
                               occ_map=occ.view(B, nt, 1, ny, nx), fb_seg_gt=fb_map.view(B, nt, 1, ny, nx).to(fb_labels.dtype), features=features)
         prep.source = (weakref.ref(input_dict['input_points']), input_dict['input_points']._version)      # a `_prepared` of another batch is refused
@@ -221,7 +229,8 @@ class MotionNet(nn.Module):
 
         # 1. pillar encoder -> BEV canvas (channels-last, one streaming pass)
         with ops.stage('pillar_encoder'):
-            input_features, is_canvas = self.pillar_encoder(input_points, None, coordinates, pillar_mean, time_indice, pidx=pidx, keep_dtype=True,
+            enc_pidx = pidx.pillar_major() if self.pillar_major_rows and device.type == 'cuda' else pidx
+            input_features, is_canvas = self.pillar_encoder(input_points, None, coordinates, pillar_mean, time_indice, pidx=enc_pidx, keep_dtype=True,
                                                             features=prep.features, canvas=True)
         # 'mixed' mode: the encoder's last pooling has written the canvas itself (ops.segment_max_canvas); otherwise rows -> canvas here
         canvas = input_features if is_canvas else ops.carry_amax(input_features, ops.pillar_scatter(input_features, pidx, self.compute_dtype))     # rows or zeros

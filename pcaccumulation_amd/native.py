@@ -47,7 +47,7 @@ EXPORTS = [
     'pcacc_frame_pillars_workspace_bytes', 'pcacc_frame_pillars', 'pcacc_compact_mask_workspace_bytes', 'pcacc_compact_mask',
     'pcacc_csr_workspace_bytes', 'pcacc_csr_build', 'pcacc_segment_mean3_maxlabel',
     'pcacc_segment_workspace_bytes', 'pcacc_segment_max', 'pcacc_segment_max_backward', 'pcacc_segment_sum', 'pcacc_scatter_sum_small_workspace_bytes', 'pcacc_scatter_sum_small',
-    'pcacc_pfn_features', 'pcacc_rows_linear', 'pcacc_rows_wgrad', 'pcacc_pillar_scatter', 'pcacc_gather_rows',
+    'pcacc_pfn_features', 'pcacc_pfn_features_ordered', 'pcacc_rows_linear', 'pcacc_rows_wgrad', 'pcacc_pillar_scatter', 'pcacc_gather_rows',
     'pcacc_bilinear_gather', 'pcacc_bilinear_gather_backward', 'pcacc_bev_warp', 'pcacc_bev_warp_dual', 'pcacc_rigid_transform',
     'pcacc_sinkhorn_kabsch_workspace_bytes', 'pcacc_sinkhorn_kabsch', 'pcacc_chamfer_workspace_bytes', 'pcacc_chamfer_forward', 'pcacc_chamfer_backward',
     'pcacc_cluster_workspace_bytes', 'pcacc_cluster', 'pcacc_conv3x3_prepare_weights', 'pcacc_conv3x3_bf16',
@@ -611,8 +611,8 @@ def rows_wgrad(dy, x, dy_mask=None, x_relu=False, split=False):
     return _split_aug(out, n, k, split, False)
 
 
-def pfn_features(points, p2v, pillar_mean, coords, time_indice, vx, vy, x_offset, y_offset, scale, n_frames):
-    """[n,9] f32 pillar-encoder inputs (models/pillar_encoder.py:98-110); time_indice [n,2] f64 (b,t)."""
+def pfn_features(points, p2v, pillar_mean, coords, time_indice, vx, vy, x_offset, y_offset, scale, n_frames, order=None):
+    """[n,9] f32 pillar-encoder inputs (models/pillar_encoder.py:98-110); time_indice [n,2] f64 (b,t).  order [n] i32: row r = point order[r]."""
     n = points.shape[0]
     out = torch.empty((n, 9), dtype=torch.float32, device=points.device)
     if coords.dtype == torch.float64:
@@ -624,11 +624,14 @@ def pfn_features(points, p2v, pillar_mean, coords, time_indice, vx, vy, x_offset
     if time_indice.dtype != torch.float64 or not time_indice.is_contiguous() or time_indice.shape[1] != 2:
         raise NativeError('time_indice must be a contiguous float64 [n,2] tensor')
     tcol = ctypes.c_void_p(time_indice.data_ptr() + 8)                   # column 1 of row 0
-    _check(lib().pcacc_pfn_features(_dev(points, torch.float32, 'points'), _dev(p2v, torch.int32, 'p2v'),
-                                    _dev(pillar_mean, torch.float32, 'pillar_mean'), _dev(coords, None, 'coordinates'), is_f64,
-                                    tcol if n else None, _i64(2), _i64(n), ctypes.c_double(vx), ctypes.c_double(vy),
-                                    ctypes.c_double(x_offset), ctypes.c_double(y_offset), ctypes.c_float(scale),
-                                    ctypes.c_float(n_frames), _dev(out), _stream()), 'pfn_features')
+    if order is not None and order.shape[0] != n:
+        raise NativeError('pfn_features: order has %d entries for %d points' % (order.shape[0], n))
+    _check(lib().pcacc_pfn_features_ordered(_dev(points, torch.float32, 'points'), _dev(p2v, torch.int32, 'p2v'),
+                                            _dev(pillar_mean, torch.float32, 'pillar_mean'), _dev(coords, None, 'coordinates'), is_f64,
+                                            tcol if n else None, _i64(2), _i64(n), ctypes.c_double(vx), ctypes.c_double(vy),
+                                            ctypes.c_double(x_offset), ctypes.c_double(y_offset), ctypes.c_float(scale),
+                                            ctypes.c_float(n_frames), _dev(order, torch.int32, 'order') if order is not None else None, _dev(out), _stream()),
+           'pfn_features')
     return out
 
 

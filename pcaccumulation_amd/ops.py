@@ -72,6 +72,20 @@ class PillarIndex(object):
         self._frames = None
         return self
 
+    def pillar_major(self):
+        """[r6] The same index for rows that are stored in the order of `self.order` (ascending pillar, ascending point inside a pillar -- the reference's own
+        [M, max_points, C] layout, libs/voxel_generator.py:41-58): `p2v` ascending, `order` the identity, everything per-pillar shared.  The pillar encoder
+        runs on such rows (MotionNet.prepare_inputs builds its nine inputs per point in this order): its poolings read consecutive rows and its
+        pillar -> point broadcasts consecutive table rows instead of gathering them at random; a stable order keeps every tie where it was."""
+        if getattr(self, '_pillar_major', None) is None:
+            import copy
+            pm = copy.copy(self)
+            pm.p2v = native.gather_rows(self.p2v.view(-1, 1), self.order).view(-1)
+            pm.order = torch.arange(self.n, dtype=torch.int32, device=self.p2v.device)
+            pm._pillar_major = pm
+            self._pillar_major = pm
+        return self._pillar_major
+
     def frame_pillars(self):
         """(sorted_pillars [M] i32, frame_offsets [B*T+1] i32): occupied pillars per frame in cell order."""
         if self._frames is None:

@@ -70,8 +70,9 @@ class PillarFeatureNet(nn.Module):
         self.x_offset = self.vx / 2 + pc_range[0]
         self.y_offset = self.vy / 2 + pc_range[1]
 
-    def point_features(self, raw_points, pidx, coordinates, pillar_mean, time_indice):
-        """The 9 inputs of pillar_encoder.py:98-110, in the same arithmetic (f64 coordinates, f32 points)."""
+    def point_features(self, raw_points, pidx, coordinates, pillar_mean, time_indice, pillar_major=False):
+        """The 9 inputs of pillar_encoder.py:98-110, in the same arithmetic (f64 coordinates, f32 points).  pillar_major: rows in the order of pidx.order
+        (forward() then takes pidx.pillar_major() as its index)."""
         coords = coordinates.contiguous()
         if coords.dtype not in (torch.float64, torch.int32):
             coords = coords.to(torch.float64)
@@ -80,7 +81,7 @@ class PillarFeatureNet(nn.Module):
             ti = ti.to(torch.float64)
         return native.pfn_features(raw_points.contiguous(), pidx.p2v, pillar_mean.contiguous(), coords, ti, float(self.vx),
                                    float(self.vy), float(self.x_offset), float(self.y_offset), float(self.scale),
-                                   float(self.n_frames))
+                                   float(self.n_frames), **({'order': pidx.order} if pillar_major else {}))
 
     def forward(self, raw_points, point_to_voxel_map, coordinates, pillar_mean, time_indice, pidx=None, keep_dtype=False, features=None, canvas=False):
         """keep_dtype: return the pooled rows in the element type of the point rows (bf16 in the bf16 compute mode; MotionNet feeds

@@ -325,3 +325,43 @@ def test_sparse_ego_feature_head_matches_the_dense_head(mode, monkeypatch):
     bad = [(k, float((g1[k] - g0[k]).norm()) / float(g0[k].norm())) for k in g0
            if float(g0[k].norm()) > 1e-5 * total and float((g1[k] - g0[k]).norm()) > 5e-2 * float(g0[k].norm())]      # (the STPN's temporal-conv biases move by 2 % for poses that differ by 1e-5: the known sensitive group)
     assert not bad, bad[:8]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['mixed', 'bf16', 'fp32x3'])
+def test_pillar_major_rows_change_no_forward_bit(mode, monkeypatch):
+    """[r6] The pillar encoder on rows stored pillar by pillar (PillarIndex.pillar_major: the reference's own [M, max_points, C] order,
+    libs/voxel_generator.py:41-58) against the same encoder on rows in point order: a per-pillar maximum does not depend on where its rows lie, a stable
+    order keeps every tie -- every result of the forward is bit-identical (LiDAR-distributed points: crowded pillars); the gradients add the same
+    terms in another order."""
+    dev = torch.device('cuda:0')
+    cfg = default_config('waymo', 'train', n_sweeps=3, xy_range=16)
+    inp = make_batch(cfg, [61, 62], 3, 9000, mode='lidar')
+    inp = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}
+    runs = {}
+    for major in (False, True):
+        cfg = default_config('waymo', 'train', n_sweeps=3, xy_range=16)
+        cfg['misc']['compute_dtype'] = mode
+        cfg['misc']['pillar_major_rows'] = major
+        model = _model(cfg, dev)
+        assert model.pillar_major_rows == major
+        torch.manual_seed(7)
+        out = model(inp)
+        stats = FuseLoss(cfg['loss'])(out, inp)
+        stats['loss'].backward()
+        keep = {k: out[k].detach().clone() for k in ('fb_seg_est', 'mos_est', 'offset_est', 'rec_est', 'ego_motion_est', 'transformed_points')}
+        runs[major] = (keep, stats['loss'].detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None})
+    for k, v in runs[False][0].items():
+        assert torch.equal(v, runs[True][0][k]), k
+    assert torch.equal(runs[False][1], runs[True][1])
+    ref, got = runs[False][2], runs[True][2]
+    assert ref.keys() == got.keys()
+    total = float(torch.sqrt(sum((g.double() ** 2).sum() for g in ref.values())))
+    for k, g in ref.items():
+        if not k.startswith('pillar_encoder.'):
+            assert torch.equal(g, got[k]), k                                # behind the canvas nothing knows about the rows' order
+            continue
+        n = float(g.norm())
+        if n < 1e-5 * total:
+            continue
+        assert float((got[k] - g).norm()) <= 2e-2 * n, (k, float((got[k] - g).norm()) / n)      # bf16 rows in the backward: sums in another order

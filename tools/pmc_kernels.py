@@ -148,5 +148,20 @@ wcf = native.conv3x3_split_prepare_weights(wc)[0]
 amx = torch.maximum(native.absmax256(ca_), native.absmax256(cb_))
 for _ in range(3):
     native.conv3x3_split_cat(ca_, cb_, amx, wcf, torch.zeros(32, device=dev), True, want_bf16=True)   # conv3x3_split_res_kernel<32,1,2,5,true> on two inputs
+# ---- round 6: the pooling that writes the canvas, the pooling it is built from, the fixed-point few-row sums, the stable few-segment CSR
+n_cells6 = 20 * 288 * 288
+p2v6 = torch.cat([torch.arange(m, device=dev), torch.randint(0, m, (rows - m,), device=dev)])[torch.randperm(rows, device=dev)].to(torch.int32)
+c2p6 = torch.full((n_cells6,), -1, dtype=torch.int32, device=dev)
+c2p6[torch.randperm(n_cells6, device=dev)[:m].sort().values] = torch.arange(m, dtype=torch.int32, device=dev)
+offs6, order6 = native.csr_build(p2v6, m)
+rows6 = f32(rows, 32)
+for _ in range(3):
+    native.segment_max_canvas(rows6, offs6, order6, m, c2p6)                        # seg_max_canvas_kernel<8, 1, false>
+    native.segment_max_dual(rows6, offs6, order6, m)                                # seg_max_kernel<8>
+slot6 = torch.randint(0, 400, (320_000,), device=dev, dtype=torch.int32)
+v16 = f32(320_000, 16)
+for _ in range(3):
+    native.scatter_sum_small(v16, slot6, 400)                                       # scatter_sum_small_kernel + its fixed-order reduce
+    native.csr_build(slot6, 400)                                                    # csr_histogram_small / csr_table_scan / csr_fill_small
 torch.cuda.synchronize()
 print('done')

@@ -56,7 +56,33 @@ KERNELS = {  # name fragment -> (label, algorithmic FLOPs per launch, algorithmi
     'rows_linear_fewk_kernel<9, 8>': ('position layer 9->64, 3.2 M rows: fp32 + bf16 outputs + maxima', 2.0 * 3.2e6 * 9 * 64, 3.2e6 * (36 + 256 + 128)),
     'conv3x3_split_res_kernel<32, 1, 2, 5, true': ('fp32x3 conv on two inputs cat(32, 32)->32 @288^2 x20 (+ bf16 second output)', 2.0 * 20 * 288 * 288 * 64 * 32 * 9, 20 * 288 * 288 * (64 * 4 + 32 * 4 + 32 * 2)),
     'head_conv_wgrad_kernel': ('fg/bg head conv weight gradient (bf16 in)', 2.0 * 20 * 288 * 288 * 32 * 2 * 9, 20 * 288 * 288 * (32 * 2 + 2 * 4)),
+    # round 6
+    'seg_max_canvas_kernel': ('pooling + pillar scatter in one pass: 3.2 M fp32 rows -> fp32 canvas + bf16 shadow + winners (20 x 288^2 cells, 1.17 M pillars)', 0.0,
+                              4 * 32 * 3_200_000 + 4 * 3_200_000 + 4 * 1_169_434 + 4 * 1_658_880 + 6 * 32 * 1_658_880 + 4 * 32 * 1_169_433),
+    'seg_max_kernel<8>': ('per-pillar max of 3.2 M fp32 rows x 32 ch (1.17 M pillars): values + bf16 copy + winners', 0.0,
+                          4 * 32 * 3_200_000 + 4 * 3_200_000 + 4 * 1_169_434 + (4 + 2 + 4) * 32 * 1_169_433),
+    'scatter_sum_small_kernel': ('few-row sums in 64-bit fixed point: 320 k rows x 16 ch into 400 rows', 0.0, 320_000 * (64 + 4)),
+    'csr_fill_small': ('stable counting-sort fill, 320 k points into 400 segments', 0.0, 320_000 * 8),
+    'csr_sort_long': ('workgroup sort of the > 64-point segments (3.2 M points / 1.17 M pillars: a handful)', 0.0, 1.0),
 }
+
+
+# [r6] which input distribution each row was measured on: the dense kernels' time does not depend on the values; the irregular ones do
+def distribution(frag):
+    if 'seg_max_canvas_kernel' in frag or frag == 'seg_max_kernel<8>':
+        return 'pillar sizes: 3.2 M points in 1.17 M pillars, every pillar >= 1 point, the rest uniform over the pillars (the bench\'s uniform synthetic points); ' \
+               'the LiDAR-shaped row (1 / r weights, a third of the cells occupied) is tools/bench_fused_canvas.py, profiles/r06_fused_canvas_variants.txt'
+    if frag.startswith('vox_'):
+        return 'the step\'s own points: 4 sequences of synthetic.make_sequence (uniform over the crop box)'
+    if 'bilinear' in frag:
+        return 'points uniform over the map (the clustered foreground case -- 20 boxes per sequence -- is tools/bench_bilinear_ab.py, profiles/r05_bilinear_ab.txt)'
+    if frag.startswith(('seg_rows', 'seg_lovasz')):
+        return 'normal logits, uniform random labels'
+    if frag.startswith(('ego_', 'sk_')):
+        return 'normal log-affinities'
+    if 'pfn_block' in frag:
+        return 'normal rows, point -> pillar map uniform random (gather side); the step\'s map is sorted by cell within a frame'
+    return 'dense tensor of normal values: no dependence on the data distribution (every element is touched once per tap)'
 
 
 def main():
@@ -77,7 +103,7 @@ def main():
             continue
         c = {k: sum(v) / len(v) for k, v in vals[frag].items()}
         us = sum(durs[frag]) / len(durs[frag])
-        row = {'what': label, 'avg_us_under_pmc': round(us, 1), 'TFLOPs': round(flops / us / 1e6, 1), 'algorithmic_GBps': round(hbm / us / 1e3, 1),
+        row = {'what': label, 'distribution': distribution(frag), 'avg_us_under_pmc': round(us, 1), 'TFLOPs': round(flops / us / 1e6, 1), 'algorithmic_GBps': round(hbm / us / 1e3, 1),
                'counters': {k: round(v, 1) for k, v in sorted(c.items())}}
         if 'SQ_VALU_MFMA_BUSY_CYCLES' in c and 'GRBM_GUI_ACTIVE' in c:
             row["mfma_busy_frac"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8 * 1024), 4)   # GRBM_GUI_ACTIVE is summed over the 8 XCDs
