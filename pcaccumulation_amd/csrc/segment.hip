@@ -904,44 +904,66 @@ extern "C" int pcacc_segment_sum_t(const void *src, int dtype, int c, const int3
 // partial NaN -- the sum is non-finite either way, the step's finite check sees it.
 // ---------------------------------------------------------------------------------------------------
 #define SSS_SLICE_MAX (1 << 22)
-__global__ __launch_bounds__(256) void scatter_sum_small_kernel(const float *__restrict__ src, const int32_t *__restrict__ idx,
-                                                                int64_t n_elem, int c, int mc, float *__restrict__ partial)
+#define SSS_THREADS 1024
+#define SSS_MAX_GRID 128
+// [r6, second form] 1 024 threads per workgroup (one table per CU needs all the CU's waves to hide its loads: the first form ran 4 waves per CU, one float per
+// lane per trip, a 64-bit division per element: 75 us for 20 MB), whole rows per workgroup, 16-byte pieces where c % 4 == 0, at most 128 tables (the fixed-order
+// reduce behind reads grid x m x c partials: 28 us at 256).  V = floats per piece.
+template <int V>
+__global__ __launch_bounds__(SSS_THREADS) void scatter_sum_small_kernel(const float *__restrict__ src, const int32_t *__restrict__ idx, int64_t n, int c,
+                                                                        int mc, int64_t rows_per_block, float *__restrict__ partial)
 {
     extern __shared__ unsigned long long acc64[];
-    __shared__ float wmax[4];
-    for (int j = threadIdx.x; j < mc; j += 256) acc64[j] = 0ull;
-    const int64_t per_block = (n_elem + gridDim.x - 1) / gridDim.x;
-    const int64_t lo = (int64_t)blockIdx.x * per_block, hi = min(n_elem, lo + per_block);
+    __shared__ float wmax[SSS_THREADS / 64];
+    for (int j = threadIdx.x; j < mc; j += SSS_THREADS) acc64[j] = 0ull;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(n, r0 + rows_per_block);
+    const int cv = c / V;                                               // pieces per row
+    const int n_pieces = r1 > r0 ? (int)((r1 - r0) * cv) : 0;          // < 2^22
+    const float *mine_src = src + r0 * c;
     float mx = 0.f;
     bool bad = false;
-    for (int64_t e = lo + threadIdx.x; e < hi; e += 256) {
-        const float v = src[e];
-        mx = fmaxf(mx, fabsf(v));
-        bad |= !(fabsf(v) < __builtin_inff());
+#pragma unroll 4
+    for (int q = threadIdx.x; q < n_pieces; q += SSS_THREADS) {
+        float x[V];
+        if (V == 4) { const float4 t = reinterpret_cast<const float4 *>(mine_src)[q]; x[0] = t.x; x[V > 1 ? 1 : 0] = t.y; x[V > 2 ? 2 : 0] = t.z; x[V > 3 ? 3 : 0] = t.w; }
+        else x[0] = mine_src[q];
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            mx = fmaxf(mx, fabsf(x[v]));
+            bad |= !(fabsf(x[v]) < __builtin_inff());
+        }
     }
     if (bad) mx = __builtin_inff();
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
     if (lane_id() == 0) wmax[threadIdx.x >> 6] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    mx = wmax[0];
+#pragma unroll
+    for (int k = 1; k < SSS_THREADS / 64; ++k) mx = fmaxf(mx, wmax[k]);
     float *mine = partial + (int64_t)blockIdx.x * mc;
     if (!(mx < __builtin_inff())) {                                     // uniform
-        for (int j = threadIdx.x; j < mc; j += 256) mine[j] = __builtin_nanf("");
+        for (int j = threadIdx.x; j < mc; j += SSS_THREADS) mine[j] = __builtin_nanf("");
         return;
     }
     int k = 0;
     if (mx > 0.f) frexpf(mx, &k);                                       // mx = f 2^k, f in [0.5, 1): scaled values below 2^40
     const float up = ldexpf(1.f, 40 - k > 126 ? 126 : 40 - k);          // (a slice of denormals only: scaled as far as a float factor reaches)
     const double down = 1.0 / (double)up;
-    for (int64_t e = lo + threadIdx.x; e < hi; e += 256) {
-        const int64_t r = e / c;
-        const int kk = (int)(e - r * c);
-        const int s = idx[r];
-        if (s >= 0) atomicAdd(&acc64[s * c + kk], (unsigned long long)(long long)llrintf(src[e] * up));
+#pragma unroll 4
+    for (int q = threadIdx.x; q < n_pieces; q += SSS_THREADS) {
+        const int r = q / cv, kk = q - r * cv;
+        float x[V];
+        if (V == 4) { const float4 t = reinterpret_cast<const float4 *>(mine_src)[q]; x[0] = t.x; x[V > 1 ? 1 : 0] = t.y; x[V > 2 ? 2 : 0] = t.z; x[V > 3 ? 3 : 0] = t.w; }
+        else x[0] = mine_src[q];
+        const int sl = idx[r0 + r];
+        if (sl >= 0) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) atomicAdd(&acc64[sl * c + kk * V + v], (unsigned long long)(long long)llrintf(x[v] * up));
+        }
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < mc; j += 256) mine[j] = (float)((double)(long long)acc64[j] * down);
+    for (int j = threadIdx.x; j < mc; j += SSS_THREADS) mine[j] = (float)((double)(long long)acc64[j] * down);
 }
 
 __global__ __launch_bounds__(1024) void scatter_sum_small_reduce_kernel(const float *__restrict__ partial, int n_parts, int elems, float *__restrict__ out)
@@ -949,19 +971,24 @@ __global__ __launch_bounds__(1024) void scatter_sum_small_reduce_kernel(const fl
     pcacc_reduce_partials<16>(partial, n_parts, elems, [&](int e, float v) { out[e] = v; });
 }
 
-static int sss_grid(int64_t n_elem)
+static int sss_grid(int64_t n, int c, int64_t *rows_per_block)
 {
-    int grid = (int)((n_elem + 256 * 32 - 1) / (256 * 32));
-    if (grid > PCACC_CUS) grid = PCACC_CUS;                              // one table per CU: the fixed-order reduce behind reads grid x m x c partials
-    const int64_t need = (n_elem + SSS_SLICE_MAX - 1) / SSS_SLICE_MAX;   // a slice never exceeds 2^22 elements (the fixed-point head room)
-    if (grid < need) grid = (int)need;
-    return grid < 1 ? 1 : grid;
+    int64_t grid = (n * c + SSS_THREADS * 16 - 1) / (SSS_THREADS * 16);  // ~four 16-byte pieces per thread and pass before a second table pays
+    if (grid > SSS_MAX_GRID) grid = SSS_MAX_GRID;
+    if (grid < 1) grid = 1;
+    int64_t rows = (n + grid - 1) / grid;
+    const int64_t cap = SSS_SLICE_MAX / c;                              // a slice never exceeds 2^22 elements (the fixed-point head room)
+    if (rows > cap) rows = cap;
+    if (rows < 1) rows = 1;
+    *rows_per_block = rows;
+    return (int)((n + rows - 1) / rows);
 }
 
 extern "C" int pcacc_scatter_sum_small_workspace_bytes(int64_t n, int c, int m, size_t *bytes)
 {
     if (!bytes || n < 0 || c <= 0 || m <= 0 || (int64_t)m * c > 8192) return PCACC_E_ARG;
-    *bytes = pcacc_align((size_t)sss_grid(n * c) * (size_t)m * c * sizeof(float));
+    int64_t rows;
+    *bytes = pcacc_align((size_t)(n > 0 ? sss_grid(n, c, &rows) : 1) * (size_t)m * c * sizeof(float));
     return PCACC_OK;
 }
 
@@ -977,13 +1004,15 @@ extern "C" int pcacc_scatter_sum_small(const float *src, const int32_t *idx, int
     }
     if (!src || !idx) return PCACC_E_ARG;
     if (!workspace || workspace_bytes < need) return PCACC_E_WORKSPACE;
-    const int64_t n_elem = n * c;
-    const int grid = sss_grid(n_elem), mc = m * c;
+    int64_t rows;
+    const int grid = sss_grid(n, c, &rows), mc = m * c;
     const size_t lds = (size_t)mc * sizeof(unsigned long long);
-    if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(scatter_sum_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    const bool vec = c % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+    auto kern = vec ? scatter_sum_small_kernel<4> : scatter_sum_small_kernel<1>;
+    if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return PCACC_E_LAUNCH;
     float *partial = static_cast<float *>(workspace);
-    scatter_sum_small_kernel<<<grid, 256, lds, s>>>(src, idx, n_elem, c, mc, partial);
+    kern<<<grid, SSS_THREADS, lds, s>>>(src, idx, n, c, mc, rows, partial);
     scatter_sum_small_reduce_kernel<<<(mc + 15) / 16, 1024, 0, s>>>(partial, grid, mc, out);
     PCACC_CHECK_LAUNCH();
     return PCACC_OK;

@@ -626,6 +626,13 @@ def pfn_features(points, p2v, pillar_mean, coords, time_indice, vx, vy, x_offset
     tcol = ctypes.c_void_p(time_indice.data_ptr() + 8)                   # column 1 of row 0
     if order is not None and order.shape[0] != n:
         raise NativeError('pfn_features: order has %d entries for %d points' % (order.shape[0], n))
+    if order is None:
+        _check(lib().pcacc_pfn_features(_dev(points, torch.float32, 'points'), _dev(p2v, torch.int32, 'p2v'),
+                                        _dev(pillar_mean, torch.float32, 'pillar_mean'), _dev(coords, None, 'coordinates'), is_f64,
+                                        tcol if n else None, _i64(2), _i64(n), ctypes.c_double(vx), ctypes.c_double(vy),
+                                        ctypes.c_double(x_offset), ctypes.c_double(y_offset), ctypes.c_float(scale),
+                                        ctypes.c_float(n_frames), _dev(out), _stream()), 'pfn_features')
+        return out
     _check(lib().pcacc_pfn_features_ordered(_dev(points, torch.float32, 'points'), _dev(p2v, torch.int32, 'p2v'),
                                             _dev(pillar_mean, torch.float32, 'pillar_mean'), _dev(coords, None, 'coordinates'), is_f64,
                                             tcol if n else None, _i64(2), _i64(n), ctypes.c_double(vx), ctypes.c_double(vy),
