@@ -131,3 +131,13 @@ for i in range(n_steps):
             span[q][2] += 1
 print('first kernel start / last kernel end inside the step (ms after the previous step\'s Adam): ' +
       ', '.join('%s %.2f .. %.2f' % (q, v[0] / v[2], v[1] / v[2]) for q, v in sorted(span.items(), key=lambda x: x[1][0] / max(x[1][2], 1))))
+# the kernels of every stream but the busiest (the side chain: what the step's length hangs on behind the lower half's forward)
+ranked = sorted(per_q.items(), key=lambda x: -sum(e - s for s, e, _ in x[1]))
+for q, lst in ranked[1:2]:
+    agg_q = collections.defaultdict(lambda: [0.0, 0])
+    for s_, e_, n_ in lst:
+        agg_q[n_][0] += (e_ - s_) / 1e6 / n_steps
+        agg_q[n_][1] += 1.0 / n_steps
+    print('\nkernels of %s %s, by time:' % (qcol or 'queue', q))
+    for n_, v in sorted(agg_q.items(), key=lambda x: -x[1][0])[:70]:
+        print('  %-96s n/step=%6.1f avg=%8.1fus tot/step=%6.2fms' % (n_[:96], v[1], v[0] / v[1] * 1e3, v[0]))
