@@ -677,90 +677,10 @@ __global__ __launch_bounds__(256) void seg_max_canvas_kernel(const float4 *__res
     }
 }
 
-// [r6] The same pass as a software pipeline.  A cell's work is a chain of four dependent memory round trips (cell table -> segment offsets -> point list ->
-// point rows) and a lane group walked it one cell at a time: whatever the occupancy, three quarters of the time a group had ONE small request in flight.
-// Here iteration t of a group issues, back to back, the table read of cell t, the offsets of cell t - 1, the point list of cell t - 2 and the rows of
-// cell t - 3, and reduces / stores cell t - 4 while they travel: one round trip per iteration instead of four, the same loads, the same comparisons in the same
-// order (bit-identical canvas and winners).  Pillars of more than four points finish alone, as before.
-template <int LPP, bool NT>
-__global__ __launch_bounds__(256) void seg_max_canvas_pipe_kernel(const float4 *__restrict__ src, const int32_t *__restrict__ seg_offsets,
-                                                                  const int32_t *__restrict__ order, const int32_t *__restrict__ cell2pillar, int64_t n_cells,
-                                                                  float4 *__restrict__ canvas32, uint16_t *__restrict__ canvas16, int4 *__restrict__ arg)
-{
-    const int sub = threadIdx.x % LPP;
-    const int64_t per_block = 256 / LPP;
-    const int64_t stride = (int64_t)gridDim.x * per_block;
-    const int64_t first = (int64_t)blockIdx.x * per_block + threadIdx.x / LPP;
-    auto ld_row = [&](int64_t i4) -> float4 {
-        if (NT) {
-            const seg_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const seg_f32x4 *>(src) + i4);
-            return make_float4(v.x, v.y, v.z, v.w);
-        }
-        return src[i4];
-    };
-    const int64_t mine = first < n_cells ? (n_cells - first + stride - 1) / stride : 0;     // cells of this lane group
-    int s1 = -1;                                                   // after stage 1 (cell t - 1): its pillar
-    int s2 = -1, b2 = 0, e2 = 0;                                   // after stage 2 (cell t - 2): + its segment
-    int s3 = -1, b3 = 0, e3 = 0, idx3[4] = {-1, -1, -1, -1};       // after stage 3 (cell t - 3): + its first four points
-    int s4 = -1, b4 = 0, e4 = 0, idx4[4] = {-1, -1, -1, -1};       // after stage 4 (cell t - 4): + their rows
-    float4 rows4[4] = {};
-    for (int64_t t = 0; t < mine + 4; ++t) {
-        // ---- the four loads of this iteration, none depends on another
-        const int64_t cell_a = first + t * stride;
-        const int sa = (t < mine) ? cell2pillar[cell_a] : -1;
-        const int bn = s1 >= 0 ? seg_offsets[s1] : 0, en = s1 >= 0 ? seg_offsets[s1 + 1] : 0;
-        int idxn[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) idxn[j] = b2 + j < e2 ? (NT ? __builtin_nontemporal_load(order + b2 + j) : order[b2 + j]) : -1;
-        float4 rowsn[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) rowsn[j] = idx3[j] >= 0 ? ld_row((int64_t)idx3[j] * LPP + sub) : make_float4(0.f, 0.f, 0.f, 0.f);
-        // ---- cell t - 4: its rows arrived during the last iteration
-        if (t >= 4) {
-            const int64_t cell = first + (t - 4) * stride;
-            float4 best = make_float4(0.f, 0.f, 0.f, 0.f);
-            int4 bi = make_int4(-1, -1, -1, -1);
-            int k0 = b4;
-            int idx[4] = {idx4[0], idx4[1], idx4[2], idx4[3]};
-            float4 rows[4] = {rows4[0], rows4[1], rows4[2], rows4[3]};
-            while (true) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int i = idx[j];
-                    if (i < 0) continue;
-                    const float4 v = rows[j];
-                    if (bi.x < 0 || v.x > best.x || (v.x == best.x && i < bi.x)) { best.x = v.x; bi.x = i; }
-                    if (bi.y < 0 || v.y > best.y || (v.y == best.y && i < bi.y)) { best.y = v.y; bi.y = i; }
-                    if (bi.z < 0 || v.z > best.z || (v.z == best.z && i < bi.z)) { best.z = v.z; bi.z = i; }
-                    if (bi.w < 0 || v.w > best.w || (v.w == best.w && i < bi.w)) { best.w = v.w; bi.w = i; }
-                }
-                k0 += 4;
-                if (k0 >= e4) break;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) idx[j] = k0 + j < e4 ? order[k0 + j] : -1;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) rows[j] = idx[j] >= 0 ? ld_row((int64_t)idx[j] * LPP + sub) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            if (s4 >= 0) {
-                if (NT) {
-                    const seg_i32x4 a = {bi.x, bi.y, bi.z, bi.w};
-                    __builtin_nontemporal_store(a, reinterpret_cast<seg_i32x4 *>(arg) + (int64_t)s4 * LPP + sub);
-                } else arg[(int64_t)s4 * LPP + sub] = bi;
-            }
-            canvas32[cell * LPP + sub] = best;
-            const seg_u32x2 pk = {pcacc_pack_bf16x2(best.x, best.y), pcacc_pack_bf16x2(best.z, best.w)};
-            __builtin_nontemporal_store(pk, reinterpret_cast<seg_u32x2 *>(canvas16) + cell * LPP + sub);
-        }
-        // ---- every cell moves one stage on
-        s4 = s3; b4 = b3; e4 = e3;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { idx4[j] = idx3[j]; rows4[j] = rowsn[j]; idx3[j] = idxn[j]; }
-        s3 = s2; b3 = b2; e3 = e2;
-        s2 = s1; b2 = bn; e2 = en;
-        s1 = sa;
-    }
-}
-
+// [r6] Tried and removed (the commit before this one has the code; profiles/r06_fused_canvas_pipeline_ab.txt): the same pass as a four-stage software pipeline --
+// iteration t of a lane group issues the table read of cell t, the offsets of cell t - 1, the point list of cell t - 2 and the rows of cell t - 3 back to back
+// and reduces cell t - 4 meanwhile: one memory round trip per iteration instead of a chain of four.  Bit-identical, 93 VGPRs, and SLOWER: 241 vs 215 us alone,
+// 250 vs 221 us in the step.  With 32 waves per CU the chain was already hidden; the kernel sits at 0.8 of what a plain copy of its 902 MB takes.
 extern "C" int pcacc_segment_max_canvas(const float *src, int c, const int32_t *seg_offsets, const int32_t *order, int64_t n, int64_t m,
                                         const int32_t *cell2pillar, int64_t n_cells, float *canvas32, uint16_t *canvas16, int32_t *arg,
                                         void *start_event, void *stop_event, void *stream)
@@ -786,8 +706,6 @@ extern "C" int pcacc_segment_max_canvas(const float *src, int c, const int32_t *
             else if (variant == 'b') { fn = reinterpret_cast<const void *>(seg_max_canvas_kernel<8, 2, false>); cpg = 2; }
             else if (variant == 'e') { fn = reinterpret_cast<const void *>(seg_max_canvas_kernel<8, 2, true>); cpg = 2; }
             else if (variant == 'd') { fn = reinterpret_cast<const void *>(seg_max_canvas_kernel<8, 4, true>); cpg = 4; }
-            else if (variant == 'p') fn = reinterpret_cast<const void *>(seg_max_canvas_pipe_kernel<8, false>);
-            else if (variant == 'q') fn = reinterpret_cast<const void *>(seg_max_canvas_pipe_kernel<8, true>);
             break;
         case 16: fn = reinterpret_cast<const void *>(seg_max_canvas_kernel<16, 1, false>); break;
         case 32: fn = reinterpret_cast<const void *>(seg_max_canvas_kernel<32, 1, false>); break;

@@ -495,11 +495,9 @@ class DataParallelStep(object):
         self.pipelined = (can and (want_side or world_size() == 1)) if pipelined is None else (bool(pipelined) and can)
         if self.pipelined and hasattr(model, 'early_parameters'):
             self.reducer.set_early(model.early_parameters())
-        # [r6] PCACC_SIDE_PRIORITY (experiment): the side stream's chain (motion heads, TubeNet and their backward) is what the step's length hangs on once the
-        # lower half's forward is done -- the early backward beside it on the main stream has ~9 ms of slack (tools/kstats_steady.py, per-stream spans);
-        # -1 = the high-priority class for the side stream's queue
-        prio = int(os.environ.get('PCACC_SIDE_PRIORITY', '0'))
-        self.side = torch.cuda.Stream(device=dev, priority=prio) if (self.pipelined and want_side) else None
+        # [r6] measured: the side stream in the high-priority class (torch.cuda.Stream(priority=-1)) changes nothing -- 30.78 / 29.57 / 29.71 ms against 29.94 /
+        # 30.28 / 29.52 ms (p50, interleaved, profiles/r06_side_priority_ab.txt), although the side chain is what the step's length hangs on
+        self.side = torch.cuda.Stream(device=dev) if (self.pipelined and want_side) else None
         # the helper thread only WITH the second stream: on one stream both threads would launch into the same queue and share native._ZERO_POOL's
         # rotating rows under one key -- and there is nothing to gain, the two halves serialise on the device anyway
         can_thread = bool(self.pipelined and dev.type == 'cuda' and self.side is not None)

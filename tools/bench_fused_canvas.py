@@ -38,7 +38,7 @@ def main():
         src, offs, order, m, c2p, n_cells, c, n = case(kind, dev)
         alg = bench.fused_alg_bytes(n_cells, c, m, n)
         ref = None
-        for variant in ('', 'c', 'b', 'p', 'q'):
+        for variant in ('', 'c', 'b', 'e', 'd'):
             if variant:
                 os.environ['PCACC_SCATTER_VARIANT'] = variant
             else:
