@@ -500,6 +500,7 @@ class DataParallelStep(object):
         self.side = torch.cuda.Stream(device=dev) if (self.pipelined and want_side) else None
         # the helper thread only WITH the second stream: on one stream both threads would launch into the same queue and share native._ZERO_POOL's
         # rotating rows under one key -- and there is nothing to gain, the two halves serialise on the device anyway
+        self._defer_early = os.environ.get('PCACC_EARLY_DEFER', '1') != '0'
         can_thread = bool(self.pipelined and dev.type == 'cuda' and self.side is not None)
         self._early_thread = bool(self._early_thread_want) and can_thread
         self._tuning = can_thread and self._early_thread_want is None
@@ -555,6 +556,7 @@ class DataParallelStep(object):
         early = []
 
         pending = []                                          # [(thread, [exception])] of an early backward issued from a helper thread
+        deferred = []
 
         def join_early():
             """Join the helper thread (if one was started) and restore the interpreter's switch interval; re-raises what the thread raised."""
@@ -598,6 +600,12 @@ class DataParallelStep(object):
             # functions): at the default 5 ms switch interval they starve each other in 5 ms turns
             self._switch_interval = sys.getswitchinterval()
             pending.append((t, err))
+            # [r6] the helper thread starts when the upper half's forward is ISSUED, not here: until then this thread has the interpreter lock to itself for the
+            # ~400 launches of the chain the step's length hangs on; the early backward's kernels have ~9 ms of slack behind that chain.  Five
+            # interleaved pairs: p50 30.03 / 29.99 / 30.01 / 29.97 / 30.04 ms against 30.30 / 30.43 / 30.27 / 30.33 / 30.24 ms (profiles/r06_early_defer_ab.txt).
+            if self._defer_early:
+                deferred.append(t)
+                return
             sys.setswitchinterval(self._helper_switch_interval)
             t.start()
         r.begin(sync=last)
@@ -619,6 +627,9 @@ class DataParallelStep(object):
                         self.model.side_stream = None
                     if before_sync is not None and hasattr(self.model, 'before_sync'):
                         self.model.before_sync = None
+                if deferred:
+                    sys.setswitchinterval(self._helper_switch_interval)
+                    deferred.pop().start()
                 if after_forward is not None:
                     after_forward()
                 two = self.side is not None and bool(early)
