@@ -500,7 +500,8 @@ class DataParallelStep(object):
         self.side = torch.cuda.Stream(device=dev) if (self.pipelined and want_side) else None
         # the helper thread only WITH the second stream: on one stream both threads would launch into the same queue and share native._ZERO_POOL's
         # rotating rows under one key -- and there is nothing to gain, the two halves serialise on the device anyway
-        self._defer_early = os.environ.get('PCACC_EARLY_DEFER', '1') != '0'
+        # (measured at one rank only; with more ranks the early start also starts the lower half's all-reduces early, so it stays unless asked for)
+        self._defer_early = os.environ.get('PCACC_EARLY_DEFER', '1' if world_size() == 1 else '0') != '0'
         can_thread = bool(self.pipelined and dev.type == 'cuda' and self.side is not None)
         self._early_thread = bool(self._early_thread_want) and can_thread
         self._tuning = can_thread and self._early_thread_want is None

@@ -63,7 +63,7 @@ KERNELS = {  # name fragment -> (label, algorithmic FLOPs per launch, algorithmi
                           4 * 32 * 3_200_000 + 4 * 3_200_000 + 4 * 1_169_434 + (4 + 2 + 4) * 32 * 1_169_433),
     'scatter_sum_small_kernel': ('few-row sums in 64-bit fixed point: 320 k rows x 16 ch into 400 rows', 0.0, 320_000 * (64 + 4)),
     'csr_fill_small': ('stable counting-sort fill, 320 k points into 400 segments', 0.0, 320_000 * 8),
-    'csr_sort_long': ('workgroup sort of the > 64-point segments (3.2 M points / 1.17 M pillars: a handful)', 0.0, 1.0),
+    'csr_sort_long': ('workgroup sort of the > 64-point segments (3.2 M points / 1.17 M pillars: a handful; no algorithmic byte count -- the ratio column is meaningless for it)', 0.0, 0.0),
 }
 
 
@@ -80,6 +80,8 @@ def distribution(frag):
         return 'normal logits, uniform random labels'
     if frag.startswith(('ego_', 'sk_')):
         return 'normal log-affinities'
+    if frag.startswith(('scatter_sum_small', 'csr_')):
+        return 'slot / segment numbers uniform random (320 k points over 400 segments; csr_sort_long: the > 64-point segments of 3.2 M uniform points over 1.17 M pillars)'
     if 'pfn_block' in frag:
         return 'normal rows, point -> pillar map uniform random (gather side); the step\'s map is sorted by cell within a frame'
     return 'dense tensor of normal values: no dependence on the data distribution (every element is touched once per tap)'
@@ -111,7 +113,8 @@ def main():
             row['lds_conflict_share'] = round(c['SQ_LDS_BANK_CONFLICT'] / c['SQ_LDS_IDX_ACTIVE'], 4)
         if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
             row['hbm_bytes'] = round((2 * c['FETCH_SIZE'] + c['WRITE_SIZE']) * 1024)
-            row['hbm_over_algorithmic'] = round(row['hbm_bytes'] / hbm, 3)
+            if hbm > 0:
+                row['hbm_over_algorithmic'] = round(row['hbm_bytes'] / hbm, 3)
         res[frag] = row
     json.dump(res, open(out, 'w'), indent=1)
     print(json.dumps(res, indent=1))
