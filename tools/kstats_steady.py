@@ -141,3 +141,15 @@ for q, lst in ranked[1:2]:
     print('\nkernels of %s %s, by time:' % (qcol or 'queue', q))
     for n_, v in sorted(agg_q.items(), key=lambda x: -x[1][0])[:70]:
         print('  %-96s n/step=%6.1f avg=%8.1fus tot/step=%6.2fms' % (n_[:96], v[1], v[0] / v[1] * 1e3, v[0]))
+# [r6] PCACC_KSTATS_DUMP=<file>: the last steady step's launches in start order -- stream, start (us after the step began), duration, gap to the previous kernel of the SAME stream, name
+if os.environ.get('PCACC_KSTATS_DUMP'):
+    lo_, hi_ = bounds[-2], bounds[-1]
+    last_end = {}
+    with open(os.environ['PCACC_KSTATS_DUMP'], 'w') as f:
+        for s_, e_, n_ in sorted(sel):
+            if s_ < lo_ or e_ > hi_:
+                continue
+            q = queue_of.get((s_, e_, n_), '0')
+            gap = (s_ - last_end[q]) / 1e3 if q in last_end else 0.0
+            last_end[q] = e_
+            f.write('%s %9.1f %7.1f %7.1f  %s\n' % (q, (s_ - lo_) / 1e3, (e_ - s_) / 1e3, gap, n_[:150]))
