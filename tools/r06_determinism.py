@@ -74,6 +74,9 @@ def main():
     ap.add_argument('--step', action='store_true')
     args = ap.parse_args()
     import test_config_parity as cp
+    if os.environ.get('PCACC_CUDNN_DET') == '1':                 # the library (fp32) mode: ask the convolution library for deterministic algorithms only
+        torch.backends.cudnn.deterministic = True
+        torch.backends.cudnn.benchmark = False
     g = np.load(os.path.join(ROOT, 'tests', 'golden', 'model_%s.npz' % args.config), allow_pickle=False)
     snaps = []
     if not args.step:
