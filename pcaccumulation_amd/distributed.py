@@ -500,8 +500,12 @@ class DataParallelStep(object):
         self.side = torch.cuda.Stream(device=dev) if (self.pipelined and want_side) else None
         # the helper thread only WITH the second stream: on one stream both threads would launch into the same queue and share native._ZERO_POOL's
         # rotating rows under one key -- and there is nothing to gain, the two halves serialise on the device anyway
-        # (measured at one rank only; with more ranks the early start also starts the lower half's all-reduces early, so it stays unless asked for)
-        self._defer_early = os.environ.get('PCACC_EARLY_DEFER', '1' if world_size() == 1 else '0') != '0'
+        # Where it pays was measured, not derived (profiles/r06_early_defer_ab.txt, r06_early_defer_other_configs.txt; one rank): 'mixed' mode at four sequences
+        # per step -0.3 ms (five pairs) and -0.15 ms on LiDAR-distributed points; at two sequences +0.3 ms, at one +2 ms, in bf16 +0.9 ms -- the upper half's
+        # kernels have to be long enough to cover the host while it issues the early backward behind them.  A three-way tuner over the warm-up steps was tried
+        # and dropped (two samples per way cannot see 1 %: profiles/r06_tuner_three_ways_noisy.txt).  So: a rule on the two variables of that table
+        # (_defer_now), PCACC_EARLY_DEFER=1 / 0 to force it; with more ranks the early start also starts the lower half's all-reduces early: off there.
+        self._defer_env = os.environ.get('PCACC_EARLY_DEFER')
         can_thread = bool(self.pipelined and dev.type == 'cuda' and self.side is not None)
         self._early_thread = bool(self._early_thread_want) and can_thread
         self._tuning = can_thread and self._early_thread_want is None
@@ -535,6 +539,15 @@ class DataParallelStep(object):
             plain / 2, threaded / 2, 'helper thread' if self._early_thread else 'this thread')
         self._tuning = False
         self._tune_events = []
+
+    def _defer_now(self, results):
+        """Start the helper thread behind the upper half's forward instead of here?  (See __init__: measured to pay in the 'mixed' mode from four sequences per step.)"""
+        if self._defer_env is not None:
+            return self._defer_env != '0'
+        if world_size() != 1 or getattr(self.model, 'compute_mode', None) != 'mixed':
+            return False
+        seg = dict.get(results, 'fb_seg_est') if isinstance(results, dict) else None      # [B, T, 2, Ny, Nx]
+        return seg is not None and seg.dim() == 5 and int(seg.shape[0]) >= 4
 
     def skipped_steps(self):
         return int(self._skipped.item())
@@ -604,7 +617,7 @@ class DataParallelStep(object):
             # [r6] the helper thread starts when the upper half's forward is ISSUED, not here: until then this thread has the interpreter lock to itself for the
             # ~400 launches of the chain the step's length hangs on; the early backward's kernels have ~9 ms of slack behind that chain.  Five
             # interleaved pairs: p50 30.03 / 29.99 / 30.01 / 29.97 / 30.04 ms against 30.30 / 30.43 / 30.27 / 30.33 / 30.24 ms (profiles/r06_early_defer_ab.txt).
-            if self._defer_early:
+            if self._defer_now(results):
                 deferred.append(t)
                 return
             sys.setswitchinterval(self._helper_switch_interval)
