@@ -253,6 +253,13 @@ def test_gpu_trajectory(name, mode, golden):
     # round 6 one sampled gradient entry of a BatchNorm bias was 2.3 % off once (bound 1 %; the same entry, the same 2.3 %, once in five suites in round 5) and one
     # late loss term left its envelope once (profiles/r06_suite_failures_fp32_trajectory.txt).  This mode -- and no other, and no 1e-3 metric assertion
     # anywhere -- is evaluated a second time against the SAME bounds when its first evaluation fails; the first failure is logged.
+    # Four more suites showed the outcome is mostly a property of the PROCESS (both evaluations of one process failed together: the library settles on its
+    # algorithms once per process), so the leg also asks for the library's deterministic algorithms: eight fresh processes with them gave the same first three
+    # losses bit for bit and 2.2e-3 at the fourth optimizer step (bound 5.3e-3), eight without scattered between 4e-5 and 1.8e-3 there with one first-evaluation
+    # failure (profiles/r06_fp32_trajectory_processes.txt).
+    det = torch.backends.cudnn.deterministic
+    if os.environ.get('PCACC_TRAJ_LIBRARY_DET', '1') != '0':
+        torch.backends.cudnn.deterministic = True                  # the library's deterministic algorithms: the forward is then the same in every process
     try:
         check(g, run_trajectory(g, torch.device('cuda:0'), mode, fused=True), **TOL[mode])
     except AssertionError as first:
@@ -265,6 +272,8 @@ def test_gpu_trajectory(name, mode, golden):
             pass
         warnings.warn('test_gpu_trajectory[fp32-%s]: first evaluation failed (%s ...); the library mode is evaluated once more against the same bounds' % (name, str(first)[:300]))
         check(g, run_trajectory(g, torch.device('cuda:0'), mode, fused=True), **TOL[mode])
+    finally:
+        torch.backends.cudnn.deterministic = det
 
 
 @pytest.mark.gpu
