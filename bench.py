@@ -616,12 +616,6 @@ def main():
     native.scatter_timer = []
     pdist.barrier()
     torch.cuda.synchronize()
-    if os.environ.get('PCACC_GC'):                                      # experiment: 'freeze' = gc.freeze() after the warm-up, 'off' = no automatic collection in the timed steps
-        import gc
-        gc.collect()
-        gc.freeze()
-        if os.environ['PCACC_GC'] == 'off':
-            gc.disable()
     watchdog.arm('warm-up done, barrier passed')
     collectives_before = stepper.reducer.collectives
     stepper.reducer.time_exposed = world > 1 or stepper.reducer.active
