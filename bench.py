@@ -619,6 +619,17 @@ def main():
     watchdog.arm('warm-up done, barrier passed')
     collectives_before = stepper.reducer.collectives
     stepper.reducer.time_exposed = world > 1 or stepper.reducer.active
+    gc_log = []
+    if os.environ.get('PCACC_BENCH_DEBUG'):                             # which collections of the interpreter's garbage collector fall into the timed steps, and how long they take
+        import gc
+        # (measured, profiles/r06_gc_pauses.txt: ~1 young-generation collection per step, 0.07 ms per step in total, no full collection in 40 steps -- the collector
+        # is not where the slow steps come from; the steps of a run get slower by ~0.03 ms each over 40 steps whatever the collector does)
+        def gc_cb(phase, info, _t=[0.0]):
+            if phase == 'start':
+                _t[0] = time.perf_counter()
+            else:
+                gc_log.append((info['generation'], (time.perf_counter() - _t[0]) * 1e3, info['collected'], time.perf_counter()))
+        gc.callbacks.append(gc_cb)
     t0 = time.perf_counter()
     marks = []                                                          # one event per step boundary on the main stream: the spread of the K steps
     for i in range(args.steps):
@@ -652,6 +663,11 @@ def main():
     per_step = sorted(per_step_in_order)
     if os.environ.get('PCACC_BENCH_DEBUG'):
         print('per-step ms, in order:', ['%.2f' % t for t in per_step_in_order], file=sys.stderr)
+        by_gen = {}
+        for g_, ms_, n_, _ in gc_log:
+            by_gen.setdefault(g_, []).append(ms_)
+        print('garbage collections inside the timed steps: ' + ', '.join('gen %d: %d, %.2f ms in total, longest %.2f ms' % (g_, len(v), sum(v), max(v)) for g_, v in sorted(by_gen.items())),
+              '| thresholds', __import__('gc').get_threshold(), file=sys.stderr)
 
     def pct(q):
         return per_step[min(len(per_step) - 1, int(round(q * (len(per_step) - 1))))] if per_step else None
